@@ -1,0 +1,118 @@
+"""fastdtw==0.3.4 restated from its published algorithm -- PARITY UNPINNED.
+
+The reference calls ``fastdtw(component_degree, patch_degree, dist=calc_dist)`` with the
+default ``radius=1`` at SubGNN/gamma.py:58 (pin: SubGNN.yml:109 ``fastdtw==0.3.4``).  The
+package is not vendored under /root/reference and is not installed in this image, and the
+reference holds no known-answer vectors for it, so this file restates the algorithm of
+Salvador & Chan's FastDTW as implemented by the pure-Python module of that release
+(recursive halving, radius-dilated projected window, one contiguous run per row, first
+minimum over the predecessors in the order (i-1,j), (i,j-1), (i-1,j-1)).
+``tie_order`` makes the predecessor order switchable because the compiled variant of the
+package may break ties differently (open point (a)).
+
+Test infrastructure only.
+"""
+INF = float('inf')
+
+# predecessor orders: each entry is (di, dj) subtracted from (i, j)
+TIE_ORDERS = {
+    0: ((1, 0), (0, 1), (1, 1)),   # pure-Python fastdtw 0.3.4: (i-1,j), (i,j-1), (i-1,j-1)
+    1: ((1, 1), (1, 0), (0, 1)),   # diagonal first (alternative for the compiled variant)
+}
+
+
+def calc_dist(a, b):
+    """gamma.py:51-52."""
+    return ((max(a, b) + 1) / (min(a, b) + 1)) - 1
+
+
+def reduce_by_half(x):
+    return [(x[i] + x[i + 1]) / 2 for i in range(0, len(x) - len(x) % 2, 2)]
+
+
+def expand_window(path, len_x, len_y, radius):
+    """Returns the window as per-row runs [(lo, hi)] (hi inclusive; (-1,-1) = empty row)
+    AND as the flat row-major cell list the published code builds."""
+    path_ = set(path)
+    for i, j in path:
+        for a in range(-radius, radius + 1):
+            for b in range(-radius, radius + 1):
+                path_.add((i + a, j + b))
+    window_ = set()
+    for i, j in path_:
+        window_.update(((i * 2, j * 2), (i * 2, j * 2 + 1), (i * 2 + 1, j * 2), (i * 2 + 1, j * 2 + 1)))
+    window = []
+    start_j = 0
+    for i in range(len_x):
+        new_start_j = None
+        for j in range(start_j, len_y):
+            if (i, j) in window_:
+                window.append((i, j))
+                if new_start_j is None:
+                    new_start_j = j
+            elif new_start_j is not None:
+                break
+        start_j = new_start_j
+    return window
+
+
+def dtw_window(x, y, window, dist, tie_order=0):
+    len_x, len_y = len(x), len(y)
+    if window is None:
+        window = [(i, j) for i in range(len_x) for j in range(len_y)]
+    D = {(0, 0): (0.0, 0, 0)}
+    order = TIE_ORDERS[tie_order]
+    for i0, j0 in window:
+        i, j = i0 + 1, j0 + 1
+        dt = dist(x[i - 1], y[j - 1])
+        best = None
+        for di, dj in order:
+            p = (i - di, j - dj)
+            c = D[p][0] + dt if p in D else INF
+            if best is None or c < best[0]:
+                best = (c, p[0], p[1])
+        D[(i, j)] = best
+    path = []
+    i, j = len_x, len_y
+    while not (i == j == 0):
+        path.append((i - 1, j - 1))
+        i, j = D[(i, j)][1], D[(i, j)][2]
+    path.reverse()
+    return D[(len_x, len_y)][0], path
+
+
+def fastdtw(x, y, radius=1, dist=None, tie_order=0):
+    x = [float(v) for v in x]
+    y = [float(v) for v in y]
+    if len(x) == 0 or len(y) == 0:
+        # padded CC rows reach fastdtw with an empty sequence (SubGNN.py:808-815).  The
+        # pure-Python module raises here; the compiled one is read as returning cost 0 with
+        # an empty path.  The value never survives: the caller
+        # overwrites padded rows with PAD (SubGNN.py:831).
+        return 0.0, []
+    if dist is None:
+        dist = lambda a, b: abs(a - b)
+    return _fastdtw(x, y, radius, dist, tie_order)
+
+
+def _fastdtw(x, y, radius, dist, tie_order):
+    min_time_size = radius + 2
+    if len(x) < min_time_size or len(y) < min_time_size:
+        return dtw_window(x, y, None, dist, tie_order)
+    xs, ys = reduce_by_half(x), reduce_by_half(y)
+    _, path = _fastdtw(xs, ys, radius, dist, tie_order)
+    window = expand_window(path, len(x), len(y), radius)
+    return dtw_window(x, y, window, dist, tie_order)
+
+
+def exact_dtw(x, y, dist):
+    return dtw_window([float(v) for v in x], [float(v) for v in y], None, dist)[0]
+
+
+def calc_dtw(component_degree, patch_degree, tie_order=0):
+    """gamma.py:54-59.  Empty component rows (padded CC rows, SubGNN.py:808-815) are given
+    similarity 1/(0+1) here; the caller overwrites them with PAD (SubGNN.py:831)."""
+    if len(component_degree) == 0 or len(patch_degree) == 0:
+        return 1.0
+    d, _ = fastdtw(component_degree, patch_degree, radius=1, dist=calc_dist, tie_order=tie_order)
+    return 1.0 / (d + 1.0)
