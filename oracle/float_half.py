@@ -1,0 +1,173 @@
+"""Float half of the SubGNN hot path restated with dense torch-CPU fp32 ops.
+
+Test infrastructure only (see oracle/__init__.py).  Functional style: parameters come in as
+a dict keyed exactly like the reference ``state_dict()`` (checkpoint
+row), so goldens can be loaded directly and gradients read back from the same tensors.
+Pinned by goldens g9, g10, g11.  The one unpinned piece is the summation order of
+torch-scatter's scatter-add (PyG 1.6.1): here messages are summed densely over the anchor
+axis, and parity is stated within 1e-4 relative.
+"""
+import torch
+import torch.nn.functional as F
+
+PAD = 0
+
+
+def _emb(E, ids):
+    """nn.Embedding.from_pretrained(..., padding_idx=PAD) (SubGNN.py:568): row PAD gets no grad."""
+    return F.embedding(ids, E, padding_idx=PAD)
+
+
+def cc_embeddings(E, cc_ids, aggregator='sum'):
+    """SubGNN.py:609-622.  E: (N+1, D) with row 0 = zeros; PAD rows take part in the max."""
+    x = _emb(E, cc_ids)
+    if aggregator == 'sum':
+        return x.sum(dim=2)
+    return x.max(dim=2)[0]
+
+
+def lstm_forward(params, prefix, x, n_layers, aggregator):
+    """SubGNN.py:60-88: bidirectional nn.LSTM(batch_first) + Linear(2h -> n_features).
+    Dropout between LSTM layers is taken as 0 (goldens use lstm_dropout = 0)."""
+    D = x.shape[-1]
+    # functional call on the caller's tensors so that gradients reach ``params``
+    flat = []
+    for l in range(n_layers):
+        for sfx in ('', '_reverse'):
+            for nm in ('weight_ih', 'weight_hh', 'bias_ih', 'bias_hh'):
+                flat.append(params['%slstm.%s_l%d%s' % (prefix, nm, l, sfx)])
+    h0 = x.new_zeros(2 * n_layers, x.shape[0], D)
+    out, _, _ = torch._VF.lstm(x, (h0, h0.clone()), flat, True, n_layers, 0.0, False, True, True)
+    agg = out[:, -1, :] if aggregator == 'last' else out.sum(dim=1)
+    return F.linear(agg, params[prefix + 'linear.weight'], params[prefix + 'linear.bias'])
+
+
+def aggregate_structure_anchor_patch(params, E, walks, hparams):
+    """aps:413-433: walks (A, W, T) ids -> (A, D)."""
+    A, W, Tn = walks.shape
+    x = _emb(E, walks).view(A * W, Tn, -1)
+    h = lstm_forward(params, 'lstm.', x, hparams['lstm_n_layers'], hparams['lstm_aggregator'])
+    return h.view(A, W, -1).sum(dim=1)
+
+
+def get_anchor_patches(params, hparams, E, subgraph_idx, cc_ids, cc_mask, anchors, split, layer, channel, inside):
+    """aps:333-399.  ``anchors`` is a dict with the sampled containers:
+    N_int/N_bor[split][layer] (S,C,A), P_int[split][layer] (S,A), P_ext[layer] (A,),
+    S[layer] = (patches (A,Lp), idx list, int_rw (A,W,T), bor_rw (A,W,T))."""
+    B, C, _ = cc_ids.shape
+    sidx = subgraph_idx.view(-1)
+    if channel == 'neighborhood':
+        src = anchors['N_int'] if inside else anchors['N_bor']
+        patches = src[split][layer][sidx]                                   # (B,C,A)
+        embeds = _emb(E, patches)
+        mask = (patches != PAD)
+        return patches.unsqueeze(-1), mask.unsqueeze(-1), embeds
+    if channel == 'position':
+        if inside:
+            patches = anchors['P_int'][split][layer][sidx].unsqueeze(1).repeat(1, C, 1)
+        else:
+            patches = anchors['P_ext'][layer].view(1, 1, -1).repeat(B, C, 1)
+        patches = patches.clone()
+        patches[~cc_mask] = PAD
+        embeds = _emb(E, patches)
+        mask = (patches != PAD)
+        return patches.unsqueeze(-1), mask.unsqueeze(-1), embeds
+    if channel == 'structure':
+        patches, idx, irw, brw = anchors['S'][layer]
+        emb = aggregate_structure_anchor_patch(params, E, irw if inside else brw, hparams)   # (A,D)
+        patches = patches.view(1, 1, *patches.shape).repeat(B, C, 1, 1).clone()
+        patches[~cc_mask] = PAD
+        mask = (patches != PAD)
+        embeds = emb.view(1, 1, *emb.shape).repeat(B, C, 1, 1)
+        embeds = embeds * cc_mask.view(B, C, 1, 1).to(embeds.dtype)         # aps:394
+        return patches, mask, embeds
+    raise ValueError(channel)
+
+
+def sg_mpn_forward(W, b, wp, bp, sims, cc_embeds, anchor_patches, anchor_embeds, anchor_mask,
+                   anchors_sim_index=None, use_mpn_projection=True, norm_pos=False):
+    """subgraph_mpn.py:133-174 as dense tensor algebra.
+
+    edges exist where anchor_mask[..., 0] (mpn:69-71); weight = sims[b,c,anchor_id-1] (N/P,
+    mpn:92-94) or sims[b,c,idx[a]] (S, mpn:88,98-99); message = w * x_anchor (mpn:231);
+    add-aggregate per CC (PyG); update = ReLU(Linear([x || agg])) on every CC row incl. padded
+    ones (mpn:233-239); read-out = Linear(D->1) of the raw messages scattered into a zero
+    (B*C*A, D) matrix, then ReLU or L2-normalise over A (mpn:105-131)."""
+    B, C, D = cc_embeds.shape
+    edge = anchor_mask[..., 0]                                               # (B,C,A)
+    if anchors_sim_index is None:
+        idx = (anchor_patches[..., 0] - 1).clamp(min=0)
+        w = torch.gather(sims, 2, idx)
+    else:
+        w = sims[:, :, torch.as_tensor(anchors_sim_index, dtype=torch.long)]
+    w = w * edge.to(w.dtype)
+    msgs = w.unsqueeze(-1) * anchor_embeds                                   # masked -> 0
+    msgs = msgs * edge.unsqueeze(-1).to(msgs.dtype)
+    agg = msgs.sum(dim=2)
+    if use_mpn_projection:
+        out = F.relu(F.linear(torch.cat([cc_embeds, agg], dim=-1), W, b))
+    else:
+        out = agg
+    pos = F.linear(msgs, wp, bp).squeeze(-1)                                  # (B,C,A)
+    pos = F.normalize(pos, p=2, dim=-1) if norm_pos else F.relu(pos)
+    return out, pos
+
+
+def batch_norm_train(x, weight, bias, eps=1e-5):
+    """nn.BatchNorm1d in training mode over (B*C, D) rows incl. padded ones (SubGNN.py:268)."""
+    return F.batch_norm(x, None, None, weight, bias, True, 0.1, eps)
+
+
+def forward(params, hparams, split, batch, anchors, cc_params=None):
+    """SubGNN.py:225-312 (ff_attn off).  ``params``: reference state-dict keys -> tensors.
+    ``cc_params``: the six (S,C,D) trainable CC embeddings when hparams['trainable_cc']."""
+    E = params['node_embeddings.weight']
+    cc_ids = batch['cc_ids']
+    sidx = batch['subgraph_idx']
+    B, C, _ = cc_ids.shape
+    init = cc_embeddings(E, cc_ids, hparams['cc_aggregator'])
+    state = {}
+    for nm in ('N_I', 'N_B', 'P_I', 'P_B', 'S_I', 'S_B'):
+        if hparams['trainable_cc']:
+            state[nm] = torch.index_select(cc_params[nm], 0, sidx.view(-1))
+        else:
+            state[nm] = init.clone()
+    mask = (cc_ids != PAD)[:, :, 0]
+    bn = bool(hparams.get('batch_norm', False))
+    norm_pos = bool(hparams.get('norm_pos_struc_embed', False))
+    outputs = []
+    chans = (('neighborhood', 'N', 'use_neighborhood', 'neighborhood_mpns'),
+             ('position', 'P', 'use_position', 'position_mpns'),
+             ('structure', 'S', 'use_structure', 'structure_mpns'))
+    for l in range(hparams['n_layers']):
+        for channel, tag, flag, modname in chans:
+            if not hparams[flag]:
+                continue
+            res = {}
+            for inside, side, sname in ((True, 'I', 'internal'), (False, 'B', 'border')):
+                if channel == 'structure':
+                    sims = batch['I_S_sim'] if inside else batch['B_S_sim']
+                    sidx_list = anchors['S'][l][1]
+                else:
+                    sims, sidx_list = batch['NP_sim'], None
+                ap, am, ae = get_anchor_patches(params, hparams, E, sidx, cc_ids, mask, anchors, split, l, channel, inside)
+                pre = '%s.%d.%s.' % (modname, l, sname)
+                o, p = sg_mpn_forward(params[pre + 'linear.weight'], params[pre + 'linear.bias'],
+                                      params[pre + 'linear_position.weight'], params[pre + 'linear_position.bias'],
+                                      sims, state[tag + '_' + side], ap, ae, am, sidx_list,
+                                      hparams['use_mpn_projection'], norm_pos)
+                if bn:
+                    key = 'batch_norm' if inside else 'batch_norm_out'
+                    o = batch_norm_train(o.view(B * C, -1), params['%s.%d.%s.weight' % (modname, l, key)],
+                                         params['%s.%d.%s.bias' % (modname, l, key)]).view(B, C, -1)
+                state[tag + '_' + side] = o
+                res[side] = (o, p)
+            if channel == 'neighborhood':
+                outputs.extend([res['I'][0], res['B'][0]])
+            else:
+                outputs.extend([res['I'][1], res['B'][1]])
+    allcc = torch.cat([init] + outputs, dim=-1)
+    sub = (allcc * mask.unsqueeze(-1).to(allcc.dtype)).sum(dim=1)            # su:213-237
+    h = F.relu(F.linear(sub, params['lin.weight'], params['lin.bias']))
+    h = F.relu(F.linear(h, params['lin2.weight'], params['lin2.bias']))
+    return F.linear(h, params['lin3.weight'], params['lin3.bias'])

@@ -1,0 +1,61 @@
+"""Shared helpers for the parity tests: golden -> tensors, relative-error check."""
+import json
+
+import numpy as np
+import torch
+
+REL_TOL = 1e-4      # BASELINE.json north_star: "within 1e-4 rel on the float channel embeddings"
+
+
+def T(x):
+    return torch.from_numpy(np.ascontiguousarray(x))
+
+
+def rel_err(a, b):
+    a = a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    b = b.detach().cpu().numpy() if isinstance(b, torch.Tensor) else np.asarray(b)
+    scale = np.abs(b).max()
+    if scale == 0:
+        return float(np.abs(a).max())
+    return float(np.abs(a - b).max() / scale)
+
+
+def assert_close(a, b, what, tol=REL_TOL):
+    e = rel_err(a, b)
+    assert e < tol, '%s: relative error %.3e >= %.1e' % (what, e, tol)
+
+
+def g11_case(g, variant):
+    """Unpack one g11 variant: hparams, params (requires_grad), batch, anchors, cc params, labels."""
+    from oracle import integer_half as IH
+    t = 'g11_%s/' % variant
+    hp = json.loads(str(g[t + 'hparams']))
+    params = {}
+    for k in g.files:
+        if k.startswith(t + 'sd/'):
+            v = T(g[k]).clone()
+            if v.dtype == torch.float32:
+                v.requires_grad_(True)
+            params[k[len(t) + 3:]] = v
+    idx = T(g[t + 'idx'])
+    cc_ids = T(IH.trim_zero_columns(g[t + 'cc_ids_train'][g[t + 'idx']]))
+    batch = {'cc_ids': cc_ids, 'subgraph_idx': idx.view(-1, 1), 'NP_sim': T(g[t + 'np_sim_train'])[idx],
+             'I_S_sim': T(g[t + 'int_sim_train'])[idx], 'B_S_sim': T(g[t + 'bor_sim_train'])[idx]}
+    L = hp['n_layers']
+    anchors = {
+        'N_int': {'train': {l: T(g[t + 'N_int_train_%d' % l]) for l in range(L)}},
+        'N_bor': {'train': {l: T(g[t + 'N_bor_train_%d' % l]) for l in range(L)}},
+        'P_int': {'train': {l: T(g[t + 'P_int_train_%d' % l]) for l in range(L)}},
+        'P_ext': {l: T(g[t + 'P_ext_%d' % l]) for l in range(L)},
+        'S': {l: (T(g[t + 'S_patches_%d' % l]), [int(i) for i in g[t + 'S_idx_%d' % l]],
+                  T(g[t + 'S_int_rw_%d' % l]), T(g[t + 'S_bor_rw_%d' % l])) for l in range(L)},
+    }
+    ccp = None
+    if hp['trainable_cc']:
+        ccp = {nm: T(g[t + 'cc_param/' + nm]).clone().requires_grad_(True)
+               for nm in ('N_I', 'N_B', 'S_I', 'S_B', 'P_I', 'P_B')}
+    labels = T(g['labels_train'])[idx]
+    return t, hp, params, batch, anchors, ccp, labels
+
+
+G11_VARIANTS = ('sum', 'max_trainable', 'bn', 'sumlstm_norm')

@@ -1,0 +1,170 @@
+"""The integer-half oracle against the golden vectors produced by the imported reference
+(tests/golden/make_goldens.py).  CPU only."""
+import numpy as np
+
+from oracle import graph as OG, integer_half as IH, tape as T, fastdtw_restate as FD
+
+
+def _graph(g):
+    return OG.from_edge_pairs([tuple(e) for e in g['edge_list']])
+
+
+def _degdict(G):
+    return {v - 1: G.degree(v) for v in G.node_order}
+
+
+def test_g1_graph_order(golden):
+    G = _graph(golden)
+    rp, col = G.csr()
+    assert G.node_order == list(golden['g1_node_order'])
+    assert np.array_equal(rp, golden['g1_rowptr'])
+    assert np.array_equal(col, golden['g1_col'])
+
+
+def test_g2_connected_components(golden):
+    G = _graph(golden)
+    for sp in ('train', 'val'):
+        cc, sub = golden['g2_cc_ids_' + sp], golden['subgraphs_' + sp]
+        for s in range(cc.shape[0]):
+            ref = {frozenset(int(v) for v in row if v != 0) for row in cc[s] if row[0] != 0}
+            mine = {frozenset(c) for c in IH.connected_components(G, [v for v in sub[s] if v != 0])}
+            assert ref == mine
+
+
+def test_g3_border_sets(golden):
+    G = _graph(golden)
+    cc = golden['g2_cc_ids_train']
+    for k in (1, 2, 3):
+        rows = golden.ragged('g3_border_k%d_train' % k, -1)
+        r = 0
+        for s in range(cc.shape[0]):
+            for c in range(cc.shape[1]):
+                assert sorted(IH.component_border_set(G, cc[s, c], k, golden.has_ego)) == rows[r]
+                r += 1
+    gb = golden['g3_border_train']          # what prepare_data stored (k = 2), PAD-filled
+    for s in range(cc.shape[0]):
+        for c in range(cc.shape[1]):
+            mine = sorted(IH.component_border_set(G, cc[s, c], 2, golden.has_ego))
+            assert [m for m in mine if m != 0] == sorted(int(v) for v in gb[s, c] if v != 0)
+
+
+def test_g4_shortest_path_similarities(golden):
+    G = _graph(golden)
+    assert np.array_equal(IH.bfs_all_pairs(G), golden['apsp'])
+    for sp in ('train', 'val'):
+        assert np.array_equal(IH.shortest_path_similarities(golden['apsp'], golden['g2_cc_ids_' + sp]),
+                              golden['g4_np_sim_' + sp])
+
+
+def test_g5_patches_and_walks(golden):
+    G = _graph(golden)
+    hp, seed = golden.hp, golden.seed
+    sa = golden['g5_structure_anchors']
+    n = hp['max_sim_epochs'] * hp['n_anchor_patches_structure'] * hp['n_layers']
+    assert np.array_equal(IH.sample_structure_anchor_patches(G, n, hp['sample_walk_len'], hp['rw_beta'], seed), sa)
+    views = golden.ragged('g5_views_int', 0)
+    iw = IH.perform_random_walks(G, sa, hp['n_triangular_walks'], hp['random_walk_len'], hp['rw_beta'], True, seed,
+                                 patch_orders=views)
+    assert np.array_equal(iw, golden['g5_int_walks'])
+    vb, inb = golden.ragged('g5_views_bor', 0), golden.ragged('g5_in_border', 0)
+    assert all(IH.patch_in_border_nodes(G, v) == b for v, b in zip(vb, inb))
+    bw = IH.perform_random_walks(G, sa, hp['n_triangular_walks'], hp['random_walk_len'], hp['rw_beta'], False, seed,
+                                 patch_orders=vb, in_borders=inb)
+    assert np.array_equal(bw, golden['g5_bor_walks'])
+
+
+def test_g6_degree_sequences(golden):
+    G = _graph(golden)
+    dd = _degdict(G)
+    sa = golden['g5_structure_anchors']
+    cc = golden['g2_cc_ids_train'].reshape(-1, golden['g2_cc_ids_train'].shape[-1])
+    for internal, key in ((True, 'int'), (False, 'ext')):
+        ref = golden.ragged('g6_anchor_deg_' + key, -1)
+        for a in range(sa.shape[0]):
+            assert IH.degree_sequence(G, sa[a], dd, internal) == ref[a]
+        ref = golden.ragged('g6_cc_deg_%s_train' % key, -1)
+        ref2 = golden.ragged('g6_cc_deg_nodict_%s_train' % key, -1)
+        for r in range(cc.shape[0]):
+            assert IH.degree_sequence(G, cc[r], dd, internal) == ref[r]
+            assert IH.degree_sequence(G, cc[r], None, internal) == ref2[r]
+
+
+def test_g6_duplicates_are_kept(golden):
+    """Walk-sampled patches revisit nodes; the degree sequence keeps one entry per visit."""
+    G = _graph(golden)
+    sa = golden['g5_structure_anchors']
+    lens = [(row != 0).sum() for row in sa]
+    uniq = [len(set(int(v) for v in row if v != 0)) for row in sa]
+    assert any(l > u for l, u in zip(lens, uniq))
+    for a in range(sa.shape[0]):
+        assert len(IH.degree_sequence(G, sa[a], None, True)) == lens[a]
+
+
+def test_g7_structure_similarities(golden):
+    """PROVISIONAL: pinned only against the restated fastdtw (parity unpinned)."""
+    G = _graph(golden)
+    dd = _degdict(G)
+    cc, sa = golden['g2_cc_ids_train'], golden['g5_structure_anchors']
+    for internal, key in ((True, 'int'), (False, 'bor')):
+        assert np.array_equal(IH.structure_similarities(G, cc, sa, dd, internal), golden['g7_%s_struc_sim_train' % key])
+
+
+def test_fastdtw_never_below_exact_dtw():
+    rng = np.random.default_rng(0)
+    for _ in range(200):
+        x = sorted(rng.integers(0, 9, rng.integers(1, 26)).tolist())
+        y = sorted(rng.integers(0, 31, rng.integers(1, 51)).tolist())
+        for tie in (0, 1):
+            d, _ = FD.fastdtw(x, y, dist=FD.calc_dist, tie_order=tie)
+            assert d >= FD.exact_dtw(x, y, FD.calc_dist) - 1e-12
+
+
+def test_g8_anchor_tensors(golden):
+    G = _graph(golden)
+    hp, seed = golden.hp, golden.seed
+    for sp in ('train', 'val'):
+        ccs, bs = golden['g2_cc_ids_' + sp], golden['g3_border_' + sp]
+        subs = golden.ragged('subgraphs_' + sp, 0)
+        for l in range(hp['n_layers']):
+            assert np.array_equal(IH.sample_neighborhood_anchors(ccs, hp['n_anchor_patches_N_in'], seed, T.stream_id(T.STREAM_N_INT, sp, l)),
+                                  golden['g8_N_int_%s_%d' % (sp, l)])
+            assert np.array_equal(IH.sample_neighborhood_anchors(bs, hp['n_anchor_patches_N_out'], seed, T.stream_id(T.STREAM_N_BOR, sp, l)),
+                                  golden['g8_N_bor_%s_%d' % (sp, l)])
+            assert np.array_equal(IH.position_anchors_internal(subs, hp['n_anchor_patches_pos_in'], seed, sp, l),
+                                  golden['g8_P_int_%s_%d' % (sp, l)])
+    sa = golden['g5_structure_anchors']
+    for l in range(hp['n_layers']):
+        assert np.array_equal(IH.position_anchors_border(G, hp['n_anchor_patches_pos_out'], seed, l), golden['g8_P_ext_%d' % l])
+        idx = IH.structure_anchor_indices(sa.shape[0], hp['n_anchor_patches_structure'], seed, l)
+        assert idx == list(golden['g8_S_idx_%d' % l])
+        assert np.array_equal(sa[idx], golden['g8_S_patches_%d' % l])
+        assert np.array_equal(golden['g5_int_walks'][idx], golden['g8_S_int_rw_%d' % l])
+
+
+def test_g8_pad_anchor_quirk(golden):
+    """aps:178,190: padded slots hold 0, not -inf, so a short component can yield the PAD anchor."""
+    seen_pad = False
+    for sp in ('train', 'val'):
+        for l in range(golden.hp['n_layers']):
+            a = golden['g8_N_int_%s_%d' % (sp, l)]
+            real = golden['g2_cc_ids_' + sp][:, :, 0] != 0
+            seen_pad |= bool((a[real] == 0).any())
+    assert seen_pad or golden.name == 'density'
+
+
+def test_g12_collate_trim(golden):
+    idx = golden['g12_idx']
+    assert np.array_equal(IH.trim_zero_columns(golden['g2_cc_ids_train'][idx]), golden['g12_cc_ids'])
+    assert np.array_equal(IH.trim_zero_columns(golden['g3_border_train'][idx]), golden['g12_N_border'])
+    assert np.array_equal(golden['g4_np_sim_train'][idx], golden['g12_NP_sim'])
+
+
+def test_tape_scalar_matches_vector():
+    item = np.repeat(np.arange(7), 5)
+    j = np.tile(np.arange(5), 7)
+    st = T.stream_id(T.STREAM_N_BOR, 'val', 3)
+    v = T.draw64_np(99, st, item, j)
+    k = T.symmetric_key_np(99, st, item, j)
+    for a, b, x, y in zip(item, j, v, k):
+        assert T.draw64(99, st, int(a), int(b)) == int(x)
+        assert T.symmetric_key(99, st, int(a), int(b)) == int(y)
