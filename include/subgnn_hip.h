@@ -1,0 +1,249 @@
+/*
+ * subgnn_hip.h -- C ABI of libsubgnn_hip.so: the MI355X (gfx950) kernels behind SubGNN's
+ * anchor-patch sampling + three-channel subgraph message-passing hot path.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer into caller-owned memory (torch tensors on the host
+ *     side); nothing is allocated or freed inside; every call is asynchronous on `stream`
+ *     (a hipStream_t passed as void*), stateless and graph-capturable;
+ *   - return value: 0 = launched, negative = SGNN_ERR_* (argument errors are detected on the
+ *     host before any launch; nothing throws across the ABI);
+ *   - node ids are 1-based, 0 = PAD (reference config.py:9, SubGNN/SubGNN.py:554-559);
+ *   - the base graph is CSR indexed by node id: rowptr int64[max_id + 2] (row 0 = PAD, empty),
+ *     col int32[nnz]; `col` keeps networkx neighbour order (needed by the walks),
+ *     `col_sorted` is the same rows sorted ascending (adjacency tests by binary search);
+ *   - ragged sets (connected components, anchor patches, subgraphs) are
+ *     set_ptr int64[n_sets + 1] + set_nodes int32[set_ptr[n_sets]], PAD already stripped,
+ *     order preserved, duplicates kept -- never the reference's dense zero padding;
+ *   - randomness is the counter-based draw tape draw64(seed, stream, item, j) (DESIGN.md,
+ *     "Draw tape"; oracle twin: oracle/tape.py).
+ *
+ * Each entry point names the reference interface it replaces (paths relative to the
+ * reference root, mims-harvard/SubGNN).
+ */
+#ifndef SUBGNN_HIP_H
+#define SUBGNN_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SGNN_OK                  0
+#define SGNN_ERR_BAD_ARG        -1
+#define SGNN_ERR_SET_TOO_LARGE  -2   /* a set exceeds the size class a kernel supports */
+#define SGNN_ERR_NNZ_TOO_LARGE  -3   /* nnz >= 2^31 (kernels index col with 32 bits) */
+#define SGNN_ERR_LAUNCH         -4   /* hipGetLastError() after a launch */
+#define SGNN_ERR_UNSUPPORTED_D  -5   /* embedding width not supported by the vector path */
+
+#define SGNN_ABI_VERSION 1
+int sgnn_abi_version(void);
+/* last hip error string for SGNN_ERR_LAUNCH (static storage) */
+const char* sgnn_last_error(void);
+
+/* ---------------------------------------------------------------------------------------
+ * a10  Structure-channel CSR gather: degree sequences of node sets.
+ * Replaces gamma.get_degree_sequence (SubGNN/gamma.py:21-49) as called for every anchor patch
+ * and every CC row at SubGNN/SubGNN.py:802-809.
+ *   internal[i] = #neighbours of set_nodes[i] inside its set (self loop counts 2, networkx)
+ *   external[i] = full_degree[id] - internal[i]; full_degree == NULL -> degree from the CSR
+ * One entry per listed node (duplicates kept); if `sorted`, each set's entries are written
+ * in ascending order (gamma.py:35,48).  out_external may be NULL.
+ * max_set_size: upper bound on set length known to the caller (0 = unknown).
+ * ------------------------------------------------------------------------------------- */
+int sgnn_degree_sequence(const int64_t* rowptr, const int32_t* col, int64_t nnz,
+                         const int32_t* full_degree,
+                         const int64_t* set_ptr, const int32_t* set_nodes, int64_t n_sets,
+                         int64_t max_set_size, int sorted,
+                         int32_t* out_internal, int32_t* out_external, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * a7  Connected components of induced subgraphs.
+ * Replaces nx.connected_components(nx.subgraph(G, ids)) at SubGNN/SubGNN.py:589-592.
+ * out_label[i] = smallest position (within its subgraph) of a node in the same component as
+ * position i; duplicates of a node share a label.  Needs col_sorted.
+ * ------------------------------------------------------------------------------------- */
+int sgnn_cc_labels(const int64_t* rowptr, const int32_t* col_sorted, int64_t nnz,
+                   const int64_t* sub_ptr, const int32_t* sub_nodes, int64_t n_subgraphs,
+                   int32_t* out_label, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * a8  k-hop border of a component, and the hop level of each border node.
+ * Replaces subgraph_utils.get_component_border_neighborhood_set (SubGNN/subgraph_utils.py:
+ * 146-176) / SubGNN.initialize_border_sets (SubGNN/SubGNN.py:673-700).
+ * Two-pass protocol: call with out_nodes == NULL to get out_count[s]; prefix-sum on the host
+ * into out_ptr; call again with out_ptr/out_nodes (and optionally out_hop) to fill.  Entries
+ * of a set come in discovery order (not sorted).
+ * ego_dict_mode != 0 reproduces the `ego_graphs.txt` path (su:168-174): 1 hop only and every
+ * border id is (true id - 1), differenced against the 1-based component (id 0 can appear).
+ * workspace: sgnn_khop_border_workspace_bytes(max_id, n_sets) bytes, ZERO-initialised by the
+ * caller (per-workgroup visited bitmap + BFS queue; the bitmaps are left zeroed).
+ * ------------------------------------------------------------------------------------- */
+int64_t sgnn_khop_border_workspace_bytes(int64_t max_id, int64_t n_sets);
+int sgnn_khop_border(const int64_t* rowptr, const int32_t* col, int64_t nnz, int64_t max_id,
+                     const int64_t* set_ptr, const int32_t* set_nodes, int64_t n_sets,
+                     int k, int ego_dict_mode,
+                     int64_t* out_count, const int64_t* out_ptr, int32_t* out_nodes, uint8_t* out_hop,
+                     void* workspace, int64_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * a4  Neighbourhood anchor sampling from padded id matrices.
+ * Replaces anchor_patch_samplers.sample_neighborhood_anchor_patch (anchor_patch_samplers.py:
+ * 163-198): for slot i and row r the winner is the argmax over the row of the tape variate
+ * z(r*n_slots+i, id), with z := 0 on PAD entries (aps:178,190) -> PAD wins when every real
+ * variate is negative and the row has a PAD entry.  ids: (n_rows, L) int64, out (n_rows, n_slots).
+ * ------------------------------------------------------------------------------------- */
+int sgnn_sample_anchors_padded(const int64_t* ids, int64_t n_rows, int64_t L, int64_t n_slots,
+                               uint64_t seed, uint64_t stream_id, int64_t* out, void* stream);
+/* same law on ragged sets; row_has_pad[r] says whether the padded row would hold a PAD */
+int sgnn_sample_anchors_ragged(const int64_t* set_ptr, const int32_t* set_nodes, int64_t n_sets,
+                               const uint8_t* row_has_pad, int64_t n_slots,
+                               uint64_t seed, uint64_t stream_id, int64_t* out, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * a5/a6  Uniform draws with replacement from a list (position anchors, structure picks).
+ * Replaces np.random.choice(seq, n, replace=True) at anchor_patch_samplers.py:206,208,326.
+ * item r draws from seq[ptr[r] .. ptr[r+1]); out (n_items, n_draws) int64.
+ * ------------------------------------------------------------------------------------- */
+int sgnn_choice_ragged(const int64_t* ptr, const int32_t* seq, int64_t n_items, int64_t n_draws,
+                       uint64_t seed, uint64_t stream_id, int64_t* out, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * a1-a3  Triangular random walks.
+ * Replaces anchor_patch_samplers.triangular_random_walk / perform_random_walks /
+ * sample_structure_anchor_patches (anchor_patch_samplers.py:20-158, 210-243).
+ *   mode 0  'graph' : start = uniform over node_order (aps:70 with the whole graph)
+ *   mode 1  'inside': walk inside the induced subgraph of patch p = item / walks_per_patch;
+ *                     start uniform over the patch's node view  patch_ptr/patch_nodes (unique)
+ *   mode 2  'border': start uniform over in_border nodes (inb_ptr/inb_nodes); neighbours
+ *                     restricted to in_border U (V \ patch) (aps:141-143)
+ * out: (n_items, walk_len) int64, PAD filled.  One tape item per walk (item = walk index).
+ * ------------------------------------------------------------------------------------- */
+int sgnn_triangular_walks(const int64_t* rowptr, const int32_t* col, const int32_t* col_sorted, int64_t nnz,
+                          const int32_t* node_order, int64_t n_nodes,
+                          const int64_t* patch_ptr, const int32_t* patch_nodes,
+                          const int64_t* inb_ptr, const int32_t* inb_nodes,
+                          int mode, int64_t n_items, int64_t walks_per_patch, int64_t walk_len, double beta,
+                          uint64_t seed, uint64_t stream_id, int64_t* out, void* stream);
+
+/* in-border nodes of a patch (subgraph_utils.get_border_nodes, subgraph_utils.py:126-144, with
+ * its id-1 / node-order indexing quirk): out_flag[i] = 1 iff patch_nodes[i] is a border node.
+ * node_order[i] = id at position i of G.nodes(); node_pos[id] = position (0-based). */
+int sgnn_patch_in_border(const int64_t* rowptr, const int32_t* col, int64_t nnz,
+                         const int32_t* node_order, const int32_t* node_pos, int64_t n_nodes,
+                         const int64_t* patch_ptr, const int32_t* patch_nodes, int64_t n_patches,
+                         uint8_t* out_flag, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * a9  Shortest-path similarities.
+ * Replaces SubGNN.compute_shortest_path_similarities (SubGNN/SubGNN.py:752-781), dense-parity
+ * form: out[r, :] = min over v in set r of apsp[v-1, :] (float64 in, float32 out), empty set
+ * -> PAD.  apsp: (n, n_cols) row-major.
+ * ------------------------------------------------------------------------------------- */
+int sgnn_sp_similarity_dense(const double* apsp, int64_t n_cols,
+                             const int64_t* set_ptr, const int32_t* set_nodes, int64_t n_sets,
+                             float* out, void* stream);
+/* sparse form for graphs where the N x N matrix cannot exist: hop distance from each of
+ * n_sources source nodes to every node, by a level-synchronous bit-parallel multi-source BFS
+ * (64 sources per machine word).  dist: (n_sources, max_id + 1) uint8, 255 = not reached within
+ * max_hops (the reference's matrix holds 0 for unreachable pairs, precompute_graph_metrics.py:
+ * 20-25; sgnn_min_hops_to_sets applies that convention).
+ * workspace: sgnn_bfs_hops_workspace_bytes(max_id, n_sources, max_hops) bytes (any content). */
+int64_t sgnn_bfs_hops_workspace_bytes(int64_t max_id, int64_t n_sources, int max_hops);
+int sgnn_bfs_hops(const int64_t* rowptr, const int32_t* col, int64_t nnz, int64_t max_id,
+                  const int32_t* sources, int64_t n_sources, int max_hops,
+                  uint8_t* dist, void* workspace, int64_t workspace_bytes, void* stream);
+/* out[r, a] = min over v in set r of (dist[a, v] == 255 ? 0 : dist[a, v])  (float32; empty set -> 0) */
+int sgnn_min_hops_to_sets(const uint8_t* dist, int64_t n_sources, int64_t max_id,
+                          const int64_t* set_ptr, const int32_t* set_nodes, int64_t n_sets,
+                          float* out, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * a11  Structure similarity: 1 / (1 + fastdtw(x, y, radius=1, dist=calc_dist)).
+ * Replaces gamma.calc_dist / gamma.calc_dtw (SubGNN/gamma.py:51-59) and the all-pairs driver
+ * SubGNN.compute_structure_patch_similarities (SubGNN/SubGNN.py:783-833).
+ * x = CC degree sequences (x_ptr/x_val, n_x rows), y = anchor degree sequences (n_y rows);
+ * out (n_x, n_y) float32; rows with an empty x are PAD (SubGNN.py:831).  fp64 DP.
+ * tie_order 0 = (i-1,j),(i,j-1),(i-1,j-1) first minimum (pure-Python fastdtw 0.3.4).
+ * workspace: sgnn_dtw_workspace_bytes(max_x_len, max_y_len) bytes (any content).
+ * ------------------------------------------------------------------------------------- */
+int64_t sgnn_dtw_workspace_bytes(int64_t max_x_len, int64_t max_y_len);
+int sgnn_dtw_similarity(const int64_t* x_ptr, const int32_t* x_val, int64_t n_x, int64_t max_x_len,
+                        const int64_t* y_ptr, const int32_t* y_val, int64_t n_y, int64_t max_y_len,
+                        int tie_order, float* out, void* workspace, int64_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * a12  CC embedding initialisation: sum or max of member node embeddings.
+ * Replaces SubGNN.initialize_cc_embeddings (SubGNN/SubGNN.py:609-622).  E: (n_emb_rows, D) f32.
+ * aggregator 0 = sum, 1 = max.  For max, a row shorter than padded_len also competes with the
+ * zero PAD row (SubGNN.py:622); out_arg (n_sets, D) int32 receives the winning node id
+ * (0 = PAD) for the backward pass.
+ * ------------------------------------------------------------------------------------- */
+int sgnn_cc_embed_fwd(const float* E, int64_t D,
+                      const int64_t* set_ptr, const int32_t* set_nodes, int64_t n_sets,
+                      int aggregator, int64_t padded_len, float* out, int32_t* out_arg, void* stream);
+/* grad_E (n_emb_rows, D) is accumulated into (float atomics), row PAD untouched */
+int sgnn_cc_embed_bwd(const float* grad_out, int64_t D,
+                      const int64_t* set_ptr, const int32_t* set_nodes, int64_t n_sets,
+                      int aggregator, const int32_t* arg, float* grad_E, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * a13+a15  One anchor -> component message-passing layer (gather, weight, aggregate, read-out).
+ * Replaces the body of SG_MPN.forward / propagate / message / generate_pos_struc_embeddings
+ * (SubGNN/subgraph_mpn.py:105-174, 227-231) together with the anchor gather of
+ * anchor_patch_samplers.get_anchor_patches / embed_anchor_patch (anchor_patch_samplers.py:
+ * 333-411).  For row r (= b*C + c) and anchor slot a:
+ *     edge(r,a)  -- see `src`
+ *     w          = sims[r*sims_ld + column(r,a)]
+ *     agg[r,:]   = sum_a edge * w * x(r,a,:)
+ *     z[r,a]     = edge ? w * <wp, x(r,a,:)> + bp : bp       (pre-activation read-out)
+ * Anchor rows x(r,a,:) come from one of three sources:
+ *   SGNN_SRC_DENSE  x = anchor_embeds[(r*A+a)*D ..]  (the reference's materialised (B,C,A,D)
+ *                   tensor); edge = edge_mask[r*A+a]
+ *   SGNN_SRC_GATHER x = E[ids[(r/id_div)*A+a]*D ..]; edge = id != 0 && row_mask[r]
+ *   SGNN_SRC_SHARED x = X[a*D ..] (P-border / structure anchors shared by every row);
+ *                   edge = row_mask[r] && (ids == NULL || ids[a] != 0)
+ * column(r,a): sim_col != NULL -> sim_col[a]; else sims_per_edge -> a; else id - 1.
+ * The Linear(2D->D)+ReLU update (subgraph_mpn.py:233-239) is a plain GEMM done by the caller.
+ * ------------------------------------------------------------------------------------- */
+#define SGNN_SRC_DENSE  0
+#define SGNN_SRC_GATHER 1
+#define SGNN_SRC_SHARED 2
+
+typedef struct sgnn_mpn_args {
+    int32_t src;               /* SGNN_SRC_* */
+    int32_t sims_per_edge;     /* 1: sims is (R, A) already gathered */
+    int64_t R, A, D;
+    const float*   x;          /* DENSE: (R,A,D) anchor_embeds; GATHER: E (rows,D); SHARED: X (A,D) */
+    const int64_t* ids;        /* DENSE/GATHER: (R/id_div, A) anchor ids; SHARED: (A) or NULL */
+    int64_t        id_div;     /* rows sharing one ids row (C for P-internal, else 1) */
+    const uint8_t* edge_mask;  /* DENSE: (R,A) */
+    const uint8_t* row_mask;   /* GATHER/SHARED: (R) cc_embed_mask, may be NULL (= all real) */
+    const float*   sims;       /* (R, sims_ld) */
+    int64_t        sims_ld;
+    const int64_t* sim_col;    /* (A) or NULL */
+    const float*   wp;         /* (D) linear_position.weight */
+    const float*   bp;         /* (1) linear_position.bias   */
+} sgnn_mpn_args;
+
+int sgnn_mpn_fwd(const sgnn_mpn_args* args, float* agg /*(R,D)*/, float* z /*(R,A)*/, void* stream);
+/* grad_x: DENSE (R,A,D) written; GATHER (rows,D) accumulated with float atomics, row PAD
+ * untouched; SHARED (A,D) accumulated.  grad_wp (D) accumulated.  Any of them may be NULL. */
+int sgnn_mpn_bwd(const sgnn_mpn_args* args, const float* grad_agg, const float* grad_z,
+                 float* grad_x, float* grad_wp, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * a16  Masked sum over the components of a subgraph (subgraph_utils.masked_sum,
+ * SubGNN/subgraph_utils.py:213-237, as used at SubGNN/SubGNN.py:303).  x (B,C,H), mask (B,C)
+ * -> out (B,H); backward scatters grad_out to the real components.
+ * ------------------------------------------------------------------------------------- */
+int sgnn_masked_sum_fwd(const float* x, const uint8_t* mask, int64_t B, int64_t C, int64_t H,
+                        float* out, void* stream);
+int sgnn_masked_sum_bwd(const float* grad_out, const uint8_t* mask, int64_t B, int64_t C, int64_t H,
+                        float* grad_x, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SUBGNN_HIP_H */

@@ -1,0 +1,91 @@
+"""ctypes loader for libsubgnn_hip.so -- the only compute backend of this package.
+
+There is deliberately NO fallback: if the HIP library is missing or a kernel reports an
+error, the call raises.  (The CPU oracle under ``oracle/`` is test infrastructure and is
+never imported from here.)
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib', 'libsubgnn_hip.so')
+
+c_i64 = ctypes.c_int64
+c_u64 = ctypes.c_uint64
+c_int = ctypes.c_int
+c_dbl = ctypes.c_double
+c_ptr = ctypes.c_void_p
+
+
+class MpnArgs(ctypes.Structure):
+    """struct sgnn_mpn_args (include/subgnn_hip.h)."""
+    _fields_ = [('src', ctypes.c_int32), ('sims_per_edge', ctypes.c_int32),
+                ('R', c_i64), ('A', c_i64), ('D', c_i64),
+                ('x', c_ptr), ('ids', c_ptr), ('id_div', c_i64), ('edge_mask', c_ptr), ('row_mask', c_ptr),
+                ('sims', c_ptr), ('sims_ld', c_i64), ('sim_col', c_ptr), ('wp', c_ptr), ('bp', c_ptr)]
+
+
+# name -> (restype, argtypes); mirrors include/subgnn_hip.h line by line
+SIGNATURES = {
+    'sgnn_abi_version': (c_int, []),
+    'sgnn_last_error': (ctypes.c_char_p, []),
+    'sgnn_degree_sequence': (c_int, [c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_int, c_ptr, c_ptr, c_ptr]),
+    'sgnn_cc_labels': (c_int, [c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_ptr, c_ptr]),
+    'sgnn_khop_border_workspace_bytes': (c_i64, [c_i64, c_i64]),
+    'sgnn_khop_border': (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_i64, c_int, c_int, c_ptr, c_ptr, c_ptr,
+                                 c_ptr, c_ptr, c_i64, c_ptr]),
+    'sgnn_sample_anchors_padded': (c_int, [c_ptr, c_i64, c_i64, c_i64, c_u64, c_u64, c_ptr, c_ptr]),
+    'sgnn_sample_anchors_ragged': (c_int, [c_ptr, c_ptr, c_i64, c_ptr, c_i64, c_u64, c_u64, c_ptr, c_ptr]),
+    'sgnn_choice_ragged': (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_u64, c_u64, c_ptr, c_ptr]),
+    'sgnn_triangular_walks': (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_int,
+                                      c_i64, c_i64, c_i64, c_dbl, c_u64, c_u64, c_ptr, c_ptr]),
+    'sgnn_patch_in_border': (c_int, [c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_ptr, c_ptr]),
+    'sgnn_sp_similarity_dense': (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_ptr, c_ptr]),
+    'sgnn_bfs_hops_workspace_bytes': (c_i64, [c_i64, c_i64, c_int]),
+    'sgnn_bfs_hops': (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_i64, c_int, c_ptr, c_ptr, c_i64, c_ptr]),
+    'sgnn_min_hops_to_sets': (c_int, [c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_i64, c_ptr, c_ptr]),
+    'sgnn_dtw_workspace_bytes': (c_i64, [c_i64, c_i64]),
+    'sgnn_dtw_similarity': (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_i64, c_i64, c_int, c_ptr, c_ptr,
+                                    c_i64, c_ptr]),
+    'sgnn_cc_embed_fwd': (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_int, c_i64, c_ptr, c_ptr, c_ptr]),
+    'sgnn_cc_embed_bwd': (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_int, c_ptr, c_ptr, c_ptr]),
+    'sgnn_mpn_fwd': (c_int, [ctypes.POINTER(MpnArgs), c_ptr, c_ptr, c_ptr]),
+    'sgnn_mpn_bwd': (c_int, [ctypes.POINTER(MpnArgs), c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
+    'sgnn_masked_sum_fwd': (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_i64, c_ptr, c_ptr]),
+    'sgnn_masked_sum_bwd': (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_i64, c_ptr, c_ptr]),
+}
+
+ERRORS = {-1: 'SGNN_ERR_BAD_ARG', -2: 'SGNN_ERR_SET_TOO_LARGE', -3: 'SGNN_ERR_NNZ_TOO_LARGE',
+          -4: 'SGNN_ERR_LAUNCH', -5: 'SGNN_ERR_UNSUPPORTED_D'}
+
+_lib = None
+
+
+class SubgnnHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared library (raises if it has not been built: no CPU fallback exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SubgnnHipError('libsubgnn_hip.so is missing (%s): build it with `python -m subgnn_amd.build`; '
+                             'this package has no CPU fallback' % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the header and the library disagree
+        fn.restype = res
+        fn.argtypes = args
+    if lib.sgnn_abi_version() != 1:
+        raise SubgnnHipError('ABI version mismatch')
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        lib = load()
+        detail = lib.sgnn_last_error().decode() if rc == -4 else ''
+        raise SubgnnHipError('%s failed: %s %s' % (what, ERRORS.get(rc, rc), detail))

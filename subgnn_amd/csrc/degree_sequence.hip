@@ -1,0 +1,281 @@
+// Structure-channel CSR gather: internal / external degree sequences of node sets.
+// Replaces gamma.get_degree_sequence (reference SubGNN/gamma.py:21-49).
+//
+// HBM-bound: per set S the algorithmic traffic is  sum_{v in S} (16 + 4 deg(v)) + 8 |S|  bytes
+// (rowptr pair, neighbour list, id in, two degrees out).  Design:
+//   * one 64-lane wavefront per set (|S| <= 64; the common case: CCs and walk patches);
+//     lane i owns member i: loads its id and rowptr pair, inserts the id into a 128-slot
+//     open-addressing hash in LDS (the set's membership structure);
+//   * the neighbour lists of all members are streamed as ONE flat range of sum(deg) items,
+//     64 items per step: lane l locates its (member, offset) by a 6-step binary search over
+//     the wave-resident inclusive degree scan (ds_bpermute), loads col[] (consecutive lanes hit
+//     consecutive addresses inside a list -> coalesced 256 B runs even across list ends),
+//     probes the LDS hash, and the hits are reduced per member with wavefront ballot +
+//     popcount over each member's bit range -- no atomics, no divergence on list length;
+//   * per-set ascending order by an in-register rank sort (n <= 64 compare rounds of readlane).
+//   * sets of 65..2048 entries take a 256-thread workgroup variant (LDS scan, LDS integer
+//     atomics, LDS bitonic sort).
+#include "common.h"
+
+#define DS_HASH_BITS 7
+#define DS_HASH (1 << DS_HASH_BITS)
+
+template <bool SORTED>
+__global__ __launch_bounds__(64) void degseq_wave_kernel(
+    const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+    const int32_t* __restrict__ full_degree,
+    const int64_t* __restrict__ set_ptr, const int32_t* __restrict__ set_nodes, int64_t n_sets,
+    int32_t* __restrict__ out_int, int32_t* __restrict__ out_ext)
+{
+    __shared__ int32_t hash[DS_HASH];
+    const int lane = threadIdx.x;
+    for (int64_t s = blockIdx.x; s < n_sets; s += gridDim.x) {
+        const int64_t beg = set_ptr[s];
+        const int n = (int)(set_ptr[s + 1] - beg);
+        if (n <= 0 || n > 64) continue;                     // wave-uniform
+        hash[lane] = 0;
+        hash[lane + 64] = 0;
+        __syncthreads();
+        int32_t v = 0, deg = 0;
+        uint32_t r0 = 0;
+        if (lane < n) {
+            v = set_nodes[beg + lane];
+            const int64_t a = rowptr[v], b = rowptr[v + 1];
+            r0 = (uint32_t)a;
+            deg = (int32_t)(b - a);
+            uint32_t h = sgnn_hash32((uint32_t)v) >> (32 - DS_HASH_BITS);
+            while (true) {
+                const int32_t old = atomicCAS(&hash[h], 0, v);
+                if (old == 0 || old == v) break;
+                h = (h + 1) & (DS_HASH - 1);
+            }
+        }
+        __syncthreads();
+        int32_t incl = deg;                                  // inclusive scan over the wave
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int32_t t = __shfl_up(incl, d);
+            if (lane >= d) incl += t;
+        }
+        const int32_t total = __shfl(incl, 63);
+        const int32_t excl = incl - deg;
+        int32_t cnt = 0, selfc = 0;
+        for (int32_t base = 0; base < total; base += 64) {
+            const int32_t t = base + lane;
+            int lo = 0, hi = 63;                             // smallest m with incl[m] > t
+#pragma unroll
+            for (int it = 0; it < 6; ++it) {
+                const int mid = (lo + hi) >> 1;
+                const int32_t x = __shfl(incl, mid);
+                if (x > t) hi = mid; else lo = mid + 1;
+            }
+            const int m = lo & 63;
+            const bool valid = t < total;
+            const int32_t m_excl = __shfl(excl, m);
+            const uint32_t m_r0 = __shfl(r0, m);
+            const int32_t m_v = __shfl(v, m);
+            bool hit = false, self = false;
+            if (valid) {
+                const int32_t u = col[m_r0 + (uint32_t)(t - m_excl)];
+                self = (u == m_v);
+                uint32_t h = sgnn_hash32((uint32_t)u) >> (32 - DS_HASH_BITS);
+                while (true) {
+                    const int32_t k = hash[h];
+                    if (k == u) { hit = true; break; }
+                    if (k == 0) break;
+                    h = (h + 1) & (DS_HASH - 1);
+                }
+            }
+            const uint64_t mh = __ballot(hit);
+            const uint64_t ms = __ballot(self);
+            int32_t lo_i = excl - base, hi_i = incl - base;   // this lane's member range in the step
+            lo_i = lo_i < 0 ? 0 : (lo_i > 64 ? 64 : lo_i);
+            hi_i = hi_i < 0 ? 0 : (hi_i > 64 ? 64 : hi_i);
+            const uint64_t below_hi = hi_i >= 64 ? ~0ull : ((1ull << hi_i) - 1ull);
+            const uint64_t below_lo = lo_i >= 64 ? ~0ull : ((1ull << lo_i) - 1ull);
+            const uint64_t rm = below_hi & ~below_lo;
+            const int32_t sc = __popcll(ms & rm);
+            cnt += __popcll(mh & rm) + sc;                    // a self loop counts twice (networkx)
+            selfc += sc;
+        }
+        int32_t full = deg + selfc;
+        if (full_degree != nullptr && lane < n) full = full_degree[v];
+        const int32_t internal = cnt;
+        const int32_t external = full - cnt;
+        if (!SORTED) {
+            if (lane < n) {
+                out_int[beg + lane] = internal;
+                if (out_ext) out_ext[beg + lane] = external;
+            }
+        } else {
+            int ri = 0, re = 0;                              // stable rank among the n entries
+            for (int j = 0; j < n; ++j) {
+                const int32_t xj = __shfl(internal, j);
+                const int32_t ej = __shfl(external, j);
+                ri += (xj < internal) || (xj == internal && j < lane);
+                re += (ej < external) || (ej == external && j < lane);
+            }
+            if (lane < n) {
+                out_int[beg + ri] = internal;
+                if (out_ext) out_ext[beg + re] = external;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ---- workgroup variant for 64 < |S| <= DSB_MAX ------------------------------------------------
+#define DSB_MAX 2048
+#define DSB_HASH_BITS 12
+#define DSB_HASH (1 << DSB_HASH_BITS)
+#define DSB_THREADS 256
+
+__device__ static inline void dsb_bitonic_sort(int32_t* a, int n_pow2, int tid) {
+    for (int k = 2; k <= n_pow2; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < n_pow2; i += DSB_THREADS) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const int32_t x = a[i], y = a[ixj];
+                    const bool up = ((i & k) == 0);
+                    if ((x > y) == up) { a[i] = y; a[ixj] = x; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+template <bool SORTED>
+__global__ __launch_bounds__(DSB_THREADS) void degseq_block_kernel(
+    const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+    const int32_t* __restrict__ full_degree,
+    const int64_t* __restrict__ set_ptr, const int32_t* __restrict__ set_nodes, int64_t n_sets,
+    int32_t* __restrict__ out_int, int32_t* __restrict__ out_ext)
+{
+    __shared__ int32_t hash[DSB_HASH];
+    __shared__ int32_t s_v[DSB_MAX];
+    __shared__ uint32_t s_r0[DSB_MAX];
+    __shared__ int32_t s_incl[DSB_MAX];
+    __shared__ int32_t s_cnt[DSB_MAX];
+    __shared__ int32_t s_self[DSB_MAX];
+    __shared__ int32_t s_part[DSB_THREADS];
+    const int tid = threadIdx.x;
+    for (int64_t s = blockIdx.x; s < n_sets; s += gridDim.x) {
+        const int64_t beg = set_ptr[s];
+        const int n = (int)(set_ptr[s + 1] - beg);
+        if (n <= 64 || n > DSB_MAX) continue;               // block-uniform
+        for (int i = tid; i < DSB_HASH; i += DSB_THREADS) hash[i] = 0;
+        __syncthreads();
+        for (int i = tid; i < n; i += DSB_THREADS) {
+            const int32_t v = set_nodes[beg + i];
+            const int64_t a = rowptr[v], b = rowptr[v + 1];
+            s_v[i] = v;
+            s_r0[i] = (uint32_t)a;
+            s_incl[i] = (int32_t)(b - a);
+            s_cnt[i] = 0;
+            s_self[i] = 0;
+            uint32_t h = sgnn_hash32((uint32_t)v) >> (32 - DSB_HASH_BITS);
+            while (true) {
+                const int32_t old = atomicCAS(&hash[h], 0, v);
+                if (old == 0 || old == v) break;
+                h = (h + 1) & (DSB_HASH - 1);
+            }
+        }
+        __syncthreads();
+        // inclusive scan of s_incl[0..n): per-thread chunks of 8, then a scan of the 256 partials
+        const int per = (n + DSB_THREADS - 1) / DSB_THREADS;
+        const int c0 = tid * per, c1 = (c0 + per < n) ? c0 + per : n;
+        int32_t acc = 0;
+        for (int i = c0; i < c1; ++i) { acc += s_incl[i]; s_incl[i] = acc; }
+        s_part[tid] = acc;
+        __syncthreads();
+        for (int d = 1; d < DSB_THREADS; d <<= 1) {
+            int32_t t = 0;
+            if (tid >= d) t = s_part[tid - d];
+            __syncthreads();
+            s_part[tid] += t;
+            __syncthreads();
+        }
+        const int32_t offset = (tid == 0) ? 0 : s_part[tid - 1];
+        for (int i = c0; i < c1; ++i) s_incl[i] += offset;
+        __syncthreads();
+        const int32_t total = s_incl[n - 1];
+        for (int32_t t = tid; t < total; t += DSB_THREADS) {
+            int lo = 0, hi = n - 1;
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (s_incl[mid] > t) hi = mid; else lo = mid + 1;
+            }
+            const int m = lo;
+            const int32_t m_excl = (m == 0) ? 0 : s_incl[m - 1];
+            const int32_t u = col[s_r0[m] + (uint32_t)(t - m_excl)];
+            uint32_t h = sgnn_hash32((uint32_t)u) >> (32 - DSB_HASH_BITS);
+            bool hit = false;
+            while (true) {
+                const int32_t k = hash[h];
+                if (k == u) { hit = true; break; }
+                if (k == 0) break;
+                h = (h + 1) & (DSB_HASH - 1);
+            }
+            if (u == s_v[m]) { atomicAdd(&s_cnt[m], 2); atomicAdd(&s_self[m], 1); }
+            else if (hit) atomicAdd(&s_cnt[m], 1);
+        }
+        __syncthreads();
+        // s_cnt = internal; reuse s_self for external
+        for (int i = tid; i < n; i += DSB_THREADS) {
+            const int32_t deg = s_incl[i] - (i == 0 ? 0 : s_incl[i - 1]);
+            const int32_t full = full_degree ? full_degree[s_v[i]] : deg + s_self[i];
+            s_r0[i] = (uint32_t)(full - s_cnt[i]);
+        }
+        __syncthreads();
+        int32_t* s_ext = reinterpret_cast<int32_t*>(s_r0);
+        if (SORTED) {
+            int np2 = 128;
+            while (np2 < n) np2 <<= 1;
+            for (int i = n + tid; i < np2; i += DSB_THREADS) { s_cnt[i] = INT32_MAX; s_ext[i] = INT32_MAX; }
+            __syncthreads();
+            dsb_bitonic_sort(s_cnt, np2, tid);
+            if (out_ext) dsb_bitonic_sort(s_ext, np2, tid);
+        }
+        for (int i = tid; i < n; i += DSB_THREADS) {
+            out_int[beg + i] = s_cnt[i];
+            if (out_ext) out_ext[beg + i] = s_ext[i];
+        }
+        __syncthreads();
+    }
+}
+
+extern "C" int sgnn_degree_sequence(const int64_t* rowptr, const int32_t* col, int64_t nnz,
+                                    const int32_t* full_degree,
+                                    const int64_t* set_ptr, const int32_t* set_nodes, int64_t n_sets,
+                                    int64_t max_set_size, int sorted,
+                                    int32_t* out_internal, int32_t* out_external, void* stream)
+{
+    if (!rowptr || !col || !set_ptr || !set_nodes || !out_internal || n_sets < 0 || max_set_size <= 0)
+        return SGNN_ERR_BAD_ARG;
+    if (nnz >= (1ll << 31)) return SGNN_ERR_NNZ_TOO_LARGE;
+    if (max_set_size > DSB_MAX) return SGNN_ERR_SET_TOO_LARGE;
+    if (n_sets == 0) return SGNN_OK;
+    hipStream_t st = (hipStream_t)stream;
+    // 64-thread workgroups, grid-stride over sets: 256 CUs x 32 waves resident
+    const int grid = (int)(n_sets < 256 * 32 ? n_sets : 256 * 32);
+    if (sorted)
+        hipLaunchKernelGGL(degseq_wave_kernel<true>, dim3(grid), dim3(64), 0, st, rowptr, col, full_degree,
+                           set_ptr, set_nodes, n_sets, out_internal, out_external);
+    else
+        hipLaunchKernelGGL(degseq_wave_kernel<false>, dim3(grid), dim3(64), 0, st, rowptr, col, full_degree,
+                           set_ptr, set_nodes, n_sets, out_internal, out_external);
+    SGNN_CHECK_LAUNCH();
+    if (max_set_size > 64) {
+        const int gridb = (int)(n_sets < 256 * 4 ? n_sets : 256 * 4);
+        if (sorted)
+            hipLaunchKernelGGL(degseq_block_kernel<true>, dim3(gridb), dim3(DSB_THREADS), 0, st, rowptr, col,
+                               full_degree, set_ptr, set_nodes, n_sets, out_internal, out_external);
+        else
+            hipLaunchKernelGGL(degseq_block_kernel<false>, dim3(gridb), dim3(DSB_THREADS), 0, st, rowptr, col,
+                               full_degree, set_ptr, set_nodes, n_sets, out_internal, out_external);
+        SGNN_CHECK_LAUNCH();
+    }
+    return SGNN_OK;
+}

@@ -1,0 +1,170 @@
+// CC embedding initialisation (a12) and the masked read-out over components (a16).
+#include "common.h"
+
+// ---------------------------------------------------------------------------------------------
+// a12  out[r,:] = sum | max over members of E[id,:]   (reference SubGNN/SubGNN.py:609-622)
+// HBM-bound random-row gather: 4*D bytes per member + 8 per member id + 4*D out per component.
+// Thread = (component row, 16-byte column slice): the D/4 lanes of a row read one embedding row
+// as consecutive float4 (256 B for D=64), different rows of a wavefront proceed independently,
+// member loop unrolled for memory-level parallelism.
+// ---------------------------------------------------------------------------------------------
+template <int AGG>
+__global__ __launch_bounds__(256) void cc_embed_fwd_kernel(
+    const float* __restrict__ E, int64_t D4,
+    const int64_t* __restrict__ set_ptr, const int32_t* __restrict__ set_nodes, int64_t n_sets,
+    int64_t padded_len, float* __restrict__ out, int32_t* __restrict__ out_arg)
+{
+    const int64_t total = n_sets * D4;
+    const float4* E4 = reinterpret_cast<const float4*>(E);
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = t / D4, dv = t % D4;
+        const int64_t beg = set_ptr[r];
+        const int n = (int)(set_ptr[r + 1] - beg);
+        float4 acc;
+        int4 arg = make_int4(0, 0, 0, 0);
+        if (AGG == 0) {
+            acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
+            for (int i = 0; i < n; ++i) {
+                const float4 x = E4[(int64_t)set_nodes[beg + i] * D4 + dv];
+                acc.x += x.x; acc.y += x.y; acc.z += x.z; acc.w += x.w;
+            }
+        } else {
+            // PAD rows (zeros) take part in the max whenever the padded row is longer than the
+            // component (SubGNN.py:622); an empty row is all PAD.
+            const bool with_pad = (n < padded_len) || (n == 0);
+            const float init = with_pad ? 0.f : -INFINITY;
+            acc = make_float4(init, init, init, init);
+#pragma unroll 4
+            for (int i = 0; i < n; ++i) {
+                const int32_t id = set_nodes[beg + i];
+                const float4 x = E4[(int64_t)id * D4 + dv];
+                if (x.x > acc.x) { acc.x = x.x; arg.x = id; }
+                if (x.y > acc.y) { acc.y = x.y; arg.y = id; }
+                if (x.z > acc.z) { acc.z = x.z; arg.z = id; }
+                if (x.w > acc.w) { acc.w = x.w; arg.w = id; }
+            }
+            if (out_arg) reinterpret_cast<int4*>(out_arg)[t] = arg;
+        }
+        reinterpret_cast<float4*>(out)[t] = acc;
+    }
+}
+
+template <int AGG>
+__global__ __launch_bounds__(256) void cc_embed_bwd_kernel(
+    const float* __restrict__ grad_out, int64_t D4,
+    const int64_t* __restrict__ set_ptr, const int32_t* __restrict__ set_nodes, int64_t n_sets,
+    const int32_t* __restrict__ arg, float* __restrict__ grad_E)
+{
+    const int64_t total = n_sets * D4;
+    const int64_t D = D4 * 4;
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = t / D4, dv = t % D4;
+        const float4 g = reinterpret_cast<const float4*>(grad_out)[t];
+        if (AGG == 0) {
+            const int64_t beg = set_ptr[r];
+            const int n = (int)(set_ptr[r + 1] - beg);
+            for (int i = 0; i < n; ++i) {
+                const int32_t id = set_nodes[beg + i];
+                if (id == 0) continue;                      // padding_idx row keeps a zero grad
+                float* dst = grad_E + (int64_t)id * D + dv * 4;
+                atomicAdd(dst + 0, g.x); atomicAdd(dst + 1, g.y); atomicAdd(dst + 2, g.z); atomicAdd(dst + 3, g.w);
+            }
+        } else {
+            const int4 a = reinterpret_cast<const int4*>(arg)[t];
+            if (a.x) atomicAdd(grad_E + (int64_t)a.x * D + dv * 4 + 0, g.x);
+            if (a.y) atomicAdd(grad_E + (int64_t)a.y * D + dv * 4 + 1, g.y);
+            if (a.z) atomicAdd(grad_E + (int64_t)a.z * D + dv * 4 + 2, g.z);
+            if (a.w) atomicAdd(grad_E + (int64_t)a.w * D + dv * 4 + 3, g.w);
+        }
+    }
+}
+
+extern "C" int sgnn_cc_embed_fwd(const float* E, int64_t D,
+                                 const int64_t* set_ptr, const int32_t* set_nodes, int64_t n_sets,
+                                 int aggregator, int64_t padded_len, float* out, int32_t* out_arg, void* stream)
+{
+    if (!E || !set_ptr || !set_nodes || !out || n_sets < 0 || D <= 0 || aggregator < 0 || aggregator > 1)
+        return SGNN_ERR_BAD_ARG;
+    if (D % 4 != 0) return SGNN_ERR_UNSUPPORTED_D;
+    if (n_sets == 0) return SGNN_OK;
+    const int64_t D4 = D / 4;
+    const int grid = sgnn_grid_for(n_sets * D4, 256);
+    if (aggregator == 0)
+        hipLaunchKernelGGL(cc_embed_fwd_kernel<0>, dim3(grid), dim3(256), 0, (hipStream_t)stream, E, D4, set_ptr,
+                           set_nodes, n_sets, padded_len, out, out_arg);
+    else
+        hipLaunchKernelGGL(cc_embed_fwd_kernel<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, E, D4, set_ptr,
+                           set_nodes, n_sets, padded_len, out, out_arg);
+    SGNN_CHECK_LAUNCH();
+    return SGNN_OK;
+}
+
+extern "C" int sgnn_cc_embed_bwd(const float* grad_out, int64_t D,
+                                 const int64_t* set_ptr, const int32_t* set_nodes, int64_t n_sets,
+                                 int aggregator, const int32_t* arg, float* grad_E, void* stream)
+{
+    if (!grad_out || !set_ptr || !set_nodes || !grad_E || n_sets < 0 || D <= 0 || aggregator < 0 || aggregator > 1)
+        return SGNN_ERR_BAD_ARG;
+    if (aggregator == 1 && !arg) return SGNN_ERR_BAD_ARG;
+    if (D % 4 != 0) return SGNN_ERR_UNSUPPORTED_D;
+    if (n_sets == 0) return SGNN_OK;
+    const int64_t D4 = D / 4;
+    const int grid = sgnn_grid_for(n_sets * D4, 256);
+    if (aggregator == 0)
+        hipLaunchKernelGGL(cc_embed_bwd_kernel<0>, dim3(grid), dim3(256), 0, (hipStream_t)stream, grad_out, D4,
+                           set_ptr, set_nodes, n_sets, arg, grad_E);
+    else
+        hipLaunchKernelGGL(cc_embed_bwd_kernel<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, grad_out, D4,
+                           set_ptr, set_nodes, n_sets, arg, grad_E);
+    SGNN_CHECK_LAUNCH();
+    return SGNN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// a16  masked sum over the components of a subgraph (reference SubGNN/subgraph_utils.py:213-237)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void masked_sum_fwd_kernel(const float* __restrict__ x, const uint8_t* __restrict__ mask,
+                                                             int64_t B, int64_t C, int64_t H, float* __restrict__ out)
+{
+    const int64_t total = B * H;
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = t / H, h = t % H;
+        float acc = 0.f;
+        for (int64_t c = 0; c < C; ++c)
+            if (mask[b * C + c]) acc += x[(b * C + c) * H + h];
+        out[t] = acc;
+    }
+}
+
+__global__ __launch_bounds__(256) void masked_sum_bwd_kernel(const float* __restrict__ g, const uint8_t* __restrict__ mask,
+                                                             int64_t B, int64_t C, int64_t H, float* __restrict__ gx)
+{
+    const int64_t total = B * C * H;
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t bc = t / H, h = t % H;
+        gx[t] = mask[bc] ? g[(bc / C) * H + h] : 0.f;
+    }
+}
+
+extern "C" int sgnn_masked_sum_fwd(const float* x, const uint8_t* mask, int64_t B, int64_t C, int64_t H,
+                                   float* out, void* stream)
+{
+    if (!x || !mask || !out || B < 0 || C < 0 || H < 0) return SGNN_ERR_BAD_ARG;
+    if (B * H == 0) return SGNN_OK;
+    hipLaunchKernelGGL(masked_sum_fwd_kernel, dim3(sgnn_grid_for(B * H, 256)), dim3(256), 0, (hipStream_t)stream, x,
+                       mask, B, C, H, out);
+    SGNN_CHECK_LAUNCH();
+    return SGNN_OK;
+}
+
+extern "C" int sgnn_masked_sum_bwd(const float* grad_out, const uint8_t* mask, int64_t B, int64_t C, int64_t H,
+                                   float* grad_x, void* stream)
+{
+    if (!grad_out || !mask || !grad_x || B < 0 || C < 0 || H < 0) return SGNN_ERR_BAD_ARG;
+    if (B * C * H == 0) return SGNN_OK;
+    hipLaunchKernelGGL(masked_sum_bwd_kernel, dim3(sgnn_grid_for(B * C * H, 256)), dim3(256), 0, (hipStream_t)stream,
+                       grad_out, mask, B, C, H, grad_x);
+    SGNN_CHECK_LAUNCH();
+    return SGNN_OK;
+}

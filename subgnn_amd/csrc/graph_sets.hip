@@ -1,0 +1,269 @@
+// Integer graph kernels on ragged node sets: connected components of induced subgraphs (a7),
+// k-hop border of a component (a8), in-border nodes of an anchor patch (a3).
+#include "common.h"
+
+// ---------------------------------------------------------------------------------------------
+// a7  connected components (reference SubGNN/SubGNN.py:589-592)
+// One wavefront per subgraph.  Positions 0..n-1 of the subgraph are the union-find elements
+// (parents in LDS); every ordered pair (i<j) is tested for adjacency by binary search in the
+// shorter of the two sorted neighbour lists, and adjacent / identical nodes are united by a
+// lock-free hook of the larger root under the smaller one, so a component's root is its
+// smallest position.  Integer-only; HBM traffic is the two rowptr pairs + O(log deg) probes.
+// ---------------------------------------------------------------------------------------------
+#define CC_MAX 2048
+
+__device__ static inline int cc_find(volatile int32_t* parent, int x) {
+    int p = parent[x];
+    while (p != x) { x = p; p = parent[x]; }
+    return x;
+}
+
+__global__ __launch_bounds__(64) void cc_labels_kernel(
+    const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col_sorted,
+    const int64_t* __restrict__ sub_ptr, const int32_t* __restrict__ sub_nodes, int64_t n_sub,
+    int32_t* __restrict__ out_label)
+{
+    __shared__ int32_t s_id[CC_MAX];
+    __shared__ int32_t s_parent[CC_MAX];
+    const int lane = threadIdx.x;
+    for (int64_t s = blockIdx.x; s < n_sub; s += gridDim.x) {
+        const int64_t beg = sub_ptr[s];
+        const int n = (int)(sub_ptr[s + 1] - beg);
+        if (n <= 0) continue;
+        if (n > CC_MAX) {                                   // flagged by the host wrapper too
+            for (int i = lane; i < n; i += 64) out_label[beg + i] = -1;
+            continue;
+        }
+        for (int i = lane; i < n; i += 64) { s_id[i] = sub_nodes[beg + i]; s_parent[i] = i; }
+        __syncthreads();
+        const int64_t npairs = (int64_t)n * n;
+        for (int64_t p = lane; p < npairs; p += 64) {
+            int i = (int)(p / n), j = (int)(p % n);
+            if (i >= j) continue;
+            const int32_t a = s_id[i], b = s_id[j];
+            bool linked = (a == b);
+            if (!linked) {
+                const int64_t a0 = rowptr[a], a1 = rowptr[a + 1], b0 = rowptr[b], b1 = rowptr[b + 1];
+                if (a1 - a0 <= b1 - b0) linked = sgnn_sorted_contains(col_sorted + a0, (int32_t)(a1 - a0), b);
+                else linked = sgnn_sorted_contains(col_sorted + b0, (int32_t)(b1 - b0), a);
+            }
+            if (linked) {
+                int x = i, y = j;
+                while (true) {
+                    x = cc_find(s_parent, x);
+                    y = cc_find(s_parent, y);
+                    if (x == y) break;
+                    if (x < y) { const int t = x; x = y; y = t; }       // hook x (larger) under y
+                    const int32_t old = atomicCAS(&s_parent[x], x, y);
+                    if (old == x) break;
+                }
+            }
+        }
+        __syncthreads();
+        for (int i = lane; i < n; i += 64) out_label[beg + i] = cc_find(s_parent, i);
+        __syncthreads();
+    }
+}
+
+extern "C" int sgnn_cc_labels(const int64_t* rowptr, const int32_t* col_sorted, int64_t nnz,
+                              const int64_t* sub_ptr, const int32_t* sub_nodes, int64_t n_subgraphs,
+                              int32_t* out_label, void* stream)
+{
+    if (!rowptr || !col_sorted || !sub_ptr || !sub_nodes || !out_label || n_subgraphs < 0) return SGNN_ERR_BAD_ARG;
+    if (nnz >= (1ll << 31)) return SGNN_ERR_NNZ_TOO_LARGE;
+    if (n_subgraphs == 0) return SGNN_OK;
+    const int grid = (int)(n_subgraphs < 256 * 32 ? n_subgraphs : 256 * 32);
+    hipLaunchKernelGGL(cc_labels_kernel, dim3(grid), dim3(64), 0, (hipStream_t)stream, rowptr, col_sorted,
+                       sub_ptr, sub_nodes, n_subgraphs, out_label);
+    SGNN_CHECK_LAUNCH();
+    return SGNN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// a8  k-hop border (reference SubGNN/subgraph_utils.py:146-176)
+// One 256-thread workgroup per component, level-synchronous BFS.  Each workgroup owns a visited
+// bitmap over node ids and a queue in the caller's workspace; a frontier node is taken by one
+// wavefront whose lanes stream its neighbour list (coalesced), claim unseen neighbours with
+// atomicOr on the bitmap word and append them to the queue.  The bitmap is un-set on exit so
+// the next component handled by the workgroup starts clean.
+// ---------------------------------------------------------------------------------------------
+#define KB_THREADS 256
+#define KB_MAX_WG 1024
+
+static inline int64_t kb_words(int64_t max_id) { return (max_id + 32) / 32; }
+static inline int64_t kb_n_wg(int64_t n_sets) { return n_sets < KB_MAX_WG ? (n_sets < 1 ? 1 : n_sets) : KB_MAX_WG; }
+
+extern "C" int64_t sgnn_khop_border_workspace_bytes(int64_t max_id, int64_t n_sets) {
+    const int64_t per_wg = kb_words(max_id) * 4 + (max_id + 1) * 4;
+    return per_wg * kb_n_wg(n_sets);
+}
+
+__global__ __launch_bounds__(KB_THREADS) void khop_border_kernel(
+    const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col, int64_t max_id,
+    const int64_t* __restrict__ set_ptr, const int32_t* __restrict__ set_nodes, int64_t n_sets,
+    int k, int ego_mode,
+    int64_t* __restrict__ out_count, const int64_t* __restrict__ out_ptr,
+    int32_t* __restrict__ out_nodes, uint8_t* __restrict__ out_hop,
+    uint32_t* __restrict__ bitmaps, int32_t* __restrict__ queues, int64_t words)
+{
+    __shared__ int32_t s_qn;
+    __shared__ int32_t s_lvl[260];
+    uint32_t* bm = bitmaps + (int64_t)blockIdx.x * words;
+    int32_t* q = queues + (int64_t)blockIdx.x * (max_id + 1);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int hops = ego_mode ? 1 : k;
+    for (int64_t s = blockIdx.x; s < n_sets; s += gridDim.x) {
+        const int64_t beg = set_ptr[s];
+        const int n = (int)(set_ptr[s + 1] - beg);
+        if (tid == 0) { s_qn = 0; s_lvl[0] = 0; }              // s_lvl[h] = queue length after hop h
+        for (int i = tid; i < n; i += KB_THREADS) {
+            const int32_t v = set_nodes[beg + i];
+            atomicOr(&bm[v >> 5], 1u << (v & 31));
+        }
+        __syncthreads();
+        for (int h = 1; h <= hops; ++h) {
+            const int f0 = (h == 1) ? 0 : s_lvl[h - 2];      // frontier of hop h = nodes found at hop h-1
+            const int f1 = (h == 1) ? n : s_lvl[h - 1];
+            for (int f = f0 + wave; f < f1; f += KB_THREADS / 64) {
+                const int32_t v = (h == 1) ? set_nodes[beg + f] : q[f];
+                const int64_t r0 = rowptr[v], r1 = rowptr[v + 1];
+                for (int64_t e = r0 + lane; e < r1; e += 64) {
+                    const int32_t c = ego_mode ? col[e] - 1 : col[e];
+                    const uint32_t bit = 1u << (c & 31);
+                    const uint32_t old = atomicOr(&bm[c >> 5], bit);
+                    if (!(old & bit)) {
+                        const int pos = atomicAdd(&s_qn, 1);
+                        q[pos] = c;
+                    }
+                }
+            }
+            __syncthreads();
+            if (tid == 0) s_lvl[h] = s_qn;
+            __syncthreads();
+        }
+        const int cnt = s_qn;
+        if (out_nodes == nullptr) {
+            if (tid == 0) out_count[s] = cnt;
+        } else {
+            const int64_t o = out_ptr[s];
+            for (int i = tid; i < cnt; i += KB_THREADS) {
+                out_nodes[o + i] = q[i];
+                if (out_hop) {
+                    int h = 1;
+                    while (h < hops && i >= s_lvl[h]) ++h;
+                    out_hop[o + i] = (uint8_t)h;
+                }
+            }
+        }
+        // un-set every bit this component touched
+        for (int i = tid; i < n; i += KB_THREADS) {
+            const int32_t v = set_nodes[beg + i];
+            atomicAnd(&bm[v >> 5], ~(1u << (v & 31)));
+        }
+        for (int i = tid; i < cnt; i += KB_THREADS) {
+            const int32_t c = q[i];
+            atomicAnd(&bm[c >> 5], ~(1u << (c & 31)));
+        }
+        __syncthreads();
+    }
+}
+
+extern "C" int sgnn_khop_border(const int64_t* rowptr, const int32_t* col, int64_t nnz, int64_t max_id,
+                                const int64_t* set_ptr, const int32_t* set_nodes, int64_t n_sets,
+                                int k, int ego_dict_mode,
+                                int64_t* out_count, const int64_t* out_ptr, int32_t* out_nodes, uint8_t* out_hop,
+                                void* workspace, int64_t workspace_bytes, void* stream)
+{
+    if (!rowptr || !col || !set_ptr || !set_nodes || !workspace || n_sets < 0 || k < 1 || k > 255)
+        return SGNN_ERR_BAD_ARG;
+    if (out_nodes == nullptr && out_count == nullptr) return SGNN_ERR_BAD_ARG;
+    if (out_nodes != nullptr && out_ptr == nullptr) return SGNN_ERR_BAD_ARG;
+    if (nnz >= (1ll << 31)) return SGNN_ERR_NNZ_TOO_LARGE;
+    if (workspace_bytes < sgnn_khop_border_workspace_bytes(max_id, n_sets)) return SGNN_ERR_BAD_ARG;
+    if (n_sets == 0) return SGNN_OK;
+    const int64_t words = kb_words(max_id);
+    const int64_t nwg = kb_n_wg(n_sets);
+    uint32_t* bitmaps = (uint32_t*)workspace;
+    int32_t* queues = (int32_t*)(bitmaps + words * nwg);
+    hipLaunchKernelGGL(khop_border_kernel, dim3((int)nwg), dim3(KB_THREADS), 0, (hipStream_t)stream, rowptr, col,
+                       max_id, set_ptr, set_nodes, n_sets, k, ego_dict_mode, out_count, out_ptr, out_nodes,
+                       out_hop, bitmaps, queues, words);
+    SGNN_CHECK_LAUNCH();
+    return SGNN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// a3  in-border nodes of a patch (reference SubGNN/subgraph_utils.py:126-144, with the id-1 /
+// node-order indexing quirk: id x is read as the node at position x-1 of G.nodes()).
+// One workgroup per patch; patch ids in an LDS hash; one thread per member walks "its" list.
+// ---------------------------------------------------------------------------------------------
+#define PB_HASH_BITS 12
+#define PB_HASH (1 << PB_HASH_BITS)
+#define PB_MAX 2048
+
+__global__ __launch_bounds__(256) void patch_in_border_kernel(
+    const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+    const int32_t* __restrict__ node_order, const int32_t* __restrict__ node_pos,
+    const int64_t* __restrict__ patch_ptr, const int32_t* __restrict__ patch_nodes, int64_t n_patches,
+    uint8_t* __restrict__ out_flag)
+{
+    __shared__ int32_t hash[PB_HASH];
+    const int tid = threadIdx.x;
+    for (int64_t p = blockIdx.x; p < n_patches; p += gridDim.x) {
+        const int64_t beg = patch_ptr[p];
+        const int n = (int)(patch_ptr[p + 1] - beg);
+        if (n <= 0) continue;
+        for (int i = tid; i < PB_HASH; i += 256) hash[i] = 0;
+        __syncthreads();
+        if (n <= PB_MAX) {
+            for (int i = tid; i < n; i += 256) {
+                const int32_t v = patch_nodes[beg + i];
+                uint32_t h = sgnn_hash32((uint32_t)v) >> (32 - PB_HASH_BITS);
+                while (true) {
+                    const int32_t old = atomicCAS(&hash[h], 0, v);
+                    if (old == 0 || old == v) break;
+                    h = (h + 1) & (PB_HASH - 1);
+                }
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < n; i += 256) {
+            if (n > PB_MAX) { out_flag[beg + i] = 255; continue; }     // unsupported size: poisoned
+            const int32_t x = patch_nodes[beg + i];
+            const int32_t px = node_order[x - 1];
+            const int64_t r0 = rowptr[px], r1 = rowptr[px + 1];
+            uint8_t flag = 0;
+            for (int64_t e = r0; e < r1 && !flag; ++e) {
+                const int32_t y = node_pos[col[e]] + 1;
+                uint32_t h = sgnn_hash32((uint32_t)y) >> (32 - PB_HASH_BITS);
+                bool member = false;
+                while (true) {
+                    const int32_t kk = hash[h];
+                    if (kk == y) { member = true; break; }
+                    if (kk == 0) break;
+                    h = (h + 1) & (PB_HASH - 1);
+                }
+                if (!member) flag = 1;
+            }
+            out_flag[beg + i] = flag;
+        }
+        __syncthreads();
+    }
+}
+
+extern "C" int sgnn_patch_in_border(const int64_t* rowptr, const int32_t* col, int64_t nnz,
+                                    const int32_t* node_order, const int32_t* node_pos, int64_t n_nodes,
+                                    const int64_t* patch_ptr, const int32_t* patch_nodes, int64_t n_patches,
+                                    uint8_t* out_flag, void* stream)
+{
+    if (!rowptr || !col || !node_order || !node_pos || !patch_ptr || !patch_nodes || !out_flag || n_patches < 0)
+        return SGNN_ERR_BAD_ARG;
+    if (nnz >= (1ll << 31)) return SGNN_ERR_NNZ_TOO_LARGE;
+    (void)n_nodes;
+    if (n_patches == 0) return SGNN_OK;
+    const int grid = (int)(n_patches < 256 * 8 ? n_patches : 256 * 8);
+    hipLaunchKernelGGL(patch_in_border_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, rowptr, col,
+                       node_order, node_pos, patch_ptr, patch_nodes, n_patches, out_flag);
+    SGNN_CHECK_LAUNCH();
+    return SGNN_OK;
+}

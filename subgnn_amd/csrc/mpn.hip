@@ -1,0 +1,242 @@
+// One anchor -> component message-passing layer: gather, weight by similarity, aggregate per
+// component, position/structure read-out (a13 + a15), forward and backward.
+// Replaces SG_MPN.forward/propagate/message/generate_pos_struc_embeddings
+// (reference SubGNN/subgraph_mpn.py:105-174,227-231) fused with the anchor-embedding gather of
+// get_anchor_patches/embed_anchor_patch (reference SubGNN/anchor_patch_samplers.py:333-411).
+//
+// HBM-bound gather-scale-reduce.  Per real component with A anchors (fp32, width D):
+//   GATHER  A*(4D + 8 + 4) + 4D + 4A  bytes  (anchor row, id, similarity; agg and read-out out)
+//   SHARED  4A + 4D + 4A per component, + 4AD once (the shared anchor matrix stays in L2)
+//   DENSE   A*(4D + 1 + 4) + 4D + 4A         (the reference's materialised (B,C,A,D) tensor)
+// Thread = (component row, 16-byte column slice).  The D/4 lanes of a row read one anchor row as
+// consecutive float4 (one 256 B segment for D = 64), accumulate w*x in registers, and reduce the
+// read-out dot product <wp, x> across the row's lanes by butterfly shuffles.  No atomics in the
+// forward pass; the backward pass scatters anchor-row gradients with float atomics whose
+// wave-instruction footprint is whole contiguous rows (the full-rate shape on gfx950).
+#include "common.h"
+
+__device__ static inline float group_sum(float v, int lanes) {
+    for (int d = lanes >> 1; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+    return v;
+}
+
+template <int SRC>
+__global__ __launch_bounds__(256) void mpn_fwd_kernel(sgnn_mpn_args a, float* __restrict__ agg, float* __restrict__ z,
+                                                      int64_t D4)
+{
+    const int64_t total = a.R * D4;
+    const float4* x4 = reinterpret_cast<const float4*>(a.x);
+    const int lanes = (int)D4;
+    const float bp = a.bp[0];
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = t / D4, dv = t % D4;
+        const bool row_real = a.row_mask ? (a.row_mask[r] != 0) : true;
+        const float4 wp = reinterpret_cast<const float4*>(a.wp)[dv];
+        const int64_t idrow = (a.id_div > 1 ? r / a.id_div : r) * a.A;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int64_t ai = 0; ai < a.A; ++ai) {
+            int64_t id = 1;
+            bool edge;
+            if (SRC == SGNN_SRC_DENSE) {
+                edge = a.edge_mask[r * a.A + ai] != 0;
+                if (a.ids) id = a.ids[idrow + ai];
+            } else if (SRC == SGNN_SRC_GATHER) {
+                id = a.ids[idrow + ai];
+                edge = (id != 0) && row_real;
+            } else {
+                if (a.ids) id = a.ids[ai];
+                edge = row_real && (id != 0);
+            }
+            float zval = bp;
+            if (edge) {                                       // uniform over the row's lanes
+                const int64_t col = a.sim_col ? a.sim_col[ai] : (a.sims_per_edge ? ai : id - 1);
+                const float w = a.sims[r * a.sims_ld + col];
+                float4 x;
+                if (SRC == SGNN_SRC_DENSE) x = x4[(r * a.A + ai) * D4 + dv];
+                else if (SRC == SGNN_SRC_GATHER) x = x4[id * D4 + dv];
+                else x = x4[ai * D4 + dv];
+                acc.x += w * x.x; acc.y += w * x.y; acc.z += w * x.z; acc.w += w * x.w;
+                const float dot = group_sum(wp.x * x.x + wp.y * x.y + wp.z * x.z + wp.w * x.w, lanes);
+                zval = w * dot + bp;
+            }
+            if (dv == 0 && z) z[r * a.A + ai] = zval;
+        }
+        reinterpret_cast<float4*>(agg)[t] = acc;
+    }
+}
+
+// backward for DENSE (grad_x written) and GATHER (grad_x accumulated with atomics)
+template <int SRC>
+__global__ __launch_bounds__(256) void mpn_bwd_kernel(sgnn_mpn_args a, const float* __restrict__ grad_agg,
+                                                      const float* __restrict__ grad_z, float* __restrict__ grad_x,
+                                                      float* __restrict__ grad_wp, int64_t D4)
+{
+    __shared__ float s_gwp[1024];
+    const int64_t D = D4 * 4;
+    if (grad_wp) {
+        for (int i = threadIdx.x; i < D; i += blockDim.x) s_gwp[i] = 0.f;
+        __syncthreads();
+    }
+    const int64_t total = a.R * D4;
+    const float4* x4 = reinterpret_cast<const float4*>(a.x);
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = t / D4, dv = t % D4;
+        const bool row_real = a.row_mask ? (a.row_mask[r] != 0) : true;
+        const float4 wp = reinterpret_cast<const float4*>(a.wp)[dv];
+        float4 ga = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (grad_agg) ga = reinterpret_cast<const float4*>(grad_agg)[t];
+        const int64_t idrow = (a.id_div > 1 ? r / a.id_div : r) * a.A;
+        float4 gw = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int64_t ai = 0; ai < a.A; ++ai) {
+            int64_t id = 1;
+            bool edge;
+            if (SRC == SGNN_SRC_DENSE) {
+                edge = a.edge_mask[r * a.A + ai] != 0;
+                if (a.ids) id = a.ids[idrow + ai];
+            } else {
+                id = a.ids[idrow + ai];
+                edge = (id != 0) && row_real;
+            }
+            float4 dx = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (edge) {
+                const int64_t col = a.sim_col ? a.sim_col[ai] : (a.sims_per_edge ? ai : id - 1);
+                const float w = a.sims[r * a.sims_ld + col];
+                const float gz = grad_z ? grad_z[r * a.A + ai] : 0.f;
+                dx.x = w * (ga.x + gz * wp.x); dx.y = w * (ga.y + gz * wp.y);
+                dx.z = w * (ga.z + gz * wp.z); dx.w = w * (ga.w + gz * wp.w);
+                if (grad_wp && gz != 0.f) {
+                    const float4 x = (SRC == SGNN_SRC_DENSE) ? x4[(r * a.A + ai) * D4 + dv] : x4[id * D4 + dv];
+                    const float s = gz * w;
+                    gw.x += s * x.x; gw.y += s * x.y; gw.z += s * x.z; gw.w += s * x.w;
+                }
+                if (SRC == SGNN_SRC_GATHER && grad_x) {
+                    float* dst = grad_x + id * D + dv * 4;
+                    atomicAdd(dst + 0, dx.x); atomicAdd(dst + 1, dx.y); atomicAdd(dst + 2, dx.z); atomicAdd(dst + 3, dx.w);
+                }
+            }
+            if (SRC == SGNN_SRC_DENSE && grad_x) reinterpret_cast<float4*>(grad_x)[(r * a.A + ai) * D4 + dv] = dx;
+        }
+        if (grad_wp) {
+            atomicAdd(&s_gwp[dv * 4 + 0], gw.x); atomicAdd(&s_gwp[dv * 4 + 1], gw.y);
+            atomicAdd(&s_gwp[dv * 4 + 2], gw.z); atomicAdd(&s_gwp[dv * 4 + 3], gw.w);
+        }
+    }
+    if (grad_wp) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < D; i += blockDim.x) atomicAdd(&grad_wp[i], s_gwp[i]);
+    }
+}
+
+// backward for SHARED anchors: dX[a,:] = sum_r edge * w[r,a] * (g_agg[r,:] + g_z[r,a] * wp).
+// One workgroup per tile of rows; thread items are (anchor, column slice); the tile's g_agg rows
+// are re-read per anchor from L1/L2; one atomic row-add per (tile, anchor).
+#define MPN_SH_TILE 64
+__global__ __launch_bounds__(256) void mpn_bwd_shared_kernel(sgnn_mpn_args a, const float* __restrict__ grad_agg,
+                                                             const float* __restrict__ grad_z,
+                                                             float* __restrict__ grad_x, float* __restrict__ grad_wp,
+                                                             int64_t D4)
+{
+    __shared__ float s_gwp[1024];
+    const int64_t D = D4 * 4;
+    if (grad_wp) {
+        for (int i = threadIdx.x; i < D; i += blockDim.x) s_gwp[i] = 0.f;
+        __syncthreads();
+    }
+    const float4* x4 = reinterpret_cast<const float4*>(a.x);
+    const int64_t n_tiles = (a.R + MPN_SH_TILE - 1) / MPN_SH_TILE;
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int64_t r0 = tile * MPN_SH_TILE;
+        const int64_t r1 = (r0 + MPN_SH_TILE < a.R) ? r0 + MPN_SH_TILE : a.R;
+        for (int64_t item = threadIdx.x; item < a.A * D4; item += blockDim.x) {
+            const int64_t ai = item / D4, dv = item % D4;
+            const int64_t id = a.ids ? a.ids[ai] : 1;
+            if (id == 0) continue;
+            const int64_t col = a.sim_col ? a.sim_col[ai] : (a.sims_per_edge ? ai : id - 1);
+            const float4 wp = reinterpret_cast<const float4*>(a.wp)[dv];
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            float sgz = 0.f;
+            for (int64_t r = r0; r < r1; ++r) {
+                if (a.row_mask && !a.row_mask[r]) continue;
+                const float w = a.sims[r * a.sims_ld + col];
+                const float gz = grad_z ? grad_z[r * a.A + ai] : 0.f;
+                float4 ga = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (grad_agg) ga = reinterpret_cast<const float4*>(grad_agg)[r * D4 + dv];
+                acc.x += w * (ga.x + gz * wp.x); acc.y += w * (ga.y + gz * wp.y);
+                acc.z += w * (ga.z + gz * wp.z); acc.w += w * (ga.w + gz * wp.w);
+                sgz += w * gz;
+            }
+            if (grad_x) {
+                float* dst = grad_x + ai * D + dv * 4;
+                atomicAdd(dst + 0, acc.x); atomicAdd(dst + 1, acc.y); atomicAdd(dst + 2, acc.z); atomicAdd(dst + 3, acc.w);
+            }
+            if (grad_wp) {
+                const float4 x = x4[ai * D4 + dv];
+                atomicAdd(&s_gwp[dv * 4 + 0], sgz * x.x); atomicAdd(&s_gwp[dv * 4 + 1], sgz * x.y);
+                atomicAdd(&s_gwp[dv * 4 + 2], sgz * x.z); atomicAdd(&s_gwp[dv * 4 + 3], sgz * x.w);
+            }
+        }
+    }
+    if (grad_wp) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < D; i += blockDim.x) atomicAdd(&grad_wp[i], s_gwp[i]);
+    }
+}
+
+static int mpn_check(const sgnn_mpn_args* a)
+{
+    if (!a || a->R < 0 || a->A < 0 || a->D <= 0 || !a->x || !a->sims || !a->wp || !a->bp) return SGNN_ERR_BAD_ARG;
+    if (a->D % 4 != 0) return SGNN_ERR_UNSUPPORTED_D;
+    const int64_t D4 = a->D / 4;
+    if (D4 > 64 || (D4 & (D4 - 1)) != 0 || a->D > 1024) return SGNN_ERR_UNSUPPORTED_D;   // lanes per row: 1,2,4..64
+    if (a->src == SGNN_SRC_DENSE && !a->edge_mask) return SGNN_ERR_BAD_ARG;
+    if (a->src == SGNN_SRC_GATHER && !a->ids) return SGNN_ERR_BAD_ARG;
+    if (a->src < 0 || a->src > 2) return SGNN_ERR_BAD_ARG;
+    if (!a->sim_col && !a->sims_per_edge && !a->ids) return SGNN_ERR_BAD_ARG;
+    if (a->id_div < 1) return SGNN_ERR_BAD_ARG;
+    return SGNN_OK;
+}
+
+extern "C" int sgnn_mpn_fwd(const sgnn_mpn_args* args, float* agg, float* z, void* stream)
+{
+    const int rc = mpn_check(args);
+    if (rc != SGNN_OK) return rc;
+    if (!agg) return SGNN_ERR_BAD_ARG;
+    if (args->R == 0) return SGNN_OK;
+    const int64_t D4 = args->D / 4;
+    const int grid = sgnn_grid_for(args->R * D4, 256);
+    hipStream_t st = (hipStream_t)stream;
+    if (args->src == SGNN_SRC_DENSE)
+        hipLaunchKernelGGL(mpn_fwd_kernel<SGNN_SRC_DENSE>, dim3(grid), dim3(256), 0, st, *args, agg, z, D4);
+    else if (args->src == SGNN_SRC_GATHER)
+        hipLaunchKernelGGL(mpn_fwd_kernel<SGNN_SRC_GATHER>, dim3(grid), dim3(256), 0, st, *args, agg, z, D4);
+    else
+        hipLaunchKernelGGL(mpn_fwd_kernel<SGNN_SRC_SHARED>, dim3(grid), dim3(256), 0, st, *args, agg, z, D4);
+    SGNN_CHECK_LAUNCH();
+    return SGNN_OK;
+}
+
+extern "C" int sgnn_mpn_bwd(const sgnn_mpn_args* args, const float* grad_agg, const float* grad_z,
+                            float* grad_x, float* grad_wp, void* stream)
+{
+    const int rc = mpn_check(args);
+    if (rc != SGNN_OK) return rc;
+    if (args->R == 0 || args->A == 0) return SGNN_OK;
+    const int64_t D4 = args->D / 4;
+    hipStream_t st = (hipStream_t)stream;
+    if (args->src == SGNN_SRC_SHARED) {
+        const int64_t n_tiles = (args->R + MPN_SH_TILE - 1) / MPN_SH_TILE;
+        const int grid = (int)(n_tiles < 4096 ? n_tiles : 4096);
+        hipLaunchKernelGGL(mpn_bwd_shared_kernel, dim3(grid), dim3(256), 0, st, *args, grad_agg, grad_z, grad_x,
+                           grad_wp, D4);
+    } else {
+        const int grid = sgnn_grid_for(args->R * D4, 256, 2048);
+        if (args->src == SGNN_SRC_DENSE)
+            hipLaunchKernelGGL(mpn_bwd_kernel<SGNN_SRC_DENSE>, dim3(grid), dim3(256), 0, st, *args, grad_agg, grad_z,
+                               grad_x, grad_wp, D4);
+        else
+            hipLaunchKernelGGL(mpn_bwd_kernel<SGNN_SRC_GATHER>, dim3(grid), dim3(256), 0, st, *args, grad_agg, grad_z,
+                               grad_x, grad_wp, D4);
+    }
+    SGNN_CHECK_LAUNCH();
+    return SGNN_OK;
+}

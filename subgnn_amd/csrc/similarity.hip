@@ -1,0 +1,395 @@
+// Similarity kernels: shortest-path similarities (a9, dense-parity and sparse forms) and the
+// structure similarity 1/(1+fastdtw) (a11).
+#include "common.h"
+
+// ---------------------------------------------------------------------------------------------
+// a9  dense-parity form (reference SubGNN/SubGNN.py:752-781): column-wise min over the APSP rows
+// of a component.  HBM-bound streaming: 8*|cc|*N bytes in, 4*N out per component; lanes walk the
+// columns (coalesced 512 B per wave-instruction), the member loop re-uses nothing.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sp_similarity_dense_kernel(
+    const double* __restrict__ apsp, int64_t n_cols,
+    const int64_t* __restrict__ set_ptr, const int32_t* __restrict__ set_nodes,
+    float* __restrict__ out)
+{
+    const int64_t r = blockIdx.y;
+    const int64_t beg = set_ptr[r];
+    const int n = (int)(set_ptr[r + 1] - beg);
+    for (int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; c < n_cols; c += (int64_t)gridDim.x * blockDim.x) {
+        float res = 0.f;
+        if (n > 0) {
+            double m = apsp[(int64_t)(set_nodes[beg] - 1) * n_cols + c];
+            for (int i = 1; i < n; ++i) {
+                const double v = apsp[(int64_t)(set_nodes[beg + i] - 1) * n_cols + c];
+                m = v < m ? v : m;
+            }
+            res = (float)m;
+        }
+        out[r * n_cols + c] = res;
+    }
+}
+
+extern "C" int sgnn_sp_similarity_dense(const double* apsp, int64_t n_cols,
+                                        const int64_t* set_ptr, const int32_t* set_nodes, int64_t n_sets,
+                                        float* out, void* stream)
+{
+    if (!apsp || !set_ptr || !set_nodes || !out || n_cols <= 0 || n_sets < 0) return SGNN_ERR_BAD_ARG;
+    if (n_sets == 0) return SGNN_OK;
+    if (n_sets > 65535 * 32768ll) return SGNN_ERR_BAD_ARG;
+    int gx = (int)((n_cols + 255) / 256);
+    if (gx > 64) gx = 64;
+    // grid.y is limited to 65535: fold larger set counts into several launches
+    for (int64_t off = 0; off < n_sets; off += 65535) {
+        const int64_t cnt = (n_sets - off) < 65535 ? (n_sets - off) : 65535;
+        hipLaunchKernelGGL(sp_similarity_dense_kernel, dim3(gx, (int)cnt), dim3(256), 0, (hipStream_t)stream,
+                           apsp, n_cols, set_ptr + off, set_nodes, out + off * n_cols);
+        SGNN_CHECK_LAUNCH();
+    }
+    return SGNN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// a9  sparse form: bit-parallel multi-source BFS.  Each node carries one 64-bit word per group
+// of 64 sources (seen / frontier / next).  A level is two grid-wide kernels:
+//   expand : every node with a non-zero frontier word ORs it into next[] of its neighbours
+//            (16-lane groups stream a neighbour list, coalesced), 64 BFS's per edge visit;
+//   commit : new = next & ~seen; seen |= new; frontier = new; dist[src][node] = level for the
+//            new bits; a device flag says whether any bit was new (later levels exit early).
+// The host enqueues max_hops levels without synchronising.
+// ---------------------------------------------------------------------------------------------
+__global__ void msbfs_init_kernel(const int32_t* __restrict__ sources, int64_t n_sources, int64_t n_words,
+                                  int64_t n_ids, uint64_t* __restrict__ seen, uint64_t* __restrict__ frontier,
+                                  uint64_t* __restrict__ next, uint8_t* __restrict__ dist, int32_t* __restrict__ flags,
+                                  int max_hops)
+{
+    const int64_t gtid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = gtid; i < n_ids * n_words; i += gsz) { seen[i] = 0; frontier[i] = 0; next[i] = 0; }
+    for (int64_t i = gtid; i < n_sources * n_ids; i += gsz) dist[i] = 255;
+    for (int64_t i = gtid; i <= max_hops; i += gsz) flags[i] = (i == 0) ? 1 : 0;
+}
+
+__global__ void msbfs_seed_kernel(const int32_t* __restrict__ sources, int64_t n_sources, int64_t n_words,
+                                  int64_t n_ids, uint64_t* __restrict__ seen, uint64_t* __restrict__ frontier,
+                                  uint8_t* __restrict__ dist)
+{
+    const int64_t s = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (s >= n_sources) return;
+    const int32_t v = sources[s];
+    const uint64_t bit = 1ull << (s & 63);
+    atomicOr((unsigned long long*)&seen[(int64_t)v * n_words + (s >> 6)], (unsigned long long)bit);
+    atomicOr((unsigned long long*)&frontier[(int64_t)v * n_words + (s >> 6)], (unsigned long long)bit);
+    dist[s * n_ids + v] = 0;
+}
+
+__global__ __launch_bounds__(256) void msbfs_expand_kernel(
+    const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col, int64_t n_ids, int64_t n_words,
+    const uint64_t* __restrict__ seen, const uint64_t* __restrict__ frontier, uint64_t* __restrict__ next,
+    const int32_t* __restrict__ flags, int level)
+{
+    if (flags[level - 1] == 0) return;                       // previous level found nothing
+    const int sub = threadIdx.x & 15;
+    const int64_t group = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 4;
+    const int64_t n_groups = ((int64_t)gridDim.x * blockDim.x) >> 4;
+    for (int64_t v = group; v < n_ids; v += n_groups) {
+        for (int64_t w = 0; w < n_words; ++w) {
+            const uint64_t f = frontier[v * n_words + w];
+            if (f == 0) continue;
+            const int64_t r0 = rowptr[v], r1 = rowptr[v + 1];
+            for (int64_t e = r0 + sub; e < r1; e += 16) {
+                const int64_t u = col[e];
+                const uint64_t m = f & ~seen[u * n_words + w];
+                if (m) atomicOr((unsigned long long*)&next[u * n_words + w], (unsigned long long)m);
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void msbfs_commit_kernel(
+    int64_t n_ids, int64_t n_words, int64_t n_sources, uint64_t* __restrict__ seen, uint64_t* __restrict__ frontier,
+    uint64_t* __restrict__ next, uint8_t* __restrict__ dist, int32_t* __restrict__ flags, int level)
+{
+    if (flags[level - 1] == 0) return;
+    bool any = false;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n_ids * n_words;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const uint64_t nw = next[i] & ~seen[i];
+        next[i] = 0;
+        frontier[i] = nw;
+        if (nw) {
+            any = true;
+            seen[i] |= nw;
+            const int64_t v = i / n_words, w = i % n_words;
+            uint64_t bits = nw;
+            while (bits) {
+                const int b = __ffsll((unsigned long long)bits) - 1;
+                bits &= bits - 1;
+                const int64_t s = w * 64 + b;
+                if (s < n_sources) dist[s * n_ids + v] = (uint8_t)level;
+            }
+        }
+    }
+    if (__any(any) && (threadIdx.x & 63) == 0) atomicOr(&flags[level], 1);
+}
+
+extern "C" int64_t sgnn_bfs_hops_workspace_bytes(int64_t max_id, int64_t n_sources, int max_hops) {
+    const int64_t n_words = (n_sources + 63) / 64;
+    return 3 * (max_id + 1) * n_words * 8 + ((int64_t)max_hops + 2) * 4;
+}
+
+extern "C" int sgnn_bfs_hops(const int64_t* rowptr, const int32_t* col, int64_t nnz, int64_t max_id,
+                             const int32_t* sources, int64_t n_sources, int max_hops,
+                             uint8_t* dist, void* workspace, int64_t workspace_bytes, void* stream)
+{
+    if (!rowptr || !col || !sources || !dist || !workspace || n_sources < 0 || max_hops < 1 || max_hops > 254)
+        return SGNN_ERR_BAD_ARG;
+    if (nnz >= (1ll << 31)) return SGNN_ERR_NNZ_TOO_LARGE;
+    if (workspace_bytes < sgnn_bfs_hops_workspace_bytes(max_id, n_sources, max_hops)) return SGNN_ERR_BAD_ARG;
+    if (n_sources == 0) return SGNN_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t n_ids = max_id + 1;
+    const int64_t n_words = (n_sources + 63) / 64;
+    uint64_t* seen = (uint64_t*)workspace;
+    uint64_t* frontier = seen + n_ids * n_words;
+    uint64_t* next = frontier + n_ids * n_words;
+    int32_t* flags = (int32_t*)(next + n_ids * n_words);
+    const int big = sgnn_grid_for(n_ids * (n_words > n_sources ? n_words : n_sources), 256);
+    hipLaunchKernelGGL(msbfs_init_kernel, dim3(big), dim3(256), 0, st, sources, n_sources, n_words, n_ids, seen,
+                       frontier, next, dist, flags, max_hops);
+    SGNN_CHECK_LAUNCH();
+    hipLaunchKernelGGL(msbfs_seed_kernel, dim3((int)((n_sources + 255) / 256)), dim3(256), 0, st, sources, n_sources,
+                       n_words, n_ids, seen, frontier, dist);
+    SGNN_CHECK_LAUNCH();
+    const int g_expand = sgnn_grid_for(n_ids * 16, 256);
+    const int g_commit = sgnn_grid_for(n_ids * n_words, 256);
+    for (int level = 1; level <= max_hops; ++level) {
+        hipLaunchKernelGGL(msbfs_expand_kernel, dim3(g_expand), dim3(256), 0, st, rowptr, col, n_ids, n_words, seen,
+                           frontier, next, flags, level);
+        SGNN_CHECK_LAUNCH();
+        hipLaunchKernelGGL(msbfs_commit_kernel, dim3(g_commit), dim3(256), 0, st, n_ids, n_words, n_sources, seen,
+                           frontier, next, dist, flags, level);
+        SGNN_CHECK_LAUNCH();
+    }
+    return SGNN_OK;
+}
+
+__global__ void min_hops_to_sets_kernel(const uint8_t* __restrict__ dist, int64_t n_sources, int64_t n_ids,
+                                        const int64_t* __restrict__ set_ptr, const int32_t* __restrict__ set_nodes,
+                                        int64_t n_sets, float* __restrict__ out)
+{
+    const int64_t total = n_sets * n_sources;
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = t / n_sources, a = t % n_sources;
+        const int64_t beg = set_ptr[r];
+        const int n = (int)(set_ptr[r + 1] - beg);
+        int m = 0;
+        for (int i = 0; i < n; ++i) {
+            int d = dist[a * n_ids + set_nodes[beg + i]];
+            if (d == 255) d = 0;                               // unreachable pairs hold 0 in the matrix
+            m = (i == 0 || d < m) ? d : m;
+        }
+        out[t] = (float)m;
+    }
+}
+
+extern "C" int sgnn_min_hops_to_sets(const uint8_t* dist, int64_t n_sources, int64_t max_id,
+                                     const int64_t* set_ptr, const int32_t* set_nodes, int64_t n_sets,
+                                     float* out, void* stream)
+{
+    if (!dist || !set_ptr || !set_nodes || !out || n_sources < 0 || n_sets < 0) return SGNN_ERR_BAD_ARG;
+    if (n_sets * n_sources == 0) return SGNN_OK;
+    hipLaunchKernelGGL(min_hops_to_sets_kernel, dim3(sgnn_grid_for(n_sets * n_sources, 256)), dim3(256), 0,
+                       (hipStream_t)stream, dist, n_sources, max_id + 1, set_ptr, set_nodes, n_sets, out);
+    SGNN_CHECK_LAUNCH();
+    return SGNN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// a11  1 / (1 + fastdtw(x, y, radius=1, dist=calc_dist))  (reference SubGNN/gamma.py:51-59)
+//
+// One lane per (component, anchor) pair; fp64 DP.  fastdtw's recursion is unrolled bottom-up:
+// the halved series of every level are built first, the coarsest level (either length < 3)
+// runs a full-window DTW, and each finer level derives its window from the coarser warp path.
+// Because a warp path is monotone, the published expand_window (dilate by radius 1, project to
+// the fine grid, keep one contiguous run per row starting no earlier than the previous row's)
+// reduces to per-row bounds
+//     lo_i = max(0, 2*(first_col[max(ci-1,0)] - 1)),   hi_i = min(ly-1, 2*(last_col[min(ci+1,lxc-1)] + 1) + 1)
+// with ci = i/2 and first/last_col the coarse path's column range per coarse row, so only those
+// two small arrays travel between levels.  The DP keeps two rolling rows plus one predecessor
+// code per window cell for the backtrack.  All per-lane state lives in a caller workspace,
+// element-interleaved across lanes so that lanes in lockstep touch consecutive addresses.
+// VALU / latency-bound (one fp64 divide per cell); not an HBM kernel.
+// ---------------------------------------------------------------------------------------------
+#define DTW_THREADS 256
+#define DTW_BLOCKS (256 * 2)
+#define DTW_NT ((int64_t)DTW_THREADS * DTW_BLOCKS)
+
+struct DtwLayout {                 // element counts per lane
+    int64_t n_dbl;                 // xs(2MX) ys(2MY) prev(MY) cur(MY)
+    int64_t n_i32;                 // rowstart(MX) lo(MX) hi(MX) first[2](MX each) last[2](MX each)
+    int64_t n_u8;                  // dir(MX*MY)
+    int64_t off_ys, off_prev, off_cur;
+    int64_t off_lo, off_hi, off_first, off_last;
+};
+
+static inline DtwLayout dtw_layout(int64_t MX, int64_t MY) {
+    DtwLayout L;
+    L.off_ys = 2 * MX;
+    L.off_prev = L.off_ys + 2 * MY;
+    L.off_cur = L.off_prev + MY;
+    L.n_dbl = L.off_cur + MY;
+    L.off_lo = MX;
+    L.off_hi = 2 * MX;
+    L.off_first = 3 * MX;          // two ping-pong halves of MX each
+    L.off_last = 5 * MX;
+    L.n_i32 = 7 * MX;
+    L.n_u8 = MX * MY;
+    return L;
+}
+
+extern "C" int64_t sgnn_dtw_workspace_bytes(int64_t max_x_len, int64_t max_y_len) {
+    if (max_x_len < 1) max_x_len = 1;
+    if (max_y_len < 1) max_y_len = 1;
+    const DtwLayout L = dtw_layout(max_x_len, max_y_len);
+    return DTW_NT * (L.n_dbl * 8 + L.n_i32 * 4 + ((L.n_u8 + 7) / 8) * 8);
+}
+
+__device__ static inline double dtw_cost(double a, double b) {            // gamma.py:51-52
+    const double mx = a > b ? a : b, mn = a > b ? b : a;
+    return (mx + 1.0) / (mn + 1.0) - 1.0;
+}
+
+__global__ __launch_bounds__(DTW_THREADS) void dtw_similarity_kernel(
+    const int64_t* __restrict__ x_ptr, const int32_t* __restrict__ x_val, int64_t n_x,
+    const int64_t* __restrict__ y_ptr, const int32_t* __restrict__ y_val, int64_t n_y,
+    int tie_order, float* __restrict__ out, double* __restrict__ wd, int32_t* __restrict__ wi,
+    uint8_t* __restrict__ wb, DtwLayout L)
+{
+    const int64_t NT = (int64_t)gridDim.x * blockDim.x;
+    const int64_t tid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+#define WD(k) wd[(int64_t)(k) * NT + tid]
+#define WI(k) wi[(int64_t)(k) * NT + tid]
+#define WB(k) wb[(int64_t)(k) * NT + tid]
+    // predecessor codes: 0 = (i-1,j), 1 = (i,j-1), 2 = (i-1,j-1); evaluation order per tie_order
+    const int o0 = tie_order == 0 ? 0 : 2, o1 = tie_order == 0 ? 1 : 0, o2 = tie_order == 0 ? 2 : 1;
+    const int64_t total = n_x * n_y;
+    for (int64_t pair = tid; pair < total; pair += NT) {
+        const int64_t r = pair / n_y, a = pair % n_y;
+        const int64_t xb = x_ptr[r], yb = y_ptr[a];
+        const int lx0 = (int)(x_ptr[r + 1] - xb), ly0 = (int)(y_ptr[a + 1] - yb);
+        if (lx0 == 0 || ly0 == 0) { out[pair] = 0.f; continue; }        // padded row: PAD (SubGNN.py:831)
+        // ---- build the halved series of every level ------------------------------------
+        for (int i = 0; i < lx0; ++i) WD(i) = (double)x_val[xb + i];
+        for (int i = 0; i < ly0; ++i) WD(L.off_ys + i) = (double)y_val[yb + i];
+        int n_levels = 1;
+        int lx = lx0, ly = ly0, xo = 0, yo = 0;
+        int lxs[24], lys[24], xos[24], yos[24];
+        lxs[0] = lx; lys[0] = ly; xos[0] = 0; yos[0] = 0;
+        while (lx >= 3 && ly >= 3) {
+            const int nlx = lx / 2, nly = ly / 2;
+            const int nxo = xo + lx, nyo = yo + ly;
+            for (int i = 0; i < nlx; ++i) WD(nxo + i) = (WD(xo + 2 * i) + WD(xo + 2 * i + 1)) / 2.0;
+            for (int i = 0; i < nly; ++i) WD(L.off_ys + nyo + i) = (WD(L.off_ys + yo + 2 * i) + WD(L.off_ys + yo + 2 * i + 1)) / 2.0;
+            lx = nlx; ly = nly; xo = nxo; yo = nyo;
+            lxs[n_levels] = lx; lys[n_levels] = ly; xos[n_levels] = xo; yos[n_levels] = yo;
+            ++n_levels;
+        }
+        double result = 0.0;
+        // ---- coarsest -> finest ---------------------------------------------------------
+        for (int lev = n_levels - 1; lev >= 0; --lev) {
+            lx = lxs[lev]; ly = lys[lev]; xo = xos[lev]; yo = yos[lev];
+            const int64_t fcur = L.off_first + (int64_t)(lev & 1) * (L.off_lo);      // ping-pong halves (MX each)
+            const int64_t lcur = L.off_last + (int64_t)(lev & 1) * (L.off_lo);
+            const int64_t fprev = L.off_first + (int64_t)((lev + 1) & 1) * (L.off_lo);
+            const int64_t lprev = L.off_last + (int64_t)((lev + 1) & 1) * (L.off_lo);
+            // window bounds per row
+            int cells = 0;
+            if (lev == n_levels - 1) {
+                for (int i = 0; i < lx; ++i) { WI(L.off_lo + i) = 0; WI(L.off_hi + i) = ly - 1; WI(i) = cells; cells += ly; }
+            } else {
+                const int lxc = lxs[lev + 1];
+                int prev_lo = 0;
+                for (int i = 0; i < lx; ++i) {
+                    const int ci = i >> 1;
+                    const int ca = ci - 1 < 0 ? 0 : (ci - 1 > lxc - 1 ? lxc - 1 : ci - 1);
+                    const int cb = ci + 1 > lxc - 1 ? lxc - 1 : ci + 1;
+                    int lo = 2 * (WI(fprev + ca) - 1);
+                    int hi = 2 * (WI(lprev + cb) + 1) + 1;
+                    if (ci - 1 > lxc - 1) { lo = ly; hi = -1; }          // no coarse cell within radius
+                    if (lo < prev_lo) lo = prev_lo;
+                    if (lo < 0) lo = 0;
+                    if (hi > ly - 1) hi = ly - 1;
+                    WI(L.off_lo + i) = lo; WI(L.off_hi + i) = hi; WI(i) = cells;
+                    if (hi >= lo) { cells += hi - lo + 1; prev_lo = lo; }
+                }
+            }
+            // DP over the window, row-major (the published evaluation order)
+            const double INF = __longlong_as_double(0x7ff0000000000000ll);
+            int64_t prow = L.off_prev, crow = L.off_cur;
+            int plo = 0, phi = -1;
+            for (int i = 0; i < lx; ++i) {
+                const int lo = WI(L.off_lo + i), hi = WI(L.off_hi + i);
+                const int rs = WI(i);
+                const double xi = WD(xo + i);
+                double left = INF;
+                for (int j = lo; j <= hi; ++j) {
+                    const double dt = dtw_cost(xi, WD(L.off_ys + yo + j));
+                    double up = INF, diag = INF;
+                    if (i == 0) { if (j == 0) diag = 0.0; }
+                    else {
+                        if (j >= plo && j <= phi) up = WD(prow + j);
+                        if (j - 1 >= plo && j - 1 <= phi) diag = WD(prow + j - 1);
+                    }
+                    if (j == lo) left = INF;
+                    double c[3];
+                    c[0] = up + dt; c[1] = left + dt; c[2] = diag + dt;
+                    int best = o0;
+                    double bc = c[o0];
+                    if (c[o1] < bc) { bc = c[o1]; best = o1; }
+                    if (c[o2] < bc) { bc = c[o2]; best = o2; }
+                    WD(crow + j) = bc;
+                    WB(rs + (j - lo)) = (uint8_t)best;
+                    left = bc;
+                }
+                if (hi >= lo) { const int64_t t = prow; prow = crow; crow = t; plo = lo; phi = hi; }
+            }
+            result = WD(prow + (ly - 1));
+            if (lev == 0) break;
+            // backtrack: column range of the path per row of THIS level
+            int i = lx - 1, j = ly - 1;
+            for (int q = 0; q < lx; ++q) { WI(fcur + q) = ly; WI(lcur + q) = -1; }
+            while (i >= 0 && j >= 0) {
+                if (WI(lcur + i) < j) WI(lcur + i) = j;
+                if (WI(fcur + i) > j) WI(fcur + i) = j;
+                const int lo = WI(L.off_lo + i), hi = WI(L.off_hi + i);
+                if (j < lo || j > hi) break;                                // cannot happen for a finite path
+                const int d = WB(WI(i) + (j - lo));
+                if (d == 0) --i; else if (d == 1) --j; else { --i; --j; }
+            }
+        }
+        out[pair] = (float)(1.0 / (result + 1.0));
+    }
+#undef WD
+#undef WI
+#undef WB
+}
+
+extern "C" int sgnn_dtw_similarity(const int64_t* x_ptr, const int32_t* x_val, int64_t n_x, int64_t max_x_len,
+                                   const int64_t* y_ptr, const int32_t* y_val, int64_t n_y, int64_t max_y_len,
+                                   int tie_order, float* out, void* workspace, int64_t workspace_bytes, void* stream)
+{
+    if (!x_ptr || !x_val || !y_ptr || !y_val || !out || !workspace || n_x < 0 || n_y < 0) return SGNN_ERR_BAD_ARG;
+    if (tie_order < 0 || tie_order > 1) return SGNN_ERR_BAD_ARG;
+    if (max_x_len < 1) max_x_len = 1;
+    if (max_y_len < 1) max_y_len = 1;
+    if (workspace_bytes < sgnn_dtw_workspace_bytes(max_x_len, max_y_len)) return SGNN_ERR_BAD_ARG;
+    if (n_x * n_y == 0) return SGNN_OK;
+    const DtwLayout L = dtw_layout(max_x_len, max_y_len);
+    double* wd = (double*)workspace;
+    int32_t* wi = (int32_t*)(wd + L.n_dbl * DTW_NT);
+    uint8_t* wb = (uint8_t*)(wi + L.n_i32 * DTW_NT);
+    hipLaunchKernelGGL(dtw_similarity_kernel, dim3(DTW_BLOCKS), dim3(DTW_THREADS), 0, (hipStream_t)stream, x_ptr,
+                       x_val, n_x, y_ptr, y_val, n_y, tie_order, out, wd, wi, wb, L);
+    SGNN_CHECK_LAUNCH();
+    return SGNN_OK;
+}

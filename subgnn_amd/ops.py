@@ -1,0 +1,445 @@
+"""Torch-facing wrappers of the C ABI in include/subgnn_hip.h.
+
+PyTorch is plumbing here (device memory, streams, autograd bookkeeping); every operator
+below runs a hand-written HIP kernel of libsubgnn_hip.so on the current stream.  Inputs
+must already live on the GPU; nothing here falls back to a CPU implementation.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import MpnArgs, check
+
+PAD = 0
+
+
+def _ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _req(t, dtype, name):
+    if t is None:
+        return
+    if not t.is_cuda:
+        raise _lib.SubgnnHipError('%s must be a CUDA/HIP tensor (there is no CPU path)' % name)
+    if t.dtype != dtype:
+        raise TypeError('%s must be %s, got %s' % (name, dtype, t.dtype))
+    if not t.is_contiguous():
+        raise ValueError('%s must be contiguous' % name)
+
+
+# ---------------------------------------------------------------------------------------
+# containers
+# ---------------------------------------------------------------------------------------
+
+class Ragged:
+    """CSR-style node sets on the device: ptr int64[n+1], nodes int32[total]."""
+
+    def __init__(self, ptr, nodes, max_len=None):
+        _req(ptr, torch.int64, 'ptr')
+        _req(nodes, torch.int32, 'nodes')
+        self.ptr, self.nodes = ptr, nodes
+        self.n = ptr.numel() - 1
+        self._max_len = max_len
+
+    @property
+    def max_len(self):
+        if self._max_len is None:
+            self._max_len = int((self.ptr[1:] - self.ptr[:-1]).max().item()) if self.n > 0 else 0
+        return self._max_len
+
+    @property
+    def lengths(self):
+        return self.ptr[1:] - self.ptr[:-1]
+
+    @property
+    def total(self):
+        return self.nodes.numel() if self.n == 0 else int(self.ptr[-1].item())
+
+    @staticmethod
+    def from_padded(ids):
+        """(rows, L) padded int64 ids -> ragged, PAD stripped, order kept (gamma.py:27,
+        aps:131, S.py:769 all strip PAD this way)."""
+        assert ids.dim() == 2
+        mask = ids != PAD
+        lens = mask.sum(dim=1)
+        ptr = torch.zeros(ids.shape[0] + 1, dtype=torch.int64, device=ids.device)
+        torch.cumsum(lens, 0, out=ptr[1:])
+        nodes = ids[mask].to(torch.int32)
+        if nodes.numel() == 0:
+            nodes = torch.zeros(1, dtype=torch.int32, device=ids.device)
+        return Ragged(ptr, nodes.contiguous(), max_len=ids.shape[1])
+
+    @staticmethod
+    def from_lists(lists, device):
+        ptr = np.zeros(len(lists) + 1, dtype=np.int64)
+        for i, l in enumerate(lists):
+            ptr[i + 1] = ptr[i] + len(l)
+        flat = np.zeros(max(int(ptr[-1]), 1), dtype=np.int32)
+        for i, l in enumerate(lists):
+            flat[ptr[i]:ptr[i + 1]] = l
+        ml = max((len(l) for l in lists), default=0)
+        return Ragged(torch.from_numpy(ptr).to(device), torch.from_numpy(flat).to(device), max_len=ml)
+
+    def to_padded(self, width=None, fill=PAD, dtype=torch.int64):
+        width = self.max_len if width is None else width
+        out = torch.full((self.n, max(width, 0)), fill, dtype=dtype, device=self.ptr.device)
+        if self.n == 0 or width == 0:
+            return out
+        lens = self.lengths
+        tot = int(self.ptr[-1].item())
+        rows = torch.repeat_interleave(torch.arange(self.n, device=self.ptr.device), lens)
+        cols = torch.arange(tot, device=self.ptr.device) - torch.repeat_interleave(self.ptr[:-1], lens)
+        out[rows, cols] = self.nodes[:tot].to(dtype)
+        return out
+
+    def to_lists(self):
+        p = self.ptr.cpu().numpy()
+        v = self.nodes.cpu().numpy()
+        return [v[p[i]:p[i + 1]].tolist() for i in range(self.n)]
+
+
+class DeviceGraph:
+    """The base graph resident in HBM: CSR by node id in networkx neighbour order (walks) and
+    sorted order (adjacency tests), node order / position (G.nodes() semantics), degrees."""
+
+    def __init__(self, rowptr, col, node_order, device, full_degree=None):
+        rowptr = np.ascontiguousarray(rowptr, dtype=np.int64)
+        col = np.ascontiguousarray(col, dtype=np.int32)
+        self.max_id = len(rowptr) - 2
+        self.nnz = int(rowptr[-1])
+        col_sorted = col.copy()
+        # sort every row ascending (vectorised: sort by (row, value))
+        rows = np.repeat(np.arange(self.max_id + 1, dtype=np.int64), np.diff(rowptr))
+        order = np.lexsort((col_sorted, rows))
+        col_sorted = col_sorted[order]
+        node_order = np.ascontiguousarray(node_order, dtype=np.int32)
+        node_pos = np.zeros(self.max_id + 1, dtype=np.int32)
+        node_pos[node_order] = np.arange(len(node_order), dtype=np.int32)
+        self.n_nodes = len(node_order)
+        self.device = device
+        self.rowptr = torch.from_numpy(rowptr).to(device)
+        self.col = torch.from_numpy(col if len(col) else np.zeros(1, np.int32)).to(device)
+        self.col_sorted = torch.from_numpy(col_sorted if len(col_sorted) else np.zeros(1, np.int32)).to(device)
+        self.node_order = torch.from_numpy(node_order).to(device)
+        self.node_pos = torch.from_numpy(node_pos).to(device)
+        self.full_degree = None
+        if full_degree is not None:
+            self.full_degree = torch.from_numpy(np.ascontiguousarray(full_degree, dtype=np.int32)).to(device)
+
+
+# ---------------------------------------------------------------------------------------
+# integer half
+# ---------------------------------------------------------------------------------------
+
+def degree_sequence(g, sets, sort=True, use_degree_dict=True, want_external=True):
+    """gamma.get_degree_sequence for every set at once -> (internal, external) int32 flat
+    tensors aligned with ``sets.nodes`` (each set's slice sorted ascending if ``sort``)."""
+    lib = _lib.load()
+    n_tot = sets.nodes.numel()
+    out_i = torch.empty(n_tot, dtype=torch.int32, device=g.device)
+    out_e = torch.empty(n_tot, dtype=torch.int32, device=g.device) if want_external else None
+    fd = g.full_degree if use_degree_dict else None
+    check(lib.sgnn_degree_sequence(_ptr(g.rowptr), _ptr(g.col), g.nnz, _ptr(fd), _ptr(sets.ptr), _ptr(sets.nodes),
+                                   sets.n, max(sets.max_len, 1), 1 if sort else 0, _ptr(out_i), _ptr(out_e),
+                                   _stream()), 'sgnn_degree_sequence')
+    return out_i, out_e
+
+
+def cc_labels(g, subs):
+    lib = _lib.load()
+    if subs.max_len > 2048:
+        raise _lib.SubgnnHipError('sgnn_cc_labels: subgraph larger than 2048 nodes')
+    out = torch.empty(subs.nodes.numel(), dtype=torch.int32, device=g.device)
+    check(lib.sgnn_cc_labels(_ptr(g.rowptr), _ptr(g.col_sorted), g.nnz, _ptr(subs.ptr), _ptr(subs.nodes), subs.n,
+                             _ptr(out), _stream()), 'sgnn_cc_labels')
+    return out
+
+
+def khop_border(g, sets, k, ego_dict_mode=False, want_hops=False):
+    """k-hop border of every set -> Ragged (discovery order) [+ uint8 hop level per entry]."""
+    lib = _lib.load()
+    ws_bytes = lib.sgnn_khop_border_workspace_bytes(g.max_id, sets.n)
+    ws = torch.zeros(ws_bytes // 4 + 1, dtype=torch.int32, device=g.device)
+    counts = torch.zeros(sets.n, dtype=torch.int64, device=g.device)
+    check(lib.sgnn_khop_border(_ptr(g.rowptr), _ptr(g.col), g.nnz, g.max_id, _ptr(sets.ptr), _ptr(sets.nodes), sets.n,
+                               k, 1 if ego_dict_mode else 0, _ptr(counts), None, None, None, _ptr(ws), ws_bytes,
+                               _stream()), 'sgnn_khop_border(count)')
+    ptr = torch.zeros(sets.n + 1, dtype=torch.int64, device=g.device)
+    torch.cumsum(counts, 0, out=ptr[1:])
+    total = int(ptr[-1].item())
+    nodes = torch.zeros(max(total, 1), dtype=torch.int32, device=g.device)
+    hops = torch.zeros(max(total, 1), dtype=torch.uint8, device=g.device) if want_hops else None
+    check(lib.sgnn_khop_border(_ptr(g.rowptr), _ptr(g.col), g.nnz, g.max_id, _ptr(sets.ptr), _ptr(sets.nodes), sets.n,
+                               k, 1 if ego_dict_mode else 0, None, _ptr(ptr), _ptr(nodes), _ptr(hops), _ptr(ws),
+                               ws_bytes, _stream()), 'sgnn_khop_border(fill)')
+    r = Ragged(ptr, nodes)
+    return (r, hops) if want_hops else r
+
+
+def sort_ragged(r, extra=None):
+    """Canonical (ascending) order inside every set: one device sort of (set, id) keys."""
+    tot = int(r.ptr[-1].item())
+    if tot == 0:
+        return (r, extra) if extra is not None else r
+    rows = torch.repeat_interleave(torch.arange(r.n, device=r.ptr.device), r.lengths)
+    key = rows * (1 << 32) + r.nodes[:tot].to(torch.int64)
+    key, order = torch.sort(key)
+    nodes = (key & 0xFFFFFFFF).to(torch.int32)
+    out = Ragged(r.ptr, nodes.contiguous(), r._max_len)
+    if extra is not None:
+        return out, extra[:tot][order].contiguous()
+    return out
+
+
+def sample_anchors_padded(ids, n_slots, seed, stream_id):
+    """sample_neighborhood_anchor_patch on a padded (rows, L) id matrix -> (rows, n_slots)."""
+    lib = _lib.load()
+    _req(ids, torch.int64, 'ids')
+    rows, L = ids.shape
+    out = torch.empty((rows, n_slots), dtype=torch.int64, device=ids.device)
+    check(lib.sgnn_sample_anchors_padded(_ptr(ids), rows, L, n_slots, seed, stream_id, _ptr(out), _stream()),
+          'sgnn_sample_anchors_padded')
+    return out
+
+
+def sample_anchors_ragged(sets, n_slots, seed, stream_id, row_has_pad=None):
+    lib = _lib.load()
+    _req(row_has_pad, torch.uint8, 'row_has_pad')
+    out = torch.empty((sets.n, n_slots), dtype=torch.int64, device=sets.ptr.device)
+    check(lib.sgnn_sample_anchors_ragged(_ptr(sets.ptr), _ptr(sets.nodes), sets.n, _ptr(row_has_pad), n_slots, seed,
+                                         stream_id, _ptr(out), _stream()), 'sgnn_sample_anchors_ragged')
+    return out
+
+
+def choice_ragged(sets, n_draws, seed, stream_id):
+    lib = _lib.load()
+    out = torch.empty((sets.n, n_draws), dtype=torch.int64, device=sets.ptr.device)
+    check(lib.sgnn_choice_ragged(_ptr(sets.ptr), _ptr(sets.nodes), sets.n, n_draws, seed, stream_id, _ptr(out),
+                                 _stream()), 'sgnn_choice_ragged')
+    return out
+
+
+def triangular_walks(g, mode, n_items, walk_len, beta, seed, stream_id, patches=None, in_border=None,
+                     walks_per_patch=1):
+    """mode 0 'graph' / 1 'inside' / 2 'border' -> (n_items, walk_len) int64, PAD filled."""
+    lib = _lib.load()
+    out = torch.empty((n_items, walk_len), dtype=torch.int64, device=g.device)
+    check(lib.sgnn_triangular_walks(_ptr(g.rowptr), _ptr(g.col), _ptr(g.col_sorted), g.nnz, _ptr(g.node_order),
+                                    g.n_nodes, _ptr(patches.ptr) if patches else None,
+                                    _ptr(patches.nodes) if patches else None,
+                                    _ptr(in_border.ptr) if in_border else None,
+                                    _ptr(in_border.nodes) if in_border else None,
+                                    mode, n_items, walks_per_patch, walk_len, float(beta), seed, stream_id,
+                                    _ptr(out), _stream()), 'sgnn_triangular_walks')
+    return out
+
+
+def patch_in_border(g, patches):
+    """uint8 flag per patch node: is it an in-border node (su.get_border_nodes semantics)."""
+    lib = _lib.load()
+    if patches.max_len > 2048:
+        raise _lib.SubgnnHipError('sgnn_patch_in_border: patch larger than 2048 nodes')
+    out = torch.zeros(patches.nodes.numel(), dtype=torch.uint8, device=g.device)
+    check(lib.sgnn_patch_in_border(_ptr(g.rowptr), _ptr(g.col), g.nnz, _ptr(g.node_order), _ptr(g.node_pos),
+                                   g.n_nodes, _ptr(patches.ptr), _ptr(patches.nodes), patches.n, _ptr(out), _stream()),
+          'sgnn_patch_in_border')
+    return out
+
+
+def sp_similarity_dense(apsp, sets):
+    lib = _lib.load()
+    _req(apsp, torch.float64, 'apsp')
+    n_cols = apsp.shape[1]
+    out = torch.empty((sets.n, n_cols), dtype=torch.float32, device=apsp.device)
+    check(lib.sgnn_sp_similarity_dense(_ptr(apsp), n_cols, _ptr(sets.ptr), _ptr(sets.nodes), sets.n, _ptr(out),
+                                       _stream()), 'sgnn_sp_similarity_dense')
+    return out
+
+
+def bfs_hops(g, sources, max_hops=64):
+    """(n_sources, max_id+1) uint8 hop counts (255 = not reached) by multi-source BFS."""
+    lib = _lib.load()
+    _req(sources, torch.int32, 'sources')
+    ns = sources.numel()
+    dist = torch.empty((ns, g.max_id + 1), dtype=torch.uint8, device=g.device)
+    wsb = lib.sgnn_bfs_hops_workspace_bytes(g.max_id, ns, max_hops)
+    ws = torch.empty(wsb // 8 + 1, dtype=torch.int64, device=g.device)
+    check(lib.sgnn_bfs_hops(_ptr(g.rowptr), _ptr(g.col), g.nnz, g.max_id, _ptr(sources), ns, max_hops, _ptr(dist),
+                            _ptr(ws), wsb, _stream()), 'sgnn_bfs_hops')
+    return dist
+
+
+def min_hops_to_sets(dist, sets):
+    lib = _lib.load()
+    _req(dist, torch.uint8, 'dist')
+    ns, n_ids = dist.shape
+    out = torch.empty((sets.n, ns), dtype=torch.float32, device=dist.device)
+    check(lib.sgnn_min_hops_to_sets(_ptr(dist), ns, n_ids - 1, _ptr(sets.ptr), _ptr(sets.nodes), sets.n, _ptr(out),
+                                    _stream()), 'sgnn_min_hops_to_sets')
+    return out
+
+
+def dtw_similarity(x_ptr, x_val, max_x, y_ptr, y_val, max_y, tie_order=0):
+    """1/(1+fastdtw) for all (x row, y row) pairs -> (n_x, n_y) float32; empty x rows -> PAD."""
+    lib = _lib.load()
+    for t, nm in ((x_ptr, 'x_ptr'), (y_ptr, 'y_ptr')):
+        _req(t, torch.int64, nm)
+    for t, nm in ((x_val, 'x_val'), (y_val, 'y_val')):
+        _req(t, torch.int32, nm)
+    nx, ny = x_ptr.numel() - 1, y_ptr.numel() - 1
+    out = torch.empty((nx, ny), dtype=torch.float32, device=x_ptr.device)
+    wsb = lib.sgnn_dtw_workspace_bytes(max_x, max_y)
+    ws = torch.empty(wsb // 8 + 1, dtype=torch.int64, device=x_ptr.device)
+    check(lib.sgnn_dtw_similarity(_ptr(x_ptr), _ptr(x_val), nx, max_x, _ptr(y_ptr), _ptr(y_val), ny, max_y, tie_order,
+                                  _ptr(out), _ptr(ws), wsb, _stream()), 'sgnn_dtw_similarity')
+    return out
+
+
+# ---------------------------------------------------------------------------------------
+# float half (autograd Functions)
+# ---------------------------------------------------------------------------------------
+
+class _CCEmbed(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, E, ptr, nodes, aggregator, padded_len):
+        lib = _lib.load()
+        _req(E, torch.float32, 'E')
+        n = ptr.numel() - 1
+        D = E.shape[1]
+        out = torch.empty((n, D), dtype=torch.float32, device=E.device)
+        arg = torch.empty((n, D), dtype=torch.int32, device=E.device) if aggregator == 1 else None
+        check(lib.sgnn_cc_embed_fwd(_ptr(E), D, _ptr(ptr), _ptr(nodes), n, aggregator, padded_len, _ptr(out), _ptr(arg),
+                                    _stream()), 'sgnn_cc_embed_fwd')
+        ctx.save_for_backward(ptr, nodes, arg)
+        ctx.aggregator, ctx.shape = aggregator, E.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        if not ctx.needs_input_grad[0]:
+            return None, None, None, None, None
+        lib = _lib.load()
+        ptr, nodes, arg = ctx.saved_tensors
+        g = g.contiguous()
+        gE = torch.zeros(ctx.shape, dtype=torch.float32, device=g.device)
+        check(lib.sgnn_cc_embed_bwd(_ptr(g), ctx.shape[1], _ptr(ptr), _ptr(nodes), ptr.numel() - 1, ctx.aggregator,
+                                    _ptr(arg), _ptr(gE), _stream()), 'sgnn_cc_embed_bwd')
+        return gE, None, None, None, None
+
+
+def cc_embed(E, sets, aggregator='sum', padded_len=0):
+    """initialize_cc_embeddings on ragged components -> (n_sets, D)."""
+    return _CCEmbed.apply(E, sets.ptr, sets.nodes, 0 if aggregator == 'sum' else 1, int(padded_len))
+
+
+SRC_DENSE, SRC_GATHER, SRC_SHARED = 0, 1, 2
+
+
+def _mpn_args(src, x, ids, id_div, edge_mask, row_mask, sims, sim_col, sims_per_edge, wp, bp, R, A, D):
+    a = MpnArgs()
+    a.src, a.sims_per_edge = src, 1 if sims_per_edge else 0
+    a.R, a.A, a.D = R, A, D
+    a.x, a.ids, a.id_div = _ptr(x), _ptr(ids), id_div
+    a.edge_mask, a.row_mask = _ptr(edge_mask), _ptr(row_mask)
+    a.sims, a.sims_ld, a.sim_col = _ptr(sims), sims.shape[-1], _ptr(sim_col)
+    a.wp, a.bp = _ptr(wp), _ptr(bp)
+    return a
+
+
+class _MPN(torch.autograd.Function):
+    """agg (R,D), z (R,A) = gather-weight-aggregate + read-out; grads for x, wp (bp via z)."""
+
+    @staticmethod
+    def forward(ctx, x, wp, bp, sims, ids, edge_mask, row_mask, sim_col, src, id_div, sims_per_edge, R, A):
+        lib = _lib.load()
+        _req(x, torch.float32, 'x')
+        _req(wp, torch.float32, 'wp')
+        _req(bp, torch.float32, 'bp')
+        _req(sims, torch.float32, 'sims')
+        _req(ids, torch.int64, 'ids')
+        _req(edge_mask, torch.uint8, 'edge_mask')
+        _req(row_mask, torch.uint8, 'row_mask')
+        _req(sim_col, torch.int64, 'sim_col')
+        D = x.shape[-1]
+        agg = torch.empty((R, D), dtype=torch.float32, device=x.device)
+        z = torch.empty((R, A), dtype=torch.float32, device=x.device)
+        if A == 0:
+            agg.zero_()
+        else:
+            a = _mpn_args(src, x, ids, id_div, edge_mask, row_mask, sims, sim_col, sims_per_edge, wp, bp, R, A, D)
+            check(lib.sgnn_mpn_fwd(ctypes.byref(a), _ptr(agg), _ptr(z), _stream()), 'sgnn_mpn_fwd')
+        ctx.save_for_backward(x, wp, bp, sims, ids, edge_mask, row_mask, sim_col)
+        ctx.meta = (src, id_div, sims_per_edge, R, A, D)
+        return agg, z
+
+    @staticmethod
+    def backward(ctx, g_agg, g_z):
+        lib = _lib.load()
+        x, wp, bp, sims, ids, edge_mask, row_mask, sim_col = ctx.saved_tensors
+        src, id_div, sims_per_edge, R, A, D = ctx.meta
+        need_x, need_wp, need_bp = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2]
+        g_agg = g_agg.contiguous() if g_agg is not None else None
+        g_z = g_z.contiguous() if g_z is not None else None
+        gx = gwp = gbp = None
+        if need_x:
+            gx = torch.empty_like(x) if src == SRC_DENSE else torch.zeros_like(x)
+        if need_wp:
+            gwp = torch.zeros(D, dtype=torch.float32, device=x.device)
+        if (need_x or need_wp) and A > 0:
+            a = _mpn_args(src, x, ids, id_div, edge_mask, row_mask, sims, sim_col, sims_per_edge, wp, bp, R, A, D)
+            check(lib.sgnn_mpn_bwd(ctypes.byref(a), _ptr(g_agg), _ptr(g_z), _ptr(gx), _ptr(gwp), _stream()),
+                  'sgnn_mpn_bwd')
+        elif need_x and src == SRC_DENSE:
+            gx.zero_()
+        if need_wp:
+            gwp = gwp.view_as(wp)
+        if need_bp:
+            gbp = g_z.sum().view_as(bp) if g_z is not None else torch.zeros_like(bp)
+        return gx, gwp, gbp, None, None, None, None, None, None, None, None, None, None
+
+
+def mpn(x, wp, bp, sims, *, src, R, A, ids=None, id_div=1, edge_mask=None, row_mask=None, sim_col=None,
+        sims_per_edge=False):
+    """Fused anchor->component layer body.  x: DENSE (R,A,D) | GATHER E (rows,D) | SHARED (A,D).
+    Returns agg (R,D) and the pre-activation read-out z (R,A)."""
+    sims2 = sims.reshape(R, -1)
+    if not sims2.is_contiguous():
+        sims2 = sims2.contiguous()
+    return _MPN.apply(x.contiguous(), wp.contiguous().view(-1), bp.contiguous().view(-1), sims2, ids, edge_mask,
+                      row_mask, sim_col, src, id_div, sims_per_edge, R, A)
+
+
+class _MaskedSum(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, mask):
+        lib = _lib.load()
+        _req(x, torch.float32, 'x')
+        _req(mask, torch.uint8, 'mask')
+        B, C, H = x.shape
+        out = torch.empty((B, H), dtype=torch.float32, device=x.device)
+        check(lib.sgnn_masked_sum_fwd(_ptr(x), _ptr(mask), B, C, H, _ptr(out), _stream()), 'sgnn_masked_sum_fwd')
+        ctx.save_for_backward(mask)
+        ctx.shape = (B, C, H)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        (mask,) = ctx.saved_tensors
+        B, C, H = ctx.shape
+        g = g.contiguous()
+        gx = torch.empty((B, C, H), dtype=torch.float32, device=g.device)
+        check(lib.sgnn_masked_sum_bwd(_ptr(g), _ptr(mask), B, C, H, _ptr(gx), _stream()), 'sgnn_masked_sum_bwd')
+        return gx, None
+
+
+def masked_sum(x, mask):
+    """subgraph_utils.masked_sum(x, mask.unsqueeze(-1), dim=1) for x (B,C,H), mask (B,C)."""
+    return _MaskedSum.apply(x.contiguous(), mask.to(torch.uint8).contiguous())

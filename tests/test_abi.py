@@ -1,0 +1,48 @@
+"""CPU: the C-ABI library builds, loads, and exports every symbol include/subgnn_hip.h declares
+(no compute calls without a GPU)."""
+import os
+import re
+
+import pytest
+
+REPO = os.path.abspath(os.path.join(os.path.dirname(__file__), '..'))
+
+
+def _declared():
+    txt = open(os.path.join(REPO, 'include', 'subgnn_hip.h')).read()
+    txt = re.sub(r'/\*.*?\*/', '', txt, flags=re.S)
+    return sorted(set(re.findall(r'\b(sgnn_[a-z0-9_]+)\s*\(', txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    from subgnn_amd import build, _lib
+    build.build(verbose=False)
+    lib = _lib.load()
+    names = _declared()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(lib, n), n
+    assert sorted(_lib.SIGNATURES) == names        # the ctypes table mirrors the header
+    assert lib.sgnn_abi_version() == 1
+
+
+def test_workspace_queries_run_on_the_host():
+    from subgnn_amd import _lib
+    lib = _lib.load()
+    assert lib.sgnn_khop_border_workspace_bytes(1000, 10) == 10 * (((1000 + 32) // 32) * 4 + 1001 * 4)
+    assert lib.sgnn_dtw_workspace_bytes(20, 50) > 0
+    assert lib.sgnn_bfs_hops_workspace_bytes(1000, 70, 16) == 3 * 1001 * 2 * 8 + 18 * 4
+
+
+def test_argument_errors_are_reported_not_thrown():
+    from subgnn_amd import _lib
+    lib = _lib.load()
+    assert lib.sgnn_degree_sequence(None, None, 0, None, None, None, 0, 1, 1, None, None, None) == -1
+    assert lib.sgnn_mpn_fwd(None, None, None, None) == -1
+
+
+def test_cpu_tensors_are_rejected():
+    import torch
+    from subgnn_amd import ops, _lib
+    with pytest.raises(_lib.SubgnnHipError):
+        ops.Ragged(torch.zeros(2, dtype=torch.int64), torch.zeros(1, dtype=torch.int32))

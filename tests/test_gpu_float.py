@@ -1,0 +1,207 @@
+"""-m gpu parity tests of the float-half HIP kernels (through the C ABI) against the oracle
+(dense torch-CPU restatement pinned by reference goldens g10/g11).  Tolerance: 1e-4 relative
+(BASELINE.json north_star), stated in helpers.REL_TOL."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import float_half as FH
+from helpers import T, assert_close
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def _ops():
+    from subgnn_amd import ops
+    return ops
+
+
+@pytest.mark.parametrize('agg', ['sum', 'max'])
+@pytest.mark.parametrize('D', [8, 32, 64, 128])
+def test_cc_embed(agg, D):
+    ops = _ops()
+    g = torch.Generator().manual_seed(D)
+    N, S, C, L = 500, 40, 3, 9
+    E = torch.randn(N + 1, D, generator=g)
+    E[0] = 0
+    cc = torch.randint(1, N + 1, (S, C, L), generator=g)
+    lens = torch.randint(0, L + 1, (S, C), generator=g)
+    lens[0, 0] = L
+    cc[torch.arange(L).view(1, 1, L) >= lens.unsqueeze(-1)] = 0
+    Ec = E.clone().requires_grad_(True)
+    ref = FH.cc_embeddings(Ec, cc, agg)
+    gout = torch.randn(ref.shape, generator=g)
+    (ref * gout).sum().backward()
+    Eg = E.to(DEV).requires_grad_(True)
+    sets = ops.Ragged.from_padded(cc.view(S * C, L).to(DEV))
+    out = ops.cc_embed(Eg, sets, agg, padded_len=L).view(S, C, D)
+    (out * gout.to(DEV)).sum().backward()
+    assert_close(out, ref, 'cc_embed fwd', 1e-6)
+    assert_close(Eg.grad, Ec.grad, 'cc_embed bwd')
+    assert float(Eg.grad[0].abs().max()) == 0.0
+
+
+def _g10(g, tag, side):
+    t = 'g10_%s_%s_' % (tag, side)
+    d = {k: T(g[t + k]) for k in ('W', 'b', 'wp', 'bp', 'sims', 'cc_embeds', 'patches', 'mask', 'anchor_embeds',
+                                  'gout_cc', 'gout_pos')}
+    d['idx'] = [int(i) for i in g[t + 'sim_index']] if tag == 'S' else None
+    return t, d
+
+
+@pytest.mark.parametrize('tag', ['N', 'P', 'S'])
+@pytest.mark.parametrize('side', ['in', 'out'])
+def test_mpn_dense_matches_reference_golden(tiny, tag, side):
+    """SRC_DENSE = the reference's own SG_MPN inputs (materialised anchor_embeds + mask)."""
+    ops = _ops()
+    t, d = _g10(tiny, tag, side)
+    B, C, A, D = d['anchor_embeds'].shape
+    R = B * C
+    ae = d['anchor_embeds'].to(DEV).requires_grad_(True)
+    wp = d['wp'].to(DEV).requires_grad_(True)
+    bp = d['bp'].to(DEV).requires_grad_(True)
+    ids = d['patches'][..., 0].contiguous().view(R, A).to(DEV)
+    em = d['mask'][..., 0].contiguous().view(R, A).to(torch.uint8).to(DEV)
+    sim_col = torch.tensor(d['idx'], dtype=torch.int64, device=DEV) if d['idx'] is not None else None
+    agg, z = ops.mpn(ae.view(R, A, D), wp, bp, d['sims'].to(DEV), src=ops.SRC_DENSE, R=R, A=A, ids=ids,
+                     edge_mask=em, sim_col=sim_col)
+    W, b = d['W'].to(DEV).requires_grad_(True), d['b'].to(DEV).requires_grad_(True)
+    cc = d['cc_embeds'].to(DEV).requires_grad_(True)
+    out = torch.relu(torch.nn.functional.linear(torch.cat([cc.view(R, D), agg], -1), W, b)).view(B, C, D)
+    pos = torch.relu(z).view(B, C, A)
+    ((out * d['gout_cc'].to(DEV)).sum() + (pos * d['gout_pos'].to(DEV)).sum()).backward()
+    g = tiny
+    assert_close(out, g[t + 'out_cc'], 'out_cc')
+    assert_close(pos, g[t + 'out_pos'], 'out_pos')
+    assert_close(cc.grad, g[t + 'grad_cc_embeds'], 'grad cc')
+    assert_close(ae.grad, g[t + 'grad_anchor_embeds'], 'grad anchor embeds')
+    assert_close(W.grad, g[t + 'grad_W'], 'grad W')
+    assert_close(wp.grad, g[t + 'grad_wp'], 'grad wp')
+    assert_close(bp.grad, g[t + 'grad_bp'], 'grad bp')
+
+
+def _rand_case(seed, R, A, D, N, C):
+    g = torch.Generator().manual_seed(seed)
+    E = torch.randn(N + 1, D, generator=g)
+    E[0] = 0
+    ids = torch.randint(0, N + 1, (R, A), generator=g)
+    ids[torch.rand(R, A, generator=g) < 0.15] = 0
+    row_mask = (torch.rand(R, generator=g) > 0.2)
+    sims = torch.rand(R, N, generator=g) * 4
+    wp = torch.randn(1, D, generator=g) * 0.3
+    bp = torch.randn(1, generator=g) * 0.1
+    gagg = torch.randn(R, D, generator=g)
+    gz = torch.randn(R, A, generator=g)
+    return E, ids, row_mask, sims, wp, bp, gagg, gz
+
+
+def _ref_mpn(x_rows, edge, w, wp, bp):
+    """agg, z from per-edge rows (R,A,D), edge mask (R,A), weights (R,A)."""
+    m = (w * edge).unsqueeze(-1) * x_rows
+    agg = m.sum(1)
+    z = (m @ wp.view(-1, 1)).squeeze(-1) + bp
+    return agg, z
+
+
+@pytest.mark.parametrize('D', [8, 32, 64, 128])
+def test_mpn_gather_random(D):
+    """SRC_GATHER (anchor rows gathered from the embedding table by id, NP slab indexed by id-1)."""
+    ops = _ops()
+    R, A, N, C = 96, 11, 300, 4
+    E, ids, row_mask, sims, wp, bp, gagg, gz = _rand_case(D, R, A, D, N, C)
+    Ec, wpc, bpc = E.clone().requires_grad_(True), wp.clone().requires_grad_(True), bp.clone().requires_grad_(True)
+    edge = ((ids != 0) & row_mask.unsqueeze(-1)).float()
+    w = torch.gather(sims, 1, (ids - 1).clamp(min=0))
+    agg_r, z_r = _ref_mpn(torch.nn.functional.embedding(ids, Ec, padding_idx=0), edge, w, wpc, bpc)
+    ((agg_r * gagg).sum() + (z_r * gz).sum()).backward()
+    Eg, wpg, bpg = E.to(DEV).requires_grad_(True), wp.to(DEV).requires_grad_(True), bp.to(DEV).requires_grad_(True)
+    agg, z = ops.mpn(Eg, wpg, bpg, sims.to(DEV), src=ops.SRC_GATHER, R=R, A=A, ids=ids.to(DEV),
+                     row_mask=row_mask.to(torch.uint8).to(DEV))
+    ((agg * gagg.to(DEV)).sum() + (z * gz.to(DEV)).sum()).backward()
+    assert_close(agg, agg_r, 'agg')
+    assert_close(z, z_r, 'z')
+    assert_close(Eg.grad, Ec.grad, 'grad E')
+    assert_close(wpg.grad, wpc.grad, 'grad wp')
+    assert_close(bpg.grad, bpc.grad, 'grad bp')
+    assert float(Eg.grad[0].abs().max()) == 0.0
+
+
+def test_mpn_gather_shared_ids_over_components():
+    """P-internal: one id row per subgraph shared by its C components (id_div = C)."""
+    ops = _ops()
+    B, C, A, D, N = 10, 3, 7, 16, 100
+    R = B * C
+    E, _, row_mask, sims, wp, bp, gagg, gz = _rand_case(3, R, A, D, N, C)
+    g = torch.Generator().manual_seed(4)
+    ids_b = torch.randint(1, N + 1, (B, A), generator=g)
+    ids = ids_b.unsqueeze(1).repeat(1, C, 1).view(R, A)
+    edge = row_mask.unsqueeze(-1).float().expand(R, A)
+    w = torch.gather(sims, 1, ids - 1)
+    agg_r, z_r = _ref_mpn(E[ids], edge, w, wp, bp)
+    agg, z = ops.mpn(E.to(DEV), wp.to(DEV), bp.to(DEV), sims.to(DEV), src=ops.SRC_GATHER, R=R, A=A, ids=ids_b.to(DEV),
+                     id_div=C, row_mask=row_mask.to(torch.uint8).to(DEV))
+    assert_close(agg, agg_r, 'agg')
+    assert_close(z, z_r, 'z')
+
+
+@pytest.mark.parametrize('D', [8, 64, 128])
+@pytest.mark.parametrize('mode', ['sim_col', 'per_edge', 'by_id'])
+def test_mpn_shared_random(D, mode):
+    """SRC_SHARED: P-border (ids -> column id-1) and structure (index list) anchors."""
+    ops = _ops()
+    R, A, N, C = 150, 13, 200, 3
+    E, _, row_mask, sims, wp, bp, gagg, gz = _rand_case(D + 1, R, A, D, N, C)
+    g = torch.Generator().manual_seed(8)
+    X = torch.randn(A, D, generator=g)
+    ids = torch.randint(1, N + 1, (A,), generator=g)
+    col = torch.randint(0, N, (A,), generator=g)
+    Xc, wpc, bpc = X.clone().requires_grad_(True), wp.clone().requires_grad_(True), bp.clone().requires_grad_(True)
+    if mode == 'sim_col':
+        w = sims[:, col]
+        kw = dict(sim_col=col.to(DEV))
+        s_in = sims
+    elif mode == 'by_id':
+        w = sims[:, ids - 1]
+        kw = dict(ids=ids.to(DEV))
+        s_in = sims
+    else:
+        w = sims[:, :A].contiguous()
+        kw = dict(sims_per_edge=True)
+        s_in = w
+    edge = row_mask.unsqueeze(-1).float().expand(R, A)
+    agg_r, z_r = _ref_mpn(Xc.unsqueeze(0).expand(R, A, D), edge, w, wpc, bpc)
+    ((agg_r * gagg).sum() + (z_r * gz).sum()).backward()
+    Xg, wpg, bpg = X.to(DEV).requires_grad_(True), wp.to(DEV).requires_grad_(True), bp.to(DEV).requires_grad_(True)
+    agg, z = ops.mpn(Xg, wpg, bpg, s_in.to(DEV), src=ops.SRC_SHARED, R=R, A=A,
+                     row_mask=row_mask.to(torch.uint8).to(DEV), **kw)
+    ((agg * gagg.to(DEV)).sum() + (z * gz.to(DEV)).sum()).backward()
+    assert_close(agg, agg_r, 'agg')
+    assert_close(z, z_r, 'z')
+    assert_close(Xg.grad, Xc.grad, 'grad X')
+    assert_close(wpg.grad, wpc.grad, 'grad wp')
+    assert_close(bpg.grad, bpc.grad, 'grad bp')
+
+
+def test_masked_sum():
+    ops = _ops()
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(17, 5, 37, generator=g)
+    mask = torch.rand(17, 5, generator=g) > 0.3
+    xc = x.clone().requires_grad_(True)
+    ref = (xc * mask.unsqueeze(-1)).sum(1)
+    go = torch.randn(ref.shape, generator=g)
+    (ref * go).sum().backward()
+    xg = x.to(DEV).requires_grad_(True)
+    out = ops.masked_sum(xg, mask.to(DEV))
+    (out * go.to(DEV)).sum().backward()
+    assert_close(out, ref, 'masked_sum', 1e-6)
+    assert_close(xg.grad, xc.grad, 'masked_sum grad', 1e-6)
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    """No silent CPU fallback: a CPU tensor is rejected, and so is a missing library."""
+    ops = _ops()
+    from subgnn_amd import _lib
+    with pytest.raises(_lib.SubgnnHipError):
+        ops.masked_sum(torch.zeros(2, 2, 4), torch.ones(2, 2, dtype=torch.bool))

@@ -1,0 +1,351 @@
+"""-m gpu parity tests of the integer-half HIP kernels (through the C ABI) against the oracle,
+on the golden fixtures (reference-pinned) and on seeded random inputs.  Bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import graph as OG, integer_half as IH, tape as T, fastdtw_restate as FD, cbind
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def _ops():
+    from subgnn_amd import ops
+    return ops
+
+
+def _graphs(golden):
+    ops = _ops()
+    G = OG.from_edge_pairs([tuple(e) for e in golden['edge_list']])
+    rp, col = G.csr()
+    deg = np.zeros(G.max_id() + 1, dtype=np.int32)
+    for v in G.node_order:
+        deg[v] = G.degree(v)
+    return G, ops.DeviceGraph(rp, col, G.node_order, DEV, full_degree=deg)
+
+
+def _rand_graph(n, m, seed):
+    import networkx as nx
+    Gx = nx.barabasi_albert_graph(n, m, seed=seed)
+    rng = np.random.default_rng(seed)
+    edges = list(Gx.edges())
+    edges = [edges[i] for i in rng.permutation(len(edges))]
+    edges += [(3, 3), (10, 10)]                           # self loops
+    return OG.from_edge_pairs(edges)
+
+
+def _dev_graph(G, with_deg=True):
+    ops = _ops()
+    rp, col = G.csr()
+    deg = np.zeros(G.max_id() + 1, dtype=np.int32)
+    for v in G.node_order:
+        deg[v] = G.degree(v)
+    return ops.DeviceGraph(rp, col, G.node_order, DEV, full_degree=deg if with_deg else None)
+
+
+# ---- a10 degree sequence ------------------------------------------------------------------
+
+def test_degree_sequence_golden(golden):
+    ops = _ops()
+    G, dg = _graphs(golden)
+    sa = torch.from_numpy(golden['g5_structure_anchors']).to(DEV)
+    cc = torch.from_numpy(golden['g2_cc_ids_train']).to(DEV)
+    cc = cc.view(-1, cc.shape[-1])
+    for ids, ki, ke in ((sa, 'g6_anchor_deg_int', 'g6_anchor_deg_ext'), (cc, 'g6_cc_deg_int_train', 'g6_cc_deg_ext_train')):
+        r = ops.Ragged.from_padded(ids)
+        for use_dict in (True, False):
+            oi, oe = ops.degree_sequence(dg, r, sort=True, use_degree_dict=use_dict)
+            got_i = ops.Ragged(r.ptr, oi).to_lists()
+            got_e = ops.Ragged(r.ptr, oe).to_lists()
+            assert got_i == golden.ragged(ki, -1)
+            assert got_e == golden.ragged(ke, -1)        # degree dict == graph degree in the fixtures
+
+
+@pytest.mark.parametrize('sizes', [(1, 64), (60, 70), (65, 300), (1000, 2048)])
+def test_degree_sequence_random(sizes):
+    """wave path (<=64), block path (65..2048), duplicates, self loops, empty sets, vs the C oracle."""
+    ops = _ops()
+    G = _rand_graph(3000, 6, 7)
+    dg = _dev_graph(G, with_deg=False)
+    rng = np.random.default_rng(sizes[1])
+    sets = []
+    for i in range(300):
+        n = int(rng.integers(sizes[0], sizes[1] + 1))
+        s = rng.integers(1, G.max_id() + 1, n).tolist()
+        if i % 7 == 0:
+            s = s + s[:3]                                  # duplicates
+        if i % 11 == 0:
+            s = [3, 10] + s
+        s = s[:sizes[1]]
+        sets.append(s)
+    sets[5] = []
+    r = ops.Ragged.from_lists(sets, DEV)
+    rp, col = G.csr()
+    for srt in (True, False):
+        oi, oe = ops.degree_sequence(dg, r, sort=srt, use_degree_dict=False)
+        ptr, flat = cbind.ragged(sets)
+        ci, ce = cbind.degree_sequence(rp, col, None, ptr, flat, srt)
+        n = int(ptr[-1])
+        assert np.array_equal(oi.cpu().numpy()[:n], ci)
+        assert np.array_equal(oe.cpu().numpy()[:n], ce)
+
+
+def test_degree_sequence_too_large_is_an_error():
+    ops = _ops()
+    from subgnn_amd._lib import SubgnnHipError
+    G = _rand_graph(3000, 3, 1)
+    dg = _dev_graph(G)
+    r = ops.Ragged.from_lists([list(range(1, 2500))], DEV)
+    with pytest.raises(SubgnnHipError):
+        ops.degree_sequence(dg, r)
+
+
+# ---- a7 connected components --------------------------------------------------------------
+
+def _labels_to_sets(nodes, labels):
+    out = {}
+    for v, l in zip(nodes, labels):
+        out.setdefault(l, set()).add(v)
+    return {frozenset(s) for s in out.values()}
+
+
+def test_cc_labels_golden(golden):
+    ops = _ops()
+    G, dg = _graphs(golden)
+    for sp in ('train', 'val'):
+        subs = golden.ragged('subgraphs_' + sp, 0)
+        r = ops.Ragged.from_lists(subs, DEV)
+        lab = ops.Ragged(r.ptr, ops.cc_labels(dg, r)).to_lists()
+        cc = golden['g2_cc_ids_' + sp]
+        for s in range(len(subs)):
+            ref = {frozenset(int(v) for v in row if v != 0) for row in cc[s] if row[0] != 0}
+            assert _labels_to_sets(subs[s], lab[s]) == ref
+            # the label is the smallest position in the component
+            for i, l in enumerate(lab[s]):
+                assert l <= i and lab[s][l] == l
+
+
+def test_cc_labels_random():
+    ops = _ops()
+    G = _rand_graph(2000, 2, 3)
+    dg = _dev_graph(G)
+    rng = np.random.default_rng(0)
+    subs = [rng.integers(1, G.max_id() + 1, int(rng.integers(1, 200))).tolist() for _ in range(100)]
+    r = ops.Ragged.from_lists(subs, DEV)
+    lab = ops.Ragged(r.ptr, ops.cc_labels(dg, r)).to_lists()
+    for s in range(len(subs)):
+        ref = {frozenset(c) for c in IH.connected_components(G, subs[s])}
+        assert _labels_to_sets(subs[s], lab[s]) == ref
+
+
+# ---- a8 k-hop border ----------------------------------------------------------------------
+
+def test_khop_border_golden(golden):
+    ops = _ops()
+    G, dg = _graphs(golden)
+    cc = torch.from_numpy(golden['g2_cc_ids_train']).to(DEV)
+    r = ops.Ragged.from_padded(cc.view(-1, cc.shape[-1]))
+    for k in (1, 2, 3):
+        b, hops = ops.khop_border(dg, r, k, ego_dict_mode=golden.has_ego, want_hops=True)
+        b, hops = ops.sort_ragged(b, hops)
+        assert b.to_lists() == golden.ragged('g3_border_k%d_train' % k, -1)
+        if not golden.has_ego:
+            ccn = golden['g2_cc_ids_train'].reshape(-1, golden['g2_cc_ids_train'].shape[-1])
+            hl = ops.Ragged(b.ptr, hops.to(torch.int32)).to_lists()
+            for row in range(ccn.shape[0]):
+                lev = IH.border_hop_levels(G, ccn[row], k)
+                assert hl[row] == [lev[v] for v in b.to_lists()[row]]
+
+
+def test_khop_border_workspace_left_clean():
+    """Many more sets than workgroups: a workgroup's bitmap must be clean for its next set."""
+    ops = _ops()
+    G = _rand_graph(500, 3, 5)
+    dg = _dev_graph(G)
+    rng = np.random.default_rng(1)
+    sets = [list({int(v) for v in rng.integers(1, G.max_id() + 1, int(rng.integers(1, 6)))}) for _ in range(3000)]
+    r = ops.Ragged.from_lists(sets, DEV)
+    b = ops.sort_ragged(ops.khop_border(dg, r, 2)).to_lists()
+    for i in range(0, 3000, 37):
+        assert b[i] == sorted(IH.component_border_set(G, sets[i], 2))
+
+
+# ---- a4 neighbourhood anchors -------------------------------------------------------------
+
+def test_sample_anchors_golden(golden):
+    ops = _ops()
+    hp, seed = golden.hp, golden.seed
+    for sp in ('train', 'val'):
+        for l in range(hp['n_layers']):
+            for mat, A, kind, key in ((golden['g2_cc_ids_' + sp], hp['n_anchor_patches_N_in'], T.STREAM_N_INT, 'g8_N_int_%s_%d'),
+                                      (golden['g3_border_' + sp], hp['n_anchor_patches_N_out'], T.STREAM_N_BOR, 'g8_N_bor_%s_%d')):
+                S, C, L = mat.shape
+                ids = torch.from_numpy(mat).to(DEV).view(S * C, L).contiguous()
+                st = T.stream_id(kind, sp, l)
+                got = ops.sample_anchors_padded(ids, A, seed, st).view(S, C, A).cpu().numpy()
+                assert np.array_equal(got, golden[key % (sp, l)])
+                # ragged form: same law, same tape, row_has_pad from the padded width
+                r = ops.Ragged.from_padded(ids)
+                has_pad = (r.lengths < L).to(torch.uint8)
+                got2 = ops.sample_anchors_ragged(r, A, seed, st, has_pad).view(S, C, A).cpu().numpy()
+                assert np.array_equal(got2, golden[key % (sp, l)])
+
+
+def test_sample_anchors_order_independent():
+    """keys are tied to node ids, not to columns: permuting a row leaves the sample unchanged."""
+    ops = _ops()
+    rng = np.random.default_rng(3)
+    ids = np.zeros((50, 40), dtype=np.int64)
+    for r in range(50):
+        n = int(rng.integers(1, 41))
+        ids[r, :n] = rng.choice(np.arange(1, 5000), n, replace=False)
+    perm = ids.copy()
+    for r in range(50):
+        n = int((ids[r] != 0).sum())
+        perm[r, :n] = rng.permutation(ids[r, :n])
+    a = ops.sample_anchors_padded(torch.from_numpy(ids).to(DEV), 9, 5, 77)
+    b = ops.sample_anchors_padded(torch.from_numpy(perm).to(DEV), 9, 5, 77)
+    assert torch.equal(a, b)
+
+
+# ---- a5/a6 choices ------------------------------------------------------------------------
+
+def test_choice_golden(golden):
+    ops = _ops()
+    G, dg = _graphs(golden)
+    hp, seed = golden.hp, golden.seed
+    for sp in ('train', 'val'):
+        subs = ops.Ragged.from_lists(golden.ragged('subgraphs_' + sp, 0), DEV)
+        for l in range(hp['n_layers']):
+            got = ops.choice_ragged(subs, hp['n_anchor_patches_pos_in'], seed, T.stream_id(T.STREAM_P_INT, sp, l))
+            assert np.array_equal(got.cpu().numpy(), golden['g8_P_int_%s_%d' % (sp, l)])
+    order = ops.Ragged.from_lists([G.node_order], DEV)
+    npatch = golden['g5_structure_anchors'].shape[0]
+    rng_list = ops.Ragged.from_lists([list(range(npatch))], DEV)
+    for l in range(hp['n_layers']):
+        got = ops.choice_ragged(order, hp['n_anchor_patches_pos_out'], seed, T.stream_id(T.STREAM_P_EXT, 0, l))
+        assert np.array_equal(got.cpu().numpy()[0], golden['g8_P_ext_%d' % l])
+        got = ops.choice_ragged(rng_list, hp['n_anchor_patches_structure'], seed, T.stream_id(T.STREAM_S_PICK, 0, l))
+        assert np.array_equal(got.cpu().numpy()[0], golden['g8_S_idx_%d' % l])
+
+
+# ---- a1-a3 walks --------------------------------------------------------------------------
+
+def test_walks_golden(golden):
+    ops = _ops()
+    G, dg = _graphs(golden)
+    hp, seed = golden.hp, golden.seed
+    sa = golden['g5_structure_anchors']
+    n = sa.shape[0]
+    got = ops.triangular_walks(dg, 0, n, hp['sample_walk_len'], hp['rw_beta'], seed, T.stream_id(T.STREAM_STRUCT_PATCH))
+    assert np.array_equal(got.cpu().numpy()[:, :sa.shape[1]], sa)
+    assert (got.cpu().numpy()[:, sa.shape[1]:] == 0).all()
+    W, Tn = hp['n_triangular_walks'], hp['random_walk_len']
+    views = ops.Ragged.from_lists(golden.ragged('g5_views_int', 0), DEV)
+    iw = ops.triangular_walks(dg, 1, n * W, Tn, hp['rw_beta'], seed, T.stream_id(T.STREAM_WALK_INT), patches=views,
+                              walks_per_patch=W)
+    assert np.array_equal(iw.view(n, W, Tn).cpu().numpy(), golden['g5_int_walks'])
+    vb = ops.Ragged.from_lists(golden.ragged('g5_views_bor', 0), DEV)
+    flags = ops.patch_in_border(dg, vb)
+    tot = int(vb.ptr[-1].item())
+    inb_lists = ops.Ragged(vb.ptr, (vb.nodes * flags.to(torch.int32))).to_lists()
+    inb_lists = [[v for v in row if v != 0] for row in inb_lists]
+    assert inb_lists == golden.ragged('g5_in_border', 0)
+    inb = ops.Ragged.from_lists(inb_lists, DEV)
+    bw = ops.triangular_walks(dg, 2, n * W, Tn, hp['rw_beta'], seed, T.stream_id(T.STREAM_WALK_BOR), patches=vb,
+                              in_border=inb, walks_per_patch=W)
+    assert np.array_equal(bw.view(n, W, Tn).cpu().numpy(), golden['g5_bor_walks'])
+
+
+def test_walks_random_vs_oracle():
+    ops = _ops()
+    G = _rand_graph(400, 4, 9)
+    dg = _dev_graph(G)
+    patches = IH.sample_structure_anchor_patches(G, 40, 30, 0.4, 123)
+    got = ops.triangular_walks(dg, 0, 40, 30, 0.4, 123, T.stream_id(T.STREAM_STRUCT_PATCH)).cpu().numpy()
+    assert np.array_equal(got[:, :patches.shape[1]], patches)
+    views = [IH.patch_unique_nodes(p) for p in patches]
+    inb = [IH.patch_in_border_nodes(G, v) for v in views]
+    vr, ir = ops.Ragged.from_lists(views, DEV), ops.Ragged.from_lists(inb, DEV)
+    for inside in (True, False):
+        ref = IH.perform_random_walks(G, patches, 4, 12, 0.4, inside, 123)
+        st = T.stream_id(T.STREAM_WALK_INT if inside else T.STREAM_WALK_BOR)
+        got = ops.triangular_walks(dg, 1 if inside else 2, 160, 12, 0.4, 123, st, patches=vr, in_border=ir,
+                                   walks_per_patch=4).view(40, 4, 12).cpu().numpy()
+        assert np.array_equal(got, ref)
+
+
+# ---- a9 shortest-path similarities --------------------------------------------------------
+
+def test_sp_similarity_dense_golden(golden):
+    ops = _ops()
+    apsp = torch.from_numpy(golden['apsp']).to(DEV)
+    for sp in ('train', 'val'):
+        cc = torch.from_numpy(golden['g2_cc_ids_' + sp]).to(DEV)
+        S, C, L = cc.shape
+        got = ops.sp_similarity_dense(apsp, ops.Ragged.from_padded(cc.view(S * C, L))).view(S, C, -1)
+        assert np.array_equal(got.cpu().numpy(), golden['g4_np_sim_' + sp])
+
+
+def test_bfs_hops_matches_apsp(golden):
+    """Sparse form == dense form on the columns of the chosen sources (the graph is connected
+    enough; unreachable pairs are 0 in both conventions)."""
+    ops = _ops()
+    G, dg = _graphs(golden)
+    rng = np.random.default_rng(2)
+    src = rng.choice(np.array(G.node_order), 70, replace=True).astype(np.int32)       # > 64: two words
+    dist = ops.bfs_hops(dg, torch.from_numpy(src).to(DEV), max_hops=32)
+    apsp = golden['apsp']
+    d = dist.cpu().numpy().astype(np.int64)
+    for i, s in enumerate(src):
+        row = d[i, 1:]
+        ref = apsp[s - 1, :]
+        reach = row != 255
+        assert np.array_equal(row[reach], ref[reach].astype(np.int64))
+        assert (ref[~reach] == 0).all()
+    cc = torch.from_numpy(golden['g2_cc_ids_train']).to(DEV)
+    S, C, L = cc.shape
+    sets = ops.Ragged.from_padded(cc.view(S * C, L))
+    got = ops.min_hops_to_sets(dist, sets).cpu().numpy()
+    ref = golden['g4_np_sim_train'].reshape(S * C, -1)[:, src - 1]
+    assert np.array_equal(got, ref)
+
+
+# ---- a11 DTW ------------------------------------------------------------------------------
+
+def test_dtw_golden(golden):
+    """PROVISIONAL pin (restated fastdtw): HIP == golden produced through the restatement."""
+    ops = _ops()
+    G, dg = _graphs(golden)
+    sa = torch.from_numpy(golden['g5_structure_anchors']).to(DEV)
+    cc = torch.from_numpy(golden['g2_cc_ids_train']).to(DEV)
+    S, C, L = cc.shape
+    ra, rc = ops.Ragged.from_padded(sa), ops.Ragged.from_padded(cc.view(S * C, L))
+    ai, ae = ops.degree_sequence(dg, ra)
+    ci, ce = ops.degree_sequence(dg, rc)
+    for xa, xc, key in ((ai, ci, 'g7_int_struc_sim_train'), (ae, ce, 'g7_bor_struc_sim_train')):
+        got = ops.dtw_similarity(rc.ptr, xc, rc.max_len, ra.ptr, xa, ra.max_len).view(S, C, -1)
+        assert np.array_equal(got.cpu().numpy(), golden[key])
+
+
+@pytest.mark.parametrize('tie', [0, 1])
+def test_dtw_random(tie):
+    ops = _ops()
+    rng = np.random.default_rng(10 + tie)
+    xs = [sorted(rng.integers(0, 12, int(rng.integers(0, 70))).tolist()) for _ in range(120)]
+    ys = [sorted(rng.integers(0, 40, int(rng.integers(1, 51))).tolist()) for _ in range(37)]
+    xp, xv = cbind.ragged(xs)
+    yp, yv = cbind.ragged(ys)
+    ref = cbind.fastdtw_sim(xp, xv, yp, yv, tie)
+    # spot-check the C oracle itself against the pure-Python restatement
+    for i in range(0, 120, 17):
+        for j in range(0, 37, 5):
+            assert ref[i, j] == (np.float32(FD.calc_dtw(xs[i], ys[j], tie)) if len(xs[i]) else 0)
+    t = lambda a: torch.from_numpy(a).to(DEV)
+    got = ops.dtw_similarity(t(xp), t(xv), 70, t(yp), t(yv), 51, tie).cpu().numpy()
+    assert np.array_equal(got, ref)
+    # size-independent properties: similarity in (0, 1], identical sequences -> 1
+    assert (got[[len(x) > 0 for x in xs]] > 0).all() and (got <= 1).all()
+    same = ops.dtw_similarity(t(yp), t(yv), 51, t(yp), t(yv), 51, tie).cpu().numpy()
+    assert (np.diag(same) == 1).all()
