@@ -1,0 +1,589 @@
+"""SubGNN module with the reference's LightningModule surface (mirrors reference
+SubGNN/SubGNN.py): same constructor ``SubGNN(hparams, graph_path, subgraph_path, embedding_path,
+similarities_path, shortest_paths_path, degree_dict_path, ego_graph_path)``, same hooks
+(prepare_data, *_dataloader, training_step, validation_step/test_step, *_epoch_end,
+configure_optimizers, backward), same ``forward`` signature, same state-dict key names, same
+``metric_scores`` / ``test_results`` attributes -- so the reference's ``train_config.py`` can
+drive it unchanged.
+
+What differs is where the work runs: the base graph, all component / anchor / similarity
+tensors and the embedding table stay resident in HBM; connected components, border sets,
+shortest-path and DTW similarities, walks, anchor draws and the per-step gather-weight-
+aggregate layers are HIP kernels (subgnn_amd.ops); the LSTM, the Linear layers, BatchNorm and
+the loss are torch modules (MIOpen / rocBLAS).  Randomness is the draw tape keyed by
+``hparams['seed']`` (subgnn_amd.tape).
+"""
+import json
+from pathlib import Path
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch.nn.parameter import Parameter
+
+from . import config, gamma, ops, subgraph_utils
+from . import anchor_patch_samplers as aps
+from .datasets import SubgraphDataset
+from .graph import load_graph
+from .subgraph_mpn import SG_MPN
+
+CHANNELS = (('neighborhood', 'N', 'use_neighborhood', 'neighborhood_mpns'),
+            ('position', 'P', 'use_position', 'position_mpns'),
+            ('structure', 'S', 'use_structure', 'structure_mpns'))
+CC_SLOTS = ('N_I', 'N_B', 'S_I', 'S_B', 'P_I', 'P_B')
+
+
+class LSTM(nn.Module):
+    """bidirectional LSTM + Linear(2h -> n_features) (S.py:60-88); keys lstm.lstm.* / lstm.linear.*"""
+
+    def __init__(self, n_features, h, dropout=0.0, num_layers=1, batch_first=True, aggregator='last'):
+        super().__init__()
+        if aggregator not in ('last', 'sum'):
+            raise NotImplementedError(aggregator)
+        self.num_layers, self.aggregator = num_layers, aggregator
+        self.lstm = nn.LSTM(n_features, h, num_layers=num_layers, batch_first=batch_first, dropout=dropout,
+                            bidirectional=True)
+        self.linear = nn.Linear(h * 2, n_features)
+
+    def forward(self, input):
+        out, _ = self.lstm(input)
+        agg = out[:, -1, :] if self.aggregator == 'last' else out.sum(dim=1)
+        return self.linear(agg)
+
+
+class _DeviceLoader:
+    """Batches assembled by whole-tensor index_select on the device (the tensors never leave
+    HBM); yields the same dict ``_pad_collate`` builds (S.py:1112-1114)."""
+
+    def __init__(self, model, split, batch_size, shuffle, drop_last):
+        self.m, self.split, self.bs, self.shuffle, self.drop_last = model, split, batch_size, shuffle, drop_last
+        self.n = len(getattr(model, split + '_sub_G'))
+
+    def __len__(self):
+        return self.n // self.bs if self.drop_last else (self.n + self.bs - 1) // self.bs
+
+    def __iter__(self):
+        order = torch.randperm(self.n) if self.shuffle else torch.arange(self.n)
+        for i in range(len(self)):
+            yield self.m.make_batch(self.split, order[i * self.bs:(i + 1) * self.bs])
+
+
+class SubGNN(nn.Module):
+    def __init__(self, hparams, graph_path, subgraph_path, embedding_path, similarities_path, shortest_paths_path,
+                 degree_dict_path, ego_graph_path):
+        super().__init__()
+        self.device = torch.device('cuda' if torch.cuda.is_available() else 'cpu')
+        self.hparams = hparams
+        self.graph_path, self.subgraph_path, self.embedding_path = graph_path, subgraph_path, embedding_path
+        self.similarities_path = Path(similarities_path)
+        self.shortest_paths_path, self.degree_dict_path, self.ego_graph_path = \
+            shortest_paths_path, degree_dict_path, ego_graph_path
+        self.read_data()
+
+        hp = self.hparams
+        D, nl = hp['node_embed_size'], hp['n_layers']
+        hid_dim = D
+        for channel, tag, flag, attr in CHANNELS:
+            layers = nn.ModuleList()
+            if hp[flag]:
+                if tag == 'N':
+                    hid_dim += nl * 2 * D
+                elif tag == 'P':
+                    hid_dim += (hp['n_anchor_patches_pos_in'] + hp['n_anchor_patches_pos_out']) * nl
+                else:
+                    hid_dim += 2 * hp['n_anchor_patches_structure'] * nl
+                for _ in range(nl):
+                    layer = nn.ModuleDict({'internal': SG_MPN(hp), 'border': SG_MPN(hp)})
+                    if hp.get('batch_norm', False):
+                        layer['batch_norm'] = nn.BatchNorm1d(D)
+                        layer['batch_norm_out'] = nn.BatchNorm1d(D)
+                    layers.append(layer)
+            setattr(self, attr, layers)
+        self.hid_dim = hid_dim
+        self.lin = nn.Linear(hid_dim, hp['linear_hidden_dim_1'])
+        self.lin2 = nn.Linear(hp['linear_hidden_dim_1'], hp['linear_hidden_dim_2'])
+        self.lin3 = nn.Linear(hp['linear_hidden_dim_2'], self.num_classes)
+        self.lin_dropout = nn.Dropout(p=hp['lin_dropout'])
+        self.lin_dropout2 = nn.Dropout(p=hp['lin_dropout'])
+        self.loss = nn.BCEWithLogitsLoss() if self.multilabel else nn.CrossEntropyLoss()
+        self.lstm = LSTM(D, D, dropout=hp['lstm_dropout'], num_layers=hp['lstm_n_layers'],
+                         aggregator=hp['lstm_aggregator'])
+        if hp.get('ff_attn', False):
+            raise NotImplementedError('ff_attn (attention.AdditiveAttention read-out) is not built yet')
+        hp.setdefault('structure_similarity_fn', 'dtw')
+        self.metric_scores = []
+        self.to(self.device)
+
+    # ------------------------------------------------------------------ data -------------
+    def read_data(self):
+        """S.py:519-570: base graph -> CSR in HBM, subgraphs + labels, embedding table with the
+        zero PAD row."""
+        root = Path(config.PROJECT_ROOT)
+        self.networkx_graph = load_graph(root / self.graph_path, self.device, root / self.degree_dict_path)
+        (self.train_sub_G, self.train_sub_G_label, self.val_sub_G, self.val_sub_G_label, self.test_sub_G,
+         self.test_sub_G_label) = subgraph_utils.read_subgraphs(root / self.subgraph_path)
+        self.multilabel = isinstance(self.train_sub_G_label, list)
+        self.multilabel_binarizer = None
+        if self.multilabel:
+            from sklearn.preprocessing import MultiLabelBinarizer
+            self.multilabel_binarizer = MultiLabelBinarizer().fit(
+                self.train_sub_G_label + self.val_sub_G_label + self.test_sub_G_label)
+        if self.hparams.get('subset_data', False):
+            bs = self.hparams['batch_size']
+            for sp in ('train', 'val', 'test'):
+                setattr(self, sp + '_sub_G', getattr(self, sp + '_sub_G')[:bs])
+                setattr(self, sp + '_sub_G_label', getattr(self, sp + '_sub_G_label')[:bs])
+        if self.multilabel:
+            self.num_classes = max(max(l) for l in self.train_sub_G_label + self.val_sub_G_label + self.test_sub_G_label) + 1
+        else:
+            self.num_classes = int(torch.max(torch.cat((self.train_sub_G_label.view(-1), self.val_sub_G_label.view(-1),
+                                                        self.test_sub_G_label.view(-1))))) + 1
+        for sp in ('train', 'val', 'test'):                                   # ids become 1-based
+            setattr(self, sp + '_sub_G', [[n + 1 for n in sg] for sg in getattr(self, sp + '_sub_G')])
+        pre = torch.load(root / self.embedding_path, map_location='cpu')
+        self.hparams['node_embed_size'] = pre.shape[1]
+        table = torch.cat((torch.zeros(1, pre.shape[1]), pre.float()), 0)
+        self.node_embeddings = nn.Embedding.from_pretrained(table, freeze=self.hparams['freeze_node_embeds'],
+                                                            padding_idx=config.PAD_VALUE)
+
+    # ------------------------------------------------------------------ components -------
+    def initialize_cc_ids(self, subgraph_ids):
+        """S.py:575-607 -> (S, max_n_cc, max_len_cc) int64 on the device.  Component order:
+        by first node; nodes in subgraph order (the reference's is CPython-set order)."""
+        subs = ops.Ragged.from_lists(subgraph_ids, self.device)
+        labels = ops.cc_labels(self.networkx_graph, subs)
+        return subgraph_utils.components_from_labels(subs.ptr, subs.nodes, labels)
+
+    def initialize_cc_embeddings(self, cc_id_list, aggregator='sum'):
+        """S.py:609-622 -> (S, C, D)."""
+        S, C, L = cc_id_list.shape
+        sets = ops.Ragged.from_padded(cc_id_list.to(self.device).reshape(S * C, L))
+        return ops.cc_embed(self.node_embeddings.weight, sets, aggregator, padded_len=L).view(S, C, -1)
+
+    def initialize_channel_embeddings(self, cc_embeddings, trainable=False):
+        if trainable:
+            return tuple(Parameter(cc_embeddings.detach().clone()) for _ in CC_SLOTS)
+        return tuple(cc_embeddings for _ in CC_SLOTS)
+
+    def init_all_embeddings(self, split='all', trainable=False):
+        which = {'all': ('train', 'val', 'test'), 'train_val': ('train', 'val')}.get(split, (split,))
+        for sp in which:
+            with torch.no_grad():
+                emb = self.initialize_cc_embeddings(getattr(self, sp + '_cc_ids'), self.hparams['cc_aggregator'])
+            six = self.initialize_channel_embeddings(emb, trainable and sp == 'train')
+            for nm, t in zip(CC_SLOTS, six):
+                setattr(self, '%s_%s_cc_embed' % (sp, nm), t)
+
+    # ------------------------------------------------------------------ border sets -------
+    def _sim_dir(self):
+        d = Path(config.PROJECT_ROOT) / self.similarities_path
+        d.mkdir(parents=True, exist_ok=True)
+        return d
+
+    def _cached(self, fname, compute, dtype=None):
+        """the reference's .npy cache (S.py:726-742, 852-873, 893-978): load unless
+        compute_similarities, else compute on the GPU and save."""
+        if fname.exists() and not self.hparams['compute_similarities']:
+            t = torch.from_numpy(np.load(fname, allow_pickle=True))
+            return t.to(self.device) if dtype is None else t.to(self.device, dtype)
+        t = compute()
+        np.save(fname, t.detach().cpu().numpy())
+        return t
+
+    def initialize_border_sets(self, fname, cc_ids, radius, ego_graph_dict=None):
+        t = subgraph_utils.border_sets(self.networkx_graph, cc_ids, radius, ego_dict_mode=ego_graph_dict is not None)
+        np.save(fname, t.cpu().numpy())
+        return t
+
+    def get_border_sets(self, split):
+        hp = self.hparams
+        need = hp['use_neighborhood'] or (hp['use_structure'] and hp['structure_similarity_fn'] == 'edit_distance')
+        splits = ('test',) if split == 'test' else ('train', 'val')
+        if not need:
+            for sp in splits:
+                setattr(self, sp + '_N_border', None)
+            return
+        ego = (Path(config.PROJECT_ROOT) / self.ego_graph_path).exists()
+        for sp in splits:
+            f = self._sim_dir() / ('%d_%d_%s_border_set.npy' % (hp['neigh_sample_border_size'], config.PAD_VALUE, sp))
+            cc = getattr(self, sp + '_cc_ids')
+            setattr(self, sp + '_N_border', self._cached(
+                f, lambda: subgraph_utils.border_sets(self.networkx_graph, cc, hp['neigh_sample_border_size'], ego)))
+
+    # ------------------------------------------------------------------ similarities ------
+    def compute_shortest_path_similarities(self, fname, shortest_paths, cc_ids):
+        """S.py:752-781: (S, C, N) float32 = column-min of the APSP rows of each component."""
+        S, C, L = cc_ids.shape
+        sets = ops.Ragged.from_padded(cc_ids.reshape(S * C, L))
+        sims = ops.sp_similarity_dense(shortest_paths, sets).view(S, C, -1)
+        np.save(fname, sims.cpu().numpy())
+        return sims
+
+    def compute_structure_patch_similarities(self, degree_dict, fname, internal, cc_ids, sim_path=None,
+                                             dataset_type=None, border_set=None):
+        """S.py:783-833: (S, C, n_patches) = 1/(1+fastdtw(deg seq of CC, deg seq of anchor))."""
+        if self.hparams['structure_similarity_fn'] != 'dtw':
+            raise NotImplementedError
+        S, C, L = cc_ids.shape
+        g = self.networkx_graph
+        use_dict = g.full_degree is not None
+        a_sets, a_seq = gamma.degree_sequences(g, self.structure_anchors, internal, use_dict)
+        c_sets, c_seq = gamma.degree_sequences(g, cc_ids.reshape(S * C, L), internal, use_dict)
+        sims = gamma.dtw_similarity_matrix(c_sets, c_seq, a_sets, a_seq).view(S, C, -1)
+        np.save(fname, sims.cpu().numpy())
+        return sims
+
+    def get_similarities(self, split):
+        hp = self.hparams
+        d = self._sim_dir()
+        splits = ('test',) if split == 'test' else ('train', 'val')
+        pad = config.PAD_VALUE
+        if hp['use_position'] or hp['use_neighborhood']:
+            apsp = None
+            for sp in splits:
+                f = d / ('%d_%s_similarities.npy' % (pad, sp))
+
+                def compute(sp=sp, f=f):
+                    nonlocal apsp
+                    if apsp is None:
+                        apsp = torch.from_numpy(np.load(Path(config.PROJECT_ROOT) / self.shortest_paths_path,
+                                                        allow_pickle=True)).to(self.device, torch.float64).contiguous()
+                    return self.compute_shortest_path_similarities(f, apsp, getattr(self, sp + '_cc_ids'))
+                setattr(self, sp + '_neigh_pos_similarities', self._cached(f, compute))
+        else:
+            for sp in splits:
+                setattr(self, sp + '_neigh_pos_similarities', None)
+        if not hp['use_structure']:
+            self.structure_anchors = None
+            for sp in splits:
+                setattr(self, sp + '_int_struc_similarities', None)
+                setattr(self, sp + '_bor_struc_similarities', None)
+            return
+        g = self.networkx_graph
+        tagp = '%d_%s_%d' % (hp['sample_walk_len'], hp['structure_patch_type'], hp['max_sim_epochs'])
+        self.structure_anchors = self._cached(
+            d / ('struc_patches_%s.npy' % tagp),
+            lambda: aps.sample_structure_anchor_patches(hp, g, self.device, hp['max_sim_epochs']))
+        tagw = '%d_%d_%s' % (hp['n_triangular_walks'], hp['random_walk_len'], tagp)
+        views = aps.patch_node_views(self.structure_anchors)
+        self.bor_structure_anchor_random_walks = self._cached(
+            d / ('bor_struc_patch_random_walks_%s.npy' % tagw),
+            lambda: aps.perform_random_walks(hp, g, self.structure_anchors, inside=False, views=views))
+        self.int_structure_anchor_random_walks = self._cached(
+            d / ('int_struc_patch_random_walks_%s.npy' % tagw),
+            lambda: aps.perform_random_walks(hp, g, self.structure_anchors, inside=True, views=views))
+        fn = '' if hp['structure_similarity_fn'] == 'dtw' else '_' + hp['structure_similarity_fn']
+        for side, internal in (('int', True), ('bor', False)):
+            for sp in splits:
+                f = d / ('%s_struc_%s_%d%s_%s_similarities.npy' % (side, tagp, pad, fn, sp))
+                cc = getattr(self, sp + '_cc_ids')
+                setattr(self, '%s_%s_struc_similarities' % (sp, side), self._cached(
+                    f, lambda f=f, cc=cc, internal=internal: self.compute_structure_patch_similarities(None, f, internal, cc)))
+
+    # ------------------------------------------------------------------ prepare -----------
+    def _prepare(self, split):
+        hp, g = self.hparams, self.networkx_graph
+        splits = ('test',) if split == 'test' else ('train', 'val')
+        for sp in splits:
+            setattr(self, sp + '_cc_ids', self.initialize_cc_ids(getattr(self, sp + '_sub_G')))
+        self.init_all_embeddings(split=split, trainable=hp['trainable_cc'])
+        self.get_border_sets(split=split)
+        self.get_similarities(split=split)
+        cc = {sp: getattr(self, sp + '_cc_ids', None) for sp in ('train', 'val', 'test')}
+        nb = {sp: getattr(self, sp + '_N_border', None) for sp in ('train', 'val', 'test')}
+        sub = {sp: getattr(self, sp + '_sub_G') for sp in ('train', 'val', 'test')}
+        if hp['use_neighborhood']:
+            ni, nbo = aps.init_anchors_neighborhood(split, hp, g, self.device, cc['train'], cc['val'], cc['test'],
+                                                    nb['train'], nb['val'], nb['test'])
+            if split == 'test' and getattr(self, 'anchors_neigh_int', None) is not None:
+                self.anchors_neigh_int.update(ni)
+                self.anchors_neigh_border.update(nbo)
+            else:
+                self.anchors_neigh_int, self.anchors_neigh_border = ni, nbo
+        else:
+            self.anchors_neigh_int, self.anchors_neigh_border = None, None
+        if hp['use_position']:
+            pi = aps.init_anchors_pos_int(split, hp, g, self.device, sub['train'], sub['val'], sub['test'])
+            if split == 'test' and getattr(self, 'anchors_pos_int', None) is not None:
+                self.anchors_pos_int.update(pi)
+            else:
+                self.anchors_pos_int = pi
+            if split != 'test':
+                self.anchors_pos_ext = aps.init_anchors_pos_ext(hp, g, self.device)
+        elif split != 'test':
+            self.anchors_pos_int, self.anchors_pos_ext = None, None
+        if split != 'test':
+            if hp['use_structure']:
+                self.anchors_structure = aps.init_anchors_structure(hp, self.structure_anchors,
+                                                                    self.int_structure_anchor_random_walks,
+                                                                    self.bor_structure_anchor_random_walks)
+            else:
+                self.anchors_structure = None
+        self._sim_col_cache = {}
+
+    def prepare_data(self):
+        """S.py:1024-1063."""
+        self._prepare('train_val')
+
+    def prepare_test_data(self):
+        """S.py:994-1022."""
+        self._prepare('test')
+
+    # ------------------------------------------------------------------ batches -----------
+    def _split_tensors(self, split):
+        return (getattr(self, split + '_cc_ids'), getattr(self, split + '_N_border', None),
+                getattr(self, split + '_neigh_pos_similarities', None),
+                getattr(self, split + '_int_struc_similarities', None),
+                getattr(self, split + '_bor_struc_similarities', None))
+
+    def make_batch(self, split, idx):
+        """Batch dict for subgraph indices ``idx`` (same keys/shapes as _pad_collate)."""
+        idx = torch.as_tensor(idx, dtype=torch.int64)
+        didx = idx.to(self.device)
+        cc, nb, npsim, isim, bsim = self._split_tensors(split)
+        subs = [getattr(self, split + '_sub_G')[int(i)] for i in idx]
+        L = max(len(s) for s in subs)
+        sub_ids = torch.zeros((len(subs), L), dtype=torch.int64)
+        for i, s in enumerate(subs):
+            sub_ids[i, :len(s)] = torch.as_tensor(s)
+        labels = getattr(self, split + '_sub_G_label')
+        if self.multilabel:
+            lab = torch.LongTensor(self.multilabel_binarizer.transform([labels[int(i)] for i in idx]))
+        else:
+            lab = labels.view(-1)[idx]
+        pick = lambda t: t.index_select(0, didx) if t is not None else None
+        return {'subgraph_ids': sub_ids.to(self.device),
+                'cc_ids': subgraph_utils.trim_zero_columns(pick(cc)),
+                'N_border': subgraph_utils.trim_zero_columns(pick(nb)) if nb is not None else None,
+                'NP_sim': pick(npsim), 'I_S_sim': pick(isim), 'B_S_sim': pick(bsim),
+                'subgraph_idx': didx.view(-1, 1), 'label': lab.to(self.device)}
+
+    def _pad_collate(self, batch):
+        """S.py:1068-1114 for a list of SubgraphDataset items."""
+        sub, cc, nb, npsim, isim, bsim, idx, labels = zip(*batch)
+        L = max(s.numel() for s in sub)
+        sub_ids = torch.zeros((len(sub), L), dtype=torch.int64)
+        for i, s in enumerate(sub):
+            sub_ids[i, :s.numel()] = s
+        st = lambda xs: None if any(x is None for x in xs) else torch.stack(xs)
+        nbs = st(nb)
+        return {'subgraph_ids': sub_ids, 'cc_ids': subgraph_utils.trim_zero_columns(torch.stack(cc)),
+                'N_border': subgraph_utils.trim_zero_columns(nbs) if nbs is not None else None,
+                'NP_sim': st(npsim), 'I_S_sim': st(isim), 'B_S_sim': st(bsim),
+                'subgraph_idx': torch.stack(idx), 'label': torch.stack(labels).squeeze()}
+
+    def _dataset(self, split):
+        cc, nb, npsim, isim, bsim = self._split_tensors(split)
+        return SubgraphDataset(getattr(self, split + '_sub_G'), getattr(self, split + '_sub_G_label'), cc, nb, npsim,
+                               isim, bsim, self.multilabel, self.multilabel_binarizer)
+
+    def train_dataloader(self):
+        bs = self.hparams['batch_size']
+        return _DeviceLoader(self, 'train', bs, shuffle=True, drop_last=bs <= len(self.train_sub_G))
+
+    def val_dataloader(self):
+        return _DeviceLoader(self, 'val', self.hparams['batch_size'], shuffle=False, drop_last=False)
+
+    def test_dataloader(self):
+        self.prepare_test_data()
+        return _DeviceLoader(self, 'test', self.hparams['batch_size'], shuffle=False, drop_last=False)
+
+    # ------------------------------------------------------------------ forward -----------
+    def run_mpn_layer(self, dataset_type, mpn_fn, subgraph_ids, subgraph_idx, cc_ids, cc_embeds, cc_embed_mask, sims,
+                      layer_num, channel, inside=True):
+        """S.py:195-223, reference-shaped: materialise (B,C,A,D) anchor embeddings, then SG_MPN."""
+        ap, am, ae = aps.get_anchor_patches(dataset_type, self.hparams, self.networkx_graph, self.node_embeddings,
+                                            subgraph_idx, cc_ids, cc_embed_mask, self.lstm, self.anchors_neigh_int,
+                                            self.anchors_neigh_border, self.anchors_pos_int, self.anchors_pos_ext,
+                                            self.anchors_structure, layer_num, channel, inside, self.device)
+        idx = self.anchors_structure[layer_num][1] if channel == 'structure' else None
+        return mpn_fn(self.networkx_graph, sims, cc_ids, cc_embeds, cc_embed_mask, ap, ae, am, idx)
+
+    def _run_mpn_layer_fused(self, dataset_type, mpn_fn, sidx, cc_embeds, cc_embed_mask, sims, layer_num, channel,
+                             inside):
+        """Same layer without the (B,C,A,D) tensor: anchors are gathered inside the kernel."""
+        B, C, _ = cc_embeds.shape
+        E = self.node_embeddings.weight
+        if channel == 'neighborhood':
+            src = self.anchors_neigh_int if inside else self.anchors_neigh_border
+            ids = src[dataset_type][layer_num].index_select(0, sidx).reshape(B * C, -1).contiguous()
+            return mpn_fn.forward_fused(sims, cc_embeds, cc_embed_mask, src=ops.SRC_GATHER, x=E, ids=ids)
+        if channel == 'position':
+            if inside:
+                ids = self.anchors_pos_int[dataset_type][layer_num].index_select(0, sidx).contiguous()
+                return mpn_fn.forward_fused(sims, cc_embeds, cc_embed_mask, src=ops.SRC_GATHER, x=E, ids=ids, id_div=C)
+            ids = self.anchors_pos_ext[layer_num]
+            X = F.embedding(ids, E, padding_idx=config.PAD_VALUE)
+            return mpn_fn.forward_fused(sims, cc_embeds, cc_embed_mask, src=ops.SRC_SHARED, x=X, ids=ids)
+        patches, indices, int_rw, bor_rw = self.anchors_structure[layer_num]
+        X = aps.aggregate_structure_anchor_patch(self.hparams, self.networkx_graph, self.lstm, self.node_embeddings,
+                                                 patches, int_rw if inside else bor_rw, inside, self.device)
+        key = layer_num
+        if key not in self._sim_col_cache:
+            self._sim_col_cache[key] = torch.as_tensor(indices, dtype=torch.int64, device=self.device)
+        return mpn_fn.forward_fused(sims, cc_embeds, cc_embed_mask, src=ops.SRC_SHARED, x=X,
+                                    sim_col=self._sim_col_cache[key])
+
+    def forward(self, dataset_type, N_I_cc_embed, N_B_cc_embed, S_I_cc_embed, S_B_cc_embed, P_I_cc_embed,
+                P_B_cc_embed, subgraph_ids, cc_ids, subgraph_idx, NP_sim, I_S_sim, B_S_sim):
+        """S.py:225-312."""
+        hp = self.hparams
+        fused = hp.get('fused_forward', True)
+        init_cc_embeds = self.initialize_cc_embeddings(cc_ids, hp['cc_aggregator'])
+        sidx = subgraph_idx.view(-1)
+        given = {'N_I': N_I_cc_embed, 'N_B': N_B_cc_embed, 'S_I': S_I_cc_embed, 'S_B': S_B_cc_embed,
+                 'P_I': P_I_cc_embed, 'P_B': P_B_cc_embed}
+        state = {}
+        for nm in CC_SLOTS:
+            state[nm] = torch.index_select(given[nm], 0, sidx) if hp['trainable_cc'] else init_cc_embeds
+        B, C, _ = init_cc_embeds.shape
+        cc_embed_mask = (cc_ids != config.PAD_VALUE)[:, :, 0]
+        bn = hp.get('batch_norm', False)
+        outputs = []
+        for l in range(hp['n_layers']):
+            for channel, tag, flag, attr in CHANNELS:
+                if not hp[flag]:
+                    continue
+                layer = getattr(self, attr)[l]
+                res = {}
+                for inside, side, name, bnname in ((True, 'I', 'internal', 'batch_norm'), (False, 'B', 'border', 'batch_norm_out')):
+                    sims = NP_sim if tag != 'S' else (I_S_sim if inside else B_S_sim)
+                    slot = tag + '_' + side
+                    if fused:
+                        o, p = self._run_mpn_layer_fused(dataset_type, layer[name], sidx, state[slot], cc_embed_mask,
+                                                         sims, l, channel, inside)
+                    else:
+                        o, p = self.run_mpn_layer(dataset_type, layer[name], subgraph_ids, subgraph_idx, cc_ids,
+                                                  state[slot], cc_embed_mask, sims, layer_num=l, channel=channel,
+                                                  inside=inside)
+                    if bn:
+                        o = layer[bnname](o.reshape(B * C, -1)).view(B, C, -1)
+                    state[slot] = o
+                    res[side] = (o, p)
+                pick = 0 if tag == 'N' else 1                      # N adds CC embeddings, P/S their read-outs
+                outputs.extend([res['I'][pick], res['B'][pick]])
+        all_cc_embeds = torch.cat([init_cc_embeds] + outputs, dim=-1)
+        subgraph_embedding = subgraph_utils.masked_sum(all_cc_embeds, cc_embed_mask.unsqueeze(-1), dim=1)
+        h = self.lin_dropout(F.relu(self.lin(subgraph_embedding)))
+        h = self.lin_dropout2(F.relu(self.lin2(h)))
+        return self.lin3(h)
+
+    # ------------------------------------------------------------------ steps -------------
+    def _forward_batch(self, split, batch):
+        e = {nm: getattr(self, '%s_%s_cc_embed' % (split, nm)) for nm in CC_SLOTS}
+        return self.forward(split, e['N_I'], e['N_B'], e['S_I'], e['S_B'], e['P_I'], e['P_B'], batch['subgraph_ids'],
+                            batch['cc_ids'], batch['subgraph_idx'], batch['NP_sim'], batch['I_S_sim'], batch['B_S_sim'])
+
+    def _loss(self, logits, labels):
+        if labels.dim() == 0:
+            labels = labels.unsqueeze(-1)
+        if self.multilabel:
+            return self.loss(logits.squeeze(1), labels.type_as(logits)), labels
+        return self.loss(logits, labels), labels
+
+    def training_step(self, train_batch, batch_idx):
+        labels = train_batch['label'].squeeze(-1)
+        logits = self._forward_batch('train', train_batch)
+        loss, labels = self._loss(logits, labels)
+        acc = subgraph_utils.calc_accuracy(logits, labels, multilabel_binarizer=self.multilabel_binarizer)
+        return {'loss': loss, 'log': {'train_loss': loss, 'train_acc': acc}}
+
+    def val_test_step(self, batch, batch_idx, is_test=False):
+        p = 'test' if is_test else 'val'
+        labels = batch['label'].squeeze(-1)
+        logits = self._forward_batch(p, batch)
+        loss, labels = self._loss(logits, labels)
+        acc = subgraph_utils.calc_accuracy(logits, labels, multilabel_binarizer=self.multilabel_binarizer)
+        f1 = subgraph_utils.calc_f1(logits, labels, avg_type='macro', multilabel_binarizer=self.multilabel_binarizer)
+        return {p + '_loss': loss, p + '_acc': acc, p + '_macro_f1': f1, p + '_logits': logits, p + '_labels': labels}
+
+    def validation_step(self, val_batch, batch_idx):
+        return self.val_test_step(val_batch, batch_idx, is_test=False)
+
+    def test_step(self, test_batch, batch_idx):
+        return self.val_test_step(test_batch, batch_idx, is_test=True)
+
+    def _epoch_metrics(self, outputs, p):
+        from sklearn.metrics import roc_auc_score
+        logits = torch.cat([x[p + '_logits'] for x in outputs], dim=0).detach()
+        labels = torch.cat([x[p + '_labels'] for x in outputs], dim=0)
+        mb = self.multilabel_binarizer
+        logs = {p + '_loss': torch.stack([x[p + '_loss'] for x in outputs]).mean().detach().cpu(),
+                p + '_micro_f1': subgraph_utils.calc_f1(logits, labels, 'micro', mb).squeeze(),
+                p + '_macro_f1': subgraph_utils.calc_f1(logits, labels, 'macro', mb).squeeze(),
+                p + '_acc': subgraph_utils.calc_accuracy(logits, labels, mb).squeeze()}
+        avg_acc = torch.stack([x[p + '_acc'] for x in outputs]).mean()
+        avg_f1 = torch.stack([x[p + '_macro_f1'] for x in outputs]).mean()
+        if p == 'val':
+            logs['avg_val_acc'], logs['avg_macro_f1'] = avg_acc, avg_f1
+        else:
+            logs['avg_test_acc'], logs['test_avg_macro_f1'] = avg_acc, avg_f1
+        lc, gc = labels.cpu(), logits.cpu()
+        try:
+            if self.multilabel:
+                logs[p + '_auroc'] = roc_auc_score(lc, torch.sigmoid(gc), multi_class='ovr')
+            elif len(torch.unique(lc)) == 2:
+                logs[p + '_auroc'] = roc_auc_score(lc, F.softmax(gc, dim=1)[:, 1])
+            else:
+                logs[p + '_auroc'] = roc_auc_score(lc, F.softmax(gc, dim=1), multi_class='ovr')
+            onehot = lc if self.multilabel else F.one_hot(lc, num_classes=gc.shape[1])
+            score = torch.sigmoid(gc) if self.multilabel else gc
+            for c in range(gc.shape[1]):
+                logs['%s_auroc_class_%d' % (p, c)] = roc_auc_score(onehot[:, c], score[:, c])
+        except ValueError:
+            logs.setdefault(p + '_auroc', float('nan'))       # a class absent from the split
+        return logs
+
+    def validation_epoch_end(self, outputs):
+        """S.py:408-464."""
+        logs = self._epoch_metrics(outputs, 'val')
+        hp = self.hparams
+        if not hp['trainable_cc']:
+            self.init_all_embeddings(split='train_val', trainable=False)
+        if hp['resample_anchor_patches']:
+            hp['seed'] = int(hp.get('seed', 0)) + 1            # a fresh tape for the new draws
+            self._prepare_anchors_only()
+        self.metric_scores.append(logs)
+        return {'avg_val_loss': logs['val_loss'], 'log': logs}
+
+    def _prepare_anchors_only(self):
+        hp, g = self.hparams, self.networkx_graph
+        if hp['use_neighborhood']:
+            self.anchors_neigh_int, self.anchors_neigh_border = aps.init_anchors_neighborhood(
+                'train_val', hp, g, self.device, self.train_cc_ids, self.val_cc_ids, None, self.train_N_border,
+                self.val_N_border, None)
+        if hp['use_position']:
+            self.anchors_pos_int = aps.init_anchors_pos_int('train_val', hp, g, self.device, self.train_sub_G,
+                                                            self.val_sub_G, self.test_sub_G)
+            self.anchors_pos_ext = aps.init_anchors_pos_ext(hp, g, self.device)
+        if hp['use_structure']:
+            self.anchors_structure = aps.init_anchors_structure(hp, self.structure_anchors,
+                                                                self.int_structure_anchor_random_walks,
+                                                                self.bor_structure_anchor_random_walks)
+            self._sim_col_cache = {}
+
+    def test_epoch_end(self, outputs):
+        """S.py:466-504."""
+        logs = self._epoch_metrics(outputs, 'test')
+        self.test_results = logs
+        return {'avg_test_loss': logs['test_loss'], 'log': logs}
+
+    # ------------------------------------------------------------------ optimisation ------
+    def configure_optimizers(self):
+        return torch.optim.Adam(self.parameters(), lr=self.hparams['learning_rate'])
+
+    def backward(self, trainer, loss, optimizer, optimizer_idx):
+        loss.backward(retain_graph=True)
+
+
+def dataset_paths(task, embedding_type='gin'):
+    """The seven dataset paths train_config.py derives from ``data.task`` (train_config.py:213-230)."""
+    t = Path(task)
+    return dict(graph_path=str(t / 'edge_list.txt'), subgraph_path=str(t / 'subgraphs.pth'),
+                embedding_path=str(t / ('%s_embeddings.pth' % embedding_type)),
+                similarities_path=str(t / 'similarities/'), shortest_paths_path=str(t / 'shortest_path_matrix.npy'),
+                degree_dict_path=str(t / 'degree_sequence.txt'), ego_graph_path=str(t / 'ego_graphs.txt'))
+
+
+__all__ = ['SubGNN', 'LSTM', 'dataset_paths', 'json']

@@ -1,0 +1,222 @@
+"""Anchor-patch sampling and retrieval (mirrors reference SubGNN/anchor_patch_samplers.py).
+
+Function names, argument meaning and returned containers follow the reference; the graph
+argument is a ``DeviceGraph`` (CSR in HBM) instead of a networkx graph, and every random
+decision reads the counter-based draw tape (tape.py) keyed by ``hparams['seed']`` instead of
+the global numpy / random / torch streams -- which is what lets walks and anchor draws run as
+parallel HIP kernels and still be reproducible draw for draw.
+"""
+from collections import defaultdict
+
+import torch
+
+from . import ops, tape
+from .config import PAD_VALUE
+
+
+def _seed(hparams):
+    return int(hparams.get('seed', 0)) & tape.MASK64
+
+
+# ---------------------------------------------------------------------------------------
+# triangular random walks (aps:20-158, 210-243)
+# ---------------------------------------------------------------------------------------
+
+def patch_node_views(anchor_patch_ids):
+    """Node view of every patch's induced subgraph: unique ids in first-occurrence order
+    (the reference iterates a networkx subgraph view whose order is CPython-set order)."""
+    P, L = anchor_patch_ids.shape
+    dev = anchor_patch_ids.device
+    ids = anchor_patch_ids
+    rows = torch.arange(P, device=dev).unsqueeze(1).expand(P, L)
+    cols = torch.arange(L, device=dev).unsqueeze(0).expand(P, L)
+    key = (rows * (1 << 32) + ids).reshape(-1)
+    skey, sidx = torch.sort(key, stable=True)
+    first = torch.ones_like(skey, dtype=torch.bool)
+    first[1:] = skey[1:] != skey[:-1]
+    keep = torch.zeros(P * L, dtype=torch.bool, device=dev)
+    keep[sidx[first]] = True
+    keep = keep.view(P, L) & (ids != PAD_VALUE)
+    lens = keep.sum(1)
+    ptr = torch.zeros(P + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(lens, 0, out=ptr[1:])
+    nodes = ids[keep].to(torch.int32)
+    if nodes.numel() == 0:
+        nodes = torch.zeros(1, dtype=torch.int32, device=dev)
+    del cols
+    return ops.Ragged(ptr, nodes.contiguous(), max_len=L)
+
+
+def in_border_sets(graph, views):
+    """per patch: the view nodes with an edge leaving the patch (su.get_border_nodes)."""
+    flags = ops.patch_in_border(graph, views)
+    tot = int(views.ptr[-1].item())
+    f = flags[:tot].bool()
+    rows = torch.repeat_interleave(torch.arange(views.n, device=views.ptr.device), views.lengths)
+    cnt = torch.zeros(views.n, dtype=torch.int64, device=views.ptr.device)
+    cnt.index_add_(0, rows, f.to(torch.int64))
+    ptr = torch.zeros(views.n + 1, dtype=torch.int64, device=views.ptr.device)
+    torch.cumsum(cnt, 0, out=ptr[1:])
+    nodes = views.nodes[:tot][f]
+    if nodes.numel() == 0:
+        nodes = torch.zeros(1, dtype=torch.int32, device=views.ptr.device)
+    return ops.Ragged(ptr, nodes.contiguous())
+
+
+def perform_random_walks(hparams, networkx_graph, anchor_patch_ids, inside, views=None, in_border=None):
+    """aps:118-158 -> (n_patches, n_triangular_walks, random_walk_len) int64, PAD filled."""
+    g = networkx_graph
+    ids = anchor_patch_ids.to(g.device)
+    P = ids.shape[0]
+    W, T = hparams['n_triangular_walks'], hparams['random_walk_len']
+    views = views if views is not None else patch_node_views(ids)
+    if inside:
+        out = ops.triangular_walks(g, 1, P * W, T, hparams['rw_beta'], _seed(hparams),
+                                   tape.stream_id(tape.STREAM_WALK_INT), patches=views, walks_per_patch=W)
+    else:
+        in_border = in_border if in_border is not None else in_border_sets(g, views)
+        out = ops.triangular_walks(g, 2, P * W, T, hparams['rw_beta'], _seed(hparams),
+                                   tape.stream_id(tape.STREAM_WALK_BOR), patches=views, in_border=in_border,
+                                   walks_per_patch=W)
+    return out.view(P, W, T)
+
+
+def sample_structure_anchor_patches(hparams, networkx_graph, device, max_sim_epochs):
+    """aps:210-243 -> (n sampled patches, max patch length) int64 (trailing all-PAD columns
+    trimmed, as padding to the longest walk does in the reference)."""
+    if hparams['structure_patch_type'] != 'triangular_random_walk':
+        raise NotImplementedError("structure_patch_type %r" % hparams['structure_patch_type'])
+    n = max_sim_epochs * hparams['n_anchor_patches_structure'] * hparams['n_layers']
+    out = ops.triangular_walks(networkx_graph, 0, n, hparams['sample_walk_len'], hparams['rw_beta'], _seed(hparams),
+                               tape.stream_id(tape.STREAM_STRUCT_PATCH))
+    longest = int((out != PAD_VALUE).sum(1).max().item()) if n > 0 else 0
+    return out[:, :max(longest, 1)].contiguous()
+
+
+# ---------------------------------------------------------------------------------------
+# sampling (aps:163-208)
+# ---------------------------------------------------------------------------------------
+
+def sample_neighborhood_anchor_patch(hparams, networkx_graph, cc_ids, border_set, sample_inside=True, split='train',
+                                     layer=0):
+    """aps:163-198 -> (S, C, n_anchor_patches_N_in | _N_out) int64."""
+    mat = cc_ids if sample_inside else border_set
+    S, C, L = mat.shape
+    A = hparams['n_anchor_patches_N_in'] if sample_inside else hparams['n_anchor_patches_N_out']
+    kind = tape.STREAM_N_INT if sample_inside else tape.STREAM_N_BOR
+    out = ops.sample_anchors_padded(mat.reshape(S * C, L).contiguous(), A, _seed(hparams),
+                                    tape.stream_id(kind, split, layer))
+    return out.view(S, C, A)
+
+
+def sample_position_anchor_patches(hparams, networkx_graph, subgraph=None, split='train', layer=0, item=0):
+    """aps:200-208 for ONE draw list (python list out, like the reference)."""
+    g = networkx_graph
+    if not subgraph:
+        r = ops.Ragged(torch.tensor([0, g.n_nodes], dtype=torch.int64, device=g.device), g.node_order)
+        return ops.choice_ragged(r, hparams['n_anchor_patches_pos_out'], _seed(hparams),
+                                 tape.stream_id(tape.STREAM_P_EXT, 0, layer))[0].tolist()
+    raise NotImplementedError('use init_anchors_pos_int (batched over subgraphs)')
+
+
+# ---------------------------------------------------------------------------------------
+# initialisation (aps:248-328)
+# ---------------------------------------------------------------------------------------
+
+_SPLITS = {'all': ['train', 'val', 'test'], 'train_val': ['train', 'val'], 'test': ['test']}
+
+
+def init_anchors_neighborhood(split, hparams, networkx_graph, device, train_cc_ids, val_cc_ids, test_cc_ids,
+                              train_N_border, val_N_border, test_N_border):
+    data = {'train': (train_cc_ids, train_N_border), 'val': (val_cc_ids, val_N_border),
+            'test': (test_cc_ids, test_N_border)}
+    anchors_int_neigh, anchors_border_neigh = defaultdict(dict), defaultdict(dict)
+    for name in _SPLITS[split]:
+        cc, bs = data[name]
+        for n in range(hparams['n_layers']):
+            anchors_int_neigh[name][n] = sample_neighborhood_anchor_patch(hparams, networkx_graph, cc, bs, True, name, n)
+            anchors_border_neigh[name][n] = sample_neighborhood_anchor_patch(hparams, networkx_graph, cc, bs, False, name, n)
+    return anchors_int_neigh, anchors_border_neigh
+
+
+def init_anchors_pos_int(split, hparams, networkx_graph, device, train_sub_G, val_sub_G, test_sub_G):
+    """(S, n_anchor_patches_pos_in) per split and layer; ``*_sub_G`` are lists of node lists."""
+    data = {'train': train_sub_G, 'val': val_sub_G, 'test': test_sub_G}
+    anchors = defaultdict(dict)
+    for name in _SPLITS[split]:
+        subs = data[name] if isinstance(data[name], ops.Ragged) else ops.Ragged.from_lists(data[name], networkx_graph.device)
+        for n in range(hparams['n_layers']):
+            anchors[name][n] = ops.choice_ragged(subs, hparams['n_anchor_patches_pos_in'], _seed(hparams),
+                                                 tape.stream_id(tape.STREAM_P_INT, name, n))
+    return anchors
+
+
+def init_anchors_pos_ext(hparams, networkx_graph, device):
+    g = networkx_graph
+    order = ops.Ragged(torch.tensor([0, g.n_nodes], dtype=torch.int64, device=g.device), g.node_order)
+    return {n: ops.choice_ragged(order, hparams['n_anchor_patches_pos_out'], _seed(hparams),
+                                 tape.stream_id(tape.STREAM_P_EXT, 0, n))[0]
+            for n in range(hparams['n_layers'])}
+
+
+def init_anchors_structure(hparams, structure_anchors, int_structure_anchor_rw, bor_structure_anchor_rw):
+    dev = structure_anchors.device
+    P = structure_anchors.shape[0]
+    pool = ops.Ragged(torch.tensor([0, P], dtype=torch.int64, device=dev), torch.arange(P, dtype=torch.int32, device=dev))
+    out = {}
+    for n in range(hparams['n_layers']):
+        idx = ops.choice_ragged(pool, hparams['n_anchor_patches_structure'], _seed(hparams),
+                                tape.stream_id(tape.STREAM_S_PICK, 0, n))[0]
+        out[n] = (structure_anchors[idx, :], [int(i) for i in idx.tolist()], int_structure_anchor_rw[idx, :, :],
+                  bor_structure_anchor_rw[idx, :, :])
+    return out
+
+
+# ---------------------------------------------------------------------------------------
+# retrieval (aps:333-433): the reference-shaped (materialising) path
+# ---------------------------------------------------------------------------------------
+
+def embed_anchor_patch(node_matrix, anchor_patch_ids, device):
+    return node_matrix(anchor_patch_ids.to(device)), (anchor_patch_ids != PAD_VALUE).bool()
+
+
+def aggregate_structure_anchor_patch(hparams, networkx_graph, lstm, node_matrix, anchor_patch_ids, all_patch_walks,
+                                     inside, device):
+    """aps:413-433: walks (A, W, T) -> LSTM over each walk's embeddings -> sum over W -> (A, D)."""
+    n = anchor_patch_ids.shape[0]
+    walk_embeds, _ = embed_anchor_patch(node_matrix, all_patch_walks, device)
+    x = walk_embeds.view(n * hparams['n_triangular_walks'], hparams['random_walk_len'], hparams['node_embed_size'])
+    h = lstm(x).view(n, hparams['n_triangular_walks'], -1)
+    return torch.sum(h, dim=1)
+
+
+def get_anchor_patches(dataset_type, hparams, networkx_graph, node_matrix, subgraph_idx, cc_ids, cc_embed_mask, lstm,
+                       anchors_neigh_int, anchors_neigh_border, anchors_pos_int, anchors_pos_ext, anchors_structure,
+                       layer_num, channel, inside, device=None):
+    """aps:333-399 -> (anchor_patches (B,C,A,Lp), anchor_mask, anchor_embeds (B,C,A,D))."""
+    B, C, _ = cc_ids.shape
+    dev = cc_ids.device
+    sidx = subgraph_idx.view(-1)
+    if channel == 'neighborhood':
+        src = anchors_neigh_int if inside else anchors_neigh_border
+        patches = src[dataset_type][layer_num].to(dev)[sidx]
+        embeds, mask = embed_anchor_patch(node_matrix, patches, dev)
+        return patches.unsqueeze(-1), mask.unsqueeze(-1), embeds
+    if channel == 'position':
+        if inside:
+            patches = anchors_pos_int[dataset_type][layer_num].to(dev)[sidx].unsqueeze(1).repeat(1, C, 1)
+        else:
+            patches = anchors_pos_ext[layer_num].to(dev).view(1, 1, -1).repeat(B, C, 1)
+        patches[~cc_embed_mask] = PAD_VALUE
+        embeds, mask = embed_anchor_patch(node_matrix, patches, dev)
+        return patches.unsqueeze(-1), mask.unsqueeze(-1), embeds
+    if channel == 'structure':
+        patches, indices, int_rw, bor_rw = anchors_structure[layer_num]
+        emb = aggregate_structure_anchor_patch(hparams, networkx_graph, lstm, node_matrix, patches,
+                                               (int_rw if inside else bor_rw).to(dev), inside, dev)
+        patches = patches.to(dev).unsqueeze(0).unsqueeze(0).repeat(B, C, 1, 1)
+        patches[~cc_embed_mask] = PAD_VALUE
+        mask = (patches != PAD_VALUE).bool()
+        embeds = emb.unsqueeze(0).unsqueeze(0).repeat(B, C, 1, 1) * cc_embed_mask.view(B, C, 1, 1).to(emb.dtype)
+        return patches, mask, embeds
+    raise Exception('An invalid channel has been entered.')

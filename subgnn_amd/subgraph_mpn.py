@@ -1,0 +1,67 @@
+"""SG_MPN: one subgraph-level message-passing layer (mirrors reference SubGNN/subgraph_mpn.py).
+
+Same constructor, same parameter names (``linear``, ``linear_position``: state-dict
+compatible), same ``forward`` signature and return values.  The body -- edge construction,
+similarity lookup, message = sim * x_anchor, add-aggregation per component, read-out -- is one
+HIP kernel (ops.mpn -> sgnn_mpn_fwd / sgnn_mpn_bwd); the Linear(2D -> D) + ReLU update is a
+plain GEMM left to rocBLAS through torch.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+
+
+class SG_MPN(nn.Module):
+    def __init__(self, hparams):
+        super().__init__()
+        self.hparams = hparams
+        D = hparams['node_embed_size']
+        self.linear = nn.Linear(D * 2, D)
+        self.linear_position = nn.Linear(D, 1)
+
+    # -- shared tail: update() and the read-out non-linearity (mpn:122-131, 233-241) -------
+    def _finish(self, cc_embeds, agg, z):
+        B, C, D = cc_embeds.shape
+        if self.hparams['use_mpn_projection']:
+            # applied to every component row, padded ones included (mpn:168,239)
+            out = F.relu(self.linear(torch.cat([cc_embeds.reshape(B * C, D), agg], dim=1)))
+        else:
+            out = agg
+        z = z.view(B, C, -1)
+        if self.hparams.get('norm_pos_struc_embed', False):
+            pos = F.normalize(z, p=2, dim=-1)
+        else:
+            pos = F.relu(z)
+        return out.view(B, C, -1), pos
+
+    def forward(self, networkx_graph, sims, cc_ids, cc_embeds, cc_embed_mask, anchor_patches, anchor_embeds,
+                anchor_mask, anchors_sim_index):
+        """Reference signature (mpn:133-174).  ``networkx_graph`` and ``cc_ids`` are unused by
+        the arithmetic, as in the reference.  anchor_patches (B,C,A,Lp) ids, anchor_embeds
+        (B,C,A,D), anchor_mask (B,C,A,Lp) bool, anchors_sim_index: list (structure) or None."""
+        B, C, D = cc_embeds.shape
+        A = anchor_patches.shape[2]
+        R = B * C
+        ids = anchor_patches[..., 0].reshape(R, A).contiguous()
+        edge = anchor_mask[..., 0].reshape(R, A).to(torch.uint8).contiguous()
+        sim_col = None
+        if anchors_sim_index is not None:
+            sim_col = torch.as_tensor([int(i) for i in anchors_sim_index], dtype=torch.int64, device=cc_embeds.device)
+        agg, z = ops.mpn(anchor_embeds.reshape(R, A, D), self.linear_position.weight, self.linear_position.bias, sims,
+                         src=ops.SRC_DENSE, R=R, A=A, ids=ids, edge_mask=edge, sim_col=sim_col)
+        return self._finish(cc_embeds, agg, z)
+
+    def forward_fused(self, sims, cc_embeds, cc_embed_mask, *, src, x, ids=None, id_div=1, sim_col=None,
+                      sims_per_edge=False):
+        """Fast path used by SubGNN.forward: the anchor rows are gathered inside the kernel
+        (src GATHER: x = embedding table, ids (R/id_div, A)) or shared by all rows (src SHARED:
+        x (A,D)), so the (B,C,A,D) tensor of get_anchor_patches is never materialised."""
+        B, C, D = cc_embeds.shape
+        R = B * C
+        A = ids.shape[-1] if ids is not None else x.shape[0]
+        row_mask = cc_embed_mask.reshape(R).to(torch.uint8).contiguous()
+        agg, z = ops.mpn(x, self.linear_position.weight, self.linear_position.bias, sims, src=src, R=R, A=A, ids=ids,
+                         id_div=id_div, row_mask=row_mask, sim_col=sim_col, sims_per_edge=sims_per_edge)
+        return self._finish(cc_embeds, agg, z)

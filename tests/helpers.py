@@ -59,3 +59,33 @@ def g11_case(g, variant):
 
 
 G11_VARIANTS = ('sum', 'max_trainable', 'bn', 'sumlstm_norm')
+
+
+def write_dataset_from_golden(g, root, name='ds'):
+    """Recreate the on-disk dataset (SURVEY.md 8f-1 formats) a golden fixture was made from."""
+    import json
+    import os
+    d = os.path.join(str(root), name)
+    os.makedirs(os.path.join(d, 'similarities'), exist_ok=True)
+    with open(os.path.join(d, 'edge_list.txt'), 'w') as f:
+        for u, v in g['edge_list']:
+            f.write('%d %d\n' % (u, v))
+    with open(os.path.join(d, 'subgraphs.pth'), 'w') as f:
+        for sp in ('train', 'val', 'test'):
+            for row, lab in zip(g['subgraphs_' + sp], g['labels_' + sp]):
+                nodes = [int(v) - 1 for v in row if v != 0]
+                f.write('-'.join(str(n) for n in nodes) + '\t' + str(int(lab)) + '\t' + sp + '\t\n')
+    torch.save(T(g['embeddings'][1:]).clone(), os.path.join(d, 'gin_embeddings.pth'))
+    np.save(os.path.join(d, 'shortest_path_matrix.npy'), g['apsp'])
+    rp, col = g['g1_rowptr'], g['g1_col']
+    deg, ego = {}, {}
+    for v in range(1, len(rp) - 1):
+        nb = col[rp[v]:rp[v + 1]]
+        deg[str(v - 1)] = int(len(nb) + (nb == v).sum())
+        ego[str(v - 1)] = [int(w) - 1 for w in nb]
+    with open(os.path.join(d, 'degree_sequence.txt'), 'w') as f:
+        json.dump(deg, f)
+    if bool(g['has_ego']):
+        with open(os.path.join(d, 'ego_graphs.txt'), 'w') as f:
+            json.dump(ego, f)
+    return name

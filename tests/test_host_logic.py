@@ -1,0 +1,94 @@
+"""CPU tests of the host-side logic of the product package (no kernels are called)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import graph as OG, integer_half as IH
+from helpers import write_dataset_from_golden
+
+
+def test_networkx_order_csr_matches_reference_graph(golden):
+    from subgnn_amd.graph import networkx_order_csr
+    rp, col, order = networkx_order_csr(golden['edge_list'])
+    assert np.array_equal(rp, golden['g1_rowptr'])
+    assert np.array_equal(col, golden['g1_col'])
+    assert np.array_equal(order, golden['g1_node_order'])
+
+
+def test_components_from_labels(golden):
+    """labels (smallest position per component) -> padded (S,C,L) tensor, checked as sets."""
+    from subgnn_amd.subgraph_utils import components_from_labels
+    G = OG.from_edge_pairs([tuple(e) for e in golden['edge_list']])
+    subs = golden.ragged('subgraphs_train', 0)
+    subs[0] = subs[0] + subs[0][:2]                         # duplicates must collapse
+    ptr = np.zeros(len(subs) + 1, dtype=np.int64)
+    flat, labels = [], []
+    for i, s in enumerate(subs):
+        comps = IH.connected_components(G, s)
+        where = {}
+        for c in comps:
+            first = min(s.index(v) for v in c)
+            for v in c:
+                where[v] = first
+        flat += s
+        labels += [where[v] for v in s]
+        ptr[i + 1] = ptr[i] + len(s)
+    out = components_from_labels(torch.from_numpy(ptr), torch.tensor(flat, dtype=torch.int32),
+                                 torch.tensor(labels, dtype=torch.int32)).numpy()
+    for i, s in enumerate(subs):
+        ref = [c for c in IH.connected_components(G, s)]
+        got = [[int(v) for v in row if v != 0] for row in out[i] if row[0] != 0]
+        assert got == ref                                   # canonical order == the oracle's canonical order
+
+
+def test_read_subgraphs_and_state_dict_keys(tmp_path, tiny):
+    """The dataset reader and the module's parameter names (checkpoint compatibility)."""
+    from subgnn_amd import config
+    from subgnn_amd.subgraph_utils import read_subgraphs
+    name = write_dataset_from_golden(tiny, tmp_path)
+    tr, trl, va, val, te, tel = read_subgraphs(os.path.join(str(tmp_path), name, 'subgraphs.pth'))
+    assert [[v + 1 for v in s] for s in tr] == tiny.ragged('subgraphs_train', 0)
+    assert np.array_equal(trl.numpy(), tiny['labels_train'])
+    assert len(va) == tiny['subgraphs_val'].shape[0] and len(te) == tiny['subgraphs_test'].shape[0]
+    from subgnn_amd.SubGNN import SubGNN, dataset_paths
+    config.PROJECT_ROOT = tmp_path
+    hp = dict(tiny.hp)
+    if torch.cuda.is_available():
+        pytest.skip('construction-only check is for the CPU box')
+    m = SubGNN(hp, **dataset_paths(name))
+    ref_keys = {k[3:] for k in tiny.files if k.startswith('sd/')}
+    assert set(m.state_dict().keys()) == ref_keys
+    for k, v in m.state_dict().items():
+        assert tuple(v.shape) == tiny['sd/' + k].shape, k
+    assert m.hid_dim == tiny['sd/lin.weight'].shape[1]
+
+
+def test_trim_zero_columns(golden):
+    from subgnn_amd.subgraph_utils import trim_zero_columns
+    idx = golden['g12_idx']
+    x = torch.from_numpy(golden['g2_cc_ids_train'][idx])
+    assert np.array_equal(trim_zero_columns(x).numpy(), golden['g12_cc_ids'])
+
+
+def test_tape_constants_match_oracle():
+    from subgnn_amd import tape
+    from oracle import tape as OT
+    for k in dir(OT):
+        if k.startswith('STREAM_'):
+            assert getattr(tape, k) == getattr(OT, k)
+    assert tape.stream_id(5, 'val', 3) == OT.stream_id(5, 'val', 3)
+    src = open(os.path.join(os.path.dirname(tape.__file__), 'csrc', 'common.h')).read()
+    for const in (OT.K_STREAM, OT.K_ITEM, OT.K_DRAW, OT.M1, OT.M2):
+        assert ('0x%016X' % const) in src.upper().replace('ULL', '').replace('0X', '0x') or ('%X' % const) in src.upper()
+
+
+def test_product_never_imports_oracle():
+    root = os.path.join(os.path.dirname(__file__), '..', 'subgnn_amd')
+    for dp, _, fs in os.walk(root):
+        for f in fs:
+            if f.endswith(('.py', '.hip', '.h')):
+                txt = open(os.path.join(dp, f)).read()
+                assert 'import oracle' not in txt and 'from oracle' not in txt, f
