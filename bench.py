@@ -1,0 +1,237 @@
+#!/usr/bin/env python3
+"""Benchmark of the SubGNN hot path on MI355X.
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[3], the one the 1/2/4/8-GPU metric is quoted on): synthetic
+DENSITY-style base graph, Barabasi-Albert n = 1M, m = 10 (10M undirected edges), BFS subgraphs
+of 20 nodes, 50k subgraphs PER GPU (weak scaling: the shard is the unit), embeddings (N, 64)
+fp32 random, hyper-parameters best_model_hyperparameters/density/all_density_hyperparams.json
+(all three channels, 1 layer, N 10/43, P 57/183, S 42) with max_sim_epochs = 5 and a 1-hop
+neighbourhood border (what the reference effectively uses when ego_graphs.txt is present).
+
+One step = one full pass of the hot path over the rank's shard, everything on the GPU:
+  anchor-patch sampling + similarities (connected components, k-hop border BFS, N/P/S anchor
+  draws, structure patches + triangular walks, degree sequences, DTW, multi-source BFS
+  position similarities)  ->  three-channel forward  ->  loss  ->  backward  ->
+  [N>1: RCCL all-gather of the per-component channel embeddings, all-reduce of the gradients]
+  ->  Adam step.
+value = subgraphs processed by all ranks / max-over-ranks step time.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline      achieved algorithmic HBM bytes/s of the structure-channel CSR gather
+                (sgnn_degree_sequence, the kernel BASELINE.json's target names), measured live
+                with HIP events on the launching stream; peak 8 TB/s.
+  cpu_baseline  the oracle (plain C + numpy + torch-CPU restatement of the same algorithm)
+                timed on this box's host cores on a bounded sample (rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+HBM_PEAK_GBS = 8000.0
+
+ALL_DENSITY_HP = {          # reference best_model_hyperparameters/density/all_density_hyperparams.json
+    "use_neighborhood": True, "use_structure": True, "use_position": True, "seed": 0,
+    "node_embed_size": 64, "structure_patch_type": "triangular_random_walk", "lstm_aggregator": "last",
+    "n_processes": 4, "resample_anchor_patches": False, "freeze_node_embeds": False,
+    "use_mpn_projection": True, "compute_similarities": True, "sample_walk_len": 50,
+    "n_triangular_walks": 5, "random_walk_len": 10, "rw_beta": 0.65, "batch_size": 64,
+    "learning_rate": 0.0002951850045886519, "grad_clip": 0.1929946246623414, "n_layers": 1,
+    "neigh_sample_border_size": 1, "n_anchor_patches_pos_out": 183, "n_anchor_patches_pos_in": 57,
+    "n_anchor_patches_N_in": 10, "n_anchor_patches_N_out": 43, "n_anchor_patches_structure": 42,
+    "linear_hidden_dim_1": 64, "linear_hidden_dim_2": 64, "lin_dropout": 0.2522849803237359,
+    "lstm_dropout": 0.0, "lstm_n_layers": 1, "cc_aggregator": "max", "trainable_cc": False,
+    "max_sim_epochs": 5, "embedding_type": "gin",
+}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--nodes', type=int, default=1_000_000)
+    ap.add_argument('--m', type=int, default=10)
+    ap.add_argument('--subgraphs', type=int, default=50_000, help='subgraphs per GPU')
+    ap.add_argument('--subgraph-nodes', type=int, default=20)
+    ap.add_argument('--embed', type=int, default=64)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-sample', type=int, default=192)
+    return ap.parse_args()
+
+
+def build_inputs(args, rank):
+    from subgnn_amd import synthetic
+    t0 = time.time()
+    edges = synthetic.barabasi_albert_edges(args.nodes, args.m, seed=42)
+    rowptr, col = synthetic.sorted_csr(edges, args.nodes)
+    subs = synthetic.bfs_subgraphs(rowptr, col, args.subgraphs, args.subgraph_nodes, seed=1000 + rank)
+    return rowptr, col, subs, time.time() - t0
+
+
+def degseq_algorithmic_bytes(rowptr, sets_lists):
+    """per set  sum_v (16 + 4 deg(v)) + 4|S| (ids in) + 4|S| (degrees out);
+    internal and external computed in one pass (the external output adds 4|S|)."""
+    deg = np.diff(rowptr)
+    total = 0
+    for s in sets_lists:
+        a = np.asarray(s, dtype=np.int64)
+        total += int((16 + 4 * deg[a]).sum()) + 12 * len(a)
+    return total
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit('launch with torch.distributed.run --nproc-per-node %d' % args.gpus)
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group('nccl', device_id=dev)
+
+    from subgnn_amd import ops, hotpath, build
+    from subgnn_amd.SubGNN import SubGNN
+    if rank == 0 and build.needs_build():
+        build.build(verbose=False)
+    if dist:
+        dist.barrier()
+
+    rowptr, col, subs, t_gen = build_inputs(args, rank)
+    n = args.nodes
+    g = ops.DeviceGraph(rowptr, col, np.arange(1, n + 1, dtype=np.int32), dev)
+    torch.manual_seed(0)
+    emb = torch.randn(n, args.embed, device=dev)
+    hp = dict(ALL_DENSITY_HP)
+    hp['node_embed_size'] = args.embed
+    labels = torch.randint(0, 3, (len(subs),), generator=torch.Generator().manual_seed(rank))
+    labels[:3] = torch.tensor([0, 1, 2])
+    model = SubGNN.from_memory(hp, g, {'train': subs, 'val': [], 'test': []},
+                               {'train': labels, 'val': labels[:0], 'test': labels[:0]}, emb)
+    model.train()
+    opt = model.configure_optimizers()
+    params = [p for p in model.parameters() if p.requires_grad]
+    S = len(subs)
+
+    stage_ms = {}
+    degseq = {'ms': 0.0, 'launches': 0}
+
+    def step(timed):
+        timer = hotpath.StageTimer(timed)
+        hotpath.prepare_sparse(model, 'train', timer)
+        batch = hotpath.full_split_batch(model, 'train')
+        out = model.training_step(batch, 0)
+        timer.mark('forward')
+        model.backward(None, out['loss'], None, 0)
+        timer.mark('backward')
+        if dist:
+            # all-gather of the per-component channel embeddings (north_star): every rank ends up
+            # with the (world * S * C, hid_dim) matrix of the global batch
+            cc = model._last_cc_embeds
+            gathered = torch.empty((world * cc.shape[0], cc.shape[1]), dtype=cc.dtype, device=dev)
+            dist.all_gather_into_tensor(gathered, cc)
+            flat = torch.cat([p.grad.reshape(-1) for p in params if p.grad is not None])
+            dist.all_reduce(flat)
+            flat /= world
+            off = 0
+            for p in params:
+                if p.grad is not None:
+                    k = p.grad.numel()
+                    p.grad.copy_(flat[off:off + k].view_as(p.grad))
+                    off += k
+            timer.mark('collectives')
+        torch.nn.utils.clip_grad_norm_(params, hp['grad_clip'])
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+        timer.mark('optimizer')
+        return timer, float(out['loss'].detach())
+
+    for _ in range(args.warmup):
+        step(False)
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    timers = []
+    for _ in range(args.steps):
+        tm, loss = step(True)
+        timers.append(tm)
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    for tm in timers:
+        for k, v in tm.summary().items():
+            stage_ms[k] = stage_ms.get(k, 0.0) + v / args.steps
+
+    # ---- roofline of the structure-channel CSR gather, measured live ------------------------
+    cc_ids = model.train_cc_ids
+    Sx, C, Lc = cc_ids.shape
+    cc_sets = ops.Ragged.from_padded(cc_ids.reshape(Sx * C, Lc))
+    alg_bytes = degseq_algorithmic_bytes(rowptr, cc_sets.to_lists())
+    reps = 20
+    ops.degree_sequence(g, cc_sets)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        ops.degree_sequence(g, cc_sets)
+    e1.record()
+    torch.cuda.synchronize()
+    ds_ms = e0.elapsed_time(e1) / reps
+    achieved = alg_bytes / (ds_ms * 1e-3) / 1e9
+
+    result = {
+        'metric': 'subgraphs/sec fwd+bwd (all 3 channels on) + achieved HBM GB/s',
+        'value': world * S * args.steps / elapsed, 'unit': 'subgraphs/s', 'n_gpus': world, 'steps': args.steps,
+        'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True,
+        'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': 'synthetic DENSITY-style BA base graph n=%d m=%d (%d undirected edges), %d BFS '
+                               'subgraphs x %d nodes per GPU, all_density hparams (N 10/43, P 57/183, S 42, 1 layer), '
+                               'D=%d, full pass = sampling + similarities + fwd + bwd + Adam' %
+                               (n, args.m, int(rowptr[-1]) // 2, S, args.subgraph_nodes, args.embed),
+                   'subgraphs_per_gpu': S, 'parallelism': 'dp%d (subgraph shards, RCCL all-gather + grad all-reduce)' % world},
+        'roofline': {'kernel': 'degseq_wave_kernel (sgnn_degree_sequence: structure-channel CSR gather)',
+                     'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                     'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
+                     'algorithmic_bytes_per_launch': alg_bytes, 'ms_per_launch': ds_ms, 'sets_per_launch': cc_sets.n,
+                     'note': 'CSR (88 MB) fits the 256 MiB Infinity Cache: bytes are served on-die, not all from HBM'},
+        'stages_ms': {k: round(v, 3) for k, v in stage_ms.items()},
+        'loss': loss, 'setup_s': round(t_gen, 1),
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:
+            from oracle import cpu_baseline
+            result['cpu_baseline'] = cpu_baseline.run(rowptr, col, subs, hp, emb.cpu(), labels, args.cpu_sample, S)
+        except Exception as ex:                      # the baseline must never hide the GPU number
+            result['cpu_baseline'] = {'error': repr(ex)}
+    if rank == 0:
+        print(json.dumps(result))
+    if dist:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

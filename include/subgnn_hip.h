@@ -96,10 +96,12 @@ int sgnn_khop_border(const int64_t* rowptr, const int32_t* col, int64_t nnz, int
  * ------------------------------------------------------------------------------------- */
 int sgnn_sample_anchors_padded(const int64_t* ids, int64_t n_rows, int64_t L, int64_t n_slots,
                                uint64_t seed, uint64_t stream_id, int64_t* out, void* stream);
-/* same law on ragged sets; row_has_pad[r] says whether the padded row would hold a PAD */
+/* same law on ragged sets; row_has_pad[r] says whether the padded row would hold a PAD.
+ * out_pos (nullable, (n_sets, n_slots)): index into set_nodes of the winner, -1 for PAD --
+ * lets the caller look up per-entry payloads (e.g. the hop level of a border node). */
 int sgnn_sample_anchors_ragged(const int64_t* set_ptr, const int32_t* set_nodes, int64_t n_sets,
                                const uint8_t* row_has_pad, int64_t n_slots,
-                               uint64_t seed, uint64_t stream_id, int64_t* out, void* stream);
+                               uint64_t seed, uint64_t stream_id, int64_t* out, int64_t* out_pos, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * a5/a6  Uniform draws with replacement from a list (position anchors, structure picks).

@@ -71,8 +71,9 @@ class _DeviceLoader:
 
 class SubGNN(nn.Module):
     def __init__(self, hparams, graph_path, subgraph_path, embedding_path, similarities_path, shortest_paths_path,
-                 degree_dict_path, ego_graph_path):
+                 degree_dict_path, ego_graph_path, _memory=None):
         super().__init__()
+        self._memory = _memory
         self.device = torch.device('cuda' if torch.cuda.is_available() else 'cpu')
         self.hparams = hparams
         self.graph_path, self.subgraph_path, self.embedding_path = graph_path, subgraph_path, embedding_path
@@ -119,6 +120,8 @@ class SubGNN(nn.Module):
     def read_data(self):
         """S.py:519-570: base graph -> CSR in HBM, subgraphs + labels, embedding table with the
         zero PAD row."""
+        if self._memory is not None:
+            return self._read_memory(self._memory)
         root = Path(config.PROJECT_ROOT)
         self.networkx_graph = load_graph(root / self.graph_path, self.device, root / self.degree_dict_path)
         (self.train_sub_G, self.train_sub_G_label, self.val_sub_G, self.val_sub_G_label, self.test_sub_G,
@@ -146,6 +149,27 @@ class SubGNN(nn.Module):
         table = torch.cat((torch.zeros(1, pre.shape[1]), pre.float()), 0)
         self.node_embeddings = nn.Embedding.from_pretrained(table, freeze=self.hparams['freeze_node_embeds'],
                                                             padding_idx=config.PAD_VALUE)
+
+    def _read_memory(self, mem):
+        """In-memory twin of read_data for synthetic inputs: ``mem`` = dict(graph=DeviceGraph,
+        sub_G={'train': [...], 'val': [...], 'test': [...]} (1-based ids), labels={split: LongTensor},
+        embeddings=(N, D) float tensor without the PAD row)."""
+        self.networkx_graph = mem['graph']
+        for sp in ('train', 'val', 'test'):
+            setattr(self, sp + '_sub_G', mem['sub_G'].get(sp, []))
+            setattr(self, sp + '_sub_G_label', mem['labels'].get(sp, torch.zeros(0, dtype=torch.int64)))
+        self.multilabel, self.multilabel_binarizer = False, None
+        self.num_classes = int(max(int(l.max()) for l in mem['labels'].values() if l.numel() > 0)) + 1
+        pre = mem['embeddings']
+        self.hparams['node_embed_size'] = pre.shape[1]
+        table = torch.cat((torch.zeros(1, pre.shape[1], device=pre.device), pre.float()), 0)
+        self.node_embeddings = nn.Embedding.from_pretrained(table, freeze=self.hparams['freeze_node_embeds'],
+                                                            padding_idx=config.PAD_VALUE)
+
+    @classmethod
+    def from_memory(cls, hparams, graph, sub_G, labels, embeddings):
+        return cls(hparams, None, None, None, 'similarities', None, None, None,
+                   _memory=dict(graph=graph, sub_G=sub_G, labels=labels, embeddings=embeddings))
 
     # ------------------------------------------------------------------ components -------
     def initialize_cc_ids(self, subgraph_ids):
@@ -352,7 +376,12 @@ class SubGNN(nn.Module):
             lab = torch.LongTensor(self.multilabel_binarizer.transform([labels[int(i)] for i in idx]))
         else:
             lab = labels.view(-1)[idx]
-        pick = lambda t: t.index_select(0, didx) if t is not None else None
+        def pick(t):
+            if t is None:
+                return None
+            if isinstance(t, dict):
+                return {k: v.index_select(0, didx) for k, v in t.items()}
+            return t.index_select(0, didx)
         return {'subgraph_ids': sub_ids.to(self.device),
                 'cc_ids': subgraph_utils.trim_zero_columns(pick(cc)),
                 'N_border': subgraph_utils.trim_zero_columns(pick(nb)) if nb is not None else None,
@@ -405,17 +434,26 @@ class SubGNN(nn.Module):
         """Same layer without the (B,C,A,D) tensor: anchors are gathered inside the kernel."""
         B, C, _ = cc_embeds.shape
         E = self.node_embeddings.weight
+        # NP_sim is either the reference's dense (B,C,N) slab (column = anchor id - 1) or, for
+        # graphs where that slab cannot exist, a dict of already-gathered (B,C,A) edge weights
+        # keyed (channel tag, side, layer) -- see hotpath.py
+        per_edge = isinstance(sims, dict)
+        if per_edge:
+            sims = sims[(channel[0].upper(), 'in' if inside else 'out', layer_num)]
         if channel == 'neighborhood':
             src = self.anchors_neigh_int if inside else self.anchors_neigh_border
             ids = src[dataset_type][layer_num].index_select(0, sidx).reshape(B * C, -1).contiguous()
-            return mpn_fn.forward_fused(sims, cc_embeds, cc_embed_mask, src=ops.SRC_GATHER, x=E, ids=ids)
+            return mpn_fn.forward_fused(sims, cc_embeds, cc_embed_mask, src=ops.SRC_GATHER, x=E, ids=ids,
+                                        sims_per_edge=per_edge)
         if channel == 'position':
             if inside:
                 ids = self.anchors_pos_int[dataset_type][layer_num].index_select(0, sidx).contiguous()
-                return mpn_fn.forward_fused(sims, cc_embeds, cc_embed_mask, src=ops.SRC_GATHER, x=E, ids=ids, id_div=C)
+                return mpn_fn.forward_fused(sims, cc_embeds, cc_embed_mask, src=ops.SRC_GATHER, x=E, ids=ids, id_div=C,
+                                            sims_per_edge=per_edge)
             ids = self.anchors_pos_ext[layer_num]
             X = F.embedding(ids, E, padding_idx=config.PAD_VALUE)
-            return mpn_fn.forward_fused(sims, cc_embeds, cc_embed_mask, src=ops.SRC_SHARED, x=X, ids=ids)
+            return mpn_fn.forward_fused(sims, cc_embeds, cc_embed_mask, src=ops.SRC_SHARED, x=X, ids=ids,
+                                        sims_per_edge=per_edge)
         patches, indices, int_rw, bor_rw = self.anchors_structure[layer_num]
         X = aps.aggregate_structure_anchor_patch(self.hparams, self.networkx_graph, self.lstm, self.node_embeddings,
                                                  patches, int_rw if inside else bor_rw, inside, self.device)
@@ -464,6 +502,7 @@ class SubGNN(nn.Module):
                 pick = 0 if tag == 'N' else 1                      # N adds CC embeddings, P/S their read-outs
                 outputs.extend([res['I'][pick], res['B'][pick]])
         all_cc_embeds = torch.cat([init_cc_embeds] + outputs, dim=-1)
+        self._last_cc_embeds = all_cc_embeds.detach().reshape(B * C, -1)     # what a DP all-gather ships
         subgraph_embedding = subgraph_utils.masked_sum(all_cc_embeds, cc_embed_mask.unsqueeze(-1), dim=1)
         h = self.lin_dropout(F.relu(self.lin(subgraph_embedding)))
         h = self.lin_dropout2(F.relu(self.lin2(h)))

@@ -42,7 +42,8 @@ __global__ __launch_bounds__(64) void sample_anchors_padded_kernel(
 
 __global__ __launch_bounds__(64) void sample_anchors_ragged_kernel(
     const int64_t* __restrict__ set_ptr, const int32_t* __restrict__ set_nodes, int64_t n_sets,
-    const uint8_t* __restrict__ row_has_pad, int64_t n_slots, uint64_t h0, int64_t* __restrict__ out)
+    const uint8_t* __restrict__ row_has_pad, int64_t n_slots, uint64_t h0, int64_t* __restrict__ out,
+    int64_t* __restrict__ out_pos)
 {
     const int lane = threadIdx.x;
     for (int64_t r = blockIdx.x; r < n_sets; r += gridDim.x) {
@@ -60,8 +61,11 @@ __global__ __launch_bounds__(64) void sample_anchors_ragged_kernel(
             }
             argmax_reduce(best, bcol, bid);
             // the PAD columns of the padded row sit after the real ones with key 0
-            if (n == 0 || (has_pad && best < 0)) bid = 0;
-            if (lane == 0) out[r * n_slots + i] = (int64_t)bid;
+            if (n == 0 || (has_pad && best < 0)) { bid = 0; bcol = -1; }
+            if (lane == 0) {
+                out[r * n_slots + i] = (int64_t)bid;
+                if (out_pos) out_pos[r * n_slots + i] = (bid == 0) ? -1 : beg + bcol;   // index into set_nodes
+            }
         }
     }
 }
@@ -80,13 +84,14 @@ extern "C" int sgnn_sample_anchors_padded(const int64_t* ids, int64_t n_rows, in
 
 extern "C" int sgnn_sample_anchors_ragged(const int64_t* set_ptr, const int32_t* set_nodes, int64_t n_sets,
                                           const uint8_t* row_has_pad, int64_t n_slots,
-                                          uint64_t seed, uint64_t stream_id, int64_t* out, void* stream)
+                                          uint64_t seed, uint64_t stream_id, int64_t* out, int64_t* out_pos,
+                                          void* stream)
 {
     if (!set_ptr || !set_nodes || !out || n_sets < 0 || n_slots < 0) return SGNN_ERR_BAD_ARG;
     if (n_sets == 0 || n_slots == 0) return SGNN_OK;
     const int grid = (int)(n_sets < 256 * 32 ? n_sets : 256 * 32);
     hipLaunchKernelGGL(sample_anchors_ragged_kernel, dim3(grid), dim3(64), 0, (hipStream_t)stream, set_ptr,
-                       set_nodes, n_sets, row_has_pad, n_slots, sgnn_tape_h0(seed, stream_id), out);
+                       set_nodes, n_sets, row_has_pad, n_slots, sgnn_tape_h0(seed, stream_id), out, out_pos);
     SGNN_CHECK_LAUNCH();
     return SGNN_OK;
 }

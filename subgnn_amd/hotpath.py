@@ -1,0 +1,157 @@
+"""Sparse precompute for base graphs where the reference's dense structures cannot exist.
+
+The reference's prepare_data needs a dense float64 APSP matrix (N x N,
+prepare_dataset/precompute_graph_metrics.py:23,69), (S, C, N) similarity slabs
+(SubGNN/SubGNN.py:763) and a dense N x N adjacency per patch (SubGNN/subgraph_utils.py:136):
+impossible at N = 1M.  ``prepare_sparse`` computes the same quantities only where the model
+reads them, all on the GPU:
+
+  * N-internal anchors lie inside their component        -> similarity 0
+  * N-border anchors lie in the k-hop border             -> similarity = hop level, a by-product
+                                                            of the border BFS (sgnn_khop_border)
+  * P-border anchors are a handful of shared nodes       -> one bit-parallel multi-source BFS
+                                                            (sgnn_bfs_hops) + a min over members
+  * P-internal anchors are nodes of the same subgraph    -> 0 for single-component subgraphs,
+                                                            multi-source BFS otherwise
+  * structure similarities                               -> unchanged (degree sequences + DTW)
+
+The result plugs into SubGNN.forward through the per-edge similarity dict (see
+SubGNN._run_mpn_layer_fused).  Values are identical to what the dense path would gather from
+its slabs (tests/test_gpu_hotpath.py).
+"""
+import torch
+
+from . import ops, tape, gamma, subgraph_utils
+from . import anchor_patch_samplers as aps
+
+MAX_PINT_SOURCES = 8192
+
+
+class StageTimer:
+    """HIP-event stage timing on the current stream (no host synchronisation until read)."""
+
+    def __init__(self, enabled=True):
+        self.enabled, self.marks = enabled, []
+
+    def mark(self, name):
+        if self.enabled:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            self.marks.append((name, e))
+
+    def summary(self):
+        out = {}
+        for (n0, e0), (n1, e1) in zip(self.marks[:-1], self.marks[1:]):
+            out[n1] = out.get(n1, 0.0) + e0.elapsed_time(e1)
+        return out
+
+
+def prepare_sparse(model, split='train', timer=None):
+    """HIP-only prepare_data for one split (SubGNN.py:1024-1063 semantics, sparse similarities)."""
+    hp, g, dev = model.hparams, model.networkx_graph, model.device
+    seed = int(hp.get('seed', 0)) & tape.MASK64
+    t = timer or StageTimer(False)
+    L = hp['n_layers']
+    t.mark('start')
+    # ---- components --------------------------------------------------------------------
+    subs = ops.Ragged.from_lists(getattr(model, split + '_sub_G'), dev) if not hasattr(model, '_subs_' + split) \
+        else getattr(model, '_subs_' + split)
+    setattr(model, '_subs_' + split, subs)
+    labels = ops.cc_labels(g, subs)
+    cc_ids = subgraph_utils.components_from_labels(subs.ptr, subs.nodes, labels)
+    setattr(model, split + '_cc_ids', cc_ids)
+    S, C, Lc = cc_ids.shape
+    cc_sets = ops.Ragged.from_padded(cc_ids.reshape(S * C, Lc))
+    real = (cc_ids[:, :, 0] != 0)
+    t.mark('components')
+    model.init_all_embeddings(split=split, trainable=hp['trainable_cc'])
+    t.mark('cc_embed')
+    sims = {}
+    # ---- neighbourhood channel -----------------------------------------------------------
+    if hp['use_neighborhood']:
+        k = hp['neigh_sample_border_size']
+        border, hops = ops.khop_border(g, cc_sets, k, want_hops=True)
+        t.mark('border_bfs')
+        has_pad_b = (border.lengths < border.max_len).to(torch.uint8)
+        has_pad_c = (cc_sets.lengths < Lc).to(torch.uint8)
+        ni, nb = {}, {}
+        for l in range(L):
+            ni[l] = ops.sample_anchors_ragged(cc_sets, hp['n_anchor_patches_N_in'], seed,
+                                              tape.stream_id(tape.STREAM_N_INT, split, l), has_pad_c).view(S, C, -1)
+            a, pos = ops.sample_anchors_ragged(border, hp['n_anchor_patches_N_out'], seed,
+                                               tape.stream_id(tape.STREAM_N_BOR, split, l), has_pad_b, want_pos=True)
+            nb[l] = a.view(S, C, -1)
+            sims[('N', 'in', l)] = torch.zeros(ni[l].shape, dtype=torch.float32, device=dev)
+            w = hops[pos.clamp(min=0)].to(torch.float32) * (pos >= 0)
+            sims[('N', 'out', l)] = w.view(S, C, -1).contiguous()
+        if getattr(model, 'anchors_neigh_int', None) is None:
+            model.anchors_neigh_int, model.anchors_neigh_border = {}, {}
+        model.anchors_neigh_int[split], model.anchors_neigh_border[split] = ni, nb
+        t.mark('N_anchors')
+    # ---- position channel ----------------------------------------------------------------
+    if hp['use_position']:
+        if getattr(model, 'anchors_pos_ext', None) is None or split != 'test':
+            model.anchors_pos_ext = aps.init_anchors_pos_ext(hp, g, dev)
+        pint = {l: ops.choice_ragged(subs, hp['n_anchor_patches_pos_in'], seed, tape.stream_id(tape.STREAM_P_INT, split, l))
+                for l in range(L)}
+        if getattr(model, 'anchors_pos_int', None) is None:
+            model.anchors_pos_int = {}
+        model.anchors_pos_int[split] = pint
+        t.mark('P_anchors')
+        for l in range(L):
+            dist = ops.bfs_hops(g, model.anchors_pos_ext[l].to(torch.int32).contiguous(), max_hops=hp.get('max_bfs_hops', 32))
+            w = ops.min_hops_to_sets(dist, cc_sets).view(S, C, -1)
+            sims[('P', 'out', l)] = (w * real.unsqueeze(-1)).contiguous()
+            if C == 1:
+                sims[('P', 'in', l)] = torch.zeros((S, C, hp['n_anchor_patches_pos_in']), dtype=torch.float32, device=dev)
+            else:
+                uniq, inv = torch.unique(pint[l], return_inverse=True)
+                if uniq.numel() > MAX_PINT_SOURCES:
+                    raise NotImplementedError('sparse P-internal similarities for multi-component subgraphs need a '
+                                              'BFS per distinct anchor (%d > %d)' % (uniq.numel(), MAX_PINT_SOURCES))
+                d = ops.bfs_hops(g, uniq.to(torch.int32).contiguous(), max_hops=hp.get('max_bfs_hops', 32))
+                full = ops.min_hops_to_sets(d, cc_sets).view(S, C, -1)               # (S, C, U)
+                w = torch.gather(full, 2, inv.view(S, 1, -1).expand(S, C, -1))
+                sims[('P', 'in', l)] = (w * real.unsqueeze(-1)).contiguous()
+        t.mark('P_bfs_sims')
+    setattr(model, split + '_neigh_pos_similarities', sims if sims else None)
+    setattr(model, split + '_N_border', None)
+    # ---- structure channel ---------------------------------------------------------------
+    if hp['use_structure']:
+        if split != 'test' or getattr(model, 'structure_anchors', None) is None:
+            model.structure_anchors = aps.sample_structure_anchor_patches(hp, g, dev, hp['max_sim_epochs'])
+            views = aps.patch_node_views(model.structure_anchors)
+            model.bor_structure_anchor_random_walks = aps.perform_random_walks(hp, g, model.structure_anchors, False, views)
+            model.int_structure_anchor_random_walks = aps.perform_random_walks(hp, g, model.structure_anchors, True, views)
+            model.anchors_structure = aps.init_anchors_structure(hp, model.structure_anchors,
+                                                                 model.int_structure_anchor_random_walks,
+                                                                 model.bor_structure_anchor_random_walks)
+        t.mark('S_patches_walks')
+        a_sets = ops.Ragged.from_padded(model.structure_anchors)
+        use_dict = g.full_degree is not None
+        ai, ae = ops.degree_sequence(g, a_sets, sort=True, use_degree_dict=use_dict)
+        ci, ce = ops.degree_sequence(g, cc_sets, sort=True, use_degree_dict=use_dict)
+        t.mark('degree_sequences')
+        mx, my = max(cc_sets.max_len, 1), max(a_sets.max_len, 1)
+        setattr(model, split + '_int_struc_similarities',
+                ops.dtw_similarity(cc_sets.ptr, ci, mx, a_sets.ptr, ai, my).view(S, C, -1))
+        setattr(model, split + '_bor_struc_similarities',
+                ops.dtw_similarity(cc_sets.ptr, ce, mx, a_sets.ptr, ae, my).view(S, C, -1))
+        t.mark('dtw')
+    else:
+        setattr(model, split + '_int_struc_similarities', None)
+        setattr(model, split + '_bor_struc_similarities', None)
+    model._sim_col_cache = {}
+    return t
+
+
+def full_split_batch(model, split):
+    """The whole split as one batch (the large-shard launch shape of the benchmark)."""
+    S = getattr(model, split + '_cc_ids').shape[0]
+    dev = model.device
+    return {'subgraph_ids': None, 'cc_ids': getattr(model, split + '_cc_ids'),
+            'N_border': None, 'NP_sim': getattr(model, split + '_neigh_pos_similarities'),
+            'I_S_sim': getattr(model, split + '_int_struc_similarities'),
+            'B_S_sim': getattr(model, split + '_bor_struc_similarities'),
+            'subgraph_idx': torch.arange(S, device=dev).view(-1, 1),
+            'label': getattr(model, split + '_sub_G_label').to(dev)}

@@ -209,13 +209,14 @@ def sample_anchors_padded(ids, n_slots, seed, stream_id):
     return out
 
 
-def sample_anchors_ragged(sets, n_slots, seed, stream_id, row_has_pad=None):
+def sample_anchors_ragged(sets, n_slots, seed, stream_id, row_has_pad=None, want_pos=False):
     lib = _lib.load()
     _req(row_has_pad, torch.uint8, 'row_has_pad')
     out = torch.empty((sets.n, n_slots), dtype=torch.int64, device=sets.ptr.device)
+    pos = torch.empty((sets.n, n_slots), dtype=torch.int64, device=sets.ptr.device) if want_pos else None
     check(lib.sgnn_sample_anchors_ragged(_ptr(sets.ptr), _ptr(sets.nodes), sets.n, _ptr(row_has_pad), n_slots, seed,
-                                         stream_id, _ptr(out), _stream()), 'sgnn_sample_anchors_ragged')
-    return out
+                                         stream_id, _ptr(out), _ptr(pos), _stream()), 'sgnn_sample_anchors_ragged')
+    return (out, pos) if want_pos else out
 
 
 def choice_ragged(sets, n_draws, seed, stream_id):
