@@ -70,6 +70,9 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch must bring in ITS HIP runtime first: loading libsubgnn_hip.so before torch would bind
+    # it to a second copy of libamdhip64 that never sees torch's device context
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise SubgnnHipError('libsubgnn_hip.so is missing (%s): build it with `python -m subgnn_amd.build`; '
                              'this package has no CPU fallback' % LIB_PATH)

@@ -61,7 +61,7 @@ def g11_case(g, variant):
 G11_VARIANTS = ('sum', 'max_trainable', 'bn', 'sumlstm_norm')
 
 
-def write_dataset_from_golden(g, root, name='ds'):
+def write_dataset_from_golden(g, root, name='ds', with_ego=None):
     """Recreate the on-disk dataset (SURVEY.md 8f-1 formats) a golden fixture was made from."""
     import json
     import os
@@ -85,7 +85,7 @@ def write_dataset_from_golden(g, root, name='ds'):
         ego[str(v - 1)] = [int(w) - 1 for w in nb]
     with open(os.path.join(d, 'degree_sequence.txt'), 'w') as f:
         json.dump(deg, f)
-    if bool(g['has_ego']):
+    if bool(g['has_ego']) if with_ego is None else with_ego:
         with open(os.path.join(d, 'ego_graphs.txt'), 'w') as f:
             json.dump(ego, f)
     return name

@@ -14,7 +14,7 @@ DEV = 'cuda:0'
 def _models(golden, tmp_path, over=None):
     from subgnn_amd import config
     from subgnn_amd.SubGNN import SubGNN, dataset_paths
-    name = write_dataset_from_golden(golden, tmp_path)
+    name = write_dataset_from_golden(golden, tmp_path, with_ego=False)   # true k-hop border in both paths
     config.PROJECT_ROOT = tmp_path
     out = []
     for _ in range(2):
