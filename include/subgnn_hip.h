@@ -79,13 +79,28 @@ int sgnn_cc_labels(const int64_t* rowptr, const int32_t* col_sorted, int64_t nnz
  * border id is (true id - 1), differenced against the 1-based component (id 0 can appear).
  * workspace: sgnn_khop_border_workspace_bytes(max_id, n_sets) bytes, ZERO-initialised by the
  * caller (per-workgroup visited bitmap + BFS queue; the bitmaps are left zeroed).
+ * bitmap_in_lds != 0 keeps the visited bitmap in the CU's LDS (allowed iff
+ * sgnn_khop_border_bitmap_fits_lds(max_id)); the results are the same either way.
  * ------------------------------------------------------------------------------------- */
 int64_t sgnn_khop_border_workspace_bytes(int64_t max_id, int64_t n_sets);
+int sgnn_khop_border_bitmap_fits_lds(int64_t max_id);
 int sgnn_khop_border(const int64_t* rowptr, const int32_t* col, int64_t nnz, int64_t max_id,
                      const int64_t* set_ptr, const int32_t* set_nodes, int64_t n_sets,
                      int k, int ego_dict_mode,
                      int64_t* out_count, const int64_t* out_ptr, int32_t* out_nodes, uint8_t* out_hop,
-                     void* workspace, int64_t workspace_bytes, void* stream);
+                     void* workspace, int64_t workspace_bytes, int bitmap_in_lds, void* stream);
+/* a8 + a4 fused: k-hop border BFS and, without materialising the border, the neighbourhood-border
+ * anchor draw of anchor_patch_samplers.sample_neighborhood_anchor_patch(sample_inside=False)
+ * (anchor_patch_samplers.py:184-194) over it.  For set s and slot i: out_anchor = argmax over the
+ * border of the tape variate z(s*n_slots+i, id) (order independent), out_hop = its hop level (the
+ * N-border similarity, = the APSP row-min of SubGNN.py:772 on that column), out_allneg = 1 iff
+ * every variate is negative -- the caller applies the PAD rule of aps:190 (PAD wins when all are
+ * negative AND the padded row is longer than this border, i.e. out_count[s] < max count). */
+int sgnn_khop_border_sample(const int64_t* rowptr, const int32_t* col, int64_t nnz, int64_t max_id,
+                            const int64_t* set_ptr, const int32_t* set_nodes, int64_t n_sets, int k,
+                            int64_t n_slots, uint64_t seed, uint64_t stream_id,
+                            int64_t* out_anchor, uint8_t* out_hop, uint8_t* out_allneg, int64_t* out_count,
+                            void* workspace, int64_t workspace_bytes, int bitmap_in_lds, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * a4  Neighbourhood anchor sampling from padded id matrices.

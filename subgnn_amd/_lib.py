@@ -32,8 +32,11 @@ SIGNATURES = {
     'sgnn_degree_sequence': (c_int, [c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_int, c_ptr, c_ptr, c_ptr]),
     'sgnn_cc_labels': (c_int, [c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_ptr, c_ptr]),
     'sgnn_khop_border_workspace_bytes': (c_i64, [c_i64, c_i64]),
+    'sgnn_khop_border_bitmap_fits_lds': (c_int, [c_i64]),
     'sgnn_khop_border': (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_i64, c_int, c_int, c_ptr, c_ptr, c_ptr,
-                                 c_ptr, c_ptr, c_i64, c_ptr]),
+                                 c_ptr, c_ptr, c_i64, c_int, c_ptr]),
+    'sgnn_khop_border_sample': (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_i64, c_int, c_i64, c_u64, c_u64,
+                                        c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_ptr]),
     'sgnn_sample_anchors_padded': (c_int, [c_ptr, c_i64, c_i64, c_i64, c_u64, c_u64, c_ptr, c_ptr]),
     'sgnn_sample_anchors_ragged': (c_int, [c_ptr, c_ptr, c_i64, c_ptr, c_i64, c_u64, c_u64, c_ptr, c_ptr, c_ptr]),
     'sgnn_choice_ragged': (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_u64, c_u64, c_ptr, c_ptr]),

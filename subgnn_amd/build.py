@@ -40,7 +40,7 @@ def build(force=False, verbose=True):
                 os.path.getmtime(src), os.path.getmtime(os.path.join(CSRC, 'common.h')),
                 os.path.getmtime(os.path.join(HERE, '..', 'include', 'subgnn_hip.h'))):
             cmd = [_hipcc(), '--offload-arch=' + ARCH, '-O3', '-fPIC', '-std=c++17', '-munsafe-fp-atomics',
-                   '-Wall', '-Wno-unused-function', '-c', src, '-o', o]
+                   '-Wall', '-Wno-unused-function'] + os.environ.get('SGNN_HIPCC_FLAGS', '').split() + ['-c', src, '-o', o]
             if verbose:
                 print(' '.join(cmd), flush=True)
             subprocess.check_call(cmd)

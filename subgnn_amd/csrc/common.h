@@ -70,3 +70,14 @@ __device__ static inline bool sgnn_sorted_contains(const int32_t* __restrict__ a
     }
     return lo < n && a[lo] == key;
 }
+
+// wave-wide argmax of (key, smallest column on ties); every lane ends with the winner
+__device__ static inline void sgnn_argmax_reduce(int64_t& key, int32_t& colv, int32_t& idv) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const int64_t k2 = __shfl_xor(key, d);
+        const int32_t c2 = __shfl_xor(colv, d);
+        const int32_t i2 = __shfl_xor(idv, d);
+        if (k2 > key || (k2 == key && c2 < colv)) { key = k2; colv = c2; idv = i2; }
+    }
+}

@@ -6,8 +6,10 @@
 //   * one 64-lane wavefront per set (|S| <= 64; the common case: CCs and walk patches);
 //     lane i owns member i: loads its id and rowptr pair, inserts the id into a 128-slot
 //     open-addressing hash in LDS (the set's membership structure);
-//   * the neighbour lists of all members are streamed as ONE flat range of sum(deg) items,
-//     64 items per step: lane l locates its (member, offset) by a 6-step binary search over
+//   * members with >= 64 neighbours (which carry most of the bytes on scale-free graphs) are
+//     streamed one list at a time with eight coalesced 256 B loads in flight and a wave
+//     sum at the end; the neighbour lists of the other members are streamed as ONE flat range
+//     of sum(deg) items: lane l locates its (member, offset) by a 6-step binary search over
 //     the wave-resident inclusive degree scan (ds_bpermute), loads col[] (consecutive lanes hit
 //     consecutive addresses inside a list -> coalesced 256 B runs even across list ends),
 //     probes the LDS hash, and the hits are reduced per member with wavefront ballot +
@@ -17,27 +19,58 @@
 //     atomics, LDS bitonic sort).
 #include "common.h"
 
-#define DS_HASH_BITS 7
+#define DS_HASH_BITS 8
 #define DS_HASH (1 << DS_HASH_BITS)
 
+#ifndef DS_BIG
+#define DS_BIG 64
+#endif
+//           // members with at least this many neighbours are streamed on their own
+
+// Membership probe with a wave-uniform probe count: the insert phase records the longest probe
+// chain of the set (P, usually 1-2 at <= 25 % load), and every lookup reads exactly P slots with
+// no data-dependent exit -- divergent loops cost scalar (exec-mask) instructions, and the CU's
+// single scalar unit was the measured bottleneck of the first version of this kernel.
+__device__ static inline int ds_probe(const int32_t* hash, int32_t u, int P) {
+    const uint32_t h = sgnn_hash32((uint32_t)u) >> (32 - DS_HASH_BITS);
+    int hit = 0;
+    for (int p = 0; p < P; ++p) hit |= (hash[(h + p) & (DS_HASH - 1)] == u);
+    return hit;
+}
+
+__device__ static inline int32_t ds_wave_sum(int32_t v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+    return v;
+}
+
+#ifndef DS_WAVES
+#define DS_WAVES 1             // wavefronts (= sets) per workgroup; 1 measured best (finest dispatch granularity)
+#endif
+
 template <bool SORTED>
-__global__ __launch_bounds__(64) void degseq_wave_kernel(
+__global__ __launch_bounds__(64 * DS_WAVES) void degseq_wave_kernel(
     const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
     const int32_t* __restrict__ full_degree,
     const int64_t* __restrict__ set_ptr, const int32_t* __restrict__ set_nodes, int64_t n_sets,
     int32_t* __restrict__ out_int, int32_t* __restrict__ out_ext)
 {
-    __shared__ int32_t hash[DS_HASH];
-    const int lane = threadIdx.x;
-    for (int64_t s = blockIdx.x; s < n_sets; s += gridDim.x) {
+    // one hash table per wavefront; a wavefront's LDS operations execute in issue order, so the
+    // waves of a workgroup never need a workgroup barrier (they work on different sets)
+    __shared__ int32_t hash_all[DS_WAVES][DS_HASH];
+    const int lane = threadIdx.x & 63;
+    int32_t* hash = hash_all[threadIdx.x >> 6];
+    for (int64_t s = (int64_t)blockIdx.x * DS_WAVES + (threadIdx.x >> 6); s < n_sets; s += (int64_t)gridDim.x * DS_WAVES) {
         const int64_t beg = set_ptr[s];
         const int n = (int)(set_ptr[s + 1] - beg);
         if (n <= 0 || n > 64) continue;                     // wave-uniform
-        hash[lane] = 0;
-        hash[lane + 64] = 0;
-        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < DS_HASH / 64; ++q) hash[lane + 64 * q] = 0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
         int32_t v = 0, deg = 0;
         uint32_t r0 = 0;
+        int chain = 0;
         if (lane < n) {
             v = set_nodes[beg + lane];
             const int64_t a = rowptr[v], b = rowptr[v + 1];
@@ -45,58 +78,98 @@ __global__ __launch_bounds__(64) void degseq_wave_kernel(
             deg = (int32_t)(b - a);
             uint32_t h = sgnn_hash32((uint32_t)v) >> (32 - DS_HASH_BITS);
             while (true) {
+                ++chain;
                 const int32_t old = atomicCAS(&hash[h], 0, v);
                 if (old == 0 || old == v) break;
                 h = (h + 1) & (DS_HASH - 1);
             }
         }
-        __syncthreads();
-        int32_t incl = deg;                                  // inclusive scan over the wave
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) { const int o = __shfl_xor(chain, d); chain = o > chain ? o : chain; }
+        const int P = chain;                                 // wave-uniform probe count
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        int32_t cnt = 0, selfc = 0;
+        // ---- phase A: members with >= 64 neighbours, one list at a time, 8 coalesced 256 B loads in flight ----
+        uint64_t big = __ballot(deg >= DS_BIG);
+        while (big) {
+            const int m = __ffsll((unsigned long long)big) - 1;
+            big &= big - 1;
+            const int32_t m_v = __shfl(v, m), m_deg = __shfl(deg, m);
+            const int32_t* __restrict__ list = col + __shfl(r0, m);
+            int32_t local = 0, selfl = 0;
+            int32_t base = 0;
+            for (; base + 512 <= m_deg; base += 512) {       // full blocks: 8 x 256 B loads in flight
+                int32_t u[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) u[q] = list[base + q * 64 + lane];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { local += ds_probe(hash, u[q], P); selfl += (u[q] == m_v); }
+            }
+            if (base < m_deg) {                              // tail (< 512 entries): clamped loads,
+                const int32_t last = m_deg - 1;              // out-of-range lanes get the never-stored key -1
+                int32_t u[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int32_t i = base + q * 64 + lane;
+                    u[q] = list[i < last ? i : last];
+                    u[q] = i <= last ? u[q] : -1;
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    if (base + q * 64 < m_deg) { local += ds_probe(hash, u[q], P); selfl += (u[q] == m_v); }   // wave-uniform
+            }
+            const int32_t st = ds_wave_sum(selfl);
+            const int32_t tot = ds_wave_sum(local) + st;      // a self loop counts twice (networkx)
+            if (lane == m) { cnt = tot; selfc = st; }
+        }
+        // ---- phase B: the remaining lists as one flat range, 128 entries per step ------------
+        const int32_t sdeg = deg >= DS_BIG ? 0 : deg;
+        int32_t incl = sdeg;                                 // inclusive scan over the wave
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
             const int32_t t = __shfl_up(incl, d);
             if (lane >= d) incl += t;
         }
         const int32_t total = __shfl(incl, 63);
-        const int32_t excl = incl - deg;
-        int32_t cnt = 0, selfc = 0;
-        for (int32_t base = 0; base < total; base += 64) {
-            const int32_t t = base + lane;
-            int lo = 0, hi = 63;                             // smallest m with incl[m] > t
+        const int32_t excl = incl - sdeg;
+        for (int32_t base = 0; base < total; base += 128) {
+            int32_t u[2], mv[2];
+            bool valid[2];
 #pragma unroll
-            for (int it = 0; it < 6; ++it) {
-                const int mid = (lo + hi) >> 1;
-                const int32_t x = __shfl(incl, mid);
-                if (x > t) hi = mid; else lo = mid + 1;
-            }
-            const int m = lo & 63;
-            const bool valid = t < total;
-            const int32_t m_excl = __shfl(excl, m);
-            const uint32_t m_r0 = __shfl(r0, m);
-            const int32_t m_v = __shfl(v, m);
-            bool hit = false, self = false;
-            if (valid) {
-                const int32_t u = col[m_r0 + (uint32_t)(t - m_excl)];
-                self = (u == m_v);
-                uint32_t h = sgnn_hash32((uint32_t)u) >> (32 - DS_HASH_BITS);
-                while (true) {
-                    const int32_t k = hash[h];
-                    if (k == u) { hit = true; break; }
-                    if (k == 0) break;
-                    h = (h + 1) & (DS_HASH - 1);
+            for (int q = 0; q < 2; ++q) {
+                const int32_t t = base + q * 64 + lane;
+                int lo = 0, hi = 63;                         // smallest m with incl[m] > t
+#pragma unroll
+                for (int it = 0; it < 6; ++it) {
+                    const int mid = (lo + hi) >> 1;
+                    const int32_t x = __shfl(incl, mid);
+                    if (x > t) hi = mid; else lo = mid + 1;
                 }
+                const int m = lo & 63;
+                valid[q] = t < total;
+                const int32_t m_excl = __shfl(excl, m);
+                const uint32_t m_r0 = __shfl(r0, m);
+                mv[q] = __shfl(v, m);
+                u[q] = valid[q] ? col[m_r0 + (uint32_t)(t - m_excl)] : -1;
             }
-            const uint64_t mh = __ballot(hit);
-            const uint64_t ms = __ballot(self);
-            int32_t lo_i = excl - base, hi_i = incl - base;   // this lane's member range in the step
-            lo_i = lo_i < 0 ? 0 : (lo_i > 64 ? 64 : lo_i);
-            hi_i = hi_i < 0 ? 0 : (hi_i > 64 ? 64 : hi_i);
-            const uint64_t below_hi = hi_i >= 64 ? ~0ull : ((1ull << hi_i) - 1ull);
-            const uint64_t below_lo = lo_i >= 64 ? ~0ull : ((1ull << lo_i) - 1ull);
-            const uint64_t rm = below_hi & ~below_lo;
-            const int32_t sc = __popcll(ms & rm);
-            cnt += __popcll(mh & rm) + sc;                    // a self loop counts twice (networkx)
-            selfc += sc;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const bool hit = ds_probe(hash, u[q], P) != 0;
+                const bool self = (u[q] == mv[q]);
+                const uint64_t mh = __ballot(hit);
+                const uint64_t ms = __ballot(self);
+                const int32_t b0 = base + q * 64;
+                int32_t lo_i = excl - b0, hi_i = incl - b0;  // this lane's member range in the step
+                lo_i = lo_i < 0 ? 0 : (lo_i > 64 ? 64 : lo_i);
+                hi_i = hi_i < 0 ? 0 : (hi_i > 64 ? 64 : hi_i);
+                const uint64_t below_hi = hi_i >= 64 ? ~0ull : ((1ull << hi_i) - 1ull);
+                const uint64_t below_lo = lo_i >= 64 ? ~0ull : ((1ull << lo_i) - 1ull);
+                const uint64_t rm = below_hi & ~below_lo;
+                const int32_t sc = __popcll(ms & rm);
+                cnt += __popcll(mh & rm) + sc;
+                selfc += sc;
+            }
         }
         int32_t full = deg + selfc;
         if (full_degree != nullptr && lane < n) full = full_degree[v];
@@ -120,7 +193,8 @@ __global__ __launch_bounds__(64) void degseq_wave_kernel(
                 if (out_ext) out_ext[beg + re] = external;
             }
         }
-        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -258,13 +332,16 @@ extern "C" int sgnn_degree_sequence(const int64_t* rowptr, const int32_t* col, i
     if (max_set_size > DSB_MAX) return SGNN_ERR_SET_TOO_LARGE;
     if (n_sets == 0) return SGNN_OK;
     hipStream_t st = (hipStream_t)stream;
-    // 64-thread workgroups, grid-stride over sets: 256 CUs x 32 waves resident
-    const int grid = (int)(n_sets < 256 * 32 ? n_sets : 256 * 32);
+    // 256-thread workgroups = 4 independent wavefronts, one set per wavefront: the hardware
+    // dispatcher hands out workgroups as CUs free up, which balances the very uneven per-set
+    // cost (sum of member degrees) better than a static grid-stride assignment
+    const int64_t want = (n_sets + DS_WAVES - 1) / DS_WAVES;
+    const int grid = (int)(want < (1 << 20) ? want : (1 << 20));
     if (sorted)
-        hipLaunchKernelGGL(degseq_wave_kernel<true>, dim3(grid), dim3(64), 0, st, rowptr, col, full_degree,
+        hipLaunchKernelGGL(degseq_wave_kernel<true>, dim3(grid), dim3(64 * DS_WAVES), 0, st, rowptr, col, full_degree,
                            set_ptr, set_nodes, n_sets, out_internal, out_external);
     else
-        hipLaunchKernelGGL(degseq_wave_kernel<false>, dim3(grid), dim3(64), 0, st, rowptr, col, full_degree,
+        hipLaunchKernelGGL(degseq_wave_kernel<false>, dim3(grid), dim3(64 * DS_WAVES), 0, st, rowptr, col, full_degree,
                            set_ptr, set_nodes, n_sets, out_internal, out_external);
     SGNN_CHECK_LAUNCH();
     if (max_set_size > 64) {

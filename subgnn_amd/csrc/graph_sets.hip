@@ -80,43 +80,75 @@ extern "C" int sgnn_cc_labels(const int64_t* rowptr, const int32_t* col_sorted, 
 }
 
 // ---------------------------------------------------------------------------------------------
-// a8  k-hop border (reference SubGNN/subgraph_utils.py:146-176)
-// One 256-thread workgroup per component, level-synchronous BFS.  Each workgroup owns a visited
-// bitmap over node ids and a queue in the caller's workspace; a frontier node is taken by one
-// wavefront whose lanes stream its neighbour list (coalesced), claim unseen neighbours with
-// atomicOr on the bitmap word and append them to the queue.  The bitmap is un-set on exit so
-// the next component handled by the workgroup starts clean.
+// a8  k-hop border (reference SubGNN/subgraph_utils.py:146-176), optionally fused with the
+// neighbourhood-border anchor draw (a4, reference anchor_patch_samplers.py:184-194).
+// One workgroup per component, level-synchronous BFS.  The visited bitmap over node ids lives in
+// LDS when it fits (max_id + 1 <= ~1.27 M bits in the CU's 160 KB: one 1024-thread workgroup per
+// CU, LDS atomics) and otherwise in the caller's workspace (256-thread workgroups, L2 atomics);
+// the BFS queue is always in the workspace.  A frontier node is taken by one wavefront whose
+// lanes stream its neighbour list (coalesced), claim unseen neighbours with atomicOr on the
+// bitmap word and append them to the queue.  Every bit set is un-set on exit so the next
+// component handled by the workgroup starts clean.
+// Fused sampling: the queue of a finished component (still hot in L2) is scanned once per group
+// of 4 anchor slots; keys are hashed from (row, slot, node id), so the draw does not depend on
+// the discovery order -- the border never has to be materialised or sorted.
 // ---------------------------------------------------------------------------------------------
-#define KB_THREADS 256
-#define KB_MAX_WG 1024
+#define KB_THREADS_G 256
+#define KB_THREADS_L 1024
+#define KB_MAX_WG_G 1024
+#define KB_MAX_WG_L 256
+#define KB_LDS_BYTES (156 * 1024)
+#define KB_SC 4
 
 static inline int64_t kb_words(int64_t max_id) { return (max_id + 32) / 32; }
-static inline int64_t kb_n_wg(int64_t n_sets) { return n_sets < KB_MAX_WG ? (n_sets < 1 ? 1 : n_sets) : KB_MAX_WG; }
-
-extern "C" int64_t sgnn_khop_border_workspace_bytes(int64_t max_id, int64_t n_sets) {
-    const int64_t per_wg = kb_words(max_id) * 4 + (max_id + 1) * 4;
-    return per_wg * kb_n_wg(n_sets);
+static inline bool kb_fits_lds(int64_t max_id) { return kb_words(max_id) * 4 <= KB_LDS_BYTES; }
+static inline int64_t kb_n_wg(int64_t n_sets, bool lds) {
+    const int64_t cap = lds ? KB_MAX_WG_L : KB_MAX_WG_G;
+    return n_sets < cap ? (n_sets < 1 ? 1 : n_sets) : cap;
 }
 
-__global__ __launch_bounds__(KB_THREADS) void khop_border_kernel(
+extern "C" int sgnn_khop_border_bitmap_fits_lds(int64_t max_id) { return kb_fits_lds(max_id) ? 1 : 0; }
+
+extern "C" int64_t sgnn_khop_border_workspace_bytes(int64_t max_id, int64_t n_sets) {
+    // sized for the global-bitmap variant (the LDS variant uses the queue part only)
+    const int64_t per_wg = kb_words(max_id) * 4 + (max_id + 1) * 4;
+    return per_wg * kb_n_wg(n_sets, false);
+}
+
+struct KbSample {             // fused neighbourhood-border anchor draw (all NULL/0 = off)
+    int64_t n_slots;
+    uint64_t h0;
+    int64_t* anchor;          // (n_sets, n_slots) winning node id
+    uint8_t* hop;             // (n_sets, n_slots) its hop level
+    uint8_t* allneg;          // (n_sets, n_slots) 1 if every key < 0 (PAD wins if the row is padded)
+};
+
+template <bool LDS_BM, int THREADS>
+__global__ __launch_bounds__(THREADS) void khop_border_kernel(
     const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col, int64_t max_id,
     const int64_t* __restrict__ set_ptr, const int32_t* __restrict__ set_nodes, int64_t n_sets,
     int k, int ego_mode,
     int64_t* __restrict__ out_count, const int64_t* __restrict__ out_ptr,
     int32_t* __restrict__ out_nodes, uint8_t* __restrict__ out_hop,
-    uint32_t* __restrict__ bitmaps, int32_t* __restrict__ queues, int64_t words)
+    uint32_t* __restrict__ bitmaps, int32_t* __restrict__ queues, int64_t words, KbSample smp)
 {
+    extern __shared__ uint32_t s_bm[];
     __shared__ int32_t s_qn;
     __shared__ int32_t s_lvl[260];
-    uint32_t* bm = bitmaps + (int64_t)blockIdx.x * words;
+    uint32_t* bm = LDS_BM ? s_bm : bitmaps + (int64_t)blockIdx.x * words;
     int32_t* q = queues + (int64_t)blockIdx.x * (max_id + 1);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    constexpr int NW = THREADS / 64;
     const int hops = ego_mode ? 1 : k;
+    if (LDS_BM) {
+        for (int64_t i = tid; i < words; i += THREADS) s_bm[i] = 0;
+        __syncthreads();
+    }
     for (int64_t s = blockIdx.x; s < n_sets; s += gridDim.x) {
         const int64_t beg = set_ptr[s];
         const int n = (int)(set_ptr[s + 1] - beg);
         if (tid == 0) { s_qn = 0; s_lvl[0] = 0; }              // s_lvl[h] = queue length after hop h
-        for (int i = tid; i < n; i += KB_THREADS) {
+        for (int i = tid; i < n; i += THREADS) {
             const int32_t v = set_nodes[beg + i];
             atomicOr(&bm[v >> 5], 1u << (v & 31));
         }
@@ -124,7 +156,7 @@ __global__ __launch_bounds__(KB_THREADS) void khop_border_kernel(
         for (int h = 1; h <= hops; ++h) {
             const int f0 = (h == 1) ? 0 : s_lvl[h - 2];      // frontier of hop h = nodes found at hop h-1
             const int f1 = (h == 1) ? n : s_lvl[h - 1];
-            for (int f = f0 + wave; f < f1; f += KB_THREADS / 64) {
+            for (int f = f0 + wave; f < f1; f += NW) {
                 const int32_t v = (h == 1) ? set_nodes[beg + f] : q[f];
                 const int64_t r0 = rowptr[v], r1 = rowptr[v + 1];
                 for (int64_t e = r0 + lane; e < r1; e += 64) {
@@ -142,11 +174,10 @@ __global__ __launch_bounds__(KB_THREADS) void khop_border_kernel(
             __syncthreads();
         }
         const int cnt = s_qn;
-        if (out_nodes == nullptr) {
-            if (tid == 0) out_count[s] = cnt;
-        } else {
+        if (out_count && tid == 0) out_count[s] = cnt;
+        if (out_nodes != nullptr) {
             const int64_t o = out_ptr[s];
-            for (int i = tid; i < cnt; i += KB_THREADS) {
+            for (int i = tid; i < cnt; i += THREADS) {
                 out_nodes[o + i] = q[i];
                 if (out_hop) {
                     int h = 1;
@@ -155,12 +186,45 @@ __global__ __launch_bounds__(KB_THREADS) void khop_border_kernel(
                 }
             }
         }
+        if (smp.n_slots > 0) {
+            // anchor draw over the queue: KB_SC slots per pass, one wavefront per slot group
+            for (int64_t s0 = (int64_t)wave * KB_SC; s0 < smp.n_slots; s0 += (int64_t)NW * KB_SC) {
+                uint64_t h1[KB_SC];
+                int64_t best[KB_SC];
+                int32_t bcol[KB_SC], bid[KB_SC];
+#pragma unroll
+                for (int u = 0; u < KB_SC; ++u) {
+                    h1[u] = sgnn_tape_h1(smp.h0, (uint64_t)(s * smp.n_slots + s0 + u));
+                    best[u] = INT64_MIN; bcol[u] = INT32_MAX; bid[u] = 0;
+                }
+                for (int c = lane; c < cnt; c += 64) {
+                    const int32_t v = q[c];
+#pragma unroll
+                    for (int u = 0; u < KB_SC; ++u) {
+                        const int64_t key = (v == 0) ? 0 : sgnn_symmetric_key(h1[u], (uint64_t)v);
+                        if (key > best[u]) { best[u] = key; bcol[u] = c; bid[u] = v; }
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < KB_SC; ++u) {
+                    sgnn_argmax_reduce(best[u], bcol[u], bid[u]);
+                    if (lane == 0 && s0 + u < smp.n_slots) {
+                        const int64_t o = s * smp.n_slots + s0 + u;
+                        int h = 0;
+                        if (cnt > 0) { h = 1; while (h < hops && bcol[u] >= s_lvl[h]) ++h; }
+                        smp.anchor[o] = cnt > 0 ? (int64_t)bid[u] : 0;
+                        smp.hop[o] = (uint8_t)h;
+                        smp.allneg[o] = (cnt == 0 || best[u] < 0) ? 1 : 0;
+                    }
+                }
+            }
+        }
         // un-set every bit this component touched
-        for (int i = tid; i < n; i += KB_THREADS) {
+        for (int i = tid; i < n; i += THREADS) {
             const int32_t v = set_nodes[beg + i];
             atomicAnd(&bm[v >> 5], ~(1u << (v & 31)));
         }
-        for (int i = tid; i < cnt; i += KB_THREADS) {
+        for (int i = tid; i < cnt; i += THREADS) {
             const int32_t c = q[i];
             atomicAnd(&bm[c >> 5], ~(1u << (c & 31)));
         }
@@ -168,28 +232,65 @@ __global__ __launch_bounds__(KB_THREADS) void khop_border_kernel(
     }
 }
 
+static int kb_launch(const int64_t* rowptr, const int32_t* col, int64_t nnz, int64_t max_id,
+                     const int64_t* set_ptr, const int32_t* set_nodes, int64_t n_sets, int k, int ego_dict_mode,
+                     int64_t* out_count, const int64_t* out_ptr, int32_t* out_nodes, uint8_t* out_hop,
+                     void* workspace, int64_t workspace_bytes, int bitmap_in_lds, KbSample smp, void* stream)
+{
+    if (!rowptr || !col || !set_ptr || !set_nodes || !workspace || n_sets < 0 || k < 1 || k > 255)
+        return SGNN_ERR_BAD_ARG;
+    if (out_nodes != nullptr && out_ptr == nullptr) return SGNN_ERR_BAD_ARG;
+    if (nnz >= (1ll << 31)) return SGNN_ERR_NNZ_TOO_LARGE;
+    if (workspace_bytes < sgnn_khop_border_workspace_bytes(max_id, n_sets)) return SGNN_ERR_BAD_ARG;
+    if (bitmap_in_lds && !kb_fits_lds(max_id)) return SGNN_ERR_BAD_ARG;
+    if (n_sets == 0) return SGNN_OK;
+    const int64_t words = kb_words(max_id);
+    const int64_t nwg = kb_n_wg(n_sets, bitmap_in_lds != 0);
+    const int64_t nwg_g = kb_n_wg(n_sets, false);
+    uint32_t* bitmaps = (uint32_t*)workspace;
+    int32_t* queues = (int32_t*)(bitmaps + words * nwg_g);        // same split for both variants
+    hipStream_t st = (hipStream_t)stream;
+    if (bitmap_in_lds) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipFuncSetAttribute((const void*)khop_border_kernel<true, KB_THREADS_L>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, KB_LDS_BYTES);
+            attr_set = true;
+        }
+        hipLaunchKernelGGL((khop_border_kernel<true, KB_THREADS_L>), dim3((int)nwg), dim3(KB_THREADS_L),
+                           (size_t)(words * 4), st, rowptr, col, max_id, set_ptr, set_nodes, n_sets, k, ego_dict_mode,
+                           out_count, out_ptr, out_nodes, out_hop, bitmaps, queues, words, smp);
+    } else {
+        hipLaunchKernelGGL((khop_border_kernel<false, KB_THREADS_G>), dim3((int)nwg), dim3(KB_THREADS_G), 0, st,
+                           rowptr, col, max_id, set_ptr, set_nodes, n_sets, k, ego_dict_mode, out_count, out_ptr,
+                           out_nodes, out_hop, bitmaps, queues, words, smp);
+    }
+    SGNN_CHECK_LAUNCH();
+    return SGNN_OK;
+}
+
 extern "C" int sgnn_khop_border(const int64_t* rowptr, const int32_t* col, int64_t nnz, int64_t max_id,
                                 const int64_t* set_ptr, const int32_t* set_nodes, int64_t n_sets,
                                 int k, int ego_dict_mode,
                                 int64_t* out_count, const int64_t* out_ptr, int32_t* out_nodes, uint8_t* out_hop,
-                                void* workspace, int64_t workspace_bytes, void* stream)
+                                void* workspace, int64_t workspace_bytes, int bitmap_in_lds, void* stream)
 {
-    if (!rowptr || !col || !set_ptr || !set_nodes || !workspace || n_sets < 0 || k < 1 || k > 255)
-        return SGNN_ERR_BAD_ARG;
     if (out_nodes == nullptr && out_count == nullptr) return SGNN_ERR_BAD_ARG;
-    if (out_nodes != nullptr && out_ptr == nullptr) return SGNN_ERR_BAD_ARG;
-    if (nnz >= (1ll << 31)) return SGNN_ERR_NNZ_TOO_LARGE;
-    if (workspace_bytes < sgnn_khop_border_workspace_bytes(max_id, n_sets)) return SGNN_ERR_BAD_ARG;
-    if (n_sets == 0) return SGNN_OK;
-    const int64_t words = kb_words(max_id);
-    const int64_t nwg = kb_n_wg(n_sets);
-    uint32_t* bitmaps = (uint32_t*)workspace;
-    int32_t* queues = (int32_t*)(bitmaps + words * nwg);
-    hipLaunchKernelGGL(khop_border_kernel, dim3((int)nwg), dim3(KB_THREADS), 0, (hipStream_t)stream, rowptr, col,
-                       max_id, set_ptr, set_nodes, n_sets, k, ego_dict_mode, out_count, out_ptr, out_nodes,
-                       out_hop, bitmaps, queues, words);
-    SGNN_CHECK_LAUNCH();
-    return SGNN_OK;
+    KbSample none = {0, 0, nullptr, nullptr, nullptr};
+    return kb_launch(rowptr, col, nnz, max_id, set_ptr, set_nodes, n_sets, k, ego_dict_mode, out_count, out_ptr,
+                     out_nodes, out_hop, workspace, workspace_bytes, bitmap_in_lds, none, stream);
+}
+
+extern "C" int sgnn_khop_border_sample(const int64_t* rowptr, const int32_t* col, int64_t nnz, int64_t max_id,
+                                       const int64_t* set_ptr, const int32_t* set_nodes, int64_t n_sets, int k,
+                                       int64_t n_slots, uint64_t seed, uint64_t stream_id,
+                                       int64_t* out_anchor, uint8_t* out_hop, uint8_t* out_allneg, int64_t* out_count,
+                                       void* workspace, int64_t workspace_bytes, int bitmap_in_lds, void* stream)
+{
+    if (!out_anchor || !out_hop || !out_allneg || !out_count || n_slots < 1) return SGNN_ERR_BAD_ARG;
+    KbSample smp = {n_slots, sgnn_tape_h0(seed, stream_id), out_anchor, out_hop, out_allneg};
+    return kb_launch(rowptr, col, nnz, max_id, set_ptr, set_nodes, n_sets, k, 0, out_count, nullptr, nullptr, nullptr,
+                     workspace, workspace_bytes, bitmap_in_lds, smp, stream);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -8,16 +8,6 @@
 // maximum key, the smallest column winning ties (torch.argmax returns the first maximum).
 // VALU-bound (two 64-bit multiplies-mix rounds per element), no memory traffic beyond the ids.
 // ---------------------------------------------------------------------------------------------
-__device__ static inline void argmax_reduce(int64_t& key, int32_t& colv, int32_t& idv) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        const int64_t k2 = __shfl_xor(key, d);
-        const int32_t c2 = __shfl_xor(colv, d);
-        const int32_t i2 = __shfl_xor(idv, d);
-        if (k2 > key || (k2 == key && c2 < colv)) { key = k2; colv = c2; idv = i2; }
-    }
-}
-
 __global__ __launch_bounds__(64) void sample_anchors_padded_kernel(
     const int64_t* __restrict__ ids, int64_t n_rows, int64_t L, int64_t n_slots,
     uint64_t h0, int64_t* __restrict__ out)
@@ -34,37 +24,51 @@ __global__ __launch_bounds__(64) void sample_anchors_padded_kernel(
                 const int64_t key = (v == 0) ? 0 : sgnn_symmetric_key(h1, (uint64_t)v);
                 if (key > best) { best = key; bcol = (int32_t)c; bid = (int32_t)v; }
             }
-            argmax_reduce(best, bcol, bid);
+            sgnn_argmax_reduce(best, bcol, bid);
             if (lane == 0) out[r * n_slots + i] = (L > 0) ? (int64_t)bid : 0;
         }
     }
 }
 
-__global__ __launch_bounds__(64) void sample_anchors_ragged_kernel(
+#define SA_SC 8               // anchor slots hashed per pass over a row
+#define SA_WAVES 4            // rows in flight per 256-thread workgroup
+
+__global__ __launch_bounds__(64 * SA_WAVES) void sample_anchors_ragged_kernel(
     const int64_t* __restrict__ set_ptr, const int32_t* __restrict__ set_nodes, int64_t n_sets,
     const uint8_t* __restrict__ row_has_pad, int64_t n_slots, uint64_t h0, int64_t* __restrict__ out,
     int64_t* __restrict__ out_pos)
 {
-    const int lane = threadIdx.x;
-    for (int64_t r = blockIdx.x; r < n_sets; r += gridDim.x) {
+    const int lane = threadIdx.x & 63;
+    for (int64_t r = (int64_t)blockIdx.x * SA_WAVES + (threadIdx.x >> 6); r < n_sets; r += (int64_t)gridDim.x * SA_WAVES) {
         const int64_t beg = set_ptr[r];
         const int64_t n = set_ptr[r + 1] - beg;
         const bool has_pad = row_has_pad ? (row_has_pad[r] != 0) : true;
-        for (int64_t i = 0; i < n_slots; ++i) {
-            const uint64_t h1 = sgnn_tape_h1(h0, (uint64_t)(r * n_slots + i));
-            int64_t best = INT64_MIN;
-            int32_t bcol = INT32_MAX, bid = 0;
-            for (int64_t c = lane; c < n; c += 64) {
-                const int32_t v = set_nodes[beg + c];
-                const int64_t key = (v == 0) ? 0 : sgnn_symmetric_key(h1, (uint64_t)v);
-                if (key > best) { best = key; bcol = (int32_t)c; bid = v; }
+        for (int64_t s0 = 0; s0 < n_slots; s0 += SA_SC) {
+            uint64_t h1[SA_SC];
+            int64_t best[SA_SC];
+            int32_t bcol[SA_SC], bid[SA_SC];
+#pragma unroll
+            for (int u = 0; u < SA_SC; ++u) {
+                h1[u] = sgnn_tape_h1(h0, (uint64_t)(r * n_slots + s0 + u));
+                best[u] = INT64_MIN; bcol[u] = INT32_MAX; bid[u] = 0;
             }
-            argmax_reduce(best, bcol, bid);
-            // the PAD columns of the padded row sit after the real ones with key 0
-            if (n == 0 || (has_pad && best < 0)) { bid = 0; bcol = -1; }
-            if (lane == 0) {
-                out[r * n_slots + i] = (int64_t)bid;
-                if (out_pos) out_pos[r * n_slots + i] = (bid == 0) ? -1 : beg + bcol;   // index into set_nodes
+            for (int64_t c = lane; c < n; c += 64) {       // one read of the row per SA_SC slots
+                const int32_t v = set_nodes[beg + c];
+#pragma unroll
+                for (int u = 0; u < SA_SC; ++u) {
+                    const int64_t key = (v == 0) ? 0 : sgnn_symmetric_key(h1[u], (uint64_t)v);
+                    if (key > best[u]) { best[u] = key; bcol[u] = (int32_t)c; bid[u] = v; }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < SA_SC; ++u) {
+                sgnn_argmax_reduce(best[u], bcol[u], bid[u]);
+                // the PAD columns of the padded row sit after the real ones with key 0
+                if (n == 0 || (has_pad && best[u] < 0)) { bid[u] = 0; bcol[u] = -1; }
+                if (lane == 0 && s0 + u < n_slots) {
+                    out[r * n_slots + s0 + u] = (int64_t)bid[u];
+                    if (out_pos) out_pos[r * n_slots + s0 + u] = (bid[u] == 0) ? -1 : beg + bcol[u];
+                }
             }
         }
     }
@@ -89,8 +93,9 @@ extern "C" int sgnn_sample_anchors_ragged(const int64_t* set_ptr, const int32_t*
 {
     if (!set_ptr || !set_nodes || !out || n_sets < 0 || n_slots < 0) return SGNN_ERR_BAD_ARG;
     if (n_sets == 0 || n_slots == 0) return SGNN_OK;
-    const int grid = (int)(n_sets < 256 * 32 ? n_sets : 256 * 32);
-    hipLaunchKernelGGL(sample_anchors_ragged_kernel, dim3(grid), dim3(64), 0, (hipStream_t)stream, set_ptr,
+    const int64_t want = (n_sets + SA_WAVES - 1) / SA_WAVES;
+    const int grid = (int)(want < 256 * 8 ? want : 256 * 8);
+    hipLaunchKernelGGL(sample_anchors_ragged_kernel, dim3(grid), dim3(64 * SA_WAVES), 0, (hipStream_t)stream, set_ptr,
                        set_nodes, n_sets, row_has_pad, n_slots, sgnn_tape_h0(seed, stream_id), out, out_pos);
     SGNN_CHECK_LAUNCH();
     return SGNN_OK;
@@ -126,12 +131,14 @@ extern "C" int sgnn_choice_ragged(const int64_t* ptr, const int32_t* seq, int64_
 
 // ---------------------------------------------------------------------------------------------
 // a1-a3  triangular random walks (reference SubGNN/anchor_patch_samplers.py:20-158, 210-243)
-// One lane per walk: a walk is a serial dependent chain (each step needs the previous node),
-// so parallelism is across walks only; the work per step is two passes over the neighbour list
-// of the current node in networkx order (count the triangle / non-triangle candidates, then
-// pick the drawn one), with the triangle test a binary search in the previous node's sorted
-// list.  Latency-bound integer work; the walks are few (patches x walks), so this kernel is
-// not on the bandwidth-critical path.
+// One WAVEFRONT per walk.  A walk is a serial dependent chain (each step needs the previous
+// node), so walks run in parallel across wavefronts, and inside a step the 64 lanes share the
+// work that dominates on hub nodes: the neighbour list of the current node is streamed in
+// networkx order 64 entries at a time (coalesced), every lane classifies its entry (valid for
+// the mode?  adjacent to the previous node? -- binary search in that node's sorted list), and
+// wavefront ballots + popcounts give the triangle / non-triangle counts (pass 1) and the
+// position of the drawn candidate (pass 2).  The walk state (tape counter, prev, curr) is
+// wave-uniform.  Latency-bound integer work; the walks are few (patches x walks).
 // ---------------------------------------------------------------------------------------------
 struct WalkCtx {
     const int64_t* rowptr;
@@ -157,21 +164,58 @@ __device__ static inline bool walk_valid(const WalkCtx& c, int32_t v) {
     return !member || walk_in_list(c.inb, c.n_inb, v);       // aps:143
 }
 
-// number of valid neighbours of v; if pick >= 0 returns the pick-th one through *out
-__device__ static inline int32_t walk_neighbors(const WalkCtx& c, int32_t v, int32_t pick, int32_t* out) {
+// pass 1: counts of valid neighbours of v that are / are not adjacent to prev (prev = 0: no test)
+__device__ static inline void walk_count(const WalkCtx& c, int32_t v, int32_t prev, int lane, int32_t& nt, int32_t& nn) {
     const int64_t r0 = c.rowptr[v], r1 = c.rowptr[v + 1];
-    int32_t cnt = 0;
-    for (int64_t e = r0; e < r1; ++e) {
-        const int32_t w = c.col[e];
-        if (walk_valid(c, w)) {
-            if (cnt == pick) { *out = w; return cnt; }
-            ++cnt;
+    int64_t p0 = 0;
+    int32_t pdeg = 0;
+    if (prev) { p0 = c.rowptr[prev]; pdeg = (int32_t)(c.rowptr[prev + 1] - p0); }
+    nt = 0; nn = 0;
+    for (int64_t base = r0; base < r1; base += 64) {
+        const int64_t e = base + lane;
+        bool ok = false, tri = false;
+        if (e < r1) {
+            const int32_t w = c.col[e];
+            ok = walk_valid(c, w);
+            if (ok && prev) tri = sgnn_sorted_contains(c.col_sorted + p0, pdeg, w);
         }
+        nt += __popcll(__ballot(ok && tri));
+        nn += __popcll(__ballot(ok && !tri));
     }
-    return cnt;
 }
 
-__global__ void triangular_walks_kernel(
+// pass 2: the pick-th (0-based, adjacency order) valid neighbour of v in the wanted class
+__device__ static inline int32_t walk_pick(const WalkCtx& c, int32_t v, int32_t prev, bool want_tri, int32_t pick, int lane) {
+    const int64_t r0 = c.rowptr[v], r1 = c.rowptr[v + 1];
+    int64_t p0 = 0;
+    int32_t pdeg = 0;
+    if (prev) { p0 = c.rowptr[prev]; pdeg = (int32_t)(c.rowptr[prev + 1] - p0); }
+    int32_t seen = 0;
+    for (int64_t base = r0; base < r1; base += 64) {
+        const int64_t e = base + lane;
+        bool hit = false;
+        int32_t w = 0;
+        if (e < r1) {
+            w = c.col[e];
+            if (walk_valid(c, w)) {
+                const bool tri = prev ? sgnn_sorted_contains(c.col_sorted + p0, pdeg, w) : false;
+                hit = (tri == want_tri);
+            }
+        }
+        const uint64_t m = __ballot(hit);
+        const int32_t cnt = __popcll(m);
+        if (seen + cnt > pick) {
+            const int32_t rank = __popcll(m & ((1ull << lane) - 1ull));
+            const uint64_t sel = __ballot(hit && (seen + rank == pick));
+            const int src = __ffsll((unsigned long long)sel) - 1;
+            return __shfl(w, src);
+        }
+        seen += cnt;
+    }
+    return 0;
+}
+
+__global__ __launch_bounds__(64) void triangular_walks_kernel(
     const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col, const int32_t* __restrict__ col_sorted,
     const int32_t* __restrict__ node_order, int64_t n_nodes,
     const int64_t* __restrict__ patch_ptr, const int32_t* __restrict__ patch_nodes,
@@ -179,10 +223,10 @@ __global__ void triangular_walks_kernel(
     int mode, int64_t n_items, int64_t walks_per_patch, int64_t walk_len, double beta,
     uint64_t h0, int64_t* __restrict__ out)
 {
-    for (int64_t item = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; item < n_items;
-         item += (int64_t)gridDim.x * blockDim.x) {
+    const int lane = threadIdx.x;
+    for (int64_t item = blockIdx.x; item < n_items; item += gridDim.x) {
         int64_t* o = out + item * walk_len;
-        for (int64_t t = 0; t < walk_len; ++t) o[t] = 0;
+        for (int64_t t = lane; t < walk_len; t += 64) o[t] = 0;
         WalkCtx c;
         c.rowptr = rowptr; c.col = col; c.col_sorted = col_sorted; c.mode = mode;
         c.patch = nullptr; c.n_patch = 0; c.inb = nullptr; c.n_inb = 0;
@@ -206,43 +250,25 @@ __global__ void triangular_walks_kernel(
             }
         }
         if (walk_len < 1) continue;
-        o[0] = prev;
-        int32_t dummy = 0;
-        const int32_t n0 = walk_neighbors(c, prev, -1, &dummy);                          // aps:72,79
-        if (n0 == 0 || walk_len < 2) continue;                                          // aps:83-84
-        int32_t curr = 0;
-        walk_neighbors(c, prev, (int32_t)sgnn_choice_index(h1, j++, (uint32_t)n0), &curr);   // aps:74,80
-        o[1] = curr;
+        __syncthreads();                            // zero fill above precedes the lane-0 writes
+        if (lane == 0) o[0] = prev;
+        int32_t nt, nn;
+        walk_count(c, prev, 0, lane, nt, nn);                                            // aps:72,79
+        if (nn == 0 || walk_len < 2) continue;                                          // aps:83-84
+        int32_t curr = walk_pick(c, prev, 0, false, (int32_t)sgnn_choice_index(h1, j++, (uint32_t)nn), lane);   // aps:74,80
+        if (lane == 0) o[1] = curr;
         for (int64_t step = 2; step < walk_len; ++step) {
-            // pass 1: count triangle / non-triangle candidates in adjacency order (aps:35-45)
-            const int64_t r0 = rowptr[curr], r1 = rowptr[curr + 1];
-            const int64_t p0 = rowptr[prev];
-            const int32_t pdeg = (int32_t)(rowptr[prev + 1] - p0);
-            int32_t nt = 0, nn = 0;
-            for (int64_t e = r0; e < r1; ++e) {
-                const int32_t w = col[e];
-                if (!walk_valid(c, w)) continue;
-                if (sgnn_sorted_contains(col_sorted + p0, pdeg, w)) ++nt; else ++nn;
-            }
+            walk_count(c, curr, prev, lane, nt, nn);                                     // aps:35-45
             if (nt + nn == 0) break;                                                     // aps:94
             bool want_tri;
             if (nt == 0) want_tri = false;                                               // aps:97-98
             else if (nn == 0) want_tri = true;                                           // aps:99-100
             else want_tri = (sgnn_uniform01(h1, j++) <= beta);                           // aps:102
             const int32_t pick = (int32_t)sgnn_choice_index(h1, j++, (uint32_t)(want_tri ? nt : nn));
-            int32_t k = 0, nxt = 0;
-            for (int64_t e = r0; e < r1; ++e) {                                          // pass 2
-                const int32_t w = col[e];
-                if (!walk_valid(c, w)) continue;
-                const bool tri = sgnn_sorted_contains(col_sorted + p0, pdeg, w);
-                if (tri == want_tri) {
-                    if (k == pick) { nxt = w; break; }
-                    ++k;
-                }
-            }
+            const int32_t nxt = walk_pick(c, curr, prev, want_tri, pick, lane);
             prev = curr;
             curr = nxt;
-            o[step] = nxt;
+            if (lane == 0) o[step] = nxt;
         }
     }
 }
@@ -261,7 +287,7 @@ extern "C" int sgnn_triangular_walks(const int64_t* rowptr, const int32_t* col, 
     if (mode == 2 && (!inb_ptr || !inb_nodes)) return SGNN_ERR_BAD_ARG;
     if (nnz >= (1ll << 31)) return SGNN_ERR_NNZ_TOO_LARGE;
     if (n_items == 0 || walk_len == 0) return SGNN_OK;
-    hipLaunchKernelGGL(triangular_walks_kernel, dim3(sgnn_grid_for(n_items, 64)), dim3(64), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(triangular_walks_kernel, dim3((int)(n_items < 256 * 32 ? n_items : 256 * 32)), dim3(64), 0, (hipStream_t)stream,
                        rowptr, col, col_sorted, node_order, n_nodes, patch_ptr, patch_nodes, inb_ptr, inb_nodes,
                        mode, n_items, walks_per_patch, walk_len, beta, sgnn_tape_h0(seed, stream_id), out);
     SGNN_CHECK_LAUNCH();

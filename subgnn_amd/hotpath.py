@@ -70,24 +70,21 @@ def prepare_sparse(model, split='train', timer=None):
     # ---- neighbourhood channel -----------------------------------------------------------
     if hp['use_neighborhood']:
         k = hp['neigh_sample_border_size']
-        border, hops = ops.khop_border(g, cc_sets, k, want_hops=True)
-        t.mark('border_bfs')
-        has_pad_b = (border.lengths < border.max_len).to(torch.uint8)
         has_pad_c = (cc_sets.lengths < Lc).to(torch.uint8)
         ni, nb = {}, {}
         for l in range(L):
             ni[l] = ops.sample_anchors_ragged(cc_sets, hp['n_anchor_patches_N_in'], seed,
                                               tape.stream_id(tape.STREAM_N_INT, split, l), has_pad_c).view(S, C, -1)
-            a, pos = ops.sample_anchors_ragged(border, hp['n_anchor_patches_N_out'], seed,
-                                               tape.stream_id(tape.STREAM_N_BOR, split, l), has_pad_b, want_pos=True)
-            nb[l] = a.view(S, C, -1)
             sims[('N', 'in', l)] = torch.zeros(ni[l].shape, dtype=torch.float32, device=dev)
-            w = hops[pos.clamp(min=0)].to(torch.float32) * (pos >= 0)
+            # border BFS fused with the border-anchor draw: the border is never materialised
+            a, w, _ = ops.khop_border_sample(g, cc_sets, k, hp['n_anchor_patches_N_out'], seed,
+                                             tape.stream_id(tape.STREAM_N_BOR, split, l))
+            nb[l] = a.view(S, C, -1)
             sims[('N', 'out', l)] = w.view(S, C, -1).contiguous()
+        t.mark('border_bfs+N_anchors')
         if getattr(model, 'anchors_neigh_int', None) is None:
             model.anchors_neigh_int, model.anchors_neigh_border = {}, {}
         model.anchors_neigh_int[split], model.anchors_neigh_border[split] = ni, nb
-        t.mark('N_anchors')
     # ---- position channel ----------------------------------------------------------------
     if hp['use_position']:
         if getattr(model, 'anchors_pos_ext', None) is None or split != 'test':

@@ -162,15 +162,20 @@ def cc_labels(g, subs):
     return out
 
 
-def khop_border(g, sets, k, ego_dict_mode=False, want_hops=False):
+def _khop_ws(lib, g, n_sets):
+    ws_bytes = lib.sgnn_khop_border_workspace_bytes(g.max_id, n_sets)
+    return torch.zeros(ws_bytes // 4 + 1, dtype=torch.int32, device=g.device), ws_bytes
+
+
+def khop_border(g, sets, k, ego_dict_mode=False, want_hops=False, bitmap_in_lds=None):
     """k-hop border of every set -> Ragged (discovery order) [+ uint8 hop level per entry]."""
     lib = _lib.load()
-    ws_bytes = lib.sgnn_khop_border_workspace_bytes(g.max_id, sets.n)
-    ws = torch.zeros(ws_bytes // 4 + 1, dtype=torch.int32, device=g.device)
+    lds = bool(lib.sgnn_khop_border_bitmap_fits_lds(g.max_id)) if bitmap_in_lds is None else bool(bitmap_in_lds)
+    ws, ws_bytes = _khop_ws(lib, g, sets.n)
     counts = torch.zeros(sets.n, dtype=torch.int64, device=g.device)
     check(lib.sgnn_khop_border(_ptr(g.rowptr), _ptr(g.col), g.nnz, g.max_id, _ptr(sets.ptr), _ptr(sets.nodes), sets.n,
                                k, 1 if ego_dict_mode else 0, _ptr(counts), None, None, None, _ptr(ws), ws_bytes,
-                               _stream()), 'sgnn_khop_border(count)')
+                               1 if lds else 0, _stream()), 'sgnn_khop_border(count)')
     ptr = torch.zeros(sets.n + 1, dtype=torch.int64, device=g.device)
     torch.cumsum(counts, 0, out=ptr[1:])
     total = int(ptr[-1].item())
@@ -178,9 +183,33 @@ def khop_border(g, sets, k, ego_dict_mode=False, want_hops=False):
     hops = torch.zeros(max(total, 1), dtype=torch.uint8, device=g.device) if want_hops else None
     check(lib.sgnn_khop_border(_ptr(g.rowptr), _ptr(g.col), g.nnz, g.max_id, _ptr(sets.ptr), _ptr(sets.nodes), sets.n,
                                k, 1 if ego_dict_mode else 0, None, _ptr(ptr), _ptr(nodes), _ptr(hops), _ptr(ws),
-                               ws_bytes, _stream()), 'sgnn_khop_border(fill)')
+                               ws_bytes, 1 if lds else 0, _stream()), 'sgnn_khop_border(fill)')
     r = Ragged(ptr, nodes)
     return (r, hops) if want_hops else r
+
+
+def khop_border_sample(g, sets, k, n_slots, seed, stream_id, bitmap_in_lds=None):
+    """Fused k-hop border BFS + neighbourhood-border anchor draw (the border is never
+    materialised).  Returns anchors (n_sets, n_slots) int64 with the reference's PAD rule applied,
+    their hop levels as float32 similarities (0 on PAD) and the border sizes."""
+    lib = _lib.load()
+    lds = bool(lib.sgnn_khop_border_bitmap_fits_lds(g.max_id)) if bitmap_in_lds is None else bool(bitmap_in_lds)
+    ws, ws_bytes = _khop_ws(lib, g, sets.n)
+    anchor = torch.empty((sets.n, n_slots), dtype=torch.int64, device=g.device)
+    hop = torch.empty((sets.n, n_slots), dtype=torch.uint8, device=g.device)
+    allneg = torch.empty((sets.n, n_slots), dtype=torch.uint8, device=g.device)
+    counts = torch.zeros(sets.n, dtype=torch.int64, device=g.device)
+    check(lib.sgnn_khop_border_sample(_ptr(g.rowptr), _ptr(g.col), g.nnz, g.max_id, _ptr(sets.ptr), _ptr(sets.nodes),
+                                      sets.n, k, n_slots, seed, stream_id, _ptr(anchor), _ptr(hop), _ptr(allneg),
+                                      _ptr(counts), _ptr(ws), ws_bytes, 1 if lds else 0, _stream()),
+          'sgnn_khop_border_sample')
+    # aps:190: padded columns hold 0, so PAD wins when every real variate is negative and the
+    # padded row (width = the largest border) has at least one PAD column
+    has_pad = (counts < counts.max()).unsqueeze(1)
+    pad = (allneg != 0) & has_pad
+    anchor = torch.where(pad, torch.zeros_like(anchor), anchor)
+    sims = torch.where(pad | (anchor == 0), torch.zeros((), device=g.device), hop.to(torch.float32))
+    return anchor, sims, counts
 
 
 def sort_ragged(r, extra=None):

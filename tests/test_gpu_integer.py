@@ -32,6 +32,7 @@ def _rand_graph(n, m, seed):
     edges = list(Gx.edges())
     edges = [edges[i] for i in rng.permutation(len(edges))]
     edges += [(3, 3), (10, 10)]                           # self loops
+    edges += [(0, i) for i in range(1, min(n, 1300))] + [(7, i) for i in range(8, min(n, 700))]   # hubs (deg >= 256 path)
     return OG.from_edge_pairs(edges)
 
 
@@ -77,6 +78,8 @@ def test_degree_sequence_random(sizes):
             s = s + s[:3]                                  # duplicates
         if i % 11 == 0:
             s = [3, 10] + s
+        if i % 5 == 0:
+            s = [1, 8] + s                                 # the two hubs (ids are +1)
         s = s[:sizes[1]]
         sets.append(s)
     sets[5] = []
@@ -146,8 +149,8 @@ def test_khop_border_golden(golden):
     G, dg = _graphs(golden)
     cc = torch.from_numpy(golden['g2_cc_ids_train']).to(DEV)
     r = ops.Ragged.from_padded(cc.view(-1, cc.shape[-1]))
-    for k in (1, 2, 3):
-        b, hops = ops.khop_border(dg, r, k, ego_dict_mode=golden.has_ego, want_hops=True)
+    for k, lds in ((1, True), (2, True), (3, True), (1, False), (2, False), (3, False)):
+        b, hops = ops.khop_border(dg, r, k, ego_dict_mode=golden.has_ego, want_hops=True, bitmap_in_lds=lds)
         b, hops = ops.sort_ragged(b, hops)
         assert b.to_lists() == golden.ragged('g3_border_k%d_train' % k, -1)
         if not golden.has_ego:
@@ -166,9 +169,38 @@ def test_khop_border_workspace_left_clean():
     rng = np.random.default_rng(1)
     sets = [list({int(v) for v in rng.integers(1, G.max_id() + 1, int(rng.integers(1, 6)))}) for _ in range(3000)]
     r = ops.Ragged.from_lists(sets, DEV)
-    b = ops.sort_ragged(ops.khop_border(dg, r, 2)).to_lists()
-    for i in range(0, 3000, 37):
-        assert b[i] == sorted(IH.component_border_set(G, sets[i], 2))
+    for lds in (True, False):
+        b = ops.sort_ragged(ops.khop_border(dg, r, 2, bitmap_in_lds=lds)).to_lists()
+        for i in range(0, 3000, 37):
+            assert b[i] == sorted(IH.component_border_set(G, sets[i], 2))
+
+
+@pytest.mark.parametrize('lds', [True, False])
+@pytest.mark.parametrize('k', [1, 2])
+def test_khop_border_sample_equals_materialised_draw(k, lds):
+    """Fused BFS + anchor draw == (materialise the border, pad it, run the reference-shaped
+    padded sampler), including the PAD rule and the hop level of every drawn anchor."""
+    ops = _ops()
+    G = _rand_graph(600, 2, 11)
+    dg = _dev_graph(G)
+    rng = np.random.default_rng(4)
+    sets = [list({int(v) for v in rng.integers(1, G.max_id() + 1, int(rng.integers(1, 5)))}) for _ in range(700)]
+    sets[3] = []
+    r = ops.Ragged.from_lists(sets, DEV)
+    A, seed, st = 7, 99, T.stream_id(T.STREAM_N_BOR, 'val', 1)
+    anchors, sims, counts = ops.khop_border_sample(dg, r, k, A, seed, st, bitmap_in_lds=lds)
+    b, hops = ops.sort_ragged(*ops.khop_border(dg, r, k, want_hops=True))
+    padded = b.to_padded()
+    ref = ops.sample_anchors_padded(padded, A, seed, st)
+    assert torch.equal(anchors, ref)
+    assert torch.equal(counts, b.lengths)
+    bl, hl = b.to_lists(), ops.Ragged(b.ptr, hops.to(torch.int32)).to_lists()
+    an, sm = anchors.cpu().numpy(), sims.cpu().numpy()
+    for i in range(0, 700, 13):
+        lev = dict(zip(bl[i], hl[i]))
+        for a in range(A):
+            assert sm[i, a] == (lev[an[i, a]] if an[i, a] != 0 else 0)
+    assert (an == 0).any()          # the PAD rule fires on small borders
 
 
 # ---- a4 neighbourhood anchors -------------------------------------------------------------
