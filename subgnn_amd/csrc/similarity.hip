@@ -208,50 +208,88 @@ extern "C" int sgnn_min_hops_to_sets(const uint8_t* dist, int64_t n_sources, int
 // a11  1 / (1 + fastdtw(x, y, radius=1, dist=calc_dist))  (reference SubGNN/gamma.py:51-59)
 //
 // One lane per (component, anchor) pair; fp64 DP.  fastdtw's recursion is unrolled bottom-up:
-// the halved series of every level are built first, the coarsest level (either length < 3)
-// runs a full-window DTW, and each finer level derives its window from the coarser warp path.
-// Because a warp path is monotone, the published expand_window (dilate by radius 1, project to
-// the fine grid, keep one contiguous run per row starting no earlier than the previous row's)
-// reduces to per-row bounds
-//     lo_i = max(0, 2*(first_col[max(ci-1,0)] - 1)),   hi_i = min(ly-1, 2*(last_col[min(ci+1,lxc-1)] + 1) + 1)
-// with ci = i/2 and first/last_col the coarse path's column range per coarse row, so only those
-// two small arrays travel between levels.  The DP keeps two rolling rows plus one predecessor
-// code per window cell for the backtrack.  All per-lane state lives in a caller workspace,
-// element-interleaved across lanes so that lanes in lockstep touch consecutive addresses.
-// VALU / latency-bound (one fp64 divide per cell); not an HBM kernel.
+//   * a pre-kernel builds the halved series ("pyramid") of every x row and every y row ONCE
+//     (each x row meets every anchor, each anchor every x row), x transposed so that the lanes
+//     of a wavefront -- consecutive components, same anchor -- read it coalesced, y read
+//     wave-uniformly;
+//   * per pair, the coarsest level (either length < 3) runs a full-window DTW, and each finer
+//     level derives its window from the coarser warp path.  Because a warp path is monotone, the
+//     published expand_window (dilate by radius 1, project to the fine grid, keep one contiguous
+//     run per row starting no earlier than the previous row's) reduces to per-row bounds
+//       lo_i = max(0, 2*(first_col[max(ci-1,0)] - 1)),  hi_i = min(ly-1, 2*(last_col[min(ci+1,lxc-1)] + 1) + 1)
+//     with ci = i/2 and first/last_col the coarse path's column range per coarse row, so only
+//     those two small arrays travel between levels;
+//   * the DP keeps two rolling rows (the diagonal predecessor stays in a register) and a 2-bit
+//     predecessor code per window cell for the backtrack.
+// Per-lane state (~1.4 KB at 20 x 50) lives in a caller workspace, element-interleaved across
+// lanes so that lanes in lockstep touch consecutive addresses; the resident thread count is kept
+// small enough for that scratch to stay in the Infinity Cache (the first version's 3.5 KB x 131k
+// lanes spilled to HBM and waited on it 78 % of the time).  VALU / latency-bound (one fp64
+// divide per cell); not an HBM kernel.
 // ---------------------------------------------------------------------------------------------
 #define DTW_THREADS 256
+#ifndef DTW_BLOCKS
 #define DTW_BLOCKS (256 * 2)
+#endif
 #define DTW_NT ((int64_t)DTW_THREADS * DTW_BLOCKS)
+#define DTW_MAX_LEVELS 16
 
-struct DtwLayout {                 // element counts per lane
-    int64_t n_dbl;                 // xs(2MX) ys(2MY) prev(MY) cur(MY)
-    int64_t n_i32;                 // rowstart(MX) lo(MX) hi(MX) first[2](MX each) last[2](MX each)
-    int64_t n_u8;                  // dir(MX*MY)
-    int64_t off_ys, off_prev, off_cur;
-    int64_t off_lo, off_hi, off_first, off_last;
+struct DtwLayout {
+    int64_t MX, MY;
+    int64_t XL, YL;                // pyramid lengths per sequence (sum of M >> k)
+    int64_t n_dbl;                 // per lane: prev(MY) cur(MY)
+    int64_t n_i32;                 // per lane: rowstart(MX) lohi(MX) firstlast[2](MX each)
+    int64_t n_dir;                 // per lane: ceil(MX*MY/16) words of 2-bit codes
+    int64_t xoff[DTW_MAX_LEVELS], yoff[DTW_MAX_LEVELS];
 };
 
 static inline DtwLayout dtw_layout(int64_t MX, int64_t MY) {
     DtwLayout L;
-    L.off_ys = 2 * MX;
-    L.off_prev = L.off_ys + 2 * MY;
-    L.off_cur = L.off_prev + MY;
-    L.n_dbl = L.off_cur + MY;
-    L.off_lo = MX;
-    L.off_hi = 2 * MX;
-    L.off_first = 3 * MX;          // two ping-pong halves of MX each
-    L.off_last = 5 * MX;
-    L.n_i32 = 7 * MX;
-    L.n_u8 = MX * MY;
+    L.MX = MX; L.MY = MY;
+    int64_t xo = 0, yo = 0;
+    for (int k = 0; k < DTW_MAX_LEVELS; ++k) {
+        L.xoff[k] = xo; L.yoff[k] = yo;
+        xo += (MX >> k) > 0 ? (MX >> k) : 0;
+        yo += (MY >> k) > 0 ? (MY >> k) : 0;
+    }
+    L.XL = xo; L.YL = yo;
+    L.n_dbl = 2 * MY;
+    L.n_i32 = 4 * MX;
+    L.n_dir = (MX * MY + 15) / 16;
     return L;
 }
 
-extern "C" int64_t sgnn_dtw_workspace_bytes(int64_t max_x_len, int64_t max_y_len) {
+static inline int64_t dtw_align8(int64_t b) { return (b + 7) / 8 * 8; }
+
+extern "C" int64_t sgnn_dtw_workspace_bytes(int64_t n_x, int64_t max_x_len, int64_t n_y, int64_t max_y_len) {
     if (max_x_len < 1) max_x_len = 1;
     if (max_y_len < 1) max_y_len = 1;
     const DtwLayout L = dtw_layout(max_x_len, max_y_len);
-    return DTW_NT * (L.n_dbl * 8 + L.n_i32 * 4 + ((L.n_u8 + 7) / 8) * 8);
+    return DTW_NT * (L.n_dbl * 8 + dtw_align8(L.n_i32 * 4) + dtw_align8(L.n_dir * 4))
+         + n_x * L.XL * 8 + n_y * L.YL * 8 + dtw_align8(n_x * 4) + dtw_align8(n_y * 4);
+}
+
+// pyramid of one series per thread.  transposed != 0: element e of sequence s at out[e * n + s]
+__global__ void dtw_pyramid_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ val, int64_t n,
+                                   int64_t M, int64_t PL, int transposed, double* __restrict__ out,
+                                   int32_t* __restrict__ len_out)
+{
+    for (int64_t s = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; s < n; s += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = ptr[s];
+        int len = (int)(ptr[s + 1] - b);
+        len_out[s] = len;
+#define PY(e) out[transposed ? (int64_t)(e) * n + s : s * PL + (e)]
+        for (int i = 0; i < len; ++i) PY(i) = (double)val[b + i];
+        int64_t off = 0;
+        int k = 0;
+        while (len >= 2 && k + 1 < DTW_MAX_LEVELS) {
+            const int64_t noff = off + (M >> k);
+            const int nlen = len / 2;
+            for (int i = 0; i < nlen; ++i) PY(noff + i) = (PY(off + 2 * i) + PY(off + 2 * i + 1)) / 2.0;
+            off = noff; len = nlen; ++k;
+        }
+#undef PY
+    }
 }
 
 __device__ static inline double dtw_cost(double a, double b) {            // gamma.py:51-52
@@ -260,87 +298,77 @@ __device__ static inline double dtw_cost(double a, double b) {            // gam
 }
 
 __global__ __launch_bounds__(DTW_THREADS) void dtw_similarity_kernel(
-    const int64_t* __restrict__ x_ptr, const int32_t* __restrict__ x_val, int64_t n_x,
-    const int64_t* __restrict__ y_ptr, const int32_t* __restrict__ y_val, int64_t n_y,
+    const double* __restrict__ xpyr, const int32_t* __restrict__ xlen, int64_t n_x,
+    const double* __restrict__ ypyr, const int32_t* __restrict__ ylen, int64_t n_y,
     int tie_order, float* __restrict__ out, double* __restrict__ wd, int32_t* __restrict__ wi,
-    uint8_t* __restrict__ wb, DtwLayout L)
+    uint32_t* __restrict__ wb, DtwLayout L)
 {
     const int64_t NT = (int64_t)gridDim.x * blockDim.x;
     const int64_t tid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
 #define WD(k) wd[(int64_t)(k) * NT + tid]
 #define WI(k) wi[(int64_t)(k) * NT + tid]
 #define WB(k) wb[(int64_t)(k) * NT + tid]
+#define ROWSTART(i) WI(i)
+#define LOHI(i) WI(L.MX + (i))
+#define FL(h, i) WI((2 + (h)) * L.MX + (i))
     // predecessor codes: 0 = (i-1,j), 1 = (i,j-1), 2 = (i-1,j-1); evaluation order per tie_order
     const int o0 = tie_order == 0 ? 0 : 2, o1 = tie_order == 0 ? 1 : 0, o2 = tie_order == 0 ? 2 : 1;
+    const double INF = __longlong_as_double(0x7ff0000000000000ll);
     const int64_t total = n_x * n_y;
     for (int64_t pair = tid; pair < total; pair += NT) {
-        const int64_t r = pair / n_y, a = pair % n_y;
-        const int64_t xb = x_ptr[r], yb = y_ptr[a];
-        const int lx0 = (int)(x_ptr[r + 1] - xb), ly0 = (int)(y_ptr[a + 1] - yb);
-        if (lx0 == 0 || ly0 == 0) { out[pair] = 0.f; continue; }        // padded row: PAD (SubGNN.py:831)
-        // ---- build the halved series of every level ------------------------------------
-        for (int i = 0; i < lx0; ++i) WD(i) = (double)x_val[xb + i];
-        for (int i = 0; i < ly0; ++i) WD(L.off_ys + i) = (double)y_val[yb + i];
+        // consecutive lanes: consecutive components, same anchor
+        const int64_t a = pair / n_x, r = pair % n_x;
+        const int lx0 = xlen[r], ly0 = ylen[a];
+        if (lx0 == 0 || ly0 == 0) { out[r * n_y + a] = 0.f; continue; }     // padded row: PAD (SubGNN.py:831)
+        const double* __restrict__ yp = ypyr + a * L.YL;
         int n_levels = 1;
-        int lx = lx0, ly = ly0, xo = 0, yo = 0;
-        int lxs[24], lys[24], xos[24], yos[24];
-        lxs[0] = lx; lys[0] = ly; xos[0] = 0; yos[0] = 0;
-        while (lx >= 3 && ly >= 3) {
-            const int nlx = lx / 2, nly = ly / 2;
-            const int nxo = xo + lx, nyo = yo + ly;
-            for (int i = 0; i < nlx; ++i) WD(nxo + i) = (WD(xo + 2 * i) + WD(xo + 2 * i + 1)) / 2.0;
-            for (int i = 0; i < nly; ++i) WD(L.off_ys + nyo + i) = (WD(L.off_ys + yo + 2 * i) + WD(L.off_ys + yo + 2 * i + 1)) / 2.0;
-            lx = nlx; ly = nly; xo = nxo; yo = nyo;
-            lxs[n_levels] = lx; lys[n_levels] = ly; xos[n_levels] = xo; yos[n_levels] = yo;
-            ++n_levels;
+        {
+            int lx = lx0, ly = ly0;
+            while (lx >= 3 && ly >= 3) { lx >>= 1; ly >>= 1; ++n_levels; }
         }
         double result = 0.0;
-        // ---- coarsest -> finest ---------------------------------------------------------
         for (int lev = n_levels - 1; lev >= 0; --lev) {
-            lx = lxs[lev]; ly = lys[lev]; xo = xos[lev]; yo = yos[lev];
-            const int64_t fcur = L.off_first + (int64_t)(lev & 1) * (L.off_lo);      // ping-pong halves (MX each)
-            const int64_t lcur = L.off_last + (int64_t)(lev & 1) * (L.off_lo);
-            const int64_t fprev = L.off_first + (int64_t)((lev + 1) & 1) * (L.off_lo);
-            const int64_t lprev = L.off_last + (int64_t)((lev + 1) & 1) * (L.off_lo);
-            // window bounds per row
-            int cells = 0;
+            const int lx = lx0 >> lev, ly = ly0 >> lev;
+            const int64_t xo = L.xoff[lev], yo = L.yoff[lev];
+            const int hc = lev & 1, hp = (lev + 1) & 1;        // ping-pong halves of first/last
             if (lev == n_levels - 1) {
-                for (int i = 0; i < lx; ++i) { WI(L.off_lo + i) = 0; WI(L.off_hi + i) = ly - 1; WI(i) = cells; cells += ly; }
+                int cells = 0;
+                for (int i = 0; i < lx; ++i) { LOHI(i) = (ly - 1) << 16; ROWSTART(i) = cells; cells += ly; }
             } else {
-                const int lxc = lxs[lev + 1];
-                int prev_lo = 0;
+                const int lxc = lx0 >> (lev + 1);
+                int prev_lo = 0, cells = 0;
                 for (int i = 0; i < lx; ++i) {
                     const int ci = i >> 1;
                     const int ca = ci - 1 < 0 ? 0 : (ci - 1 > lxc - 1 ? lxc - 1 : ci - 1);
                     const int cb = ci + 1 > lxc - 1 ? lxc - 1 : ci + 1;
-                    int lo = 2 * (WI(fprev + ca) - 1);
-                    int hi = 2 * (WI(lprev + cb) + 1) + 1;
-                    if (ci - 1 > lxc - 1) { lo = ly; hi = -1; }          // no coarse cell within radius
+                    int lo = 2 * ((FL(hp, ca) & 0xffff) - 1);
+                    int hi = 2 * ((FL(hp, cb) >> 16) + 1) + 1;
                     if (lo < prev_lo) lo = prev_lo;
                     if (lo < 0) lo = 0;
                     if (hi > ly - 1) hi = ly - 1;
-                    WI(L.off_lo + i) = lo; WI(L.off_hi + i) = hi; WI(i) = cells;
+                    if (hi < lo) { lo = 1; hi = 0; }           // empty row marker
+                    LOHI(i) = (hi << 16) | lo;
+                    ROWSTART(i) = cells;
                     if (hi >= lo) { cells += hi - lo + 1; prev_lo = lo; }
                 }
             }
-            // DP over the window, row-major (the published evaluation order)
-            const double INF = __longlong_as_double(0x7ff0000000000000ll);
-            int64_t prow = L.off_prev, crow = L.off_cur;
+            // DP over the window, row-major (any topological order gives the same cells)
+            int64_t prow = 0, crow = L.MY;
             int plo = 0, phi = -1;
+            uint32_t acc = 0;
+            int cell = 0;
             for (int i = 0; i < lx; ++i) {
-                const int lo = WI(L.off_lo + i), hi = WI(L.off_hi + i);
-                const int rs = WI(i);
-                const double xi = WD(xo + i);
+                const int lohi = LOHI(i);
+                const int lo = lohi & 0xffff, hi = lohi >> 16;
+                const double xi = xpyr[(xo + i) * n_x + r];
                 double left = INF;
+                double diag = INF;
+                if (i == 0) { if (lo == 0) diag = 0.0; }
+                else if (lo - 1 >= plo && lo - 1 <= phi) diag = WD(prow + lo - 1);
                 for (int j = lo; j <= hi; ++j) {
-                    const double dt = dtw_cost(xi, WD(L.off_ys + yo + j));
-                    double up = INF, diag = INF;
-                    if (i == 0) { if (j == 0) diag = 0.0; }
-                    else {
-                        if (j >= plo && j <= phi) up = WD(prow + j);
-                        if (j - 1 >= plo && j - 1 <= phi) diag = WD(prow + j - 1);
-                    }
-                    if (j == lo) left = INF;
+                    const double dt = dtw_cost(xi, yp[yo + j]);
+                    double up = INF;
+                    if (i > 0 && j >= plo && j <= phi) up = WD(prow + j);
                     double c[3];
                     c[0] = up + dt; c[1] = left + dt; c[2] = diag + dt;
                     int best = o0;
@@ -348,30 +376,42 @@ __global__ __launch_bounds__(DTW_THREADS) void dtw_similarity_kernel(
                     if (c[o1] < bc) { bc = c[o1]; best = o1; }
                     if (c[o2] < bc) { bc = c[o2]; best = o2; }
                     WD(crow + j) = bc;
-                    WB(rs + (j - lo)) = (uint8_t)best;
+                    acc |= (uint32_t)best << ((cell & 15) * 2);
+                    if ((cell & 15) == 15) { WB(cell >> 4) = acc; acc = 0; }
+                    ++cell;
                     left = bc;
+                    diag = up;                                  // (i-1, j) is the diagonal of (i, j+1)
                 }
                 if (hi >= lo) { const int64_t t = prow; prow = crow; crow = t; plo = lo; phi = hi; }
             }
+            if (cell & 15) WB(cell >> 4) = acc;
             result = WD(prow + (ly - 1));
             if (lev == 0) break;
             // backtrack: column range of the path per row of THIS level
+            for (int q = 0; q < lx; ++q) FL(hc, q) = ((-1) << 16) | 0xffff;     // last = -1, first = 65535
             int i = lx - 1, j = ly - 1;
-            for (int q = 0; q < lx; ++q) { WI(fcur + q) = ly; WI(lcur + q) = -1; }
             while (i >= 0 && j >= 0) {
-                if (WI(lcur + i) < j) WI(lcur + i) = j;
-                if (WI(fcur + i) > j) WI(fcur + i) = j;
-                const int lo = WI(L.off_lo + i), hi = WI(L.off_hi + i);
-                if (j < lo || j > hi) break;                                // cannot happen for a finite path
-                const int d = WB(WI(i) + (j - lo));
+                const int fl = FL(hc, i);
+                int first = fl & 0xffff, last = fl >> 16;
+                if (last < j) last = j;
+                if (first > j) first = j;
+                FL(hc, i) = (last << 16) | first;
+                const int lohi = LOHI(i);
+                const int lo = lohi & 0xffff, hi = lohi >> 16;
+                if (j < lo || j > hi) break;                    // cannot happen for a finite path
+                const int c = ROWSTART(i) + (j - lo);
+                const int d = (WB(c >> 4) >> ((c & 15) * 2)) & 3;
                 if (d == 0) --i; else if (d == 1) --j; else { --i; --j; }
             }
         }
-        out[pair] = (float)(1.0 / (result + 1.0));
+        out[r * n_y + a] = (float)(1.0 / (result + 1.0));
     }
 #undef WD
 #undef WI
 #undef WB
+#undef ROWSTART
+#undef LOHI
+#undef FL
 }
 
 extern "C" int sgnn_dtw_similarity(const int64_t* x_ptr, const int32_t* x_val, int64_t n_x, int64_t max_x_len,
@@ -382,14 +422,27 @@ extern "C" int sgnn_dtw_similarity(const int64_t* x_ptr, const int32_t* x_val, i
     if (tie_order < 0 || tie_order > 1) return SGNN_ERR_BAD_ARG;
     if (max_x_len < 1) max_x_len = 1;
     if (max_y_len < 1) max_y_len = 1;
-    if (workspace_bytes < sgnn_dtw_workspace_bytes(max_x_len, max_y_len)) return SGNN_ERR_BAD_ARG;
+    if (max_x_len > 32767 || max_y_len > 32767) return SGNN_ERR_SET_TOO_LARGE;
+    if (workspace_bytes < sgnn_dtw_workspace_bytes(n_x, max_x_len, n_y, max_y_len)) return SGNN_ERR_BAD_ARG;
     if (n_x * n_y == 0) return SGNN_OK;
     const DtwLayout L = dtw_layout(max_x_len, max_y_len);
-    double* wd = (double*)workspace;
-    int32_t* wi = (int32_t*)(wd + L.n_dbl * DTW_NT);
-    uint8_t* wb = (uint8_t*)(wi + L.n_i32 * DTW_NT);
-    hipLaunchKernelGGL(dtw_similarity_kernel, dim3(DTW_BLOCKS), dim3(DTW_THREADS), 0, (hipStream_t)stream, x_ptr,
-                       x_val, n_x, y_ptr, y_val, n_y, tie_order, out, wd, wi, wb, L);
+    hipStream_t st = (hipStream_t)stream;
+    char* w = (char*)workspace;
+    double* wd = (double*)w;               w += DTW_NT * L.n_dbl * 8;
+    int32_t* wi = (int32_t*)w;             w += DTW_NT * dtw_align8(L.n_i32 * 4);
+    uint32_t* wb = (uint32_t*)w;           w += DTW_NT * dtw_align8(L.n_dir * 4);
+    double* xpyr = (double*)w;             w += n_x * L.XL * 8;
+    double* ypyr = (double*)w;             w += n_y * L.YL * 8;
+    int32_t* xlen = (int32_t*)w;           w += dtw_align8(n_x * 4);
+    int32_t* ylen = (int32_t*)w;
+    hipLaunchKernelGGL(dtw_pyramid_kernel, dim3(sgnn_grid_for(n_x, 256)), dim3(256), 0, st, x_ptr, x_val, n_x,
+                       max_x_len, L.XL, 1, xpyr, xlen);
+    SGNN_CHECK_LAUNCH();
+    hipLaunchKernelGGL(dtw_pyramid_kernel, dim3(sgnn_grid_for(n_y, 256)), dim3(256), 0, st, y_ptr, y_val, n_y,
+                       max_y_len, L.YL, 0, ypyr, ylen);
+    SGNN_CHECK_LAUNCH();
+    hipLaunchKernelGGL(dtw_similarity_kernel, dim3(DTW_BLOCKS), dim3(DTW_THREADS), 0, st, xpyr, xlen, n_x, ypyr, ylen,
+                       n_y, tie_order, out, wd, wi, wb, L);
     SGNN_CHECK_LAUNCH();
     return SGNN_OK;
 }

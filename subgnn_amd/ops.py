@@ -325,7 +325,7 @@ def dtw_similarity(x_ptr, x_val, max_x, y_ptr, y_val, max_y, tie_order=0):
         _req(t, torch.int32, nm)
     nx, ny = x_ptr.numel() - 1, y_ptr.numel() - 1
     out = torch.empty((nx, ny), dtype=torch.float32, device=x_ptr.device)
-    wsb = lib.sgnn_dtw_workspace_bytes(max_x, max_y)
+    wsb = lib.sgnn_dtw_workspace_bytes(nx, max_x, ny, max_y)
     ws = torch.empty(wsb // 8 + 1, dtype=torch.int64, device=x_ptr.device)
     check(lib.sgnn_dtw_similarity(_ptr(x_ptr), _ptr(x_val), nx, max_x, _ptr(y_ptr), _ptr(y_val), ny, max_y, tie_order,
                                   _ptr(out), _ptr(ws), wsb, _stream()), 'sgnn_dtw_similarity')

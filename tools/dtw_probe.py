@@ -1,0 +1,27 @@
+"""Stand-alone driver of the DTW similarity kernel on benchmark-shaped inputs (for rocprofv3)."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from subgnn_amd import ops, synthetic, tape
+
+n, m, S = 1_000_000, 10, 50_000
+edges = synthetic.barabasi_albert_edges(n, m, seed=42)
+rowptr, col = synthetic.sorted_csr(edges, n)
+subs = synthetic.bfs_subgraphs(rowptr, col, S, 20, seed=1000)
+dev = torch.device('cuda:0')
+g = ops.DeviceGraph(rowptr, col, np.arange(1, n + 1, dtype=np.int32), dev)
+sets = ops.Ragged.from_lists(subs, dev)
+patches = ops.triangular_walks(g, 0, 210, 50, 0.65, 0, tape.stream_id(tape.STREAM_STRUCT_PATCH))
+a_sets = ops.Ragged.from_padded(patches)
+ai, ae = ops.degree_sequence(g, a_sets)
+ci, ce = ops.degree_sequence(g, sets)
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+for nm, x, y in (('internal', ci, ai), ('external', ce, ae)):
+    ops.dtw_similarity(sets.ptr, x, 20, a_sets.ptr, y, 50)
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    for _ in range(reps):
+        out = ops.dtw_similarity(sets.ptr, x, 20, a_sets.ptr, y, 50)
+    torch.cuda.synchronize()
+    print(nm, (time.perf_counter() - t) / reps * 1e3, 'ms', float(out.double().sum()))
