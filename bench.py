@@ -107,6 +107,7 @@ def main():
         dist.init_process_group('nccl', device_id=dev)
 
     from subgnn_amd import ops, hotpath, build
+    from subgnn_amd import dist as sdist
     from subgnn_amd.SubGNN import SubGNN
     if rank == 0 and build.needs_build():
         build.build(verbose=False)
@@ -141,20 +142,12 @@ def main():
         model.backward(None, out['loss'], None, 0)
         timer.mark('backward')
         if dist:
-            # all-gather of the per-component channel embeddings (north_star): every rank ends up
-            # with the (world * S * C, hid_dim) matrix of the global batch
-            cc = model._last_cc_embeds
-            gathered = torch.empty((world * cc.shape[0], cc.shape[1]), dtype=cc.dtype, device=dev)
-            dist.all_gather_into_tensor(gathered, cc)
-            flat = torch.cat([p.grad.reshape(-1) for p in params if p.grad is not None])
-            dist.all_reduce(flat)
-            flat /= world
-            off = 0
-            for p in params:
-                if p.grad is not None:
-                    k = p.grad.numel()
-                    p.grad.copy_(flat[off:off + k].view_as(p.grad))
-                    off += k
+            # the path's one exchange step: all-gather of the per-component channel embeddings
+            # (every rank ends up with the (world * S * C, hid_dim) matrix of the global batch);
+            # DP training additionally all-reduces the gradients, one flat bucket
+            gathered = sdist.all_gather_rows(model._last_cc_embeds)
+            assert gathered.shape[0] == world * model._last_cc_embeds.shape[0]
+            sdist.all_reduce_gradients(params)
             timer.mark('collectives')
         torch.nn.utils.clip_grad_norm_(params, hp['grad_clip'])
         opt.step()

@@ -1,0 +1,195 @@
+"""cpu_baseline leg of bench.py: the oracle (plain C + numpy + torch-CPU restatement of the
+same sparse algorithm the GPU path runs) timed on the host cores.  TEST INFRASTRUCTURE.
+
+The reference's own Python cannot run at this scale (dense N x N structures, SURVEY.md section 7
+hard part 5) and does not travel to the GPU box, so kind = "port".  A full CPU pass over the
+50k-subgraph shard would take hours; the baseline is therefore measured on a BOUNDED sample and
+extrapolated linearly, stage by stage:
+
+  per-subgraph stages (components, 1-hop border, N/P anchor draws, degree sequences, DTW against
+      all structure patches, position similarities, forward + backward + Adam)  -> timed on
+      ``n_sample`` subgraphs, scaled by S / n_sample;
+  shared stages (structure patches + their walks, multi-source BFS from the P-border anchors) ->
+      timed on a few patches / sources, scaled to the full count, counted once per pass.
+"""
+import time
+
+import numpy as np
+import torch
+
+from . import cbind, float_half as FH, integer_half as IH, tape as T
+from .graph import CSRGraph
+
+
+def _bfs_hops_numpy(rowptr, col, src, n):
+    dist = np.full(n + 1, 255, dtype=np.uint8)
+    dist[src] = 0
+    frontier = np.array([src], dtype=np.int64)
+    level = 0
+    while len(frontier) and level < 254:
+        level += 1
+        starts, ends = rowptr[frontier], rowptr[frontier + 1]
+        lens = ends - starts
+        idx = np.repeat(starts - np.cumsum(lens) + lens, lens) + np.arange(int(lens.sum()))
+        nb = np.unique(col[idx])
+        nb = nb[dist[nb] == 255]
+        dist[nb] = level
+        frontier = nb.astype(np.int64)
+    return dist
+
+
+def run(rowptr, col, subs, hp, emb, labels, n_sample, S_total):
+    t_all = time.perf_counter()
+    G = CSRGraph(rowptr, col)
+    n = G.n
+    seed = int(hp.get('seed', 0))
+    rng = np.random.default_rng(0)
+    sample = [subs[i] for i in rng.choice(len(subs), n_sample, replace=False)]
+    L = hp['n_layers']
+    t = {}
+
+    # ---- shared stages on a sub-sample, scaled ---------------------------------------------
+    n_patches = hp['max_sim_epochs'] * hp['n_anchor_patches_structure'] * L
+    np_s = min(8, n_patches)
+    t0 = time.perf_counter()
+    patches = np.zeros((np_s, hp['sample_walk_len']), dtype=np.int64)
+    for i in range(np_s):
+        w = IH.triangular_walk(G, hp['sample_walk_len'], hp['rw_beta'],
+                               IH._Draws(seed, T.stream_id(T.STREAM_STRUCT_PATCH), i), 'graph')
+        patches[i, :len(w)] = w
+    iw = IH.perform_random_walks(G, patches, hp['n_triangular_walks'], hp['random_walk_len'], hp['rw_beta'], True, seed)
+    bw = IH.perform_random_walks(G, patches, hp['n_triangular_walks'], hp['random_walk_len'], hp['rw_beta'], False, seed)
+    t['shared_patches_walks'] = (time.perf_counter() - t0) * n_patches / np_s
+    pext = IH.position_anchors_border(G, hp['n_anchor_patches_pos_out'], seed, 0)
+    nb_s = min(4, len(pext))
+    t0 = time.perf_counter()
+    dist = np.stack([_bfs_hops_numpy(rowptr, col, int(s), n) for s in pext[:nb_s]])
+    t['shared_pext_bfs'] = (time.perf_counter() - t0) * len(pext) / nb_s
+    dist = np.concatenate([dist] * (len(pext) // nb_s + 1))[:len(pext)]
+    allp = np.concatenate([patches] * (n_patches // np_s + 1))[:n_patches]
+    iw = np.concatenate([iw] * (n_patches // np_s + 1))[:n_patches]
+    bw = np.concatenate([bw] * (n_patches // np_s + 1))[:n_patches]
+    pp, pf = cbind.ragged([[int(v) for v in row if v] for row in allp])
+    t0 = time.perf_counter()
+    pi, pe = cbind.degree_sequence(rowptr, col, None, pp, pf, True)
+    t['shared_patch_degree_seq'] = time.perf_counter() - t0
+
+    # ---- per-subgraph stages on the sample -------------------------------------------------
+    t0 = time.perf_counter()
+    ccs = [IH.connected_components(G, s) for s in sample]
+    cc_ids = IH.pad_cc_ids(ccs)
+    t['components'] = time.perf_counter() - t0
+    S, C, Lc = cc_ids.shape
+    rows = cc_ids.reshape(S * C, Lc)
+    t0 = time.perf_counter()
+    borders = []
+    for r in rows:
+        members = r[r != 0]
+        if len(members) == 0:
+            borders.append(np.zeros(0, dtype=np.int64))
+            continue
+        nb = np.unique(np.concatenate([G.neighbors(int(v)) for v in members]))
+        borders.append(np.setdiff1d(nb, members).astype(np.int64))
+    t['border'] = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    A_in, A_out = hp['n_anchor_patches_N_in'], hp['n_anchor_patches_N_out']
+    maxb = max(len(b) for b in borders)
+    n_int = np.zeros((S * C, A_in), dtype=np.int64)
+    n_bor = np.zeros((S * C, A_out), dtype=np.int64)
+    for r in range(S * C):
+        for ids, A, out, kind, width in ((rows[r][rows[r] != 0], A_in, n_int, T.STREAM_N_INT, Lc),
+                                         (borders[r], A_out, n_bor, T.STREAM_N_BOR, maxb)):
+            if len(ids) == 0:
+                continue
+            item = (np.uint64(r) * np.uint64(A) + np.arange(A, dtype=np.uint64))[:, None]
+            keys = T.symmetric_key_np(seed, T.stream_id(kind, 'train', 0), np.broadcast_to(item, (A, len(ids))),
+                                      np.broadcast_to(ids.astype(np.uint64)[None, :], (A, len(ids))))
+            best = keys.argmax(axis=1)
+            pick = ids[best]
+            if len(ids) < width:
+                pick = np.where(keys[np.arange(A), best] < 0, 0, pick)
+            out[r] = pick
+    p_int = IH.position_anchors_internal(sample, hp['n_anchor_patches_pos_in'], seed, 'train', 0)
+    t['anchors'] = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    cp, cf = cbind.ragged([[int(v) for v in r if v] for r in rows])
+    ci, ce = cbind.degree_sequence(rowptr, col, None, cp, cf, True)
+    t['degree_seq'] = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    int_sim = cbind.fastdtw_sim(cp, ci, pp, pi, 0).reshape(S, C, -1)
+    bor_sim = cbind.fastdtw_sim(cp, ce, pp, pe, 0).reshape(S, C, -1)
+    t['dtw'] = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    d = dist.astype(np.int64)
+    d[d == 255] = 0
+    p_out = np.stack([d[:, r[r != 0]].min(axis=1) if (r != 0).any() else np.zeros(len(pext)) for r in rows])
+    t['position_sims'] = time.perf_counter() - t0
+
+    # ---- float half: forward + backward + Adam on the sample ---------------------------------
+    D = emb.shape[1]
+    g = torch.Generator().manual_seed(0)
+    E = torch.cat([torch.zeros(1, D), emb.float()], 0).requires_grad_(True)
+    params = {'node_embeddings.weight': E}
+
+    def lin(name, o, i):
+        params[name + '.weight'] = (torch.randn(o, i, generator=g) / i ** 0.5).requires_grad_(True)
+        params[name + '.bias'] = torch.zeros(o, requires_grad=True)
+    for mod in ('neighborhood_mpns', 'position_mpns', 'structure_mpns'):
+        for side in ('internal', 'border'):
+            lin('%s.0.%s.linear' % (mod, side), D, 2 * D)
+            lin('%s.0.%s.linear_position' % (mod, side), 1, D)
+    for sfx in ('', '_reverse'):
+        params['lstm.lstm.weight_ih_l0' + sfx] = (torch.randn(4 * D, D, generator=g) / D ** 0.5).requires_grad_(True)
+        params['lstm.lstm.weight_hh_l0' + sfx] = (torch.randn(4 * D, D, generator=g) / D ** 0.5).requires_grad_(True)
+        params['lstm.lstm.bias_ih_l0' + sfx] = torch.zeros(4 * D, requires_grad=True)
+        params['lstm.lstm.bias_hh_l0' + sfx] = torch.zeros(4 * D, requires_grad=True)
+    lin('lstm.linear', D, 2 * D)
+    hid = D + 2 * D + hp['n_anchor_patches_pos_in'] + hp['n_anchor_patches_pos_out'] + 2 * hp['n_anchor_patches_structure']
+    lin('lin', hp['linear_hidden_dim_1'], hid)
+    lin('lin2', hp['linear_hidden_dim_2'], hp['linear_hidden_dim_1'])
+    lin('lin3', 3, hp['linear_hidden_dim_2'])
+    opt = torch.optim.Adam(list(params.values()), lr=hp['learning_rate'])
+    idx = IH.structure_anchor_indices(n_patches, hp['n_anchor_patches_structure'], seed, 0)
+    Tt = torch.from_numpy
+    anchors = {'N_int': {'train': {0: Tt(n_int).view(S, C, -1)}}, 'N_bor': {'train': {0: Tt(n_bor).view(S, C, -1)}},
+               'P_int': {'train': {0: Tt(p_int)}}, 'P_ext': {0: Tt(pext)},
+               'S': {0: (Tt(allp[idx]), idx, Tt(iw[idx]), Tt(bw[idx]))}}
+    real = Tt((cc_ids[:, :, 0] != 0))
+    sims = {('N', 'in', 0): torch.zeros(S, C, A_in), ('N', 'out', 0): (Tt(n_bor).view(S, C, -1) != 0).float(),
+            ('P', 'in', 0): torch.zeros(S, C, hp['n_anchor_patches_pos_in']),
+            ('P', 'out', 0): Tt(p_out).float().view(S, C, -1) * real.unsqueeze(-1)}
+    batch = {'cc_ids': Tt(cc_ids), 'subgraph_idx': torch.arange(S).view(-1, 1), 'NP_sim': sims,
+             'I_S_sim': Tt(int_sim), 'B_S_sim': Tt(bor_sim)}
+    lab = labels[:S].long()
+    hp_f = dict(hp)
+    hp_f['lstm_n_layers'] = 1
+    steps = 2
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        logits = FH.forward(params, hp_f, 'train', batch, anchors, None)
+        loss = torch.nn.functional.cross_entropy(logits, lab)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+    t_fb = (time.perf_counter() - t0) / steps
+    # the dense (N+1, D) embedding gradient + Adam update is a per-STEP cost, not per subgraph:
+    # time it alone and count it once per pass
+    t0 = time.perf_counter()
+    E.grad = torch.zeros_like(E)
+    torch.optim.Adam([E], lr=1e-3).step()
+    t_table = time.perf_counter() - t0
+    t['fwd_bwd_adam'] = max(t_fb - t_table, 0.0)
+
+    per_sample = sum(v for k, v in t.items() if not k.startswith('shared_'))
+    shared = sum(v for k, v in t.items() if k.startswith('shared_')) + t_table
+    est_pass = shared + per_sample * S_total / n_sample
+    return {'value': S_total / est_pass, 'unit': 'subgraphs/s', 'cores': int(torch.get_num_threads()),
+            'kind': 'port',
+            'sample': ('oracle (C + numpy + torch-CPU, same sparse algorithm) on %d of %d subgraphs; per-subgraph stages '
+                       'scaled x%.0f, shared stages (structure patches/walks on %d of %d patches, P-border BFS on %d of %d '
+                       'sources, dense embedding-table Adam) scaled and counted once; integer stages are single-threaded, '
+                       'torch stages use %d threads; %.1f s of CPU work measured'
+                       % (n_sample, S_total, S_total / n_sample, np_s, n_patches, nb_s, len(pext), torch.get_num_threads(),
+                          time.perf_counter() - t_all)),
+            'stage_seconds_measured': {k: round(v, 3) for k, v in t.items()},
+            'estimated_full_pass_s': round(est_pass, 1)}

@@ -148,6 +148,10 @@ def forward(params, hparams, split, batch, anchors, cc_params=None):
                 if channel == 'structure':
                     sims = batch['I_S_sim'] if inside else batch['B_S_sim']
                     sidx_list = anchors['S'][l][1]
+                elif isinstance(batch['NP_sim'], dict):
+                    # already-gathered (B,C,A) edge weights (sparse path): column a of slot a
+                    sims = batch['NP_sim'][(tag, 'in' if inside else 'out', l)]
+                    sidx_list = list(range(sims.shape[-1]))
                 else:
                     sims, sidx_list = batch['NP_sim'], None
                 ap, am, ae = get_anchor_patches(params, hparams, E, sidx, cc_ids, mask, anchors, split, l, channel, inside)

@@ -85,3 +85,36 @@ def read_edgelist(path, relabel_plus_one=True):
             s = line.split()
             pairs.append((int(s[0]), int(s[1])))
     return from_edge_pairs(pairs, relabel_plus_one)
+
+
+class _IdentityPos:
+    """pos[v] = v - 1 for a graph whose node order is 1..n."""
+
+    def __getitem__(self, v):
+        return int(v) - 1
+
+
+class CSRGraph:
+    """Same interface as OracleGraph, backed by CSR arrays (rows sorted ascending, node order
+    1..n): for graphs too large for python dicts (the 1M-node benchmark graph)."""
+
+    def __init__(self, rowptr, col):
+        self.rowptr, self.col = rowptr, col
+        self.n = len(rowptr) - 2
+        self.node_order = range(1, self.n + 1)
+        self.pos = _IdentityPos()
+
+    def neighbors(self, v):
+        return self.col[self.rowptr[v]:self.rowptr[v + 1]]
+
+    def has_edge(self, u, v):
+        a = self.neighbors(u)
+        i = int(np.searchsorted(a, v))
+        return i < len(a) and a[i] == v
+
+    def degree(self, v):
+        a = self.neighbors(v)
+        return len(a) + (1 if self.has_edge(v, v) else 0)
+
+    def max_id(self):
+        return self.n
