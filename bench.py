@@ -67,7 +67,7 @@ def parse():
     ap.add_argument('--subgraph-nodes', type=int, default=20)
     ap.add_argument('--embed', type=int, default=64)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-sample', type=int, default=192)
+    ap.add_argument('--cpu-sample', type=int, default=1024)
     return ap.parse_args()
 
 
@@ -196,6 +196,14 @@ def main():
     ds_ms = e0.elapsed_time(e1) / reps
     achieved = alg_bytes / (ds_ms * 1e-3) / 1e9
 
+    traffic, traffic_src = None, None
+    tf = os.path.join(REPO, 'profiles', 'r01b_degseq_traffic.json')
+    if os.path.exists(tf) and args.nodes == 1_000_000 and S == 50_000:
+        # PMC passes cannot run inside this process; this is the committed rocprofv3 measurement of
+        # the same launch (same graph seed, same 50k sets): raw FETCH_SIZE + WRITE_SIZE bytes
+        with open(tf) as f:
+            tj = json.load(f)
+        traffic, traffic_src = tj['hbm_bytes_per_launch_raw'], 'profiles/r01b_degseq_traffic.json (rocprofv3 --pmc, separate passes)'
     result = {
         'metric': 'subgraphs/sec fwd+bwd (all 3 channels on) + achieved HBM GB/s',
         'value': world * S * args.steps / elapsed, 'unit': 'subgraphs/s', 'n_gpus': world, 'steps': args.steps,
@@ -208,9 +216,9 @@ def main():
                    'subgraphs_per_gpu': S, 'parallelism': 'dp%d (subgraph shards, RCCL all-gather + grad all-reduce)' % world},
         'roofline': {'kernel': 'degseq_wave_kernel (sgnn_degree_sequence: structure-channel CSR gather)',
                      'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                     'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
+                     'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_src,
                      'algorithmic_bytes_per_launch': alg_bytes, 'ms_per_launch': ds_ms, 'sets_per_launch': cc_sets.n,
-                     'note': 'CSR (88 MB) fits the 256 MiB Infinity Cache: bytes are served on-die, not all from HBM'},
+                     'note': 'algorithmic bytes / time; the CSR (88 MB) fits the 256 MiB Infinity Cache and hub lists are re-read from the XCD L2s, so most of these bytes are served on-die (memory-side traffic is ~0.24 GB per launch)'},
         'stages_ms': {k: round(v, 3) for k, v in stage_ms.items()},
         'loss': loss, 'setup_s': round(t_gen, 1),
     }
