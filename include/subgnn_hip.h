@@ -186,6 +186,9 @@ int sgnn_min_hops_to_sets(const uint8_t* dist, int64_t n_sources, int64_t max_id
  * workspace: sgnn_dtw_workspace_bytes(n_x, max_x_len, n_y, max_y_len) bytes (any content).
  * ------------------------------------------------------------------------------------- */
 int64_t sgnn_dtw_workspace_bytes(int64_t n_x, int64_t max_x_len, int64_t n_y, int64_t max_y_len);
+/* test hook: force the general (workspace-resident) kernel instead of the register-resident one
+ * that serves x rows of at most 32 entries; returns the previous setting */
+int sgnn_dtw_force_general(int on);
 int sgnn_dtw_similarity(const int64_t* x_ptr, const int32_t* x_val, int64_t n_x, int64_t max_x_len,
                         const int64_t* y_ptr, const int32_t* y_val, int64_t n_y, int64_t max_y_len,
                         int tie_order, float* out, void* workspace, int64_t workspace_bytes, void* stream);

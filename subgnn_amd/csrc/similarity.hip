@@ -265,7 +265,9 @@ extern "C" int64_t sgnn_dtw_workspace_bytes(int64_t n_x, int64_t max_x_len, int6
     if (max_x_len < 1) max_x_len = 1;
     if (max_y_len < 1) max_y_len = 1;
     const DtwLayout L = dtw_layout(max_x_len, max_y_len);
-    return DTW_NT * (L.n_dbl * 8 + dtw_align8(L.n_i32 * 4) + dtw_align8(L.n_dir * 4))
+    int64_t lane = L.n_dbl * 8 + dtw_align8(L.n_i32 * 4) + dtw_align8(L.n_dir * 4);
+    if (L.YL * 8 > lane) lane = L.YL * 8;                     // register variant: one word per column and level
+    return DTW_NT * lane
          + n_x * L.XL * 8 + n_y * L.YL * 8 + dtw_align8(n_x * 4) + dtw_align8(n_y * 4);
 }
 
@@ -414,6 +416,153 @@ __global__ __launch_bounds__(DTW_THREADS) void dtw_similarity_kernel(
 #undef FL
 }
 
+// ---- register-resident variant for components of at most DTW_R entries ---------------------------
+// The DP runs column-major (any topological order fills identical cells and makes identical
+// predecessor choices): the DTW_R row values of the previous column live in registers and are
+// updated in place while the column index j walks the anchor series, so the DP state never
+// leaves the register file.  The row loop is fully unrolled (static register indexing); rows
+// outside a lane's window are skipped by the exec mask, and a (row, column) slot no lane of the
+// wavefront needs is skipped altogether.  One 64-bit word of 2-bit predecessor codes per column
+// is the only per-cell state written to memory (write-once, coalesced); the backtrack reads it
+// back and keeps the per-row column range of the path in registers for the next finer level.
+#define DTW_R 32
+
+// one level of the register-resident DP, unrolled over RR <= DTW_R rows (the coarse levels and short
+// components take the narrow instantiations, so the unrolled row loop does not sweep empty rows)
+template <int RR, int TIE>
+__device__ __forceinline__ double dtw_reg_level(
+    int32_t (&fl)[DTW_R], const double* __restrict__ xcol, int64_t n_x, const double* __restrict__ ycol,
+    int lx, int ly, int lxc, int lyc, bool coarsest, bool finest, uint64_t* __restrict__ wq, int64_t NT)
+{
+    const double INF = __longlong_as_double(0x7ff0000000000000ll);
+    const int32_t EMPTY = 1;                                  // lo = 1, hi = 0
+    int32_t lohi[RR];
+    if (coarsest) {
+#pragma unroll
+        for (int i = 0; i < RR; ++i) lohi[i] = i < lx ? ((ly - 1) << 16) : EMPTY;
+    } else {
+        int prev_lo = 0;
+#pragma unroll
+        for (int i = 0; i < RR; ++i) {
+            const int ci = i >> 1;
+            const int ca = ci - 1 < 0 ? 0 : ci - 1;                          // <= lxc - 1 for every real row
+            const int cb = ci + 1;                                           // static; rows past the coarse
+            const int firstc = fl[ca] & 0xffff;                              // path end take its last column
+            const int lastc = (cb < lxc) ? (fl[cb < DTW_R ? cb : DTW_R - 1] >> 16) : (lyc - 1);
+            int lo = 2 * (firstc - 1);
+            int hi = 2 * (lastc + 1) + 1;
+            if (lo < prev_lo) lo = prev_lo;
+            if (lo < 0) lo = 0;
+            if (hi > ly - 1) hi = ly - 1;
+            int32_t v = (hi << 16) | lo;
+            if (hi < lo || i >= lx) v = EMPTY; else prev_lo = lo;
+            lohi[i] = v;
+        }
+    }
+    double xv[RR], col[RR];
+#pragma unroll
+    for (int i = 0; i < RR; ++i) {
+        xv[i] = i < lx ? xcol[(int64_t)i * n_x] : 0.0;
+        col[i] = INF;
+    }
+    for (int j = 0; j < ly; ++j) {
+        const double yj = ycol[j];
+        uint64_t word = 0;
+        double up = INF;
+        double diag = (j == 0) ? 0.0 : INF;                                  // virtual origin D[0][0] = 0
+#pragma unroll
+        for (int i = 0; i < RR; ++i) {
+            const int lo = lohi[i] & 0xffff, hi = lohi[i] >> 16;
+            const double old = col[i];
+            double nv = INF;
+            if (j >= lo && j <= hi) {
+                const double dt = dtw_cost(xv[i], yj);
+                const double c_up = up + dt, c_left = old + dt, c_diag = diag + dt;
+                int best;
+                if (TIE == 0) {                                              // (i-1,j), (i,j-1), (i-1,j-1)
+                    best = 0; nv = c_up;
+                    if (c_left < nv) { nv = c_left; best = 1; }
+                    if (c_diag < nv) { nv = c_diag; best = 2; }
+                } else {                                                     // (i-1,j-1), (i-1,j), (i,j-1)
+                    best = 2; nv = c_diag;
+                    if (c_up < nv) { nv = c_up; best = 0; }
+                    if (c_left < nv) { nv = c_left; best = 1; }
+                }
+                word |= (uint64_t)best << (2 * i);
+            }
+            col[i] = nv;
+            diag = old;                                                      // (i, j-1) is the diagonal of (i+1, j)
+            up = nv;
+        }
+        wq[(int64_t)j * NT] = word;
+    }
+    double result = 0.0;
+#pragma unroll
+    for (int i = 0; i < RR; ++i) if (i == lx - 1) result = col[i];
+    if (finest) return result;
+    // backtrack through the predecessor codes; record the path's column range per row
+#pragma unroll
+    for (int q = 0; q < RR; ++q) fl[q] = 0xffff;                             // first = 65535, last = 0
+    int i = lx - 1, j = ly - 1;
+    while (i >= 0 && j >= 0) {
+#pragma unroll
+        for (int q = 0; q < RR; ++q) {
+            if (q == i) {
+                int f = fl[q] & 0xffff, l = fl[q] >> 16;
+                f = j < f ? j : f;
+                l = j > l ? j : l;
+                fl[q] = (l << 16) | f;
+            }
+        }
+        const int d = (int)((wq[(int64_t)j * NT] >> (2 * i)) & 3);
+        if (d == 0) --i; else if (d == 1) --j; else { --i; --j; }
+    }
+    return result;
+}
+
+template <int TIE>
+__global__ __launch_bounds__(DTW_THREADS, 2) void dtw_similarity_reg_kernel(
+    const double* __restrict__ xpyr, const int32_t* __restrict__ xlen, int64_t n_x,
+    const double* __restrict__ ypyr, const int32_t* __restrict__ ylen, int64_t n_y,
+    float* __restrict__ out, uint64_t* __restrict__ wq, DtwLayout L)
+{
+    const int64_t NT = (int64_t)gridDim.x * blockDim.x;
+    const int64_t tid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    const int64_t total = n_x * n_y;
+    for (int64_t pair = tid; pair < total; pair += NT) {
+        const int64_t a = pair / n_x, r = pair % n_x;        // consecutive lanes: consecutive components
+        const int lx0 = xlen[r], ly0 = ylen[a];
+        if (lx0 == 0 || ly0 == 0) { out[r * n_y + a] = 0.f; continue; }
+        const double* __restrict__ yp = ypyr + a * L.YL;
+        int n_levels = 1;
+        {
+            int lx = lx0, ly = ly0;
+            while (lx >= 3 && ly >= 3) { lx >>= 1; ly >>= 1; ++n_levels; }
+        }
+        int32_t fl[DTW_R];                                    // coarser path: first col | last col << 16 per row
+#pragma unroll
+        for (int q = 0; q < DTW_R; ++q) fl[q] = 0;
+        double result = 0.0;
+        for (int lev = n_levels - 1; lev >= 0; --lev) {
+            const int lx = lx0 >> lev, ly = ly0 >> lev;
+            const int lxc = lx0 >> (lev + 1), lyc = ly0 >> (lev + 1);
+            const double* xcol = xpyr + L.xoff[lev] * n_x + r;
+            const double* ycol = yp + L.yoff[lev];
+            uint64_t* w = wq + L.yoff[lev] * NT + tid;
+            const bool coarsest = lev == n_levels - 1, finest = lev == 0;
+            if (lx <= 8) result = dtw_reg_level<8, TIE>(fl, xcol, n_x, ycol, lx, ly, lxc, lyc, coarsest, finest, w, NT);
+            else if (lx <= 16) result = dtw_reg_level<16, TIE>(fl, xcol, n_x, ycol, lx, ly, lxc, lyc, coarsest, finest, w, NT);
+            else if (lx <= 24) result = dtw_reg_level<24, TIE>(fl, xcol, n_x, ycol, lx, ly, lxc, lyc, coarsest, finest, w, NT);
+            else result = dtw_reg_level<32, TIE>(fl, xcol, n_x, ycol, lx, ly, lxc, lyc, coarsest, finest, w, NT);
+        }
+        out[r * n_y + a] = (float)(1.0 / (result + 1.0));
+    }
+}
+
+static int g_dtw_force_general = 0;
+/* test hook: 1 = always take the general (workspace-resident) kernel, 0 = pick by size */
+extern "C" int sgnn_dtw_force_general(int on) { const int old = g_dtw_force_general; g_dtw_force_general = on; return old; }
+
 extern "C" int sgnn_dtw_similarity(const int64_t* x_ptr, const int32_t* x_val, int64_t n_x, int64_t max_x_len,
                                    const int64_t* y_ptr, const int32_t* y_val, int64_t n_y, int64_t max_y_len,
                                    int tie_order, float* out, void* workspace, int64_t workspace_bytes, void* stream)
@@ -428,9 +577,12 @@ extern "C" int sgnn_dtw_similarity(const int64_t* x_ptr, const int32_t* x_val, i
     const DtwLayout L = dtw_layout(max_x_len, max_y_len);
     hipStream_t st = (hipStream_t)stream;
     char* w = (char*)workspace;
-    double* wd = (double*)w;               w += DTW_NT * L.n_dbl * 8;
-    int32_t* wi = (int32_t*)w;             w += DTW_NT * dtw_align8(L.n_i32 * 4);
-    uint32_t* wb = (uint32_t*)w;           w += DTW_NT * dtw_align8(L.n_dir * 4);
+    int64_t lane = L.n_dbl * 8 + dtw_align8(L.n_i32 * 4) + dtw_align8(L.n_dir * 4);
+    if (L.YL * 8 > lane) lane = L.YL * 8;
+    double* wd = (double*)w;
+    int32_t* wi = (int32_t*)(w + DTW_NT * L.n_dbl * 8);
+    uint32_t* wb = (uint32_t*)(w + DTW_NT * (L.n_dbl * 8 + dtw_align8(L.n_i32 * 4)));
+    uint64_t* wq = (uint64_t*)w;           w += DTW_NT * lane;
     double* xpyr = (double*)w;             w += n_x * L.XL * 8;
     double* ypyr = (double*)w;             w += n_y * L.YL * 8;
     int32_t* xlen = (int32_t*)w;           w += dtw_align8(n_x * 4);
@@ -441,8 +593,17 @@ extern "C" int sgnn_dtw_similarity(const int64_t* x_ptr, const int32_t* x_val, i
     hipLaunchKernelGGL(dtw_pyramid_kernel, dim3(sgnn_grid_for(n_y, 256)), dim3(256), 0, st, y_ptr, y_val, n_y,
                        max_y_len, L.YL, 0, ypyr, ylen);
     SGNN_CHECK_LAUNCH();
-    hipLaunchKernelGGL(dtw_similarity_kernel, dim3(DTW_BLOCKS), dim3(DTW_THREADS), 0, st, xpyr, xlen, n_x, ypyr, ylen,
-                       n_y, tie_order, out, wd, wi, wb, L);
+    if (max_x_len <= DTW_R && !g_dtw_force_general) {
+        if (tie_order == 0)
+            hipLaunchKernelGGL(dtw_similarity_reg_kernel<0>, dim3(DTW_BLOCKS), dim3(DTW_THREADS), 0, st, xpyr, xlen, n_x,
+                               ypyr, ylen, n_y, out, wq, L);
+        else
+            hipLaunchKernelGGL(dtw_similarity_reg_kernel<1>, dim3(DTW_BLOCKS), dim3(DTW_THREADS), 0, st, xpyr, xlen, n_x,
+                               ypyr, ylen, n_y, out, wq, L);
+    } else {
+        hipLaunchKernelGGL(dtw_similarity_kernel, dim3(DTW_BLOCKS), dim3(DTW_THREADS), 0, st, xpyr, xlen, n_x, ypyr,
+                           ylen, n_y, tie_order, out, wd, wi, wb, L);
+    }
     SGNN_CHECK_LAUNCH();
     return SGNN_OK;
 }

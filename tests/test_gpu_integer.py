@@ -381,3 +381,29 @@ def test_dtw_random(tie):
     assert (got[[len(x) > 0 for x in xs]] > 0).all() and (got <= 1).all()
     same = ops.dtw_similarity(t(yp), t(yv), 51, t(yp), t(yv), 51, tie).cpu().numpy()
     assert (np.diag(same) == 1).all()
+
+
+@pytest.mark.parametrize('tie', [0, 1])
+def test_dtw_register_kernel_equals_general_kernel(tie):
+    """x rows of <= 32 entries take the register-resident column-major kernel; it must agree bit for
+    bit with the C oracle and with the general kernel (forced through the test hook)."""
+    ops = _ops()
+    from subgnn_amd import _lib
+    rng = np.random.default_rng(50 + tie)
+    xs = [sorted(rng.integers(0, 30, int(rng.integers(0, 33))).tolist()) for _ in range(300)]
+    xs[0], xs[1], xs[2] = [5], [1, 2], list(range(32))
+    ys = [sorted(rng.integers(0, 200, int(rng.integers(1, 61))).tolist()) for _ in range(41)]
+    ys[0], ys[1] = [7], [3, 3]
+    xp, xv = cbind.ragged(xs)
+    yp, yv = cbind.ragged(ys)
+    ref = cbind.fastdtw_sim(xp, xv, yp, yv, tie)
+    t = lambda a: torch.from_numpy(a).to(DEV)
+    fast = ops.dtw_similarity(t(xp), t(xv), 32, t(yp), t(yv), 60, tie).cpu().numpy()
+    lib = _lib.load()
+    old = lib.sgnn_dtw_force_general(1)
+    try:
+        general = ops.dtw_similarity(t(xp), t(xv), 32, t(yp), t(yv), 60, tie).cpu().numpy()
+    finally:
+        lib.sgnn_dtw_force_general(old)
+    assert np.array_equal(fast, ref)
+    assert np.array_equal(general, ref)
