@@ -75,6 +75,34 @@ def uniform01(seed, stream, item, j):
     return draw32(seed, stream, item, j) * (1.0 / 4294967296.0)
 
 
+def lowbias32(x):
+    """32-bit avalanche hash (two multiplies): cheap on GPUs, where 64-bit multiplies run at a
+    fraction of the 32-bit rate and this draw is evaluated for every (border node, slot) pair."""
+    x &= 0xFFFFFFFF
+    x ^= x >> 16
+    x = (x * 0x21F0AAAD) & 0xFFFFFFFF
+    x ^= x >> 15
+    x = (x * 0x735A2D97) & 0xFFFFFFFF
+    x ^= x >> 15
+    return x
+
+
+def symmetric_key_from_h1(h1, j):
+    """Signed 53-bit key from the per-item state h1 (64 bits) and the node id j:
+    hi = lowbias32(j ^ lo32(h1)) as a signed 32-bit value, lo = lowbias32(j ^ hi32(h1)) >> 11."""
+    a, b = h1 & 0xFFFFFFFF, (h1 >> 32) & 0xFFFFFFFF
+    hi = lowbias32((j & 0xFFFFFFFF) ^ a)
+    lo = lowbias32((j & 0xFFFFFFFF) ^ b)
+    if hi >= (1 << 31):
+        hi -= (1 << 32)
+    return hi * (1 << 21) + (lo >> 11)
+
+
+def item_state(seed, stream, item):
+    h = mix64((seed & MASK64) ^ ((stream * K_STREAM) & MASK64))
+    return mix64((h + item * K_ITEM) & MASK64)
+
+
 def symmetric_key(seed, stream, item, j):
     """Signed 53-bit integer key k in [-2**52, 2**52); the 'randn' value is k * 2**-52.
 
@@ -82,11 +110,10 @@ def symmetric_key(seed, stream, item, j):
     sample_neighborhood_anchor_patch (aps:177-179, 189-191), so any symmetric continuous
     law gives the same distribution of sampled ids; 53-bit integers convert to float64
     exactly, so comparing keys as integers (HIP) and as doubles (reference) agree.
+    The per-(row, slot) state comes from the 64-bit tape chain; the per-node part is two
+    32-bit hashes (see lowbias32).
     """
-    h = draw64(seed, stream, item, j)
-    if h >= (1 << 63):
-        h -= (1 << 64)
-    return h >> 11
+    return symmetric_key_from_h1(item_state(seed, stream, item), j)
 
 
 # ---- vectorised numpy versions (uint64 wrap-around arithmetic) -------------------------
@@ -108,6 +135,23 @@ def draw64_np(seed, stream, item, j):
     return h
 
 
+def _lowbias32_np(x):
+    x = x.astype(np.uint32)
+    x = x ^ (x >> np.uint32(16))
+    x = x * np.uint32(0x21F0AAAD)
+    x = x ^ (x >> np.uint32(15))
+    x = x * np.uint32(0x735A2D97)
+    return x ^ (x >> np.uint32(15))
+
+
 def symmetric_key_np(seed, stream, item, j):
-    h = draw64_np(seed, stream, item, j).view(np.int64) if False else draw64_np(seed, stream, item, j).astype(np.uint64)
-    return h.view(np.int64) >> np.int64(11)
+    with np.errstate(over='ignore'):
+        item = np.asarray(item).astype(np.uint64)
+        j32 = np.asarray(j).astype(np.uint64).astype(np.uint32)
+        h0 = np.uint64(mix64((seed & MASK64) ^ ((stream * K_STREAM) & MASK64)))
+        h1 = _mix64_np(h0 + item * np.uint64(K_ITEM))
+        a = (h1 & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+        b = (h1 >> np.uint64(32)).astype(np.uint32)
+        hi = _lowbias32_np(j32 ^ a).view(np.int32).astype(np.int64)
+        lo = _lowbias32_np(j32 ^ b).astype(np.int64)
+    return hi * np.int64(1 << 21) + (lo >> np.int64(11))

@@ -52,9 +52,18 @@ __host__ __device__ static inline double sgnn_uniform01(uint64_t h1, uint64_t j)
     uint32_t u = (uint32_t)(sgnn_tape_draw(h1, j) >> 32);
     return (double)u * (1.0 / 4294967296.0);
 }
-// signed 53-bit key; the reference-side 'randn' value is key * 2^-52
+// 32-bit avalanche hash (two multiplies; 64-bit multiplies run at a fraction of this rate)
+__host__ __device__ static inline uint32_t sgnn_lowbias32(uint32_t x) {
+    x ^= x >> 16; x *= 0x21F0AAADu; x ^= x >> 15; x *= 0x735A2D97u; x ^= x >> 15;
+    return x;
+}
+// signed 53-bit key; the reference-side 'randn' value is key * 2^-52.  h1 = per-(row, slot) state
+// from the 64-bit tape chain, j = node id: hi word = lowbias32(j ^ lo32(h1)) (signed), low 21 bits
+// from lowbias32(j ^ hi32(h1)).
 __host__ __device__ static inline int64_t sgnn_symmetric_key(uint64_t h1, uint64_t j) {
-    return ((int64_t)sgnn_tape_draw(h1, j)) >> 11;
+    const uint32_t hi = sgnn_lowbias32((uint32_t)j ^ (uint32_t)h1);
+    const uint32_t lo = sgnn_lowbias32((uint32_t)j ^ (uint32_t)(h1 >> 32));
+    return (int64_t)(int32_t)hi * (int64_t)(1 << 21) + (int64_t)(lo >> 11);
 }
 
 // ---- small device helpers ---------------------------------------------------------------

@@ -98,7 +98,7 @@ extern "C" int sgnn_cc_labels(const int64_t* rowptr, const int32_t* col_sorted, 
 #define KB_MAX_WG_G 1024
 #define KB_MAX_WG_L 256
 #define KB_LDS_BYTES (156 * 1024)
-#define KB_SC 4
+#define KB_SC 8
 
 static inline int64_t kb_words(int64_t max_id) { return (max_id + 32) / 32; }
 static inline bool kb_fits_lds(int64_t max_id) { return kb_words(max_id) * 4 <= KB_LDS_BYTES; }
@@ -122,6 +122,50 @@ struct KbSample {             // fused neighbourhood-border anchor draw (all NUL
     uint8_t* hop;             // (n_sets, n_slots) its hop level
     uint8_t* allneg;          // (n_sets, n_slots) 1 if every key < 0 (PAD wins if the row is padded)
 };
+
+template <int SC, int NW>
+__device__ __forceinline__ void kb_draw(const KbSample& smp, int64_t s, const int32_t* __restrict__ q, int cnt, int hops,
+                                        const int32_t* s_lvl, int wave, int lane)
+{
+    for (int64_t s0 = (int64_t)wave * SC; s0 < smp.n_slots; s0 += (int64_t)NW * SC) {
+        uint64_t h1[SC];
+        int64_t best[SC];
+        int32_t bcol[SC], bid[SC];
+#pragma unroll
+        for (int u = 0; u < SC; ++u) {
+            h1[u] = sgnn_tape_h1(smp.h0, (uint64_t)(s * smp.n_slots + s0 + u));
+            best[u] = INT64_MIN; bcol[u] = INT32_MAX; bid[u] = 0;
+        }
+        for (int c0 = lane; c0 < cnt; c0 += 256) {          // 4 independent loads in flight per lane
+            int32_t v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { const int c = c0 + 64 * k; v[k] = q[c < cnt ? c : cnt - 1]; }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int c = c0 + 64 * k;
+                if (c < cnt) {
+#pragma unroll
+                    for (int u = 0; u < SC; ++u) {
+                        const int64_t key = (v[k] == 0) ? 0 : sgnn_symmetric_key(h1[u], (uint64_t)v[k]);
+                        if (key > best[u]) { best[u] = key; bcol[u] = c; bid[u] = v[k]; }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < SC; ++u) {
+            sgnn_argmax_reduce(best[u], bcol[u], bid[u]);
+            if (lane == 0 && s0 + u < smp.n_slots) {
+                const int64_t o = s * smp.n_slots + s0 + u;
+                int h = 0;
+                if (cnt > 0) { h = 1; while (h < hops && bcol[u] >= s_lvl[h]) ++h; }
+                smp.anchor[o] = cnt > 0 ? (int64_t)bid[u] : 0;
+                smp.hop[o] = (uint8_t)h;
+                smp.allneg[o] = (cnt == 0 || best[u] < 0) ? 1 : 0;
+            }
+        }
+    }
+}
 
 template <bool LDS_BM, int THREADS>
 __global__ __launch_bounds__(THREADS) void khop_border_kernel(
@@ -159,13 +203,23 @@ __global__ __launch_bounds__(THREADS) void khop_border_kernel(
             for (int f = f0 + wave; f < f1; f += NW) {
                 const int32_t v = (h == 1) ? set_nodes[beg + f] : q[f];
                 const int64_t r0 = rowptr[v], r1 = rowptr[v + 1];
-                for (int64_t e = r0 + lane; e < r1; e += 64) {
-                    const int32_t c = ego_mode ? col[e] - 1 : col[e];
-                    const uint32_t bit = 1u << (c & 31);
-                    const uint32_t old = atomicOr(&bm[c >> 5], bit);
-                    if (!(old & bit)) {
-                        const int pos = atomicAdd(&s_qn, 1);
-                        q[pos] = c;
+                for (int64_t e0 = r0; e0 < r1; e0 += 64) {      // wave-uniform trip count
+                    const int64_t e = e0 + lane;
+                    bool fresh = false;
+                    int32_t c = 0;
+                    if (e < r1) {
+                        c = ego_mode ? col[e] - 1 : col[e];
+                        const uint32_t bit = 1u << (c & 31);
+                        const uint32_t old = atomicOr(&bm[c >> 5], bit);
+                        fresh = !(old & bit);
+                    }
+                    // wave-aggregated append: one LDS atomic per wavefront instead of one per node
+                    const uint64_t m = __ballot(fresh);
+                    if (m) {
+                        int base = 0;
+                        if (lane == 0) base = atomicAdd(&s_qn, (int)__popcll(m));
+                        base = __shfl(base, 0);
+                        if (fresh) q[base + __popcll(m & ((1ull << lane) - 1ull))] = c;
                     }
                 }
             }
@@ -187,37 +241,13 @@ __global__ __launch_bounds__(THREADS) void khop_border_kernel(
             }
         }
         if (smp.n_slots > 0) {
-            // anchor draw over the queue: KB_SC slots per pass, one wavefront per slot group
-            for (int64_t s0 = (int64_t)wave * KB_SC; s0 < smp.n_slots; s0 += (int64_t)NW * KB_SC) {
-                uint64_t h1[KB_SC];
-                int64_t best[KB_SC];
-                int32_t bcol[KB_SC], bid[KB_SC];
-#pragma unroll
-                for (int u = 0; u < KB_SC; ++u) {
-                    h1[u] = sgnn_tape_h1(smp.h0, (uint64_t)(s * smp.n_slots + s0 + u));
-                    best[u] = INT64_MIN; bcol[u] = INT32_MAX; bid[u] = 0;
-                }
-                for (int c = lane; c < cnt; c += 64) {
-                    const int32_t v = q[c];
-#pragma unroll
-                    for (int u = 0; u < KB_SC; ++u) {
-                        const int64_t key = (v == 0) ? 0 : sgnn_symmetric_key(h1[u], (uint64_t)v);
-                        if (key > best[u]) { best[u] = key; bcol[u] = c; bid[u] = v; }
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < KB_SC; ++u) {
-                    sgnn_argmax_reduce(best[u], bcol[u], bid[u]);
-                    if (lane == 0 && s0 + u < smp.n_slots) {
-                        const int64_t o = s * smp.n_slots + s0 + u;
-                        int h = 0;
-                        if (cnt > 0) { h = 1; while (h < hops && bcol[u] >= s_lvl[h]) ++h; }
-                        smp.anchor[o] = cnt > 0 ? (int64_t)bid[u] : 0;
-                        smp.hop[o] = (uint8_t)h;
-                        smp.allneg[o] = (cnt == 0 || best[u] < 0) ? 1 : 0;
-                    }
-                }
-            }
+            // anchor draw over the queue (hot in L2): the slots are dealt to the wavefronts in groups
+            // of ceil(n_slots / waves) (<= 4 per pass), each wavefront scans the queue once per group
+            const int spw = (int)((smp.n_slots + NW - 1) / NW);
+            if (spw <= 1) kb_draw<1, NW>(smp, s, q, cnt, hops, s_lvl, wave, lane);
+            else if (spw == 2) kb_draw<2, NW>(smp, s, q, cnt, hops, s_lvl, wave, lane);
+            else if (spw == 3) kb_draw<3, NW>(smp, s, q, cnt, hops, s_lvl, wave, lane);
+            else kb_draw<4, NW>(smp, s, q, cnt, hops, s_lvl, wave, lane);
         }
         // un-set every bit this component touched
         for (int i = tid; i < n; i += THREADS) {

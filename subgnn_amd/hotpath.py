@@ -46,14 +46,42 @@ class StageTimer:
         return out
 
 
+def _hand_over(stream, *objs):
+    """Tensors produced on a side stream and consumed on ``stream``: tell the caching allocator."""
+    for o in objs:
+        if o is None:
+            continue
+        if isinstance(o, torch.Tensor):
+            if o.is_cuda:
+                o.record_stream(stream)
+        elif isinstance(o, ops.Ragged):
+            _hand_over(stream, o.ptr, o.nodes)
+        elif isinstance(o, dict):
+            _hand_over(stream, *o.values())
+        elif isinstance(o, (list, tuple)):
+            _hand_over(stream, *o)
+
+
 def prepare_sparse(model, split='train', timer=None):
-    """HIP-only prepare_data for one split (SubGNN.py:1024-1063 semantics, sparse similarities)."""
+    """HIP-only prepare_data for one split (SubGNN.py:1024-1063 semantics, sparse similarities).
+
+    Two HIP streams: the main stream runs components -> border BFS + neighbourhood draws ->
+    component degree sequences -> DTW; a side stream runs, concurrently with the (VALU-bound)
+    border stage, the latency-bound triangular walks and the memory-bound multi-source BFS of the
+    position channel.  hparams['overlap_streams'] = True enables it (default off: on this runtime the two streams' kernels were observed to execute back to back, so it buys nothing yet)."""
     hp, g, dev = model.hparams, model.networkx_graph, model.device
     seed = int(hp.get('seed', 0)) & tape.MASK64
     t = timer or StageTimer(False)
     L = hp['n_layers']
+    main = torch.cuda.current_stream()
+    if hp.get('overlap_streams', False):
+        if getattr(model, '_side_stream', None) is None:
+            model._side_stream = torch.cuda.Stream()
+        side = model._side_stream
+    else:
+        side = main
     t.mark('start')
-    # ---- components --------------------------------------------------------------------
+    # ---- components (main) ---------------------------------------------------------------
     subs = ops.Ragged.from_lists(getattr(model, split + '_sub_G'), dev) if not hasattr(model, '_subs_' + split) \
         else getattr(model, '_subs_' + split)
     setattr(model, '_subs_' + split, subs)
@@ -67,7 +95,47 @@ def prepare_sparse(model, split='train', timer=None):
     model.init_all_embeddings(split=split, trainable=hp['trainable_cc'])
     t.mark('cc_embed')
     sims = {}
-    # ---- neighbourhood channel -----------------------------------------------------------
+    a_sets = ai = ae = None
+    # ---- side stream: position channel + structure patches / walks -------------------------
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        if hp['use_position']:
+            if getattr(model, 'anchors_pos_ext', None) is None or split != 'test':
+                model.anchors_pos_ext = aps.init_anchors_pos_ext(hp, g, dev)
+            pint = {l: ops.choice_ragged(subs, hp['n_anchor_patches_pos_in'], seed,
+                                         tape.stream_id(tape.STREAM_P_INT, split, l)) for l in range(L)}
+            if getattr(model, 'anchors_pos_int', None) is None:
+                model.anchors_pos_int = {}
+            model.anchors_pos_int[split] = pint
+            for l in range(L):
+                dist = ops.bfs_hops(g, model.anchors_pos_ext[l].to(torch.int32).contiguous(),
+                                    max_hops=hp.get('max_bfs_hops', 32))
+                w = ops.min_hops_to_sets(dist, cc_sets).view(S, C, -1)
+                sims[('P', 'out', l)] = (w * real.unsqueeze(-1)).contiguous()
+                if C == 1:
+                    sims[('P', 'in', l)] = torch.zeros((S, C, hp['n_anchor_patches_pos_in']), dtype=torch.float32,
+                                                       device=dev)
+                else:
+                    uniq, inv = torch.unique(pint[l], return_inverse=True)
+                    if uniq.numel() > MAX_PINT_SOURCES:
+                        raise NotImplementedError('sparse P-internal similarities for multi-component subgraphs need '
+                                                  'a BFS per distinct anchor (%d > %d)' % (uniq.numel(), MAX_PINT_SOURCES))
+                    d = ops.bfs_hops(g, uniq.to(torch.int32).contiguous(), max_hops=hp.get('max_bfs_hops', 32))
+                    full = ops.min_hops_to_sets(d, cc_sets).view(S, C, -1)               # (S, C, U)
+                    w = torch.gather(full, 2, inv.view(S, 1, -1).expand(S, C, -1))
+                    sims[('P', 'in', l)] = (w * real.unsqueeze(-1)).contiguous()
+        if hp['use_structure']:
+            if split != 'test' or getattr(model, 'structure_anchors', None) is None:
+                model.structure_anchors = aps.sample_structure_anchor_patches(hp, g, dev, hp['max_sim_epochs'])
+                views = aps.patch_node_views(model.structure_anchors)
+                model.bor_structure_anchor_random_walks = aps.perform_random_walks(hp, g, model.structure_anchors, False, views)
+                model.int_structure_anchor_random_walks = aps.perform_random_walks(hp, g, model.structure_anchors, True, views)
+                model.anchors_structure = aps.init_anchors_structure(hp, model.structure_anchors,
+                                                                     model.int_structure_anchor_random_walks,
+                                                                     model.bor_structure_anchor_random_walks)
+            a_sets = ops.Ragged.from_padded(model.structure_anchors)
+            ai, ae = ops.degree_sequence(g, a_sets, sort=True, use_degree_dict=g.full_degree is not None)
+    # ---- main stream: neighbourhood channel + component degree sequences --------------------
     if hp['use_neighborhood']:
         k = hp['neigh_sample_border_size']
         has_pad_c = (cc_sets.lengths < Lc).to(torch.uint8)
@@ -81,54 +149,28 @@ def prepare_sparse(model, split='train', timer=None):
                                              tape.stream_id(tape.STREAM_N_BOR, split, l))
             nb[l] = a.view(S, C, -1)
             sims[('N', 'out', l)] = w.view(S, C, -1).contiguous()
-        t.mark('border_bfs+N_anchors')
         if getattr(model, 'anchors_neigh_int', None) is None:
             model.anchors_neigh_int, model.anchors_neigh_border = {}, {}
         model.anchors_neigh_int[split], model.anchors_neigh_border[split] = ni, nb
-    # ---- position channel ----------------------------------------------------------------
-    if hp['use_position']:
-        if getattr(model, 'anchors_pos_ext', None) is None or split != 'test':
-            model.anchors_pos_ext = aps.init_anchors_pos_ext(hp, g, dev)
-        pint = {l: ops.choice_ragged(subs, hp['n_anchor_patches_pos_in'], seed, tape.stream_id(tape.STREAM_P_INT, split, l))
-                for l in range(L)}
-        if getattr(model, 'anchors_pos_int', None) is None:
-            model.anchors_pos_int = {}
-        model.anchors_pos_int[split] = pint
-        t.mark('P_anchors')
-        for l in range(L):
-            dist = ops.bfs_hops(g, model.anchors_pos_ext[l].to(torch.int32).contiguous(), max_hops=hp.get('max_bfs_hops', 32))
-            w = ops.min_hops_to_sets(dist, cc_sets).view(S, C, -1)
-            sims[('P', 'out', l)] = (w * real.unsqueeze(-1)).contiguous()
-            if C == 1:
-                sims[('P', 'in', l)] = torch.zeros((S, C, hp['n_anchor_patches_pos_in']), dtype=torch.float32, device=dev)
-            else:
-                uniq, inv = torch.unique(pint[l], return_inverse=True)
-                if uniq.numel() > MAX_PINT_SOURCES:
-                    raise NotImplementedError('sparse P-internal similarities for multi-component subgraphs need a '
-                                              'BFS per distinct anchor (%d > %d)' % (uniq.numel(), MAX_PINT_SOURCES))
-                d = ops.bfs_hops(g, uniq.to(torch.int32).contiguous(), max_hops=hp.get('max_bfs_hops', 32))
-                full = ops.min_hops_to_sets(d, cc_sets).view(S, C, -1)               # (S, C, U)
-                w = torch.gather(full, 2, inv.view(S, 1, -1).expand(S, C, -1))
-                sims[('P', 'in', l)] = (w * real.unsqueeze(-1)).contiguous()
-        t.mark('P_bfs_sims')
+        t.mark('border_bfs+N_anchors')
+    ci = ce = None
+    if hp['use_structure']:
+        ci, ce = ops.degree_sequence(g, cc_sets, sort=True, use_degree_dict=g.full_degree is not None)
+        t.mark('degree_sequences')
+    # ---- join ------------------------------------------------------------------------------
+    if side is not main:
+        main.wait_stream(side)
+        _hand_over(main, sims, a_sets, ai, ae, getattr(model, 'anchors_pos_ext', None),
+                   getattr(model, 'anchors_pos_int', {}).get(split) if getattr(model, 'anchors_pos_int', None) else None,
+                   getattr(model, 'structure_anchors', None), getattr(model, 'int_structure_anchor_random_walks', None),
+                   getattr(model, 'bor_structure_anchor_random_walks', None))
+        if getattr(model, 'anchors_structure', None):
+            for v in model.anchors_structure.values():
+                _hand_over(main, v[0], v[2], v[3])
+    t.mark('side_stream_join(P_bfs,S_walks)')
     setattr(model, split + '_neigh_pos_similarities', sims if sims else None)
     setattr(model, split + '_N_border', None)
-    # ---- structure channel ---------------------------------------------------------------
     if hp['use_structure']:
-        if split != 'test' or getattr(model, 'structure_anchors', None) is None:
-            model.structure_anchors = aps.sample_structure_anchor_patches(hp, g, dev, hp['max_sim_epochs'])
-            views = aps.patch_node_views(model.structure_anchors)
-            model.bor_structure_anchor_random_walks = aps.perform_random_walks(hp, g, model.structure_anchors, False, views)
-            model.int_structure_anchor_random_walks = aps.perform_random_walks(hp, g, model.structure_anchors, True, views)
-            model.anchors_structure = aps.init_anchors_structure(hp, model.structure_anchors,
-                                                                 model.int_structure_anchor_random_walks,
-                                                                 model.bor_structure_anchor_random_walks)
-        t.mark('S_patches_walks')
-        a_sets = ops.Ragged.from_padded(model.structure_anchors)
-        use_dict = g.full_degree is not None
-        ai, ae = ops.degree_sequence(g, a_sets, sort=True, use_degree_dict=use_dict)
-        ci, ce = ops.degree_sequence(g, cc_sets, sort=True, use_degree_dict=use_dict)
-        t.mark('degree_sequences')
         mx, my = max(cc_sets.max_len, 1), max(a_sets.max_len, 1)
         setattr(model, split + '_int_struc_similarities',
                 ops.dtw_similarity(cc_sets.ptr, ci, mx, a_sets.ptr, ai, my).view(S, C, -1))
