@@ -1,0 +1,169 @@
+"""Build-owned counterpart of the reference driver SubGNN/train_config.py.
+
+The reference driver cannot travel (it imports optuna, commentjson and pytorch-lightning 0.7.1 at
+module level, train_config.py:8,21-29); this file replays the same call sequence against the same
+``config.json`` schema (SubGNN/config_files/README.md:5-116) with nothing but the standard library
+and torch, so the drop-in module can be exercised end to end on the GPU box:
+
+  read json (// comments allowed)                                  train_config.py:44-52
+  -> dataset paths from data.task + hyperparams_fix.embedding_type  :213-232
+  -> fixed + "suggested" hyper-parameters merged into one dict      :60-86
+  -> seed torch / numpy                                             :96-101
+  -> SubGNN(hparams, 7 paths)                                       :104-106
+  -> hyperparams.json                                               :174-183
+  -> fit: prepare_data, configure_optimizers, per batch training_step -> model.backward ->
+     clip grad-norm to grad_clip -> optimizer.step/zero_grad; per epoch validation_step* ->
+     validation_epoch_end; keep the best monitored metric           (PL 0.7.x hook order)
+  -> final_metric_scores.json from model.metric_scores[-1]          :189-193
+  -> return the monitored metric                                    :196-200
+
+There is no hyper-parameter search here: a ``FixedTrial`` answers every ``suggest_*`` call with the
+first categorical choice / the lower bound (or a value supplied by the caller).
+"""
+import argparse
+import json
+import random
+import re
+from collections import OrderedDict
+from pathlib import Path
+
+import numpy as np
+import torch
+
+from . import config
+from .SubGNN import SubGNN, dataset_paths
+
+
+def read_json(fname):
+    """commentjson.load(..., object_hook=OrderedDict): strips // and /* */ comments."""
+    txt = Path(fname).read_text()
+    txt = re.sub(r'/\*.*?\*/', '', txt, flags=re.S)
+    txt = re.sub(r'(^|[\s,{\[])//[^\n]*', r'\1', txt)
+    txt = re.sub(r',(\s*[}\]])', r'\1', txt)
+    return json.loads(txt, object_pairs_hook=OrderedDict)
+
+
+class FixedTrial:
+    """Deterministic stand-in for optuna.Trial: first categorical choice, lower bound of ranges."""
+
+    def __init__(self, values=None):
+        self.values, self.params = dict(values or {}), {}
+
+    def _pick(self, name, default):
+        v = self.values.get(name, default)
+        self.params[name] = v
+        return v
+
+    def suggest_categorical(self, name, choices):
+        return self._pick(name, choices[0])
+
+    def suggest_float(self, name, low, high, **kw):
+        return self._pick(name, float(low))
+
+    def suggest_int(self, name, low, high, **kw):
+        return self._pick(name, int(low))
+
+    suggest_uniform = suggest_loguniform = suggest_discrete_uniform = suggest_float
+
+    def report(self, *a, **k):
+        pass
+
+    def should_prune(self):
+        return False
+
+
+def get_hyperparams(run_config, trial):
+    hp = dict(run_config['hyperparams_fix'])
+    for name, spec in run_config.get('hyperparams_optuna', {}).items():
+        hp[name] = getattr(trial, spec['type'])(name, *spec.get('args', []), **spec.get('kwargs', {}))
+    return hp
+
+
+def build_model(run_config, trial=None):
+    trial = trial or FixedTrial()
+    hp = get_hyperparams(run_config, trial)
+    if 'seed' in hp:
+        torch.manual_seed(hp['seed'])
+        np.random.seed(hp['seed'])
+        random.seed(hp['seed'])
+        if torch.cuda.is_available():
+            torch.cuda.manual_seed_all(hp['seed'])
+    paths = dataset_paths(run_config['data']['task'], hp.get('embedding_type', 'gin'))
+    return SubGNN(hp, **paths), hp
+
+
+class Trainer:
+    """The slice of pl.Trainer the reference uses (train_config.py:121-156): max_epochs,
+    gradient clipping, validation every epoch, best-by-monitor bookkeeping."""
+
+    def __init__(self, max_epochs, gradient_clip_val=0.0, monitor='val_micro_f1', mode='max', log=print):
+        self.max_epochs, self.clip, self.monitor, self.mode, self.log = max_epochs, gradient_clip_val, monitor, mode, log
+        self.best, self.history = None, []
+
+    def fit(self, model):
+        model.prepare_data()
+        opt = model.configure_optimizers()
+        for epoch in range(self.max_epochs):
+            model.train()
+            losses = []
+            for bi, batch in enumerate(model.train_dataloader()):
+                out = model.training_step(batch, bi)
+                opt.zero_grad(set_to_none=True)
+                model.backward(self, out['loss'], opt, 0)
+                if self.clip and self.clip > 0:
+                    torch.nn.utils.clip_grad_norm_(model.parameters(), self.clip)
+                opt.step()
+                losses.append(out['loss'].detach())
+            model.eval()
+            with torch.no_grad():
+                outs = [model.validation_step(b, i) for i, b in enumerate(model.val_dataloader())]
+                res = model.validation_epoch_end(outs)
+            val = float(res['log'][self.monitor])
+            if self.best is None or (val > self.best if self.mode == 'max' else val < self.best):
+                self.best = val
+            tl = float(torch.stack(losses).mean()) if losses else float('nan')
+            self.history.append({'epoch': epoch, 'train_loss': tl, 'val_loss': float(res['avg_val_loss']), self.monitor: val})
+            self.log('epoch %d  train_loss %.4f  val_loss %.4f  %s %.4f' % (epoch, tl, float(res['avg_val_loss']), self.monitor, val))
+        return self
+
+    def test(self, model):
+        model.eval()
+        with torch.no_grad():
+            outs = [model.test_step(b, i) for i, b in enumerate(model.test_dataloader())]
+            return model.test_epoch_end(outs)
+
+
+def train_model(run_config, trial=None, results_dir=None, log=print):
+    model, hp = build_model(run_config, trial)
+    opt_cfg = run_config.get('optuna', {})
+    monitor = opt_cfg.get('monitor_metric', 'val_micro_f1')
+    mode = 'max' if opt_cfg.get('opt_direction', 'maximize') == 'maximize' else 'min'
+    trainer = Trainer(hp['max_epochs'], hp.get('grad_clip', 0.0), monitor, mode, log)
+    if results_dir is not None:
+        Path(results_dir).mkdir(parents=True, exist_ok=True)
+        with open(Path(results_dir) / 'hyperparams.json', 'w') as f:
+            json.dump({k: v for k, v in hp.items()}, f, indent=2, default=str)
+    trainer.fit(model)
+    scores = {k: (float(v) if hasattr(v, '__float__') else v) for k, v in model.metric_scores[-1].items()}
+    if results_dir is not None:
+        with open(Path(results_dir) / 'final_metric_scores.json', 'w') as f:
+            json.dump(scores, f, indent=2)
+    return trainer.best, model, trainer
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description='Train SubGNN on MI355X from a reference-format config.json')
+    ap.add_argument('-config_path', type=str, required=True)
+    ap.add_argument('-project_root', type=str, default=None, help='overrides subgnn_amd.config.PROJECT_ROOT')
+    ap.add_argument('-results_dir', type=str, default=None)
+    args = ap.parse_args(argv)
+    if args.project_root:
+        config.PROJECT_ROOT = Path(args.project_root)
+    run_config = read_json(args.config_path)
+    best, model, trainer = train_model(run_config, results_dir=args.results_dir)
+    print('best %s: %.4f' % (trainer.monitor, best))
+    return best
+
+
+if __name__ == '__main__':
+    main()

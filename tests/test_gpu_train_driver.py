@@ -1,0 +1,56 @@
+"""-m gpu: the build-owned counterpart of train_config.py drives the drop-in module end to end from a
+reference-format config.json (with // comments and an optuna block), and training reduces the loss."""
+import json
+import os
+
+import pytest
+import torch
+
+from helpers import write_dataset_from_golden
+
+pytestmark = pytest.mark.gpu
+
+CONFIG = '''{
+    "data": {"task": "ds"},
+    //"no_gpu": true,
+    "tb": {"tb_logging": false, "dir": "tensorboard", "name": "x"},
+    "optuna": {"opt_n_trials": 1, "opt_n_cores": 1, "monitor_metric": "val_micro_f1", "opt_direction": "maximize",
+               "sampler": "random", "pruning": false},
+    "hyperparams_fix": %s,
+    "hyperparams_optuna": {
+        "batch_size": {"type": "suggest_categorical", "args": [[8, 16]]},
+        "learning_rate": {"type": "suggest_float", "args": [5e-3, 1e-2], "kwargs": {"log": true}},
+        "grad_clip": {"type": "suggest_float", "args": [0.5, 1.0]},
+        "n_layers": {"type": "suggest_int", "args": [1, 2]}
+    }
+}'''
+
+
+def test_train_driver_end_to_end(tiny, tmp_path):
+    from subgnn_amd import config, train_config
+    write_dataset_from_golden(tiny, tmp_path, 'ds')
+    fix = dict(tiny.hp)
+    for k in ('batch_size', 'learning_rate', 'n_layers'):
+        fix.pop(k, None)
+    fix.update({'max_epochs': 6, 'seed': 3, 'lin_dropout': 0.0, 'compute_similarities': True})
+    cfg = tmp_path / 'config.json'
+    cfg.write_text(CONFIG % json.dumps(fix))
+    config.PROJECT_ROOT = tmp_path
+    rc = train_config.read_json(cfg)
+    assert rc['optuna']['monitor_metric'] == 'val_micro_f1' and 'no_gpu' not in rc
+    best, model, trainer = train_config.train_model(rc, results_dir=tmp_path / 'results', log=lambda *a: None)
+    assert model.hparams['batch_size'] == 8 and model.hparams['n_layers'] == 1
+    assert len(model.metric_scores) == 6 and 0.0 <= best <= 1.0
+    assert {'val_loss', 'val_micro_f1', 'val_macro_f1', 'val_acc', 'avg_val_acc', 'avg_macro_f1', 'val_auroc'} <= set(model.metric_scores[-1])
+    h = trainer.history
+    assert all(torch.isfinite(torch.tensor(e['train_loss'])) for e in h)
+    assert h[-1]['train_loss'] < h[0]['train_loss']                 # it learns the 10 training subgraphs
+    assert os.path.exists(tmp_path / 'results' / 'final_metric_scores.json')
+    assert os.path.exists(tmp_path / 'results' / 'hyperparams.json')
+    # the similarity cache was written with the reference's file names
+    sim = tmp_path / 'ds' / 'similarities'
+    names = set(os.listdir(sim))
+    assert '0_train_similarities.npy' in names and '2_0_train_border_set.npy' in names
+    assert any(n.startswith('int_struc_12_triangular_random_walk_2_0_train') for n in names)
+    res = trainer.test(model)
+    assert 'test_micro_f1' in model.test_results and torch.isfinite(res['avg_test_loss'])
