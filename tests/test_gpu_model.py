@@ -143,3 +143,21 @@ def test_forward_backward_parity_g11(tiny, tmp_path, variant, fused):
             assert_close(p.grad, ref, 'grad ' + nm)
             n += 1
     assert n > 10
+
+
+def test_precompute_graph_metrics(golden, tmp_path):
+    """GPU graph-metric precompute (the SNAP script's outputs) against the fixture's own files."""
+    import json as _json
+    import os
+    from subgnn_amd import precompute_graph_metrics as pgm
+    name = write_dataset_from_golden(golden, tmp_path, with_ego=True)
+    d = tmp_path / name
+    ref_deg = _json.load(open(d / 'degree_sequence.txt'))
+    ref_ego = _json.load(open(d / 'ego_graphs.txt'))
+    for f in ('degree_sequence.txt', 'ego_graphs.txt', 'shortest_path_matrix.npy'):
+        os.remove(d / f)
+    pgm.calculate_stats(d, torch.device(DEV))
+    assert np.array_equal(np.load(d / 'shortest_path_matrix.npy'), golden['apsp'])
+    assert _json.load(open(d / 'degree_sequence.txt')) == ref_deg
+    got = _json.load(open(d / 'ego_graphs.txt'))
+    assert {k: sorted(v) for k, v in got.items()} == {k: sorted(v) for k, v in ref_ego.items()}
