@@ -92,3 +92,18 @@ def test_product_never_imports_oracle():
             if f.endswith(('.py', '.hip', '.h')):
                 txt = open(os.path.join(dp, f)).read()
                 assert 'import oracle' not in txt and 'from oracle' not in txt, f
+
+
+def test_density_dataset_writer_round_trips(tmp_path):
+    """The synthetic DENSITY-style writer produces files the loaders read back."""
+    from subgnn_amd.prepare_dataset import write_density_dataset
+    from subgnn_amd.subgraph_utils import read_subgraphs
+    from subgnn_amd.graph import parse_edge_list, networkx_order_csr
+    d = write_density_dataset(tmp_path / 'density', n_nodes=300, m=4, n_subgraphs=40, subgraph_nodes=10, embed_dim=8)
+    tr, trl, va, val, te, tel = read_subgraphs(d / 'subgraphs.pth')
+    assert len(tr) == 32 and len(va) == 4 and len(te) == 4
+    assert set(trl.tolist()) <= {0, 1, 2} and all(len(s) == 10 for s in tr)
+    edges = parse_edge_list(d / 'edge_list.txt')
+    rp, col, order = networkx_order_csr(edges)
+    assert len(order) == 300 and rp[-1] == 2 * len(edges)
+    assert torch.load(d / 'gin_embeddings.pth').shape == (300, 8)
