@@ -102,7 +102,7 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     dist = None
-    if world > 1:
+    if world > 1 or 'RANK' in os.environ:            # launched by torch.distributed.run: one rank per GPU over RCCL
         import torch.distributed as dist
         dist.init_process_group('nccl', device_id=dev)
 

@@ -77,12 +77,14 @@ int sgnn_cc_labels(const int64_t* rowptr, const int32_t* col_sorted, int64_t nnz
  * of a set come in discovery order (not sorted).
  * ego_dict_mode != 0 reproduces the `ego_graphs.txt` path (su:168-174): 1 hop only and every
  * border id is (true id - 1), differenced against the 1-based component (id 0 can appear).
- * workspace: sgnn_khop_border_workspace_bytes(max_id, n_sets) bytes, ZERO-initialised by the
- * caller (per-workgroup visited bitmap + BFS queue; the bitmaps are left zeroed).
  * bitmap_in_lds != 0 keeps the visited bitmap in the CU's LDS (allowed iff
  * sgnn_khop_border_bitmap_fits_lds(max_id)); the results are the same either way.
+ * workspace: sgnn_khop_border_workspace_bytes(max_id, n_sets, bitmap_in_lds) bytes: per-workgroup
+ * BFS queues and, for the global variant, the visited bitmaps, which must be ZERO on entry (they
+ * are left zeroed, so one buffer can be reused across calls); the LDS variant needs no
+ * initialisation.
  * ------------------------------------------------------------------------------------- */
-int64_t sgnn_khop_border_workspace_bytes(int64_t max_id, int64_t n_sets);
+int64_t sgnn_khop_border_workspace_bytes(int64_t max_id, int64_t n_sets, int bitmap_in_lds);
 int sgnn_khop_border_bitmap_fits_lds(int64_t max_id);
 int sgnn_khop_border(const int64_t* rowptr, const int32_t* col, int64_t nnz, int64_t max_id,
                      const int64_t* set_ptr, const int32_t* set_nodes, int64_t n_sets,

@@ -109,10 +109,11 @@ static inline int64_t kb_n_wg(int64_t n_sets, bool lds) {
 
 extern "C" int sgnn_khop_border_bitmap_fits_lds(int64_t max_id) { return kb_fits_lds(max_id) ? 1 : 0; }
 
-extern "C" int64_t sgnn_khop_border_workspace_bytes(int64_t max_id, int64_t n_sets) {
-    // sized for the global-bitmap variant (the LDS variant uses the queue part only)
-    const int64_t per_wg = kb_words(max_id) * 4 + (max_id + 1) * 4;
-    return per_wg * kb_n_wg(n_sets, false);
+extern "C" int64_t sgnn_khop_border_workspace_bytes(int64_t max_id, int64_t n_sets, int bitmap_in_lds) {
+    // per workgroup: a BFS queue, plus the visited bitmap when it does not live in LDS
+    const bool lds = bitmap_in_lds != 0;
+    const int64_t per_wg = (lds ? 0 : kb_words(max_id) * 4) + (max_id + 1) * 4;
+    return per_wg * kb_n_wg(n_sets, lds);
 }
 
 struct KbSample {             // fused neighbourhood-border anchor draw (all NULL/0 = off)
@@ -271,14 +272,13 @@ static int kb_launch(const int64_t* rowptr, const int32_t* col, int64_t nnz, int
         return SGNN_ERR_BAD_ARG;
     if (out_nodes != nullptr && out_ptr == nullptr) return SGNN_ERR_BAD_ARG;
     if (nnz >= (1ll << 31)) return SGNN_ERR_NNZ_TOO_LARGE;
-    if (workspace_bytes < sgnn_khop_border_workspace_bytes(max_id, n_sets)) return SGNN_ERR_BAD_ARG;
     if (bitmap_in_lds && !kb_fits_lds(max_id)) return SGNN_ERR_BAD_ARG;
+    if (workspace_bytes < sgnn_khop_border_workspace_bytes(max_id, n_sets, bitmap_in_lds)) return SGNN_ERR_BAD_ARG;
     if (n_sets == 0) return SGNN_OK;
     const int64_t words = kb_words(max_id);
     const int64_t nwg = kb_n_wg(n_sets, bitmap_in_lds != 0);
-    const int64_t nwg_g = kb_n_wg(n_sets, false);
-    uint32_t* bitmaps = (uint32_t*)workspace;
-    int32_t* queues = (int32_t*)(bitmaps + words * nwg_g);        // same split for both variants
+    uint32_t* bitmaps = (uint32_t*)workspace;                     // empty region for the LDS variant
+    int32_t* queues = (int32_t*)(bitmaps + (bitmap_in_lds ? 0 : words * nwg));
     hipStream_t st = (hipStream_t)stream;
     if (bitmap_in_lds) {
         static bool attr_set = false;

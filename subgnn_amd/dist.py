@@ -26,7 +26,7 @@ def all_gather_rows(x):
     """(rows_r, H) per rank -> (sum rows, H) on every rank, ranks in order.  Row counts may
     differ between ranks (last shard shorter): rows are padded to the maximum for the collective
     and trimmed afterwards."""
-    if not is_initialized() or dist.get_world_size() == 1:
+    if not is_initialized():
         return x
     world = dist.get_world_size()
     n = torch.tensor([x.shape[0]], dtype=torch.int64, device=x.device)
@@ -50,7 +50,7 @@ def all_gather_rows(x):
 
 def all_reduce_gradients(params, average=True):
     """One flat all-reduce over every existing gradient (single bucket)."""
-    if not is_initialized() or dist.get_world_size() == 1:
+    if not is_initialized():
         return
     grads = [p.grad for p in params if p.grad is not None]
     if not grads:

@@ -124,6 +124,8 @@ def prepare_sparse(model, split='train', timer=None):
                     full = ops.min_hops_to_sets(d, cc_sets).view(S, C, -1)               # (S, C, U)
                     w = torch.gather(full, 2, inv.view(S, 1, -1).expand(S, C, -1))
                     sims[('P', 'in', l)] = (w * real.unsqueeze(-1)).contiguous()
+            if side is main:
+                t.mark('P_bfs_sims')
         if hp['use_structure']:
             if split != 'test' or getattr(model, 'structure_anchors', None) is None:
                 model.structure_anchors = aps.sample_structure_anchor_patches(hp, g, dev, hp['max_sim_epochs'])
@@ -135,6 +137,8 @@ def prepare_sparse(model, split='train', timer=None):
                                                                      model.bor_structure_anchor_random_walks)
             a_sets = ops.Ragged.from_padded(model.structure_anchors)
             ai, ae = ops.degree_sequence(g, a_sets, sort=True, use_degree_dict=g.full_degree is not None)
+            if side is main:
+                t.mark('S_patches_walks')
     # ---- main stream: neighbourhood channel + component degree sequences --------------------
     if hp['use_neighborhood']:
         k = hp['neigh_sample_border_size']
@@ -167,7 +171,8 @@ def prepare_sparse(model, split='train', timer=None):
         if getattr(model, 'anchors_structure', None):
             for v in model.anchors_structure.values():
                 _hand_over(main, v[0], v[2], v[3])
-    t.mark('side_stream_join(P_bfs,S_walks)')
+    if side is not main:
+        t.mark('side_stream_join(P_bfs,S_walks)')
     setattr(model, split + '_neigh_pos_similarities', sims if sims else None)
     setattr(model, split + '_N_border', None)
     if hp['use_structure']:

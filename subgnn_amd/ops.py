@@ -162,16 +162,26 @@ def cc_labels(g, subs):
     return out
 
 
-def _khop_ws(lib, g, n_sets):
-    ws_bytes = lib.sgnn_khop_border_workspace_bytes(g.max_id, n_sets)
-    return torch.zeros(ws_bytes // 4 + 1, dtype=torch.int32, device=g.device), ws_bytes
+_KHOP_WS = {}
+
+
+def _khop_ws(lib, g, n_sets, lds):
+    """Workspace of the border BFS, kept across calls (the kernel leaves the bitmaps zeroed, so the
+    buffer is zero-filled once when it is created; the LDS variant needs no initialisation)."""
+    ws_bytes = lib.sgnn_khop_border_workspace_bytes(g.max_id, n_sets, 1 if lds else 0)
+    key = (str(g.device), bool(lds))
+    buf = _KHOP_WS.get(key)
+    if buf is None or buf.numel() * 4 < ws_bytes:
+        buf = torch.zeros(ws_bytes // 4 + 1, dtype=torch.int32, device=g.device)
+        _KHOP_WS[key] = buf
+    return buf, ws_bytes
 
 
 def khop_border(g, sets, k, ego_dict_mode=False, want_hops=False, bitmap_in_lds=None):
     """k-hop border of every set -> Ragged (discovery order) [+ uint8 hop level per entry]."""
     lib = _lib.load()
     lds = bool(lib.sgnn_khop_border_bitmap_fits_lds(g.max_id)) if bitmap_in_lds is None else bool(bitmap_in_lds)
-    ws, ws_bytes = _khop_ws(lib, g, sets.n)
+    ws, ws_bytes = _khop_ws(lib, g, sets.n, lds)
     counts = torch.zeros(sets.n, dtype=torch.int64, device=g.device)
     check(lib.sgnn_khop_border(_ptr(g.rowptr), _ptr(g.col), g.nnz, g.max_id, _ptr(sets.ptr), _ptr(sets.nodes), sets.n,
                                k, 1 if ego_dict_mode else 0, _ptr(counts), None, None, None, _ptr(ws), ws_bytes,
@@ -194,7 +204,7 @@ def khop_border_sample(g, sets, k, n_slots, seed, stream_id, bitmap_in_lds=None)
     their hop levels as float32 similarities (0 on PAD) and the border sizes."""
     lib = _lib.load()
     lds = bool(lib.sgnn_khop_border_bitmap_fits_lds(g.max_id)) if bitmap_in_lds is None else bool(bitmap_in_lds)
-    ws, ws_bytes = _khop_ws(lib, g, sets.n)
+    ws, ws_bytes = _khop_ws(lib, g, sets.n, lds)
     anchor = torch.empty((sets.n, n_slots), dtype=torch.int64, device=g.device)
     hop = torch.empty((sets.n, n_slots), dtype=torch.uint8, device=g.device)
     allneg = torch.empty((sets.n, n_slots), dtype=torch.uint8, device=g.device)

@@ -20,13 +20,12 @@ def timeit(f, reps=3):
     torch.cuda.synchronize(); return (time.perf_counter() - t) / reps * 1e3
 
 def count_only(lds):
-    ws, wsb = ops._khop_ws(lib, g, sets.n)
+    ws, wsb = ops._khop_ws(lib, g, sets.n, lds)
     counts = torch.zeros(sets.n, dtype=torch.int64, device=dev)
     _lib.check(lib.sgnn_khop_border(ops._ptr(g.rowptr), ops._ptr(g.col), g.nnz, g.max_id, ops._ptr(sets.ptr), ops._ptr(sets.nodes),
                sets.n, 1, 0, ops._ptr(counts), None, None, None, ops._ptr(ws), wsb, 1 if lds else 0, ops._stream()), 'khop')
     return counts
 
-print('ws alloc+zero only', timeit(lambda: ops._khop_ws(lib, g, sets.n)))
 print('BFS count-only, LDS bitmap', timeit(lambda: count_only(True)))
 print('BFS count-only, global bitmap', timeit(lambda: count_only(False)))
 for A in (4, 16, 43):
