@@ -127,6 +127,49 @@ __global__ __launch_bounds__(256) void mpn_bwd_kernel(sgnn_mpn_args a, const flo
     }
 }
 
+// backward for GATHER with one lane per COLUMN: the lanes of a row are consecutive floats, so every
+// float-atomic wave-instruction covers whole contiguous row segments (256 B for D = 64) -- the
+// full-rate shape of global_atomic_add_f32 on gfx950; the float4-per-lane mapping of the forward
+// pass would issue four strided 16-lane fragments per row instead.  Edges whose weight is exactly
+// 0 (every N-internal edge: the similarity of a node inside the component is 0) add nothing and
+// are skipped.
+__global__ __launch_bounds__(256) void mpn_bwd_gather_kernel(sgnn_mpn_args a, const float* __restrict__ grad_agg,
+                                                             const float* __restrict__ grad_z,
+                                                             float* __restrict__ grad_x, float* __restrict__ grad_wp)
+{
+    __shared__ float s_gwp[1024];
+    const int64_t D = a.D;
+    if (grad_wp) {
+        for (int i = threadIdx.x; i < D; i += blockDim.x) s_gwp[i] = 0.f;
+        __syncthreads();
+    }
+    const int64_t total = a.R * D;
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = t / D, d = t % D;
+        const bool row_real = a.row_mask ? (a.row_mask[r] != 0) : true;
+        if (!row_real) continue;
+        const float wp = a.wp[d];
+        const float ga = grad_agg ? grad_agg[t] : 0.f;
+        const int64_t idrow = (a.id_div > 1 ? r / a.id_div : r) * a.A;
+        float gw = 0.f;
+        for (int64_t ai = 0; ai < a.A; ++ai) {
+            const int64_t id = a.ids[idrow + ai];
+            if (id == 0) continue;
+            const int64_t col = a.sim_col ? a.sim_col[ai] : (a.sims_per_edge ? ai : id - 1);
+            const float w = a.sims[r * a.sims_ld + col];
+            if (w == 0.f) continue;
+            const float gz = grad_z ? grad_z[r * a.A + ai] : 0.f;
+            if (grad_x) atomicAdd(grad_x + id * D + d, w * (ga + gz * wp));
+            if (grad_wp && gz != 0.f) gw += gz * w * a.x[id * D + d];
+        }
+        if (grad_wp) atomicAdd(&s_gwp[d], gw);
+    }
+    if (grad_wp) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < D; i += blockDim.x) atomicAdd(&grad_wp[i], s_gwp[i]);
+    }
+}
+
 // backward for SHARED anchors: dX[a,:] = sum_r edge * w[r,a] * (g_agg[r,:] + g_z[r,a] * wp).
 // One workgroup per tile of rows; thread items are (anchor, column slice); the tile's g_agg rows
 // are re-read per anchor from L1/L2; one atomic row-add per (tile, anchor).
@@ -234,8 +277,8 @@ extern "C" int sgnn_mpn_bwd(const sgnn_mpn_args* args, const float* grad_agg, co
             hipLaunchKernelGGL(mpn_bwd_kernel<SGNN_SRC_DENSE>, dim3(grid), dim3(256), 0, st, *args, grad_agg, grad_z,
                                grad_x, grad_wp, D4);
         else
-            hipLaunchKernelGGL(mpn_bwd_kernel<SGNN_SRC_GATHER>, dim3(grid), dim3(256), 0, st, *args, grad_agg, grad_z,
-                               grad_x, grad_wp, D4);
+            hipLaunchKernelGGL(mpn_bwd_gather_kernel, dim3(sgnn_grid_for(args->R * args->D, 256, 8192)), dim3(256), 0, st,
+                               *args, grad_agg, grad_z, grad_x, grad_wp);
     }
     SGNN_CHECK_LAUNCH();
     return SGNN_OK;

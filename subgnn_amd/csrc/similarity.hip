@@ -92,12 +92,16 @@ __global__ __launch_bounds__(256) void msbfs_expand_kernel(
     const int64_t group = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 4;
     const int64_t n_groups = ((int64_t)gridDim.x * blockDim.x) >> 4;
     for (int64_t v = group; v < n_ids; v += n_groups) {
-        for (int64_t w = 0; w < n_words; ++w) {
-            const uint64_t f = frontier[v * n_words + w];
-            if (f == 0) continue;
-            const int64_t r0 = rowptr[v], r1 = rowptr[v + 1];
-            for (int64_t e = r0 + sub; e < r1; e += 16) {
-                const int64_t u = col[e];
+        uint64_t any = 0;
+        for (int64_t w = 0; w < n_words; ++w) any |= frontier[v * n_words + w];
+        if (any == 0) continue;
+        // one pass over the neighbour list for all source words: col[] is read once, and the
+        // n_words seen/next words of a neighbour are contiguous
+        const int64_t r0 = rowptr[v], r1 = rowptr[v + 1];
+        for (int64_t e = r0 + sub; e < r1; e += 16) {
+            const int64_t u = col[e];
+            for (int64_t w = 0; w < n_words; ++w) {
+                const uint64_t f = frontier[v * n_words + w];
                 const uint64_t m = f & ~seen[u * n_words + w];
                 if (m) atomicOr((unsigned long long*)&next[u * n_words + w], (unsigned long long)m);
             }

@@ -146,10 +146,8 @@ def components_from_labels(sub_ptr, sub_nodes, labels):
     ckey_k = ckey[keep]
     order = torch.sort(ckey_k, stable=True)[1]
     sorted_key = ckey_k[order]
-    grp_start = torch.ones(sorted_key.numel(), dtype=torch.bool, device=dev)
-    grp_start[1:] = sorted_key[1:] != sorted_key[:-1]
     idx = torch.arange(sorted_key.numel(), device=dev)
-    start_idx = torch.cummax(torch.where(grp_start, idx, torch.zeros_like(idx)), 0)[0]
+    start_idx = torch.searchsorted(sorted_key, sorted_key, right=False)      # first index of my group
     within = idx - start_idx
     L = int(within.max().item()) + 1
     out = torch.zeros((S * C, L), dtype=torch.int64, device=dev)
