@@ -140,6 +140,11 @@ extern "C" int sgnn_choice_ragged(const int64_t* ptr, const int32_t* seq, int64_
 // position of the drawn candidate (pass 2).  The walk state (tape counter, prev, curr) is
 // wave-uniform.  Latency-bound integer work; the walks are few (patches x walks).
 // ---------------------------------------------------------------------------------------------
+#define WK_HASH_BITS 8
+#define WK_HASH (1 << WK_HASH_BITS)
+#define WK_HASH_MAX 96          // patches / in-border sets up to this size use the LDS hash (else linear scan)
+#define WK_CHUNKS 1024          // classification masks cached for neighbour lists up to 64 * WK_CHUNKS entries
+
 struct WalkCtx {
     const int64_t* rowptr;
     const int32_t* col;
@@ -149,6 +154,9 @@ struct WalkCtx {
     const int32_t* inb;       // in-border nodes (mode 2)
     int32_t n_inb;
     int mode;
+    const int32_t* hpatch;    // LDS hash of the patch (nullptr: linear scan)
+    const int32_t* hinb;      // LDS hash of the in-border set
+    int pp, pi;               // wave-uniform probe counts of the two hashes
 };
 
 __device__ static inline bool walk_in_list(const int32_t* a, int32_t n, int32_t v) {
@@ -157,21 +165,56 @@ __device__ static inline bool walk_in_list(const int32_t* a, int32_t n, int32_t 
     return false;
 }
 
-__device__ static inline bool walk_valid(const WalkCtx& c, int32_t v) {
-    if (c.mode == 0) return true;
-    const bool member = walk_in_list(c.patch, c.n_patch, v);
-    if (c.mode == 1) return member;
-    return !member || walk_in_list(c.inb, c.n_inb, v);       // aps:143
+__device__ static inline bool walk_in_hash(const int32_t* h, int P, int32_t v) {
+    const uint32_t b = sgnn_hash32((uint32_t)v) >> (32 - WK_HASH_BITS);
+    int hit = 0;
+    for (int p = 0; p < P; ++p) hit |= (h[(b + p) & (WK_HASH - 1)] == v);
+    return hit != 0;
 }
 
-// pass 1: counts of valid neighbours of v that are / are not adjacent to prev (prev = 0: no test)
-__device__ static inline void walk_count(const WalkCtx& c, int32_t v, int32_t prev, int lane, int32_t& nt, int32_t& nn) {
+// wave-cooperative build of a membership hash; returns the longest probe chain (wave-uniform)
+__device__ static inline int walk_build_hash(int32_t* h, const int32_t* a, int32_t n, int lane) {
+#pragma unroll
+    for (int q = 0; q < WK_HASH / 64; ++q) h[lane + 64 * q] = 0;
+    __syncthreads();
+    int chain = 0;
+    for (int i = lane; i < n; i += 64) {
+        const int32_t v = a[i];
+        uint32_t b = sgnn_hash32((uint32_t)v) >> (32 - WK_HASH_BITS);
+        int c = 0;
+        while (true) {
+            ++c;
+            const int32_t old = atomicCAS(&h[b], 0, v);
+            if (old == 0 || old == v) break;
+            b = (b + 1) & (WK_HASH - 1);
+        }
+        chain = c > chain ? c : chain;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { const int o = __shfl_xor(chain, d); chain = o > chain ? o : chain; }
+    __syncthreads();
+    return chain;
+}
+
+__device__ static inline bool walk_valid(const WalkCtx& c, int32_t v) {
+    if (c.mode == 0) return true;
+    const bool member = c.hpatch ? walk_in_hash(c.hpatch, c.pp, v) : walk_in_list(c.patch, c.n_patch, v);
+    if (c.mode == 1) return member;
+    if (!member) return true;                                                        // aps:143
+    return c.hinb ? walk_in_hash(c.hinb, c.pi, v) : walk_in_list(c.inb, c.n_inb, v);
+}
+
+// pass 1: classify the valid neighbours of v (adjacent to prev or not; prev = 0: no test), count both
+// classes and keep the per-chunk ballots in LDS for pass 2 (lists longer than the cache: not kept)
+__device__ static inline void walk_count(const WalkCtx& c, int32_t v, int32_t prev, int lane, int32_t& nt, int32_t& nn,
+                                         uint64_t* s_tri, uint64_t* s_non) {
     const int64_t r0 = c.rowptr[v], r1 = c.rowptr[v + 1];
     int64_t p0 = 0;
     int32_t pdeg = 0;
     if (prev) { p0 = c.rowptr[prev]; pdeg = (int32_t)(c.rowptr[prev + 1] - p0); }
     nt = 0; nn = 0;
-    for (int64_t base = r0; base < r1; base += 64) {
+    int chunk = 0;
+    for (int64_t base = r0; base < r1; base += 64, ++chunk) {
         const int64_t e = base + lane;
         bool ok = false, tri = false;
         if (e < r1) {
@@ -179,18 +222,37 @@ __device__ static inline void walk_count(const WalkCtx& c, int32_t v, int32_t pr
             ok = walk_valid(c, w);
             if (ok && prev) tri = sgnn_sorted_contains(c.col_sorted + p0, pdeg, w);
         }
-        nt += __popcll(__ballot(ok && tri));
-        nn += __popcll(__ballot(ok && !tri));
+        const uint64_t mt = __ballot(ok && tri), mn = __ballot(ok && !tri);
+        if (chunk < WK_CHUNKS && lane == 0) { s_tri[chunk] = mt; s_non[chunk] = mn; }
+        nt += __popcll(mt);
+        nn += __popcll(mn);
     }
 }
 
-// pass 2: the pick-th (0-based, adjacency order) valid neighbour of v in the wanted class
-__device__ static inline int32_t walk_pick(const WalkCtx& c, int32_t v, int32_t prev, bool want_tri, int32_t pick, int lane) {
+// pass 2: the pick-th (0-based, adjacency order) valid neighbour of v in the wanted class, from the
+// cached ballots (one load of col[]), or by re-classifying when the list exceeded the cache
+__device__ static inline int32_t walk_pick(const WalkCtx& c, int32_t v, int32_t prev, bool want_tri, int32_t pick, int lane,
+                                           const uint64_t* s_tri, const uint64_t* s_non) {
     const int64_t r0 = c.rowptr[v], r1 = c.rowptr[v + 1];
+    const int64_t n_chunks = (r1 - r0 + 63) / 64;
+    int32_t seen = 0;
+    if (n_chunks <= WK_CHUNKS) {
+        const uint64_t* s = want_tri ? s_tri : s_non;
+        for (int64_t ch = 0; ch < n_chunks; ++ch) {
+            uint64_t m = s[ch];
+            const int32_t cnt = __popcll(m);
+            if (seen + cnt > pick) {
+                int k = pick - seen;                          // k-th set bit of m
+                while (k-- > 0) m &= m - 1;
+                return c.col[r0 + ch * 64 + (__ffsll((unsigned long long)m) - 1)];
+            }
+            seen += cnt;
+        }
+        return 0;
+    }
     int64_t p0 = 0;
     int32_t pdeg = 0;
     if (prev) { p0 = c.rowptr[prev]; pdeg = (int32_t)(c.rowptr[prev + 1] - p0); }
-    int32_t seen = 0;
     for (int64_t base = r0; base < r1; base += 64) {
         const int64_t e = base + lane;
         bool hit = false;
@@ -223,6 +285,8 @@ __global__ __launch_bounds__(64) void triangular_walks_kernel(
     int mode, int64_t n_items, int64_t walks_per_patch, int64_t walk_len, double beta,
     uint64_t h0, int64_t* __restrict__ out)
 {
+    __shared__ uint64_t s_tri[WK_CHUNKS], s_non[WK_CHUNKS];
+    __shared__ int32_t s_hp[WK_HASH], s_hi[WK_HASH];
     const int lane = threadIdx.x;
     for (int64_t item = blockIdx.x; item < n_items; item += gridDim.x) {
         int64_t* o = out + item * walk_len;
@@ -230,9 +294,11 @@ __global__ __launch_bounds__(64) void triangular_walks_kernel(
         WalkCtx c;
         c.rowptr = rowptr; c.col = col; c.col_sorted = col_sorted; c.mode = mode;
         c.patch = nullptr; c.n_patch = 0; c.inb = nullptr; c.n_inb = 0;
+        c.hpatch = nullptr; c.hinb = nullptr; c.pp = 0; c.pi = 0;
         const uint64_t h1 = sgnn_tape_h1(h0, (uint64_t)item);
         uint64_t j = 0;
         int32_t prev;
+        __syncthreads();                            // previous item's LDS tables are no longer read
         if (mode == 0) {
             prev = node_order[sgnn_choice_index(h1, j++, (uint32_t)n_nodes)];          // aps:70
         } else {
@@ -240,12 +306,14 @@ __global__ __launch_bounds__(64) void triangular_walks_kernel(
             c.patch = patch_nodes + patch_ptr[p];
             c.n_patch = (int32_t)(patch_ptr[p + 1] - patch_ptr[p]);
             if (c.n_patch == 0) continue;                                              // aps:134-135
+            if (c.n_patch <= WK_HASH_MAX) { c.pp = walk_build_hash(s_hp, c.patch, c.n_patch, lane); c.hpatch = s_hp; }
             if (mode == 1) {
                 prev = c.patch[sgnn_choice_index(h1, j++, (uint32_t)c.n_patch)];      // aps:70
             } else {
                 c.inb = inb_nodes + inb_ptr[p];
                 c.n_inb = (int32_t)(inb_ptr[p + 1] - inb_ptr[p]);
                 if (c.n_inb == 0) continue;        // reference raises ValueError here (aps:78)
+                if (c.n_inb <= WK_HASH_MAX) { c.pi = walk_build_hash(s_hi, c.inb, c.n_inb, lane); c.hinb = s_hi; }
                 prev = c.inb[sgnn_choice_index(h1, j++, (uint32_t)c.n_inb)];          // aps:78
             }
         }
@@ -253,19 +321,22 @@ __global__ __launch_bounds__(64) void triangular_walks_kernel(
         __syncthreads();                            // zero fill above precedes the lane-0 writes
         if (lane == 0) o[0] = prev;
         int32_t nt, nn;
-        walk_count(c, prev, 0, lane, nt, nn);                                            // aps:72,79
+        walk_count(c, prev, 0, lane, nt, nn, s_tri, s_non);                              // aps:72,79
         if (nn == 0 || walk_len < 2) continue;                                          // aps:83-84
-        int32_t curr = walk_pick(c, prev, 0, false, (int32_t)sgnn_choice_index(h1, j++, (uint32_t)nn), lane);   // aps:74,80
+        __syncthreads();
+        int32_t curr = walk_pick(c, prev, 0, false, (int32_t)sgnn_choice_index(h1, j++, (uint32_t)nn), lane, s_tri, s_non);   // aps:74,80
         if (lane == 0) o[1] = curr;
         for (int64_t step = 2; step < walk_len; ++step) {
-            walk_count(c, curr, prev, lane, nt, nn);                                     // aps:35-45
+            __syncthreads();                        // pass 2 of the previous step has read the masks
+            walk_count(c, curr, prev, lane, nt, nn, s_tri, s_non);                       // aps:35-45
             if (nt + nn == 0) break;                                                     // aps:94
             bool want_tri;
             if (nt == 0) want_tri = false;                                               // aps:97-98
             else if (nn == 0) want_tri = true;                                           // aps:99-100
             else want_tri = (sgnn_uniform01(h1, j++) <= beta);                           // aps:102
             const int32_t pick = (int32_t)sgnn_choice_index(h1, j++, (uint32_t)(want_tri ? nt : nn));
-            const int32_t nxt = walk_pick(c, curr, prev, want_tri, pick, lane);
+            __syncthreads();
+            const int32_t nxt = walk_pick(c, curr, prev, want_tri, pick, lane, s_tri, s_non);
             prev = curr;
             curr = nxt;
             if (lane == 0) o[step] = nxt;
