@@ -171,10 +171,12 @@ int sgnn_sp_similarity_dense(const double* apsp, int64_t n_cols,
  * workspace: sgnn_bfs_hops_workspace_bytes(max_id, n_sources, max_hops) bytes (any content). */
 int64_t sgnn_bfs_hops_workspace_bytes(int64_t max_id, int64_t n_sources, int max_hops);
 int sgnn_bfs_hops(const int64_t* rowptr, const int32_t* col, int64_t nnz, int64_t max_id,
-                  const int32_t* sources, int64_t n_sources, int max_hops,
+                  const int32_t* sources, int64_t n_sources, int max_hops, int node_major,
                   uint8_t* dist, void* workspace, int64_t workspace_bytes, void* stream);
 /* out[r, a] = min over v in set r of (dist[a, v] == 255 ? 0 : dist[a, v])  (float32; empty set -> 0) */
-int sgnn_min_hops_to_sets(const uint8_t* dist, int64_t n_sources, int64_t max_id,
+/* node_major != 0: dist is laid out (max_id + 1, n_sources) instead -- the sources of a node are
+ * contiguous, which coalesces both the BFS writes and the per-(set, source) min below */
+int sgnn_min_hops_to_sets(const uint8_t* dist, int64_t n_sources, int64_t max_id, int node_major,
                           const int64_t* set_ptr, const int32_t* set_nodes, int64_t n_sets,
                           float* out, void* stream);
 

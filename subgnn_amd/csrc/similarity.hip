@@ -60,7 +60,7 @@ extern "C" int sgnn_sp_similarity_dense(const double* apsp, int64_t n_cols,
 __global__ void msbfs_init_kernel(const int32_t* __restrict__ sources, int64_t n_sources, int64_t n_words,
                                   int64_t n_ids, uint64_t* __restrict__ seen, uint64_t* __restrict__ frontier,
                                   uint64_t* __restrict__ next, uint8_t* __restrict__ dist, int32_t* __restrict__ flags,
-                                  int max_hops)
+                                  int max_hops)  // dist layout-agnostic: filled as a flat array
 {
     const int64_t gtid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
@@ -71,7 +71,7 @@ __global__ void msbfs_init_kernel(const int32_t* __restrict__ sources, int64_t n
 
 __global__ void msbfs_seed_kernel(const int32_t* __restrict__ sources, int64_t n_sources, int64_t n_words,
                                   int64_t n_ids, uint64_t* __restrict__ seen, uint64_t* __restrict__ frontier,
-                                  uint8_t* __restrict__ dist)
+                                  uint8_t* __restrict__ dist, int64_t ss, int64_t sv)
 {
     const int64_t s = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (s >= n_sources) return;
@@ -79,7 +79,7 @@ __global__ void msbfs_seed_kernel(const int32_t* __restrict__ sources, int64_t n
     const uint64_t bit = 1ull << (s & 63);
     atomicOr((unsigned long long*)&seen[(int64_t)v * n_words + (s >> 6)], (unsigned long long)bit);
     atomicOr((unsigned long long*)&frontier[(int64_t)v * n_words + (s >> 6)], (unsigned long long)bit);
-    dist[s * n_ids + v] = 0;
+    dist[s * ss + v * sv] = 0;
 }
 
 __global__ __launch_bounds__(256) void msbfs_expand_kernel(
@@ -111,7 +111,8 @@ __global__ __launch_bounds__(256) void msbfs_expand_kernel(
 
 __global__ __launch_bounds__(256) void msbfs_commit_kernel(
     int64_t n_ids, int64_t n_words, int64_t n_sources, uint64_t* __restrict__ seen, uint64_t* __restrict__ frontier,
-    uint64_t* __restrict__ next, uint8_t* __restrict__ dist, int32_t* __restrict__ flags, int level)
+    uint64_t* __restrict__ next, uint8_t* __restrict__ dist, int32_t* __restrict__ flags, int level,
+    int64_t ss, int64_t sv)
 {
     if (flags[level - 1] == 0) return;
     bool any = false;
@@ -129,7 +130,7 @@ __global__ __launch_bounds__(256) void msbfs_commit_kernel(
                 const int b = __ffsll((unsigned long long)bits) - 1;
                 bits &= bits - 1;
                 const int64_t s = w * 64 + b;
-                if (s < n_sources) dist[s * n_ids + v] = (uint8_t)level;
+                if (s < n_sources) dist[s * ss + v * sv] = (uint8_t)level;
             }
         }
     }
@@ -142,7 +143,7 @@ extern "C" int64_t sgnn_bfs_hops_workspace_bytes(int64_t max_id, int64_t n_sourc
 }
 
 extern "C" int sgnn_bfs_hops(const int64_t* rowptr, const int32_t* col, int64_t nnz, int64_t max_id,
-                             const int32_t* sources, int64_t n_sources, int max_hops,
+                             const int32_t* sources, int64_t n_sources, int max_hops, int node_major,
                              uint8_t* dist, void* workspace, int64_t workspace_bytes, void* stream)
 {
     if (!rowptr || !col || !sources || !dist || !workspace || n_sources < 0 || max_hops < 1 || max_hops > 254)
@@ -153,6 +154,7 @@ extern "C" int sgnn_bfs_hops(const int64_t* rowptr, const int32_t* col, int64_t 
     hipStream_t st = (hipStream_t)stream;
     const int64_t n_ids = max_id + 1;
     const int64_t n_words = (n_sources + 63) / 64;
+    const int64_t ss = node_major ? 1 : n_ids, sv = node_major ? n_sources : 1;
     uint64_t* seen = (uint64_t*)workspace;
     uint64_t* frontier = seen + n_ids * n_words;
     uint64_t* next = frontier + n_ids * n_words;
@@ -162,7 +164,7 @@ extern "C" int sgnn_bfs_hops(const int64_t* rowptr, const int32_t* col, int64_t 
                        frontier, next, dist, flags, max_hops);
     SGNN_CHECK_LAUNCH();
     hipLaunchKernelGGL(msbfs_seed_kernel, dim3((int)((n_sources + 255) / 256)), dim3(256), 0, st, sources, n_sources,
-                       n_words, n_ids, seen, frontier, dist);
+                       n_words, n_ids, seen, frontier, dist, ss, sv);
     SGNN_CHECK_LAUNCH();
     const int g_expand = sgnn_grid_for(n_ids * 16, 256);
     const int g_commit = sgnn_grid_for(n_ids * n_words, 256);
@@ -171,7 +173,7 @@ extern "C" int sgnn_bfs_hops(const int64_t* rowptr, const int32_t* col, int64_t 
                            frontier, next, flags, level);
         SGNN_CHECK_LAUNCH();
         hipLaunchKernelGGL(msbfs_commit_kernel, dim3(g_commit), dim3(256), 0, st, n_ids, n_words, n_sources, seen,
-                           frontier, next, dist, flags, level);
+                           frontier, next, dist, flags, level, ss, sv);
         SGNN_CHECK_LAUNCH();
     }
     return SGNN_OK;
@@ -179,7 +181,7 @@ extern "C" int sgnn_bfs_hops(const int64_t* rowptr, const int32_t* col, int64_t 
 
 __global__ void min_hops_to_sets_kernel(const uint8_t* __restrict__ dist, int64_t n_sources, int64_t n_ids,
                                         const int64_t* __restrict__ set_ptr, const int32_t* __restrict__ set_nodes,
-                                        int64_t n_sets, float* __restrict__ out)
+                                        int64_t n_sets, float* __restrict__ out, int64_t ss, int64_t sv)
 {
     const int64_t total = n_sets * n_sources;
     for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
@@ -188,7 +190,7 @@ __global__ void min_hops_to_sets_kernel(const uint8_t* __restrict__ dist, int64_
         const int n = (int)(set_ptr[r + 1] - beg);
         int m = 0;
         for (int i = 0; i < n; ++i) {
-            int d = dist[a * n_ids + set_nodes[beg + i]];
+            int d = dist[a * ss + (int64_t)set_nodes[beg + i] * sv];
             if (d == 255) d = 0;                               // unreachable pairs hold 0 in the matrix
             m = (i == 0 || d < m) ? d : m;
         }
@@ -196,14 +198,15 @@ __global__ void min_hops_to_sets_kernel(const uint8_t* __restrict__ dist, int64_
     }
 }
 
-extern "C" int sgnn_min_hops_to_sets(const uint8_t* dist, int64_t n_sources, int64_t max_id,
+extern "C" int sgnn_min_hops_to_sets(const uint8_t* dist, int64_t n_sources, int64_t max_id, int node_major,
                                      const int64_t* set_ptr, const int32_t* set_nodes, int64_t n_sets,
                                      float* out, void* stream)
 {
     if (!dist || !set_ptr || !set_nodes || !out || n_sources < 0 || n_sets < 0) return SGNN_ERR_BAD_ARG;
     if (n_sets * n_sources == 0) return SGNN_OK;
     hipLaunchKernelGGL(min_hops_to_sets_kernel, dim3(sgnn_grid_for(n_sets * n_sources, 256)), dim3(256), 0,
-                       (hipStream_t)stream, dist, n_sources, max_id + 1, set_ptr, set_nodes, n_sets, out);
+                       (hipStream_t)stream, dist, n_sources, max_id + 1, set_ptr, set_nodes, n_sets, out,
+                       node_major ? 1 : max_id + 1, node_major ? n_sources : 1);
     SGNN_CHECK_LAUNCH();
     return SGNN_OK;
 }

@@ -109,8 +109,8 @@ def prepare_sparse(model, split='train', timer=None):
             model.anchors_pos_int[split] = pint
             for l in range(L):
                 dist = ops.bfs_hops(g, model.anchors_pos_ext[l].to(torch.int32).contiguous(),
-                                    max_hops=hp.get('max_bfs_hops', 32))
-                w = ops.min_hops_to_sets(dist, cc_sets).view(S, C, -1)
+                                    max_hops=hp.get('max_bfs_hops', 32), node_major=True)
+                w = ops.min_hops_to_sets(dist, cc_sets, node_major=True).view(S, C, -1)
                 sims[('P', 'out', l)] = (w * real.unsqueeze(-1)).contiguous()
                 if C == 1:
                     sims[('P', 'in', l)] = torch.zeros((S, C, hp['n_anchor_patches_pos_in']), dtype=torch.float32,
@@ -120,8 +120,9 @@ def prepare_sparse(model, split='train', timer=None):
                     if uniq.numel() > MAX_PINT_SOURCES:
                         raise NotImplementedError('sparse P-internal similarities for multi-component subgraphs need '
                                                   'a BFS per distinct anchor (%d > %d)' % (uniq.numel(), MAX_PINT_SOURCES))
-                    d = ops.bfs_hops(g, uniq.to(torch.int32).contiguous(), max_hops=hp.get('max_bfs_hops', 32))
-                    full = ops.min_hops_to_sets(d, cc_sets).view(S, C, -1)               # (S, C, U)
+                    d = ops.bfs_hops(g, uniq.to(torch.int32).contiguous(), max_hops=hp.get('max_bfs_hops', 32),
+                                     node_major=True)
+                    full = ops.min_hops_to_sets(d, cc_sets, node_major=True).view(S, C, -1)     # (S, C, U)
                     w = torch.gather(full, 2, inv.view(S, 1, -1).expand(S, C, -1))
                     sims[('P', 'in', l)] = (w * real.unsqueeze(-1)).contiguous()
             if side is main:

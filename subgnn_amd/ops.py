@@ -303,26 +303,31 @@ def sp_similarity_dense(apsp, sets):
     return out
 
 
-def bfs_hops(g, sources, max_hops=64):
-    """(n_sources, max_id+1) uint8 hop counts (255 = not reached) by multi-source BFS."""
+def bfs_hops(g, sources, max_hops=64, node_major=False):
+    """uint8 hop counts (255 = not reached) by multi-source BFS: (n_sources, max_id+1), or
+    (max_id+1, n_sources) when ``node_major`` (coalesced for min_hops_to_sets)."""
     lib = _lib.load()
     _req(sources, torch.int32, 'sources')
     ns = sources.numel()
-    dist = torch.empty((ns, g.max_id + 1), dtype=torch.uint8, device=g.device)
+    shape = (g.max_id + 1, ns) if node_major else (ns, g.max_id + 1)
+    dist = torch.empty(shape, dtype=torch.uint8, device=g.device)
     wsb = lib.sgnn_bfs_hops_workspace_bytes(g.max_id, ns, max_hops)
     ws = torch.empty(wsb // 8 + 1, dtype=torch.int64, device=g.device)
-    check(lib.sgnn_bfs_hops(_ptr(g.rowptr), _ptr(g.col), g.nnz, g.max_id, _ptr(sources), ns, max_hops, _ptr(dist),
-                            _ptr(ws), wsb, _stream()), 'sgnn_bfs_hops')
+    check(lib.sgnn_bfs_hops(_ptr(g.rowptr), _ptr(g.col), g.nnz, g.max_id, _ptr(sources), ns, max_hops,
+                            1 if node_major else 0, _ptr(dist), _ptr(ws), wsb, _stream()), 'sgnn_bfs_hops')
     return dist
 
 
-def min_hops_to_sets(dist, sets):
+def min_hops_to_sets(dist, sets, node_major=False):
     lib = _lib.load()
     _req(dist, torch.uint8, 'dist')
-    ns, n_ids = dist.shape
+    if node_major:
+        n_ids, ns = dist.shape
+    else:
+        ns, n_ids = dist.shape
     out = torch.empty((sets.n, ns), dtype=torch.float32, device=dist.device)
-    check(lib.sgnn_min_hops_to_sets(_ptr(dist), ns, n_ids - 1, _ptr(sets.ptr), _ptr(sets.nodes), sets.n, _ptr(out),
-                                    _stream()), 'sgnn_min_hops_to_sets')
+    check(lib.sgnn_min_hops_to_sets(_ptr(dist), ns, n_ids - 1, 1 if node_major else 0, _ptr(sets.ptr), _ptr(sets.nodes),
+                                    sets.n, _ptr(out), _stream()), 'sgnn_min_hops_to_sets')
     return out
 
 

@@ -342,6 +342,9 @@ def test_bfs_hops_matches_apsp(golden):
     got = ops.min_hops_to_sets(dist, sets).cpu().numpy()
     ref = golden['g4_np_sim_train'].reshape(S * C, -1)[:, src - 1]
     assert np.array_equal(got, ref)
+    dist_t = ops.bfs_hops(dg, torch.from_numpy(src).to(DEV), max_hops=32, node_major=True)      # (ids, sources)
+    assert torch.equal(dist_t.t().contiguous(), dist)
+    assert np.array_equal(ops.min_hops_to_sets(dist_t, sets, node_major=True).cpu().numpy(), ref)
 
 
 # ---- a11 DTW ------------------------------------------------------------------------------
