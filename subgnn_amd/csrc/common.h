@@ -66,6 +66,31 @@ __host__ __device__ static inline int64_t sgnn_symmetric_key(uint64_t h1, uint64
     return (int64_t)(int32_t)hi * (int64_t)(1 << 21) + (int64_t)(lo >> 11);
 }
 
+// The key orders lexicographically by (hi word signed, low 21 bits), so a running argmax only needs
+// the second hash when the first one ties or beats the current best -- which happens O(log n) times
+// per lane over n entries.  (id 0 = PAD-as-member holds key 0.)
+__host__ __device__ static inline int32_t sgnn_key_hi(uint64_t h1, uint32_t v) {
+    return v == 0 ? 0 : (int32_t)sgnn_lowbias32(v ^ (uint32_t)h1);
+}
+__host__ __device__ static inline uint32_t sgnn_key_lo(uint64_t h1, uint32_t v) {
+    return v == 0 ? 0u : (sgnn_lowbias32(v ^ (uint32_t)(h1 >> 32)) >> 11);
+}
+__host__ __device__ static inline int64_t sgnn_key_join(int32_t hi, uint32_t lo) {
+    return (int64_t)hi * (int64_t)(1 << 21) + (int64_t)lo;
+}
+// running argmax update for one candidate (col c, id v); best_lo is valid whenever best_hi came from
+// a real candidate; ties on the full key keep the earlier column
+#define SGNN_KEY_UPDATE(h1, v, c, best_hi, best_lo, bcol, bid)                                   \
+    do {                                                                                         \
+        const int32_t _hi = sgnn_key_hi((h1), (uint32_t)(v));                                    \
+        if (_hi >= (best_hi)) {                                                                  \
+            const uint32_t _lo = sgnn_key_lo((h1), (uint32_t)(v));                               \
+            if (_hi > (best_hi) || _lo > (best_lo) || (bcol) == INT32_MAX) {                      \
+                (best_hi) = _hi; (best_lo) = _lo; (bcol) = (int32_t)(c); (bid) = (int32_t)(v);    \
+            }                                                                                    \
+        }                                                                                        \
+    } while (0)
+
 // ---- small device helpers ---------------------------------------------------------------
 __device__ static inline uint32_t sgnn_hash32(uint32_t x) { return x * 2654435761u; }
 

@@ -130,12 +130,12 @@ __device__ __forceinline__ void kb_draw(const KbSample& smp, int64_t s, const in
 {
     for (int64_t s0 = (int64_t)wave * SC; s0 < smp.n_slots; s0 += (int64_t)NW * SC) {
         uint64_t h1[SC];
-        int64_t best[SC];
-        int32_t bcol[SC], bid[SC];
+        int32_t bhi[SC], bcol[SC], bid[SC];
+        uint32_t blo[SC];
 #pragma unroll
         for (int u = 0; u < SC; ++u) {
             h1[u] = sgnn_tape_h1(smp.h0, (uint64_t)(s * smp.n_slots + s0 + u));
-            best[u] = INT64_MIN; bcol[u] = INT32_MAX; bid[u] = 0;
+            bhi[u] = INT32_MIN; blo[u] = 0; bcol[u] = INT32_MAX; bid[u] = 0;
         }
         for (int c0 = lane; c0 < cnt; c0 += 256) {          // 4 independent loads in flight per lane
             int32_t v[4];
@@ -146,13 +146,13 @@ __device__ __forceinline__ void kb_draw(const KbSample& smp, int64_t s, const in
                 const int c = c0 + 64 * k;
                 if (c < cnt) {
 #pragma unroll
-                    for (int u = 0; u < SC; ++u) {
-                        const int64_t key = (v[k] == 0) ? 0 : sgnn_symmetric_key(h1[u], (uint64_t)v[k]);
-                        if (key > best[u]) { best[u] = key; bcol[u] = c; bid[u] = v[k]; }
-                    }
+                    for (int u = 0; u < SC; ++u) SGNN_KEY_UPDATE(h1[u], v[k], c, bhi[u], blo[u], bcol[u], bid[u]);
                 }
             }
         }
+        int64_t best[SC];
+#pragma unroll
+        for (int u = 0; u < SC; ++u) best[u] = bcol[u] == INT32_MAX ? INT64_MIN : sgnn_key_join(bhi[u], blo[u]);
 #pragma unroll
         for (int u = 0; u < SC; ++u) {
             sgnn_argmax_reduce(best[u], bcol[u], bid[u]);

@@ -17,13 +17,13 @@ __global__ __launch_bounds__(64) void sample_anchors_padded_kernel(
         const int64_t* row = ids + r * L;
         for (int64_t i = 0; i < n_slots; ++i) {
             const uint64_t h1 = sgnn_tape_h1(h0, (uint64_t)(r * n_slots + i));
-            int64_t best = INT64_MIN;
-            int32_t bcol = INT32_MAX, bid = 0;
+            int32_t bhi = INT32_MIN, bcol = INT32_MAX, bid = 0;
+            uint32_t blo = 0;
             for (int64_t c = lane; c < L; c += 64) {
                 const int64_t v = row[c];
-                const int64_t key = (v == 0) ? 0 : sgnn_symmetric_key(h1, (uint64_t)v);
-                if (key > best) { best = key; bcol = (int32_t)c; bid = (int32_t)v; }
+                SGNN_KEY_UPDATE(h1, v, c, bhi, blo, bcol, bid);
             }
+            int64_t best = bcol == INT32_MAX ? INT64_MIN : sgnn_key_join(bhi, blo);
             sgnn_argmax_reduce(best, bcol, bid);
             if (lane == 0) out[r * n_slots + i] = (L > 0) ? (int64_t)bid : 0;
         }
@@ -45,21 +45,21 @@ __global__ __launch_bounds__(64 * SA_WAVES) void sample_anchors_ragged_kernel(
         const bool has_pad = row_has_pad ? (row_has_pad[r] != 0) : true;
         for (int64_t s0 = 0; s0 < n_slots; s0 += SA_SC) {
             uint64_t h1[SA_SC];
-            int64_t best[SA_SC];
-            int32_t bcol[SA_SC], bid[SA_SC];
+            int32_t bhi[SA_SC], bcol[SA_SC], bid[SA_SC];
+            uint32_t blo[SA_SC];
 #pragma unroll
             for (int u = 0; u < SA_SC; ++u) {
                 h1[u] = sgnn_tape_h1(h0, (uint64_t)(r * n_slots + s0 + u));
-                best[u] = INT64_MIN; bcol[u] = INT32_MAX; bid[u] = 0;
+                bhi[u] = INT32_MIN; blo[u] = 0; bcol[u] = INT32_MAX; bid[u] = 0;
             }
             for (int64_t c = lane; c < n; c += 64) {       // one read of the row per SA_SC slots
                 const int32_t v = set_nodes[beg + c];
 #pragma unroll
-                for (int u = 0; u < SA_SC; ++u) {
-                    const int64_t key = (v == 0) ? 0 : sgnn_symmetric_key(h1[u], (uint64_t)v);
-                    if (key > best[u]) { best[u] = key; bcol[u] = (int32_t)c; bid[u] = v; }
-                }
+                for (int u = 0; u < SA_SC; ++u) SGNN_KEY_UPDATE(h1[u], v, c, bhi[u], blo[u], bcol[u], bid[u]);
             }
+            int64_t best[SA_SC];
+#pragma unroll
+            for (int u = 0; u < SA_SC; ++u) best[u] = bcol[u] == INT32_MAX ? INT64_MIN : sgnn_key_join(bhi[u], blo[u]);
 #pragma unroll
             for (int u = 0; u < SA_SC; ++u) {
                 sgnn_argmax_reduce(best[u], bcol[u], bid[u]);
