@@ -187,6 +187,8 @@ int sgnn_min_hops_to_sets(const uint8_t* dist, int64_t n_sources, int64_t max_id
  * x = CC degree sequences (x_ptr/x_val, n_x rows), y = anchor degree sequences (n_y rows);
  * out (n_x, n_y) float32; rows with an empty x are PAD (SubGNN.py:831).  fp64 DP.
  * tie_order 0 = (i-1,j),(i,j-1),(i-1,j-1) first minimum (pure-Python fastdtw 0.3.4).
+ * x_order (nullable, int32[n_x], a permutation): processing order of the x rows -- results are
+ * unaffected; putting similar rows next to each other keeps a wavefront's lanes in step.
  * workspace: sgnn_dtw_workspace_bytes(n_x, max_x_len, n_y, max_y_len) bytes (any content).
  * ------------------------------------------------------------------------------------- */
 int64_t sgnn_dtw_workspace_bytes(int64_t n_x, int64_t max_x_len, int64_t n_y, int64_t max_y_len);
@@ -195,7 +197,8 @@ int64_t sgnn_dtw_workspace_bytes(int64_t n_x, int64_t max_x_len, int64_t n_y, in
 int sgnn_dtw_force_general(int on);
 int sgnn_dtw_similarity(const int64_t* x_ptr, const int32_t* x_val, int64_t n_x, int64_t max_x_len,
                         const int64_t* y_ptr, const int32_t* y_val, int64_t n_y, int64_t max_y_len,
-                        int tie_order, float* out, void* workspace, int64_t workspace_bytes, void* stream);
+                        int tie_order, const int32_t* x_order, float* out, void* workspace,
+                        int64_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * a12  CC embedding initialisation: sum or max of member node embeddings.

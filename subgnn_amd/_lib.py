@@ -49,7 +49,7 @@ SIGNATURES = {
     'sgnn_min_hops_to_sets': (c_int, [c_ptr, c_i64, c_i64, c_int, c_ptr, c_ptr, c_i64, c_ptr, c_ptr]),
     'sgnn_dtw_workspace_bytes': (c_i64, [c_i64, c_i64, c_i64, c_i64]),
     'sgnn_dtw_force_general': (c_int, [c_int]),
-    'sgnn_dtw_similarity': (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_i64, c_i64, c_int, c_ptr, c_ptr,
+    'sgnn_dtw_similarity': (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_i64, c_i64, c_int, c_ptr, c_ptr, c_ptr,
                                     c_i64, c_ptr]),
     'sgnn_cc_embed_fwd': (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_int, c_i64, c_ptr, c_ptr, c_ptr]),
     'sgnn_cc_embed_bwd': (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_int, c_ptr, c_ptr, c_ptr]),

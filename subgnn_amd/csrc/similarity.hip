@@ -531,13 +531,16 @@ template <int TIE>
 __global__ __launch_bounds__(DTW_THREADS, 2) void dtw_similarity_reg_kernel(
     const double* __restrict__ xpyr, const int32_t* __restrict__ xlen, int64_t n_x,
     const double* __restrict__ ypyr, const int32_t* __restrict__ ylen, int64_t n_y,
-    float* __restrict__ out, uint64_t* __restrict__ wq, DtwLayout L)
+    float* __restrict__ out, uint64_t* __restrict__ wq, DtwLayout L, const int32_t* __restrict__ x_order)
 {
     const int64_t NT = (int64_t)gridDim.x * blockDim.x;
     const int64_t tid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     const int64_t total = n_x * n_y;
     for (int64_t pair = tid; pair < total; pair += NT) {
-        const int64_t a = pair / n_x, r = pair % n_x;        // consecutive lanes: consecutive components
+        // consecutive lanes: same anchor, consecutive components of the caller's processing order
+        // (similar series side by side keep the lanes' windows aligned)
+        const int64_t a = pair / n_x;
+        const int64_t r = x_order ? x_order[pair % n_x] : pair % n_x;
         const int lx0 = xlen[r], ly0 = ylen[a];
         if (lx0 == 0 || ly0 == 0) { out[r * n_y + a] = 0.f; continue; }
         const double* __restrict__ yp = ypyr + a * L.YL;
@@ -557,10 +560,16 @@ __global__ __launch_bounds__(DTW_THREADS, 2) void dtw_similarity_reg_kernel(
             const double* ycol = yp + L.yoff[lev];
             uint64_t* w = wq + L.yoff[lev] * NT + tid;
             const bool coarsest = lev == n_levels - 1, finest = lev == 0;
-            if (lx <= 8) result = dtw_reg_level<8, TIE>(fl, xcol, n_x, ycol, lx, ly, lxc, lyc, coarsest, finest, w, NT);
-            else if (lx <= 16) result = dtw_reg_level<16, TIE>(fl, xcol, n_x, ycol, lx, ly, lxc, lyc, coarsest, finest, w, NT);
-            else if (lx <= 24) result = dtw_reg_level<24, TIE>(fl, xcol, n_x, ycol, lx, ly, lxc, lyc, coarsest, finest, w, NT);
-            else result = dtw_reg_level<32, TIE>(fl, xcol, n_x, ycol, lx, ly, lxc, lyc, coarsest, finest, w, NT);
+#define DTW_LEVEL(RR) result = dtw_reg_level<RR, TIE>(fl, xcol, n_x, ycol, lx, ly, lxc, lyc, coarsest, finest, w, NT)
+            if (lx <= 4) DTW_LEVEL(4);                       // narrow instantiations: the unrolled row
+            else if (lx <= 8) DTW_LEVEL(8);                  // loop sweeps at most 3 empty rows
+            else if (lx <= 12) DTW_LEVEL(12);
+            else if (lx <= 16) DTW_LEVEL(16);
+            else if (lx <= 20) DTW_LEVEL(20);
+            else if (lx <= 24) DTW_LEVEL(24);
+            else if (lx <= 28) DTW_LEVEL(28);
+            else DTW_LEVEL(32);
+#undef DTW_LEVEL
         }
         out[r * n_y + a] = (float)(1.0 / (result + 1.0));
     }
@@ -572,7 +581,8 @@ extern "C" int sgnn_dtw_force_general(int on) { const int old = g_dtw_force_gene
 
 extern "C" int sgnn_dtw_similarity(const int64_t* x_ptr, const int32_t* x_val, int64_t n_x, int64_t max_x_len,
                                    const int64_t* y_ptr, const int32_t* y_val, int64_t n_y, int64_t max_y_len,
-                                   int tie_order, float* out, void* workspace, int64_t workspace_bytes, void* stream)
+                                   int tie_order, const int32_t* x_order, float* out, void* workspace,
+                                   int64_t workspace_bytes, void* stream)
 {
     if (!x_ptr || !x_val || !y_ptr || !y_val || !out || !workspace || n_x < 0 || n_y < 0) return SGNN_ERR_BAD_ARG;
     if (tie_order < 0 || tie_order > 1) return SGNN_ERR_BAD_ARG;
@@ -603,10 +613,10 @@ extern "C" int sgnn_dtw_similarity(const int64_t* x_ptr, const int32_t* x_val, i
     if (max_x_len <= DTW_R && !g_dtw_force_general) {
         if (tie_order == 0)
             hipLaunchKernelGGL(dtw_similarity_reg_kernel<0>, dim3(DTW_BLOCKS), dim3(DTW_THREADS), 0, st, xpyr, xlen, n_x,
-                               ypyr, ylen, n_y, out, wq, L);
+                               ypyr, ylen, n_y, out, wq, L, x_order);
         else
             hipLaunchKernelGGL(dtw_similarity_reg_kernel<1>, dim3(DTW_BLOCKS), dim3(DTW_THREADS), 0, st, xpyr, xlen, n_x,
-                               ypyr, ylen, n_y, out, wq, L);
+                               ypyr, ylen, n_y, out, wq, L, x_order);
     } else {
         hipLaunchKernelGGL(dtw_similarity_kernel, dim3(DTW_BLOCKS), dim3(DTW_THREADS), 0, st, xpyr, xlen, n_x, ypyr,
                            ylen, n_y, tie_order, out, wd, wi, wb, L);
