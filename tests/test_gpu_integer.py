@@ -410,3 +410,20 @@ def test_dtw_register_kernel_equals_general_kernel(tie):
         lib.sgnn_dtw_force_general(old)
     assert np.array_equal(fast, ref)
     assert np.array_equal(general, ref)
+
+
+def test_dtw_row_dedupe_changes_nothing():
+    """Identical x rows are computed once and gathered back: same matrix as the plain call."""
+    ops = _ops()
+    rng = np.random.default_rng(77)
+    base = [sorted(rng.integers(0, 6, int(rng.integers(0, 21))).tolist()) for _ in range(40)]
+    xs = [base[int(i)] for i in rng.integers(0, 40, 3000)]
+    ys = [sorted(rng.integers(0, 50, int(rng.integers(1, 51))).tolist()) for _ in range(23)]
+    xp, xv = cbind.ragged(xs)
+    yp, yv = cbind.ragged(ys)
+    t = lambda a: torch.from_numpy(a).to(DEV)
+    a = ops.dtw_similarity(t(xp), t(xv), 20, t(yp), t(yv), 50, 0, dedupe=True)
+    b = ops.dtw_similarity(t(xp), t(xv), 20, t(yp), t(yv), 50, 0, dedupe=False, order_rows=False)
+    assert torch.equal(a, b)
+    ref = cbind.fastdtw_sim(xp, xv, yp, yv, 0)
+    assert np.array_equal(a.cpu().numpy(), ref)
