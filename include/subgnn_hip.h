@@ -91,6 +91,13 @@ int sgnn_khop_border(const int64_t* rowptr, const int32_t* col, int64_t nnz, int
                      int k, int ego_dict_mode,
                      int64_t* out_count, const int64_t* out_ptr, int32_t* out_nodes, uint8_t* out_hop,
                      void* workspace, int64_t workspace_bytes, int bitmap_in_lds, void* stream);
+/* one-pass materialisation: slice s of `arena` (starting at arena_off[s], guaranteed by the caller to
+ * hold the border: for k = 1, sum of the members' degrees always does) is used as the BFS queue, so
+ * the border is written by the BFS itself; out_count[s] entries are valid, in discovery order. */
+int sgnn_khop_border_arena(const int64_t* rowptr, const int32_t* col, int64_t nnz, int64_t max_id,
+                           const int64_t* set_ptr, const int32_t* set_nodes, int64_t n_sets, int k,
+                           const int64_t* arena_off, int32_t* arena, int64_t* out_count,
+                           void* workspace, int64_t workspace_bytes, int bitmap_in_lds, void* stream);
 /* a8 + a4 fused: k-hop border BFS and, without materialising the border, the neighbourhood-border
  * anchor draw of anchor_patch_samplers.sample_neighborhood_anchor_patch(sample_inside=False)
  * (anchor_patch_samplers.py:184-194) over it.  For set s and slot i: out_anchor = argmax over the
@@ -115,10 +122,13 @@ int sgnn_sample_anchors_padded(const int64_t* ids, int64_t n_rows, int64_t L, in
                                uint64_t seed, uint64_t stream_id, int64_t* out, void* stream);
 /* same law on ragged sets; row_has_pad[r] says whether the padded row would hold a PAD.
  * out_pos (nullable, (n_sets, n_slots)): index into set_nodes of the winner, -1 for PAD --
- * lets the caller look up per-entry payloads (e.g. the hop level of a border node). */
+ * lets the caller look up per-entry payloads (e.g. the hop level of a border node).
+ * set_cnt (nullable, int64[n_sets]): the sets are spans -- set r = set_nodes[set_ptr[r] .. +set_cnt[r])
+ * (slices of an arena, see sgnn_khop_border_arena) instead of back-to-back CSR rows. */
 int sgnn_sample_anchors_ragged(const int64_t* set_ptr, const int32_t* set_nodes, int64_t n_sets,
                                const uint8_t* row_has_pad, int64_t n_slots,
-                               uint64_t seed, uint64_t stream_id, int64_t* out, int64_t* out_pos, void* stream);
+                               uint64_t seed, uint64_t stream_id, int64_t* out, int64_t* out_pos,
+                               const int64_t* set_cnt, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * a5/a6  Uniform draws with replacement from a list (position anchors, structure picks).

@@ -83,11 +83,14 @@ __host__ __device__ static inline int64_t sgnn_key_join(int32_t hi, uint32_t lo)
 #define SGNN_KEY_UPDATE(h1, v, c, best_hi, best_lo, bcol, bid)                                   \
     do {                                                                                         \
         const int32_t _hi = sgnn_key_hi((h1), (uint32_t)(v));                                    \
-        if (_hi >= (best_hi)) {                                                                  \
+        const bool _cand = _hi >= (best_hi);                                                     \
+        if (__ballot(_cand)) {              /* wave-uniform branch: no exec-mask bookkeeping */  \
             const uint32_t _lo = sgnn_key_lo((h1), (uint32_t)(v));                               \
-            if (_hi > (best_hi) || _lo > (best_lo) || (bcol) == INT32_MAX) {                      \
-                (best_hi) = _hi; (best_lo) = _lo; (bcol) = (int32_t)(c); (bid) = (int32_t)(v);    \
-            }                                                                                    \
+            const bool _take = _cand && (_hi > (best_hi) || _lo > (best_lo) || (bcol) == INT32_MAX); \
+            (best_hi) = _take ? _hi : (best_hi);                                                 \
+            (best_lo) = _take ? _lo : (best_lo);                                                 \
+            (bcol) = _take ? (int32_t)(c) : (bcol);                                              \
+            (bid) = _take ? (int32_t)(v) : (bid);                                                \
         }                                                                                        \
     } while (0)
 

@@ -175,13 +175,13 @@ __global__ __launch_bounds__(THREADS) void khop_border_kernel(
     int k, int ego_mode,
     int64_t* __restrict__ out_count, const int64_t* __restrict__ out_ptr,
     int32_t* __restrict__ out_nodes, uint8_t* __restrict__ out_hop,
-    uint32_t* __restrict__ bitmaps, int32_t* __restrict__ queues, int64_t words, KbSample smp)
+    uint32_t* __restrict__ bitmaps, int32_t* __restrict__ queues, int64_t words, KbSample smp, int queue_in_output)
 {
     extern __shared__ uint32_t s_bm[];
     __shared__ int32_t s_qn;
     __shared__ int32_t s_lvl[260];
     uint32_t* bm = LDS_BM ? s_bm : bitmaps + (int64_t)blockIdx.x * words;
-    int32_t* q = queues + (int64_t)blockIdx.x * (max_id + 1);
+    int32_t* q = queue_in_output ? nullptr : queues + (int64_t)blockIdx.x * (max_id + 1);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     constexpr int NW = THREADS / 64;
     const int hops = ego_mode ? 1 : k;
@@ -192,6 +192,7 @@ __global__ __launch_bounds__(THREADS) void khop_border_kernel(
     for (int64_t s = blockIdx.x; s < n_sets; s += gridDim.x) {
         const int64_t beg = set_ptr[s];
         const int n = (int)(set_ptr[s + 1] - beg);
+        if (queue_in_output) q = out_nodes + out_ptr[s];        // the caller's slice IS the queue
         if (tid == 0) { s_qn = 0; s_lvl[0] = 0; }              // s_lvl[h] = queue length after hop h
         for (int i = tid; i < n; i += THREADS) {
             const int32_t v = set_nodes[beg + i];
@@ -230,7 +231,7 @@ __global__ __launch_bounds__(THREADS) void khop_border_kernel(
         }
         const int cnt = s_qn;
         if (out_count && tid == 0) out_count[s] = cnt;
-        if (out_nodes != nullptr) {
+        if (out_nodes != nullptr && !queue_in_output) {
             const int64_t o = out_ptr[s];
             for (int i = tid; i < cnt; i += THREADS) {
                 out_nodes[o + i] = q[i];
@@ -266,7 +267,8 @@ __global__ __launch_bounds__(THREADS) void khop_border_kernel(
 static int kb_launch(const int64_t* rowptr, const int32_t* col, int64_t nnz, int64_t max_id,
                      const int64_t* set_ptr, const int32_t* set_nodes, int64_t n_sets, int k, int ego_dict_mode,
                      int64_t* out_count, const int64_t* out_ptr, int32_t* out_nodes, uint8_t* out_hop,
-                     void* workspace, int64_t workspace_bytes, int bitmap_in_lds, KbSample smp, void* stream)
+                     void* workspace, int64_t workspace_bytes, int bitmap_in_lds, KbSample smp, void* stream,
+                     int queue_in_output = 0)
 {
     if (!rowptr || !col || !set_ptr || !set_nodes || !workspace || n_sets < 0 || k < 1 || k > 255)
         return SGNN_ERR_BAD_ARG;
@@ -289,11 +291,11 @@ static int kb_launch(const int64_t* rowptr, const int32_t* col, int64_t nnz, int
         }
         hipLaunchKernelGGL((khop_border_kernel<true, KB_THREADS_L>), dim3((int)nwg), dim3(KB_THREADS_L),
                            (size_t)(words * 4), st, rowptr, col, max_id, set_ptr, set_nodes, n_sets, k, ego_dict_mode,
-                           out_count, out_ptr, out_nodes, out_hop, bitmaps, queues, words, smp);
+                           out_count, out_ptr, out_nodes, out_hop, bitmaps, queues, words, smp, queue_in_output);
     } else {
         hipLaunchKernelGGL((khop_border_kernel<false, KB_THREADS_G>), dim3((int)nwg), dim3(KB_THREADS_G), 0, st,
                            rowptr, col, max_id, set_ptr, set_nodes, n_sets, k, ego_dict_mode, out_count, out_ptr,
-                           out_nodes, out_hop, bitmaps, queues, words, smp);
+                           out_nodes, out_hop, bitmaps, queues, words, smp, queue_in_output);
     }
     SGNN_CHECK_LAUNCH();
     return SGNN_OK;
@@ -309,6 +311,21 @@ extern "C" int sgnn_khop_border(const int64_t* rowptr, const int32_t* col, int64
     KbSample none = {0, 0, nullptr, nullptr, nullptr};
     return kb_launch(rowptr, col, nnz, max_id, set_ptr, set_nodes, n_sets, k, ego_dict_mode, out_count, out_ptr,
                      out_nodes, out_hop, workspace, workspace_bytes, bitmap_in_lds, none, stream);
+}
+
+/* One-pass variant: the caller reserves, for every set, a slice of `arena` that is guaranteed to hold
+ * its border (slice s starts at arena_off[s]); the BFS uses the slice as its queue, so the border is
+ * materialised by the BFS itself -- no count pass, no copy.  For k = 1 the bound
+ * sum_{v in set} deg(v) always suffices. */
+extern "C" int sgnn_khop_border_arena(const int64_t* rowptr, const int32_t* col, int64_t nnz, int64_t max_id,
+                                      const int64_t* set_ptr, const int32_t* set_nodes, int64_t n_sets, int k,
+                                      const int64_t* arena_off, int32_t* arena, int64_t* out_count,
+                                      void* workspace, int64_t workspace_bytes, int bitmap_in_lds, void* stream)
+{
+    if (!arena_off || !arena || !out_count) return SGNN_ERR_BAD_ARG;
+    KbSample none = {0, 0, nullptr, nullptr, nullptr};
+    return kb_launch(rowptr, col, nnz, max_id, set_ptr, set_nodes, n_sets, k, 0, out_count, arena_off, arena, nullptr,
+                     workspace, workspace_bytes, bitmap_in_lds, none, stream, 1);
 }
 
 extern "C" int sgnn_khop_border_sample(const int64_t* rowptr, const int32_t* col, int64_t nnz, int64_t max_id,

@@ -31,17 +31,17 @@ __global__ __launch_bounds__(64) void sample_anchors_padded_kernel(
 }
 
 #define SA_SC 8               // anchor slots hashed per pass over a row
-#define SA_WAVES 4            // rows in flight per 256-thread workgroup
+#define SA_WAVES 1            // rows per workgroup: one, so the dispatcher balances rows of very different length
 
 __global__ __launch_bounds__(64 * SA_WAVES) void sample_anchors_ragged_kernel(
     const int64_t* __restrict__ set_ptr, const int32_t* __restrict__ set_nodes, int64_t n_sets,
     const uint8_t* __restrict__ row_has_pad, int64_t n_slots, uint64_t h0, int64_t* __restrict__ out,
-    int64_t* __restrict__ out_pos)
+    int64_t* __restrict__ out_pos, const int64_t* __restrict__ set_cnt)
 {
     const int lane = threadIdx.x & 63;
     for (int64_t r = (int64_t)blockIdx.x * SA_WAVES + (threadIdx.x >> 6); r < n_sets; r += (int64_t)gridDim.x * SA_WAVES) {
         const int64_t beg = set_ptr[r];
-        const int64_t n = set_ptr[r + 1] - beg;
+        const int64_t n = set_cnt ? set_cnt[r] : set_ptr[r + 1] - beg;      // spans: (start, count)
         const bool has_pad = row_has_pad ? (row_has_pad[r] != 0) : true;
         for (int64_t s0 = 0; s0 < n_slots; s0 += SA_SC) {
             uint64_t h1[SA_SC];
@@ -52,10 +52,18 @@ __global__ __launch_bounds__(64 * SA_WAVES) void sample_anchors_ragged_kernel(
                 h1[u] = sgnn_tape_h1(h0, (uint64_t)(r * n_slots + s0 + u));
                 bhi[u] = INT32_MIN; blo[u] = 0; bcol[u] = INT32_MAX; bid[u] = 0;
             }
-            for (int64_t c = lane; c < n; c += 64) {       // one read of the row per SA_SC slots
-                const int32_t v = set_nodes[beg + c];
+            for (int64_t c0 = lane; c0 < n; c0 += 256) {   // one read of the row per SA_SC slots, 4 loads in flight
+                int32_t v[4];
 #pragma unroll
-                for (int u = 0; u < SA_SC; ++u) SGNN_KEY_UPDATE(h1[u], v, c, bhi[u], blo[u], bcol[u], bid[u]);
+                for (int k = 0; k < 4; ++k) { const int64_t c = c0 + 64 * k; v[k] = set_nodes[beg + (c < n ? c : n - 1)]; }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int64_t c = c0 + 64 * k;
+                    if (c < n) {
+#pragma unroll
+                        for (int u = 0; u < SA_SC; ++u) SGNN_KEY_UPDATE(h1[u], v[k], c, bhi[u], blo[u], bcol[u], bid[u]);
+                    }
+                }
             }
             int64_t best[SA_SC];
 #pragma unroll
@@ -89,14 +97,14 @@ extern "C" int sgnn_sample_anchors_padded(const int64_t* ids, int64_t n_rows, in
 extern "C" int sgnn_sample_anchors_ragged(const int64_t* set_ptr, const int32_t* set_nodes, int64_t n_sets,
                                           const uint8_t* row_has_pad, int64_t n_slots,
                                           uint64_t seed, uint64_t stream_id, int64_t* out, int64_t* out_pos,
-                                          void* stream)
+                                          const int64_t* set_cnt, void* stream)
 {
     if (!set_ptr || !set_nodes || !out || n_sets < 0 || n_slots < 0) return SGNN_ERR_BAD_ARG;
     if (n_sets == 0 || n_slots == 0) return SGNN_OK;
     const int64_t want = (n_sets + SA_WAVES - 1) / SA_WAVES;
-    const int grid = (int)(want < 256 * 8 ? want : 256 * 8);
+    const int grid = (int)(want < (1 << 20) ? want : (1 << 20));
     hipLaunchKernelGGL(sample_anchors_ragged_kernel, dim3(grid), dim3(64 * SA_WAVES), 0, (hipStream_t)stream, set_ptr,
-                       set_nodes, n_sets, row_has_pad, n_slots, sgnn_tape_h0(seed, stream_id), out, out_pos);
+                       set_nodes, n_sets, row_has_pad, n_slots, sgnn_tape_h0(seed, stream_id), out, out_pos, set_cnt);
     SGNN_CHECK_LAUNCH();
     return SGNN_OK;
 }

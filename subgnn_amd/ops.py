@@ -198,17 +198,40 @@ def khop_border(g, sets, k, ego_dict_mode=False, want_hops=False, bitmap_in_lds=
     return (r, hops) if want_hops else r
 
 
-def khop_border_sample(g, sets, k, n_slots, seed, stream_id, bitmap_in_lds=None):
-    """Fused k-hop border BFS + neighbourhood-border anchor draw (the border is never
-    materialised).  Returns anchors (n_sets, n_slots) int64 with the reference's PAD rule applied,
-    their hop levels as float32 similarities (0 on PAD) and the border sizes."""
+def khop_border_sample(g, sets, k, n_slots, seed, stream_id, bitmap_in_lds=None, one_pass=None):
+    """k-hop border BFS + neighbourhood-border anchor draw without a padded border matrix.  Returns
+    anchors (n_sets, n_slots) int64 with the reference's PAD rule applied, their hop levels as
+    float32 similarities (0 on PAD) and the border sizes.
+
+    k = 1 (``one_pass``): the BFS writes every border straight into its slice of an arena sized by
+    the bound  sum of the members' degrees  (no count pass), and the draw is a separate
+    full-occupancy kernel over those spans.  k > 1: one fused kernel draws from the BFS queue while
+    it is hot in L2 (the border is never materialised)."""
     lib = _lib.load()
     lds = bool(lib.sgnn_khop_border_bitmap_fits_lds(g.max_id)) if bitmap_in_lds is None else bool(bitmap_in_lds)
     ws, ws_bytes = _khop_ws(lib, g, sets.n, lds)
+    counts = torch.zeros(sets.n, dtype=torch.int64, device=g.device)
     anchor = torch.empty((sets.n, n_slots), dtype=torch.int64, device=g.device)
+    one_pass = (k == 1) if one_pass is None else (one_pass and k == 1)
+    if one_pass:
+        tot = int(sets.ptr[-1].item())
+        deg = (g.rowptr[1:] - g.rowptr[:-1])[sets.nodes[:tot].long()]
+        csum = torch.zeros(tot + 1, dtype=torch.int64, device=g.device)
+        torch.cumsum(deg, 0, out=csum[1:])
+        bound = csum[sets.ptr[1:]] - csum[sets.ptr[:-1]]                  # capacity of each slice
+        off = torch.zeros(sets.n + 1, dtype=torch.int64, device=g.device)
+        torch.cumsum(bound, 0, out=off[1:])
+        arena = torch.empty(max(int(off[-1].item()), 1), dtype=torch.int32, device=g.device)
+        check(lib.sgnn_khop_border_arena(_ptr(g.rowptr), _ptr(g.col), g.nnz, g.max_id, _ptr(sets.ptr), _ptr(sets.nodes),
+                                         sets.n, 1, _ptr(off), _ptr(arena), _ptr(counts), _ptr(ws), ws_bytes,
+                                         1 if lds else 0, _stream()), 'sgnn_khop_border_arena')
+        has_pad = (counts < counts.max()).to(torch.uint8)
+        check(lib.sgnn_sample_anchors_ragged(_ptr(off), _ptr(arena), sets.n, _ptr(has_pad), n_slots, seed, stream_id,
+                                             _ptr(anchor), None, _ptr(counts), _stream()), 'sgnn_sample_anchors_ragged')
+        sims = (anchor != 0).to(torch.float32)                              # every 1-hop border node is at hop 1
+        return anchor, sims, counts
     hop = torch.empty((sets.n, n_slots), dtype=torch.uint8, device=g.device)
     allneg = torch.empty((sets.n, n_slots), dtype=torch.uint8, device=g.device)
-    counts = torch.zeros(sets.n, dtype=torch.int64, device=g.device)
     check(lib.sgnn_khop_border_sample(_ptr(g.rowptr), _ptr(g.col), g.nnz, g.max_id, _ptr(sets.ptr), _ptr(sets.nodes),
                                       sets.n, k, n_slots, seed, stream_id, _ptr(anchor), _ptr(hop), _ptr(allneg),
                                       _ptr(counts), _ptr(ws), ws_bytes, 1 if lds else 0, _stream()),
@@ -254,7 +277,7 @@ def sample_anchors_ragged(sets, n_slots, seed, stream_id, row_has_pad=None, want
     out = torch.empty((sets.n, n_slots), dtype=torch.int64, device=sets.ptr.device)
     pos = torch.empty((sets.n, n_slots), dtype=torch.int64, device=sets.ptr.device) if want_pos else None
     check(lib.sgnn_sample_anchors_ragged(_ptr(sets.ptr), _ptr(sets.nodes), sets.n, _ptr(row_has_pad), n_slots, seed,
-                                         stream_id, _ptr(out), _ptr(pos), _stream()), 'sgnn_sample_anchors_ragged')
+                                         stream_id, _ptr(out), _ptr(pos), None, _stream()), 'sgnn_sample_anchors_ragged')
     return (out, pos) if want_pos else out
 
 

@@ -189,6 +189,9 @@ def test_khop_border_sample_equals_materialised_draw(k, lds):
     r = ops.Ragged.from_lists(sets, DEV)
     A, seed, st = 7, 99, T.stream_id(T.STREAM_N_BOR, 'val', 1)
     anchors, sims, counts = ops.khop_border_sample(dg, r, k, A, seed, st, bitmap_in_lds=lds)
+    if k == 1:       # one-pass arena path (default for k = 1) and the fused path must agree
+        a2, s2, c2 = ops.khop_border_sample(dg, r, k, A, seed, st, bitmap_in_lds=lds, one_pass=False)
+        assert torch.equal(anchors, a2) and torch.equal(sims, s2) and torch.equal(counts, c2)
     b, hops = ops.sort_ragged(*ops.khop_border(dg, r, k, want_hops=True))
     padded = b.to_padded()
     ref = ops.sample_anchors_padded(padded, A, seed, st)
