@@ -271,6 +271,17 @@ int sgnn_mpn_bwd(const sgnn_mpn_args* args, const float* grad_agg, const float* 
                  float* grad_x, float* grad_wp, void* stream);
 
 /* ---------------------------------------------------------------------------------------
+ * a16 (optional ff_attn read-out)  Additive-attention scores over a subgraph's components.
+ * Replaces attention.AdditiveAttention._forward_internal (SubGNN/attention.py:130-139) as used at
+ * SubGNN/SubGNN.py:298-301:  out[r] = sum_j v[j] * tanh(qW[r / rows_per_batch, j] + (X U)[r, j]).
+ * X (R, H) component embeddings, U (H, H) = _u_matrix, qW (R / rows_per_batch, H) = vector @ _w_matrix,
+ * v (H) = _v_vector.  The X U contraction runs on the matrix cores (v_mfma_f32_32x32x2_f32, exact
+ * f32); the (R, H) intermediate is never materialised.  H <= 1215.
+ * ------------------------------------------------------------------------------------- */
+int sgnn_attn_scores_fwd(const float* X, const float* U, const float* qW, const float* v,
+                         int64_t R, int64_t H, int64_t rows_per_batch, float* out, void* stream);
+
+/* ---------------------------------------------------------------------------------------
  * a16  Masked sum over the components of a subgraph (subgraph_utils.masked_sum,
  * SubGNN/subgraph_utils.py:213-237, as used at SubGNN/SubGNN.py:303).  x (B,C,H), mask (B,C)
  * -> out (B,H); backward scatters grad_out to the real components.

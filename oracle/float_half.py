@@ -171,7 +171,17 @@ def forward(params, hparams, split, batch, anchors, cc_params=None):
             else:
                 outputs.extend([res['I'][1], res['B'][1]])
     allcc = torch.cat([init] + outputs, dim=-1)
-    sub = (allcc * mask.unsqueeze(-1).to(allcc.dtype)).sum(dim=1)            # su:213-237
+    if hparams.get('ff_attn', False):
+        # attention.AdditiveAttention + masked_softmax + weighted_sum (attention.py:22-57,130-139; S.py:298-301)
+        q = params['attn_vector'].view(1, -1).repeat(B, 1)
+        inter = torch.tanh(q.matmul(params['attention._w_matrix']).unsqueeze(1) + allcc.matmul(params['attention._u_matrix']))
+        scores = inter.matmul(params['attention._v_vector']).squeeze(2)
+        m = mask.to(scores.dtype)
+        w = F.softmax(scores * m, dim=-1) * m
+        w = w / (w.sum(dim=-1, keepdim=True) + 1e-13)
+        sub = torch.bmm(w.unsqueeze(1), allcc).squeeze(1)
+    else:
+        sub = (allcc * mask.unsqueeze(-1).to(allcc.dtype)).sum(dim=1)        # su:213-237
     h = F.relu(F.linear(sub, params['lin.weight'], params['lin.bias']))
     h = F.relu(F.linear(h, params['lin2.weight'], params['lin2.bias']))
     return F.linear(h, params['lin3.weight'], params['lin3.bias'])

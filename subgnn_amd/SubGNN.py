@@ -110,8 +110,11 @@ class SubGNN(nn.Module):
         self.loss = nn.BCEWithLogitsLoss() if self.multilabel else nn.CrossEntropyLoss()
         self.lstm = LSTM(D, D, dropout=hp['lstm_dropout'], num_layers=hp['lstm_n_layers'],
                          aggregator=hp['lstm_aggregator'])
-        if hp.get('ff_attn', False):
-            raise NotImplementedError('ff_attn (attention.AdditiveAttention read-out) is not built yet')
+        if hp.get('ff_attn', False):                                   # S.py:179-183
+            from .attention import AdditiveAttention
+            self.attn_vector = Parameter(torch.zeros((hid_dim, 1), dtype=torch.float))
+            nn.init.xavier_uniform_(self.attn_vector)
+            self.attention = AdditiveAttention(hid_dim, hid_dim)
         hp.setdefault('structure_similarity_fn', 'dtw')
         self.metric_scores = []
         self.to(self.device)
@@ -503,7 +506,12 @@ class SubGNN(nn.Module):
                 outputs.extend([res['I'][pick], res['B'][pick]])
         all_cc_embeds = torch.cat([init_cc_embeds] + outputs, dim=-1)
         self._last_cc_embeds = all_cc_embeds.detach().reshape(B * C, -1)     # what a DP all-gather ships
-        subgraph_embedding = subgraph_utils.masked_sum(all_cc_embeds, cc_embed_mask.unsqueeze(-1), dim=1)
+        if hp.get('ff_attn', False):                                    # S.py:298-301
+            batched_attn = self.attn_vector.squeeze().unsqueeze(0).repeat(all_cc_embeds.shape[0], 1)
+            attn_weights = self.attention(batched_attn, all_cc_embeds, cc_embed_mask)
+            subgraph_embedding = subgraph_utils.weighted_sum(all_cc_embeds, attn_weights)
+        else:
+            subgraph_embedding = subgraph_utils.masked_sum(all_cc_embeds, cc_embed_mask.unsqueeze(-1), dim=1)
         h = self.lin_dropout(F.relu(self.lin(subgraph_embedding)))
         h = self.lin_dropout2(F.relu(self.lin2(h)))
         return self.lin3(h)

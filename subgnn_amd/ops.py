@@ -539,3 +539,37 @@ class _MaskedSum(torch.autograd.Function):
 def masked_sum(x, mask):
     """subgraph_utils.masked_sum(x, mask.unsqueeze(-1), dim=1) for x (B,C,H), mask (B,C)."""
     return _MaskedSum.apply(x.contiguous(), mask.to(torch.uint8).contiguous())
+
+
+class _AttnScores(torch.autograd.Function):
+    """Additive-attention scores: forward on the matrix cores (sgnn_attn_scores_fwd); the backward
+    recomputes tanh(qW + X U) with library GEMMs (plain dense contractions)."""
+
+    @staticmethod
+    def forward(ctx, X, U, qW, v, rows_per_batch):
+        lib = _lib.load()
+        for t, nm in ((X, 'X'), (U, 'U'), (qW, 'qW'), (v, 'v')):
+            _req(t, torch.float32, nm)
+        R, H = X.shape
+        out = torch.empty(R, dtype=torch.float32, device=X.device)
+        check(lib.sgnn_attn_scores_fwd(_ptr(X), _ptr(U), _ptr(qW), _ptr(v), R, H, rows_per_batch, _ptr(out), _stream()),
+              'sgnn_attn_scores_fwd')
+        ctx.save_for_backward(X, U, qW, v)
+        ctx.rpb = rows_per_batch
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        X, U, qW, v = ctx.saved_tensors
+        t = torch.tanh(torch.repeat_interleave(qW, ctx.rpb, dim=0) + X @ U)           # (R, H)
+        d = g.unsqueeze(1) * v.view(1, -1) * (1 - t * t)
+        gX = d @ U.t() if ctx.needs_input_grad[0] else None
+        gU = X.t() @ d if ctx.needs_input_grad[1] else None
+        gq = d.view(-1, ctx.rpb, d.shape[1]).sum(1) if ctx.needs_input_grad[2] else None
+        gv = (t * g.unsqueeze(1)).sum(0) if ctx.needs_input_grad[3] else None
+        return gX, gU, gq, gv, None
+
+
+def attn_scores(X, U, qW, v, rows_per_batch):
+    """score[r] = sum_j v_j tanh(qW[r // rows_per_batch, j] + (X U)[r, j]) for X (R, H)."""
+    return _AttnScores.apply(X.contiguous(), U.contiguous(), qW.contiguous(), v.contiguous().view(-1), int(rows_per_batch))

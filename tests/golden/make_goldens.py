@@ -645,6 +645,7 @@ def main():
                     'max_trainable': {'cc_aggregator': 'max', 'trainable_cc': True, 'lstm_n_layers': 2},
                     'bn': {'batch_norm': True, 'n_layers': 1},
                     'sumlstm_norm': {'lstm_aggregator': 'sum', 'norm_pos_struc_embed': True, 'n_layers': 1},
+                    'ff_attn': {'ff_attn': True, 'n_layers': 1},
                 })
             np.savez_compressed(HERE / (name + '.npz'), **out)
             print(name, 'written:', len(out), 'arrays,', (HERE / (name + '.npz')).stat().st_size // 1024, 'KiB')

@@ -58,7 +58,7 @@ def g11_case(g, variant):
     return t, hp, params, batch, anchors, ccp, labels
 
 
-G11_VARIANTS = ('sum', 'max_trainable', 'bn', 'sumlstm_norm')
+G11_VARIANTS = ('sum', 'max_trainable', 'bn', 'sumlstm_norm', 'ff_attn')
 
 
 def write_dataset_from_golden(g, root, name='ds', with_ego=None):

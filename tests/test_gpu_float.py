@@ -205,3 +205,26 @@ def test_missing_library_fails_loudly(monkeypatch):
     from subgnn_amd import _lib
     with pytest.raises(_lib.SubgnnHipError):
         ops.masked_sum(torch.zeros(2, 2, 4), torch.ones(2, 2, dtype=torch.bool))
+
+
+@pytest.mark.parametrize('R,H,C', [(5, 8, 1), (70, 37, 7), (193, 420, 1), (64, 615, 4)])
+def test_attn_scores_mfma(R, H, C):
+    """Matrix-core attention scores vs dense torch fp32: asymmetric operands (catches a row/column
+    swap of the accumulator map), H not a multiple of the MFMA tile, rows not a multiple of 32."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(R * 1000 + H)
+    X = torch.randn(R - R % C if R % C else R, H, generator=g)
+    R = X.shape[0]
+    U = torch.randn(H, H, generator=g) / H ** 0.5
+    qW = torch.randn(R // C, H, generator=g)
+    v = torch.randn(H, generator=g)
+    Xc, Uc, qc, vc = [t.clone().requires_grad_(True) for t in (X, U, qW, v)]
+    ref = (torch.tanh(torch.repeat_interleave(qc, C, dim=0) + Xc @ Uc) * vc).sum(1)
+    go = torch.randn(R, generator=g)
+    (ref * go).sum().backward()
+    Xg, Ug, qg, vg = [t.to(DEV).requires_grad_(True) for t in (X, U, qW, v)]
+    out = ops.attn_scores(Xg, Ug, qg, vg, C)
+    (out * go.to(DEV)).sum().backward()
+    assert_close(out, ref, 'scores', 2e-5)
+    for a, b, nm in ((Xg, Xc, 'X'), (Ug, Uc, 'U'), (qg, qc, 'qW'), (vg, vc, 'v')):
+        assert_close(a.grad, b.grad, 'grad ' + nm)
