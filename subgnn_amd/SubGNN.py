@@ -183,10 +183,16 @@ class SubGNN(nn.Module):
         return subgraph_utils.components_from_labels(subs.ptr, subs.nodes, labels)
 
     def initialize_cc_embeddings(self, cc_id_list, aggregator='sum'):
-        """S.py:609-622 -> (S, C, D)."""
+        """S.py:609-622 -> (S, C, D).  The padded rows are handed to the kernel as fixed-stride sets
+        (PAD entries included): row 0 of the table is zero, so PAD adds nothing to a sum and competes
+        in a max exactly as it does in the reference -- and no host synchronisation (a compaction
+        would need the number of non-PAD entries on the host) sits in the per-step path."""
         S, C, L = cc_id_list.shape
-        sets = ops.Ragged.from_padded(cc_id_list.to(self.device).reshape(S * C, L))
-        return ops.cc_embed(self.node_embeddings.weight, sets, aggregator, padded_len=L).view(S, C, -1)
+        ids = cc_id_list.to(self.device).reshape(S * C * L).to(torch.int32)
+        ptr = torch.arange(S * C + 1, dtype=torch.int64, device=self.device) * L
+        sets = ops.Ragged(ptr, ids.contiguous() if ids.numel() else torch.zeros(1, dtype=torch.int32, device=self.device),
+                          max_len=L)
+        return ops.cc_embed(self.node_embeddings.weight, sets, aggregator, padded_len=0).view(S, C, -1)
 
     def initialize_channel_embeddings(self, cc_embeddings, trainable=False):
         if trainable:
@@ -348,6 +354,7 @@ class SubGNN(nn.Module):
             else:
                 self.anchors_structure = None
         self._sim_col_cache = {}
+        self.__dict__.pop('_resident', None)
 
     def prepare_data(self):
         """S.py:1024-1063."""
@@ -364,32 +371,54 @@ class SubGNN(nn.Module):
                 getattr(self, split + '_int_struc_similarities', None),
                 getattr(self, split + '_bor_struc_similarities', None))
 
+    def _resident_split(self, split):
+        """Per-split tensors that never change (padded subgraph ids, labels), uploaded once."""
+        cache = self.__dict__.setdefault('_resident', {})
+        if split not in cache:
+            subs = getattr(self, split + '_sub_G')
+            L = max((len(s) for s in subs), default=1)
+            ids = torch.zeros((len(subs), max(L, 1)), dtype=torch.int64)
+            for i, s_ in enumerate(subs):
+                ids[i, :len(s_)] = torch.as_tensor(s_)
+            labels = getattr(self, split + '_sub_G_label')
+            if self.multilabel:
+                lab = torch.LongTensor(self.multilabel_binarizer.transform(labels))
+            else:
+                lab = labels.view(-1)
+            # widths of the left-justified padded rows, per subgraph, on the HOST: trimming a batch to
+            # its widest row (S.py:1098-1099,1109-1110) then needs no device round trip
+            cc = getattr(self, split + '_cc_ids')
+            nb = getattr(self, split + '_N_border', None)
+            w_cc = (cc != 0).sum(dim=2).amax(dim=1).cpu()
+            w_nb = (nb != 0).sum(dim=2).amax(dim=1).cpu() if nb is not None else None
+            cache[split] = (ids.to(self.device), lab.to(self.device), w_cc, w_nb)
+        return cache[split]
+
     def make_batch(self, split, idx):
-        """Batch dict for subgraph indices ``idx`` (same keys/shapes as _pad_collate)."""
+        """Batch dict for subgraph indices ``idx`` (same keys as _pad_collate, S.py:1112-1114); every
+        tensor is gathered on the device and nothing in here waits for the GPU.
+        ``subgraph_ids`` keeps the split's padded width (forward never reads it)."""
         idx = torch.as_tensor(idx, dtype=torch.int64)
         didx = idx.to(self.device)
         cc, nb, npsim, isim, bsim = self._split_tensors(split)
-        subs = [getattr(self, split + '_sub_G')[int(i)] for i in idx]
-        L = max(len(s) for s in subs)
-        sub_ids = torch.zeros((len(subs), L), dtype=torch.int64)
-        for i, s in enumerate(subs):
-            sub_ids[i, :len(s)] = torch.as_tensor(s)
-        labels = getattr(self, split + '_sub_G_label')
-        if self.multilabel:
-            lab = torch.LongTensor(self.multilabel_binarizer.transform([labels[int(i)] for i in idx]))
-        else:
-            lab = labels.view(-1)[idx]
+        sub_ids, lab, w_cc, w_nb = self._resident_split(split)
+
         def pick(t):
             if t is None:
                 return None
             if isinstance(t, dict):
                 return {k: v.index_select(0, didx) for k, v in t.items()}
             return t.index_select(0, didx)
-        return {'subgraph_ids': sub_ids.to(self.device),
-                'cc_ids': subgraph_utils.trim_zero_columns(pick(cc)),
-                'N_border': subgraph_utils.trim_zero_columns(pick(nb)) if nb is not None else None,
+        wc = max(int(w_cc[idx.cpu()].max()), 0) if idx.numel() else 0
+        batch_nb = None
+        if nb is not None:
+            wn = max(int(w_nb[idx.cpu()].max()), 0) if idx.numel() else 0
+            batch_nb = pick(nb)[:, :, :wn].contiguous()
+        return {'subgraph_ids': pick(sub_ids),
+                'cc_ids': pick(cc)[:, :, :wc].contiguous(),
+                'N_border': batch_nb,
                 'NP_sim': pick(npsim), 'I_S_sim': pick(isim), 'B_S_sim': pick(bsim),
-                'subgraph_idx': didx.view(-1, 1), 'label': lab.to(self.device)}
+                'subgraph_idx': didx.view(-1, 1), 'label': pick(lab)}
 
     def _pad_collate(self, batch):
         """S.py:1068-1114 for a list of SubgraphDataset items."""
@@ -559,8 +588,8 @@ class SubGNN(nn.Module):
         logs = {p + '_loss': torch.stack([x[p + '_loss'] for x in outputs]).mean().detach().cpu(),
                 p + '_micro_f1': subgraph_utils.calc_f1(logits, labels, 'micro', mb).squeeze(),
                 p + '_macro_f1': subgraph_utils.calc_f1(logits, labels, 'macro', mb).squeeze(),
-                p + '_acc': subgraph_utils.calc_accuracy(logits, labels, mb).squeeze()}
-        avg_acc = torch.stack([x[p + '_acc'] for x in outputs]).mean()
+                p + '_acc': subgraph_utils.calc_accuracy(logits, labels, mb).squeeze().cpu()}
+        avg_acc = torch.stack([x[p + '_acc'] for x in outputs]).mean().cpu()
         avg_f1 = torch.stack([x[p + '_macro_f1'] for x in outputs]).mean()
         if p == 'val':
             logs['avg_val_acc'], logs['avg_macro_f1'] = avg_acc, avg_f1

@@ -92,12 +92,15 @@ def calc_f1(logits, labels, avg_type='macro', multilabel_binarizer=None):
 
 
 def calc_accuracy(logits, labels, multilabel_binarizer=None):
-    from sklearn.metrics import accuracy_score
+    """su.calc_accuracy (su:108-124): sklearn accuracy_score semantics (exact-match for multilabel),
+    evaluated on the device -- training_step calls this every batch and a host round trip there
+    would serialise the step."""
     if multilabel_binarizer is not None:
         pred = torch.sigmoid(logits) > 0.5
+        acc = (pred == labels.bool()).all(dim=-1).float().mean()
     else:
-        pred = torch.argmax(logits, 1)
-    return torch.tensor([accuracy_score(labels.cpu().detach(), pred.cpu().detach())])
+        acc = (torch.argmax(logits, 1) == labels).float().mean()
+    return acc.reshape(1)
 
 
 def trim_zero_columns(x):
