@@ -63,10 +63,15 @@ class _DeviceLoader:
     def __len__(self):
         return self.n // self.bs if self.drop_last else (self.n + self.bs - 1) // self.bs
 
-    def __iter__(self):
+    def index_batches(self):
+        """The subgraph indices of each batch (what graph_step.CapturedTrainStep.replay takes)."""
         order = torch.randperm(self.n) if self.shuffle else torch.arange(self.n)
         for i in range(len(self)):
-            yield self.m.make_batch(self.split, order[i * self.bs:(i + 1) * self.bs])
+            yield order[i * self.bs:(i + 1) * self.bs]
+
+    def __iter__(self):
+        for idx in self.index_batches():
+            yield self.m.make_batch(self.split, idx)
 
 
 class SubGNN(nn.Module):
@@ -353,7 +358,7 @@ class SubGNN(nn.Module):
                                                                     self.bor_structure_anchor_random_walks)
             else:
                 self.anchors_structure = None
-        self._sim_col_cache = {}
+        self._build_sim_cols()
         self.__dict__.pop('_resident', None)
 
     def prepare_data(self):
@@ -394,10 +399,12 @@ class SubGNN(nn.Module):
             cache[split] = (ids.to(self.device), lab.to(self.device), w_cc, w_nb)
         return cache[split]
 
-    def make_batch(self, split, idx):
+    def make_batch(self, split, idx, trim=True):
         """Batch dict for subgraph indices ``idx`` (same keys as _pad_collate, S.py:1112-1114); every
         tensor is gathered on the device and nothing in here waits for the GPU.
-        ``subgraph_ids`` keeps the split's padded width (forward never reads it)."""
+        ``subgraph_ids`` keeps the split's padded width (forward never reads it).  ``trim=False``
+        keeps the split's full padded widths too (``idx`` may then be a device tensor whose values
+        the host never sees -- the form a recorded step needs)."""
         idx = torch.as_tensor(idx, dtype=torch.int64)
         didx = idx.to(self.device)
         cc, nb, npsim, isim, bsim = self._split_tensors(split)
@@ -409,14 +416,15 @@ class SubGNN(nn.Module):
             if isinstance(t, dict):
                 return {k: v.index_select(0, didx) for k, v in t.items()}
             return t.index_select(0, didx)
-        wc = max(int(w_cc[idx.cpu()].max()), 0) if idx.numel() else 0
-        batch_nb = None
-        if nb is not None:
-            wn = max(int(w_nb[idx.cpu()].max()), 0) if idx.numel() else 0
-            batch_nb = pick(nb)[:, :, :wn].contiguous()
-        return {'subgraph_ids': pick(sub_ids),
-                'cc_ids': pick(cc)[:, :, :wc].contiguous(),
-                'N_border': batch_nb,
+        batch_cc, batch_nb = pick(cc), pick(nb)
+        if trim:
+            hidx = idx.cpu()
+            wc = max(int(w_cc[hidx].max()), 0) if idx.numel() else 0
+            batch_cc = batch_cc[:, :, :wc].contiguous()
+            if nb is not None:
+                wn = max(int(w_nb[hidx].max()), 0) if idx.numel() else 0
+                batch_nb = batch_nb[:, :, :wn].contiguous()
+        return {'subgraph_ids': pick(sub_ids), 'cc_ids': batch_cc, 'N_border': batch_nb,
                 'NP_sim': pick(npsim), 'I_S_sim': pick(isim), 'B_S_sim': pick(bsim),
                 'subgraph_idx': didx.view(-1, 1), 'label': pick(lab)}
 
@@ -489,11 +497,8 @@ class SubGNN(nn.Module):
         patches, indices, int_rw, bor_rw = self.anchors_structure[layer_num]
         X = aps.aggregate_structure_anchor_patch(self.hparams, self.networkx_graph, self.lstm, self.node_embeddings,
                                                  patches, int_rw if inside else bor_rw, inside, self.device)
-        key = layer_num
-        if key not in self._sim_col_cache:
-            self._sim_col_cache[key] = torch.as_tensor(indices, dtype=torch.int64, device=self.device)
         return mpn_fn.forward_fused(sims, cc_embeds, cc_embed_mask, src=ops.SRC_SHARED, x=X,
-                                    sim_col=self._sim_col_cache[key])
+                                    sim_col=self._sim_col_cache[layer_num])
 
     def forward(self, dataset_type, N_I_cc_embed, N_B_cc_embed, S_I_cc_embed, S_B_cc_embed, P_I_cc_embed,
                 P_B_cc_embed, subgraph_ids, cc_ids, subgraph_idx, NP_sim, I_S_sim, B_S_sim):
@@ -637,7 +642,15 @@ class SubGNN(nn.Module):
             self.anchors_structure = aps.init_anchors_structure(hp, self.structure_anchors,
                                                                 self.int_structure_anchor_random_walks,
                                                                 self.bor_structure_anchor_random_walks)
-            self._sim_col_cache = {}
+        self._build_sim_cols()
+
+    def _build_sim_cols(self):
+        """Per layer, the columns of the S similarity rows its sampled patches read (S.py:206-210),
+        resident on the device so that forward never uploads anything."""
+        self._sim_col_cache = {}
+        if getattr(self, 'anchors_structure', None) is not None:
+            for l, (_, indices, _, _) in self.anchors_structure.items():
+                self._sim_col_cache[l] = torch.as_tensor(indices, dtype=torch.int64, device=self.device)
 
     def test_epoch_end(self, outputs):
         """S.py:466-504."""

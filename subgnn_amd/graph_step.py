@@ -1,0 +1,93 @@
+"""One SubGNN training step captured in a hipGraph.
+
+With the reference's hyper-parameters (batch of 64 subgraphs, D = 128) a training step is ~250 small
+kernel launches: on MI355X the GPU finishes each of them before the host has issued the next one, so
+the step time is the host's launch time.  The step itself is static once the batch indices are data
+rather than control flow -- gathers from the split-resident tensors, the three channels' message
+passing, the read-out, the loss, backward, gradient clipping and Adam never look at a value on the
+host (SubGNN.make_batch(trim=False), SubGNN.initialize_cc_embeddings and subgraph_utils.calc_accuracy
+were written for that) -- so it is recorded once and replayed with a new index vector per batch.
+
+The recorded sequence is exactly Trainer.fit's body (training_step -> zero_grad -> model.backward ->
+clip_grad_norm_ -> optimizer.step, train_config.py: PL 0.7.x hook order).  What changes from the
+eager step: batches are not trimmed to their widest row (PAD columns add zeros, S.py:1098-1110 is a
+memory optimisation) and Adam runs with ``capturable=True`` (its step counter lives on the device).
+
+Anything that replaces tensors the graph reads -- SubGNN._prepare_anchors_only after
+``resample_anchor_patches``, a new prepare_data -- invalidates the recording; ``stale()`` reports it
+and the trainer records again.
+"""
+import torch
+
+
+def make_capturable(optimizer):
+    """Adam keeps ``step`` on the host unless told otherwise; a host counter cannot be replayed."""
+    for g in optimizer.param_groups:
+        if 'capturable' in g:
+            g['capturable'] = True
+    for st in optimizer.state.values():
+        if 'step' in st and torch.is_tensor(st['step']) and not st['step'].is_cuda:
+            p = next(v for v in st.values() if torch.is_tensor(v) and v.is_cuda)
+            st['step'] = st['step'].to(p.device)
+    return optimizer
+
+
+class CapturedTrainStep:
+    """Record ``step(idx)`` for batches of exactly ``batch_size`` subgraphs of ``split``.
+
+    ``replay(idx)`` copies the indices into the graph's input and launches it; the returned loss and
+    accuracy are the graph's static outputs (clone them to keep them past the next replay)."""
+
+    def __init__(self, model, optimizer, batch_size, clip=0.0, split='train', warmup=3):
+        if not torch.cuda.is_available():
+            raise RuntimeError('CapturedTrainStep needs the GPU: there is no CPU path')
+        self.model, self.opt, self.B, self.clip, self.split = model, optimizer, int(batch_size), clip, split
+        self.idx = torch.zeros(self.B, dtype=torch.int64, device=model.device)
+        self._token = self._anchor_token()
+        make_capturable(optimizer)
+        self.graph, self.loss, self.acc = None, None, None
+        self._warm_left = warmup
+
+    # -- what the recording depends on -----------------------------------------------------
+    def _anchor_token(self):
+        m = self.model
+        objs = [getattr(m, a, None) for a in ('anchors_neigh_int', 'anchors_neigh_border', 'anchors_pos_int',
+                                              'anchors_pos_ext', 'anchors_structure')]
+        objs += [getattr(m, self.split + a, None) for a in ('_cc_ids', '_N_border', '_neigh_pos_similarities')]
+        return tuple(id(o) for o in objs)
+
+    def stale(self):
+        return self._anchor_token() != self._token
+
+    # -- the step, identical in eager and recorded form -------------------------------------
+    def _body(self):
+        m = self.model
+        batch = m.make_batch(self.split, self.idx, trim=False)
+        out = m.training_step(batch, 0)
+        self.opt.zero_grad(set_to_none=True)
+        m.backward(None, out['loss'], self.opt, 0)
+        if self.clip and self.clip > 0:
+            torch.nn.utils.clip_grad_norm_(m.parameters(), self.clip)
+        self.opt.step()
+        return out['loss'].detach(), out['log']['train_acc'].detach()
+
+    def _record(self):
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self.loss, self.acc = self._body()
+        self.graph = g
+
+    def replay(self, idx):
+        """One training step on subgraphs ``idx`` (length must be ``batch_size``)."""
+        idx = torch.as_tensor(idx)
+        if idx.numel() != self.B:
+            raise ValueError('captured step takes %d indices, got %d' % (self.B, idx.numel()))
+        self.idx.copy_(idx.view(-1), non_blocking=True)
+        if self.graph is None:
+            if self._warm_left > 0:                       # lazy initialisations (handles, optimizer state,
+                self._warm_left -= 1                      # autograd buffers) must not land in the recording
+                return self._body()
+            self._record()
+        self.graph.replay()
+        return self.loss, self.acc

@@ -186,7 +186,7 @@ def prepare_sparse(model, split='train', timer=None):
     else:
         setattr(model, split + '_int_struc_similarities', None)
         setattr(model, split + '_bor_struc_similarities', None)
-    model._sim_col_cache = {}
+    model._build_sim_cols()
     return t
 
 

@@ -96,24 +96,45 @@ class Trainer:
     """The slice of pl.Trainer the reference uses (train_config.py:121-156): max_epochs,
     gradient clipping, validation every epoch, best-by-monitor bookkeeping."""
 
-    def __init__(self, max_epochs, gradient_clip_val=0.0, monitor='val_micro_f1', mode='max', log=print):
+    def __init__(self, max_epochs, gradient_clip_val=0.0, monitor='val_micro_f1', mode='max', log=print,
+                 hip_graph_step=False):
         self.max_epochs, self.clip, self.monitor, self.mode, self.log = max_epochs, gradient_clip_val, monitor, mode, log
         self.best, self.history = None, []
+        self.hip_graph_step = hip_graph_step
+
+    def _eager_step(self, model, opt, batch, bi):
+        out = model.training_step(batch, bi)
+        opt.zero_grad(set_to_none=True)
+        model.backward(self, out['loss'], opt, 0)
+        if self.clip and self.clip > 0:
+            torch.nn.utils.clip_grad_norm_(model.parameters(), self.clip)
+        opt.step()
+        return out['loss'].detach()
 
     def fit(self, model):
         model.prepare_data()
         opt = model.configure_optimizers()
+        captured = None
+        if self.hip_graph_step:
+            from .graph_step import CapturedTrainStep, make_capturable
+            make_capturable(opt)
         for epoch in range(self.max_epochs):
             model.train()
             losses = []
-            for bi, batch in enumerate(model.train_dataloader()):
-                out = model.training_step(batch, bi)
-                opt.zero_grad(set_to_none=True)
-                model.backward(self, out['loss'], opt, 0)
-                if self.clip and self.clip > 0:
-                    torch.nn.utils.clip_grad_norm_(model.parameters(), self.clip)
-                opt.step()
-                losses.append(out['loss'].detach())
+            loader = model.train_dataloader()
+            if self.hip_graph_step:
+                # full batches replay the recorded step (graph_step.py); a ragged last batch, or
+                # anchors resampled at the end of the previous epoch, fall back / record again
+                if captured is None or captured.stale():
+                    captured = CapturedTrainStep(model, opt, loader.bs, self.clip, warmup=3 if captured is None else 0)
+                for bi, idx in enumerate(loader.index_batches()):
+                    if idx.numel() == loader.bs:
+                        losses.append(captured.replay(idx)[0].clone())
+                    else:
+                        losses.append(self._eager_step(model, opt, model.make_batch('train', idx), bi))
+            else:
+                for bi, batch in enumerate(loader):
+                    losses.append(self._eager_step(model, opt, batch, bi))
             model.eval()
             with torch.no_grad():
                 outs = [model.validation_step(b, i) for i, b in enumerate(model.val_dataloader())]
@@ -138,7 +159,8 @@ def train_model(run_config, trial=None, results_dir=None, log=print):
     opt_cfg = run_config.get('optuna', {})
     monitor = opt_cfg.get('monitor_metric', 'val_micro_f1')
     mode = 'max' if opt_cfg.get('opt_direction', 'maximize') == 'maximize' else 'min'
-    trainer = Trainer(hp['max_epochs'], hp.get('grad_clip', 0.0), monitor, mode, log)
+    trainer = Trainer(hp['max_epochs'], hp.get('grad_clip', 0.0), monitor, mode, log,
+                      hip_graph_step=bool(hp.get('hip_graph_step', False)))
     if results_dir is not None:
         Path(results_dir).mkdir(parents=True, exist_ok=True)
         with open(Path(results_dir) / 'hyperparams.json', 'w') as f:

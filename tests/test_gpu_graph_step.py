@@ -1,0 +1,62 @@
+"""-m gpu: the training step replayed from a hipGraph (subgnn_amd/graph_step.py) takes the model to
+the same place as the eager step -- same batches, same losses, same parameters (float atomics in the
+backward kernels reorder sums, hence a tolerance) -- including across an anchor resample, which
+invalidates the recording."""
+import json
+
+import pytest
+import torch
+
+from helpers import write_dataset_from_golden
+from test_gpu_train_driver import CONFIG
+
+pytestmark = pytest.mark.gpu
+
+
+def _fit(tiny, root, graph, resample, epochs=7):
+    from subgnn_amd import config, train_config
+    write_dataset_from_golden(tiny, root, 'ds')
+    fix = dict(tiny.hp)
+    for k in ('batch_size', 'learning_rate', 'n_layers'):
+        fix.pop(k, None)
+    fix.update({'max_epochs': epochs, 'seed': 3, 'lin_dropout': 0.0, 'compute_similarities': True,
+                'resample_anchor_patches': resample, 'hip_graph_step': graph})
+    (root / 'config.json').write_text(CONFIG % json.dumps(fix))
+    config.PROJECT_ROOT = root
+    rc = train_config.read_json(root / 'config.json')
+    trial = train_config.FixedTrial({'batch_size': 4, 'n_layers': 2})
+    torch.manual_seed(11)
+    best, model, trainer = train_config.train_model(rc, trial=trial, log=lambda *a: None)
+    return model, trainer
+
+
+@pytest.mark.parametrize('resample', [False, True])
+def test_captured_step_matches_eager(tiny, tmp_path, resample):
+    (tmp_path / 'a').mkdir()
+    (tmp_path / 'b').mkdir()
+    m0, t0 = _fit(tiny, tmp_path / 'a', False, resample)
+    m1, t1 = _fit(tiny, tmp_path / 'b', True, resample)
+    assert t1.hip_graph_step and not t0.hip_graph_step
+    l0 = torch.tensor([e['train_loss'] for e in t0.history])
+    l1 = torch.tensor([e['train_loss'] for e in t1.history])
+    assert torch.allclose(l0, l1, rtol=2e-3, atol=1e-5), (l0, l1)
+    assert l1[-1] < l1[0]
+    sd0, sd1 = m0.state_dict(), m1.state_dict()
+    assert sd0.keys() == sd1.keys()
+    for k in sd0:
+        a, b = sd0[k].float(), sd1[k].float()
+        assert torch.allclose(a, b, rtol=5e-3, atol=2e-4), (k, (a - b).abs().max())
+
+
+def test_captured_step_rejects_other_batch_size(tiny, tmp_path):
+    from subgnn_amd.graph_step import CapturedTrainStep
+    (tmp_path / 'a').mkdir()
+    m, t = _fit(tiny, tmp_path / 'a', False, False, epochs=1)
+    opt = m.configure_optimizers()
+    cap = CapturedTrainStep(m, opt, 4, 1.0)
+    with pytest.raises(ValueError):
+        cap.replay(torch.arange(3))
+    m.train()
+    for _ in range(5):                                      # 3 eager warm-ups, 1 recording, replays
+        loss, acc = cap.replay(torch.arange(4))
+    assert cap.graph is not None and torch.isfinite(loss) and 0.0 <= float(acc) <= 1.0

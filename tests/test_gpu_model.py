@@ -97,7 +97,7 @@ def _inject(m, g, t, hp):
     m.anchors_pos_ext = {l: d(g[t + 'P_ext_%d' % l]) for l in range(L)}
     m.anchors_structure = {l: (d(g[t + 'S_patches_%d' % l]), [int(i) for i in g[t + 'S_idx_%d' % l]],
                                d(g[t + 'S_int_rw_%d' % l]), d(g[t + 'S_bor_rw_%d' % l])) for l in range(L)}
-    m._sim_col_cache = {}
+    m._build_sim_cols()
     m.init_all_embeddings(split='train', trainable=hp['trainable_cc'])
     if hp['trainable_cc']:
         with torch.no_grad():

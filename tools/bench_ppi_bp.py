@@ -67,6 +67,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--steps', type=int, default=50)
     ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--graph', action='store_true', help='replay the step from a hipGraph (graph_step.py)')
     args = ap.parse_args()
     from subgnn_amd import config, precompute_graph_metrics as pgm
     from subgnn_amd.SubGNN import SubGNN, dataset_paths
@@ -100,6 +101,19 @@ def main():
         torch.nn.utils.clip_grad_norm_(model.parameters(), H2['grad_clip'])
         opt.step()
         return out['loss']
+    if args.graph:
+        from subgnn_amd.graph_step import CapturedTrainStep
+        cap = CapturedTrainStep(model, opt, B, H2['grad_clip'])
+
+        def index_batches():
+            while True:
+                for idx in model.train_dataloader().index_batches():
+                    if idx.numel() == B:
+                        yield idx
+        iti = index_batches()
+
+        def step():
+            return cap.replay(next(iti))[0]
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -117,7 +131,7 @@ def main():
                                'trainable_cc), batch of 64, training step = fwd + bwd + clip + Adam' % n_edges,
                    'cc_ids_shape': list(model.train_cc_ids.shape)},
         'prepare_data_s': round(t_prep, 2), 'dataset_write_and_graph_metrics_s': round(t_data, 2),
-        'loss': float(loss.detach())}))
+        'loss': float(loss.detach()), 'hip_graph_step': bool(args.graph)}))
 
 
 if __name__ == '__main__':
