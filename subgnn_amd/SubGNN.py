@@ -491,7 +491,7 @@ class SubGNN(nn.Module):
                 return mpn_fn.forward_fused(sims, cc_embeds, cc_embed_mask, src=ops.SRC_GATHER, x=E, ids=ids, id_div=C,
                                             sims_per_edge=per_edge)
             ids = self.anchors_pos_ext[layer_num]
-            X = F.embedding(ids, E, padding_idx=config.PAD_VALUE)
+            X = ops.gather_rows(E, ids)
             return mpn_fn.forward_fused(sims, cc_embeds, cc_embed_mask, src=ops.SRC_SHARED, x=X, ids=ids,
                                         sims_per_edge=per_edge)
         patches, indices, int_rw, bor_rw = self.anchors_structure[layer_num]

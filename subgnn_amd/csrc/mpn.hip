@@ -171,13 +171,16 @@ __global__ __launch_bounds__(256) void mpn_bwd_gather_kernel(sgnn_mpn_args a, co
 }
 
 // backward for SHARED anchors: dX[a,:] = sum_r edge * w[r,a] * (g_agg[r,:] + g_z[r,a] * wp).
-// One workgroup per tile of rows; thread items are (anchor, column slice); the tile's g_agg rows
-// are re-read per anchor from L1/L2; one atomic row-add per (tile, anchor).
+// One workgroup per (tile of rows, chunk of 256 (anchor, column slice) items); the tile's g_agg
+// rows are re-read per anchor from L1/L2; one atomic row-add per (tile, anchor).  The host picks
+// the tile height: 64 rows when there are enough rows to fill the chip that way (large shards),
+// down to 4 rows for a batch of a few hundred component rows, where the item chunks become the
+// second grid dimension instead of a loop.
 #define MPN_SH_TILE 64
 __global__ __launch_bounds__(256) void mpn_bwd_shared_kernel(sgnn_mpn_args a, const float* __restrict__ grad_agg,
                                                              const float* __restrict__ grad_z,
                                                              float* __restrict__ grad_x, float* __restrict__ grad_wp,
-                                                             int64_t D4)
+                                                             int64_t D4, int64_t tile_rows)
 {
     __shared__ float s_gwp[1024];
     const int64_t D = D4 * 4;
@@ -186,11 +189,12 @@ __global__ __launch_bounds__(256) void mpn_bwd_shared_kernel(sgnn_mpn_args a, co
         __syncthreads();
     }
     const float4* x4 = reinterpret_cast<const float4*>(a.x);
-    const int64_t n_tiles = (a.R + MPN_SH_TILE - 1) / MPN_SH_TILE;
+    const int64_t n_tiles = (a.R + tile_rows - 1) / tile_rows;
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const int64_t r0 = tile * MPN_SH_TILE;
-        const int64_t r1 = (r0 + MPN_SH_TILE < a.R) ? r0 + MPN_SH_TILE : a.R;
-        for (int64_t item = threadIdx.x; item < a.A * D4; item += blockDim.x) {
+        const int64_t r0 = tile * tile_rows;
+        const int64_t r1 = (r0 + tile_rows < a.R) ? r0 + tile_rows : a.R;
+        for (int64_t item = (int64_t)blockIdx.y * blockDim.x + threadIdx.x; item < a.A * D4;
+             item += (int64_t)gridDim.y * blockDim.x) {
             const int64_t ai = item / D4, dv = item % D4;
             const int64_t id = a.ids ? a.ids[ai] : 1;
             if (id == 0) continue;
@@ -267,10 +271,18 @@ extern "C" int sgnn_mpn_bwd(const sgnn_mpn_args* args, const float* grad_agg, co
     const int64_t D4 = args->D / 4;
     hipStream_t st = (hipStream_t)stream;
     if (args->src == SGNN_SRC_SHARED) {
-        const int64_t n_tiles = (args->R + MPN_SH_TILE - 1) / MPN_SH_TILE;
+        int64_t tile_rows = MPN_SH_TILE, chunks = 1;
+        int64_t n_tiles = (args->R + tile_rows - 1) / tile_rows;
+        if (n_tiles < 1024) {                       // too few rows to fill 256 CUs with 64-row tiles
+            chunks = (args->A * D4 + 255) / 256;
+            const int64_t want = (1024 + chunks - 1) / chunks;
+            tile_rows = (args->R + want - 1) / want;
+            tile_rows = tile_rows < 4 ? 4 : (tile_rows > MPN_SH_TILE ? MPN_SH_TILE : tile_rows);
+            n_tiles = (args->R + tile_rows - 1) / tile_rows;
+        }
         const int grid = (int)(n_tiles < 4096 ? n_tiles : 4096);
-        hipLaunchKernelGGL(mpn_bwd_shared_kernel, dim3(grid), dim3(256), 0, st, *args, grad_agg, grad_z, grad_x,
-                           grad_wp, D4);
+        hipLaunchKernelGGL(mpn_bwd_shared_kernel, dim3(grid, (unsigned)chunks), dim3(256), 0, st, *args, grad_agg, grad_z,
+                           grad_x, grad_wp, D4, tile_rows);
     } else {
         const int grid = sgnn_grid_for(args->R * D4, 256, 2048);
         if (args->src == SGNN_SRC_DENSE)

@@ -541,6 +541,30 @@ def masked_sum(x, mask):
     return _MaskedSum.apply(x.contiguous(), mask.to(torch.uint8).contiguous())
 
 
+class _GatherRows(torch.autograd.Function):
+    """``nn.Embedding(padding_idx=0)`` lookup for a handful of ids (the shared P anchors, the walks
+    of the structure patches): the backward scatters the few rows with ``index_add_`` instead of
+    torch's dense-embedding backward, which serialises a short id list on two workgroups."""
+
+    @staticmethod
+    def forward(ctx, weight, ids):
+        flat = ids.reshape(-1)
+        ctx.save_for_backward(flat)
+        ctx.n_rows = weight.shape[0]
+        return weight.index_select(0, flat).view(*ids.shape, weight.shape[1])
+
+    @staticmethod
+    def backward(ctx, grad):
+        flat, = ctx.saved_tensors
+        g = grad.reshape(flat.numel(), -1) * (flat != 0).unsqueeze(1).to(grad.dtype)     # PAD row takes no gradient
+        return torch.zeros(ctx.n_rows, g.shape[1], dtype=grad.dtype, device=grad.device).index_add_(0, flat, g), None
+
+
+def gather_rows(weight, ids):
+    """weight[ids] with the PAD row (id 0) excluded from the gradient (aps:404-411 embed_anchor_patch)."""
+    return _GatherRows.apply(weight, ids.to(torch.int64))
+
+
 class _AttnScores(torch.autograd.Function):
     """Additive-attention scores: forward on the matrix cores (sgnn_attn_scores_fwd); the backward
     recomputes tanh(qW + X U) with library GEMMs (plain dense contractions)."""

@@ -4,6 +4,7 @@
 import numpy as np
 import pytest
 import torch
+import torch.nn.functional as F
 
 from oracle import float_half as FH
 from helpers import T, assert_close
@@ -147,10 +148,12 @@ def test_mpn_gather_shared_ids_over_components():
 
 @pytest.mark.parametrize('D', [8, 64, 128])
 @pytest.mark.parametrize('mode', ['sim_col', 'per_edge', 'by_id'])
-def test_mpn_shared_random(D, mode):
-    """SRC_SHARED: P-border (ids -> column id-1) and structure (index list) anchors."""
+@pytest.mark.parametrize('R', [150, 66000])
+def test_mpn_shared_random(D, mode, R):
+    """SRC_SHARED: P-border (ids -> column id-1) and structure (index list) anchors; a batch-sized
+    row count (short row tiles x item chunks in the backward) and a shard-sized one (64-row tiles)."""
     ops = _ops()
-    R, A, N, C = 150, 13, 200, 3
+    A, N, C = 13, 200, 3
     E, _, row_mask, sims, wp, bp, gagg, gz = _rand_case(D + 1, R, A, D, N, C)
     g = torch.Generator().manual_seed(8)
     X = torch.randn(A, D, generator=g)
@@ -181,6 +184,25 @@ def test_mpn_shared_random(D, mode):
     assert_close(Xg.grad, Xc.grad, 'grad X')
     assert_close(wpg.grad, wpc.grad, 'grad wp')
     assert_close(bpg.grad, bpc.grad, 'grad bp')
+
+
+def test_gather_rows_matches_embedding_with_padding_idx():
+    ops = _ops()
+    g = torch.Generator().manual_seed(5)
+    W = torch.randn(50, 16, generator=g)
+    W[0] = 0
+    ids = torch.randint(0, 50, (7, 3, 5), generator=g)
+    ids[0, 0, :] = 0
+    go = torch.randn(7, 3, 5, 16, generator=g)
+    Wc = W.clone().requires_grad_(True)
+    ref = F.embedding(ids, Wc, padding_idx=0)
+    (ref * go).sum().backward()
+    Wg = W.to(DEV).requires_grad_(True)
+    out = ops.gather_rows(Wg, ids.to(DEV))
+    (out * go.to(DEV)).sum().backward()
+    assert torch.equal(out.cpu(), ref.detach())
+    assert_close(Wg.grad, Wc.grad, 'grad W')
+    assert float(Wg.grad[0].abs().max()) == 0.0
 
 
 def test_masked_sum():
