@@ -24,7 +24,7 @@ import torch
 from . import ops, tape, gamma, subgraph_utils
 from . import anchor_patch_samplers as aps
 
-MAX_PINT_SOURCES = 8192
+MAX_PINT_BYTES = 16 << 30          # hop table (max_id+1) x (#distinct P-internal anchors) uint8 kept in HBM
 
 
 class StageTimer:
@@ -117,9 +117,10 @@ def prepare_sparse(model, split='train', timer=None):
                                                        device=dev)
                 else:
                     uniq, inv = torch.unique(pint[l], return_inverse=True)
-                    if uniq.numel() > MAX_PINT_SOURCES:
+                    if uniq.numel() * (g.max_id + 1) > MAX_PINT_BYTES:
                         raise NotImplementedError('sparse P-internal similarities for multi-component subgraphs need '
-                                                  'a BFS per distinct anchor (%d > %d)' % (uniq.numel(), MAX_PINT_SOURCES))
+                                                  'a BFS per distinct anchor: %d sources x %d nodes exceeds the %d GiB '
+                                                  'hop-table budget' % (uniq.numel(), g.max_id + 1, MAX_PINT_BYTES >> 30))
                     d = ops.bfs_hops(g, uniq.to(torch.int32).contiguous(), max_hops=hp.get('max_bfs_hops', 32),
                                      node_major=True)
                     full = ops.min_hops_to_sets(d, cc_sets, node_major=True).view(S, C, -1)     # (S, C, U)
