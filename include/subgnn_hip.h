@@ -178,8 +178,13 @@ int sgnn_sp_similarity_dense(const double* apsp, int64_t n_cols,
  * (64 sources per machine word).  dist: (n_sources, max_id + 1) uint8, 255 = not reached within
  * max_hops (the reference's matrix holds 0 for unreachable pairs, precompute_graph_metrics.py:
  * 20-25; sgnn_min_hops_to_sets applies that convention).
- * workspace: sgnn_bfs_hops_workspace_bytes(max_id, n_sources, max_hops) bytes (any content). */
+ * workspace: sgnn_bfs_hops_workspace_bytes(max_id, n_sources, max_hops) bytes (any content).
+ * The expansion is direction-optimising: a level pulls (every incomplete node ORs its neighbours'
+ * frontier words) instead of pushing once the frontier's edge volume exceeds 1/alpha of all edges.
+ * sgnn_bfs_hops_tuning sets alpha process-wide (default 16; 0 = always push); results do not depend
+ * on it. */
 int64_t sgnn_bfs_hops_workspace_bytes(int64_t max_id, int64_t n_sources, int max_hops);
+int sgnn_bfs_hops_tuning(int alpha);
 int sgnn_bfs_hops(const int64_t* rowptr, const int32_t* col, int64_t nnz, int64_t max_id,
                   const int32_t* sources, int64_t n_sources, int max_hops, int node_major,
                   uint8_t* dist, void* workspace, int64_t workspace_bytes, void* stream);

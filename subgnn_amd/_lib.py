@@ -47,6 +47,7 @@ SIGNATURES = {
     'sgnn_patch_in_border': (c_int, [c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_ptr, c_ptr]),
     'sgnn_sp_similarity_dense': (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_ptr, c_ptr]),
     'sgnn_bfs_hops_workspace_bytes': (c_i64, [c_i64, c_i64, c_int]),
+    'sgnn_bfs_hops_tuning': (c_int, [c_int]),
     'sgnn_bfs_hops': (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_i64, c_int, c_int, c_ptr, c_ptr, c_i64, c_ptr]),
     'sgnn_min_hops_to_sets': (c_int, [c_ptr, c_i64, c_i64, c_int, c_ptr, c_ptr, c_i64, c_ptr, c_ptr]),
     'sgnn_dtw_workspace_bytes': (c_i64, [c_i64, c_i64, c_i64, c_i64]),

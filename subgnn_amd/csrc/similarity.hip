@@ -51,22 +51,39 @@ extern "C" int sgnn_sp_similarity_dense(const double* apsp, int64_t n_cols,
 // ---------------------------------------------------------------------------------------------
 // a9  sparse form: bit-parallel multi-source BFS.  Each node carries one 64-bit word per group
 // of 64 sources (seen / frontier / next).  A level is two grid-wide kernels:
-//   expand : every node with a non-zero frontier word ORs it into next[] of its neighbours
-//            (16-lane groups stream a neighbour list, coalesced), 64 BFS's per edge visit;
+//   expand : direction-optimising.  While the frontier is small it PUSHES: every node with a
+//            non-zero frontier word ORs it into next[] of its neighbours (16-lane groups stream
+//            a neighbour list, coalesced; 64 BFS's per edge visit; atomics).  Once the frontier's
+//            edge volume passes 1/alpha of all edges it PULLS: every node that still misses a
+//            source ORs the frontier words of its neighbours into its own next[] -- no atomics,
+//            nodes that have seen every source are skipped and a list is abandoned as soon as
+//            nothing is missing any more (on a scale-free graph almost every node is complete
+//            after 3-4 levels).  The choice is made on the device from a counter the previous
+//            commit left behind, so the host still enqueues all levels without synchronising.
 //   commit : new = next & ~seen; seen |= new; frontier = new; dist[src][node] = level for the
-//            new bits; a device flag says whether any bit was new (later levels exit early).
-// The host enqueues max_hops levels without synchronising.
+//            new bits; flags[level] says whether any bit was new (later levels exit early);
+//            fvol[level] = sum over new frontier words of the node's degree.
 // ---------------------------------------------------------------------------------------------
+static int g_bfs_alpha = 16;    // pull when frontier word-edges * alpha > nnz * n_words; 0 = never pull
+
+extern "C" int sgnn_bfs_hops_tuning(int alpha)
+{
+    if (alpha < 0) return SGNN_ERR_BAD_ARG;
+    g_bfs_alpha = alpha;
+    return SGNN_OK;
+}
+
 __global__ void msbfs_init_kernel(const int32_t* __restrict__ sources, int64_t n_sources, int64_t n_words,
                                   int64_t n_ids, uint64_t* __restrict__ seen, uint64_t* __restrict__ frontier,
                                   uint64_t* __restrict__ next, uint8_t* __restrict__ dist, int32_t* __restrict__ flags,
+                                  unsigned long long* __restrict__ fvol,
                                   int max_hops)  // dist layout-agnostic: filled as a flat array
 {
     const int64_t gtid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = gtid; i < n_ids * n_words; i += gsz) { seen[i] = 0; frontier[i] = 0; next[i] = 0; }
     for (int64_t i = gtid; i < n_sources * n_ids; i += gsz) dist[i] = 255;
-    for (int64_t i = gtid; i <= max_hops; i += gsz) flags[i] = (i == 0) ? 1 : 0;
+    for (int64_t i = gtid; i <= max_hops; i += gsz) { flags[i] = (i == 0) ? 1 : 0; fvol[i] = 0; }
 }
 
 __global__ void msbfs_seed_kernel(const int32_t* __restrict__ sources, int64_t n_sources, int64_t n_words,
@@ -82,40 +99,104 @@ __global__ void msbfs_seed_kernel(const int32_t* __restrict__ sources, int64_t n
     dist[s * ss + v * sv] = 0;
 }
 
+#define MSBFS_WCHUNK 4          // source words a pull pass keeps in registers
+
+__device__ __forceinline__ uint64_t msbfs_group_or(uint64_t x)
+{
+    // OR over the 16 lanes of a group (xor-butterfly: every lane ends with the full value)
+    for (int off = 8; off >= 1; off >>= 1) {
+        const uint32_t lo = __shfl_xor((int)(uint32_t)x, off, 64);
+        const uint32_t hi = __shfl_xor((int)(uint32_t)(x >> 32), off, 64);
+        x |= ((uint64_t)hi << 32) | lo;
+    }
+    return x;
+}
+
 __global__ __launch_bounds__(256) void msbfs_expand_kernel(
     const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col, int64_t n_ids, int64_t n_words,
-    const uint64_t* __restrict__ seen, const uint64_t* __restrict__ frontier, uint64_t* __restrict__ next,
-    const int32_t* __restrict__ flags, int level)
+    int64_t n_sources, const uint64_t* __restrict__ seen, const uint64_t* __restrict__ frontier,
+    uint64_t* __restrict__ next, const int32_t* __restrict__ flags, const unsigned long long* __restrict__ fvol,
+    unsigned long long pull_above, int level)
 {
     if (flags[level - 1] == 0) return;                       // previous level found nothing
     const int sub = threadIdx.x & 15;
     const int64_t group = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 4;
     const int64_t n_groups = ((int64_t)gridDim.x * blockDim.x) >> 4;
+    const bool pull = level > 1 && pull_above != ~0ull && fvol[level - 1] > pull_above;
+    if (!pull) {
+        for (int64_t v = group; v < n_ids; v += n_groups) {
+            uint64_t any = 0;
+            for (int64_t w = 0; w < n_words; ++w) any |= frontier[v * n_words + w];
+            if (any == 0) continue;
+            // one pass over the neighbour list for all source words: col[] is read once, and the
+            // n_words seen/next words of a neighbour are contiguous
+            const int64_t r0 = rowptr[v], r1 = rowptr[v + 1];
+            for (int64_t e = r0 + sub; e < r1; e += 16) {
+                const int64_t u = col[e];
+                for (int64_t w = 0; w < n_words; ++w) {
+                    const uint64_t f = frontier[v * n_words + w];
+                    const uint64_t m = f & ~seen[u * n_words + w];
+                    if (m) atomicOr((unsigned long long*)&next[u * n_words + w], (unsigned long long)m);
+                }
+            }
+        }
+        return;
+    }
     for (int64_t v = group; v < n_ids; v += n_groups) {
-        uint64_t any = 0;
-        for (int64_t w = 0; w < n_words; ++w) any |= frontier[v * n_words + w];
-        if (any == 0) continue;
-        // one pass over the neighbour list for all source words: col[] is read once, and the
-        // n_words seen/next words of a neighbour are contiguous
         const int64_t r0 = rowptr[v], r1 = rowptr[v + 1];
-        for (int64_t e = r0 + sub; e < r1; e += 16) {
-            const int64_t u = col[e];
-            for (int64_t w = 0; w < n_words; ++w) {
-                const uint64_t f = frontier[v * n_words + w];
-                const uint64_t m = f & ~seen[u * n_words + w];
-                if (m) atomicOr((unsigned long long*)&next[u * n_words + w], (unsigned long long)m);
+        for (int64_t w0 = 0; w0 < n_words; w0 += MSBFS_WCHUNK) {
+            uint64_t need[MSBFS_WCHUNK], acc[MSBFS_WCHUNK];
+            uint64_t missing = 0;
+#pragma unroll
+            for (int k = 0; k < MSBFS_WCHUNK; ++k) {
+                const int64_t w = w0 + k;
+                uint64_t valid = 0;
+                if (w < n_words) {
+                    const int64_t left = n_sources - w * 64;
+                    valid = left >= 64 ? ~0ull : ((1ull << left) - 1);
+                    valid &= ~seen[v * n_words + w];
+                }
+                need[k] = valid;
+                acc[k] = 0;
+                missing |= valid;
+            }
+            if (missing == 0) continue;                      // this node has every source of the chunk
+            int since = 0;
+            for (int64_t e = r0 + sub; e < r1 + sub; e += 16) {          // uniform trip count per group
+                if (e < r1) {
+                    const int64_t u = col[e];
+#pragma unroll
+                    for (int k = 0; k < MSBFS_WCHUNK; ++k)
+                        if (w0 + k < n_words) acc[k] |= frontier[u * n_words + w0 + k];
+                }
+                if (++since == 8) {                          // every 128 neighbours: anything still missing?
+                    since = 0;
+                    uint64_t left = 0;
+#pragma unroll
+                    for (int k = 0; k < MSBFS_WCHUNK; ++k) { acc[k] = msbfs_group_or(acc[k]); left |= need[k] & ~acc[k]; }
+                    if (left == 0) break;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < MSBFS_WCHUNK; ++k) {
+                acc[k] = msbfs_group_or(acc[k]);
+                if (sub == k && w0 + k < n_words) {
+                    const uint64_t m = acc[k] & need[k];
+                    if (m) next[v * n_words + w0 + k] = m;   // next[] is all zero before a pull level
+                }
             }
         }
     }
 }
 
 __global__ __launch_bounds__(256) void msbfs_commit_kernel(
-    int64_t n_ids, int64_t n_words, int64_t n_sources, uint64_t* __restrict__ seen, uint64_t* __restrict__ frontier,
-    uint64_t* __restrict__ next, uint8_t* __restrict__ dist, int32_t* __restrict__ flags, int level,
-    int64_t ss, int64_t sv)
+    const int64_t* __restrict__ rowptr, int64_t n_ids, int64_t n_words, int64_t n_sources, uint64_t* __restrict__ seen,
+    uint64_t* __restrict__ frontier, uint64_t* __restrict__ next, uint8_t* __restrict__ dist, int32_t* __restrict__ flags,
+    unsigned long long* __restrict__ fvol, int level, int64_t ss, int64_t sv)
 {
     if (flags[level - 1] == 0) return;
     bool any = false;
+    unsigned long long vol = 0;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n_ids * n_words;
          i += (int64_t)gridDim.x * blockDim.x) {
         const uint64_t nw = next[i] & ~seen[i];
@@ -125,6 +206,7 @@ __global__ __launch_bounds__(256) void msbfs_commit_kernel(
             any = true;
             seen[i] |= nw;
             const int64_t v = i / n_words, w = i % n_words;
+            vol += (unsigned long long)(rowptr[v + 1] - rowptr[v]);
             uint64_t bits = nw;
             while (bits) {
                 const int b = __ffsll((unsigned long long)bits) - 1;
@@ -134,12 +216,19 @@ __global__ __launch_bounds__(256) void msbfs_commit_kernel(
             }
         }
     }
-    if (__any(any) && (threadIdx.x & 63) == 0) atomicOr(&flags[level], 1);
+    if (__any(any)) {
+        for (int off = 32; off >= 1; off >>= 1) {
+            const uint32_t lo = __shfl_xor((int)(uint32_t)vol, off, 64);
+            const uint32_t hi = __shfl_xor((int)(uint32_t)(vol >> 32), off, 64);
+            vol += ((unsigned long long)hi << 32) | lo;
+        }
+        if ((threadIdx.x & 63) == 0) { atomicOr(&flags[level], 1); atomicAdd(&fvol[level], vol); }
+    }
 }
 
 extern "C" int64_t sgnn_bfs_hops_workspace_bytes(int64_t max_id, int64_t n_sources, int max_hops) {
     const int64_t n_words = (n_sources + 63) / 64;
-    return 3 * (max_id + 1) * n_words * 8 + ((int64_t)max_hops + 2) * 4;
+    return 3 * (max_id + 1) * n_words * 8 + ((int64_t)max_hops + 2) * 8 + ((int64_t)max_hops + 2) * 4;
 }
 
 extern "C" int sgnn_bfs_hops(const int64_t* rowptr, const int32_t* col, int64_t nnz, int64_t max_id,
@@ -158,10 +247,13 @@ extern "C" int sgnn_bfs_hops(const int64_t* rowptr, const int32_t* col, int64_t 
     uint64_t* seen = (uint64_t*)workspace;
     uint64_t* frontier = seen + n_ids * n_words;
     uint64_t* next = frontier + n_ids * n_words;
-    int32_t* flags = (int32_t*)(next + n_ids * n_words);
+    unsigned long long* fvol = (unsigned long long*)(next + n_ids * n_words);
+    int32_t* flags = (int32_t*)(fvol + max_hops + 2);
+    const unsigned long long pull_above =
+        g_bfs_alpha > 0 ? (unsigned long long)((nnz * n_words) / g_bfs_alpha) : ~0ull;
     const int big = sgnn_grid_for(n_ids * (n_words > n_sources ? n_words : n_sources), 256);
     hipLaunchKernelGGL(msbfs_init_kernel, dim3(big), dim3(256), 0, st, sources, n_sources, n_words, n_ids, seen,
-                       frontier, next, dist, flags, max_hops);
+                       frontier, next, dist, flags, fvol, max_hops);
     SGNN_CHECK_LAUNCH();
     hipLaunchKernelGGL(msbfs_seed_kernel, dim3((int)((n_sources + 255) / 256)), dim3(256), 0, st, sources, n_sources,
                        n_words, n_ids, seen, frontier, dist, ss, sv);
@@ -169,11 +261,11 @@ extern "C" int sgnn_bfs_hops(const int64_t* rowptr, const int32_t* col, int64_t 
     const int g_expand = sgnn_grid_for(n_ids * 16, 256);
     const int g_commit = sgnn_grid_for(n_ids * n_words, 256);
     for (int level = 1; level <= max_hops; ++level) {
-        hipLaunchKernelGGL(msbfs_expand_kernel, dim3(g_expand), dim3(256), 0, st, rowptr, col, n_ids, n_words, seen,
-                           frontier, next, flags, level);
+        hipLaunchKernelGGL(msbfs_expand_kernel, dim3(g_expand), dim3(256), 0, st, rowptr, col, n_ids, n_words, n_sources,
+                           seen, frontier, next, flags, fvol, pull_above, level);
         SGNN_CHECK_LAUNCH();
-        hipLaunchKernelGGL(msbfs_commit_kernel, dim3(g_commit), dim3(256), 0, st, n_ids, n_words, n_sources, seen,
-                           frontier, next, dist, flags, level, ss, sv);
+        hipLaunchKernelGGL(msbfs_commit_kernel, dim3(g_commit), dim3(256), 0, st, rowptr, n_ids, n_words, n_sources, seen,
+                           frontier, next, dist, flags, fvol, level, ss, sv);
         SGNN_CHECK_LAUNCH();
     }
     return SGNN_OK;

@@ -326,6 +326,11 @@ def sp_similarity_dense(apsp, sets):
     return out
 
 
+def bfs_hops_tuning(alpha):
+    """Direction switch of the multi-source BFS: pull once frontier edges * alpha > all edges (0 = always push)."""
+    check(_lib.load().sgnn_bfs_hops_tuning(int(alpha)), 'sgnn_bfs_hops_tuning')
+
+
 def bfs_hops(g, sources, max_hops=64, node_major=False):
     """uint8 hop counts (255 = not reached) by multi-source BFS: (n_sources, max_id+1), or
     (max_id+1, n_sources) when ``node_major`` (coalesced for min_hops_to_sets)."""

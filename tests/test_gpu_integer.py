@@ -323,9 +323,52 @@ def test_sp_similarity_dense_golden(golden):
         assert np.array_equal(got.cpu().numpy(), golden['g4_np_sim_' + sp])
 
 
-def test_bfs_hops_matches_apsp(golden):
+@pytest.fixture
+def bfs_alpha(request):
+    ops = _ops()
+    ops.bfs_hops_tuning(request.param)
+    yield request.param
+    ops.bfs_hops_tuning(16)
+
+
+@pytest.mark.parametrize('n_src', [70, 300])
+def test_bfs_hops_push_pull_agree_and_match_scipy(n_src):
+    """The direction switch never changes a hop count: always-push, always-pull and the default mix
+    agree on a scale-free graph (300 sources = 5 words: two register chunks in the pull pass), and
+    equal scipy's BFS distances; isolated ids stay unreached."""
+    import scipy.sparse as sp
+    from scipy.sparse.csgraph import shortest_path
+    from subgnn_amd import synthetic
+    ops = _ops()
+    n = 6000
+    edges = synthetic.barabasi_albert_edges(n - 50, 6, seed=9)          # ids n-49..n are isolated
+    rowptr, col = synthetic.sorted_csr(edges, n)
+    dg = ops.DeviceGraph(rowptr, col, np.arange(1, n + 1, dtype=np.int32), DEV)
+    src = np.random.default_rng(n_src).integers(1, n + 1, n_src).astype(np.int32)
+    src[0] = n                                                           # an isolated source
+    out = {}
+    try:
+        for alpha in (0, 16, 1 << 30):
+            ops.bfs_hops_tuning(alpha)
+            out[alpha] = ops.bfs_hops(dg, torch.from_numpy(src).to(DEV), max_hops=32)
+            out[(alpha, 't')] = ops.bfs_hops(dg, torch.from_numpy(src).to(DEV), max_hops=32, node_major=True)
+    finally:
+        ops.bfs_hops_tuning(16)
+    assert torch.equal(out[0], out[16]) and torch.equal(out[0], out[1 << 30])
+    for alpha in (0, 16, 1 << 30):
+        assert torch.equal(out[(alpha, 't')].t().contiguous(), out[0])
+    A = sp.csr_matrix((np.ones(len(col), dtype=np.int8), col.astype(np.int64) - 1, rowptr[1:] - rowptr[1]), shape=(n, n))
+    ref = shortest_path(A, method='D', unweighted=True, indices=src[:40].astype(np.int64) - 1)
+    got = out[0][:40, 1:].cpu().numpy().astype(np.float64)
+    got[got == 255] = np.inf
+    assert np.array_equal(got, ref)
+    assert (got[0][:n - 1] == np.inf).all() and got[0][n - 1] == 0
+
+
+@pytest.mark.parametrize('bfs_alpha', [0, 16, 1 << 30], indirect=True)
+def test_bfs_hops_matches_apsp(golden, bfs_alpha):
     """Sparse form == dense form on the columns of the chosen sources (the graph is connected
-    enough; unreachable pairs are 0 in both conventions)."""
+    enough; unreachable pairs are 0 in both conventions); pushed, mixed and pulled expansion."""
     ops = _ops()
     G, dg = _graphs(golden)
     rng = np.random.default_rng(2)

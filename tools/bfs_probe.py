@@ -1,0 +1,33 @@
+"""Timing of the multi-source BFS (position channel) on the benchmark graph for several push/pull
+switch points (sgnn_bfs_hops_tuning), checking that every setting returns the same hop table."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from subgnn_amd import ops, synthetic
+
+n, m = 1_000_000, 10
+edges = synthetic.barabasi_albert_edges(n, m, seed=42)
+rowptr, col = synthetic.sorted_csr(edges, n)
+dev = torch.device('cuda:0')
+g = ops.DeviceGraph(rowptr, col, np.arange(1, n + 1, dtype=np.int32), dev)
+
+
+def timeit(f, reps=5):
+    f(); torch.cuda.synchronize(); t = time.perf_counter()
+    for _ in range(reps): f()
+    torch.cuda.synchronize(); return (time.perf_counter() - t) / reps * 1e3
+
+
+for ns in (57, 183, 1000):
+    src = torch.from_numpy(np.random.default_rng(5).integers(1, n + 1, ns).astype(np.int32)).to(dev)
+    ref = None
+    for alpha in (0, 2, 4, 8, 16, 32, 64, 1 << 30):
+        ops.bfs_hops_tuning(alpha)
+        ms = timeit(lambda: ops.bfs_hops(g, src, max_hops=32, node_major=True))
+        d = ops.bfs_hops(g, src, max_hops=32, node_major=True)
+        if ref is None:
+            ref = d
+        print('sources %5d  alpha %10d  %8.3f ms  same=%s  max hop %d' % (ns, alpha, ms, bool(torch.equal(d, ref)),
+                                                                         int(d[d != 255].max())))
+ops.bfs_hops_tuning(16)
