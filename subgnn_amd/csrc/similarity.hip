@@ -331,6 +331,10 @@ extern "C" int sgnn_min_hops_to_sets(const uint8_t* dist, int64_t n_sources, int
 #define DTW_BLOCKS (256 * 2)
 #endif
 #define DTW_NT ((int64_t)DTW_THREADS * DTW_BLOCKS)
+#ifndef DTW_REG_BLOCKS
+#define DTW_REG_BLOCKS (256 * 4)      // register variant: its scratch is LDS, more and shorter-lived workgroups balance better
+#endif
+#define DTW_REG_NT ((int64_t)DTW_THREADS * DTW_REG_BLOCKS)
 #define DTW_MAX_LEVELS 16
 
 struct DtwLayout {
@@ -364,38 +368,61 @@ extern "C" int64_t sgnn_dtw_workspace_bytes(int64_t n_x, int64_t max_x_len, int6
     if (max_x_len < 1) max_x_len = 1;
     if (max_y_len < 1) max_y_len = 1;
     const DtwLayout L = dtw_layout(max_x_len, max_y_len);
-    int64_t lane = L.n_dbl * 8 + dtw_align8(L.n_i32 * 4) + dtw_align8(L.n_dir * 4);
-    if (L.YL * 8 > lane) lane = L.YL * 8;                     // register variant: one word per column and level
-    return DTW_NT * lane
-         + n_x * L.XL * 8 + n_y * L.YL * 8 + dtw_align8(n_x * 4) + dtw_align8(n_y * 4);
+    const int64_t lane = L.n_dbl * 8 + dtw_align8(L.n_i32 * 4) + dtw_align8(L.n_dir * 4);
+    int64_t scratch = DTW_NT * lane;
+    if (DTW_REG_NT * L.YL * 8 > scratch) scratch = DTW_REG_NT * L.YL * 8;   // register variant: one word per column and level
+    return scratch
+         + 2 * (n_x * L.XL * 8 + n_y * L.YL * 8) + dtw_align8(n_x * 4) + dtw_align8(n_y * 4);   // value + reciprocal pyramids
 }
 
-// pyramid of one series per thread.  transposed != 0: element e of sequence s at out[e * n + s]
+// pyramid of one series per thread.  transposed != 0: element e of sequence s at out[e * n + s].
+// rec (same layout) receives 1 / (value + 1), correctly rounded: the register kernel's cost
+// function divides by multiplying with it (see dtw_cost_rcp).
 __global__ void dtw_pyramid_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ val, int64_t n,
                                    int64_t M, int64_t PL, int transposed, double* __restrict__ out,
-                                   int32_t* __restrict__ len_out)
+                                   double* __restrict__ rec, int32_t* __restrict__ len_out)
 {
     for (int64_t s = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; s < n; s += (int64_t)gridDim.x * blockDim.x) {
         const int64_t b = ptr[s];
         int len = (int)(ptr[s + 1] - b);
         len_out[s] = len;
-#define PY(e) out[transposed ? (int64_t)(e) * n + s : s * PL + (e)]
-        for (int i = 0; i < len; ++i) PY(i) = (double)val[b + i];
+#define PYI(e) (transposed ? (int64_t)(e) * n + s : s * PL + (e))
+#define PY(e) out[PYI(e)]
+        for (int i = 0; i < len; ++i) { const double v = (double)val[b + i]; PY(i) = v; rec[PYI(i)] = 1.0 / (v + 1.0); }
         int64_t off = 0;
         int k = 0;
         while (len >= 2 && k + 1 < DTW_MAX_LEVELS) {
             const int64_t noff = off + (M >> k);
             const int nlen = len / 2;
-            for (int i = 0; i < nlen; ++i) PY(noff + i) = (PY(off + 2 * i) + PY(off + 2 * i + 1)) / 2.0;
+            for (int i = 0; i < nlen; ++i) {
+                const double v = (PY(off + 2 * i) + PY(off + 2 * i + 1)) / 2.0;
+                PY(noff + i) = v;
+                rec[PYI(noff + i)] = 1.0 / (v + 1.0);
+            }
             off = noff; len = nlen; ++k;
         }
 #undef PY
+#undef PYI
     }
 }
 
 __device__ static inline double dtw_cost(double a, double b) {            // gamma.py:51-52
     const double mx = a > b ? a : b, mn = a > b ? b : a;
     return (mx + 1.0) / (mn + 1.0) - 1.0;
+}
+
+// The same cost from a1 = a + 1, b1 = b + 1 and their correctly rounded reciprocals ra, rb, without
+// a divide instruction sequence: q0 = RN(mx * r), rem = mx - q0 * mn (exact in an fma),
+// q = RN(q0 + rem * r) is the correctly rounded quotient mx / mn when r = RN(1 / mn) (Markstein's
+// division step; it can only fail for divisors whose significand is all ones, and mn is a small
+// dyadic rational here).  tests/test_oracle_integer.py::test_reciprocal_division_is_exact runs the
+// identity exhaustively over the integer range and on 10^7 random dyadic pairs on the CPU.
+__device__ __forceinline__ double dtw_cost_rcp(double a1, double ra, double b1, double rb) {
+    const bool sw = a1 > b1;
+    const double mx = sw ? a1 : b1, mn = sw ? b1 : a1, r = sw ? rb : ra;
+    const double q0 = __dmul_rn(mx, r);
+    const double rem = __fma_rn(-q0, mn, mx);
+    return __dadd_rn(__fma_rn(rem, r, q0), -1.0);
 }
 
 __global__ __launch_bounds__(DTW_THREADS) void dtw_similarity_kernel(
@@ -525,14 +552,29 @@ __global__ __launch_bounds__(DTW_THREADS) void dtw_similarity_kernel(
 // is the only per-cell state written to memory (write-once, coalesced); the backtrack reads it
 // back and keeps the per-row column range of the path in registers for the next finer level.
 #define DTW_R 32
+#ifndef DTW_MINB12
+#define DTW_MINB12 3            // resident 256-thread blocks per CU the 12-row kernel is compiled for
+#endif
+#ifndef DTW_MINB32
+#define DTW_MINB32 1
+#endif
+#ifndef DTW_MINB20
+#define DTW_MINB20 2
+#endif
 
 // one level of the register-resident DP, unrolled over RR <= DTW_R rows (the coarse levels and short
 // components take the narrow instantiations, so the unrolled row loop does not sweep empty rows)
-template <int RR, int TIE>
+// fl: this lane's column of the workgroup's LDS table (stride DTW_THREADS words) holding the coarser
+// path's first | last << 16 column per row.  Predecessor codes of a non-finest level go to wl (LDS,
+// 32-bit words: such a level has at most 16 rows) when WLDS, else to the global scratch wq.
+template <int RMAX, int RR, int TIE, bool WLDS>
 __device__ __forceinline__ double dtw_reg_level(
-    int32_t (&fl)[DTW_R], const double* __restrict__ xcol, int64_t n_x, const double* __restrict__ ycol,
-    int lx, int ly, int lxc, int lyc, bool coarsest, bool finest, uint64_t* __restrict__ wq, int64_t NT)
+    int32_t* __restrict__ fl, const double* __restrict__ xcol, const double* __restrict__ xrcol, int64_t n_x,
+    const double* __restrict__ ycol, const double* __restrict__ yrcol,
+    int lx, int ly, int lxc, int lyc, bool coarsest, bool finest, uint32_t* __restrict__ wl,
+    uint64_t* __restrict__ wq, int64_t NT)
 {
+#define FLQ(q) fl[(q) * DTW_THREADS]
     const double INF = __longlong_as_double(0x7ff0000000000000ll);
     const int32_t EMPTY = 1;                                  // lo = 1, hi = 0
     int32_t lohi[RR];
@@ -546,8 +588,8 @@ __device__ __forceinline__ double dtw_reg_level(
             const int ci = i >> 1;
             const int ca = ci - 1 < 0 ? 0 : ci - 1;                          // <= lxc - 1 for every real row
             const int cb = ci + 1;                                           // static; rows past the coarse
-            const int firstc = fl[ca] & 0xffff;                              // path end take its last column
-            const int lastc = (cb < lxc) ? (fl[cb < DTW_R ? cb : DTW_R - 1] >> 16) : (lyc - 1);
+            const int firstc = FLQ(ca) & 0xffff;                             // path end take its last column
+            const int lastc = (cb < lxc) ? (FLQ(cb < RMAX ? cb : RMAX - 1) >> 16) : (lyc - 1);
             int lo = 2 * (firstc - 1);
             int hi = 2 * (lastc + 1) + 1;
             if (lo < prev_lo) lo = prev_lo;
@@ -558,42 +600,70 @@ __device__ __forceinline__ double dtw_reg_level(
             lohi[i] = v;
         }
     }
-    double xv[RR], col[RR];
+    // rows in blocks of 4: a block is swept for the columns [min lo, max hi + 1] of its rows (the
+    // extra column lets every cell of the block fall back to INF once), and skipped with one test
+    // elsewhere -- most (row, column) pairs lie outside the radius-1 window
+    int32_t blk[RR / 4];
+#pragma unroll
+    for (int b = 0; b < RR / 4; ++b) {
+        int lo = 0x7fff, hi = -1;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int l = lohi[4 * b + q] & 0xffff, h = lohi[4 * b + q] >> 16;
+            if (h >= l) { lo = l < lo ? l : lo; hi = h > hi ? h : hi; }
+        }
+        blk[b] = hi < 0 ? EMPTY : (((hi + 1) << 16) | lo);
+    }
+    double xp1[RR], xr[RR], col[RR];
 #pragma unroll
     for (int i = 0; i < RR; ++i) {
-        xv[i] = i < lx ? xcol[(int64_t)i * n_x] : 0.0;
+        xp1[i] = i < lx ? xcol[(int64_t)i * n_x] + 1.0 : 1.0;
+        xr[i] = i < lx ? xrcol[(int64_t)i * n_x] : 1.0;
         col[i] = INF;
     }
+    double y_next = ycol[0], yr_next = yrcol[0];
     for (int j = 0; j < ly; ++j) {
-        const double yj = ycol[j];
+        const double yp1 = y_next + 1.0, yr = yr_next;
+        if (j + 1 < ly) { y_next = ycol[j + 1]; yr_next = yrcol[j + 1]; }       // in flight during this column
         uint64_t word = 0;
         double up = INF;
         double diag = (j == 0) ? 0.0 : INF;                                  // virtual origin D[0][0] = 0
 #pragma unroll
-        for (int i = 0; i < RR; ++i) {
-            const int lo = lohi[i] & 0xffff, hi = lohi[i] >> 16;
-            const double old = col[i];
-            double nv = INF;
-            if (j >= lo && j <= hi) {
-                const double dt = dtw_cost(xv[i], yj);
-                const double c_up = up + dt, c_left = old + dt, c_diag = diag + dt;
-                int best;
-                if (TIE == 0) {                                              // (i-1,j), (i,j-1), (i-1,j-1)
-                    best = 0; nv = c_up;
-                    if (c_left < nv) { nv = c_left; best = 1; }
-                    if (c_diag < nv) { nv = c_diag; best = 2; }
-                } else {                                                     // (i-1,j-1), (i-1,j), (i,j-1)
-                    best = 2; nv = c_diag;
-                    if (c_up < nv) { nv = c_up; best = 0; }
-                    if (c_left < nv) { nv = c_left; best = 1; }
+        for (int b = 0; b < RR / 4; ++b) {
+            if (j >= (blk[b] & 0xffff) && j <= (blk[b] >> 16)) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int i = 4 * b + q;
+                    const int lo = lohi[i] & 0xffff, hi = lohi[i] >> 16;
+                    const double old = col[i];
+                    double nv = INF;
+                    if (j >= lo && j <= hi) {
+                        const double dt = dtw_cost_rcp(xp1[i], xr[i], yp1, yr);
+                        const double c_up = up + dt, c_left = old + dt, c_diag = diag + dt;
+                        int best;
+                        if (TIE == 0) {                                      // (i-1,j), (i,j-1), (i-1,j-1)
+                            best = 0; nv = c_up;
+                            if (c_left < nv) { nv = c_left; best = 1; }
+                            if (c_diag < nv) { nv = c_diag; best = 2; }
+                        } else {                                             // (i-1,j-1), (i-1,j), (i,j-1)
+                            best = 2; nv = c_diag;
+                            if (c_up < nv) { nv = c_up; best = 0; }
+                            if (c_left < nv) { nv = c_left; best = 1; }
+                        }
+                        word |= (uint64_t)best << (2 * i);
+                    }
+                    col[i] = nv;
+                    diag = old;                                              // (i, j-1) is the diagonal of (i+1, j)
+                    up = nv;
                 }
-                word |= (uint64_t)best << (2 * i);
+            } else {                                                         // every cell of the block is INF
+                up = INF;                                                    // in this column and the previous one
+                diag = INF;
             }
-            col[i] = nv;
-            diag = old;                                                      // (i, j-1) is the diagonal of (i+1, j)
-            up = nv;
         }
-        wq[(int64_t)j * NT] = word;
+        if (!finest) {                                                       // the finest level is never backtracked
+            if (WLDS) wl[j * DTW_THREADS] = (uint32_t)word; else wq[(int64_t)j * NT] = word;
+        }
     }
     double result = 0.0;
 #pragma unroll
@@ -601,30 +671,35 @@ __device__ __forceinline__ double dtw_reg_level(
     if (finest) return result;
     // backtrack through the predecessor codes; record the path's column range per row
 #pragma unroll
-    for (int q = 0; q < RR; ++q) fl[q] = 0xffff;                             // first = 65535, last = 0
+    for (int q = 0; q < RR; ++q) FLQ(q) = 0xffff;                            // first = 65535, last = 0
     int i = lx - 1, j = ly - 1;
     while (i >= 0 && j >= 0) {
-#pragma unroll
-        for (int q = 0; q < RR; ++q) {
-            if (q == i) {
-                int f = fl[q] & 0xffff, l = fl[q] >> 16;
-                f = j < f ? j : f;
-                l = j > l ? j : l;
-                fl[q] = (l << 16) | f;
-            }
-        }
-        const int d = (int)((wq[(int64_t)j * NT] >> (2 * i)) & 3);
+        const int v = FLQ(i);
+        int f = v & 0xffff, l = v >> 16;
+        f = j < f ? j : f;
+        l = j > l ? j : l;
+        FLQ(i) = (l << 16) | f;
+        const uint64_t word = WLDS ? (uint64_t)wl[j * DTW_THREADS] : wq[(int64_t)j * NT];
+        const int d = (int)((word >> (2 * i)) & 3);
         if (d == 0) --i; else if (d == 1) --j; else { --i; --j; }
     }
     return result;
+#undef FLQ
 }
 
-template <int TIE>
-__global__ __launch_bounds__(DTW_THREADS, 2) void dtw_similarity_reg_kernel(
+// RMAX = rows the instantiation can hold (12 / 20 / 32): the register budget -- and with it the
+// number of resident wavefronts that hide the fp64 dependency chains -- follows the longest
+// component of the call, not the longest the kernel family supports.
+template <int RMAX, int TIE, int MINB, bool WLDS>
+__global__ __launch_bounds__(DTW_THREADS, MINB) void dtw_similarity_reg_kernel(
     const double* __restrict__ xpyr, const int32_t* __restrict__ xlen, int64_t n_x,
     const double* __restrict__ ypyr, const int32_t* __restrict__ ylen, int64_t n_y,
     float* __restrict__ out, uint64_t* __restrict__ wq, DtwLayout L, const int32_t* __restrict__ x_order)
 {
+    __shared__ int32_t s_fl[RMAX * DTW_THREADS];
+    extern __shared__ uint32_t s_words[];                    // WLDS: (max_y_len / 2) x DTW_THREADS predecessor words
+    int32_t* fl = s_fl + threadIdx.x;
+    uint32_t* wl = s_words + threadIdx.x;
     const int64_t NT = (int64_t)gridDim.x * blockDim.x;
     const int64_t tid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     const int64_t total = n_x * n_y;
@@ -641,26 +716,25 @@ __global__ __launch_bounds__(DTW_THREADS, 2) void dtw_similarity_reg_kernel(
             int lx = lx0, ly = ly0;
             while (lx >= 3 && ly >= 3) { lx >>= 1; ly >>= 1; ++n_levels; }
         }
-        int32_t fl[DTW_R];                                    // coarser path: first col | last col << 16 per row
-#pragma unroll
-        for (int q = 0; q < DTW_R; ++q) fl[q] = 0;
         double result = 0.0;
         for (int lev = n_levels - 1; lev >= 0; --lev) {
             const int lx = lx0 >> lev, ly = ly0 >> lev;
             const int lxc = lx0 >> (lev + 1), lyc = ly0 >> (lev + 1);
             const double* xcol = xpyr + L.xoff[lev] * n_x + r;
+            const double* xrcol = xcol + L.XL * n_x;                        // reciprocal pyramids follow the values
             const double* ycol = yp + L.yoff[lev];
+            const double* yrcol = ycol + L.YL * n_y;
             uint64_t* w = wq + L.yoff[lev] * NT + tid;
             const bool coarsest = lev == n_levels - 1, finest = lev == 0;
-#define DTW_LEVEL(RR) result = dtw_reg_level<RR, TIE>(fl, xcol, n_x, ycol, lx, ly, lxc, lyc, coarsest, finest, w, NT)
+#define DTW_LEVEL(RR) result = dtw_reg_level<RMAX, (RR) <= RMAX ? (RR) : RMAX, TIE, WLDS>(fl, xcol, xrcol, n_x, ycol, yrcol, lx, ly, lxc, lyc, coarsest, finest, wl, w, NT)
             if (lx <= 4) DTW_LEVEL(4);                       // narrow instantiations: the unrolled row
             else if (lx <= 8) DTW_LEVEL(8);                  // loop sweeps at most 3 empty rows
             else if (lx <= 12) DTW_LEVEL(12);
-            else if (lx <= 16) DTW_LEVEL(16);
-            else if (lx <= 20) DTW_LEVEL(20);
-            else if (lx <= 24) DTW_LEVEL(24);
-            else if (lx <= 28) DTW_LEVEL(28);
-            else DTW_LEVEL(32);
+            else if (RMAX > 12 && lx <= 16) DTW_LEVEL(16);
+            else if (RMAX > 12 && lx <= 20) DTW_LEVEL(20);
+            else if (RMAX > 20 && lx <= 24) DTW_LEVEL(24);
+            else if (RMAX > 20 && lx <= 28) DTW_LEVEL(28);
+            else if (RMAX > 20) DTW_LEVEL(32);
 #undef DTW_LEVEL
         }
         out[r * n_y + a] = (float)(1.0 / (result + 1.0));
@@ -686,29 +760,37 @@ extern "C" int sgnn_dtw_similarity(const int64_t* x_ptr, const int32_t* x_val, i
     const DtwLayout L = dtw_layout(max_x_len, max_y_len);
     hipStream_t st = (hipStream_t)stream;
     char* w = (char*)workspace;
-    int64_t lane = L.n_dbl * 8 + dtw_align8(L.n_i32 * 4) + dtw_align8(L.n_dir * 4);
-    if (L.YL * 8 > lane) lane = L.YL * 8;
+    const int64_t lane = L.n_dbl * 8 + dtw_align8(L.n_i32 * 4) + dtw_align8(L.n_dir * 4);
+    int64_t scratch = DTW_NT * lane;
+    if (DTW_REG_NT * L.YL * 8 > scratch) scratch = DTW_REG_NT * L.YL * 8;
     double* wd = (double*)w;
     int32_t* wi = (int32_t*)(w + DTW_NT * L.n_dbl * 8);
     uint32_t* wb = (uint32_t*)(w + DTW_NT * (L.n_dbl * 8 + dtw_align8(L.n_i32 * 4)));
-    uint64_t* wq = (uint64_t*)w;           w += DTW_NT * lane;
-    double* xpyr = (double*)w;             w += n_x * L.XL * 8;
-    double* ypyr = (double*)w;             w += n_y * L.YL * 8;
+    uint64_t* wq = (uint64_t*)w;           w += scratch;
+    double* xpyr = (double*)w;             w += 2 * n_x * L.XL * 8;          // values, then reciprocals of value + 1
+    double* ypyr = (double*)w;             w += 2 * n_y * L.YL * 8;
     int32_t* xlen = (int32_t*)w;           w += dtw_align8(n_x * 4);
     int32_t* ylen = (int32_t*)w;
     hipLaunchKernelGGL(dtw_pyramid_kernel, dim3(sgnn_grid_for(n_x, 256)), dim3(256), 0, st, x_ptr, x_val, n_x,
-                       max_x_len, L.XL, 1, xpyr, xlen);
+                       max_x_len, L.XL, 1, xpyr, xpyr + n_x * L.XL, xlen);
     SGNN_CHECK_LAUNCH();
     hipLaunchKernelGGL(dtw_pyramid_kernel, dim3(sgnn_grid_for(n_y, 256)), dim3(256), 0, st, y_ptr, y_val, n_y,
-                       max_y_len, L.YL, 0, ypyr, ylen);
+                       max_y_len, L.YL, 0, ypyr, ypyr + n_y * L.YL, ylen);
     SGNN_CHECK_LAUNCH();
     if (max_x_len <= DTW_R && !g_dtw_force_general) {
-        if (tie_order == 0)
-            hipLaunchKernelGGL(dtw_similarity_reg_kernel<0>, dim3(DTW_BLOCKS), dim3(DTW_THREADS), 0, st, xpyr, xlen, n_x,
-                               ypyr, ylen, n_y, out, wq, L, x_order);
-        else
-            hipLaunchKernelGGL(dtw_similarity_reg_kernel<1>, dim3(DTW_BLOCKS), dim3(DTW_THREADS), 0, st, xpyr, xlen, n_x,
-                               ypyr, ylen, n_y, out, wq, L, x_order);
+        // predecessor words of the coarse levels in LDS when (max_y_len / 2) words per lane fit
+        const int64_t words = max_y_len >> 1;
+        const bool wlds = words * DTW_THREADS * 4 <= 48 * 1024;
+        const size_t dyn = wlds ? (size_t)((words > 0 ? words : 1) * DTW_THREADS * 4) : 0;
+#define DTW_LAUNCH2(RMAX, TIE, MINB, WL) \
+        hipLaunchKernelGGL((dtw_similarity_reg_kernel<RMAX, TIE, MINB, WL>), dim3(DTW_REG_BLOCKS), dim3(DTW_THREADS), dyn, st, \
+                           xpyr, xlen, n_x, ypyr, ylen, n_y, out, wq, L, x_order)
+#define DTW_LAUNCH(RMAX, TIE, MINB) do { if (wlds) DTW_LAUNCH2(RMAX, TIE, MINB, true); else DTW_LAUNCH2(RMAX, TIE, MINB, false); } while (0)
+        if (max_x_len <= 12) { if (tie_order == 0) DTW_LAUNCH(12, 0, DTW_MINB12); else DTW_LAUNCH(12, 1, DTW_MINB12); }
+        else if (max_x_len <= 20) { if (tie_order == 0) DTW_LAUNCH(20, 0, DTW_MINB20); else DTW_LAUNCH(20, 1, DTW_MINB20); }
+        else { if (tie_order == 0) DTW_LAUNCH(32, 0, DTW_MINB32); else DTW_LAUNCH(32, 1, DTW_MINB32); }
+#undef DTW_LAUNCH2
+#undef DTW_LAUNCH
     } else {
         hipLaunchKernelGGL(dtw_similarity_kernel, dim3(DTW_BLOCKS), dim3(DTW_THREADS), 0, st, xpyr, xlen, n_x, ypyr,
                            ylen, n_y, tie_order, out, wd, wi, wb, L);

@@ -168,3 +168,18 @@ def test_tape_scalar_matches_vector():
     for a, b, x, y in zip(item, j, v, k):
         assert T.draw64(99, st, int(a), int(b)) == int(x)
         assert T.symmetric_key(99, st, int(a), int(b)) == int(y)
+
+
+def test_reciprocal_division_is_exact():
+    """The register DTW kernel divides by multiplying with a correctly rounded reciprocal plus one
+    fma correction (similarity.hip dtw_cost_rcp); on the operands it can meet that IS the IEEE
+    quotient the reference's `/` produces (gamma.py:51-52) -- checked here on the CPU, exhaustively
+    for integers up to 3000 and on 10^7 random dyadic rationals."""
+    import os
+    import subprocess
+    here = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'oracle')
+    subprocess.check_call(['make', '-s', '-C', here, '_build/division_check'])
+    out = subprocess.run([os.path.join(here, '_build', 'division_check'), '3000', '10000000'], capture_output=True,
+                         text=True)
+    assert out.returncode == 0 and 'bad 0' in out.stdout, out.stdout + out.stderr
+

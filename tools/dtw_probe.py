@@ -8,7 +8,8 @@ from subgnn_amd import ops, synthetic, tape
 n, m, S = 1_000_000, 10, 50_000
 edges = synthetic.barabasi_albert_edges(n, m, seed=42)
 rowptr, col = synthetic.sorted_csr(edges, n)
-subs = synthetic.bfs_subgraphs(rowptr, col, S, 20, seed=1000)
+NX = int(sys.argv[2]) if len(sys.argv) > 2 else 20          # nodes per subgraph = rows of the DP
+subs = synthetic.bfs_subgraphs(rowptr, col, S, NX, seed=1000)
 dev = torch.device('cuda:0')
 g = ops.DeviceGraph(rowptr, col, np.arange(1, n + 1, dtype=np.int32), dev)
 sets = ops.Ragged.from_lists(subs, dev)
@@ -18,10 +19,10 @@ ai, ae = ops.degree_sequence(g, a_sets)
 ci, ce = ops.degree_sequence(g, sets)
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 for nm, x, y in (('internal', ci, ai), ('external', ce, ae)):
-    ops.dtw_similarity(sets.ptr, x, 20, a_sets.ptr, y, 50)
+    ops.dtw_similarity(sets.ptr, x, NX, a_sets.ptr, y, 50)
     torch.cuda.synchronize()
     t = time.perf_counter()
     for _ in range(reps):
-        out = ops.dtw_similarity(sets.ptr, x, 20, a_sets.ptr, y, 50)
+        out = ops.dtw_similarity(sets.ptr, x, NX, a_sets.ptr, y, 50)
     torch.cuda.synchronize()
     print(nm, (time.perf_counter() - t) / reps * 1e3, 'ms', float(out.double().sum()))

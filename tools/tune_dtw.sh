@@ -1,9 +1,10 @@
 #!/bin/bash
-for flags in "-DDTW_BLOCKS=256" "-DDTW_BLOCKS=512" "-DDTW_BLOCKS=1024" "-DDTW_BLOCKS=2048"; do
+# Rebuild the library with different compile-time DTW settings on the GPU box and time the
+# DTW calls of tools/dtw_probe.py for 12-, 20- and 32-node subgraphs.  Usage: bash tools/tune_dtw.sh
+for flags in "-DDTW_MINB12=3 -DDTW_MINB32=2" "-DDTW_MINB12=2 -DDTW_MINB32=1" "-DDTW_MINB12=4 -DDTW_REG_BLOCKS=2048"; do
   SGNN_HIPCC_FLAGS="$flags" python -m subgnn_amd.build --force > /dev/null 2>&1
-  echo "$flags: $(python tools/dtw_probe.py 3 | tr '\n' ' ')"
+  for nx in 12 20 32; do
+    echo "$flags nx=$nx: $(python tools/dtw_probe.py 3 $nx 2>&1 | grep -v amdgpu.ids | tr '\n' ' ')"
+  done
 done
 python -m subgnn_amd.build --force > /dev/null 2>&1
-export TMPDIR=/tmp
-rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES --output-format csv -d gpurun_out/pmc_dtw3 -- python3 tools/dtw_probe.py 1 > /dev/null 2>&1
-rocprofv3 --pmc FETCH_SIZE SQ_INSTS_SMEM SQ_INSTS_BRANCH --output-format csv -d gpurun_out/pmc_dtw4 -- python3 tools/dtw_probe.py 1 > /dev/null 2>&1
