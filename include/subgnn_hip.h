@@ -100,11 +100,13 @@ int sgnn_khop_border_arena(const int64_t* rowptr, const int32_t* col, int64_t nn
                            void* workspace, int64_t workspace_bytes, int bitmap_in_lds, void* stream);
 /* a8 + a4 fused: k-hop border BFS and, without materialising the border, the neighbourhood-border
  * anchor draw of anchor_patch_samplers.sample_neighborhood_anchor_patch(sample_inside=False)
- * (anchor_patch_samplers.py:184-194) over it.  For set s and slot i: out_anchor = argmax over the
- * border of the tape variate z(s*n_slots+i, id) (order independent), out_hop = its hop level (the
- * N-border similarity, = the APSP row-min of SubGNN.py:772 on that column), out_allneg = 1 iff
- * every variate is negative -- the caller applies the PAD rule of aps:190 (PAD wins when all are
- * negative AND the padded row is longer than this border, i.e. out_count[s] < max count). */
+ * (anchor_patch_samplers.py:184-194) over it, under the neighbourhood-anchor law stated at
+ * sgnn_sample_anchors_padded.  For set s and slot i (tape item s*n_slots+i): out_anchor = the k-th
+ * smallest border id (a rank query on the visited bitmap -- no sort, no per-node hashing), out_hop =
+ * its hop level (the N-border similarity, = the APSP row-min of SubGNN.py:772 on that column),
+ * out_allneg = the item's "every variate negative" draw -- the caller applies the PAD rule of
+ * aps:190 (PAD wins when it is set AND the padded row is longer than this border, i.e.
+ * out_count[s] < max count).  An empty border yields anchor 0. */
 int sgnn_khop_border_sample(const int64_t* rowptr, const int32_t* col, int64_t nnz, int64_t max_id,
                             const int64_t* set_ptr, const int32_t* set_nodes, int64_t n_sets, int k,
                             int64_t n_slots, uint64_t seed, uint64_t stream_id,
@@ -114,21 +116,22 @@ int sgnn_khop_border_sample(const int64_t* rowptr, const int32_t* col, int64_t n
 /* ---------------------------------------------------------------------------------------
  * a4  Neighbourhood anchor sampling from padded id matrices.
  * Replaces anchor_patch_samplers.sample_neighborhood_anchor_patch (anchor_patch_samplers.py:
- * 163-198): for slot i and row r the winner is the argmax over the row of the tape variate
- * z(r*n_slots+i, id), with z := 0 on PAD entries (aps:178,190) -> PAD wins when every real
- * variate is negative and the row has a PAD entry.  ids: (n_rows, L) int64, out (n_rows, n_slots).
+ * 163-198).  The reference draws one N(0,1) variate per column, zeroes the PAD columns and takes
+ * the argmax (aps:177-179,189-191); in law: each non-PAD entry equally likely, except that PAD wins
+ * when all n real variates are negative (probability 2^-n) and the row has a PAD column.  The
+ * tape's neighbourhood-anchor law states exactly that with two draws of item r*n_slots+i:
+ *   draw 0: index (u32 * n) >> 32 into the row's non-PAD entries in ASCENDING id order;
+ *   draw 1: "every variate negative" iff n <= 32 and the top n bits of u32 are zero.
+ * ids: (n_rows, L) int64 in CANONICAL form -- non-PAD entries ascending, PADs (0) last;
+ * out (n_rows, n_slots).  (subgnn_amd.ops canonicalises arbitrary rows before the call.)
  * ------------------------------------------------------------------------------------- */
 int sgnn_sample_anchors_padded(const int64_t* ids, int64_t n_rows, int64_t L, int64_t n_slots,
                                uint64_t seed, uint64_t stream_id, int64_t* out, void* stream);
-/* same law on ragged sets; row_has_pad[r] says whether the padded row would hold a PAD.
- * out_pos (nullable, (n_sets, n_slots)): index into set_nodes of the winner, -1 for PAD --
- * lets the caller look up per-entry payloads (e.g. the hop level of a border node).
- * set_cnt (nullable, int64[n_sets]): the sets are spans -- set r = set_nodes[set_ptr[r] .. +set_cnt[r])
- * (slices of an arena, see sgnn_khop_border_arena) instead of back-to-back CSR rows. */
+/* same law on ragged sets, each ascending; row_has_pad[r] (nullable = all 1) says whether the
+ * padded row would hold a PAD. */
 int sgnn_sample_anchors_ragged(const int64_t* set_ptr, const int32_t* set_nodes, int64_t n_sets,
                                const uint8_t* row_has_pad, int64_t n_slots,
-                               uint64_t seed, uint64_t stream_id, int64_t* out, int64_t* out_pos,
-                               const int64_t* set_cnt, void* stream);
+                               uint64_t seed, uint64_t stream_id, int64_t* out, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * a5/a6  Uniform draws with replacement from a list (position anchors, structure picks).

@@ -101,14 +101,11 @@ def run(rowptr, col, subs, hp, emb, labels, n_sample, S_total):
                                          (borders[r], A_out, n_bor, T.STREAM_N_BOR, maxb)):
             if len(ids) == 0:
                 continue
-            item = (np.uint64(r) * np.uint64(A) + np.arange(A, dtype=np.uint64))[:, None]
-            keys = T.symmetric_key_np(seed, T.stream_id(kind, 'train', 0), np.broadcast_to(item, (A, len(ids))),
-                                      np.broadcast_to(ids.astype(np.uint64)[None, :], (A, len(ids))))
-            best = keys.argmax(axis=1)
-            pick = ids[best]
-            if len(ids) < width:
-                pick = np.where(keys[np.arange(A), best] < 0, 0, pick)
-            out[r] = pick
+            real = np.sort(ids)
+            st = T.stream_id(kind, 'train', 0)
+            for i in range(A):
+                k = T.nanchor_pick(seed, st, r * A + i, len(real), len(real) < width)
+                out[r, i] = 0 if k < 0 else real[k]
     p_int = IH.position_anchors_internal(sample, hp['n_anchor_patches_pos_in'], seed, 'train', 0)
     t['anchors'] = time.perf_counter() - t0
     t0 = time.perf_counter()

@@ -351,22 +351,19 @@ def perform_random_walks(G, anchor_patch_ids, n_walks, walk_len, beta, inside, s
 # ---------------------------------------------------------------------------------------
 
 def sample_neighborhood_anchors(id_matrix, n_slots, seed, stream):
-    """id_matrix: (S, C, L) padded ids (cc_ids for inside, border sets for border).
-    For slot i and row r: argmax over columns of z(r,i,id) with z := 0 on PAD columns
-    (aps:177-179 / 189-191) -> the id, or PAD when every real z < 0 and the row has padding."""
+    """id_matrix: (S, C, L) padded ids (cc_ids for inside, border sets for border), any order.
+    Slot i of row r (tape item r*n_slots+i) takes the tape's neighbourhood-anchor pick
+    (oracle/tape.py nanchor_pick) among the row's non-PAD entries in ascending order, or PAD --
+    the law of aps:177-179 / 189-191 (argmax of iid symmetric variates with PAD columns at 0)."""
     S, C, L = id_matrix.shape
     rows = id_matrix.reshape(S * C, L)
     out = np.zeros((S * C, n_slots), dtype=np.int64)
     for r in range(S * C):
-        ids = rows[r]
+        real = np.sort(rows[r][rows[r] != PAD])
+        n = len(real)
         for i in range(n_slots):
-            best_k, best_id = None, PAD
-            for c in range(L):
-                v = int(ids[c])
-                k = 0 if v == PAD else T.symmetric_key(seed, stream, r * n_slots + i, v)
-                if best_k is None or k > best_k:
-                    best_k, best_id = k, v
-            out[r, i] = best_id
+            k = T.nanchor_pick(seed, stream, r * n_slots + i, n, n < L)
+            out[r, i] = PAD if k < 0 else real[k]
     return out.reshape(S, C, n_slots)
 
 

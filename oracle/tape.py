@@ -75,45 +75,26 @@ def uniform01(seed, stream, item, j):
     return draw32(seed, stream, item, j) * (1.0 / 4294967296.0)
 
 
-def lowbias32(x):
-    """32-bit avalanche hash (two multiplies): cheap on GPUs, where 64-bit multiplies run at a
-    fraction of the 32-bit rate and this draw is evaluated for every (border node, slot) pair."""
-    x &= 0xFFFFFFFF
-    x ^= x >> 16
-    x = (x * 0x21F0AAAD) & 0xFFFFFFFF
-    x ^= x >> 15
-    x = (x * 0x735A2D97) & 0xFFFFFFFF
-    x ^= x >> 15
-    return x
+def nanchor_pick(seed, stream, item, n, has_pad):
+    """Neighbourhood-anchor law (twin of common.h sgnn_nanchor_index / sgnn_nanchor_allneg).
 
-
-def symmetric_key_from_h1(h1, j):
-    """Signed 53-bit key from the per-item state h1 (64 bits) and the node id j:
-    hi = lowbias32(j ^ lo32(h1)) as a signed 32-bit value, lo = lowbias32(j ^ hi32(h1)) >> 11."""
-    a, b = h1 & 0xFFFFFFFF, (h1 >> 32) & 0xFFFFFFFF
-    hi = lowbias32((j & 0xFFFFFFFF) ^ a)
-    lo = lowbias32((j & 0xFFFFFFFF) ^ b)
-    if hi >= (1 << 31):
-        hi -= (1 << 32)
-    return hi * (1 << 21) + (lo >> 11)
+    The reference draws one N(0,1) variate per column of the padded id row, zeroes the PAD columns
+    and takes the argmax (aps:177-179, 189-191).  In law: every non-PAD entry equally likely,
+    except that PAD wins when all n real variates are negative (probability 2**-n) and the row has
+    a PAD column.  The tape states that with two draws of the (row, slot) item:
+      draw 1: all negative  iff  n <= 32 and the top n bits of u32 are zero;
+      draw 0: index (u32 * n) >> 32 into the non-PAD entries in ASCENDING id order.
+    Returns that index, or -1 when PAD wins (n == 0 included)."""
+    if n == 0:
+        return -1
+    if has_pad and n <= 32 and (draw32(seed, stream, item, 1) >> (32 - n)) == 0:
+        return -1
+    return choice_index(seed, stream, item, 0, n)
 
 
 def item_state(seed, stream, item):
     h = mix64((seed & MASK64) ^ ((stream * K_STREAM) & MASK64))
     return mix64((h + item * K_ITEM) & MASK64)
-
-
-def symmetric_key(seed, stream, item, j):
-    """Signed 53-bit integer key k in [-2**52, 2**52); the 'randn' value is k * 2**-52.
-
-    Only the sign pattern and the argmax of the iid variates matter to
-    sample_neighborhood_anchor_patch (aps:177-179, 189-191), so any symmetric continuous
-    law gives the same distribution of sampled ids; 53-bit integers convert to float64
-    exactly, so comparing keys as integers (HIP) and as doubles (reference) agree.
-    The per-(row, slot) state comes from the 64-bit tape chain; the per-node part is two
-    32-bit hashes (see lowbias32).
-    """
-    return symmetric_key_from_h1(item_state(seed, stream, item), j)
 
 
 # ---- vectorised numpy versions (uint64 wrap-around arithmetic) -------------------------
@@ -133,25 +114,3 @@ def draw64_np(seed, stream, item, j):
         h = _mix64_np(h0 + item * np.uint64(K_ITEM))
         h = _mix64_np(h + j * np.uint64(K_DRAW))
     return h
-
-
-def _lowbias32_np(x):
-    x = x.astype(np.uint32)
-    x = x ^ (x >> np.uint32(16))
-    x = x * np.uint32(0x21F0AAAD)
-    x = x ^ (x >> np.uint32(15))
-    x = x * np.uint32(0x735A2D97)
-    return x ^ (x >> np.uint32(15))
-
-
-def symmetric_key_np(seed, stream, item, j):
-    with np.errstate(over='ignore'):
-        item = np.asarray(item).astype(np.uint64)
-        j32 = np.asarray(j).astype(np.uint64).astype(np.uint32)
-        h0 = np.uint64(mix64((seed & MASK64) ^ ((stream * K_STREAM) & MASK64)))
-        h1 = _mix64_np(h0 + item * np.uint64(K_ITEM))
-        a = (h1 & np.uint64(0xFFFFFFFF)).astype(np.uint32)
-        b = (h1 >> np.uint64(32)).astype(np.uint32)
-        hi = _lowbias32_np(j32 ^ a).view(np.int32).astype(np.int64)
-        lo = _lowbias32_np(j32 ^ b).astype(np.int64)
-    return hi * np.int64(1 << 21) + (lo >> np.int64(11))

@@ -52,47 +52,24 @@ __host__ __device__ static inline double sgnn_uniform01(uint64_t h1, uint64_t j)
     uint32_t u = (uint32_t)(sgnn_tape_draw(h1, j) >> 32);
     return (double)u * (1.0 / 4294967296.0);
 }
-// 32-bit avalanche hash (two multiplies; 64-bit multiplies run at a fraction of this rate)
-__host__ __device__ static inline uint32_t sgnn_lowbias32(uint32_t x) {
-    x ^= x >> 16; x *= 0x21F0AAADu; x ^= x >> 15; x *= 0x735A2D97u; x ^= x >> 15;
-    return x;
+// ---- neighbourhood-anchor law (a4) ------------------------------------------------------------
+// The reference draws, per (row, slot), one N(0,1) variate per column of the padded id row, zeroes
+// the PAD columns and takes the argmax (anchor_patch_samplers.py:177-179,189-191).  In law that is:
+// every non-PAD entry of the row equally likely -- except that PAD wins when all n real variates
+// are negative (probability 2^-n) and the row has a PAD column.  The tape states exactly that,
+// with two draws of the (row, slot) item instead of one variate per entry:
+//   draw 0 -> index k = (u32 * n) >> 32 into the row's non-PAD entries taken in ASCENDING id order
+//             (duplicates counted; the order in which a set was discovered never matters);
+//   draw 1 -> "every variate negative" iff n <= 32 and the top n bits of u32 are all zero.
+// O(1) per slot instead of one hash per (entry, slot): the selection becomes a rank query.
+__host__ __device__ static inline uint32_t sgnn_nanchor_index(uint64_t h1, uint32_t n) {
+    return sgnn_choice_index(h1, 0, n);
 }
-// signed 53-bit key; the reference-side 'randn' value is key * 2^-52.  h1 = per-(row, slot) state
-// from the 64-bit tape chain, j = node id: hi word = lowbias32(j ^ lo32(h1)) (signed), low 21 bits
-// from lowbias32(j ^ hi32(h1)).
-__host__ __device__ static inline int64_t sgnn_symmetric_key(uint64_t h1, uint64_t j) {
-    const uint32_t hi = sgnn_lowbias32((uint32_t)j ^ (uint32_t)h1);
-    const uint32_t lo = sgnn_lowbias32((uint32_t)j ^ (uint32_t)(h1 >> 32));
-    return (int64_t)(int32_t)hi * (int64_t)(1 << 21) + (int64_t)(lo >> 11);
+__host__ __device__ static inline bool sgnn_nanchor_allneg(uint64_t h1, uint32_t n) {   // n >= 1
+    if (n > 32) return false;
+    const uint32_t u = (uint32_t)(sgnn_tape_draw(h1, 1) >> 32);
+    return n == 32 ? (u == 0) : ((u >> (32 - n)) == 0);
 }
-
-// The key orders lexicographically by (hi word signed, low 21 bits), so a running argmax only needs
-// the second hash when the first one ties or beats the current best -- which happens O(log n) times
-// per lane over n entries.  (id 0 = PAD-as-member holds key 0.)
-__host__ __device__ static inline int32_t sgnn_key_hi(uint64_t h1, uint32_t v) {
-    return v == 0 ? 0 : (int32_t)sgnn_lowbias32(v ^ (uint32_t)h1);
-}
-__host__ __device__ static inline uint32_t sgnn_key_lo(uint64_t h1, uint32_t v) {
-    return v == 0 ? 0u : (sgnn_lowbias32(v ^ (uint32_t)(h1 >> 32)) >> 11);
-}
-__host__ __device__ static inline int64_t sgnn_key_join(int32_t hi, uint32_t lo) {
-    return (int64_t)hi * (int64_t)(1 << 21) + (int64_t)lo;
-}
-// running argmax update for one candidate (col c, id v); best_lo is valid whenever best_hi came from
-// a real candidate; ties on the full key keep the earlier column
-#define SGNN_KEY_UPDATE(h1, v, c, best_hi, best_lo, bcol, bid)                                   \
-    do {                                                                                         \
-        const int32_t _hi = sgnn_key_hi((h1), (uint32_t)(v));                                    \
-        const bool _cand = _hi >= (best_hi);                                                     \
-        if (__ballot(_cand)) {              /* wave-uniform branch: no exec-mask bookkeeping */  \
-            const uint32_t _lo = sgnn_key_lo((h1), (uint32_t)(v));                               \
-            const bool _take = _cand && (_hi > (best_hi) || _lo > (best_lo) || (bcol) == INT32_MAX); \
-            (best_hi) = _take ? _hi : (best_hi);                                                 \
-            (best_lo) = _take ? _lo : (best_lo);                                                 \
-            (bcol) = _take ? (int32_t)(c) : (bcol);                                              \
-            (bid) = _take ? (int32_t)(v) : (bid);                                                \
-        }                                                                                        \
-    } while (0)
 
 // ---- small device helpers ---------------------------------------------------------------
 __device__ static inline uint32_t sgnn_hash32(uint32_t x) { return x * 2654435761u; }
@@ -108,13 +85,3 @@ __device__ static inline bool sgnn_sorted_contains(const int32_t* __restrict__ a
     return lo < n && a[lo] == key;
 }
 
-// wave-wide argmax of (key, smallest column on ties); every lane ends with the winner
-__device__ static inline void sgnn_argmax_reduce(int64_t& key, int32_t& colv, int32_t& idv) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        const int64_t k2 = __shfl_xor(key, d);
-        const int32_t c2 = __shfl_xor(colv, d);
-        const int32_t i2 = __shfl_xor(idv, d);
-        if (k2 > key || (k2 == key && c2 < colv)) { key = k2; colv = c2; idv = i2; }
-    }
-}

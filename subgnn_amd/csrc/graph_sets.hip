@@ -89,16 +89,19 @@ extern "C" int sgnn_cc_labels(const int64_t* rowptr, const int32_t* col_sorted, 
 // lanes stream its neighbour list (coalesced), claim unseen neighbours with atomicOr on the
 // bitmap word and append them to the queue.  Every bit set is un-set on exit so the next
 // component handled by the workgroup starts clean.
-// Fused sampling: the queue of a finished component (still hot in L2) is scanned once per group
-// of 4 anchor slots; keys are hashed from (row, slot, node id), so the draw does not depend on
-// the discovery order -- the border never has to be materialised or sorted.
+// Fused sampling (neighbourhood-anchor law, common.h): a slot needs "the k-th smallest border id".
+// Once the members' bits are un-set the bitmap IS the border in ascending order, so the workgroup
+// popcounts it once (each thread a contiguous run of words, odd stride = no LDS bank conflicts),
+// prefix-sums the runs, and every slot is answered by one thread with a binary search over the
+// run prefixes plus a walk through one run -- the border is never materialised or sorted, and
+// a slot costs O(log) instead of one hash per border node.
 // ---------------------------------------------------------------------------------------------
 #define KB_THREADS_G 256
 #define KB_THREADS_L 1024
 #define KB_MAX_WG_G 1024
 #define KB_MAX_WG_L 256
-#define KB_LDS_BYTES (156 * 1024)
-#define KB_SC 8
+#define KB_LDS_BYTES (150 * 1024)      // bitmap; the rest of the 160 KB holds the rank tables of the fused draw
+#define KB_SEL_CHUNK 256                // slots answered per pass (selected ids staged in LDS for the hop lookup)
 
 static inline int64_t kb_words(int64_t max_id) { return (max_id + 32) / 32; }
 static inline bool kb_fits_lds(int64_t max_id) { return kb_words(max_id) * 4 <= KB_LDS_BYTES; }
@@ -119,51 +122,80 @@ extern "C" int64_t sgnn_khop_border_workspace_bytes(int64_t max_id, int64_t n_se
 struct KbSample {             // fused neighbourhood-border anchor draw (all NULL/0 = off)
     int64_t n_slots;
     uint64_t h0;
-    int64_t* anchor;          // (n_sets, n_slots) winning node id
+    int64_t* anchor;          // (n_sets, n_slots) chosen border node id (0 for an empty border)
     uint8_t* hop;             // (n_sets, n_slots) its hop level
-    uint8_t* allneg;          // (n_sets, n_slots) 1 if every key < 0 (PAD wins if the row is padded)
+    uint8_t* allneg;          // (n_sets, n_slots) 1 if "every variate negative" (PAD wins if the row is padded)
 };
 
-template <int SC, int NW>
-__device__ __forceinline__ void kb_draw(const KbSample& smp, int64_t s, const int32_t* __restrict__ q, int cnt, int hops,
-                                        const int32_t* s_lvl, int wave, int lane)
+// The global-memory bitmap is written with L2 atomics only; a plain load could be served from a
+// line the CU's vector L1 cached during the previous set's rank query, so read it at L2 too.
+template <bool LDS_BM>
+__device__ __forceinline__ uint32_t kb_word(const uint32_t* bm, int64_t w)
 {
-    for (int64_t s0 = (int64_t)wave * SC; s0 < smp.n_slots; s0 += (int64_t)NW * SC) {
-        uint64_t h1[SC];
-        int32_t bhi[SC], bcol[SC], bid[SC];
-        uint32_t blo[SC];
+    if (LDS_BM) return bm[w];
+    return __hip_atomic_load(bm + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// rank tables + draw over the bitmap bm[0..words) that holds exactly the cnt border nodes of set s
+template <bool LDS_BM, int THREADS>
+__device__ __forceinline__ void kb_select(const KbSample& smp, int64_t s, const uint32_t* bm, int64_t words,
+                                          const int32_t* __restrict__ q, int cnt, int hops, const int32_t* s_lvl,
+                                          int32_t* s_pref, int32_t* s_wtot, int32_t* s_sel, int tid)
+{
+    constexpr int NW = THREADS / 64;
+    const int lane = tid & 63, wave = tid >> 6;
+    // phase 1: popcount of this thread's run of words, exclusive prefix over the workgroup
+    const int64_t run = ((words + THREADS - 1) / THREADS) | 1;             // odd: conflict-free LDS strides
+    const int64_t w0 = (int64_t)tid * run;
+    const int64_t w1 = w0 + run < words ? w0 + run : words;
+    int c = 0;
+    for (int64_t w = w0; w < w1; ++w) c += __popc(kb_word<LDS_BM>(bm, w));
+    int inc = c;
 #pragma unroll
-        for (int u = 0; u < SC; ++u) {
-            h1[u] = sgnn_tape_h1(smp.h0, (uint64_t)(s * smp.n_slots + s0 + u));
-            bhi[u] = INT32_MIN; blo[u] = 0; bcol[u] = INT32_MAX; bid[u] = 0;
-        }
-        for (int c0 = lane; c0 < cnt; c0 += 256) {          // 4 independent loads in flight per lane
-            int32_t v[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) { const int c = c0 + 64 * k; v[k] = q[c < cnt ? c : cnt - 1]; }
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int c = c0 + 64 * k;
-                if (c < cnt) {
-#pragma unroll
-                    for (int u = 0; u < SC; ++u) SGNN_KEY_UPDATE(h1[u], v[k], c, bhi[u], blo[u], bcol[u], bid[u]);
-                }
+    for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(inc, d); if (lane >= d) inc += t; }
+    if (lane == 63) s_wtot[wave] = inc;
+    __syncthreads();
+    if (tid == 0) { int acc = 0; for (int w = 0; w < NW; ++w) { const int t = s_wtot[w]; s_wtot[w] = acc; acc += t; } }
+    __syncthreads();
+    s_pref[tid] = s_wtot[wave] + inc - c;
+    __syncthreads();
+    // phase 2: one thread per slot
+    for (int64_t c0 = 0; c0 < smp.n_slots; c0 += KB_SEL_CHUNK) {
+        const int64_t slot = c0 + tid;
+        if (tid < KB_SEL_CHUNK && slot < smp.n_slots) {
+            const int64_t o = s * smp.n_slots + slot;
+            int32_t id = 0;
+            uint8_t an = 1;
+            if (cnt > 0) {
+                const uint64_t h1 = sgnn_tape_h1(smp.h0, (uint64_t)o);
+                an = sgnn_nanchor_allneg(h1, (uint32_t)cnt) ? 1 : 0;
+                int rem = (int)sgnn_nanchor_index(h1, (uint32_t)cnt);
+                int lo = 0, hi = THREADS - 1;                                // largest T with s_pref[T] <= rem
+                while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (s_pref[mid] <= rem) lo = mid; else hi = mid - 1; }
+                rem -= s_pref[lo];
+                int64_t w = (int64_t)lo * run;
+                uint32_t word = kb_word<LDS_BM>(bm, w);
+                int pc = __popc(word);
+                while (rem >= pc) { rem -= pc; word = kb_word<LDS_BM>(bm, ++w); pc = __popc(word); }
+                for (int t = 0; t < rem; ++t) word &= word - 1;             // drop the rem lowest set bits
+                id = (int32_t)(w * 32 + (__ffs((int)word) - 1));
             }
+            smp.anchor[o] = (int64_t)id;
+            smp.allneg[o] = an;
+            smp.hop[o] = (uint8_t)(cnt > 0 ? 1 : 0);
+            if (hops > 1) s_sel[tid] = id;
         }
-        int64_t best[SC];
-#pragma unroll
-        for (int u = 0; u < SC; ++u) best[u] = bcol[u] == INT32_MAX ? INT64_MIN : sgnn_key_join(bhi[u], blo[u]);
-#pragma unroll
-        for (int u = 0; u < SC; ++u) {
-            sgnn_argmax_reduce(best[u], bcol[u], bid[u]);
-            if (lane == 0 && s0 + u < smp.n_slots) {
-                const int64_t o = s * smp.n_slots + s0 + u;
-                int h = 0;
-                if (cnt > 0) { h = 1; while (h < hops && bcol[u] >= s_lvl[h]) ++h; }
-                smp.anchor[o] = cnt > 0 ? (int64_t)bid[u] : 0;
-                smp.hop[o] = (uint8_t)h;
-                smp.allneg[o] = (cnt == 0 || best[u] < 0) ? 1 : 0;
+        if (hops > 1) {
+            // hop level of the chosen nodes: their position in the (unsorted) BFS queue tells it
+            __syncthreads();
+            const int ns = (int)(smp.n_slots - c0 < KB_SEL_CHUNK ? smp.n_slots - c0 : KB_SEL_CHUNK);
+            for (int i = s_lvl[1] + tid; i < cnt; i += THREADS) {            // hop-1 nodes keep the default
+                const int32_t v = q[i];
+                int h = 2;
+                while (h < hops && i >= s_lvl[h]) ++h;
+                for (int u = 0; u < ns; ++u) if (s_sel[u] == v) smp.hop[s * smp.n_slots + c0 + u] = (uint8_t)h;
             }
+            __syncthreads();
         }
     }
 }
@@ -180,6 +212,9 @@ __global__ __launch_bounds__(THREADS) void khop_border_kernel(
     extern __shared__ uint32_t s_bm[];
     __shared__ int32_t s_qn;
     __shared__ int32_t s_lvl[260];
+    __shared__ int32_t s_pref[THREADS];
+    __shared__ int32_t s_wtot[THREADS / 64];
+    __shared__ int32_t s_sel[KB_SEL_CHUNK];
     uint32_t* bm = LDS_BM ? s_bm : bitmaps + (int64_t)blockIdx.x * words;
     int32_t* q = queue_in_output ? nullptr : queues + (int64_t)blockIdx.x * (max_id + 1);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -242,20 +277,17 @@ __global__ __launch_bounds__(THREADS) void khop_border_kernel(
                 }
             }
         }
-        if (smp.n_slots > 0) {
-            // anchor draw over the queue (hot in L2): the slots are dealt to the wavefronts in groups
-            // of ceil(n_slots / waves) (<= 4 per pass), each wavefront scans the queue once per group
-            const int spw = (int)((smp.n_slots + NW - 1) / NW);
-            if (spw <= 1) kb_draw<1, NW>(smp, s, q, cnt, hops, s_lvl, wave, lane);
-            else if (spw == 2) kb_draw<2, NW>(smp, s, q, cnt, hops, s_lvl, wave, lane);
-            else if (spw == 3) kb_draw<3, NW>(smp, s, q, cnt, hops, s_lvl, wave, lane);
-            else kb_draw<4, NW>(smp, s, q, cnt, hops, s_lvl, wave, lane);
-        }
-        // un-set every bit this component touched
+        // un-set the members' bits: what is left in the bitmap is exactly the border
         for (int i = tid; i < n; i += THREADS) {
             const int32_t v = set_nodes[beg + i];
             atomicAnd(&bm[v >> 5], ~(1u << (v & 31)));
         }
+        if (smp.n_slots > 0) {
+            __syncthreads();
+            kb_select<LDS_BM, THREADS>(smp, s, bm, words, q, cnt, hops, s_lvl, s_pref, s_wtot, s_sel, tid);
+            __syncthreads();
+        }
+        // un-set every border bit so the next component handled by the workgroup starts clean
         for (int i = tid; i < cnt; i += THREADS) {
             const int32_t c = q[i];
             atomicAnd(&bm[c >> 5], ~(1u << (c & 31)));

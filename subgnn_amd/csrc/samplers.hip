@@ -2,83 +2,48 @@
 #include "common.h"
 
 // ---------------------------------------------------------------------------------------------
-// a4  neighbourhood anchors (reference SubGNN/anchor_patch_samplers.py:163-198)
-// One wavefront per row; for each slot the lanes scan the row's columns, hash (row, slot, id)
-// into a signed 53-bit key (PAD columns hold key 0), and a butterfly reduction picks the
-// maximum key, the smallest column winning ties (torch.argmax returns the first maximum).
-// VALU-bound (two 64-bit multiplies-mix rounds per element), no memory traffic beyond the ids.
+// a4  neighbourhood anchors (reference SubGNN/anchor_patch_samplers.py:163-198) under the tape's
+// neighbourhood-anchor law (common.h): per (row, slot) one index draw into the row's non-PAD
+// entries in ascending order, one "all variates negative" draw for the PAD rule.  The rows are
+// taken in canonical form -- ascending, PADs last (the host wrapper sorts; the fused border kernel
+// answers the same rank query from its visited bitmap without ever sorting) -- so a slot is O(1).
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void sample_anchors_padded_kernel(
+__global__ __launch_bounds__(256) void sample_anchors_padded_kernel(
     const int64_t* __restrict__ ids, int64_t n_rows, int64_t L, int64_t n_slots,
     uint64_t h0, int64_t* __restrict__ out)
 {
-    const int lane = threadIdx.x;
-    for (int64_t r = blockIdx.x; r < n_rows; r += gridDim.x) {
+    const int64_t total = n_rows * n_slots;
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = t / n_slots;
         const int64_t* row = ids + r * L;
-        for (int64_t i = 0; i < n_slots; ++i) {
-            const uint64_t h1 = sgnn_tape_h1(h0, (uint64_t)(r * n_slots + i));
-            int32_t bhi = INT32_MIN, bcol = INT32_MAX, bid = 0;
-            uint32_t blo = 0;
-            for (int64_t c = lane; c < L; c += 64) {
-                const int64_t v = row[c];
-                SGNN_KEY_UPDATE(h1, v, c, bhi, blo, bcol, bid);
-            }
-            int64_t best = bcol == INT32_MAX ? INT64_MIN : sgnn_key_join(bhi, blo);
-            sgnn_argmax_reduce(best, bcol, bid);
-            if (lane == 0) out[r * n_slots + i] = (L > 0) ? (int64_t)bid : 0;
+        int64_t lo = 0, hi = L;                               // n = first PAD column of the canonical row
+        while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (row[mid] != 0) lo = mid + 1; else hi = mid; }
+        const int64_t n = lo;
+        int64_t v = 0;
+        if (n > 0) {
+            const uint64_t h1 = sgnn_tape_h1(h0, (uint64_t)t);
+            if (!(n < L && sgnn_nanchor_allneg(h1, (uint32_t)n))) v = row[sgnn_nanchor_index(h1, (uint32_t)n)];
         }
+        out[t] = v;
     }
 }
 
-#define SA_SC 8               // anchor slots hashed per pass over a row
-#define SA_WAVES 1            // rows per workgroup: one, so the dispatcher balances rows of very different length
-
-__global__ __launch_bounds__(64 * SA_WAVES) void sample_anchors_ragged_kernel(
+__global__ __launch_bounds__(256) void sample_anchors_ragged_kernel(
     const int64_t* __restrict__ set_ptr, const int32_t* __restrict__ set_nodes, int64_t n_sets,
-    const uint8_t* __restrict__ row_has_pad, int64_t n_slots, uint64_t h0, int64_t* __restrict__ out,
-    int64_t* __restrict__ out_pos, const int64_t* __restrict__ set_cnt)
+    const uint8_t* __restrict__ row_has_pad, int64_t n_slots, uint64_t h0, int64_t* __restrict__ out)
 {
-    const int lane = threadIdx.x & 63;
-    for (int64_t r = (int64_t)blockIdx.x * SA_WAVES + (threadIdx.x >> 6); r < n_sets; r += (int64_t)gridDim.x * SA_WAVES) {
+    const int64_t total = n_sets * n_slots;
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = t / n_slots;
         const int64_t beg = set_ptr[r];
-        const int64_t n = set_cnt ? set_cnt[r] : set_ptr[r + 1] - beg;      // spans: (start, count)
+        const int64_t n = set_ptr[r + 1] - beg;
         const bool has_pad = row_has_pad ? (row_has_pad[r] != 0) : true;
-        for (int64_t s0 = 0; s0 < n_slots; s0 += SA_SC) {
-            uint64_t h1[SA_SC];
-            int32_t bhi[SA_SC], bcol[SA_SC], bid[SA_SC];
-            uint32_t blo[SA_SC];
-#pragma unroll
-            for (int u = 0; u < SA_SC; ++u) {
-                h1[u] = sgnn_tape_h1(h0, (uint64_t)(r * n_slots + s0 + u));
-                bhi[u] = INT32_MIN; blo[u] = 0; bcol[u] = INT32_MAX; bid[u] = 0;
-            }
-            for (int64_t c0 = lane; c0 < n; c0 += 256) {   // one read of the row per SA_SC slots, 4 loads in flight
-                int32_t v[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) { const int64_t c = c0 + 64 * k; v[k] = set_nodes[beg + (c < n ? c : n - 1)]; }
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int64_t c = c0 + 64 * k;
-                    if (c < n) {
-#pragma unroll
-                        for (int u = 0; u < SA_SC; ++u) SGNN_KEY_UPDATE(h1[u], v[k], c, bhi[u], blo[u], bcol[u], bid[u]);
-                    }
-                }
-            }
-            int64_t best[SA_SC];
-#pragma unroll
-            for (int u = 0; u < SA_SC; ++u) best[u] = bcol[u] == INT32_MAX ? INT64_MIN : sgnn_key_join(bhi[u], blo[u]);
-#pragma unroll
-            for (int u = 0; u < SA_SC; ++u) {
-                sgnn_argmax_reduce(best[u], bcol[u], bid[u]);
-                // the PAD columns of the padded row sit after the real ones with key 0
-                if (n == 0 || (has_pad && best[u] < 0)) { bid[u] = 0; bcol[u] = -1; }
-                if (lane == 0 && s0 + u < n_slots) {
-                    out[r * n_slots + s0 + u] = (int64_t)bid[u];
-                    if (out_pos) out_pos[r * n_slots + s0 + u] = (bid[u] == 0) ? -1 : beg + bcol[u];
-                }
-            }
+        int64_t v = 0;
+        if (n > 0) {
+            const uint64_t h1 = sgnn_tape_h1(h0, (uint64_t)t);
+            if (!(has_pad && sgnn_nanchor_allneg(h1, (uint32_t)n))) v = set_nodes[beg + sgnn_nanchor_index(h1, (uint32_t)n)];
         }
+        out[t] = v;
     }
 }
 
@@ -86,25 +51,23 @@ extern "C" int sgnn_sample_anchors_padded(const int64_t* ids, int64_t n_rows, in
                                           uint64_t seed, uint64_t stream_id, int64_t* out, void* stream)
 {
     if (!ids || !out || n_rows < 0 || L < 0 || n_slots < 0) return SGNN_ERR_BAD_ARG;
+    if (L >= (1ll << 32)) return SGNN_ERR_SET_TOO_LARGE;
     if (n_rows == 0 || n_slots == 0) return SGNN_OK;
-    const int grid = (int)(n_rows < 256 * 32 ? n_rows : 256 * 32);
-    hipLaunchKernelGGL(sample_anchors_padded_kernel, dim3(grid), dim3(64), 0, (hipStream_t)stream, ids, n_rows, L,
-                       n_slots, sgnn_tape_h0(seed, stream_id), out);
+    hipLaunchKernelGGL(sample_anchors_padded_kernel, dim3(sgnn_grid_for(n_rows * n_slots, 256)), dim3(256), 0,
+                       (hipStream_t)stream, ids, n_rows, L, n_slots, sgnn_tape_h0(seed, stream_id), out);
     SGNN_CHECK_LAUNCH();
     return SGNN_OK;
 }
 
 extern "C" int sgnn_sample_anchors_ragged(const int64_t* set_ptr, const int32_t* set_nodes, int64_t n_sets,
                                           const uint8_t* row_has_pad, int64_t n_slots,
-                                          uint64_t seed, uint64_t stream_id, int64_t* out, int64_t* out_pos,
-                                          const int64_t* set_cnt, void* stream)
+                                          uint64_t seed, uint64_t stream_id, int64_t* out, void* stream)
 {
     if (!set_ptr || !set_nodes || !out || n_sets < 0 || n_slots < 0) return SGNN_ERR_BAD_ARG;
     if (n_sets == 0 || n_slots == 0) return SGNN_OK;
-    const int64_t want = (n_sets + SA_WAVES - 1) / SA_WAVES;
-    const int grid = (int)(want < (1 << 20) ? want : (1 << 20));
-    hipLaunchKernelGGL(sample_anchors_ragged_kernel, dim3(grid), dim3(64 * SA_WAVES), 0, (hipStream_t)stream, set_ptr,
-                       set_nodes, n_sets, row_has_pad, n_slots, sgnn_tape_h0(seed, stream_id), out, out_pos, set_cnt);
+    hipLaunchKernelGGL(sample_anchors_ragged_kernel, dim3(sgnn_grid_for(n_sets * n_slots, 256)), dim3(256), 0,
+                       (hipStream_t)stream, set_ptr, set_nodes, n_sets, row_has_pad, n_slots,
+                       sgnn_tape_h0(seed, stream_id), out);
     SGNN_CHECK_LAUNCH();
     return SGNN_OK;
 }

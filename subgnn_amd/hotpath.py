@@ -145,12 +145,15 @@ def prepare_sparse(model, split='train', timer=None):
     if hp['use_neighborhood']:
         k = hp['neigh_sample_border_size']
         has_pad_c = (cc_sets.lengths < Lc).to(torch.uint8)
+        cc_canon = ops.sort_ragged(cc_sets)                     # the draw ranks the ascending members
         ni, nb = {}, {}
         for l in range(L):
-            ni[l] = ops.sample_anchors_ragged(cc_sets, hp['n_anchor_patches_N_in'], seed,
-                                              tape.stream_id(tape.STREAM_N_INT, split, l), has_pad_c).view(S, C, -1)
+            ni[l] = ops.sample_anchors_ragged(cc_canon, hp['n_anchor_patches_N_in'], seed,
+                                              tape.stream_id(tape.STREAM_N_INT, split, l), has_pad_c,
+                                              canonical=True).view(S, C, -1)
             sims[('N', 'in', l)] = torch.zeros(ni[l].shape, dtype=torch.float32, device=dev)
-            # border BFS fused with the border-anchor draw: the border is never materialised
+            # border BFS fused with the border-anchor draw (rank query on the visited bitmap): the
+            # border is never materialised
             a, w, _ = ops.khop_border_sample(g, cc_sets, k, hp['n_anchor_patches_N_out'], seed,
                                              tape.stream_id(tape.STREAM_N_BOR, split, l))
             nb[l] = a.view(S, C, -1)

@@ -166,15 +166,19 @@ _KHOP_WS = {}
 
 
 def _khop_ws(lib, g, n_sets, lds):
-    """Workspace of the border BFS, kept across calls (the kernel leaves the bitmaps zeroed, so the
-    buffer is zero-filled once when it is created; the LDS variant needs no initialisation)."""
+    """Workspace of the border BFS, kept across calls with the same layout (the kernel leaves the
+    bitmaps zeroed, so the buffer is zero-filled once when it is created; the LDS variant needs no
+    initialisation).  The layout -- per-workgroup bitmaps first, then the queues -- depends on the
+    graph size and the workgroup count, and a queue region is not zero: a call with another
+    layout gets a fresh buffer."""
     ws_bytes = lib.sgnn_khop_border_workspace_bytes(g.max_id, n_sets, 1 if lds else 0)
     key = (str(g.device), bool(lds))
-    buf = _KHOP_WS.get(key)
-    if buf is None or buf.numel() * 4 < ws_bytes:
-        buf = torch.zeros(ws_bytes // 4 + 1, dtype=torch.int32, device=g.device)
-        _KHOP_WS[key] = buf
-    return buf, ws_bytes
+    layout = (int(g.max_id), int(ws_bytes))
+    hit = _KHOP_WS.get(key)
+    if hit is None or hit[0] != layout:
+        hit = (layout, torch.zeros(ws_bytes // 4 + 1, dtype=torch.int32, device=g.device))
+        _KHOP_WS[key] = hit
+    return hit[1], ws_bytes
 
 
 def khop_border(g, sets, k, ego_dict_mode=False, want_hops=False, bitmap_in_lds=None):
@@ -198,38 +202,38 @@ def khop_border(g, sets, k, ego_dict_mode=False, want_hops=False, bitmap_in_lds=
     return (r, hops) if want_hops else r
 
 
-def khop_border_sample(g, sets, k, n_slots, seed, stream_id, bitmap_in_lds=None, one_pass=None):
+def khop_border_one_pass(g, sets, bitmap_in_lds=None):
+    """1-hop borders written by the BFS itself into slices of one arena sized by the bound
+    sum of the members' degrees (no count pass).  Returns (arena int32, slice offsets int64[n+1],
+    counts int64[n]): set s = arena[off[s] : off[s] + counts[s]], discovery order."""
+    lib = _lib.load()
+    lds = bool(lib.sgnn_khop_border_bitmap_fits_lds(g.max_id)) if bitmap_in_lds is None else bool(bitmap_in_lds)
+    ws, ws_bytes = _khop_ws(lib, g, sets.n, lds)
+    counts = torch.zeros(sets.n, dtype=torch.int64, device=g.device)
+    tot = int(sets.ptr[-1].item())
+    deg = (g.rowptr[1:] - g.rowptr[:-1])[sets.nodes[:tot].long()]
+    csum = torch.zeros(tot + 1, dtype=torch.int64, device=g.device)
+    torch.cumsum(deg, 0, out=csum[1:])
+    bound = csum[sets.ptr[1:]] - csum[sets.ptr[:-1]]                      # capacity of each slice
+    off = torch.zeros(sets.n + 1, dtype=torch.int64, device=g.device)
+    torch.cumsum(bound, 0, out=off[1:])
+    arena = torch.empty(max(int(off[-1].item()), 1), dtype=torch.int32, device=g.device)
+    check(lib.sgnn_khop_border_arena(_ptr(g.rowptr), _ptr(g.col), g.nnz, g.max_id, _ptr(sets.ptr), _ptr(sets.nodes),
+                                     sets.n, 1, _ptr(off), _ptr(arena), _ptr(counts), _ptr(ws), ws_bytes,
+                                     1 if lds else 0, _stream()), 'sgnn_khop_border_arena')
+    return arena, off, counts
+
+
+def khop_border_sample(g, sets, k, n_slots, seed, stream_id, bitmap_in_lds=None):
     """k-hop border BFS + neighbourhood-border anchor draw without a padded border matrix.  Returns
     anchors (n_sets, n_slots) int64 with the reference's PAD rule applied, their hop levels as
-    float32 similarities (0 on PAD) and the border sizes.
-
-    k = 1 (``one_pass``): the BFS writes every border straight into its slice of an arena sized by
-    the bound  sum of the members' degrees  (no count pass), and the draw is a separate
-    full-occupancy kernel over those spans.  k > 1: one fused kernel draws from the BFS queue while
-    it is hot in L2 (the border is never materialised)."""
+    float32 similarities (0 on PAD) and the border sizes.  One fused kernel: the draw is a rank
+    query on the BFS's visited bitmap (the border is never materialised or sorted)."""
     lib = _lib.load()
     lds = bool(lib.sgnn_khop_border_bitmap_fits_lds(g.max_id)) if bitmap_in_lds is None else bool(bitmap_in_lds)
     ws, ws_bytes = _khop_ws(lib, g, sets.n, lds)
     counts = torch.zeros(sets.n, dtype=torch.int64, device=g.device)
     anchor = torch.empty((sets.n, n_slots), dtype=torch.int64, device=g.device)
-    one_pass = (k == 1) if one_pass is None else (one_pass and k == 1)
-    if one_pass:
-        tot = int(sets.ptr[-1].item())
-        deg = (g.rowptr[1:] - g.rowptr[:-1])[sets.nodes[:tot].long()]
-        csum = torch.zeros(tot + 1, dtype=torch.int64, device=g.device)
-        torch.cumsum(deg, 0, out=csum[1:])
-        bound = csum[sets.ptr[1:]] - csum[sets.ptr[:-1]]                  # capacity of each slice
-        off = torch.zeros(sets.n + 1, dtype=torch.int64, device=g.device)
-        torch.cumsum(bound, 0, out=off[1:])
-        arena = torch.empty(max(int(off[-1].item()), 1), dtype=torch.int32, device=g.device)
-        check(lib.sgnn_khop_border_arena(_ptr(g.rowptr), _ptr(g.col), g.nnz, g.max_id, _ptr(sets.ptr), _ptr(sets.nodes),
-                                         sets.n, 1, _ptr(off), _ptr(arena), _ptr(counts), _ptr(ws), ws_bytes,
-                                         1 if lds else 0, _stream()), 'sgnn_khop_border_arena')
-        has_pad = (counts < counts.max()).to(torch.uint8)
-        check(lib.sgnn_sample_anchors_ragged(_ptr(off), _ptr(arena), sets.n, _ptr(has_pad), n_slots, seed, stream_id,
-                                             _ptr(anchor), None, _ptr(counts), _stream()), 'sgnn_sample_anchors_ragged')
-        sims = (anchor != 0).to(torch.float32)                              # every 1-hop border node is at hop 1
-        return anchor, sims, counts
     hop = torch.empty((sets.n, n_slots), dtype=torch.uint8, device=g.device)
     allneg = torch.empty((sets.n, n_slots), dtype=torch.uint8, device=g.device)
     check(lib.sgnn_khop_border_sample(_ptr(g.rowptr), _ptr(g.col), g.nnz, g.max_id, _ptr(sets.ptr), _ptr(sets.nodes),
@@ -260,25 +264,38 @@ def sort_ragged(r, extra=None):
     return out
 
 
-def sample_anchors_padded(ids, n_slots, seed, stream_id):
-    """sample_neighborhood_anchor_patch on a padded (rows, L) id matrix -> (rows, n_slots)."""
+def canonical_rows(ids):
+    """Padded id rows in the canonical form of the neighbourhood-anchor law: non-PAD entries
+    ascending, PADs last."""
+    big = torch.iinfo(torch.int64).max
+    srt = torch.sort(torch.where(ids == 0, torch.full_like(ids, big), ids), dim=1).values
+    return torch.where(srt == big, torch.zeros_like(srt), srt).contiguous()
+
+
+def sample_anchors_padded(ids, n_slots, seed, stream_id, canonical=False):
+    """sample_neighborhood_anchor_patch on a padded (rows, L) id matrix -> (rows, n_slots).
+    ``canonical``: the rows are already ascending with PADs last."""
     lib = _lib.load()
     _req(ids, torch.int64, 'ids')
     rows, L = ids.shape
+    if not canonical and rows * L > 0:
+        ids = canonical_rows(ids)
     out = torch.empty((rows, n_slots), dtype=torch.int64, device=ids.device)
     check(lib.sgnn_sample_anchors_padded(_ptr(ids), rows, L, n_slots, seed, stream_id, _ptr(out), _stream()),
           'sgnn_sample_anchors_padded')
     return out
 
 
-def sample_anchors_ragged(sets, n_slots, seed, stream_id, row_has_pad=None, want_pos=False):
+def sample_anchors_ragged(sets, n_slots, seed, stream_id, row_has_pad=None, canonical=False):
+    """Same draw on ragged sets (``canonical``: every set is already ascending)."""
     lib = _lib.load()
     _req(row_has_pad, torch.uint8, 'row_has_pad')
+    if not canonical:
+        sets = sort_ragged(sets)
     out = torch.empty((sets.n, n_slots), dtype=torch.int64, device=sets.ptr.device)
-    pos = torch.empty((sets.n, n_slots), dtype=torch.int64, device=sets.ptr.device) if want_pos else None
     check(lib.sgnn_sample_anchors_ragged(_ptr(sets.ptr), _ptr(sets.nodes), sets.n, _ptr(row_has_pad), n_slots, seed,
-                                         stream_id, _ptr(out), _ptr(pos), None, _stream()), 'sgnn_sample_anchors_ragged')
-    return (out, pos) if want_pos else out
+                                         stream_id, _ptr(out), _stream()), 'sgnn_sample_anchors_ragged')
+    return out
 
 
 def choice_ragged(sets, n_draws, seed, stream_id):

@@ -3,7 +3,8 @@
 Randomness in the sampling kernels is a pure function  draw64(seed, stream, item, j):
 ``seed`` the run seed, ``stream`` which sampler / split / layer is drawing, ``item`` the
 independent unit (walk number, row * slots + slot, subgraph number), ``j`` that unit's own
-draw counter (for the neighbourhood anchors: the node id).  It replaces the three global
+draw counter (the neighbourhood anchors use two: draw 0 = rank of the pick among the row's
+ascending entries, draw 1 = the "every variate negative" event of the PAD rule).  It replaces the three global
 serial RNG streams of the reference (anchor_patch_samplers.py:70-106,177,189,206-222,326),
 which cannot be consumed in parallel; see DESIGN.md "Draw tape".
 """

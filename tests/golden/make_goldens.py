@@ -124,14 +124,22 @@ class _PyRandomShim:
 
 class _TorchShim:
     def randn(self, shape):
+        """One 'randn' matrix per anchor slot (aps:177,189).  Only the argmax after the reference
+        zeroes the PAD columns matters, so the matrix holds +1 at the column of the entry the tape's
+        neighbourhood-anchor law picks for (row, slot) and -1 elsewhere (all -1 = every variate
+        negative = PAD wins on a padded row)."""
         ids = CTX.rand_matrix
         assert tuple(shape) == tuple(ids.shape)
         R, L = ids.shape
-        rows = np.repeat(np.arange(R, dtype=np.uint64), L)
-        item = rows * np.uint64(CTX.rand_slots) + np.uint64(CTX.rand_slot)
-        keys = T.symmetric_key_np(CTX.seed, CTX.rand_stream, item, ids.reshape(-1).astype(np.uint64))
+        z = -np.ones((R, L), dtype=np.float64)
+        for r in range(R):
+            cols = np.nonzero(ids[r])[0]
+            order = cols[np.argsort(ids[r][cols], kind='stable')]      # columns by ascending id
+            k = T.nanchor_pick(CTX.seed, CTX.rand_stream, r * CTX.rand_slots + CTX.rand_slot, len(cols), len(cols) < L)
+            if k >= 0:
+                z[r, order[k]] = 1.0
         CTX.rand_slot += 1
-        return torch.from_numpy((keys.astype(np.float64) * 2.0 ** -52).reshape(R, L))
+        return torch.from_numpy(z)
 
     def __getattr__(self, k):
         return getattr(torch, k)

@@ -176,6 +176,22 @@ def test_khop_border_workspace_left_clean():
 
 
 @pytest.mark.parametrize('lds', [True, False])
+def test_khop_border_one_pass_arena(lds):
+    """The arena variant (BFS queue = caller's slice) materialises the same 1-hop borders."""
+    ops = _ops()
+    G = _rand_graph(400, 3, 21)
+    dg = _dev_graph(G)
+    rng = np.random.default_rng(8)
+    sets = [list({int(v) for v in rng.integers(1, G.max_id() + 1, int(rng.integers(1, 6)))}) for _ in range(900)]
+    r = ops.Ragged.from_lists(sets, DEV)
+    arena, off, counts = ops.khop_border_one_pass(dg, r, bitmap_in_lds=lds)
+    ref = ops.sort_ragged(ops.khop_border(dg, r, 1, bitmap_in_lds=lds)).to_lists()
+    a, o, c = arena.cpu().numpy(), off.cpu().numpy(), counts.cpu().numpy()
+    for i in range(900):
+        assert sorted(a[o[i]:o[i] + c[i]].tolist()) == ref[i]
+
+
+@pytest.mark.parametrize('lds', [True, False])
 @pytest.mark.parametrize('k', [1, 2])
 def test_khop_border_sample_equals_materialised_draw(k, lds):
     """Fused BFS + anchor draw == (materialise the border, pad it, run the reference-shaped
@@ -189,9 +205,6 @@ def test_khop_border_sample_equals_materialised_draw(k, lds):
     r = ops.Ragged.from_lists(sets, DEV)
     A, seed, st = 7, 99, T.stream_id(T.STREAM_N_BOR, 'val', 1)
     anchors, sims, counts = ops.khop_border_sample(dg, r, k, A, seed, st, bitmap_in_lds=lds)
-    if k == 1:       # one-pass arena path (default for k = 1) and the fused path must agree
-        a2, s2, c2 = ops.khop_border_sample(dg, r, k, A, seed, st, bitmap_in_lds=lds, one_pass=False)
-        assert torch.equal(anchors, a2) and torch.equal(sims, s2) and torch.equal(counts, c2)
     b, hops = ops.sort_ragged(*ops.khop_border(dg, r, k, want_hops=True))
     padded = b.to_padded()
     ref = ops.sample_anchors_padded(padded, A, seed, st)
@@ -204,6 +217,39 @@ def test_khop_border_sample_equals_materialised_draw(k, lds):
         for a in range(A):
             assert sm[i, a] == (lev[an[i, a]] if an[i, a] != 0 else 0)
     assert (an == 0).any()          # the PAD rule fires on small borders
+    # and against the oracle (ascending border, tape pick) for a sample of rows
+    mx = int(counts.max())
+    for i in range(0, 700, 29):
+        real = sorted(bl[i])
+        for a in range(A):
+            kk = T.nanchor_pick(seed, st, i * A + a, len(real), len(real) < mx)
+            assert an[i, a] == (0 if kk < 0 else real[kk])
+
+
+def test_khop_border_sample_large_border_rank_query():
+    """Hubs: borders of thousands of nodes spread over the whole id range, many anchor slots (more
+    than one 256-slot pass) -- every drawn anchor is the tape-ranked element of the sorted border."""
+    from subgnn_amd import synthetic
+    ops = _ops()
+    n = 40000
+    rowptr, col = synthetic.sorted_csr(synthetic.barabasi_albert_edges(n, 8, seed=3), n)
+    dg = ops.DeviceGraph(rowptr, col, np.arange(1, n + 1, dtype=np.int32), DEV)
+    sets = synthetic.bfs_subgraphs(rowptr, col, 300, 12, seed=5)
+    r = ops.Ragged.from_lists(sets, DEV)
+    A, seed, st = 300, 7, T.stream_id(T.STREAM_N_BOR, 'train', 0)
+    for lds in (True, False):
+        for k in (1, 2):
+            anchors, sims, counts = ops.khop_border_sample(dg, r, k, A, seed, st, bitmap_in_lds=lds)
+            b, hops = ops.sort_ragged(*ops.khop_border(dg, r, k, want_hops=True))
+            assert torch.equal(counts, b.lengths)
+            bl, hl = b.to_lists(), ops.Ragged(b.ptr, hops.to(torch.int32)).to_lists()
+            an, sm, mx = anchors.cpu().numpy(), sims.cpu().numpy(), int(counts.max())
+            for i in range(0, 300, 17):
+                lev = dict(zip(bl[i], hl[i]))
+                for a in range(0, A, 7):
+                    kk = T.nanchor_pick(seed, st, i * A + a, len(bl[i]), len(bl[i]) < mx)
+                    assert an[i, a] == (0 if kk < 0 else bl[i][kk])
+                    assert sm[i, a] == (lev[an[i, a]] if an[i, a] != 0 else 0)
 
 
 # ---- a4 neighbourhood anchors -------------------------------------------------------------
@@ -228,7 +274,7 @@ def test_sample_anchors_golden(golden):
 
 
 def test_sample_anchors_order_independent():
-    """keys are tied to node ids, not to columns: permuting a row leaves the sample unchanged."""
+    """the pick is a rank among the ascending entries: permuting a row leaves the sample unchanged."""
     ops = _ops()
     rng = np.random.default_rng(3)
     ids = np.zeros((50, 40), dtype=np.int64)

@@ -164,10 +164,28 @@ def test_tape_scalar_matches_vector():
     j = np.tile(np.arange(5), 7)
     st = T.stream_id(T.STREAM_N_BOR, 'val', 3)
     v = T.draw64_np(99, st, item, j)
-    k = T.symmetric_key_np(99, st, item, j)
-    for a, b, x, y in zip(item, j, v, k):
+    for a, b, x in zip(item, j, v):
         assert T.draw64(99, st, int(a), int(b)) == int(x)
-        assert T.symmetric_key(99, st, int(a), int(b)) == int(y)
+
+
+def test_neighbourhood_anchor_law():
+    """The two-draw law has the distribution of the reference's argmax over iid symmetric variates
+    with PAD columns at 0: PAD with probability 2**-n on padded rows, else uniform over the entries."""
+    st = T.stream_id(T.STREAM_N_INT, 'train', 0)
+    assert T.nanchor_pick(5, st, 0, 0, True) == -1 and T.nanchor_pick(5, st, 0, 0, False) == -1
+    for n in (1, 2, 3):
+        picks = np.array([T.nanchor_pick(5, st, i, n, True) for i in range(20000)])
+        assert abs((picks == -1).mean() - 2.0 ** -n) < 0.015
+        for k in range(n):
+            assert abs((picks == k).mean() - (1 - 2.0 ** -n) / n) < 0.015
+        assert (np.array([T.nanchor_pick(5, st, i, n, False) for i in range(2000)]) >= 0).all()
+    big = np.array([T.nanchor_pick(5, st, i, 1000, True) for i in range(5000)])
+    assert big.min() >= 0 and big.max() < 1000 and abs(big.mean() - 499.5) < 15
+    # the pick is defined on the ascending order of the entries: the oracle ignores the row order
+    m = np.array([[[9, 4, 7, 0, 0]], [[3, 0, 0, 0, 0]]])
+    a = IH.sample_neighborhood_anchors(m, 6, 11, st)
+    b = IH.sample_neighborhood_anchors(m[:, :, [2, 0, 1, 3, 4]], 6, 11, st)
+    assert np.array_equal(a, b) and set(a[0, 0]) <= {0, 4, 7, 9} and set(a[1, 0]) <= {0, 3}
 
 
 def test_reciprocal_division_is_exact():

@@ -29,7 +29,6 @@ def count_only(lds):
 print('BFS count-only, LDS bitmap', timeit(lambda: count_only(True)))
 print('BFS count-only, global bitmap', timeit(lambda: count_only(False)))
 for A in (4, 16, 43):
-    print('BFS + draw, %d slots fused' % A, timeit(lambda: ops.khop_border_sample(g, sets, 1, A, 0, 77, one_pass=False)))
-    print('BFS + draw, %d slots arena' % A, timeit(lambda: ops.khop_border_sample(g, sets, 1, A, 0, 77, one_pass=True)))
+    print('BFS + draw (bitmap rank query), %d slots' % A, timeit(lambda: ops.khop_border_sample(g, sets, 1, A, 0, 77)))
 c = count_only(True)
 print('border entries total', int(c.sum()), 'mean', float(c.float().mean()), 'max', int(c.max()))
