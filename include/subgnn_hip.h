@@ -50,10 +50,12 @@ const char* sgnn_last_error(void);
  *   external[i] = full_degree[id] - internal[i]; full_degree == NULL -> degree from the CSR
  * One entry per listed node (duplicates kept); if `sorted`, each set's entries are written
  * in ascending order (gamma.py:35,48).  out_external may be NULL.
+ * self_loops (nullable): uint8[max_id + 1], number of self-loop entries in each node's CSR row;
+ * when given, the kernel does not have to test every streamed neighbour against the row's owner.
  * max_set_size: upper bound on set length known to the caller (0 = unknown).
  * ------------------------------------------------------------------------------------- */
 int sgnn_degree_sequence(const int64_t* rowptr, const int32_t* col, int64_t nnz,
-                         const int32_t* full_degree,
+                         const int32_t* full_degree, const uint8_t* self_loops,
                          const int64_t* set_ptr, const int32_t* set_nodes, int64_t n_sets,
                          int64_t max_set_size, int sorted,
                          int32_t* out_internal, int32_t* out_external, void* stream);

@@ -29,7 +29,8 @@ class MpnArgs(ctypes.Structure):
 SIGNATURES = {
     'sgnn_abi_version': (c_int, []),
     'sgnn_last_error': (ctypes.c_char_p, []),
-    'sgnn_degree_sequence': (c_int, [c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_int, c_ptr, c_ptr, c_ptr]),
+    'sgnn_degree_sequence': (c_int, [c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_int, c_ptr, c_ptr,
+                                     c_ptr]),
     'sgnn_cc_labels': (c_int, [c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_ptr, c_ptr]),
     'sgnn_khop_border_workspace_bytes': (c_i64, [c_i64, c_i64, c_int]),
     'sgnn_khop_border_bitmap_fits_lds': (c_int, [c_i64]),

@@ -4,8 +4,9 @@
 // HBM-bound: per set S the algorithmic traffic is  sum_{v in S} (16 + 4 deg(v)) + 8 |S|  bytes
 // (rowptr pair, neighbour list, id in, two degrees out).  Design:
 //   * one 64-lane wavefront per set (|S| <= 64; the common case: CCs and walk patches);
-//     lane i owns member i: loads its id and rowptr pair, inserts the id into a 128-slot
-//     open-addressing hash in LDS (the set's membership structure);
+//     lane i owns member i: loads its id and rowptr pair, inserts the id into a 1024-slot table
+//     in LDS (the set's membership structure; collision-free under one of four multipliers, so a
+//     lookup is a single slot read);
 //   * members with >= 64 neighbours (which carry most of the bytes on scale-free graphs) are
 //     streamed one list at a time with eight coalesced 256 B loads in flight and a wave
 //     sum at the end; the neighbour lists of the other members are streamed as ONE flat range
@@ -19,22 +20,36 @@
 //     atomics, LDS bitonic sort).
 #include "common.h"
 
-#define DS_HASH_BITS 8
+#define DS_HASH_BITS 10
 #define DS_HASH (1 << DS_HASH_BITS)
+#define DS_TRIES 4
 
 #ifndef DS_BIG
 #define DS_BIG 64
 #endif
 //           // members with at least this many neighbours are streamed on their own
 
-// Membership probe with a wave-uniform probe count: the insert phase records the longest probe
-// chain of the set (P, usually 1-2 at <= 25 % load), and every lookup reads exactly P slots with
-// no data-dependent exit -- divergent loops cost scalar (exec-mask) instructions, and the CU's
-// single scalar unit was the measured bottleneck of the first version of this kernel.
-__device__ static inline int ds_probe(const int32_t* hash, int32_t u, int P) {
-    const uint32_t h = sgnn_hash32((uint32_t)u) >> (32 - DS_HASH_BITS);
+// Membership structure of a set: a 1024-slot table in LDS, one per wavefront.  The slot of an id
+// is the top 10 bits of a 24 x 24-bit product (v_mul_u32_u24 issues at full rate; the 32-bit
+// multiply at a quarter of it -- and this hash is evaluated once per streamed neighbour).  The
+// insert phase tries up to four multipliers until the <= 64 members land in distinct slots
+// (83 % per try for 20 members), so a lookup is ONE slot read with no probe loop; if every try
+// collides the table falls back to linear probing with a wave-uniform probe count P (no
+// data-dependent exit: divergent loops cost scalar instructions, and the CU's single scalar unit
+// was the measured bottleneck of the first version of this kernel).
+__device__ static const uint32_t ds_mult[DS_TRIES] = {0x9E3779u | 1u, 0x85EBCBu, 0xC2B2AFu, 0x27D4EBu};
+
+__device__ __forceinline__ uint32_t ds_slot4(int32_t u, uint32_t k24) {
+    // byte offset of the slot: bits [31:22] of the product, already scaled by 4
+    return (__umul24((uint32_t)u & 0xFFFFFFu, k24) >> (32 - DS_HASH_BITS - 2)) & ((DS_HASH - 1) << 2);
+}
+template <bool P1>
+__device__ __forceinline__ int ds_probe(const int32_t* hash, int32_t u, uint32_t k24, int P) {
+    const uint32_t o = ds_slot4(u, k24);
+    const char* base = reinterpret_cast<const char*>(hash);
+    if (P1) return *reinterpret_cast<const int32_t*>(base + o) == u;
     int hit = 0;
-    for (int p = 0; p < P; ++p) hit |= (hash[(h + p) & (DS_HASH - 1)] == u);
+    for (int p = 0; p < P; ++p) hit |= (*reinterpret_cast<const int32_t*>(base + ((o + 4 * p) & ((DS_HASH - 1) << 2))) == u);
     return hit;
 }
 
@@ -48,10 +63,93 @@ __device__ static inline int32_t ds_wave_sum(int32_t v) {
 #define DS_WAVES 1             // wavefronts (= sets) per workgroup; 1 measured best (finest dispatch granularity)
 #endif
 
+// hits of every member's neighbour list in the set's table -> cnt (per lane = per member); SELF:
+// count the self-loop entries of each list here (the caller has no per-node self-loop table)
+template <bool P1, bool SELF>
+__device__ __forceinline__ void ds_count(const int32_t* __restrict__ col, const int32_t* hash, uint32_t k24, int P,
+                                         int lane, int32_t v, int32_t deg, uint32_t r0, int32_t& cnt, int32_t& selfc)
+{
+    // ---- phase A: members with >= 64 neighbours, one list at a time, 8 coalesced 256 B loads in flight ----
+    uint64_t big = __ballot(deg >= DS_BIG);
+    while (big) {
+        const int m = __ffsll((unsigned long long)big) - 1;
+        big &= big - 1;
+        const int32_t m_v = __shfl(v, m), m_deg = __shfl(deg, m);
+        const int32_t* __restrict__ list = col + __shfl(r0, m);
+        int32_t local = 0, selfl = 0;
+        int32_t base = 0;
+        for (; base + 512 <= m_deg; base += 512) {       // full blocks: 8 x 256 B loads in flight
+            int32_t u[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) u[q] = list[base + q * 64 + lane];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { local += ds_probe<P1>(hash, u[q], k24, P); if (SELF) selfl += (u[q] == m_v); }
+        }
+        if (base < m_deg) {                              // tail (< 512 entries): clamped loads,
+            const int32_t last = m_deg - 1;              // out-of-range lanes get the never-stored key -1
+            int32_t u[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int32_t i = base + q * 64 + lane;
+                u[q] = list[i < last ? i : last];
+                u[q] = i <= last ? u[q] : -1;
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                if (base + q * 64 < m_deg) { local += ds_probe<P1>(hash, u[q], k24, P); if (SELF) selfl += (u[q] == m_v); }   // wave-uniform
+        }
+        const int32_t st = SELF ? ds_wave_sum(selfl) : 0;
+        const int32_t tot = ds_wave_sum(local);
+        if (lane == m) { cnt = tot; if (SELF) selfc = st; }
+    }
+    // ---- phase B: the remaining lists as one flat range, 128 entries per step ------------
+    const int32_t sdeg = deg >= DS_BIG ? 0 : deg;
+    int32_t incl = sdeg;                                 // inclusive scan over the wave
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int32_t t = __shfl_up(incl, d);
+        if (lane >= d) incl += t;
+    }
+    const int32_t total = __shfl(incl, 63);
+    const int32_t excl = incl - sdeg;
+    for (int32_t base = 0; base < total; base += 128) {
+        int32_t u[2], mv[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int32_t t = base + q * 64 + lane;
+            int lo = 0, hi = 63;                         // smallest m with incl[m] > t
+#pragma unroll
+            for (int it = 0; it < 6; ++it) {
+                const int mid = (lo + hi) >> 1;
+                const int32_t x = __shfl(incl, mid);
+                if (x > t) hi = mid; else lo = mid + 1;
+            }
+            const int m = lo & 63;
+            const int32_t m_excl = __shfl(excl, m);
+            const uint32_t m_r0 = __shfl(r0, m);
+            mv[q] = __shfl(v, m);
+            u[q] = t < total ? col[m_r0 + (uint32_t)(t - m_excl)] : -1;
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const uint64_t mh = __ballot(ds_probe<P1>(hash, u[q], k24, P) != 0);
+            const int32_t b0 = base + q * 64;
+            int32_t lo_i = excl - b0, hi_i = incl - b0;  // this lane's member range in the step
+            lo_i = lo_i < 0 ? 0 : (lo_i > 64 ? 64 : lo_i);
+            hi_i = hi_i < 0 ? 0 : (hi_i > 64 ? 64 : hi_i);
+            const uint64_t below_hi = hi_i >= 64 ? ~0ull : ((1ull << hi_i) - 1ull);
+            const uint64_t below_lo = lo_i >= 64 ? ~0ull : ((1ull << lo_i) - 1ull);
+            const uint64_t rm = below_hi & ~below_lo;
+            cnt += __popcll(mh & rm);
+            if (SELF) selfc += __popcll(__ballot(u[q] == mv[q]) & rm);
+        }
+    }
+}
+
 template <bool SORTED>
 __global__ __launch_bounds__(64 * DS_WAVES) void degseq_wave_kernel(
     const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
-    const int32_t* __restrict__ full_degree,
+    const int32_t* __restrict__ full_degree, const uint8_t* __restrict__ self_loops,
     const int64_t* __restrict__ set_ptr, const int32_t* __restrict__ set_nodes, int64_t n_sets,
     int32_t* __restrict__ out_int, int32_t* __restrict__ out_ext)
 {
@@ -64,113 +162,53 @@ __global__ __launch_bounds__(64 * DS_WAVES) void degseq_wave_kernel(
         const int64_t beg = set_ptr[s];
         const int n = (int)(set_ptr[s + 1] - beg);
         if (n <= 0 || n > 64) continue;                     // wave-uniform
-#pragma unroll
-        for (int q = 0; q < DS_HASH / 64; ++q) hash[lane + 64 * q] = 0;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
         int32_t v = 0, deg = 0;
         uint32_t r0 = 0;
-        int chain = 0;
         if (lane < n) {
             v = set_nodes[beg + lane];
             const int64_t a = rowptr[v], b = rowptr[v + 1];
             r0 = (uint32_t)a;
             deg = (int32_t)(b - a);
-            uint32_t h = sgnn_hash32((uint32_t)v) >> (32 - DS_HASH_BITS);
-            while (true) {
-                ++chain;
-                const int32_t old = atomicCAS(&hash[h], 0, v);
-                if (old == 0 || old == v) break;
-                h = (h + 1) & (DS_HASH - 1);
-            }
         }
+        // ---- build the table: first multiplier under which no two members share a slot --------
+        uint32_t k24 = ds_mult[0];
+        int P = 1;
+        for (int t = 0; t < DS_TRIES; ++t) {
+            k24 = ds_mult[t];
 #pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) { const int o = __shfl_xor(chain, d); chain = o > chain ? o : chain; }
-        const int P = chain;                                 // wave-uniform probe count
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+            for (int q = 0; q < DS_HASH / 256; ++q)          // 16 B per lane per store
+                reinterpret_cast<int4*>(hash)[lane + 64 * q] = make_int4(0, 0, 0, 0);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            int chain = 0;
+            if (lane < n) {
+                uint32_t h = ds_slot4(v, k24) >> 2;
+                const bool last_try = (t == DS_TRIES - 1);
+                while (true) {
+                    ++chain;
+                    const int32_t old = atomicCAS(&hash[h], 0, v);
+                    if (old == 0 || old == v) break;
+                    if (!last_try) { chain = 2; break; }     // collision: this multiplier is rejected
+                    h = (h + 1) & (DS_HASH - 1);
+                }
+            }
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) { const int o = __shfl_xor(chain, d); chain = o > chain ? o : chain; }
+            P = chain;                                       // wave-uniform
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (P <= 1) break;
+        }
         int32_t cnt = 0, selfc = 0;
-        // ---- phase A: members with >= 64 neighbours, one list at a time, 8 coalesced 256 B loads in flight ----
-        uint64_t big = __ballot(deg >= DS_BIG);
-        while (big) {
-            const int m = __ffsll((unsigned long long)big) - 1;
-            big &= big - 1;
-            const int32_t m_v = __shfl(v, m), m_deg = __shfl(deg, m);
-            const int32_t* __restrict__ list = col + __shfl(r0, m);
-            int32_t local = 0, selfl = 0;
-            int32_t base = 0;
-            for (; base + 512 <= m_deg; base += 512) {       // full blocks: 8 x 256 B loads in flight
-                int32_t u[8];
-#pragma unroll
-                for (int q = 0; q < 8; ++q) u[q] = list[base + q * 64 + lane];
-#pragma unroll
-                for (int q = 0; q < 8; ++q) { local += ds_probe(hash, u[q], P); selfl += (u[q] == m_v); }
-            }
-            if (base < m_deg) {                              // tail (< 512 entries): clamped loads,
-                const int32_t last = m_deg - 1;              // out-of-range lanes get the never-stored key -1
-                int32_t u[8];
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const int32_t i = base + q * 64 + lane;
-                    u[q] = list[i < last ? i : last];
-                    u[q] = i <= last ? u[q] : -1;
-                }
-#pragma unroll
-                for (int q = 0; q < 8; ++q)
-                    if (base + q * 64 < m_deg) { local += ds_probe(hash, u[q], P); selfl += (u[q] == m_v); }   // wave-uniform
-            }
-            const int32_t st = ds_wave_sum(selfl);
-            const int32_t tot = ds_wave_sum(local) + st;      // a self loop counts twice (networkx)
-            if (lane == m) { cnt = tot; selfc = st; }
+        if (self_loops != nullptr) {
+            if (lane < n) selfc = self_loops[v];
+            if (P <= 1) ds_count<true, false>(col, hash, k24, P, lane, v, deg, r0, cnt, selfc);
+            else ds_count<false, false>(col, hash, k24, P, lane, v, deg, r0, cnt, selfc);
+        } else {
+            if (P <= 1) ds_count<true, true>(col, hash, k24, P, lane, v, deg, r0, cnt, selfc);
+            else ds_count<false, true>(col, hash, k24, P, lane, v, deg, r0, cnt, selfc);
         }
-        // ---- phase B: the remaining lists as one flat range, 128 entries per step ------------
-        const int32_t sdeg = deg >= DS_BIG ? 0 : deg;
-        int32_t incl = sdeg;                                 // inclusive scan over the wave
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const int32_t t = __shfl_up(incl, d);
-            if (lane >= d) incl += t;
-        }
-        const int32_t total = __shfl(incl, 63);
-        const int32_t excl = incl - sdeg;
-        for (int32_t base = 0; base < total; base += 128) {
-            int32_t u[2], mv[2];
-            bool valid[2];
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const int32_t t = base + q * 64 + lane;
-                int lo = 0, hi = 63;                         // smallest m with incl[m] > t
-#pragma unroll
-                for (int it = 0; it < 6; ++it) {
-                    const int mid = (lo + hi) >> 1;
-                    const int32_t x = __shfl(incl, mid);
-                    if (x > t) hi = mid; else lo = mid + 1;
-                }
-                const int m = lo & 63;
-                valid[q] = t < total;
-                const int32_t m_excl = __shfl(excl, m);
-                const uint32_t m_r0 = __shfl(r0, m);
-                mv[q] = __shfl(v, m);
-                u[q] = valid[q] ? col[m_r0 + (uint32_t)(t - m_excl)] : -1;
-            }
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const bool hit = ds_probe(hash, u[q], P) != 0;
-                const bool self = (u[q] == mv[q]);
-                const uint64_t mh = __ballot(hit);
-                const uint64_t ms = __ballot(self);
-                const int32_t b0 = base + q * 64;
-                int32_t lo_i = excl - b0, hi_i = incl - b0;  // this lane's member range in the step
-                lo_i = lo_i < 0 ? 0 : (lo_i > 64 ? 64 : lo_i);
-                hi_i = hi_i < 0 ? 0 : (hi_i > 64 ? 64 : hi_i);
-                const uint64_t below_hi = hi_i >= 64 ? ~0ull : ((1ull << hi_i) - 1ull);
-                const uint64_t below_lo = lo_i >= 64 ? ~0ull : ((1ull << lo_i) - 1ull);
-                const uint64_t rm = below_hi & ~below_lo;
-                const int32_t sc = __popcll(ms & rm);
-                cnt += __popcll(mh & rm) + sc;
-                selfc += sc;
-            }
-        }
+        cnt += selfc;                                        // a self loop counts twice (networkx)
         int32_t full = deg + selfc;
         if (full_degree != nullptr && lane < n) full = full_degree[v];
         const int32_t internal = cnt;
@@ -321,7 +359,7 @@ __global__ __launch_bounds__(DSB_THREADS) void degseq_block_kernel(
 }
 
 extern "C" int sgnn_degree_sequence(const int64_t* rowptr, const int32_t* col, int64_t nnz,
-                                    const int32_t* full_degree,
+                                    const int32_t* full_degree, const uint8_t* self_loops,
                                     const int64_t* set_ptr, const int32_t* set_nodes, int64_t n_sets,
                                     int64_t max_set_size, int sorted,
                                     int32_t* out_internal, int32_t* out_external, void* stream)
@@ -339,10 +377,10 @@ extern "C" int sgnn_degree_sequence(const int64_t* rowptr, const int32_t* col, i
     const int grid = (int)(want < (1 << 20) ? want : (1 << 20));
     if (sorted)
         hipLaunchKernelGGL(degseq_wave_kernel<true>, dim3(grid), dim3(64 * DS_WAVES), 0, st, rowptr, col, full_degree,
-                           set_ptr, set_nodes, n_sets, out_internal, out_external);
+                           self_loops, set_ptr, set_nodes, n_sets, out_internal, out_external);
     else
         hipLaunchKernelGGL(degseq_wave_kernel<false>, dim3(grid), dim3(64 * DS_WAVES), 0, st, rowptr, col, full_degree,
-                           set_ptr, set_nodes, n_sets, out_internal, out_external);
+                           self_loops, set_ptr, set_nodes, n_sets, out_internal, out_external);
     SGNN_CHECK_LAUNCH();
     if (max_set_size > 64) {
         const int gridb = (int)(n_sets < 256 * 4 ? n_sets : 256 * 4);

@@ -132,13 +132,18 @@ class DeviceGraph:
         self.full_degree = None
         if full_degree is not None:
             self.full_degree = torch.from_numpy(np.ascontiguousarray(full_degree, dtype=np.int32)).to(device)
+        # self-loop entries per row (0 or 1 on a simple graph): spares the degree-sequence kernel a
+        # compare per streamed neighbour
+        n_self = np.bincount(rows[col[:len(rows)] == rows], minlength=self.max_id + 1) if len(rows) else \
+            np.zeros(self.max_id + 1, dtype=np.int64)
+        self.self_loops = torch.from_numpy(np.minimum(n_self, 255).astype(np.uint8)).to(device)
 
 
 # ---------------------------------------------------------------------------------------
 # integer half
 # ---------------------------------------------------------------------------------------
 
-def degree_sequence(g, sets, sort=True, use_degree_dict=True, want_external=True):
+def degree_sequence(g, sets, sort=True, use_degree_dict=True, want_external=True, use_self_loop_table=True):
     """gamma.get_degree_sequence for every set at once -> (internal, external) int32 flat
     tensors aligned with ``sets.nodes`` (each set's slice sorted ascending if ``sort``)."""
     lib = _lib.load()
@@ -146,9 +151,10 @@ def degree_sequence(g, sets, sort=True, use_degree_dict=True, want_external=True
     out_i = torch.empty(n_tot, dtype=torch.int32, device=g.device)
     out_e = torch.empty(n_tot, dtype=torch.int32, device=g.device) if want_external else None
     fd = g.full_degree if use_degree_dict else None
-    check(lib.sgnn_degree_sequence(_ptr(g.rowptr), _ptr(g.col), g.nnz, _ptr(fd), _ptr(sets.ptr), _ptr(sets.nodes),
-                                   sets.n, max(sets.max_len, 1), 1 if sort else 0, _ptr(out_i), _ptr(out_e),
-                                   _stream()), 'sgnn_degree_sequence')
+    sl = g.self_loops if use_self_loop_table else None
+    check(lib.sgnn_degree_sequence(_ptr(g.rowptr), _ptr(g.col), g.nnz, _ptr(fd), _ptr(sl), _ptr(sets.ptr),
+                                   _ptr(sets.nodes), sets.n, max(sets.max_len, 1), 1 if sort else 0, _ptr(out_i),
+                                   _ptr(out_e), _stream()), 'sgnn_degree_sequence')
     return out_i, out_e
 
 

@@ -38,7 +38,7 @@ def test_workspace_queries_run_on_the_host():
 def test_argument_errors_are_reported_not_thrown():
     from subgnn_amd import _lib
     lib = _lib.load()
-    assert lib.sgnn_degree_sequence(None, None, 0, None, None, None, 0, 1, 1, None, None, None) == -1
+    assert lib.sgnn_degree_sequence(None, None, 0, None, None, None, None, 0, 1, 1, None, None, None) == -1
     assert lib.sgnn_mpn_fwd(None, None, None, None) == -1
 
 

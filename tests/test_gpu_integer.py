@@ -86,12 +86,13 @@ def test_degree_sequence_random(sizes):
     r = ops.Ragged.from_lists(sets, DEV)
     rp, col = G.csr()
     for srt in (True, False):
-        oi, oe = ops.degree_sequence(dg, r, sort=srt, use_degree_dict=False)
-        ptr, flat = cbind.ragged(sets)
-        ci, ce = cbind.degree_sequence(rp, col, None, ptr, flat, srt)
-        n = int(ptr[-1])
-        assert np.array_equal(oi.cpu().numpy()[:n], ci)
-        assert np.array_equal(oe.cpu().numpy()[:n], ce)
+        for table in (True, False):        # self loops from the per-node table / counted while streaming
+            oi, oe = ops.degree_sequence(dg, r, sort=srt, use_degree_dict=False, use_self_loop_table=table)
+            ptr, flat = cbind.ragged(sets)
+            ci, ce = cbind.degree_sequence(rp, col, None, ptr, flat, srt)
+            n = int(ptr[-1])
+            assert np.array_equal(oi.cpu().numpy()[:n], ci)
+            assert np.array_equal(oe.cpu().numpy()[:n], ce)
 
 
 def test_degree_sequence_too_large_is_an_error():

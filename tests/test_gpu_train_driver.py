@@ -54,3 +54,24 @@ def test_train_driver_end_to_end(tiny, tmp_path):
     assert any(n.startswith('int_struc_12_triangular_random_walk_2_0_train') for n in names)
     res = trainer.test(model)
     assert 'test_micro_f1' in model.test_results and torch.isfinite(res['avg_test_loss'])
+
+
+def test_seed_sweep_driver(tiny, tmp_path):
+    """SubGNN/test.py: one fresh model per seed, test metrics aggregated into experiment_results.json."""
+    from subgnn_amd import config, train_config
+    from subgnn_amd import test as sweep
+    write_dataset_from_golden(tiny, tmp_path, 'ds')
+    fix = dict(tiny.hp)
+    for k in ('batch_size', 'learning_rate', 'n_layers'):
+        fix.pop(k, None)
+    fix.update({'max_epochs': 2, 'lin_dropout': 0.0, 'compute_similarities': True})
+    cfg = tmp_path / 'config.json'
+    cfg.write_text(CONFIG % json.dumps(fix))
+    config.PROJECT_ROOT = tmp_path
+    exp = sweep.run_seeds(train_config.read_json(cfg), n_seeds=3, results_dir=tmp_path / 'sweep', log=lambda *a: None)
+    assert len(exp['test_acc']) == 3 and len(exp['test_micro_f1']) == 3 and len(exp['test_auroc']) == 3
+    assert abs(exp['test_acc_mean'] - sum(exp['test_acc']) / 3) < 1e-12 and exp['test_micro_f1_sd'] >= 0
+    saved = json.loads((tmp_path / 'sweep' / 'experiment_results.json').read_text())
+    assert saved['test_micro_f1'] == exp['test_micro_f1']
+    assert os.path.exists(tmp_path / 'sweep' / 'version_2' / 'final_metric_scores.json')
+
