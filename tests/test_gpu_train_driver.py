@@ -75,3 +75,26 @@ def test_seed_sweep_driver(tiny, tmp_path):
     assert saved['test_micro_f1'] == exp['test_micro_f1']
     assert os.path.exists(tmp_path / 'sweep' / 'version_2' / 'final_metric_scores.json')
 
+
+def test_component_recipe_through_the_model(tiny, tmp_path):
+    """A generated COMPONENT dataset (stapled components) read, prepared and trained by the drop-in
+    module: the components the HIP union-find finds per subgraph are the ones the generator stapled."""
+    import networkx as nx
+    from subgnn_amd import config, train_config, prepare_dataset as pd, precompute_graph_metrics as pgm
+    from subgnn_amd.subgraph_utils import read_subgraphs
+    out, info = pd.write_dataset(tmp_path / 'ds', 'cc', seed=9, embed_dim=16, n=250, n_subgraphs=24, n_subgraph_nodes=6)
+    pgm.calculate_stats(out)
+    fix = dict(tiny.hp)
+    for k in ('batch_size', 'learning_rate', 'n_layers'):
+        fix.pop(k, None)
+    fix.update({'max_epochs': 1, 'seed': 1, 'lin_dropout': 0.0, 'compute_similarities': True, 'node_embed_size': 16})
+    cfg = tmp_path / 'config.json'
+    cfg.write_text(CONFIG % json.dumps(fix))
+    config.PROJECT_ROOT = tmp_path
+    best, model, trainer = train_config.train_model(train_config.read_json(cfg), log=lambda *a: None)
+    G = nx.read_edgelist(str(out / 'edge_list.txt'), nodetype=int)
+    tr = read_subgraphs(out / 'subgraphs.pth')[0]
+    got = (model.train_cc_ids[:, :, 0] != 0).sum(dim=1).cpu().tolist()
+    assert got == [nx.number_connected_components(G.subgraph(s)) for s in tr]
+    assert model.num_classes == 2 and torch.isfinite(torch.tensor(trainer.history[0]['train_loss']))
+

@@ -102,8 +102,53 @@ def test_density_dataset_writer_round_trips(tmp_path):
     d = write_density_dataset(tmp_path / 'density', n_nodes=300, m=4, n_subgraphs=40, subgraph_nodes=10, embed_dim=8)
     tr, trl, va, val, te, tel = read_subgraphs(d / 'subgraphs.pth')
     assert len(tr) == 32 and len(va) == 4 and len(te) == 4
-    assert set(trl.tolist()) <= {0, 1, 2} and all(len(s) == 10 for s in tr)
+    assert set(trl.tolist()) <= {0, 1, 2} and all(1 <= len(s) <= 10 for s in tr)      # edits can cut a member off
     edges = parse_edge_list(d / 'edge_list.txt')
     rp, col, order = networkx_order_csr(edges)
-    assert len(order) == 300 and rp[-1] == 2 * len(edges)
-    assert torch.load(d / 'gin_embeddings.pth').shape == (300, 8)
+    assert 250 <= len(order) <= 300 and rp[-1] == 2 * len(edges)                      # largest component only
+    assert torch.load(d / 'gin_embeddings.pth').shape == (len(order), 8)
+
+
+# ---- synthetic dataset recipes (prepare_dataset.py restatement) ------------------------------
+
+@pytest.mark.parametrize('prop,over', [
+    ('density', dict(n=600, n_subgraphs=40)),
+    ('cut_ratio', dict(n=600, n_subgraphs=30)),
+    ('coreness', dict(n=500, n_subgraphs=6)),
+    ('cc', dict(n=300, n_subgraphs=40)),
+])
+def test_dataset_recipes(prop, over, tmp_path):
+    """Each recipe writes a loadable dataset whose labels are the property's bins: densities / cut
+    ratios edited to their targets, component counts as stapled, letters in ascending bin order."""
+    import networkx as nx
+    from subgnn_amd import prepare_dataset as pd
+    from subgnn_amd.subgraph_utils import read_subgraphs
+    out, info = pd.write_dataset(tmp_path / prop, prop, seed=5, embed_dim=8, **over)
+    G = nx.read_edgelist(str(out / 'edge_list.txt'), nodetype=int)
+    assert nx.is_connected(G) and sorted(G.nodes) == list(range(G.number_of_nodes()))
+    tr, trl, va, val, te, tel = read_subgraphs(out / 'subgraphs.pth')
+    n = len(tr) + len(va) + len(te)
+    assert n == info['n_subgraphs'] and abs(len(tr) - 0.8 * n) <= 1 and abs(len(va) - len(te)) <= 1
+    assert torch.load(out / 'gin_embeddings.pth').shape == (G.number_of_nodes(), 8)
+    vals, labs = np.array(info['values'], dtype=float), np.array(info['labels'])
+    assert set(labs) == {chr(65 + i) for i in range(len(set(labs)))} and len(set(labs)) >= 2
+    for a, b in zip(sorted(set(labs))[:-1], sorted(set(labs))[1:]):          # bins ascend with the letters
+        assert vals[labs == a].max() <= vals[labs == b].min()
+    if prop == 'density':
+        hit = [min(abs(v - t) for t in pd.DENSITY_RANGE) < pd.DENSITY_EPSILON for v in vals]
+        assert np.mean(hit) > 0.3      # later edits and the largest-component cut disturb earlier subgraphs (as upstream)
+    if prop == 'cut_ratio':
+        assert vals.min() > 0 and vals.max() < 0.05
+    if prop == 'cc':
+        assert set(int(v) for v in vals) <= set(pd.CC_RANGE) and (vals == 1).any() and (vals >= 5).any()
+        assert all((l == 'A') == (v == 1) for l, v in zip(labs, vals))
+    if prop == 'coreness':
+        assert vals.min() >= 1.0
+
+
+def test_equal_count_bins_and_letters():
+    from subgnn_amd import prepare_dataset as pd
+    vals = [0.1, 0.5, 0.2, 0.9, 0.3, 0.7]
+    cuts = pd.equal_count_bins(vals, 3)
+    assert np.allclose(cuts, [0.2, 0.5])
+    assert pd.letters(np.digitize(vals, bins=cuts)) == ['A', 'C', 'B', 'C', 'B', 'C']
