@@ -1,6 +1,7 @@
 // Similarity kernels: shortest-path similarities (a9, dense-parity and sparse forms) and the
 // structure similarity 1/(1+fastdtw) (a11).
 #include "common.h"
+#include <type_traits>
 
 // ---------------------------------------------------------------------------------------------
 // a9  dense-parity form (reference SubGNN/SubGNN.py:752-781): column-wise min over the APSP rows
@@ -418,8 +419,8 @@ __device__ static inline double dtw_cost(double a, double b) {            // gam
 // dyadic rational here).  tests/test_oracle_integer.py::test_reciprocal_division_is_exact runs the
 // identity exhaustively over the integer range and on 10^7 random dyadic pairs on the CPU.
 __device__ __forceinline__ double dtw_cost_rcp(double a1, double ra, double b1, double rb) {
-    const bool sw = a1 > b1;
-    const double mx = sw ? a1 : b1, mn = sw ? b1 : a1, r = sw ? rb : ra;
+    // v_max_f64 / v_min_f64 instead of compare + two selects each (the operands are never NaN)
+    const double mx = fmax(a1, b1), mn = fmin(a1, b1), r = a1 > b1 ? rb : ra;
     const double q0 = __dmul_rn(mx, r);
     const double rem = __fma_rn(-q0, mn, mx);
     return __dadd_rn(__fma_rn(rem, r, q0), -1.0);
@@ -567,13 +568,17 @@ __global__ __launch_bounds__(DTW_THREADS) void dtw_similarity_kernel(
 // fl: this lane's column of the workgroup's LDS table (stride DTW_THREADS words) holding the coarser
 // path's first | last << 16 column per row.  Predecessor codes of a non-finest level go to wl (LDS,
 // 32-bit words: such a level has at most 16 rows) when WLDS, else to the global scratch wq.
-template <int RMAX, int RR, int TIE, bool WLDS>
+// FINEST: the level whose distance is the result -- it is never backtracked, so it neither tracks
+// nor stores predecessor codes (it holds more than half of all cells).
+template <int RMAX, int RR, int TIE, bool WLDS, bool FINEST>
 __device__ __forceinline__ double dtw_reg_level(
     int32_t* __restrict__ fl, const double* __restrict__ xcol, const double* __restrict__ xrcol, int64_t n_x,
     const double* __restrict__ ycol, const double* __restrict__ yrcol,
-    int lx, int ly, int lxc, int lyc, bool coarsest, bool finest, uint32_t* __restrict__ wl,
+    int lx, int ly, int lxc, int lyc, bool coarsest, uint32_t* __restrict__ wl,
     uint64_t* __restrict__ wq, int64_t NT)
 {
+    constexpr bool finest = FINEST;
+    typedef typename std::conditional<(RR <= 16), uint32_t, uint64_t>::type word_t;   // 2 bits per row
 #define FLQ(q) fl[(q) * DTW_THREADS]
     const double INF = __longlong_as_double(0x7ff0000000000000ll);
     const int32_t EMPTY = 1;                                  // lo = 1, hi = 0
@@ -625,7 +630,7 @@ __device__ __forceinline__ double dtw_reg_level(
     for (int j = 0; j < ly; ++j) {
         const double yp1 = y_next + 1.0, yr = yr_next;
         if (j + 1 < ly) { y_next = ycol[j + 1]; yr_next = yrcol[j + 1]; }       // in flight during this column
-        uint64_t word = 0;
+        word_t word = 0;
         double up = INF;
         double diag = (j == 0) ? 0.0 : INF;                                  // virtual origin D[0][0] = 0
 #pragma unroll
@@ -640,17 +645,14 @@ __device__ __forceinline__ double dtw_reg_level(
                     if (j >= lo && j <= hi) {
                         const double dt = dtw_cost_rcp(xp1[i], xr[i], yp1, yr);
                         const double c_up = up + dt, c_left = old + dt, c_diag = diag + dt;
-                        int best;
-                        if (TIE == 0) {                                      // (i-1,j), (i,j-1), (i-1,j-1)
-                            best = 0; nv = c_up;
-                            if (c_left < nv) { nv = c_left; best = 1; }
-                            if (c_diag < nv) { nv = c_diag; best = 2; }
-                        } else {                                             // (i-1,j-1), (i-1,j), (i,j-1)
-                            best = 2; nv = c_diag;
-                            if (c_up < nv) { nv = c_up; best = 0; }
-                            if (c_left < nv) { nv = c_left; best = 1; }
+                        nv = fmin(fmin(c_up, c_left), c_diag);               // two v_min_f64 (no NaNs here)
+                        if (!FINEST) {
+                            // predecessor = the first candidate, in the tie order, that attains the minimum
+                            int best;
+                            if (TIE == 0) best = c_up == nv ? 0 : (c_left == nv ? 1 : 2);    // (i-1,j), (i,j-1), (i-1,j-1)
+                            else best = c_diag == nv ? 2 : (c_up == nv ? 0 : 1);              // (i-1,j-1), (i-1,j), (i,j-1)
+                            word |= (word_t)best << (2 * i);
                         }
-                        word |= (uint64_t)best << (2 * i);
                     }
                     col[i] = nv;
                     diag = old;                                              // (i, j-1) is the diagonal of (i+1, j)
@@ -662,7 +664,7 @@ __device__ __forceinline__ double dtw_reg_level(
             }
         }
         if (!finest) {                                                       // the finest level is never backtracked
-            if (WLDS) wl[j * DTW_THREADS] = (uint32_t)word; else wq[(int64_t)j * NT] = word;
+            if (WLDS) wl[j * DTW_THREADS] = (uint32_t)word; else wq[(int64_t)j * NT] = (uint64_t)word;
         }
     }
     double result = 0.0;
@@ -726,7 +728,8 @@ __global__ __launch_bounds__(DTW_THREADS, MINB) void dtw_similarity_reg_kernel(
             const double* yrcol = ycol + L.YL * n_y;
             uint64_t* w = wq + L.yoff[lev] * NT + tid;
             const bool coarsest = lev == n_levels - 1, finest = lev == 0;
-#define DTW_LEVEL(RR) result = dtw_reg_level<RMAX, (RR) <= RMAX ? (RR) : RMAX, TIE, WLDS>(fl, xcol, xrcol, n_x, ycol, yrcol, lx, ly, lxc, lyc, coarsest, finest, wl, w, NT)
+#define DTW_LEVEL_F(RR, F) result = dtw_reg_level<RMAX, (RR) <= RMAX ? (RR) : RMAX, TIE, WLDS, F>(fl, xcol, xrcol, n_x, ycol, yrcol, lx, ly, lxc, lyc, coarsest, wl, w, NT)
+#define DTW_LEVEL(RR) do { if (finest) DTW_LEVEL_F(RR, true); else DTW_LEVEL_F(RR, false); } while (0)
             if (lx <= 4) DTW_LEVEL(4);                       // narrow instantiations: the unrolled row
             else if (lx <= 8) DTW_LEVEL(8);                  // loop sweeps at most 3 empty rows
             else if (lx <= 12) DTW_LEVEL(12);
@@ -736,6 +739,7 @@ __global__ __launch_bounds__(DTW_THREADS, MINB) void dtw_similarity_reg_kernel(
             else if (RMAX > 20 && lx <= 28) DTW_LEVEL(28);
             else if (RMAX > 20) DTW_LEVEL(32);
 #undef DTW_LEVEL
+#undef DTW_LEVEL_F
         }
         out[r * n_y + a] = (float)(1.0 / (result + 1.0));
     }
