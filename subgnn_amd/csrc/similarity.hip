@@ -333,7 +333,7 @@ extern "C" int sgnn_min_hops_to_sets(const uint8_t* dist, int64_t n_sources, int
 #endif
 #define DTW_NT ((int64_t)DTW_THREADS * DTW_BLOCKS)
 #ifndef DTW_REG_BLOCKS
-#define DTW_REG_BLOCKS (256 * 4)      // register variant: its scratch is LDS, more and shorter-lived workgroups balance better
+#define DTW_REG_BLOCKS (256 * 8)      // register variant: its scratch is LDS, more and shorter-lived workgroups balance better
 #endif
 #define DTW_REG_NT ((int64_t)DTW_THREADS * DTW_REG_BLOCKS)
 #define DTW_MAX_LEVELS 16
@@ -379,13 +379,18 @@ extern "C" int64_t sgnn_dtw_workspace_bytes(int64_t n_x, int64_t max_x_len, int6
 // pyramid of one series per thread.  transposed != 0: element e of sequence s at out[e * n + s].
 // rec (same layout) receives 1 / (value + 1), correctly rounded: the register kernel's cost
 // function divides by multiplying with it (see dtw_cost_rcp).
+// order (nullable): position s of the output holds sequence order[s] -- the register kernel walks the
+// x rows in the caller's processing order, and with the pyramids laid out in that order the lanes of
+// a wavefront read consecutive addresses instead of gathering 64 cache lines per load.
 __global__ void dtw_pyramid_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ val, int64_t n,
                                    int64_t M, int64_t PL, int transposed, double* __restrict__ out,
-                                   double* __restrict__ rec, int32_t* __restrict__ len_out)
+                                   double* __restrict__ rec, int32_t* __restrict__ len_out,
+                                   const int32_t* __restrict__ order)
 {
     for (int64_t s = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; s < n; s += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t b = ptr[s];
-        int len = (int)(ptr[s + 1] - b);
+        const int64_t src = order ? order[s] : s;
+        const int64_t b = ptr[src];
+        int len = (int)(ptr[src + 1] - b);
         len_out[s] = len;
 #define PYI(e) (transposed ? (int64_t)(e) * n + s : s * PL + (e))
 #define PY(e) out[PYI(e)]
@@ -556,6 +561,9 @@ __global__ __launch_bounds__(DTW_THREADS) void dtw_similarity_kernel(
 #ifndef DTW_MINB12
 #define DTW_MINB12 3            // resident 256-thread blocks per CU the 12-row kernel is compiled for
 #endif
+#ifndef DTW_BRANCHLESS_ROWS
+#define DTW_BRANCHLESS_ROWS 1
+#endif
 #ifndef DTW_MINB32
 #define DTW_MINB32 1
 #endif
@@ -641,6 +649,23 @@ __device__ __forceinline__ double dtw_reg_level(
                     const int i = 4 * b + q;
                     const int lo = lohi[i] & 0xffff, hi = lohi[i] >> 16;
                     const double old = col[i];
+#if DTW_BRANCHLESS_ROWS
+                    // every row of a live block is evaluated and the result selected by the row's own
+                    // window test: no per-row branch (a branch stalls the wavefront's issue; the block
+                    // test above already removed most out-of-window rows)
+                    const bool in = j >= lo && j <= hi;
+                    const double dt = dtw_cost_rcp(xp1[i], xr[i], yp1, yr);
+                    const double c_up = up + dt, c_left = old + dt, c_diag = diag + dt;
+                    const double mv = fmin(fmin(c_up, c_left), c_diag);      // two v_min_f64 (no NaNs here)
+                    const double nv = in ? mv : INF;
+                    if (!FINEST) {
+                        // predecessor = the first candidate, in the tie order, that attains the minimum
+                        int best;
+                        if (TIE == 0) best = c_up == mv ? 0 : (c_left == mv ? 1 : 2);        // (i-1,j), (i,j-1), (i-1,j-1)
+                        else best = c_diag == mv ? 2 : (c_up == mv ? 0 : 1);                  // (i-1,j-1), (i-1,j), (i,j-1)
+                        word |= in ? ((word_t)best << (2 * i)) : (word_t)0;
+                    }
+#else
                     double nv = INF;
                     if (j >= lo && j <= hi) {
                         const double dt = dtw_cost_rcp(xp1[i], xr[i], yp1, yr);
@@ -654,6 +679,7 @@ __device__ __forceinline__ double dtw_reg_level(
                             word |= (word_t)best << (2 * i);
                         }
                     }
+#endif
                     col[i] = nv;
                     diag = old;                                              // (i, j-1) is the diagonal of (i+1, j)
                     up = nv;
@@ -709,8 +735,9 @@ __global__ __launch_bounds__(DTW_THREADS, MINB) void dtw_similarity_reg_kernel(
         // consecutive lanes: same anchor, consecutive components of the caller's processing order
         // (similar series side by side keep the lanes' windows aligned)
         const int64_t a = pair / n_x;
-        const int64_t r = x_order ? x_order[pair % n_x] : pair % n_x;
-        const int lx0 = xlen[r], ly0 = ylen[a];
+        const int64_t pos = pair % n_x;                                    // position in the processing order:
+        const int64_t r = x_order ? x_order[pos] : pos;                    // the pyramids are laid out by position
+        const int lx0 = xlen[pos], ly0 = ylen[a];
         if (lx0 == 0 || ly0 == 0) { out[r * n_y + a] = 0.f; continue; }
         const double* __restrict__ yp = ypyr + a * L.YL;
         int n_levels = 1;
@@ -722,7 +749,7 @@ __global__ __launch_bounds__(DTW_THREADS, MINB) void dtw_similarity_reg_kernel(
         for (int lev = n_levels - 1; lev >= 0; --lev) {
             const int lx = lx0 >> lev, ly = ly0 >> lev;
             const int lxc = lx0 >> (lev + 1), lyc = ly0 >> (lev + 1);
-            const double* xcol = xpyr + L.xoff[lev] * n_x + r;
+            const double* xcol = xpyr + L.xoff[lev] * n_x + pos;
             const double* xrcol = xcol + L.XL * n_x;                        // reciprocal pyramids follow the values
             const double* ycol = yp + L.yoff[lev];
             const double* yrcol = ycol + L.YL * n_y;
@@ -775,13 +802,14 @@ extern "C" int sgnn_dtw_similarity(const int64_t* x_ptr, const int32_t* x_val, i
     double* ypyr = (double*)w;             w += 2 * n_y * L.YL * 8;
     int32_t* xlen = (int32_t*)w;           w += dtw_align8(n_x * 4);
     int32_t* ylen = (int32_t*)w;
+    const bool use_reg = max_x_len <= DTW_R && !g_dtw_force_general;
     hipLaunchKernelGGL(dtw_pyramid_kernel, dim3(sgnn_grid_for(n_x, 256)), dim3(256), 0, st, x_ptr, x_val, n_x,
-                       max_x_len, L.XL, 1, xpyr, xpyr + n_x * L.XL, xlen);
+                       max_x_len, L.XL, 1, xpyr, xpyr + n_x * L.XL, xlen, use_reg ? x_order : (const int32_t*)nullptr);
     SGNN_CHECK_LAUNCH();
     hipLaunchKernelGGL(dtw_pyramid_kernel, dim3(sgnn_grid_for(n_y, 256)), dim3(256), 0, st, y_ptr, y_val, n_y,
-                       max_y_len, L.YL, 0, ypyr, ypyr + n_y * L.YL, ylen);
+                       max_y_len, L.YL, 0, ypyr, ypyr + n_y * L.YL, ylen, (const int32_t*)nullptr);
     SGNN_CHECK_LAUNCH();
-    if (max_x_len <= DTW_R && !g_dtw_force_general) {
+    if (use_reg) {
         // predecessor words of the coarse levels in LDS when (max_y_len / 2) words per lane fit
         const int64_t words = max_y_len >> 1;
         const bool wlds = words * DTW_THREADS * 4 <= 48 * 1024;
