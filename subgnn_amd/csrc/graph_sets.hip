@@ -215,11 +215,16 @@ __global__ __launch_bounds__(THREADS) void khop_border_kernel(
     __shared__ int32_t s_pref[THREADS];
     __shared__ int32_t s_wtot[THREADS / 64];
     __shared__ int32_t s_sel[KB_SEL_CHUNK];
+    __shared__ int32_t s_tincl[64];               // frontier tile: inclusive degree scan, row starts
+    __shared__ uint32_t s_tr0[64];
     uint32_t* bm = LDS_BM ? s_bm : bitmaps + (int64_t)blockIdx.x * words;
     int32_t* q = queue_in_output ? nullptr : queues + (int64_t)blockIdx.x * (max_id + 1);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     constexpr int NW = THREADS / 64;
     const int hops = ego_mode ? 1 : k;
+    // the queue feeds the next hop's frontier, the materialised output and the bit clean-up; a
+    // one-hop count / fused draw on the LDS bitmap needs none of them (the bitmap is wiped whole)
+    const bool need_queue = !(LDS_BM && hops == 1 && out_nodes == nullptr);
     if (LDS_BM) {
         for (int64_t i = tid; i < words; i += THREADS) s_bm[i] = 0;
         __syncthreads();
@@ -237,30 +242,72 @@ __global__ __launch_bounds__(THREADS) void khop_border_kernel(
         for (int h = 1; h <= hops; ++h) {
             const int f0 = (h == 1) ? 0 : s_lvl[h - 2];      // frontier of hop h = nodes found at hop h-1
             const int f1 = (h == 1) ? n : s_lvl[h - 1];
-            for (int f = f0 + wave; f < f1; f += NW) {
-                const int32_t v = (h == 1) ? set_nodes[beg + f] : q[f];
-                const int64_t r0 = rowptr[v], r1 = rowptr[v + 1];
-                for (int64_t e0 = r0; e0 < r1; e0 += 64) {      // wave-uniform trip count
-                    const int64_t e = e0 + lane;
-                    bool fresh = false;
-                    int32_t c = 0;
-                    if (e < r1) {
-                        c = ego_mode ? col[e] - 1 : col[e];
-                        const uint32_t bit = 1u << (c & 31);
-                        const uint32_t old = atomicOr(&bm[c >> 5], bit);
-                        fresh = !(old & bit);
+            // The frontier is taken 64 nodes at a time and their neighbour lists are handled as ONE
+            // flat edge range dealt to the wavefronts in 64-edge chunks (a hub's list is shared by
+            // all wavefronts instead of serialising one of them), two chunks in flight per wavefront.
+            for (int t0 = f0; t0 < f1; t0 += 64) {
+                if (wave == 0) {
+                    int32_t deg = 0;
+                    uint32_t r0 = 0;
+                    if (t0 + lane < f1) {
+                        const int32_t v = (h == 1) ? set_nodes[beg + t0 + lane] : q[t0 + lane];
+                        const int64_t a = rowptr[v], b = rowptr[v + 1];
+                        r0 = (uint32_t)a;
+                        deg = (int32_t)(b - a);
                     }
-                    // wave-aggregated append: one LDS atomic per wavefront instead of one per node
-                    const uint64_t m = __ballot(fresh);
-                    if (m) {
-                        int base = 0;
-                        if (lane == 0) base = atomicAdd(&s_qn, (int)__popcll(m));
-                        base = __shfl(base, 0);
-                        if (fresh) q[base + __popcll(m & ((1ull << lane) - 1ull))] = c;
+                    int32_t incl = deg;
+#pragma unroll
+                    for (int d = 1; d < 64; d <<= 1) { const int32_t t = __shfl_up(incl, d); if (lane >= d) incl += t; }
+                    s_tincl[lane] = incl;
+                    s_tr0[lane] = r0;
+                }
+                __syncthreads();
+                const int32_t incl = s_tincl[lane];
+                const uint32_t r0 = s_tr0[lane];
+                int32_t excl = __shfl_up(incl, 1);
+                if (lane == 0) excl = 0;
+                const int32_t total = __shfl(incl, 63);
+                for (int32_t cb = wave * 64; cb < total; cb += 2 * NW * 64) {
+                    int32_t c[2];
+                    bool valid[2];
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const int32_t t = cb + u * NW * 64 + lane;
+                        valid[u] = t < total;
+                        int lo = 0, hi = 63;                      // smallest m with incl[m] > t
+#pragma unroll
+                        for (int it = 0; it < 6; ++it) {
+                            const int mid = (lo + hi) >> 1;
+                            const int32_t x = __shfl(incl, mid);
+                            if (x > t) hi = mid; else lo = mid + 1;
+                        }
+                        const int m = lo & 63;
+                        const int32_t m_excl = __shfl(excl, m);
+                        const uint32_t m_r0 = __shfl(r0, m);
+                        c[u] = valid[u] ? col[m_r0 + (uint32_t)(t - m_excl)] : 0;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        if (cb + u * NW * 64 >= total) break;     // wave-uniform
+                        bool fresh = false;
+                        const int32_t cc = ego_mode ? c[u] - 1 : c[u];
+                        if (valid[u]) {
+                            const uint32_t bit = 1u << (cc & 31);
+                            const uint32_t old = atomicOr(&bm[cc >> 5], bit);
+                            fresh = !(old & bit);
+                        }
+                        // wave-aggregated append: one LDS atomic per wavefront instead of one per node
+                        const uint64_t mk = __ballot(fresh);
+                        if (mk) {
+                            int base = 0;
+                            if (lane == 0) base = atomicAdd(&s_qn, (int)__popcll(mk));
+                            base = __shfl(base, 0);
+                            if (fresh && need_queue) q[base + __popcll(mk & ((1ull << lane) - 1ull))] = cc;
+                        }
                     }
                 }
+                __syncthreads();                                  // the tile tables are rewritten next
             }
-            __syncthreads();
             if (tid == 0) s_lvl[h] = s_qn;
             __syncthreads();
         }
@@ -288,9 +335,15 @@ __global__ __launch_bounds__(THREADS) void khop_border_kernel(
             __syncthreads();
         }
         // un-set every border bit so the next component handled by the workgroup starts clean
-        for (int i = tid; i < cnt; i += THREADS) {
-            const int32_t c = q[i];
-            atomicAnd(&bm[c >> 5], ~(1u << (c & 31)));
+        if (LDS_BM && (!need_queue || (int64_t)cnt * 8 > words)) {
+            // cheaper than re-reading the queue: wipe the LDS bitmap with 16-byte stores
+            int4* bm4 = reinterpret_cast<int4*>(s_bm);
+            for (int64_t i = tid; i < (words + 3) / 4; i += THREADS) bm4[i] = make_int4(0, 0, 0, 0);
+        } else {
+            for (int i = tid; i < cnt; i += THREADS) {
+                const int32_t c = q[i];
+                atomicAnd(&bm[c >> 5], ~(1u << (c & 31)));
+            }
         }
         __syncthreads();
     }
@@ -322,7 +375,7 @@ static int kb_launch(const int64_t* rowptr, const int32_t* col, int64_t nnz, int
             attr_set = true;
         }
         hipLaunchKernelGGL((khop_border_kernel<true, KB_THREADS_L>), dim3((int)nwg), dim3(KB_THREADS_L),
-                           (size_t)(words * 4), st, rowptr, col, max_id, set_ptr, set_nodes, n_sets, k, ego_dict_mode,
+                           (size_t)(((words + 3) / 4) * 16), st, rowptr, col, max_id, set_ptr, set_nodes, n_sets, k, ego_dict_mode,
                            out_count, out_ptr, out_nodes, out_hop, bitmaps, queues, words, smp, queue_in_output);
     } else {
         hipLaunchKernelGGL((khop_border_kernel<false, KB_THREADS_G>), dim3((int)nwg), dim3(KB_THREADS_G), 0, st,
