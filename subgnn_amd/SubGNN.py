@@ -187,6 +187,12 @@ class SubGNN(nn.Module):
         labels = ops.cc_labels(self.networkx_graph, subs)
         return subgraph_utils.components_from_labels(subs.ptr, subs.nodes, labels)
 
+    def _table(self):
+        """The embedding table as the fused ops read it: inside ``forward`` a tapped alias whose
+        consumers add their gradients into one shared buffer (ops.tap_table), else the parameter."""
+        t = self.__dict__.get('_tapped_table')         # kept out of nn.Module's parameter registry
+        return t if t is not None else self.node_embeddings.weight
+
     def initialize_cc_embeddings(self, cc_id_list, aggregator='sum'):
         """S.py:609-622 -> (S, C, D).  The padded rows are handed to the kernel as fixed-stride sets
         (PAD entries included): row 0 of the table is zero, so PAD adds nothing to a sum and competes
@@ -197,7 +203,7 @@ class SubGNN(nn.Module):
         ptr = torch.arange(S * C + 1, dtype=torch.int64, device=self.device) * L
         sets = ops.Ragged(ptr, ids.contiguous() if ids.numel() else torch.zeros(1, dtype=torch.int32, device=self.device),
                           max_len=L)
-        return ops.cc_embed(self.node_embeddings.weight, sets, aggregator, padded_len=0).view(S, C, -1)
+        return ops.cc_embed(self._table(), sets, aggregator, padded_len=0).view(S, C, -1)
 
     def initialize_channel_embeddings(self, cc_embeddings, trainable=False):
         if trainable:
@@ -473,7 +479,7 @@ class SubGNN(nn.Module):
                              inside):
         """Same layer without the (B,C,A,D) tensor: anchors are gathered inside the kernel."""
         B, C, _ = cc_embeds.shape
-        E = self.node_embeddings.weight
+        E = self._table()
         # NP_sim is either the reference's dense (B,C,N) slab (column = anchor id - 1) or, for
         # graphs where that slab cannot exist, a dict of already-gathered (B,C,A) edge weights
         # keyed (channel tag, side, layer) -- see hotpath.py
@@ -496,13 +502,24 @@ class SubGNN(nn.Module):
                                         sims_per_edge=per_edge)
         patches, indices, int_rw, bor_rw = self.anchors_structure[layer_num]
         X = aps.aggregate_structure_anchor_patch(self.hparams, self.networkx_graph, self.lstm, self.node_embeddings,
-                                                 patches, int_rw if inside else bor_rw, inside, self.device)
+                                                 patches, int_rw if inside else bor_rw, inside, self.device, table=E)
         return mpn_fn.forward_fused(sims, cc_embeds, cc_embed_mask, src=ops.SRC_SHARED, x=X,
                                     sim_col=self._sim_col_cache[layer_num])
 
     def forward(self, dataset_type, N_I_cc_embed, N_B_cc_embed, S_I_cc_embed, S_B_cc_embed, P_I_cc_embed,
                 P_B_cc_embed, subgraph_ids, cc_ids, subgraph_idx, NP_sim, I_S_sim, B_S_sim):
         """S.py:225-312."""
+        hp = self.hparams
+        fused = hp.get('fused_forward', True)
+        self.__dict__['_tapped_table'] = ops.tap_table(self.node_embeddings.weight) if fused else None
+        try:
+            return self._forward(dataset_type, N_I_cc_embed, N_B_cc_embed, S_I_cc_embed, S_B_cc_embed, P_I_cc_embed,
+                                 P_B_cc_embed, subgraph_ids, cc_ids, subgraph_idx, NP_sim, I_S_sim, B_S_sim)
+        finally:
+            self.__dict__['_tapped_table'] = None
+
+    def _forward(self, dataset_type, N_I_cc_embed, N_B_cc_embed, S_I_cc_embed, S_B_cc_embed, P_I_cc_embed,
+                 P_B_cc_embed, subgraph_ids, cc_ids, subgraph_idx, NP_sim, I_S_sim, B_S_sim):
         hp = self.hparams
         fused = hp.get('fused_forward', True)
         init_cc_embeds = self.initialize_cc_embeddings(cc_ids, hp['cc_aggregator'])

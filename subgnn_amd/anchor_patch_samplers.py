@@ -181,10 +181,10 @@ def embed_anchor_patch(node_matrix, anchor_patch_ids, device):
 
 
 def aggregate_structure_anchor_patch(hparams, networkx_graph, lstm, node_matrix, anchor_patch_ids, all_patch_walks,
-                                     inside, device):
+                                     inside, device, table=None):
     """aps:413-433: walks (A, W, T) -> LSTM over each walk's embeddings -> sum over W -> (A, D)."""
     n = anchor_patch_ids.shape[0]
-    walk_embeds = ops.gather_rows(node_matrix.weight, all_patch_walks.to(device))
+    walk_embeds = ops.gather_rows(node_matrix.weight if table is None else table, all_patch_walks.to(device))
     x = walk_embeds.view(n * hparams['n_triangular_walks'], hparams['random_walk_len'], hparams['node_embed_size'])
     h = lstm(x).view(n, hparams['n_triangular_walks'], -1)
     return torch.sum(h, dim=1)
