@@ -153,13 +153,18 @@ int sgnn_choice_ragged(const int64_t* ptr, const int32_t* seq, int64_t n_items, 
  *   mode 2  'border': start uniform over in_border nodes (inb_ptr/inb_nodes); neighbours
  *                     restricted to in_border U (V \ patch) (aps:141-143)
  * out: (n_items, walk_len) int64, PAD filled.  One tape item per walk (item = walk index).
+ * max_id: largest node id (rowptr has max_id + 2 entries); when the id range fits an LDS bitmap
+ * (~1.1 M ids) a workgroup-per-walk kernel is used (adjacency to the previous node = one bit
+ * test), else a wavefront-per-walk kernel (binary search in the sorted list); max_id <= 0 or
+ * sgnn_walks_force_wave(1) select the latter.  Both give the same walks.
  * ------------------------------------------------------------------------------------- */
 int sgnn_triangular_walks(const int64_t* rowptr, const int32_t* col, const int32_t* col_sorted, int64_t nnz,
                           const int32_t* node_order, int64_t n_nodes,
                           const int64_t* patch_ptr, const int32_t* patch_nodes,
                           const int64_t* inb_ptr, const int32_t* inb_nodes,
                           int mode, int64_t n_items, int64_t walks_per_patch, int64_t walk_len, double beta,
-                          uint64_t seed, uint64_t stream_id, int64_t* out, void* stream);
+                          uint64_t seed, uint64_t stream_id, int64_t max_id, int64_t* out, void* stream);
+int sgnn_walks_force_wave(int on);
 
 /* in-border nodes of a patch (subgraph_utils.get_border_nodes, subgraph_utils.py:126-144, with
  * its id-1 / node-order indexing quirk): out_flag[i] = 1 iff patch_nodes[i] is a border node.

@@ -315,12 +315,233 @@ __global__ __launch_bounds__(64) void triangular_walks_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Workgroup-per-walk variant (graphs whose id range fits an LDS bitmap, ~1.1 M ids).
+// The wavefront-per-walk kernel above spends a step on a hub in (a) streaming the hub's list 64
+// entries at a time on ONE wavefront and (b) a binary search in the previous node's sorted list
+// per entry -- ~13 dependent global loads per 64 entries.  Here the 16 wavefronts of a 1024-thread
+// workgroup share the list (chunks of 64 dealt round-robin), and "adjacent to prev?" is one bit
+// test in an LDS bitmap that holds N(prev): when the walk moves on, the bits of the old N(prev)
+// are un-set and those of the new one set by two more cooperative, coalesced streams.  The walks
+// are few (patches x walks per patch), so giving each a whole CU costs nothing.
+// Same tape, same draws, same results as the wavefront kernel (tests compare both).
+// ---------------------------------------------------------------------------------------------
+#define WKB_THREADS 1024
+#define WKB_LDS_BYTES (136 * 1024)
+
+__device__ static inline void wkb_bits(uint32_t* bm, const int32_t* __restrict__ list, int32_t n, bool set, int tid) {
+    for (int32_t i = tid; i < n; i += WKB_THREADS) {
+        const int32_t w = list[i];
+        if (set) atomicOr(&bm[w >> 5], 1u << (w & 31)); else atomicAnd(&bm[w >> 5], ~(1u << (w & 31)));
+    }
+}
+
+// workgroup-cooperative build of a membership hash; returns the longest probe chain (uniform)
+__device__ static inline int wkb_build_hash(int32_t* h, const int32_t* a, int32_t n, int tid, int32_t* s_red) {
+    for (int i = tid; i < WK_HASH; i += WKB_THREADS) h[i] = 0;
+    if (tid == 0) *s_red = 0;
+    __syncthreads();
+    int chain = 0;
+    for (int i = tid; i < n; i += WKB_THREADS) {
+        const int32_t v = a[i];
+        uint32_t b = sgnn_hash32((uint32_t)v) >> (32 - WK_HASH_BITS);
+        int c = 0;
+        while (true) {
+            ++c;
+            const int32_t old = atomicCAS(&h[b], 0, v);
+            if (old == 0 || old == v) break;
+            b = (b + 1) & (WK_HASH - 1);
+        }
+        chain = c > chain ? c : chain;
+    }
+    if (chain) atomicMax(s_red, chain);
+    __syncthreads();
+    return *s_red;
+}
+
+// pass 1 on the whole workgroup: classify the valid neighbours of v, keep the per-chunk ballots
+__device__ static inline void wkb_count(const WalkCtx& c, int32_t v, bool has_prev, const uint32_t* bm, int tid,
+                                        int32_t& nt, int32_t& nn, uint64_t* s_tri, uint64_t* s_non, int32_t* s_cnt) {
+    const int lane = tid & 63, wave = tid >> 6;
+    const int64_t r0 = c.rowptr[v], r1 = c.rowptr[v + 1];
+    const int64_t n_chunks = (r1 - r0 + 63) / 64;
+    if (tid == 0) { s_cnt[0] = 0; s_cnt[1] = 0; }
+    __syncthreads();
+    int32_t lt = 0, ln = 0;
+    for (int64_t ch = wave; ch < n_chunks; ch += WKB_THREADS / 64) {
+        const int64_t e = r0 + ch * 64 + lane;
+        bool ok = false, tri = false;
+        if (e < r1) {
+            const int32_t w = c.col[e];
+            ok = walk_valid(c, w);
+            if (ok && has_prev) tri = (bm[w >> 5] >> (w & 31)) & 1u;
+        }
+        const uint64_t mt = __ballot(ok && tri), mn = __ballot(ok && !tri);
+        if (ch < WK_CHUNKS && lane == 0) { s_tri[ch] = mt; s_non[ch] = mn; }
+        lt += __popcll(mt);
+        ln += __popcll(mn);
+    }
+    if (lane == 0 && (lt | ln)) { atomicAdd(&s_cnt[0], lt); atomicAdd(&s_cnt[1], ln); }
+    __syncthreads();
+    nt = s_cnt[0];
+    nn = s_cnt[1];
+}
+
+// pass 2: the pick-th valid neighbour of v in the wanted class (adjacency order) -> *s_next
+__device__ static inline int32_t wkb_pick(const WalkCtx& c, int32_t v, bool has_prev, const uint32_t* bm, bool want_tri,
+                                          int32_t pick, int tid, const uint64_t* s_tri, const uint64_t* s_non, int32_t* s_next) {
+    const int lane = tid & 63;
+    const int64_t r0 = c.rowptr[v], r1 = c.rowptr[v + 1];
+    const int64_t n_chunks = (r1 - r0 + 63) / 64;
+    if (tid < 64) {
+        if (n_chunks <= WK_CHUNKS) {
+            // lane l owns chunks [l*per, (l+1)*per): popcount them, scan over the wave, the owner of
+            // the crossing walks its chunks
+            const uint64_t* s = want_tri ? s_tri : s_non;
+            const int per = (int)((n_chunks + 63) / 64);
+            const int c0 = lane * per, c1 = (c0 + per < n_chunks) ? c0 + per : (int)n_chunks;
+            int32_t mine = 0;
+            for (int ch = c0; ch < c1; ++ch) mine += __popcll(s[ch]);
+            int32_t incl = mine;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const int32_t t = __shfl_up(incl, d); if (lane >= d) incl += t; }
+            const int32_t excl = incl - mine;
+            if (pick >= excl && pick < incl) {
+                int32_t seen = excl;
+                for (int ch = c0; ch < c1; ++ch) {
+                    uint64_t m = s[ch];
+                    const int32_t cnt = __popcll(m);
+                    if (seen + cnt > pick) {
+                        int k = pick - seen;
+                        while (k-- > 0) m &= m - 1;
+                        *s_next = c.col[r0 + (int64_t)ch * 64 + (__ffsll((unsigned long long)m) - 1)];
+                        break;
+                    }
+                    seen += cnt;
+                }
+            }
+        } else {
+            // list longer than the ballot cache: wavefront 0 re-classifies it in order
+            int32_t seen = 0, res = 0;
+            bool done = false;
+            for (int64_t base = r0; base < r1 && !done; base += 64) {
+                const int64_t e = base + lane;
+                bool hit = false;
+                int32_t w = 0;
+                if (e < r1) {
+                    w = c.col[e];
+                    if (walk_valid(c, w)) {
+                        const bool tri = has_prev ? (((bm[w >> 5] >> (w & 31)) & 1u) != 0) : false;
+                        hit = (tri == want_tri);
+                    }
+                }
+                const uint64_t m = __ballot(hit);
+                const int32_t cnt = __popcll(m);
+                if (seen + cnt > pick) {
+                    const int32_t rank = __popcll(m & ((1ull << lane) - 1ull));
+                    const uint64_t sel = __ballot(hit && (seen + rank == pick));
+                    res = __shfl(w, __ffsll((unsigned long long)sel) - 1);
+                    done = true;
+                }
+                seen += cnt;
+            }
+            if (lane == 0) *s_next = res;
+        }
+    }
+    __syncthreads();
+    return *s_next;
+}
+
+__global__ __launch_bounds__(WKB_THREADS) void triangular_walks_wg_kernel(
+    const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col, const int32_t* __restrict__ col_sorted,
+    const int32_t* __restrict__ node_order, int64_t n_nodes,
+    const int64_t* __restrict__ patch_ptr, const int32_t* __restrict__ patch_nodes,
+    const int64_t* __restrict__ inb_ptr, const int32_t* __restrict__ inb_nodes,
+    int mode, int64_t n_items, int64_t walks_per_patch, int64_t walk_len, double beta,
+    uint64_t h0, int64_t* __restrict__ out, int64_t words)
+{
+    extern __shared__ uint32_t s_adj[];                    // bitmap over node ids: N(prev)
+    __shared__ uint64_t s_tri[WK_CHUNKS], s_non[WK_CHUNKS];
+    __shared__ int32_t s_hp[WK_HASH], s_hi[WK_HASH];
+    __shared__ int32_t s_cnt[2], s_next, s_red;
+    const int tid = threadIdx.x;
+    for (int64_t i = tid; i < words; i += WKB_THREADS) s_adj[i] = 0;
+    __syncthreads();
+    for (int64_t item = blockIdx.x; item < n_items; item += gridDim.x) {
+        int64_t* o = out + item * walk_len;
+        for (int64_t t = tid; t < walk_len; t += WKB_THREADS) o[t] = 0;
+        WalkCtx c;
+        c.rowptr = rowptr; c.col = col; c.col_sorted = col_sorted; c.mode = mode;
+        c.patch = nullptr; c.n_patch = 0; c.inb = nullptr; c.n_inb = 0;
+        c.hpatch = nullptr; c.hinb = nullptr; c.pp = 0; c.pi = 0;
+        const uint64_t h1 = sgnn_tape_h1(h0, (uint64_t)item);
+        uint64_t j = 0;
+        int32_t prev;
+        __syncthreads();                            // previous item's LDS tables are no longer read
+        if (mode == 0) {
+            prev = node_order[sgnn_choice_index(h1, j++, (uint32_t)n_nodes)];          // aps:70
+        } else {
+            const int64_t p = item / walks_per_patch;
+            c.patch = patch_nodes + patch_ptr[p];
+            c.n_patch = (int32_t)(patch_ptr[p + 1] - patch_ptr[p]);
+            if (c.n_patch == 0) continue;                                              // aps:134-135
+            if (c.n_patch <= WK_HASH_MAX) { c.pp = wkb_build_hash(s_hp, c.patch, c.n_patch, tid, &s_red); c.hpatch = s_hp; }
+            if (mode == 1) {
+                prev = c.patch[sgnn_choice_index(h1, j++, (uint32_t)c.n_patch)];      // aps:70
+            } else {
+                c.inb = inb_nodes + inb_ptr[p];
+                c.n_inb = (int32_t)(inb_ptr[p + 1] - inb_ptr[p]);
+                if (c.n_inb == 0) continue;        // reference raises ValueError here (aps:78)
+                if (c.n_inb <= WK_HASH_MAX) { c.pi = wkb_build_hash(s_hi, c.inb, c.n_inb, tid, &s_red); c.hinb = s_hi; }
+                prev = c.inb[sgnn_choice_index(h1, j++, (uint32_t)c.n_inb)];          // aps:78
+            }
+        }
+        if (walk_len < 1) continue;
+        __syncthreads();                            // zero fill above precedes the thread-0 writes
+        if (tid == 0) o[0] = prev;
+        int32_t nt, nn;
+        wkb_count(c, prev, false, s_adj, tid, nt, nn, s_tri, s_non, s_cnt);             // aps:72,79
+        if (nn == 0 || walk_len < 2) continue;                                          // aps:83-84
+        int32_t curr = wkb_pick(c, prev, false, s_adj, false, (int32_t)sgnn_choice_index(h1, j++, (uint32_t)nn), tid,
+                                s_tri, s_non, &s_next);                                  // aps:74,80
+        if (tid == 0) o[1] = curr;
+        // the bitmap holds N(prev) from here on
+        wkb_bits(s_adj, col + rowptr[prev], (int32_t)(rowptr[prev + 1] - rowptr[prev]), true, tid);
+        __syncthreads();
+        for (int64_t step = 2; step < walk_len; ++step) {
+            wkb_count(c, curr, true, s_adj, tid, nt, nn, s_tri, s_non, s_cnt);          // aps:35-45
+            if (nt + nn == 0) break;                                                     // aps:94
+            bool want_tri;
+            if (nt == 0) want_tri = false;                                               // aps:97-98
+            else if (nn == 0) want_tri = true;                                           // aps:99-100
+            else want_tri = (sgnn_uniform01(h1, j++) <= beta);                           // aps:102
+            const int32_t pick = (int32_t)sgnn_choice_index(h1, j++, (uint32_t)(want_tri ? nt : nn));
+            const int32_t nxt = wkb_pick(c, curr, true, s_adj, want_tri, pick, tid, s_tri, s_non, &s_next);
+            if (tid == 0) o[step] = nxt;
+            // N(prev) out, N(curr) in: curr becomes prev
+            wkb_bits(s_adj, col + rowptr[prev], (int32_t)(rowptr[prev + 1] - rowptr[prev]), false, tid);
+            __syncthreads();
+            if (step + 1 < walk_len) wkb_bits(s_adj, col + rowptr[curr], (int32_t)(rowptr[curr + 1] - rowptr[curr]), true, tid);
+            __syncthreads();
+            prev = (step + 1 < walk_len) ? curr : 0;
+            curr = nxt;
+        }
+        // leave the bitmap clean for the next item of this workgroup
+        if (prev) wkb_bits(s_adj, col + rowptr[prev], (int32_t)(rowptr[prev + 1] - rowptr[prev]), false, tid);
+        __syncthreads();
+    }
+}
+
+static int g_walks_force_wave = 0;
+/* test hook: 1 = always take the wavefront-per-walk kernel, 0 = pick by graph size */
+extern "C" int sgnn_walks_force_wave(int on) { const int old = g_walks_force_wave; g_walks_force_wave = on; return old; }
+
 extern "C" int sgnn_triangular_walks(const int64_t* rowptr, const int32_t* col, const int32_t* col_sorted, int64_t nnz,
                                      const int32_t* node_order, int64_t n_nodes,
                                      const int64_t* patch_ptr, const int32_t* patch_nodes,
                                      const int64_t* inb_ptr, const int32_t* inb_nodes,
                                      int mode, int64_t n_items, int64_t walks_per_patch, int64_t walk_len, double beta,
-                                     uint64_t seed, uint64_t stream_id, int64_t* out, void* stream)
+                                     uint64_t seed, uint64_t stream_id, int64_t max_id, int64_t* out, void* stream)
 {
     if (!rowptr || !col || !col_sorted || !out || n_items < 0 || walk_len < 0 || mode < 0 || mode > 2)
         return SGNN_ERR_BAD_ARG;
@@ -329,6 +550,21 @@ extern "C" int sgnn_triangular_walks(const int64_t* rowptr, const int32_t* col, 
     if (mode == 2 && (!inb_ptr || !inb_nodes)) return SGNN_ERR_BAD_ARG;
     if (nnz >= (1ll << 31)) return SGNN_ERR_NNZ_TOO_LARGE;
     if (n_items == 0 || walk_len == 0) return SGNN_OK;
+    const int64_t words = (max_id + 32) / 32;
+    if (max_id > 0 && words * 4 <= WKB_LDS_BYTES && !g_walks_force_wave) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute((const void*)triangular_walks_wg_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      WKB_LDS_BYTES);
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(triangular_walks_wg_kernel, dim3((int)(n_items < 2048 ? n_items : 2048)), dim3(WKB_THREADS),
+                           (size_t)(words * 4), (hipStream_t)stream, rowptr, col, col_sorted, node_order, n_nodes, patch_ptr,
+                           patch_nodes, inb_ptr, inb_nodes, mode, n_items, walks_per_patch, walk_len, beta,
+                           sgnn_tape_h0(seed, stream_id), out, words);
+        SGNN_CHECK_LAUNCH();
+        return SGNN_OK;
+    }
     hipLaunchKernelGGL(triangular_walks_kernel, dim3((int)(n_items < 256 * 32 ? n_items : 256 * 32)), dim3(64), 0, (hipStream_t)stream,
                        rowptr, col, col_sorted, node_order, n_nodes, patch_ptr, patch_nodes, inb_ptr, inb_nodes,
                        mode, n_items, walks_per_patch, walk_len, beta, sgnn_tape_h0(seed, stream_id), out);

@@ -323,7 +323,7 @@ def triangular_walks(g, mode, n_items, walk_len, beta, seed, stream_id, patches=
                                     _ptr(in_border.ptr) if in_border else None,
                                     _ptr(in_border.nodes) if in_border else None,
                                     mode, n_items, walks_per_patch, walk_len, float(beta), seed, stream_id,
-                                    _ptr(out), _stream()), 'sgnn_triangular_walks')
+                                    g.max_id, _ptr(out), _stream()), 'sgnn_triangular_walks')
     return out
 
 

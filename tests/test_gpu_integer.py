@@ -314,7 +314,18 @@ def test_choice_golden(golden):
 
 # ---- a1-a3 walks --------------------------------------------------------------------------
 
-def test_walks_golden(golden):
+@pytest.fixture(params=['workgroup', 'wavefront'])
+def walk_kernel(request):
+    """Both walk kernels: a workgroup per walk with the LDS adjacency bitmap (the default when the
+    id range fits) and a wavefront per walk with binary searches."""
+    from subgnn_amd import _lib
+    lib = _lib.load()
+    lib.sgnn_walks_force_wave(1 if request.param == 'wavefront' else 0)
+    yield request.param
+    lib.sgnn_walks_force_wave(0)
+
+
+def test_walks_golden(golden, walk_kernel):
     ops = _ops()
     G, dg = _graphs(golden)
     hp, seed = golden.hp, golden.seed
@@ -340,7 +351,7 @@ def test_walks_golden(golden):
     assert np.array_equal(bw.view(n, W, Tn).cpu().numpy(), golden['g5_bor_walks'])
 
 
-def test_walks_random_vs_oracle():
+def test_walks_random_vs_oracle(walk_kernel):
     ops = _ops()
     G = _rand_graph(400, 4, 9)
     dg = _dev_graph(G)
@@ -356,6 +367,25 @@ def test_walks_random_vs_oracle():
         got = ops.triangular_walks(dg, 1 if inside else 2, 160, 12, 0.4, 123, st, patches=vr, in_border=ir,
                                    walks_per_patch=4).view(40, 4, 12).cpu().numpy()
         assert np.array_equal(got, ref)
+
+
+def test_walks_hubs_both_kernels_agree():
+    """Long walks over hubs (lists longer than one 64-entry chunk per wavefront, several workgroup
+    passes over the items): the two kernels return the same walks."""
+    from subgnn_amd import synthetic, _lib
+    ops = _ops()
+    n = 30000
+    rowptr, col = synthetic.sorted_csr(synthetic.barabasi_albert_edges(n, 12, seed=4), n)
+    dg = ops.DeviceGraph(rowptr, col, np.arange(1, n + 1, dtype=np.int32), DEV)
+    lib = _lib.load()
+    out = {}
+    try:
+        for force in (0, 1):
+            lib.sgnn_walks_force_wave(force)
+            out[force] = ops.triangular_walks(dg, 0, 3000, 40, 0.65, 5, T.stream_id(T.STREAM_STRUCT_PATCH))
+    finally:
+        lib.sgnn_walks_force_wave(0)
+    assert torch.equal(out[0], out[1]) and int((out[0] != 0).sum()) > 3000 * 20
 
 
 # ---- a9 shortest-path similarities --------------------------------------------------------
