@@ -69,6 +69,16 @@ int sgnn_degree_sequence(const int64_t* rowptr, const int32_t* col, int64_t nnz,
 int sgnn_cc_labels(const int64_t* rowptr, const int32_t* col_sorted, int64_t nnz,
                    const int64_t* sub_ptr, const int32_t* sub_nodes, int64_t n_subgraphs,
                    int32_t* out_label, void* stream);
+/* labels -> the padded component tensor of SubGNN.initialize_cc_ids (SubGNN/SubGNN.py:575-607) in
+ * canonical order: components by the position of their first node, nodes in subgraph order,
+ * duplicates dropped, PAD = 0.  Two steps: _stats gives, per subgraph, the number of components and
+ * the longest one (the caller takes the maxima C and L and zero-fills out (n_subgraphs, C, L) int64);
+ * sgnn_cc_compact writes the ids.  max_sub_len: longest subgraph (<= 2048; 0 = unknown). */
+int sgnn_cc_compact_stats(const int64_t* sub_ptr, const int32_t* sub_nodes, const int32_t* labels,
+                          int64_t n_subgraphs, int64_t max_sub_len, int32_t* out_n_components,
+                          int32_t* out_longest, void* stream);
+int sgnn_cc_compact(const int64_t* sub_ptr, const int32_t* sub_nodes, const int32_t* labels,
+                    int64_t n_subgraphs, int64_t max_sub_len, int64_t C, int64_t L, int64_t* out, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * a8  k-hop border of a component, and the hop level of each border node.

@@ -185,7 +185,7 @@ class SubGNN(nn.Module):
         by first node; nodes in subgraph order (the reference's is CPython-set order)."""
         subs = ops.Ragged.from_lists(subgraph_ids, self.device)
         labels = ops.cc_labels(self.networkx_graph, subs)
-        return subgraph_utils.components_from_labels(subs.ptr, subs.nodes, labels)
+        return subgraph_utils.components_from_labels(subs.ptr, subs.nodes, labels, subs.max_len)
 
     def _table(self):
         """The embedding table as the fused ops read it: inside ``forward`` a tapped alias whose

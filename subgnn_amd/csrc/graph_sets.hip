@@ -80,6 +80,147 @@ extern "C" int sgnn_cc_labels(const int64_t* rowptr, const int32_t* col_sorted, 
 }
 
 // ---------------------------------------------------------------------------------------------
+// a7 (second half)  labels -> the padded (S, C, L) component tensor of SubGNN.initialize_cc_ids
+// (SubGNN/SubGNN.py:575-607) in canonical order: components by the position of their first node,
+// nodes in subgraph order, duplicates of a node dropped (first position kept).
+// One wavefront per subgraph, two launches of the same code: a statistics pass (number of
+// components, longest component -> the host takes the maxima for C and L) and the write pass.
+// Rank of a component = roots at smaller positions (ballot + popcount prefix); position inside a
+// component = kept nodes of the same label before me (64 broadcast steps per 64-node chunk plus a
+// running per-label counter in LDS).  Subgraphs of up to 64 nodes need no hash; longer ones find
+// duplicates through an LDS hash keyed by node id that keeps the smallest position.
+// ---------------------------------------------------------------------------------------------
+#define CCK_HASH 4096
+
+template <bool BIG, bool WRITE>
+__global__ __launch_bounds__(64) void cc_compact_kernel(
+    const int64_t* __restrict__ sub_ptr, const int32_t* __restrict__ sub_nodes, const int32_t* __restrict__ labels,
+    int64_t n_sub, int64_t C, int64_t L, int32_t* __restrict__ out_ncc, int32_t* __restrict__ out_maxlen,
+    int64_t* __restrict__ out)
+{
+    constexpr int NMAX = BIG ? CC_MAX : 64;
+    __shared__ int32_t s_rank[NMAX], s_cnt[NMAX];
+    __shared__ int32_t s_hk[BIG ? CCK_HASH : 1], s_hv[BIG ? CCK_HASH : 1];
+    const int lane = threadIdx.x;
+    const uint64_t lt = (1ull << lane) - 1ull;
+    for (int64_t s = blockIdx.x; s < n_sub; s += gridDim.x) {
+        const int64_t beg = sub_ptr[s];
+        const int n = (int)(sub_ptr[s + 1] - beg);
+        if (n <= 0 || n > NMAX || (BIG && n <= 64)) {
+            if (!WRITE && n <= 0) { if (lane == 0) { out_ncc[s] = 0; out_maxlen[s] = 0; } }
+            continue;                                           // the other instantiation owns it
+        }
+        for (int i = lane; i < n; i += 64) s_cnt[i] = 0;
+        if (BIG) {
+            for (int i = lane; i < CCK_HASH; i += 64) { s_hk[i] = 0; s_hv[i] = 0x7fffffff; }
+            __syncthreads();
+            for (int i = lane; i < n; i += 64) {
+                const int32_t v = sub_nodes[beg + i];
+                uint32_t h = sgnn_hash32((uint32_t)v) >> 20;
+                while (true) {
+                    const int32_t old = atomicCAS(&s_hk[h], 0, v);
+                    if (old == 0 || old == v) { atomicMin(&s_hv[h], i); break; }
+                    h = (h + 1) & (CCK_HASH - 1);
+                }
+            }
+        }
+        __syncthreads();
+        int running = 0, maxlen = 0;
+        // roots and their ranks
+        for (int c0 = 0; c0 < n; c0 += 64) {
+            const int i = c0 + lane;
+            int32_t v = 0, lab = -1;
+            if (i < n) { v = sub_nodes[beg + i]; lab = labels[beg + i]; }
+            const bool root = (i < n) && lab == i;              // a root is the first position of its node
+            const uint64_t m = __ballot(root);
+            if (root) s_rank[i] = running + __popcll(m & lt);
+            running += __popcll(m);
+        }
+        __syncthreads();
+        for (int c0 = 0; c0 < n; c0 += 64) {
+            const int i = c0 + lane;
+            int32_t v = 0, lab = -1;
+            if (i < n) { v = sub_nodes[beg + i]; lab = labels[beg + i]; }
+            bool keep = i < n;
+            if (BIG) {
+                if (keep) {
+                    uint32_t h = sgnn_hash32((uint32_t)v) >> 20;
+                    while (s_hk[h] != v) h = (h + 1) & (CCK_HASH - 1);
+                    keep = (s_hv[h] == i);
+                }
+            } else {
+                for (int l = 0; l < n; ++l) { const int32_t vl = __shfl(v, l); if (l < lane && vl == v) keep = false; }
+            }
+            const int32_t my = keep ? lab : -1 - lane;          // distinct sentinels for dropped lanes
+            int before = 0;
+            bool later = false;
+            const int lim = (n - c0) < 64 ? (n - c0) : 64;
+            for (int l = 0; l < lim; ++l) {
+                const int32_t o = __shfl(my, l);
+                before += (o == my && l < lane) ? 1 : 0;
+                later = later || (o == my && l > lane);
+            }
+            int within = 0;
+            if (keep) within = s_cnt[lab] + before;
+            if (keep && !later) s_cnt[lab] = within + 1;         // last of its component in this chunk
+            if (keep) {
+                maxlen = within + 1 > maxlen ? within + 1 : maxlen;
+                if (WRITE) out[((int64_t)s * C + s_rank[lab]) * L + within] = (int64_t)v;
+            }
+        }
+        if (!WRITE) {
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) { const int o = __shfl_xor(maxlen, d); maxlen = o > maxlen ? o : maxlen; }
+            if (lane == 0) { out_ncc[s] = running; out_maxlen[s] = maxlen; }
+        }
+        __syncthreads();
+    }
+}
+
+static int cc_compact_launch(bool write, const int64_t* sub_ptr, const int32_t* sub_nodes, const int32_t* labels,
+                             int64_t n_sub, int64_t max_sub_len, int64_t C, int64_t L, int32_t* out_ncc,
+                             int32_t* out_maxlen, int64_t* out, void* stream)
+{
+    if (!sub_ptr || !sub_nodes || !labels || n_sub < 0) return SGNN_ERR_BAD_ARG;
+    if (max_sub_len > CC_MAX) return SGNN_ERR_SET_TOO_LARGE;
+    if (n_sub == 0) return SGNN_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = (int)(n_sub < 256 * 64 ? n_sub : 256 * 64);
+    if (write) {
+        hipLaunchKernelGGL((cc_compact_kernel<false, true>), dim3(grid), dim3(64), 0, st, sub_ptr, sub_nodes, labels, n_sub,
+                           C, L, out_ncc, out_maxlen, out);
+        if (max_sub_len > 64 || max_sub_len <= 0)
+            hipLaunchKernelGGL((cc_compact_kernel<true, true>), dim3(grid < 2048 ? grid : 2048), dim3(64), 0, st, sub_ptr,
+                               sub_nodes, labels, n_sub, C, L, out_ncc, out_maxlen, out);
+    } else {
+        hipLaunchKernelGGL((cc_compact_kernel<false, false>), dim3(grid), dim3(64), 0, st, sub_ptr, sub_nodes, labels,
+                           n_sub, C, L, out_ncc, out_maxlen, out);
+        if (max_sub_len > 64 || max_sub_len <= 0)
+            hipLaunchKernelGGL((cc_compact_kernel<true, false>), dim3(grid < 2048 ? grid : 2048), dim3(64), 0, st, sub_ptr,
+                               sub_nodes, labels, n_sub, C, L, out_ncc, out_maxlen, out);
+    }
+    SGNN_CHECK_LAUNCH();
+    return SGNN_OK;
+}
+
+extern "C" int sgnn_cc_compact_stats(const int64_t* sub_ptr, const int32_t* sub_nodes, const int32_t* labels,
+                                     int64_t n_subgraphs, int64_t max_sub_len, int32_t* out_n_components,
+                                     int32_t* out_longest, void* stream)
+{
+    if (!out_n_components || !out_longest) return SGNN_ERR_BAD_ARG;
+    return cc_compact_launch(false, sub_ptr, sub_nodes, labels, n_subgraphs, max_sub_len, 0, 0, out_n_components,
+                             out_longest, nullptr, stream);
+}
+
+extern "C" int sgnn_cc_compact(const int64_t* sub_ptr, const int32_t* sub_nodes, const int32_t* labels,
+                               int64_t n_subgraphs, int64_t max_sub_len, int64_t C, int64_t L, int64_t* out, void* stream)
+{
+    if (!out || C < 1 || L < 1) return SGNN_ERR_BAD_ARG;
+    return cc_compact_launch(true, sub_ptr, sub_nodes, labels, n_subgraphs, max_sub_len, C, L, nullptr, nullptr, out,
+                             stream);
+}
+
+// ---------------------------------------------------------------------------------------------
 // a8  k-hop border (reference SubGNN/subgraph_utils.py:146-176), optionally fused with the
 // neighbourhood-border anchor draw (a4, reference anchor_patch_samplers.py:184-194).
 // One workgroup per component, level-synchronous BFS.  The visited bitmap over node ids lives in

@@ -86,7 +86,7 @@ def prepare_sparse(model, split='train', timer=None):
         else getattr(model, '_subs_' + split)
     setattr(model, '_subs_' + split, subs)
     labels = ops.cc_labels(g, subs)
-    cc_ids = subgraph_utils.components_from_labels(subs.ptr, subs.nodes, labels)
+    cc_ids = subgraph_utils.components_from_labels(subs.ptr, subs.nodes, labels, subs.max_len)
     setattr(model, split + '_cc_ids', cc_ids)
     S, C, Lc = cc_ids.shape
     cc_sets = ops.Ragged.from_padded(cc_ids.reshape(S * C, Lc))

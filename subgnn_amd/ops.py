@@ -168,6 +168,23 @@ def cc_labels(g, subs):
     return out
 
 
+def cc_compact(sub_ptr, sub_nodes, labels, max_sub_len=0):
+    """cc labels -> the padded (S, C, L) int64 component tensor of initialize_cc_ids, canonical order
+    (components by their first node's position, nodes in subgraph order, duplicates dropped)."""
+    lib = _lib.load()
+    _req(labels, torch.int32, 'labels')
+    S = sub_ptr.numel() - 1
+    dev = sub_ptr.device
+    stats = torch.zeros((2, max(S, 1)), dtype=torch.int32, device=dev)
+    check(lib.sgnn_cc_compact_stats(_ptr(sub_ptr), _ptr(sub_nodes), _ptr(labels), S, int(max_sub_len), _ptr(stats[0]),
+                                    _ptr(stats[1]), _stream()), 'sgnn_cc_compact_stats')
+    C, L = (max(int(v), 1) for v in stats.amax(dim=1).tolist())           # the one host round trip
+    out = torch.zeros((S, C, L), dtype=torch.int64, device=dev)
+    check(lib.sgnn_cc_compact(_ptr(sub_ptr), _ptr(sub_nodes), _ptr(labels), S, int(max_sub_len), C, L, _ptr(out),
+                              _stream()), 'sgnn_cc_compact')
+    return out
+
+
 _KHOP_WS = {}
 
 

@@ -111,48 +111,8 @@ def trim_zero_columns(x):
     return flat[:, keep].reshape(B, C, -1)
 
 
-def components_from_labels(sub_ptr, sub_nodes, labels):
+def components_from_labels(sub_ptr, sub_nodes, labels, max_sub_len=0):
     """cc labels (smallest position per component) -> padded (S, C, L) int64 component tensor
     in canonical order: components by their first node's position, nodes in subgraph order
-    (duplicates dropped).  Pure index plumbing on the device."""
-    dev = sub_ptr.device
-    S = sub_ptr.numel() - 1
-    lens = sub_ptr[1:] - sub_ptr[:-1]
-    tot = int(sub_ptr[-1].item())
-    if tot == 0:
-        return torch.zeros((S, 1, 1), dtype=torch.int64, device=dev)
-    sub_of = torch.repeat_interleave(torch.arange(S, device=dev), lens)
-    posn = torch.arange(tot, device=dev) - sub_ptr[:-1][sub_of]
-    lab = labels[:tot].to(torch.int64)
-    nodes = sub_nodes[:tot].to(torch.int64)
-    # drop duplicates of a node inside a subgraph (keep the first position)
-    key = sub_of * (1 << 32) + nodes
-    skey, sidx = torch.sort(key, stable=True)
-    first = torch.ones(tot, dtype=torch.bool, device=dev)
-    first[1:] = skey[1:] != skey[:-1]
-    keep = torch.zeros(tot, dtype=torch.bool, device=dev)
-    keep[sidx[first]] = True
-    is_root = (lab == posn) & keep
-    # component rank inside its subgraph = number of roots at smaller positions
-    root_cum = torch.cumsum(is_root.to(torch.int64), 0)
-    root_before_sub = torch.zeros(S, dtype=torch.int64, device=dev)
-    starts = sub_ptr[:-1]
-    nonempty = lens > 0
-    root_before_sub[nonempty] = root_cum[starts[nonempty]] - is_root[starts[nonempty]].to(torch.int64)
-    rank_at_root = root_cum - 1 - root_before_sub[sub_of]
-    comp_rank = rank_at_root[starts[sub_of] + lab]                       # rank of my component
-    n_cc = torch.zeros(S, dtype=torch.int64, device=dev)
-    n_cc.index_add_(0, sub_of, is_root.to(torch.int64))
-    C = max(int(n_cc.max().item()), 1)
-    # position inside the component = number of kept nodes of the same component before me
-    ckey = (sub_of * C + comp_rank)
-    ckey_k = ckey[keep]
-    order = torch.sort(ckey_k, stable=True)[1]
-    sorted_key = ckey_k[order]
-    idx = torch.arange(sorted_key.numel(), device=dev)
-    start_idx = torch.searchsorted(sorted_key, sorted_key, right=False)      # first index of my group
-    within = idx - start_idx
-    L = int(within.max().item()) + 1
-    out = torch.zeros((S * C, L), dtype=torch.int64, device=dev)
-    out[sorted_key, within] = nodes[keep][order]
-    return out.view(S, C, L)
+    (duplicates dropped) -- sgnn_cc_compact (one statistics launch, one write launch)."""
+    return ops.cc_compact(sub_ptr, sub_nodes, labels, max_sub_len)

@@ -143,6 +143,57 @@ def test_cc_labels_random():
         assert _labels_to_sets(subs[s], lab[s]) == ref
 
 
+def test_components_from_labels(golden):
+    """labels (smallest position per component) -> padded (S,C,L) tensor in canonical order (HIP compaction)."""
+    _ops()
+    from subgnn_amd.subgraph_utils import components_from_labels
+    G, _dg = _graphs(golden)
+    subs = golden.ragged('subgraphs_train', 0)
+    subs[0] = subs[0] + subs[0][:2]                         # duplicates must collapse
+    ptr = np.zeros(len(subs) + 1, dtype=np.int64)
+    flat, labels = [], []
+    for i, s in enumerate(subs):
+        comps = IH.connected_components(G, s)
+        where = {}
+        for c in comps:
+            first = min(s.index(v) for v in c)
+            for v in c:
+                where[v] = first
+        flat += s
+        labels += [where[v] for v in s]
+        ptr[i + 1] = ptr[i] + len(s)
+    out = components_from_labels(torch.from_numpy(ptr).to(DEV), torch.tensor(flat, dtype=torch.int32, device=DEV),
+                                 torch.tensor(labels, dtype=torch.int32, device=DEV)).cpu().numpy()
+    for i, s in enumerate(subs):
+        ref = [c for c in IH.connected_components(G, s)]
+        got = [[int(v) for v in row if v != 0] for row in out[i] if row[0] != 0]
+        assert got == ref                                   # canonical order == the oracle's canonical order
+
+def test_cc_compact_large_and_duplicates():
+    """Subgraphs beyond 64 nodes (hash-based duplicate detection, several 64-node chunks per
+    component), many components, duplicates, an empty subgraph: cc_labels + cc_compact == the oracle."""
+    ops = _ops()
+    from subgnn_amd.subgraph_utils import components_from_labels
+    G = _rand_graph(2500, 2, 13)
+    dg = _dev_graph(G)
+    rng = np.random.default_rng(2)
+    subs = []
+    for i in range(60):
+        n = int(rng.integers(1, 400)) if i % 3 else int(rng.integers(1, 40))
+        s = rng.integers(1, G.max_id() + 1, n).tolist()
+        if i % 4 == 0:
+            s = s + s[:5]
+        subs.append(s)
+    subs[7] = []
+    r = ops.Ragged.from_lists(subs, DEV)
+    out = components_from_labels(r.ptr, r.nodes, ops.cc_labels(dg, r), r.max_len).cpu().numpy()
+    assert out.shape[0] == 60
+    for i, s in enumerate(subs):
+        ref = IH.connected_components(G, s) if s else []
+        got = [[int(v) for v in row if v != 0] for row in out[i] if row[0] != 0]
+        assert got == ref, i
+
+
 # ---- a8 k-hop border ----------------------------------------------------------------------
 
 def test_khop_border_golden(golden):

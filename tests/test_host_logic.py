@@ -18,32 +18,6 @@ def test_networkx_order_csr_matches_reference_graph(golden):
     assert np.array_equal(order, golden['g1_node_order'])
 
 
-def test_components_from_labels(golden):
-    """labels (smallest position per component) -> padded (S,C,L) tensor, checked as sets."""
-    from subgnn_amd.subgraph_utils import components_from_labels
-    G = OG.from_edge_pairs([tuple(e) for e in golden['edge_list']])
-    subs = golden.ragged('subgraphs_train', 0)
-    subs[0] = subs[0] + subs[0][:2]                         # duplicates must collapse
-    ptr = np.zeros(len(subs) + 1, dtype=np.int64)
-    flat, labels = [], []
-    for i, s in enumerate(subs):
-        comps = IH.connected_components(G, s)
-        where = {}
-        for c in comps:
-            first = min(s.index(v) for v in c)
-            for v in c:
-                where[v] = first
-        flat += s
-        labels += [where[v] for v in s]
-        ptr[i + 1] = ptr[i] + len(s)
-    out = components_from_labels(torch.from_numpy(ptr), torch.tensor(flat, dtype=torch.int32),
-                                 torch.tensor(labels, dtype=torch.int32)).numpy()
-    for i, s in enumerate(subs):
-        ref = [c for c in IH.connected_components(G, s)]
-        got = [[int(v) for v in row if v != 0] for row in out[i] if row[0] != 0]
-        assert got == ref                                   # canonical order == the oracle's canonical order
-
-
 def test_read_subgraphs_and_state_dict_keys(tmp_path, tiny):
     """The dataset reader and the module's parameter names (checkpoint compatibility)."""
     from subgnn_amd import config
