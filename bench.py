@@ -139,15 +139,20 @@ def main():
         batch = hotpath.full_split_batch(model, 'train')
         out = model.training_step(batch, 0)
         timer.mark('forward')
-        model.backward(None, out['loss'], None, 0)
-        timer.mark('backward')
+        pending = None
         if dist:
             # the path's one exchange step: all-gather of the per-component channel embeddings
             # (every rank ends up with the (world * S * C, hid_dim) matrix of the global batch);
-            # DP training additionally all-reduces the gradients, one flat bucket
-            gathered = sdist.all_gather_rows(model._last_cc_embeds)
-            assert gathered.shape[0] == world * model._last_cc_embeds.shape[0]
+            # issued now, on RCCL's stream, so that it travels while backward computes
+            pending = sdist.all_gather_rows(model._last_cc_embeds, equal_rows=True, async_op=True)
+        model.backward(None, out['loss'], None, 0)
+        timer.mark('backward')
+        if dist:
+            # DP training additionally all-reduces the gradients (table gradient in place, the
+            # small ones in one flat bucket)
             sdist.all_reduce_gradients(params)
+            gathered = pending.wait()
+            assert gathered.shape[0] == world * model._last_cc_embeds.shape[0]
             timer.mark('collectives')
         torch.nn.utils.clip_grad_norm_(params, hp['grad_clip'])
         opt.step()

@@ -22,45 +22,84 @@ def shard_range(n_items, rank, world):
     return start, start + base + (1 if rank < rem else 0)
 
 
-def all_gather_rows(x):
+class _Pending:
+    """Handle of a collective in flight: ``wait()`` returns its result."""
+
+    def __init__(self, work, finish):
+        self._work, self._finish = work, finish
+
+    def wait(self):
+        if self._work is not None:
+            self._work.wait()
+            self._work = None
+        return self._finish()
+
+
+def all_gather_rows(x, equal_rows=False, async_op=False):
     """(rows_r, H) per rank -> (sum rows, H) on every rank, ranks in order.  Row counts may
     differ between ranks (last shard shorter): rows are padded to the maximum for the collective
-    and trimmed afterwards."""
+    and trimmed afterwards; ``equal_rows`` promises equal counts and skips that exchange (no host
+    round trip).  ``async_op``: returns a handle whose ``wait()`` gives the result -- the collective
+    runs on RCCL's stream while the caller keeps computing (the benchmark overlaps it with backward)."""
     if not is_initialized():
-        return x
+        return _Pending(None, lambda: x) if async_op else x
     world = dist.get_world_size()
-    n = torch.tensor([x.shape[0]], dtype=torch.int64, device=x.device)
-    sizes = [torch.zeros_like(n) for _ in range(world)]
-    dist.all_gather(sizes, n)
-    sizes = [int(s.item()) for s in sizes]
+    if equal_rows:
+        sizes = [x.shape[0]] * world
+    else:
+        n = torch.tensor([x.shape[0]], dtype=torch.int64, device=x.device)
+        got = [torch.zeros_like(n) for _ in range(world)]
+        dist.all_gather(got, n)
+        sizes = [int(s.item()) for s in got]
     m = max(sizes)
     if x.shape[0] < m:
         x = torch.cat([x, x.new_zeros((m - x.shape[0],) + tuple(x.shape[1:]))], 0)
+    x = x.contiguous()
     out = torch.empty((world * m,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+    parts = None
     try:
-        dist.all_gather_into_tensor(out, x.contiguous())
+        work = dist.all_gather_into_tensor(out, x, async_op=True)
     except (RuntimeError, NotImplementedError):               # backends without the flat form
         parts = [torch.empty_like(x) for _ in range(world)]
-        dist.all_gather(parts, x.contiguous())
-        out = torch.cat(parts, 0)
-    if all(s == m for s in sizes):
-        return out
-    return torch.cat([out[r * m:r * m + sizes[r]] for r in range(world)], 0)
+        work = dist.all_gather(parts, x, async_op=True)
+
+    def finish():
+        res = out if parts is None else torch.cat(parts, 0)
+        if all(s == m for s in sizes):
+            return res
+        return torch.cat([res[r * m:r * m + sizes[r]] for r in range(world)], 0)
+    pending = _Pending(work, finish)
+    return pending if async_op else pending.wait()
 
 
-def all_reduce_gradients(params, average=True):
-    """One flat all-reduce over every existing gradient (single bucket)."""
+def all_reduce_gradients(params, average=True, big_bytes=16 << 20):
+    """All-reduce of every existing gradient: tensors of at least ``big_bytes`` (the dense
+    embedding-table gradient: 256 MB at N = 1M, D = 64) are reduced in place, each as its own
+    collective; the small ones travel together in one flat bucket.  All collectives are issued
+    before any is waited for."""
     if not is_initialized():
         return
     grads = [p.grad for p in params if p.grad is not None]
     if not grads:
         return
-    flat = torch.cat([g.reshape(-1) for g in grads])
-    dist.all_reduce(flat)
+    world = dist.get_world_size()
+    big = [g for g in grads if g.numel() * g.element_size() >= big_bytes and g.is_contiguous()]
+    small = [g for g in grads if not any(g is b for b in big)]
+    works = [dist.all_reduce(g, async_op=True) for g in big]
+    flat = None
+    if small:
+        flat = torch.cat([g.reshape(-1) for g in small])
+        works.append(dist.all_reduce(flat, async_op=True))
+    for w in works:
+        w.wait()
     if average:
-        flat /= dist.get_world_size()
-    off = 0
-    for g in grads:
-        k = g.numel()
-        g.copy_(flat[off:off + k].view_as(g))
-        off += k
+        for g in big:
+            g /= world
+    if flat is not None:
+        if average:
+            flat /= world
+        off = 0
+        for g in small:
+            k = g.numel()
+            g.copy_(flat[off:off + k].view_as(g))
+            off += k

@@ -26,6 +26,13 @@ def _worker(rank, world, port, q):
     full = torch.arange(n * 3, dtype=torch.float32).view(n, 3)
     got = D.all_gather_rows(full[a:b].clone())                # uneven shards: 6 + 5 rows
     ok_gather = torch.equal(got, full)
+    # the benchmark's form: equal shards, issued asynchronously, waited for after other work
+    eq = torch.arange(8, dtype=torch.float32).view(4, 2) + 100 * rank
+    pending = D.all_gather_rows(eq, equal_rows=True, async_op=True)
+    busy = (eq @ eq.t()).sum()                                 # "backward" while the gather travels
+    ge = pending.wait()
+    ok_gather = ok_gather and torch.equal(ge, torch.cat([eq - 100 * rank + 100 * r for r in range(world)], 0)) \
+        and bool(torch.isfinite(busy))
     w = torch.nn.Linear(3, 2)
     torch.manual_seed(0)
     with torch.no_grad():
@@ -33,7 +40,7 @@ def _worker(rank, world, port, q):
         w.bias.zero_()
     loss = w(full[a:b]).sum()
     loss.backward()
-    D.all_reduce_gradients(list(w.parameters()))
+    D.all_reduce_gradients(list(w.parameters()), big_bytes=20)     # weight (24 B) in place, bias in the bucket
     ref = torch.nn.Linear(3, 2)
     with torch.no_grad():
         ref.weight.fill_(0.5)
