@@ -66,6 +66,8 @@ def parse():
     ap.add_argument('--subgraphs', type=int, default=50_000, help='subgraphs per GPU')
     ap.add_argument('--subgraph-nodes', type=int, default=20)
     ap.add_argument('--embed', type=int, default=64)
+    ap.add_argument('--embedding-dtype', choices=['fp32', 'fp16'], default='fp32',
+                    help="fp16: the fused kernels read an IEEE-half copy of the embedding table (fp32 accumulate, fp32 master)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-sample', type=int, default=1024)
     return ap.parse_args()
@@ -121,6 +123,7 @@ def main():
     emb = torch.randn(n, args.embed, device=dev)
     hp = dict(ALL_DENSITY_HP)
     hp['node_embed_size'] = args.embed
+    hp['embedding_dtype'] = args.embedding_dtype
     labels = torch.randint(0, 3, (len(subs),), generator=torch.Generator().manual_seed(rank))
     labels[:3] = torch.tensor([0, 1, 2])
     model = SubGNN.from_memory(hp, g, {'train': subs, 'val': [], 'test': []},
@@ -213,7 +216,9 @@ def main():
         'metric': 'subgraphs/sec fwd+bwd (all 3 channels on) + achieved HBM GB/s',
         'value': world * S * args.steps / elapsed, 'unit': 'subgraphs/s', 'n_gpus': world, 'steps': args.steps,
         'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True,
-        'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'scaling': 'weak', 'vs_baseline': None,
+        'dtype': 'f32' if args.embedding_dtype == 'fp32' else 'f32 (embedding table stored fp16, fp32 accumulate)',
+        'data': 'synthetic',
         'config': {'workload': 'synthetic DENSITY-style BA base graph n=%d m=%d (%d undirected edges), %d BFS '
                                'subgraphs x %d nodes per GPU, all_density hparams (N 10/43, P 57/183, S 42, 1 layer), '
                                'D=%d, full pass = sampling + similarities + fwd + bwd + Adam' %

@@ -245,6 +245,11 @@ int sgnn_dtw_similarity(const int64_t* x_ptr, const int32_t* x_val, int64_t n_x,
 int sgnn_cc_embed_fwd(const float* E, int64_t D,
                       const int64_t* set_ptr, const int32_t* set_nodes, int64_t n_sets,
                       int aggregator, int64_t padded_len, float* out, int32_t* out_arg, void* stream);
+/* same with the table stored as IEEE half (rows, D): read as half, accumulated and returned in fp32
+ * (BASELINE.json configs[4]: "fp16 embeddings"); the backward is sgnn_cc_embed_bwd (fp32 gradient). */
+int sgnn_cc_embed_fwd_f16(const uint16_t* E_half, int64_t D,
+                          const int64_t* set_ptr, const int32_t* set_nodes, int64_t n_sets,
+                          int aggregator, int64_t padded_len, float* out, int32_t* out_arg, void* stream);
 /* grad_E (n_emb_rows, D) is accumulated into (float atomics), row PAD untouched */
 int sgnn_cc_embed_bwd(const float* grad_out, int64_t D,
                       const int64_t* set_ptr, const int32_t* set_nodes, int64_t n_sets,
@@ -287,6 +292,9 @@ typedef struct sgnn_mpn_args {
     const int64_t* sim_col;    /* (A) or NULL */
     const float*   wp;         /* (D) linear_position.weight */
     const float*   bp;         /* (1) linear_position.bias   */
+    int32_t        x_f16;      /* GATHER only: x points at an IEEE half table (rows, D), read as
+                                * half and accumulated in fp32 (gradients stay fp32) */
+    int32_t        reserved_;
 } sgnn_mpn_args;
 
 int sgnn_mpn_fwd(const sgnn_mpn_args* args, float* agg /*(R,D)*/, float* z /*(R,A)*/, void* stream);

@@ -187,11 +187,27 @@ class SubGNN(nn.Module):
         labels = ops.cc_labels(self.networkx_graph, subs)
         return subgraph_utils.components_from_labels(subs.ptr, subs.nodes, labels, subs.max_len)
 
+    def _half_table(self):
+        """hparams['embedding_dtype'] in ('fp16', 'float16', 'half'): the table is additionally kept in
+        IEEE half and the fused kernels read that copy (fp32 accumulate); the fp32 parameter stays the
+        master the optimizer updates, and the half copy is refreshed whenever the master changed."""
+        if str(self.hparams.get('embedding_dtype', 'fp32')).lower() not in ('fp16', 'float16', 'half'):
+            return None
+        w = self.node_embeddings.weight
+        st = self.__dict__.get('_half_state')
+        if st is None or st[0] != w._version or st[1].device != w.device:
+            st = (w._version, w.detach().to(torch.float16))
+            self.__dict__['_half_state'] = st
+        return st[1]
+
     def _table(self):
         """The embedding table as the fused ops read it: inside ``forward`` a tapped alias whose
         consumers add their gradients into one shared buffer (ops.tap_table), else the parameter."""
         t = self.__dict__.get('_tapped_table')         # kept out of nn.Module's parameter registry
-        return t if t is not None else self.node_embeddings.weight
+        if t is not None:
+            return t
+        half = self._half_table()
+        return self.node_embeddings.weight if half is None else ops.tap_table(self.node_embeddings.weight, half)
 
     def initialize_cc_embeddings(self, cc_id_list, aggregator='sum'):
         """S.py:609-622 -> (S, C, D).  The padded rows are handed to the kernel as fixed-stride sets
@@ -511,7 +527,7 @@ class SubGNN(nn.Module):
         """S.py:225-312."""
         hp = self.hparams
         fused = hp.get('fused_forward', True)
-        self.__dict__['_tapped_table'] = ops.tap_table(self.node_embeddings.weight) if fused else None
+        self.__dict__['_tapped_table'] = ops.tap_table(self.node_embeddings.weight, self._half_table()) if fused else None
         try:
             return self._forward(dataset_type, N_I_cc_embed, N_B_cc_embed, S_I_cc_embed, S_B_cc_embed, P_I_cc_embed,
                                  P_B_cc_embed, subgraph_ids, cc_ids, subgraph_idx, NP_sim, I_S_sim, B_S_sim)

@@ -22,7 +22,8 @@ class MpnArgs(ctypes.Structure):
     _fields_ = [('src', ctypes.c_int32), ('sims_per_edge', ctypes.c_int32),
                 ('R', c_i64), ('A', c_i64), ('D', c_i64),
                 ('x', c_ptr), ('ids', c_ptr), ('id_div', c_i64), ('edge_mask', c_ptr), ('row_mask', c_ptr),
-                ('sims', c_ptr), ('sims_ld', c_i64), ('sim_col', c_ptr), ('wp', c_ptr), ('bp', c_ptr)]
+                ('sims', c_ptr), ('sims_ld', c_i64), ('sim_col', c_ptr), ('wp', c_ptr), ('bp', c_ptr),
+                ('x_f16', ctypes.c_int32), ('reserved_', ctypes.c_int32)]
 
 
 # name -> (restype, argtypes); mirrors include/subgnn_hip.h line by line
@@ -31,6 +32,7 @@ SIGNATURES = {
     'sgnn_last_error': (ctypes.c_char_p, []),
     'sgnn_degree_sequence': (c_int, [c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_int, c_ptr, c_ptr,
                                      c_ptr]),
+    'sgnn_cc_embed_fwd_f16': (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_int, c_i64, c_ptr, c_ptr, c_ptr]),
     'sgnn_cc_labels': (c_int, [c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_ptr, c_ptr]),
     'sgnn_cc_compact_stats': (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_ptr]),
     'sgnn_cc_compact': (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_i64, c_ptr, c_ptr]),

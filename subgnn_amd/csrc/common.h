@@ -71,6 +71,19 @@ __host__ __device__ static inline bool sgnn_nanchor_allneg(uint64_t h1, uint32_t
     return n == 32 ? (u == 0) : ((u >> (32 - n)) == 0);
 }
 
+// ---- table rows in fp32 or IEEE half: 4 consecutive elements of row `row` at slice dv ------------
+#include <hip/hip_fp16.h>
+template <typename T> __device__ __forceinline__ float4 sgnn_load4(const T* base, int64_t row, int64_t D4, int64_t dv);
+template <> __device__ __forceinline__ float4 sgnn_load4<float>(const float* base, int64_t row, int64_t D4, int64_t dv) {
+    return reinterpret_cast<const float4*>(base)[row * D4 + dv];
+}
+template <> __device__ __forceinline__ float4 sgnn_load4<__half>(const __half* base, int64_t row, int64_t D4, int64_t dv) {
+    const uint2 raw = reinterpret_cast<const uint2*>(base)[row * D4 + dv];          // 8 bytes = 4 halves
+    const __half2 lo = *reinterpret_cast<const __half2*>(&raw.x), hi = *reinterpret_cast<const __half2*>(&raw.y);
+    const float2 a = __half22float2(lo), b = __half22float2(hi);
+    return make_float4(a.x, a.y, b.x, b.y);
+}
+
 // ---- small device helpers ---------------------------------------------------------------
 __device__ static inline uint32_t sgnn_hash32(uint32_t x) { return x * 2654435761u; }
 

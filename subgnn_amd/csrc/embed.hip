@@ -8,14 +8,13 @@
 // as consecutive float4 (256 B for D=64), different rows of a wavefront proceed independently,
 // member loop unrolled for memory-level parallelism.
 // ---------------------------------------------------------------------------------------------
-template <int AGG>
+template <int AGG, typename T>
 __global__ __launch_bounds__(256) void cc_embed_fwd_kernel(
-    const float* __restrict__ E, int64_t D4,
+    const T* __restrict__ E, int64_t D4,
     const int64_t* __restrict__ set_ptr, const int32_t* __restrict__ set_nodes, int64_t n_sets,
     int64_t padded_len, float* __restrict__ out, int32_t* __restrict__ out_arg)
 {
     const int64_t total = n_sets * D4;
-    const float4* E4 = reinterpret_cast<const float4*>(E);
     for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
         const int64_t r = t / D4, dv = t % D4;
         const int64_t beg = set_ptr[r];
@@ -26,7 +25,7 @@ __global__ __launch_bounds__(256) void cc_embed_fwd_kernel(
             acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll 4
             for (int i = 0; i < n; ++i) {
-                const float4 x = E4[(int64_t)set_nodes[beg + i] * D4 + dv];
+                const float4 x = sgnn_load4<T>(E, (int64_t)set_nodes[beg + i], D4, dv);
                 acc.x += x.x; acc.y += x.y; acc.z += x.z; acc.w += x.w;
             }
         } else {
@@ -38,7 +37,7 @@ __global__ __launch_bounds__(256) void cc_embed_fwd_kernel(
 #pragma unroll 4
             for (int i = 0; i < n; ++i) {
                 const int32_t id = set_nodes[beg + i];
-                const float4 x = E4[(int64_t)id * D4 + dv];
+                const float4 x = sgnn_load4<T>(E, (int64_t)id, D4, dv);
                 if (x.x > acc.x) { acc.x = x.x; arg.x = id; }
                 if (x.y > acc.y) { acc.y = x.y; arg.y = id; }
                 if (x.z > acc.z) { acc.z = x.z; arg.z = id; }
@@ -80,9 +79,9 @@ __global__ __launch_bounds__(256) void cc_embed_bwd_kernel(
     }
 }
 
-extern "C" int sgnn_cc_embed_fwd(const float* E, int64_t D,
-                                 const int64_t* set_ptr, const int32_t* set_nodes, int64_t n_sets,
-                                 int aggregator, int64_t padded_len, float* out, int32_t* out_arg, void* stream)
+template <typename T>
+static int cc_embed_fwd_launch(const T* E, int64_t D, const int64_t* set_ptr, const int32_t* set_nodes, int64_t n_sets,
+                               int aggregator, int64_t padded_len, float* out, int32_t* out_arg, void* stream)
 {
     if (!E || !set_ptr || !set_nodes || !out || n_sets < 0 || D <= 0 || aggregator < 0 || aggregator > 1)
         return SGNN_ERR_BAD_ARG;
@@ -91,13 +90,28 @@ extern "C" int sgnn_cc_embed_fwd(const float* E, int64_t D,
     const int64_t D4 = D / 4;
     const int grid = sgnn_grid_for(n_sets * D4, 256);
     if (aggregator == 0)
-        hipLaunchKernelGGL(cc_embed_fwd_kernel<0>, dim3(grid), dim3(256), 0, (hipStream_t)stream, E, D4, set_ptr,
+        hipLaunchKernelGGL((cc_embed_fwd_kernel<0, T>), dim3(grid), dim3(256), 0, (hipStream_t)stream, E, D4, set_ptr,
                            set_nodes, n_sets, padded_len, out, out_arg);
     else
-        hipLaunchKernelGGL(cc_embed_fwd_kernel<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, E, D4, set_ptr,
+        hipLaunchKernelGGL((cc_embed_fwd_kernel<1, T>), dim3(grid), dim3(256), 0, (hipStream_t)stream, E, D4, set_ptr,
                            set_nodes, n_sets, padded_len, out, out_arg);
     SGNN_CHECK_LAUNCH();
     return SGNN_OK;
+}
+
+extern "C" int sgnn_cc_embed_fwd(const float* E, int64_t D,
+                                 const int64_t* set_ptr, const int32_t* set_nodes, int64_t n_sets,
+                                 int aggregator, int64_t padded_len, float* out, int32_t* out_arg, void* stream)
+{
+    return cc_embed_fwd_launch<float>(E, D, set_ptr, set_nodes, n_sets, aggregator, padded_len, out, out_arg, stream);
+}
+
+extern "C" int sgnn_cc_embed_fwd_f16(const uint16_t* E_half, int64_t D,
+                                     const int64_t* set_ptr, const int32_t* set_nodes, int64_t n_sets,
+                                     int aggregator, int64_t padded_len, float* out, int32_t* out_arg, void* stream)
+{
+    return cc_embed_fwd_launch<__half>(reinterpret_cast<const __half*>(E_half), D, set_ptr, set_nodes, n_sets, aggregator,
+                                       padded_len, out, out_arg, stream);
 }
 
 extern "C" int sgnn_cc_embed_bwd(const float* grad_out, int64_t D,

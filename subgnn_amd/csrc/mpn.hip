@@ -20,12 +20,14 @@ __device__ static inline float group_sum(float v, int lanes) {
     return v;
 }
 
-template <int SRC>
+// T: element type of the GATHER table (float, or __half for an fp16-stored table; fp32 accumulate)
+template <int SRC, typename T = float>
 __global__ __launch_bounds__(256) void mpn_fwd_kernel(sgnn_mpn_args a, float* __restrict__ agg, float* __restrict__ z,
                                                       int64_t D4)
 {
     const int64_t total = a.R * D4;
     const float4* x4 = reinterpret_cast<const float4*>(a.x);
+    const T* xt = reinterpret_cast<const T*>(a.x);
     const int lanes = (int)D4;
     const float bp = a.bp[0];
     for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
@@ -53,7 +55,7 @@ __global__ __launch_bounds__(256) void mpn_fwd_kernel(sgnn_mpn_args a, float* __
                 const float w = a.sims[r * a.sims_ld + col];
                 float4 x;
                 if (SRC == SGNN_SRC_DENSE) x = x4[(r * a.A + ai) * D4 + dv];
-                else if (SRC == SGNN_SRC_GATHER) x = x4[id * D4 + dv];
+                else if (SRC == SGNN_SRC_GATHER) x = sgnn_load4<T>(xt, id, D4, dv);
                 else x = x4[ai * D4 + dv];
                 acc.x += w * x.x; acc.y += w * x.y; acc.z += w * x.z; acc.w += w * x.w;
                 const float dot = group_sum(wp.x * x.x + wp.y * x.y + wp.z * x.z + wp.w * x.w, lanes);
@@ -160,7 +162,8 @@ __global__ __launch_bounds__(256) void mpn_bwd_gather_kernel(sgnn_mpn_args a, co
             if (w == 0.f) continue;
             const float gz = grad_z ? grad_z[r * a.A + ai] : 0.f;
             if (grad_x) atomicAdd(grad_x + id * D + d, w * (ga + gz * wp));
-            if (grad_wp && gz != 0.f) gw += gz * w * a.x[id * D + d];
+            if (grad_wp && gz != 0.f)
+                gw += gz * w * (a.x_f16 ? __half2float(reinterpret_cast<const __half*>(a.x)[id * D + d]) : a.x[id * D + d]);
         }
         if (grad_wp) atomicAdd(&s_gwp[d], gw);
     }
@@ -238,6 +241,7 @@ static int mpn_check(const sgnn_mpn_args* a)
     if (a->src == SGNN_SRC_DENSE && !a->edge_mask) return SGNN_ERR_BAD_ARG;
     if (a->src == SGNN_SRC_GATHER && !a->ids) return SGNN_ERR_BAD_ARG;
     if (a->src < 0 || a->src > 2) return SGNN_ERR_BAD_ARG;
+    if (a->x_f16 && a->src != SGNN_SRC_GATHER) return SGNN_ERR_BAD_ARG;
     if (!a->sim_col && !a->sims_per_edge && !a->ids) return SGNN_ERR_BAD_ARG;
     if (a->id_div < 1) return SGNN_ERR_BAD_ARG;
     return SGNN_OK;
@@ -254,6 +258,8 @@ extern "C" int sgnn_mpn_fwd(const sgnn_mpn_args* args, float* agg, float* z, voi
     hipStream_t st = (hipStream_t)stream;
     if (args->src == SGNN_SRC_DENSE)
         hipLaunchKernelGGL(mpn_fwd_kernel<SGNN_SRC_DENSE>, dim3(grid), dim3(256), 0, st, *args, agg, z, D4);
+    else if (args->src == SGNN_SRC_GATHER && args->x_f16)
+        hipLaunchKernelGGL((mpn_fwd_kernel<SGNN_SRC_GATHER, __half>), dim3(grid), dim3(256), 0, st, *args, agg, z, D4);
     else if (args->src == SGNN_SRC_GATHER)
         hipLaunchKernelGGL(mpn_fwd_kernel<SGNN_SRC_GATHER>, dim3(grid), dim3(256), 0, st, *args, agg, z, D4);
     else

@@ -501,13 +501,21 @@ class _TableTap(torch.autograd.Function):
         return (buf if g is None else buf.add_(g)), None
 
 
-def tap_table(E):
-    """Route the gradients of every fused consumer of ``E`` in this forward pass into one buffer."""
-    if not (torch.is_grad_enabled() and E.requires_grad):
+def tap_table(E, half=None):
+    """Route the gradients of every fused consumer of ``E`` in this forward pass into one buffer.
+    ``half``: an IEEE-half copy of the table (same shape): the fused ops then READ the half copy
+    (half the gather bytes, fp32 accumulation) while gradients still flow to the fp32 ``E``."""
+    if torch.is_grad_enabled() and E.requires_grad:
+        acc = _GradAcc()
+        t = _TableTap.apply(E, acc)
+        t._sgnn_acc = acc
+    elif half is not None:
+        t = E.detach()                       # a fresh tensor object to carry the attribute
+    else:
         return E
-    acc = _GradAcc()
-    t = _TableTap.apply(E, acc)
-    t._sgnn_acc = acc
+    if half is not None:
+        _req(half, torch.float16, 'half table')
+        t._sgnn_half = half
     return t
 
 
@@ -515,14 +523,19 @@ class _CCEmbed(torch.autograd.Function):
     @staticmethod
     def forward(ctx, E, ptr, nodes, aggregator, padded_len):
         ctx.acc = getattr(E, '_sgnn_acc', None)
+        half = getattr(E, '_sgnn_half', None)
         lib = _lib.load()
         _req(E, torch.float32, 'E')
         n = ptr.numel() - 1
         D = E.shape[1]
         out = torch.empty((n, D), dtype=torch.float32, device=E.device)
         arg = torch.empty((n, D), dtype=torch.int32, device=E.device) if aggregator == 1 else None
-        check(lib.sgnn_cc_embed_fwd(_ptr(E), D, _ptr(ptr), _ptr(nodes), n, aggregator, padded_len, _ptr(out), _ptr(arg),
-                                    _stream()), 'sgnn_cc_embed_fwd')
+        if half is not None:
+            check(lib.sgnn_cc_embed_fwd_f16(_ptr(half), D, _ptr(ptr), _ptr(nodes), n, aggregator, padded_len, _ptr(out),
+                                            _ptr(arg), _stream()), 'sgnn_cc_embed_fwd_f16')
+        else:
+            check(lib.sgnn_cc_embed_fwd(_ptr(E), D, _ptr(ptr), _ptr(nodes), n, aggregator, padded_len, _ptr(out),
+                                        _ptr(arg), _stream()), 'sgnn_cc_embed_fwd')
         ctx.save_for_backward(ptr, nodes, arg)
         ctx.aggregator, ctx.shape = aggregator, E.shape
         return out
@@ -553,7 +566,9 @@ def _mpn_args(src, x, ids, id_div, edge_mask, row_mask, sims, sim_col, sims_per_
     a = MpnArgs()
     a.src, a.sims_per_edge = src, 1 if sims_per_edge else 0
     a.R, a.A, a.D = R, A, D
-    a.x, a.ids, a.id_div = _ptr(x), _ptr(ids), id_div
+    half = getattr(x, '_sgnn_half', None) if src == SRC_GATHER else None     # fp16-stored twin of the table
+    a.x, a.ids, a.id_div = _ptr(half if half is not None else x), _ptr(ids), id_div
+    a.x_f16 = 1 if half is not None else 0
     a.edge_mask, a.row_mask = _ptr(edge_mask), _ptr(row_mask)
     a.sims, a.sims_ld, a.sim_col = _ptr(sims), sims.shape[-1], _ptr(sim_col)
     a.wp, a.bp = _ptr(wp), _ptr(bp)
@@ -585,6 +600,7 @@ class _MPN(torch.autograd.Function):
         ctx.save_for_backward(x, wp, bp, sims, ids, edge_mask, row_mask, sim_col)
         ctx.meta = (src, id_div, sims_per_edge, R, A, D)
         ctx.acc = getattr(x, '_sgnn_acc', None) if src == SRC_GATHER else None     # x is the tapped table
+        ctx.half = getattr(x, '_sgnn_half', None) if src == SRC_GATHER else None
         return agg, z
 
     @staticmethod
@@ -604,6 +620,8 @@ class _MPN(torch.autograd.Function):
         if need_wp:
             gwp = torch.zeros(D, dtype=torch.float32, device=x.device)
         if (need_x or need_wp) and A > 0:
+            if ctx.half is not None:
+                x._sgnn_half = ctx.half               # saved tensors come back as new objects
             a = _mpn_args(src, x, ids, id_div, edge_mask, row_mask, sims, sim_col, sims_per_edge, wp, bp, R, A, D)
             check(lib.sgnn_mpn_bwd(ctypes.byref(a), _ptr(g_agg), _ptr(g_z), _ptr(gx), _ptr(gwp), _stream()),
                   'sgnn_mpn_bwd')
@@ -667,7 +685,9 @@ class _GatherRows(torch.autograd.Function):
         ctx.save_for_backward(flat)
         ctx.n_rows = weight.shape[0]
         ctx.acc = getattr(weight, '_sgnn_acc', None)
-        return weight.index_select(0, flat).view(*ids.shape, weight.shape[1])
+        half = getattr(weight, '_sgnn_half', None)
+        src = weight if half is None else half
+        return src.index_select(0, flat).to(torch.float32).view(*ids.shape, weight.shape[1])
 
     @staticmethod
     def backward(ctx, grad):

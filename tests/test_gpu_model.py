@@ -145,6 +145,48 @@ def test_forward_backward_parity_g11(tiny, tmp_path, variant, fused):
     assert n > 10
 
 
+@pytest.mark.parametrize('variant', ['sum', 'max_trainable'])
+def test_fp16_stored_table_equals_fp32_on_rounded_values(tiny, tmp_path, variant):
+    """hparams['embedding_dtype'] = 'fp16' (BASELINE.json configs[4]): the fused kernels read an IEEE
+    half copy of the table and accumulate in fp32.  With a master table whose values are exactly
+    representable in half, the fp16-storage path must reproduce the fp32 path -- logits, loss and
+    every gradient (which still flows to the fp32 master) -- and the half copy must follow the master
+    when the optimizer changes it."""
+    g = tiny
+    t = 'g11_%s/' % variant
+    res = {}
+    for mode in ('fp32', 'fp16'):
+        hp = json.loads(str(g[t + 'hparams']))
+        hp['embedding_dtype'] = mode
+        m = _model(g, tmp_path, hp)
+        hp = m.hparams
+        sd = {k[len(t) + 3:]: T(g[k]) for k in g.files if k.startswith(t + 'sd/')}
+        m.load_state_dict({k: v for k, v in sd.items() if not k.startswith('train_')}, strict=False)
+        with torch.no_grad():
+            m.node_embeddings.weight.copy_(m.node_embeddings.weight.half().float())     # half-representable master
+        _inject(m, g, t, hp)
+        m.train()
+        batch = m.make_batch('train', g[t + 'idx'])
+        out = m.training_step(batch, 0)
+        m.zero_grad()
+        m.backward(None, out['loss'], None, 0)
+        res[mode] = (out['loss'].detach().clone(), m._forward_batch('train', batch).detach(),
+                     {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None})
+        if mode == 'fp16':
+            h0 = m._half_table()
+            assert h0.dtype == torch.float16 and h0 is m._half_table()                  # cached while unchanged
+            with torch.no_grad():
+                m.node_embeddings.weight.add_(1.0)
+            h1 = m._half_table()
+            assert h1 is not h0 and torch.equal(h1.float(), m.node_embeddings.weight.half().float())
+    assert_close(res['fp16'][0], res['fp32'][0].cpu().numpy(), 'loss')
+    assert_close(res['fp16'][1], res['fp32'][1].cpu().numpy(), 'logits')
+    assert res['fp16'][2].keys() == res['fp32'][2].keys()
+    for k in res['fp32'][2]:
+        assert_close(res['fp16'][2][k], res['fp32'][2][k].cpu().numpy(), 'grad ' + k)
+    assert float(res['fp16'][2]['node_embeddings.weight'].abs().max()) > 0
+
+
 def test_precompute_graph_metrics(golden, tmp_path):
     """GPU graph-metric precompute (the SNAP script's outputs) against the fixture's own files."""
     import json as _json

@@ -54,7 +54,8 @@ PRESETS = {
             "n_anchor_patches_N_in": 16, "n_anchor_patches_N_out": 32, "n_anchor_patches_structure": 35,
             "n_triangular_walks": 10, "random_walk_len": 23, "sample_walk_len": 22, "rw_beta": 0.1816027331132596,
             "lstm_dropout": 0.01599628663889252, "lin_dropout": 0.003486968525571843, "lstm_n_layers": 1,
-            "cc_aggregator": "sum", "trainable_cc": True, "structure_similarity_fn": "dtw"}),
+            "cc_aggregator": "sum", "trainable_cc": True, "structure_similarity_fn": "dtw",
+            "embedding_dtype": "fp16"}),          # configs[4]: "fp16 embeddings"
 }
 
 
