@@ -214,6 +214,17 @@ int sgnn_bfs_hops(const int64_t* rowptr, const int32_t* col, int64_t nnz, int64_
 int sgnn_min_hops_to_sets(const uint8_t* dist, int64_t n_sources, int64_t max_id, int node_major,
                           const int64_t* set_ptr, const int32_t* set_nodes, int64_t n_sets,
                           float* out, void* stream);
+/* both steps in one: out[r, s] = min over the members of set r of the hop distance from source s
+ * (0 when some member is unreachable from s: the reference's matrix holds 0 there and its row-min
+ * runs over it) -- compute_shortest_path_similarities
+ * (SubGNN/SubGNN.py:752-781) restricted to the anchor columns, without the (sources x nodes) hop
+ * table: after every BFS level each set ORs its members' new frontier words and records the level for
+ * the sources it sees for the first time.  out: (n_sets, n_sources) float32. */
+int64_t sgnn_bfs_min_hops_workspace_bytes(int64_t max_id, int64_t n_sources, int max_hops, int64_t n_sets);
+int sgnn_bfs_min_hops_to_sets(const int64_t* rowptr, const int32_t* col, int64_t nnz, int64_t max_id,
+                              const int32_t* sources, int64_t n_sources, int max_hops,
+                              const int64_t* set_ptr, const int32_t* set_nodes, int64_t n_sets,
+                              float* out, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * a11  Structure similarity: 1 / (1 + fastdtw(x, y, radius=1, dist=calc_dist)).

@@ -83,7 +83,7 @@ __global__ void msbfs_init_kernel(const int32_t* __restrict__ sources, int64_t n
     const int64_t gtid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = gtid; i < n_ids * n_words; i += gsz) { seen[i] = 0; frontier[i] = 0; next[i] = 0; }
-    for (int64_t i = gtid; i < n_sources * n_ids; i += gsz) dist[i] = 255;
+    if (dist) for (int64_t i = gtid; i < n_sources * n_ids; i += gsz) dist[i] = 255;
     for (int64_t i = gtid; i <= max_hops; i += gsz) { flags[i] = (i == 0) ? 1 : 0; fvol[i] = 0; }
 }
 
@@ -97,7 +97,7 @@ __global__ void msbfs_seed_kernel(const int32_t* __restrict__ sources, int64_t n
     const uint64_t bit = 1ull << (s & 63);
     atomicOr((unsigned long long*)&seen[(int64_t)v * n_words + (s >> 6)], (unsigned long long)bit);
     atomicOr((unsigned long long*)&frontier[(int64_t)v * n_words + (s >> 6)], (unsigned long long)bit);
-    dist[s * ss + v * sv] = 0;
+    if (dist) dist[s * ss + v * sv] = 0;
 }
 
 #define MSBFS_WCHUNK 4          // source words a pull pass keeps in registers
@@ -213,7 +213,7 @@ __global__ __launch_bounds__(256) void msbfs_commit_kernel(
                 const int b = __ffsll((unsigned long long)bits) - 1;
                 bits &= bits - 1;
                 const int64_t s = w * 64 + b;
-                if (s < n_sources) dist[s * ss + v * sv] = (uint8_t)level;
+                if (dist && s < n_sources) dist[s * ss + v * sv] = (uint8_t)level;
             }
         }
     }
@@ -232,16 +232,62 @@ extern "C" int64_t sgnn_bfs_hops_workspace_bytes(int64_t max_id, int64_t n_sourc
     return 3 * (max_id + 1) * n_words * 8 + ((int64_t)max_hops + 2) * 8 + ((int64_t)max_hops + 2) * 4;
 }
 
-extern "C" int sgnn_bfs_hops(const int64_t* rowptr, const int32_t* col, int64_t nnz, int64_t max_id,
-                             const int32_t* sources, int64_t n_sources, int max_hops, int node_major,
-                             uint8_t* dist, void* workspace, int64_t workspace_bytes, void* stream)
+// Per level, for every set: which sources reached one of its members for the first time?  The new
+// frontier words of the members are OR-ed, masked with what the set has not seen yet, and the level
+// is written for those sources: out[set, source] = min over members of the hop distance, without a
+// (sources x nodes) hop table.  One thread per (set, word).
+__global__ __launch_bounds__(256) void msbfs_set_reduce_kernel(
+    const uint64_t* __restrict__ frontier, int64_t n_words, int64_t n_sources,
+    const int64_t* __restrict__ set_ptr, const int32_t* __restrict__ set_nodes, int64_t n_sets,
+    uint64_t* __restrict__ set_seen, float* __restrict__ out, const int32_t* __restrict__ flags, int level)
 {
-    if (!rowptr || !col || !sources || !dist || !workspace || n_sources < 0 || max_hops < 1 || max_hops > 254)
-        return SGNN_ERR_BAD_ARG;
-    if (nnz >= (1ll << 31)) return SGNN_ERR_NNZ_TOO_LARGE;
-    if (workspace_bytes < sgnn_bfs_hops_workspace_bytes(max_id, n_sources, max_hops)) return SGNN_ERR_BAD_ARG;
-    if (n_sources == 0) return SGNN_OK;
-    hipStream_t st = (hipStream_t)stream;
+    if (level > 0 && flags[level] == 0) return;              // this level found nothing
+    const int64_t total = n_sets * n_words;
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = t / n_words, w = t % n_words;
+        uint64_t acc = 0;
+        for (int64_t i = set_ptr[r]; i < set_ptr[r + 1]; ++i) acc |= frontier[(int64_t)set_nodes[i] * n_words + w];
+        const uint64_t fresh = acc & ~set_seen[t];
+        if (fresh) {
+            set_seen[t] |= fresh;
+            uint64_t bits = fresh;
+            while (bits) {
+                const int b = __ffsll((unsigned long long)bits) - 1;
+                bits &= bits - 1;
+                const int64_t s = w * 64 + b;
+                if (s < n_sources) out[r * n_sources + s] = (float)level;
+            }
+        }
+    }
+}
+
+// The reference's matrix holds 0 for unreachable pairs, and its row-min runs over those zeros: a
+// source that never reaches SOME member of a set gives 0 for the whole set (SubGNN.py:772).  After
+// the last level: AND the members' seen words, zero the sources missing from it.
+__global__ __launch_bounds__(256) void msbfs_set_finalize_kernel(
+    const uint64_t* __restrict__ seen, int64_t n_words, int64_t n_sources,
+    const int64_t* __restrict__ set_ptr, const int32_t* __restrict__ set_nodes, int64_t n_sets, float* __restrict__ out)
+{
+    const int64_t total = n_sets * n_words;
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = t / n_words, w = t % n_words;
+        uint64_t all = ~0ull;
+        for (int64_t i = set_ptr[r]; i < set_ptr[r + 1]; ++i) all &= seen[(int64_t)set_nodes[i] * n_words + w];
+        uint64_t missing = ~all;
+        while (missing) {
+            const int b = __ffsll((unsigned long long)missing) - 1;
+            missing &= missing - 1;
+            const int64_t s = w * 64 + b;
+            if (s < n_sources) out[r * n_sources + s] = 0.f;
+        }
+    }
+}
+
+static int msbfs_run(const int64_t* rowptr, const int32_t* col, int64_t nnz, int64_t max_id,
+                     const int32_t* sources, int64_t n_sources, int max_hops, int node_major, uint8_t* dist,
+                     const int64_t* set_ptr, const int32_t* set_nodes, int64_t n_sets, float* set_out,
+                     void* workspace, hipStream_t st)
+{
     const int64_t n_ids = max_id + 1;
     const int64_t n_words = (n_sources + 63) / 64;
     const int64_t ss = node_major ? 1 : n_ids, sv = node_major ? n_sources : 1;
@@ -250,15 +296,24 @@ extern "C" int sgnn_bfs_hops(const int64_t* rowptr, const int32_t* col, int64_t 
     uint64_t* next = frontier + n_ids * n_words;
     unsigned long long* fvol = (unsigned long long*)(next + n_ids * n_words);
     int32_t* flags = (int32_t*)(fvol + max_hops + 2);
+    uint64_t* set_seen = (uint64_t*)(((uintptr_t)(flags + max_hops + 2) + 7) & ~(uintptr_t)7);
     const unsigned long long pull_above =
         g_bfs_alpha > 0 ? (unsigned long long)((nnz * n_words) / g_bfs_alpha) : ~0ull;
-    const int big = sgnn_grid_for(n_ids * (n_words > n_sources ? n_words : n_sources), 256);
+    const int big = sgnn_grid_for(n_ids * ((dist && n_sources > n_words) ? n_sources : n_words), 256);
     hipLaunchKernelGGL(msbfs_init_kernel, dim3(big), dim3(256), 0, st, sources, n_sources, n_words, n_ids, seen,
                        frontier, next, dist, flags, fvol, max_hops);
     SGNN_CHECK_LAUNCH();
     hipLaunchKernelGGL(msbfs_seed_kernel, dim3((int)((n_sources + 255) / 256)), dim3(256), 0, st, sources, n_sources,
                        n_words, n_ids, seen, frontier, dist, ss, sv);
     SGNN_CHECK_LAUNCH();
+    const int g_sets = set_out ? sgnn_grid_for(n_sets * n_words, 256) : 0;
+    if (set_out) {
+        (void)hipMemsetAsync(set_seen, 0, (size_t)(n_sets * n_words * 8), st);
+        (void)hipMemsetAsync(set_out, 0, (size_t)(n_sets * n_sources * 4), st);  // unreachable pairs hold 0
+        hipLaunchKernelGGL(msbfs_set_reduce_kernel, dim3(g_sets), dim3(256), 0, st, frontier, n_words, n_sources, set_ptr,
+                           set_nodes, n_sets, set_seen, set_out, flags, 0);
+        SGNN_CHECK_LAUNCH();
+    }
     const int g_expand = sgnn_grid_for(n_ids * 16, 256);
     const int g_commit = sgnn_grid_for(n_ids * n_words, 256);
     for (int level = 1; level <= max_hops; ++level) {
@@ -268,8 +323,51 @@ extern "C" int sgnn_bfs_hops(const int64_t* rowptr, const int32_t* col, int64_t 
         hipLaunchKernelGGL(msbfs_commit_kernel, dim3(g_commit), dim3(256), 0, st, rowptr, n_ids, n_words, n_sources, seen,
                            frontier, next, dist, flags, fvol, level, ss, sv);
         SGNN_CHECK_LAUNCH();
+        if (set_out) {
+            hipLaunchKernelGGL(msbfs_set_reduce_kernel, dim3(g_sets), dim3(256), 0, st, frontier, n_words, n_sources,
+                               set_ptr, set_nodes, n_sets, set_seen, set_out, flags, level);
+            SGNN_CHECK_LAUNCH();
+        }
+    }
+    if (set_out) {
+        hipLaunchKernelGGL(msbfs_set_finalize_kernel, dim3(g_sets), dim3(256), 0, st, seen, n_words, n_sources, set_ptr,
+                           set_nodes, n_sets, set_out);
+        SGNN_CHECK_LAUNCH();
     }
     return SGNN_OK;
+}
+
+extern "C" int sgnn_bfs_hops(const int64_t* rowptr, const int32_t* col, int64_t nnz, int64_t max_id,
+                             const int32_t* sources, int64_t n_sources, int max_hops, int node_major,
+                             uint8_t* dist, void* workspace, int64_t workspace_bytes, void* stream)
+{
+    if (!rowptr || !col || !sources || !dist || !workspace || n_sources < 0 || max_hops < 1 || max_hops > 254)
+        return SGNN_ERR_BAD_ARG;
+    if (nnz >= (1ll << 31)) return SGNN_ERR_NNZ_TOO_LARGE;
+    if (workspace_bytes < sgnn_bfs_hops_workspace_bytes(max_id, n_sources, max_hops)) return SGNN_ERR_BAD_ARG;
+    if (n_sources == 0) return SGNN_OK;
+    return msbfs_run(rowptr, col, nnz, max_id, sources, n_sources, max_hops, node_major, dist, nullptr, nullptr, 0,
+                     nullptr, workspace, (hipStream_t)stream);
+}
+
+extern "C" int64_t sgnn_bfs_min_hops_workspace_bytes(int64_t max_id, int64_t n_sources, int max_hops, int64_t n_sets) {
+    const int64_t n_words = (n_sources + 63) / 64;
+    return sgnn_bfs_hops_workspace_bytes(max_id, n_sources, max_hops) + 8 + n_sets * n_words * 8;
+}
+
+extern "C" int sgnn_bfs_min_hops_to_sets(const int64_t* rowptr, const int32_t* col, int64_t nnz, int64_t max_id,
+                                         const int32_t* sources, int64_t n_sources, int max_hops,
+                                         const int64_t* set_ptr, const int32_t* set_nodes, int64_t n_sets,
+                                         float* out, void* workspace, int64_t workspace_bytes, void* stream)
+{
+    if (!rowptr || !col || !sources || !set_ptr || !set_nodes || !out || !workspace || n_sources < 0 || n_sets < 0 ||
+        max_hops < 1 || max_hops > 254)
+        return SGNN_ERR_BAD_ARG;
+    if (nnz >= (1ll << 31)) return SGNN_ERR_NNZ_TOO_LARGE;
+    if (workspace_bytes < sgnn_bfs_min_hops_workspace_bytes(max_id, n_sources, max_hops, n_sets)) return SGNN_ERR_BAD_ARG;
+    if (n_sources == 0 || n_sets == 0) return SGNN_OK;
+    return msbfs_run(rowptr, col, nnz, max_id, sources, n_sources, max_hops, 0, nullptr, set_ptr, set_nodes, n_sets, out,
+                     workspace, (hipStream_t)stream);
 }
 
 __global__ void min_hops_to_sets_kernel(const uint8_t* __restrict__ dist, int64_t n_sources, int64_t n_ids,

@@ -108,9 +108,8 @@ def prepare_sparse(model, split='train', timer=None):
                 model.anchors_pos_int = {}
             model.anchors_pos_int[split] = pint
             for l in range(L):
-                dist = ops.bfs_hops(g, model.anchors_pos_ext[l].to(torch.int32).contiguous(),
-                                    max_hops=hp.get('max_bfs_hops', 32), node_major=True)
-                w = ops.min_hops_to_sets(dist, cc_sets, node_major=True).view(S, C, -1)
+                w = ops.bfs_min_hops_to_sets(g, model.anchors_pos_ext[l].to(torch.int32).contiguous(), cc_sets,
+                                             max_hops=hp.get('max_bfs_hops', 32)).view(S, C, -1)
                 sims[('P', 'out', l)] = (w * real.unsqueeze(-1)).contiguous()
                 if C == 1:
                     sims[('P', 'in', l)] = torch.zeros((S, C, hp['n_anchor_patches_pos_in']), dtype=torch.float32,

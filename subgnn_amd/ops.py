@@ -386,6 +386,21 @@ def bfs_hops(g, sources, max_hops=64, node_major=False):
     return dist
 
 
+def bfs_min_hops_to_sets(g, sources, sets, max_hops=64):
+    """min over the members of every set of the hop distance from every source -> (n_sets, n_sources)
+    float32, 0 for unreachable pairs; one multi-source BFS, no (sources x nodes) hop table."""
+    lib = _lib.load()
+    _req(sources, torch.int32, 'sources')
+    ns = sources.numel()
+    out = torch.empty((sets.n, ns), dtype=torch.float32, device=g.device)
+    wsb = lib.sgnn_bfs_min_hops_workspace_bytes(g.max_id, ns, max_hops, sets.n)
+    ws = torch.empty(wsb // 8 + 1, dtype=torch.int64, device=g.device)
+    check(lib.sgnn_bfs_min_hops_to_sets(_ptr(g.rowptr), _ptr(g.col), g.nnz, g.max_id, _ptr(sources), ns, max_hops,
+                                        _ptr(sets.ptr), _ptr(sets.nodes), sets.n, _ptr(out), _ptr(ws), wsb, _stream()),
+          'sgnn_bfs_min_hops_to_sets')
+    return out
+
+
 def min_hops_to_sets(dist, sets, node_major=False):
     lib = _lib.load()
     _req(dist, torch.uint8, 'dist')

@@ -485,6 +485,13 @@ def test_bfs_hops_push_pull_agree_and_match_scipy(n_src):
     assert torch.equal(out[0], out[16]) and torch.equal(out[0], out[1 << 30])
     for alpha in (0, 16, 1 << 30):
         assert torch.equal(out[(alpha, 't')].t().contiguous(), out[0])
+    # fused BFS + min over members == the two-step form (sets with isolated members, an empty set)
+    rng = np.random.default_rng(1)
+    sets_l = [rng.integers(1, n + 1, int(rng.integers(1, 30))).tolist() for _ in range(400)]
+    sets_l[5] = []
+    sets = ops.Ragged.from_lists(sets_l, DEV)
+    two_step = ops.min_hops_to_sets(out[16], sets)
+    assert torch.equal(ops.bfs_min_hops_to_sets(dg, torch.from_numpy(src).to(DEV), sets, max_hops=32), two_step)
     A = sp.csr_matrix((np.ones(len(col), dtype=np.int8), col.astype(np.int64) - 1, rowptr[1:] - rowptr[1]), shape=(n, n))
     ref = shortest_path(A, method='D', unweighted=True, indices=src[:40].astype(np.int64) - 1)
     got = out[0][:40, 1:].cpu().numpy().astype(np.float64)
@@ -519,6 +526,8 @@ def test_bfs_hops_matches_apsp(golden, bfs_alpha):
     dist_t = ops.bfs_hops(dg, torch.from_numpy(src).to(DEV), max_hops=32, node_major=True)      # (ids, sources)
     assert torch.equal(dist_t.t().contiguous(), dist)
     assert np.array_equal(ops.min_hops_to_sets(dist_t, sets, node_major=True).cpu().numpy(), ref)
+    # fused form: BFS + min over members in one call, no hop table
+    assert np.array_equal(ops.bfs_min_hops_to_sets(dg, torch.from_numpy(src).to(DEV), sets, max_hops=32).cpu().numpy(), ref)
 
 
 # ---- a11 DTW ------------------------------------------------------------------------------
