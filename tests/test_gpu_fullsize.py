@@ -1,0 +1,128 @@
+"""-m gpu: the kernels at BASELINE.json's full size (1M-node / 10M-edge base graph, 50k subgraphs of 20
+nodes -- the oracle cannot replay that in seconds), checked through size-independent properties and
+against the oracle on samples: checksums of degree sequences, sortedness, idempotence, exact border
+sizes and tape-ranked anchors on sampled rows, BFS levels against scipy, DTW against the C oracle on
+sampled pairs and under row reordering / de-duplication, walks that only ever follow edges."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import tape as T, cbind
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+N, M, S, K = 1_000_000, 10, 50_000, 20
+
+
+@pytest.fixture(scope='module')
+def full():
+    from subgnn_amd import ops, synthetic
+    edges = synthetic.barabasi_albert_edges(N, M, seed=42)
+    rowptr, col = synthetic.sorted_csr(edges, N)
+    subs = synthetic.bfs_subgraphs(rowptr, col, S, K, seed=1000)
+    g = ops.DeviceGraph(rowptr, col, np.arange(1, N + 1, dtype=np.int32), DEV)
+    sets = ops.Ragged.from_lists(subs, DEV)
+    return dict(ops=ops, rowptr=rowptr, col=col, subs=subs, g=g, sets=sets)
+
+
+def test_degree_sequences_checksums_sorted_idempotent(full):
+    ops, g, sets, rowptr = full['ops'], full['g'], full['sets'], full['rowptr']
+    oi, oe = ops.degree_sequence(g, sets, sort=True, use_degree_dict=False)
+    oi2, oe2 = ops.degree_sequence(g, sets, sort=True, use_degree_dict=False)
+    assert torch.equal(oi, oi2) and torch.equal(oe, oe2)                          # idempotent (no atomics races)
+    i2 = oi.view(S, K).long()
+    e2 = oe.view(S, K).long()
+    assert bool((i2[:, 1:] >= i2[:, :-1]).all()) and bool((e2[:, 1:] >= e2[:, :-1]).all())     # ascending per set
+    deg = torch.from_numpy(np.diff(rowptr)).to(DEV)
+    full_sum = deg[sets.nodes[:S * K].long()].view(S, K).sum(1)
+    assert torch.equal(i2.sum(1) + e2.sum(1), full_sum)                           # internal + external = degree
+    assert bool((i2.sum(1) % 2 == 0).all())                                       # every internal edge counted twice
+    assert bool((i2.sum(1) >= 2 * (K - 1)).all())                                 # BFS subgraphs are connected
+    # unsorted form is a permutation of the sorted one
+    ui, ue = ops.degree_sequence(g, sets, sort=False, use_degree_dict=False)
+    assert torch.equal(torch.sort(ui.view(S, K), dim=1).values, oi.view(S, K))
+    # sampled sets against the C oracle
+    idx = np.random.default_rng(0).choice(S, 300, replace=False)
+    ptr, flat = cbind.ragged([full['subs'][i] for i in idx])
+    ci, ce = cbind.degree_sequence(rowptr, full['col'], None, ptr, flat, True)
+    assert np.array_equal(i2[idx].cpu().numpy().reshape(-1), ci) and np.array_equal(e2[idx].cpu().numpy().reshape(-1), ce)
+
+
+def test_components_of_connected_subgraphs(full):
+    ops, g, sets = full['ops'], full['g'], full['sets']
+    from subgnn_amd.subgraph_utils import components_from_labels
+    cc = components_from_labels(sets.ptr, sets.nodes, ops.cc_labels(g, sets), sets.max_len)
+    assert tuple(cc.shape) == (S, 1, K)                                           # one component each
+    assert torch.equal(cc.view(S, K), sets.nodes[:S * K].view(S, K).long())       # in subgraph order
+
+
+def test_border_sizes_and_anchor_ranks_on_samples(full):
+    ops, g, sets, rowptr, col = full['ops'], full['g'], full['sets'], full['rowptr'], full['col']
+    A, seed, st = 43, 7, T.stream_id(T.STREAM_N_BOR, 'train', 0)
+    anchors, sims, counts = ops.khop_border_sample(g, sets, 1, A, seed, st)
+    a2, s2, c2 = ops.khop_border_sample(g, sets, 1, A, seed, st)
+    assert torch.equal(anchors, a2) and torch.equal(counts, c2)                   # idempotent, workspace left clean
+    an, cn, mx = anchors.cpu().numpy(), counts.cpu().numpy(), int(counts.max())
+    assert bool(((sims == 1) == (anchors != 0)).all())                            # 1-hop border: hop level 1
+    for i in np.random.default_rng(1).choice(S, 60, replace=False):
+        members = np.asarray(full['subs'][i])
+        border = np.setdiff1d(np.unique(np.concatenate([col[rowptr[v]:rowptr[v + 1]] for v in members])), members)
+        assert cn[i] == len(border)
+        for a in range(A):
+            kk = T.nanchor_pick(seed, st, int(i) * A + a, len(border), len(border) < mx)
+            assert an[i, a] == (0 if kk < 0 else border[kk])
+
+
+def test_bfs_levels_against_scipy(full):
+    import scipy.sparse as sp
+    from scipy.sparse.csgraph import breadth_first_order, shortest_path
+    ops, g, rowptr, col = full['ops'], full['g'], full['rowptr'], full['col']
+    src = np.random.default_rng(2).integers(1, N + 1, 183).astype(np.int32)
+    dist = ops.bfs_hops(g, torch.from_numpy(src).to(DEV), max_hops=32)
+    assert int(dist[torch.arange(183), torch.from_numpy(src).long()].max()) == 0  # a source is at distance 0
+    d = dist[:, 1:]
+    assert int(d.max()) < 255                                                     # BA graph: connected
+    A = sp.csr_matrix((np.ones(len(col), dtype=np.int8), col.astype(np.int64) - 1, rowptr[1:] - rowptr[1]), shape=(N, N))
+    ref = shortest_path(A, method='D', unweighted=True, indices=src[:3].astype(np.int64) - 1)
+    assert np.array_equal(d[:3].cpu().numpy().astype(np.float64), ref)
+    # fused min over members == two-step form on the full 50k sets
+    two = ops.min_hops_to_sets(dist, full['sets'])
+    assert torch.equal(ops.bfs_min_hops_to_sets(g, torch.from_numpy(src).to(DEV), full['sets'], max_hops=32), two)
+
+
+def test_walks_follow_edges_and_dtw_properties(full):
+    ops, g, sets, rowptr, col = full['ops'], full['g'], full['sets'], full['rowptr'], full['col']
+    walks = ops.triangular_walks(g, 0, 210, 50, 0.65, 0, T.stream_id(T.STREAM_STRUCT_PATCH))
+    w = walks.cpu().numpy()
+    for row in w:
+        nz = row[row != 0]
+        for a, b in zip(nz[:-1], nz[1:]):
+            nb = col[rowptr[a]:rowptr[a + 1]]
+            assert nb[np.searchsorted(nb, b)] == b                                 # consecutive nodes are adjacent
+    a_sets = ops.Ragged.from_padded(walks)
+    ai, ae = ops.degree_sequence(g, a_sets)
+    ci, ce = ops.degree_sequence(g, sets)
+    sim = ops.dtw_similarity(sets.ptr, ce, K, a_sets.ptr, ae, 50)
+    assert tuple(sim.shape) == (S, 210) and bool((sim > 0).all()) and bool((sim <= 1).all())
+    # a series against itself: distance 0, similarity exactly 1
+    self_sim = ops.dtw_similarity(a_sets.ptr, ae, 50, a_sets.ptr, ae, 50, dedupe=False)
+    assert bool((torch.diagonal(self_sim) == 1).all())
+    # processing order and de-duplication change nothing: a 3000-row slice recomputed plainly
+    sub = ops.Ragged(sets.ptr[:3001].clone(), ce[:3000 * K].clone(), max_len=K)
+    plain = ops.dtw_similarity(sub.ptr, sub.nodes, K, a_sets.ptr, ae, 50, order_rows=False, dedupe=False)
+    assert torch.equal(plain, sim[:3000])
+    int_sim = ops.dtw_similarity(sets.ptr, ci, K, a_sets.ptr, ai, 50)               # de-duplicated side
+    plain_i = ops.dtw_similarity(sub.ptr, ci[:3000 * K].clone(), K, a_sets.ptr, ai, 50, order_rows=False, dedupe=False)
+    assert torch.equal(plain_i, int_sim[:3000])
+    # sampled pairs against the C oracle (fastdtw restatement)
+    rng = np.random.default_rng(3)
+    rows, cols_ = rng.choice(S, 40, replace=False), rng.choice(210, 5, replace=False)
+    xs = ce.view(S, K)[torch.from_numpy(rows).to(DEV)].cpu().numpy()
+    yl, yv = a_sets.to_lists(), ae.cpu().numpy()
+    yp = a_sets.ptr.cpu().numpy()
+    ys = [yv[yp[c]:yp[c + 1]] for c in cols_]
+    xp, xf = cbind.ragged([list(map(int, x)) for x in xs])
+    ypp, yf = cbind.ragged([list(map(int, y)) for y in ys])
+    ref = cbind.fastdtw_sim(xp, xf, ypp, yf, 0).reshape(40, 5)
+    got = sim[torch.from_numpy(rows).to(DEV)][:, torch.from_numpy(cols_).to(DEV)].cpu().numpy()
+    assert np.array_equal(got, ref)
