@@ -649,6 +649,34 @@ class _MPN(torch.autograd.Function):
         return (None if ctx.acc is not None else gx), gwp, gbp, None, None, None, None, None, None, None, None, None, None
 
 
+SHARED_GEMM_MIN_ROWS = 4096
+
+
+def _mpn_shared_gemm(x, wp, bp, sims2, ids, row_mask, sim_col, sims_per_edge, R, A):
+    """SRC_SHARED for shard-sized row counts: with one anchor matrix X (A, D) for all R rows the layer
+    body IS a dense contraction -- agg = W X, read-out z = W * (X wp) + bp with W the (R, A) edge
+    weights -- and so is its backward (dX = W^T g_agg + ...).  Plain GEMMs go to the library
+    (rocBLAS / hipBLASLt through torch.matmul); autograd derives the backward GEMMs.  The hand-written
+    kernel keeps the batch-sized calls, where launch count matters and the GEMM would be tiny."""
+    if sim_col is not None:
+        W = sims2.index_select(1, sim_col)
+    elif sims_per_edge:
+        W = sims2[:, :A]
+    else:
+        W = sims2.index_select(1, (ids - 1).clamp(min=0))
+    edge = None
+    if ids is not None:
+        edge = (ids != 0).to(W.dtype).view(1, A)
+    if row_mask is not None:
+        rm = (row_mask != 0).to(W.dtype).view(R, 1)
+        edge = rm if edge is None else edge * rm
+    if edge is not None:
+        W = W * edge
+    agg = W @ x
+    z = W * (x @ wp.view(-1)).view(1, A) + bp.view(1, 1)
+    return agg, z
+
+
 def mpn(x, wp, bp, sims, *, src, R, A, ids=None, id_div=1, edge_mask=None, row_mask=None, sim_col=None,
         sims_per_edge=False):
     """Fused anchor->component layer body.  x: DENSE (R,A,D) | GATHER E (rows,D) | SHARED (A,D).
@@ -656,6 +684,8 @@ def mpn(x, wp, bp, sims, *, src, R, A, ids=None, id_div=1, edge_mask=None, row_m
     sims2 = sims.reshape(R, -1)
     if not sims2.is_contiguous():
         sims2 = sims2.contiguous()
+    if src == SRC_SHARED and R >= SHARED_GEMM_MIN_ROWS and A > 0:
+        return _mpn_shared_gemm(x, wp, bp, sims2, ids, row_mask, sim_col, sims_per_edge, R, A)
     return _MPN.apply(x.contiguous(), wp.contiguous().view(-1), bp.contiguous().view(-1), sims2, ids, edge_mask,
                       row_mask, sim_col, src, id_div, sims_per_edge, R, A)
 
