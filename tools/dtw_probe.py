@@ -26,3 +26,15 @@ for nm, x, y in (('internal', ci, ai), ('external', ce, ae)):
         out = ops.dtw_similarity(sets.ptr, x, NX, a_sets.ptr, y, 50)
     torch.cuda.synchronize()
     print(nm, (time.perf_counter() - t) / reps * 1e3, 'ms', float(out.double().sum()))
+
+# ---- where the wrapper's time goes (external side) -------------------------------------------
+def _t(f, reps=5):
+    f(); torch.cuda.synchronize(); t = time.perf_counter()
+    for _ in range(reps): f()
+    torch.cuda.synchronize(); return (time.perf_counter() - t) / reps * 1e3
+
+rows = ops.Ragged(sets.ptr, ce, max_len=NX).to_padded(width=NX, fill=-1, dtype=torch.int32)
+print('to_padded', _t(lambda: ops.Ragged(sets.ptr, ce, max_len=NX).to_padded(width=NX, fill=-1, dtype=torch.int32)))
+print('_unique_rows', _t(lambda: ops._unique_rows(rows)))
+print('call without dedupe', _t(lambda: ops.dtw_similarity(sets.ptr, ce, NX, a_sets.ptr, ae, 50, dedupe=False)))
+print('call without dedupe/order', _t(lambda: ops.dtw_similarity(sets.ptr, ce, NX, a_sets.ptr, ae, 50, dedupe=False, order_rows=False)))
