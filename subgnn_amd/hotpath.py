@@ -112,8 +112,7 @@ def prepare_sparse(model, split='train', timer=None):
                                              max_hops=hp.get('max_bfs_hops', 32)).view(S, C, -1)
                 sims[('P', 'out', l)] = (w * real.unsqueeze(-1)).contiguous()
                 if C == 1:
-                    sims[('P', 'in', l)] = torch.zeros((S, C, hp['n_anchor_patches_pos_in']), dtype=torch.float32,
-                                                       device=dev)
+                    sims[('P', 'in', l)] = ops.ZeroSims((S, C, hp['n_anchor_patches_pos_in']), dev)
                 else:
                     uniq, inv = torch.unique(pint[l], return_inverse=True)
                     if uniq.numel() * (g.max_id + 1) > MAX_PINT_BYTES:
@@ -150,7 +149,7 @@ def prepare_sparse(model, split='train', timer=None):
             ni[l] = ops.sample_anchors_ragged(cc_canon, hp['n_anchor_patches_N_in'], seed,
                                               tape.stream_id(tape.STREAM_N_INT, split, l), has_pad_c,
                                               canonical=True).view(S, C, -1)
-            sims[('N', 'in', l)] = torch.zeros(ni[l].shape, dtype=torch.float32, device=dev)
+            sims[('N', 'in', l)] = ops.ZeroSims(ni[l].shape, dev)
             # border BFS fused with the border-anchor draw (rank query on the visited bitmap): the
             # border is never materialised
             a, w, _ = ops.khop_border_sample(g, cc_sets, k, hp['n_anchor_patches_N_out'], seed,

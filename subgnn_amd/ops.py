@@ -649,6 +649,22 @@ class _MPN(torch.autograd.Function):
         return (None if ctx.acc is not None else gx), gwp, gbp, None, None, None, None, None, None, None, None, None, None
 
 
+class ZeroSims:
+    """Edge weights known to be all zero (the similarity of an anchor that lies inside its own
+    component -- every N-internal edge, every P-internal edge of a single-component subgraph): the
+    layer body then contributes agg = 0 and the read-out z = bp without launching anything."""
+
+    def __init__(self, shape, device):
+        self.shape, self.device = tuple(shape), device
+
+    def index_select(self, dim, idx):
+        assert dim == 0
+        return ZeroSims((idx.numel(),) + self.shape[1:], self.device)
+
+    def dense(self):
+        return torch.zeros(self.shape, dtype=torch.float32, device=self.device)
+
+
 SHARED_GEMM_MIN_ROWS = 4096
 
 

@@ -61,6 +61,10 @@ class SG_MPN(nn.Module):
         B, C, D = cc_embeds.shape
         R = B * C
         A = ids.shape[-1] if ids is not None else x.shape[0]
+        if isinstance(sims, ops.ZeroSims):          # all edge weights 0: messages vanish, read-out = bias
+            agg = torch.zeros((R, D), dtype=cc_embeds.dtype, device=cc_embeds.device)
+            z = self.linear_position.bias.view(1, 1).expand(R, A)
+            return self._finish(cc_embeds, agg, z)
         row_mask = cc_embed_mask.reshape(R).to(torch.uint8).contiguous()
         agg, z = ops.mpn(x, self.linear_position.weight, self.linear_position.bias, sims, src=src, R=R, A=A, ids=ids,
                          id_div=id_div, row_mask=row_mask, sim_col=sim_col, sims_per_edge=sims_per_edge)

@@ -52,7 +52,8 @@ def test_sparse_prepare_equals_dense_prepare(name, tmp_path):
                          (('P', 'out', l), dense.anchors_pos_ext[l].view(1, 1, -1).expand(S, C, -1))):
             edge = (ids != 0) & real.unsqueeze(-1)
             want = torch.gather(slab, 2, (ids - 1).clamp(min=0)) * edge
-            got = sparse.train_neigh_pos_similarities[key] * edge
+            got = sparse.train_neigh_pos_similarities[key]
+            got = (got.dense() if hasattr(got, 'dense') else got) * edge          # ops.ZeroSims: known-zero weights
             assert torch.equal(got, want), key
     assert torch.equal(dense.structure_anchors, sparse.structure_anchors)
     assert torch.equal(dense.train_int_struc_similarities, sparse.train_int_struc_similarities)
