@@ -440,7 +440,12 @@ def dtw_similarity(x_ptr, x_val, max_x, y_ptr, y_val, max_y, tie_order=0, order_
     that the lanes of a wavefront work on similar series.  Neither changes any value."""
     if dedupe and x_ptr.numel() - 1 > 1024 and max_x <= 64:
         rows = Ragged(x_ptr, x_val, max_len=max_x).to_padded(width=max_x, fill=-1, dtype=torch.int32)
-        uniq, inv = _unique_rows(rows)
+        # cheap look first: if a 2048-row sample has (almost) no repeats, the full grouping is skipped
+        probe = rows[:: max(rows.shape[0] // 2048, 1)][:2048]
+        if _unique_rows(probe)[0].shape[0] * 4 > probe.shape[0] * 3:
+            uniq = rows
+        else:
+            uniq, inv = _unique_rows(rows)
         if uniq.shape[0] * 2 <= rows.shape[0]:
             mask = uniq >= 0
             lens = mask.sum(dim=1)
@@ -463,11 +468,12 @@ def dtw_similarity(x_ptr, x_val, max_x, y_ptr, y_val, max_y, tie_order=0, order_
         lens = x_ptr[1:] - x_ptr[:-1]
         csum = torch.zeros(x_val.numel() + 1, dtype=torch.int64, device=x_val.device)
         torch.cumsum(x_val, 0, out=csum[1:])
-        sums = (csum[x_ptr[1:]] - csum[x_ptr[:-1]]).double()
-        med = x_val[(x_ptr[:-1] + lens // 2).clamp(max=x_val.numel() - 1)].double() * (lens > 0)
+        sums = csum[x_ptr[1:]] - csum[x_ptr[:-1]]
+        med = x_val[(x_ptr[:-1] + lens // 2).clamp(max=x_val.numel() - 1)].long() * (lens > 0)
         # (length, median, sum): rows are sorted degree sequences, the median places the bulk of the
-        # series and the sum breaks ties -- one fp64 key, exact for any realistic degree
-        key = (lens.double() * (float(med.max().item()) + 1.0) + med) * (float(sums.max().item()) + 1.0) + sums
+        # series and the sum breaks ties -- packed into one int64 key (16 | 24 | 23 bits, saturating),
+        # no host round trip
+        key = (lens.clamp(max=0xFFFF) << 47) | (med.long().clamp(max=0xFFFFFF) << 23) | sums.long().clamp(max=0x7FFFFF)
         order = torch.argsort(key).to(torch.int32).contiguous()
     wsb = lib.sgnn_dtw_workspace_bytes(nx, max_x, ny, max_y)
     ws = torch.empty(wsb // 8 + 1, dtype=torch.int64, device=x_ptr.device)
