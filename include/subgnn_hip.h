@@ -68,6 +68,7 @@ int sgnn_degree_sequence(const int64_t* rowptr, const int32_t* col, int64_t nnz,
  * ------------------------------------------------------------------------------------- */
 int sgnn_cc_labels(const int64_t* rowptr, const int32_t* col_sorted, int64_t nnz,
                    const int64_t* sub_ptr, const int32_t* sub_nodes, int64_t n_subgraphs,
+                   int64_t max_sub_len /* longest subgraph, <= 2048; 0 = unknown */,
                    int32_t* out_label, void* stream);
 /* labels -> the padded component tensor of SubGNN.initialize_cc_ids (SubGNN/SubGNN.py:575-607) in
  * canonical order: components by the position of their first node, nodes in subgraph order,

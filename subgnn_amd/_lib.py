@@ -33,7 +33,7 @@ SIGNATURES = {
     'sgnn_degree_sequence': (c_int, [c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_int, c_ptr, c_ptr,
                                      c_ptr]),
     'sgnn_cc_embed_fwd_f16': (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_int, c_i64, c_ptr, c_ptr, c_ptr]),
-    'sgnn_cc_labels': (c_int, [c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_ptr, c_ptr]),
+    'sgnn_cc_labels': (c_int, [c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr]),
     'sgnn_cc_compact_stats': (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_ptr]),
     'sgnn_cc_compact': (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_i64, c_ptr, c_ptr]),
     'sgnn_khop_border_workspace_bytes': (c_i64, [c_i64, c_i64, c_int]),

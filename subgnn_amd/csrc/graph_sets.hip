@@ -18,18 +18,22 @@ __device__ static inline int cc_find(volatile int32_t* parent, int x) {
     return x;
 }
 
+// NMAX = 64: subgraphs of at most 64 nodes (the common case) keep 512 B of LDS per wavefront, so
+// the CU holds its full complement of wavefronts; NMAX = CC_MAX handles the rest (and only those).
+template <int NMAX>
 __global__ __launch_bounds__(64) void cc_labels_kernel(
     const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col_sorted,
     const int64_t* __restrict__ sub_ptr, const int32_t* __restrict__ sub_nodes, int64_t n_sub,
     int32_t* __restrict__ out_label)
 {
-    __shared__ int32_t s_id[CC_MAX];
-    __shared__ int32_t s_parent[CC_MAX];
+    __shared__ int32_t s_id[NMAX];
+    __shared__ int32_t s_parent[NMAX];
     const int lane = threadIdx.x;
     for (int64_t s = blockIdx.x; s < n_sub; s += gridDim.x) {
         const int64_t beg = sub_ptr[s];
         const int n = (int)(sub_ptr[s + 1] - beg);
         if (n <= 0) continue;
+        if (NMAX == 64 ? n > 64 : n <= 64) continue;        // the other instantiation owns it
         if (n > CC_MAX) {                                   // flagged by the host wrapper too
             for (int i = lane; i < n; i += 64) out_label[beg + i] = -1;
             continue;
@@ -67,14 +71,17 @@ __global__ __launch_bounds__(64) void cc_labels_kernel(
 
 extern "C" int sgnn_cc_labels(const int64_t* rowptr, const int32_t* col_sorted, int64_t nnz,
                               const int64_t* sub_ptr, const int32_t* sub_nodes, int64_t n_subgraphs,
-                              int32_t* out_label, void* stream)
+                              int64_t max_sub_len, int32_t* out_label, void* stream)
 {
     if (!rowptr || !col_sorted || !sub_ptr || !sub_nodes || !out_label || n_subgraphs < 0) return SGNN_ERR_BAD_ARG;
     if (nnz >= (1ll << 31)) return SGNN_ERR_NNZ_TOO_LARGE;
     if (n_subgraphs == 0) return SGNN_OK;
     const int grid = (int)(n_subgraphs < 256 * 32 ? n_subgraphs : 256 * 32);
-    hipLaunchKernelGGL(cc_labels_kernel, dim3(grid), dim3(64), 0, (hipStream_t)stream, rowptr, col_sorted,
+    hipLaunchKernelGGL(cc_labels_kernel<64>, dim3(grid), dim3(64), 0, (hipStream_t)stream, rowptr, col_sorted,
                        sub_ptr, sub_nodes, n_subgraphs, out_label);
+    if (max_sub_len <= 0 || max_sub_len > 64)
+        hipLaunchKernelGGL(cc_labels_kernel<CC_MAX>, dim3(grid < 2048 ? grid : 2048), dim3(64), 0, (hipStream_t)stream,
+                           rowptr, col_sorted, sub_ptr, sub_nodes, n_subgraphs, out_label);
     SGNN_CHECK_LAUNCH();
     return SGNN_OK;
 }

@@ -164,7 +164,7 @@ def cc_labels(g, subs):
         raise _lib.SubgnnHipError('sgnn_cc_labels: subgraph larger than 2048 nodes')
     out = torch.empty(subs.nodes.numel(), dtype=torch.int32, device=g.device)
     check(lib.sgnn_cc_labels(_ptr(g.rowptr), _ptr(g.col_sorted), g.nnz, _ptr(subs.ptr), _ptr(subs.nodes), subs.n,
-                             _ptr(out), _stream()), 'sgnn_cc_labels')
+                             int(subs.max_len), _ptr(out), _stream()), 'sgnn_cc_labels')
     return out
 
 
