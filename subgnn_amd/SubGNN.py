@@ -579,9 +579,9 @@ class SubGNN(nn.Module):
             subgraph_embedding = subgraph_utils.weighted_sum(all_cc_embeds, attn_weights)
         else:
             subgraph_embedding = subgraph_utils.masked_sum(all_cc_embeds, cc_embed_mask.unsqueeze(-1), dim=1)
-        h = self.lin_dropout(F.relu(self.lin(subgraph_embedding)))
-        h = self.lin_dropout2(F.relu(self.lin2(h)))
-        return self.lin3(h)
+        h = self.lin_dropout(F.relu(ops.linear(subgraph_embedding, self.lin.weight, self.lin.bias)))
+        h = self.lin_dropout2(F.relu(ops.linear(h, self.lin2.weight, self.lin2.bias)))
+        return ops.linear(h, self.lin3.weight, self.lin3.bias)
 
     # ------------------------------------------------------------------ steps -------------
     def _forward_batch(self, split, batch):

@@ -26,7 +26,8 @@ class SG_MPN(nn.Module):
         B, C, D = cc_embeds.shape
         if self.hparams['use_mpn_projection']:
             # applied to every component row, padded ones included (mpn:168,239)
-            out = F.relu(self.linear(torch.cat([cc_embeds.reshape(B * C, D), agg], dim=1)))
+            out = F.relu(ops.linear(torch.cat([cc_embeds.reshape(B * C, D), agg], dim=1), self.linear.weight,
+                                    self.linear.bias))
         else:
             out = agg
         z = z.view(B, C, -1)
