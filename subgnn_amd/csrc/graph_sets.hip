@@ -249,6 +249,9 @@ extern "C" int sgnn_cc_compact(const int64_t* sub_ptr, const int32_t* sub_nodes,
 #define KB_MAX_WG_G 1024
 #define KB_MAX_WG_L 256
 #define KB_LDS_BYTES (150 * 1024)      // bitmap; the rest of the 160 KB holds the rank tables of the fused draw
+#ifndef KB_INFLIGHT
+#define KB_INFLIGHT 2                    // 64-edge chunks a wavefront has in flight during the expansion
+#endif
 #define KB_SEL_CHUNK 256                // slots answered per pass (selected ids staged in LDS for the hop lookup)
 
 static inline int64_t kb_words(int64_t max_id) { return (max_id + 32) / 32; }
@@ -392,7 +395,7 @@ __global__ __launch_bounds__(THREADS) void khop_border_kernel(
             const int f1 = (h == 1) ? n : s_lvl[h - 1];
             // The frontier is taken 64 nodes at a time and their neighbour lists are handled as ONE
             // flat edge range dealt to the wavefronts in 64-edge chunks (a hub's list is shared by
-            // all wavefronts instead of serialising one of them), two chunks in flight per wavefront.
+            // all wavefronts instead of serialising one of them), KB_INFLIGHT chunks in flight per wavefront.
             for (int t0 = f0; t0 < f1; t0 += 64) {
                 if (wave == 0) {
                     int32_t deg = 0;
@@ -415,11 +418,11 @@ __global__ __launch_bounds__(THREADS) void khop_border_kernel(
                 int32_t excl = __shfl_up(incl, 1);
                 if (lane == 0) excl = 0;
                 const int32_t total = __shfl(incl, 63);
-                for (int32_t cb = wave * 64; cb < total; cb += 2 * NW * 64) {
-                    int32_t c[2];
-                    bool valid[2];
+                for (int32_t cb = wave * 64; cb < total; cb += KB_INFLIGHT * NW * 64) {
+                    int32_t c[KB_INFLIGHT];
+                    bool valid[KB_INFLIGHT];
 #pragma unroll
-                    for (int u = 0; u < 2; ++u) {
+                    for (int u = 0; u < KB_INFLIGHT; ++u) {
                         const int32_t t = cb + u * NW * 64 + lane;
                         valid[u] = t < total;
                         int lo = 0, hi = 63;                      // smallest m with incl[m] > t
@@ -435,7 +438,7 @@ __global__ __launch_bounds__(THREADS) void khop_border_kernel(
                         c[u] = valid[u] ? col[m_r0 + (uint32_t)(t - m_excl)] : 0;
                     }
 #pragma unroll
-                    for (int u = 0; u < 2; ++u) {
+                    for (int u = 0; u < KB_INFLIGHT; ++u) {
                         if (cb + u * NW * 64 >= total) break;     // wave-uniform
                         bool fresh = false;
                         const int32_t cc = ego_mode ? c[u] - 1 : c[u];
