@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256) void msbfs_expand_kernel(
                     const int64_t u = col[e];
 #pragma unroll
                     for (int k = 0; k < MSBFS_WCHUNK; ++k)
-                        if (w0 + k < n_words) acc[k] |= frontier[u * n_words + w0 + k];
+                        if (need[k]) acc[k] |= frontier[u * n_words + w0 + k];      // words this node has completed are not read
                 }
                 if (++since == 8) {                          // every 128 neighbours: anything still missing?
                     since = 0;
