@@ -249,6 +249,9 @@ extern "C" int sgnn_cc_compact(const int64_t* sub_ptr, const int32_t* sub_nodes,
 #define KB_MAX_WG_G 1024
 #define KB_MAX_WG_L 256
 #define KB_LDS_BYTES (150 * 1024)      // bitmap; the rest of the 160 KB holds the rank tables of the fused draw
+#ifndef KB_BIG
+#define KB_BIG 1024                     // list length from which a frontier node's list is streamed on its own
+#endif
 #ifndef KB_INFLIGHT
 #define KB_INFLIGHT 2                    // 64-edge chunks a wavefront has in flight during the expansion
 #endif
@@ -368,6 +371,8 @@ __global__ __launch_bounds__(THREADS) void khop_border_kernel(
     __shared__ int32_t s_sel[KB_SEL_CHUNK];
     __shared__ int32_t s_tincl[64];               // frontier tile: inclusive degree scan, row starts
     __shared__ uint32_t s_tr0[64];
+    __shared__ int32_t s_tdeg[64];
+    __shared__ uint32_t s_big[2];                 // members of the tile whose list is streamed on its own
     uint32_t* bm = LDS_BM ? s_bm : bitmaps + (int64_t)blockIdx.x * words;
     int32_t* q = queue_in_output ? nullptr : queues + (int64_t)blockIdx.x * (max_id + 1);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -406,13 +411,73 @@ __global__ __launch_bounds__(THREADS) void khop_border_kernel(
                         r0 = (uint32_t)a;
                         deg = (int32_t)(b - a);
                     }
-                    int32_t incl = deg;
+                    // lists of at least KB_BIG entries are streamed one at a time by all wavefronts (no
+                    // search per chunk); the short ones form the flat range
+                    const uint64_t bigm = __ballot(deg >= KB_BIG);
+                    int32_t incl = deg >= KB_BIG ? 0 : deg;
 #pragma unroll
                     for (int d = 1; d < 64; d <<= 1) { const int32_t t = __shfl_up(incl, d); if (lane >= d) incl += t; }
                     s_tincl[lane] = incl;
                     s_tr0[lane] = r0;
+                    s_tdeg[lane] = deg;
+                    if (lane == 0) { s_big[0] = (uint32_t)bigm; s_big[1] = (uint32_t)(bigm >> 32); }
                 }
                 __syncthreads();
+                int wave_new = 0;
+                // claim the unseen neighbours of all chunks of a group first, then append them with ONE
+                // reservation on the queue counter per wavefront and group (the counter is a single LDS
+                // word shared by 16 wavefronts); a count / draw that needs no queue counts in a register
+#define KB_PROCESS_GROUP()                                                                                     \
+                do {                                                                                           \
+                    uint64_t mk[KB_INFLIGHT];                                                                  \
+                    int32_t cc[KB_INFLIGHT];                                                                   \
+                    int n_new = 0;                                                                             \
+                    _Pragma("unroll") for (int u = 0; u < KB_INFLIGHT; ++u) {                                  \
+                        bool fresh = false;                                                                    \
+                        cc[u] = ego_mode ? c[u] - 1 : c[u];                                                    \
+                        if (valid[u]) {                                                                        \
+                            const uint32_t bit = 1u << (cc[u] & 31);                                           \
+                            const uint32_t old = atomicOr(&bm[cc[u] >> 5], bit);                               \
+                            fresh = !(old & bit);                                                              \
+                        }                                                                                      \
+                        mk[u] = __ballot(fresh);                                                               \
+                        n_new += (int)__popcll(mk[u]);                                                         \
+                    }                                                                                          \
+                    if (n_new) {                                                                               \
+                        if (need_queue) {                                                                      \
+                            int base = 0;                                                                      \
+                            if (lane == 0) base = atomicAdd(&s_qn, n_new);                                     \
+                            base = __shfl(base, 0);                                                            \
+                            _Pragma("unroll") for (int u = 0; u < KB_INFLIGHT; ++u) {                          \
+                                if ((mk[u] >> lane) & 1ull) q[base + __popcll(mk[u] & ((1ull << lane) - 1ull))] = cc[u]; \
+                                base += (int)__popcll(mk[u]);                                                  \
+                            }                                                                                  \
+                        } else {                                                                               \
+                            wave_new += n_new;                                                                 \
+                        }                                                                                      \
+                    }                                                                                          \
+                } while (0)
+#ifndef KB_DEBUG_SKIP_EDGES
+                // (a) the long lists, one after the other, every wavefront a share of each
+                uint64_t bigm = ((uint64_t)s_big[1] << 32) | s_big[0];
+                while (bigm) {
+                    const int m = __ffsll((unsigned long long)bigm) - 1;
+                    bigm &= bigm - 1;
+                    const uint32_t m_r0 = s_tr0[m];
+                    const int32_t m_deg = s_tdeg[m];
+                    for (int32_t cb = wave * 64; cb < m_deg; cb += KB_INFLIGHT * NW * 64) {
+                        int32_t c[KB_INFLIGHT];
+                        bool valid[KB_INFLIGHT];
+#pragma unroll
+                        for (int u = 0; u < KB_INFLIGHT; ++u) {
+                            const int32_t t = cb + u * NW * 64 + lane;
+                            valid[u] = t < m_deg;
+                            c[u] = valid[u] ? col[m_r0 + (uint32_t)t] : 0;
+                        }
+                        KB_PROCESS_GROUP();
+                    }
+                }
+                // (b) the short lists as one flat edge range
                 const int32_t incl = s_tincl[lane];
                 const uint32_t r0 = s_tr0[lane];
                 int32_t excl = __shfl_up(incl, 1);
@@ -437,25 +502,12 @@ __global__ __launch_bounds__(THREADS) void khop_border_kernel(
                         const uint32_t m_r0 = __shfl(r0, m);
                         c[u] = valid[u] ? col[m_r0 + (uint32_t)(t - m_excl)] : 0;
                     }
-#pragma unroll
-                    for (int u = 0; u < KB_INFLIGHT; ++u) {
-                        if (cb + u * NW * 64 >= total) break;     // wave-uniform
-                        bool fresh = false;
-                        const int32_t cc = ego_mode ? c[u] - 1 : c[u];
-                        if (valid[u]) {
-                            const uint32_t bit = 1u << (cc & 31);
-                            const uint32_t old = atomicOr(&bm[cc >> 5], bit);
-                            fresh = !(old & bit);
-                        }
-                        // wave-aggregated append: one LDS atomic per wavefront instead of one per node
-                        const uint64_t mk = __ballot(fresh);
-                        if (mk) {
-                            int base = 0;
-                            if (lane == 0) base = atomicAdd(&s_qn, (int)__popcll(mk));
-                            base = __shfl(base, 0);
-                            if (fresh && need_queue) q[base + __popcll(mk & ((1ull << lane) - 1ull))] = cc;
-                        }
-                    }
+                    KB_PROCESS_GROUP();
+                }
+#endif
+#undef KB_PROCESS_GROUP
+                if (!need_queue && wave_new) {                     // wave-uniform
+                    if (lane == 0) atomicAdd(&s_qn, wave_new);
                 }
                 __syncthreads();                                  // the tile tables are rewritten next
             }
