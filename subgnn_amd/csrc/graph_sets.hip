@@ -390,11 +390,16 @@ __global__ __launch_bounds__(THREADS) void khop_border_kernel(
         const int n = (int)(set_ptr[s + 1] - beg);
         if (queue_in_output) q = out_nodes + out_ptr[s];        // the caller's slice IS the queue
         if (tid == 0) { s_qn = 0; s_lvl[0] = 0; }              // s_lvl[h] = queue length after hop h
-        for (int i = tid; i < n; i += THREADS) {
-            const int32_t v = set_nodes[beg + i];
-            atomicOr(&bm[v >> 5], 1u << (v & 31));
+        // members' bits: a set of at most 64 nodes is one frontier tile, whose builder (wavefront 0)
+        // sets them on the way -- one load round and one barrier less per set
+        const bool members_in_tile = n <= 64;
+        if (!members_in_tile) {
+            for (int i = tid; i < n; i += THREADS) {
+                const int32_t v = set_nodes[beg + i];
+                atomicOr(&bm[v >> 5], 1u << (v & 31));
+            }
+            __syncthreads();
         }
-        __syncthreads();
         for (int h = 1; h <= hops; ++h) {
             const int f0 = (h == 1) ? 0 : s_lvl[h - 2];      // frontier of hop h = nodes found at hop h-1
             const int f1 = (h == 1) ? n : s_lvl[h - 1];
@@ -407,6 +412,7 @@ __global__ __launch_bounds__(THREADS) void khop_border_kernel(
                     uint32_t r0 = 0;
                     if (t0 + lane < f1) {
                         const int32_t v = (h == 1) ? set_nodes[beg + t0 + lane] : q[t0 + lane];
+                        if (h == 1 && members_in_tile) atomicOr(&bm[v >> 5], 1u << (v & 31));
                         const int64_t a = rowptr[v], b = rowptr[v + 1];
                         r0 = (uint32_t)a;
                         deg = (int32_t)(b - a);
