@@ -659,6 +659,9 @@ __global__ __launch_bounds__(DTW_THREADS) void dtw_similarity_kernel(
 #ifndef DTW_MINB12
 #define DTW_MINB12 3            // resident 256-thread blocks per CU the 12-row kernel is compiled for
 #endif
+#ifndef DTW_UNIFORM_BLOCKS
+#define DTW_UNIFORM_BLOCKS 0            // scalar block tests from wave-union ranges: measured no gain (8.86 vs 8.81 ms)
+#endif
 #ifndef DTW_BRANCHLESS_ROWS
 #define DTW_BRANCHLESS_ROWS 1
 #endif
@@ -680,7 +683,7 @@ template <int RMAX, int RR, int TIE, bool WLDS, bool FINEST>
 __device__ __forceinline__ double dtw_reg_level(
     int32_t* __restrict__ fl, const double* __restrict__ xcol, const double* __restrict__ xrcol, int64_t n_x,
     const double* __restrict__ ycol, const double* __restrict__ yrcol,
-    int lx, int ly, int lxc, int lyc, bool coarsest, uint32_t* __restrict__ wl,
+    int lx, int ly, int lxc, int lyc, bool coarsest, int32_t* ublk, uint32_t* __restrict__ wl,
     uint64_t* __restrict__ wq, int64_t NT)
 {
     constexpr bool finest = FINEST;
@@ -725,6 +728,33 @@ __device__ __forceinline__ double dtw_reg_level(
         }
         blk[b] = hi < 0 ? EMPTY : (((hi + 1) << 16) | lo);
     }
+#if DTW_UNIFORM_BLOCKS
+    // The block tests of the column loop become scalar: the lanes of a wavefront work on similar
+    // series, so the union of their block ranges (LDS min / max over the active lanes, once per level,
+    // read back into scalar registers) is what the wavefront executes anyway -- testing it with
+    // s_cmp / s_cbranch costs the vector pipeline nothing, where the per-lane test cost ~5 vector
+    // instructions per block and column.  Rows inside a live block select by their own window.
+    int ublo[RR / 4], ubhi[RR / 4];
+    {
+        int32_t* su = ublk + (threadIdx.x >> 6) * 16;
+        const int l16 = threadIdx.x & 15;
+        if ((threadIdx.x & 63) < 16) su[l16] = (l16 & 1) ? -1 : 0x7fff;          // even: lo, odd: hi
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int b = 0; b < RR / 4; ++b)
+            if (blk[b] != EMPTY) { atomicMin(&su[2 * b], blk[b] & 0xffff); atomicMax(&su[2 * b + 1], blk[b] >> 16); }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int b = 0; b < RR / 4; ++b) {
+            ublo[b] = __builtin_amdgcn_readfirstlane(su[2 * b]);
+            ubhi[b] = __builtin_amdgcn_readfirstlane(su[2 * b + 1]);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+#endif
     double xp1[RR], xr[RR], col[RR];
 #pragma unroll
     for (int i = 0; i < RR; ++i) {
@@ -741,7 +771,11 @@ __device__ __forceinline__ double dtw_reg_level(
         double diag = (j == 0) ? 0.0 : INF;                                  // virtual origin D[0][0] = 0
 #pragma unroll
         for (int b = 0; b < RR / 4; ++b) {
+#if DTW_UNIFORM_BLOCKS
+            if (j >= ublo[b] && j <= ubhi[b]) {
+#else
             if (j >= (blk[b] & 0xffff) && j <= (blk[b] >> 16)) {
+#endif
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int i = 4 * b + q;
@@ -823,6 +857,7 @@ __global__ __launch_bounds__(DTW_THREADS, MINB) void dtw_similarity_reg_kernel(
     float* __restrict__ out, uint64_t* __restrict__ wq, DtwLayout L, const int32_t* __restrict__ x_order)
 {
     __shared__ int32_t s_fl[RMAX * DTW_THREADS];
+    __shared__ int32_t s_ublk[(DTW_THREADS / 64) * 16];                   // per wavefront: union block ranges
     extern __shared__ uint32_t s_words[];                    // WLDS: (max_y_len / 2) x DTW_THREADS predecessor words
     int32_t* fl = s_fl + threadIdx.x;
     uint32_t* wl = s_words + threadIdx.x;
@@ -853,7 +888,7 @@ __global__ __launch_bounds__(DTW_THREADS, MINB) void dtw_similarity_reg_kernel(
             const double* yrcol = ycol + L.YL * n_y;
             uint64_t* w = wq + L.yoff[lev] * NT + tid;
             const bool coarsest = lev == n_levels - 1, finest = lev == 0;
-#define DTW_LEVEL_F(RR, F) result = dtw_reg_level<RMAX, (RR) <= RMAX ? (RR) : RMAX, TIE, WLDS, F>(fl, xcol, xrcol, n_x, ycol, yrcol, lx, ly, lxc, lyc, coarsest, wl, w, NT)
+#define DTW_LEVEL_F(RR, F) result = dtw_reg_level<RMAX, (RR) <= RMAX ? (RR) : RMAX, TIE, WLDS, F>(fl, xcol, xrcol, n_x, ycol, yrcol, lx, ly, lxc, lyc, coarsest, s_ublk, wl, w, NT)
 #define DTW_LEVEL(RR) do { if (finest) DTW_LEVEL_F(RR, true); else DTW_LEVEL_F(RR, false); } while (0)
             if (lx <= 4) DTW_LEVEL(4);                       // narrow instantiations: the unrolled row
             else if (lx <= 8) DTW_LEVEL(8);                  // loop sweeps at most 3 empty rows
