@@ -146,7 +146,9 @@ __device__ __forceinline__ void ds_count(const int32_t* __restrict__ col, const 
     }
 }
 
-template <bool SORTED>
+// FEW: instantiation taken by launches over a handful of sets (the anchor patches: a few hundred);
+// same code -- it only keeps those microsecond launches apart from the shard-sized ones in profiles.
+template <bool SORTED, bool FEW = false>
 __global__ __launch_bounds__(64 * DS_WAVES) void degseq_wave_kernel(
     const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
     const int32_t* __restrict__ full_degree, const uint8_t* __restrict__ self_loops,
@@ -375,12 +377,12 @@ extern "C" int sgnn_degree_sequence(const int64_t* rowptr, const int32_t* col, i
     // cost (sum of member degrees) better than a static grid-stride assignment
     const int64_t want = (n_sets + DS_WAVES - 1) / DS_WAVES;
     const int grid = (int)(want < (1 << 20) ? want : (1 << 20));
-    if (sorted)
-        hipLaunchKernelGGL(degseq_wave_kernel<true>, dim3(grid), dim3(64 * DS_WAVES), 0, st, rowptr, col, full_degree,
-                           self_loops, set_ptr, set_nodes, n_sets, out_internal, out_external);
-    else
-        hipLaunchKernelGGL(degseq_wave_kernel<false>, dim3(grid), dim3(64 * DS_WAVES), 0, st, rowptr, col, full_degree,
-                           self_loops, set_ptr, set_nodes, n_sets, out_internal, out_external);
+    const bool few = n_sets <= 4096;
+#define DS_LAUNCH(S, F) hipLaunchKernelGGL((degseq_wave_kernel<S, F>), dim3(grid), dim3(64 * DS_WAVES), 0, st, rowptr, col, \
+                                           full_degree, self_loops, set_ptr, set_nodes, n_sets, out_internal, out_external)
+    if (sorted) { if (few) DS_LAUNCH(true, true); else DS_LAUNCH(true, false); }
+    else { if (few) DS_LAUNCH(false, true); else DS_LAUNCH(false, false); }
+#undef DS_LAUNCH
     SGNN_CHECK_LAUNCH();
     if (max_set_size > 64) {
         const int gridb = (int)(n_sets < 256 * 4 ? n_sets : 256 * 4);
