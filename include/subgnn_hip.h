@@ -53,12 +53,14 @@ const char* sgnn_last_error(void);
  * self_loops (nullable): uint8[max_id + 1], number of self-loop entries in each node's CSR row;
  * when given, the kernel does not have to test every streamed neighbour against the row's owner.
  * max_set_size: upper bound on set length known to the caller (0 = unknown).
+ * set_order (nullable): int32[n_sets], a permutation: the order in which sets are handed to the
+ * hardware dispatcher (results are unaffected); heaviest-first shortens the tail of the launch.
  * ------------------------------------------------------------------------------------- */
 int sgnn_degree_sequence(const int64_t* rowptr, const int32_t* col, int64_t nnz,
                          const int32_t* full_degree, const uint8_t* self_loops,
                          const int64_t* set_ptr, const int32_t* set_nodes, int64_t n_sets,
                          int64_t max_set_size, int sorted,
-                         int32_t* out_internal, int32_t* out_external, void* stream);
+                         int32_t* out_internal, int32_t* out_external, const int32_t* set_order, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * a7  Connected components of induced subgraphs.
@@ -124,6 +126,7 @@ int sgnn_khop_border_sample(const int64_t* rowptr, const int32_t* col, int64_t n
                             const int64_t* set_ptr, const int32_t* set_nodes, int64_t n_sets, int k,
                             int64_t n_slots, uint64_t seed, uint64_t stream_id,
                             int64_t* out_anchor, uint8_t* out_hop, uint8_t* out_allneg, int64_t* out_count,
+                            const int32_t* set_order /* nullable: dispatch order of the sets, a permutation */,
                             void* workspace, int64_t workspace_bytes, int bitmap_in_lds, void* stream);
 
 /* ---------------------------------------------------------------------------------------

@@ -153,14 +153,16 @@ __global__ __launch_bounds__(64 * DS_WAVES) void degseq_wave_kernel(
     const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
     const int32_t* __restrict__ full_degree, const uint8_t* __restrict__ self_loops,
     const int64_t* __restrict__ set_ptr, const int32_t* __restrict__ set_nodes, int64_t n_sets,
-    int32_t* __restrict__ out_int, int32_t* __restrict__ out_ext)
+    int32_t* __restrict__ out_int, int32_t* __restrict__ out_ext, const int32_t* __restrict__ set_order)
 {
     // one hash table per wavefront; a wavefront's LDS operations execute in issue order, so the
     // waves of a workgroup never need a workgroup barrier (they work on different sets)
     __shared__ int32_t hash_all[DS_WAVES][DS_HASH];
     const int lane = threadIdx.x & 63;
     int32_t* hash = hash_all[threadIdx.x >> 6];
-    for (int64_t s = (int64_t)blockIdx.x * DS_WAVES + (threadIdx.x >> 6); s < n_sets; s += (int64_t)gridDim.x * DS_WAVES) {
+    for (int64_t si = (int64_t)blockIdx.x * DS_WAVES + (threadIdx.x >> 6); si < n_sets; si += (int64_t)gridDim.x * DS_WAVES) {
+        // set_order: the caller's dispatch order (heaviest sets first keeps the tail of the launch short)
+        const int64_t s = set_order ? set_order[si] : si;
         const int64_t beg = set_ptr[s];
         const int n = (int)(set_ptr[s + 1] - beg);
         if (n <= 0 || n > 64) continue;                     // wave-uniform
@@ -364,7 +366,8 @@ extern "C" int sgnn_degree_sequence(const int64_t* rowptr, const int32_t* col, i
                                     const int32_t* full_degree, const uint8_t* self_loops,
                                     const int64_t* set_ptr, const int32_t* set_nodes, int64_t n_sets,
                                     int64_t max_set_size, int sorted,
-                                    int32_t* out_internal, int32_t* out_external, void* stream)
+                                    int32_t* out_internal, int32_t* out_external, const int32_t* set_order,
+                                    void* stream)
 {
     if (!rowptr || !col || !set_ptr || !set_nodes || !out_internal || n_sets < 0 || max_set_size <= 0)
         return SGNN_ERR_BAD_ARG;
@@ -379,7 +382,7 @@ extern "C" int sgnn_degree_sequence(const int64_t* rowptr, const int32_t* col, i
     const int grid = (int)(want < (1 << 20) ? want : (1 << 20));
     const bool few = n_sets <= 4096;
 #define DS_LAUNCH(S, F) hipLaunchKernelGGL((degseq_wave_kernel<S, F>), dim3(grid), dim3(64 * DS_WAVES), 0, st, rowptr, col, \
-                                           full_degree, self_loops, set_ptr, set_nodes, n_sets, out_internal, out_external)
+                                           full_degree, self_loops, set_ptr, set_nodes, n_sets, out_internal, out_external, set_order)
     if (sorted) { if (few) DS_LAUNCH(true, true); else DS_LAUNCH(true, false); }
     else { if (few) DS_LAUNCH(false, true); else DS_LAUNCH(false, false); }
 #undef DS_LAUNCH

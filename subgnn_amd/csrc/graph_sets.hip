@@ -270,7 +270,7 @@ extern "C" int64_t sgnn_khop_border_workspace_bytes(int64_t max_id, int64_t n_se
     // per workgroup: a BFS queue, plus the visited bitmap when it does not live in LDS
     const bool lds = bitmap_in_lds != 0;
     const int64_t per_wg = (lds ? 0 : kb_words(max_id) * 4) + (max_id + 1) * 4;
-    return per_wg * kb_n_wg(n_sets, lds);
+    return per_wg * kb_n_wg(n_sets, lds) + 16;                  // + the device-wide set counter
 }
 
 struct KbSample {             // fused neighbourhood-border anchor draw (all NULL/0 = off)
@@ -361,7 +361,8 @@ __global__ __launch_bounds__(THREADS) void khop_border_kernel(
     int k, int ego_mode,
     int64_t* __restrict__ out_count, const int64_t* __restrict__ out_ptr,
     int32_t* __restrict__ out_nodes, uint8_t* __restrict__ out_hop,
-    uint32_t* __restrict__ bitmaps, int32_t* __restrict__ queues, int64_t words, KbSample smp, int queue_in_output)
+    uint32_t* __restrict__ bitmaps, int32_t* __restrict__ queues, int64_t words, KbSample smp, int queue_in_output,
+    unsigned long long* __restrict__ next_set, const int32_t* __restrict__ set_order)
 {
     extern __shared__ uint32_t s_bm[];
     __shared__ int32_t s_qn;
@@ -385,7 +386,16 @@ __global__ __launch_bounds__(THREADS) void khop_border_kernel(
         for (int64_t i = tid; i < words; i += THREADS) s_bm[i] = 0;
         __syncthreads();
     }
-    for (int64_t s = blockIdx.x; s < n_sets; s += gridDim.x) {
+    // Sets are taken from a device-wide counter (their cost varies by orders of magnitude with the
+    // members' degrees: a static round-robin leaves CUs idle behind the unlucky ones), in the caller's
+    // dispatch order when given (heaviest first).
+    __shared__ long long s_next;
+    while (true) {
+        if (tid == 0) s_next = (long long)atomicAdd(next_set, 1ull);
+        __syncthreads();
+        const int64_t si = s_next;
+        if (si >= n_sets) break;
+        const int64_t s = set_order ? set_order[si] : si;
         const int64_t beg = set_ptr[s];
         const int n = (int)(set_ptr[s + 1] - beg);
         if (queue_in_output) q = out_nodes + out_ptr[s];        // the caller's slice IS the queue
@@ -562,7 +572,7 @@ static int kb_launch(const int64_t* rowptr, const int32_t* col, int64_t nnz, int
                      const int64_t* set_ptr, const int32_t* set_nodes, int64_t n_sets, int k, int ego_dict_mode,
                      int64_t* out_count, const int64_t* out_ptr, int32_t* out_nodes, uint8_t* out_hop,
                      void* workspace, int64_t workspace_bytes, int bitmap_in_lds, KbSample smp, void* stream,
-                     int queue_in_output = 0)
+                     int queue_in_output = 0, const int32_t* set_order = nullptr)
 {
     if (!rowptr || !col || !set_ptr || !set_nodes || !workspace || n_sets < 0 || k < 1 || k > 255)
         return SGNN_ERR_BAD_ARG;
@@ -576,6 +586,10 @@ static int kb_launch(const int64_t* rowptr, const int32_t* col, int64_t nnz, int
     uint32_t* bitmaps = (uint32_t*)workspace;                     // empty region for the LDS variant
     int32_t* queues = (int32_t*)(bitmaps + (bitmap_in_lds ? 0 : words * nwg));
     hipStream_t st = (hipStream_t)stream;
+    // the set counter sits behind the per-workgroup regions, 8-byte aligned
+    const int64_t body = ((bitmap_in_lds ? 0 : words * 4) + (max_id + 1) * 4) * nwg;
+    unsigned long long* next_set = (unsigned long long*)((char*)workspace + ((body + 7) & ~(int64_t)7));
+    (void)hipMemsetAsync(next_set, 0, 8, st);
     if (bitmap_in_lds) {
         static bool attr_set = false;
         if (!attr_set) {
@@ -585,11 +599,12 @@ static int kb_launch(const int64_t* rowptr, const int32_t* col, int64_t nnz, int
         }
         hipLaunchKernelGGL((khop_border_kernel<true, KB_THREADS_L>), dim3((int)nwg), dim3(KB_THREADS_L),
                            (size_t)(((words + 3) / 4) * 16), st, rowptr, col, max_id, set_ptr, set_nodes, n_sets, k, ego_dict_mode,
-                           out_count, out_ptr, out_nodes, out_hop, bitmaps, queues, words, smp, queue_in_output);
+                           out_count, out_ptr, out_nodes, out_hop, bitmaps, queues, words, smp, queue_in_output, next_set,
+                           set_order);
     } else {
         hipLaunchKernelGGL((khop_border_kernel<false, KB_THREADS_G>), dim3((int)nwg), dim3(KB_THREADS_G), 0, st,
                            rowptr, col, max_id, set_ptr, set_nodes, n_sets, k, ego_dict_mode, out_count, out_ptr,
-                           out_nodes, out_hop, bitmaps, queues, words, smp, queue_in_output);
+                           out_nodes, out_hop, bitmaps, queues, words, smp, queue_in_output, next_set, set_order);
     }
     SGNN_CHECK_LAUNCH();
     return SGNN_OK;
@@ -626,12 +641,13 @@ extern "C" int sgnn_khop_border_sample(const int64_t* rowptr, const int32_t* col
                                        const int64_t* set_ptr, const int32_t* set_nodes, int64_t n_sets, int k,
                                        int64_t n_slots, uint64_t seed, uint64_t stream_id,
                                        int64_t* out_anchor, uint8_t* out_hop, uint8_t* out_allneg, int64_t* out_count,
+                                       const int32_t* set_order,
                                        void* workspace, int64_t workspace_bytes, int bitmap_in_lds, void* stream)
 {
     if (!out_anchor || !out_hop || !out_allneg || !out_count || n_slots < 1) return SGNN_ERR_BAD_ARG;
     KbSample smp = {n_slots, sgnn_tape_h0(seed, stream_id), out_anchor, out_hop, out_allneg};
     return kb_launch(rowptr, col, nnz, max_id, set_ptr, set_nodes, n_sets, k, 0, out_count, nullptr, nullptr, nullptr,
-                     workspace, workspace_bytes, bitmap_in_lds, smp, stream);
+                     workspace, workspace_bytes, bitmap_in_lds, smp, stream, 0, set_order);
 }
 
 // ---------------------------------------------------------------------------------------------

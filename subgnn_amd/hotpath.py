@@ -94,6 +94,14 @@ def prepare_sparse(model, split='train', timer=None):
     t.mark('components')
     model.init_all_embeddings(split=split, trainable=hp['trainable_cc'])
     t.mark('cc_embed')
+    # dispatch order of the component sets, heaviest (largest total degree) first: a property of the
+    # split's subgraphs and the graph, computed once per split and kept.  The set kernels whose cost is
+    # the members' degree sum (degree sequences, border BFS) take their sets in this order.
+    orders = model.__dict__.setdefault('_degseq_order', {})
+    if orders.get(split) is None or orders[split].numel() != cc_sets.n:
+        orders[split] = ops.heaviest_first(g, cc_sets)
+        t.mark('set_dispatch_order(first pass only)')
+    set_order = orders[split]
     sims = {}
     a_sets = ai = ae = None
     # ---- side stream: position channel + structure patches / walks -------------------------
@@ -153,7 +161,7 @@ def prepare_sparse(model, split='train', timer=None):
             # border BFS fused with the border-anchor draw (rank query on the visited bitmap): the
             # border is never materialised
             a, w, _ = ops.khop_border_sample(g, cc_sets, k, hp['n_anchor_patches_N_out'], seed,
-                                             tape.stream_id(tape.STREAM_N_BOR, split, l))
+                                             tape.stream_id(tape.STREAM_N_BOR, split, l), order=set_order)
             nb[l] = a.view(S, C, -1)
             sims[('N', 'out', l)] = w.view(S, C, -1).contiguous()
         if getattr(model, 'anchors_neigh_int', None) is None:
@@ -162,7 +170,8 @@ def prepare_sparse(model, split='train', timer=None):
         t.mark('border_bfs+N_anchors')
     ci = ce = None
     if hp['use_structure']:
-        ci, ce = ops.degree_sequence(g, cc_sets, sort=True, use_degree_dict=g.full_degree is not None)
+        ci, ce = ops.degree_sequence(g, cc_sets, sort=True, use_degree_dict=g.full_degree is not None,
+                                     order=set_order)
         t.mark('degree_sequences')
     # ---- join ------------------------------------------------------------------------------
     if side is not main:

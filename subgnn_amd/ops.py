@@ -143,7 +143,17 @@ class DeviceGraph:
 # integer half
 # ---------------------------------------------------------------------------------------
 
-def degree_sequence(g, sets, sort=True, use_degree_dict=True, want_external=True, use_self_loop_table=True):
+def heaviest_first(g, sets):
+    """Dispatch order for set kernels whose cost is the members' total degree: heaviest sets first."""
+    tot = int(sets.ptr[-1].item())
+    deg = (g.rowptr[1:] - g.rowptr[:-1])[sets.nodes[:tot].long()]
+    csum = torch.zeros(tot + 1, dtype=torch.int64, device=g.device)
+    torch.cumsum(deg, 0, out=csum[1:])
+    work = csum[sets.ptr[1:]] - csum[sets.ptr[:-1]]
+    return torch.argsort(work, descending=True).to(torch.int32).contiguous()
+
+
+def degree_sequence(g, sets, sort=True, use_degree_dict=True, want_external=True, use_self_loop_table=True, order=None):
     """gamma.get_degree_sequence for every set at once -> (internal, external) int32 flat
     tensors aligned with ``sets.nodes`` (each set's slice sorted ascending if ``sort``)."""
     lib = _lib.load()
@@ -154,7 +164,7 @@ def degree_sequence(g, sets, sort=True, use_degree_dict=True, want_external=True
     sl = g.self_loops if use_self_loop_table else None
     check(lib.sgnn_degree_sequence(_ptr(g.rowptr), _ptr(g.col), g.nnz, _ptr(fd), _ptr(sl), _ptr(sets.ptr),
                                    _ptr(sets.nodes), sets.n, max(sets.max_len, 1), 1 if sort else 0, _ptr(out_i),
-                                   _ptr(out_e), _stream()), 'sgnn_degree_sequence')
+                                   _ptr(out_e), _ptr(order), _stream()), 'sgnn_degree_sequence')
     return out_i, out_e
 
 
@@ -247,7 +257,7 @@ def khop_border_one_pass(g, sets, bitmap_in_lds=None):
     return arena, off, counts
 
 
-def khop_border_sample(g, sets, k, n_slots, seed, stream_id, bitmap_in_lds=None):
+def khop_border_sample(g, sets, k, n_slots, seed, stream_id, bitmap_in_lds=None, order=None):
     """k-hop border BFS + neighbourhood-border anchor draw without a padded border matrix.  Returns
     anchors (n_sets, n_slots) int64 with the reference's PAD rule applied, their hop levels as
     float32 similarities (0 on PAD) and the border sizes.  One fused kernel: the draw is a rank
@@ -261,7 +271,7 @@ def khop_border_sample(g, sets, k, n_slots, seed, stream_id, bitmap_in_lds=None)
     allneg = torch.empty((sets.n, n_slots), dtype=torch.uint8, device=g.device)
     check(lib.sgnn_khop_border_sample(_ptr(g.rowptr), _ptr(g.col), g.nnz, g.max_id, _ptr(sets.ptr), _ptr(sets.nodes),
                                       sets.n, k, n_slots, seed, stream_id, _ptr(anchor), _ptr(hop), _ptr(allneg),
-                                      _ptr(counts), _ptr(ws), ws_bytes, 1 if lds else 0, _stream()),
+                                      _ptr(counts), _ptr(order), _ptr(ws), ws_bytes, 1 if lds else 0, _stream()),
           'sgnn_khop_border_sample')
     # aps:190: padded columns hold 0, so PAD wins when every real variate is negative and the
     # padded row (width = the largest border) has at least one PAD column

@@ -85,6 +85,11 @@ def test_degree_sequence_random(sizes):
     sets[5] = []
     r = ops.Ragged.from_lists(sets, DEV)
     rp, col = G.csr()
+    hf = ops.heaviest_first(dg, r)                       # a permutation; the dispatch order changes nothing
+    assert sorted(hf.cpu().tolist()) == list(range(len(sets)))
+    a0, b0 = ops.degree_sequence(dg, r, use_degree_dict=False)
+    a1, b1 = ops.degree_sequence(dg, r, use_degree_dict=False, order=hf)
+    assert torch.equal(a0, a1) and torch.equal(b0, b1)
     for srt in (True, False):
         for table in (True, False):        # self loops from the per-node table / counted while streaming
             oi, oe = ops.degree_sequence(dg, r, sort=srt, use_degree_dict=False, use_self_loop_table=table)

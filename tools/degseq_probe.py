@@ -22,3 +22,14 @@ for srt in (True,):
         ops.degree_sequence(g, sets, sort=srt)
     torch.cuda.synchronize()
     print('sorted' if srt else 'unsorted', (time.perf_counter() - t) / reps * 1e3, 'ms')
+
+order = ops.heaviest_first(g, sets)
+ops.degree_sequence(g, sets, order=order)
+torch.cuda.synchronize()
+t = time.perf_counter()
+for _ in range(reps):
+    oi2, oe2 = ops.degree_sequence(g, sets, order=order)
+torch.cuda.synchronize()
+print('heaviest first', (time.perf_counter() - t) / reps * 1e3, 'ms')
+oi, oe = ops.degree_sequence(g, sets)
+print('same results', bool(torch.equal(oi, oi2) and torch.equal(oe, oe2)))

@@ -30,5 +30,7 @@ print('BFS count-only, LDS bitmap', timeit(lambda: count_only(True)))
 print('BFS count-only, global bitmap', timeit(lambda: count_only(False)))
 for A in (4, 16, 43):
     print('BFS + draw (bitmap rank query), %d slots' % A, timeit(lambda: ops.khop_border_sample(g, sets, 1, A, 0, 77)))
+order = ops.heaviest_first(g, sets)
+print('BFS + draw, 43 slots, heaviest-first dispatch', timeit(lambda: ops.khop_border_sample(g, sets, 1, 43, 0, 77, order=order)))
 c = count_only(True)
 print('border entries total', int(c.sum()), 'mean', float(c.float().mean()), 'max', int(c.max()))
