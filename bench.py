@@ -210,13 +210,13 @@ def main():
     achieved = alg_bytes / (ds_ms * 1e-3) / 1e9
 
     traffic, traffic_src = None, None
-    tf = os.path.join(REPO, 'profiles', 'r01i_degseq_traffic.json')
+    tf = os.path.join(REPO, 'profiles', 'r01z_degseq_traffic.json')
     if os.path.exists(tf) and args.nodes == 1_000_000 and S == 50_000:
         # PMC passes cannot run inside this process; this is the committed rocprofv3 measurement of
         # the same launch (same graph seed, same 50k sets): raw FETCH_SIZE + WRITE_SIZE bytes
         with open(tf) as f:
             tj = json.load(f)
-        traffic, traffic_src = tj['hbm_bytes_per_launch_raw'], 'profiles/r01i_degseq_traffic.json (rocprofv3 --pmc, separate passes)'
+        traffic, traffic_src = tj['hbm_bytes_per_launch_raw'], 'profiles/r01z_degseq_traffic.json (rocprofv3 --pmc, separate passes)'
     result = {
         'metric': 'subgraphs/sec fwd+bwd (all 3 channels on) + achieved HBM GB/s',
         'value': world * S * args.steps / elapsed, 'unit': 'subgraphs/s', 'n_gpus': world, 'steps': args.steps,
@@ -233,7 +233,7 @@ def main():
                      'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                      'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_src,
                      'algorithmic_bytes_per_launch': alg_bytes, 'ms_per_launch': ds_ms, 'ms_per_launch_back_to_back': ds_ms_b2b, 'sets_per_launch': cc_sets.n,
-                     'note': 'algorithmic bytes / time; the CSR (88 MB) fits the 256 MiB Infinity Cache and hub lists are re-read from the XCD L2s, so most of these bytes are served on-die (memory-side traffic is ~0.27 GB per launch)'},
+                     'note': 'algorithmic bytes / time; the CSR (88 MB) fits the 256 MiB Infinity Cache and hub lists are re-read from the XCD L2s, so most of these bytes are served on-die (memory-side traffic is ~0.26 GB per launch)'},
         'stages_ms': {k: round(v, 3) for k, v in stage_ms.items()},
         'loss': loss, 'setup_s': round(t_gen, 1),
     }

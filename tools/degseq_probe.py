@@ -14,7 +14,8 @@ dev = torch.device('cuda:0')
 g = ops.DeviceGraph(rowptr, col, np.arange(1, n + 1, dtype=np.int32), dev)
 sets = ops.Ragged.from_lists(subs, dev)
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
-for srt in (True,):
+ONLY_ORDERED = len(sys.argv) > 2 and sys.argv[2] == 'ordered'      # PMC passes: only the benchmark's form of the launch
+for srt in (() if ONLY_ORDERED else (True,)):
     ops.degree_sequence(g, sets, sort=srt)
     torch.cuda.synchronize()
     t = time.perf_counter()
@@ -31,5 +32,6 @@ for _ in range(reps):
     oi2, oe2 = ops.degree_sequence(g, sets, order=order)
 torch.cuda.synchronize()
 print('heaviest first', (time.perf_counter() - t) / reps * 1e3, 'ms')
-oi, oe = ops.degree_sequence(g, sets)
-print('same results', bool(torch.equal(oi, oi2) and torch.equal(oe, oe2)))
+if not ONLY_ORDERED:
+    oi, oe = ops.degree_sequence(g, sets)
+    print('same results', bool(torch.equal(oi, oi2) and torch.equal(oe, oe2)))
