@@ -186,6 +186,9 @@ def main():
     for tm in timers:
         for k, v in tm.summary().items():
             stage_ms[k] = stage_ms.get(k, 0.0) + v / args.steps
+    if os.environ.get('SGNN_BENCH_PER_STEP'):
+        for i, tm in enumerate(timers):
+            print('step', i, {k: round(v, 3) for k, v in tm.summary().items()}, file=sys.stderr)
 
     # ---- roofline of the structure-channel CSR gather, measured live ------------------------
     cc_ids = model.train_cc_ids
