@@ -65,7 +65,7 @@ extern "C" int sgnn_sp_similarity_dense(const double* apsp, int64_t n_cols,
 //            new bits; flags[level] says whether any bit was new (later levels exit early);
 //            fvol[level] = sum over new frontier words of the node's degree.
 // ---------------------------------------------------------------------------------------------
-static int g_bfs_alpha = 16;    // pull when frontier word-edges * alpha > nnz * n_words; 0 = never pull
+static int g_bfs_alpha = 256;    // pull when frontier word-edges * alpha > nnz * n_words; 0 = never pull
 
 extern "C" int sgnn_bfs_hops_tuning(int alpha)
 {
@@ -77,11 +77,12 @@ extern "C" int sgnn_bfs_hops_tuning(int alpha)
 __global__ void msbfs_init_kernel(const int32_t* __restrict__ sources, int64_t n_sources, int64_t n_words,
                                   int64_t n_ids, uint64_t* __restrict__ seen, uint64_t* __restrict__ frontier,
                                   uint64_t* __restrict__ next, uint8_t* __restrict__ dist, int32_t* __restrict__ flags,
-                                  unsigned long long* __restrict__ fvol,
+                                  unsigned long long* __restrict__ fvol, uint32_t* __restrict__ fbits,
                                   int max_hops)  // dist layout-agnostic: filled as a flat array
 {
     const int64_t gtid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = gtid; i < 2 * ((n_ids + 31) / 32); i += gsz) fbits[i] = 0;
     for (int64_t i = gtid; i < n_ids * n_words; i += gsz) { seen[i] = 0; frontier[i] = 0; next[i] = 0; }
     if (dist) for (int64_t i = gtid; i < n_sources * n_ids; i += gsz) dist[i] = 255;
     for (int64_t i = gtid; i <= max_hops; i += gsz) { flags[i] = (i == 0) ? 1 : 0; fvol[i] = 0; }
@@ -89,11 +90,12 @@ __global__ void msbfs_init_kernel(const int32_t* __restrict__ sources, int64_t n
 
 __global__ void msbfs_seed_kernel(const int32_t* __restrict__ sources, int64_t n_sources, int64_t n_words,
                                   int64_t n_ids, uint64_t* __restrict__ seen, uint64_t* __restrict__ frontier,
-                                  uint8_t* __restrict__ dist, int64_t ss, int64_t sv)
+                                  uint8_t* __restrict__ dist, int64_t ss, int64_t sv, uint32_t* __restrict__ fbits)
 {
     const int64_t s = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (s >= n_sources) return;
     const int32_t v = sources[s];
+    atomicOr(&fbits[v >> 5], 1u << (v & 31));                 // level-0 frontier nodes
     const uint64_t bit = 1ull << (s & 63);
     atomicOr((unsigned long long*)&seen[(int64_t)v * n_words + (s >> 6)], (unsigned long long)bit);
     atomicOr((unsigned long long*)&frontier[(int64_t)v * n_words + (s >> 6)], (unsigned long long)bit);
@@ -117,13 +119,14 @@ __global__ __launch_bounds__(256) void msbfs_expand_kernel(
     const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col, int64_t n_ids, int64_t n_words,
     int64_t n_sources, const uint64_t* __restrict__ seen, const uint64_t* __restrict__ frontier,
     uint64_t* __restrict__ next, const int32_t* __restrict__ flags, const unsigned long long* __restrict__ fvol,
-    unsigned long long pull_above, int level)
+    unsigned long long pull_above, int level, const uint32_t* __restrict__ fnode, unsigned long long sparse_below)
 {
     if (flags[level - 1] == 0) return;                       // previous level found nothing
     const int sub = threadIdx.x & 15;
     const int64_t group = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 4;
     const int64_t n_groups = ((int64_t)gridDim.x * blockDim.x) >> 4;
     const bool pull = level > 1 && pull_above != ~0ull && fvol[level - 1] > pull_above;
+    const bool sparse_frontier = fvol[level - 1] < sparse_below;
     if (!pull) {
         for (int64_t v = group; v < n_ids; v += n_groups) {
             uint64_t any = 0;
@@ -166,9 +169,14 @@ __global__ __launch_bounds__(256) void msbfs_expand_kernel(
             for (int64_t e = r0 + sub; e < r1 + sub; e += 16) {          // uniform trip count per group
                 if (e < r1) {
                     const int64_t u = col[e];
+                    // one bit per node says whether it is on the frontier at all: a 125 KB table that
+                    // stays in L2, consulted before the 24-byte gather from the 24 MB word array -- while the
+                    // frontier is sparse (once most nodes are on it the test only adds a load)
+                    if (!sparse_frontier || ((fnode[u >> 5] >> (u & 31)) & 1u)) {
 #pragma unroll
-                    for (int k = 0; k < MSBFS_WCHUNK; ++k)
-                        if (need[k]) acc[k] |= frontier[u * n_words + w0 + k];      // words this node has completed are not read
+                        for (int k = 0; k < MSBFS_WCHUNK; ++k)
+                            if (need[k]) acc[k] |= frontier[u * n_words + w0 + k];  // completed words are not read
+                    }
                 }
                 if (++since == 8) {                          // every 128 neighbours: anything still missing?
                     since = 0;
@@ -193,9 +201,14 @@ __global__ __launch_bounds__(256) void msbfs_expand_kernel(
 __global__ __launch_bounds__(256) void msbfs_commit_kernel(
     const int64_t* __restrict__ rowptr, int64_t n_ids, int64_t n_words, int64_t n_sources, uint64_t* __restrict__ seen,
     uint64_t* __restrict__ frontier, uint64_t* __restrict__ next, uint8_t* __restrict__ dist, int32_t* __restrict__ flags,
-    unsigned long long* __restrict__ fvol, int level, int64_t ss, int64_t sv)
+    unsigned long long* __restrict__ fvol, int level, int64_t ss, int64_t sv, uint32_t* __restrict__ fcur,
+    uint32_t* __restrict__ fold)
 {
     if (flags[level - 1] == 0) return;
+    // fold: the node bitmap of the frontier before last -- nobody reads it any more; it becomes the
+    // clean slate of the next level.  fcur (clean since the previous commit) receives this level's nodes.
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < (n_ids + 31) / 32;
+         i += (int64_t)gridDim.x * blockDim.x) fold[i] = 0;
     bool any = false;
     unsigned long long vol = 0;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n_ids * n_words;
@@ -207,6 +220,7 @@ __global__ __launch_bounds__(256) void msbfs_commit_kernel(
             any = true;
             seen[i] |= nw;
             const int64_t v = i / n_words, w = i % n_words;
+            atomicOr(&fcur[v >> 5], 1u << (v & 31));
             vol += (unsigned long long)(rowptr[v + 1] - rowptr[v]);
             uint64_t bits = nw;
             while (bits) {
@@ -229,7 +243,8 @@ __global__ __launch_bounds__(256) void msbfs_commit_kernel(
 
 extern "C" int64_t sgnn_bfs_hops_workspace_bytes(int64_t max_id, int64_t n_sources, int max_hops) {
     const int64_t n_words = (n_sources + 63) / 64;
-    return 3 * (max_id + 1) * n_words * 8 + ((int64_t)max_hops + 2) * 8 + ((int64_t)max_hops + 2) * 4;
+    return 3 * (max_id + 1) * n_words * 8 + ((int64_t)max_hops + 2) * 8 + ((int64_t)max_hops + 2) * 4 +
+           8 + 2 * ((max_id + 32) / 32) * 4;                      // + two frontier-node bitmaps
 }
 
 // Per level, for every set: which sources reached one of its members for the first time?  The new
@@ -296,15 +311,17 @@ static int msbfs_run(const int64_t* rowptr, const int32_t* col, int64_t nnz, int
     uint64_t* next = frontier + n_ids * n_words;
     unsigned long long* fvol = (unsigned long long*)(next + n_ids * n_words);
     int32_t* flags = (int32_t*)(fvol + max_hops + 2);
-    uint64_t* set_seen = (uint64_t*)(((uintptr_t)(flags + max_hops + 2) + 7) & ~(uintptr_t)7);
+    uint32_t* fbits = (uint32_t*)(((uintptr_t)(flags + max_hops + 2) + 7) & ~(uintptr_t)7);
+    const int64_t fwords = (n_ids + 31) / 32;
+    uint64_t* set_seen = (uint64_t*)(((uintptr_t)(fbits + 2 * fwords) + 7) & ~(uintptr_t)7);
     const unsigned long long pull_above =
         g_bfs_alpha > 0 ? (unsigned long long)((nnz * n_words) / g_bfs_alpha) : ~0ull;
     const int big = sgnn_grid_for(n_ids * ((dist && n_sources > n_words) ? n_sources : n_words), 256);
     hipLaunchKernelGGL(msbfs_init_kernel, dim3(big), dim3(256), 0, st, sources, n_sources, n_words, n_ids, seen,
-                       frontier, next, dist, flags, fvol, max_hops);
+                       frontier, next, dist, flags, fvol, fbits, max_hops);
     SGNN_CHECK_LAUNCH();
     hipLaunchKernelGGL(msbfs_seed_kernel, dim3((int)((n_sources + 255) / 256)), dim3(256), 0, st, sources, n_sources,
-                       n_words, n_ids, seen, frontier, dist, ss, sv);
+                       n_words, n_ids, seen, frontier, dist, ss, sv, fbits);
     SGNN_CHECK_LAUNCH();
     const int g_sets = set_out ? sgnn_grid_for(n_sets * n_words, 256) : 0;
     if (set_out) {
@@ -318,10 +335,12 @@ static int msbfs_run(const int64_t* rowptr, const int32_t* col, int64_t nnz, int
     const int g_commit = sgnn_grid_for(n_ids * n_words, 256);
     for (int level = 1; level <= max_hops; ++level) {
         hipLaunchKernelGGL(msbfs_expand_kernel, dim3(g_expand), dim3(256), 0, st, rowptr, col, n_ids, n_words, n_sources,
-                           seen, frontier, next, flags, fvol, pull_above, level);
+                           seen, frontier, next, flags, fvol, pull_above, level, fbits + ((level - 1) & 1) * fwords,
+                           (unsigned long long)((nnz * n_words) / 4));
         SGNN_CHECK_LAUNCH();
         hipLaunchKernelGGL(msbfs_commit_kernel, dim3(g_commit), dim3(256), 0, st, rowptr, n_ids, n_words, n_sources, seen,
-                           frontier, next, dist, flags, fvol, level, ss, sv);
+                           frontier, next, dist, flags, fvol, level, ss, sv, fbits + (level & 1) * fwords,
+                           fbits + ((level + 1) & 1) * fwords);
         SGNN_CHECK_LAUNCH();
         if (set_out) {
             hipLaunchKernelGGL(msbfs_set_reduce_kernel, dim3(g_sets), dim3(256), 0, st, frontier, n_words, n_sources,
@@ -352,7 +371,7 @@ extern "C" int sgnn_bfs_hops(const int64_t* rowptr, const int32_t* col, int64_t 
 
 extern "C" int64_t sgnn_bfs_min_hops_workspace_bytes(int64_t max_id, int64_t n_sources, int max_hops, int64_t n_sets) {
     const int64_t n_words = (n_sources + 63) / 64;
-    return sgnn_bfs_hops_workspace_bytes(max_id, n_sources, max_hops) + 8 + n_sets * n_words * 8;
+    return sgnn_bfs_hops_workspace_bytes(max_id, n_sources, max_hops) + 16 + n_sets * n_words * 8;
 }
 
 extern "C" int sgnn_bfs_min_hops_to_sets(const int64_t* rowptr, const int32_t* col, int64_t nnz, int64_t max_id,

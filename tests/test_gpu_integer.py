@@ -461,7 +461,7 @@ def bfs_alpha(request):
     ops = _ops()
     ops.bfs_hops_tuning(request.param)
     yield request.param
-    ops.bfs_hops_tuning(16)
+    ops.bfs_hops_tuning(256)
 
 
 @pytest.mark.parametrize('n_src', [70, 300])
@@ -481,21 +481,21 @@ def test_bfs_hops_push_pull_agree_and_match_scipy(n_src):
     src[0] = n                                                           # an isolated source
     out = {}
     try:
-        for alpha in (0, 16, 1 << 30):
+        for alpha in (0, 256, 1 << 30):
             ops.bfs_hops_tuning(alpha)
             out[alpha] = ops.bfs_hops(dg, torch.from_numpy(src).to(DEV), max_hops=32)
             out[(alpha, 't')] = ops.bfs_hops(dg, torch.from_numpy(src).to(DEV), max_hops=32, node_major=True)
     finally:
-        ops.bfs_hops_tuning(16)
-    assert torch.equal(out[0], out[16]) and torch.equal(out[0], out[1 << 30])
-    for alpha in (0, 16, 1 << 30):
+        ops.bfs_hops_tuning(256)
+    assert torch.equal(out[0], out[256]) and torch.equal(out[0], out[1 << 30])
+    for alpha in (0, 256, 1 << 30):
         assert torch.equal(out[(alpha, 't')].t().contiguous(), out[0])
     # fused BFS + min over members == the two-step form (sets with isolated members, an empty set)
     rng = np.random.default_rng(1)
     sets_l = [rng.integers(1, n + 1, int(rng.integers(1, 30))).tolist() for _ in range(400)]
     sets_l[5] = []
     sets = ops.Ragged.from_lists(sets_l, DEV)
-    two_step = ops.min_hops_to_sets(out[16], sets)
+    two_step = ops.min_hops_to_sets(out[256], sets)
     assert torch.equal(ops.bfs_min_hops_to_sets(dg, torch.from_numpy(src).to(DEV), sets, max_hops=32), two_step)
     A = sp.csr_matrix((np.ones(len(col), dtype=np.int8), col.astype(np.int64) - 1, rowptr[1:] - rowptr[1]), shape=(n, n))
     ref = shortest_path(A, method='D', unweighted=True, indices=src[:40].astype(np.int64) - 1)
@@ -505,7 +505,7 @@ def test_bfs_hops_push_pull_agree_and_match_scipy(n_src):
     assert (got[0][:n - 1] == np.inf).all() and got[0][n - 1] == 0
 
 
-@pytest.mark.parametrize('bfs_alpha', [0, 16, 1 << 30], indirect=True)
+@pytest.mark.parametrize('bfs_alpha', [0, 256, 1 << 30], indirect=True)
 def test_bfs_hops_matches_apsp(golden, bfs_alpha):
     """Sparse form == dense form on the columns of the chosen sources (the graph is connected
     enough; unreachable pairs are 0 in both conventions); pushed, mixed and pulled expansion."""

@@ -22,7 +22,7 @@ def timeit(f, reps=5):
 for ns in (57, 183, 1000):
     src = torch.from_numpy(np.random.default_rng(5).integers(1, n + 1, ns).astype(np.int32)).to(dev)
     ref = None
-    for alpha in (0, 2, 4, 8, 16, 32, 64, 1 << 30):
+    for alpha in (0, 16, 64, 256, 1024, 4096, 1 << 30):
         ops.bfs_hops_tuning(alpha)
         ms = timeit(lambda: ops.bfs_hops(g, src, max_hops=32, node_major=True))
         d = ops.bfs_hops(g, src, max_hops=32, node_major=True)
@@ -30,4 +30,4 @@ for ns in (57, 183, 1000):
             ref = d
         print('sources %5d  alpha %10d  %8.3f ms  same=%s  max hop %d' % (ns, alpha, ms, bool(torch.equal(d, ref)),
                                                                          int(d[d != 255].max())))
-ops.bfs_hops_tuning(16)
+ops.bfs_hops_tuning(256)
