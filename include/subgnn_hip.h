@@ -72,6 +72,14 @@ int sgnn_cc_labels(const int64_t* rowptr, const int32_t* col_sorted, int64_t nnz
                    const int64_t* sub_ptr, const int32_t* sub_nodes, int64_t n_subgraphs,
                    int64_t max_sub_len /* longest subgraph, <= 2048; 0 = unknown */,
                    int32_t* out_label, void* stream);
+/* Canonical order inside every set: ids ascending, equal ids in their original relative order.
+ * The neighbourhood-anchor draw ranks "the ascending members" of a component / border set where the
+ * reference walks a python set (SubGNN/anchor_patch_samplers.py:60-75, sample_neighborhood_anchor_patch);
+ * this is the order both sides agree on.  out_pos (nullable): flat index the id came from, for
+ * payloads that travel with the ids (hop labels).  max_set_size <= 1024, else SGNN_ERR_SET_TOO_LARGE
+ * (the caller sorts (set, id) keys device-wide instead).  out_nodes must not alias set_nodes. */
+int sgnn_sort_sets(const int64_t* set_ptr, const int32_t* set_nodes, int64_t n_sets, int64_t max_set_size,
+                   int32_t* out_nodes, int32_t* out_pos, void* stream);
 /* labels -> the padded component tensor of SubGNN.initialize_cc_ids (SubGNN/SubGNN.py:575-607) in
  * canonical order: components by the position of their first node, nodes in subgraph order,
  * duplicates dropped, PAD = 0.  Two steps: _stats gives, per subgraph, the number of components and

@@ -264,6 +264,71 @@ static inline int64_t kb_n_wg(int64_t n_sets, bool lds) {
     return n_sets < cap ? (n_sets < 1 ? 1 : n_sets) : cap;
 }
 
+// ---------------------------------------------------------------------------------------------
+// canonical order inside every set (ascending ids; equal ids keep their relative order): a rank
+// sort per set.  A group of G lanes owns a set: the ids are staged in LDS, every element counts
+// the elements that sort before it (broadcast LDS reads) and is written to that slot.  Sets are
+// the components / border sets of single subgraphs (tens of ids; up to SORT_SETS_MAX with G = 64,
+// O(n^2 / 64) per wave) -- one launch instead of a device-wide sort of (set, id) keys.
+// ---------------------------------------------------------------------------------------------
+#define SORT_SETS_MAX 1024
+template <int G>
+__global__ __launch_bounds__(256) void sort_sets_kernel(const int64_t* __restrict__ set_ptr,
+                                                        const int32_t* __restrict__ nodes, int64_t n_sets, int cap,
+                                                        int32_t* __restrict__ out_nodes, int32_t* __restrict__ out_pos)
+{
+    extern __shared__ int32_t s_keys[];
+    const int sub = threadIdx.x % G;
+    const int grp = threadIdx.x / G;
+    int32_t* keys = s_keys + (int64_t)grp * cap;
+    const int64_t n_groups = (int64_t)gridDim.x * (256 / G);
+    // the trip count is made uniform over the wave (groups of one wave sit on different sets)
+    const int64_t first = (int64_t)blockIdx.x * (256 / G) + grp;
+    const int64_t first_of_wave = (int64_t)blockIdx.x * (256 / G) + (threadIdx.x / 64) * (64 / G);
+    for (int64_t base = first_of_wave, s = first; base < n_sets; base += n_groups, s += n_groups) {
+        const bool live = s < n_sets;
+        const int64_t b = live ? set_ptr[s] : 0;
+        const int len = live ? (int)(set_ptr[s + 1] - b) : 0;
+        for (int i = sub; i < len; i += G) keys[i] = nodes[b + i];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (int i = sub; i < len; i += G) {
+            const int32_t k = keys[i];
+            int rank = 0;
+            for (int j = 0; j < len; ++j) {
+                const int32_t o = keys[j];
+                rank += (o < k || (o == k && j < i)) ? 1 : 0;
+            }
+            out_nodes[b + rank] = k;
+            if (out_pos) out_pos[b + rank] = (int32_t)(b + i);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+extern "C" int sgnn_sort_sets(const int64_t* set_ptr, const int32_t* set_nodes, int64_t n_sets, int64_t max_set_size,
+                              int32_t* out_nodes, int32_t* out_pos, void* stream)
+{
+    if (!set_ptr || !set_nodes || !out_nodes || n_sets < 0 || max_set_size < 0) return SGNN_ERR_BAD_ARG;
+    if (max_set_size > SORT_SETS_MAX) return SGNN_ERR_SET_TOO_LARGE;
+    if (n_sets == 0 || max_set_size == 0) return SGNN_OK;
+    hipStream_t st = (hipStream_t)stream;
+    if (max_set_size <= 16) {
+        hipLaunchKernelGGL(sort_sets_kernel<16>, dim3(sgnn_grid_for(n_sets, 16)), dim3(256), 16 * 16 * 4, st, set_ptr,
+                           set_nodes, n_sets, 16, out_nodes, out_pos);
+    } else if (max_set_size <= 32) {
+        hipLaunchKernelGGL(sort_sets_kernel<32>, dim3(sgnn_grid_for(n_sets, 8)), dim3(256), 8 * 32 * 4, st, set_ptr,
+                           set_nodes, n_sets, 32, out_nodes, out_pos);
+    } else {
+        const int cap = (int)max_set_size;
+        hipLaunchKernelGGL(sort_sets_kernel<64>, dim3(sgnn_grid_for(n_sets, 4)), dim3(256), (size_t)4 * cap * 4, st,
+                           set_ptr, set_nodes, n_sets, cap, out_nodes, out_pos);
+    }
+    SGNN_CHECK_LAUNCH();
+    return SGNN_OK;
+}
+
 extern "C" int sgnn_khop_border_bitmap_fits_lds(int64_t max_id) { return kb_fits_lds(max_id) ? 1 : 0; }
 
 extern "C" int64_t sgnn_khop_border_workspace_bytes(int64_t max_id, int64_t n_sets, int bitmap_in_lds) {

@@ -82,7 +82,7 @@ __global__ void msbfs_init_kernel(const int32_t* __restrict__ sources, int64_t n
 {
     const int64_t gtid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = gtid; i < 2 * ((n_ids + 31) / 32); i += gsz) fbits[i] = 0;
+    for (int64_t i = gtid; i < (n_ids + 31) / 32; i += gsz) fbits[i] = 0;
     for (int64_t i = gtid; i < n_ids * n_words; i += gsz) { seen[i] = 0; frontier[i] = 0; next[i] = 0; }
     if (dist) for (int64_t i = gtid; i < n_sources * n_ids; i += gsz) dist[i] = 255;
     for (int64_t i = gtid; i <= max_hops; i += gsz) { flags[i] = (i == 0) ? 1 : 0; fvol[i] = 0; }
@@ -201,43 +201,69 @@ __global__ __launch_bounds__(256) void msbfs_expand_kernel(
 __global__ __launch_bounds__(256) void msbfs_commit_kernel(
     const int64_t* __restrict__ rowptr, int64_t n_ids, int64_t n_words, int64_t n_sources, uint64_t* __restrict__ seen,
     uint64_t* __restrict__ frontier, uint64_t* __restrict__ next, uint8_t* __restrict__ dist, int32_t* __restrict__ flags,
-    unsigned long long* __restrict__ fvol, int level, int64_t ss, int64_t sv, uint32_t* __restrict__ fcur,
-    uint32_t* __restrict__ fold)
+    unsigned long long* __restrict__ fvol, int level, int64_t ss, int64_t sv, uint32_t* __restrict__ fcur)
 {
     if (flags[level - 1] == 0) return;
-    // fold: the node bitmap of the frontier before last -- nobody reads it any more; it becomes the
-    // clean slate of the next level.  fcur (clean since the previous commit) receives this level's nodes.
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < (n_ids + 31) / 32;
-         i += (int64_t)gridDim.x * blockDim.x) fold[i] = 0;
+    // One lane per node, a wave per 64 consecutive nodes: the ballot of "some word of my node is new"
+    // IS the two 32-bit words of the frontier-node bitmap for those nodes -- plain stores, every word of
+    // fcur rewritten each level (nobody reads it while this kernel runs: expand of this level is done).
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
+    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    const int64_t fwords = (n_ids + 31) / 32;
     bool any = false;
     unsigned long long vol = 0;
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n_ids * n_words;
-         i += (int64_t)gridDim.x * blockDim.x) {
-        const uint64_t nw = next[i] & ~seen[i];
-        next[i] = 0;
-        frontier[i] = nw;
-        if (nw) {
-            any = true;
-            seen[i] |= nw;
-            const int64_t v = i / n_words, w = i % n_words;
-            atomicOr(&fcur[v >> 5], 1u << (v & 31));
-            vol += (unsigned long long)(rowptr[v + 1] - rowptr[v]);
-            uint64_t bits = nw;
-            while (bits) {
-                const int b = __ffsll((unsigned long long)bits) - 1;
-                bits &= bits - 1;
-                const int64_t s = w * 64 + b;
-                if (dist && s < n_sources) dist[s * ss + v * sv] = (uint8_t)level;
+    for (int64_t base = wave * 64; base < n_ids; base += n_waves * 64) {
+        const int64_t v = base + lane;
+        int n_new = 0;
+        if (v < n_ids) {
+            for (int64_t w = 0; w < n_words; ++w) {
+                const int64_t i = v * n_words + w;
+                const uint64_t nx = next[i];
+                const uint64_t sn = seen[i];
+                const uint64_t nw = nx & ~sn;
+                if (nx) next[i] = 0;
+                frontier[i] = nw;
+                if (nw) {
+                    ++n_new;
+                    seen[i] = sn | nw;
+                    if (dist) {
+                        uint64_t bits = nw;
+                        while (bits) {
+                            const int b = __ffsll((unsigned long long)bits) - 1;
+                            bits &= bits - 1;
+                            const int64_t s = w * 64 + b;
+                            if (s < n_sources) dist[s * ss + v * sv] = (uint8_t)level;
+                        }
+                    }
+                }
+            }
+            if (n_new) {
+                any = true;
+                vol += (unsigned long long)n_new * (unsigned long long)(rowptr[v + 1] - rowptr[v]);
             }
         }
-    }
-    if (__any(any)) {
-        for (int off = 32; off >= 1; off >>= 1) {
-            const uint32_t lo = __shfl_xor((int)(uint32_t)vol, off, 64);
-            const uint32_t hi = __shfl_xor((int)(uint32_t)(vol >> 32), off, 64);
-            vol += ((unsigned long long)hi << 32) | lo;
+        const unsigned long long mask = __ballot(n_new != 0);
+        if (lane == 0) {
+            fcur[base >> 5] = (uint32_t)mask;
+            if ((base >> 5) + 1 < fwords) fcur[(base >> 5) + 1] = (uint32_t)(mask >> 32);
         }
-        if ((threadIdx.x & 63) == 0) { atomicOr(&flags[level], 1); atomicAdd(&fvol[level], vol); }
+    }
+    // one pair of atomics per workgroup: every wave adding to the same two words serialises at the
+    // memory side (16k waves -> ~150 us of a 200 us launch)
+    __shared__ unsigned long long s_vol[4];
+    for (int off = 32; off >= 1; off >>= 1) {
+        const uint32_t lo = __shfl_xor((int)(uint32_t)vol, off, 64);
+        const uint32_t hi = __shfl_xor((int)(uint32_t)(vol >> 32), off, 64);
+        vol += ((unsigned long long)hi << 32) | lo;
+    }
+    const bool wave_any = __any(any);
+    if (lane == 0) s_vol[threadIdx.x >> 6] = wave_any ? (vol | (1ull << 63)) : 0;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long t = 0, flag = 0;
+        for (int k = 0; k < (int)(blockDim.x >> 6); ++k) { t += s_vol[k] & ~(1ull << 63); flag |= s_vol[k] >> 63; }
+        if (flag) { atomicOr(&flags[level], 1); atomicAdd(&fvol[level], t); }
     }
 }
 
@@ -332,15 +358,14 @@ static int msbfs_run(const int64_t* rowptr, const int32_t* col, int64_t nnz, int
         SGNN_CHECK_LAUNCH();
     }
     const int g_expand = sgnn_grid_for(n_ids * 16, 256);
-    const int g_commit = sgnn_grid_for(n_ids * n_words, 256);
+    const int g_commit = sgnn_grid_for(n_ids, 256, 256 * 4);
     for (int level = 1; level <= max_hops; ++level) {
         hipLaunchKernelGGL(msbfs_expand_kernel, dim3(g_expand), dim3(256), 0, st, rowptr, col, n_ids, n_words, n_sources,
-                           seen, frontier, next, flags, fvol, pull_above, level, fbits + ((level - 1) & 1) * fwords,
+                           seen, frontier, next, flags, fvol, pull_above, level, fbits,
                            (unsigned long long)((nnz * n_words) / 4));
         SGNN_CHECK_LAUNCH();
         hipLaunchKernelGGL(msbfs_commit_kernel, dim3(g_commit), dim3(256), 0, st, rowptr, n_ids, n_words, n_sources, seen,
-                           frontier, next, dist, flags, fvol, level, ss, sv, fbits + (level & 1) * fwords,
-                           fbits + ((level + 1) & 1) * fwords);
+                           frontier, next, dist, flags, fvol, level, ss, sv, fbits);
         SGNN_CHECK_LAUNCH();
         if (set_out) {
             hipLaunchKernelGGL(msbfs_set_reduce_kernel, dim3(g_sets), dim3(256), 0, st, frontier, n_words, n_sources,

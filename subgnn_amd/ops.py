@@ -282,8 +282,27 @@ def khop_border_sample(g, sets, k, n_slots, seed, stream_id, bitmap_in_lds=None,
     return anchor, sims, counts
 
 
+SORT_SETS_MAX = 1024
+
+
 def sort_ragged(r, extra=None):
-    """Canonical (ascending) order inside every set: one device sort of (set, id) keys."""
+    """Canonical (ascending) order inside every set.  Sets known to be small (components, border
+    sets of one subgraph: ``max_len`` given by the producer, <= 1024) take the per-set rank sort
+    (sgnn_sort_sets, one launch, no host round trip); anything else one device-wide sort of
+    (set, id) keys."""
+    if r._max_len is not None and r._max_len <= SORT_SETS_MAX and r.nodes.numel() > 0 and r.n > 0:
+        lib = _lib.load()
+        _req(r.ptr, torch.int64, 'ptr')
+        _req(r.nodes, torch.int32, 'nodes')
+        out = torch.zeros_like(r.nodes)
+        pos = torch.zeros_like(r.nodes) if extra is not None else None
+        check(lib.sgnn_sort_sets(_ptr(r.ptr), _ptr(r.nodes), r.n, r._max_len, _ptr(out), _ptr(pos), _stream()),
+              'sgnn_sort_sets')
+        res = Ragged(r.ptr, out, r._max_len)
+        if extra is not None:
+            tot = int(r.ptr[-1].item())
+            return res, extra[pos[:tot].long()].contiguous()
+        return res
     tot = int(r.ptr[-1].item())
     if tot == 0:
         return (r, extra) if extra is not None else r
@@ -426,16 +445,24 @@ def min_hops_to_sets(dist, sets, node_major=False):
 
 def _unique_rows(rows):
     """torch.unique(rows, dim=0, return_inverse=True) up to the order of the unique rows, via a
-    64-bit row hash and a 1-D unique (a lexicographic sort of 50k x 20 rows costs ~1.2 ms, this
-    ~0.2 ms).  Exactness does not rest on the hash: every row is compared with its group's
-    representative, and any mismatch (a hash collision) falls back to the exact routine."""
+    64-bit row hash and one 1-D sort (a lexicographic sort of 50k x 20 rows costs ~1.2 ms, this
+    ~0.15 ms).  Exactness does not rest on the hash: every row is compared with its group's
+    representative, and any mismatch (a hash collision) falls back to the exact routine.
+    The groups come from the sorted hashes directly (boundaries -> running group number -> scattered
+    back through the permutation, which has no collisions); a scatter-min of row numbers into the
+    groups serialises on the atomics of the big groups (0.37 ms for 50k rows in 2.7k groups)."""
     n, w = rows.shape
     g = torch.Generator(device='cpu').manual_seed(0x5DEECE66D)
     coef = (torch.randint(-(1 << 62), 1 << 62, (w,), generator=g, dtype=torch.int64) | 1).to(rows.device)
     h = (rows.to(torch.int64) * coef).sum(dim=1)                          # wraps modulo 2^64
-    uh, inv = torch.unique(h, return_inverse=True)
-    rep = torch.full((uh.numel(),), n, dtype=torch.int64, device=rows.device)
-    rep.scatter_reduce_(0, inv, torch.arange(n, device=rows.device), reduce='amin')
+    hs, perm = torch.sort(h)
+    first = torch.ones(n, dtype=torch.bool, device=rows.device)
+    if n > 1:
+        first[1:] = hs[1:] != hs[:-1]
+    gid = torch.cumsum(first, 0) - 1
+    inv = torch.empty(n, dtype=torch.int64, device=rows.device)
+    inv[perm] = gid
+    rep = perm[first]                                                      # one row of every group
     uniq = rows.index_select(0, rep)
     if bool((uniq.index_select(0, inv) == rows).all()):
         return uniq, inv
@@ -665,6 +692,40 @@ class _MPN(torch.autograd.Function):
         return (None if ctx.acc is not None else gx), gwp, gbp, None, None, None, None, None, None, None, None, None, None
 
 
+def column_sum(t, chunk=512):
+    """t.sum(0) for a tall (R, A) matrix.  torch's reduction over the leading dimension of a tall,
+    narrow matrix runs on one workgroup per few output columns (50k x 183 -> 192 threads' worth of
+    grid, 0.5 ms); summing row blocks first -- (R/chunk, chunk, A) over the middle dimension -- gives
+    it R/chunk x A outputs to spread over the chip, and the second, small sum finishes."""
+    R = t.shape[0]
+    nb = R // chunk
+    if t.dim() != 2 or nb < 8:
+        return t.sum(0)
+    head = t[:nb * chunk].view(nb, chunk, t.shape[1]).sum(1).sum(0)
+    return head + t[nb * chunk:].sum(0) if nb * chunk < R else head
+
+
+class _ReadoutShared(torch.autograd.Function):
+    """z = W * s + b for edge weights W (R, A) (no gradient), per-anchor scores s (A) and a scalar b:
+    the read-out of the shared-anchor layer body.  Its backward is two reductions over the rows,
+    done with column_sum."""
+
+    @staticmethod
+    def forward(ctx, W, s, b):
+        ctx.save_for_backward(W)
+        ctx.b_shape = b.shape
+        return torch.addcmul(b.view(1, 1), W, s.view(1, -1))
+
+    @staticmethod
+    def backward(ctx, g):
+        (W,) = ctx.saved_tensors
+        if ctx.needs_input_grad[0]:
+            raise RuntimeError('_ReadoutShared: edge weights carry no gradient')
+        gs = column_sum(g * W) if ctx.needs_input_grad[1] else None
+        gb = column_sum(g).sum().view(ctx.b_shape) if ctx.needs_input_grad[2] else None
+        return None, gs, gb
+
+
 class _LinearTallSkinny(torch.autograd.Function):
     """y = x W^T + b for a tall x (R >> features).  The library picks a single-pass kernel for the
     weight gradient g^T x -- an (out x in) result contracted over R = 50k rows runs on (out/32) x
@@ -694,7 +755,7 @@ class _LinearTallSkinny(torch.autograd.Function):
                 gW = head + g[nb * k:].t() @ x[nb * k:] if nb * k < R else head
             else:
                 gW = g.t() @ x
-        gb = g.sum(0) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        gb = column_sum(g) if ctx.has_bias and ctx.needs_input_grad[2] else None
         return gx, gW, gb
 
 
@@ -745,7 +806,7 @@ def _mpn_shared_gemm(x, wp, bp, sims2, ids, row_mask, sim_col, sims_per_edge, R,
     if edge is not None:
         W = W * edge
     agg = W @ x
-    z = W * (x @ wp.view(-1)).view(1, A) + bp.view(1, 1)
+    z = _ReadoutShared.apply(W, x @ wp.view(-1), bp)
     return agg, z
 
 
@@ -846,7 +907,7 @@ class _AttnScores(torch.autograd.Function):
         gX = d @ U.t() if ctx.needs_input_grad[0] else None
         gU = X.t() @ d if ctx.needs_input_grad[1] else None
         gq = d.view(-1, ctx.rpb, d.shape[1]).sum(1) if ctx.needs_input_grad[2] else None
-        gv = (t * g.unsqueeze(1)).sum(0) if ctx.needs_input_grad[3] else None
+        gv = column_sum(t * g.unsqueeze(1)) if ctx.needs_input_grad[3] else None
         return gX, gU, gq, gv, None
 
 

@@ -615,3 +615,43 @@ def test_dtw_row_dedupe_changes_nothing():
     assert torch.equal(a, b)
     ref = cbind.fastdtw_sim(xp, xv, yp, yv, 0)
     assert np.array_equal(a.cpu().numpy(), ref)
+
+
+@pytest.mark.parametrize('max_len', [1, 9, 16, 20, 32, 47, 64, 65, 300, 1024])
+def test_sort_sets_matches_stable_sort(max_len):
+    """sgnn_sort_sets: every set ascending, equal ids in their original order (out_pos carries the
+    payload), empty sets untouched; the three group widths and the multi-pass wave path."""
+    ops = _ops()
+    rng = np.random.default_rng(max_len)
+    n_sets = 700
+    lens = rng.integers(0, max_len + 1, n_sets)
+    lens[:3] = (0, max_len, max_len)
+    lists = [rng.integers(1, max(4, max_len // 2) + 1, l).tolist() for l in lens]       # many repeats
+    r = ops.Ragged.from_lists(lists, DEV)
+    r._max_len = max_len
+    payload = torch.arange(int(lens.sum()), device=DEV, dtype=torch.int32)
+    out, pay = ops.sort_ragged(r, payload)
+    got = out.to_lists()
+    pay = pay.cpu().numpy()
+    off = 0
+    for l, g in zip(lists, got):
+        order = np.argsort(np.array(l, dtype=np.int64), kind='stable')
+        assert g == [l[i] for i in order]
+        assert np.array_equal(pay[off:off + len(l)], off + order)
+        off += len(l)
+    # the device-wide key sort (sets of unknown size) gives the same sets
+    r2 = ops.Ragged.from_lists(lists, DEV)
+    r2._max_len = None
+    assert ops.sort_ragged(r2).to_lists() == got
+
+
+def test_sort_sets_rejects_large_sets():
+    import ctypes
+    from subgnn_amd import _lib
+    lib = _lib.load()
+    ptr = torch.tensor([0, 2000], dtype=torch.int64, device=DEV)
+    nodes = torch.arange(2000, dtype=torch.int32, device=DEV)
+    out = torch.empty_like(nodes)
+    rc = lib.sgnn_sort_sets(ctypes.c_void_p(ptr.data_ptr()), ctypes.c_void_p(nodes.data_ptr()), 1, 2000,
+                            ctypes.c_void_p(out.data_ptr()), None, None)
+    assert rc == -2
