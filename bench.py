@@ -124,6 +124,8 @@ def main():
     hp = dict(ALL_DENSITY_HP)
     hp['node_embed_size'] = args.embed
     hp['embedding_dtype'] = args.embedding_dtype
+    if os.environ.get('SGNN_OVERLAP_STREAMS'):
+        hp['overlap_streams'] = True
     labels = torch.randint(0, 3, (len(subs),), generator=torch.Generator().manual_seed(rank))
     labels[:3] = torch.tensor([0, 1, 2])
     model = SubGNN.from_memory(hp, g, {'train': subs, 'val': [], 'test': []},
@@ -189,6 +191,7 @@ def main():
     if os.environ.get('SGNN_BENCH_PER_STEP'):
         for i, tm in enumerate(timers):
             print('step', i, {k: round(v, 3) for k, v in tm.summary().items()}, file=sys.stderr)
+            print('     host', {k: round(v, 3) for k, v in tm.host_summary().items()}, file=sys.stderr)
 
     # ---- roofline of the structure-channel CSR gather, measured live ------------------------
     cc_ids = model.train_cc_ids

@@ -680,6 +680,10 @@ class SubGNN(nn.Module):
     def _build_sim_cols(self):
         """Per layer, the columns of the S similarity rows its sampled patches read (S.py:206-210),
         resident on the device so that forward never uploads anything."""
+        src = getattr(self, 'anchors_structure', None)
+        if src is not None and self.__dict__.get('_sim_cols_src') is src:
+            return                                            # already uploaded for these patches
+        self.__dict__['_sim_cols_src'] = src
         self._sim_col_cache = {}
         if getattr(self, 'anchors_structure', None) is not None:
             for l, (_, indices, _, _) in self.anchors_structure.items():

@@ -19,6 +19,8 @@ The result plugs into SubGNN.forward through the per-edge similarity dict (see
 SubGNN._run_mpn_layer_fused).  Values are identical to what the dense path would gather from
 its slabs (tests/test_gpu_hotpath.py).
 """
+import time
+
 import torch
 
 from . import ops, tape, gamma, subgraph_utils
@@ -31,13 +33,19 @@ class StageTimer:
     """HIP-event stage timing on the current stream (no host synchronisation until read)."""
 
     def __init__(self, enabled=True):
-        self.enabled, self.marks = enabled, []
+        self.enabled, self.marks, self.host = enabled, [], []
 
     def mark(self, name):
         if self.enabled:
             e = torch.cuda.Event(enable_timing=True)
             e.record()
             self.marks.append((name, e))
+            self.host.append(time.perf_counter())          # when the host got here (it runs ahead of the device)
+
+    def host_summary(self):
+        """ms between the host reaching consecutive marks: a stage whose host time exceeds its device
+        time is bound by launching, not by the kernels."""
+        return {n1: 1e3 * (t1 - t0) for (n1, _), t0, t1 in zip(self.marks[1:], self.host[:-1], self.host[1:])}
 
     def summary(self):
         out = {}
@@ -143,6 +151,9 @@ def prepare_sparse(model, split='train', timer=None):
                 model.anchors_structure = aps.init_anchors_structure(hp, model.structure_anchors,
                                                                      model.int_structure_anchor_random_walks,
                                                                      model.bor_structure_anchor_random_walks)
+                # the column upload is a blocking host->device copy: do it here, before the long DTW
+                # launches are queued, so that the host is free to queue forward/backward behind them
+                model._build_sim_cols()
             a_sets = ops.Ragged.from_padded(model.structure_anchors)
             ai, ae = ops.degree_sequence(g, a_sets, sort=True, use_degree_dict=g.full_degree is not None)
             if side is main:
@@ -201,6 +212,16 @@ def prepare_sparse(model, split='train', timer=None):
     return t
 
 
+def _device_labels(model, split):
+    """The split's labels on the device, uploaded once (a pageable host->device copy blocks the host
+    until the stream reaches it -- behind the DTW launches that is the whole DTW)."""
+    src = getattr(model, split + '_sub_G_label')
+    cache = model.__dict__.setdefault('_device_label_cache', {})
+    if split not in cache or cache[split][0] is not src:
+        cache[split] = (src, src.to(model.device))
+    return cache[split][1]
+
+
 def full_split_batch(model, split):
     """The whole split as one batch (the large-shard launch shape of the benchmark)."""
     S = getattr(model, split + '_cc_ids').shape[0]
@@ -210,4 +231,4 @@ def full_split_batch(model, split):
             'I_S_sim': getattr(model, split + '_int_struc_similarities'),
             'B_S_sim': getattr(model, split + '_bor_struc_similarities'),
             'subgraph_idx': torch.arange(S, device=dev).view(-1, 1),
-            'label': getattr(model, split + '_sub_G_label').to(dev)}
+            'label': _device_labels(model, split)}
