@@ -213,7 +213,7 @@ int sgnn_sp_similarity_dense(const double* apsp, int64_t n_cols,
  * workspace: sgnn_bfs_hops_workspace_bytes(max_id, n_sources, max_hops) bytes (any content).
  * The expansion is direction-optimising: a level pulls (every incomplete node ORs its neighbours'
  * frontier words) instead of pushing once the frontier's edge volume exceeds 1/alpha of all edges.
- * sgnn_bfs_hops_tuning sets alpha process-wide (default 256; 0 = always push); results do not depend
+ * sgnn_bfs_hops_tuning sets alpha process-wide (default 32; 0 = always push); results do not depend
  * on it. */
 int64_t sgnn_bfs_hops_workspace_bytes(int64_t max_id, int64_t n_sources, int max_hops);
 int sgnn_bfs_hops_tuning(int alpha);

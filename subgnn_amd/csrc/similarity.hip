@@ -65,7 +65,7 @@ extern "C" int sgnn_sp_similarity_dense(const double* apsp, int64_t n_cols,
 //            new bits; flags[level] says whether any bit was new (later levels exit early);
 //            fvol[level] = sum over new frontier words of the node's degree.
 // ---------------------------------------------------------------------------------------------
-static int g_bfs_alpha = 256;    // pull when frontier word-edges * alpha > nnz * n_words; 0 = never pull
+static int g_bfs_alpha = 32;     // pull when frontier word-edges * alpha > nnz * n_words; 0 = never pull
 
 extern "C" int sgnn_bfs_hops_tuning(int alpha)
 {
@@ -82,7 +82,7 @@ __global__ void msbfs_init_kernel(const int32_t* __restrict__ sources, int64_t n
 {
     const int64_t gtid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = gtid; i < (n_ids + 31) / 32; i += gsz) fbits[i] = 0;
+    for (int64_t i = gtid; i < 2 * ((n_ids + 31) / 32); i += gsz) fbits[i] = 0;   // frontier nodes | complete nodes
     for (int64_t i = gtid; i < n_ids * n_words; i += gsz) { seen[i] = 0; frontier[i] = 0; next[i] = 0; }
     if (dist) for (int64_t i = gtid; i < n_sources * n_ids; i += gsz) dist[i] = 255;
     for (int64_t i = gtid; i <= max_hops; i += gsz) { flags[i] = (i == 0) ? 1 : 0; fvol[i] = 0; }
@@ -103,6 +103,9 @@ __global__ void msbfs_seed_kernel(const int32_t* __restrict__ sources, int64_t n
 }
 
 #define MSBFS_WCHUNK 4          // source words a pull pass keeps in registers
+#define MSBFS_HUB_DEGREE 128     // push: lists this long go to the whole workgroup
+#define MSBFS_HUB_SLOTS 128
+#define MSBFS_PULL_HUB_DEGREE 512
 
 __device__ __forceinline__ uint64_t msbfs_group_or(uint64_t x)
 {
@@ -119,15 +122,28 @@ __global__ __launch_bounds__(256) void msbfs_expand_kernel(
     const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col, int64_t n_ids, int64_t n_words,
     int64_t n_sources, const uint64_t* __restrict__ seen, const uint64_t* __restrict__ frontier,
     uint64_t* __restrict__ next, const int32_t* __restrict__ flags, const unsigned long long* __restrict__ fvol,
-    unsigned long long pull_above, int level, const uint32_t* __restrict__ fnode, unsigned long long sparse_below)
+    unsigned long long pull_above, int level, const uint32_t* __restrict__ fnode, unsigned long long sparse_below,
+    const uint32_t* __restrict__ fdone)
 {
     if (flags[level - 1] == 0) return;                       // previous level found nothing
     const int sub = threadIdx.x & 15;
-    const int64_t group = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 4;
-    const int64_t n_groups = ((int64_t)gridDim.x * blockDim.x) >> 4;
+    // node ids are dealt out to the workgroups round-robin (group g of workgroup b takes b + G*(g + 16 i)):
+    // consecutive ids -- the oldest, highest-degree nodes of a preferential-attachment graph sit next to
+    // each other at the low ids -- land in different workgroups
+    const int64_t group = blockIdx.x + (int64_t)gridDim.x * (threadIdx.x >> 4);
+    const int64_t n_groups = (int64_t)gridDim.x * (blockDim.x >> 4);
     const bool pull = level > 1 && pull_above != ~0ull && fvol[level - 1] > pull_above;
     const bool sparse_frontier = fvol[level - 1] < sparse_below;
+    __shared__ int32_t s_hub[MSBFS_HUB_SLOTS];
+    __shared__ int s_nhub;
+    __shared__ unsigned long long s_acc[MSBFS_WCHUNK];
+    if (threadIdx.x == 0) s_nhub = 0;
+    __syncthreads();
     if (!pull) {
+        // A frontier node's list is streamed by its 16-lane group -- except long lists (hubs: a BA graph
+        // of 1M nodes has lists of 10k+ entries, and hubs are on the frontier from level 1 on), which one
+        // group would walk for a millisecond while the rest of the chip is done: those are parked in LDS
+        // and streamed by the whole workgroup afterwards.
         for (int64_t v = group; v < n_ids; v += n_groups) {
             uint64_t any = 0;
             for (int64_t w = 0; w < n_words; ++w) any |= frontier[v * n_words + w];
@@ -135,7 +151,30 @@ __global__ __launch_bounds__(256) void msbfs_expand_kernel(
             // one pass over the neighbour list for all source words: col[] is read once, and the
             // n_words seen/next words of a neighbour are contiguous
             const int64_t r0 = rowptr[v], r1 = rowptr[v + 1];
+            if (r1 - r0 >= MSBFS_HUB_DEGREE) {
+                int slot = 0;
+                if (sub == 0) slot = atomicAdd(&s_nhub, 1);
+                slot = __shfl(slot, (threadIdx.x & 63) & ~15, 64);
+                if (slot < MSBFS_HUB_SLOTS) {
+                    if (sub == 0) s_hub[slot] = (int32_t)v;
+                    continue;
+                }
+            }
             for (int64_t e = r0 + sub; e < r1; e += 16) {
+                const int64_t u = col[e];
+                for (int64_t w = 0; w < n_words; ++w) {
+                    const uint64_t f = frontier[v * n_words + w];
+                    const uint64_t m = f & ~seen[u * n_words + w];
+                    if (m) atomicOr((unsigned long long*)&next[u * n_words + w], (unsigned long long)m);
+                }
+            }
+        }
+        __syncthreads();
+        const int n_hub = s_nhub < MSBFS_HUB_SLOTS ? s_nhub : MSBFS_HUB_SLOTS;
+        for (int h = 0; h < n_hub; ++h) {
+            const int64_t v = s_hub[h];
+            const int64_t r0 = rowptr[v], r1 = rowptr[v + 1];
+            for (int64_t e = r0 + threadIdx.x; e < r1; e += blockDim.x) {
                 const int64_t u = col[e];
                 for (int64_t w = 0; w < n_words; ++w) {
                     const uint64_t f = frontier[v * n_words + w];
@@ -147,6 +186,9 @@ __global__ __launch_bounds__(256) void msbfs_expand_kernel(
         return;
     }
     for (int64_t v = group; v < n_ids; v += n_groups) {
+        // one bit per node: every source has reached it (kept by commit) -- from level 3-4 on that is
+        // almost every node, and the test replaces the row-pointer and seen-word loads of the skip path
+        if ((fdone[v >> 5] >> (v & 31)) & 1u) continue;
         const int64_t r0 = rowptr[v], r1 = rowptr[v + 1];
         for (int64_t w0 = 0; w0 < n_words; w0 += MSBFS_WCHUNK) {
             uint64_t need[MSBFS_WCHUNK], acc[MSBFS_WCHUNK];
@@ -165,6 +207,15 @@ __global__ __launch_bounds__(256) void msbfs_expand_kernel(
                 missing |= valid;
             }
             if (missing == 0) continue;                      // this node has every source of the chunk
+            if (r1 - r0 >= MSBFS_PULL_HUB_DEGREE) {          // long list: the whole workgroup, below
+                int slot = 0;
+                if (sub == 0) slot = atomicAdd(&s_nhub, 1);
+                slot = __shfl(slot, (threadIdx.x & 63) & ~15, 64);
+                if (slot < MSBFS_HUB_SLOTS) {
+                    if (sub == 0) s_hub[slot] = (int32_t)v;
+                    break;                                   // all chunks of this node are done there
+                }
+            }
             int since = 0;
             for (int64_t e = r0 + sub; e < r1 + sub; e += 16) {          // uniform trip count per group
                 if (e < r1) {
@@ -196,12 +247,57 @@ __global__ __launch_bounds__(256) void msbfs_expand_kernel(
             }
         }
     }
+    // parked long lists: 256 lanes per list, the words OR-ed through LDS
+    __syncthreads();
+    const int n_hub = s_nhub < MSBFS_HUB_SLOTS ? s_nhub : MSBFS_HUB_SLOTS;
+    for (int h = 0; h < n_hub; ++h) {
+        const int64_t v = s_hub[h];
+        const int64_t r0 = rowptr[v], r1 = rowptr[v + 1];
+        for (int64_t w0 = 0; w0 < n_words; w0 += MSBFS_WCHUNK) {
+            uint64_t need[MSBFS_WCHUNK], acc[MSBFS_WCHUNK];
+            uint64_t missing = 0;
+#pragma unroll
+            for (int k = 0; k < MSBFS_WCHUNK; ++k) {
+                const int64_t w = w0 + k;
+                uint64_t valid = 0;
+                if (w < n_words) {
+                    const int64_t left = n_sources - w * 64;
+                    valid = left >= 64 ? ~0ull : ((1ull << left) - 1);
+                    valid &= ~seen[v * n_words + w];
+                }
+                need[k] = valid;
+                acc[k] = 0;
+                missing |= valid;
+            }
+            if (missing == 0) continue;                      // uniform over the workgroup
+            if (threadIdx.x < MSBFS_WCHUNK) s_acc[threadIdx.x] = 0;
+            __syncthreads();
+            for (int64_t e = r0 + threadIdx.x; e < r1; e += blockDim.x) {
+                const int64_t u = col[e];
+                if (!sparse_frontier || ((fnode[u >> 5] >> (u & 31)) & 1u)) {
+#pragma unroll
+                    for (int k = 0; k < MSBFS_WCHUNK; ++k)
+                        if (need[k]) acc[k] |= frontier[u * n_words + w0 + k];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < MSBFS_WCHUNK; ++k)
+                if (acc[k]) atomicOr(&s_acc[k], (unsigned long long)acc[k]);
+            __syncthreads();
+            if (threadIdx.x < MSBFS_WCHUNK && w0 + threadIdx.x < n_words) {
+                const uint64_t m = s_acc[threadIdx.x] & need[threadIdx.x];
+                if (m) next[v * n_words + w0 + threadIdx.x] = m;
+            }
+            __syncthreads();
+        }
+    }
 }
 
 __global__ __launch_bounds__(256) void msbfs_commit_kernel(
     const int64_t* __restrict__ rowptr, int64_t n_ids, int64_t n_words, int64_t n_sources, uint64_t* __restrict__ seen,
     uint64_t* __restrict__ frontier, uint64_t* __restrict__ next, uint8_t* __restrict__ dist, int32_t* __restrict__ flags,
-    unsigned long long* __restrict__ fvol, int level, int64_t ss, int64_t sv, uint32_t* __restrict__ fcur)
+    unsigned long long* __restrict__ fvol, int level, int64_t ss, int64_t sv, uint32_t* __restrict__ fcur,
+    uint32_t* __restrict__ fdone)
 {
     if (flags[level - 1] == 0) return;
     // One lane per node, a wave per 64 consecutive nodes: the ballot of "some word of my node is new"
@@ -216,12 +312,15 @@ __global__ __launch_bounds__(256) void msbfs_commit_kernel(
     for (int64_t base = wave * 64; base < n_ids; base += n_waves * 64) {
         const int64_t v = base + lane;
         int n_new = 0;
+        bool done = v < n_ids;
         if (v < n_ids) {
             for (int64_t w = 0; w < n_words; ++w) {
                 const int64_t i = v * n_words + w;
                 const uint64_t nx = next[i];
                 const uint64_t sn = seen[i];
                 const uint64_t nw = nx & ~sn;
+                const int64_t left = n_sources - w * 64;
+                done = done && ((sn | nw) == (left >= 64 ? ~0ull : ((1ull << left) - 1)));
                 if (nx) next[i] = 0;
                 frontier[i] = nw;
                 if (nw) {
@@ -244,9 +343,14 @@ __global__ __launch_bounds__(256) void msbfs_commit_kernel(
             }
         }
         const unsigned long long mask = __ballot(n_new != 0);
+        const unsigned long long dmask = __ballot(done);
         if (lane == 0) {
             fcur[base >> 5] = (uint32_t)mask;
-            if ((base >> 5) + 1 < fwords) fcur[(base >> 5) + 1] = (uint32_t)(mask >> 32);
+            fdone[base >> 5] = (uint32_t)dmask;
+            if ((base >> 5) + 1 < fwords) {
+                fcur[(base >> 5) + 1] = (uint32_t)(mask >> 32);
+                fdone[(base >> 5) + 1] = (uint32_t)(dmask >> 32);
+            }
         }
     }
     // one pair of atomics per workgroup: every wave adding to the same two words serialises at the
@@ -362,10 +466,10 @@ static int msbfs_run(const int64_t* rowptr, const int32_t* col, int64_t nnz, int
     for (int level = 1; level <= max_hops; ++level) {
         hipLaunchKernelGGL(msbfs_expand_kernel, dim3(g_expand), dim3(256), 0, st, rowptr, col, n_ids, n_words, n_sources,
                            seen, frontier, next, flags, fvol, pull_above, level, fbits,
-                           (unsigned long long)((nnz * n_words) / 4));
+                           (unsigned long long)((nnz * n_words) / 4), fbits + fwords);
         SGNN_CHECK_LAUNCH();
         hipLaunchKernelGGL(msbfs_commit_kernel, dim3(g_commit), dim3(256), 0, st, rowptr, n_ids, n_words, n_sources, seen,
-                           frontier, next, dist, flags, fvol, level, ss, sv, fbits);
+                           frontier, next, dist, flags, fvol, level, ss, sv, fbits, fbits + fwords);
         SGNN_CHECK_LAUNCH();
         if (set_out) {
             hipLaunchKernelGGL(msbfs_set_reduce_kernel, dim3(g_sets), dim3(256), 0, st, frontier, n_words, n_sources,

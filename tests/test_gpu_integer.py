@@ -461,7 +461,7 @@ def bfs_alpha(request):
     ops = _ops()
     ops.bfs_hops_tuning(request.param)
     yield request.param
-    ops.bfs_hops_tuning(256)
+    ops.bfs_hops_tuning(32)
 
 
 @pytest.mark.parametrize('n_src', [70, 300])
@@ -486,7 +486,7 @@ def test_bfs_hops_push_pull_agree_and_match_scipy(n_src):
             out[alpha] = ops.bfs_hops(dg, torch.from_numpy(src).to(DEV), max_hops=32)
             out[(alpha, 't')] = ops.bfs_hops(dg, torch.from_numpy(src).to(DEV), max_hops=32, node_major=True)
     finally:
-        ops.bfs_hops_tuning(256)
+        ops.bfs_hops_tuning(32)
     assert torch.equal(out[0], out[256]) and torch.equal(out[0], out[1 << 30])
     for alpha in (0, 256, 1 << 30):
         assert torch.equal(out[(alpha, 't')].t().contiguous(), out[0])

@@ -30,4 +30,18 @@ for ns in (57, 183, 1000):
             ref = d
         print('sources %5d  alpha %10d  %8.3f ms  same=%s  max hop %d' % (ns, alpha, ms, bool(torch.equal(d, ref)),
                                                                          int(d[d != 255].max())))
-ops.bfs_hops_tuning(256)
+ops.bfs_hops_tuning(32)
+
+# the fused form the position channel uses (min over the members of 50k component sets)
+rng = np.random.default_rng(7)
+sets = ops.Ragged.from_padded(torch.from_numpy(rng.integers(1, n + 1, (50_000, 20)).astype(np.int64)).to(dev))
+src = torch.from_numpy(np.random.default_rng(5).integers(1, n + 1, 183).astype(np.int32)).to(dev)
+ref = None
+for alpha in (0, 2, 4, 8, 16, 32, 64, 128, 256, 1024):
+    ops.bfs_hops_tuning(alpha)
+    ms = timeit(lambda: ops.bfs_min_hops_to_sets(g, src, sets, max_hops=32), reps=10)
+    w = ops.bfs_min_hops_to_sets(g, src, sets, max_hops=32)
+    if ref is None:
+        ref = w
+    print('min-hops-to-sets 183 sources  alpha %6d  %8.3f ms  same=%s' % (alpha, ms, bool(torch.equal(w, ref))))
+ops.bfs_hops_tuning(32)
