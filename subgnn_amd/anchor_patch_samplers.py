@@ -24,43 +24,38 @@ def _seed(hparams):
 
 def patch_node_views(anchor_patch_ids):
     """Node view of every patch's induced subgraph: unique ids in first-occurrence order
-    (the reference iterates a networkx subgraph view whose order is CPython-set order)."""
+    (the reference iterates a networkx subgraph view whose order is CPython-set order).
+    No host round trip: an entry is kept when no earlier entry of its row has the same id (rows are
+    walks of a few dozen steps: the L x L comparison per row is a handful of launches; very long
+    rows take the sort-based form), and the kept entries are packed by ops.Ragged.from_mask."""
     P, L = anchor_patch_ids.shape
     dev = anchor_patch_ids.device
     ids = anchor_patch_ids
-    rows = torch.arange(P, device=dev).unsqueeze(1).expand(P, L)
-    cols = torch.arange(L, device=dev).unsqueeze(0).expand(P, L)
-    key = (rows * (1 << 32) + ids).reshape(-1)
-    skey, sidx = torch.sort(key, stable=True)
-    first = torch.ones_like(skey, dtype=torch.bool)
-    first[1:] = skey[1:] != skey[:-1]
-    keep = torch.zeros(P * L, dtype=torch.bool, device=dev)
-    keep[sidx[first]] = True
-    keep = keep.view(P, L) & (ids != PAD_VALUE)
-    lens = keep.sum(1)
-    ptr = torch.zeros(P + 1, dtype=torch.int64, device=dev)
-    torch.cumsum(lens, 0, out=ptr[1:])
-    nodes = ids[keep].to(torch.int32)
-    if nodes.numel() == 0:
-        nodes = torch.zeros(1, dtype=torch.int32, device=dev)
-    del cols
-    return ops.Ragged(ptr, nodes.contiguous(), max_len=L)
+    if P * L * L <= (1 << 26):
+        earlier = torch.ones(L, L, dtype=torch.bool, device=dev).tril(-1)          # [i, j]: j < i
+        dup = ((ids.unsqueeze(2) == ids.unsqueeze(1)) & earlier.unsqueeze(0)).any(dim=2)
+        keep = ~dup & (ids != PAD_VALUE)
+    else:
+        rows = torch.arange(P, device=dev).unsqueeze(1).expand(P, L)
+        key = (rows * (1 << 32) + ids).reshape(-1)
+        skey, sidx = torch.sort(key, stable=True)
+        first = torch.ones_like(skey, dtype=torch.bool)
+        first[1:] = skey[1:] != skey[:-1]
+        keep = torch.zeros(P * L, dtype=torch.bool, device=dev)
+        keep[sidx] = first
+        keep = keep.view(P, L) & (ids != PAD_VALUE)
+    return ops.Ragged.from_mask(ids, keep)
 
 
 def in_border_sets(graph, views):
     """per patch: the view nodes with an edge leaving the patch (su.get_border_nodes)."""
     flags = ops.patch_in_border(graph, views)
-    tot = int(views.ptr[-1].item())
-    f = flags[:tot].bool()
-    rows = torch.repeat_interleave(torch.arange(views.n, device=views.ptr.device), views.lengths)
-    cnt = torch.zeros(views.n, dtype=torch.int64, device=views.ptr.device)
-    cnt.index_add_(0, rows, f.to(torch.int64))
-    ptr = torch.zeros(views.n + 1, dtype=torch.int64, device=views.ptr.device)
-    torch.cumsum(cnt, 0, out=ptr[1:])
-    nodes = views.nodes[:tot][f]
-    if nodes.numel() == 0:
-        nodes = torch.zeros(1, dtype=torch.int32, device=views.ptr.device)
-    return ops.Ragged(ptr, nodes.contiguous())
+    L = views._max_len
+    if L is None:
+        L = views.max_len
+    padded = views.to_padded(width=L, fill=PAD_VALUE)
+    fpad = ops.Ragged(views.ptr, flags.to(torch.int32), max_len=L).to_padded(width=L, fill=0)
+    return ops.Ragged.from_mask(padded, fpad != 0)
 
 
 def perform_random_walks(hparams, networkx_graph, anchor_patch_ids, inside, views=None, in_border=None):
@@ -151,24 +146,40 @@ def init_anchors_pos_int(split, hparams, networkx_graph, device, train_sub_G, va
     return anchors
 
 
+_SPAN_PTR = {}
+
+
+def _span_ptr(n, device):
+    """[0, n] on the device: the row pointer of a one-set pool.  Uploaded once per (n, device) -- a
+    host->device copy of a fresh tensor blocks the host until the stream has drained."""
+    key = (int(n), str(device))
+    if key not in _SPAN_PTR:
+        _SPAN_PTR[key] = torch.tensor([0, int(n)], dtype=torch.int64, device=device)
+    return _SPAN_PTR[key]
+
+
 def init_anchors_pos_ext(hparams, networkx_graph, device):
     g = networkx_graph
-    order = ops.Ragged(torch.tensor([0, g.n_nodes], dtype=torch.int64, device=g.device), g.node_order)
+    order = ops.Ragged(_span_ptr(g.n_nodes, g.device), g.node_order)
     return {n: ops.choice_ragged(order, hparams['n_anchor_patches_pos_out'], _seed(hparams),
                                  tape.stream_id(tape.STREAM_P_EXT, 0, n))[0]
             for n in range(hparams['n_layers'])}
 
 
-def init_anchors_structure(hparams, structure_anchors, int_structure_anchor_rw, bor_structure_anchor_rw):
+def init_anchors_structure(hparams, structure_anchors, int_structure_anchor_rw, bor_structure_anchor_rw,
+                           indices_on_device=False):
+    """aps:300-328.  The second entry of every layer's tuple is the list of picked patch numbers, as in
+    the reference; ``indices_on_device`` keeps it as the device tensor it was drawn into (the per-pass
+    path: no device->host->device round trip for a value only ever used as a column index)."""
     dev = structure_anchors.device
     P = structure_anchors.shape[0]
-    pool = ops.Ragged(torch.tensor([0, P], dtype=torch.int64, device=dev), torch.arange(P, dtype=torch.int32, device=dev))
+    pool = ops.Ragged(_span_ptr(P, dev), torch.arange(P, dtype=torch.int32, device=dev))
     out = {}
     for n in range(hparams['n_layers']):
         idx = ops.choice_ragged(pool, hparams['n_anchor_patches_structure'], _seed(hparams),
                                 tape.stream_id(tape.STREAM_S_PICK, 0, n))[0]
-        out[n] = (structure_anchors[idx, :], [int(i) for i in idx.tolist()], int_structure_anchor_rw[idx, :, :],
-                  bor_structure_anchor_rw[idx, :, :])
+        out[n] = (structure_anchors[idx, :], idx if indices_on_device else [int(i) for i in idx.tolist()],
+                  int_structure_anchor_rw[idx, :, :], bor_structure_anchor_rw[idx, :, :])
     return out
 
 

@@ -150,7 +150,8 @@ def prepare_sparse(model, split='train', timer=None):
                 model.int_structure_anchor_random_walks = aps.perform_random_walks(hp, g, model.structure_anchors, True, views)
                 model.anchors_structure = aps.init_anchors_structure(hp, model.structure_anchors,
                                                                      model.int_structure_anchor_random_walks,
-                                                                     model.bor_structure_anchor_random_walks)
+                                                                     model.bor_structure_anchor_random_walks,
+                                                                     indices_on_device=True)
                 # the column upload is a blocking host->device copy: do it here, before the long DTW
                 # launches are queued, so that the host is free to queue forward/backward behind them
                 model._build_sim_cols()

@@ -67,14 +67,26 @@ class Ragged:
         """(rows, L) padded int64 ids -> ragged, PAD stripped, order kept (gamma.py:27,
         aps:131, S.py:769 all strip PAD this way)."""
         assert ids.dim() == 2
-        mask = ids != PAD
-        lens = mask.sum(dim=1)
-        ptr = torch.zeros(ids.shape[0] + 1, dtype=torch.int64, device=ids.device)
-        torch.cumsum(lens, 0, out=ptr[1:])
-        nodes = ids[mask].to(torch.int32)
-        if nodes.numel() == 0:
-            nodes = torch.zeros(1, dtype=torch.int32, device=ids.device)
-        return Ragged(ptr, nodes.contiguous(), max_len=ids.shape[1])
+        return Ragged.from_mask(ids, ids != PAD)
+
+    @staticmethod
+    def from_mask(ids, mask):
+        """The masked entries of every row of a padded (rows, L) matrix, packed, order kept -- without
+        a host round trip: the packed position of an entry is its row's offset plus its rank among the
+        row's kept entries, dropped entries go to one spare slot behind the data (the node array is an
+        arena of rows*L + 1 entries; ``ptr`` says what is live)."""
+        assert ids.dim() == 2 and mask.shape == ids.shape
+        n, L = ids.shape
+        dev = ids.device
+        ptr = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+        if n == 0 or L == 0:
+            return Ragged(ptr, torch.zeros(1, dtype=torch.int32, device=dev), max_len=L)
+        rank = torch.cumsum(mask, dim=1)
+        torch.cumsum(rank[:, -1], 0, out=ptr[1:])
+        dst = torch.where(mask, ptr[:-1].view(-1, 1) + rank - 1, n * L)
+        nodes = torch.zeros(n * L + 1, dtype=torch.int32, device=dev)
+        nodes.scatter_(0, dst.reshape(-1), ids.reshape(-1).to(torch.int32))
+        return Ragged(ptr, nodes, max_len=L)
 
     @staticmethod
     def from_lists(lists, device):
@@ -88,16 +100,17 @@ class Ragged:
         return Ragged(torch.from_numpy(ptr).to(device), torch.from_numpy(flat).to(device), max_len=ml)
 
     def to_padded(self, width=None, fill=PAD, dtype=torch.int64):
+        """(n, width) matrix, rows left-aligned, ``fill`` behind them.  A gather (entry (i, j) reads
+        nodes[ptr[i] + j] where j < len_i): no data-dependent sizes, so no host round trip when
+        ``width`` is given."""
         width = self.max_len if width is None else width
-        out = torch.full((self.n, max(width, 0)), fill, dtype=dtype, device=self.ptr.device)
-        if self.n == 0 or width == 0:
-            return out
-        lens = self.lengths
-        tot = int(self.ptr[-1].item())
-        rows = torch.repeat_interleave(torch.arange(self.n, device=self.ptr.device), lens)
-        cols = torch.arange(tot, device=self.ptr.device) - torch.repeat_interleave(self.ptr[:-1], lens)
-        out[rows, cols] = self.nodes[:tot].to(dtype)
-        return out
+        dev = self.ptr.device
+        if self.n == 0 or width <= 0 or self.nodes.numel() == 0:
+            return torch.full((self.n, max(width, 0)), fill, dtype=dtype, device=dev)
+        j = torch.arange(width, device=dev).view(1, -1)
+        idx = (self.ptr[:-1].view(-1, 1) + j).clamp_(max=self.nodes.numel() - 1)
+        vals = self.nodes[idx].to(dtype)
+        return torch.where(j < self.lengths.view(-1, 1), vals, torch.full_like(vals, fill))
 
     def to_lists(self):
         p = self.ptr.cpu().numpy()
@@ -443,30 +456,40 @@ def min_hops_to_sets(dist, sets, node_major=False):
     return out
 
 
-def _unique_rows(rows):
-    """torch.unique(rows, dim=0, return_inverse=True) up to the order of the unique rows, via a
-    64-bit row hash and one 1-D sort (a lexicographic sort of 50k x 20 rows costs ~1.2 ms, this
-    ~0.15 ms).  Exactness does not rest on the hash: every row is compared with its group's
-    representative, and any mismatch (a hash collision) falls back to the exact routine.
-    The groups come from the sorted hashes directly (boundaries -> running group number -> scattered
-    back through the permutation, which has no collisions); a scatter-min of row numbers into the
-    groups serialises on the atomics of the big groups (0.37 ms for 50k rows in 2.7k groups)."""
+_HASH_COEF = {}
+
+
+def _row_representatives(rows):
+    """For every row of an (n, w) integer matrix the index of one representative row with the same
+    content, without a host round trip: a 64-bit row hash is sorted, runs of equal hashes are the
+    groups, the first row of a run (in sorted order) represents it.  Exactness does not rest on the
+    hash: a row that differs from its representative (a collision) represents itself."""
     n, w = rows.shape
-    g = torch.Generator(device='cpu').manual_seed(0x5DEECE66D)
-    coef = (torch.randint(-(1 << 62), 1 << 62, (w,), generator=g, dtype=torch.int64) | 1).to(rows.device)
+    dev = rows.device
+    coef = _HASH_COEF.get((w, dev))
+    if coef is None:                                  # uploaded once per width (a blocking host->device copy)
+        g = torch.Generator(device='cpu').manual_seed(0x5DEECE66D)
+        coef = _HASH_COEF[(w, dev)] = (torch.randint(-(1 << 62), 1 << 62, (w,), generator=g, dtype=torch.int64) | 1).to(dev)
     h = (rows.to(torch.int64) * coef).sum(dim=1)                          # wraps modulo 2^64
     hs, perm = torch.sort(h)
-    first = torch.ones(n, dtype=torch.bool, device=rows.device)
+    pos = torch.arange(n, device=dev)
+    first = torch.ones(n, dtype=torch.bool, device=dev)
     if n > 1:
         first[1:] = hs[1:] != hs[:-1]
-    gid = torch.cumsum(first, 0) - 1
-    inv = torch.empty(n, dtype=torch.int64, device=rows.device)
-    inv[perm] = gid
-    rep = perm[first]                                                      # one row of every group
-    uniq = rows.index_select(0, rep)
-    if bool((uniq.index_select(0, inv) == rows).all()):
-        return uniq, inv
-    return torch.unique(rows, dim=0, return_inverse=True)
+    start = torch.cummax(torch.where(first, pos, torch.zeros_like(pos)), 0).values   # run start, sorted order
+    rep = torch.empty(n, dtype=torch.int64, device=dev)
+    rep[perm] = perm[start]
+    same = (rows.index_select(0, rep) == rows).all(dim=1)
+    return torch.where(same, rep, pos)
+
+
+def _unique_rows(rows):
+    """torch.unique(rows, dim=0, return_inverse=True) up to the order of the unique rows (host
+    round trip for the count; the DTW path uses _row_representatives and stays on the device)."""
+    rep = _row_representatives(rows)
+    is_rep = rep == torch.arange(rows.shape[0], device=rows.device)
+    gid = torch.cumsum(is_rep, 0) - 1
+    return rows[is_rep], gid[rep]
 
 
 def dtw_similarity(x_ptr, x_val, max_x, y_ptr, y_val, max_y, tie_order=0, order_rows=True, dedupe=True):
@@ -476,23 +499,22 @@ def dtw_similarity(x_ptr, x_val, max_x, y_ptr, y_val, max_y, tie_order=0, order_
     result rows gathered back.  ``order_rows``: process the x rows sorted by (length, median, sum) so
     that the lanes of a wavefront work on similar series.  Neither changes any value."""
     if dedupe and x_ptr.numel() - 1 > 1024 and max_x <= 64:
+        # no host round trip: every row keeps its slot, the rows that repeat an earlier one are given
+        # length 0 (their pairs exit at once -- sorted by length they fill whole wavefronts) and read
+        # their representative's result row afterwards
+        n = x_ptr.numel() - 1
         rows = Ragged(x_ptr, x_val, max_len=max_x).to_padded(width=max_x, fill=-1, dtype=torch.int32)
-        # cheap look first: if a 2048-row sample has (almost) no repeats, the full grouping is skipped
-        probe = rows[:: max(rows.shape[0] // 2048, 1)][:2048]
-        if _unique_rows(probe)[0].shape[0] * 4 > probe.shape[0] * 3:
-            uniq = rows
-        else:
-            uniq, inv = _unique_rows(rows)
-        if uniq.shape[0] * 2 <= rows.shape[0]:
-            mask = uniq >= 0
-            lens = mask.sum(dim=1)
-            uptr = torch.zeros(uniq.shape[0] + 1, dtype=torch.int64, device=x_ptr.device)
-            torch.cumsum(lens, 0, out=uptr[1:])
-            uval = uniq[mask].contiguous()
-            if uval.numel() == 0:
-                uval = torch.zeros(1, dtype=torch.int32, device=x_ptr.device)
-            out_u = dtw_similarity(uptr, uval, max_x, y_ptr, y_val, max_y, tie_order, order_rows, dedupe=False)
-            return out_u.index_select(0, inv)
+        rep = _row_representatives(rows)
+        pos = torch.arange(n, device=x_ptr.device)
+        lens = torch.where(rep == pos, x_ptr[1:] - x_ptr[:-1], torch.zeros_like(pos))
+        uptr = torch.zeros(n + 1, dtype=torch.int64, device=x_ptr.device)
+        torch.cumsum(lens, 0, out=uptr[1:])
+        j = torch.arange(max_x, device=x_ptr.device).view(1, -1)
+        dst = torch.where(j < lens.view(-1, 1), uptr[:-1].view(-1, 1) + j, x_val.numel())   # dropped entries -> spare slot
+        uval = torch.zeros(x_val.numel() + 1, dtype=torch.int32, device=x_ptr.device)
+        uval.scatter_(0, dst.reshape(-1), rows.reshape(-1))
+        out_u = dtw_similarity(uptr, uval, max_x, y_ptr, y_val, max_y, tie_order, order_rows, dedupe=False)
+        return out_u.index_select(0, rep)
     lib = _lib.load()
     for t, nm in ((x_ptr, 'x_ptr'), (y_ptr, 'y_ptr')):
         _req(t, torch.int64, nm)
