@@ -115,6 +115,14 @@ def prepare_sparse(model, split='train', timer=None):
     # ---- side stream: position channel + structure patches / walks -------------------------
     side.wait_stream(main)
     with torch.cuda.stream(side):
+        # The structure patches are drawn first: trimming them to the longest walk is the one host round
+        # trip of this block, and it is taken while the queue is still short -- everything after it
+        # (multi-source BFS, views, walks) is queued without waiting, behind the long BFS launches.
+        new_patches = hp['use_structure'] and (split != 'test' or getattr(model, 'structure_anchors', None) is None)
+        if new_patches:
+            model.structure_anchors = aps.sample_structure_anchor_patches(hp, g, dev, hp['max_sim_epochs'])
+            if side is main:
+                t.mark('S_patches_walks')
         if hp['use_position']:
             if getattr(model, 'anchors_pos_ext', None) is None or split != 'test':
                 model.anchors_pos_ext = aps.init_anchors_pos_ext(hp, g, dev)
@@ -143,8 +151,7 @@ def prepare_sparse(model, split='train', timer=None):
             if side is main:
                 t.mark('P_bfs_sims')
         if hp['use_structure']:
-            if split != 'test' or getattr(model, 'structure_anchors', None) is None:
-                model.structure_anchors = aps.sample_structure_anchor_patches(hp, g, dev, hp['max_sim_epochs'])
+            if new_patches:
                 views = aps.patch_node_views(model.structure_anchors)
                 model.bor_structure_anchor_random_walks = aps.perform_random_walks(hp, g, model.structure_anchors, False, views)
                 model.int_structure_anchor_random_walks = aps.perform_random_walks(hp, g, model.structure_anchors, True, views)
