@@ -338,6 +338,28 @@ int sgnn_attn_scores_fwd(const float* X, const float* U, const float* qW, const 
                          int64_t R, int64_t H, int64_t rows_per_batch, float* out, void* stream);
 
 /* ---------------------------------------------------------------------------------------
+ * a14 (walk aggregator)  One bidirectional LSTM layer, whole sequence per launch.
+ * Replaces the nn.LSTM(bidirectional=True, batch_first=True) inside the reference's LSTM module
+ * (SubGNN/SubGNN.py:60-88) as called by aggregate_structure_anchor_patch
+ * (SubGNN/anchor_patch_samplers.py:413-433) on (patches x walks, walk_len, D).  h0 = c0 = 0.
+ *   x      (B, T, I)            inputs
+ *   wcat   (2, 4H, I + H)       per direction [weight_ih | weight_hh], gate rows i, f, g, o (torch order)
+ *   bias   (2, 4H)              bias_ih + bias_hh
+ *   y      (B, T, 2H)           [forward h_t | reverse h_t]  (torch's output layout)
+ *   gates  (2, B, T, 4H), cell (2, B, T, H)   activations kept for the backward pass
+ * backward: dy (B, T, 2H) -> gate gradients dgates (2, B, T, 4H; scratch the caller provides) written;
+ * dx (B, T, I) (the two directions add into it), dwcat (2, 4H, I + H) and dbias (2, 4H) ACCUMULATED
+ * (zero them first).  Supported sizes: H in {32, 64}, I in {H, 2H} (sgnn_lstm_supported), else
+ * SGNN_ERR_UNSUPPORTED_D -- the caller keeps the library LSTM for those.
+ * ------------------------------------------------------------------------------------- */
+int sgnn_lstm_supported(int64_t input_size, int64_t hidden_size);
+int sgnn_lstm_fwd(const float* x, const float* wcat, const float* bias, int64_t B, int64_t T,
+                  int64_t input_size, int64_t hidden_size, float* y, float* gates, float* cell, void* stream);
+int sgnn_lstm_bwd(const float* x, const float* wcat, const float* y, const float* gates, const float* cell,
+                  const float* dy, int64_t B, int64_t T, int64_t input_size, int64_t hidden_size, float* dx,
+                  float* dgates, float* dwcat, float* dbias, void* stream);
+
+/* ---------------------------------------------------------------------------------------
  * a16  Masked sum over the components of a subgraph (subgraph_utils.masked_sum,
  * SubGNN/subgraph_utils.py:213-237, as used at SubGNN/SubGNN.py:303).  x (B,C,H), mask (B,C)
  * -> out (B,H); backward scatters grad_out to the real components.

@@ -46,8 +46,26 @@ class LSTM(nn.Module):
                             bidirectional=True)
         self.linear = nn.Linear(h * 2, n_features)
 
+    def _fused(self, input):
+        """The recurrence in one launch per layer and direction pair (ops.bilstm_layer) when the sizes
+        are ones the kernel is built for; the parameters are nn.LSTM's own (state-dict compatible)."""
+        m = self.lstm
+        out = input
+        for l in range(self.num_layers):
+            params = [getattr(m, '%s_l%d%s' % (n, l, sfx)) for sfx in ('', '_reverse')
+                      for n in ('weight_ih', 'weight_hh', 'bias_ih', 'bias_hh')]
+            out = ops.bilstm_layer(out, params)
+            if l < self.num_layers - 1 and m.dropout > 0 and self.training:
+                out = nn.functional.dropout(out, m.dropout, True)
+        return out
+
     def forward(self, input):
-        out, _ = self.lstm(input)
+        m = self.lstm
+        if (input.is_cuda and input.dtype == torch.float32 and m.batch_first and m.bias and input.dim() == 3
+                and ops.lstm_supported(m.input_size, m.hidden_size)):
+            out = self._fused(input)
+        else:
+            out, _ = m(input)                     # sizes outside the kernel's set: the library LSTM
         agg = out[:, -1, :] if self.aggregator == 'last' else out.sum(dim=1)
         return self.linear(agg)
 

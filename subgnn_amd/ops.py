@@ -904,6 +904,53 @@ def gather_rows(weight, ids):
     return _GatherRows.apply(weight, ids.to(torch.int64))
 
 
+class _BiLSTMLayer(torch.autograd.Function):
+    """One bidirectional LSTM layer (sgnn_lstm_fwd / _bwd): x (B, T, I) -> (B, T, 2H), zero initial
+    state.  Parameters in torch's nn.LSTM layout (weight_ih (4H, I), weight_hh (4H, H), two biases,
+    per direction)."""
+
+    @staticmethod
+    def forward(ctx, x, w_ih_f, w_hh_f, b_ih_f, b_hh_f, w_ih_r, w_hh_r, b_ih_r, b_hh_r):
+        lib = _lib.load()
+        _req(x, torch.float32, 'x')
+        B, T, I = x.shape
+        H = w_hh_f.shape[1]
+        wcat = torch.stack((torch.cat((w_ih_f, w_hh_f), 1), torch.cat((w_ih_r, w_hh_r), 1))).contiguous()
+        bias = torch.stack((b_ih_f + b_hh_f, b_ih_r + b_hh_r)).contiguous()
+        y = torch.empty((B, T, 2 * H), dtype=torch.float32, device=x.device)
+        gates = torch.empty((2, B, T, 4 * H), dtype=torch.float32, device=x.device)
+        cell = torch.empty((2, B, T, H), dtype=torch.float32, device=x.device)
+        check(lib.sgnn_lstm_fwd(_ptr(x), _ptr(wcat), _ptr(bias), B, T, I, H, _ptr(y), _ptr(gates), _ptr(cell), _stream()),
+              'sgnn_lstm_fwd')
+        ctx.save_for_backward(x, wcat, y, gates, cell)
+        ctx.dims = (B, T, I, H)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, wcat, y, gates, cell = ctx.saved_tensors
+        B, T, I, H = ctx.dims
+        dy = dy.contiguous()
+        dx = torch.zeros_like(x)
+        dgates = torch.empty_like(gates)
+        dw = torch.zeros_like(wcat)
+        db = torch.zeros((2, 4 * H), dtype=torch.float32, device=x.device)
+        check(lib.sgnn_lstm_bwd(_ptr(x), _ptr(wcat), _ptr(y), _ptr(gates), _ptr(cell), _ptr(dy), B, T, I, H, _ptr(dx),
+                                _ptr(dgates), _ptr(dw), _ptr(db), _stream()), 'sgnn_lstm_bwd')
+        return (dx, dw[0, :, :I], dw[0, :, I:], db[0], db[0], dw[1, :, :I], dw[1, :, I:], db[1], db[1])
+
+
+def lstm_supported(input_size, hidden_size):
+    return bool(_lib.load().sgnn_lstm_supported(int(input_size), int(hidden_size)))
+
+
+def bilstm_layer(x, params):
+    """``params``: (weight_ih, weight_hh, bias_ih, bias_hh) of the forward direction followed by the
+    same four of the reverse direction."""
+    return _BiLSTMLayer.apply(x.contiguous(), *[p.contiguous() for p in params])
+
+
 class _AttnScores(torch.autograd.Function):
     """Additive-attention scores: forward on the matrix cores (sgnn_attn_scores_fwd); the backward
     recomputes tanh(qW + X U) with library GEMMs (plain dense contractions)."""

@@ -250,3 +250,65 @@ def test_attn_scores_mfma(R, H, C):
     assert_close(out, ref, 'scores', 2e-5)
     for a, b, nm in ((Xg, Xc, 'X'), (Ug, Uc, 'U'), (qg, qc, 'qW'), (vg, vc, 'v')):
         assert_close(a.grad, b.grad, 'grad ' + nm)
+
+
+# ---- fused bidirectional LSTM layer (sgnn_lstm_fwd / _bwd) vs torch's nn.LSTM in fp32 on the CPU --------
+
+def _lstm_params(m, layer):
+    return [getattr(m, '%s_l%d%s' % (n, layer, sfx)) for sfx in ('', '_reverse')
+            for n in ('weight_ih', 'weight_hh', 'bias_ih', 'bias_hh')]
+
+
+@pytest.mark.parametrize('H,I', [(64, 64), (64, 128), (32, 32), (32, 64)])
+@pytest.mark.parametrize('B,Tn', [(1, 1), (7, 3), (210, 10), (19, 20), (8, 10)])
+def test_bilstm_layer_matches_torch(H, I, B, Tn):
+    from subgnn_amd import ops
+    torch.manual_seed(H + I + B + Tn)
+    ref = torch.nn.LSTM(I, H, num_layers=1, batch_first=True, bidirectional=True)
+    x = torch.randn(B, Tn, I)
+    g = torch.randn(B, Tn, 2 * H)
+    xr = x.clone().requires_grad_()
+    yr, _ = ref(xr)
+    (yr * g).sum().backward()
+    dev_params = [p.detach().to(DEV).requires_grad_() for p in _lstm_params(ref, 0)]
+    xd = x.to(DEV).requires_grad_()
+    y = ops.bilstm_layer(xd, dev_params)
+    (y * g.to(DEV)).sum().backward()
+    tol = dict(rtol=1e-4, atol=2e-5)
+    assert torch.allclose(y.cpu(), yr.detach(), **tol)
+    assert torch.allclose(xd.grad.cpu(), xr.grad, **tol)
+    for p, q in zip(dev_params, _lstm_params(ref, 0)):
+        scale = max(float(q.grad.abs().max()), 1.0)
+        assert torch.allclose(p.grad.cpu() / scale, q.grad / scale, rtol=1e-4, atol=2e-5), (p.shape,)
+
+
+@pytest.mark.parametrize('layers,agg', [(1, 'last'), (2, 'last'), (2, 'sum')])
+def test_lstm_module_uses_fused_layers_and_matches_library(layers, agg):
+    """The module of SubGNN.py:60-88 with the kernel inside equals the same parameters run through the
+    library nn.LSTM (state-dict compatible: same parameter names)."""
+    from subgnn_amd.SubGNN import LSTM
+    torch.manual_seed(3)
+    m = LSTM(64, 64, dropout=0.0, num_layers=layers, aggregator=agg).to(DEV)
+    assert sorted(k for k in m.state_dict() if k.startswith('lstm.')) == sorted('lstm.' + k for k in m.lstm.state_dict())
+    x = torch.randn(30, 12, 64, device=DEV, requires_grad=True)
+    out = m(x)
+    out.square().sum().backward()
+    gx, gw = x.grad.clone(), [p.grad.clone() for p in m.parameters()]
+    x.grad = None
+    m.zero_grad()
+    lib_out, _ = m.lstm(x)
+    lib = m.linear(lib_out[:, -1, :] if agg == 'last' else lib_out.sum(dim=1))
+    lib.square().sum().backward()
+    assert torch.allclose(out, lib, rtol=1e-4, atol=1e-5)
+    assert torch.allclose(gx, x.grad, rtol=1e-3, atol=1e-5)
+    for a, p in zip(gw, m.parameters()):
+        s = max(float(p.grad.abs().max()), 1.0)
+        assert torch.allclose(a / s, p.grad / s, rtol=1e-3, atol=2e-5)
+
+
+def test_lstm_unsupported_sizes_stay_on_the_library():
+    from subgnn_amd import ops
+    from subgnn_amd.SubGNN import LSTM
+    assert ops.lstm_supported(64, 64) and ops.lstm_supported(128, 64) and not ops.lstm_supported(48, 48)
+    m = LSTM(48, 48).to(DEV)
+    assert m(torch.randn(5, 4, 48, device=DEV)).shape == (5, 48)
