@@ -347,17 +347,19 @@ int sgnn_attn_scores_fwd(const float* X, const float* U, const float* qW, const 
  *   bias   (2, 4H)              bias_ih + bias_hh
  *   y      (B, T, 2H)           [forward h_t | reverse h_t]  (torch's output layout)
  *   gates  (2, B, T, 4H), cell (2, B, T, H)   activations kept for the backward pass
- * backward: dy (B, T, 2H) -> gate gradients dgates (2, B, T, 4H; scratch the caller provides) written;
- * dx (B, T, I) (the two directions add into it), dwcat (2, 4H, I + H) and dbias (2, 4H) ACCUMULATED
- * (zero them first).  Supported sizes: H in {32, 64}, I in {H, 2H} (sgnn_lstm_supported), else
- * SGNN_ERR_UNSUPPORTED_D -- the caller keeps the library LSTM for those.
+ *   xh     (2, B, T, I + H)     [x_t | h_{t-1}] per direction, kept for the weight gradient
+ * backward: dy (B, T, 2H) -> gate gradients dgates (2, B, T, 4H) written, dx (B, T, I) ACCUMULATED (the
+ * two directions add into it: zero it first).  The weight gradient is the caller's GEMM over all
+ * (sequence, step) rows: d wcat[d] = dgates[d]^T xh[d], d bias[d] = column sums of dgates[d].
+ * Supported sizes: H in {32, 64}, I in {H, 2H} (sgnn_lstm_supported), else SGNN_ERR_UNSUPPORTED_D --
+ * the caller keeps the library LSTM for those.
  * ------------------------------------------------------------------------------------- */
 int sgnn_lstm_supported(int64_t input_size, int64_t hidden_size);
 int sgnn_lstm_fwd(const float* x, const float* wcat, const float* bias, int64_t B, int64_t T,
-                  int64_t input_size, int64_t hidden_size, float* y, float* gates, float* cell, void* stream);
-int sgnn_lstm_bwd(const float* x, const float* wcat, const float* y, const float* gates, const float* cell,
-                  const float* dy, int64_t B, int64_t T, int64_t input_size, int64_t hidden_size, float* dx,
-                  float* dgates, float* dwcat, float* dbias, void* stream);
+                  int64_t input_size, int64_t hidden_size, float* y, float* gates, float* cell, float* xh,
+                  void* stream);
+int sgnn_lstm_bwd(const float* wcat, const float* gates, const float* cell, const float* dy, int64_t B,
+                  int64_t T, int64_t input_size, int64_t hidden_size, float* dx, float* dgates, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * a16  Masked sum over the components of a subgraph (subgraph_utils.masked_sum,

@@ -920,24 +920,27 @@ class _BiLSTMLayer(torch.autograd.Function):
         y = torch.empty((B, T, 2 * H), dtype=torch.float32, device=x.device)
         gates = torch.empty((2, B, T, 4 * H), dtype=torch.float32, device=x.device)
         cell = torch.empty((2, B, T, H), dtype=torch.float32, device=x.device)
-        check(lib.sgnn_lstm_fwd(_ptr(x), _ptr(wcat), _ptr(bias), B, T, I, H, _ptr(y), _ptr(gates), _ptr(cell), _stream()),
-              'sgnn_lstm_fwd')
-        ctx.save_for_backward(x, wcat, y, gates, cell)
+        xh = torch.empty((2, B, T, I + H), dtype=torch.float32, device=x.device)
+        check(lib.sgnn_lstm_fwd(_ptr(x), _ptr(wcat), _ptr(bias), B, T, I, H, _ptr(y), _ptr(gates), _ptr(cell), _ptr(xh),
+                                _stream()), 'sgnn_lstm_fwd')
+        ctx.save_for_backward(wcat, gates, cell, xh)
         ctx.dims = (B, T, I, H)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         lib = _lib.load()
-        x, wcat, y, gates, cell = ctx.saved_tensors
+        wcat, gates, cell, xh = ctx.saved_tensors
         B, T, I, H = ctx.dims
         dy = dy.contiguous()
-        dx = torch.zeros_like(x)
+        dx = torch.zeros((B, T, I), dtype=torch.float32, device=dy.device)
         dgates = torch.empty_like(gates)
-        dw = torch.zeros_like(wcat)
-        db = torch.zeros((2, 4 * H), dtype=torch.float32, device=x.device)
-        check(lib.sgnn_lstm_bwd(_ptr(x), _ptr(wcat), _ptr(y), _ptr(gates), _ptr(cell), _ptr(dy), B, T, I, H, _ptr(dx),
-                                _ptr(dgates), _ptr(dw), _ptr(db), _stream()), 'sgnn_lstm_bwd')
+        check(lib.sgnn_lstm_bwd(_ptr(wcat), _ptr(gates), _ptr(cell), _ptr(dy), B, T, I, H, _ptr(dx), _ptr(dgates),
+                                _stream()), 'sgnn_lstm_bwd')
+        # weight gradient: one batched GEMM over all (sequence, step) rows, per direction
+        dg = dgates.view(2, B * T, 4 * H)
+        dw = torch.bmm(dg.transpose(1, 2), xh.view(2, B * T, I + H))
+        db = dg.sum(dim=1)
         return (dx, dw[0, :, :I], dw[0, :, I:], db[0], db[0], dw[1, :, :I], dw[1, :, I:], db[1], db[1])
 
 
