@@ -935,8 +935,15 @@ __device__ __forceinline__ double dtw_reg_level(
                     // test above already removed most out-of-window rows)
                     const bool in = j >= lo && j <= hi;
                     const double dt = dtw_cost_rcp(xp1[i], xr[i], yp1, yr);
-                    const double c_up = up + dt, c_left = old + dt, c_diag = diag + dt;
-                    const double mv = fmin(fmin(c_up, c_left), c_diag);      // two v_min_f64 (no NaNs here)
+                    double mv, c_up = 0.0, c_left = 0.0, c_diag = 0.0;
+                    if (FINEST) {
+                        // only the value is needed: rounding is monotone, so the smallest of the three rounded
+                        // sums is the rounded sum of the smallest candidate -- one add instead of three
+                        mv = fmin(fmin(up, old), diag) + dt;
+                    } else {
+                        c_up = up + dt; c_left = old + dt; c_diag = diag + dt;
+                        mv = fmin(fmin(c_up, c_left), c_diag);               // two v_min_f64 (no NaNs here)
+                    }
                     const double nv = in ? mv : INF;
                     if (!FINEST) {
                         // predecessor = the first candidate, in the tie order, that attains the minimum

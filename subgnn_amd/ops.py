@@ -38,6 +38,9 @@ def _req(t, dtype, name):
 # containers
 # ---------------------------------------------------------------------------------------
 
+_TRI = {}
+
+
 class Ragged:
     """CSR-style node sets on the device: ptr int64[n+1], nodes int32[total]."""
 
@@ -81,7 +84,16 @@ class Ragged:
         ptr = torch.zeros(n + 1, dtype=torch.int64, device=dev)
         if n == 0 or L == 0:
             return Ragged(ptr, torch.zeros(1, dtype=torch.int32, device=dev), max_len=L)
-        rank = torch.cumsum(mask, dim=1)
+        # rank of an entry among its row's kept entries.  torch's scan along the innermost dimension of
+        # a (50k, 20) matrix takes 0.15 ms; for the short rows of this path the same numbers come out of
+        # one small GEMM with a triangular matrix (counts < 2^24 are exact in fp32)
+        if L <= 256:
+            tri = _TRI.get((L, dev))
+            if tri is None:
+                tri = _TRI[(L, dev)] = torch.ones(L, L, dtype=torch.float32, device=dev).triu()
+            rank = (mask.to(torch.float32) @ tri).to(torch.int64)
+        else:
+            rank = torch.cumsum(mask, dim=1)
         torch.cumsum(rank[:, -1], 0, out=ptr[1:])
         dst = torch.where(mask, ptr[:-1].view(-1, 1) + rank - 1, n * L)
         nodes = torch.zeros(n * L + 1, dtype=torch.int32, device=dev)
@@ -476,7 +488,13 @@ def _row_representatives(rows):
     first = torch.ones(n, dtype=torch.bool, device=dev)
     if n > 1:
         first[1:] = hs[1:] != hs[:-1]
-    start = torch.cummax(torch.where(first, pos, torch.zeros_like(pos)), 0).values   # run start, sorted order
+    # run start (sorted order) of every entry: the run number is a prefix sum of the run-start flags; the
+    # start position of run g is scattered from its first entry (the others write to a spare slot) --
+    # torch.cummax over one long row is a serial scan (0.13 ms for 50k)
+    gid = torch.cumsum(first, 0) - 1
+    run_start = torch.empty(n + 1, dtype=torch.int64, device=dev)
+    run_start.scatter_(0, torch.where(first, gid, n), pos)
+    start = run_start[gid]
     rep = torch.empty(n, dtype=torch.int64, device=dev)
     rep[perm] = perm[start]
     same = (rows.index_select(0, rep) == rows).all(dim=1)
