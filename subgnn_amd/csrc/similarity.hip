@@ -827,6 +827,9 @@ __global__ __launch_bounds__(DTW_THREADS) void dtw_similarity_kernel(
 // 32-bit words: such a level has at most 16 rows) when WLDS, else to the global scratch wq.
 // FINEST: the level whose distance is the result -- it is never backtracked, so it neither tracks
 // nor stores predecessor codes (it holds more than half of all cells).
+#ifndef DTW_BLK
+#define DTW_BLK 4          // rows per block of the column sweep (divides 12, 20 and 32)
+#endif
 template <int RMAX, int RR, int TIE, bool WLDS, bool FINEST>
 __device__ __forceinline__ double dtw_reg_level(
     int32_t* __restrict__ fl, const double* __restrict__ xcol, const double* __restrict__ xrcol, int64_t n_x,
@@ -862,16 +865,16 @@ __device__ __forceinline__ double dtw_reg_level(
             lohi[i] = v;
         }
     }
-    // rows in blocks of 4: a block is swept for the columns [min lo, max hi + 1] of its rows (the
+    // rows in blocks of DTW_BLK: a block is swept for the columns [min lo, max hi + 1] of its rows (the
     // extra column lets every cell of the block fall back to INF once), and skipped with one test
     // elsewhere -- most (row, column) pairs lie outside the radius-1 window
-    int32_t blk[RR / 4];
+    int32_t blk[RR / DTW_BLK];
 #pragma unroll
-    for (int b = 0; b < RR / 4; ++b) {
+    for (int b = 0; b < RR / DTW_BLK; ++b) {
         int lo = 0x7fff, hi = -1;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int l = lohi[4 * b + q] & 0xffff, h = lohi[4 * b + q] >> 16;
+        for (int q = 0; q < DTW_BLK; ++q) {
+            const int l = lohi[DTW_BLK * b + q] & 0xffff, h = lohi[DTW_BLK * b + q] >> 16;
             if (h >= l) { lo = l < lo ? l : lo; hi = h > hi ? h : hi; }
         }
         blk[b] = hi < 0 ? EMPTY : (((hi + 1) << 16) | lo);
@@ -882,7 +885,7 @@ __device__ __forceinline__ double dtw_reg_level(
     // read back into scalar registers) is what the wavefront executes anyway -- testing it with
     // s_cmp / s_cbranch costs the vector pipeline nothing, where the per-lane test cost ~5 vector
     // instructions per block and column.  Rows inside a live block select by their own window.
-    int ublo[RR / 4], ubhi[RR / 4];
+    int ublo[RR / DTW_BLK], ubhi[RR / DTW_BLK];
     {
         int32_t* su = ublk + (threadIdx.x >> 6) * 16;
         const int l16 = threadIdx.x & 15;
@@ -890,12 +893,12 @@ __device__ __forceinline__ double dtw_reg_level(
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int b = 0; b < RR / 4; ++b)
+        for (int b = 0; b < RR / DTW_BLK; ++b)
             if (blk[b] != EMPTY) { atomicMin(&su[2 * b], blk[b] & 0xffff); atomicMax(&su[2 * b + 1], blk[b] >> 16); }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int b = 0; b < RR / 4; ++b) {
+        for (int b = 0; b < RR / DTW_BLK; ++b) {
             ublo[b] = __builtin_amdgcn_readfirstlane(su[2 * b]);
             ubhi[b] = __builtin_amdgcn_readfirstlane(su[2 * b + 1]);
         }
@@ -918,15 +921,15 @@ __device__ __forceinline__ double dtw_reg_level(
         double up = INF;
         double diag = (j == 0) ? 0.0 : INF;                                  // virtual origin D[0][0] = 0
 #pragma unroll
-        for (int b = 0; b < RR / 4; ++b) {
+        for (int b = 0; b < RR / DTW_BLK; ++b) {
 #if DTW_UNIFORM_BLOCKS
             if (j >= ublo[b] && j <= ubhi[b]) {
 #else
             if (j >= (blk[b] & 0xffff) && j <= (blk[b] >> 16)) {
 #endif
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int i = 4 * b + q;
+                for (int q = 0; q < DTW_BLK; ++q) {
+                    const int i = DTW_BLK * b + q;
                     const int lo = lohi[i] & 0xffff, hi = lohi[i] >> 16;
                     const double old = col[i];
 #if DTW_BRANCHLESS_ROWS

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Rebuild the library with different compile-time DTW settings on the GPU box and time the
 # DTW calls of tools/dtw_probe.py for 12-, 20- and 32-node subgraphs.  Usage: bash tools/tune_dtw.sh
-for flags in "-DDTW_UNIFORM_BLOCKS=0" "-DDTW_UNIFORM_BLOCKS=1"; do
+for flags in "-DDTW_BLK=4" "-DDTW_BLK=2" "-DDTW_BLK=1"; do
   SGNN_HIPCC_FLAGS="$flags" python -m subgnn_amd.build --force > /dev/null 2>&1
   for nx in 12 20 32; do
     echo "$flags nx=$nx: $(python tools/dtw_probe.py 3 $nx 2>&1 | grep -v amdgpu.ids | head -2 | tr '\n' ' ')"
