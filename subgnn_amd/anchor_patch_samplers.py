@@ -22,6 +22,9 @@ def _seed(hparams):
 # triangular random walks (aps:20-158, 210-243)
 # ---------------------------------------------------------------------------------------
 
+VIEW_PAIRWISE_MAX = 1 << 26      # P * L * L entries of the pairwise comparison; above it the sort-based form
+
+
 def patch_node_views(anchor_patch_ids):
     """Node view of every patch's induced subgraph: unique ids in first-occurrence order
     (the reference iterates a networkx subgraph view whose order is CPython-set order).
@@ -31,7 +34,7 @@ def patch_node_views(anchor_patch_ids):
     P, L = anchor_patch_ids.shape
     dev = anchor_patch_ids.device
     ids = anchor_patch_ids
-    if P * L * L <= (1 << 26):
+    if P * L * L <= VIEW_PAIRWISE_MAX:
         earlier = torch.ones(L, L, dtype=torch.bool, device=dev).tril(-1)          # [i, j]: j < i
         dup = ((ids.unsqueeze(2) == ids.unsqueeze(1)) & earlier.unsqueeze(0)).any(dim=2)
         keep = ~dup & (ids != PAD_VALUE)

@@ -655,3 +655,60 @@ def test_sort_sets_rejects_large_sets():
     rc = lib.sgnn_sort_sets(ctypes.c_void_p(ptr.data_ptr()), ctypes.c_void_p(nodes.data_ptr()), 1, 2000,
                             ctypes.c_void_p(out.data_ptr()), None, None)
     assert rc == -2
+
+
+def test_dtw_row_grouping_survives_hash_collisions(monkeypatch):
+    """The row grouping of the DTW dedupe trusts no hash: with every row hashing to the same value
+    (coefficients forced to zero) rows that differ from their group's representative represent
+    themselves, and the similarities are still the plain ones."""
+    ops = _ops()
+    rng = np.random.default_rng(5)
+    base = [sorted(rng.integers(0, 6, int(rng.integers(0, 21))).tolist()) for _ in range(25)]
+    xs = [base[int(i)] for i in rng.integers(0, 25, 1500)]
+    ys = [sorted(rng.integers(0, 50, int(rng.integers(1, 51))).tolist()) for _ in range(9)]
+    xp, xv = cbind.ragged(xs)
+    yp, yv = cbind.ragged(ys)
+    t = lambda a: torch.from_numpy(a).to(DEV)
+    plain = ops.dtw_similarity(t(xp), t(xv), 20, t(yp), t(yv), 50, 0, dedupe=False, order_rows=False)
+    monkeypatch.setattr(ops, '_HASH_COEF', {(20, torch.device(DEV)): torch.zeros(20, dtype=torch.int64, device=DEV)})
+    rows = ops.Ragged(t(xp), t(xv), max_len=20).to_padded(width=20, fill=-1, dtype=torch.int32)
+    rep = ops._row_representatives(rows)
+    assert bool((rows[rep] == rows).all()) and bool((rep[rep] == rep).all())
+    assert torch.equal(ops.dtw_similarity(t(xp), t(xv), 20, t(yp), t(yv), 50, 0, dedupe=True), plain)
+    monkeypatch.setattr(ops, '_HASH_COEF', {})
+    rep2 = ops._row_representatives(rows)                          # the real hash: one representative per distinct row
+    assert int(rep2.unique().numel()) == len({tuple(x) for x in xs})
+
+
+def test_ragged_packing_without_host_round_trips():
+    """Ragged.from_mask / to_padded (scatter-pack and gather forms) against plain python lists,
+    including empty rows, empty matrices and rows of full width."""
+    ops = _ops()
+    rng = np.random.default_rng(11)
+    ids = torch.from_numpy(rng.integers(1, 1000, (300, 17))).to(DEV)
+    mask = torch.from_numpy(rng.random((300, 17)) < 0.4).to(DEV)
+    mask[0] = False
+    mask[1] = True
+    r = ops.Ragged.from_mask(ids, mask)
+    want = [[int(v) for v, m in zip(row, mr) if m] for row, mr in zip(ids.cpu().tolist(), mask.cpu().tolist())]
+    assert r.to_lists() == want
+    back = r.to_padded(width=17, fill=-1)
+    for row, w in zip(back.cpu().tolist(), want):
+        assert row == w + [-1] * (17 - len(w))
+    padded = ids * mask                                                      # PAD = 0 where dropped
+    assert ops.Ragged.from_padded(padded).to_lists() == [[v for v in row if v != 0] for row in padded.cpu().tolist()]
+    assert ops.Ragged.from_padded(torch.zeros((4, 5), dtype=torch.int64, device=DEV)).to_lists() == [[], [], [], []]
+    wide = torch.from_numpy(rng.integers(0, 3, (20, 300))).to(DEV)           # wider than the triangular-product form
+    assert ops.Ragged.from_padded(wide).to_lists() == [[v for v in row if v != 0] for row in wide.cpu().tolist()]
+
+
+def test_patch_node_views_both_forms(monkeypatch):
+    """First-occurrence unique ids per patch: the L x L comparison form and the sort-based form of
+    anchor_patch_samplers.patch_node_views agree with python."""
+    from subgnn_amd import anchor_patch_samplers as aps
+    rng = np.random.default_rng(2)
+    ids = torch.from_numpy(rng.integers(0, 12, (40, 30))).to(DEV)            # many repeats and PADs
+    want = [list(dict.fromkeys(v for v in row if v != 0)) for row in ids.cpu().tolist()]
+    assert aps.patch_node_views(ids).to_lists() == want
+    monkeypatch.setattr(aps, 'VIEW_PAIRWISE_MAX', 0)                       # force the sort-based form
+    assert aps.patch_node_views(ids).to_lists() == want
