@@ -180,7 +180,7 @@ def prepare_sparse(model, split='train', timer=None):
             # border BFS fused with the border-anchor draw (rank query on the visited bitmap): the
             # border is never materialised
             a, w, _ = ops.khop_border_sample(g, cc_sets, k, hp['n_anchor_patches_N_out'], seed,
-                                             tape.stream_id(tape.STREAM_N_BOR, split, l), order=set_order)
+                                             tape.stream_id(tape.STREAM_N_BOR, split, l))     # taken dynamically: a dispatch order buys nothing here
             nb[l] = a.view(S, C, -1)
             sims[('N', 'out', l)] = w.view(S, C, -1).contiguous()
         if getattr(model, 'anchors_neigh_int', None) is None:

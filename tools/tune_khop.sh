@@ -1,6 +1,6 @@
 #!/bin/bash
 # Rebuild with different border-BFS settings and time the border stage (tools/khop_probe.py).
-for flags in "-DKB_BIG=1024" "-DKB_BIG=256" "-DKB_BIG=4096" "-DKB_BIG=1024 -DKB_INFLIGHT=4" "-DKB_BIG=100000000"; do
+for flags in "-DKB_TAKE=1" "-DKB_TAKE=2" "-DKB_TAKE=4"; do
   SGNN_HIPCC_FLAGS="$flags" python -m subgnn_amd.build --force > /dev/null 2>&1
   echo "$flags: $(python tools/khop_probe.py 2>&1 | grep -v amdgpu.ids | grep 'count-only, LDS\|43 slots' | tr '\n' ' ')"
 done
