@@ -510,7 +510,7 @@ def _unique_rows(rows):
     return rows[is_rep], gid[rep]
 
 
-def dtw_similarity(x_ptr, x_val, max_x, y_ptr, y_val, max_y, tie_order=0, order_rows=True, dedupe=True):
+def dtw_similarity(x_ptr, x_val, max_x, y_ptr, y_val, max_y, tie_order=0, order_rows=True, dedupe=True, order=None):
     """1/(1+fastdtw) for all (x row, y row) pairs -> (n_x, n_y) float32; empty x rows -> PAD.
     ``dedupe``: identical x rows (sorted degree sequences of small components repeat a lot: 50k BFS
     components of the benchmark have 2.7k distinct internal sequences) are computed once and the
@@ -531,7 +531,7 @@ def dtw_similarity(x_ptr, x_val, max_x, y_ptr, y_val, max_y, tie_order=0, order_
         dst = torch.where(j < lens.view(-1, 1), uptr[:-1].view(-1, 1) + j, x_val.numel())   # dropped entries -> spare slot
         uval = torch.zeros(x_val.numel() + 1, dtype=torch.int32, device=x_ptr.device)
         uval.scatter_(0, dst.reshape(-1), rows.reshape(-1))
-        out_u = dtw_similarity(uptr, uval, max_x, y_ptr, y_val, max_y, tie_order, order_rows, dedupe=False)
+        out_u = dtw_similarity(uptr, uval, max_x, y_ptr, y_val, max_y, tie_order, order_rows, dedupe=False, order=order)
         return out_u.index_select(0, rep)
     lib = _lib.load()
     for t, nm in ((x_ptr, 'x_ptr'), (y_ptr, 'y_ptr')):
@@ -540,8 +540,9 @@ def dtw_similarity(x_ptr, x_val, max_x, y_ptr, y_val, max_y, tie_order=0, order_
         _req(t, torch.int32, nm)
     nx, ny = x_ptr.numel() - 1, y_ptr.numel() - 1
     out = torch.empty((nx, ny), dtype=torch.float32, device=x_ptr.device)
-    order = None
-    if order_rows and nx > 64:
+    if order is not None:                                   # caller's processing order (tuning)
+        order = order.to(torch.int32).contiguous()
+    elif order_rows and nx > 64:
         lens = x_ptr[1:] - x_ptr[:-1]
         csum = torch.zeros(x_val.numel() + 1, dtype=torch.int64, device=x_val.device)
         torch.cumsum(x_val, 0, out=csum[1:])

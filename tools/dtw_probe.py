@@ -38,3 +38,31 @@ print('to_padded', _t(lambda: ops.Ragged(sets.ptr, ce, max_len=NX).to_padded(wid
 print('_unique_rows', _t(lambda: ops._unique_rows(rows)))
 print('call without dedupe', _t(lambda: ops.dtw_similarity(sets.ptr, ce, NX, a_sets.ptr, ae, 50, dedupe=False)))
 print('call without dedupe/order', _t(lambda: ops.dtw_similarity(sets.ptr, ce, NX, a_sets.ptr, ae, 50, dedupe=False, order_rows=False)))
+
+# ---- processing orders of the x rows (external side): how much does grouping similar series buy? ----
+if len(sys.argv) > 3 and sys.argv[3] == 'orders':
+    R = rows.long()
+    lens = (R >= 0).sum(1)
+    Rz = R.clamp(min=0)
+    def lex(cols):
+        o = torch.arange(R.shape[0], device=dev)
+        for c in reversed(cols):                     # least significant first, stable
+            o = o[torch.sort(Rz[o, c], stable=True).indices]
+        return o
+    half = NX // 2
+    cands = {
+        'default (len, median, sum)': None,
+        'random': torch.randperm(R.shape[0], device=dev),
+        'identity': torch.arange(R.shape[0], device=dev),
+        'lex first->last': lex(list(range(NX))),
+        'lex last->first': lex(list(range(NX - 1, -1, -1))),
+        'len, then lex last->first': None,
+        'sum': torch.argsort(Rz.sum(1)),
+        'len, max, sum': torch.argsort((lens << 50) | (Rz.max(1).values.clamp(max=(1 << 24) - 1) << 26) | Rz.sum(1).clamp(max=(1 << 26) - 1)),
+        'quartile sums': torch.argsort((Rz[:, 3 * NX // 4:].sum(1).clamp(max=(1 << 20) - 1) << 40) | (Rz[:, NX // 2:3 * NX // 4].sum(1).clamp(max=(1 << 20) - 1) << 20) | Rz[:, :NX // 2].sum(1).clamp(max=(1 << 20) - 1)),
+    }
+    o = lex(list(range(NX - 1, -1, -1)))
+    cands['len, then lex last->first'] = o[torch.sort(lens[o], stable=True).indices]
+    for name, o in cands.items():
+        f = lambda: ops.dtw_similarity(sets.ptr, ce, NX, a_sets.ptr, ae, 50, dedupe=False, order=o)
+        print('%-32s %8.3f ms' % (name, _t(f, 3)))
