@@ -514,7 +514,7 @@ def dtw_similarity(x_ptr, x_val, max_x, y_ptr, y_val, max_y, tie_order=0, order_
     """1/(1+fastdtw) for all (x row, y row) pairs -> (n_x, n_y) float32; empty x rows -> PAD.
     ``dedupe``: identical x rows (sorted degree sequences of small components repeat a lot: 50k BFS
     components of the benchmark have 2.7k distinct internal sequences) are computed once and the
-    result rows gathered back.  ``order_rows``: process the x rows sorted by (length, median, sum) so
+    result rows gathered back.  ``order_rows``: process the x rows sorted by (length, four quantiles) so
     that the lanes of a wavefront work on similar series.  Neither changes any value."""
     if dedupe and x_ptr.numel() - 1 > 1024 and max_x <= 64:
         # no host round trip: every row keeps its slot, the rows that repeat an earlier one are given
@@ -544,14 +544,19 @@ def dtw_similarity(x_ptr, x_val, max_x, y_ptr, y_val, max_y, tie_order=0, order_
         order = order.to(torch.int32).contiguous()
     elif order_rows and nx > 64:
         lens = x_ptr[1:] - x_ptr[:-1]
-        csum = torch.zeros(x_val.numel() + 1, dtype=torch.int64, device=x_val.device)
-        torch.cumsum(x_val, 0, out=csum[1:])
-        sums = csum[x_ptr[1:]] - csum[x_ptr[:-1]]
-        med = x_val[(x_ptr[:-1] + lens // 2).clamp(max=x_val.numel() - 1)].long() * (lens > 0)
-        # (length, median, sum): rows are sorted degree sequences, the median places the bulk of the
-        # series and the sum breaks ties -- packed into one int64 key (16 | 24 | 23 bits, saturating),
-        # no host round trip
-        key = (lens.clamp(max=0xFFFF) << 47) | (med.long().clamp(max=0xFFFFFF) << 23) | sums.long().clamp(max=0x7FFFFF)
+        last = x_val.numel() - 1
+        live = lens > 0
+
+        def at(off):
+            return x_val[(x_ptr[:-1] + off).clamp(max=last)].long() * live
+
+        # (length, then the series sampled at its start, thirds and end): rows are sorted degree
+        # sequences, four quantiles place a series' shape well enough that the lanes of a wavefront
+        # sweep similar windows -- packed into one int64 key (12 | 12 | 12 | 13 | 14 bits, saturating),
+        # no host round trip.  Measured on the benchmark's external side: unordered 8.9 ms,
+        # (length, median, sum) 8.1 ms, this key 7.5 ms, full lexicographic order 7.9 ms.
+        key = ((lens.clamp(max=0xFFF) << 51) | (at(0).clamp(max=0xFFF) << 39) | (at(lens // 3).clamp(max=0xFFF) << 27)
+               | (at((2 * lens) // 3).clamp(max=0x1FFF) << 14) | at((lens - 1).clamp(min=0)).clamp(max=0x3FFF))
         order = torch.argsort(key).to(torch.int32).contiguous()
     wsb = lib.sgnn_dtw_workspace_bytes(nx, max_x, ny, max_y)
     ws = torch.empty(wsb // 8 + 1, dtype=torch.int64, device=x_ptr.device)

@@ -61,6 +61,23 @@ if len(sys.argv) > 3 and sys.argv[3] == 'orders':
         'len, max, sum': torch.argsort((lens << 50) | (Rz.max(1).values.clamp(max=(1 << 24) - 1) << 26) | Rz.sum(1).clamp(max=(1 << 26) - 1)),
         'quartile sums': torch.argsort((Rz[:, 3 * NX // 4:].sum(1).clamp(max=(1 << 20) - 1) << 40) | (Rz[:, NX // 2:3 * NX // 4].sum(1).clamp(max=(1 << 20) - 1) << 20) | Rz[:, :NX // 2].sum(1).clamp(max=(1 << 20) - 1)),
     }
+    c16 = lambda c: Rz[:, c].clamp(max=0xFFFF)
+    cands['first 4 packed'] = torch.argsort((c16(0) << 48) | (c16(1) << 32) | (c16(2) << 16) | c16(3))
+    cands['x0, x1, median, sum'] = torch.argsort((Rz[:, 0].clamp(max=0xFFF) << 52) | (Rz[:, 1].clamp(max=0xFFF) << 40) | (Rz[:, NX // 2].clamp(max=0xFFFF) << 24) | Rz.sum(1).clamp(max=(1 << 24) - 1))
+    cands['x0, x4, x8, x12 packed'] = torch.argsort((c16(0) << 48) | (c16(NX // 5) << 32) | (c16(2 * NX // 5) << 16) | c16(3 * NX // 5))
+    cands['median, x0, sum'] = torch.argsort((Rz[:, NX // 2].clamp(max=0xFFFF) << 40) | (Rz[:, 0].clamp(max=0xFFF) << 28) | Rz.sum(1).clamp(max=(1 << 28) - 1))
+    def packed(pos, bits):
+        k = torch.zeros(R.shape[0], dtype=torch.int64, device=dev)
+        for c in pos:
+            k = (k << bits) | Rz[:, min(c, NX - 1)].clamp(max=(1 << bits) - 1)
+        return torch.argsort(k)
+    cands['B q(0,1/4,1/2,3/4) x16'] = packed([0, NX // 4, NX // 2, 3 * NX // 4], 16)
+    cands['C q(1/5..4/5) x16'] = packed([NX // 5, 2 * NX // 5, 3 * NX // 5, 4 * NX // 5], 16)
+    cands['D q(0..4/5) x12'] = packed([0, NX // 5, 2 * NX // 5, 3 * NX // 5, 4 * NX // 5], 12)
+    cands['E q(1/2,1/4,3/4,0) x16'] = packed([NX // 2, NX // 4, 3 * NX // 4, 0], 16)
+    cands['F q(0,1/3,2/3,last) x16'] = packed([0, NX // 3, 2 * NX // 3, NX - 1], 16)
+    cands['G 6 quantiles x10'] = packed([0, NX // 6, 2 * NX // 6, 3 * NX // 6, 4 * NX // 6, 5 * NX // 6], 10)
+    cands['H q(0,1/5,2/5) x16 + sum'] = torch.argsort((c16(0) << 48) | (c16(NX // 5) << 36) | (Rz[:, 2 * NX // 5].clamp(max=0xFFF) << 24) | Rz.sum(1).clamp(max=(1 << 24) - 1))
     o = lex(list(range(NX - 1, -1, -1)))
     cands['len, then lex last->first'] = o[torch.sort(lens[o], stable=True).indices]
     for name, o in cands.items():
