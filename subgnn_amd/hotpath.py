@@ -208,10 +208,18 @@ def prepare_sparse(model, split='train', timer=None):
     setattr(model, split + '_N_border', None)
     if hp['use_structure']:
         mx, my = max(cc_sets.max_len, 1), max(a_sets.max_len, 1)
+        # Grouping repeated component sequences pays on the internal side (2.7k distinct rows among the
+        # benchmark's 50k) and is pure overhead on the external side (nearly all distinct).  Which it is
+        # depends only on the split's components and the graph: decided on the first pass, kept.
+        group = model.__dict__.setdefault('_dtw_group_rows', {})
+        if group.get(split) is None or group[split][0] != cc_sets.n:
+            group[split] = (cc_sets.n, ops.distinct_row_fraction(cc_sets.ptr, ci, mx) <= 0.5,
+                            ops.distinct_row_fraction(cc_sets.ptr, ce, mx) <= 0.5)
+            t.mark('dtw_row_grouping_decision(first pass only)')
         setattr(model, split + '_int_struc_similarities',
-                ops.dtw_similarity(cc_sets.ptr, ci, mx, a_sets.ptr, ai, my).view(S, C, -1))
+                ops.dtw_similarity(cc_sets.ptr, ci, mx, a_sets.ptr, ai, my, dedupe=group[split][1]).view(S, C, -1))
         setattr(model, split + '_bor_struc_similarities',
-                ops.dtw_similarity(cc_sets.ptr, ce, mx, a_sets.ptr, ae, my).view(S, C, -1))
+                ops.dtw_similarity(cc_sets.ptr, ce, mx, a_sets.ptr, ae, my, dedupe=group[split][2]).view(S, C, -1))
         t.mark('dtw')
     else:
         setattr(model, split + '_int_struc_similarities', None)

@@ -510,6 +510,18 @@ def _unique_rows(rows):
     return rows[is_rep], gid[rep]
 
 
+def distinct_row_fraction(x_ptr, x_val, max_x):
+    """Share of the x rows that are distinct (one host round trip): what decides whether grouping
+    repeated rows before the DTW pays.  A property of the split's components and the graph -- callers
+    that run the same rows every pass (hotpath.prepare_sparse) ask once and keep the answer."""
+    n = x_ptr.numel() - 1
+    if n <= 1024 or max_x > 64:
+        return 1.0
+    rows = Ragged(x_ptr, x_val, max_len=max_x).to_padded(width=max_x, fill=-1, dtype=torch.int32)
+    rep = _row_representatives(rows)
+    return float((rep == torch.arange(n, device=rows.device)).sum().item()) / n
+
+
 def dtw_similarity(x_ptr, x_val, max_x, y_ptr, y_val, max_y, tie_order=0, order_rows=True, dedupe=True, order=None):
     """1/(1+fastdtw) for all (x row, y row) pairs -> (n_x, n_y) float32; empty x rows -> PAD.
     ``dedupe``: identical x rows (sorted degree sequences of small components repeat a lot: 50k BFS

@@ -78,6 +78,23 @@ if len(sys.argv) > 3 and sys.argv[3] == 'orders':
     cands['F q(0,1/3,2/3,last) x16'] = packed([0, NX // 3, 2 * NX // 3, NX - 1], 16)
     cands['G 6 quantiles x10'] = packed([0, NX // 6, 2 * NX // 6, 3 * NX // 6, 4 * NX // 6, 5 * NX // 6], 10)
     cands['H q(0,1/5,2/5) x16 + sum'] = torch.argsort((c16(0) << 48) | (c16(NX // 5) << 36) | (Rz[:, 2 * NX // 5].clamp(max=0xFFF) << 24) | Rz.sum(1).clamp(max=(1 << 24) - 1))
+    def morton(fields, bits):
+        k = torch.zeros(R.shape[0], dtype=torch.int64, device=dev)
+        for b in range(bits - 1, -1, -1):
+            for f in fields:
+                k = (k << 1) | ((f >> b) & 1)
+        return torch.argsort(k)
+    qpos = [0, NX // 3, 2 * NX // 3, NX - 1]
+    lin = [Rz[:, c].clamp(max=4095) for c in qpos]
+    lg = [(8 * torch.log2(1.0 + Rz[:, c].double())).long().clamp(max=127) for c in qpos]
+    cands['morton 4 quantiles x12 (linear)'] = morton(lin, 12)
+    cands['morton 4 quantiles x7 (log)'] = morton(lg, 7)
+    k = torch.zeros(R.shape[0], dtype=torch.int64, device=dev)
+    for f in lg:
+        k = (k << 7) | f
+    cands['packed 4 quantiles x7 (log)'] = torch.argsort(k)
+    lg6 = [(8 * torch.log2(1.0 + Rz[:, c].double())).long().clamp(max=127) for c in [0, NX // 5, 2 * NX // 5, 3 * NX // 5, 4 * NX // 5, NX - 1]]
+    cands['morton 6 quantiles x7 (log)'] = morton(lg6, 7)
     o = lex(list(range(NX - 1, -1, -1)))
     cands['len, then lex last->first'] = o[torch.sort(lens[o], stable=True).indices]
     for name, o in cands.items():
