@@ -257,6 +257,15 @@ int sgnn_dtw_similarity(const int64_t* x_ptr, const int32_t* x_val, int64_t n_x,
                         const int64_t* y_ptr, const int32_t* y_val, int64_t n_y, int64_t max_y_len,
                         int tie_order, const int32_t* x_order, float* out, void* workspace,
                         int64_t workspace_bytes, void* stream);
+/* Same, for callers whose x rows are mostly empty (repeated rows given length 0 by a grouping step):
+ * x_live_range (device, int64[2] = {first, count}, nullable) names the positions of the processing
+ * order x_order that hold the non-empty rows -- x_order must list the empty rows first -- and only those
+ * are computed; the caller zero-fills (PAD) the output beforehand.  The range lives on the device so
+ * that no host round trip is needed to learn it. */
+int sgnn_dtw_similarity_live(const int64_t* x_ptr, const int32_t* x_val, int64_t n_x, int64_t max_x_len,
+                             const int64_t* y_ptr, const int32_t* y_val, int64_t n_y, int64_t max_y_len,
+                             int tie_order, const int32_t* x_order, const int64_t* x_live_range, float* out,
+                             void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * a12  CC embedding initialisation: sum or max of member node embeddings.

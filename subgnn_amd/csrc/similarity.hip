@@ -1012,7 +1012,8 @@ template <int RMAX, int TIE, int MINB, bool WLDS>
 __global__ __launch_bounds__(DTW_THREADS, MINB) void dtw_similarity_reg_kernel(
     const double* __restrict__ xpyr, const int32_t* __restrict__ xlen, int64_t n_x,
     const double* __restrict__ ypyr, const int32_t* __restrict__ ylen, int64_t n_y,
-    float* __restrict__ out, uint64_t* __restrict__ wq, DtwLayout L, const int32_t* __restrict__ x_order)
+    float* __restrict__ out, uint64_t* __restrict__ wq, DtwLayout L, const int32_t* __restrict__ x_order,
+    const int64_t* __restrict__ x_live)
 {
     __shared__ int32_t s_fl[RMAX * DTW_THREADS];
     __shared__ int32_t s_ublk[(DTW_THREADS / 64) * 16];                   // per wavefront: union block ranges
@@ -1021,12 +1022,17 @@ __global__ __launch_bounds__(DTW_THREADS, MINB) void dtw_similarity_reg_kernel(
     uint32_t* wl = s_words + threadIdx.x;
     const int64_t NT = (int64_t)gridDim.x * blockDim.x;
     const int64_t tid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    const int64_t total = n_x * n_y;
+    // x_live = {first, count}: only these positions of the processing order hold non-empty rows (the caller
+    // sorted the empty ones to the front and zeroed their output rows) -- the pairs are then dealt out over
+    // the live rows only; with thousands of empty rows in front the lanes' shares were very uneven
+    const int64_t first_live = x_live ? x_live[0] : 0;
+    const int64_t n_live = x_live ? x_live[1] : n_x;
+    const int64_t total = n_live * n_y;
     for (int64_t pair = tid; pair < total; pair += NT) {
         // consecutive lanes: same anchor, consecutive components of the caller's processing order
         // (similar series side by side keep the lanes' windows aligned)
-        const int64_t a = pair / n_x;
-        const int64_t pos = pair % n_x;                                    // position in the processing order:
+        const int64_t a = pair / n_live;
+        const int64_t pos = first_live + pair % n_live;                    // position in the processing order:
         const int64_t r = x_order ? x_order[pos] : pos;                    // the pyramids are laid out by position
         const int lx0 = xlen[pos], ly0 = ylen[a];
         if (lx0 == 0 || ly0 == 0) { out[r * n_y + a] = 0.f; continue; }
@@ -1067,10 +1073,10 @@ static int g_dtw_force_general = 0;
 /* test hook: 1 = always take the general (workspace-resident) kernel, 0 = pick by size */
 extern "C" int sgnn_dtw_force_general(int on) { const int old = g_dtw_force_general; g_dtw_force_general = on; return old; }
 
-extern "C" int sgnn_dtw_similarity(const int64_t* x_ptr, const int32_t* x_val, int64_t n_x, int64_t max_x_len,
-                                   const int64_t* y_ptr, const int32_t* y_val, int64_t n_y, int64_t max_y_len,
-                                   int tie_order, const int32_t* x_order, float* out, void* workspace,
-                                   int64_t workspace_bytes, void* stream)
+static int dtw_run(const int64_t* x_ptr, const int32_t* x_val, int64_t n_x, int64_t max_x_len,
+                   const int64_t* y_ptr, const int32_t* y_val, int64_t n_y, int64_t max_y_len,
+                   int tie_order, const int32_t* x_order, const int64_t* x_live, float* out, void* workspace,
+                   int64_t workspace_bytes, void* stream)
 {
     if (!x_ptr || !x_val || !y_ptr || !y_val || !out || !workspace || n_x < 0 || n_y < 0) return SGNN_ERR_BAD_ARG;
     if (tie_order < 0 || tie_order > 1) return SGNN_ERR_BAD_ARG;
@@ -1107,7 +1113,7 @@ extern "C" int sgnn_dtw_similarity(const int64_t* x_ptr, const int32_t* x_val, i
         const size_t dyn = wlds ? (size_t)((words > 0 ? words : 1) * DTW_THREADS * 4) : 0;
 #define DTW_LAUNCH2(RMAX, TIE, MINB, WL) \
         hipLaunchKernelGGL((dtw_similarity_reg_kernel<RMAX, TIE, MINB, WL>), dim3(DTW_REG_BLOCKS), dim3(DTW_THREADS), dyn, st, \
-                           xpyr, xlen, n_x, ypyr, ylen, n_y, out, wq, L, x_order)
+                           xpyr, xlen, n_x, ypyr, ylen, n_y, out, wq, L, x_order, x_live)
 #define DTW_LAUNCH(RMAX, TIE, MINB) do { if (wlds) DTW_LAUNCH2(RMAX, TIE, MINB, true); else DTW_LAUNCH2(RMAX, TIE, MINB, false); } while (0)
         if (max_x_len <= 12) { if (tie_order == 0) DTW_LAUNCH(12, 0, DTW_MINB12); else DTW_LAUNCH(12, 1, DTW_MINB12); }
         else if (max_x_len <= 20) { if (tie_order == 0) DTW_LAUNCH(20, 0, DTW_MINB20); else DTW_LAUNCH(20, 1, DTW_MINB20); }
@@ -1120,4 +1126,23 @@ extern "C" int sgnn_dtw_similarity(const int64_t* x_ptr, const int32_t* x_val, i
     }
     SGNN_CHECK_LAUNCH();
     return SGNN_OK;
+}
+
+extern "C" int sgnn_dtw_similarity(const int64_t* x_ptr, const int32_t* x_val, int64_t n_x, int64_t max_x_len,
+                                   const int64_t* y_ptr, const int32_t* y_val, int64_t n_y, int64_t max_y_len,
+                                   int tie_order, const int32_t* x_order, float* out, void* workspace,
+                                   int64_t workspace_bytes, void* stream)
+{
+    return dtw_run(x_ptr, x_val, n_x, max_x_len, y_ptr, y_val, n_y, max_y_len, tie_order, x_order, nullptr, out, workspace,
+                   workspace_bytes, stream);
+}
+
+extern "C" int sgnn_dtw_similarity_live(const int64_t* x_ptr, const int32_t* x_val, int64_t n_x, int64_t max_x_len,
+                                        const int64_t* y_ptr, const int32_t* y_val, int64_t n_y, int64_t max_y_len,
+                                        int tie_order, const int32_t* x_order, const int64_t* x_live_range, float* out,
+                                        void* workspace, int64_t workspace_bytes, void* stream)
+{
+    if (x_live_range && !x_order) return SGNN_ERR_BAD_ARG;
+    return dtw_run(x_ptr, x_val, n_x, max_x_len, y_ptr, y_val, n_y, max_y_len, tie_order, x_order, x_live_range, out,
+                   workspace, workspace_bytes, stream);
 }

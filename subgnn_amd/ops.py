@@ -522,7 +522,8 @@ def distinct_row_fraction(x_ptr, x_val, max_x):
     return float((rep == torch.arange(n, device=rows.device)).sum().item()) / n
 
 
-def dtw_similarity(x_ptr, x_val, max_x, y_ptr, y_val, max_y, tie_order=0, order_rows=True, dedupe=True, order=None):
+def dtw_similarity(x_ptr, x_val, max_x, y_ptr, y_val, max_y, tie_order=0, order_rows=True, dedupe=True, order=None,
+                   _live=None):
     """1/(1+fastdtw) for all (x row, y row) pairs -> (n_x, n_y) float32; empty x rows -> PAD.
     ``dedupe``: identical x rows (sorted degree sequences of small components repeat a lot: 50k BFS
     components of the benchmark have 2.7k distinct internal sequences) are computed once and the
@@ -543,7 +544,14 @@ def dtw_similarity(x_ptr, x_val, max_x, y_ptr, y_val, max_y, tie_order=0, order_
         dst = torch.where(j < lens.view(-1, 1), uptr[:-1].view(-1, 1) + j, x_val.numel())   # dropped entries -> spare slot
         uval = torch.zeros(x_val.numel() + 1, dtype=torch.int32, device=x_ptr.device)
         uval.scatter_(0, dst.reshape(-1), rows.reshape(-1))
-        out_u = dtw_similarity(uptr, uval, max_x, y_ptr, y_val, max_y, tie_order, order_rows, dedupe=False, order=order)
+        live = None
+        if order is None and order_rows:
+            # the length-first processing order puts the emptied rows in front: hand the kernel the live
+            # range (a device-side pair, no round trip) so that it deals its lanes over the live rows only
+            n_live = (lens > 0).sum()
+            live = torch.stack((n - n_live, n_live))
+        out_u = dtw_similarity(uptr, uval, max_x, y_ptr, y_val, max_y, tie_order, order_rows, dedupe=False, order=order,
+                               _live=live)
         return out_u.index_select(0, rep)
     lib = _lib.load()
     for t, nm in ((x_ptr, 'x_ptr'), (y_ptr, 'y_ptr')):
@@ -551,7 +559,7 @@ def dtw_similarity(x_ptr, x_val, max_x, y_ptr, y_val, max_y, tie_order=0, order_
     for t, nm in ((x_val, 'x_val'), (y_val, 'y_val')):
         _req(t, torch.int32, nm)
     nx, ny = x_ptr.numel() - 1, y_ptr.numel() - 1
-    out = torch.empty((nx, ny), dtype=torch.float32, device=x_ptr.device)
+    out = (torch.empty if _live is None else torch.zeros)((nx, ny), dtype=torch.float32, device=x_ptr.device)
     if order is not None:                                   # caller's processing order (tuning)
         order = order.to(torch.int32).contiguous()
     elif order_rows and nx > 64:
@@ -572,6 +580,11 @@ def dtw_similarity(x_ptr, x_val, max_x, y_ptr, y_val, max_y, tie_order=0, order_
         order = torch.argsort(key).to(torch.int32).contiguous()
     wsb = lib.sgnn_dtw_workspace_bytes(nx, max_x, ny, max_y)
     ws = torch.empty(wsb // 8 + 1, dtype=torch.int64, device=x_ptr.device)
+    if _live is not None and order is not None:
+        check(lib.sgnn_dtw_similarity_live(_ptr(x_ptr), _ptr(x_val), nx, max_x, _ptr(y_ptr), _ptr(y_val), ny, max_y,
+                                           tie_order, _ptr(order), _ptr(_live), _ptr(out), _ptr(ws), wsb, _stream()),
+              'sgnn_dtw_similarity_live')
+        return out
     check(lib.sgnn_dtw_similarity(_ptr(x_ptr), _ptr(x_val), nx, max_x, _ptr(y_ptr), _ptr(y_val), ny, max_y, tie_order,
                                   _ptr(order), _ptr(out), _ptr(ws), wsb, _stream()), 'sgnn_dtw_similarity')
     return out
