@@ -13,9 +13,10 @@ idx = [i for i, r in enumerate(rows) if 'cc_labels_kernel' in r['Kernel_Name']]
 p = rows[idx[-2]:idx[-1]]
 ours = ('cc_labels', 'cc_compact', 'cc_embed', 'choice_ragged', 'msbfs', 'triangular', 'degseq', 'khop', 'dtw_', 'mpn_',
         'masked_sum', 'sample_anchors', 'patch_in_border', 'attn_scores', 'sp_sim', 'min_hops', 'sort_sets')
-marks = [('msbfs_init', 'position'), ('triangular_walks', 'walks'), ('sort_sets', 'border'), ('khop_border', 'border'),
-         ('degseq_wave_kernel<true, false>', 'degseq+dtw_prep'), ('dtw_pyramid', 'dtw'), ('cc_embed_fwd_kernel', 'fwd+bwd+opt')]
-order = ['components', 'position', 'walks', 'border', 'degseq+dtw_prep', 'dtw', 'fwd+bwd+opt']
+marks = [('triangular_walks', 'patches'), ('msbfs_init', 'position'), ('triangular_walks', 'walks'), ('sort_sets', 'border'),
+         ('khop_border', 'border'), ('degseq_wave_kernel<true, false>', 'degseq+dtw_prep'), ('dtw_pyramid', 'dtw'),
+         ('cc_embed_fwd_kernel', 'fwd+bwd+opt')]
+order = ['components', 'patches', 'position', 'walks', 'border', 'degseq+dtw_prep', 'dtw', 'fwd+bwd+opt']
 stage = 'components'
 tot = collections.defaultdict(lambda: [0.0, 0.0, 0, 0])
 names = collections.defaultdict(collections.Counter)
@@ -24,10 +25,12 @@ big = []
 for r in p:
     n = r['Kernel_Name']
     for m, s in marks:
-        if m in n and order.index(s) >= order.index(stage):
-            if s == 'fwd+bwd+opt' and stage != 'dtw':
-                continue
+        if m in n and order.index(s) == order.index(stage) + 1:          # stages follow each other in this order
             stage = s
+            break
+        if m in n and s in ('border',) and order.index(s) > order.index(stage):
+            stage = s
+            break
     d = (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
     o = any(k in n for k in ours)
     tot[stage][0 if o else 1] += d
