@@ -148,8 +148,11 @@ __device__ __forceinline__ void ds_count(const int32_t* __restrict__ col, const 
 
 // FEW: instantiation taken by launches over a handful of sets (the anchor patches: a few hundred);
 // same code -- it only keeps those microsecond launches apart from the shard-sized ones in profiles.
+#ifndef DS_MIN_WAVES
+#define DS_MIN_WAVES 5         // wavefronts per SIMD the register allocation aims for (86 VGPRs -> 5); 4 / 5 / 6 / 7 / 8 measured 0.392 / 0.391 / 0.396 / 0.398 / 0.401 ms: not occupancy-bound
+#endif
 template <bool SORTED, bool FEW = false>
-__global__ __launch_bounds__(64 * DS_WAVES) void degseq_wave_kernel(
+__global__ __launch_bounds__(64 * DS_WAVES) __attribute__((amdgpu_waves_per_eu(DS_MIN_WAVES))) void degseq_wave_kernel(
     const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
     const int32_t* __restrict__ full_degree, const uint8_t* __restrict__ self_loops,
     const int64_t* __restrict__ set_ptr, const int32_t* __restrict__ set_nodes, int64_t n_sets,
