@@ -76,14 +76,19 @@ __device__ __forceinline__ void ds_count(const int32_t* __restrict__ col, const 
         big &= big - 1;
         const int32_t m_v = __shfl(v, m), m_deg = __shfl(deg, m);
         const int32_t* __restrict__ list = col + __shfl(r0, m);
-        int32_t local = 0, selfl = 0;
+        // hits are counted per 64-entry chunk with ballot + scalar popcount: the running totals live in
+        // scalar registers and no wave reduction is needed at the end of a list
+        int32_t tot = 0, st = 0;
         int32_t base = 0;
         for (; base + 512 <= m_deg; base += 512) {       // full blocks: 8 x 256 B loads in flight
             int32_t u[8];
 #pragma unroll
             for (int q = 0; q < 8; ++q) u[q] = list[base + q * 64 + lane];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) { local += ds_probe<P1>(hash, u[q], k24, P); if (SELF) selfl += (u[q] == m_v); }
+            for (int q = 0; q < 8; ++q) {
+                tot += (int32_t)__popcll(__ballot(ds_probe<P1>(hash, u[q], k24, P) != 0));
+                if (SELF) st += (int32_t)__popcll(__ballot(u[q] == m_v));
+            }
         }
         if (base < m_deg) {                              // tail (< 512 entries): clamped loads,
             const int32_t last = m_deg - 1;              // out-of-range lanes get the never-stored key -1
@@ -96,10 +101,11 @@ __device__ __forceinline__ void ds_count(const int32_t* __restrict__ col, const 
             }
 #pragma unroll
             for (int q = 0; q < 8; ++q)
-                if (base + q * 64 < m_deg) { local += ds_probe<P1>(hash, u[q], k24, P); if (SELF) selfl += (u[q] == m_v); }   // wave-uniform
+                if (base + q * 64 < m_deg) {                                                   // wave-uniform
+                    tot += (int32_t)__popcll(__ballot(ds_probe<P1>(hash, u[q], k24, P) != 0));
+                    if (SELF) st += (int32_t)__popcll(__ballot(u[q] == m_v));
+                }
         }
-        const int32_t st = SELF ? ds_wave_sum(selfl) : 0;
-        const int32_t tot = ds_wave_sum(local);
         if (lane == m) { cnt = tot; if (SELF) selfc = st; }
     }
     // ---- phase B: the remaining lists as one flat range, 128 entries per step ------------
@@ -148,6 +154,9 @@ __device__ __forceinline__ void ds_count(const int32_t* __restrict__ col, const 
 
 // FEW: instantiation taken by launches over a handful of sets (the anchor patches: a few hundred);
 // same code -- it only keeps those microsecond launches apart from the shard-sized ones in profiles.
+#ifndef DS_GRID_CAP
+#define DS_GRID_CAP (1 << 20)    // workgroups of the wave kernel: one set each up to this many, grid-stride beyond (50k / 25k / 16k / 8k / 5k workgroups for 50k sets: 0.395 / 0.406 / 0.423 / 0.467 / 0.537 ms -- finer is better)
+#endif
 #ifndef DS_MIN_WAVES
 #define DS_MIN_WAVES 5         // wavefronts per SIMD the register allocation aims for (86 VGPRs -> 5); 4 / 5 / 6 / 7 / 8 measured 0.392 / 0.391 / 0.396 / 0.398 / 0.401 ms: not occupancy-bound
 #endif
@@ -382,7 +391,7 @@ extern "C" int sgnn_degree_sequence(const int64_t* rowptr, const int32_t* col, i
     // dispatcher hands out workgroups as CUs free up, which balances the very uneven per-set
     // cost (sum of member degrees) better than a static grid-stride assignment
     const int64_t want = (n_sets + DS_WAVES - 1) / DS_WAVES;
-    const int grid = (int)(want < (1 << 20) ? want : (1 << 20));
+    const int grid = (int)(want < DS_GRID_CAP ? want : DS_GRID_CAP);
     const bool few = n_sets <= 4096;
 #define DS_LAUNCH(S, F) hipLaunchKernelGGL((degseq_wave_kernel<S, F>), dim3(grid), dim3(64 * DS_WAVES), 0, st, rowptr, col, \
                                            full_degree, self_loops, set_ptr, set_nodes, n_sets, out_internal, out_external, set_order)
