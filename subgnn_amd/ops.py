@@ -989,7 +989,7 @@ class _BiLSTMLayer(torch.autograd.Function):
         # weight gradient: one batched GEMM over all (sequence, step) rows, per direction
         dg = dgates.view(2, B * T, 4 * H)
         dw = torch.bmm(dg.transpose(1, 2), xh.view(2, B * T, I + H))
-        db = dg.sum(dim=1)
+        db = torch.bmm(torch.ones((2, 1, B * T), dtype=dg.dtype, device=dg.device), dg).view(2, 4 * H)   # column sums as a GEMM: torch's reduction over the long dimension of (2, B*T, 4H) takes 30 us
         return (dx, dw[0, :, :I], dw[0, :, I:], db[0], db[0], dw[1, :, :I], dw[1, :, I:], db[1], db[1])
 
 
