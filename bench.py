@@ -216,13 +216,14 @@ def main():
     achieved = alg_bytes / (ds_ms * 1e-3) / 1e9
 
     traffic, traffic_src = None, None
-    tf = os.path.join(REPO, 'profiles', 'r01z_degseq_traffic.json')
+    tname = 'r01_final_degseq_traffic.json'
+    tf = os.path.join(REPO, 'profiles', tname)
     if os.path.exists(tf) and args.nodes == 1_000_000 and S == 50_000:
         # PMC passes cannot run inside this process; this is the committed rocprofv3 measurement of
         # the same launch (same graph seed, same 50k sets): raw FETCH_SIZE + WRITE_SIZE bytes
         with open(tf) as f:
             tj = json.load(f)
-        traffic, traffic_src = tj['hbm_bytes_per_launch_raw'], 'profiles/r01z_degseq_traffic.json (rocprofv3 --pmc, separate passes)'
+        traffic, traffic_src = tj['hbm_bytes_per_launch_raw'], 'profiles/%s (rocprofv3 --pmc, separate passes)' % tname
     result = {
         'metric': 'subgraphs/sec fwd+bwd (all 3 channels on) + achieved HBM GB/s',
         'value': world * S * args.steps / elapsed, 'unit': 'subgraphs/s', 'n_gpus': world, 'steps': args.steps,
