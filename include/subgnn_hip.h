@@ -347,28 +347,29 @@ int sgnn_attn_scores_fwd(const float* X, const float* U, const float* qW, const 
                          int64_t R, int64_t H, int64_t rows_per_batch, float* out, void* stream);
 
 /* ---------------------------------------------------------------------------------------
- * a14 (walk aggregator)  One bidirectional LSTM layer, whole sequence per launch.
+ * a14 (walk aggregator)  The recurrence of one bidirectional LSTM layer, whole sequence per launch.
  * Replaces the nn.LSTM(bidirectional=True, batch_first=True) inside the reference's LSTM module
  * (SubGNN/SubGNN.py:60-88) as called by aggregate_structure_anchor_patch
  * (SubGNN/anchor_patch_samplers.py:413-433) on (patches x walks, walk_len, D).  h0 = c0 = 0.
- *   x      (B, T, I)            inputs
- *   wcat   (2, 4H, I + H)       per direction [weight_ih | weight_hh], gate rows i, f, g, o (torch order)
- *   bias   (2, 4H)              bias_ih + bias_hh
- *   y      (B, T, 2H)           [forward h_t | reverse h_t]  (torch's output layout)
- *   gates  (2, B, T, 4H), cell (2, B, T, H)   activations kept for the backward pass
- *   xh     (2, B, T, I + H)     [x_t | h_{t-1}] per direction, kept for the weight gradient
- * backward: dy (B, T, 2H) -> gate gradients dgates (2, B, T, 4H) written, dx (B, T, I) ACCUMULATED (the
- * two directions add into it: zero it first).  The weight gradient is the caller's GEMM over all
- * (sequence, step) rows: d wcat[d] = dgates[d]^T xh[d], d bias[d] = column sums of dgates[d].
- * Supported sizes: H in {32, 64}, I in {H, 2H} (sgnn_lstm_supported), else SGNN_ERR_UNSUPPORTED_D --
- * the caller keeps the library LSTM for those.
+ * The non-recurrent contractions are plain GEMMs over all (sequence, step) rows and stay with the
+ * caller's BLAS: the input projection before the forward call, dx / dW_ih / dW_hh / db after the
+ * backward call.  Gate order i, f, g, o (torch).
+ *   pre_x  (B, T, 2, 4H)   x W_ih^T + b_ih + b_hh per direction (0 = forward, 1 = reverse)
+ *   whh    (2, 4H, H)      weight_hh per direction
+ *   y      (B, T, 2H)      [forward h_t | reverse h_t]  (torch's output layout)
+ *   gates  (B, T, 2, 4H), cell (2, B, T, H), hprev (2, B, T, H) = h_{t-1} in the direction's order:
+ *          activations kept for the backward pass
+ * backward: dy (B, T, 2H) -> dgates (B, T, 2, 4H), the gradient w.r.t. pre_x.  Then, with
+ * dG = dgates viewed (B T, 8H):  dx = dG [W_ih_f; W_ih_r],  d[W_ih_f; W_ih_r] = dG^T x,
+ * dW_hh[d] = dgates[:, :, d, :]^T hprev[d],  db = column sums of dG.
+ * Hidden sizes 32, 64, 128 (sgnn_lstm_supported), any input size; else SGNN_ERR_UNSUPPORTED_D -- the
+ * caller keeps the library LSTM for those.
  * ------------------------------------------------------------------------------------- */
-int sgnn_lstm_supported(int64_t input_size, int64_t hidden_size);
-int sgnn_lstm_fwd(const float* x, const float* wcat, const float* bias, int64_t B, int64_t T,
-                  int64_t input_size, int64_t hidden_size, float* y, float* gates, float* cell, float* xh,
-                  void* stream);
-int sgnn_lstm_bwd(const float* wcat, const float* gates, const float* cell, const float* dy, int64_t B,
-                  int64_t T, int64_t input_size, int64_t hidden_size, float* dx, float* dgates, void* stream);
+int sgnn_lstm_supported(int64_t hidden_size);
+int sgnn_lstm_fwd(const float* pre_x, const float* whh, int64_t B, int64_t T, int64_t hidden_size,
+                  float* y, float* gates, float* cell, float* hprev, void* stream);
+int sgnn_lstm_bwd(const float* whh, const float* gates, const float* cell, const float* dy, int64_t B,
+                  int64_t T, int64_t hidden_size, float* dgates, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * a16  Masked sum over the components of a subgraph (subgraph_utils.masked_sum,

@@ -65,7 +65,7 @@ class LSTM(nn.Module):
                 and ops.lstm_supported(m.input_size, m.hidden_size)):
             out = self._fused(input)
         else:
-            out, _ = m(input)                     # sizes outside the kernel's set: the library LSTM
+            out, _ = m(input)                     # hidden sizes other than 32 / 64 / 128: the library LSTM
         agg = out[:, -1, :] if self.aggregator == 'last' else out.sum(dim=1)
         return self.linear(agg)
 

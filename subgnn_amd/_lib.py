@@ -71,9 +71,9 @@ SIGNATURES = {
     'sgnn_mpn_fwd': (c_int, [ctypes.POINTER(MpnArgs), c_ptr, c_ptr, c_ptr]),
     'sgnn_mpn_bwd': (c_int, [ctypes.POINTER(MpnArgs), c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
     'sgnn_attn_scores_fwd': (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_ptr, c_ptr]),
-    'sgnn_lstm_supported': (c_int, [c_i64, c_i64]),
-    'sgnn_lstm_fwd': (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
-    'sgnn_lstm_bwd': (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_i64, c_ptr, c_ptr, c_ptr]),
+    'sgnn_lstm_supported': (c_int, [c_i64]),
+    'sgnn_lstm_fwd': (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
+    'sgnn_lstm_bwd': (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_ptr, c_ptr]),
     'sgnn_masked_sum_fwd': (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_i64, c_ptr, c_ptr]),
     'sgnn_masked_sum_bwd': (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_i64, c_ptr, c_ptr]),
 }

@@ -1,67 +1,94 @@
-// One bidirectional LSTM layer over short sequences, forward and backward, one launch each.
-// Replaces the nn.LSTM(bidirectional=True) of the structure channel's walk aggregator (reference
-// SubGNN/SubGNN.py:60-88, called from SubGNN/anchor_patch_samplers.py:413-433 on (patches x walks,
-// walk_len, D) inputs: a few hundred sequences of 10-20 steps, hidden size D).  The vendor library
-// runs such a layer as one small GEMM plus one point-wise launch per time step and direction --
-// ~80 launches forward and ~80 backward, each a few microseconds of launch latency around
-// nanoseconds of arithmetic; here the recurrence stays inside one kernel.
+// The recurrence of one bidirectional LSTM layer over short sequences, forward and backward, one
+// launch each.  Replaces the nn.LSTM(bidirectional=True) of the structure channel's walk aggregator
+// (reference SubGNN/SubGNN.py:60-88, called from SubGNN/anchor_patch_samplers.py:413-433 on
+// (patches x walks, walk_len, D) inputs: a few hundred sequences of 10-20 steps, hidden size D).
+// The vendor library runs such a layer as one small GEMM plus one point-wise launch per time step
+// and direction -- ~80 launches forward and ~80 backward per call, each a few microseconds of launch
+// latency around nanoseconds of arithmetic; here the recurrence stays inside one kernel.
 //
-// Layout.  A workgroup owns a tile of BT sequences of one direction and has 4H lanes: lane j
-// holds row j of [W_ih | W_hh] (gate order i, f, g, o as in torch) in registers for the whole
-// sequence.  Per step: [x_t | h_{t-1}] of the tile is staged in LDS, every lane forms its gate
-// pre-activation for the BT sequences (broadcast LDS reads, K = I + H fma per sequence), the
-// pre-activations cross to the lanes that own (sequence, hidden unit) pairs through LDS, and those
-// apply the non-linearities and keep c in registers.  Gates and cell states are saved for the
-// backward pass, which walks the steps in reverse: gate gradients in the owner lanes, then dx and
-// the recurrent dh as a (BT x 4H) x (4H x K) product whose weight columns sit in registers (lane
-// (k, half) holds half of column k).  The forward pass also leaves [x_t | h_{t-1}] in memory and the
-// backward pass the gate gradients: the weight gradient is their plain product over all
-// (sequence, step) rows, one library GEMM for the caller (SubGNN's batches are a few hundred
-// sequences: a per-tile accumulation with atomics was 3x the cost of the recurrence itself).
-// The tile height BT (2, 4 or 8 sequences) is chosen by the host so that a small batch still
-// spreads over the chip: the recurrence is a latency chain, a workgroup is one wavefront per SIMD.
+// Split of the work.  Everything that is NOT recurrent is a plain GEMM over all (sequence, step)
+// rows at once and stays with the library (the caller): the input projection x W_ih^T + b of both
+// directions before the forward kernel, and in the backward pass dx = dgates W_ih, dW_ih = dgates^T x,
+// dW_hh = dgates^T h_prev, db = column sums of dgates.  The kernels hold only W_hh, which is what
+// makes hidden size 128 fit: a direction's W_hh is 4H x H = 256 KB at H = 128, i.e. H registers in
+// each of 4H lanes.
+//
+// Forward.  A workgroup owns a tile of BT sequences of one direction and has 4H lanes: lane j holds
+// row j of W_hh (gate order i, f, g, o as in torch) in registers for the whole sequence.  Per step:
+// the lane's pre-activation starts from the projected input (loaded one step ahead), adds
+// W_hh[j, :] . h_{t-1} for the BT sequences (h in LDS, broadcast reads), the pre-activations cross
+// to the lanes that own (sequence, hidden unit) pairs through LDS, and those apply the
+// non-linearities and keep c in registers.  Gates, cell states and h_{t-1} are kept for backward.
+// Backward walks the steps in reverse: gate gradients in the owner lanes (written out for the
+// caller's GEMMs), then dh_{t-1} = dgates . W_hh as a (BT x 4H) x (4H x H) product whose weight
+// columns sit in registers (lane (k, part) holds a quarter of column k).
+//
+// The barriers inside the step loops order LDS traffic only (fence on the "local" address space):
+// a __syncthreads() would also drain the global loads issued one step ahead and the stores of the
+// kept activations, which is most of a step's latency.  Nothing a lane writes to global memory is
+// read by another lane of the same launch.
+// The tile height BT (2, 4 or 8 sequences) is chosen by the host so that a small batch still spreads
+// over the chip: the recurrence is a latency chain, a workgroup is one or two wavefronts per SIMD.
 #include "common.h"
 
 __device__ __forceinline__ float lstm_sigmoid(float x) { return 1.f / (1.f + expf(-x)); }
 
-template <int H, int I, int BT>
-__global__ __launch_bounds__(4 * H) void lstm_fwd_kernel(
-    const float* __restrict__ x, const float* __restrict__ wcat, const float* __restrict__ bias, int64_t B, int64_t T,
-    float* __restrict__ y, float* __restrict__ gates, float* __restrict__ cst, float* __restrict__ xh)
+__device__ __forceinline__ void lstm_lds_barrier()
 {
-    constexpr int G = 4 * H, K = I + H;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+// pre_x: (B, T, 2, 4H) projected inputs incl. bias; whh: (2, 4H, H)
+// y: (B, T, 2H); gates: (B, T, 2, 4H); cst, hprev: (2, B, T, H)
+template <int H, int BT>
+__global__ __launch_bounds__(4 * H) void lstm_fwd_kernel(
+    const float* __restrict__ pre_x, const float* __restrict__ whh, int64_t B, int64_t T,
+    float* __restrict__ y, float* __restrict__ gates, float* __restrict__ cst, float* __restrict__ hprev)
+{
+    constexpr int G = 4 * H;
     constexpr int OWN = (BT * H + G - 1) / G;              // (sequence, unit) pairs per owner lane
-    __shared__ __attribute__((aligned(16))) float s_in[BT][K];            // [x_t | h_{t-1}]
+    __shared__ __attribute__((aligned(16))) float s_h[BT][H];
     __shared__ float s_pre[BT][G];
     const int j = threadIdx.x, d = blockIdx.y;
     const int64_t b0 = (int64_t)blockIdx.x * BT;
-    float w[K];
+    float w[H];
 #pragma unroll
-    for (int k = 0; k < K; ++k) w[k] = wcat[((int64_t)d * G + j) * K + k];
-    const float bj = bias[d * G + j];
+    for (int k = 0; k < H; ++k) w[k] = whh[((int64_t)d * G + j) * H + k];
     float c_own[OWN];
 #pragma unroll
     for (int q = 0; q < OWN; ++q) c_own[q] = 0.f;
-    for (int idx = j; idx < BT * H; idx += G) s_in[idx / H][I + idx % H] = 0.f;
+    for (int idx = j; idx < BT * H; idx += G) s_h[idx / H][idx % H] = 0.f;
+    float cur[BT], nxt[BT];
+    {
+        const int64_t t0 = d ? T - 1 : 0;
+#pragma unroll
+        for (int b = 0; b < BT; ++b) {
+            cur[b] = (b0 + b < B) ? pre_x[(((b0 + b) * T + t0) * 2 + d) * G + j] : 0.f;
+            nxt[b] = 0.f;
+        }
+    }
+    lstm_lds_barrier();
     for (int64_t step = 0; step < T; ++step) {
         const int64_t t = d ? T - 1 - step : step;
-        for (int idx = j; idx < BT * I; idx += G) {
-            const int b = idx / I, k = idx % I;
-            s_in[b][k] = (b0 + b < B) ? x[((b0 + b) * T + t) * I + k] : 0.f;
+        if (step + 1 < T) {                                 // next step's projected input, in flight during this one
+            const int64_t tn = d ? t - 1 : t + 1;
+#pragma unroll
+            for (int b = 0; b < BT; ++b) nxt[b] = (b0 + b < B) ? pre_x[(((b0 + b) * T + tn) * 2 + d) * G + j] : 0.f;
         }
-        __syncthreads();
-        for (int idx = j; idx < BT * K; idx += G) {         // kept for the weight gradient
-            const int b = idx / K, k = idx % K;
-            if (b0 + b < B) xh[(((int64_t)d * B + b0 + b) * T + t) * K + k] = s_in[b][k];
+        for (int idx = j; idx < BT * H; idx += G) {         // h_{t-1}, kept for the caller's dW_hh
+            const int b = idx / H, k = idx % H;
+            if (b0 + b < B) hprev[(((int64_t)d * B + b0 + b) * T + t) * H + k] = s_h[b][k];
         }
         float acc[BT];
 #pragma unroll
-        for (int b = 0; b < BT; ++b) acc[b] = bj;
+        for (int b = 0; b < BT; ++b) acc[b] = cur[b];
 #pragma unroll
-        for (int k = 0; k < K; k += 4) {
+        for (int k = 0; k < H; k += 4) {
 #pragma unroll
             for (int b = 0; b < BT; ++b) {
-                const float4 v = *reinterpret_cast<const float4*>(&s_in[b][k]);
+                const float4 v = *reinterpret_cast<const float4*>(&s_h[b][k]);
                 acc[b] = fmaf(w[k], v.x, acc[b]);
                 acc[b] = fmaf(w[k + 1], v.y, acc[b]);
                 acc[b] = fmaf(w[k + 2], v.z, acc[b]);
@@ -70,7 +97,7 @@ __global__ __launch_bounds__(4 * H) void lstm_fwd_kernel(
         }
 #pragma unroll
         for (int b = 0; b < BT; ++b) s_pre[b][j] = acc[b];
-        __syncthreads();
+        lstm_lds_barrier();                                 // all dot products done: s_h may be rewritten
 #pragma unroll
         for (int q = 0; q < OWN; ++q) {
             const int p = j + q * G;
@@ -81,51 +108,49 @@ __global__ __launch_bounds__(4 * H) void lstm_fwd_kernel(
                 const float c = gf * c_own[q] + gi * gg;
                 const float h = go * tanhf(c);
                 c_own[q] = c;
-                s_in[b][I + u] = h;                          // h_{t-1} of the next step (the x part is rewritten above)
+                s_h[b][u] = h;
                 if (b0 + b < B) {
-                    float* gp = gates + (((int64_t)d * B + b0 + b) * T + t) * G;
+                    float* gp = gates + (((b0 + b) * T + t) * 2 + d) * G;
                     gp[u] = gi; gp[H + u] = gf; gp[2 * H + u] = gg; gp[3 * H + u] = go;
                     cst[(((int64_t)d * B + b0 + b) * T + t) * H + u] = c;
                     y[((b0 + b) * T + t) * (2 * H) + d * H + u] = h;
                 }
             }
         }
-        // the next step's staging writes s_in[.][0..I) only, its dot products start after the barrier
-        // that follows -- by then every owner lane has stored its h
+        lstm_lds_barrier();                                 // new h visible; s_pre may be rewritten
+#pragma unroll
+        for (int b = 0; b < BT; ++b) cur[b] = nxt[b];
     }
 }
 
-template <int H, int I, int BT>
+// dgates: (B, T, 2, 4H) written
+template <int H, int BT>
 __global__ __launch_bounds__(4 * H) void lstm_bwd_kernel(
-    const float* __restrict__ wcat, const float* __restrict__ gates, const float* __restrict__ cst,
-    const float* __restrict__ dy, int64_t B, int64_t T, float* __restrict__ dx, float* __restrict__ dpre)
+    const float* __restrict__ whh, const float* __restrict__ gates, const float* __restrict__ cst,
+    const float* __restrict__ dy, int64_t B, int64_t T, float* __restrict__ dgates)
 {
-    constexpr int G = 4 * H, K = I + H;
+    constexpr int G = 4 * H;
     constexpr int OWN = (BT * H + G - 1) / G;
-    constexpr int NJ = (G % K == 0) ? G / K : 1;           // lanes per output column of the dx/dh product
-    constexpr int ROWS = G / NJ;                            // gate rows one lane sums over
-    constexpr bool REGW = ROWS <= 128;                      // its share of the weight column fits in registers
+    constexpr int NJ = 4;                                   // lanes per output column of the dh product: 4H lanes, H columns
+    constexpr int ROWS = G / NJ;                            // = H gate rows per lane
     __shared__ __attribute__((aligned(16))) float s_dpre_t[G][BT];        // gate gradients [row][sequence]: broadcast reads over rows
     __shared__ float s_dh[BT][H];                                          // recurrent dh from the step after
-    __shared__ float s_part[BT][K];
+    __shared__ float s_part[NJ - 1][BT][H];
     const int j = threadIdx.x, d = blockIdx.y;
     const int64_t b0 = (int64_t)blockIdx.x * BT;
-    const int kcol = j % K, part = j / K;
-    const float* wp = wcat + (int64_t)d * G * K + kcol + (int64_t)(part < NJ ? part : 0) * ROWS * K;
-    float wreg[REGW ? ROWS : 1];
-    if (REGW) {
+    const int kcol = j % H, part = j / H;
+    float wreg[ROWS];
 #pragma unroll
-        for (int r = 0; r < (REGW ? ROWS : 1); ++r) wreg[r] = wp[(int64_t)r * K];
-    }
+    for (int r = 0; r < ROWS; ++r) wreg[r] = whh[((int64_t)d * G + part * ROWS + r) * H + kcol];
     float dc_own[OWN];
 #pragma unroll
     for (int q = 0; q < OWN; ++q) dc_own[q] = 0.f;
     for (int idx = j; idx < BT * H; idx += G) s_dh[idx / H][idx % H] = 0.f;
+    lstm_lds_barrier();
     for (int64_t step = 0; step < T; ++step) {
         const int64_t sf = T - 1 - step;                    // forward step being undone
         const int64_t t = d ? T - 1 - sf : sf;
         const int64_t tp = d ? t + 1 : t - 1;               // time index of the forward step before it
-        __syncthreads();                                    // s_dh / s_part / s_dpre_t of the previous step are done with
 #pragma unroll
         for (int q = 0; q < OWN; ++q) {
             const int p = j + q * G;
@@ -133,10 +158,10 @@ __global__ __launch_bounds__(4 * H) void lstm_bwd_kernel(
                 const int b = p / H, u = p % H;
                 float pi = 0.f, pf = 0.f, pg = 0.f, po = 0.f;
                 if (b0 + b < B) {
-                    const int64_t row = ((int64_t)d * B + b0 + b) * T + t;
-                    const float* gp = gates + row * G;
+                    const int64_t rowg = ((b0 + b) * T + t) * 2 + d;
+                    const float* gp = gates + rowg * G;
                     const float gi = gp[u], gf = gp[H + u], gg = gp[2 * H + u], go = gp[3 * H + u];
-                    const float c = cst[row * H + u];
+                    const float c = cst[(((int64_t)d * B + b0 + b) * T + t) * H + u];
                     const float cprev = sf > 0 ? cst[(((int64_t)d * B + b0 + b) * T + tp) * H + u] : 0.f;
                     const float dh = dy[((b0 + b) * T + t) * (2 * H) + d * H + u] + s_dh[b][u];
                     const float tc = tanhf(c);
@@ -146,81 +171,56 @@ __global__ __launch_bounds__(4 * H) void lstm_bwd_kernel(
                     pf = dc * cprev * gf * (1.f - gf);
                     pg = dc * gi * (1.f - gg * gg);
                     po = dh * tc * go * (1.f - go);
-                    float* dp = dpre + row * G;
+                    float* dp = dgates + rowg * G;
                     dp[u] = pi; dp[H + u] = pf; dp[2 * H + u] = pg; dp[3 * H + u] = po;
                 }
                 s_dpre_t[u][b] = pi; s_dpre_t[H + u][b] = pf; s_dpre_t[2 * H + u][b] = pg; s_dpre_t[3 * H + u][b] = po;
             }
         }
-        __syncthreads();
-        // [dx_t | dh_{t-1}][b, k] = sum_j dpre[b, j] * W[j, k]: lane (k, part) sums its share of the rows
-        {
-            float acc[BT];
+        lstm_lds_barrier();                                 // gate gradients visible; s_dh fully read
+        // dh_{t-1}[b, k] = sum_j dgates[b, j] * W_hh[j, k]: lane (k, part) sums its quarter of the rows
+        float acc[BT];
 #pragma unroll
-            for (int b = 0; b < BT; ++b) acc[b] = 0.f;
-            if (part < NJ) {
-                const int j0 = part * ROWS;
-                if (REGW) {
+        for (int b = 0; b < BT; ++b) acc[b] = 0.f;
 #pragma unroll
-                    for (int r = 0; r < (REGW ? ROWS : 1); ++r) {
+        for (int r = 0; r < ROWS; ++r) {
 #pragma unroll
-                        for (int b = 0; b < BT; ++b) acc[b] = fmaf(s_dpre_t[j0 + r][b], wreg[r], acc[b]);
-                    }
-                } else {
-#pragma unroll 1
-                    for (int r0 = 0; r0 < ROWS; r0 += 16) {  // 16 weight loads in flight, then their products
-                        float wv[16];
+            for (int b = 0; b < BT; ++b) acc[b] = fmaf(s_dpre_t[part * ROWS + r][b], wreg[r], acc[b]);
+        }
+        if (part > 0) {
 #pragma unroll
-                        for (int i = 0; i < 16; ++i) wv[i] = wp[(int64_t)(r0 + i) * K];
+            for (int b = 0; b < BT; ++b) s_part[part - 1][b][kcol] = acc[b];
+        }
+        lstm_lds_barrier();
+        if (part == 0) {
 #pragma unroll
-                        for (int i = 0; i < 16; ++i) {
+            for (int b = 0; b < BT; ++b) {
+                float v = acc[b];
 #pragma unroll
-                            for (int b = 0; b < BT; ++b) acc[b] = fmaf(s_dpre_t[j0 + r0 + i][b], wv[i], acc[b]);
-                        }
-                    }
-                }
-            }
-            if (NJ > 1) {
-                if (part == 1) {
-#pragma unroll
-                    for (int b = 0; b < BT; ++b) s_part[b][kcol] = acc[b];
-                }
-                __syncthreads();
-                if (part == 0) {
-#pragma unroll
-                    for (int b = 0; b < BT; ++b) acc[b] += s_part[b][kcol];
-                }
-            }
-            if (part == 0) {
-#pragma unroll
-                for (int b = 0; b < BT; ++b) {
-                    if (kcol < I) {
-                        if (b0 + b < B) atomicAdd(&dx[((b0 + b) * T + t) * I + kcol], acc[b]);   // + the other direction's share
-                    } else {
-                        s_dh[b][kcol - I] = acc[b];
-                    }
-                }
+                for (int pp = 0; pp < NJ - 1; ++pp) v += s_part[pp][b][kcol];
+                s_dh[b][kcol] = v;
             }
         }
+        lstm_lds_barrier();                                 // s_dh ready; s_dpre_t / s_part may be rewritten
     }
 }
 
-template <int H, int I, int BT>
-static int lstm_launch_fwd(const float* x, const float* wcat, const float* bias, int64_t B, int64_t T, float* y,
-                           float* gates, float* cst, float* xh, hipStream_t st)
+template <int H, int BT>
+static int lstm_launch_fwd(const float* pre_x, const float* whh, int64_t B, int64_t T, float* y, float* gates,
+                           float* cst, float* hprev, hipStream_t st)
 {
-    hipLaunchKernelGGL((lstm_fwd_kernel<H, I, BT>), dim3((unsigned)((B + BT - 1) / BT), 2), dim3(4 * H), 0, st, x, wcat,
-                       bias, B, T, y, gates, cst, xh);
+    hipLaunchKernelGGL((lstm_fwd_kernel<H, BT>), dim3((unsigned)((B + BT - 1) / BT), 2), dim3(4 * H), 0, st, pre_x, whh,
+                       B, T, y, gates, cst, hprev);
     SGNN_CHECK_LAUNCH();
     return SGNN_OK;
 }
 
-template <int H, int I, int BT>
-static int lstm_launch_bwd(const float* wcat, const float* gates, const float* cst, const float* dy, int64_t B, int64_t T,
-                           float* dx, float* dpre, hipStream_t st)
+template <int H, int BT>
+static int lstm_launch_bwd(const float* whh, const float* gates, const float* cst, const float* dy, int64_t B, int64_t T,
+                           float* dgates, hipStream_t st)
 {
-    hipLaunchKernelGGL((lstm_bwd_kernel<H, I, BT>), dim3((unsigned)((B + BT - 1) / BT), 2), dim3(4 * H), 0, st, wcat,
-                       gates, cst, dy, B, T, dx, dpre);
+    hipLaunchKernelGGL((lstm_bwd_kernel<H, BT>), dim3((unsigned)((B + BT - 1) / BT), 2), dim3(4 * H), 0, st, whh, gates,
+                       cst, dy, B, T, dgates);
     SGNN_CHECK_LAUNCH();
     return SGNN_OK;
 }
@@ -231,43 +231,40 @@ static int lstm_tile(int64_t B) { return B >= 2048 ? 8 : (B >= 768 ? 4 : 2); }
 #define LSTM_DISPATCH(CALL)                                                                  \
     do {                                                                                     \
         const int bt = lstm_tile(B);                                                         \
-        if (hidden_size == 64 && input_size == 64) {                                         \
-            if (bt == 8) return CALL(64, 64, 8); if (bt == 4) return CALL(64, 64, 4); return CALL(64, 64, 2);      \
+        if (hidden_size == 128) {                                                            \
+            if (bt == 8) return CALL(128, 8); if (bt == 4) return CALL(128, 4); return CALL(128, 2);   \
         } else if (hidden_size == 64) {                                                      \
-            if (bt == 8) return CALL(64, 128, 8); if (bt == 4) return CALL(64, 128, 4); return CALL(64, 128, 2);   \
-        } else if (input_size == 32) {                                                       \
-            if (bt == 8) return CALL(32, 32, 8); if (bt == 4) return CALL(32, 32, 4); return CALL(32, 32, 2);      \
+            if (bt == 8) return CALL(64, 8); if (bt == 4) return CALL(64, 4); return CALL(64, 2);      \
         } else {                                                                             \
-            if (bt == 8) return CALL(32, 64, 8); if (bt == 4) return CALL(32, 64, 4); return CALL(32, 64, 2);      \
+            if (bt == 8) return CALL(32, 8); if (bt == 4) return CALL(32, 4); return CALL(32, 2);      \
         }                                                                                    \
     } while (0)
 
-extern "C" int sgnn_lstm_supported(int64_t input_size, int64_t hidden_size)
+extern "C" int sgnn_lstm_supported(int64_t hidden_size)
 {
-    return ((hidden_size == 64 || hidden_size == 32) && (input_size == hidden_size || input_size == 2 * hidden_size)) ? 1 : 0;
+    return (hidden_size == 128 || hidden_size == 64 || hidden_size == 32) ? 1 : 0;
 }
 
-extern "C" int sgnn_lstm_fwd(const float* x, const float* wcat, const float* bias, int64_t B, int64_t T,
-                             int64_t input_size, int64_t hidden_size, float* y, float* gates, float* cell, float* xh,
-                             void* stream)
+extern "C" int sgnn_lstm_fwd(const float* pre_x, const float* whh, int64_t B, int64_t T, int64_t hidden_size,
+                             float* y, float* gates, float* cell, float* hprev, void* stream)
 {
-    if (!x || !wcat || !bias || !y || !gates || !cell || !xh || B < 0 || T < 0) return SGNN_ERR_BAD_ARG;
-    if (!sgnn_lstm_supported(input_size, hidden_size)) return SGNN_ERR_UNSUPPORTED_D;
+    if (!pre_x || !whh || !y || !gates || !cell || !hprev || B < 0 || T < 0) return SGNN_ERR_BAD_ARG;
+    if (!sgnn_lstm_supported(hidden_size)) return SGNN_ERR_UNSUPPORTED_D;
     if (B == 0 || T == 0) return SGNN_OK;
     hipStream_t st = (hipStream_t)stream;
-#define LSTM_FWD(HH, II, BB) lstm_launch_fwd<HH, II, BB>(x, wcat, bias, B, T, y, gates, cell, xh, st)
+#define LSTM_FWD(HH, BB) lstm_launch_fwd<HH, BB>(pre_x, whh, B, T, y, gates, cell, hprev, st)
     LSTM_DISPATCH(LSTM_FWD);
 #undef LSTM_FWD
 }
 
-extern "C" int sgnn_lstm_bwd(const float* wcat, const float* gates, const float* cell, const float* dy, int64_t B,
-                             int64_t T, int64_t input_size, int64_t hidden_size, float* dx, float* dgates, void* stream)
+extern "C" int sgnn_lstm_bwd(const float* whh, const float* gates, const float* cell, const float* dy, int64_t B,
+                             int64_t T, int64_t hidden_size, float* dgates, void* stream)
 {
-    if (!wcat || !gates || !cell || !dy || !dx || !dgates || B < 0 || T < 0) return SGNN_ERR_BAD_ARG;
-    if (!sgnn_lstm_supported(input_size, hidden_size)) return SGNN_ERR_UNSUPPORTED_D;
+    if (!whh || !gates || !cell || !dy || !dgates || B < 0 || T < 0) return SGNN_ERR_BAD_ARG;
+    if (!sgnn_lstm_supported(hidden_size)) return SGNN_ERR_UNSUPPORTED_D;
     if (B == 0 || T == 0) return SGNN_OK;
     hipStream_t st = (hipStream_t)stream;
-#define LSTM_BWD(HH, II, BB) lstm_launch_bwd<HH, II, BB>(wcat, gates, cell, dy, B, T, dx, dgates, st)
+#define LSTM_BWD(HH, BB) lstm_launch_bwd<HH, BB>(whh, gates, cell, dy, B, T, dgates, st)
     LSTM_DISPATCH(LSTM_BWD);
 #undef LSTM_BWD
 }

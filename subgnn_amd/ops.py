@@ -954,9 +954,10 @@ def gather_rows(weight, ids):
 
 
 class _BiLSTMLayer(torch.autograd.Function):
-    """One bidirectional LSTM layer (sgnn_lstm_fwd / _bwd): x (B, T, I) -> (B, T, 2H), zero initial
-    state.  Parameters in torch's nn.LSTM layout (weight_ih (4H, I), weight_hh (4H, H), two biases,
-    per direction)."""
+    """One bidirectional LSTM layer: x (B, T, I) -> (B, T, 2H), zero initial state.  Parameters in
+    torch's nn.LSTM layout (weight_ih (4H, I), weight_hh (4H, H), two biases, per direction).  The
+    recurrence runs in sgnn_lstm_fwd / _bwd; the input projection and the weight / input gradients
+    are GEMMs over all (sequence, step) rows at once."""
 
     @staticmethod
     def forward(ctx, x, w_ih_f, w_hh_f, b_ih_f, b_hh_f, w_ih_r, w_hh_r, b_ih_r, b_hh_r):
@@ -964,37 +965,43 @@ class _BiLSTMLayer(torch.autograd.Function):
         _req(x, torch.float32, 'x')
         B, T, I = x.shape
         H = w_hh_f.shape[1]
-        wcat = torch.stack((torch.cat((w_ih_f, w_hh_f), 1), torch.cat((w_ih_r, w_hh_r), 1))).contiguous()
-        bias = torch.stack((b_ih_f + b_hh_f, b_ih_r + b_hh_r)).contiguous()
-        y = torch.empty((B, T, 2 * H), dtype=torch.float32, device=x.device)
-        gates = torch.empty((2, B, T, 4 * H), dtype=torch.float32, device=x.device)
-        cell = torch.empty((2, B, T, H), dtype=torch.float32, device=x.device)
-        xh = torch.empty((2, B, T, I + H), dtype=torch.float32, device=x.device)
-        check(lib.sgnn_lstm_fwd(_ptr(x), _ptr(wcat), _ptr(bias), B, T, I, H, _ptr(y), _ptr(gates), _ptr(cell), _ptr(xh),
+        wih = torch.cat((w_ih_f, w_ih_r), 0)                                   # (8H, I)
+        bias = torch.cat((b_ih_f + b_hh_f, b_ih_r + b_hh_r), 0)
+        x2 = x.reshape(B * T, I)
+        pre_x = torch.addmm(bias, x2, wih.t())                                 # (B T, 8H) = (B, T, 2, 4H)
+        whh = torch.stack((w_hh_f, w_hh_r)).contiguous()
+        dev = x.device
+        y = torch.empty((B, T, 2 * H), dtype=torch.float32, device=dev)
+        gates = torch.empty((B, T, 2, 4 * H), dtype=torch.float32, device=dev)
+        cell = torch.empty((2, B, T, H), dtype=torch.float32, device=dev)
+        hprev = torch.empty((2, B, T, H), dtype=torch.float32, device=dev)
+        check(lib.sgnn_lstm_fwd(_ptr(pre_x), _ptr(whh), B, T, H, _ptr(y), _ptr(gates), _ptr(cell), _ptr(hprev),
                                 _stream()), 'sgnn_lstm_fwd')
-        ctx.save_for_backward(wcat, gates, cell, xh)
+        ctx.save_for_backward(x2, wih, whh, gates, cell, hprev)
         ctx.dims = (B, T, I, H)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         lib = _lib.load()
-        wcat, gates, cell, xh = ctx.saved_tensors
+        x2, wih, whh, gates, cell, hprev = ctx.saved_tensors
         B, T, I, H = ctx.dims
         dy = dy.contiguous()
-        dx = torch.zeros((B, T, I), dtype=torch.float32, device=dy.device)
         dgates = torch.empty_like(gates)
-        check(lib.sgnn_lstm_bwd(_ptr(wcat), _ptr(gates), _ptr(cell), _ptr(dy), B, T, I, H, _ptr(dx), _ptr(dgates),
-                                _stream()), 'sgnn_lstm_bwd')
-        # weight gradient: one batched GEMM over all (sequence, step) rows, per direction
-        dg = dgates.view(2, B * T, 4 * H)
-        dw = torch.bmm(dg.transpose(1, 2), xh.view(2, B * T, I + H))
-        db = torch.bmm(torch.ones((2, 1, B * T), dtype=dg.dtype, device=dg.device), dg).view(2, 4 * H)   # column sums as a GEMM: torch's reduction over the long dimension of (2, B*T, 4H) takes 30 us
-        return (dx, dw[0, :, :I], dw[0, :, I:], db[0], db[0], dw[1, :, :I], dw[1, :, I:], db[1], db[1])
+        check(lib.sgnn_lstm_bwd(_ptr(whh), _ptr(gates), _ptr(cell), _ptr(dy), B, T, H, _ptr(dgates), _stream()),
+              'sgnn_lstm_bwd')
+        dg = dgates.view(B * T, 8 * H)
+        dx = (dg @ wih).view(B, T, I) if ctx.needs_input_grad[0] else None
+        dwih = dg.t() @ x2                                                      # (8H, I)
+        dg3 = dgates.view(B * T, 2, 4 * H)
+        dwhh = [dg3[:, d, :].t() @ hprev[d].view(B * T, H) for d in (0, 1)]
+        db = (torch.ones((1, B * T), dtype=dg.dtype, device=dg.device) @ dg).view(8 * H)
+        G = 4 * H
+        return (dx, dwih[:G], dwhh[0], db[:G], db[:G], dwih[G:], dwhh[1], db[G:], db[G:])
 
 
 def lstm_supported(input_size, hidden_size):
-    return bool(_lib.load().sgnn_lstm_supported(int(input_size), int(hidden_size)))
+    return bool(_lib.load().sgnn_lstm_supported(int(hidden_size)))
 
 
 def bilstm_layer(x, params):

@@ -259,7 +259,7 @@ def _lstm_params(m, layer):
             for n in ('weight_ih', 'weight_hh', 'bias_ih', 'bias_hh')]
 
 
-@pytest.mark.parametrize('H,I', [(64, 64), (64, 128), (32, 32), (32, 64)])
+@pytest.mark.parametrize('H,I', [(64, 64), (64, 128), (32, 32), (32, 64), (128, 128), (128, 256), (64, 20)])
 @pytest.mark.parametrize('B,Tn', [(1, 1), (7, 3), (210, 10), (19, 20), (8, 10)])
 def test_bilstm_layer_matches_torch(H, I, B, Tn):
     from subgnn_amd import ops
@@ -282,15 +282,15 @@ def test_bilstm_layer_matches_torch(H, I, B, Tn):
         assert torch.allclose(p.grad.cpu() / scale, q.grad / scale, rtol=1e-4, atol=2e-5), (p.shape,)
 
 
-@pytest.mark.parametrize('layers,agg', [(1, 'last'), (2, 'last'), (2, 'sum')])
-def test_lstm_module_uses_fused_layers_and_matches_library(layers, agg):
+@pytest.mark.parametrize('layers,agg,D', [(1, 'last', 64), (2, 'last', 64), (2, 'sum', 64), (2, 'last', 128)])
+def test_lstm_module_uses_fused_layers_and_matches_library(layers, agg, D):
     """The module of SubGNN.py:60-88 with the kernel inside equals the same parameters run through the
     library nn.LSTM (state-dict compatible: same parameter names)."""
     from subgnn_amd.SubGNN import LSTM
     torch.manual_seed(3)
-    m = LSTM(64, 64, dropout=0.0, num_layers=layers, aggregator=agg).to(DEV)
+    m = LSTM(D, D, dropout=0.0, num_layers=layers, aggregator=agg).to(DEV)
     assert sorted(k for k in m.state_dict() if k.startswith('lstm.')) == sorted('lstm.' + k for k in m.lstm.state_dict())
-    x = torch.randn(30, 12, 64, device=DEV, requires_grad=True)
+    x = torch.randn(30, 12, D, device=DEV, requires_grad=True)
     out = m(x)
     out.square().sum().backward()
     gx, gw = x.grad.clone(), [p.grad.clone() for p in m.parameters()]
@@ -309,6 +309,7 @@ def test_lstm_module_uses_fused_layers_and_matches_library(layers, agg):
 def test_lstm_unsupported_sizes_stay_on_the_library():
     from subgnn_amd import ops
     from subgnn_amd.SubGNN import LSTM
-    assert ops.lstm_supported(64, 64) and ops.lstm_supported(128, 64) and not ops.lstm_supported(48, 48)
+    assert ops.lstm_supported(64, 64) and ops.lstm_supported(128, 64) and ops.lstm_supported(128, 128)
+    assert not ops.lstm_supported(48, 48)
     m = LSTM(48, 48).to(DEV)
     assert m(torch.randn(5, 4, 48, device=DEV)).shape == (5, 48)
