@@ -30,13 +30,18 @@ __global__ __launch_bounds__(256) void mpn_fwd_kernel(sgnn_mpn_args a, float* __
     const T* xt = reinterpret_cast<const T*>(a.x);
     const int lanes = (int)D4;
     const float bp = a.bp[0];
+    // batch-sized calls (a few hundred component rows) do not fill the chip with one lane group per row and
+    // walk their anchors one dependent load after the other: the anchors are then split over grid.y
+    const int64_t a_per = (a.A + gridDim.y - 1) / gridDim.y;
+    const int64_t a0 = blockIdx.y * a_per;
+    const int64_t a1 = a0 + a_per < a.A ? a0 + a_per : a.A;
     for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
         const int64_t r = t / D4, dv = t % D4;
         const bool row_real = a.row_mask ? (a.row_mask[r] != 0) : true;
         const float4 wp = reinterpret_cast<const float4*>(a.wp)[dv];
         const int64_t idrow = (a.id_div > 1 ? r / a.id_div : r) * a.A;
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int64_t ai = 0; ai < a.A; ++ai) {
+        for (int64_t ai = a0; ai < a1; ++ai) {
             int64_t id = 1;
             bool edge;
             if (SRC == SGNN_SRC_DENSE) {
@@ -63,7 +68,12 @@ __global__ __launch_bounds__(256) void mpn_fwd_kernel(sgnn_mpn_args a, float* __
             }
             if (dv == 0 && z) z[r * a.A + ai] = zval;
         }
-        reinterpret_cast<float4*>(agg)[t] = acc;
+        if (gridDim.y == 1) {
+            reinterpret_cast<float4*>(agg)[t] = acc;
+        } else {                                              // anchor chunks of one row add up (agg zeroed by the launcher)
+            float* dst = agg + t * 4;
+            atomicAdd(dst + 0, acc.x); atomicAdd(dst + 1, acc.y); atomicAdd(dst + 2, acc.z); atomicAdd(dst + 3, acc.w);
+        }
     }
 }
 
@@ -146,6 +156,9 @@ __global__ __launch_bounds__(256) void mpn_bwd_gather_kernel(sgnn_mpn_args a, co
         __syncthreads();
     }
     const int64_t total = a.R * D;
+    const int64_t a_per = (a.A + gridDim.y - 1) / gridDim.y;  // batch-sized calls split the anchors over grid.y
+    const int64_t a0 = blockIdx.y * a_per;
+    const int64_t a1 = a0 + a_per < a.A ? a0 + a_per : a.A;
     for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
         const int64_t r = t / D, d = t % D;
         const bool row_real = a.row_mask ? (a.row_mask[r] != 0) : true;
@@ -154,7 +167,7 @@ __global__ __launch_bounds__(256) void mpn_bwd_gather_kernel(sgnn_mpn_args a, co
         const float ga = grad_agg ? grad_agg[t] : 0.f;
         const int64_t idrow = (a.id_div > 1 ? r / a.id_div : r) * a.A;
         float gw = 0.f;
-        for (int64_t ai = 0; ai < a.A; ++ai) {
+        for (int64_t ai = a0; ai < a1; ++ai) {
             const int64_t id = a.ids[idrow + ai];
             if (id == 0) continue;
             const int64_t col = a.sim_col ? a.sim_col[ai] : (a.sims_per_edge ? ai : id - 1);
@@ -254,16 +267,24 @@ extern "C" int sgnn_mpn_fwd(const sgnn_mpn_args* args, float* agg, float* z, voi
     if (!agg) return SGNN_ERR_BAD_ARG;
     if (args->R == 0) return SGNN_OK;
     const int64_t D4 = args->D / 4;
-    const int grid = sgnn_grid_for(args->R * D4, 256);
+    const int gx = sgnn_grid_for(args->R * D4, 256);
     hipStream_t st = (hipStream_t)stream;
+    int chunks = 1;
+    if (gx < 512 && args->A >= 16) {                          // too few rows to fill 256 CUs: split the anchors
+        chunks = (1024 + gx - 1) / gx;
+        const int64_t most = (args->A + 7) / 8;               // at least 8 anchors per chunk
+        if (chunks > most) chunks = (int)most;
+    }
+    if (chunks > 1) (void)hipMemsetAsync(agg, 0, (size_t)(args->R * args->D * 4), st);
+    const dim3 grid(gx, chunks);
     if (args->src == SGNN_SRC_DENSE)
-        hipLaunchKernelGGL(mpn_fwd_kernel<SGNN_SRC_DENSE>, dim3(grid), dim3(256), 0, st, *args, agg, z, D4);
+        hipLaunchKernelGGL(mpn_fwd_kernel<SGNN_SRC_DENSE>, grid, dim3(256), 0, st, *args, agg, z, D4);
     else if (args->src == SGNN_SRC_GATHER && args->x_f16)
-        hipLaunchKernelGGL((mpn_fwd_kernel<SGNN_SRC_GATHER, __half>), dim3(grid), dim3(256), 0, st, *args, agg, z, D4);
+        hipLaunchKernelGGL((mpn_fwd_kernel<SGNN_SRC_GATHER, __half>), grid, dim3(256), 0, st, *args, agg, z, D4);
     else if (args->src == SGNN_SRC_GATHER)
-        hipLaunchKernelGGL(mpn_fwd_kernel<SGNN_SRC_GATHER>, dim3(grid), dim3(256), 0, st, *args, agg, z, D4);
+        hipLaunchKernelGGL(mpn_fwd_kernel<SGNN_SRC_GATHER>, grid, dim3(256), 0, st, *args, agg, z, D4);
     else
-        hipLaunchKernelGGL(mpn_fwd_kernel<SGNN_SRC_SHARED>, dim3(grid), dim3(256), 0, st, *args, agg, z, D4);
+        hipLaunchKernelGGL(mpn_fwd_kernel<SGNN_SRC_SHARED>, grid, dim3(256), 0, st, *args, agg, z, D4);
     SGNN_CHECK_LAUNCH();
     return SGNN_OK;
 }
@@ -295,8 +316,17 @@ extern "C" int sgnn_mpn_bwd(const sgnn_mpn_args* args, const float* grad_agg, co
             hipLaunchKernelGGL(mpn_bwd_kernel<SGNN_SRC_DENSE>, dim3(grid), dim3(256), 0, st, *args, grad_agg, grad_z,
                                grad_x, grad_wp, D4);
         else
-            hipLaunchKernelGGL(mpn_bwd_gather_kernel, dim3(sgnn_grid_for(args->R * args->D, 256, 8192)), dim3(256), 0, st,
-                               *args, grad_agg, grad_z, grad_x, grad_wp);
+        {
+            const int gx = sgnn_grid_for(args->R * args->D, 256, 8192);
+            int chunks = 1;
+            if (gx < 512 && args->A >= 16) {
+                chunks = (1024 + gx - 1) / gx;
+                const int64_t most = (args->A + 7) / 8;
+                if (chunks > most) chunks = (int)most;
+            }
+            hipLaunchKernelGGL(mpn_bwd_gather_kernel, dim3(gx, chunks), dim3(256), 0, st, *args, grad_agg, grad_z, grad_x,
+                               grad_wp);
+        }
     }
     SGNN_CHECK_LAUNCH();
     return SGNN_OK;
