@@ -165,6 +165,23 @@ def main():
         timer.mark('optimizer')
         return timer, float(out['loss'].detach())
 
+    if dist:
+        # communicator set-up happens lazily at the first collective of each kind and size class: do it
+        # here, with the shapes the step uses, so that it never lands in a timed step
+        sdist.all_gather_rows(torch.zeros((S, 8), device=dev), equal_rows=True)
+        big = max((p.numel() for p in params), default=1)
+        scratch = torch.zeros(big, device=dev)
+        dist.all_reduce(scratch)
+        dist.all_reduce(torch.zeros(1024, device=dev))
+        del scratch
+        torch.cuda.synchronize()
+    # one-time work is kept out of the W warm-up steps the caller asked for: the first pass computes what is
+    # kept per split (dispatch order, row-grouping decision), the second is the first to run the steady
+    # path and grows the caching allocator to its final footprint (with --warmup 1 the timed steps were
+    # 30 ms instead of 20)
+    PRIMING_PASSES = 2
+    for _ in range(PRIMING_PASSES):
+        step(False)
     for _ in range(args.warmup):
         step(False)
     torch.cuda.synchronize()
@@ -242,7 +259,7 @@ def main():
                      'algorithmic_bytes_per_launch': alg_bytes, 'ms_per_launch': ds_ms, 'ms_per_launch_back_to_back': ds_ms_b2b, 'sets_per_launch': cc_sets.n,
                      'note': 'algorithmic bytes / time; the CSR (88 MB) fits the 256 MiB Infinity Cache and hub lists are re-read from the XCD L2s, so most of these bytes are served on-die (memory-side traffic is ~0.26 GB per launch)'},
         'stages_ms': {k: round(v, 3) for k, v in stage_ms.items()},
-        'loss': loss, 'setup_s': round(t_gen, 1),
+        'loss': loss, 'setup_s': round(t_gen, 1), 'priming_passes_before_warmup': PRIMING_PASSES,
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
