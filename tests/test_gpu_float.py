@@ -105,11 +105,12 @@ def _ref_mpn(x_rows, edge, w, wp, bp):
     return agg, z
 
 
+@pytest.mark.parametrize('A', [11, 69])            # 69: batch-sized calls split their anchors over grid.y
 @pytest.mark.parametrize('D', [8, 32, 64, 128])
-def test_mpn_gather_random(D):
+def test_mpn_gather_random(D, A):
     """SRC_GATHER (anchor rows gathered from the embedding table by id, NP slab indexed by id-1)."""
     ops = _ops()
-    R, A, N, C = 96, 11, 300, 4
+    R, N, C = 96, 300, 4
     E, ids, row_mask, sims, wp, bp, gagg, gz = _rand_case(D, R, A, D, N, C)
     Ec, wpc, bpc = E.clone().requires_grad_(True), wp.clone().requires_grad_(True), bp.clone().requires_grad_(True)
     edge = ((ids != 0) & row_mask.unsqueeze(-1)).float()
@@ -148,12 +149,12 @@ def test_mpn_gather_shared_ids_over_components():
 
 @pytest.mark.parametrize('D', [8, 64, 128])
 @pytest.mark.parametrize('mode', ['sim_col', 'per_edge', 'by_id'])
-@pytest.mark.parametrize('R', [150, 66000])
-def test_mpn_shared_random(D, mode, R):
+@pytest.mark.parametrize('R,A', [(150, 13), (150, 123), (66000, 13)])
+def test_mpn_shared_random(D, mode, R, A):
     """SRC_SHARED: P-border (ids -> column id-1) and structure (index list) anchors; a batch-sized
     row count (short row tiles x item chunks in the backward) and a shard-sized one (64-row tiles)."""
     ops = _ops()
-    A, N, C = 13, 200, 3
+    N, C = 200, 3
     E, _, row_mask, sims, wp, bp, gagg, gz = _rand_case(D + 1, R, A, D, N, C)
     g = torch.Generator().manual_seed(8)
     X = torch.randn(A, D, generator=g)
