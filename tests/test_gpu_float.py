@@ -129,6 +129,30 @@ def test_mpn_gather_random(D, A):
     assert float(Eg.grad[0].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize('A', [9, 70])
+def test_mpn_dense_random(A):
+    """SRC_DENSE (the reference-shaped (R, A, D) anchor tensor) on random inputs, with few and with many
+    anchors per row (the latter takes the anchor-split launch at batch size)."""
+    ops = _ops()
+    R, D, N, C = 90, 32, 250, 3
+    E, ids, row_mask, sims, wp, bp, gagg, gz = _rand_case(A, R, A, D, N, C)
+    edge_b = (ids != 0) & row_mask.unsqueeze(-1)
+    w = torch.gather(sims, 1, (ids - 1).clamp(min=0))
+    X = torch.nn.functional.embedding(ids, E, padding_idx=0)                     # (R, A, D)
+    Xc, wpc, bpc = X.clone().requires_grad_(True), wp.clone().requires_grad_(True), bp.clone().requires_grad_(True)
+    agg_r, z_r = _ref_mpn(Xc, edge_b.float(), w, wpc, bpc)
+    ((agg_r * gagg).sum() + (z_r * gz).sum()).backward()
+    Xg, wpg, bpg = X.to(DEV).requires_grad_(True), wp.to(DEV).requires_grad_(True), bp.to(DEV).requires_grad_(True)
+    agg, z = ops.mpn(Xg, wpg, bpg, sims.to(DEV), src=ops.SRC_DENSE, R=R, A=A, ids=ids.to(DEV),
+                     edge_mask=edge_b.to(torch.uint8).to(DEV))
+    ((agg * gagg.to(DEV)).sum() + (z * gz.to(DEV)).sum()).backward()
+    assert_close(agg, agg_r, 'agg')
+    assert_close(z, z_r, 'z')
+    assert_close(Xg.grad, Xc.grad, 'grad X')
+    assert_close(wpg.grad, wpc.grad, 'grad wp')
+    assert_close(bpg.grad, bpc.grad, 'grad bp')
+
+
 def test_mpn_gather_shared_ids_over_components():
     """P-internal: one id row per subgraph shared by its C components (id_div = C)."""
     ops = _ops()
