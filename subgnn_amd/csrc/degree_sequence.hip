@@ -27,6 +27,9 @@
 #ifndef DS_BIG
 #define DS_BIG 64
 #endif
+#ifndef DS_INFLIGHT
+#define DS_INFLIGHT 32          // 256-byte loads a wavefront keeps in flight while it streams a long list (4 / 8 / 16 / 32: 0.414 / 0.396 / 0.388 / 0.372 ms)
+#endif
 //           // members with at least this many neighbours are streamed on their own
 
 // Membership structure of a set: a 1024-slot table in LDS, one per wavefront.  The slot of an id
@@ -80,17 +83,17 @@ __device__ __forceinline__ void ds_count(const int32_t* __restrict__ col, const 
         // scalar registers and no wave reduction is needed at the end of a list
         int32_t tot = 0, st = 0;
         int32_t base = 0;
-        for (; base + 512 <= m_deg; base += 512) {       // full blocks: 8 x 256 B loads in flight
-            int32_t u[8];
+        for (; base + 64 * DS_INFLIGHT <= m_deg; base += 64 * DS_INFLIGHT) {   // full blocks: DS_INFLIGHT x 256 B loads in flight
+            int32_t u[DS_INFLIGHT];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) u[q] = list[base + q * 64 + lane];
+            for (int q = 0; q < DS_INFLIGHT; ++q) u[q] = list[base + q * 64 + lane];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
+            for (int q = 0; q < DS_INFLIGHT; ++q) {
                 tot += (int32_t)__popcll(__ballot(ds_probe<P1>(hash, u[q], k24, P) != 0));
                 if (SELF) st += (int32_t)__popcll(__ballot(u[q] == m_v));
             }
         }
-        if (base < m_deg) {                              // tail (< 512 entries): clamped loads,
+        for (; base < m_deg; base += 512) {              // tail (< 64 x DS_INFLIGHT entries) in blocks of 8 clamped loads:
             const int32_t last = m_deg - 1;              // out-of-range lanes get the never-stored key -1
             int32_t u[8];
 #pragma unroll
