@@ -61,6 +61,16 @@ int sgnn_degree_sequence(const int64_t* rowptr, const int32_t* col, int64_t nnz,
                          const int64_t* set_ptr, const int32_t* set_nodes, int64_t n_sets,
                          int64_t max_set_size, int sorted,
                          int32_t* out_internal, int32_t* out_external, const int32_t* set_order, void* stream);
+/* Same, for callers that also hold the CSR with every row's neighbour ids in ascending order
+ * (col_sorted, same rowptr; a simple graph: no id twice in a row).  Lists of >= 512 entries are then
+ * not streamed at all: every member of the set binary-searches its id in the list (log2(deg)
+ * dependent loads for the whole set instead of deg/64 wave loads and table probes) -- on scale-free
+ * graphs the hub lists carry most of the bytes.  Results are identical. */
+int sgnn_degree_sequence_sorted_rows(const int64_t* rowptr, const int32_t* col, const int32_t* col_sorted,
+                                     int64_t nnz, const int32_t* full_degree, const uint8_t* self_loops,
+                                     const int64_t* set_ptr, const int32_t* set_nodes, int64_t n_sets,
+                                     int64_t max_set_size, int sorted, int32_t* out_internal,
+                                     int32_t* out_external, const int32_t* set_order, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * a7  Connected components of induced subgraphs.

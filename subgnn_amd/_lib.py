@@ -32,6 +32,8 @@ SIGNATURES = {
     'sgnn_last_error': (ctypes.c_char_p, []),
     'sgnn_degree_sequence': (c_int, [c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_int, c_ptr, c_ptr,
                                      c_ptr, c_ptr]),
+    'sgnn_degree_sequence_sorted_rows': (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_int,
+                                                 c_ptr, c_ptr, c_ptr, c_ptr]),
     'sgnn_cc_embed_fwd_f16': (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_int, c_i64, c_ptr, c_ptr, c_ptr]),
     'sgnn_cc_labels': (c_int, [c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr]),
     'sgnn_cc_compact_stats': (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_ptr]),

@@ -27,6 +27,12 @@
 #ifndef DS_BIG
 #define DS_BIG 64
 #endif
+#ifndef DS_SEARCH
+#define DS_SEARCH 512           // lists at least this long are searched (sorted rows given) instead of streamed (256 / 512 / 1024 / 2048 with three lists per round: 0.215 / 0.210 / 0.213 / 0.229 ms; all streamed: 0.372)
+#endif
+#ifndef DS_WIDE
+#define DS_WIDE 0               // > 0: lists of at least 256 x DS_WIDE entries are read 16 bytes per lane, DS_WIDE loads in flight
+#endif
 #ifndef DS_INFLIGHT
 #define DS_INFLIGHT 32          // 256-byte loads a wavefront keeps in flight while it streams a long list (4 / 8 / 16 / 32: 0.414 / 0.396 / 0.388 / 0.372 ms)
 #endif
@@ -69,11 +75,68 @@ __device__ static inline int32_t ds_wave_sum(int32_t v) {
 // hits of every member's neighbour list in the set's table -> cnt (per lane = per member); SELF:
 // count the self-loop entries of each list here (the caller has no per-node self-loop table)
 template <bool P1, bool SELF>
-__device__ __forceinline__ void ds_count(const int32_t* __restrict__ col, const int32_t* hash, uint32_t k24, int P,
-                                         int lane, int32_t v, int32_t deg, uint32_t r0, int32_t& cnt, int32_t& selfc)
+__device__ __forceinline__ void ds_count(const int32_t* __restrict__ col, const int32_t* __restrict__ col_sorted,
+                                         const int32_t* hash, uint32_t k24, int P, int lane, int n, int32_t v,
+                                         bool dup, int32_t deg, uint32_t r0, int32_t& cnt, int32_t& selfc)
 {
-    // ---- phase A: members with >= 64 neighbours, one list at a time, 8 coalesced 256 B loads in flight ----
     uint64_t big = __ballot(deg >= DS_BIG);
+    // ---- phase A0: very long lists, when the caller has the rows in ascending order: the set is looked up
+    // IN the list instead of the list in the set.  Every member (one lane each) binary-searches its id in the
+    // list -- log2(deg) dependent 4-byte loads for the whole set, where streaming a 30k-entry hub list costs
+    // 470 wave loads and as many table probes.  (Simple graph: an id occurs at most once in a list.)
+    if (col_sorted != nullptr) {
+        uint64_t huge = __ballot(deg >= DS_SEARCH);
+        big &= ~huge;
+        // G = 64 / n lists are searched at a time: lane l works for list slot l / n as member l % n (a search
+        // is a chain of dependent loads; a set of 20 members keeps three chains going in its 64 lanes)
+        const int G = 64 / n;
+        const int slot = lane / n, idx = lane - slot * n;
+        const int32_t my_v = __shfl(v, idx);
+        const bool my_dup = __shfl((int)dup, idx) != 0;
+        while (huge) {
+            int m_of_slot = -1;                                   // the list this lane's slot searches
+            int taken = 0;
+            uint64_t rest = huge;
+            for (int gsl = 0; gsl < G && rest; ++gsl) {           // uniform: G and huge are
+                const int m = __ffsll((unsigned long long)rest) - 1;
+                rest &= rest - 1;
+                if (slot == gsl) m_of_slot = m;
+                ++taken;
+            }
+            huge = rest;
+            const bool act = slot < taken;
+            const int ms = act ? m_of_slot : 0;
+            const int32_t m_deg = act ? __shfl(deg, ms) : 0;
+            const int32_t* __restrict__ list = col_sorted + __shfl(r0, ms);
+            int32_t lo = 0, hi = m_deg;                           // lower bound of my_v in list[0, m_deg)
+            int steps = act ? 32 - __clz(m_deg) : 0;
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) { const int o = __shfl_xor(steps, d); steps = o > steps ? o : steps; }
+            for (int it = 0; it < steps; ++it) {
+                const int32_t mid = (lo + hi) >> 1;
+                const int32_t x = lo < hi ? list[mid] : 0;
+                const bool right = lo < hi && x < my_v;
+                lo = right ? mid + 1 : lo;
+                hi = (lo < hi && !right) ? mid : hi;
+            }
+            const bool found = act && lo < m_deg && list[lo < m_deg ? lo : 0] == my_v;
+            const uint64_t fm = __ballot(found && !my_dup);       // an id listed twice in the set counts once
+            const uint64_t fself = __ballot(found);
+            // lane m of the set reads the count of the slot that searched ITS list (the first lane of every
+            // slot knows which list the slot took)
+            int my_slot = -1;
+            for (int gsl = 0; gsl < taken; ++gsl) {
+                const int mm = __shfl(m_of_slot, gsl * n);
+                if (mm == lane) my_slot = gsl;
+            }
+            if (my_slot >= 0) {
+                const uint64_t range = (n >= 64 ? ~0ull : ((1ull << n) - 1ull)) << (my_slot * n);
+                cnt = (int32_t)__popcll(fm & range);
+                if (SELF) selfc = (int32_t)((fself >> (my_slot * n + lane)) & 1ull);
+            }
+        }
+    }
+    // ---- phase A: members with >= 64 neighbours, one list at a time, coalesced 256 B loads in flight ----
     while (big) {
         const int m = __ffsll((unsigned long long)big) - 1;
         big &= big - 1;
@@ -83,6 +146,39 @@ __device__ __forceinline__ void ds_count(const int32_t* __restrict__ col, const 
         // scalar registers and no wave reduction is needed at the end of a list
         int32_t tot = 0, st = 0;
         int32_t base = 0;
+#if DS_WIDE
+        // very long lists: 16 bytes per lane (1 KB per wave instruction) from the first 16-byte boundary on;
+        // the <= 3 entries before it and the remainder go through the 4-byte forms below
+        if (m_deg >= 64 * 4 * DS_WIDE + 3) {
+            const int32_t head = (int32_t)((4u - (__shfl(r0, m) & 3u)) & 3u);
+            if (head) {
+                const int32_t u0 = lane < head ? list[lane] : -1;
+                tot += (int32_t)__popcll(__ballot(ds_probe<P1>(hash, u0, k24, P) != 0));
+                if (SELF) st += (int32_t)__popcll(__ballot(u0 == m_v));
+                base = head;
+            }
+            const int4* __restrict__ list4 = reinterpret_cast<const int4*>(list + base);
+            const int32_t n4 = (m_deg - base) >> 2;
+            int32_t i4 = 0;
+            for (; i4 + 64 * DS_WIDE <= n4; i4 += 64 * DS_WIDE) {
+                int4 w[DS_WIDE];
+#pragma unroll
+                for (int q = 0; q < DS_WIDE; ++q) w[q] = list4[i4 + q * 64 + lane];
+#pragma unroll
+                for (int q = 0; q < DS_WIDE; ++q) {
+                    tot += (int32_t)__popcll(__ballot(ds_probe<P1>(hash, w[q].x, k24, P) != 0));
+                    tot += (int32_t)__popcll(__ballot(ds_probe<P1>(hash, w[q].y, k24, P) != 0));
+                    tot += (int32_t)__popcll(__ballot(ds_probe<P1>(hash, w[q].z, k24, P) != 0));
+                    tot += (int32_t)__popcll(__ballot(ds_probe<P1>(hash, w[q].w, k24, P) != 0));
+                    if (SELF) {
+                        st += (int32_t)__popcll(__ballot(w[q].x == m_v)) + (int32_t)__popcll(__ballot(w[q].y == m_v));
+                        st += (int32_t)__popcll(__ballot(w[q].z == m_v)) + (int32_t)__popcll(__ballot(w[q].w == m_v));
+                    }
+                }
+            }
+            base += i4 * 4;
+        }
+#endif
         for (; base + 64 * DS_INFLIGHT <= m_deg; base += 64 * DS_INFLIGHT) {   // full blocks: DS_INFLIGHT x 256 B loads in flight
             int32_t u[DS_INFLIGHT];
 #pragma unroll
@@ -168,7 +264,8 @@ __global__ __launch_bounds__(64 * DS_WAVES) __attribute__((amdgpu_waves_per_eu(D
     const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
     const int32_t* __restrict__ full_degree, const uint8_t* __restrict__ self_loops,
     const int64_t* __restrict__ set_ptr, const int32_t* __restrict__ set_nodes, int64_t n_sets,
-    int32_t* __restrict__ out_int, int32_t* __restrict__ out_ext, const int32_t* __restrict__ set_order)
+    int32_t* __restrict__ out_int, int32_t* __restrict__ out_ext, const int32_t* __restrict__ set_order,
+    const int32_t* __restrict__ col_sorted)
 {
     // one hash table per wavefront; a wavefront's LDS operations execute in issue order, so the
     // waves of a workgroup never need a workgroup barrier (they work on different sets)
@@ -192,6 +289,7 @@ __global__ __launch_bounds__(64 * DS_WAVES) __attribute__((amdgpu_waves_per_eu(D
         // ---- build the table: first multiplier under which no two members share a slot --------
         uint32_t k24 = ds_mult[0];
         int P = 1;
+        bool dup = false;
         for (int t = 0; t < DS_TRIES; ++t) {
             k24 = ds_mult[t];
 #pragma unroll
@@ -200,13 +298,14 @@ __global__ __launch_bounds__(64 * DS_WAVES) __attribute__((amdgpu_waves_per_eu(D
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             int chain = 0;
+            dup = false;
             if (lane < n) {
                 uint32_t h = ds_slot4(v, k24) >> 2;
                 const bool last_try = (t == DS_TRIES - 1);
                 while (true) {
                     ++chain;
                     const int32_t old = atomicCAS(&hash[h], 0, v);
-                    if (old == 0 || old == v) break;
+                    if (old == 0 || old == v) { dup = (old == v); break; }    // dup: another lane holds the same id
                     if (!last_try) { chain = 2; break; }     // collision: this multiplier is rejected
                     h = (h + 1) & (DS_HASH - 1);
                 }
@@ -221,11 +320,11 @@ __global__ __launch_bounds__(64 * DS_WAVES) __attribute__((amdgpu_waves_per_eu(D
         int32_t cnt = 0, selfc = 0;
         if (self_loops != nullptr) {
             if (lane < n) selfc = self_loops[v];
-            if (P <= 1) ds_count<true, false>(col, hash, k24, P, lane, v, deg, r0, cnt, selfc);
-            else ds_count<false, false>(col, hash, k24, P, lane, v, deg, r0, cnt, selfc);
+            if (P <= 1) ds_count<true, false>(col, col_sorted, hash, k24, P, lane, n, v, dup, deg, r0, cnt, selfc);
+            else ds_count<false, false>(col, col_sorted, hash, k24, P, lane, n, v, dup, deg, r0, cnt, selfc);
         } else {
-            if (P <= 1) ds_count<true, true>(col, hash, k24, P, lane, v, deg, r0, cnt, selfc);
-            else ds_count<false, true>(col, hash, k24, P, lane, v, deg, r0, cnt, selfc);
+            if (P <= 1) ds_count<true, true>(col, col_sorted, hash, k24, P, lane, n, v, dup, deg, r0, cnt, selfc);
+            else ds_count<false, true>(col, col_sorted, hash, k24, P, lane, n, v, dup, deg, r0, cnt, selfc);
         }
         cnt += selfc;                                        // a self loop counts twice (networkx)
         int32_t full = deg + selfc;
@@ -377,12 +476,12 @@ __global__ __launch_bounds__(DSB_THREADS) void degseq_block_kernel(
     }
 }
 
-extern "C" int sgnn_degree_sequence(const int64_t* rowptr, const int32_t* col, int64_t nnz,
-                                    const int32_t* full_degree, const uint8_t* self_loops,
-                                    const int64_t* set_ptr, const int32_t* set_nodes, int64_t n_sets,
-                                    int64_t max_set_size, int sorted,
-                                    int32_t* out_internal, int32_t* out_external, const int32_t* set_order,
-                                    void* stream)
+static int ds_run(const int64_t* rowptr, const int32_t* col, const int32_t* col_sorted, int64_t nnz,
+                  const int32_t* full_degree, const uint8_t* self_loops,
+                  const int64_t* set_ptr, const int32_t* set_nodes, int64_t n_sets,
+                  int64_t max_set_size, int sorted,
+                  int32_t* out_internal, int32_t* out_external, const int32_t* set_order,
+                  void* stream)
 {
     if (!rowptr || !col || !set_ptr || !set_nodes || !out_internal || n_sets < 0 || max_set_size <= 0)
         return SGNN_ERR_BAD_ARG;
@@ -397,7 +496,7 @@ extern "C" int sgnn_degree_sequence(const int64_t* rowptr, const int32_t* col, i
     const int grid = (int)(want < DS_GRID_CAP ? want : DS_GRID_CAP);
     const bool few = n_sets <= 4096;
 #define DS_LAUNCH(S, F) hipLaunchKernelGGL((degseq_wave_kernel<S, F>), dim3(grid), dim3(64 * DS_WAVES), 0, st, rowptr, col, \
-                                           full_degree, self_loops, set_ptr, set_nodes, n_sets, out_internal, out_external, set_order)
+                                           full_degree, self_loops, set_ptr, set_nodes, n_sets, out_internal, out_external, set_order, col_sorted)
     if (sorted) { if (few) DS_LAUNCH(true, true); else DS_LAUNCH(true, false); }
     else { if (few) DS_LAUNCH(false, true); else DS_LAUNCH(false, false); }
 #undef DS_LAUNCH
@@ -413,4 +512,25 @@ extern "C" int sgnn_degree_sequence(const int64_t* rowptr, const int32_t* col, i
         SGNN_CHECK_LAUNCH();
     }
     return SGNN_OK;
+}
+
+extern "C" int sgnn_degree_sequence(const int64_t* rowptr, const int32_t* col, int64_t nnz,
+                                    const int32_t* full_degree, const uint8_t* self_loops,
+                                    const int64_t* set_ptr, const int32_t* set_nodes, int64_t n_sets,
+                                    int64_t max_set_size, int sorted,
+                                    int32_t* out_internal, int32_t* out_external, const int32_t* set_order,
+                                    void* stream)
+{
+    return ds_run(rowptr, col, nullptr, nnz, full_degree, self_loops, set_ptr, set_nodes, n_sets, max_set_size, sorted,
+                  out_internal, out_external, set_order, stream);
+}
+
+extern "C" int sgnn_degree_sequence_sorted_rows(const int64_t* rowptr, const int32_t* col, const int32_t* col_sorted,
+                                                int64_t nnz, const int32_t* full_degree, const uint8_t* self_loops,
+                                                const int64_t* set_ptr, const int32_t* set_nodes, int64_t n_sets,
+                                                int64_t max_set_size, int sorted, int32_t* out_internal,
+                                                int32_t* out_external, const int32_t* set_order, void* stream)
+{
+    return ds_run(rowptr, col, col_sorted, nnz, full_degree, self_loops, set_ptr, set_nodes, n_sets, max_set_size, sorted,
+                  out_internal, out_external, set_order, stream);
 }

@@ -178,18 +178,27 @@ def heaviest_first(g, sets):
     return torch.argsort(work, descending=True).to(torch.int32).contiguous()
 
 
-def degree_sequence(g, sets, sort=True, use_degree_dict=True, want_external=True, use_self_loop_table=True, order=None):
+def degree_sequence(g, sets, sort=True, use_degree_dict=True, want_external=True, use_self_loop_table=True, order=None,
+                    search_long_lists=True):
     """gamma.get_degree_sequence for every set at once -> (internal, external) int32 flat
-    tensors aligned with ``sets.nodes`` (each set's slice sorted ascending if ``sort``)."""
+    tensors aligned with ``sets.nodes`` (each set's slice sorted ascending if ``sort``).
+    ``search_long_lists``: hand the kernel the row-sorted CSR as well, so that hub lists are searched
+    for the set's members instead of streamed (same results; off = stream everything)."""
     lib = _lib.load()
     n_tot = sets.nodes.numel()
     out_i = torch.empty(n_tot, dtype=torch.int32, device=g.device)
     out_e = torch.empty(n_tot, dtype=torch.int32, device=g.device) if want_external else None
     fd = g.full_degree if use_degree_dict else None
     sl = g.self_loops if use_self_loop_table else None
-    check(lib.sgnn_degree_sequence(_ptr(g.rowptr), _ptr(g.col), g.nnz, _ptr(fd), _ptr(sl), _ptr(sets.ptr),
-                                   _ptr(sets.nodes), sets.n, max(sets.max_len, 1), 1 if sort else 0, _ptr(out_i),
-                                   _ptr(out_e), _ptr(order), _stream()), 'sgnn_degree_sequence')
+    if search_long_lists:
+        check(lib.sgnn_degree_sequence_sorted_rows(_ptr(g.rowptr), _ptr(g.col), _ptr(g.col_sorted), g.nnz, _ptr(fd), _ptr(sl),
+                                                   _ptr(sets.ptr), _ptr(sets.nodes), sets.n, max(sets.max_len, 1),
+                                                   1 if sort else 0, _ptr(out_i), _ptr(out_e), _ptr(order), _stream()),
+              'sgnn_degree_sequence_sorted_rows')
+    else:
+        check(lib.sgnn_degree_sequence(_ptr(g.rowptr), _ptr(g.col), g.nnz, _ptr(fd), _ptr(sl), _ptr(sets.ptr),
+                                       _ptr(sets.nodes), sets.n, max(sets.max_len, 1), 1 if sort else 0, _ptr(out_i),
+                                       _ptr(out_e), _ptr(order), _stream()), 'sgnn_degree_sequence')
     return out_i, out_e
 
 

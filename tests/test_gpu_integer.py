@@ -31,7 +31,7 @@ def _rand_graph(n, m, seed):
     rng = np.random.default_rng(seed)
     edges = list(Gx.edges())
     edges = [edges[i] for i in rng.permutation(len(edges))]
-    edges += [(3, 3), (10, 10)]                           # self loops
+    edges += [(3, 3), (10, 10), (0, 0)]                   # self loops (one of them on a hub whose list is searched, not streamed)
     edges += [(0, i) for i in range(1, min(n, 1300))] + [(7, i) for i in range(8, min(n, 700))]   # hubs (deg >= 256 path)
     return OG.from_edge_pairs(edges)
 
@@ -90,6 +90,10 @@ def test_degree_sequence_random(sizes):
     a0, b0 = ops.degree_sequence(dg, r, use_degree_dict=False)
     a1, b1 = ops.degree_sequence(dg, r, use_degree_dict=False, order=hf)
     assert torch.equal(a0, a1) and torch.equal(b0, b1)
+    for table in (True, False):                          # hub lists searched for the members vs streamed
+        a2, b2 = ops.degree_sequence(dg, r, use_degree_dict=False, use_self_loop_table=table, search_long_lists=False)
+        a3, b3 = ops.degree_sequence(dg, r, use_degree_dict=False, use_self_loop_table=table, search_long_lists=True)
+        assert torch.equal(a2, a3) and torch.equal(b2, b3)
     for srt in (True, False):
         for table in (True, False):        # self loops from the per-node table / counted while streaming
             oi, oe = ops.degree_sequence(dg, r, sort=srt, use_degree_dict=False, use_self_loop_table=table)

@@ -83,3 +83,13 @@ if len(sys.argv) > 2 and sys.argv[2] == 'orders':
         o2[is_h] = heavy[: int(is_h.sum())]
         o2[~is_h] = desc[nh:][: int((~is_h).sum())]
         print('every %d-th position heavy, next-heaviest between' % k, tm(o2))
+
+if len(sys.argv) > 2 and sys.argv[2] == 'search':
+    def tm(**kw):
+        ops.degree_sequence(g, sets, order=order, **kw); torch.cuda.synchronize(); t = time.perf_counter()
+        for _ in range(reps): ops.degree_sequence(g, sets, order=order, **kw)
+        torch.cuda.synchronize(); return (time.perf_counter() - t) / reps * 1e3
+    a = ops.degree_sequence(g, sets, order=order, search_long_lists=False)
+    b = ops.degree_sequence(g, sets, order=order, search_long_lists=True)
+    print('same results', bool(torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])))
+    print('streamed', tm(search_long_lists=False), 'ms;  long lists searched', tm(search_long_lists=True), 'ms')
