@@ -259,7 +259,9 @@ __device__ __forceinline__ void ds_count(const int32_t* __restrict__ col, const 
 #ifndef DS_MIN_WAVES
 #define DS_MIN_WAVES 5         // wavefronts per SIMD the register allocation aims for (86 VGPRs -> 5); 4 / 5 / 6 / 7 / 8 measured 0.392 / 0.391 / 0.396 / 0.398 / 0.401 ms: not occupancy-bound
 #endif
-template <bool SORTED, bool FEW = false>
+// SEARCH: instantiation given the row-sorted CSR (long lists searched) -- the same code with col_sorted == nullptr
+// would do, but profiles should tell the two forms of the launch apart.
+template <bool SORTED, bool FEW = false, bool SEARCH = false>
 __global__ __launch_bounds__(64 * DS_WAVES) __attribute__((amdgpu_waves_per_eu(DS_MIN_WAVES))) void degseq_wave_kernel(
     const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
     const int32_t* __restrict__ full_degree, const uint8_t* __restrict__ self_loops,
@@ -320,11 +322,11 @@ __global__ __launch_bounds__(64 * DS_WAVES) __attribute__((amdgpu_waves_per_eu(D
         int32_t cnt = 0, selfc = 0;
         if (self_loops != nullptr) {
             if (lane < n) selfc = self_loops[v];
-            if (P <= 1) ds_count<true, false>(col, col_sorted, hash, k24, P, lane, n, v, dup, deg, r0, cnt, selfc);
-            else ds_count<false, false>(col, col_sorted, hash, k24, P, lane, n, v, dup, deg, r0, cnt, selfc);
+            if (P <= 1) ds_count<true, false>(col, SEARCH ? col_sorted : nullptr, hash, k24, P, lane, n, v, dup, deg, r0, cnt, selfc);
+            else ds_count<false, false>(col, SEARCH ? col_sorted : nullptr, hash, k24, P, lane, n, v, dup, deg, r0, cnt, selfc);
         } else {
-            if (P <= 1) ds_count<true, true>(col, col_sorted, hash, k24, P, lane, n, v, dup, deg, r0, cnt, selfc);
-            else ds_count<false, true>(col, col_sorted, hash, k24, P, lane, n, v, dup, deg, r0, cnt, selfc);
+            if (P <= 1) ds_count<true, true>(col, SEARCH ? col_sorted : nullptr, hash, k24, P, lane, n, v, dup, deg, r0, cnt, selfc);
+            else ds_count<false, true>(col, SEARCH ? col_sorted : nullptr, hash, k24, P, lane, n, v, dup, deg, r0, cnt, selfc);
         }
         cnt += selfc;                                        // a self loop counts twice (networkx)
         int32_t full = deg + selfc;
@@ -495,11 +497,13 @@ static int ds_run(const int64_t* rowptr, const int32_t* col, const int32_t* col_
     const int64_t want = (n_sets + DS_WAVES - 1) / DS_WAVES;
     const int grid = (int)(want < DS_GRID_CAP ? want : DS_GRID_CAP);
     const bool few = n_sets <= 4096;
-#define DS_LAUNCH(S, F) hipLaunchKernelGGL((degseq_wave_kernel<S, F>), dim3(grid), dim3(64 * DS_WAVES), 0, st, rowptr, col, \
+#define DS_LAUNCH2(S, F, X) hipLaunchKernelGGL((degseq_wave_kernel<S, F, X>), dim3(grid), dim3(64 * DS_WAVES), 0, st, rowptr, col, \
                                            full_degree, self_loops, set_ptr, set_nodes, n_sets, out_internal, out_external, set_order, col_sorted)
+#define DS_LAUNCH(S, F) do { if (col_sorted) DS_LAUNCH2(S, F, true); else DS_LAUNCH2(S, F, false); } while (0)
     if (sorted) { if (few) DS_LAUNCH(true, true); else DS_LAUNCH(true, false); }
     else { if (few) DS_LAUNCH(false, true); else DS_LAUNCH(false, false); }
 #undef DS_LAUNCH
+#undef DS_LAUNCH2
     SGNN_CHECK_LAUNCH();
     if (max_set_size > 64) {
         const int gridb = (int)(n_sets < 256 * 4 ? n_sets : 256 * 4);

@@ -14,7 +14,7 @@ p = rows[idx[-2]:idx[-1]]
 ours = ('cc_labels', 'cc_compact', 'cc_embed', 'choice_ragged', 'msbfs', 'triangular', 'degseq', 'khop', 'dtw_', 'mpn_',
         'masked_sum', 'sample_anchors', 'patch_in_border', 'attn_scores', 'sp_sim', 'min_hops', 'sort_sets')
 marks = [('triangular_walks', 'patches'), ('msbfs_init', 'position'), ('triangular_walks', 'walks'), ('sort_sets', 'border'),
-         ('khop_border', 'border'), ('degseq_wave_kernel<true, false>', 'degseq+dtw_prep'), ('dtw_pyramid', 'dtw'),
+         ('khop_border', 'border'), ('degseq_wave_kernel<true, false', 'degseq+dtw_prep'), ('dtw_pyramid', 'dtw'),
          ('cc_embed_fwd_kernel', 'fwd+bwd+opt')]
 order = ['components', 'patches', 'position', 'walks', 'border', 'degseq+dtw_prep', 'dtw', 'fwd+bwd+opt']
 stage = 'components'
