@@ -162,6 +162,10 @@ class DeviceGraph:
         n_self = np.bincount(rows[col[:len(rows)] == rows], minlength=self.max_id + 1) if len(rows) else \
             np.zeros(self.max_id + 1, dtype=np.int64)
         self.self_loops = torch.from_numpy(np.minimum(n_self, 255).astype(np.uint8)).to(device)
+        # no id twice in a row: what lets the degree-sequence kernel search long lists instead of streaming
+        # them (a repeated entry would be counted once instead of twice)
+        rs = rows[order] if len(rows) else rows
+        self.simple_rows = not bool(len(col_sorted) > 1 and np.any((col_sorted[1:] == col_sorted[:-1]) & (rs[1:] == rs[:-1])))
 
 
 # ---------------------------------------------------------------------------------------
@@ -190,7 +194,7 @@ def degree_sequence(g, sets, sort=True, use_degree_dict=True, want_external=True
     out_e = torch.empty(n_tot, dtype=torch.int32, device=g.device) if want_external else None
     fd = g.full_degree if use_degree_dict else None
     sl = g.self_loops if use_self_loop_table else None
-    if search_long_lists:
+    if search_long_lists and getattr(g, 'simple_rows', False):
         check(lib.sgnn_degree_sequence_sorted_rows(_ptr(g.rowptr), _ptr(g.col), _ptr(g.col_sorted), g.nnz, _ptr(fd), _ptr(sl),
                                                    _ptr(sets.ptr), _ptr(sets.nodes), sets.n, max(sets.max_len, 1),
                                                    1 if sort else 0, _ptr(out_i), _ptr(out_e), _ptr(order), _stream()),

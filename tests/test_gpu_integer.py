@@ -716,3 +716,21 @@ def test_patch_node_views_both_forms(monkeypatch):
     assert aps.patch_node_views(ids).to_lists() == want
     monkeypatch.setattr(aps, 'VIEW_PAIRWISE_MAX', 0)                       # force the sort-based form
     assert aps.patch_node_views(ids).to_lists() == want
+
+
+def test_degree_sequence_multigraph_rows_are_streamed():
+    """A CSR with an id twice in a row is not a simple graph: the search form of the degree-sequence
+    launch (which would count the repeated neighbour once) must not be taken."""
+    ops = _ops()
+    n = 700
+    rowptr = np.zeros(n + 2, dtype=np.int64)
+    hub = list(range(2, n + 1)) + [5, 5]                 # node 1: neighbours 2..n, and 5 two more times
+    cols = [hub] + [[1] for _ in range(2, n + 1)]
+    cols[5 - 1] = [1, 1, 1]                              # node 5 lists the hub three times (kept symmetric)
+    col = np.concatenate([np.array(c, dtype=np.int32) for c in cols])
+    rowptr[2:] = np.cumsum([len(c) for c in cols])
+    g = ops.DeviceGraph(rowptr, col, np.arange(1, n + 1, dtype=np.int32), DEV)
+    assert not g.simple_rows
+    r = ops.Ragged.from_lists([[1, 5, 9], [5]], DEV)
+    oi, oe = ops.degree_sequence(g, r, sort=False, use_degree_dict=False)
+    assert ops.Ragged(r.ptr, oi).to_lists() == [[4, 3, 1], [0]]          # hub: 5 (x3) + 9; node 5: hub x3; node 9: hub
