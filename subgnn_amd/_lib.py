@@ -66,6 +66,7 @@ SIGNATURES = {
     'sgnn_dtw_force_general': (c_int, [c_int]),
     'sgnn_dtw_similarity': (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_i64, c_i64, c_int, c_ptr, c_ptr, c_ptr,
                                     c_i64, c_ptr]),
+    'sgnn_dtw_order_keys': (c_int, [c_ptr, c_ptr, c_i64, c_ptr, c_ptr]),
     'sgnn_dtw_similarity_live': (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_i64, c_i64, c_int, c_ptr, c_ptr, c_ptr,
                                          c_ptr, c_i64, c_ptr]),
     'sgnn_cc_embed_fwd': (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_int, c_i64, c_ptr, c_ptr, c_ptr]),

@@ -1069,6 +1069,36 @@ __global__ __launch_bounds__(DTW_THREADS, MINB) void dtw_similarity_reg_kernel(
     }
 }
 
+// Processing-order key of the x rows of a DTW call: (length, the series sampled at its start, thirds and
+// end), saturating fields of 12 | 12 | 12 | 13 | 14 bits.  Rows are sorted degree sequences; sorting them by
+// this key puts series of similar shape side by side, so that the lanes of a wavefront sweep similar
+// windows (8.9 ms unordered, 7.5 ms in this order on the benchmark's external side).  One launch
+// instead of ~40 element-wise ones.
+__global__ void dtw_order_keys_kernel(const int64_t* __restrict__ x_ptr, const int32_t* __restrict__ x_val, int64_t n_x,
+                                      int64_t* __restrict__ keys)
+{
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= n_x) return;
+    const int64_t b = x_ptr[i], len = x_ptr[i + 1] - b;
+    int64_t key = 0;
+    if (len > 0) {
+        const int64_t q0 = x_val[b], q1 = x_val[b + len / 3], q2 = x_val[b + (2 * len) / 3], q3 = x_val[b + len - 1];
+        auto sat = [](int64_t v, int64_t m) { return v < 0 ? (int64_t)0 : (v > m ? m : v); };
+        key = (sat(len, 0xFFF) << 51) | (sat(q0, 0xFFF) << 39) | (sat(q1, 0xFFF) << 27) | (sat(q2, 0x1FFF) << 14) | sat(q3, 0x3FFF);
+    }
+    keys[i] = key;
+}
+
+extern "C" int sgnn_dtw_order_keys(const int64_t* x_ptr, const int32_t* x_val, int64_t n_x, int64_t* out_keys, void* stream)
+{
+    if (!x_ptr || !x_val || !out_keys || n_x < 0) return SGNN_ERR_BAD_ARG;
+    if (n_x == 0) return SGNN_OK;
+    hipLaunchKernelGGL(dtw_order_keys_kernel, dim3((unsigned)((n_x + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x_ptr,
+                       x_val, n_x, out_keys);
+    SGNN_CHECK_LAUNCH();
+    return SGNN_OK;
+}
+
 static int g_dtw_force_general = 0;
 /* test hook: 1 = always take the general (workspace-resident) kernel, 0 = pick by size */
 extern "C" int sgnn_dtw_force_general(int on) { const int old = g_dtw_force_general; g_dtw_force_general = on; return old; }

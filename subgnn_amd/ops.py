@@ -576,20 +576,13 @@ def dtw_similarity(x_ptr, x_val, max_x, y_ptr, y_val, max_y, tie_order=0, order_
     if order is not None:                                   # caller's processing order (tuning)
         order = order.to(torch.int32).contiguous()
     elif order_rows and nx > 64:
-        lens = x_ptr[1:] - x_ptr[:-1]
-        last = x_val.numel() - 1
-        live = lens > 0
-
-        def at(off):
-            return x_val[(x_ptr[:-1] + off).clamp(max=last)].long() * live
-
         # (length, then the series sampled at its start, thirds and end): rows are sorted degree
         # sequences, four quantiles place a series' shape well enough that the lanes of a wavefront
-        # sweep similar windows -- packed into one int64 key (12 | 12 | 12 | 13 | 14 bits, saturating),
-        # no host round trip.  Measured on the benchmark's external side: unordered 8.9 ms,
-        # (length, median, sum) 8.1 ms, this key 7.5 ms, full lexicographic order 7.9 ms.
-        key = ((lens.clamp(max=0xFFF) << 51) | (at(0).clamp(max=0xFFF) << 39) | (at(lens // 3).clamp(max=0xFFF) << 27)
-               | (at((2 * lens) // 3).clamp(max=0x1FFF) << 14) | at((lens - 1).clamp(min=0)).clamp(max=0x3FFF))
+        # sweep similar windows -- one int64 key per row (sgnn_dtw_order_keys), no host round trip.
+        # Measured on the benchmark's external side: unordered 8.9 ms, (length, median, sum) 8.1 ms,
+        # this key 7.5 ms, full lexicographic order 7.9 ms.
+        key = torch.empty(nx, dtype=torch.int64, device=x_ptr.device)
+        check(lib.sgnn_dtw_order_keys(_ptr(x_ptr), _ptr(x_val), nx, _ptr(key), _stream()), 'sgnn_dtw_order_keys')
         order = torch.argsort(key).to(torch.int32).contiguous()
     wsb = lib.sgnn_dtw_workspace_bytes(nx, max_x, ny, max_y)
     ws = torch.empty(wsb // 8 + 1, dtype=torch.int64, device=x_ptr.device)
