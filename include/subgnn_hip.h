@@ -394,6 +394,14 @@ int sgnn_masked_sum_fwd(const float* x, const uint8_t* mask, int64_t B, int64_t 
 int sgnn_masked_sum_bwd(const float* grad_out, const uint8_t* mask, int64_t B, int64_t C, int64_t H,
                         float* grad_x, void* stream);
 
+/* ---------------------------------------------------------------------------------------
+ * Measurement aid (no reference counterpart): streaming copy of n_bytes with 4 or 16 bytes per lane.
+ * The rocprofv3 memory-side counters (FETCH_SIZE / WRITE_SIZE) are calibrated on it -- a known byte
+ * count in the access width of the CSR gather -- before they are read as HBM traffic of
+ * sgnn_degree_sequence (tools/degseq_hbm_probe.py, bench.py roofline.traffic).
+ * ------------------------------------------------------------------------------------- */
+int sgnn_probe_stream_copy(const void* src, void* dst, int64_t n_bytes, int bytes_per_lane, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -79,6 +79,7 @@ SIGNATURES = {
     'sgnn_lstm_bwd': (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_ptr, c_ptr]),
     'sgnn_masked_sum_fwd': (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_i64, c_ptr, c_ptr]),
     'sgnn_masked_sum_bwd': (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_i64, c_ptr, c_ptr]),
+    'sgnn_probe_stream_copy': (c_int, [c_ptr, c_ptr, c_i64, c_int, c_ptr]),
 }
 
 ERRORS = {-1: 'SGNN_ERR_BAD_ARG', -2: 'SGNN_ERR_SET_TOO_LARGE', -3: 'SGNN_ERR_NNZ_TOO_LARGE',

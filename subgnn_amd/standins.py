@@ -1,0 +1,148 @@
+"""Stand-in datasets for the BASELINE.json configurations whose real data is not available offline
+(PPI-BP, HPO-METAB, EM-USER: a Dropbox link, reference README.md:24) plus the reference's own
+DENSITY recipe at its published scale.  Graph statistics as quoted in SURVEY.md section 8; every
+result produced from them is labelled "stand-in".  Everything is written in the reference's on-disk
+formats (edge_list.txt, subgraphs.pth, *_embeddings.pth; graph metrics by
+precompute_graph_metrics.calculate_stats) so that the drop-in ``SubGNN(hparams, **dataset_paths())``
+constructor reads them like real data.
+
+  density_n  configs[0]  DENSITY recipe (prepare_dataset.py) BA n=1000 m=5, 250 BFS subgraphs x 20
+                         nodes; best_model_hyperparameters/density/N_density_hyperparams.json
+                         (neighbourhood channel only, 5 layers)
+  ppi_bp     configs[1]  BA n=17 080 m=19 (~322 k edges), 1 591 subgraphs of ~10 nodes in ~7 pieces;
+                         train.py:109-148 hyper-parameters (all three channels, B=64, D=128)
+  hpo_metab  configs[2]  BA n=14 587 m=222 (~3.0 M edges), 2 400 subgraphs of ~14 nodes in 1-2
+                         pieces; best_model_hyperparameters/hpo_metab/hyperparams.json with all
+                         three channels on (4 layers, 360 structure patches: DTW stressed)
+  em_user    configs[4]  BA n=57 333 m=80 (~4.5 M edges), 324 subgraphs of ~155 nodes in ~52 pieces;
+                         best_model_hyperparameters/em_user/hyperparams.json (k=2 border, B=32,
+                         trainable_cc) with all three channels on, fp16-stored table; the dense
+                         (N, N) float64 hop matrix would be 26 GB -> hotpath.prepare_sparse
+"""
+import os
+
+import numpy as np
+import torch
+
+_COMMON = {"max_epochs": 200, "structure_patch_type": "triangular_random_walk", "lstm_aggregator": "last",
+           "n_processes": 4, "resample_anchor_patches": False, "freeze_node_embeds": False, "use_mpn_projection": True,
+           "print_train_times": False, "compute_similarities": True, "set2set": False, "ff_attn": False,
+           "linear_hidden_dim_1": 64, "linear_hidden_dim_2": 32, "max_sim_epochs": 5, "embedding_type": "gin",
+           "use_neighborhood": True, "use_structure": True, "use_position": True, "node_embed_size": 128}
+
+H1 = {  # reference best_model_hyperparameters/density/N_density_hyperparams.json (+ the two config-file keys)
+    "max_epochs": 200, "use_neighborhood": True, "use_structure": False, "use_position": False, "seed": 0,
+    "node_embed_size": 32, "structure_patch_type": "triangular_random_walk", "lstm_aggregator": "last",
+    "n_processes": 4, "resample_anchor_patches": False, "freeze_node_embeds": False, "use_mpn_projection": True,
+    "print_train_times": False, "compute_similarities": True, "batch_size": 64,
+    "learning_rate": 0.00025922124890367574, "grad_clip": 0.4827462116072751, "n_layers": 5,
+    "neigh_sample_border_size": 2, "n_anchor_patches_pos_out": 99, "n_anchor_patches_pos_in": 53,
+    "n_anchor_patches_N_in": 20, "n_anchor_patches_N_out": 37, "n_anchor_patches_structure": 28,
+    "linear_hidden_dim_1": 64, "linear_hidden_dim_2": 32, "n_triangular_walks": 6, "random_walk_len": 20,
+    "sample_walk_len": 20, "rw_beta": 0.31289948259603506, "lstm_dropout": 0.00382614656521465,
+    "lin_dropout": 0.09405144951216626, "lstm_n_layers": 2, "cc_aggregator": "sum", "trainable_cc": False,
+    "max_sim_epochs": 5, "embedding_type": "gin",
+}
+
+H2 = {  # reference SubGNN/train.py:109-148 get_hyperparams (+ the two keys the config files add)
+    "max_epochs": 200, "use_neighborhood": True, "use_structure": True, "use_position": True, "seed": 3,
+    "node_embed_size": 128, "structure_patch_type": "triangular_random_walk", "lstm_aggregator": "last",
+    "n_processes": 4, "resample_anchor_patches": False, "freeze_node_embeds": False, "use_mpn_projection": True,
+    "print_train_times": False, "compute_similarities": True, "sample_walk_len": 50, "n_triangular_walks": 5,
+    "random_walk_len": 10, "rw_beta": 0.65, "set2set": False, "ff_attn": False, "batch_size": 64,
+    "learning_rate": 0.00025420762516423353, "grad_clip": 0.2160947806012501, "n_layers": 1,
+    "neigh_sample_border_size": 1, "n_anchor_patches_pos_out": 123, "n_anchor_patches_pos_in": 34,
+    "n_anchor_patches_N_in": 19, "n_anchor_patches_N_out": 69, "n_anchor_patches_structure": 37,
+    "linear_hidden_dim_1": 64, "linear_hidden_dim_2": 32, "lstm_dropout": 0.21923625197416907, "lstm_n_layers": 2,
+    "lin_dropout": 0.04617609616314509, "cc_aggregator": "max", "trainable_cc": True, "auto_lr_find": True,
+    "max_sim_epochs": 5, "embedding_type": "gin",
+}
+
+
+def _ppi_pieces(rng):
+    return [int(s) for s in rng.permutation([1, 1, 1, 1, 1, 2, 3])[:int(rng.integers(5, 8))]]
+
+
+PRESETS = {
+    'density_n': dict(recipe='density', n=1000, n_sub=250, D=32, sparse=False, hp=H1),
+    'ppi_bp': dict(n=17080, m=19, n_sub=1591, n_classes=6, D=128, sparse=False, pieces=_ppi_pieces, hp=H2),
+    'hpo_metab': dict(
+        n=14587, m=222, n_sub=2400, n_classes=6, D=128, sparse=False,
+        pieces=lambda rng: [10, 4] if rng.random() < 0.6 else [14],
+        hp=dict(_COMMON, **{
+            "seed": 0, "sample_walk_len": 50, "n_triangular_walks": 5, "random_walk_len": 10, "rw_beta": 0.65,
+            "batch_size": 64, "learning_rate": 0.0003658242069498871, "grad_clip": 0.26758489792349655, "n_layers": 4,
+            "neigh_sample_border_size": 2, "n_anchor_patches_pos_out": 90, "n_anchor_patches_pos_in": 56,
+            "n_anchor_patches_N_in": 13, "n_anchor_patches_N_out": 34, "n_anchor_patches_structure": 18,
+            "lstm_dropout": 0.09909551715384933, "lstm_n_layers": 2, "lin_dropout": 0.21096188558408646,
+            "cc_aggregator": "sum", "trainable_cc": False})),
+    'em_user': dict(
+        n=57333, m=80, n_sub=324, n_classes=2, D=128, sparse=True,
+        pieces=lambda rng: [int(rng.integers(40, 60)), int(rng.integers(30, 50))] + [1] * int(rng.integers(40, 56))
+        + [int(rng.integers(2, 5)) for _ in range(4)],
+        hp=dict(_COMMON, **{
+            "seed": 160761, "batch_size": 32, "learning_rate": 0.0007225432908901084, "grad_clip": 0.13742538368745078,
+            "n_layers": 1, "neigh_sample_border_size": 2, "n_anchor_patches_pos_out": 77, "n_anchor_patches_pos_in": 48,
+            "n_anchor_patches_N_in": 16, "n_anchor_patches_N_out": 32, "n_anchor_patches_structure": 35,
+            "n_triangular_walks": 10, "random_walk_len": 23, "sample_walk_len": 22, "rw_beta": 0.1816027331132596,
+            "lstm_dropout": 0.01599628663889252, "lin_dropout": 0.003486968525571843, "lstm_n_layers": 1,
+            "cc_aggregator": "sum", "trainable_cc": True, "structure_similarity_fn": "dtw",
+            "embedding_dtype": "fp16"})),          # configs[4]: "fp16 embeddings"
+}
+
+
+def write_standin(root, name, seed=7):
+    """Write the stand-in dataset ``name`` under ``root``/<name>_standin -> (directory, #edges)."""
+    from . import synthetic
+    P = PRESETS[name]
+    d = os.path.join(str(root), name + '_standin')
+    if P.get('recipe'):
+        from . import prepare_dataset as pd
+        out, info = pd.write_dataset(d, P['recipe'], seed=42, embed_dim=P['D'], n=P['n'], n_subgraphs=P['n_sub'])
+        with open(os.path.join(str(out), 'edge_list.txt')) as f:
+            n_edges = sum(1 for line in f if line.strip())
+        return str(out), n_edges
+    os.makedirs(os.path.join(d, 'similarities'), exist_ok=True)
+    n, m, n_sub = P['n'], P['m'], P['n_sub']
+    edges = synthetic.barabasi_albert_edges(n, m, seed)
+    rowptr, col = synthetic.sorted_csr(edges, n)
+    und = np.unique(np.sort(edges, axis=1), axis=0)
+    np.savetxt(os.path.join(d, 'edge_list.txt'), und, fmt='%d')
+    rng = np.random.default_rng(seed)
+    lines = []
+    for i in range(n_sub):
+        nodes = []
+        for size in P['pieces'](rng):
+            nodes.extend(synthetic.bfs_subgraphs(rowptr, col, 1, int(size), int(rng.integers(1 << 30)))[0])
+        nodes = list(dict.fromkeys(nodes))
+        sp = 'train' if i < int(0.8 * n_sub) else ('val' if i < int(0.9 * n_sub) else 'test')
+        lines.append('-'.join(str(v - 1) for v in nodes) + '\t' + str(i % P['n_classes']) + '\t' + sp + '\t\n')
+    with open(os.path.join(d, 'subgraphs.pth'), 'w') as f:
+        f.write(''.join(lines))
+    torch.save(torch.randn(n, P['D'], generator=torch.Generator().manual_seed(seed)),
+               os.path.join(d, 'gin_embeddings.pth'))
+    return d, len(und)
+
+
+def build_model(root, name, hp_over=None, device=None, prepare=True):
+    """Write the stand-in, its graph metrics (GPU precompute) and return the prepared drop-in model:
+    dense reference-shaped ``prepare_data`` or, for the presets whose (N, N) matrices cannot exist,
+    ``hotpath.prepare_sparse`` on the train and val splits."""
+    from . import config, hotpath, precompute_graph_metrics as pgm
+    from .SubGNN import SubGNN, dataset_paths
+    P = PRESETS[name]
+    d, n_edges = write_standin(root, name)
+    pgm.calculate_stats(d, device, shortest_paths=not P['sparse'], ego=not P['sparse'])
+    config.PROJECT_ROOT = str(root)
+    hp = dict(P['hp'])
+    if hp_over:
+        hp.update(hp_over)
+    torch.manual_seed(3)
+    model = SubGNN(hp, **dataset_paths(os.path.basename(d)))
+    if prepare:
+        if P['sparse']:
+            for sp in ('val', 'train'):
+                hotpath.prepare_sparse(model, sp)
+        else:
+            model.prepare_data()
+    return model, d, n_edges

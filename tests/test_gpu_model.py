@@ -203,3 +203,68 @@ def test_precompute_graph_metrics(golden, tmp_path):
     assert _json.load(open(d / 'degree_sequence.txt')) == ref_deg
     got = _json.load(open(d / 'ego_graphs.txt'))
     assert {k: sorted(v) for k, v in got.items()} == {k: sorted(v) for k, v in ref_ego.items()}
+
+
+def _golden_prepared(m, g, sp='train'):
+    """The reference's own prepared tensors (its component order is CPython-set order, so batches of
+    the product's own prepare_data cannot be compared row by row) put into the model."""
+    d = lambda x: T(x).to(DEV)
+    hp = m.hparams
+    L = hp['n_layers']
+    m.train_cc_ids = d(g['g2_cc_ids_train'])
+    m.train_N_border = d(g['g3_border_train'])
+    m.train_neigh_pos_similarities = d(g['g4_np_sim_train'])
+    m.train_int_struc_similarities = d(g['g7_int_struc_sim_train'])
+    m.train_bor_struc_similarities = d(g['g7_bor_struc_sim_train'])
+    m.anchors_neigh_int = {'train': {l: d(g['g8_N_int_train_%d' % l]) for l in range(L)}}
+    m.anchors_neigh_border = {'train': {l: d(g['g8_N_bor_train_%d' % l]) for l in range(L)}}
+    m.anchors_pos_int = {'train': {l: d(g['g8_P_int_train_%d' % l]) for l in range(L)}}
+    m.anchors_pos_ext = {l: d(g['g8_P_ext_%d' % l]) for l in range(L)}
+    m.anchors_structure = {l: (d(g['g8_S_patches_%d' % l]), [int(i) for i in g['g8_S_idx_%d' % l]],
+                               d(g['g8_S_int_rw_%d' % l]), d(g['g8_S_bor_rw_%d' % l])) for l in range(L)}
+    m.__dict__.pop('_resident', None)
+
+
+def test_pad_collate_and_make_batch_g12(golden, tmp_path):
+    """g12 at the product level: SubgraphDataset items through SubGNN._pad_collate, and the
+    device-resident make_batch the loaders use, both give the batch the reference's _pad_collate
+    built from the same prepared tensors (S.py:1068-1114)."""
+    m = _model(golden, tmp_path)
+    _golden_prepared(m, golden)
+    idxs = [int(i) for i in golden['g12_idx']]
+    ds = m._dataset('train')
+    b1 = m._pad_collate([ds[i] for i in idxs])
+    b2 = m.make_batch('train', idxs)
+    for k in ('cc_ids', 'N_border', 'NP_sim', 'I_S_sim', 'B_S_sim', 'subgraph_idx', 'label'):
+        assert np.array_equal(b1[k].cpu().numpy(), golden['g12_' + k]), k
+        assert np.array_equal(b2[k].cpu().numpy(), golden['g12_' + k]), k
+    assert np.array_equal(b1['subgraph_ids'].cpu().numpy(), golden['g12_subgraph_ids'])
+    w = golden['g12_subgraph_ids'].shape[1]                     # make_batch keeps the split's padded width
+    s2 = b2['subgraph_ids'].cpu().numpy()
+    assert np.array_equal(s2[:, :w], golden['g12_subgraph_ids']) and (s2[:, w:] == 0).all()
+
+
+@pytest.mark.parametrize('ch,inside', [(c, i) for c in ('N', 'P', 'S') for i in (True, False)])
+def test_get_anchor_patches_g9(tiny, tmp_path, ch, inside):
+    """g9 at the product level: anchor_patch_samplers.get_anchor_patches (aps:333-399) with the
+    reference's parameters and sampled anchors -> the reference's (patches, mask, embeds)."""
+    from subgnn_amd import anchor_patch_samplers as aps
+    g = tiny
+    m = _model(g, tmp_path)
+    sd = {k[3:]: T(g[k]) for k in g.files if k.startswith('sd/')}
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert not unexpected and not missing
+    _golden_prepared(m, g)
+    cc_ids = T(g['g12_cc_ids']).to(DEV)
+    mask = (cc_ids != 0)[:, :, 0]
+    channel = {'N': 'neighborhood', 'P': 'position', 'S': 'structure'}[ch]
+    m.eval()
+    with torch.no_grad():
+        ap, am, ae = aps.get_anchor_patches('train', m.hparams, m.networkx_graph, m.node_embeddings,
+                                            T(g['g12_subgraph_idx']).to(DEV), cc_ids, mask, m.lstm, m.anchors_neigh_int,
+                                            m.anchors_neigh_border, m.anchors_pos_int, m.anchors_pos_ext,
+                                            m.anchors_structure, 1, channel, inside, m.device)
+    tag = 'g9_%s_%s_' % (ch, 'in' if inside else 'out')
+    assert np.array_equal(ap.cpu().numpy(), g[tag + 'patches'])
+    assert np.array_equal(am.cpu().numpy(), g[tag + 'mask'])
+    assert_close(ae, g[tag + 'embeds'], 'anchor embeds')

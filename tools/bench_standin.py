@@ -2,6 +2,7 @@
 """Stand-in benchmarks for BASELINE.json configs[2] and configs[4] (the real datasets are not
 available offline; graph statistics as quoted in SURVEY.md section 8, every line labelled stand-in):
 
+  (density_n and ppi_bp: configs[0] and configs[1], same driver; presets in subgnn_amd/standins.py)
   hpo_metab  "HPO-METAB, all three channels, 1 x MI355X, structure-channel DTW gamma kernel
              stressed": BA n=14 587, m=222 (~3.2 M edges, mean degree ~440), 2 400 subgraphs of ~14
              nodes in 1-2 components; best_model_hyperparameters/hpo_metab/hyperparams.json with the
@@ -16,7 +17,7 @@ available offline; graph statistics as quoted in SURVEY.md section 8, every line
 Prints one JSON line: prepare_data seconds (and its stage split for the sparse path), ms per training
 step (fwd + bwd + clip + Adam) eager and replayed from a hipGraph.
 
-    python tools/bench_standin.py --config hpo_metab|em_user [--steps 30] [--warmup 5]
+    python tools/bench_standin.py --config density_n|ppi_bp|hpo_metab|em_user [--steps 30] [--warmup 5]
 """
 import argparse
 import json
@@ -29,57 +30,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
 
-COMMON = {"max_epochs": 200, "structure_patch_type": "triangular_random_walk", "lstm_aggregator": "last",
-          "n_processes": 4, "resample_anchor_patches": False, "freeze_node_embeds": False, "use_mpn_projection": True,
-          "print_train_times": False, "compute_similarities": True, "set2set": False, "ff_attn": False,
-          "linear_hidden_dim_1": 64, "linear_hidden_dim_2": 32, "max_sim_epochs": 5, "embedding_type": "gin",
-          "use_neighborhood": True, "use_structure": True, "use_position": True, "node_embed_size": 128}
-
-PRESETS = {
-    'hpo_metab': dict(
-        n=14587, m=222, n_sub=2400, n_classes=6, sparse=False,
-        pieces=lambda rng: [10, 4] if rng.random() < 0.6 else [14],
-        hp={"seed": 0, "sample_walk_len": 50, "n_triangular_walks": 5, "random_walk_len": 10, "rw_beta": 0.65,
-            "batch_size": 64, "learning_rate": 0.0003658242069498871, "grad_clip": 0.26758489792349655, "n_layers": 4,
-            "neigh_sample_border_size": 2, "n_anchor_patches_pos_out": 90, "n_anchor_patches_pos_in": 56,
-            "n_anchor_patches_N_in": 13, "n_anchor_patches_N_out": 34, "n_anchor_patches_structure": 18,
-            "lstm_dropout": 0.09909551715384933, "lstm_n_layers": 2, "lin_dropout": 0.21096188558408646,
-            "cc_aggregator": "sum", "trainable_cc": False}),
-    'em_user': dict(
-        n=57333, m=80, n_sub=324, n_classes=2, sparse=True,
-        pieces=lambda rng: [int(rng.integers(40, 60)), int(rng.integers(30, 50))] + [1] * int(rng.integers(40, 56))
-        + [int(rng.integers(2, 5)) for _ in range(4)],
-        hp={"seed": 160761, "batch_size": 32, "learning_rate": 0.0007225432908901084, "grad_clip": 0.13742538368745078,
-            "n_layers": 1, "neigh_sample_border_size": 2, "n_anchor_patches_pos_out": 77, "n_anchor_patches_pos_in": 48,
-            "n_anchor_patches_N_in": 16, "n_anchor_patches_N_out": 32, "n_anchor_patches_structure": 35,
-            "n_triangular_walks": 10, "random_walk_len": 23, "sample_walk_len": 22, "rw_beta": 0.1816027331132596,
-            "lstm_dropout": 0.01599628663889252, "lin_dropout": 0.003486968525571843, "lstm_n_layers": 1,
-            "cc_aggregator": "sum", "trainable_cc": True, "structure_similarity_fn": "dtw",
-            "embedding_dtype": "fp16"}),          # configs[4]: "fp16 embeddings"
-}
-
-
-def write_standin(root, name, n, m, n_sub, n_classes, pieces, seed=7, D=128):
-    from subgnn_amd import synthetic
-    d = os.path.join(root, name)
-    os.makedirs(os.path.join(d, 'similarities'), exist_ok=True)
-    edges = synthetic.barabasi_albert_edges(n, m, seed)
-    rowptr, col = synthetic.sorted_csr(edges, n)
-    und = np.unique(np.sort(edges, axis=1), axis=0)
-    np.savetxt(os.path.join(d, 'edge_list.txt'), und, fmt='%d')
-    rng = np.random.default_rng(seed)
-    lines = []
-    for i in range(n_sub):
-        nodes = []
-        for size in pieces(rng):
-            nodes.extend(synthetic.bfs_subgraphs(rowptr, col, 1, int(size), int(rng.integers(1 << 30)))[0])
-        nodes = list(dict.fromkeys(nodes))
-        sp = 'train' if i < int(0.8 * n_sub) else ('val' if i < int(0.9 * n_sub) else 'test')
-        lines.append('-'.join(str(v - 1) for v in nodes) + '\t' + str(i % n_classes) + '\t' + sp + '\t\n')
-    with open(os.path.join(d, 'subgraphs.pth'), 'w') as f:
-        f.write(''.join(lines))
-    torch.save(torch.randn(n, D, generator=torch.Generator().manual_seed(seed)), os.path.join(d, 'gin_embeddings.pth'))
-    return d, len(und)
+from subgnn_amd.standins import PRESETS, write_standin          # noqa: E402  (the presets live with the package: tests use them too)
 
 
 def time_steps(model, opt, hp, steps, warmup, graph):
@@ -124,12 +75,11 @@ def main():
     from subgnn_amd import config, hotpath, precompute_graph_metrics as pgm
     from subgnn_amd.SubGNN import SubGNN, dataset_paths
     P = PRESETS[args.config]
-    hp = dict(COMMON)
-    hp.update(P['hp'])
+    hp = dict(P['hp'])
     root = tempfile.mkdtemp(prefix=args.config + '_')
     name = args.config + '_standin'
     t0 = time.time()
-    d, n_edges = write_standin(root, name, P['n'], P['m'], P['n_sub'], P['n_classes'], P['pieces'])
+    d, n_edges = write_standin(root, args.config)
     t_write = time.time() - t0
     t0 = time.time()
     pgm.calculate_stats(d, shortest_paths=not P['sparse'], ego=not P['sparse'])
@@ -161,10 +111,10 @@ def main():
         'eager': {'value': B * 1e3 / ms_eager, 'ms_per_step': ms_eager},
         'steps': args.steps, 'warmup': args.warmup, 'higher_is_better': True, 'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': '%s stand-in (BA n=%d m=%d, %d edges, %d subgraphs), %s prepare, batch of %d, training '
-                               'step = fwd + bwd + clip + Adam' % (args.config, P['n'], P['m'], n_edges, P['n_sub'],
+                               'step = fwd + bwd + clip + Adam' % (args.config, P['n'], P.get('m', 5), n_edges, P['n_sub'],
                                                                    'sparse' if P['sparse'] else 'dense reference-shaped', B),
                    'cc_ids_shape': list(model.train_cc_ids.shape), 'n_layers': hp['n_layers'],
-                   'structure_patches': int(model.structure_anchors.shape[0])},
+                   'structure_patches': int(model.structure_anchors.shape[0]) if model.structure_anchors is not None else 0},
         'prepare_data_s': round(t_prep, 2), 'prepare_stages_ms_train_split': stages,
         'dataset_write_s': round(t_write, 2), 'graph_metrics_s': round(t_metrics, 2),
         'loss': loss, 'loss_graph': loss_g}))

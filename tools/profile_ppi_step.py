@@ -2,16 +2,9 @@
 import cProfile, pstats, io, os, sys, tempfile, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from tools import bench_ppi_bp as B
-from subgnn_amd import config, precompute_graph_metrics as pgm
-from subgnn_amd.SubGNN import SubGNN, dataset_paths
+from subgnn_amd import standins as B
 root = tempfile.mkdtemp(prefix='ppi_bp_')
-d, _ = B.write_standin(root)
-pgm.calculate_stats(d)
-config.PROJECT_ROOT = root
-torch.manual_seed(3)
-model = SubGNN(dict(B.H2), **dataset_paths('ppi_bp_standin'))
-model.prepare_data()
+model, d, _ = B.build_model(root, 'ppi_bp')
 opt = model.configure_optimizers()
 model.train()
 loader = model.train_dataloader()
