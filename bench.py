@@ -21,9 +21,11 @@ One step = one full pass of the hot path over the rank's shard, everything on th
 value = subgraphs processed by all ranks / max-over-ranks step time.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-  roofline      achieved algorithmic HBM bytes/s of the structure-channel CSR gather
-                (sgnn_degree_sequence, the kernel BASELINE.json's target names), measured live
-                with HIP events on the launching stream; peak 8 TB/s.
+  roofline      the structure-channel CSR gather (sgnn_degree_sequence, the kernel BASELINE.json's
+                target names) as a bandwidth: SURVEY.md 8(d) algorithmic bytes / time of the launch
+                that moves them (every neighbour list streamed), HIP events on the launching
+                stream, peak 8 TB/s; hbm_frac = memory-side counter bytes / same time; the shipped
+                launch (long lists binary-searched) with ITS byte count next to it.
   cpu_baseline  the oracle (plain C + numpy + torch-CPU restatement of the same algorithm)
                 timed on this box's host cores on a bounded sample (rank 0, N = 1 only).
 """
@@ -82,14 +84,23 @@ def build_inputs(args, rank):
     return rowptr, col, subs, time.time() - t0
 
 
-def degseq_algorithmic_bytes(rowptr, sets_lists):
+DS_SEARCH = 512      # csrc/degree_sequence.hip: with row-sorted CSR, lists of >= DS_SEARCH entries are searched, not streamed
+
+
+def degseq_algorithmic_bytes(rowptr, sets_lists, search=False):
     """SURVEY.md 8(d): per set  sum_v (16 + 4 deg(v)) + 4|S| (ids in) + 4|S| (degrees out);
-    internal and external computed in one pass (the external output adds 4|S|)."""
+    internal and external computed in one pass (the external output adds 4|S|).
+    ``search``: the byte count of the shipped launch -- a list of >= DS_SEARCH entries is not read: each
+    of the |S| members binary-searches it, floor(log2 deg) + 1 probes and one verifying read of 4 bytes."""
     deg = np.diff(rowptr)
     total = 0
     for s in sets_lists:
-        a = np.asarray(s, dtype=np.int64)
-        total += int((16 + 4 * deg[a]).sum()) + 12 * len(a)
+        d = deg[np.asarray(s, dtype=np.int64)].astype(np.int64)
+        per_list = 4 * d
+        if search:
+            steps = np.floor(np.log2(np.maximum(d, 1))).astype(np.int64) + 2
+            per_list = np.where(d >= DS_SEARCH, np.minimum(4 * d, 4 * steps * len(d)), per_list)
+        total += int((16 + per_list).sum()) + 12 * len(d)
     return total
 
 
@@ -214,41 +225,51 @@ def main():
     cc_ids = model.train_cc_ids
     Sx, C, Lc = cc_ids.shape
     cc_sets = ops.Ragged.from_padded(cc_ids.reshape(Sx * C, Lc))
-    alg_bytes = degseq_algorithmic_bytes(rowptr, cc_sets.to_lists())
-    # (1) inside the timed region: HIP events on the launching stream bracket the stage that is this
-    #     one launch (hotpath.prepare_sparse marks 'degree_sequences' around ops.degree_sequence);
-    # (2) 20 back-to-back launches after the timed region, as a cross-check.
+    set_lists = cc_sets.to_lists()
+    alg_bytes = degseq_algorithmic_bytes(rowptr, set_lists)                      # every list read in full
+    alg_bytes_search = degseq_algorithmic_bytes(rowptr, set_lists, search=True)  # what the shipped launch reads
     reps = 20
     ds_order = model._degseq_order['train']
-    ops.degree_sequence(g, cc_sets, order=ds_order)
-    torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps):
-        ops.degree_sequence(g, cc_sets, order=ds_order)
-    e1.record()
-    torch.cuda.synchronize()
-    ds_ms_b2b = e0.elapsed_time(e1) / reps
-    ds_ms = stage_ms.get('degree_sequences', ds_ms_b2b)
-    achieved = alg_bytes / (ds_ms * 1e-3) / 1e9
-    # the same launch in its pure streaming form (every neighbour list read in full: what the algorithmic
-    # byte count describes); the shipped form searches lists of >= 512 entries for the set's members instead
-    e0.record()
-    for _ in range(reps):
-        ops.degree_sequence(g, cc_sets, order=ds_order, search_long_lists=False)
-    e1.record()
-    torch.cuda.synchronize()
-    ds_ms_stream = e0.elapsed_time(e1) / reps
 
-    traffic, traffic_src = None, None
-    tname = 'r01_final_degseq_traffic.json'
-    tf = os.path.join(REPO, 'profiles', tname)
-    if os.path.exists(tf) and args.nodes == 1_000_000 and S == 50_000:
-        # PMC passes cannot run inside this process; this is the committed rocprofv3 measurement of
-        # the same launch (same graph seed, same 50k sets): raw FETCH_SIZE + WRITE_SIZE bytes
+    def back_to_back(**kw):
+        ops.degree_sequence(g, cc_sets, order=ds_order, **kw)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(reps):
+            ops.degree_sequence(g, cc_sets, order=ds_order, **kw)
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+    # The roofline figure is a bandwidth, so it is taken on the launch that MOVES the algorithmic bytes: the
+    # streaming form of the kernel (every neighbour list read in full; sgnn_degree_sequence without the
+    # row-sorted CSR), 20 launches back to back on the launching stream.  The shipped launch (lists of
+    # >= 512 entries binary-searched for the set's members: same results, fewer bytes) is timed inside the
+    # timed region by the 'degree_sequences' stage events and priced with its own byte count.
+    ds_ms_stream = back_to_back(search_long_lists=False)
+    ds_ms_b2b = back_to_back()
+    ds_ms = stage_ms.get('degree_sequences', ds_ms_b2b)
+    achieved = alg_bytes / (ds_ms_stream * 1e-3) / 1e9
+
+    traffic = traffic_src = hbm_frac = None
+    out_of_cache = None
+    tf = os.path.join(REPO, 'profiles', 'r02_degseq_traffic.json')
+    if os.path.exists(tf):
+        # PMC passes cannot run inside this process; these are the committed rocprofv3 measurements
+        # (tools/run_hbm_probe.sh: separate --pmc passes, FETCH_SIZE calibrated on a copy of known size)
         with open(tf) as f:
             tj = json.load(f)
-        traffic, traffic_src = tj['hbm_bytes_per_launch_raw'], 'profiles/%s (rocprofv3 --pmc, separate passes)' % tname
+        if args.nodes == 1_000_000 and S == 50_000 and args.m == 10:
+            traffic = tj['benchmark_graph']['streaming']['memory_side_bytes_per_launch']
+            traffic_src = 'profiles/r02_degseq_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; ' \
+                          'FETCH_SIZE x2 per the 4 B/lane calibration copy)'
+            hbm_frac = traffic / (ds_ms_stream * 1e-3) / 1e9 / HBM_PEAK_GBS
+        out_of_cache = {'graph': tj['out_of_cache']['bfs_sets']['graph'], 'csr_bytes': tj['out_of_cache']['bfs_sets']['csr_bytes'],
+                        'source': 'profiles/r02_degseq_traffic.json (committed measurement, not re-run here)'}
+        for fam, c in tj['out_of_cache'].items():
+            out_of_cache[fam] = {form: {k: c[form][k] for k in ('ms_per_launch', 'algorithmic_frac_of_8TBs',
+                                                                'memory_side_frac_of_8TBs', 'traffic_over_algorithmic')}
+                                 for form in ('streaming', 'shipped_search')}
     result = {
         'metric': 'subgraphs/sec fwd+bwd (all 3 channels on) + achieved HBM GB/s',
         'value': world * S * args.steps / elapsed, 'unit': 'subgraphs/s', 'n_gpus': world, 'steps': args.steps,
@@ -261,20 +282,26 @@ def main():
                                'D=%d, full pass = sampling + similarities + fwd + bwd + Adam' %
                                (n, args.m, int(rowptr[-1]) // 2, S, args.subgraph_nodes, args.embed),
                    'subgraphs_per_gpu': S, 'parallelism': 'dp%d (subgraph shards, RCCL all-gather + grad all-reduce)' % world},
-        'roofline': {'kernel': 'degseq_wave_kernel (sgnn_degree_sequence: structure-channel CSR gather)',
+        'roofline': {'kernel': 'degseq_wave_kernel<true, false, false> (sgnn_degree_sequence: structure-channel CSR gather, '
+                               'every neighbour list streamed)',
                      'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                     'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_src,
-                     'algorithmic_bytes_per_launch': alg_bytes, 'ms_per_launch': ds_ms, 'ms_per_launch_back_to_back': ds_ms_b2b, 'sets_per_launch': cc_sets.n,
-                     'streaming_form': {'ms_per_launch_back_to_back': ds_ms_stream,
-                                        'achieved': alg_bytes / (ds_ms_stream * 1e-3) / 1e9,
-                                        'frac': alg_bytes / (ds_ms_stream * 1e-3) / 1e9 / HBM_PEAK_GBS},
-                     'note': 'achieved = algorithmic bytes (SURVEY 8d: every member\'s whole neighbour list) / launch time. '
-                             'The shipped launch does not read lists of >= 512 entries: the set\'s members binary-search them '
-                             '(row-sorted CSR), so frac can exceed 1 -- it is the speed-up over a launch that has to move the '
-                             'algorithmic bytes at HBM speed, not a bandwidth. streaming_form is the same kernel with every '
-                             'list streamed in full (sgnn_degree_sequence without the sorted rows): that figure is a '
-                             'bandwidth, and an on-die one: the CSR (88 MB) fits the 256 MiB Infinity Cache and hub lists '
-                             'are re-read from the XCD L2s (memory-side traffic per launch: the traffic field)'},
+                     'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'hbm_frac': hbm_frac,
+                     'traffic_source': traffic_src,
+                     'algorithmic_bytes_per_launch': alg_bytes, 'ms_per_launch': ds_ms_stream, 'sets_per_launch': cc_sets.n,
+                     'shipped_form': {'kernel': 'degseq_wave_kernel<true, false, true> (lists of >= %d entries searched)' % DS_SEARCH,
+                                      'ms_per_launch': ds_ms, 'ms_per_launch_back_to_back': ds_ms_b2b,
+                                      'algorithmic_bytes_per_launch': alg_bytes_search,
+                                      'achieved': alg_bytes_search / (ds_ms * 1e-3) / 1e9,
+                                      'frac': alg_bytes_search / (ds_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                      'speedup_vs_streaming': ds_ms_stream / ds_ms},
+                     'out_of_cache': out_of_cache,
+                     'note': 'achieved = SURVEY 8(d) algorithmic bytes (every member\'s whole neighbour list) / time of the '
+                             'launch that streams them, measured here with HIP events.  On the benchmark graph that is an '
+                             'ON-DIE rate: the CSR (88 MB) fits the 256 MiB Infinity Cache and hub lists are re-read from '
+                             'the XCD L2s -- hbm_frac is the memory-side counter traffic over the same time.  The pass itself '
+                             'runs shipped_form (same results; it is latency-, not bandwidth-bound: its frac prices the bytes '
+                             'it actually reads).  out_of_cache: the same kernel on a BA n=8M m=16 graph (CSR 1.09 GB), '
+                             'tools/degseq_hbm_probe.py + rocprofv3 counters, profiles/r02_degseq_traffic.json'},
         'stages_ms': {k: round(v, 3) for k, v in stage_ms.items()},
         'loss': loss, 'setup_s': round(t_gen, 1), 'priming_passes_before_warmup': PRIMING_PASSES,
     }

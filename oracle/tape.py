@@ -40,11 +40,11 @@ STREAM_S_PICK = 9           # aps:326  which presampled structure patches a laye
 SPLIT_CODE = {'train': 0, 'val': 1, 'test': 2}
 
 
-def stream_id(kind, split=0, layer=0):
-    """Fold (kind, split, layer) into one 64-bit stream number."""
+def stream_id(kind, split=0, layer=0, epoch=0):
+    """Fold (kind, split, layer, resample epoch) into one 64-bit stream number."""
     if isinstance(split, str):
         split = SPLIT_CODE[split]
-    return (kind << 32) | (split << 24) | layer
+    return (kind << 32) | (split << 24) | (epoch << 8) | layer
 
 
 def mix64(z):

@@ -208,15 +208,34 @@ class SubGNN(nn.Module):
     def _half_table(self):
         """hparams['embedding_dtype'] in ('fp16', 'float16', 'half'): the table is additionally kept in
         IEEE half and the fused kernels read that copy (fp32 accumulate); the fp32 parameter stays the
-        master the optimizer updates, and the half copy is refreshed whenever the master changed."""
+        master the optimizer updates.  The copy is ONE persistent buffer refreshed in place.  The master's
+        version counter cannot be trusted to say when: torch's fused Adam updates the parameter without
+        moving it, and so does a replayed hipGraph.  Hence: a read with gradients enabled on a trainable
+        table (a training forward: an optimizer step is expected to follow) always refreshes and leaves
+        the copy marked dirty; a read without (validation, init_all_embeddings) refreshes a dirty copy
+        once; while a step is being recorded the refresh is part of the recording, so every replay starts
+        from the current master; ``invalidate_half_table`` marks the copy dirty by hand.  One conversion
+        of the table (N x D read + half of it written) per training forward."""
         if str(self.hparams.get('embedding_dtype', 'fp32')).lower() not in ('fp16', 'float16', 'half'):
             return None
         w = self.node_embeddings.weight
         st = self.__dict__.get('_half_state')
-        if st is None or st[0] != w._version or st[1].device != w.device:
-            st = (w._version, w.detach().to(torch.float16))
-            self.__dict__['_half_state'] = st
+        if st is None or st[1].device != w.device or st[1].shape != w.shape:
+            st = self.__dict__['_half_state'] = [None, torch.empty(w.shape, dtype=torch.float16, device=w.device), True]
+        capturing = w.is_cuda and torch.cuda.is_current_stream_capturing()
+        training_read = torch.is_grad_enabled() and w.requires_grad
+        if st[2] or st[0] != w._version or capturing or training_read:
+            st[1].copy_(w.detach())
+            st[0] = w._version
+        st[2] = training_read or capturing
         return st[1]
+
+    def invalidate_half_table(self):
+        """The master table changed in a way nothing above can see (``.data`` edits, foreign in-place
+        kernels): the next reader refreshes the half copy."""
+        st = self.__dict__.get('_half_state')
+        if st is not None:
+            st[2] = True
 
     def _table(self):
         """The embedding table as the fused ops read it: inside ``forward`` a tapped alias whose
@@ -400,6 +419,7 @@ class SubGNN(nn.Module):
                 self.anchors_structure = None
         self._build_sim_cols()
         self.__dict__.pop('_resident', None)
+        self._bump_generation()
 
     def prepare_data(self):
         """S.py:1024-1063."""
@@ -674,26 +694,37 @@ class SubGNN(nn.Module):
         if not hp['trainable_cc']:
             self.init_all_embeddings(split='train_val', trainable=False)
         if hp['resample_anchor_patches']:
-            hp['seed'] = int(hp.get('seed', 0)) + 1            # a fresh tape for the new draws
+            # a fresh tape stream for the new draws; hparams['seed'] (already written to hyperparams.json
+            # by the caller, and what prepare_test_data draws from) stays what the caller set
+            self.__dict__['_resample_epoch'] = self.__dict__.get('_resample_epoch', 0) + 1
             self._prepare_anchors_only()
         self.metric_scores.append(logs)
         return {'avg_val_loss': logs['val_loss'], 'log': logs}
 
     def _prepare_anchors_only(self):
+        """S.py:453-460: new anchor draws on the prepared sets (resample_anchor_patches); the draws read
+        the tape streams of resample epoch ``_resample_epoch``."""
         hp, g = self.hparams, self.networkx_graph
+        ep = self.__dict__.get('_resample_epoch', 0)
         if hp['use_neighborhood']:
             self.anchors_neigh_int, self.anchors_neigh_border = aps.init_anchors_neighborhood(
                 'train_val', hp, g, self.device, self.train_cc_ids, self.val_cc_ids, None, self.train_N_border,
-                self.val_N_border, None)
+                self.val_N_border, None, epoch=ep)
         if hp['use_position']:
             self.anchors_pos_int = aps.init_anchors_pos_int('train_val', hp, g, self.device, self.train_sub_G,
-                                                            self.val_sub_G, self.test_sub_G)
-            self.anchors_pos_ext = aps.init_anchors_pos_ext(hp, g, self.device)
+                                                            self.val_sub_G, self.test_sub_G, epoch=ep)
+            self.anchors_pos_ext = aps.init_anchors_pos_ext(hp, g, self.device, epoch=ep)
         if hp['use_structure']:
             self.anchors_structure = aps.init_anchors_structure(hp, self.structure_anchors,
                                                                 self.int_structure_anchor_random_walks,
-                                                                self.bor_structure_anchor_random_walks)
+                                                                self.bor_structure_anchor_random_walks, epoch=ep)
         self._build_sim_cols()
+        self._bump_generation()
+
+    def _bump_generation(self):
+        """Every replacement of tensors a recorded step reads (prepared sets, anchors, similarity rows)
+        moves this counter; graph_step.CapturedTrainStep compares it instead of object ids."""
+        self.__dict__['_prep_generation'] = self.__dict__.get('_prep_generation', 0) + 1
 
     def _build_sim_cols(self):
         """Per layer, the columns of the S similarity rows its sampled patches read (S.py:206-210),

@@ -96,25 +96,35 @@ def sample_structure_anchor_patches(hparams, networkx_graph, device, max_sim_epo
 # ---------------------------------------------------------------------------------------
 
 def sample_neighborhood_anchor_patch(hparams, networkx_graph, cc_ids, border_set, sample_inside=True, split='train',
-                                     layer=0):
+                                     layer=0, epoch=0):
     """aps:163-198 -> (S, C, n_anchor_patches_N_in | _N_out) int64."""
     mat = cc_ids if sample_inside else border_set
     S, C, L = mat.shape
     A = hparams['n_anchor_patches_N_in'] if sample_inside else hparams['n_anchor_patches_N_out']
     kind = tape.STREAM_N_INT if sample_inside else tape.STREAM_N_BOR
     out = ops.sample_anchors_padded(mat.reshape(S * C, L).contiguous(), A, _seed(hparams),
-                                    tape.stream_id(kind, split, layer))
+                                    tape.stream_id(kind, split, layer, epoch))
     return out.view(S, C, A)
 
 
-def sample_position_anchor_patches(hparams, networkx_graph, subgraph=None, split='train', layer=0, item=0):
-    """aps:200-208 for ONE draw list (python list out, like the reference)."""
+def sample_position_anchor_patches(hparams, networkx_graph, subgraph=None, split='train', layer=0, item=0, epoch=0):
+    """aps:200-208 for ONE draw list (python list out, like the reference): without ``subgraph`` the
+    n_anchor_patches_pos_out shared border anchors drawn from all graph nodes (aps:206), with it the
+    n_anchor_patches_pos_in internal anchors drawn from that subgraph's node list (aps:208).
+    ``item`` is the subgraph's number within its split -- the tape item the batched form
+    (init_anchors_pos_int) uses for the same subgraph, so both forms give the same draws."""
     g = networkx_graph
     if not subgraph:
-        r = ops.Ragged(torch.tensor([0, g.n_nodes], dtype=torch.int64, device=g.device), g.node_order)
+        r = ops.Ragged(_span_ptr(g.n_nodes, g.device), g.node_order)
         return ops.choice_ragged(r, hparams['n_anchor_patches_pos_out'], _seed(hparams),
-                                 tape.stream_id(tape.STREAM_P_EXT, 0, layer))[0].tolist()
-    raise NotImplementedError('use init_anchors_pos_int (batched over subgraphs)')
+                                 tape.stream_id(tape.STREAM_P_EXT, 0, layer, epoch))[0].tolist()
+    # the kernel numbers its tape items by set: hand it ``item`` empty sets in front of the subgraph
+    nodes = torch.as_tensor([int(v) for v in subgraph], dtype=torch.int32, device=g.device)
+    ptr = torch.zeros(int(item) + 2, dtype=torch.int64, device=g.device)
+    ptr[-1] = nodes.numel()
+    r = ops.Ragged(ptr, nodes, max_len=int(nodes.numel()))
+    return ops.choice_ragged(r, hparams['n_anchor_patches_pos_in'], _seed(hparams),
+                             tape.stream_id(tape.STREAM_P_INT, split, layer, epoch))[int(item)].tolist()
 
 
 # ---------------------------------------------------------------------------------------
@@ -125,19 +135,19 @@ _SPLITS = {'all': ['train', 'val', 'test'], 'train_val': ['train', 'val'], 'test
 
 
 def init_anchors_neighborhood(split, hparams, networkx_graph, device, train_cc_ids, val_cc_ids, test_cc_ids,
-                              train_N_border, val_N_border, test_N_border):
+                              train_N_border, val_N_border, test_N_border, epoch=0):
     data = {'train': (train_cc_ids, train_N_border), 'val': (val_cc_ids, val_N_border),
             'test': (test_cc_ids, test_N_border)}
     anchors_int_neigh, anchors_border_neigh = defaultdict(dict), defaultdict(dict)
     for name in _SPLITS[split]:
         cc, bs = data[name]
         for n in range(hparams['n_layers']):
-            anchors_int_neigh[name][n] = sample_neighborhood_anchor_patch(hparams, networkx_graph, cc, bs, True, name, n)
-            anchors_border_neigh[name][n] = sample_neighborhood_anchor_patch(hparams, networkx_graph, cc, bs, False, name, n)
+            anchors_int_neigh[name][n] = sample_neighborhood_anchor_patch(hparams, networkx_graph, cc, bs, True, name, n, epoch)
+            anchors_border_neigh[name][n] = sample_neighborhood_anchor_patch(hparams, networkx_graph, cc, bs, False, name, n, epoch)
     return anchors_int_neigh, anchors_border_neigh
 
 
-def init_anchors_pos_int(split, hparams, networkx_graph, device, train_sub_G, val_sub_G, test_sub_G):
+def init_anchors_pos_int(split, hparams, networkx_graph, device, train_sub_G, val_sub_G, test_sub_G, epoch=0):
     """(S, n_anchor_patches_pos_in) per split and layer; ``*_sub_G`` are lists of node lists."""
     data = {'train': train_sub_G, 'val': val_sub_G, 'test': test_sub_G}
     anchors = defaultdict(dict)
@@ -145,7 +155,7 @@ def init_anchors_pos_int(split, hparams, networkx_graph, device, train_sub_G, va
         subs = data[name] if isinstance(data[name], ops.Ragged) else ops.Ragged.from_lists(data[name], networkx_graph.device)
         for n in range(hparams['n_layers']):
             anchors[name][n] = ops.choice_ragged(subs, hparams['n_anchor_patches_pos_in'], _seed(hparams),
-                                                 tape.stream_id(tape.STREAM_P_INT, name, n))
+                                                 tape.stream_id(tape.STREAM_P_INT, name, n, epoch))
     return anchors
 
 
@@ -161,16 +171,16 @@ def _span_ptr(n, device):
     return _SPAN_PTR[key]
 
 
-def init_anchors_pos_ext(hparams, networkx_graph, device):
+def init_anchors_pos_ext(hparams, networkx_graph, device, epoch=0):
     g = networkx_graph
     order = ops.Ragged(_span_ptr(g.n_nodes, g.device), g.node_order)
     return {n: ops.choice_ragged(order, hparams['n_anchor_patches_pos_out'], _seed(hparams),
-                                 tape.stream_id(tape.STREAM_P_EXT, 0, n))[0]
+                                 tape.stream_id(tape.STREAM_P_EXT, 0, n, epoch))[0]
             for n in range(hparams['n_layers'])}
 
 
 def init_anchors_structure(hparams, structure_anchors, int_structure_anchor_rw, bor_structure_anchor_rw,
-                           indices_on_device=False):
+                           indices_on_device=False, epoch=0):
     """aps:300-328.  The second entry of every layer's tuple is the list of picked patch numbers, as in
     the reference; ``indices_on_device`` keeps it as the device tensor it was drawn into (the per-pass
     path: no device->host->device round trip for a value only ever used as a column index)."""
@@ -180,7 +190,7 @@ def init_anchors_structure(hparams, structure_anchors, int_structure_anchor_rw, 
     out = {}
     for n in range(hparams['n_layers']):
         idx = ops.choice_ragged(pool, hparams['n_anchor_patches_structure'], _seed(hparams),
-                                tape.stream_id(tape.STREAM_S_PICK, 0, n))[0]
+                                tape.stream_id(tape.STREAM_S_PICK, 0, n, epoch))[0]
         out[n] = (structure_anchors[idx, :], idx if indices_on_device else [int(i) for i in idx.tolist()],
                   int_structure_anchor_rw[idx, :, :], bor_structure_anchor_rw[idx, :, :])
     return out

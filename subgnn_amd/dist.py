@@ -73,18 +73,26 @@ def all_gather_rows(x, equal_rows=False, async_op=False):
 
 
 def all_reduce_gradients(params, average=True, big_bytes=16 << 20):
-    """All-reduce of every existing gradient: tensors of at least ``big_bytes`` (the dense
-    embedding-table gradient: 256 MB at N = 1M, D = 64) are reduced in place, each as its own
-    collective; the small ones travel together in one flat bucket.  All collectives are issued
-    before any is waited for."""
+    """All-reduce of the gradients of ``params`` (every rank passes the same parameters in the same
+    order).  The bucket layout is a function of the PARAMETERS, not of which gradients happen to exist
+    on this rank: a parameter whose gradient is None here (a layer this rank's shard never exercised --
+    e.g. the P-internal read-out weight when all of the shard's subgraphs have one component) enters as
+    zeros and receives the reduced gradient, so ranks can never disagree on the collective's size.
+    Tensors of at least ``big_bytes`` (the dense embedding-table gradient: 256 MB at N = 1M, D = 64) are
+    reduced in place, each as its own collective; the small ones travel together in one flat bucket.
+    All collectives are issued before any is waited for."""
     if not is_initialized():
         return
-    grads = [p.grad for p in params if p.grad is not None]
-    if not grads:
+    params = [p for p in params if p.requires_grad]
+    if not params:
         return
     world = dist.get_world_size()
-    big = [g for g in grads if g.numel() * g.element_size() >= big_bytes and g.is_contiguous()]
-    small = [g for g in grads if not any(g is b for b in big)]
+    for p in params:
+        if p.grad is None:
+            p.grad = torch.zeros_like(p, memory_format=torch.contiguous_format)
+    is_big = [p.numel() * p.element_size() >= big_bytes and p.grad.is_contiguous() for p in params]
+    big = [p.grad for p, b in zip(params, is_big) if b]
+    small = [p.grad for p, b in zip(params, is_big) if not b]
     works = [dist.all_reduce(g, async_op=True) for g in big]
     flat = None
     if small:

@@ -50,11 +50,11 @@ class CapturedTrainStep:
 
     # -- what the recording depends on -----------------------------------------------------
     def _anchor_token(self):
-        m = self.model
-        objs = [getattr(m, a, None) for a in ('anchors_neigh_int', 'anchors_neigh_border', 'anchors_pos_int',
-                                              'anchors_pos_ext', 'anchors_structure')]
-        objs += [getattr(m, self.split + a, None) for a in ('_cc_ids', '_N_border', '_neigh_pos_similarities')]
-        return tuple(id(o) for o in objs)
+        """The model's preparation generation: every code path that replaces a tensor the recording reads
+        (prepare_data / prepare_test_data, hotpath.prepare_sparse, the anchor resample, the structure
+        column lists) bumps it (SubGNN._bump_generation).  Object ids would miss the similarity tensors
+        and can be reused after garbage collection."""
+        return self.model.__dict__.get('_prep_generation', 0)
 
     def stale(self):
         return self._anchor_token() != self._token
@@ -90,4 +90,6 @@ class CapturedTrainStep:
                 return self._body()
             self._record()
         self.graph.replay()
+        # the replayed Adam step changed the master table without moving its host-side version counter
+        self.model.invalidate_half_table()
         return self.loss, self.acc

@@ -225,6 +225,7 @@ def prepare_sparse(model, split='train', timer=None):
         setattr(model, split + '_int_struc_similarities', None)
         setattr(model, split + '_bor_struc_similarities', None)
     model._build_sim_cols()
+    model._bump_generation()
     return t
 
 

@@ -168,6 +168,37 @@ class DeviceGraph:
         self.simple_rows = not bool(len(col_sorted) > 1 and np.any((col_sorted[1:] == col_sorted[:-1]) & (rs[1:] == rs[:-1])))
 
 
+    @classmethod
+    def from_device_csr(cls, rowptr, col):
+        """A graph that is already a device-resident CSR with ascending rows and node order 1..n (the
+        synthetic generators): nothing is staged through the host, so graphs far beyond the host-side
+        constructor's reach (a 1 GB ``col``) can be built.  ``col`` serves as ``col_sorted`` too."""
+        _req(rowptr, torch.int64, 'rowptr')
+        _req(col, torch.int32, 'col')
+        self = cls.__new__(cls)
+        dev = rowptr.device
+        self.max_id = rowptr.numel() - 2
+        self.nnz = int(rowptr[-1].item())
+        self.n_nodes = self.max_id
+        self.device = dev
+        self.rowptr, self.col, self.col_sorted = rowptr, col, col
+        self.node_order = torch.arange(1, self.max_id + 1, dtype=torch.int32, device=dev)
+        self.node_pos = torch.zeros(self.max_id + 1, dtype=torch.int32, device=dev)
+        self.node_pos[1:] = torch.arange(self.max_id, dtype=torch.int32, device=dev)
+        self.full_degree = None
+        deg = rowptr[1:] - rowptr[:-1]
+        rows = torch.repeat_interleave(torch.arange(self.max_id + 1, dtype=torch.int32, device=dev), deg)
+        n_self = torch.zeros(self.max_id + 1, dtype=torch.int64, device=dev)
+        n_self.index_add_(0, rows.long(), (col[:self.nnz] == rows).to(torch.int64))
+        self.self_loops = n_self.clamp_(max=255).to(torch.uint8)
+        same = (col[1:self.nnz] == col[:self.nnz - 1]) & (rows[1:] == rows[:-1]) if self.nnz > 1 else None
+        asc = bool(((col[1:self.nnz] >= col[:self.nnz - 1]) | (rows[1:] != rows[:-1])).all()) if self.nnz > 1 else True
+        if not asc:
+            raise ValueError('from_device_csr needs ascending rows')
+        self.simple_rows = not bool(same.any()) if same is not None else True
+        return self
+
+
 # ---------------------------------------------------------------------------------------
 # integer half
 # ---------------------------------------------------------------------------------------
@@ -431,6 +462,14 @@ def sp_similarity_dense(apsp, sets):
     check(lib.sgnn_sp_similarity_dense(_ptr(apsp), n_cols, _ptr(sets.ptr), _ptr(sets.nodes), sets.n, _ptr(out),
                                        _stream()), 'sgnn_sp_similarity_dense')
     return out
+
+
+def probe_stream_copy(src, dst, bytes_per_lane):
+    """Measurement aid: copy ``src`` to ``dst`` (same byte size) with 4 or 16 bytes per lane."""
+    nbytes = src.numel() * src.element_size()
+    assert dst.numel() * dst.element_size() == nbytes and src.is_cuda and dst.is_cuda
+    check(_lib.load().sgnn_probe_stream_copy(_ptr(src), _ptr(dst), nbytes, int(bytes_per_lane), _stream()),
+          'sgnn_probe_stream_copy')
 
 
 def bfs_hops_tuning(alpha):

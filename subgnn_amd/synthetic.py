@@ -89,3 +89,48 @@ def bfs_subgraphs(rowptr, col, n_subgraphs, n_nodes_each, seed):
                         break
         out.append(seen)
     return out
+
+
+def barabasi_albert_csr_device(n, m, seed, device):
+    """The same preferential-attachment construction as ``barabasi_albert_edges`` + ``sorted_csr``,
+    carried out with torch on the GPU (a graph whose CSR exceeds the 256 MiB Infinity Cache --
+    n = 8M, m = 16: 0.25 G directed entries -- takes minutes and tens of GB in numpy).  Returns
+    (rowptr int64[n+2], col int32[nnz]) on ``device``, rows ascending, ids 1-based.  Its own random
+    stream (torch's generator): the graph is defined by (n, m, seed) for THIS function."""
+    import torch
+    g = torch.Generator(device=device).manual_seed(int(seed))
+    src = torch.arange(m + 1, n, dtype=torch.int64, device=device).repeat_interleave(m)
+    k = src.numel()
+    prefix = 2 * m + 2 * m * (src - (m + 1))
+    pos = (torch.rand(k, generator=g, dtype=torch.float64, device=device) * prefix).to(torch.int64)
+    del prefix
+    # entry r of the endpoint list: r < 2m -> the initial star; else e = r - 2m: even -> src[e // 2],
+    # odd -> the target of draw e // 2, i.e. follow that draw's own reference (pointer jumping)
+    ref = pos.clone()
+    for _ in range(200):
+        follow = (ref >= 2 * m) & (((ref - 2 * m) & 1) == 1)
+        if not bool(follow.any()):
+            break
+        ref = torch.where(follow, pos[((ref - 2 * m) >> 1).clamp_(min=0)], ref)
+    else:
+        raise RuntimeError('pointer jumping did not converge')
+    init = torch.empty(2 * m, dtype=torch.int64, device=device)
+    init[0::2] = torch.arange(m, device=device)
+    init[1::2] = m
+    e = (ref - 2 * m).clamp_(min=0) >> 1
+    tgt = torch.where(ref < 2 * m, init[ref.clamp(max=2 * m - 1)], src[e])
+    del ref, pos, e
+    star_a = torch.arange(m, dtype=torch.int64, device=device)
+    a = torch.cat([star_a, src]) + 1
+    b = torch.cat([torch.full((m,), m, dtype=torch.int64, device=device), tgt]) + 1
+    del src, tgt
+    keep = a != b
+    a, b = a[keep], b[keep]
+    key = torch.unique(torch.cat([a * (n + 2) + b, b * (n + 2) + a]))
+    del a, b
+    rows = key // (n + 2)
+    col = (key - rows * (n + 2)).to(torch.int32)
+    del key
+    rowptr = torch.zeros(n + 2, dtype=torch.int64, device=device)
+    rowptr[1:] = torch.cumsum(torch.bincount(rows, minlength=n + 1), 0)
+    return rowptr, col

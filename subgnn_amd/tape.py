@@ -23,7 +23,10 @@ STREAM_S_PICK = 9
 SPLIT_CODE = {'train': 0, 'val': 1, 'test': 2}
 
 
-def stream_id(kind, split=0, layer=0):
+def stream_id(kind, split=0, layer=0, epoch=0):
+    """``epoch``: resample epoch (resample_anchor_patches draws fresh anchors after every validation
+    epoch, SubGNN.py:453-460); 0 for the draws of prepare_data / prepare_test_data."""
     if isinstance(split, str):
         split = SPLIT_CODE[split]
-    return (kind << 32) | (split << 24) | layer
+    assert 0 <= layer < 256 and 0 <= epoch < 65536
+    return (kind << 32) | (split << 24) | (epoch << 8) | layer

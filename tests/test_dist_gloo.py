@@ -48,6 +48,16 @@ def _worker(rank, world, port, q):
     parts = [ref(full[slice(*D.shard_range(n, r, world))]).sum() for r in range(world)]
     (sum(parts) / world).backward()
     ok_grad = torch.allclose(w.weight.grad, ref.weight.grad) and torch.allclose(w.bias.grad, ref.bias.grad)
+    # a parameter only rank 0's shard exercises: rank 1 has no gradient for it, yet both ranks must issue
+    # the same collective (the bucket layout follows the parameters, not the existing gradients)
+    extra = torch.nn.Parameter(torch.ones(4))
+    w.zero_grad(set_to_none=True)
+    loss = w(full[a:b]).sum() + ((extra * torch.arange(4.0)).sum() if rank == 0 else 0.0)
+    loss.backward()
+    assert (extra.grad is None) == (rank != 0)
+    D.all_reduce_gradients(list(w.parameters()) + [extra], big_bytes=1 << 20)
+    ok_grad = ok_grad and torch.allclose(extra.grad, torch.arange(4.0) / world) and \
+        torch.allclose(w.weight.grad, ref.weight.grad)
     q.put((rank, (a, b), bool(ok_gather), bool(ok_grad)))
     dist.destroy_process_group()
 

@@ -13,7 +13,7 @@ from test_gpu_train_driver import CONFIG
 pytestmark = pytest.mark.gpu
 
 
-def _fit(tiny, root, graph, resample, epochs=7):
+def _fit(tiny, root, graph, resample, epochs=7, extra=None):
     from subgnn_amd import config, train_config
     write_dataset_from_golden(tiny, root, 'ds')
     fix = dict(tiny.hp)
@@ -21,6 +21,7 @@ def _fit(tiny, root, graph, resample, epochs=7):
         fix.pop(k, None)
     fix.update({'max_epochs': epochs, 'seed': 3, 'lin_dropout': 0.0, 'compute_similarities': True,
                 'resample_anchor_patches': resample, 'hip_graph_step': graph})
+    fix.update(extra or {})
     (root / 'config.json').write_text(CONFIG % json.dumps(fix))
     config.PROJECT_ROOT = root
     rc = train_config.read_json(root / 'config.json')
@@ -60,3 +61,34 @@ def test_captured_step_rejects_other_batch_size(tiny, tmp_path):
     for _ in range(5):                                      # 3 eager warm-ups, 1 recording, replays
         loss, acc = cap.replay(torch.arange(4))
     assert cap.graph is not None and torch.isfinite(loss) and 0.0 <= float(acc) <= 1.0
+
+
+def test_captured_step_with_fp16_table_keeps_validation_fresh(tiny, tmp_path):
+    """embedding_dtype='fp16' + hip_graph_step: a replayed Adam step changes the master table without
+    moving its host-side version counter.  The half copy the eager validation reads must follow it --
+    after every epoch the copy equals the rounded master, and the run matches the eager fp16 run."""
+    (tmp_path / 'a').mkdir()
+    (tmp_path / 'b').mkdir()
+    m0, t0 = _fit(tiny, tmp_path / 'a', False, False, epochs=4, extra={'embedding_dtype': 'fp16'})
+    m1, t1 = _fit(tiny, tmp_path / 'b', True, False, epochs=4, extra={'embedding_dtype': 'fp16'})
+    assert t1.hip_graph_step
+    with torch.no_grad():                     # a read that does not refresh by itself: what the last validation saw
+        for m in (m0, m1):
+            assert torch.equal(m._half_table().float(), m.node_embeddings.weight.detach().half().float())
+    v0 = torch.tensor([float(e['val_loss']) for e in m0.metric_scores])
+    v1 = torch.tensor([float(e['val_loss']) for e in m1.metric_scores])
+    assert len(v0) == 4 and torch.allclose(v0, v1, rtol=5e-3, atol=1e-5), (v0, v1)
+    # the table moved during training, so a stale copy would have shown
+    assert float((m1.node_embeddings.weight.detach() - torch.from_numpy(tiny['embeddings']).to(m1.device)).abs().max()) > 0
+
+
+def test_recording_goes_stale_when_prepared_tensors_are_replaced(tiny, tmp_path):
+    from subgnn_amd.graph_step import CapturedTrainStep
+    (tmp_path / 'a').mkdir()
+    m, t = _fit(tiny, tmp_path / 'a', False, False, epochs=1)
+    cap = CapturedTrainStep(m, m.configure_optimizers(), 4, 1.0)
+    assert not cap.stale()
+    m._build_sim_cols()                      # nothing replaced: same patches
+    assert not cap.stale()
+    m.prepare_data()                         # every prepared tensor is a new object now
+    assert cap.stale()

@@ -372,6 +372,24 @@ def test_choice_golden(golden):
         assert np.array_equal(got.cpu().numpy()[0], golden['g8_S_idx_%d' % l])
 
 
+def test_sample_position_anchor_patches_per_subgraph(golden):
+    """aps:200-208 with the reference's own signature: one subgraph at a time (internal) or none (the
+    shared border anchors) -> the python lists the reference returns, equal to the reference's draws
+    under the tape (g8) -- and hence to the batched init_anchors_pos_int."""
+    from subgnn_amd import anchor_patch_samplers as aps
+    G, dg = _graphs(golden)
+    hp = dict(golden.hp)
+    hp['seed'] = golden.seed
+    for l in range(hp['n_layers']):
+        got = aps.sample_position_anchor_patches(hp, dg, None, layer=l)
+        assert isinstance(got, list) and got == golden['g8_P_ext_%d' % l].tolist()
+        for sp in ('train', 'val'):
+            subs = golden.ragged('subgraphs_' + sp, 0)
+            for i in (0, len(subs) // 2, len(subs) - 1):
+                got = aps.sample_position_anchor_patches(hp, dg, subs[i], split=sp, layer=l, item=i)
+                assert got == golden['g8_P_int_%s_%d' % (sp, l)][i].tolist()
+
+
 # ---- a1-a3 walks --------------------------------------------------------------------------
 
 @pytest.fixture(params=['workgroup', 'wavefront'])

@@ -174,11 +174,27 @@ def test_fp16_stored_table_equals_fp32_on_rounded_values(tiny, tmp_path, variant
                      {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None})
         if mode == 'fp16':
             h0 = m._half_table()
-            assert h0.dtype == torch.float16 and h0 is m._half_table()                  # cached while unchanged
+            assert h0.dtype == torch.float16 and h0 is m._half_table()                  # one persistent buffer
             with torch.no_grad():
                 m.node_embeddings.weight.add_(1.0)
-            h1 = m._half_table()
-            assert h1 is not h0 and torch.equal(h1.float(), m.node_embeddings.weight.half().float())
+                h1 = m._half_table()                                                    # refreshed in place
+                assert h1 is h0 and torch.equal(h1.float(), m.node_embeddings.weight.half().float())
+                # a change nothing can see (fused Adam and graph replays are handled by the dirty mark a
+                # training read leaves; this is a raw .data edit)
+                m.node_embeddings.weight.data.sub_(0.5)
+                assert not torch.equal(m._half_table().float(), m.node_embeddings.weight.half().float())
+                m.invalidate_half_table()
+                assert torch.equal(m._half_table().float(), m.node_embeddings.weight.half().float())
+            # fused Adam does not move the parameter's version counter: the copy must follow all the same
+            opt = m.configure_optimizers()
+            out = m.training_step(batch, 0)
+            opt.zero_grad()
+            m.backward(None, out['loss'], None, 0)
+            before = m.node_embeddings.weight.detach().clone()
+            opt.step()
+            assert not torch.equal(before, m.node_embeddings.weight.detach())
+            with torch.no_grad():
+                assert torch.equal(m._half_table().float(), m.node_embeddings.weight.half().float())
     assert_close(res['fp16'][0], res['fp32'][0].cpu().numpy(), 'loss')
     assert_close(res['fp16'][1], res['fp32'][1].cpu().numpy(), 'logits')
     assert res['fp16'][2].keys() == res['fp32'][2].keys()
