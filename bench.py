@@ -7,16 +7,22 @@
 
 Workload (BASELINE.json configs[3], the one the 1/2/4/8-GPU metric is quoted on): synthetic
 DENSITY-style base graph, Barabasi-Albert n = 1M, m = 10 (10M undirected edges), BFS subgraphs
-of 20 nodes, 50k subgraphs PER GPU (weak scaling: the shard is the unit), embeddings (N, 64)
-fp32 random, hyper-parameters best_model_hyperparameters/density/all_density_hyperparams.json
-(all three channels, 1 layer, N 10/43, P 57/183, S 42) with max_sim_epochs = 5 and a 1-hop
-neighbourhood border (what the reference effectively uses when ego_graphs.txt is present).
+of 20 nodes, embeddings (N, 64) fp32 random, hyper-parameters
+best_model_hyperparameters/density/all_density_hyperparams.json (all three channels, 1 layer,
+N 10/43, P 57/183, S 42) with max_sim_epochs = 5 and a 1-hop neighbourhood border (what the
+reference effectively uses when ego_graphs.txt is present).
+  --scaling weak   (default) 50k subgraphs PER GPU: the shard is the unit, per-GPU work is fixed;
+  --scaling strong 50k subgraphs IN TOTAL, dealt to the ranks in contiguous blocks; the shared
+                   per-layer work (the position channel's BFS sources) is dealt across ranks too.
 
 One step = one full pass of the hot path over the rank's shard, everything on the GPU:
   anchor-patch sampling + similarities (connected components, k-hop border BFS, N/P/S anchor
   draws, structure patches + triangular walks, degree sequences, DTW, multi-source BFS
-  position similarities)  ->  three-channel forward  ->  loss  ->  backward  ->
-  [N>1: RCCL all-gather of the per-component channel embeddings, all-reduce of the gradients]
+  position similarities)  ->  three channels forward  ->
+  [N>1: RCCL all-gather of the per-component channel embeddings: the read-out + MLP head + loss
+   run replicated on the global batch]  ->  backward  ->
+  [N>1: all-reduce of the small channel gradients; reduce-scatter of the embedding-table
+   gradient, owner-computes Adam, all-gather of the updated rows under the next pass]
   ->  Adam step.
 value = subgraphs processed by all ranks / max-over-ranks step time.
 
@@ -65,7 +71,8 @@ def parse():
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--nodes', type=int, default=1_000_000)
     ap.add_argument('--m', type=int, default=10)
-    ap.add_argument('--subgraphs', type=int, default=50_000, help='subgraphs per GPU')
+    ap.add_argument('--subgraphs', type=int, default=50_000, help='subgraphs per GPU (weak) / in total (strong)')
+    ap.add_argument('--scaling', choices=['weak', 'strong'], default='weak')
     ap.add_argument('--subgraph-nodes', type=int, default=20)
     ap.add_argument('--embed', type=int, default=64)
     ap.add_argument('--embedding-dtype', choices=['fp32', 'fp16'], default='fp32',
@@ -75,13 +82,23 @@ def parse():
     return ap.parse_args()
 
 
-def build_inputs(args, rank):
+def build_inputs(args, rank, world):
+    """Graph (identical on every rank) and this rank's subgraphs.  weak: rank r draws its own
+    ``--subgraphs`` subgraphs (seed 1000 + r); strong: every rank draws the same ``--subgraphs`` subgraphs
+    (seed 1000) and keeps its contiguous block."""
     from subgnn_amd import synthetic
+    from subgnn_amd.dist import shard_range
     t0 = time.time()
     edges = synthetic.barabasi_albert_edges(args.nodes, args.m, seed=42)
     rowptr, col = synthetic.sorted_csr(edges, args.nodes)
-    subs = synthetic.bfs_subgraphs(rowptr, col, args.subgraphs, args.subgraph_nodes, seed=1000 + rank)
-    return rowptr, col, subs, time.time() - t0
+    if args.scaling == 'strong':
+        a, b = shard_range(args.subgraphs, rank, world)
+        subs = synthetic.bfs_subgraphs(rowptr, col, args.subgraphs, args.subgraph_nodes, seed=1000)[a:b]
+        total = args.subgraphs
+    else:
+        subs = synthetic.bfs_subgraphs(rowptr, col, args.subgraphs, args.subgraph_nodes, seed=1000 + rank)
+        total = args.subgraphs * world
+    return rowptr, col, subs, total, time.time() - t0
 
 
 DS_SEARCH = 512      # csrc/degree_sequence.hip: with row-sorted CSR, lists of >= DS_SEARCH entries are searched, not streamed
@@ -112,12 +129,19 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit('launch with torch.distributed.run --nproc-per-node %d' % args.gpus)
+    # SGNN_DIST_BACKEND=gloo: functional check of the multi-rank path on a box with fewer GPUs than ranks
+    # (ranks then share GPUs and the collectives go through host memory); never a measurement
+    backend = os.environ.get('SGNN_DIST_BACKEND', 'nccl')
+    local = local % max(torch.cuda.device_count(), 1) if backend != 'nccl' else local
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     dist = None
     if world > 1 or 'RANK' in os.environ:            # launched by torch.distributed.run: one rank per GPU over RCCL
         import torch.distributed as dist
-        dist.init_process_group('nccl', device_id=dev)
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from subgnn_amd import ops, hotpath, build
     from subgnn_amd import dist as sdist
@@ -127,7 +151,7 @@ def main():
     if dist:
         dist.barrier()
 
-    rowptr, col, subs, t_gen = build_inputs(args, rank)
+    rowptr, col, subs, total_subgraphs, t_gen = build_inputs(args, rank, world)
     n = args.nodes
     g = ops.DeviceGraph(rowptr, col, np.arange(1, n + 1, dtype=np.int32), dev)
     torch.manual_seed(0)
@@ -137,42 +161,71 @@ def main():
     hp['embedding_dtype'] = args.embedding_dtype
     if os.environ.get('SGNN_OVERLAP_STREAMS'):
         hp['overlap_streams'] = True
-    labels = torch.randint(0, 3, (len(subs),), generator=torch.Generator().manual_seed(rank))
-    labels[:3] = torch.tensor([0, 1, 2])
-    model = SubGNN.from_memory(hp, g, {'train': subs, 'val': [], 'test': []},
-                               {'train': labels, 'val': labels[:0], 'test': labels[:0]}, emb)
-    model.train()
-    opt = model.configure_optimizers()
-    params = [p for p in model.parameters() if p.requires_grad]
     S = len(subs)
+    multi = dist is not None and world > 1
+    shard = sdist.Shard(total_subgraphs, rank, world, deal_shared=(args.scaling == 'strong')) if multi else None
+    if multi and shard.size != S:
+        raise SystemExit('shard size mismatch')
+    # labels of the GLOBAL batch (a function of the global subgraph number): the replicated head needs them all
+    all_labels = torch.randint(0, 3, (total_subgraphs,), generator=torch.Generator().manual_seed(0))
+    all_labels[:3] = torch.tensor([0, 1, 2])
+    first = shard.start if multi else 0
+    labels = all_labels[first:first + S].clone()
+    if multi:
+        if total_subgraphs % world:
+            raise SystemExit('the replicated head needs equal shards: %d subgraphs over %d ranks' % (total_subgraphs, world))
+        hp['dp_gather_embeddings'] = True
+    model = SubGNN.from_memory(hp, g, {'train': subs, 'val': [], 'test': []},
+                               {'train': labels, 'val': labels[:0], 'test': labels[:0]}, emb, num_classes=3)
+    model.train()
+    table = model.node_embeddings.weight
+    head = {id(p) for m_ in (model.lin, model.lin2, model.lin3) for p in m_.parameters()}
+    if multi:
+        # table: reduce-scatter + owner-computes Adam (dist.ShardedTableAdam); everything else: torch's fused Adam
+        small = [p for p in model.parameters() if p.requires_grad and p is not table]
+        opt = torch.optim.Adam(small, lr=hp['learning_rate'], fused=True)
+        table_opt = sdist.ShardedTableAdam(table, hp['learning_rate'])
+        model._table_sync = table_opt.wait
+        channel_params = [p for p in small if id(p) not in head]
+        labels_dev = all_labels.to(dev)
+    else:
+        opt = model.configure_optimizers()
+    params = [p for p in model.parameters() if p.requires_grad]
 
     stage_ms = {}
-    degseq = {'ms': 0.0, 'launches': 0}
 
     def step(timed):
         timer = hotpath.StageTimer(timed)
-        hotpath.prepare_sparse(model, 'train', timer)
+        hotpath.prepare_sparse(model, 'train', timer, shard)
         batch = hotpath.full_split_batch(model, 'train')
+        if multi:
+            batch['label'] = labels_dev                          # the head runs on the gathered global batch
         out = model.training_step(batch, 0)
         timer.mark('forward')
-        pending = None
-        if dist:
-            # the path's one exchange step: all-gather of the per-component channel embeddings
-            # (every rank ends up with the (world * S * C, hid_dim) matrix of the global batch);
-            # issued now, on RCCL's stream, so that it travels while backward computes
-            pending = sdist.all_gather_rows(model._last_cc_embeds, equal_rows=True, async_op=True)
         model.backward(None, out['loss'], None, 0)
         timer.mark('backward')
-        if dist:
-            # DP training additionally all-reduces the gradients (table gradient in place, the
-            # small ones in one flat bucket)
-            sdist.all_reduce_gradients(params)
-            gathered = pending.wait()
-            assert gathered.shape[0] == world * model._last_cc_embeds.shape[0]
-            timer.mark('collectives')
-        torch.nn.utils.clip_grad_norm_(params, hp['grad_clip'])
+        if not multi:
+            torch.nn.utils.clip_grad_norm_(params, hp['grad_clip'])
+            opt.step()
+            opt.zero_grad(set_to_none=True)
+            timer.mark('optimizer')
+            return timer, float(out['loss'].detach())
+        # The loss is the mean over the GLOBAL batch and the head is replicated: head gradients are already
+        # complete and identical on every rank; channel parameters (message-passing layers, LSTM, the table)
+        # hold this rank's share of the sum.
+        sdist.all_reduce_gradients(channel_params, average=False)
+        sq = table_opt.reduce_grad()
+        torch.distributed.all_reduce(sq)
+        total = torch.sqrt(sq + sum((p.grad.float() ** 2).sum() for p in small if p.grad is not None))
+        coef = torch.clamp(hp['grad_clip'] / (total + 1e-6), max=1.0)         # clip_grad_norm_'s rule on the global norm
+        timer.mark('collectives')
+        for p in small:
+            if p.grad is not None:
+                p.grad.mul_(coef)
         opt.step()
+        table_opt.step(grad_scale=coef)                          # its all-gather is waited for inside the next prepare_sparse
         opt.zero_grad(set_to_none=True)
+        table.grad = None
         timer.mark('optimizer')
         return timer, float(out['loss'].detach())
 
@@ -180,11 +233,7 @@ def main():
         # communicator set-up happens lazily at the first collective of each kind and size class: do it
         # here, with the shapes the step uses, so that it never lands in a timed step
         sdist.all_gather_rows(torch.zeros((S, 8), device=dev), equal_rows=True)
-        big = max((p.numel() for p in params), default=1)
-        scratch = torch.zeros(big, device=dev)
-        dist.all_reduce(scratch)
         dist.all_reduce(torch.zeros(1024, device=dev))
-        del scratch
         torch.cuda.synchronize()
     # one-time work is kept out of the W warm-up steps the caller asked for: the first pass computes what is
     # kept per split (dispatch order, row-grouping decision), the second is the first to run the steady
@@ -204,6 +253,8 @@ def main():
     for _ in range(args.steps):
         tm, loss = step(True)
         timers.append(tm)
+    if multi:
+        table_opt.wait()                                         # the last step's table all-gather belongs to the timed region
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
@@ -259,7 +310,7 @@ def main():
         # (tools/run_hbm_probe.sh: separate --pmc passes, FETCH_SIZE calibrated on a copy of known size)
         with open(tf) as f:
             tj = json.load(f)
-        if args.nodes == 1_000_000 and S == 50_000 and args.m == 10:
+        if args.nodes == 1_000_000 and S == 50_000 and args.m == 10 and rank == 0:
             traffic = tj['benchmark_graph']['streaming']['memory_side_bytes_per_launch']
             traffic_src = 'profiles/r02_degseq_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; ' \
                           'FETCH_SIZE x2 per the 4 B/lane calibration copy)'
@@ -272,16 +323,19 @@ def main():
                                  for form in ('streaming', 'shipped_search')}
     result = {
         'metric': 'subgraphs/sec fwd+bwd (all 3 channels on) + achieved HBM GB/s',
-        'value': world * S * args.steps / elapsed, 'unit': 'subgraphs/s', 'n_gpus': world, 'steps': args.steps,
+        'value': total_subgraphs * args.steps / elapsed, 'unit': 'subgraphs/s', 'n_gpus': world, 'steps': args.steps,
         'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True,
-        'scaling': 'weak', 'vs_baseline': None,
+        'scaling': args.scaling, 'vs_baseline': None,
         'dtype': 'f32' if args.embedding_dtype == 'fp32' else 'f32 (embedding table stored fp16, fp32 accumulate)',
-        'data': 'synthetic',
+        'data': 'synthetic' if backend == 'nccl' else 'synthetic (FUNCTIONAL CHECK over %s, not a measurement)' % backend,
         'config': {'workload': 'synthetic DENSITY-style BA base graph n=%d m=%d (%d undirected edges), %d BFS '
-                               'subgraphs x %d nodes per GPU, all_density hparams (N 10/43, P 57/183, S 42, 1 layer), '
+                               'subgraphs x %d nodes %s, all_density hparams (N 10/43, P 57/183, S 42, 1 layer), '
                                'D=%d, full pass = sampling + similarities + fwd + bwd + Adam' %
-                               (n, args.m, int(rowptr[-1]) // 2, S, args.subgraph_nodes, args.embed),
-                   'subgraphs_per_gpu': S, 'parallelism': 'dp%d (subgraph shards, RCCL all-gather + grad all-reduce)' % world},
+                               (n, args.m, int(rowptr[-1]) // 2, args.subgraphs, args.subgraph_nodes,
+                                'per GPU' if args.scaling == 'weak' else 'in total', args.embed),
+                   'subgraphs_per_gpu': S, 'subgraphs_total': total_subgraphs,
+                   'parallelism': 'dp%d (subgraph shards; RCCL all-gather of the channel embeddings into a replicated head, '
+                                  'all-reduce of channel gradients, reduce-scatter / all-gather of the embedding table)' % world},
         'roofline': {'kernel': 'degseq_wave_kernel<true, false, false> (sgnn_degree_sequence: structure-channel CSR gather, '
                                'every neighbour list streamed)',
                      'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',

@@ -37,7 +37,7 @@ extern "C" {
 #define SGNN_ERR_LAUNCH         -4   /* hipGetLastError() after a launch */
 #define SGNN_ERR_UNSUPPORTED_D  -5   /* embedding width not supported by the vector path */
 
-#define SGNN_ABI_VERSION 1
+#define SGNN_ABI_VERSION 2
 int sgnn_abi_version(void);
 /* last hip error string for SGNN_ERR_LAUNCH (static storage) */
 const char* sgnn_last_error(void);
@@ -135,6 +135,7 @@ int sgnn_khop_border_arena(const int64_t* rowptr, const int32_t* col, int64_t nn
  * anchor draw of anchor_patch_samplers.sample_neighborhood_anchor_patch(sample_inside=False)
  * (anchor_patch_samplers.py:184-194) over it, under the neighbourhood-anchor law stated at
  * sgnn_sample_anchors_padded.  For set s and slot i (tape item s*n_slots+i): out_anchor = the k-th
+ * (item_base + s)*n_slots+i when the sets are rows item_base.. of a larger, sharded launch) --
  * smallest border id (a rank query on the visited bitmap -- no sort, no per-node hashing), out_hop =
  * its hop level (the N-border similarity, = the APSP row-min of SubGNN.py:772 on that column),
  * out_allneg = the item's "every variate negative" draw -- the caller applies the PAD rule of
@@ -142,7 +143,7 @@ int sgnn_khop_border_arena(const int64_t* rowptr, const int32_t* col, int64_t nn
  * out_count[s] < max count).  An empty border yields anchor 0. */
 int sgnn_khop_border_sample(const int64_t* rowptr, const int32_t* col, int64_t nnz, int64_t max_id,
                             const int64_t* set_ptr, const int32_t* set_nodes, int64_t n_sets, int k,
-                            int64_t n_slots, uint64_t seed, uint64_t stream_id,
+                            int64_t n_slots, uint64_t seed, uint64_t stream_id, int64_t item_base,
                             int64_t* out_anchor, uint8_t* out_hop, uint8_t* out_allneg, int64_t* out_count,
                             const int32_t* set_order /* nullable: dispatch order of the sets, a permutation */,
                             void* workspace, int64_t workspace_bytes, int bitmap_in_lds, void* stream);
@@ -162,18 +163,20 @@ int sgnn_khop_border_sample(const int64_t* rowptr, const int32_t* col, int64_t n
 int sgnn_sample_anchors_padded(const int64_t* ids, int64_t n_rows, int64_t L, int64_t n_slots,
                                uint64_t seed, uint64_t stream_id, int64_t* out, void* stream);
 /* same law on ragged sets, each ascending; row_has_pad[r] (nullable = all 1) says whether the
- * padded row would hold a PAD. */
+ * padded row would hold a PAD.  item_base: number of the first set within the whole (possibly
+ * sharded) matrix -- set r draws as tape item (item_base + r)*n_slots + slot, so a shard of the rows
+ * reproduces the draws of the unsharded call. */
 int sgnn_sample_anchors_ragged(const int64_t* set_ptr, const int32_t* set_nodes, int64_t n_sets,
                                const uint8_t* row_has_pad, int64_t n_slots,
-                               uint64_t seed, uint64_t stream_id, int64_t* out, void* stream);
+                               uint64_t seed, uint64_t stream_id, int64_t item_base, int64_t* out, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * a5/a6  Uniform draws with replacement from a list (position anchors, structure picks).
  * Replaces np.random.choice(seq, n, replace=True) at anchor_patch_samplers.py:206,208,326.
- * item r draws from seq[ptr[r] .. ptr[r+1]); out (n_items, n_draws) int64.
+ * list r draws as tape item item_base + r from seq[ptr[r] .. ptr[r+1]); out (n_items, n_draws) int64.
  * ------------------------------------------------------------------------------------- */
 int sgnn_choice_ragged(const int64_t* ptr, const int32_t* seq, int64_t n_items, int64_t n_draws,
-                       uint64_t seed, uint64_t stream_id, int64_t* out, void* stream);
+                       uint64_t seed, uint64_t stream_id, int64_t item_base, int64_t* out, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * a1-a3  Triangular random walks.

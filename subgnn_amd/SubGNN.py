@@ -185,7 +185,7 @@ class SubGNN(nn.Module):
             setattr(self, sp + '_sub_G', mem['sub_G'].get(sp, []))
             setattr(self, sp + '_sub_G_label', mem['labels'].get(sp, torch.zeros(0, dtype=torch.int64)))
         self.multilabel, self.multilabel_binarizer = False, None
-        self.num_classes = int(max(int(l.max()) for l in mem['labels'].values() if l.numel() > 0)) + 1
+        self.num_classes = mem.get('num_classes') or int(max(int(l.max()) for l in mem['labels'].values() if l.numel() > 0)) + 1
         pre = mem['embeddings']
         self.hparams['node_embed_size'] = pre.shape[1]
         table = torch.cat((torch.zeros(1, pre.shape[1], device=pre.device), pre.float()), 0)
@@ -193,9 +193,10 @@ class SubGNN(nn.Module):
                                                             padding_idx=config.PAD_VALUE)
 
     @classmethod
-    def from_memory(cls, hparams, graph, sub_G, labels, embeddings):
+    def from_memory(cls, hparams, graph, sub_G, labels, embeddings, num_classes=None):
+        """``num_classes``: give it when the labels at hand are one shard of the data (a class may be absent)."""
         return cls(hparams, None, None, None, 'similarities', None, None, None,
-                   _memory=dict(graph=graph, sub_G=sub_G, labels=labels, embeddings=embeddings))
+                   _memory=dict(graph=graph, sub_G=sub_G, labels=labels, embeddings=embeddings, num_classes=num_classes))
 
     # ------------------------------------------------------------------ components -------
     def initialize_cc_ids(self, subgraph_ids):
@@ -450,12 +451,14 @@ class SubGNN(nn.Module):
                 lab = torch.LongTensor(self.multilabel_binarizer.transform(labels))
             else:
                 lab = labels.view(-1)
-            # widths of the left-justified padded rows, per subgraph, on the HOST: trimming a batch to
-            # its widest row (S.py:1098-1099,1109-1110) then needs no device round trip
+            # which columns of the padded rows hold a non-PAD entry, per subgraph, on the HOST: dropping a
+            # batch's all-PAD columns (S.py:1098-1099,1109-1110) then needs no device round trip.  Not
+            # just a width: with ego_graphs.txt a border row can hold the id 0 itself (su:168-174), which
+            # the trim cannot tell from PAD -- an all-zero column is dropped wherever it lies.
             cc = getattr(self, split + '_cc_ids')
             nb = getattr(self, split + '_N_border', None)
-            w_cc = (cc != 0).sum(dim=2).amax(dim=1).cpu()
-            w_nb = (nb != 0).sum(dim=2).amax(dim=1).cpu() if nb is not None else None
+            w_cc = (cc != 0).any(dim=1).cpu()
+            w_nb = (nb != 0).any(dim=1).cpu() if nb is not None else None
             cache[split] = (ids.to(self.device), lab.to(self.device), w_cc, w_nb)
         return cache[split]
 
@@ -479,11 +482,16 @@ class SubGNN(nn.Module):
         batch_cc, batch_nb = pick(cc), pick(nb)
         if trim:
             hidx = idx.cpu()
-            wc = max(int(w_cc[hidx].max()), 0) if idx.numel() else 0
-            batch_cc = batch_cc[:, :, :wc].contiguous()
+
+            def drop_pad_columns(t, nz):
+                keep = nz[hidx].any(dim=0) if idx.numel() else torch.zeros(t.shape[2], dtype=torch.bool)
+                k = int(keep.sum())
+                if bool(keep[:k].all()):                       # left-justified rows: the kept columns are a prefix
+                    return t[:, :, :k].contiguous()
+                return t.index_select(2, keep.nonzero().view(-1).to(t.device))
+            batch_cc = drop_pad_columns(batch_cc, w_cc)
             if nb is not None:
-                wn = max(int(w_nb[hidx].max()), 0) if idx.numel() else 0
-                batch_nb = batch_nb[:, :, :wn].contiguous()
+                batch_nb = drop_pad_columns(batch_nb, w_nb)
         return {'subgraph_ids': pick(sub_ids), 'cc_ids': batch_cc, 'N_border': batch_nb,
                 'NP_sim': pick(npsim), 'I_S_sim': pick(isim), 'B_S_sim': pick(bsim),
                 'subgraph_idx': didx.view(-1, 1), 'label': pick(lab)}
@@ -610,7 +618,19 @@ class SubGNN(nn.Module):
                 pick = 0 if tag == 'N' else 1                      # N adds CC embeddings, P/S their read-outs
                 outputs.extend([res['I'][pick], res['B'][pick]])
         all_cc_embeds = torch.cat([init_cc_embeds] + outputs, dim=-1)
-        self._last_cc_embeds = all_cc_embeds.detach().reshape(B * C, -1)     # what a DP all-gather ships
+        self._last_cc_embeds = all_cc_embeds.detach().reshape(B * C, -1)
+        if hp.get('dp_gather_embeddings', False):
+            # data parallelism over subgraph shards: the one exchange of the data path.  Every rank has
+            # computed the per-component channel embeddings of ITS subgraphs; the all-gather (RCCL over xGMI)
+            # assembles the global batch on every rank and the read-out + MLP head + loss below run
+            # replicated on it -- identical on all ranks, so head gradients need no reduction, and each
+            # rank's slice of d loss / d embeddings flows back into its own channels
+            # (dist.gather_rows_replicated).  The caller supplies the labels of the global batch.
+            from . import dist as sdist
+            H = all_cc_embeds.shape[-1]
+            all_cc_embeds = sdist.gather_rows_replicated(all_cc_embeds.reshape(B * C, H)).view(-1, C, H)
+            cc_embed_mask = sdist.all_gather_rows(cc_embed_mask.reshape(B * C, 1).to(torch.uint8),
+                                                  equal_rows=True).view(-1, C).bool()
         if hp.get('ff_attn', False):                                    # S.py:298-301
             batched_attn = self.attn_vector.squeeze().unsqueeze(0).repeat(all_cc_embeds.shape[0], 1)
             attn_weights = self.attention(batched_attn, all_cc_embeds, cc_embed_mask)

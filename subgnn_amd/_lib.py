@@ -45,11 +45,11 @@ SIGNATURES = {
                                  c_ptr, c_ptr, c_i64, c_int, c_ptr]),
     'sgnn_khop_border_arena': (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_i64, c_int, c_ptr, c_ptr, c_ptr, c_ptr,
                                        c_i64, c_int, c_ptr]),
-    'sgnn_khop_border_sample': (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_i64, c_int, c_i64, c_u64, c_u64,
+    'sgnn_khop_border_sample': (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_i64, c_int, c_i64, c_u64, c_u64, c_i64,
                                         c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_ptr]),
     'sgnn_sample_anchors_padded': (c_int, [c_ptr, c_i64, c_i64, c_i64, c_u64, c_u64, c_ptr, c_ptr]),
-    'sgnn_sample_anchors_ragged': (c_int, [c_ptr, c_ptr, c_i64, c_ptr, c_i64, c_u64, c_u64, c_ptr, c_ptr]),
-    'sgnn_choice_ragged': (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_u64, c_u64, c_ptr, c_ptr]),
+    'sgnn_sample_anchors_ragged': (c_int, [c_ptr, c_ptr, c_i64, c_ptr, c_i64, c_u64, c_u64, c_i64, c_ptr, c_ptr]),
+    'sgnn_choice_ragged': (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_u64, c_u64, c_i64, c_ptr, c_ptr]),
     'sgnn_triangular_walks': (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_int,
                                       c_i64, c_i64, c_i64, c_dbl, c_u64, c_u64, c_i64, c_ptr, c_ptr]),
     'sgnn_walks_force_wave': (c_int, [c_int]),
@@ -108,7 +108,7 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the header and the library disagree
         fn.restype = res
         fn.argtypes = args
-    if lib.sgnn_abi_version() != 1:
+    if lib.sgnn_abi_version() != 2:
         raise SubgnnHipError('ABI version mismatch')
     _lib = lib
     return lib

@@ -118,13 +118,9 @@ def sample_position_anchor_patches(hparams, networkx_graph, subgraph=None, split
         r = ops.Ragged(_span_ptr(g.n_nodes, g.device), g.node_order)
         return ops.choice_ragged(r, hparams['n_anchor_patches_pos_out'], _seed(hparams),
                                  tape.stream_id(tape.STREAM_P_EXT, 0, layer, epoch))[0].tolist()
-    # the kernel numbers its tape items by set: hand it ``item`` empty sets in front of the subgraph
-    nodes = torch.as_tensor([int(v) for v in subgraph], dtype=torch.int32, device=g.device)
-    ptr = torch.zeros(int(item) + 2, dtype=torch.int64, device=g.device)
-    ptr[-1] = nodes.numel()
-    r = ops.Ragged(ptr, nodes, max_len=int(nodes.numel()))
+    r = ops.Ragged.from_lists([[int(v) for v in subgraph]], g.device)
     return ops.choice_ragged(r, hparams['n_anchor_patches_pos_in'], _seed(hparams),
-                             tape.stream_id(tape.STREAM_P_INT, split, layer, epoch))[int(item)].tolist()
+                             tape.stream_id(tape.STREAM_P_INT, split, layer, epoch), item_base=int(item))[0].tolist()
 
 
 # ---------------------------------------------------------------------------------------

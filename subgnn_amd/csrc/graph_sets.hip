@@ -344,6 +344,7 @@ struct KbSample {             // fused neighbourhood-border anchor draw (all NUL
     int64_t* anchor;          // (n_sets, n_slots) chosen border node id (0 for an empty border)
     uint8_t* hop;             // (n_sets, n_slots) its hop level
     uint8_t* allneg;          // (n_sets, n_slots) 1 if "every variate negative" (PAD wins if the row is padded)
+    int64_t item_base;        // tape item of (set s, slot i) = (item_base + s) * n_slots + i
 };
 
 // The global-memory bitmap is written with L2 atomics only; a plain load could be served from a
@@ -393,7 +394,7 @@ __device__ __forceinline__ void kb_select(const KbSample& smp, int64_t s, const 
             int32_t id = 0;
             uint8_t an = 1;
             if (cnt > 0) {
-                const uint64_t h1 = sgnn_tape_h1(smp.h0, (uint64_t)o);
+                const uint64_t h1 = sgnn_tape_h1(smp.h0, (uint64_t)(o + smp.item_base * smp.n_slots));
                 an = sgnn_nanchor_allneg(h1, (uint32_t)cnt) ? 1 : 0;
                 int rem = (int)sgnn_nanchor_index(h1, (uint32_t)cnt);
                 int lo = 0, hi = THREADS - 1;                                // largest T with s_pref[T] <= rem
@@ -721,13 +722,13 @@ extern "C" int sgnn_khop_border_arena(const int64_t* rowptr, const int32_t* col,
 
 extern "C" int sgnn_khop_border_sample(const int64_t* rowptr, const int32_t* col, int64_t nnz, int64_t max_id,
                                        const int64_t* set_ptr, const int32_t* set_nodes, int64_t n_sets, int k,
-                                       int64_t n_slots, uint64_t seed, uint64_t stream_id,
+                                       int64_t n_slots, uint64_t seed, uint64_t stream_id, int64_t item_base,
                                        int64_t* out_anchor, uint8_t* out_hop, uint8_t* out_allneg, int64_t* out_count,
                                        const int32_t* set_order,
                                        void* workspace, int64_t workspace_bytes, int bitmap_in_lds, void* stream)
 {
-    if (!out_anchor || !out_hop || !out_allneg || !out_count || n_slots < 1) return SGNN_ERR_BAD_ARG;
-    KbSample smp = {n_slots, sgnn_tape_h0(seed, stream_id), out_anchor, out_hop, out_allneg};
+    if (!out_anchor || !out_hop || !out_allneg || !out_count || n_slots < 1 || item_base < 0) return SGNN_ERR_BAD_ARG;
+    KbSample smp = {n_slots, sgnn_tape_h0(seed, stream_id), out_anchor, out_hop, out_allneg, item_base};
     return kb_launch(rowptr, col, nnz, max_id, set_ptr, set_nodes, n_sets, k, 0, out_count, nullptr, nullptr, nullptr,
                      workspace, workspace_bytes, bitmap_in_lds, smp, stream, 0, set_order);
 }

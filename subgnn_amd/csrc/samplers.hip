@@ -30,7 +30,7 @@ __global__ __launch_bounds__(256) void sample_anchors_padded_kernel(
 
 __global__ __launch_bounds__(256) void sample_anchors_ragged_kernel(
     const int64_t* __restrict__ set_ptr, const int32_t* __restrict__ set_nodes, int64_t n_sets,
-    const uint8_t* __restrict__ row_has_pad, int64_t n_slots, uint64_t h0, int64_t* __restrict__ out)
+    const uint8_t* __restrict__ row_has_pad, int64_t n_slots, uint64_t h0, int64_t item_base, int64_t* __restrict__ out)
 {
     const int64_t total = n_sets * n_slots;
     for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
@@ -40,7 +40,7 @@ __global__ __launch_bounds__(256) void sample_anchors_ragged_kernel(
         const bool has_pad = row_has_pad ? (row_has_pad[r] != 0) : true;
         int64_t v = 0;
         if (n > 0) {
-            const uint64_t h1 = sgnn_tape_h1(h0, (uint64_t)t);
+            const uint64_t h1 = sgnn_tape_h1(h0, (uint64_t)(t + item_base * n_slots));
             if (!(has_pad && sgnn_nanchor_allneg(h1, (uint32_t)n))) v = set_nodes[beg + sgnn_nanchor_index(h1, (uint32_t)n)];
         }
         out[t] = v;
@@ -61,13 +61,13 @@ extern "C" int sgnn_sample_anchors_padded(const int64_t* ids, int64_t n_rows, in
 
 extern "C" int sgnn_sample_anchors_ragged(const int64_t* set_ptr, const int32_t* set_nodes, int64_t n_sets,
                                           const uint8_t* row_has_pad, int64_t n_slots,
-                                          uint64_t seed, uint64_t stream_id, int64_t* out, void* stream)
+                                          uint64_t seed, uint64_t stream_id, int64_t item_base, int64_t* out, void* stream)
 {
-    if (!set_ptr || !set_nodes || !out || n_sets < 0 || n_slots < 0) return SGNN_ERR_BAD_ARG;
+    if (!set_ptr || !set_nodes || !out || n_sets < 0 || n_slots < 0 || item_base < 0) return SGNN_ERR_BAD_ARG;
     if (n_sets == 0 || n_slots == 0) return SGNN_OK;
     hipLaunchKernelGGL(sample_anchors_ragged_kernel, dim3(sgnn_grid_for(n_sets * n_slots, 256)), dim3(256), 0,
                        (hipStream_t)stream, set_ptr, set_nodes, n_sets, row_has_pad, n_slots,
-                       sgnn_tape_h0(seed, stream_id), out);
+                       sgnn_tape_h0(seed, stream_id), item_base, out);
     SGNN_CHECK_LAUNCH();
     return SGNN_OK;
 }
@@ -76,7 +76,8 @@ extern "C" int sgnn_sample_anchors_ragged(const int64_t* set_ptr, const int32_t*
 // a5/a6  np.random.choice(seq, n, replace=True) (reference anchor_patch_samplers.py:206,208,326)
 // ---------------------------------------------------------------------------------------------
 __global__ void choice_ragged_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ seq,
-                                     int64_t n_items, int64_t n_draws, uint64_t h0, int64_t* __restrict__ out)
+                                     int64_t n_items, int64_t n_draws, uint64_t h0, int64_t item_base,
+                                     int64_t* __restrict__ out)
 {
     const int64_t total = n_items * n_draws;
     for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
@@ -84,18 +85,18 @@ __global__ void choice_ragged_kernel(const int64_t* __restrict__ ptr, const int3
         const int64_t beg = ptr[r];
         const int64_t n = ptr[r + 1] - beg;
         int64_t v = 0;
-        if (n > 0) v = seq[beg + sgnn_choice_index(sgnn_tape_h1(h0, (uint64_t)r), (uint64_t)j, (uint32_t)n)];
+        if (n > 0) v = seq[beg + sgnn_choice_index(sgnn_tape_h1(h0, (uint64_t)(r + item_base)), (uint64_t)j, (uint32_t)n)];
         out[t] = v;
     }
 }
 
 extern "C" int sgnn_choice_ragged(const int64_t* ptr, const int32_t* seq, int64_t n_items, int64_t n_draws,
-                                  uint64_t seed, uint64_t stream_id, int64_t* out, void* stream)
+                                  uint64_t seed, uint64_t stream_id, int64_t item_base, int64_t* out, void* stream)
 {
-    if (!ptr || !seq || !out || n_items < 0 || n_draws < 0) return SGNN_ERR_BAD_ARG;
+    if (!ptr || !seq || !out || n_items < 0 || n_draws < 0 || item_base < 0) return SGNN_ERR_BAD_ARG;
     if (n_items * n_draws == 0) return SGNN_OK;
     hipLaunchKernelGGL(choice_ragged_kernel, dim3(sgnn_grid_for(n_items * n_draws, 256)), dim3(256), 0,
-                       (hipStream_t)stream, ptr, seq, n_items, n_draws, sgnn_tape_h0(seed, stream_id), out);
+                       (hipStream_t)stream, ptr, seq, n_items, n_draws, sgnn_tape_h0(seed, stream_id), item_base, out);
     SGNN_CHECK_LAUNCH();
     return SGNN_OK;
 }

@@ -22,6 +22,30 @@ def shard_range(n_items, rank, world):
     return start, start + base + (1 if rank < rem else 0)
 
 
+class Shard:
+    """This rank's contiguous block of a split's ``total`` subgraphs.  ``start`` is what makes a sharded
+    pass reproduce the unsharded one bit for bit: every per-subgraph draw reads the tape item of the
+    subgraph's GLOBAL number (hotpath.prepare_sparse passes it on as the samplers' ``item_base``).
+    ``deal_shared``: also deal the shared (per-layer, subgraph-independent) work across ranks -- the
+    sources of the position channel's multi-source BFS -- and exchange the results; pays when the
+    shard is a slice of a fixed total (strong scaling), needs equal shard sizes."""
+
+    def __init__(self, total, rank=None, world=None, deal_shared=False, collectives=True):
+        self.world = world if world is not None else (dist.get_world_size() if is_initialized() else 1)
+        self.rank = rank if rank is not None else (dist.get_rank() if is_initialized() else 0)
+        self.total = int(total)
+        self.start, self.stop = shard_range(self.total, self.rank, self.world)
+        self.collectives = collectives and self.world > 1        # False: a single process replaying one rank's shard (tests)
+        self.deal_shared = bool(deal_shared) and self.collectives and self.total % self.world == 0
+
+    @property
+    def size(self):
+        return self.stop - self.start
+
+    def reduce_max(self, t):
+        return all_reduce_max_(t) if self.collectives else t
+
+
 class _Pending:
     """Handle of a collective in flight: ``wait()`` returns its result."""
 
@@ -111,3 +135,189 @@ def all_reduce_gradients(params, average=True, big_bytes=16 << 20):
             k = g.numel()
             g.copy_(flat[off:off + k].view_as(g))
             off += k
+
+
+# ---------------------------------------------------------------------------------------------
+# the data path's exchange step as a differentiable operator
+# ---------------------------------------------------------------------------------------------
+
+class _GatherRowsReplicated(torch.autograd.Function):
+    """All-gather of row blocks whose consumer is REPLICATED: every rank runs the same computation on
+    the gathered matrix and arrives at the same scalar loss.  The gradient of that loss with respect to
+    rank r's rows is then simply rows r of the gradient every rank holds -- no reduction (a reduction
+    would count the loss ``world`` times)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.rows = x.shape[0]
+        return all_gather_rows(x.contiguous(), equal_rows=True)
+
+    @staticmethod
+    def backward(ctx, g):
+        r = dist.get_rank() if is_initialized() else 0
+        return g[r * ctx.rows:(r + 1) * ctx.rows]
+
+
+def gather_rows_replicated(x):
+    """(rows, H) per rank (equal row counts) -> (world * rows, H) on every rank, differentiable; see
+    _GatherRowsReplicated for the contract on the consumer."""
+    if not is_initialized() or dist.get_world_size() == 1:
+        return x
+    return _GatherRowsReplicated.apply(x)
+
+
+def all_to_all_row_blocks(x):
+    """x (world * rows, H): block b goes to rank b.  Returns (world * rows, H) whose block b came from
+    rank b.  (Each rank computed some columns of a matrix for ALL ranks' rows; afterwards each rank
+    holds every rank's columns for ITS rows.)"""
+    if not is_initialized() or dist.get_world_size() == 1:
+        return x
+    x = x.contiguous()
+    out = torch.empty_like(x)
+    try:
+        dist.all_to_all_single(out, x)
+    except (RuntimeError, NotImplementedError):             # backends without all-to-all: gather everything, keep ours
+        world, r = dist.get_world_size(), dist.get_rank()
+        rows = x.shape[0] // world
+        parts = [torch.empty_like(x) for _ in range(world)]
+        dist.all_gather(parts, x)
+        out = torch.cat([p[r * rows:(r + 1) * rows] for p in parts], 0)
+    return out
+
+
+def all_reduce_max_(t):
+    """In-place MAX over ranks of a small device tensor (global padded widths, border sizes)."""
+    if is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return t
+
+
+# ---------------------------------------------------------------------------------------------
+# embedding-table gradient: owner-computes update (reduce-scatter -> Adam on 1/world of the rows ->
+# all-gather of the updated rows, overlapped with the next pass's integer stages)
+# ---------------------------------------------------------------------------------------------
+
+class ShardedTableAdam:
+    """Adam for ONE large parameter (the (N+1, D) embedding table) under data parallelism, without the
+    dense all-reduce + replicated update: the gradient is reduce-scattered (each rank receives the sum
+    of one contiguous 1/world slice), the owner updates its slice of the parameter (its moments exist
+    only there: optimizer state / world), and the updated slices are all-gathered back -- asynchronously:
+    ``wait()`` is called right before the next reader of the table, so the gather travels on RCCL's stream
+    while the next pass's sampling and similarity stages (which never read the table) compute.  Same
+    bytes on the wire as a ring all-reduce, half of them hidden, and the 2 x N x D moment update drops
+    to 1/world.  The update rule is torch.optim.Adam's (bias-corrected, eps outside the square root).
+
+    Why not a sparse (row id, row) exchange: on the benchmark shard ~40 % of the table's
+    rows are touched per rank and ~95 % by the union of 8 ranks -- the gradient is dense; see
+    ``sparse_row_all_reduce`` for the regime where it is not."""
+
+    def __init__(self, param, lr, betas=(0.9, 0.999), eps=1e-8, average=False):
+        self.p, self.lr, self.b1, self.b2, self.eps, self.average = param, lr, betas[0], betas[1], eps, average
+        self.world = dist.get_world_size() if is_initialized() else 1
+        self.rank = dist.get_rank() if is_initialized() else 0
+        n = param.numel()
+        self.chunk = n // self.world                      # equal slices; the < world trailing elements are replicated
+        self.tail = n - self.chunk * self.world
+        self.lo, self.hi = self.rank * self.chunk, (self.rank + 1) * self.chunk
+        dev = param.device
+        self.m = torch.zeros(self.chunk + self.tail, dtype=torch.float32, device=dev)
+        self.v = torch.zeros_like(self.m)
+        self.gslice = torch.empty(self.chunk, dtype=torch.float32, device=dev)
+        self.t = 0
+        self._pending = None
+
+    def reduce_grad(self):
+        """Start of the update: reduce-scatter of param.grad.  Returns the squared norm of this rank's
+        reduced slice (+ the replicated tail on rank 0 only), for a global clip norm."""
+        g = self.p.grad.reshape(-1)
+        body = g[:self.chunk * self.world]
+        if self.world > 1:
+            try:
+                dist.reduce_scatter_tensor(self.gslice, body)
+            except (RuntimeError, NotImplementedError):     # backends without reduce-scatter
+                full = body.clone()
+                dist.all_reduce(full)
+                self.gslice.copy_(full[self.lo:self.hi])
+            if self.tail:
+                dist.all_reduce(g[self.chunk * self.world:])
+            if self.average:
+                self.gslice /= self.world
+                if self.tail:
+                    g[self.chunk * self.world:] /= self.world
+        else:
+            self.gslice.copy_(body)
+        sq = (self.gslice * self.gslice).sum()
+        if self.tail and self.rank == 0:
+            sq = sq + (g[self.chunk * self.world:] ** 2).sum()
+        return sq
+
+    def step(self, grad_scale=None):
+        """Adam on the owned slice (and the replicated tail), then the asynchronous all-gather."""
+        self.t += 1
+        flat = self.p.data.view(-1)
+        g = self.p.grad.reshape(-1)
+        gs = self.gslice if not self.tail else torch.cat([self.gslice, g[self.chunk * self.world:]])
+        if grad_scale is not None:
+            gs = gs * grad_scale
+        self.m.mul_(self.b1).add_(gs, alpha=1 - self.b1)
+        self.v.mul_(self.b2).addcmul_(gs, gs, value=1 - self.b2)
+        bc1, bc2 = 1 - self.b1 ** self.t, 1 - self.b2 ** self.t
+        upd = (self.m / bc1) / ((self.v / bc2).sqrt_().add_(self.eps))
+        flat[self.lo:self.hi].add_(upd[:self.chunk], alpha=-self.lr)
+        if self.tail:
+            flat[self.chunk * self.world:].add_(upd[self.chunk:], alpha=-self.lr)
+        if self.world > 1:
+            body = flat[:self.chunk * self.world]
+            mine = flat[self.lo:self.hi].clone()            # the collective must not read and write the same bytes
+            try:
+                self._pending = dist.all_gather_into_tensor(body, mine, async_op=True)
+            except (RuntimeError, NotImplementedError):
+                parts = [torch.empty_like(mine) for _ in range(self.world)]
+                dist.all_gather(parts, mine)
+                body.copy_(torch.cat(parts))
+                self._pending = None
+
+    def wait(self):
+        """Call before anything reads the parameter."""
+        if self._pending is not None:
+            self._pending.wait()
+            self._pending = None
+
+
+def sparse_row_all_reduce(grad, max_fraction=0.25):
+    """Sum over ranks of a (rows, D) gradient that is mostly zero rows (a batch of a few dozen subgraphs
+    touches a few thousand rows of a table of millions): all-gather of (row id, row) pairs of the
+    touched rows instead of an all-reduce of the dense table.  Falls back to the dense
+    all-reduce when more than ``max_fraction`` of the rows are touched on some rank (then the pairs would
+    outweigh the table).  In place; returns the number of rows exchanged per rank (0 = dense path)."""
+    if not is_initialized() or dist.get_world_size() == 1:
+        return 0
+    world = dist.get_world_size()
+    rows, D = grad.shape
+    touched = (grad != 0).any(dim=1)
+    n = touched.sum().view(1)
+    nmax = n.clone()
+    dist.all_reduce(nmax, op=dist.ReduceOp.MAX)
+    k = int(nmax.item())
+    if k == 0:
+        return 0
+    if k > max_fraction * rows:
+        dist.all_reduce(grad)
+        return 0
+    ids = torch.full((k,), -1, dtype=torch.int64, device=grad.device)
+    mine = touched.nonzero().view(-1)
+    ids[:mine.numel()] = mine
+    vals = torch.zeros((k, D), dtype=grad.dtype, device=grad.device)
+    vals[:mine.numel()] = grad[mine]
+    all_ids = [torch.empty_like(ids) for _ in range(world)]
+    all_vals = [torch.empty_like(vals) for _ in range(world)]
+    w1 = dist.all_gather(all_ids, ids, async_op=True)
+    w2 = dist.all_gather(all_vals, vals, async_op=True)
+    w1.wait()
+    w2.wait()
+    grad.zero_()
+    # ranks added in rank order on every rank: the sum is the same bits everywhere
+    for i, v in zip(all_ids, all_vals):
+        keep = i >= 0
+        grad.index_add_(0, i[keep], v[keep])
+    return k

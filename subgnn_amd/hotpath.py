@@ -70,8 +70,34 @@ def _hand_over(stream, *objs):
             _hand_over(stream, *o)
 
 
-def prepare_sparse(model, split='train', timer=None):
+def _dealt_position_sims(g, anchors, cc_sets, cc_ids, shard, max_hops):
+    """P-border similarities with the BFS sources dealt across ranks (strong scaling): this rank runs the
+    multi-source BFS for ITS share of the shared anchors only -- one 64-source word instead of
+    ceil(A / 64) -- but for every rank's components (the padded component tensors are all-gathered:
+    4 MB at the benchmark size), and an all-to-all hands every rank all anchors' columns for its own
+    rows.  Values are identical to the replicated form."""
+    from . import dist as sdist
+    S, C, Lc = cc_ids.shape
+    A = anchors.numel()
+    all_cc = sdist.all_gather_rows(cc_ids.reshape(S * C, Lc), equal_rows=True)
+    all_sets = ops.Ragged.from_padded(all_cc)
+    a, b = sdist.shard_range(A, shard.rank, shard.world)
+    width = (A + shard.world - 1) // shard.world
+    part = torch.zeros((all_sets.n, width), dtype=torch.float32, device=cc_ids.device)
+    if b > a:
+        part[:, :b - a] = ops.bfs_min_hops_to_sets(g, anchors[a:b].to(torch.int32).contiguous(), all_sets, max_hops=max_hops)
+    got = sdist.all_to_all_row_blocks(part)                         # block j: rank j's anchors, my rows
+    rows = S * C
+    cols = [got[j * rows:(j + 1) * rows, :sdist.shard_range(A, j, shard.world)[1] - sdist.shard_range(A, j, shard.world)[0]]
+            for j in range(shard.world)]
+    return torch.cat(cols, dim=1)
+
+
+def prepare_sparse(model, split='train', timer=None, shard=None):
     """HIP-only prepare_data for one split (SubGNN.py:1024-1063 semantics, sparse similarities).
+    ``shard`` (dist.Shard): the model holds one rank's block of the split's subgraphs; draws then read the
+    tape items of the GLOBAL subgraph numbers and padded widths are reduced over ranks, so that the
+    sharded passes together reproduce the single-rank pass bit for bit.
 
     Two HIP streams: the main stream runs components -> border BFS + neighbourhood draws ->
     component degree sequences -> DTW; a side stream runs, concurrently with the (VALU-bound)
@@ -94,14 +120,14 @@ def prepare_sparse(model, split='train', timer=None):
         else getattr(model, '_subs_' + split)
     setattr(model, '_subs_' + split, subs)
     labels = ops.cc_labels(g, subs)
-    cc_ids = subgraph_utils.components_from_labels(subs.ptr, subs.nodes, labels, subs.max_len)
+    cc_ids = subgraph_utils.components_from_labels(subs.ptr, subs.nodes, labels, subs.max_len,
+                                                   dims_reduce=shard.reduce_max if shard is not None else None)
     setattr(model, split + '_cc_ids', cc_ids)
     S, C, Lc = cc_ids.shape
+    base = shard.start if shard is not None else 0             # global number of this rank's first subgraph
     cc_sets = ops.Ragged.from_padded(cc_ids.reshape(S * C, Lc))
     real = (cc_ids[:, :, 0] != 0)
     t.mark('components')
-    model.init_all_embeddings(split=split, trainable=hp['trainable_cc'])
-    t.mark('cc_embed')
     # dispatch order of the component sets, heaviest (largest total degree) first: a property of the
     # split's subgraphs and the graph, computed once per split and kept.  The set kernels whose cost is
     # the members' degree sum (degree sequences, border BFS) take their sets in this order.
@@ -127,13 +153,17 @@ def prepare_sparse(model, split='train', timer=None):
             if getattr(model, 'anchors_pos_ext', None) is None or split != 'test':
                 model.anchors_pos_ext = aps.init_anchors_pos_ext(hp, g, dev)
             pint = {l: ops.choice_ragged(subs, hp['n_anchor_patches_pos_in'], seed,
-                                         tape.stream_id(tape.STREAM_P_INT, split, l)) for l in range(L)}
+                                         tape.stream_id(tape.STREAM_P_INT, split, l), item_base=base) for l in range(L)}
             if getattr(model, 'anchors_pos_int', None) is None:
                 model.anchors_pos_int = {}
             model.anchors_pos_int[split] = pint
             for l in range(L):
-                w = ops.bfs_min_hops_to_sets(g, model.anchors_pos_ext[l].to(torch.int32).contiguous(), cc_sets,
-                                             max_hops=hp.get('max_bfs_hops', 32)).view(S, C, -1)
+                if shard is not None and shard.deal_shared:
+                    w = _dealt_position_sims(g, model.anchors_pos_ext[l], cc_sets, cc_ids, shard,
+                                             hp.get('max_bfs_hops', 32)).view(S, C, -1)
+                else:
+                    w = ops.bfs_min_hops_to_sets(g, model.anchors_pos_ext[l].to(torch.int32).contiguous(), cc_sets,
+                                                 max_hops=hp.get('max_bfs_hops', 32)).view(S, C, -1)
                 sims[('P', 'out', l)] = (w * real.unsqueeze(-1)).contiguous()
                 if C == 1:
                     sims[('P', 'in', l)] = ops.ZeroSims((S, C, hp['n_anchor_patches_pos_in']), dev)
@@ -175,12 +205,14 @@ def prepare_sparse(model, split='train', timer=None):
         for l in range(L):
             ni[l] = ops.sample_anchors_ragged(cc_canon, hp['n_anchor_patches_N_in'], seed,
                                               tape.stream_id(tape.STREAM_N_INT, split, l), has_pad_c,
-                                              canonical=True).view(S, C, -1)
+                                              canonical=True, item_base=base * C).view(S, C, -1)
             sims[('N', 'in', l)] = ops.ZeroSims(ni[l].shape, dev)
             # border BFS fused with the border-anchor draw (rank query on the visited bitmap): the
             # border is never materialised
             a, w, _ = ops.khop_border_sample(g, cc_sets, k, hp['n_anchor_patches_N_out'], seed,
-                                             tape.stream_id(tape.STREAM_N_BOR, split, l))     # taken dynamically: a dispatch order buys nothing here
+                                             tape.stream_id(tape.STREAM_N_BOR, split, l),     # taken dynamically: a dispatch order buys nothing here
+                                             item_base=base * C,
+                                             count_reduce=shard.reduce_max if shard is not None else None)
             nb[l] = a.view(S, C, -1)
             sims[('N', 'out', l)] = w.view(S, C, -1).contiguous()
         if getattr(model, 'anchors_neigh_int', None) is None:
@@ -225,6 +257,13 @@ def prepare_sparse(model, split='train', timer=None):
         setattr(model, split + '_int_struc_similarities', None)
         setattr(model, split + '_bor_struc_similarities', None)
     model._build_sim_cols()
+    # last: the component embeddings are the first stage of a pass to read the embedding table -- a sharded
+    # optimizer's all-gather of the updated table (dist.ShardedTableAdam) travels under everything above
+    if getattr(model, '_table_sync', None) is not None:
+        model._table_sync()
+        t.mark('table_all_gather_wait')
+    model.init_all_embeddings(split=split, trainable=hp['trainable_cc'])
+    t.mark('cc_embed')
     model._bump_generation()
     return t
 

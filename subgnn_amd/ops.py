@@ -247,9 +247,11 @@ def cc_labels(g, subs):
     return out
 
 
-def cc_compact(sub_ptr, sub_nodes, labels, max_sub_len=0):
+def cc_compact(sub_ptr, sub_nodes, labels, max_sub_len=0, dims_reduce=None):
     """cc labels -> the padded (S, C, L) int64 component tensor of initialize_cc_ids, canonical order
-    (components by their first node's position, nodes in subgraph order, duplicates dropped)."""
+    (components by their first node's position, nodes in subgraph order, duplicates dropped).
+    ``dims_reduce``: callable applied to the device tensor [C, L] before it is read -- under data
+    parallelism the padded shape is a property of ALL ranks' subgraphs (dist.all_reduce_max_)."""
     lib = _lib.load()
     _req(labels, torch.int32, 'labels')
     S = sub_ptr.numel() - 1
@@ -257,7 +259,10 @@ def cc_compact(sub_ptr, sub_nodes, labels, max_sub_len=0):
     stats = torch.zeros((2, max(S, 1)), dtype=torch.int32, device=dev)
     check(lib.sgnn_cc_compact_stats(_ptr(sub_ptr), _ptr(sub_nodes), _ptr(labels), S, int(max_sub_len), _ptr(stats[0]),
                                     _ptr(stats[1]), _stream()), 'sgnn_cc_compact_stats')
-    C, L = (max(int(v), 1) for v in stats.amax(dim=1).tolist())           # the one host round trip
+    dims = stats.amax(dim=1)
+    if dims_reduce is not None:
+        dims = dims_reduce(dims)
+    C, L = (max(int(v), 1) for v in dims.tolist())                        # the one host round trip
     out = torch.zeros((S, C, L), dtype=torch.int64, device=dev)
     check(lib.sgnn_cc_compact(_ptr(sub_ptr), _ptr(sub_nodes), _ptr(labels), S, int(max_sub_len), C, L, _ptr(out),
                               _stream()), 'sgnn_cc_compact')
@@ -326,7 +331,8 @@ def khop_border_one_pass(g, sets, bitmap_in_lds=None):
     return arena, off, counts
 
 
-def khop_border_sample(g, sets, k, n_slots, seed, stream_id, bitmap_in_lds=None, order=None):
+def khop_border_sample(g, sets, k, n_slots, seed, stream_id, bitmap_in_lds=None, order=None, item_base=0,
+                       count_reduce=None):
     """k-hop border BFS + neighbourhood-border anchor draw without a padded border matrix.  Returns
     anchors (n_sets, n_slots) int64 with the reference's PAD rule applied, their hop levels as
     float32 similarities (0 on PAD) and the border sizes.  One fused kernel: the draw is a rank
@@ -339,12 +345,17 @@ def khop_border_sample(g, sets, k, n_slots, seed, stream_id, bitmap_in_lds=None,
     hop = torch.empty((sets.n, n_slots), dtype=torch.uint8, device=g.device)
     allneg = torch.empty((sets.n, n_slots), dtype=torch.uint8, device=g.device)
     check(lib.sgnn_khop_border_sample(_ptr(g.rowptr), _ptr(g.col), g.nnz, g.max_id, _ptr(sets.ptr), _ptr(sets.nodes),
-                                      sets.n, k, n_slots, seed, stream_id, _ptr(anchor), _ptr(hop), _ptr(allneg),
+                                      sets.n, k, n_slots, seed, stream_id, int(item_base), _ptr(anchor), _ptr(hop), _ptr(allneg),
                                       _ptr(counts), _ptr(order), _ptr(ws), ws_bytes, 1 if lds else 0, _stream()),
           'sgnn_khop_border_sample')
     # aps:190: padded columns hold 0, so PAD wins when every real variate is negative and the
     # padded row (width = the largest border) has at least one PAD column
-    has_pad = (counts < counts.max()).unsqueeze(1)
+    # (``count_reduce``: applied to the device scalar holding the largest border when these sets are one shard
+    # of the matrix -- the padded width is a property of ALL rows: dist.all_reduce_max_)
+    width = counts.max().view(1)
+    if count_reduce is not None:
+        width = count_reduce(width)
+    has_pad = (counts < width).unsqueeze(1)
     pad = (allneg != 0) & has_pad
     anchor = torch.where(pad, torch.zeros_like(anchor), anchor)
     sims = torch.where(pad | (anchor == 0), torch.zeros((), device=g.device), hop.to(torch.float32))
@@ -407,23 +418,24 @@ def sample_anchors_padded(ids, n_slots, seed, stream_id, canonical=False):
     return out
 
 
-def sample_anchors_ragged(sets, n_slots, seed, stream_id, row_has_pad=None, canonical=False):
-    """Same draw on ragged sets (``canonical``: every set is already ascending)."""
+def sample_anchors_ragged(sets, n_slots, seed, stream_id, row_has_pad=None, canonical=False, item_base=0):
+    """Same draw on ragged sets (``canonical``: every set is already ascending).  ``item_base``: number of
+    the first set within the whole matrix when ``sets`` is a shard of its rows."""
     lib = _lib.load()
     _req(row_has_pad, torch.uint8, 'row_has_pad')
     if not canonical:
         sets = sort_ragged(sets)
     out = torch.empty((sets.n, n_slots), dtype=torch.int64, device=sets.ptr.device)
     check(lib.sgnn_sample_anchors_ragged(_ptr(sets.ptr), _ptr(sets.nodes), sets.n, _ptr(row_has_pad), n_slots, seed,
-                                         stream_id, _ptr(out), _stream()), 'sgnn_sample_anchors_ragged')
+                                         stream_id, int(item_base), _ptr(out), _stream()), 'sgnn_sample_anchors_ragged')
     return out
 
 
-def choice_ragged(sets, n_draws, seed, stream_id):
+def choice_ragged(sets, n_draws, seed, stream_id, item_base=0):
     lib = _lib.load()
     out = torch.empty((sets.n, n_draws), dtype=torch.int64, device=sets.ptr.device)
-    check(lib.sgnn_choice_ragged(_ptr(sets.ptr), _ptr(sets.nodes), sets.n, n_draws, seed, stream_id, _ptr(out),
-                                 _stream()), 'sgnn_choice_ragged')
+    check(lib.sgnn_choice_ragged(_ptr(sets.ptr), _ptr(sets.nodes), sets.n, n_draws, seed, stream_id, int(item_base),
+                                 _ptr(out), _stream()), 'sgnn_choice_ragged')
     return out
 
 

@@ -85,3 +85,89 @@ def test_shard_range_partitions():
             assert spans[0][0] == 0 and spans[-1][1] == n
             assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
             assert max(b - a for a, b in spans) - min(b - a for a, b in spans) <= 1
+
+
+def _worker_dp_ops(rank, world, port, q):
+    """The data-parallel operators of the sharded pass, 2 ranks over gloo, each checked against the
+    single-process computation on the full data."""
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from subgnn_amd import dist as D
+    torch.manual_seed(0)
+    ok = {}
+    # --- replicated head on gathered rows: gradients equal the single-process ones ------------------
+    B, H = 6, 5
+    X = torch.randn(world * B, H)
+    Wc = torch.randn(H, H)                       # a "channel" parameter (sharded rows flow through it)
+    Wh = torch.randn(H, 3)                       # the head (replicated)
+    y = torch.randint(0, 3, (world * B,))
+
+    def loss_of(xrows, wc, wh, gather):
+        e = torch.tanh(xrows @ wc)
+        e = D.gather_rows_replicated(e) if gather else e
+        return torch.nn.functional.cross_entropy(e @ wh, y)
+    wc_f, wh_f = Wc.clone().requires_grad_(True), Wh.clone().requires_grad_(True)
+    loss_of(X, wc_f, wh_f, False).backward()
+    wc, wh = Wc.clone().requires_grad_(True), Wh.clone().requires_grad_(True)
+    a, b = D.shard_range(world * B, rank, world)
+    loss_of(X[a:b], wc, wh, True).backward()
+    D.all_reduce_gradients([wc], average=False)                      # channel params: SUM of the shares
+    ok['head'] = torch.allclose(wh.grad, wh_f.grad, atol=1e-6)       # head: complete on every rank, no reduction
+    ok['channel'] = torch.allclose(wc.grad, wc_f.grad, atol=1e-6)
+    # --- all-to-all of row blocks ---------------------------------------------------------------------
+    rows = 3
+    part = torch.arange(world * rows * 2, dtype=torch.float32).view(world * rows, 2) + 1000 * rank
+    got = D.all_to_all_row_blocks(part)
+    want = torch.cat([torch.arange(world * rows * 2, dtype=torch.float32).view(world * rows, 2)[rank * rows:(rank + 1) * rows]
+                      + 1000 * j for j in range(world)], 0)
+    ok['a2a'] = torch.equal(got, want)
+    # --- sharded table Adam == torch Adam on the summed gradient, over several steps ---------------------
+    N, Dm = 13, 3                                                    # 39 elements: a replicated tail of 1
+    table = torch.nn.Parameter(torch.randn(N, Dm))
+    ref = torch.nn.Parameter(table.detach().clone())
+    opt_ref = torch.optim.Adam([ref], lr=0.05)
+    sh = D.ShardedTableAdam(table, 0.05)
+    gen = torch.Generator().manual_seed(5)
+    for it in range(4):
+        g_all = [torch.randn(N, Dm, generator=gen) * (torch.rand(N, 1, generator=gen) < 0.6) for _ in range(world)]
+        table.grad = g_all[rank].clone()
+        ref.grad = sum(g_all)
+        sq = sh.reduce_grad()
+        dist.all_reduce(sq)
+        ok['norm%d' % it] = torch.allclose(sq, (ref.grad ** 2).sum(), rtol=1e-5)
+        sh.step()
+        sh.wait()
+        opt_ref.step()
+        ok['adam%d' % it] = torch.allclose(table.detach(), ref.detach(), atol=1e-6)
+    # --- sparse (row id, row) exchange ----------------------------------------------------------------
+    g = torch.zeros(200, 4)
+    mine = torch.tensor([3, 50, 77]) + rank
+    g[mine] = torch.randn(3, 4, generator=torch.Generator().manual_seed(rank))
+    dense = g.clone()
+    dist.all_reduce(dense)
+    k = D.sparse_row_all_reduce(g)
+    ok['sparse'] = k == 3 and torch.allclose(g, dense)
+    g2 = torch.ones(8, 2) * (rank + 1)                               # dense gradient: falls back to the all-reduce
+    ok['sparse_dense_fallback'] = D.sparse_row_all_reduce(g2) == 0 and torch.equal(g2, torch.full((8, 2), 3.0))
+    # --- Shard bookkeeping -----------------------------------------------------------------------------
+    shd = D.Shard(10, deal_shared=True)
+    ok['shard'] = (shd.start, shd.stop) == D.shard_range(10, rank, world) and shd.deal_shared and \
+        int(shd.reduce_max(torch.tensor([rank + 4]))[0]) == world + 3
+    q.put((rank, ok))
+    dist.destroy_process_group()
+
+
+def test_two_rank_dp_operators():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_dp_ops, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, ok in res:
+        assert all(ok.values()), (rank, ok)

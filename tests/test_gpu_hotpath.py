@@ -82,3 +82,51 @@ def test_full_split_step_runs_and_is_deterministic(tmp_path):
         b = m._forward_batch('train', hotpath.full_split_batch(m, 'train'))
     assert torch.equal(a, b)
     assert a.shape[0] == len(m.train_sub_G)
+
+
+@pytest.mark.parametrize('name,world', [('tiny', 3), ('density', 4)])
+def test_sharded_passes_reproduce_the_single_rank_pass(name, world, tmp_path):
+    """Data parallelism over subgraph shards (dist.Shard): each rank's pass over ITS block of the split --
+    draws keyed by the global subgraph number, padded widths reduced over ranks -- yields exactly the rows
+    the single-rank pass yields for those subgraphs: component tensors, every anchor tensor, every
+    similarity.  One process plays the ranks in turn (uneven blocks included); the reductions over ranks
+    are replaced by the known global values."""
+    from conftest import load_golden
+    from subgnn_amd import hotpath, ops
+    from subgnn_amd import dist as sdist
+    golden = load_golden(name)
+    full, part = _models(golden, tmp_path)
+    hotpath.prepare_sparse(full, 'train')
+    hp = full.hparams
+    S, C, L = full.train_cc_ids.shape
+    sets = ops.Ragged.from_padded(full.train_cc_ids.reshape(S * C, L))
+    width = ops.khop_border(full.networkx_graph, sets, hp['neigh_sample_border_size']).lengths.max().view(1)
+    dims = torch.tensor([C, L], device=width.device)
+
+    class PlayedShard(sdist.Shard):
+        def reduce_max(self, t):
+            return torch.maximum(t, (dims if t.numel() == 2 else width).to(t.dtype))
+    all_subs, all_labels = list(full.train_sub_G), full.train_sub_G_label
+    for r in range(world):
+        sh = PlayedShard(S, r, world, collectives=False)
+        a, b = sh.start, sh.stop
+        part.train_sub_G, part.train_sub_G_label = all_subs[a:b], all_labels[a:b]
+        part.__dict__.pop('_subs_train', None)
+        for k in ('_degseq_order', '_dtw_group_rows'):
+            part.__dict__.pop(k, None)
+        hotpath.prepare_sparse(part, 'train', shard=sh)
+        assert torch.equal(part.train_cc_ids, full.train_cc_ids[a:b])
+        for l in range(hp['n_layers']):
+            assert torch.equal(part.anchors_neigh_int['train'][l], full.anchors_neigh_int['train'][l][a:b])
+            assert torch.equal(part.anchors_neigh_border['train'][l], full.anchors_neigh_border['train'][l][a:b])
+            assert torch.equal(part.anchors_pos_int['train'][l], full.anchors_pos_int['train'][l][a:b])
+            assert torch.equal(part.anchors_pos_ext[l], full.anchors_pos_ext[l])
+            for key in (('N', 'out', l), ('P', 'out', l), ('P', 'in', l)):
+                x, y = part.train_neigh_pos_similarities[key], full.train_neigh_pos_similarities[key]
+                if isinstance(y, ops.ZeroSims):
+                    assert isinstance(x, ops.ZeroSims) and x.shape[1:] == y.shape[1:]
+                else:
+                    assert torch.equal(x, y[a:b]), key
+        assert torch.equal(part.structure_anchors, full.structure_anchors)
+        assert torch.equal(part.train_int_struc_similarities, full.train_int_struc_similarities[a:b])
+        assert torch.equal(part.train_bor_struc_similarities, full.train_bor_struc_similarities[a:b])
