@@ -134,14 +134,20 @@ int sgnn_khop_border_arena(const int64_t* rowptr, const int32_t* col, int64_t nn
 /* a8 + a4 fused: k-hop border BFS and, without materialising the border, the neighbourhood-border
  * anchor draw of anchor_patch_samplers.sample_neighborhood_anchor_patch(sample_inside=False)
  * (anchor_patch_samplers.py:184-194) over it, under the neighbourhood-anchor law stated at
- * sgnn_sample_anchors_padded.  For set s and slot i (tape item s*n_slots+i): out_anchor = the k-th
- * (item_base + s)*n_slots+i when the sets are rows item_base.. of a larger, sharded launch) --
+ * sgnn_sample_anchors_padded.  For set s and slot i (tape item (item_base + s)*n_slots+i; item_base = the
+ * number of the first set when the sets are rows of a larger, sharded matrix): out_anchor = the k-th
  * smallest border id (a rank query on the visited bitmap -- no sort, no per-node hashing), out_hop =
  * its hop level (the N-border similarity, = the APSP row-min of SubGNN.py:772 on that column),
  * out_allneg = the item's "every variate negative" draw -- the caller applies the PAD rule of
  * aps:190 (PAD wins when it is set AND the padded row is longer than this border, i.e.
- * out_count[s] < max count).  An empty border yields anchor 0. */
-int sgnn_khop_border_sample(const int64_t* rowptr, const int32_t* col, int64_t nnz, int64_t max_id,
+ * out_count[s] < max count).  An empty border yields anchor 0.
+ * col_sorted (nullable): the rows in ascending order.  k = 1 takes a specialised kernel (bits ORed without
+ * return value, a 16-lane group per slot); with col_sorted it also serves id ranges beyond the LDS bitmap
+ * (~1.2 M ids) by processing the range in slices -- without it such graphs keep the bitmap in `workspace`.
+ * bitmap_in_lds: 0 = bitmap in workspace, 1 = in LDS, > 1 = in LDS using at most this many bytes (smaller
+ * slices; a test hook that needs no global state).  workspace: sgnn_khop_border_sample_workspace_bytes. */
+int64_t sgnn_khop_border_sample_workspace_bytes(int64_t max_id, int64_t n_sets, int k, int rows_sorted, int bitmap_in_lds);
+int sgnn_khop_border_sample(const int64_t* rowptr, const int32_t* col, const int32_t* col_sorted, int64_t nnz, int64_t max_id,
                             const int64_t* set_ptr, const int32_t* set_nodes, int64_t n_sets, int k,
                             int64_t n_slots, uint64_t seed, uint64_t stream_id, int64_t item_base,
                             int64_t* out_anchor, uint8_t* out_hop, uint8_t* out_allneg, int64_t* out_count,

@@ -45,7 +45,8 @@ SIGNATURES = {
                                  c_ptr, c_ptr, c_i64, c_int, c_ptr]),
     'sgnn_khop_border_arena': (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_i64, c_int, c_ptr, c_ptr, c_ptr, c_ptr,
                                        c_i64, c_int, c_ptr]),
-    'sgnn_khop_border_sample': (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_i64, c_int, c_i64, c_u64, c_u64, c_i64,
+    'sgnn_khop_border_sample_workspace_bytes': (c_i64, [c_i64, c_i64, c_int, c_int, c_int]),
+    'sgnn_khop_border_sample': (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_i64, c_int, c_i64, c_u64, c_u64, c_i64,
                                         c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_ptr]),
     'sgnn_sample_anchors_padded': (c_int, [c_ptr, c_i64, c_i64, c_i64, c_u64, c_u64, c_ptr, c_ptr]),
     'sgnn_sample_anchors_ragged': (c_int, [c_ptr, c_ptr, c_i64, c_ptr, c_i64, c_u64, c_u64, c_i64, c_ptr, c_ptr]),

@@ -631,13 +631,19 @@ __global__ __launch_bounds__(THREADS) void khop_border_kernel(
             const int32_t v = set_nodes[beg + i];
             atomicAnd(&bm[v >> 5], ~(1u << (v & 31)));
         }
+#ifndef KB_DEBUG_SKIP_SELECT
         if (smp.n_slots > 0) {
             __syncthreads();
             kb_select<LDS_BM, THREADS>(smp, s, bm, words, q, cnt, hops, s_lvl, s_pref, s_wtot, s_sel, tid);
             __syncthreads();
         }
+#endif
         // un-set every border bit so the next component handled by the workgroup starts clean
+#ifdef KB_DEBUG_SKIP_WIPE
+        if (false) {
+#else
         if (LDS_BM && (!need_queue || (int64_t)cnt * 8 > words)) {
+#endif
             // cheaper than re-reading the queue: wipe the LDS bitmap with 16-byte stores
             int4* bm4 = reinterpret_cast<int4*>(s_bm);
             for (int64_t i = tid; i < (words + 3) / 4; i += THREADS) bm4[i] = make_int4(0, 0, 0, 0);
@@ -720,7 +726,392 @@ extern "C" int sgnn_khop_border_arena(const int64_t* rowptr, const int32_t* col,
                      workspace, workspace_bytes, bitmap_in_lds, none, stream, 1);
 }
 
-extern "C" int sgnn_khop_border_sample(const int64_t* rowptr, const int32_t* col, int64_t nnz, int64_t max_id,
+// ---------------------------------------------------------------------------------------------
+// One-hop border + fused neighbourhood-border anchor draw, specialised (k = 1, no materialised border):
+// the shape of the benchmark and of every reference configuration with ego_graphs.txt present.
+// What differs from the general kernel above:
+//   * the expansion only ORs bits -- LDS atomics WITHOUT return value, no ballots, no queue: the border
+//     size is the popcount total the rank query computes anyway.  Nothing in the edge loop waits for
+//     LDS, so its global loads stay in flight;
+//   * every wavefront loads the members and their row pointers itself (20 cached loads) instead of
+//     waiting at a barrier for a tile table built by wavefront 0; every list is shared by all 16
+//     wavefronts in 64-entry chunks (no flat-range search);
+//   * a slot of the draw is answered by a group of 16 lanes instead of one thread: two LDS reads find the
+//     run (16 coarse prefixes, then 64 fine ones as 4 per lane), one round per 16 words scans the run --
+//     ~10 dependent steps where a single thread's binary search + walk took ~70;
+//   * id ranges beyond the LDS bitmap are processed in slices of the range (SLICED; rows ascending,
+//     each member's slice of its list found by binary search): pass A counts the border per slice,
+//     pass B rebuilds each slice and answers the slots whose rank falls into it -- twice the edge
+//     traffic, against the ~9x of keeping the bitmap in L2.
+// ---------------------------------------------------------------------------------------------
+#define K1_THREADS 1024
+#define K1_MAX_SLICES 32
+#ifndef K1_INFLIGHT
+#define K1_INFLIGHT 4           // 64-entry chunk loads a wavefront issues before it sets any bit
+#endif
+#ifndef K1_RANK_UNROLL
+#define K1_RANK_UNROLL 8
+#endif
+#ifndef K1_TAKE
+#define K1_TAKE 8               // sets per trip to the device-wide counter (all but the first of a trip are prefetched)
+#endif
+
+#ifdef K1_DEBUG_TIMING
+__device__ unsigned long long k1_dbg[16];
+#define K1_T(i) do { if (tid == 0) { const unsigned long long now_ = clock64(); atomicAdd(&k1_dbg[i], now_ - t_last); t_last = now_; } } while (0)
+extern "C" int sgnn_debug_k1_timing(unsigned long long* out16, int reset) {
+    if (reset) { unsigned long long z[16] = {0}; return (int)hipMemcpyToSymbol(HIP_SYMBOL(k1_dbg), z, sizeof(z)); }
+    return (int)hipMemcpyFromSymbol(out16, HIP_SYMBOL(k1_dbg), 16 * 8);
+}
+#else
+#define K1_T(i) do { } while (0)
+#endif
+
+__device__ __forceinline__ void k1_lds_barrier()
+{
+    // orders LDS only: the global loads queued for the next set stay in flight across it
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+__device__ __forceinline__ int64_t sgnn_readlane64(int64_t v, int l)       // l wave-uniform
+{
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, l);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)v >> 32), l);
+    return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+
+__device__ __forceinline__ int k1_nth_set_bit(uint32_t word, int n)           // position of the n-th (0-based) set bit
+{
+    int pos = 0;
+#pragma unroll
+    for (int shift = 16; shift >= 1; shift >>= 1) {
+        const int c = __popc((word >> pos) & ((1u << shift) - 1u));
+        if (n >= c) { n -= c; pos += shift; }
+    }
+    return pos;
+}
+
+template <bool SLICED>
+__global__ __launch_bounds__(K1_THREADS) void khop1_sample_kernel(
+    const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col, int64_t max_id,
+    const int64_t* __restrict__ set_ptr, const int32_t* __restrict__ set_nodes, int64_t n_sets,
+    int64_t* __restrict__ out_count, KbSample smp, int64_t slice_ids, int n_slices,
+    unsigned long long* __restrict__ next_set, const int32_t* __restrict__ set_order)
+{
+    extern __shared__ uint32_t s_bm[];                       // bitmap of one slice of the id range
+    __shared__ __attribute__((aligned(16))) int32_t s_pref[K1_THREADS];
+    __shared__ int32_t s_wtot[K1_THREADS / 64 + 1];
+    __shared__ int32_t s_cum[K1_MAX_SLICES + 1];
+    __shared__ int32_t s_rank[K1_THREADS / 16], s_an[K1_THREADS / 16];
+    __shared__ long long s_next;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int wave_s = __builtin_amdgcn_readfirstlane(tid >> 6);          // the same number, known to be uniform
+    constexpr int NW = K1_THREADS / 64;
+    const int grp = tid >> 4, gl = tid & 15, gshift = (lane >> 4) * 16;     // 64 groups of 16 lanes
+    const int64_t words_max = (slice_ids + 31) / 32;
+    {
+        int4* bm4 = reinterpret_cast<int4*>(s_bm);
+        for (int64_t i = tid; i < (words_max + 3) / 4; i += K1_THREADS) bm4[i] = make_int4(0, 0, 0, 0);
+    }
+    __syncthreads();
+    int64_t si_next = 0, si_end = 0;
+#ifdef K1_DEBUG_TIMING
+    unsigned long long t_last = clock64();
+#endif
+    bool have_pf = false;
+    uint32_t pf_r0 = 0;
+    int32_t pf_deg = 0, pf_v = 0;
+    int64_t trip0 = 0, trip_ptr = 0;
+    while (true) {
+        if (si_next >= si_end) {
+            if (tid == 0) s_next = (long long)atomicAdd(next_set, (unsigned long long)K1_TAKE);
+            __syncthreads();
+            si_next = s_next;
+            si_end = si_next + K1_TAKE;
+            __syncthreads();
+            // the trip's slice of set_ptr in one load (lane j: set si_next + j), read back lane by lane below
+            trip0 = si_next;
+            trip_ptr = 0;
+            if (set_order == nullptr && lane <= K1_TAKE && si_next + lane <= n_sets) trip_ptr = set_ptr[si_next + lane];
+        }
+        K1_T(0);                                                   // dispatch
+        const int64_t si = si_next++;
+        if (si >= n_sets) break;
+        const int64_t s = set_order ? set_order[si] : si;
+        const int tj = __builtin_amdgcn_readfirstlane((int)(si - trip0));     // position within the trip (wave-uniform)
+        // (the first 64 members' row pointers may have been fetched while the previous set was being processed)
+        const int64_t beg = set_order ? set_ptr[s] : sgnn_readlane64(trip_ptr, tj);
+        const int n = (int)((set_order ? set_ptr[s + 1] : sgnn_readlane64(trip_ptr, tj + 1)) - beg);
+        const uint32_t r0_pf = pf_r0;
+        const int32_t deg_pf = pf_deg;
+        const bool use_pf = have_pf;
+        have_pf = false;
+        // the next set of this trip, if there is one: its members are loaded now and their row pointers after
+        // the expansion -- each step is issued long after the previous one returned, and the LDS-only barriers
+        // in between leave the loads in flight: the set_ptr -> members -> row pointers -> lists chain of
+        // dependent global latencies (~4 x 1 us per set on one resident workgroup) is paid once per trip
+        const bool can_pf = !SLICED && set_order == nullptr && si_next < si_end && si_next < n_sets;
+        int64_t nx_beg = 0, nx_end = 0;
+        int32_t nx_v = 0;
+        if (can_pf) {
+            nx_beg = sgnn_readlane64(trip_ptr, tj + 1);
+            nx_end = sgnn_readlane64(trip_ptr, tj + 2);
+        }
+        const int32_t v_pf = pf_v;                                 // this set's first 64 members, if prefetched
+        int32_t v_tile0 = 0;
+        int cnt = 0;
+        for (int pass = 0; pass < (SLICED ? 2 : 1); ++pass) {
+            for (int sl = 0; sl < n_slices; ++sl) {
+                const int64_t lo_id = (int64_t)sl * slice_ids;
+                const int64_t hi_id = lo_id + slice_ids < max_id + 1 ? lo_id + slice_ids : max_id + 1;
+                const int64_t words = (hi_id - lo_id + 31) / 32;
+                // ---- expansion: OR the bits of every member's neighbours (of this slice) ----------------
+                // Every wavefront holds the tile's row starts and degrees (lane m = member m) and the 64-entry
+                // chunks of all lists are numbered through: chunk q belongs to wavefront q % 16, which finds
+                // its member by a scalar search over the in-register chunk scan and keeps K1_INFLIGHT chunk
+                // loads in flight before any bit is set (a list per iteration would serialise 20 latencies).
+                for (int t0 = 0; t0 < n; t0 += 64) {
+                    uint32_t r0 = 0;
+                    int32_t deg = 0;
+                    if (t0 == 0 && use_pf) { r0 = r0_pf; deg = deg_pf; v_tile0 = v_pf; }
+                    else if (t0 + lane < n) {
+                        const int32_t v = set_nodes[beg + t0 + lane];
+                        if (t0 == 0) v_tile0 = v;
+                        int64_t a = rowptr[v], b = rowptr[v + 1];
+                        if (SLICED) {                              // rows ascending: the list's part inside [lo_id, hi_id)
+                            int64_t l = a, h = b;
+                            while (l < h) { const int64_t m = (l + h) >> 1; if ((int64_t)col[m] < lo_id) l = m + 1; else h = m; }
+                            const int64_t first = l;
+                            h = b;
+                            while (l < h) { const int64_t m = (l + h) >> 1; if ((int64_t)col[m] < hi_id) l = m + 1; else h = m; }
+                            a = first; b = l;
+                        }
+                        r0 = (uint32_t)a;
+                        deg = (int32_t)(b - a);
+                    }
+                    int32_t incl = (deg + 63) >> 6;                                   // chunks of this member's list
+#pragma unroll
+                    for (int d = 1; d < 64; d <<= 1) { const int32_t t = __shfl_up(incl, d); if (lane >= d) incl += t; }
+                    const int32_t n_chunks = __builtin_amdgcn_readlane(incl, 63);
+                    // everything that locates a chunk is wave-uniform and kept in scalar registers: the member
+                    // index only ever moves forward, so a chunk costs about one v_readlane -- a 6-step search per
+                    // chunk in vector registers made this loop issue-bound (16 wavefronts x ~110 instructions per
+                    // chunk: 16 k cycles per set, whatever the loads did)
+                    K1_T(6);                                       // (debug) tile ready
+                    // step 1 of the prefetch, issued only now: a load issued before the prefetched row pointers
+                    // above are consumed would have to complete first (the counter of outstanding loads cannot
+                    // tell them apart across the loop's back edge)
+                    if (t0 == 0 && can_pf && lane < nx_end - nx_beg) nx_v = set_nodes[nx_beg + lane];
+                    int m = 0;
+                    int32_t m_incl = __builtin_amdgcn_readlane(incl, 0);
+                    int32_t m_deg = __builtin_amdgcn_readlane(deg, 0);
+                    uint32_t m_r0 = (uint32_t)__builtin_amdgcn_readlane((int)r0, 0);
+                    for (int32_t q0 = wave_s; q0 < n_chunks; q0 += K1_INFLIGHT * NW) {
+                        int32_t c[K1_INFLIGHT];
+#pragma unroll
+                        for (int u = 0; u < K1_INFLIGHT; ++u) {
+                            const int32_t q = q0 + u * NW;
+                            c[u] = -1;
+                            if (q < n_chunks) {
+                                while (m_incl <= q) {                                 // scalar loop
+                                    ++m;
+                                    m_incl = __builtin_amdgcn_readlane(incl, m);
+                                    m_deg = __builtin_amdgcn_readlane(deg, m);
+                                    m_r0 = (uint32_t)__builtin_amdgcn_readlane((int)r0, m);
+                                }
+                                const int32_t t = (q - (m_incl - ((m_deg + 63) >> 6))) * 64 + lane;
+#ifdef K1_DEBUG_NO_LOAD
+                                if (t < m_deg) c[u] = (int32_t)((m_r0 + (uint32_t)t) * 2654435761u % (uint32_t)max_id);
+#else
+                                if (t < m_deg) c[u] = col[m_r0 + (uint32_t)t];
+#endif
+                            }
+                        }
+#pragma unroll
+                        for (int u = 0; u < K1_INFLIGHT; ++u) {
+                            if (c[u] >= 0) {
+                                const int32_t x = c[u] - (int32_t)lo_id;
+#ifdef K1_DEBUG_NO_OR
+                                if (x == 0x7fffffff) s_bm[0] = 1;
+#else
+                                __hip_atomic_fetch_or(&s_bm[x >> 5], 1u << (x & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
+                            }
+                        }
+                    }
+                }
+                K1_T(7);                                               // (debug) own chunks done
+                if (n == 0 && can_pf && lane < nx_end - nx_beg) nx_v = set_nodes[nx_beg + lane];    // (no tile ran step 1)
+                if (can_pf) {                                          // step 2 of the prefetch: the next set's row pointers
+                    pf_r0 = 0; pf_deg = 0;
+                    if (lane < nx_end - nx_beg) {
+                        const int64_t a = rowptr[nx_v], b = rowptr[nx_v + 1];
+                        pf_r0 = (uint32_t)a;
+                        pf_deg = (int32_t)(b - a);
+                    }
+                    pf_v = nx_v;
+                    have_pf = true;
+                }
+                k1_lds_barrier();
+                K1_T(1);                                           // expansion
+                // ---- the members themselves are not border ---------------------------------------------
+                for (int i = tid; i < n; i += K1_THREADS) {
+                    const int64_t v = i < 64 ? (int64_t)v_tile0 : (int64_t)set_nodes[beg + i];    // wavefront 0 still holds the first tile
+                    if (v >= lo_id && v < hi_id) {
+                        const int32_t x = (int32_t)(v - lo_id);
+                        __hip_atomic_fetch_and(&s_bm[x >> 5], ~(1u << (x & 31)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                }
+                k1_lds_barrier();
+                K1_T(2);                                           // members un-set
+                // ---- rank table: popcount of each thread's run of words, exclusive prefix ----------------
+                const int64_t run = ((words + K1_THREADS - 1) / K1_THREADS) | 1;       // odd: conflict-free strides
+                const int64_t w0 = (int64_t)tid * run;
+                const int64_t w1 = w0 + run < words ? w0 + run : words;
+                int c = 0;
+                for (int64_t wb = w0; wb < w0 + run; wb += K1_RANK_UNROLL) {   // independent reads per step (a read per
+                    uint32_t x[K1_RANK_UNROLL];                                // iteration is a chain of LDS latencies)
+#pragma unroll
+                    for (int u = 0; u < K1_RANK_UNROLL; ++u) x[u] = wb + u < w1 ? s_bm[wb + u] : 0u;
+#pragma unroll
+                    for (int u = 0; u < K1_RANK_UNROLL; ++u) c += __popc(x[u]);
+                }
+                int inc = c;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(inc, d); if (lane >= d) inc += t; }
+                if (lane == 63) s_wtot[wave] = inc;
+                k1_lds_barrier();
+                if (tid == 0) {
+                    int acc = 0;
+                    for (int w = 0; w < NW; ++w) { const int t = s_wtot[w]; s_wtot[w] = acc; acc += t; }
+                    s_wtot[NW] = acc;
+                    if (SLICED && pass == 0) { if (sl == 0) s_cum[0] = 0; s_cum[sl + 1] = s_cum[sl] + acc; }
+                }
+                k1_lds_barrier();
+                s_pref[tid] = s_wtot[wave] + inc - c;
+                const int total = s_wtot[NW];
+                k1_lds_barrier();
+                K1_T(3);                                           // rank table
+                if (!(SLICED && pass == 0)) {
+                    cnt = SLICED ? s_cum[n_slices] : total;
+                    const int cum_lo = SLICED ? s_cum[sl] : 0;
+                    if (sl == 0 && tid == 0 && out_count) out_count[s] = cnt;
+                    // ---- the draw: 64 slots per round, a group of 16 lanes each ---------------------------
+                    for (int64_t c0 = 0; c0 < smp.n_slots; c0 += K1_THREADS / 16) {
+                        // the slots' tape draws (three 64-bit mixes each) once per slot, by the first lanes of the
+                        // workgroup -- not once per lane of the group that then looks the rank up
+                        if (tid < K1_THREADS / 16) {
+                            int32_t rk = -1;
+                            int32_t an_ = 1;
+                            if (c0 + tid < smp.n_slots && cnt > 0) {
+                                const uint64_t h1_ = sgnn_tape_h1(smp.h0, (uint64_t)(s * smp.n_slots + c0 + tid + smp.item_base * smp.n_slots));
+                                rk = (int32_t)sgnn_nanchor_index(h1_, (uint32_t)cnt);
+                                an_ = sgnn_nanchor_allneg(h1_, (uint32_t)cnt) ? 1 : 0;
+                            }
+                            s_rank[tid] = rk;
+                            s_an[tid] = an_;
+                        }
+                        k1_lds_barrier();
+                        if (c0 + wave_s * 4 >= smp.n_slots) continue;                // none of this wavefront's four slots exists
+                        const int64_t slot = c0 + grp;
+                        const bool active = slot < smp.n_slots;
+                        const int64_t o = s * smp.n_slots + (active ? slot : 0);
+                        int rem = s_rank[grp];
+                        const uint8_t an = (uint8_t)s_an[grp];
+                        rem -= cum_lo;
+                        const bool mine = active && cnt > 0 && rem >= 0 && rem < total;       // the rank lies in this slice
+                        if (!mine) rem = 0;
+                        // coarse: 16 prefixes, one per 64 runs
+                        const int v1 = s_pref[gl * 64];
+                        const uint32_t b1 = (uint32_t)(__ballot(v1 <= rem) >> gshift) & 0xffffu;
+                        const int blk = 31 - __clz((int)(b1 | 1u));
+                        // fine: the block's 64 prefixes, 4 per lane
+                        const int4 e = *reinterpret_cast<const int4*>(&s_pref[blk * 64 + gl * 4]);
+                        int n_le = __popc((uint32_t)(__ballot(e.x <= rem) >> gshift) & 0xffffu);
+                        n_le += __popc((uint32_t)(__ballot(e.y <= rem) >> gshift) & 0xffffu);
+                        n_le += __popc((uint32_t)(__ballot(e.z <= rem) >> gshift) & 0xffffu);
+                        n_le += __popc((uint32_t)(__ballot(e.w <= rem) >> gshift) & 0xffffu);
+                        const int T = blk * 64 + (n_le > 0 ? n_le - 1 : 0);
+                        rem -= s_pref[T];
+                        // the run's words, 16 per round in word order
+                        const int64_t rw0 = (int64_t)T * run;
+                        const int64_t rw1 = rw0 + run < words ? rw0 + run : words;
+                        bool found = false;
+                        int32_t id = 0;
+                        for (int64_t wb = 0; wb < run; wb += 16) {                            // run is the same for every group
+                            const int64_t w = rw0 + wb + gl;
+                            const uint32_t word = w < rw1 ? s_bm[w] : 0u;
+                            const int pc = __popc(word);
+                            int incl = pc;
+#pragma unroll
+                            for (int d = 1; d < 16; d <<= 1) { const int t = __shfl_up(incl, d, 16); if (gl >= d) incl += t; }
+                            const uint32_t over = (uint32_t)(__ballot(incl > rem) >> gshift) & 0xffffu;
+                            const int tot16 = __shfl(incl, 15, 16);
+                            if (!found && over) {
+                                const int L = __ffs((int)over) - 1;
+                                if (gl == L) id = (int32_t)(lo_id + w * 32 + k1_nth_set_bit(word, rem - (incl - pc)));
+                                id = __shfl(id, L, 16);
+                                found = true;
+                            }
+                            if (!found) rem -= tot16;
+                        }
+                        if (mine && gl == 0) {
+                            smp.anchor[o] = (int64_t)id;
+                            smp.allneg[o] = an;
+                            smp.hop[o] = 1;
+                        }
+                        if (active && cnt == 0 && sl == 0 && gl == 0) { smp.anchor[o] = 0; smp.allneg[o] = 1; smp.hop[o] = 0; }
+                        if (c0 + K1_THREADS / 16 < smp.n_slots) k1_lds_barrier();             // s_rank is rewritten next round (only reached when every wavefront had slots)
+                    }
+                }
+                // ---- wipe for the next slice / set ------------------------------------------------------
+                k1_lds_barrier();
+                K1_T(4);                                           // draw
+                {
+                    int4* bm4 = reinterpret_cast<int4*>(s_bm);
+                    for (int64_t i = tid; i < (words + 3) / 4; i += K1_THREADS) bm4[i] = make_int4(0, 0, 0, 0);
+                }
+                k1_lds_barrier();
+                K1_T(5);                                           // wipe
+            }
+        }
+    }
+}
+
+static int k1_plan(int64_t max_id, int64_t lds_budget, int64_t* slice_ids, int* n_slices)
+{
+    const int64_t ids = max_id + 1;
+    const int64_t cap = (lds_budget / 16) * 16 * 8;                      // ids one slice can hold
+    if (cap < 128) return 0;
+    int64_t ns = (ids + cap - 1) / cap;
+    if (ns > K1_MAX_SLICES) return 0;
+    int64_t per = ((ids + ns - 1) / ns + 127) / 128 * 128;
+    if (per > cap) per = cap;
+    *slice_ids = per;
+    *n_slices = (int)((ids + per - 1) / per);
+    return *n_slices <= K1_MAX_SLICES;
+}
+
+static bool k1_applies(int64_t max_id, int k, int rows_sorted, int bitmap_in_lds, int64_t* slice_ids, int* n_slices)
+{
+    if (k != 1 || !bitmap_in_lds) return false;
+    const int64_t budget = bitmap_in_lds > 1 ? (bitmap_in_lds < KB_LDS_BYTES ? bitmap_in_lds : KB_LDS_BYTES) : KB_LDS_BYTES;
+    return k1_plan(max_id, budget, slice_ids, n_slices) && (*n_slices == 1 || rows_sorted);
+}
+
+extern "C" int64_t sgnn_khop_border_sample_workspace_bytes(int64_t max_id, int64_t n_sets, int k, int rows_sorted,
+                                                           int bitmap_in_lds)
+{
+    int64_t slice_ids = 0;
+    int n_slices = 0;
+    if (k1_applies(max_id, k, rows_sorted, bitmap_in_lds, &slice_ids, &n_slices)) return 16;     // the set counter
+    return sgnn_khop_border_workspace_bytes(max_id, n_sets, bitmap_in_lds && kb_fits_lds(max_id) ? 1 : 0);
+}
+
+extern "C" int sgnn_khop_border_sample(const int64_t* rowptr, const int32_t* col, const int32_t* col_sorted, int64_t nnz,
+                                       int64_t max_id,
                                        const int64_t* set_ptr, const int32_t* set_nodes, int64_t n_sets, int k,
                                        int64_t n_slots, uint64_t seed, uint64_t stream_id, int64_t item_base,
                                        int64_t* out_anchor, uint8_t* out_hop, uint8_t* out_allneg, int64_t* out_count,
@@ -729,6 +1120,38 @@ extern "C" int sgnn_khop_border_sample(const int64_t* rowptr, const int32_t* col
 {
     if (!out_anchor || !out_hop || !out_allneg || !out_count || n_slots < 1 || item_base < 0) return SGNN_ERR_BAD_ARG;
     KbSample smp = {n_slots, sgnn_tape_h0(seed, stream_id), out_anchor, out_hop, out_allneg, item_base};
+    {
+        // the specialised one-hop kernel; bitmap_in_lds > 1 = LDS bytes the bitmap may take (tests: forces slicing)
+        int64_t slice_ids = 0;
+        int n_slices = 0;
+        if (k1_applies(max_id, k, col_sorted != nullptr, bitmap_in_lds, &slice_ids, &n_slices)) {
+            if (!rowptr || !col || !set_ptr || !set_nodes || !workspace || n_sets < 0) return SGNN_ERR_BAD_ARG;
+            if (nnz >= (1ll << 31)) return SGNN_ERR_NNZ_TOO_LARGE;
+            if (workspace_bytes < 16) return SGNN_ERR_BAD_ARG;
+            if (n_sets == 0) return SGNN_OK;
+            hipStream_t st = (hipStream_t)stream;
+            // the set counter: the last 8-byte aligned 8 bytes of the workspace
+            unsigned long long* next_set = (unsigned long long*)((char*)workspace + ((workspace_bytes - 8) & ~(int64_t)7));
+            (void)hipMemsetAsync(next_set, 0, 8, st);
+            static bool attr_set = false;
+            if (!attr_set) {
+                hipFuncSetAttribute((const void*)khop1_sample_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, KB_LDS_BYTES);
+                hipFuncSetAttribute((const void*)khop1_sample_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, KB_LDS_BYTES);
+                attr_set = true;
+            }
+            const int64_t nwg = kb_n_wg(n_sets, true);
+            const size_t lds = (size_t)((((slice_ids + 31) / 32 + 3) / 4) * 16);
+            if (n_slices == 1)
+                hipLaunchKernelGGL(khop1_sample_kernel<false>, dim3((int)nwg), dim3(K1_THREADS), lds, st, rowptr, col, max_id,
+                                   set_ptr, set_nodes, n_sets, out_count, smp, slice_ids, 1, next_set, set_order);
+            else
+                hipLaunchKernelGGL(khop1_sample_kernel<true>, dim3((int)nwg), dim3(K1_THREADS), lds, st, rowptr, col_sorted, max_id,
+                                   set_ptr, set_nodes, n_sets, out_count, smp, slice_ids, n_slices, next_set, set_order);
+            SGNN_CHECK_LAUNCH();
+            return SGNN_OK;
+        }
+    }
+    bitmap_in_lds = bitmap_in_lds && kb_fits_lds(max_id) ? 1 : 0;      // general kernel; beyond the LDS bitmap: bitmap in L2
     return kb_launch(rowptr, col, nnz, max_id, set_ptr, set_nodes, n_sets, k, 0, out_count, nullptr, nullptr, nullptr,
                      workspace, workspace_bytes, bitmap_in_lds, smp, stream, 0, set_order);
 }

@@ -336,17 +336,25 @@ def khop_border_sample(g, sets, k, n_slots, seed, stream_id, bitmap_in_lds=None,
     """k-hop border BFS + neighbourhood-border anchor draw without a padded border matrix.  Returns
     anchors (n_sets, n_slots) int64 with the reference's PAD rule applied, their hop levels as
     float32 similarities (0 on PAD) and the border sizes.  One fused kernel: the draw is a rank
-    query on the BFS's visited bitmap (the border is never materialised or sorted)."""
+    query on the BFS's visited bitmap (the border is never materialised or sorted).
+    ``bitmap_in_lds``: None = LDS (id ranges beyond the LDS bitmap are processed in slices when k = 1, else
+    the bitmap moves to the workspace); False = workspace; an int > 1 = LDS bytes the bitmap may take."""
     lib = _lib.load()
-    lds = bool(lib.sgnn_khop_border_bitmap_fits_lds(g.max_id)) if bitmap_in_lds is None else bool(bitmap_in_lds)
-    ws, ws_bytes = _khop_ws(lib, g, sets.n, lds)
+    mode = 1 if bitmap_in_lds is None else (int(bitmap_in_lds) if not isinstance(bitmap_in_lds, bool) else (1 if bitmap_in_lds else 0))
+    ws_bytes = lib.sgnn_khop_border_sample_workspace_bytes(g.max_id, sets.n, k, 1, mode)
+    if ws_bytes <= 16:
+        ws = _KHOP_WS.get(('k1', str(g.device)))
+        if ws is None:
+            ws = _KHOP_WS[('k1', str(g.device))] = torch.zeros(4, dtype=torch.int32, device=g.device)
+    else:
+        ws, ws_bytes = _khop_ws(lib, g, sets.n, mode != 0 and bool(lib.sgnn_khop_border_bitmap_fits_lds(g.max_id)))
     counts = torch.zeros(sets.n, dtype=torch.int64, device=g.device)
     anchor = torch.empty((sets.n, n_slots), dtype=torch.int64, device=g.device)
     hop = torch.empty((sets.n, n_slots), dtype=torch.uint8, device=g.device)
     allneg = torch.empty((sets.n, n_slots), dtype=torch.uint8, device=g.device)
-    check(lib.sgnn_khop_border_sample(_ptr(g.rowptr), _ptr(g.col), g.nnz, g.max_id, _ptr(sets.ptr), _ptr(sets.nodes),
-                                      sets.n, k, n_slots, seed, stream_id, int(item_base), _ptr(anchor), _ptr(hop), _ptr(allneg),
-                                      _ptr(counts), _ptr(order), _ptr(ws), ws_bytes, 1 if lds else 0, _stream()),
+    check(lib.sgnn_khop_border_sample(_ptr(g.rowptr), _ptr(g.col), _ptr(g.col_sorted), g.nnz, g.max_id, _ptr(sets.ptr),
+                                      _ptr(sets.nodes), sets.n, k, n_slots, seed, stream_id, int(item_base), _ptr(anchor),
+                                      _ptr(hop), _ptr(allneg), _ptr(counts), _ptr(order), _ptr(ws), ws_bytes, mode, _stream()),
           'sgnn_khop_border_sample')
     # aps:190: padded columns hold 0, so PAD wins when every real variate is negative and the
     # padded row (width = the largest border) has at least one PAD column

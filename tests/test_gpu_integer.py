@@ -252,7 +252,7 @@ def test_khop_border_one_pass_arena(lds):
         assert sorted(a[o[i]:o[i] + c[i]].tolist()) == ref[i]
 
 
-@pytest.mark.parametrize('lds', [True, False])
+@pytest.mark.parametrize('lds', [True, False, 32])          # 32: an LDS bitmap of 32 bytes = 256 ids per slice (k = 1: sliced)
 @pytest.mark.parametrize('k', [1, 2])
 def test_khop_border_sample_equals_materialised_draw(k, lds):
     """Fused BFS + anchor draw == (materialise the border, pad it, run the reference-shaped
@@ -263,6 +263,8 @@ def test_khop_border_sample_equals_materialised_draw(k, lds):
     rng = np.random.default_rng(4)
     sets = [list({int(v) for v in rng.integers(1, G.max_id() + 1, int(rng.integers(1, 5)))}) for _ in range(700)]
     sets[3] = []
+    sets[5] = list(range(1, 151))                   # more members than one 64-lane tile
+    sets[6] = list(range(1, G.max_id() + 1))        # everything: empty border
     r = ops.Ragged.from_lists(sets, DEV)
     A, seed, st = 7, 99, T.stream_id(T.STREAM_N_BOR, 'val', 1)
     anchors, sims, counts = ops.khop_border_sample(dg, r, k, A, seed, st, bitmap_in_lds=lds)
@@ -298,7 +300,7 @@ def test_khop_border_sample_large_border_rank_query():
     sets = synthetic.bfs_subgraphs(rowptr, col, 300, 12, seed=5)
     r = ops.Ragged.from_lists(sets, DEV)
     A, seed, st = 300, 7, T.stream_id(T.STREAM_N_BOR, 'train', 0)
-    for lds in (True, False):
+    for lds in (True, False, 1024):                  # 1024 bytes of bitmap: 8192 ids per slice, 5 slices
         for k in (1, 2):
             anchors, sims, counts = ops.khop_border_sample(dg, r, k, A, seed, st, bitmap_in_lds=lds)
             b, hops = ops.sort_ragged(*ops.khop_border(dg, r, k, want_hops=True))
@@ -311,6 +313,42 @@ def test_khop_border_sample_large_border_rank_query():
                     kk = T.nanchor_pick(seed, st, i * A + a, len(bl[i]), len(bl[i]) < mx)
                     assert an[i, a] == (0 if kk < 0 else bl[i][kk])
                     assert sm[i, a] == (lev[an[i, a]] if an[i, a] != 0 else 0)
+
+
+def test_khop_border_sample_beyond_the_lds_bitmap():
+    """1.5 M ids: more than the 150 KB LDS bitmap holds (1.22 M).  The one-hop draw then processes the id
+    range in two LDS-sized slices (rows ascending; pass A counts per slice, pass B answers the slots);
+    results equal the workspace-bitmap kernel's and the tape-ranked sorted border, and item_base shifts
+    the tape items of a shard of the rows."""
+    from subgnn_amd import synthetic, _lib
+    ops = _ops()
+    n = 1_500_000
+    rowptr, col = synthetic.barabasi_albert_csr_device(n, 4, 9, torch.device(DEV))
+    dg = ops.DeviceGraph.from_device_csr(rowptr, col)
+    lib = _lib.load()
+    assert not lib.sgnn_khop_border_bitmap_fits_lds(dg.max_id)
+    assert lib.sgnn_khop_border_sample_workspace_bytes(dg.max_id, 100, 1, 1, 1) == 16          # sliced LDS path
+    assert lib.sgnn_khop_border_sample_workspace_bytes(dg.max_id, 100, 2, 1, 1) > 1 << 20      # k = 2: bitmap in workspace
+    rp, cl = rowptr.cpu().numpy(), col.cpu().numpy()
+    sets = synthetic.bfs_subgraphs(rp, cl, 1500, 20, seed=2)
+    r = ops.Ragged.from_lists(sets, DEV)
+    A, seed, st = 43, 5, T.stream_id(T.STREAM_N_BOR, 'train', 0)
+    a1, s1, c1 = ops.khop_border_sample(dg, r, 1, A, seed, st)                     # sliced, LDS
+    a0, s0, c0 = ops.khop_border_sample(dg, r, 1, A, seed, st, bitmap_in_lds=False)
+    assert torch.equal(a1, a0) and torch.equal(s1, s0) and torch.equal(c1, c0)
+    an, cn, mx = a1.cpu().numpy(), c1.cpu().numpy(), int(c1.max())
+    for i in range(0, 1500, 97):
+        members = np.asarray(sets[i])
+        border = np.setdiff1d(np.unique(np.concatenate([cl[rp[v]:rp[v + 1]] for v in members])), members)
+        assert cn[i] == len(border)
+        for a in range(A):
+            kk = T.nanchor_pick(seed, st, i * A + a, len(border), len(border) < mx)
+            assert an[i, a] == (0 if kk < 0 else border[kk])
+    # a shard of the rows with item_base reproduces those rows of the full call (same padded width)
+    sub = ops.Ragged.from_lists(sets[700:900], DEV)
+    width = c1.max().view(1)
+    a2, s2, c2 = ops.khop_border_sample(dg, sub, 1, A, seed, st, item_base=700, count_reduce=lambda t: torch.maximum(t, width))
+    assert torch.equal(a2, a1[700:900]) and torch.equal(c2, c1[700:900])
 
 
 # ---- a4 neighbourhood anchors -------------------------------------------------------------
