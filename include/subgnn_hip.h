@@ -348,12 +348,19 @@ typedef struct sgnn_mpn_args {
     const float*   bp;         /* (1) linear_position.bias   */
     int32_t        x_f16;      /* GATHER only: x points at an IEEE half table (rows, D), read as
                                 * half and accumulated in fp32 (gradients stay fp32) */
-    int32_t        reserved_;
+    int32_t        flags;      /* SGNN_MPN_WP_PARTIAL: sgnn_mpn_bwd (DENSE) writes grad_wp as per-row partial sums (R, D)
+                                * for the caller to add up in a fixed order, instead of adding into (D) with atomics */
 } sgnn_mpn_args;
+#define SGNN_MPN_WP_PARTIAL 1
 
-int sgnn_mpn_fwd(const sgnn_mpn_args* args, float* agg /*(R,D)*/, float* z /*(R,A)*/, void* stream);
+/* Batch-sized calls (a few hundred rows) split the anchors of a row over sgnn_mpn_fwd_chunks(args) chunks so that
+ * the launch fills the chip; chunk c writes its partial aggregate to agg + c * R * D and the caller adds the
+ * chunks up (a fixed order: no atomics).  agg: (chunks, R, D); 1 chunk for shard-sized calls. */
+int sgnn_mpn_fwd_chunks(const sgnn_mpn_args* args);
+int sgnn_mpn_fwd(const sgnn_mpn_args* args, float* agg /*(chunks,R,D)*/, float* z /*(R,A)*/, void* stream);
 /* grad_x: DENSE (R,A,D) written; GATHER (rows,D) accumulated with float atomics, row PAD
- * untouched; SHARED (A,D) accumulated.  grad_wp (D) accumulated.  Any of them may be NULL. */
+ * untouched (the atomics-free form of GATHER: sgnn_mpn_bwd_edges + sgnn_scatter_add_rows_sorted); SHARED (A,D)
+ * accumulated.  grad_wp (D) accumulated, or (R,D) written with SGNN_MPN_WP_PARTIAL.  Any of them may be NULL. */
 int sgnn_mpn_bwd(const sgnn_mpn_args* args, const float* grad_agg, const float* grad_z,
                  float* grad_x, float* grad_wp, void* stream);
 
@@ -402,6 +409,30 @@ int sgnn_masked_sum_fwd(const float* x, const uint8_t* mask, int64_t B, int64_t 
                         float* out, void* stream);
 int sgnn_masked_sum_bwd(const float* grad_out, const uint8_t* mask, int64_t B, int64_t C, int64_t H,
                         float* grad_x, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * a18  Embedding-table gradient without atomics (the backward of every op that gathers table rows:
+ * autograd of SubGNN/SubGNN.py:609-622, anchor_patch_samplers.py:404-411, subgraph_mpn.py:227-231 as
+ * run by loss.backward(), SubGNN/SubGNN.py:1163-1164).
+ *   table[key[e], :] += c1[e] * G[row(e), :] + c2[e] * v[:]      for e = order[0], order[1], ...
+ * order: the edge numbers sorted STABLY by target key; key_sorted[p] = key of order[p] (ascending); key 0
+ * (the PAD row) contributes nothing.  row(e) = edge_row[e], or e / edges_per_row when edge_row is NULL.
+ * c1 NULL = 1; c2 / v NULL = no second term; G NULL = only the second term.  arg (nullable, (rows, D) int32):
+ * column d of edge e counts only where arg[row(e), d] == key (the max aggregator's argmax).
+ * Every table row has one writer and a fixed summation order: results are bit-reproducible.
+ * sgnn_mpn_bwd_edges: keys and coefficients of a GATHER message-passing layer's backward (c1 = the edge
+ * weight w, c2 = w * grad_z; masked or zero-weight edges get key 0); sgnn_mpn_bwd_wp_partial: that layer's
+ * read-out weight gradient as per-row partial sums (R, D) for the caller to add up.
+ * ------------------------------------------------------------------------------------- */
+int64_t sgnn_scatter_add_rows_workspace_bytes(int64_t n_edges, int64_t D);
+int sgnn_scatter_add_rows_sorted(const int32_t* order, const int32_t* key_sorted, int64_t n_edges,
+                                 const int32_t* edge_row, int64_t edges_per_row,
+                                 const float* G, int64_t D, const float* c1, const float* c2, const float* v,
+                                 const int32_t* arg, float* table,
+                                 void* workspace, int64_t workspace_bytes, void* stream);
+int sgnn_mpn_bwd_edges(const struct sgnn_mpn_args* args, const float* grad_z, int32_t* out_keys, float* out_c1,
+                       float* out_c2, void* stream);
+int sgnn_mpn_bwd_wp_partial(const struct sgnn_mpn_args* args, const float* grad_z, float* partial, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Measurement aid (no reference counterpart): streaming copy of n_bytes with 4 or 16 bytes per lane.

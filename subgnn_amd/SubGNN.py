@@ -257,7 +257,7 @@ class SubGNN(nn.Module):
         ptr = torch.arange(S * C + 1, dtype=torch.int64, device=self.device) * L
         sets = ops.Ragged(ptr, ids.contiguous() if ids.numel() else torch.zeros(1, dtype=torch.int32, device=self.device),
                           max_len=L)
-        return ops.cc_embed(self._table(), sets, aggregator, padded_len=0).view(S, C, -1)
+        return ops.cc_embed(self._table(), sets, aggregator, padded_len=0, stride=L).view(S, C, -1)
 
     def initialize_channel_embeddings(self, cc_embeddings, trainable=False):
         if trainable:

@@ -23,7 +23,7 @@ class MpnArgs(ctypes.Structure):
                 ('R', c_i64), ('A', c_i64), ('D', c_i64),
                 ('x', c_ptr), ('ids', c_ptr), ('id_div', c_i64), ('edge_mask', c_ptr), ('row_mask', c_ptr),
                 ('sims', c_ptr), ('sims_ld', c_i64), ('sim_col', c_ptr), ('wp', c_ptr), ('bp', c_ptr),
-                ('x_f16', ctypes.c_int32), ('reserved_', ctypes.c_int32)]
+                ('x_f16', ctypes.c_int32), ('flags', ctypes.c_int32)]
 
 
 # name -> (restype, argtypes); mirrors include/subgnn_hip.h line by line
@@ -72,6 +72,7 @@ SIGNATURES = {
                                          c_ptr, c_i64, c_ptr]),
     'sgnn_cc_embed_fwd': (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_int, c_i64, c_ptr, c_ptr, c_ptr]),
     'sgnn_cc_embed_bwd': (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_int, c_ptr, c_ptr, c_ptr]),
+    'sgnn_mpn_fwd_chunks': (c_int, [ctypes.POINTER(MpnArgs)]),
     'sgnn_mpn_fwd': (c_int, [ctypes.POINTER(MpnArgs), c_ptr, c_ptr, c_ptr]),
     'sgnn_mpn_bwd': (c_int, [ctypes.POINTER(MpnArgs), c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
     'sgnn_attn_scores_fwd': (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_ptr, c_ptr]),
@@ -81,6 +82,11 @@ SIGNATURES = {
     'sgnn_masked_sum_fwd': (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_i64, c_ptr, c_ptr]),
     'sgnn_masked_sum_bwd': (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_i64, c_ptr, c_ptr]),
     'sgnn_probe_stream_copy': (c_int, [c_ptr, c_ptr, c_i64, c_int, c_ptr]),
+    'sgnn_scatter_add_rows_workspace_bytes': (c_i64, [c_i64, c_i64]),
+    'sgnn_scatter_add_rows_sorted': (c_int, [c_ptr, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr,
+                                             c_ptr, c_i64, c_ptr]),
+    'sgnn_mpn_bwd_edges': (c_int, [ctypes.POINTER(MpnArgs), c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
+    'sgnn_mpn_bwd_wp_partial': (c_int, [ctypes.POINTER(MpnArgs), c_ptr, c_ptr, c_ptr]),
 }
 
 ERRORS = {-1: 'SGNN_ERR_BAD_ARG', -2: 'SGNN_ERR_SET_TOO_LARGE', -3: 'SGNN_ERR_NNZ_TOO_LARGE',

@@ -68,12 +68,8 @@ __global__ __launch_bounds__(256) void mpn_fwd_kernel(sgnn_mpn_args a, float* __
             }
             if (dv == 0 && z) z[r * a.A + ai] = zval;
         }
-        if (gridDim.y == 1) {
-            reinterpret_cast<float4*>(agg)[t] = acc;
-        } else {                                              // anchor chunks of one row add up (agg zeroed by the launcher)
-            float* dst = agg + t * 4;
-            atomicAdd(dst + 0, acc.x); atomicAdd(dst + 1, acc.y); atomicAdd(dst + 2, acc.z); atomicAdd(dst + 3, acc.w);
-        }
+        // anchor chunks of one row: each writes its partial aggregate to its own (R, D) slice, the caller adds them up
+        reinterpret_cast<float4*>(agg)[(int64_t)blockIdx.y * total + t] = acc;
     }
 }
 
@@ -129,11 +125,15 @@ __global__ __launch_bounds__(256) void mpn_bwd_kernel(sgnn_mpn_args a, const flo
             if (SRC == SGNN_SRC_DENSE && grad_x) reinterpret_cast<float4*>(grad_x)[(r * a.A + ai) * D4 + dv] = dx;
         }
         if (grad_wp) {
-            atomicAdd(&s_gwp[dv * 4 + 0], gw.x); atomicAdd(&s_gwp[dv * 4 + 1], gw.y);
-            atomicAdd(&s_gwp[dv * 4 + 2], gw.z); atomicAdd(&s_gwp[dv * 4 + 3], gw.w);
+            if (a.flags & SGNN_MPN_WP_PARTIAL) {
+                reinterpret_cast<float4*>(grad_wp)[t] = gw;                  // (R, D) partials, summed by the caller
+            } else {
+                atomicAdd(&s_gwp[dv * 4 + 0], gw.x); atomicAdd(&s_gwp[dv * 4 + 1], gw.y);
+                atomicAdd(&s_gwp[dv * 4 + 2], gw.z); atomicAdd(&s_gwp[dv * 4 + 3], gw.w);
+            }
         }
     }
-    if (grad_wp) {
+    if (grad_wp && !(a.flags & SGNN_MPN_WP_PARTIAL)) {
         __syncthreads();
         for (int i = threadIdx.x; i < D; i += blockDim.x) atomicAdd(&grad_wp[i], s_gwp[i]);
     }
@@ -245,6 +245,57 @@ __global__ __launch_bounds__(256) void mpn_bwd_shared_kernel(sgnn_mpn_args a, co
     }
 }
 
+// ---- deterministic backward of the GATHER source (embedding-table gradient without atomics) ---------------
+// Per edge (component row r, anchor slot ai) of a GATHER layer: the target table row and the two
+// coefficients of its contribution  dE[id, :] += w * g_agg[r, :] + (w * g_z[r, ai]) * wp  -- the input of
+// sgnn_scatter_add_rows_sorted (scatter.hip) once the keys are sorted.  Masked edges (PAD anchor, padded
+// component row, weight exactly 0) get key 0.
+__global__ __launch_bounds__(256) void mpn_bwd_edges_kernel(sgnn_mpn_args a, const float* __restrict__ grad_z,
+                                                            int32_t* __restrict__ keys, float* __restrict__ c1,
+                                                            float* __restrict__ c2)
+{
+    const int64_t total = a.R * a.A;
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = e / a.A, ai = e % a.A;
+        const bool row_real = a.row_mask ? (a.row_mask[r] != 0) : true;
+        const int64_t id = a.ids[(a.id_div > 1 ? r / a.id_div : r) * a.A + ai];
+        float w = 0.f;
+        if (row_real && id != 0) {
+            const int64_t col = a.sim_col ? a.sim_col[ai] : (a.sims_per_edge ? ai : id - 1);
+            w = a.sims[r * a.sims_ld + col];
+        }
+        keys[e] = w != 0.f ? (int32_t)id : 0;
+        c1[e] = w;
+        if (c2) c2[e] = grad_z ? w * grad_z[e] : 0.f;
+    }
+}
+
+// grad_wp of a GATHER layer as per-row partial sums (no atomics): partial[r, d] = sum_ai g_z[r, ai] * w * x[id, d];
+// the caller sums the rows (a fixed reduction tree).
+__global__ __launch_bounds__(256) void mpn_bwd_wp_partial_kernel(sgnn_mpn_args a, const float* __restrict__ grad_z,
+                                                                 float* __restrict__ partial)
+{
+    const int64_t D = a.D, total = a.R * D;
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = t / D, d = t % D;
+        float gw = 0.f;
+        if (!a.row_mask || a.row_mask[r]) {
+            const int64_t idrow = (a.id_div > 1 ? r / a.id_div : r) * a.A;
+            for (int64_t ai = 0; ai < a.A; ++ai) {
+                const int64_t id = a.ids[idrow + ai];
+                if (id == 0) continue;
+                const float gz = grad_z[r * a.A + ai];
+                if (gz == 0.f) continue;
+                const int64_t col = a.sim_col ? a.sim_col[ai] : (a.sims_per_edge ? ai : id - 1);
+                const float w = a.sims[r * a.sims_ld + col];
+                if (w == 0.f) continue;
+                gw += gz * w * (a.x_f16 ? __half2float(reinterpret_cast<const __half*>(a.x)[id * D + d]) : a.x[id * D + d]);
+            }
+        }
+        partial[t] = gw;
+    }
+}
+
 static int mpn_check(const sgnn_mpn_args* a)
 {
     if (!a || a->R < 0 || a->A < 0 || a->D <= 0 || !a->x || !a->sims || !a->wp || !a->bp) return SGNN_ERR_BAD_ARG;
@@ -260,6 +311,24 @@ static int mpn_check(const sgnn_mpn_args* a)
     return SGNN_OK;
 }
 
+static int mpn_fwd_chunks(const sgnn_mpn_args* args)
+{
+    const int gx = sgnn_grid_for(args->R * (args->D / 4), 256);
+    int chunks = 1;
+    if (gx < 512 && args->A >= 16) {                          // too few rows to fill 256 CUs: split the anchors
+        chunks = (1024 + gx - 1) / gx;
+        const int64_t most = (args->A + 7) / 8;               // at least 8 anchors per chunk
+        if (chunks > most) chunks = (int)most;
+    }
+    return chunks < 1 ? 1 : chunks;
+}
+
+extern "C" int sgnn_mpn_fwd_chunks(const sgnn_mpn_args* args)
+{
+    if (mpn_check(args) != SGNN_OK || args->R == 0) return 1;
+    return mpn_fwd_chunks(args);
+}
+
 extern "C" int sgnn_mpn_fwd(const sgnn_mpn_args* args, float* agg, float* z, void* stream)
 {
     const int rc = mpn_check(args);
@@ -269,13 +338,7 @@ extern "C" int sgnn_mpn_fwd(const sgnn_mpn_args* args, float* agg, float* z, voi
     const int64_t D4 = args->D / 4;
     const int gx = sgnn_grid_for(args->R * D4, 256);
     hipStream_t st = (hipStream_t)stream;
-    int chunks = 1;
-    if (gx < 512 && args->A >= 16) {                          // too few rows to fill 256 CUs: split the anchors
-        chunks = (1024 + gx - 1) / gx;
-        const int64_t most = (args->A + 7) / 8;               // at least 8 anchors per chunk
-        if (chunks > most) chunks = (int)most;
-    }
-    if (chunks > 1) (void)hipMemsetAsync(agg, 0, (size_t)(args->R * args->D * 4), st);
+    const int chunks = mpn_fwd_chunks(args);
     const dim3 grid(gx, chunks);
     if (args->src == SGNN_SRC_DENSE)
         hipLaunchKernelGGL(mpn_fwd_kernel<SGNN_SRC_DENSE>, grid, dim3(256), 0, st, *args, agg, z, D4);
@@ -328,6 +391,31 @@ extern "C" int sgnn_mpn_bwd(const sgnn_mpn_args* args, const float* grad_agg, co
                                grad_wp);
         }
     }
+    SGNN_CHECK_LAUNCH();
+    return SGNN_OK;
+}
+
+extern "C" int sgnn_mpn_bwd_edges(const sgnn_mpn_args* args, const float* grad_z, int32_t* out_keys, float* out_c1,
+                                  float* out_c2, void* stream)
+{
+    const int rc = mpn_check(args);
+    if (rc != SGNN_OK) return rc;
+    if (args->src != SGNN_SRC_GATHER || !out_keys || !out_c1) return SGNN_ERR_BAD_ARG;
+    if (args->R * args->A == 0) return SGNN_OK;
+    hipLaunchKernelGGL(mpn_bwd_edges_kernel, dim3(sgnn_grid_for(args->R * args->A, 256, 8192)), dim3(256), 0,
+                       (hipStream_t)stream, *args, grad_z, out_keys, out_c1, out_c2);
+    SGNN_CHECK_LAUNCH();
+    return SGNN_OK;
+}
+
+extern "C" int sgnn_mpn_bwd_wp_partial(const sgnn_mpn_args* args, const float* grad_z, float* partial, void* stream)
+{
+    const int rc = mpn_check(args);
+    if (rc != SGNN_OK) return rc;
+    if (args->src != SGNN_SRC_GATHER || !grad_z || !partial) return SGNN_ERR_BAD_ARG;
+    if (args->R == 0) return SGNN_OK;
+    hipLaunchKernelGGL(mpn_bwd_wp_partial_kernel, dim3(sgnn_grid_for(args->R * args->D, 256, 8192)), dim3(256), 0,
+                       (hipStream_t)stream, *args, grad_z, partial);
     SGNN_CHECK_LAUNCH();
     return SGNN_OK;
 }

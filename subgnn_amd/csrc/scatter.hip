@@ -1,0 +1,191 @@
+// Deterministic row scatter-add: table[key[e], :] += c1[e] * G[row[e], :] + c2[e] * v[:]  for edges e
+// given in an order sorted (stably) by target key.  Replaces the float atomics of the embedding-table
+// gradient (a18: SubGNN/SubGNN.py:1163-1164 through autograd of a12 / a13 / a15): with atomics the
+// 137.6 M adds of the benchmark's neighbourhood-border layer ran at the ~6 G cache-line operations per
+// second the memory side sustains for device-scope float atomics, in an order that changes from run to
+// run.  Here every table row has exactly one writer and a fixed summation order:
+//
+//   kernel A  one wavefront per run of 64 consecutive sorted positions, lane = column.  The run's
+//             keys / edge numbers / coefficients are loaded one per lane and read back lane by lane
+//             (scalar), the source rows are read as whole contiguous rows (256 B for D = 64), and a
+//             register accumulates until the key changes.  A segment that lies inside the run is added
+//             to the table with a plain read-modify-write; the first / last segment of a run that
+//             continues from / into the neighbouring run goes to a carry slot instead;
+//   kernel B  one wavefront per chain of carry slots (a target with thousands of edges -- a hub that
+//             sits in 15 k subgraphs -- spans hundreds of runs): the partials are summed in run order
+//             and added to the table.
+//
+// Traffic: the sorted order (8 B per edge), the coefficient gathers, one source row per edge (L2 hits:
+// a source row is shared by all edges of its component) and one table row per DISTINCT target.
+#include "common.h"
+
+#define SC_RUN 64
+#define SC_MAXC 4              // columns per lane: D <= 256
+
+struct ScArgs {
+    const int32_t* order;      // E: edge numbers, sorted by target key (stable)
+    const int32_t* key;        // E: key of order[p], ascending; key 0 (PAD) contributes nothing
+    int64_t E;
+    const int32_t* edge_row;   // nullable: source row of edge e; NULL: e / edges_per_row
+    int64_t edges_per_row;
+    const float* G;            // (rows, D), nullable (then only the c2 * v term exists)
+    int64_t D;
+    const float* c1;           // nullable per-edge multiplier of the source row (NULL = 1)
+    const float* c2;           // nullable per-edge multiplier of v
+    const float* v;            // (D), with c2
+    const int32_t* arg;        // nullable (rows, D): column d of edge e counts only if arg[row, d] == key
+    float* table;
+    int32_t* carry_key;        // 2 per run: head, tail
+    int32_t* carry_flag;       // 2 per run: bit 0 = present, bit 1 (head only) = the segment runs on into the next run
+    float* carry_val;          // 2 per run x D
+};
+
+__global__ __launch_bounds__(256) void scatter_runs_kernel(ScArgs a)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t run = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t p0 = run * SC_RUN;
+    if (p0 >= a.E) return;
+    const int cnt = (int)(a.E - p0 < SC_RUN ? a.E - p0 : SC_RUN);
+    const int64_t D = a.D;
+    // one sorted position per lane
+    int32_t k_l = 0, row_l = 0;
+    float c1_l = 0.f, c2_l = 0.f;
+    if (lane < cnt) {
+        k_l = a.key[p0 + lane];
+        const int32_t e = a.order[p0 + lane];
+        row_l = a.edge_row ? a.edge_row[e] : (int32_t)(e / a.edges_per_row);
+        c1_l = a.c1 ? a.c1[e] : 1.f;
+        c2_l = a.c2 ? a.c2[e] : 0.f;
+    }
+    const int32_t prev_key = p0 > 0 ? a.key[p0 - 1] : -1;
+    const int32_t next_key = p0 + cnt < a.E ? a.key[p0 + cnt] : -1;
+    float vv[SC_MAXC];
+#pragma unroll
+    for (int c = 0; c < SC_MAXC; ++c) vv[c] = (a.v && lane + 64 * c < D) ? a.v[lane + 64 * c] : 0.f;
+    float acc[SC_MAXC];
+#pragma unroll
+    for (int c = 0; c < SC_MAXC; ++c) acc[c] = 0.f;
+    int32_t cur = __builtin_amdgcn_readlane(k_l, 0);
+    // arg mode (max aggregator): a member listed twice in its set counts once, as the argmax records one id per
+    // column -- the stable sort keeps the entries of one source row adjacent inside a segment, so "same row as
+    // the previous entry of this key" identifies the repeats (also across the run boundary)
+    int64_t last_row = -1;
+    if (a.arg && p0 > 0 && prev_key == cur) {
+        const int32_t pe = a.order[p0 - 1];
+        last_row = a.edge_row ? a.edge_row[pe] : pe / a.edges_per_row;
+    }
+    bool first_seg = true;
+    int32_t head_flag = 0, tail_flag = 0;
+
+    auto flush = [&](int32_t key, bool is_last) {
+        // where does the finished segment go?
+        const bool from_prev = first_seg && key == prev_key;
+        const bool into_next = is_last && key == next_key;
+        if (key != 0) {
+            if (from_prev) {                                   // head carry (maybe running on)
+                head_flag = 1 | (into_next ? 2 : 0);
+#pragma unroll
+                for (int c = 0; c < SC_MAXC; ++c)
+                    if (lane + 64 * c < D) a.carry_val[(2 * run) * D + lane + 64 * c] = acc[c];
+                if (lane == 0) a.carry_key[2 * run] = key;
+            } else if (into_next) {                            // tail carry: starts a chain
+                tail_flag = 1;
+#pragma unroll
+                for (int c = 0; c < SC_MAXC; ++c)
+                    if (lane + 64 * c < D) a.carry_val[(2 * run + 1) * D + lane + 64 * c] = acc[c];
+                if (lane == 0) a.carry_key[2 * run + 1] = key;
+            } else {                                           // the segment is ours alone
+#pragma unroll
+                for (int c = 0; c < SC_MAXC; ++c)
+                    if (lane + 64 * c < D) a.table[(int64_t)key * D + lane + 64 * c] += acc[c];
+            }
+        }
+        first_seg = false;
+#pragma unroll
+        for (int c = 0; c < SC_MAXC; ++c) acc[c] = 0.f;
+    };
+
+    for (int j = 0; j < cnt; ++j) {
+        const int32_t k = __builtin_amdgcn_readlane(k_l, j);
+        if (k != cur) { flush(cur, false); cur = k; last_row = -1; }
+        if (k == 0) continue;
+        const int64_t row = __builtin_amdgcn_readlane(row_l, j);
+        if (a.arg) { if (row == last_row) continue; last_row = row; }
+        const float c1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c1_l), j));
+        const float c2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c2_l), j));
+#pragma unroll
+        for (int c = 0; c < SC_MAXC; ++c) {
+            const int64_t d = lane + 64 * c;
+            if (d < D) {
+                float val = c2 * vv[c];
+                if (a.G) {
+                    const float g = a.G[row * D + d];
+                    if (a.arg) { if (a.arg[row * D + d] == k) val += c1 * g; }
+                    else val += c1 * g;
+                }
+                acc[c] += val;
+            }
+        }
+    }
+    flush(cur, true);
+    if (lane == 0) { a.carry_flag[2 * run] = head_flag; a.carry_flag[2 * run + 1] = tail_flag; }
+}
+
+__global__ __launch_bounds__(256) void scatter_chains_kernel(ScArgs a, int64_t n_runs)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t run = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (run >= n_runs) return;
+    if (!(a.carry_flag[2 * run + 1] & 1)) return;              // no chain starts here
+    const int64_t D = a.D;
+    const int32_t key = a.carry_key[2 * run + 1];
+    float acc[SC_MAXC];
+#pragma unroll
+    for (int c = 0; c < SC_MAXC; ++c) acc[c] = lane + 64 * c < D ? a.carry_val[(2 * run + 1) * D + lane + 64 * c] : 0.f;
+    for (int64_t j = run + 1; j < n_runs; ++j) {
+        const int32_t f = a.carry_flag[2 * j];
+        if (!(f & 1)) break;                                   // (cannot happen: a tail implies a head next door)
+#pragma unroll
+        for (int c = 0; c < SC_MAXC; ++c)
+            if (lane + 64 * c < D) acc[c] += a.carry_val[(2 * j) * D + lane + 64 * c];
+        if (!(f & 2)) break;
+    }
+#pragma unroll
+    for (int c = 0; c < SC_MAXC; ++c)
+        if (lane + 64 * c < D) a.table[(int64_t)key * D + lane + 64 * c] += acc[c];
+}
+
+extern "C" int64_t sgnn_scatter_add_rows_workspace_bytes(int64_t n_edges, int64_t D)
+{
+    const int64_t n_runs = (n_edges + SC_RUN - 1) / SC_RUN;
+    return n_runs * 2 * (D * 4 + 8) + 64;
+}
+
+extern "C" int sgnn_scatter_add_rows_sorted(const int32_t* order, const int32_t* key_sorted, int64_t n_edges,
+                                            const int32_t* edge_row, int64_t edges_per_row,
+                                            const float* G, int64_t D, const float* c1, const float* c2, const float* v,
+                                            const int32_t* arg, float* table,
+                                            void* workspace, int64_t workspace_bytes, void* stream)
+{
+    if (!order || !key_sorted || !table || n_edges < 0 || D <= 0 || (!G && !c2) || (c2 && !v) || (arg && !G)) return SGNN_ERR_BAD_ARG;
+    if (!edge_row && edges_per_row < 1) return SGNN_ERR_BAD_ARG;
+    if (D > 64 * SC_MAXC) return SGNN_ERR_UNSUPPORTED_D;
+    if (n_edges >= (1ll << 31)) return SGNN_ERR_SET_TOO_LARGE;
+    if (n_edges == 0) return SGNN_OK;
+    if (!workspace || workspace_bytes < sgnn_scatter_add_rows_workspace_bytes(n_edges, D)) return SGNN_ERR_BAD_ARG;
+    const int64_t n_runs = (n_edges + SC_RUN - 1) / SC_RUN;
+    ScArgs a;
+    a.order = order; a.key = key_sorted; a.E = n_edges; a.edge_row = edge_row; a.edges_per_row = edges_per_row;
+    a.G = G; a.D = D; a.c1 = c1; a.c2 = c2; a.v = v; a.arg = arg; a.table = table;
+    a.carry_val = (float*)workspace;
+    a.carry_key = (int32_t*)(a.carry_val + n_runs * 2 * D);
+    a.carry_flag = a.carry_key + n_runs * 2;
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned grid = (unsigned)((n_runs + 3) / 4);
+    hipLaunchKernelGGL(scatter_runs_kernel, dim3(grid), dim3(256), 0, st, a);
+    SGNN_CHECK_LAUNCH();
+    hipLaunchKernelGGL(scatter_chains_kernel, dim3(grid), dim3(256), 0, st, a, n_runs);
+    SGNN_CHECK_LAUNCH();
+    return SGNN_OK;
+}

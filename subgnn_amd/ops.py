@@ -659,6 +659,34 @@ def dtw_similarity(x_ptr, x_val, max_x, y_ptr, y_val, max_y, tie_order=0, order_
 # float half (autograd Functions)
 # ---------------------------------------------------------------------------------------
 
+DETERMINISTIC = True       # table gradients by sorted segmented sums (bit-reproducible); False: float atomics
+
+
+def scatter_add_rows(table, keys, G=None, edge_row=None, edges_per_row=1, c1=None, c2=None, v=None, arg=None):
+    """table[keys[e], :] += c1[e] * G[row(e), :] + c2[e] * v   without atomics (sgnn_scatter_add_rows_sorted):
+    the edges are sorted stably by target row and every row is summed by one owner in that order, so the
+    result is bit-reproducible.  keys int32 (E), 0 = no contribution; row(e) = edge_row[e] or e // edges_per_row."""
+    lib = _lib.load()
+    E = keys.numel()
+    if E == 0:
+        return table
+    _req(keys, torch.int32, 'keys')
+    _req(table, torch.float32, 'table')
+    for t, nm in ((G, 'G'), (c1, 'c1'), (c2, 'c2'), (v, 'v')):
+        _req(t, torch.float32, nm)
+    _req(edge_row, torch.int32, 'edge_row')
+    _req(arg, torch.int32, 'arg')
+    D = table.shape[1]
+    sk, order = torch.sort(keys, stable=True)
+    order = order.to(torch.int32)
+    wsb = lib.sgnn_scatter_add_rows_workspace_bytes(E, D)
+    ws = torch.empty(wsb // 4 + 1, dtype=torch.int32, device=table.device)
+    check(lib.sgnn_scatter_add_rows_sorted(_ptr(order), _ptr(sk), E, _ptr(edge_row), int(edges_per_row), _ptr(G), D, _ptr(c1),
+                                           _ptr(c2), _ptr(v), _ptr(arg), _ptr(table), _ptr(ws), wsb, _stream()),
+          'sgnn_scatter_add_rows_sorted')
+    return table
+
+
 class _GradAcc:
     """One dense gradient buffer for an embedding table, shared by every op that reads the table in
     a forward pass.  Without it each consumer returns its own zero-filled (N+1, D) gradient (256 MB
@@ -715,7 +743,7 @@ def tap_table(E, half=None):
 
 class _CCEmbed(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, E, ptr, nodes, aggregator, padded_len):
+    def forward(ctx, E, ptr, nodes, aggregator, padded_len, stride):
         ctx.acc = getattr(E, '_sgnn_acc', None)
         half = getattr(E, '_sgnn_half', None)
         lib = _lib.load()
@@ -732,25 +760,41 @@ class _CCEmbed(torch.autograd.Function):
                                         _ptr(arg), _stream()), 'sgnn_cc_embed_fwd')
         ctx.save_for_backward(ptr, nodes, arg)
         ctx.aggregator, ctx.shape = aggregator, E.shape
+        ctx.stride = stride
         return out
 
     @staticmethod
     def backward(ctx, g):
         if not ctx.needs_input_grad[0]:
-            return None, None, None, None, None
+            return None, None, None, None, None, None
         lib = _lib.load()
         ptr, nodes, arg = ctx.saved_tensors
         g = g.contiguous()
         gE = ctx.acc.buffer(ctx.shape, g.device) if ctx.acc is not None else \
             torch.zeros(ctx.shape, dtype=torch.float32, device=g.device)
-        check(lib.sgnn_cc_embed_bwd(_ptr(g), ctx.shape[1], _ptr(ptr), _ptr(nodes), ptr.numel() - 1, ctx.aggregator,
-                                    _ptr(arg), _ptr(gE), _stream()), 'sgnn_cc_embed_bwd')
-        return (None if ctx.acc is not None else gE), None, None, None, None
+        if DETERMINISTIC and ctx.shape[1] <= 256:
+            # every (member, component) pair is an edge member -> component row; sorted by member, one owner per
+            # table row (sgnn_scatter_add_rows_sorted).  Max aggregator: a column counts where the member is its argmax.
+            n = ptr.numel() - 1
+            E = nodes.numel()
+            am = arg if ctx.aggregator == 1 else None
+            if ctx.stride > 0:                         # fixed-stride sets: row = entry // stride
+                scatter_add_rows(gE, nodes, G=g, edges_per_row=ctx.stride, arg=am)
+            else:                                      # ragged (the node array may be an arena longer than ptr[-1])
+                pos = torch.arange(E, device=g.device)
+                rows = (torch.searchsorted(ptr, pos, right=True) - 1).clamp_(min=0, max=max(n - 1, 0)).to(torch.int32)
+                keys = torch.where(pos < ptr[-1], nodes, torch.zeros_like(nodes))
+                scatter_add_rows(gE, keys.contiguous(), G=g, edge_row=rows.contiguous(), arg=am)
+        else:
+            check(lib.sgnn_cc_embed_bwd(_ptr(g), ctx.shape[1], _ptr(ptr), _ptr(nodes), ptr.numel() - 1, ctx.aggregator,
+                                        _ptr(arg), _ptr(gE), _stream()), 'sgnn_cc_embed_bwd')
+        return (None if ctx.acc is not None else gE), None, None, None, None, None
 
 
-def cc_embed(E, sets, aggregator='sum', padded_len=0):
-    """initialize_cc_embeddings on ragged components -> (n_sets, D)."""
-    return _CCEmbed.apply(E, sets.ptr, sets.nodes, 0 if aggregator == 'sum' else 1, int(padded_len))
+def cc_embed(E, sets, aggregator='sum', padded_len=0, stride=0):
+    """initialize_cc_embeddings on ragged components -> (n_sets, D).  ``stride`` > 0: the caller promises
+    fixed-stride sets (ptr[i] = i * stride, PAD entries included) -- spares the backward a search."""
+    return _CCEmbed.apply(E, sets.ptr, sets.nodes, 0 if aggregator == 'sum' else 1, int(padded_len), int(stride))
 
 
 SRC_DENSE, SRC_GATHER, SRC_SHARED = 0, 1, 2
@@ -784,14 +828,17 @@ class _MPN(torch.autograd.Function):
         _req(row_mask, torch.uint8, 'row_mask')
         _req(sim_col, torch.int64, 'sim_col')
         D = x.shape[-1]
-        agg = torch.empty((R, D), dtype=torch.float32, device=x.device)
         z = torch.empty((R, A), dtype=torch.float32, device=x.device)
         if A == 0:
-            agg.zero_()
+            agg = torch.zeros((R, D), dtype=torch.float32, device=x.device)
         else:
             a = _mpn_args(src, x, ids, id_div, edge_mask, row_mask, sims, sim_col, sims_per_edge, wp, bp, R, A, D)
+            chunks = lib.sgnn_mpn_fwd_chunks(ctypes.byref(a))       # batch-sized calls split a row's anchors
+            agg = torch.empty((chunks, R, D), dtype=torch.float32, device=x.device)
             check(lib.sgnn_mpn_fwd(ctypes.byref(a), _ptr(agg), _ptr(z), _stream()), 'sgnn_mpn_fwd')
+            agg = agg[0] if chunks == 1 else agg.sum(0)              # a fixed order: no atomics
         ctx.save_for_backward(x, wp, bp, sims, ids, edge_mask, row_mask, sim_col)
+        ctx.set_materialize_grads(False)              # an unused output (the N channel never reads z) arrives as None
         ctx.meta = (src, id_div, sims_per_edge, R, A, D)
         ctx.acc = getattr(x, '_sgnn_acc', None) if src == SRC_GATHER else None     # x is the tapped table
         ctx.half = getattr(x, '_sgnn_half', None) if src == SRC_GATHER else None
@@ -813,12 +860,35 @@ class _MPN(torch.autograd.Function):
                 gx = torch.empty_like(x) if src == SRC_DENSE else torch.zeros_like(x)
         if need_wp:
             gwp = torch.zeros(D, dtype=torch.float32, device=x.device)
-        if (need_x or need_wp) and A > 0:
+        if (need_x or need_wp) and A > 0 and src == SRC_GATHER and DETERMINISTIC and D <= 256:
+            # table gradient by a sorted segmented sum, read-out weight gradient by per-row partials: no atomics
+            if ctx.half is not None:
+                x._sgnn_half = ctx.half
+            a = _mpn_args(src, x, ids, id_div, edge_mask, row_mask, sims, sim_col, sims_per_edge, wp, bp, R, A, D)
+            if need_x and (g_agg is not None or g_z is not None):
+                keys = torch.empty(R * A, dtype=torch.int32, device=x.device)
+                c1 = torch.empty(R * A, dtype=torch.float32, device=x.device)
+                c2 = torch.empty(R * A, dtype=torch.float32, device=x.device) if g_z is not None else None
+                check(lib.sgnn_mpn_bwd_edges(ctypes.byref(a), _ptr(g_z), _ptr(keys), _ptr(c1), _ptr(c2), _stream()),
+                      'sgnn_mpn_bwd_edges')
+                scatter_add_rows(gx, keys, G=g_agg, edges_per_row=A, c1=c1, c2=c2, v=wp if c2 is not None else None)
+            if need_wp and g_z is not None:
+                partial = torch.empty((R, D), dtype=torch.float32, device=x.device)
+                check(lib.sgnn_mpn_bwd_wp_partial(ctypes.byref(a), _ptr(g_z), _ptr(partial), _stream()),
+                      'sgnn_mpn_bwd_wp_partial')
+                gwp = column_sum(partial)
+        elif (need_x or need_wp) and A > 0:
             if ctx.half is not None:
                 x._sgnn_half = ctx.half               # saved tensors come back as new objects
             a = _mpn_args(src, x, ids, id_div, edge_mask, row_mask, sims, sim_col, sims_per_edge, wp, bp, R, A, D)
-            check(lib.sgnn_mpn_bwd(ctypes.byref(a), _ptr(g_agg), _ptr(g_z), _ptr(gx), _ptr(gwp), _stream()),
-                  'sgnn_mpn_bwd')
+            partial = None
+            if need_wp and src == SRC_DENSE and DETERMINISTIC:
+                a.flags = 1                           # SGNN_MPN_WP_PARTIAL: per-row partials, summed below in a fixed order
+                partial = torch.empty((R, D), dtype=torch.float32, device=x.device)
+            check(lib.sgnn_mpn_bwd(ctypes.byref(a), _ptr(g_agg), _ptr(g_z), _ptr(gx), _ptr(partial if partial is not None else gwp),
+                                   _stream()), 'sgnn_mpn_bwd')
+            if partial is not None:
+                gwp = column_sum(partial)
         elif need_x and src == SRC_DENSE:
             gx.zero_()
         if need_wp:
@@ -953,7 +1023,9 @@ def mpn(x, wp, bp, sims, *, src, R, A, ids=None, id_div=1, edge_mask=None, row_m
     sims2 = sims.reshape(R, -1)
     if not sims2.is_contiguous():
         sims2 = sims2.contiguous()
-    if src == SRC_SHARED and R >= SHARED_GEMM_MIN_ROWS and A > 0:
+    if src == SRC_SHARED and A > 0 and (R >= SHARED_GEMM_MIN_ROWS or DETERMINISTIC):
+        # (the hand-written SHARED backward adds row-tile partials with atomics: with DETERMINISTIC the GEMM form
+        # serves batch-sized calls too)
         return _mpn_shared_gemm(x, wp, bp, sims2, ids, row_mask, sim_col, sims_per_edge, R, A)
     return _MPN.apply(x.contiguous(), wp.contiguous().view(-1), bp.contiguous().view(-1), sims2, ids, edge_mask,
                       row_mask, sim_col, src, id_div, sims_per_edge, R, A)
@@ -1006,6 +1078,12 @@ class _GatherRows(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad):
         flat, = ctx.saved_tensors
+        if DETERMINISTIC and grad.is_cuda and grad.shape[-1] <= 256:
+            g = grad.reshape(flat.numel(), -1).to(torch.float32).contiguous()
+            buf = ctx.acc.buffer((ctx.n_rows, g.shape[1]), grad.device) if ctx.acc is not None else \
+                torch.zeros(ctx.n_rows, g.shape[1], dtype=torch.float32, device=grad.device)
+            scatter_add_rows(buf, flat.to(torch.int32).contiguous(), G=g, edges_per_row=1)      # key 0 = PAD: skipped
+            return (None if ctx.acc is not None else buf.to(grad.dtype)), None
         g = grad.reshape(flat.numel(), -1) * (flat != 0).unsqueeze(1).to(grad.dtype)     # PAD row takes no gradient
         if ctx.acc is not None:
             ctx.acc.buffer((ctx.n_rows, g.shape[1]), grad.device).index_add_(0, flat, g.to(torch.float32))

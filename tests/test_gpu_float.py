@@ -18,9 +18,20 @@ def _ops():
     return ops
 
 
+@pytest.fixture(params=['sorted', 'atomics'])
+def det(request):
+    """Both backward forms of the ops that add into the embedding table: sorted segmented sums (the default,
+    bit-reproducible; batch-sized SHARED layers then run as GEMMs) and float atomics (+ the hand-written
+    SHARED kernels)."""
+    from subgnn_amd import ops
+    ops.DETERMINISTIC = request.param == 'sorted'
+    yield request.param
+    ops.DETERMINISTIC = True
+
+
 @pytest.mark.parametrize('agg', ['sum', 'max'])
 @pytest.mark.parametrize('D', [8, 32, 64, 128])
-def test_cc_embed(agg, D):
+def test_cc_embed(agg, D, det):
     ops = _ops()
     g = torch.Generator().manual_seed(D)
     N, S, C, L = 500, 40, 3, 9
@@ -53,7 +64,7 @@ def _g10(g, tag, side):
 
 @pytest.mark.parametrize('tag', ['N', 'P', 'S'])
 @pytest.mark.parametrize('side', ['in', 'out'])
-def test_mpn_dense_matches_reference_golden(tiny, tag, side):
+def test_mpn_dense_matches_reference_golden(tiny, tag, side, det):
     """SRC_DENSE = the reference's own SG_MPN inputs (materialised anchor_embeds + mask)."""
     ops = _ops()
     t, d = _g10(tiny, tag, side)
@@ -107,7 +118,7 @@ def _ref_mpn(x_rows, edge, w, wp, bp):
 
 @pytest.mark.parametrize('A', [11, 69])            # 69: batch-sized calls split their anchors over grid.y
 @pytest.mark.parametrize('D', [8, 32, 64, 128])
-def test_mpn_gather_random(D, A):
+def test_mpn_gather_random(D, A, det):
     """SRC_GATHER (anchor rows gathered from the embedding table by id, NP slab indexed by id-1)."""
     ops = _ops()
     R, N, C = 96, 300, 4
@@ -130,7 +141,7 @@ def test_mpn_gather_random(D, A):
 
 
 @pytest.mark.parametrize('A', [9, 70])
-def test_mpn_dense_random(A):
+def test_mpn_dense_random(A, det):
     """SRC_DENSE (the reference-shaped (R, A, D) anchor tensor) on random inputs, with few and with many
     anchors per row (the latter takes the anchor-split launch at batch size)."""
     ops = _ops()
@@ -153,7 +164,7 @@ def test_mpn_dense_random(A):
     assert_close(bpg.grad, bpc.grad, 'grad bp')
 
 
-def test_mpn_gather_shared_ids_over_components():
+def test_mpn_gather_shared_ids_over_components(det):
     """P-internal: one id row per subgraph shared by its C components (id_div = C)."""
     ops = _ops()
     B, C, A, D, N = 10, 3, 7, 16, 100
@@ -174,7 +185,7 @@ def test_mpn_gather_shared_ids_over_components():
 @pytest.mark.parametrize('D', [8, 64, 128])
 @pytest.mark.parametrize('mode', ['sim_col', 'per_edge', 'by_id'])
 @pytest.mark.parametrize('R,A', [(150, 13), (150, 123), (66000, 13)])
-def test_mpn_shared_random(D, mode, R, A):
+def test_mpn_shared_random(D, mode, R, A, det):
     """SRC_SHARED: P-border (ids -> column id-1) and structure (index list) anchors; a batch-sized
     row count (short row tiles x item chunks in the backward) and a shard-sized one (64-row tiles)."""
     ops = _ops()
@@ -211,7 +222,7 @@ def test_mpn_shared_random(D, mode, R, A):
     assert_close(bpg.grad, bpc.grad, 'grad bp')
 
 
-def test_gather_rows_matches_embedding_with_padding_idx():
+def test_gather_rows_matches_embedding_with_padding_idx(det):
     ops = _ops()
     g = torch.Generator().manual_seed(5)
     W = torch.randn(50, 16, generator=g)
@@ -338,3 +349,82 @@ def test_lstm_unsupported_sizes_stay_on_the_library():
     assert not ops.lstm_supported(48, 48)
     m = LSTM(48, 48).to(DEV)
     assert m(torch.randn(5, 4, 48, device=DEV)).shape == (5, 48)
+
+
+# ---- a18 deterministic table-gradient scatter -------------------------------------------------------
+
+@pytest.mark.parametrize('D', [8, 64, 128, 200])
+def test_scatter_add_rows_sorted_matches_index_add_and_is_reproducible(D):
+    """sgnn_scatter_add_rows_sorted against a float64 index_add: PAD keys, a hub target with thousands of
+    edges (a chain over hundreds of 64-edge runs), both coefficient terms, explicit and implicit source rows;
+    two runs give the same bits."""
+    from subgnn_amd import ops
+    g = torch.Generator().manual_seed(D)
+    n_rows, R, A = 5000, 700, 13
+    E = R * A
+    keys = torch.randint(0, n_rows, (E,), generator=g)
+    keys[torch.rand(E, generator=g) < 0.3] = 7                         # a hub: ~2700 edges
+    keys[torch.rand(E, generator=g) < 0.1] = 0                         # PAD
+    keys[:200] = 11                                                    # a segment that starts at position 0 after the sort? no: low key
+    G = torch.randn(R, D, generator=g)
+    c1, c2, v = torch.randn(E, generator=g), torch.randn(E, generator=g), torch.randn(D, generator=g)
+    want = torch.zeros(n_rows, D, dtype=torch.float64)
+    rows = torch.arange(E) // A
+    contrib = c1.double().unsqueeze(1) * G.double()[rows] + c2.double().unsqueeze(1) * v.double()
+    contrib[keys == 0] = 0
+    want.index_add_(0, keys, contrib)
+    want[0] = 0
+    d = lambda t: t.to(DEV)
+    outs = []
+    for _ in range(2):
+        table = torch.zeros(n_rows, D, device=DEV)
+        ops.scatter_add_rows(table, d(keys.to(torch.int32)), G=d(G), edges_per_row=A, c1=d(c1), c2=d(c2), v=d(v))
+        outs.append(table)
+    assert torch.equal(outs[0], outs[1])
+    assert_close(outs[0], want.float(), 'scatter', 1e-5)
+    # explicit rows, no coefficients, adds on top of what is there
+    er = torch.randint(0, R, (E,), generator=g)
+    table = torch.ones(n_rows, D, device=DEV)
+    ops.scatter_add_rows(table, d(keys.to(torch.int32)), G=d(G), edge_row=d(er.to(torch.int32)))
+    want2 = torch.ones(n_rows, D, dtype=torch.float64)
+    c = G.double()[er]
+    c[keys == 0] = 0
+    want2.index_add_(0, keys, c)
+    want2[0] = 1
+    assert_close(table, want2.float(), 'scatter (rows)', 1e-5)
+
+
+def test_table_gradient_is_bit_reproducible():
+    """The embedding-table gradient of the fused ops (component embeddings sum / max, a GATHER message-passing
+    layer with duplicated anchors, gather_rows) is the same bits on every run -- and equal to the atomics
+    path within float tolerance."""
+    from subgnn_amd import ops
+    g = torch.Generator().manual_seed(3)
+    N, D, R, A, L = 3000, 64, 900, 11, 9
+    E0 = torch.randn(N + 1, D, generator=g)
+    E0[0] = 0
+    cc = torch.randint(0, 40, (R, L), generator=g)                    # few distinct nodes: long segments
+    ids = torch.randint(0, 60, (R, A), generator=g)
+    sims = torch.rand(R, A, generator=g)
+    wp, bp = torch.randn(D, generator=g) * 0.1, torch.zeros(1)
+    walk = torch.randint(0, 50, (30, 5), generator=g)
+
+    def run(det):
+        ops.DETERMINISTIC = det
+        try:
+            E = E0.to(DEV).requires_grad_(True)
+            Et = ops.tap_table(E)
+            sets = ops.Ragged(torch.arange(R + 1, dtype=torch.int64, device=DEV) * L, cc.reshape(-1).to(torch.int32).to(DEV), max_len=L)
+            a = ops.cc_embed(Et, sets, 'sum', stride=L)
+            b = ops.cc_embed(Et, sets, 'max', stride=L)
+            agg, z = ops.mpn(Et, wp.to(DEV).requires_grad_(True), bp.to(DEV), sims.to(DEV), src=ops.SRC_GATHER, R=R, A=A,
+                             ids=ids.to(DEV), sims_per_edge=True)
+            w = ops.gather_rows(Et, walk.to(DEV))
+            ((a * 1.5).sum() + (b * b).sum() + (agg * a).sum() + z.sum() + (w ** 2).sum()).backward()
+            return E.grad.clone()
+        finally:
+            ops.DETERMINISTIC = True
+    g1, g2, g0 = run(True), run(True), run(False)
+    assert torch.equal(g1, g2)
+    assert float(g1[0].abs().max()) == 0
+    assert_close(g1, g0, 'deterministic vs atomics', 1e-5)

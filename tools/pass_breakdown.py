@@ -12,7 +12,8 @@ rows.sort(key=lambda r: int(r['Start_Timestamp']))
 idx = [i for i, r in enumerate(rows) if 'cc_labels_kernel' in r['Kernel_Name']]
 p = rows[idx[-2]:idx[-1]]
 ours = ('cc_labels', 'cc_compact', 'cc_embed', 'choice_ragged', 'msbfs', 'triangular', 'degseq', 'khop', 'dtw_', 'mpn_',
-        'masked_sum', 'sample_anchors', 'patch_in_border', 'attn_scores', 'sp_sim', 'min_hops', 'sort_sets')
+        'masked_sum', 'sample_anchors', 'patch_in_border', 'attn_scores', 'sp_sim', 'min_hops', 'sort_sets', 'scatter_runs',
+        'scatter_chains', 'lstm_', 'update_', 'head_')
 marks = [('triangular_walks', 'patches'), ('msbfs_init', 'position'), ('triangular_walks', 'walks'), ('sort_sets', 'border'),
          ('khop_border', 'border'), ('degseq_wave_kernel<true, false', 'degseq+dtw_prep'), ('dtw_pyramid', 'dtw'),
          ('cc_embed_fwd_kernel', 'fwd+bwd+opt')]
@@ -43,7 +44,7 @@ print('pass span %.1f us, kernel time %.1f us' % ((int(p[-1]['End_Timestamp']) -
 for s in order:
     v = tot[s]
     print('%-16s ours %7.0f us (%3d)   other %7.0f us (%3d)' % (s, v[0], v[2], v[1], v[3]))
-    for n, d in names[s].most_common(4):
+    for n, d in names[s].most_common(int(sys.argv[3]) if len(sys.argv) > 3 else 4):
         print('        %6.0f  %s' % (d, n))
 print()
 for t, d, s, n in big:
