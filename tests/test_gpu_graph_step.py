@@ -1,7 +1,9 @@
 """-m gpu: the training step replayed from a hipGraph (subgnn_amd/graph_step.py) takes the model to
-the same place as the eager step -- same batches, same losses, same parameters (float atomics in the
-backward kernels reorder sums, hence a tolerance) -- including across an anchor resample, which
-invalidates the recording."""
+the same place as the eager step -- same batches, same losses, same parameters -- including across an
+anchor resample, which invalidates the recording.  The backward pass has no float atomics any more
+(sorted segmented sums, per-row partials), so what is left between the two runs is the batch trimming
+(the recorded step keeps the split's padded widths: PAD columns add zeros but regroup the sums) and Adam's
+capturable form: tolerances of 1e-5."""
 import json
 
 import pytest
@@ -40,13 +42,13 @@ def test_captured_step_matches_eager(tiny, tmp_path, resample):
     assert t1.hip_graph_step and not t0.hip_graph_step
     l0 = torch.tensor([e['train_loss'] for e in t0.history])
     l1 = torch.tensor([e['train_loss'] for e in t1.history])
-    assert torch.allclose(l0, l1, rtol=2e-3, atol=1e-5), (l0, l1)
+    assert torch.allclose(l0, l1, rtol=1e-5, atol=1e-6), (l0, l1)
     assert l1[-1] < l1[0]
     sd0, sd1 = m0.state_dict(), m1.state_dict()
     assert sd0.keys() == sd1.keys()
     for k in sd0:
         a, b = sd0[k].float(), sd1[k].float()
-        assert torch.allclose(a, b, rtol=5e-3, atol=2e-4), (k, (a - b).abs().max())
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-5), (k, (a - b).abs().max())
 
 
 def test_captured_step_rejects_other_batch_size(tiny, tmp_path):
@@ -77,7 +79,7 @@ def test_captured_step_with_fp16_table_keeps_validation_fresh(tiny, tmp_path):
             assert torch.equal(m._half_table().float(), m.node_embeddings.weight.detach().half().float())
     v0 = torch.tensor([float(e['val_loss']) for e in m0.metric_scores])
     v1 = torch.tensor([float(e['val_loss']) for e in m1.metric_scores])
-    assert len(v0) == 4 and torch.allclose(v0, v1, rtol=5e-3, atol=1e-5), (v0, v1)
+    assert len(v0) == 4 and torch.allclose(v0, v1, rtol=1e-4, atol=1e-5), (v0, v1)
     # the table moved during training, so a stale copy would have shown
     assert float((m1.node_embeddings.weight.detach() - torch.from_numpy(tiny['embeddings']).to(m1.device)).abs().max()) > 0
 
@@ -92,3 +94,15 @@ def test_recording_goes_stale_when_prepared_tensors_are_replaced(tiny, tmp_path)
     assert not cap.stale()
     m.prepare_data()                         # every prepared tensor is a new object now
     assert cap.stale()
+
+
+def test_training_step_is_bit_reproducible(tiny, tmp_path):
+    """Two models built and trained identically end with identical bits in every parameter: nothing in the
+    step (forward, backward, clipping, Adam) depends on the order in which workgroups happen to run."""
+    (tmp_path / 'a').mkdir()
+    (tmp_path / 'b').mkdir()
+    m0, _ = _fit(tiny, tmp_path / 'a', False, False, epochs=3)
+    m1, _ = _fit(tiny, tmp_path / 'b', False, False, epochs=3)
+    sd0, sd1 = m0.state_dict(), m1.state_dict()
+    for k in sd0:
+        assert torch.equal(sd0[k], sd1[k]), k
