@@ -310,13 +310,38 @@ def patch_in_border_nodes(G, patch_nodes):
     return out
 
 
-def sample_structure_anchor_patches(G, n_samples, sample_walk_len, beta, seed):
-    """aps:210-243 for structure_patch_type == 'triangular_random_walk'.  The start nodes
-    drawn at aps:222 are ignored by this patch type (the walk re-draws its own, aps:70)."""
+def ego_graph_nodes(G, center, radius):
+    """list(nx.ego_graph(G, center, radius).nodes) (aps:228): the nodes within ``radius`` hops of the
+    centre, centre included, in the order of the base graph's node view (the ego graph is a copy of a
+    subgraph VIEW, which iterates G's nodes filtered by membership)."""
+    dist = {center: 0}
+    frontier = [center]
+    for h in range(radius):
+        nxt = []
+        for v in frontier:
+            for w in G.neighbors(v):
+                if w not in dist:
+                    dist[w] = h + 1
+                    nxt.append(w)
+        frontier = nxt
+    return [v for v in G.node_order if v in dist]
+
+
+def sample_structure_anchor_patches(G, n_samples, sample_walk_len, beta, seed, patch_type='triangular_random_walk',
+                                    radius=1):
+    """aps:210-243.  'triangular_random_walk': the start nodes drawn at aps:222 are ignored (the walk
+    re-draws its own, aps:70).  'ego_graph': patch i = the ego graph around the i-th start node
+    (aps:226-228), one np.random.choice call for all starts (tape item 0, draw i)."""
     patches = []
-    for i in range(n_samples):
-        d = _Draws(seed, T.stream_id(T.STREAM_STRUCT_PATCH), i)
-        patches.append(triangular_walk(G, sample_walk_len, beta, d, 'graph'))
+    if patch_type == 'ego_graph':
+        order = list(G.node_order)
+        st = T.stream_id(T.STREAM_STRUCT_START)
+        for i in range(n_samples):
+            patches.append(ego_graph_nodes(G, order[T.choice_index(seed, st, 0, i, len(order))], radius))
+    else:
+        for i in range(n_samples):
+            d = _Draws(seed, T.stream_id(T.STREAM_STRUCT_PATCH), i)
+            patches.append(triangular_walk(G, sample_walk_len, beta, d, 'graph'))
     L = max(len(p) for p in patches)
     out = np.zeros((n_samples, L), dtype=np.int64)
     for i, p in enumerate(patches):

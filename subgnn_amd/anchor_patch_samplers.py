@@ -81,12 +81,36 @@ def perform_random_walks(hparams, networkx_graph, anchor_patch_ids, inside, view
 
 def sample_structure_anchor_patches(hparams, networkx_graph, device, max_sim_epochs):
     """aps:210-243 -> (n sampled patches, max patch length) int64 (trailing all-PAD columns
-    trimmed, as padding to the longest walk does in the reference)."""
-    if hparams['structure_patch_type'] != 'triangular_random_walk':
-        raise NotImplementedError("structure_patch_type %r" % hparams['structure_patch_type'])
+    trimmed, as padding to the longest patch does in the reference).
+    'triangular_random_walk': every patch is a walk of sample_walk_len steps over the whole graph.
+    'ego_graph' (aps:226-228): patch i = the nodes within structure_anchor_patch_radius hops of the i-th
+    start node (the starts are one np.random.choice over the graph's nodes: tape item 0, draw i), centre
+    included, listed in the base graph's node order like the node view of nx.ego_graph -- the k-hop BFS
+    kernel (sgnn_khop_border) from singleton sets."""
+    g = networkx_graph
     n = max_sim_epochs * hparams['n_anchor_patches_structure'] * hparams['n_layers']
-    out = ops.triangular_walks(networkx_graph, 0, n, hparams['sample_walk_len'], hparams['rw_beta'], _seed(hparams),
-                               tape.stream_id(tape.STREAM_STRUCT_PATCH))
+    kind = hparams['structure_patch_type']
+    if kind == 'triangular_random_walk':
+        out = ops.triangular_walks(g, 0, n, hparams['sample_walk_len'], hparams['rw_beta'], _seed(hparams),
+                                   tape.stream_id(tape.STREAM_STRUCT_PATCH))
+    elif kind == 'ego_graph':
+        pool = ops.Ragged(_span_ptr(g.n_nodes, g.device), g.node_order)
+        starts = ops.choice_ragged(pool, n, _seed(hparams), tape.stream_id(tape.STREAM_STRUCT_START))[0]
+        singles = ops.Ragged(torch.arange(n + 1, dtype=torch.int64, device=g.device), starts.to(torch.int32).contiguous(), max_len=1)
+        hood = ops.khop_border(g, singles, int(hparams['structure_anchor_patch_radius']))
+        # node-view order: by position in the graph's node order (ids -> position + 1, sorted per patch, back to ids)
+        L = int(hood.lengths.max().item()) + 1 if n > 0 else 1
+        width = max(L, 1)
+        pos = torch.zeros((n, width), dtype=torch.int64, device=g.device)
+        pos[:, 0] = g.node_pos[starts].long() + 1
+        if width > 1:
+            hp_ = ops.Ragged(hood.ptr, (g.node_pos[hood.nodes.long()] + 1).to(torch.int32), max_len=width - 1).to_padded(width - 1)
+            pos[:, 1:] = hp_
+        big = torch.iinfo(torch.int64).max
+        srt = torch.sort(torch.where(pos == 0, torch.full_like(pos, big), pos), dim=1).values
+        out = torch.where(srt == big, torch.zeros_like(srt), g.node_order[(srt - 1).clamp(min=0, max=g.n_nodes - 1)].long())
+    else:
+        raise NotImplementedError("structure_patch_type %r" % kind)
     longest = int((out != PAD_VALUE).sum(1).max().item()) if n > 0 else 0
     return out[:, :max(longest, 1)].contiguous()
 

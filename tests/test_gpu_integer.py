@@ -790,3 +790,36 @@ def test_degree_sequence_multigraph_rows_are_streamed():
     r = ops.Ragged.from_lists([[1, 5, 9], [5]], DEV)
     oi, oe = ops.degree_sequence(g, r, sort=False, use_degree_dict=False)
     assert ops.Ragged(r.ptr, oi).to_lists() == [[4, 3, 1], [0]]          # hub: 5 (x3) + 9; node 5: hub x3; node 9: hub
+
+
+@pytest.mark.parametrize('radius', [1, 2])
+def test_ego_graph_structure_patches_golden(tiny, radius):
+    """structure_patch_type == 'ego_graph' (aps:226-228) through the product's sampler: the reference's patches
+    as sets, in the base graph's node order, equal to the oracle's; border walks over the reference's recorded
+    views bit for bit."""
+    import json
+    import os
+    from conftest import GOLDEN_DIR
+    from subgnn_amd import anchor_patch_samplers as aps
+    ops = _ops()
+    z = np.load(os.path.join(GOLDEN_DIR, 'extra.npz'), allow_pickle=False)
+    G, dg = _graphs(tiny)
+    t = 'ego_r%d_' % radius
+    hp = json.loads(str(z[t + 'hparams']))
+    hp['seed'] = int(z['seed'])
+    want = z[t + 'structure_anchors']
+    got = aps.sample_structure_anchor_patches(hp, dg, DEV, hp['max_sim_epochs']).cpu().numpy()
+    ref = IH.sample_structure_anchor_patches(G, want.shape[0], hp['sample_walk_len'], hp['rw_beta'], hp['seed'], 'ego_graph', radius)
+    assert np.array_equal(got, ref)
+    assert [sorted(r.tolist()) for r in got] == [sorted(r.tolist()) for r in want]
+    W, Tn = hp['n_triangular_walks'], hp['random_walk_len']
+    vb = ops.Ragged.from_lists([[int(v) for v in r if v != -1] for r in z[t + 'views_bor']], DEV)
+    inb = ops.Ragged.from_lists([[int(v) for v in r if v != -1] for r in z[t + 'in_border']], DEV)
+    n = want.shape[0]
+    bw = ops.triangular_walks(dg, 2, n * W, Tn, hp['rw_beta'], hp['seed'], T.stream_id(T.STREAM_WALK_BOR), patches=vb,
+                              in_border=inb, walks_per_patch=W)
+    assert np.array_equal(bw.view(n, W, Tn).cpu().numpy(), z[t + 'bor_rw'])
+    # and the whole structure channel runs on ego patches (degree sequences, DTW, walks from canonical views)
+    views = aps.patch_node_views(torch.from_numpy(got).to(DEV))
+    iw = aps.perform_random_walks(hp, dg, torch.from_numpy(got).to(DEV), True, views)
+    assert tuple(iw.shape) == (n, W, Tn)

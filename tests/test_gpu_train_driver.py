@@ -1,6 +1,8 @@
 """-m gpu: the build-owned counterpart of train_config.py drives the drop-in module end to end from a
 reference-format config.json (with // comments and an optuna block), and training reduces the loss."""
 import json
+
+import numpy as np
 import os
 
 import pytest
@@ -98,3 +100,34 @@ def test_component_recipe_through_the_model(tiny, tmp_path):
     assert got == [nx.number_connected_components(G.subgraph(s)) for s in tr]
     assert model.num_classes == 2 and torch.isfinite(torch.tensor(trainer.history[0]['train_loss']))
 
+
+
+def test_one_trainer_step_matches_the_reference(tiny, tmp_path):
+    """SURVEY 8(b) caller pin: the parameters after ONE trainer step (training_step -> backward ->
+    clip_grad_norm_ -> Adam.step, the PL 0.7.x order) on g11's 'sum' case, against the imported reference's."""
+    import os
+    from conftest import GOLDEN_DIR
+    from helpers import T, assert_close
+    from test_gpu_model import _model, _inject
+    from subgnn_amd import train_config as TC
+    z = np.load(os.path.join(GOLDEN_DIR, 'extra.npz'), allow_pickle=False)
+    g, t = tiny, 'g11_sum/'
+    hp = json.loads(str(g[t + 'hparams']))
+    m = _model(g, tmp_path, hp)
+    sd = {k[len(t) + 3:]: T(g[k]) for k in g.files if k.startswith(t + 'sd/')}
+    m.load_state_dict({k: v for k, v in sd.items() if not k.startswith('train_')}, strict=False)
+    _inject(m, g, t, m.hparams)
+    m.train()
+    trainer = TC.Trainer(1, gradient_clip_val=float(z['step_clip']))
+    opt = m.configure_optimizers()
+    loss = trainer._eager_step(m, opt, m.make_batch('train', g[t + 'idx']), 0)
+    assert_close(loss, z['step_loss'], 'loss')
+    post = m.state_dict()
+    n = 0
+    for k in z.files:
+        if k.startswith('step_post/'):
+            name = k[len('step_post/'):]
+            if name in post and post[name].dtype == torch.float32:
+                assert_close(post[name], z[k], 'post-step ' + name, 1e-4)
+                n += 1
+    assert n > 20

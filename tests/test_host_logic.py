@@ -126,3 +126,96 @@ def test_equal_count_bins_and_letters():
     cuts = pd.equal_count_bins(vals, 3)
     assert np.allclose(cuts, [0.2, 0.5])
     assert pd.letters(np.digitize(vals, bins=cuts)) == ['A', 'C', 'B', 'C', 'B', 'C']
+
+
+# ---- extra.npz: caller pins, metrics (8f-4), dataset recipe (8f-3) -------------------------
+
+def _extra():
+    from conftest import GOLDEN_DIR
+    return np.load(os.path.join(GOLDEN_DIR, 'extra.npz'), allow_pickle=False)
+
+
+def test_caller_merged_hparams_match_the_reference(tmp_path):
+    """train_config.py:44-86: the same config.json through the reference's read_json +
+    get_hyperparams_optuna (fixed trial: first choice / lower bound) and through this repository's."""
+    import json
+    from subgnn_amd import train_config as TC
+    z = _extra()
+    cfg = tmp_path / 'config.json'
+    cfg.write_text(str(z['caller_config_text']))
+    rc = TC.read_json(cfg)
+    assert list(rc.keys()) == json.loads(str(z['caller_run_config_keys']))
+    hp = TC.get_hyperparams(rc, TC.FixedTrial())
+    assert hp == json.loads(str(z['caller_merged_hparams']))
+    assert list(hp.keys()) == json.loads(str(z['caller_merged_hparams_order']))
+
+
+def test_metrics_match_the_reference():
+    """subgraph_utils.calc_f1 / calc_accuracy (su:94-124), single- and multi-label, and the epoch metrics of
+    validation_epoch_end (S.py:408-464) recomputed from the reference's own per-batch outputs."""
+    import json
+    import types
+    from subgnn_amd import subgraph_utils as su
+    from subgnn_amd.SubGNN import SubGNN
+    z = _extra()
+    logits, labels, ml = torch.from_numpy(z['m_logits']), torch.from_numpy(z['m_labels']), torch.from_numpy(z['ml_labels'])
+    for avg in ('macro', 'micro'):
+        assert np.allclose(su.calc_f1(logits, labels, avg).numpy(), z['m_f1_' + avg])
+        assert np.allclose(su.calc_f1(logits, ml, avg, multilabel_binarizer=object()).numpy(), z['ml_f1_' + avg])
+    assert np.allclose(su.calc_accuracy(logits, labels).numpy(), z['m_acc'])
+    assert np.allclose(su.calc_accuracy(logits, ml, multilabel_binarizer=object()).numpy(), z['ml_acc'])
+    outs = []
+    for i in range(int(z['val_n_batches'])):
+        pre = 'val_out/%d/' % i
+        outs.append({k[len(pre):]: torch.from_numpy(np.asarray(z[k])) for k in z.files if k.startswith(pre)})
+    me = types.SimpleNamespace(multilabel=False, multilabel_binarizer=None)
+    logs = SubGNN._epoch_metrics(me, outs, 'val')
+    want = json.loads(str(z['val_metric_values']))
+    assert list(logs.keys()) == json.loads(str(z['val_metric_keys']))
+    for k, v in want.items():
+        assert abs(float(logs[k]) - v) < 1e-6 or (np.isnan(v) and np.isnan(float(logs[k]))), k
+
+
+def test_density_recipe_against_the_reference_run():
+    """prepare_dataset.py on the DENSITY recipe (fixture: the reference's own run, its seeds).  Pinned exactly:
+    the property function, the equal-count bins, the letters and the BFS subgraphs (same start node on the
+    same base graph -> the same first n nodes); pinned in distribution: what the density edits reach and
+    the split sizes (the edits consume the reference's global random stream, which is not replayed)."""
+    import json
+    import random
+    import networkx as nx
+    from subgnn_amd import prepare_dataset as pd
+    z = _extra()
+    P = json.loads(str(z['recipe_params']))
+    subs = [[int(v) for v in row if v != -1] for row in z['recipe_subgraphs']]
+    G = nx.Graph()
+    G.add_nodes_from(int(v) for v in z['recipe_final_nodes'])
+    G.add_edges_from((int(u), int(v)) for u, v in z['recipe_final_edges'])
+    dens = [pd.density(G, s) for s in subs]
+    assert np.allclose(dens, z['recipe_density'], rtol=0, atol=0)
+    labels = pd.letters(np.digitize(dens, bins=pd.equal_count_bins(dens, P['n_bins'])))
+    assert labels == [str(l) for l in z['recipe_labels']]
+    base = nx.barabasi_albert_graph(P['n'], P['m'], seed=P['seed'])
+    assert sorted(tuple(sorted(e)) for e in base.edges()) == [tuple(e) for e in z['recipe_base_edges'].tolist()]
+
+    class StartAt:
+        def __init__(self, v):
+            self.v = v
+
+        def choice(self, seq):
+            return self.v
+    for s in subs:
+        assert pd.bfs_subgraph(base, P['n_subgraph_nodes'], StartAt(s[0])) == s
+    # the edits: overlapping subgraphs undo each other's edits (in the reference's run 10 % of the subgraphs end
+    # within epsilon of a target), so what can be compared is where the densities end up overall
+    G2, subs2, labels2, values2 = pd.generate('density', seed=P['seed'], n=P['n'], m=P['m'], n_subgraphs=P['n_subgraphs'],
+                                              n_subgraph_nodes=P['n_subgraph_nodes'], n_bins=P['n_bins'])
+    assert len(subs2) == len(subs) and all(0 < len(s) <= P['n_subgraph_nodes'] for s in subs2)
+    assert np.mean([len(s) == P['n_subgraph_nodes'] for s in subs2]) > 0.8       # edits can cut a node off the giant component
+    ref = z['recipe_density']
+    assert abs(np.mean(values2) - np.mean(ref)) < 0.1 and abs(np.std(values2) - np.std(ref)) < 0.1
+    assert min(values2) < 0.15 and max(values2) > 0.35 and min(ref) < 0.15 and max(ref) > 0.35     # all three target bands occur
+    assert sorted(set(labels2)) == sorted(set(labels))
+    mask = pd.split_mask(len(subs), random.Random(1))
+    ref_mask = z['recipe_mask'].tolist()
+    assert [mask.count(k) for k in ('train', 'val', 'test')] == [ref_mask.count(k) for k in (0, 1, 2)]

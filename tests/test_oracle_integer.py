@@ -1,6 +1,7 @@
 """The integer-half oracle against the golden vectors produced by the imported reference
 (tests/golden/make_goldens.py).  CPU only."""
 import numpy as np
+import pytest
 
 from oracle import graph as OG, integer_half as IH, tape as T, fastdtw_restate as FD
 
@@ -201,3 +202,39 @@ def test_reciprocal_division_is_exact():
                          text=True)
     assert out.returncode == 0 and 'bad 0' in out.stdout, out.stdout + out.stderr
 
+
+
+# ---- extra.npz: structure patches with structure_patch_type == 'ego_graph' (aps:226-228) ----------------
+
+def _extra():
+    import os
+    from conftest import GOLDEN_DIR
+    return np.load(os.path.join(GOLDEN_DIR, 'extra.npz'), allow_pickle=False)
+
+
+@pytest.mark.parametrize('radius', [1, 2])
+def test_ego_graph_structure_patches_golden(tiny, radius):
+    """The reference's ego-graph patches, as sets (the node order inside nx.ego_graph's node view is CPython-set
+    order for small patches and graph order for large ones -- canonical here: graph order), and the border walks
+    over them bit for bit given the reference's recorded views."""
+    import json
+    z = _extra()
+    G = _graph(tiny)
+    t = 'ego_r%d_' % radius
+    hp = json.loads(str(z[t + 'hparams']))
+    want = z[t + 'structure_anchors']
+    got = IH.sample_structure_anchor_patches(G, want.shape[0], hp['sample_walk_len'], hp['rw_beta'], int(z['seed']),
+                                             'ego_graph', radius)
+    assert got.shape == want.shape
+    for a, b in zip(got, want):
+        assert sorted(a.tolist()) == sorted(b.tolist())
+    pos = {v: i for i, v in enumerate(G.node_order)}
+    for row in got:                                   # canonical order: the base graph's node order
+        nz = [int(v) for v in row if v != 0]
+        assert nz == sorted(nz, key=lambda v: pos[v])
+    vb = [[int(v) for v in r if v != -1] for r in z[t + 'views_bor']]
+    inb = [[int(v) for v in r if v != -1] for r in z[t + 'in_border']]
+    assert all(IH.patch_in_border_nodes(G, v) == b for v, b in zip(vb, inb))
+    bw = IH.perform_random_walks(G, want, hp['n_triangular_walks'], hp['random_walk_len'], hp['rw_beta'], False,
+                                 int(z['seed']), patch_orders=vb, in_borders=inb)
+    assert np.array_equal(bw, z[t + 'bor_rw'])
