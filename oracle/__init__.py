@@ -15,4 +15,9 @@ Parity pins (see DESIGN.md section "Oracle"):
   * PARITY UNPINNED: fastdtw==0.3.4 (absent from the reference tree and from this image;
     restated from its published algorithm in oracle/fastdtw_restate.py) and the float
     summation order of torch-scatter's scatter-add (PyG 1.6.1, also absent).
+    fastdtw's predecessor rule on ties is a switch (``tie_order`` 0 / 1 / 2, described in
+    fastdtw_restate.py).  The product defaults to 0, the pure-Python module's rule -- the only form of
+    that release whose source is unambiguous (a Python ``min`` over three tuples); 2 is the shape the
+    compiled variant most plausibly has.  All three are property-tested against exact DTW; the goldens
+    (g7) are a self-consistency pin under rule 0.
 """

@@ -7,8 +7,21 @@ reference holds no known-answer vectors for it, so this file restates the algori
 Salvador & Chan's FastDTW as implemented by the pure-Python module of that release
 (recursive halving, radius-dilated projected window, one contiguous run per row, first
 minimum over the predecessors in the order (i-1,j), (i,j-1), (i-1,j-1)).
-``tie_order`` makes the predecessor order switchable because the compiled variant of the
-package may break ties differently (open point (a)).
+``tie_order`` makes the predecessor rule switchable because the compiled variant of the
+package may break ties differently (open point (a)):
+
+  0  pure-Python module: min() over the three SUMS cost + dist in the order (i-1,j), (i,j-1), (i-1,j-1),
+     first minimum wins.  This is the rule the product defaults to: it is the one form of fastdtw 0.3.4
+     whose source text is unambiguous (a Python ``min`` over a tuple of tuples), and the reference's
+     environment file pins the package, not a build of it.
+  1  the same first-minimum-over-sums rule with the diagonal first: (i-1,j-1), (i-1,j), (i,j-1).
+  2  the shape a compiled loop most plausibly has: compare the three PREDECESSOR costs (not the sums) with
+     ``<=`` -- the diagonal if it is <= both others, else (i-1,j) if it is <= (i,j-1), else (i,j-1) -- then
+     add the distance.  Differs from 1 only where rounding makes or breaks a tie between sums.
+
+All three are valid DTW recurrences: each returns a warp-path cost >= the exact DTW distance and equal to
+it whenever the window is the whole grid (either length < radius + 2, or a window that happens to cover it)
+-- tests/test_oracle_integer.py::test_fastdtw_tie_orders_bound_exact_dtw.
 
 Test infrastructure only.
 """
@@ -18,6 +31,7 @@ INF = float('inf')
 TIE_ORDERS = {
     0: ((1, 0), (0, 1), (1, 1)),   # pure-Python fastdtw 0.3.4: (i-1,j), (i,j-1), (i-1,j-1)
     1: ((1, 1), (1, 0), (0, 1)),   # diagonal first (alternative for the compiled variant)
+    2: ((1, 1), (1, 0), (0, 1)),   # same order, decided on the predecessor costs with <= (see the module docstring)
 }
 
 
@@ -66,11 +80,16 @@ def dtw_window(x, y, window, dist, tie_order=0):
         i, j = i0 + 1, j0 + 1
         dt = dist(x[i - 1], y[j - 1])
         best = None
-        for di, dj in order:
-            p = (i - di, j - dj)
-            c = D[p][0] + dt if p in D else INF
-            if best is None or c < best[0]:
-                best = (c, p[0], p[1])
+        if tie_order == 2:
+            pc = [D[(i - di, j - dj)][0] if (i - di, j - dj) in D else INF for di, dj in order]
+            k = 0 if (pc[0] <= pc[1] and pc[0] <= pc[2]) else (1 if pc[1] <= pc[2] else 2)
+            best = (pc[k] + dt, i - order[k][0], j - order[k][1])
+        else:
+            for di, dj in order:
+                p = (i - di, j - dj)
+                c = D[p][0] + dt if p in D else INF
+                if best is None or c < best[0]:
+                    best = (c, p[0], p[1])
         D[(i, j)] = best
     path = []
     i, j = len_x, len_y

@@ -73,11 +73,18 @@ static double dtw_window(const double* x, int lx, const double* y, int ly, const
             c[0] = (i > 0) ? D[(int64_t)(i - 1) * ly + j] : INFINITY;
             c[1] = (j > 0) ? D[(int64_t)i * ly + j - 1] : INFINITY;
             c[2] = (i > 0 && j > 0) ? D[(int64_t)(i - 1) * ly + j - 1] : ((i == 0 && j == 0) ? 0.0 : INFINITY);
-            int best = order[tie_order][0];
-            double bc = c[best] + dt;
-            for (int t = 1; t < 3; ++t) {
-                const int o = order[tie_order][t];
-                if (c[o] + dt < bc) { bc = c[o] + dt; best = o; }
+            int best;
+            double bc;
+            if (tie_order == 2) {                        /* predecessor costs compared with <=: diagonal, (i-1,j), (i,j-1) */
+                best = (c[2] <= c[0] && c[2] <= c[1]) ? 2 : (c[0] <= c[1] ? 0 : 1);
+                bc = c[best] + dt;
+            } else {
+                best = order[tie_order][0];
+                bc = c[best] + dt;
+                for (int t = 1; t < 3; ++t) {
+                    const int o = order[tie_order][t];
+                    if (c[o] + dt < bc) { bc = c[o] + dt; best = o; }
+                }
             }
             D[(int64_t)i * ly + j] = bc;
             P[(int64_t)i * ly + j] = (uint8_t)best;

@@ -692,6 +692,8 @@ __global__ __launch_bounds__(DTW_THREADS) void dtw_similarity_kernel(
 #define LOHI(i) WI(L.MX + (i))
 #define FL(h, i) WI((2 + (h)) * L.MX + (i))
     // predecessor codes: 0 = (i-1,j), 1 = (i,j-1), 2 = (i-1,j-1); evaluation order per tie_order
+    // tie_order 0 / 1: first minimum over the three sums in that order; 2: the predecessor costs compared with <=
+    // (diagonal, then (i-1,j), then (i,j-1)) before the distance is added (oracle/fastdtw_restate.py)
     const int o0 = tie_order == 0 ? 0 : 2, o1 = tie_order == 0 ? 1 : 0, o2 = tie_order == 0 ? 2 : 1;
     const double INF = __longlong_as_double(0x7ff0000000000000ll);
     const int64_t total = n_x * n_y;
@@ -753,8 +755,13 @@ __global__ __launch_bounds__(DTW_THREADS) void dtw_similarity_kernel(
                     c[0] = up + dt; c[1] = left + dt; c[2] = diag + dt;
                     int best = o0;
                     double bc = c[o0];
-                    if (c[o1] < bc) { bc = c[o1]; best = o1; }
-                    if (c[o2] < bc) { bc = c[o2]; best = o2; }
+                    if (tie_order == 2) {
+                        best = (diag <= up && diag <= left) ? 2 : (up <= left ? 0 : 1);
+                        bc = c[best];
+                    } else {
+                        if (c[o1] < bc) { bc = c[o1]; best = o1; }
+                        if (c[o2] < bc) { bc = c[o2]; best = o2; }
+                    }
                     WD(crow + j) = bc;
                     acc |= (uint32_t)best << ((cell & 15) * 2);
                     if ((cell & 15) == 15) { WB(cell >> 4) = acc; acc = 0; }
@@ -952,7 +959,8 @@ __device__ __forceinline__ double dtw_reg_level(
                         // predecessor = the first candidate, in the tie order, that attains the minimum
                         int best;
                         if (TIE == 0) best = c_up == mv ? 0 : (c_left == mv ? 1 : 2);        // (i-1,j), (i,j-1), (i-1,j-1)
-                        else best = c_diag == mv ? 2 : (c_up == mv ? 0 : 1);                  // (i-1,j-1), (i-1,j), (i,j-1)
+                        else if (TIE == 1) best = c_diag == mv ? 2 : (c_up == mv ? 0 : 1);    // (i-1,j-1), (i-1,j), (i,j-1)
+                        else best = (diag <= up && diag <= old) ? 2 : (up <= old ? 0 : 1);    // on the predecessor costs, <=
                         word |= in ? ((word_t)best << (2 * i)) : (word_t)0;
                     }
 #else
@@ -965,7 +973,8 @@ __device__ __forceinline__ double dtw_reg_level(
                             // predecessor = the first candidate, in the tie order, that attains the minimum
                             int best;
                             if (TIE == 0) best = c_up == nv ? 0 : (c_left == nv ? 1 : 2);    // (i-1,j), (i,j-1), (i-1,j-1)
-                            else best = c_diag == nv ? 2 : (c_up == nv ? 0 : 1);              // (i-1,j-1), (i-1,j), (i,j-1)
+                            else if (TIE == 1) best = c_diag == nv ? 2 : (c_up == nv ? 0 : 1);   // (i-1,j-1), (i-1,j), (i,j-1)
+                            else best = (diag <= up && diag <= old) ? 2 : (up <= old ? 0 : 1);
                             word |= (word_t)best << (2 * i);
                         }
                     }
@@ -1109,7 +1118,7 @@ static int dtw_run(const int64_t* x_ptr, const int32_t* x_val, int64_t n_x, int6
                    int64_t workspace_bytes, void* stream)
 {
     if (!x_ptr || !x_val || !y_ptr || !y_val || !out || !workspace || n_x < 0 || n_y < 0) return SGNN_ERR_BAD_ARG;
-    if (tie_order < 0 || tie_order > 1) return SGNN_ERR_BAD_ARG;
+    if (tie_order < 0 || tie_order > 2) return SGNN_ERR_BAD_ARG;
     if (max_x_len < 1) max_x_len = 1;
     if (max_y_len < 1) max_y_len = 1;
     if (max_x_len > 32767 || max_y_len > 32767) return SGNN_ERR_SET_TOO_LARGE;
@@ -1145,9 +1154,11 @@ static int dtw_run(const int64_t* x_ptr, const int32_t* x_val, int64_t n_x, int6
         hipLaunchKernelGGL((dtw_similarity_reg_kernel<RMAX, TIE, MINB, WL>), dim3(DTW_REG_BLOCKS), dim3(DTW_THREADS), dyn, st, \
                            xpyr, xlen, n_x, ypyr, ylen, n_y, out, wq, L, x_order, x_live)
 #define DTW_LAUNCH(RMAX, TIE, MINB) do { if (wlds) DTW_LAUNCH2(RMAX, TIE, MINB, true); else DTW_LAUNCH2(RMAX, TIE, MINB, false); } while (0)
-        if (max_x_len <= 12) { if (tie_order == 0) DTW_LAUNCH(12, 0, DTW_MINB12); else DTW_LAUNCH(12, 1, DTW_MINB12); }
-        else if (max_x_len <= 20) { if (tie_order == 0) DTW_LAUNCH(20, 0, DTW_MINB20); else DTW_LAUNCH(20, 1, DTW_MINB20); }
-        else { if (tie_order == 0) DTW_LAUNCH(32, 0, DTW_MINB32); else DTW_LAUNCH(32, 1, DTW_MINB32); }
+#define DTW_LAUNCH_T(RMAX, MINB) do { if (tie_order == 0) DTW_LAUNCH(RMAX, 0, MINB); else if (tie_order == 1) DTW_LAUNCH(RMAX, 1, MINB); else DTW_LAUNCH(RMAX, 2, MINB); } while (0)
+        if (max_x_len <= 12) DTW_LAUNCH_T(12, DTW_MINB12);
+        else if (max_x_len <= 20) DTW_LAUNCH_T(20, DTW_MINB20);
+        else DTW_LAUNCH_T(32, DTW_MINB32);
+#undef DTW_LAUNCH_T
 #undef DTW_LAUNCH2
 #undef DTW_LAUNCH
     } else {

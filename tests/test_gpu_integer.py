@@ -612,7 +612,7 @@ def test_dtw_golden(golden):
         assert np.array_equal(got.cpu().numpy(), golden[key])
 
 
-@pytest.mark.parametrize('tie', [0, 1])
+@pytest.mark.parametrize('tie', [0, 1, 2])
 def test_dtw_random(tie):
     ops = _ops()
     rng = np.random.default_rng(10 + tie)
@@ -634,7 +634,7 @@ def test_dtw_random(tie):
     assert (np.diag(same) == 1).all()
 
 
-@pytest.mark.parametrize('tie', [0, 1])
+@pytest.mark.parametrize('tie', [0, 1, 2])
 def test_dtw_register_kernel_equals_general_kernel(tie):
     """x rows of <= 32 entries take the register-resident column-major kernel; it must agree bit for
     bit with the C oracle and with the general kernel (forced through the test hook)."""

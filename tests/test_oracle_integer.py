@@ -238,3 +238,37 @@ def test_ego_graph_structure_patches_golden(tiny, radius):
     bw = IH.perform_random_walks(G, want, hp['n_triangular_walks'], hp['random_walk_len'], hp['rw_beta'], False,
                                  int(z['seed']), patch_orders=vb, in_borders=inb)
     assert np.array_equal(bw, z[t + 'bor_rw'])
+
+
+# ---- fastdtw restatement: the three predecessor rules --------------------------------------------------
+
+def test_fastdtw_tie_orders_bound_exact_dtw():
+    """Whatever the compiled fastdtw 0.3.4 does on ties, each plausible rule (oracle/fastdtw_restate.py) is a
+    valid DTW recurrence: its cost is that of some warp path, hence >= the exact DTW distance, and equal to it
+    when the window is the whole grid (a series shorter than radius + 2, or a window that covers it).  The C
+    oracle agrees with the Python restatement for every rule, and the rules do differ on some inputs."""
+    from oracle import cbind
+    rng = np.random.default_rng(5)
+    differ = 0
+    xs, ys = [], []
+    for _ in range(300):
+        lx, ly = int(rng.integers(1, 24)), int(rng.integers(1, 40))
+        x = np.sort(rng.integers(0, 12, lx)).tolist()
+        y = np.sort(rng.integers(0, 30, ly)).tolist()
+        xs.append(x)
+        ys.append(y)
+        exact = FD.exact_dtw(x, y, FD.calc_dist)
+        costs = [FD.fastdtw(x, y, 1, FD.calc_dist, t)[0] for t in (0, 1, 2)]
+        for c in costs:
+            assert c >= exact - 1e-12
+            if lx < 3 or ly < 3:
+                assert c == exact
+        differ += len(set(costs)) > 1
+    assert differ > 0
+    xp, xv = cbind.ragged(xs)
+    yp, yv = cbind.ragged(ys)
+    for t in (0, 1, 2):
+        got = cbind.fastdtw_sim(xp, xv, yp, yv, t)
+        for i in range(0, 300, 7):
+            for j in range(0, 300, 11):
+                assert got[i, j] == np.float32(FD.calc_dtw(xs[i], ys[j], t))
