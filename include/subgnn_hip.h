@@ -369,11 +369,20 @@ int sgnn_mpn_bwd(const sgnn_mpn_args* args, const float* grad_agg, const float* 
  * Replaces attention.AdditiveAttention._forward_internal (SubGNN/attention.py:130-139) as used at
  * SubGNN/SubGNN.py:298-301:  out[r] = sum_j v[j] * tanh(qW[r / rows_per_batch, j] + (X U)[r, j]).
  * X (R, H) component embeddings, U (H, H) = _u_matrix, qW (R / rows_per_batch, H) = vector @ _w_matrix,
- * v (H) = _v_vector.  The X U contraction runs on the matrix cores (v_mfma_f32_32x32x2_f32, exact
- * f32); the (R, H) intermediate is never materialised.  H <= 1215.
+ * v (H) = _v_vector.
  * ------------------------------------------------------------------------------------- */
-int sgnn_attn_scores_fwd(const float* X, const float* U, const float* qW, const float* v,
-                         int64_t R, int64_t H, int64_t rows_per_batch, float* out, void* stream);
+/* exact f32 form: the caller's BLAS computes XU = X U (a plain dense GEMM); this is everything after it, fused:
+ * out[r] = sum_j v_j tanh(XU[r, j] + qW[r / rows_per_batch, j]). */
+int sgnn_attn_scores_epilogue(const float* XU, const float* qW, const float* v, int64_t R, int64_t H,
+                              int64_t rows_per_batch, float* out, void* stream);
+/* half operands on the matrix cores, one kernel (v_mfma_f32_32x32x8_f16, fp32 accumulate; X and U are rounded to IEEE
+ * half on the way in; four wavefronts per workgroup share each 32-column panel of U through LDS): the fp16 form of
+ * BASELINE.json configs[4].  H <= 640, else SGNN_ERR_UNSUPPORTED_D (the caller takes the exact form).
+ * workspace: sgnn_attn_scores_f16_workspace_bytes(H) bytes (the transposed half copy of U). */
+int64_t sgnn_attn_scores_f16_workspace_bytes(int64_t H);
+int sgnn_attn_scores_fwd_f16(const float* X, const float* U, const float* qW, const float* v,
+                             int64_t R, int64_t H, int64_t rows_per_batch, float* out,
+                             void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * a14 (walk aggregator)  The recurrence of one bidirectional LSTM layer, whole sequence per launch.

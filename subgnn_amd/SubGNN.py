@@ -137,7 +137,8 @@ class SubGNN(nn.Module):
             from .attention import AdditiveAttention
             self.attn_vector = Parameter(torch.zeros((hid_dim, 1), dtype=torch.float))
             nn.init.xavier_uniform_(self.attn_vector)
-            self.attention = AdditiveAttention(hid_dim, hid_dim)
+            self.attention = AdditiveAttention(hid_dim, hid_dim, half_operands=str(hp.get('embedding_dtype', 'fp32')).lower()
+                                               in ('fp16', 'float16', 'half'))
         hp.setdefault('structure_similarity_fn', 'dtw')
         self.metric_scores = []
         self.to(self.device)

@@ -75,7 +75,9 @@ SIGNATURES = {
     'sgnn_mpn_fwd_chunks': (c_int, [ctypes.POINTER(MpnArgs)]),
     'sgnn_mpn_fwd': (c_int, [ctypes.POINTER(MpnArgs), c_ptr, c_ptr, c_ptr]),
     'sgnn_mpn_bwd': (c_int, [ctypes.POINTER(MpnArgs), c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
-    'sgnn_attn_scores_fwd': (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_ptr, c_ptr]),
+    'sgnn_attn_scores_epilogue': (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_ptr, c_ptr]),
+    'sgnn_attn_scores_f16_workspace_bytes': (c_i64, [c_i64]),
+    'sgnn_attn_scores_fwd_f16': (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_ptr, c_ptr, c_i64, c_ptr]),
     'sgnn_lstm_supported': (c_int, [c_i64]),
     'sgnn_lstm_fwd': (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
     'sgnn_lstm_bwd': (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_ptr, c_ptr]),

@@ -33,9 +33,10 @@ def masked_softmax(vector, mask, dim=-1, memory_efficient=False):
 class AdditiveAttention(nn.Module):
     """score = V tanh(W x + U y) (attention.py:102-139), softmax-normalised over the rows of y."""
 
-    def __init__(self, vector_dim, matrix_dim, normalize=True):
+    def __init__(self, vector_dim, matrix_dim, normalize=True, half_operands=False):
         super().__init__()
         self._normalize = normalize
+        self.half_operands = half_operands           # embedding_dtype = 'fp16': the score GEMM takes half operands
         self._w_matrix = Parameter(torch.Tensor(vector_dim, vector_dim))
         self._u_matrix = Parameter(torch.Tensor(matrix_dim, vector_dim))
         self._v_vector = Parameter(torch.Tensor(vector_dim, 1))
@@ -49,5 +50,6 @@ class AdditiveAttention(nn.Module):
     def forward(self, vector, matrix, matrix_mask=None):
         B, C, H = matrix.shape
         qW = vector.matmul(self._w_matrix)                                   # (B, H): tiny
-        scores = ops.attn_scores(matrix.reshape(B * C, H), self._u_matrix, qW, self._v_vector, C).view(B, C)
+        scores = ops.attn_scores(matrix.reshape(B * C, H), self._u_matrix, qW, self._v_vector, C,
+                                 half_operands=self.half_operands).view(B, C)
         return masked_softmax(scores, matrix_mask) if self._normalize else scores

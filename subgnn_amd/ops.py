@@ -1158,14 +1158,24 @@ class _AttnScores(torch.autograd.Function):
     recomputes tanh(qW + X U) with library GEMMs (plain dense contractions)."""
 
     @staticmethod
-    def forward(ctx, X, U, qW, v, rows_per_batch):
+    def forward(ctx, X, U, qW, v, rows_per_batch, half_operands):
         lib = _lib.load()
         for t, nm in ((X, 'X'), (U, 'U'), (qW, 'qW'), (v, 'v')):
             _req(t, torch.float32, nm)
         R, H = X.shape
         out = torch.empty(R, dtype=torch.float32, device=X.device)
-        check(lib.sgnn_attn_scores_fwd(_ptr(X), _ptr(U), _ptr(qW), _ptr(v), R, H, rows_per_batch, _ptr(out), _stream()),
-              'sgnn_attn_scores_fwd')
+        if half_operands and H <= ATTN_F16_MAX_H and R >= ATTN_F16_MIN_ROWS:
+            wsb = lib.sgnn_attn_scores_f16_workspace_bytes(H)
+            ws = torch.empty(wsb // 2 + 1, dtype=torch.float16, device=X.device)
+            check(lib.sgnn_attn_scores_fwd_f16(_ptr(X), _ptr(U), _ptr(qW), _ptr(v), R, H, rows_per_batch, _ptr(out),
+                                               _ptr(ws), wsb, _stream()), 'sgnn_attn_scores_fwd_f16')
+        else:
+            # exact form: the contraction is a plain dense GEMM (library); + qW, tanh, x v and the sum over the columns
+            # are one fused pass over it.  With half_operands the operands are rounded first (a batch of a few hundred
+            # rows is four workgroups of the hand-written kernel: the library fills the chip better there).
+            XU = X.half().float() @ U.half().float() if half_operands else X @ U      # (products of halves are exact in fp32)
+            check(lib.sgnn_attn_scores_epilogue(_ptr(XU), _ptr(qW), _ptr(v), R, H, rows_per_batch, _ptr(out), _stream()),
+                  'sgnn_attn_scores_epilogue')
         ctx.save_for_backward(X, U, qW, v)
         ctx.rpb = rows_per_batch
         return out
@@ -1179,9 +1189,18 @@ class _AttnScores(torch.autograd.Function):
         gU = X.t() @ d if ctx.needs_input_grad[1] else None
         gq = d.view(-1, ctx.rpb, d.shape[1]).sum(1) if ctx.needs_input_grad[2] else None
         gv = column_sum(t * g.unsqueeze(1)) if ctx.needs_input_grad[3] else None
-        return gX, gU, gq, gv, None
+        return gX, gU, gq, gv, None, None
 
 
-def attn_scores(X, U, qW, v, rows_per_batch):
-    """score[r] = sum_j v_j tanh(qW[r // rows_per_batch, j] + (X U)[r, j]) for X (R, H)."""
-    return _AttnScores.apply(X.contiguous(), U.contiguous(), qW.contiguous(), v.contiguous().view(-1), int(rows_per_batch))
+ATTN_F16_MAX_H = 640
+ATTN_F16_MIN_ROWS = 2048     # below: the library GEMM (on half-rounded operands) + the fused epilogue
+
+
+def attn_scores(X, U, qW, v, rows_per_batch, half_operands=False):
+    """score[r] = sum_j v_j tanh(qW[r // rows_per_batch, j] + (X U)[r, j]) for X (R, H).
+    Exact form: library GEMM + the fused epilogue (sgnn_attn_scores_epilogue).  ``half_operands``: X and U are
+    rounded to IEEE half and the whole thing is one hand-written kernel on the matrix cores
+    (v_mfma_f32_32x32x8_f16, fp32 accumulate; for H <= 640 and at least a few thousand rows); the backward pass
+    recomputes in fp32 either way."""
+    return _AttnScores.apply(X.contiguous(), U.contiguous(), qW.contiguous(), v.contiguous().view(-1), int(rows_per_batch),
+                             bool(half_operands))

@@ -288,6 +288,40 @@ def test_attn_scores_mfma(R, H, C):
         assert_close(a.grad, b.grad, 'grad ' + nm)
 
 
+@pytest.mark.parametrize('kernel', ['mfma', 'auto'])
+@pytest.mark.parametrize('R,H,C', [(5, 8, 1), (70, 37, 7), (193, 420, 1), (640, 615, 4), (300, 640, 1), (129, 128, 1), (4100, 420, 1)])
+def test_attn_scores_mfma_half_operands(R, H, C, kernel, monkeypatch):
+    """The fp16 form (v_mfma_f32_32x32x8_f16, BASELINE configs[4]): against fp32 arithmetic on the half-ROUNDED
+    operands it is exact up to the accumulation order (products of halves are exact in fp32); against the
+    unrounded reference it is within half precision.  Sizes cover all three register instantiations, partial row
+    tiles and column panels, several rows per batch; the backward pass is the fp32 recomputation."""
+    ops = _ops()
+    if kernel == 'mfma':
+        monkeypatch.setattr(ops, 'ATTN_F16_MIN_ROWS', 0)       # the hand-written kernel at every size (by default a
+    g = torch.Generator().manual_seed(R * 1000 + H)            # batch of a few hundred rows takes the library GEMM)
+    R = R - R % C
+    X = torch.randn(R, H, generator=g)
+    U = torch.randn(H, H, generator=g) / H ** 0.5
+    qW = torch.randn(R // C, H, generator=g)
+    v = torch.randn(H, generator=g)
+    ref_h = (torch.tanh(torch.repeat_interleave(qW, C, dim=0) + X.half().float() @ U.half().float()) * v).sum(1)
+    ref = (torch.tanh(torch.repeat_interleave(qW, C, dim=0) + X @ U) * v).sum(1)
+    Xg, Ug, qg, vg = [t.to(DEV).requires_grad_(True) for t in (X, U, qW, v)]
+    out = ops.attn_scores(Xg, Ug, qg, vg, C, half_operands=True)
+    assert_close(out, ref_h, 'scores vs half-rounded operands', 5e-5)
+    assert_close(out, ref, 'scores vs fp32', 2e-2)
+    out.sum().backward()
+    assert Xg.grad is not None and torch.isfinite(Xg.grad).all() and float(Ug.grad.abs().max()) > 0
+    # beyond the register budget of the half kernel (H > 640) the library GEMM on the rounded operands serves the call
+    if H == 8:
+        Xb = torch.randn(40, 700, generator=g)
+        Ub = torch.randn(700, 700, generator=g) / 26
+        qb, vb = torch.randn(40, 700, generator=g), torch.randn(700, generator=g)
+        a = ops.attn_scores(Xb.to(DEV), Ub.to(DEV), qb.to(DEV), vb.to(DEV), 1, half_operands=True)
+        want = (torch.tanh(qb + Xb.half().float() @ Ub.half().float()) * vb).sum(1)
+        assert_close(a, want, 'H = 700', 1e-3)
+
+
 # ---- fused bidirectional LSTM layer (sgnn_lstm_fwd / _bwd) vs torch's nn.LSTM in fp32 on the CPU --------
 
 def _lstm_params(m, layer):

@@ -284,3 +284,29 @@ def test_get_anchor_patches_g9(tiny, tmp_path, ch, inside):
     assert np.array_equal(ap.cpu().numpy(), g[tag + 'patches'])
     assert np.array_equal(am.cpu().numpy(), g[tag + 'mask'])
     assert_close(ae, g[tag + 'embeds'], 'anchor embeds')
+
+
+def test_ff_attn_with_fp16_takes_the_half_mfma_scores(tiny, tmp_path):
+    """BASELINE configs[4] wiring: embedding_dtype = 'fp16' + ff_attn -> the attention scores of the read-out run
+    on v_mfma_f32_32x32x8_f16 (AdditiveAttention.half_operands); logits stay within half precision of the
+    exact model and every parameter still receives a gradient."""
+    g = tiny
+    t = 'g11_ff_attn/'
+    outs = {}
+    for mode in ('fp32', 'fp16'):
+        hp = json.loads(str(g[t + 'hparams']))
+        hp['embedding_dtype'] = mode
+        m = _model(g, tmp_path, hp)
+        sd = {k[len(t) + 3:]: T(g[k]) for k in g.files if k.startswith(t + 'sd/')}
+        m.load_state_dict({k: v for k, v in sd.items() if not k.startswith('train_')}, strict=False)
+        _inject(m, g, t, m.hparams)
+        assert m.attention.half_operands == (mode == 'fp16')
+        m.train()
+        batch = m.make_batch('train', g[t + 'idx'])
+        out = m.training_step(batch, 0)
+        m.zero_grad()
+        m.backward(None, out['loss'], None, 0)
+        outs[mode] = (m._forward_batch('train', batch).detach(), m.attention._u_matrix.grad.clone())
+    assert_close(outs['fp32'][0], g[t + 'logits'], 'logits fp32')
+    assert_close(outs['fp16'][0], outs['fp32'][0].cpu().numpy(), 'logits fp16 vs fp32', 2e-2)
+    assert float(outs['fp16'][1].abs().max()) > 0
