@@ -5,7 +5,9 @@
  * Conventions
  *   - every pointer is a DEVICE pointer into caller-owned memory (torch tensors on the host
  *     side); nothing is allocated or freed inside; every call is asynchronous on `stream`
- *     (a hipStream_t passed as void*), stateless and graph-capturable;
+ *     (a hipStream_t passed as void*), graph-capturable, and stateless -- except for three process-wide
+ *     test / tuning switches (sgnn_bfs_hops_tuning, sgnn_dtw_force_general, sgnn_walks_force_wave), which select
+ *     between kernels that compute the same values and are not meant to be flipped while calls are in flight;
  *   - return value: 0 = launched, negative = SGNN_ERR_* (argument errors are detected on the
  *     host before any launch; nothing throws across the ABI);
  *   - node ids are 1-based, 0 = PAD (reference config.py:9, SubGNN/SubGNN.py:554-559);
@@ -52,7 +54,8 @@ const char* sgnn_last_error(void);
  * in ascending order (gamma.py:35,48).  out_external may be NULL.
  * self_loops (nullable): uint8[max_id + 1], number of self-loop entries in each node's CSR row;
  * when given, the kernel does not have to test every streamed neighbour against the row's owner.
- * max_set_size: upper bound on set length known to the caller (0 = unknown).
+ * max_set_size: upper bound on set length known to the caller (<= 64 selects the wavefront-per-set kernel; a set
+ * that breaks the promise gets INT32_MIN in all its outputs, never stale memory).
  * set_order (nullable): int32[n_sets], a permutation: the order in which sets are handed to the
  * hardware dispatcher (results are unaffected); heaviest-first shortens the tail of the launch.
  * ------------------------------------------------------------------------------------- */

@@ -279,7 +279,16 @@ __global__ __launch_bounds__(64 * DS_WAVES) __attribute__((amdgpu_waves_per_eu(D
         const int64_t s = set_order ? set_order[si] : si;
         const int64_t beg = set_ptr[s];
         const int n = (int)(set_ptr[s + 1] - beg);
-        if (n <= 0 || n > 64) continue;                     // wave-uniform
+        if (n <= 0) continue;                               // wave-uniform
+        if (n > 64) {
+            // the caller promised sets of at most 64 entries (max_set_size) and this one is larger: its outputs are
+            // poisoned, never left as they were -- a wrong bound shows up as INT32_MIN, not as stale memory
+            for (int i = lane; i < n; i += 64) {
+                out_int[beg + i] = INT32_MIN;
+                if (out_ext) out_ext[beg + i] = INT32_MIN;
+            }
+            continue;
+        }
         int32_t v = 0, deg = 0;
         uint32_t r0 = 0;
         if (lane < n) {

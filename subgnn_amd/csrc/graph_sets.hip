@@ -678,7 +678,7 @@ static int kb_launch(const int64_t* rowptr, const int32_t* col, int64_t nnz, int
     // the set counter sits behind the per-workgroup regions, 8-byte aligned
     const int64_t body = ((bitmap_in_lds ? 0 : words * 4) + (max_id + 1) * 4) * nwg;
     unsigned long long* next_set = (unsigned long long*)((char*)workspace + ((body + 7) & ~(int64_t)7));
-    (void)hipMemsetAsync(next_set, 0, 8, st);
+    { const hipError_t me = hipMemsetAsync(next_set, 0, 8, st); if (me != hipSuccess) { sgnn_set_last_error(me); return SGNN_ERR_LAUNCH; } }
     if (bitmap_in_lds) {
         static bool attr_set = false;
         if (!attr_set) {
@@ -1132,7 +1132,7 @@ extern "C" int sgnn_khop_border_sample(const int64_t* rowptr, const int32_t* col
             hipStream_t st = (hipStream_t)stream;
             // the set counter: the last 8-byte aligned 8 bytes of the workspace
             unsigned long long* next_set = (unsigned long long*)((char*)workspace + ((workspace_bytes - 8) & ~(int64_t)7));
-            (void)hipMemsetAsync(next_set, 0, 8, st);
+            { const hipError_t me = hipMemsetAsync(next_set, 0, 8, st); if (me != hipSuccess) { sgnn_set_last_error(me); return SGNN_ERR_LAUNCH; } }
             static bool attr_set = false;
             if (!attr_set) {
                 hipFuncSetAttribute((const void*)khop1_sample_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, KB_LDS_BYTES);

@@ -455,8 +455,9 @@ static int msbfs_run(const int64_t* rowptr, const int32_t* col, int64_t nnz, int
     SGNN_CHECK_LAUNCH();
     const int g_sets = set_out ? sgnn_grid_for(n_sets * n_words, 256) : 0;
     if (set_out) {
-        (void)hipMemsetAsync(set_seen, 0, (size_t)(n_sets * n_words * 8), st);
-        (void)hipMemsetAsync(set_out, 0, (size_t)(n_sets * n_sources * 4), st);  // unreachable pairs hold 0
+        hipError_t me = hipMemsetAsync(set_seen, 0, (size_t)(n_sets * n_words * 8), st);
+        if (me == hipSuccess) me = hipMemsetAsync(set_out, 0, (size_t)(n_sets * n_sources * 4), st);  // unreachable pairs hold 0
+        if (me != hipSuccess) { sgnn_set_last_error(me); return SGNN_ERR_LAUNCH; }
         hipLaunchKernelGGL(msbfs_set_reduce_kernel, dim3(g_sets), dim3(256), 0, st, frontier, n_words, n_sources, set_ptr,
                            set_nodes, n_sets, set_seen, set_out, flags, 0);
         SGNN_CHECK_LAUNCH();

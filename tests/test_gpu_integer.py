@@ -823,3 +823,23 @@ def test_ego_graph_structure_patches_golden(tiny, radius):
     views = aps.patch_node_views(torch.from_numpy(got).to(DEV))
     iw = aps.perform_random_walks(hp, dg, torch.from_numpy(got).to(DEV), True, views)
     assert tuple(iw.shape) == (n, W, Tn)
+
+
+def test_degree_sequence_understated_set_bound_is_loud():
+    """A caller that promises sets of at most 64 entries and hands over a longer one gets INT32_MIN in that set's
+    outputs (not whatever the buffer held); the other sets are unaffected."""
+    from subgnn_amd import _lib
+    ops = _ops()
+    G = _rand_graph(300, 3, 2)
+    dg = _dev_graph(G)
+    sets = [list(range(1, 21)), list(range(1, 101)), list(range(30, 45))]
+    r = ops.Ragged.from_lists(sets, DEV)
+    good_i, good_e = ops.degree_sequence(dg, r)                                   # true bound: the block kernel for the long set
+    lib = _lib.load()
+    oi = torch.full((r.nodes.numel(),), 7, dtype=torch.int32, device=DEV)
+    oe = torch.full_like(oi, 7)
+    p = ops._ptr
+    _lib.check(lib.sgnn_degree_sequence(p(dg.rowptr), p(dg.col), dg.nnz, p(dg.full_degree), p(dg.self_loops), p(r.ptr), p(r.nodes),
+                                        r.n, 64, 1, p(oi), p(oe), None, ops._stream()), 'sgnn_degree_sequence')
+    assert bool((oi[20:120] == torch.iinfo(torch.int32).min).all()) and bool((oe[20:120] == torch.iinfo(torch.int32).min).all())
+    assert torch.equal(oi[:20], good_i[:20]) and torch.equal(oi[120:135], good_i[120:135])
