@@ -437,7 +437,7 @@ int sgnn_masked_sum_bwd(const float* grad_out, const uint8_t* mask, int64_t B, i
  * read-out weight gradient as per-row partial sums (R, D) for the caller to add up.
  * ------------------------------------------------------------------------------------- */
 int64_t sgnn_scatter_add_rows_workspace_bytes(int64_t n_edges, int64_t D);
-int sgnn_scatter_add_rows_sorted(const int32_t* order, const int32_t* key_sorted, int64_t n_edges,
+int sgnn_scatter_add_rows_sorted(const int64_t* order, const int32_t* key_sorted, int64_t n_edges,
                                  const int32_t* edge_row, int64_t edges_per_row,
                                  const float* G, int64_t D, const float* c1, const float* c2, const float* v,
                                  const int32_t* arg, float* table,

@@ -140,6 +140,10 @@ class SubGNN(nn.Module):
             self.attention = AdditiveAttention(hid_dim, hid_dim, half_operands=str(hp.get('embedding_dtype', 'fp32')).lower()
                                                in ('fp16', 'float16', 'half'))
         hp.setdefault('structure_similarity_fn', 'dtw')
+        # hparams['deterministic'] (default True): gradients by sorted segmented sums and per-row partials -- bit-
+        # reproducible; False: float atomics (fewer launches per batch-sized step, sums in arbitrary order).
+        # Process-wide (ops.DETERMINISTIC), like the kernels' other switches.
+        ops.DETERMINISTIC = bool(hp.get('deterministic', True))
         self.metric_scores = []
         self.to(self.device)
 
@@ -458,8 +462,10 @@ class SubGNN(nn.Module):
             # the trim cannot tell from PAD -- an all-zero column is dropped wherever it lies.
             cc = getattr(self, split + '_cc_ids')
             nb = getattr(self, split + '_N_border', None)
-            w_cc = (cc != 0).any(dim=1).cpu()
-            w_nb = (nb != 0).any(dim=1).cpu() if nb is not None else None
+            # (numpy on purpose: a torch CPU reduction of this size starts an intra-op parallel region, and on a
+            # 128-thread host that costs ~10 ms per call -- measured: 40 ms eager steps instead of 5)
+            w_cc = (cc != 0).any(dim=1).cpu().numpy()
+            w_nb = (nb != 0).any(dim=1).cpu().numpy() if nb is not None else None
             cache[split] = (ids.to(self.device), lab.to(self.device), w_cc, w_nb)
         return cache[split]
 
@@ -482,14 +488,14 @@ class SubGNN(nn.Module):
             return t.index_select(0, didx)
         batch_cc, batch_nb = pick(cc), pick(nb)
         if trim:
-            hidx = idx.cpu()
+            hidx = idx.cpu().numpy()
 
             def drop_pad_columns(t, nz):
-                keep = nz[hidx].any(dim=0) if idx.numel() else torch.zeros(t.shape[2], dtype=torch.bool)
+                keep = nz[hidx].any(axis=0) if idx.numel() else np.zeros(t.shape[2], dtype=bool)
                 k = int(keep.sum())
                 if bool(keep[:k].all()):                       # left-justified rows: the kept columns are a prefix
                     return t[:, :, :k].contiguous()
-                return t.index_select(2, keep.nonzero().view(-1).to(t.device))
+                return t.index_select(2, torch.from_numpy(np.nonzero(keep)[0]).to(t.device))
             batch_cc = drop_pad_columns(batch_cc, w_cc)
             if nb is not None:
                 batch_nb = drop_pad_columns(batch_nb, w_nb)

@@ -23,7 +23,7 @@
 #define SC_MAXC 4              // columns per lane: D <= 256
 
 struct ScArgs {
-    const int32_t* order;      // E: edge numbers, sorted by target key (stable)
+    const int64_t* order;      // E: edge numbers, sorted by target key (stable) -- int64: what a library sort returns
     const int32_t* key;        // E: key of order[p], ascending; key 0 (PAD) contributes nothing
     int64_t E;
     const int32_t* edge_row;   // nullable: source row of edge e; NULL: e / edges_per_row
@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void scatter_runs_kernel(ScArgs a)
     float c1_l = 0.f, c2_l = 0.f;
     if (lane < cnt) {
         k_l = a.key[p0 + lane];
-        const int32_t e = a.order[p0 + lane];
+        const int64_t e = a.order[p0 + lane];
         row_l = a.edge_row ? a.edge_row[e] : (int32_t)(e / a.edges_per_row);
         c1_l = a.c1 ? a.c1[e] : 1.f;
         c2_l = a.c2 ? a.c2[e] : 0.f;
@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256) void scatter_runs_kernel(ScArgs a)
     // the previous entry of this key" identifies the repeats (also across the run boundary)
     int64_t last_row = -1;
     if (a.arg && p0 > 0 && prev_key == cur) {
-        const int32_t pe = a.order[p0 - 1];
+        const int64_t pe = a.order[p0 - 1];
         last_row = a.edge_row ? a.edge_row[pe] : pe / a.edges_per_row;
     }
     bool first_seg = true;
@@ -162,7 +162,7 @@ extern "C" int64_t sgnn_scatter_add_rows_workspace_bytes(int64_t n_edges, int64_
     return n_runs * 2 * (D * 4 + 8) + 64;
 }
 
-extern "C" int sgnn_scatter_add_rows_sorted(const int32_t* order, const int32_t* key_sorted, int64_t n_edges,
+extern "C" int sgnn_scatter_add_rows_sorted(const int64_t* order, const int32_t* key_sorted, int64_t n_edges,
                                             const int32_t* edge_row, int64_t edges_per_row,
                                             const float* G, int64_t D, const float* c1, const float* c2, const float* v,
                                             const int32_t* arg, float* table,

@@ -677,8 +677,7 @@ def scatter_add_rows(table, keys, G=None, edge_row=None, edges_per_row=1, c1=Non
     _req(edge_row, torch.int32, 'edge_row')
     _req(arg, torch.int32, 'arg')
     D = table.shape[1]
-    sk, order = torch.sort(keys, stable=True)
-    order = order.to(torch.int32)
+    sk, order = torch.sort(keys, stable=True)                 # int64 positions: taken as they are
     wsb = lib.sgnn_scatter_add_rows_workspace_bytes(E, D)
     ws = torch.empty(wsb // 4 + 1, dtype=torch.int32, device=table.device)
     check(lib.sgnn_scatter_add_rows_sorted(_ptr(order), _ptr(sk), E, _ptr(edge_row), int(edges_per_row), _ptr(G), D, _ptr(c1),

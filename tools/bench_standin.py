@@ -71,11 +71,13 @@ def main():
     ap.add_argument('--config', choices=sorted(PRESETS), required=True)
     ap.add_argument('--steps', type=int, default=30)
     ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--atomics', action='store_true', help="hparams['deterministic'] = False: float atomics in the backward pass")
     args = ap.parse_args()
     from subgnn_amd import config, hotpath, precompute_graph_metrics as pgm
     from subgnn_amd.SubGNN import SubGNN, dataset_paths
     P = PRESETS[args.config]
     hp = dict(P['hp'])
+    hp['deterministic'] = not args.atomics
     root = tempfile.mkdtemp(prefix=args.config + '_')
     name = args.config + '_standin'
     t0 = time.time()
@@ -115,7 +117,7 @@ def main():
                                                                    'sparse' if P['sparse'] else 'dense reference-shaped', B),
                    'cc_ids_shape': list(model.train_cc_ids.shape), 'n_layers': hp['n_layers'],
                    'structure_patches': int(model.structure_anchors.shape[0]) if model.structure_anchors is not None else 0},
-        'prepare_data_s': round(t_prep, 2), 'prepare_stages_ms_train_split': stages,
+        'deterministic_backward': not args.atomics, 'prepare_data_s': round(t_prep, 2), 'prepare_stages_ms_train_split': stages,
         'dataset_write_s': round(t_write, 2), 'graph_metrics_s': round(t_metrics, 2),
         'loss': loss, 'loss_graph': loss_g}))
 

@@ -1,0 +1,37 @@
+#!/bin/bash
+# Counter passes of the DTW kernel on the benchmark's inputs (tools/dtw_probe.py): issue / wait split of the
+# wave-cycles, instruction mix, LDS activity.  Separate passes (8 SQ counters per pass), no tracing.
+export TMPDIR=/tmp
+O=gpurun_out
+i=0
+for c in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS" \
+         "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_INST_CYCLES_SALU SQ_LDS_BANK_CONFLICT" \
+         "GRBM_GUI_ACTIVE GRBM_COUNT"; do
+  i=$((i+1))
+  rm -rf $O/r02_dtwpmc_$i
+  rocprofv3 --pmc $c --output-format csv -d $O/r02_dtwpmc_$i -- python3 tools/dtw_probe.py 2 20 > $O/r02_dtwpmc_$i.log 2>&1
+done
+python tools/pmc_summary.py $O/r02_dtwpmc_1 $O/r02_dtwpmc_2 $O/r02_dtwpmc_3 > $O/r02_dtw_pmc_raw.json
+python - <<'PY'
+import json
+d = json.load(open('gpurun_out/r02_dtw_pmc_raw.json'))
+out = {'what': 'rocprofv3 --pmc passes (tools/run_dtw_pmc.sh) on tools/dtw_probe.py 2 20: the DTW launches of the benchmark '
+               '(50k components x 210 anchor patches, internal and external side); per-dispatch averages'}
+for k, v in d.items():
+    if 'dtw_similarity' in k:
+        c = {n: x['mean'] for n, x in v.items()}
+        r = dict(c)
+        wc = c.get('SQ_WAVE_CYCLES')
+        if wc:
+            r['frac_wave_cycles_issuing'] = c.get('SQ_ACTIVE_INST_ANY', 0) / wc
+            r['frac_wave_cycles_waiting_waitcnt_or_barrier'] = c.get('SQ_WAIT_ANY', 0) / wc
+            r['frac_wave_cycles_issue_stalled'] = c.get('SQ_WAIT_INST_ANY', 0) / wc
+            r['frac_wave_cycles_valu_active'] = c.get('SQ_ACTIVE_INST_VALU', 0) / wc
+        if c.get('SQ_WAVES') and c.get('SQ_INSTS_VALU'):
+            r['valu_instructions_per_wave'] = c['SQ_INSTS_VALU'] / c['SQ_WAVES']
+            r['salu_instructions_per_wave'] = c.get('SQ_INSTS_SALU', 0) / c['SQ_WAVES']
+            r['lds_instructions_per_wave'] = c.get('SQ_INSTS_LDS', 0) / c['SQ_WAVES']
+        out[k] = r
+json.dump(out, open('gpurun_out/r02_dtw_pmc.json', 'w'), indent=1)
+print(json.dumps(out, indent=1)[:3000])
+PY

@@ -1,0 +1,12 @@
+#!/bin/bash
+# Everything profiles/ holds for a round, in one go on the GPU box.  usage: tools/run_round_profiles.sh r02
+T=$1
+O=gpurun_out
+python bench.py > $O/${T}_final_bench_default.json 2> $O/${T}_final_bench_default.err
+bash tools/profile_bench.sh ${T}_final > /dev/null 2>&1
+python bench.py --subgraphs 6250 --no-cpu-baseline --steps 10 > $O/${T}_bench_shard6250.json 2>/dev/null
+for c in density_n ppi_bp hpo_metab em_user; do
+  python tools/bench_standin.py --config $c > $O/${T}_bench_standin_$c.json 2> $O/${T}_bench_standin_$c.err
+done
+bash tools/check_multirank.sh > $O/${T}_multirank_check.txt 2>&1
+ls -la $O | grep ${T}_ | head -40
