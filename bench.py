@@ -264,6 +264,7 @@ def main():
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+    hotpath.check_pending(model)                                 # the last pass's BFS level hints (raises if one was too small)
     for tm in timers:
         for k, v in tm.summary().items():
             stage_ms[k] = stage_ms.get(k, 0.0) + v / args.steps

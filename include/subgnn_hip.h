@@ -253,12 +253,17 @@ int sgnn_min_hops_to_sets(const uint8_t* dist, int64_t n_sources, int64_t max_id
  * runs over it) -- compute_shortest_path_similarities
  * (SubGNN/SubGNN.py:752-781) restricted to the anchor columns, without the (sources x nodes) hop
  * table: after every BFS level each set ORs its members' new frontier words and records the level for
- * the sources it sees for the first time.  out: (n_sets, n_sources) float32. */
+ * the sources it sees for the first time.  out: (n_sets, n_sources) float32.
+ * All max_hops levels are enqueued without a host synchronisation (levels behind the last productive one exit at
+ * once).  out_status (nullable, int32[2], device): [0] = the last level that found anything, [1] = 1 if level
+ * max_hops itself still did -- the caller enqueued too few levels and the result may be incomplete.  A caller that
+ * repeats the same search (the same graph and anchors every pass) can read [0] once and pass max_hops = [0] + a
+ * margin afterwards, checking [1] at its next synchronisation point. */
 int64_t sgnn_bfs_min_hops_workspace_bytes(int64_t max_id, int64_t n_sources, int max_hops, int64_t n_sets);
 int sgnn_bfs_min_hops_to_sets(const int64_t* rowptr, const int32_t* col, int64_t nnz, int64_t max_id,
                               const int32_t* sources, int64_t n_sources, int max_hops,
                               const int64_t* set_ptr, const int32_t* set_nodes, int64_t n_sets,
-                              float* out, void* workspace, int64_t workspace_bytes, void* stream);
+                              float* out, int32_t* out_status, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * a11  Structure similarity: 1 / (1 + fastdtw(x, y, radius=1, dist=calc_dist)).

@@ -59,7 +59,7 @@ SIGNATURES = {
     'sgnn_bfs_hops_workspace_bytes': (c_i64, [c_i64, c_i64, c_int]),
     'sgnn_bfs_hops_tuning': (c_int, [c_int]),
     'sgnn_bfs_min_hops_workspace_bytes': (c_i64, [c_i64, c_i64, c_int, c_i64]),
-    'sgnn_bfs_min_hops_to_sets': (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_i64, c_int, c_ptr, c_ptr, c_i64, c_ptr,
+    'sgnn_bfs_min_hops_to_sets': (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_i64, c_int, c_ptr, c_ptr, c_i64, c_ptr, c_ptr,
                                           c_ptr, c_i64, c_ptr]),
     'sgnn_bfs_hops': (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_i64, c_int, c_int, c_ptr, c_ptr, c_i64, c_ptr]),
     'sgnn_min_hops_to_sets': (c_int, [c_ptr, c_i64, c_i64, c_int, c_ptr, c_ptr, c_i64, c_ptr, c_ptr]),

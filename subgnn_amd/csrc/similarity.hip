@@ -428,10 +428,22 @@ __global__ __launch_bounds__(256) void msbfs_set_finalize_kernel(
     }
 }
 
+// status[0] = the last level that found anything, status[1] = 1 if the LAST enqueued level still found something
+// (the search may be incomplete: the caller enqueued too few levels)
+__global__ void msbfs_status_kernel(const int32_t* __restrict__ flags, int max_hops, int32_t* __restrict__ status)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        int last = 0;
+        for (int l = 1; l <= max_hops; ++l) if (flags[l]) last = l;
+        status[0] = last;
+        status[1] = flags[max_hops] != 0;
+    }
+}
+
 static int msbfs_run(const int64_t* rowptr, const int32_t* col, int64_t nnz, int64_t max_id,
                      const int32_t* sources, int64_t n_sources, int max_hops, int node_major, uint8_t* dist,
                      const int64_t* set_ptr, const int32_t* set_nodes, int64_t n_sets, float* set_out,
-                     void* workspace, hipStream_t st)
+                     void* workspace, hipStream_t st, int32_t* status = nullptr)
 {
     const int64_t n_ids = max_id + 1;
     const int64_t n_words = (n_sources + 63) / 64;
@@ -483,6 +495,10 @@ static int msbfs_run(const int64_t* rowptr, const int32_t* col, int64_t nnz, int
                            set_nodes, n_sets, set_out);
         SGNN_CHECK_LAUNCH();
     }
+    if (status) {
+        hipLaunchKernelGGL(msbfs_status_kernel, dim3(1), dim3(64), 0, st, flags, max_hops, status);
+        SGNN_CHECK_LAUNCH();
+    }
     return SGNN_OK;
 }
 
@@ -507,7 +523,8 @@ extern "C" int64_t sgnn_bfs_min_hops_workspace_bytes(int64_t max_id, int64_t n_s
 extern "C" int sgnn_bfs_min_hops_to_sets(const int64_t* rowptr, const int32_t* col, int64_t nnz, int64_t max_id,
                                          const int32_t* sources, int64_t n_sources, int max_hops,
                                          const int64_t* set_ptr, const int32_t* set_nodes, int64_t n_sets,
-                                         float* out, void* workspace, int64_t workspace_bytes, void* stream)
+                                         float* out, int32_t* out_status, void* workspace, int64_t workspace_bytes,
+                                         void* stream)
 {
     if (!rowptr || !col || !sources || !set_ptr || !set_nodes || !out || !workspace || n_sources < 0 || n_sets < 0 ||
         max_hops < 1 || max_hops > 254)
@@ -516,7 +533,7 @@ extern "C" int sgnn_bfs_min_hops_to_sets(const int64_t* rowptr, const int32_t* c
     if (workspace_bytes < sgnn_bfs_min_hops_workspace_bytes(max_id, n_sources, max_hops, n_sets)) return SGNN_ERR_BAD_ARG;
     if (n_sources == 0 || n_sets == 0) return SGNN_OK;
     return msbfs_run(rowptr, col, nnz, max_id, sources, n_sources, max_hops, 0, nullptr, set_ptr, set_nodes, n_sets, out,
-                     workspace, (hipStream_t)stream);
+                     workspace, (hipStream_t)stream, out_status);
 }
 
 __global__ void min_hops_to_sets_kernel(const uint8_t* __restrict__ dist, int64_t n_sources, int64_t n_ids,

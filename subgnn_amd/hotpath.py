@@ -70,6 +70,54 @@ def _hand_over(stream, *objs):
             _hand_over(stream, *o)
 
 
+BFS_LEVEL_MARGIN = 2
+
+
+def _bfs_levels(model, key, max_hops):
+    """How many BFS levels to enqueue for the position channel's search ``key``.  The kernels run without a host
+    synchronisation, so every enqueued level costs three launches whether or not the search has ended -- with the
+    default cap of 32 hops and a small-world graph that is ~26 empty levels (~0.3 ms of a 19 ms pass).  The first
+    search of a kind runs the full cap and its status (last productive level) is read back once; later ones
+    enqueue that many levels plus a margin, and their status -- did the LAST level still find something? -- is
+    kept on the model and verified by ``check_pending`` at the next point where the host waits for the device anyway."""
+    hint = model.__dict__.setdefault('_bfs_level_hint', {})
+    k = hint.get(key)
+    return max_hops if k is None else min(max_hops, k + BFS_LEVEL_MARGIN)
+
+
+def _bfs_note(model, key, status, max_hops, enqueued):
+    hint = model.__dict__.setdefault('_bfs_level_hint', {})
+    if hint.get(key) is None:
+        last, more = status.tolist()                           # first search of this kind: one read-back
+        if more:
+            raise RuntimeError('position-channel BFS: level %d still reached new nodes -- hparams["max_bfs_hops"] = %d '
+                               'is smaller than the depth of this graph from the anchors' % (max_hops, max_hops))
+        hint[key] = last
+    else:
+        model.__dict__.setdefault('_bfs_pending', []).append((key, status, enqueued, max_hops))
+
+
+def check_pending(model):
+    """Verify the searches queued since the last call (call it where the host has just waited for the device, e.g.
+    after reading the loss; ``prepare_sparse`` calls it on entry).  A search whose last enqueued level still found
+    something is an error, loudly: its similarities were incomplete.  The hint is dropped so that the next pass runs
+    the full cap again."""
+    pend = model.__dict__.pop('_bfs_pending', [])
+    if not pend:
+        return
+    got = torch.stack([st for _, st, _, _ in pend]).tolist() if len(pend) > 1 else [pend[0][1].tolist()]
+    bad = [(key, enq, cap) for (key, _, enq, cap), (_, more) in zip(pend, got) if more]
+    hint = model.__dict__.get('_bfs_level_hint', {})
+    for (key, _, _, _), (last, _) in zip(pend, got):
+        if key in hint:
+            hint[key] = max(hint[key], last)                   # the hint only grows: anchors are redrawn every pass
+    if bad:
+        for key, _, _ in bad:
+            hint.pop(key, None)
+        raise RuntimeError('position-channel BFS ran out of levels (search, levels enqueued, cap): %r -- the previous '
+                           'pass used incomplete similarities; the level hint has been dropped, repeat the pass' % (bad,))
+
+
 def _dealt_position_sims(g, anchors, cc_sets, cc_ids, shard, max_hops):
     """P-border similarities with the BFS sources dealt across ranks (strong scaling): this rank runs the
     multi-source BFS for ITS share of the shared anchors only -- one 64-source word instead of
@@ -105,6 +153,7 @@ def prepare_sparse(model, split='train', timer=None, shard=None):
     position channel.  hparams['overlap_streams'] = True enables it (default off: on this runtime the two streams' kernels were observed to execute back to back, so it buys nothing yet)."""
     hp, g, dev = model.hparams, model.networkx_graph, model.device
     seed = int(hp.get('seed', 0)) & tape.MASK64
+    check_pending(model)                           # (the previous pass's BFS level hints; see _bfs_levels)
     t = timer or StageTimer(False)
     L = hp['n_layers']
     main = torch.cuda.current_stream()
@@ -162,8 +211,12 @@ def prepare_sparse(model, split='train', timer=None, shard=None):
                     w = _dealt_position_sims(g, model.anchors_pos_ext[l], cc_sets, cc_ids, shard,
                                              hp.get('max_bfs_hops', 32)).view(S, C, -1)
                 else:
-                    w = ops.bfs_min_hops_to_sets(g, model.anchors_pos_ext[l].to(torch.int32).contiguous(), cc_sets,
-                                                 max_hops=hp.get('max_bfs_hops', 32)).view(S, C, -1)
+                    cap = hp.get('max_bfs_hops', 32)
+                    nlev = _bfs_levels(model, ('P_out', split, l), cap)
+                    w, status = ops.bfs_min_hops_to_sets(g, model.anchors_pos_ext[l].to(torch.int32).contiguous(), cc_sets,
+                                                         max_hops=nlev, want_status=True)
+                    _bfs_note(model, ('P_out', split, l), status, cap, nlev)
+                    w = w.view(S, C, -1)
                 sims[('P', 'out', l)] = (w * real.unsqueeze(-1)).contiguous()
                 if C == 1:
                     sims[('P', 'in', l)] = ops.ZeroSims((S, C, hp['n_anchor_patches_pos_in']), dev)

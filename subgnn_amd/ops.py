@@ -512,19 +512,22 @@ def bfs_hops(g, sources, max_hops=64, node_major=False):
     return dist
 
 
-def bfs_min_hops_to_sets(g, sources, sets, max_hops=64):
+def bfs_min_hops_to_sets(g, sources, sets, max_hops=64, want_status=False):
     """min over the members of every set of the hop distance from every source -> (n_sets, n_sources)
-    float32, 0 for unreachable pairs; one multi-source BFS, no (sources x nodes) hop table."""
+    float32, 0 for unreachable pairs; one multi-source BFS, no (sources x nodes) hop table.
+    ``want_status``: also an int32[2] device tensor -- [0] the last level that found anything, [1] whether level
+    ``max_hops`` itself still did (too few levels enqueued: the result may be incomplete)."""
     lib = _lib.load()
     _req(sources, torch.int32, 'sources')
     ns = sources.numel()
     out = torch.empty((sets.n, ns), dtype=torch.float32, device=g.device)
+    status = torch.zeros(2, dtype=torch.int32, device=g.device) if want_status else None
     wsb = lib.sgnn_bfs_min_hops_workspace_bytes(g.max_id, ns, max_hops, sets.n)
     ws = torch.empty(wsb // 8 + 1, dtype=torch.int64, device=g.device)
     check(lib.sgnn_bfs_min_hops_to_sets(_ptr(g.rowptr), _ptr(g.col), g.nnz, g.max_id, _ptr(sources), ns, max_hops,
-                                        _ptr(sets.ptr), _ptr(sets.nodes), sets.n, _ptr(out), _ptr(ws), wsb, _stream()),
-          'sgnn_bfs_min_hops_to_sets')
-    return out
+                                        _ptr(sets.ptr), _ptr(sets.nodes), sets.n, _ptr(out), _ptr(status), _ptr(ws), wsb,
+                                        _stream()), 'sgnn_bfs_min_hops_to_sets')
+    return (out, status) if want_status else out
 
 
 def min_hops_to_sets(dist, sets, node_major=False):

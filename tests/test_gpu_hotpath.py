@@ -130,3 +130,38 @@ def test_sharded_passes_reproduce_the_single_rank_pass(name, world, tmp_path):
         assert torch.equal(part.structure_anchors, full.structure_anchors)
         assert torch.equal(part.train_int_struc_similarities, full.train_int_struc_similarities[a:b])
         assert torch.equal(part.train_bor_struc_similarities, full.train_bor_struc_similarities[a:b])
+
+
+def test_bfs_level_hint_gives_the_same_similarities_and_a_short_hint_is_caught(tmp_path):
+    """The second pass enqueues (levels the first pass needed + margin) BFS levels instead of max_bfs_hops: same
+    similarities; a hint that is too small is reported at the next pass's entry and dropped."""
+    from conftest import load_golden
+    from subgnn_amd import hotpath
+    golden = load_golden('density')
+    (m, _) = _models(golden, tmp_path)
+    hotpath.prepare_sparse(m, 'train')
+    L = m.hparams['n_layers']
+    first = [m.train_neigh_pos_similarities[('P', 'out', l)].clone() for l in range(L)]
+    hint = dict(m._bfs_level_hint)
+    assert set(hint) == {('P_out', 'train', l) for l in range(L)} and all(1 <= v < 32 for v in hint.values())
+    hotpath.prepare_sparse(m, 'train')                                # hinted
+    assert len(m._bfs_pending) == L and all(enq == hint[key] + hotpath.BFS_LEVEL_MARGIN for key, _, enq, _ in m._bfs_pending)
+    for l in range(L):
+        assert torch.equal(m.train_neigh_pos_similarities[('P', 'out', l)], first[l])
+    hotpath.check_pending(m)
+    assert not m.__dict__.get('_bfs_pending')
+    # a hint that is too small: the search stops early, and the next entry says so
+    for key in hint:
+        m._bfs_level_hint[key] = 1 - hotpath.BFS_LEVEL_MARGIN         # enqueue exactly one level
+    hotpath.prepare_sparse(m, 'train')
+    with pytest.raises(RuntimeError, match='ran out of levels'):
+        hotpath.prepare_sparse(m, 'train')
+    assert not m._bfs_level_hint                                      # dropped: the next pass runs the full cap
+    hotpath.prepare_sparse(m, 'train')
+    for l in range(L):
+        assert torch.equal(m.train_neigh_pos_similarities[('P', 'out', l)], first[l])
+    # the cap itself is checked too
+    m._bfs_level_hint.clear()
+    m.hparams['max_bfs_hops'] = 1
+    with pytest.raises(RuntimeError, match='max_bfs_hops'):
+        hotpath.prepare_sparse(m, 'train')

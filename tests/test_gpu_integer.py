@@ -593,6 +593,17 @@ def test_bfs_hops_matches_apsp(golden, bfs_alpha):
     assert np.array_equal(ops.min_hops_to_sets(dist_t, sets, node_major=True).cpu().numpy(), ref)
     # fused form: BFS + min over members in one call, no hop table
     assert np.array_equal(ops.bfs_min_hops_to_sets(dg, torch.from_numpy(src).to(DEV), sets, max_hops=32).cpu().numpy(), ref)
+    # status: the last productive level == the largest finite hop count from these sources; enqueueing exactly that
+    # many levels is reported as possibly incomplete (the last level found something), one more is complete
+    _, st = ops.bfs_min_hops_to_sets(dg, torch.from_numpy(src).to(DEV), sets, max_hops=32, want_status=True)
+    depth = int(d[d != 255].max())
+    assert st.tolist() == [depth, 0]
+    w1, st1 = ops.bfs_min_hops_to_sets(dg, torch.from_numpy(src).to(DEV), sets, max_hops=depth, want_status=True)
+    assert st1.tolist() == [depth, 1] and np.array_equal(w1.cpu().numpy(), ref)
+    w2, st2 = ops.bfs_min_hops_to_sets(dg, torch.from_numpy(src).to(DEV), sets, max_hops=depth + 1, want_status=True)
+    assert st2.tolist() == [depth, 0] and np.array_equal(w2.cpu().numpy(), ref)
+    _, st3 = ops.bfs_min_hops_to_sets(dg, torch.from_numpy(src).to(DEV), sets, max_hops=depth - 1, want_status=True)
+    assert st3.tolist() == [depth - 1, 1]
 
 
 # ---- a11 DTW ------------------------------------------------------------------------------
