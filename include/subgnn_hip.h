@@ -39,7 +39,7 @@ extern "C" {
 #define SGNN_ERR_LAUNCH         -4   /* hipGetLastError() after a launch */
 #define SGNN_ERR_UNSUPPORTED_D  -5   /* embedding width not supported by the vector path */
 
-#define SGNN_ABI_VERSION 2
+#define SGNN_ABI_VERSION 3
 int sgnn_abi_version(void);
 /* last hip error string for SGNN_ERR_LAUNCH (static storage) */
 const char* sgnn_last_error(void);
@@ -442,7 +442,13 @@ int sgnn_masked_sum_bwd(const float* grad_out, const uint8_t* mask, int64_t B, i
  * read-out weight gradient as per-row partial sums (R, D) for the caller to add up.
  * ------------------------------------------------------------------------------------- */
 int64_t sgnn_scatter_add_rows_workspace_bytes(int64_t n_edges, int64_t D);
-int sgnn_scatter_add_rows_sorted(const int64_t* order, const int32_t* key_sorted, int64_t n_edges,
+/* The stable sort the scatter needs: key_sorted / order (int32, n_edges each) from keys in [0, max_key] -- a radix
+ * sort over the bits max_key has (rocPRIM), positions as the payload.  An order that does not change between
+ * passes (the component members of a split) can be computed once and kept. */
+int64_t sgnn_sort_edges_by_key_workspace_bytes(int64_t n_edges, int64_t max_key);
+int sgnn_sort_edges_by_key(const int32_t* keys, int64_t n_edges, int64_t max_key, int32_t* key_sorted, int32_t* order,
+                           void* workspace, int64_t workspace_bytes, void* stream);
+int sgnn_scatter_add_rows_sorted(const int32_t* order, const int32_t* key_sorted, int64_t n_edges,
                                  const int32_t* edge_row, int64_t edges_per_row,
                                  const float* G, int64_t D, const float* c1, const float* c2, const float* v,
                                  const int32_t* arg, float* table,

@@ -262,7 +262,11 @@ class SubGNN(nn.Module):
         ptr = torch.arange(S * C + 1, dtype=torch.int64, device=self.device) * L
         sets = ops.Ragged(ptr, ids.contiguous() if ids.numel() else torch.zeros(1, dtype=torch.int32, device=self.device),
                           max_len=L)
-        return ops.cc_embed(self._table(), sets, aggregator, padded_len=0, stride=L).view(S, C, -1)
+        # (hotpath.prepare_sparse attaches the members' sorted order to the split's cc_ids tensor: kept across passes)
+        pre = getattr(cc_id_list, '_sgnn_member_order', None)
+        if pre is not None and pre[0].numel() != ids.numel():
+            pre = None
+        return ops.cc_embed(self._table(), sets, aggregator, padded_len=0, stride=L, presorted=pre).view(S, C, -1)
 
     def initialize_channel_embeddings(self, cc_embeddings, trainable=False):
         if trainable:

@@ -85,6 +85,8 @@ SIGNATURES = {
     'sgnn_masked_sum_bwd': (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_i64, c_ptr, c_ptr]),
     'sgnn_probe_stream_copy': (c_int, [c_ptr, c_ptr, c_i64, c_int, c_ptr]),
     'sgnn_scatter_add_rows_workspace_bytes': (c_i64, [c_i64, c_i64]),
+    'sgnn_sort_edges_by_key_workspace_bytes': (c_i64, [c_i64, c_i64]),
+    'sgnn_sort_edges_by_key': (c_int, [c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_i64, c_ptr]),
     'sgnn_scatter_add_rows_sorted': (c_int, [c_ptr, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr,
                                              c_ptr, c_i64, c_ptr]),
     'sgnn_mpn_bwd_edges': (c_int, [ctypes.POINTER(MpnArgs), c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
@@ -117,7 +119,7 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the header and the library disagree
         fn.restype = res
         fn.argtypes = args
-    if lib.sgnn_abi_version() != 2:
+    if lib.sgnn_abi_version() != 3:
         raise SubgnnHipError('ABI version mismatch')
     _lib = lib
     return lib

@@ -18,12 +18,16 @@
 // Traffic: the sorted order (8 B per edge), the coefficient gathers, one source row per edge (L2 hits:
 // a source row is shared by all edges of its component) and one table row per DISTINCT target.
 #include "common.h"
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/iterator/counting_iterator.hpp>
 
 #define SC_RUN 64
+#define SC_AHEAD 8             // carry slots in flight per wavefront in the chain kernel
 #define SC_MAXC 4              // columns per lane: D <= 256
 
 struct ScArgs {
-    const int64_t* order;      // E: edge numbers, sorted by target key (stable) -- int64: what a library sort returns
+    const int32_t* order;      // E: edge numbers, sorted by target key (stable)
     const int32_t* key;        // E: key of order[p], ascending; key 0 (PAD) contributes nothing
     int64_t E;
     const int32_t* edge_row;   // nullable: source row of edge e; NULL: e / edges_per_row
@@ -40,6 +44,14 @@ struct ScArgs {
     float* carry_val;          // 2 per run x D
 };
 
+// AHEAD source rows are requested together, MAXC columns per lane.  For D <= 64: (64, 1) when the launch has fewer
+// wavefronts than the chip holds -- the whole run's rows are in registers before the first add and nothing in the
+// walk waits on memory (with fewer rows in flight the wait for the next group's rows also waits for the table adds
+// issued in between: the memory counter is in-order) -- and (8, 1) for large launches, where 8 resident wavefronts
+// per SIMD hide those waits better than 3 with 159 registers each (benchmark, 2.1 M border edges: 293 us with 64 rows
+// in flight, 218 with 8; what remains is the random 256-byte read-modify-write of ~0.9 M distinct table rows in HBM).
+// (16, 1) with the argmax ids, (16, 2) for D <= 128, (8, 4) up to 256.
+template <int AHEAD, int MAXC>
 __global__ __launch_bounds__(256) void scatter_runs_kernel(ScArgs a)
 {
     const int lane = threadIdx.x & 63;
@@ -60,12 +72,12 @@ __global__ __launch_bounds__(256) void scatter_runs_kernel(ScArgs a)
     }
     const int32_t prev_key = p0 > 0 ? a.key[p0 - 1] : -1;
     const int32_t next_key = p0 + cnt < a.E ? a.key[p0 + cnt] : -1;
-    float vv[SC_MAXC];
+    float vv[MAXC];
 #pragma unroll
-    for (int c = 0; c < SC_MAXC; ++c) vv[c] = (a.v && lane + 64 * c < D) ? a.v[lane + 64 * c] : 0.f;
-    float acc[SC_MAXC];
+    for (int c = 0; c < MAXC; ++c) vv[c] = (a.v && lane + 64 * c < D) ? a.v[lane + 64 * c] : 0.f;
+    float acc[MAXC];
 #pragma unroll
-    for (int c = 0; c < SC_MAXC; ++c) acc[c] = 0.f;
+    for (int c = 0; c < MAXC; ++c) acc[c] = 0.f;
     int32_t cur = __builtin_amdgcn_readlane(k_l, 0);
     // arg mode (max aggregator): a member listed twice in its set counts once, as the argmax records one id per
     // column -- the stable sort keeps the entries of one source row adjacent inside a segment, so "same row as
@@ -86,45 +98,69 @@ __global__ __launch_bounds__(256) void scatter_runs_kernel(ScArgs a)
             if (from_prev) {                                   // head carry (maybe running on)
                 head_flag = 1 | (into_next ? 2 : 0);
 #pragma unroll
-                for (int c = 0; c < SC_MAXC; ++c)
+                for (int c = 0; c < MAXC; ++c)
                     if (lane + 64 * c < D) a.carry_val[(2 * run) * D + lane + 64 * c] = acc[c];
                 if (lane == 0) a.carry_key[2 * run] = key;
             } else if (into_next) {                            // tail carry: starts a chain
                 tail_flag = 1;
 #pragma unroll
-                for (int c = 0; c < SC_MAXC; ++c)
+                for (int c = 0; c < MAXC; ++c)
                     if (lane + 64 * c < D) a.carry_val[(2 * run + 1) * D + lane + 64 * c] = acc[c];
                 if (lane == 0) a.carry_key[2 * run + 1] = key;
             } else {                                           // the segment is ours alone
+                // one writer per table row in this launch, so a returnless float add is as deterministic as a
+                // read-modify-write -- and the wavefront does not wait for the row to come back (a run of the
+                // benchmark's border edges ends ~30 segments: 30 dependent round trips before)
 #pragma unroll
-                for (int c = 0; c < SC_MAXC; ++c)
-                    if (lane + 64 * c < D) a.table[(int64_t)key * D + lane + 64 * c] += acc[c];
+                for (int c = 0; c < MAXC; ++c)
+                    if (lane + 64 * c < D) unsafeAtomicAdd(&a.table[(int64_t)key * D + lane + 64 * c], acc[c]);
             }
         }
         first_seg = false;
 #pragma unroll
-        for (int c = 0; c < SC_MAXC; ++c) acc[c] = 0.f;
+        for (int c = 0; c < MAXC; ++c) acc[c] = 0.f;
     };
 
-    for (int j = 0; j < cnt; ++j) {
-        const int32_t k = __builtin_amdgcn_readlane(k_l, j);
-        if (k != cur) { flush(cur, false); cur = k; last_row = -1; }
-        if (k == 0) continue;
-        const int64_t row = __builtin_amdgcn_readlane(row_l, j);
-        if (a.arg) { if (row == last_row) continue; last_row = row; }
-        const float c1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c1_l), j));
-        const float c2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c2_l), j));
+    // The run is walked AHEAD edges at a time: their source rows (one coalesced row read each, an L2 hit) are
+    // requested together, then added in order.  Reading them one by one made the run a chain of 64 dependent
+    // cache round trips per wavefront (0.27 ms for the benchmark's 2.1 M border edges).
+    for (int j0 = 0; j0 < cnt; j0 += AHEAD) {
+        float g[AHEAD][MAXC];
+        int32_t am[AHEAD][MAXC];
+        // (keys ascend: the PAD edges -- masked or zero-weight ones -- fill whole runs at the front; no rows are read for them)
+        if (a.G && __builtin_amdgcn_readlane(k_l, (j0 + AHEAD - 1) < cnt ? (j0 + AHEAD - 1) : cnt - 1) != 0) {
 #pragma unroll
-        for (int c = 0; c < SC_MAXC; ++c) {
-            const int64_t d = lane + 64 * c;
-            if (d < D) {
-                float val = c2 * vv[c];
-                if (a.G) {
-                    const float g = a.G[row * D + d];
-                    if (a.arg) { if (a.arg[row * D + d] == k) val += c1 * g; }
-                    else val += c1 * g;
+            for (int u = 0; u < AHEAD; ++u) {
+                const int64_t row = __builtin_amdgcn_readlane(row_l, (j0 + u) & 63);   // lanes past cnt hold row 0: a valid row
+#pragma unroll
+                for (int c = 0; c < MAXC; ++c) {
+                    const int64_t d = lane + 64 * c;
+                    g[u][c] = d < D ? a.G[row * D + d] : 0.f;
+                    am[u][c] = (a.arg && d < D) ? a.arg[row * D + d] : 0;
                 }
-                acc[c] += val;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < AHEAD; ++u) {
+            const int j = j0 + u;
+            if (j >= cnt) break;
+            const int32_t k = __builtin_amdgcn_readlane(k_l, j);
+            if (k != cur) { flush(cur, false); cur = k; last_row = -1; }
+            if (k == 0) continue;
+            const int64_t row = __builtin_amdgcn_readlane(row_l, j);
+            if (a.arg) { if (row == last_row) continue; last_row = row; }
+            const float c1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c1_l), j));
+            const float c2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c2_l), j));
+#pragma unroll
+            for (int c = 0; c < MAXC; ++c) {
+                if (lane + 64 * c < D) {
+                    float val = c2 * vv[c];
+                    if (a.G) {
+                        if (a.arg) { if (am[u][c] == k) val += c1 * g[u][c]; }
+                        else val += c1 * g[u][c];
+                    }
+                    acc[c] += val;
+                }
             }
         }
     }
@@ -143,13 +179,29 @@ __global__ __launch_bounds__(256) void scatter_chains_kernel(ScArgs a, int64_t n
     float acc[SC_MAXC];
 #pragma unroll
     for (int c = 0; c < SC_MAXC; ++c) acc[c] = lane + 64 * c < D ? a.carry_val[(2 * run + 1) * D + lane + 64 * c] : 0.f;
-    for (int64_t j = run + 1; j < n_runs; ++j) {
-        const int32_t f = a.carry_flag[2 * j];
-        if (!(f & 1)) break;                                   // (cannot happen: a tail implies a head next door)
+    // SC_AHEAD links at a time: flags and partials of the next runs are requested together and added in run order
+    // (a hub that sits in 15 k components spans ~230 runs: 460 dependent round trips one by one)
+    bool more = true;
+    for (int64_t j0 = run + 1; more && j0 < n_runs; j0 += SC_AHEAD) {
+        int32_t f[SC_AHEAD];
+        float val[SC_AHEAD][SC_MAXC];
 #pragma unroll
-        for (int c = 0; c < SC_MAXC; ++c)
-            if (lane + 64 * c < D) acc[c] += a.carry_val[(2 * j) * D + lane + 64 * c];
-        if (!(f & 2)) break;
+        for (int u = 0; u < SC_AHEAD; ++u) {
+            const int64_t j = j0 + u < n_runs ? j0 + u : n_runs - 1;
+            f[u] = a.carry_flag[2 * j];
+#pragma unroll
+            for (int c = 0; c < SC_MAXC; ++c) val[u][c] = lane + 64 * c < D ? a.carry_val[(2 * j) * D + lane + 64 * c] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < SC_AHEAD; ++u) {
+            if (more && j0 + u < n_runs && (f[u] & 1)) {       // (a tail implies a head next door)
+#pragma unroll
+                for (int c = 0; c < SC_MAXC; ++c) acc[c] += val[u][c];
+                if (!(f[u] & 2)) more = false;
+            } else {
+                more = false;
+            }
+        }
     }
 #pragma unroll
     for (int c = 0; c < SC_MAXC; ++c)
@@ -162,7 +214,43 @@ extern "C" int64_t sgnn_scatter_add_rows_workspace_bytes(int64_t n_edges, int64_
     return n_runs * 2 * (D * 4 + 8) + 64;
 }
 
-extern "C" int sgnn_scatter_add_rows_sorted(const int64_t* order, const int32_t* key_sorted, int64_t n_edges,
+// ---- stable sort of the edges by target key -------------------------------------------------------
+// rocPRIM's radix sort of (key, position) pairs over the bits the keys can have (20 for a million-node
+// table: 3 passes instead of the 4 a full 32-bit sort takes), positions as int32.
+static inline int sc_key_bits(int64_t max_key) { int b = 1; while (b < 31 && (1ll << b) <= max_key) ++b; return b; }
+
+static hipError_t sc_sort(void* temp, size_t& temp_bytes, const int32_t* keys, int32_t* keys_out, int32_t* order_out,
+                          int64_t n, int bits, hipStream_t st)
+{
+    return rocprim::radix_sort_pairs(temp, temp_bytes, reinterpret_cast<const uint32_t*>(keys), reinterpret_cast<uint32_t*>(keys_out),
+                                     rocprim::counting_iterator<int32_t>(0), order_out, (size_t)n, 0u, (unsigned)bits, st);
+}
+
+extern "C" int64_t sgnn_sort_edges_by_key_workspace_bytes(int64_t n_edges, int64_t max_key)
+{
+    if (n_edges <= 0) return 0;
+    size_t bytes = 0;
+    if (sc_sort(nullptr, bytes, nullptr, nullptr, nullptr, n_edges, sc_key_bits(max_key), nullptr) != hipSuccess) return -1;
+    return (int64_t)bytes + 256;
+}
+
+extern "C" int sgnn_sort_edges_by_key(const int32_t* keys, int64_t n_edges, int64_t max_key, int32_t* key_sorted,
+                                      int32_t* order, void* workspace, int64_t workspace_bytes, void* stream)
+{
+    if (n_edges < 0 || max_key < 0 || max_key >= (1ll << 31)) return SGNN_ERR_BAD_ARG;
+    if (n_edges == 0) return SGNN_OK;
+    if (!keys || !key_sorted || !order || !workspace) return SGNN_ERR_BAD_ARG;
+    if (n_edges >= (1ll << 31)) return SGNN_ERR_SET_TOO_LARGE;
+    const int bits = sc_key_bits(max_key);
+    size_t need = 0;
+    if (sc_sort(nullptr, need, nullptr, nullptr, nullptr, n_edges, bits, nullptr) != hipSuccess) return SGNN_ERR_LAUNCH;
+    if ((int64_t)need > workspace_bytes) return SGNN_ERR_BAD_ARG;
+    const hipError_t e = sc_sort(workspace, need, keys, key_sorted, order, n_edges, bits, (hipStream_t)stream);
+    if (e != hipSuccess) { sgnn_set_last_error(e); return SGNN_ERR_LAUNCH; }
+    return SGNN_OK;
+}
+
+extern "C" int sgnn_scatter_add_rows_sorted(const int32_t* order, const int32_t* key_sorted, int64_t n_edges,
                                             const int32_t* edge_row, int64_t edges_per_row,
                                             const float* G, int64_t D, const float* c1, const float* c2, const float* v,
                                             const int32_t* arg, float* table,
@@ -183,7 +271,11 @@ extern "C" int sgnn_scatter_add_rows_sorted(const int64_t* order, const int32_t*
     a.carry_flag = a.carry_key + n_runs * 2;
     hipStream_t st = (hipStream_t)stream;
     const unsigned grid = (unsigned)((n_runs + 3) / 4);
-    hipLaunchKernelGGL(scatter_runs_kernel, dim3(grid), dim3(256), 0, st, a);
+    if (D <= 64 && !arg && n_runs <= 8192) hipLaunchKernelGGL((scatter_runs_kernel<64, 1>), dim3(grid), dim3(256), 0, st, a);
+    else if (D <= 64 && !arg) hipLaunchKernelGGL((scatter_runs_kernel<8, 1>), dim3(grid), dim3(256), 0, st, a);
+    else if (D <= 64) hipLaunchKernelGGL((scatter_runs_kernel<16, 1>), dim3(grid), dim3(256), 0, st, a);   // (+ the argmax ids: 2 registers per row)
+    else if (D <= 128) hipLaunchKernelGGL((scatter_runs_kernel<16, 2>), dim3(grid), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((scatter_runs_kernel<8, 4>), dim3(grid), dim3(256), 0, st, a);
     SGNN_CHECK_LAUNCH();
     hipLaunchKernelGGL(scatter_chains_kernel, dim3(grid), dim3(256), 0, st, a, n_runs);
     SGNN_CHECK_LAUNCH();

@@ -173,6 +173,13 @@ def prepare_sparse(model, split='train', timer=None, shard=None):
                                                    dims_reduce=shard.reduce_max if shard is not None else None)
     setattr(model, split + '_cc_ids', cc_ids)
     S, C, Lc = cc_ids.shape
+    if ops.DETERMINISTIC:
+        # the component-embedding backward scatters per member id in sorted order: the members of a split's
+        # components are the same every pass, so their order is computed on the first pass and kept
+        mo = model.__dict__.setdefault('_cc_member_order', {})
+        if mo.get(split) is None or mo[split][0].numel() != cc_ids.numel():
+            mo[split] = ops.sort_edges_by_key(cc_ids.reshape(-1).to(torch.int32), g.max_id)
+        cc_ids._sgnn_member_order = mo[split]
     base = shard.start if shard is not None else 0             # global number of this rank's first subgraph
     cc_sets = ops.Ragged.from_padded(cc_ids.reshape(S * C, Lc))
     real = (cc_ids[:, :, 0] != 0)

@@ -665,10 +665,30 @@ def dtw_similarity(x_ptr, x_val, max_x, y_ptr, y_val, max_y, tie_order=0, order_
 DETERMINISTIC = True       # table gradients by sorted segmented sums (bit-reproducible); False: float atomics
 
 
-def scatter_add_rows(table, keys, G=None, edge_row=None, edges_per_row=1, c1=None, c2=None, v=None, arg=None):
+def sort_edges_by_key(keys, max_key):
+    """Stable sort of edge numbers by int32 target key in [0, max_key] (sgnn_sort_edges_by_key: radix sort over the
+    bits max_key has) -> (key_sorted, order), int32 each.  What scatter_add_rows consumes; an order that does not
+    change between passes can be computed once and handed to it as ``presorted``."""
+    lib = _lib.load()
+    _req(keys, torch.int32, 'keys')
+    E = keys.numel()
+    sk, order = torch.empty_like(keys), torch.empty_like(keys)
+    if E:
+        wsb = lib.sgnn_sort_edges_by_key_workspace_bytes(E, int(max_key))
+        if wsb < 0:
+            raise RuntimeError('sgnn_sort_edges_by_key_workspace_bytes failed')
+        ws = torch.empty(wsb // 8 + 1, dtype=torch.int64, device=keys.device)
+        check(lib.sgnn_sort_edges_by_key(_ptr(keys), E, int(max_key), _ptr(sk), _ptr(order), _ptr(ws), wsb, _stream()),
+              'sgnn_sort_edges_by_key')
+    return sk, order
+
+
+def scatter_add_rows(table, keys, G=None, edge_row=None, edges_per_row=1, c1=None, c2=None, v=None, arg=None,
+                     presorted=None):
     """table[keys[e], :] += c1[e] * G[row(e), :] + c2[e] * v   without atomics (sgnn_scatter_add_rows_sorted):
     the edges are sorted stably by target row and every row is summed by one owner in that order, so the
-    result is bit-reproducible.  keys int32 (E), 0 = no contribution; row(e) = edge_row[e] or e // edges_per_row."""
+    result is bit-reproducible.  keys int32 (E), 0 = no contribution; row(e) = edge_row[e] or e // edges_per_row.
+    presorted: sort_edges_by_key(keys, ...) of these very keys, when the caller keeps it."""
     lib = _lib.load()
     E = keys.numel()
     if E == 0:
@@ -680,7 +700,9 @@ def scatter_add_rows(table, keys, G=None, edge_row=None, edges_per_row=1, c1=Non
     _req(edge_row, torch.int32, 'edge_row')
     _req(arg, torch.int32, 'arg')
     D = table.shape[1]
-    sk, order = torch.sort(keys, stable=True)                 # int64 positions: taken as they are
+    sk, order = presorted if presorted is not None else sort_edges_by_key(keys.reshape(-1), table.shape[0] - 1)
+    if sk.numel() != E or order.numel() != E:
+        raise ValueError('presorted order does not belong to these keys')
     wsb = lib.sgnn_scatter_add_rows_workspace_bytes(E, D)
     ws = torch.empty(wsb // 4 + 1, dtype=torch.int32, device=table.device)
     check(lib.sgnn_scatter_add_rows_sorted(_ptr(order), _ptr(sk), E, _ptr(edge_row), int(edges_per_row), _ptr(G), D, _ptr(c1),
@@ -745,8 +767,9 @@ def tap_table(E, half=None):
 
 class _CCEmbed(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, E, ptr, nodes, aggregator, padded_len, stride):
+    def forward(ctx, E, ptr, nodes, aggregator, padded_len, stride, presorted):
         ctx.acc = getattr(E, '_sgnn_acc', None)
+        ctx.presorted = presorted
         half = getattr(E, '_sgnn_half', None)
         lib = _lib.load()
         _req(E, torch.float32, 'E')
@@ -768,7 +791,7 @@ class _CCEmbed(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         if not ctx.needs_input_grad[0]:
-            return None, None, None, None, None, None
+            return None, None, None, None, None, None, None
         lib = _lib.load()
         ptr, nodes, arg = ctx.saved_tensors
         g = g.contiguous()
@@ -781,7 +804,7 @@ class _CCEmbed(torch.autograd.Function):
             E = nodes.numel()
             am = arg if ctx.aggregator == 1 else None
             if ctx.stride > 0:                         # fixed-stride sets: row = entry // stride
-                scatter_add_rows(gE, nodes, G=g, edges_per_row=ctx.stride, arg=am)
+                scatter_add_rows(gE, nodes, G=g, edges_per_row=ctx.stride, arg=am, presorted=ctx.presorted)
             else:                                      # ragged (the node array may be an arena longer than ptr[-1])
                 pos = torch.arange(E, device=g.device)
                 rows = (torch.searchsorted(ptr, pos, right=True) - 1).clamp_(min=0, max=max(n - 1, 0)).to(torch.int32)
@@ -790,13 +813,16 @@ class _CCEmbed(torch.autograd.Function):
         else:
             check(lib.sgnn_cc_embed_bwd(_ptr(g), ctx.shape[1], _ptr(ptr), _ptr(nodes), ptr.numel() - 1, ctx.aggregator,
                                         _ptr(arg), _ptr(gE), _stream()), 'sgnn_cc_embed_bwd')
-        return (None if ctx.acc is not None else gE), None, None, None, None, None
+        return (None if ctx.acc is not None else gE), None, None, None, None, None, None
 
 
-def cc_embed(E, sets, aggregator='sum', padded_len=0, stride=0):
+def cc_embed(E, sets, aggregator='sum', padded_len=0, stride=0, presorted=None):
     """initialize_cc_embeddings on ragged components -> (n_sets, D).  ``stride`` > 0: the caller promises
-    fixed-stride sets (ptr[i] = i * stride, PAD entries included) -- spares the backward a search."""
-    return _CCEmbed.apply(E, sets.ptr, sets.nodes, 0 if aggregator == 'sum' else 1, int(padded_len), int(stride))
+    fixed-stride sets (ptr[i] = i * stride, PAD entries included) -- spares the backward a search.
+    ``presorted`` (with stride): sort_edges_by_key(sets.nodes, ...) kept by the caller -- the members of a split's
+    components do not change between passes, so the backward's sort need not be repeated."""
+    return _CCEmbed.apply(E, sets.ptr, sets.nodes, 0 if aggregator == 'sum' else 1, int(padded_len), int(stride),
+                          presorted if stride > 0 else None)
 
 
 SRC_DENSE, SRC_GATHER, SRC_SHARED = 0, 1, 2

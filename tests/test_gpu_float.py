@@ -428,6 +428,33 @@ def test_scatter_add_rows_sorted_matches_index_add_and_is_reproducible(D):
     assert_close(table, want2.float(), 'scatter (rows)', 1e-5)
 
 
+@pytest.mark.parametrize('n,max_key', [(1, 5), (63, 1), (1000, 999), (300_000, 1_000_000), (70_000, (1 << 31) - 1)])
+def test_sort_edges_by_key_is_a_stable_sort(n, max_key):
+    from subgnn_amd import ops
+    g = torch.Generator().manual_seed(n)
+    keys = torch.randint(0, min(max_key, 5000) + 1, (n,), generator=g).to(torch.int32)
+    keys[torch.rand(n, generator=g) < 0.05] = max_key                       # the top of the range (all key bits in use)
+    sk, order = ops.sort_edges_by_key(keys.to(DEV), max_key)
+    want_k, want_o = torch.sort(keys, stable=True)
+    assert sk.dtype == torch.int32 and order.dtype == torch.int32
+    assert torch.equal(sk.cpu(), want_k) and torch.equal(order.cpu().long(), want_o)
+
+
+def test_scatter_add_rows_takes_a_kept_order():
+    from subgnn_amd import ops
+    g = torch.Generator().manual_seed(5)
+    n_rows, R, A, D = 4000, 500, 9, 64
+    keys = torch.randint(0, n_rows, (R * A,), generator=g).to(torch.int32).to(DEV)
+    G = torch.randn(R, D, generator=g).to(DEV)
+    a, b = torch.zeros(n_rows, D, device=DEV), torch.zeros(n_rows, D, device=DEV)
+    ops.scatter_add_rows(a, keys, G=G, edges_per_row=A)
+    pre = ops.sort_edges_by_key(keys, n_rows - 1)
+    ops.scatter_add_rows(b, keys, G=G, edges_per_row=A, presorted=pre)
+    assert torch.equal(a, b)
+    with pytest.raises(ValueError):
+        ops.scatter_add_rows(b, keys[:-1].contiguous(), G=G, edges_per_row=A, presorted=pre)
+
+
 def test_table_gradient_is_bit_reproducible():
     """The embedding-table gradient of the fused ops (component embeddings sum / max, a GATHER message-passing
     layer with duplicated anchors, gather_rows) is the same bits on every run -- and equal to the atomics
