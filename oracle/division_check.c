@@ -4,6 +4,8 @@
  * gamma.calc_dist (SubGNN/gamma.py:51-52) -- over the operands that kernel can meet: value + 1 for
  * degrees and their pairwise averages (dyadic rationals).
  *   q0 = RN(mx * r); rem = fma(-q0, mn, mx); q = fma(rem, r, q0)   with r = RN(1 / mn)
+ * The kernel forms BOTH quotients this way, a / b and b / a, and takes the larger: checked as well -- the larger one
+ * must be the IEEE quotient max / min (the smaller only has to stay <= 1).
  * usage: division_check <max_int> <n_random>     prints "bad <count>" */
 #include <math.h>
 #include <stdint.h>
@@ -24,8 +26,11 @@ int main(int argc, char** argv)
     long bad = 0, n = 0;
     for (int b = 1; b <= max_int; ++b) {
         const double db = b, r = 1.0 / db;
-        for (int a = b; a <= max_int; ++a, ++n)
-            if (rcp_div((double)a, db, r) != (double)a / db) ++bad;
+        for (int a = b; a <= max_int; ++a, ++n) {
+            const double da = a;
+            if (rcp_div(da, db, r) != da / db) ++bad;
+            if (fmax(rcp_div(da, db, r), rcp_div(db, da, 1.0 / da)) != da / db) ++bad;
+        }
     }
     uint64_t s = 88172645463325252ull;
     for (long i = 0; i < n_random; ++i, ++n) {
@@ -35,6 +40,7 @@ int main(int argc, char** argv)
         double a = (double)(x + 1) / (double)(1 << L), b = (double)(y + 1) / (double)(1 << L);
         if (a < b) { const double t = a; a = b; b = t; }
         if (rcp_div(a, b, 1.0 / b) != a / b) ++bad;
+        if (fmax(rcp_div(a, b, 1.0 / b), rcp_div(b, a, 1.0 / a)) != a / b) ++bad;
     }
     printf("checked %ld\nbad %ld\n", n, bad);
     return bad != 0;

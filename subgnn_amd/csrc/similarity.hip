@@ -688,11 +688,22 @@ __device__ static inline double dtw_cost(double a, double b) {            // gam
 // dyadic rational here).  tests/test_oracle_integer.py::test_reciprocal_division_is_exact runs the
 // identity exhaustively over the integer range and on 10^7 random dyadic pairs on the CPU.
 __device__ __forceinline__ double dtw_cost_rcp(double a1, double ra, double b1, double rb) {
-    // v_max_f64 / v_min_f64 instead of compare + two selects each (the operands are never NaN)
-    const double mx = fmax(a1, b1), mn = fmin(a1, b1), r = a1 > b1 ? rb : ra;
-    const double q0 = __dmul_rn(mx, r);
-    const double rem = __fma_rn(-q0, mn, mx);
-    return __dadd_rn(__fma_rn(rem, r, q0), -1.0);
+    // Both quotients, the larger one is max / min: rounding is monotone, so RN(a1 / b1) >= 1 >= RN(b1 / a1) when
+    // a1 >= b1 -- the division step only has to be exact for the quotient that is >= 1 (the direction the CPU test
+    // covers); the other one only has to stay <= 1, and b1 / a1 <= 1 - 2^-24 for these operands.  7 instructions
+    // instead of compare + two 64-bit selects + max + min + the division step.
+    const double qa0 = __dmul_rn(a1, rb), qb0 = __dmul_rn(b1, ra);
+    const double qa = __fma_rn(__fma_rn(-qa0, b1, a1), rb, qa0);
+    const double qb = __fma_rn(__fma_rn(-qb0, a1, b1), ra, qb0);
+    return __dadd_rn(fmax(qa, qb), -1.0);
+}
+
+// A cost for a cell outside the lane's window: only the HIGH word is replaced (one v_cndmask instead of the two a
+// 64-bit select of INF takes), giving a finite value >= 2^1023 whatever the low word holds.  Such a cell then carries
+// min(...) + BIG = BIG or INF: it loses every later comparison against a reachable cell, exactly like INF (no product
+// or difference is ever taken of these values, so no NaN can arise).
+__device__ __forceinline__ double dtw_mask_cost(bool in, double dt) {
+    return __hiloint2double(in ? __double2hiint(dt) : 0x7fe00000, __double2loint(dt));
 }
 
 __global__ __launch_bounds__(DTW_THREADS) void dtw_similarity_kernel(
@@ -962,7 +973,7 @@ __device__ __forceinline__ double dtw_reg_level(
                     // window test: no per-row branch (a branch stalls the wavefront's issue; the block
                     // test above already removed most out-of-window rows)
                     const bool in = j >= lo && j <= hi;
-                    const double dt = dtw_cost_rcp(xp1[i], xr[i], yp1, yr);
+                    const double dt = dtw_mask_cost(in, dtw_cost_rcp(xp1[i], xr[i], yp1, yr));
                     double mv, c_up = 0.0, c_left = 0.0, c_diag = 0.0;
                     if (FINEST) {
                         // only the value is needed: rounding is monotone, so the smallest of the three rounded
@@ -972,7 +983,7 @@ __device__ __forceinline__ double dtw_reg_level(
                         c_up = up + dt; c_left = old + dt; c_diag = diag + dt;
                         mv = fmin(fmin(c_up, c_left), c_diag);               // two v_min_f64 (no NaNs here)
                     }
-                    const double nv = in ? mv : INF;
+                    const double nv = mv;                                    // (outside the window: >= 2^1023, see dtw_mask_cost)
                     if (!FINEST) {
                         // predecessor = the first candidate, in the tie order, that attains the minimum
                         int best;

@@ -440,6 +440,29 @@ def test_sort_edges_by_key_is_a_stable_sort(n, max_key):
     assert torch.equal(sk.cpu(), want_k) and torch.equal(order.cpu().long(), want_o)
 
 
+def test_scatter_add_rows_large_launch_form():
+    """More than 8192 runs of 64 edges: the D <= 64 launch keeps 8 source rows in flight instead of the whole run."""
+    from subgnn_amd import ops
+    g = torch.Generator().manual_seed(11)
+    n_rows, R, A, D = 20000, 46000, 13, 64
+    E = R * A
+    keys = torch.randint(0, n_rows, (E,), generator=g)
+    keys[torch.rand(E, generator=g) < 0.2] = 0
+    keys[torch.rand(E, generator=g) < 0.05] = 9                      # a hub: a chain over ~470 runs
+    G, c1 = torch.randn(R, D, generator=g), torch.randn(E, generator=g)
+    want = torch.zeros(n_rows, D, dtype=torch.float64)
+    contrib = c1.double().unsqueeze(1) * G.double()[torch.arange(E) // A]
+    contrib[keys == 0] = 0
+    want.index_add_(0, keys, contrib)
+    outs = []
+    for _ in range(2):
+        table = torch.zeros(n_rows, D, device=DEV)
+        ops.scatter_add_rows(table, keys.to(torch.int32).to(DEV), G=G.to(DEV), edges_per_row=A, c1=c1.to(DEV))
+        outs.append(table)
+    assert torch.equal(outs[0], outs[1])
+    assert_close(outs[0], want.float(), 'scatter (large)', 1e-5)
+
+
 def test_scatter_add_rows_takes_a_kept_order():
     from subgnn_amd import ops
     g = torch.Generator().manual_seed(5)
