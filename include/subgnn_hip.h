@@ -458,6 +458,22 @@ int sgnn_mpn_bwd_edges(const struct sgnn_mpn_args* args, const float* grad_z, in
 int sgnn_mpn_bwd_wp_partial(const struct sgnn_mpn_args* args, const float* grad_z, float* partial, void* stream);
 
 /* ---------------------------------------------------------------------------------------
+ * a12  update(): out = relu([x | aggr] W^T + b) and its backward (SubGNN/subgraph_mpn.py:233-241 with the
+ * nn.Linear(2 D, D) of subgraph_mpn.py:33), one row per component.  x, aggr, out, grad_*: (R, D) float32 row-major;
+ * W (D, 2 D); b (D), nullable in the forward.  D in {32, 64, 128} (else SGNN_ERR_UNSUPPORTED_D: the caller keeps
+ * the library-GEMM form).  fp32 operands and accumulation (v_mfma_f32_32x32x2_f32).
+ * Backward: dpre = grad_out * (out > 0); [grad_x | grad_aggr] = dpre W (either may be NULL: not computed);
+ * grad_W = dpre^T [x | aggr], grad_b = column sums of dpre (either may be NULL) -- contracted over row blocks whose
+ * partial sums (workspace) are added in block order: bit-reproducible.
+ * ------------------------------------------------------------------------------------- */
+int sgnn_update_fwd(const float* x, const float* aggr, const float* W, const float* b, int64_t R, int64_t D,
+                    float* out, void* stream);
+int64_t sgnn_update_bwd_workspace_bytes(int64_t R, int64_t D);
+int sgnn_update_bwd(const float* grad_out, const float* out, const float* x, const float* aggr, const float* W,
+                    int64_t R, int64_t D, float* grad_x, float* grad_aggr, float* grad_W, float* grad_b,
+                    void* workspace, int64_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------
  * Measurement aid (no reference counterpart): streaming copy of n_bytes with 4 or 16 bytes per lane.
  * The rocprofv3 memory-side counters (FETCH_SIZE / WRITE_SIZE) are calibrated on it -- a known byte
  * count in the access width of the CSR gather -- before they are read as HBM traffic of

@@ -549,7 +549,7 @@ class SubGNN(nn.Module):
         return mpn_fn(self.networkx_graph, sims, cc_ids, cc_embeds, cc_embed_mask, ap, ae, am, idx)
 
     def _run_mpn_layer_fused(self, dataset_type, mpn_fn, sidx, cc_embeds, cc_embed_mask, sims, layer_num, channel,
-                             inside):
+                             inside, need_out=True):
         """Same layer without the (B,C,A,D) tensor: anchors are gathered inside the kernel."""
         B, C, _ = cc_embeds.shape
         E = self._table()
@@ -563,21 +563,21 @@ class SubGNN(nn.Module):
             src = self.anchors_neigh_int if inside else self.anchors_neigh_border
             ids = src[dataset_type][layer_num].index_select(0, sidx).reshape(B * C, -1).contiguous()
             return mpn_fn.forward_fused(sims, cc_embeds, cc_embed_mask, src=ops.SRC_GATHER, x=E, ids=ids,
-                                        sims_per_edge=per_edge)
+                                        sims_per_edge=per_edge, need_out=need_out)
         if channel == 'position':
             if inside:
                 ids = self.anchors_pos_int[dataset_type][layer_num].index_select(0, sidx).contiguous()
                 return mpn_fn.forward_fused(sims, cc_embeds, cc_embed_mask, src=ops.SRC_GATHER, x=E, ids=ids, id_div=C,
-                                            sims_per_edge=per_edge)
+                                            sims_per_edge=per_edge, need_out=need_out)
             ids = self.anchors_pos_ext[layer_num]
             X = ops.gather_rows(E, ids)
             return mpn_fn.forward_fused(sims, cc_embeds, cc_embed_mask, src=ops.SRC_SHARED, x=X, ids=ids,
-                                        sims_per_edge=per_edge)
+                                        sims_per_edge=per_edge, need_out=need_out)
         patches, indices, int_rw, bor_rw = self.anchors_structure[layer_num]
         X = aps.aggregate_structure_anchor_patch(self.hparams, self.networkx_graph, self.lstm, self.node_embeddings,
                                                  patches, int_rw if inside else bor_rw, inside, self.device, table=E)
         return mpn_fn.forward_fused(sims, cc_embeds, cc_embed_mask, src=ops.SRC_SHARED, x=X,
-                                    sim_col=self._sim_col_cache[layer_num])
+                                    sim_col=self._sim_col_cache[layer_num], need_out=need_out)
 
     def forward(self, dataset_type, N_I_cc_embed, N_B_cc_embed, S_I_cc_embed, S_B_cc_embed, P_I_cc_embed,
                 P_B_cc_embed, subgraph_ids, cc_ids, subgraph_idx, NP_sim, I_S_sim, B_S_sim):
@@ -612,21 +612,23 @@ class SubGNN(nn.Module):
                     continue
                 layer = getattr(self, attr)[l]
                 res = {}
+                pick = 0 if tag == 'N' else 1                      # N adds CC embeddings, P/S their read-outs
+                # the updated component embeddings of a P / S layer only feed the next layer: not computed for the last
+                need_out = pick == 0 or l + 1 < hp['n_layers']
                 for inside, side, name, bnname in ((True, 'I', 'internal', 'batch_norm'), (False, 'B', 'border', 'batch_norm_out')):
                     sims = NP_sim if tag != 'S' else (I_S_sim if inside else B_S_sim)
                     slot = tag + '_' + side
                     if fused:
                         o, p = self._run_mpn_layer_fused(dataset_type, layer[name], sidx, state[slot], cc_embed_mask,
-                                                         sims, l, channel, inside)
+                                                         sims, l, channel, inside, need_out=need_out)
                     else:
                         o, p = self.run_mpn_layer(dataset_type, layer[name], subgraph_ids, subgraph_idx, cc_ids,
                                                   state[slot], cc_embed_mask, sims, layer_num=l, channel=channel,
                                                   inside=inside)
-                    if bn:
+                    if bn and o is not None:
                         o = layer[bnname](o.reshape(B * C, -1)).view(B, C, -1)
                     state[slot] = o
                     res[side] = (o, p)
-                pick = 0 if tag == 'N' else 1                      # N adds CC embeddings, P/S their read-outs
                 outputs.extend([res['I'][pick], res['B'][pick]])
         all_cc_embeds = torch.cat([init_cc_embeds] + outputs, dim=-1)
         self._last_cc_embeds = all_cc_embeds.detach().reshape(B * C, -1)

@@ -85,6 +85,9 @@ SIGNATURES = {
     'sgnn_masked_sum_bwd': (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_i64, c_ptr, c_ptr]),
     'sgnn_probe_stream_copy': (c_int, [c_ptr, c_ptr, c_i64, c_int, c_ptr]),
     'sgnn_scatter_add_rows_workspace_bytes': (c_i64, [c_i64, c_i64]),
+    'sgnn_update_fwd': (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr]),
+    'sgnn_update_bwd_workspace_bytes': (c_i64, [c_i64, c_i64]),
+    'sgnn_update_bwd': (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr]),
     'sgnn_sort_edges_by_key_workspace_bytes': (c_i64, [c_i64, c_i64]),
     'sgnn_sort_edges_by_key': (c_int, [c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_i64, c_ptr]),
     'sgnn_scatter_add_rows_sorted': (c_int, [c_ptr, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr,

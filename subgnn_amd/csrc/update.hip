@@ -1,0 +1,272 @@
+// a12 update():  out = relu([x | aggr] W^T + b)   (reference SubGNN/subgraph_mpn.py:233-241, nn.Linear(2D, D) of
+// subgraph_mpn.py:33) and its backward, for one row per component: x = the component embeddings (R, D), aggr = the
+// aggregated messages (R, D), W (D, 2D) row-major, b (D).
+//
+// As torch ops the layer was cat (R x 2D written and read back) + a library GEMM whose 64-column output runs far from
+// the chip's width + relu, and five more launches per direction in the backward: 47 us forward, 215 us forward +
+// backward per layer at R = 50k, D = 64, six layers per pass (fused: 20 us and 96 us).  Here:
+//   forward   one wavefront per 32 rows.  v_mfma_f32_32x32x2_f32 takes A as (row = lane % 32, k = lane / 32): the lane
+//             with k-half 0 holds its row of x, the lane with k-half 1 the same row of aggr -- the contraction index
+//             is simply walked as (half, position), the same permutation on the W side -- so every lane reads ONE
+//             contiguous row of D floats straight into registers, no concatenation, no LDS staging.  Bias and relu are
+//             applied to the accumulator fragment.
+//   backward  dpre = grad_out * (out > 0) is formed on the fly in both kernels:
+//             dx kernel   [grad_x | grad_aggr] = dpre W, one wavefront per 32 rows, contraction over the D outputs;
+//             dw kernel   grad_W = dpre^T [x | aggr] and grad_b = column sums of dpre, contracted over the rows: one
+//                         workgroup of four wavefronts per (block of UPD_ROWS rows, 32 output features), partial sums per block written
+//                         to the workspace and added up in block order by a small second kernel -- a fixed order, so
+//                         the gradients are bit-reproducible.
+// HBM / cache traffic per layer: forward reads 2 R D and writes R D floats; backward reads 4 R D (+ the row blocks'
+// second read in the dw kernel) and writes 2 R D.  All MFMA operands are fp32, accumulation fp32.
+#include "common.h"
+
+typedef float upd_f32x16 __attribute__((ext_vector_type(16)));
+
+#define UPD_WAVE_ROWS 64        // rows one wavefront contracts in the weight-gradient kernel (128 / 64 / 32: 54 / 37 / 45 us at R = 50k, D = 64)
+#define UPD_ROWS (4 * UPD_WAVE_ROWS)   // rows per partial sum (a workgroup of four wavefronts)
+#define UPD_STEPS 8             // contraction steps of the weight gradient whose operands are in flight together
+#define UPD_KC 64               // contraction positions held in registers at a time (per k-half)
+
+// accumulator element v of lane l: row 8 * (v / 4) + 4 * (l / 32) + v % 4, column l % 32
+__device__ __forceinline__ int upd_acc_row(int v, int h) { return 8 * (v >> 2) + 4 * h + (v & 3); }
+
+template <int D>
+__global__ __launch_bounds__(64) void update_fwd_kernel(const float* __restrict__ x, const float* __restrict__ aggr,
+                                                        const float* __restrict__ W, const float* __restrict__ b,
+                                                        int64_t R, float* __restrict__ out)
+{
+    constexpr int KC = D < UPD_KC ? D : UPD_KC;
+    const int lane = threadIdx.x, i = lane & 31, h = lane >> 5;
+    const int64_t row0 = (int64_t)blockIdx.x * 32;
+    const int64_t row = row0 + i < R ? row0 + i : R - 1;                 // (rows past the end: loaded, never stored)
+    const float* __restrict__ src = (h ? aggr : x) + row * D;
+    float a[KC];
+    if (D <= UPD_KC) {
+#pragma unroll
+        for (int c = 0; c < KC / 4; ++c) {
+            const float4 v = reinterpret_cast<const float4*>(src)[c];
+            a[4 * c] = v.x; a[4 * c + 1] = v.y; a[4 * c + 2] = v.z; a[4 * c + 3] = v.w;
+        }
+    }
+    for (int nt = 0; nt < D / 32; ++nt) {
+        upd_f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        const float* __restrict__ wrow = W + (int64_t)(nt * 32 + i) * (2 * D) + h * D;
+#pragma unroll 1
+        for (int kc = 0; kc < D; kc += KC) {
+            float w[KC];
+#pragma unroll
+            for (int c = 0; c < KC / 4; ++c) {
+                const float4 v = reinterpret_cast<const float4*>(wrow + kc)[c];
+                w[4 * c] = v.x; w[4 * c + 1] = v.y; w[4 * c + 2] = v.z; w[4 * c + 3] = v.w;
+            }
+            if (D > UPD_KC) {
+#pragma unroll
+                for (int c = 0; c < KC / 4; ++c) {
+                    const float4 v = reinterpret_cast<const float4*>(src + kc)[c];
+                    a[4 * c] = v.x; a[4 * c + 1] = v.y; a[4 * c + 2] = v.z; a[4 * c + 3] = v.w;
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < KC; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], w[s], acc, 0, 0, 0);
+        }
+        const int col = nt * 32 + i;
+        const float bias = b ? b[col] : 0.f;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const int64_t r = row0 + upd_acc_row(v, h);
+            if (r < R) out[r * D + col] = fmaxf(acc[v] + bias, 0.f);
+        }
+    }
+}
+
+// [grad_x | grad_aggr](r, c) = sum_n dpre(r, n) W(n, c): contraction index n walked as (half, position)
+template <int D>
+__global__ __launch_bounds__(64) void update_bwd_dx_kernel(const float* __restrict__ g, const float* __restrict__ out,
+                                                           const float* __restrict__ W, int64_t R,
+                                                           float* __restrict__ gx, float* __restrict__ gaggr)
+{
+    constexpr int H = D / 2;                                             // contraction positions per k-half
+    const int lane = threadIdx.x, i = lane & 31, h = lane >> 5;
+    const int64_t row0 = (int64_t)blockIdx.x * 32;
+    const int64_t row = row0 + i < R ? row0 + i : R - 1;
+    float a[H];
+#pragma unroll
+    for (int c = 0; c < H / 4; ++c) {
+        const float4 gv = reinterpret_cast<const float4*>(g + row * D + h * H)[c];
+        const float4 ov = reinterpret_cast<const float4*>(out + row * D + h * H)[c];
+        a[4 * c] = ov.x > 0.f ? gv.x : 0.f; a[4 * c + 1] = ov.y > 0.f ? gv.y : 0.f;
+        a[4 * c + 2] = ov.z > 0.f ? gv.z : 0.f; a[4 * c + 3] = ov.w > 0.f ? gv.w : 0.f;
+    }
+    for (int ct = 0; ct < 2 * D / 32; ++ct) {
+        float* __restrict__ dst = ct * 32 < D ? gx : gaggr;
+        if (!dst) continue;
+        upd_f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        const float* __restrict__ wcol = W + (int64_t)(h * H) * (2 * D) + ct * 32 + i;     // W(h * H + s, ct * 32 + i)
+#pragma unroll
+        for (int s = 0; s < H; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], wcol[(int64_t)s * (2 * D)], acc, 0, 0, 0);
+        const int col = (ct * 32) % D + i;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const int64_t r = row0 + upd_acc_row(v, h);
+            if (r < R) dst[r * D + col] = acc[v];
+        }
+    }
+}
+
+// partial grad_W(n, c) = sum over the block's rows of dpre(r, n) [x | aggr](r, c); partial grad_b(n) = sum dpre(r, n).
+// blockIdx.x = row block, blockIdx.y = tile of 32 output features n.  The rows are the contraction: step s covers
+// rows r0 + 2 s + (lane / 32).
+template <int D>
+__global__ __launch_bounds__(256) void update_bwd_dw_kernel(const float* __restrict__ g, const float* __restrict__ out,
+                                                           const float* __restrict__ x, const float* __restrict__ aggr,
+                                                           int64_t R, float* __restrict__ pW, float* __restrict__ pb)
+{
+    constexpr int CT = 2 * D / 32;                                       // column tiles of [x | aggr]
+    __shared__ float s_acc[(CT * 16 + 1) * 64];
+    const int lane = threadIdx.x & 63, i = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t r0 = (int64_t)blockIdx.x * UPD_ROWS + (int64_t)wave * UPD_WAVE_ROWS;
+    const int nt = blockIdx.y;
+    upd_f32x16 acc[CT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc[c][v] = 0.f;
+    float bsum = 0.f;
+    const int64_t r_end = r0 + UPD_WAVE_ROWS < R ? r0 + UPD_WAVE_ROWS : R;
+    // UPD_STEPS contraction steps (2 rows each) at a time: all their operands are requested together, then the MFMAs
+    // run back to back -- one step at a time the wavefront waited a memory round trip per step (154 us at R = 50k)
+    for (int64_t rb = r0; rb < r_end; rb += 2 * UPD_STEPS) {
+        float av[UPD_STEPS], bv[UPD_STEPS][CT];
+#pragma unroll
+        for (int u = 0; u < UPD_STEPS; ++u) {
+            const int64_t r = rb + 2 * u + h;
+            const bool live = r < r_end;
+            const int64_t rr = live ? r : (r_end > 0 ? r_end - 1 : 0);
+            const float ov = out[rr * D + nt * 32 + i];
+            const float gv = g[rr * D + nt * 32 + i];
+            av[u] = (live && ov > 0.f) ? gv : 0.f;
+#pragma unroll
+            for (int c = 0; c < CT; ++c) {
+                const float* __restrict__ src = c * 32 < D ? x : aggr;
+                bv[u][c] = src[rr * D + (c * 32) % D + i];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UPD_STEPS; ++u) {
+            bsum += av[u];
+#pragma unroll
+            for (int c = 0; c < CT; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u][c], acc[c], 0, 0, 0);
+        }
+    }
+    bsum += __shfl_xor(bsum, 32, 64);                                    // the two row halves
+    // the four wavefronts' sums are added in wavefront order through LDS; the last one holds the workgroup's partial
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int c = 0; c < CT; ++c)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    const int idx = (c * 16 + v) * 64 + lane;
+                    if (w > 0) acc[c][v] += s_acc[idx];
+                    if (w < 3) s_acc[idx] = acc[c][v];
+                }
+            if (w > 0) bsum += s_acc[CT * 16 * 64 + lane];
+            if (w < 3) s_acc[CT * 16 * 64 + lane] = bsum;
+        }
+        __syncthreads();
+    }
+    if (wave != 3) return;
+    float* __restrict__ dst = pW + (int64_t)blockIdx.x * D * (2 * D);
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+#pragma unroll
+        for (int v = 0; v < 16; ++v)
+            dst[(int64_t)(nt * 32 + upd_acc_row(v, h)) * (2 * D) + c * 32 + i] = acc[c][v];
+    if (h == 0) pb[(int64_t)blockIdx.x * D + nt * 32 + i] = bsum;
+}
+
+// out[j] = sum over blocks of part[block * n + j], in a fixed order: a workgroup owns 64 outputs; its four wavefronts
+// each add up a contiguous quarter of the blocks, and the quarters are added in order through LDS
+__global__ __launch_bounds__(256) void update_reduce_kernel(const float* __restrict__ part, int64_t n_blocks, int64_t n,
+                                                            float* __restrict__ out)
+{
+    __shared__ float s_q[4 * 64];
+    const int o = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int64_t j = (int64_t)blockIdx.x * 64 + o;
+    const int64_t per = (n_blocks + 3) / 4;
+    const int64_t b0 = q * per, b1 = b0 + per < n_blocks ? b0 + per : n_blocks;
+    float s = 0.f;
+    if (j < n) {
+#pragma unroll 8
+        for (int64_t b = b0; b < b1; ++b) s += part[b * n + j];
+    }
+    s_q[q * 64 + o] = s;
+    __syncthreads();
+    if (q == 0 && j < n) out[j] = ((s_q[o] + s_q[64 + o]) + s_q[128 + o]) + s_q[192 + o];
+}
+
+extern "C" int sgnn_update_fwd(const float* x, const float* aggr, const float* W, const float* b, int64_t R, int64_t D,
+                               float* out, void* stream)
+{
+    if (!x || !aggr || !W || !out || R < 0) return SGNN_ERR_BAD_ARG;
+    if (D != 32 && D != 64 && D != 128) return SGNN_ERR_UNSUPPORTED_D;
+    if (R == 0) return SGNN_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned grid = (unsigned)((R + 31) / 32);
+    if (D == 32) hipLaunchKernelGGL(update_fwd_kernel<32>, dim3(grid), dim3(64), 0, st, x, aggr, W, b, R, out);
+    else if (D == 64) hipLaunchKernelGGL(update_fwd_kernel<64>, dim3(grid), dim3(64), 0, st, x, aggr, W, b, R, out);
+    else hipLaunchKernelGGL(update_fwd_kernel<128>, dim3(grid), dim3(64), 0, st, x, aggr, W, b, R, out);
+    SGNN_CHECK_LAUNCH();
+    return SGNN_OK;
+}
+
+extern "C" int64_t sgnn_update_bwd_workspace_bytes(int64_t R, int64_t D)
+{
+    const int64_t nb = (R + UPD_ROWS - 1) / UPD_ROWS;
+    return nb * (D * 2 * D + D) * 4 + 64;
+}
+
+extern "C" int sgnn_update_bwd(const float* grad_out, const float* out, const float* x, const float* aggr, const float* W,
+                               int64_t R, int64_t D, float* grad_x, float* grad_aggr, float* grad_W, float* grad_b,
+                               void* workspace, int64_t workspace_bytes, void* stream)
+{
+    if (!grad_out || !out || !W || R < 0) return SGNN_ERR_BAD_ARG;
+    if ((grad_W || grad_b) && (!x || !aggr)) return SGNN_ERR_BAD_ARG;
+    if (D != 32 && D != 64 && D != 128) return SGNN_ERR_UNSUPPORTED_D;
+    hipStream_t st = (hipStream_t)stream;
+    if (R == 0) {
+        hipError_t e = hipSuccess;
+        if (grad_W) e = hipMemsetAsync(grad_W, 0, (size_t)(D * 2 * D * 4), st);
+        if (e == hipSuccess && grad_b) e = hipMemsetAsync(grad_b, 0, (size_t)(D * 4), st);
+        if (e != hipSuccess) { sgnn_set_last_error(e); return SGNN_ERR_LAUNCH; }
+        return SGNN_OK;
+    }
+    if (grad_x || grad_aggr) {
+        const unsigned grid = (unsigned)((R + 31) / 32);
+        if (D == 32) hipLaunchKernelGGL(update_bwd_dx_kernel<32>, dim3(grid), dim3(64), 0, st, grad_out, out, W, R, grad_x, grad_aggr);
+        else if (D == 64) hipLaunchKernelGGL(update_bwd_dx_kernel<64>, dim3(grid), dim3(64), 0, st, grad_out, out, W, R, grad_x, grad_aggr);
+        else hipLaunchKernelGGL(update_bwd_dx_kernel<128>, dim3(grid), dim3(64), 0, st, grad_out, out, W, R, grad_x, grad_aggr);
+        SGNN_CHECK_LAUNCH();
+    }
+    if (grad_W || grad_b) {
+        if (!workspace || workspace_bytes < sgnn_update_bwd_workspace_bytes(R, D)) return SGNN_ERR_BAD_ARG;
+        const int64_t nb = (R + UPD_ROWS - 1) / UPD_ROWS;
+        float* pW = (float*)workspace;
+        float* pb = pW + nb * D * 2 * D;
+        const dim3 grid((unsigned)nb, (unsigned)(D / 32));
+        if (D == 32) hipLaunchKernelGGL(update_bwd_dw_kernel<32>, grid, dim3(256), 0, st, grad_out, out, x, aggr, R, pW, pb);
+        else if (D == 64) hipLaunchKernelGGL(update_bwd_dw_kernel<64>, grid, dim3(256), 0, st, grad_out, out, x, aggr, R, pW, pb);
+        else hipLaunchKernelGGL(update_bwd_dw_kernel<128>, grid, dim3(256), 0, st, grad_out, out, x, aggr, R, pW, pb);
+        SGNN_CHECK_LAUNCH();
+        if (grad_W) {
+            hipLaunchKernelGGL(update_reduce_kernel, dim3((unsigned)((D * 2 * D + 63) / 64)), dim3(256), 0, st, pW, nb, D * 2 * D, grad_W);
+            SGNN_CHECK_LAUNCH();
+        }
+        if (grad_b) {
+            hipLaunchKernelGGL(update_reduce_kernel, dim3((unsigned)((D + 63) / 64)), dim3(256), 0, st, pb, nb, D, grad_b);
+            SGNN_CHECK_LAUNCH();
+        }
+    }
+    return SGNN_OK;
+}

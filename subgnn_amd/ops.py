@@ -1000,6 +1000,53 @@ def linear(x, weight, bias):
     return torch.nn.functional.linear(x, weight, bias)
 
 
+UPDATE_DIMS = (32, 64, 128)
+
+
+class _UpdateLayer(torch.autograd.Function):
+    """out = relu([x | aggr] W^T + b) (sgnn_update_fwd / sgnn_update_bwd): the message-passing layer's update(),
+    without the concatenation and with bias, relu and their backward fused around fp32 MFMA contractions."""
+
+    @staticmethod
+    def forward(ctx, x, aggr, W, b):
+        lib = _lib.load()
+        for t, nm in ((x, 'x'), (aggr, 'aggr'), (W, 'W'), (b, 'b')):
+            _req(t, torch.float32, nm)
+        R, D = x.shape
+        if aggr.shape != x.shape or tuple(W.shape) != (D, 2 * D):
+            raise ValueError('update layer: x %s, aggr %s, W %s' % (tuple(x.shape), tuple(aggr.shape), tuple(W.shape)))
+        out = torch.empty((R, D), dtype=torch.float32, device=x.device)
+        check(lib.sgnn_update_fwd(_ptr(x), _ptr(aggr), _ptr(W), _ptr(b), R, D, _ptr(out), _stream()), 'sgnn_update_fwd')
+        ctx.save_for_backward(x, aggr, W, out)
+        ctx.has_bias = b is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        x, aggr, W, out = ctx.saved_tensors
+        g = g.contiguous()
+        R, D = x.shape
+        nx, na, nw, nb = ctx.needs_input_grad
+        gx = torch.empty_like(x) if nx else None
+        ga = torch.empty_like(aggr) if na else None
+        gW = torch.empty_like(W) if nw else None
+        gb = torch.empty(D, dtype=torch.float32, device=x.device) if (nb and ctx.has_bias) else None
+        wsb = lib.sgnn_update_bwd_workspace_bytes(R, D)
+        ws = torch.empty(wsb // 4 + 1, dtype=torch.float32, device=x.device) if (gW is not None or gb is not None) else None
+        check(lib.sgnn_update_bwd(_ptr(g), _ptr(out), _ptr(x), _ptr(aggr), _ptr(W), R, D, _ptr(gx), _ptr(ga), _ptr(gW),
+                                  _ptr(gb), _ptr(ws), wsb, _stream()), 'sgnn_update_bwd')
+        return gx, ga, gW, gb
+
+
+def update_layer(x, aggr, weight, bias):
+    """relu(nn.Linear(2 D, D)(cat([x, aggr], 1))) for (R, D) inputs (subgraph_mpn.py:233-241).  The fused HIP form
+    for D in UPDATE_DIMS; other widths keep the library GEMM (torch) around the same arithmetic."""
+    if x.is_cuda and x.dim() == 2 and x.shape[1] in UPDATE_DIMS and x.dtype == torch.float32:
+        return _UpdateLayer.apply(x.contiguous(), aggr.contiguous(), weight, bias)
+    return torch.relu(linear(torch.cat([x, aggr], dim=1), weight, bias))
+
+
 class ZeroSims:
     """Edge weights known to be all zero (the similarity of an anchor that lies inside its own
     component -- every N-internal edge, every P-internal edge of a single-component subgraph): the

@@ -22,12 +22,15 @@ class SG_MPN(nn.Module):
         self.linear_position = nn.Linear(D, 1)
 
     # -- shared tail: update() and the read-out non-linearity (mpn:122-131, 233-241) -------
-    def _finish(self, cc_embeds, agg, z):
+    def _finish(self, cc_embeds, agg, z, need_out=True):
         B, C, D = cc_embeds.shape
-        if self.hparams['use_mpn_projection']:
+        if not need_out:
+            # the caller reads only the position read-out of this layer (the last layer of the position / structure
+            # channels: their updated component embeddings would feed a next layer that does not exist)
+            out = None
+        elif self.hparams['use_mpn_projection']:
             # applied to every component row, padded ones included (mpn:168,239)
-            out = F.relu(ops.linear(torch.cat([cc_embeds.reshape(B * C, D), agg], dim=1), self.linear.weight,
-                                    self.linear.bias))
+            out = ops.update_layer(cc_embeds.reshape(B * C, D), agg, self.linear.weight, self.linear.bias)
         else:
             out = agg
         z = z.view(B, C, -1)
@@ -35,7 +38,7 @@ class SG_MPN(nn.Module):
             pos = F.normalize(z, p=2, dim=-1)
         else:
             pos = F.relu(z)
-        return out.view(B, C, -1), pos
+        return (out.view(B, C, -1) if out is not None else None), pos
 
     def forward(self, networkx_graph, sims, cc_ids, cc_embeds, cc_embed_mask, anchor_patches, anchor_embeds,
                 anchor_mask, anchors_sim_index):
@@ -55,7 +58,7 @@ class SG_MPN(nn.Module):
         return self._finish(cc_embeds, agg, z)
 
     def forward_fused(self, sims, cc_embeds, cc_embed_mask, *, src, x, ids=None, id_div=1, sim_col=None,
-                      sims_per_edge=False):
+                      sims_per_edge=False, need_out=True):
         """Fast path used by SubGNN.forward: the anchor rows are gathered inside the kernel
         (src GATHER: x = embedding table, ids (R/id_div, A)) or shared by all rows (src SHARED:
         x (A,D)), so the (B,C,A,D) tensor of get_anchor_patches is never materialised."""
@@ -65,8 +68,8 @@ class SG_MPN(nn.Module):
         if isinstance(sims, ops.ZeroSims):          # all edge weights 0: messages vanish, read-out = bias
             agg = torch.zeros((R, D), dtype=cc_embeds.dtype, device=cc_embeds.device)
             z = self.linear_position.bias.view(1, 1).expand(R, A)
-            return self._finish(cc_embeds, agg, z)
+            return self._finish(cc_embeds, agg, z, need_out)
         row_mask = cc_embed_mask.reshape(R).to(torch.uint8).contiguous()
         agg, z = ops.mpn(x, self.linear_position.weight, self.linear_position.bias, sims, src=src, R=R, A=A, ids=ids,
                          id_div=id_div, row_mask=row_mask, sim_col=sim_col, sims_per_edge=sims_per_edge)
-        return self._finish(cc_embeds, agg, z)
+        return self._finish(cc_embeds, agg, z, need_out)
