@@ -18,12 +18,14 @@ reference effectively uses when ego_graphs.txt is present).
 One step = one full pass of the hot path over the rank's shard, everything on the GPU:
   anchor-patch sampling + similarities (connected components, k-hop border BFS, N/P/S anchor
   draws, structure patches + triangular walks, degree sequences, DTW, multi-source BFS
-  position similarities)  ->  three channels forward  ->
-  [N>1: RCCL all-gather of the per-component channel embeddings: the read-out + MLP head + loss
-   run replicated on the global batch]  ->  backward  ->
-  [N>1: all-reduce of the small channel gradients; reduce-scatter of the embedding-table
-   gradient, owner-computes Adam, all-gather of the updated rows under the next pass]
-  ->  Adam step.
+  position similarities)  ->  three channels forward  ->  read-out + MLP head + loss  ->  backward  ->
+  [N>1: all-reduce of the small gradients; reduce-scatter of the embedding-table gradient,
+   owner-computes Adam, all-gather of the updated rows under the next pass]  ->  Adam step.
+  N>1, --head sharded (default): every rank runs the head on ITS subgraphs; the loss is the mean over the global
+       batch (equal shards: the mean of the ranks' means), so all gradients are averaged over ranks.
+  N>1, --head replicated: north_star's exchange -- an RCCL all-gather of the per-component channel embeddings
+       (84 MB per rank) and the head replicated on the global batch; what batch_norm / a consumer that needs
+       every rank's embeddings requires, at world x the head work per rank.
 value = subgraphs processed by all ranks / max-over-ranks step time.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
@@ -73,6 +75,9 @@ def parse():
     ap.add_argument('--m', type=int, default=10)
     ap.add_argument('--subgraphs', type=int, default=50_000, help='subgraphs per GPU (weak) / in total (strong)')
     ap.add_argument('--scaling', choices=['weak', 'strong'], default='weak')
+    ap.add_argument('--head', choices=['sharded', 'replicated'], default='sharded',
+                    help='N>1: the read-out + MLP head on the rank\'s own rows (gradients averaged), or replicated on the '
+                         'all-gathered channel embeddings')
     ap.add_argument('--subgraph-nodes', type=int, default=20)
     ap.add_argument('--embed', type=int, default=64)
     ap.add_argument('--embedding-dtype', choices=['fp32', 'fp16'], default='fp32',
@@ -161,6 +166,8 @@ def main():
     hp['embedding_dtype'] = args.embedding_dtype
     if os.environ.get('SGNN_OVERLAP_STREAMS'):
         hp['overlap_streams'] = True
+    if os.environ.get('SGNN_BENCH_HP'):                          # functional checks only (e.g. '{"lin_dropout": 0.0}')
+        hp.update(json.loads(os.environ['SGNN_BENCH_HP']))
     S = len(subs)
     multi = dist is not None and world > 1
     shard = sdist.Shard(total_subgraphs, rank, world, deal_shared=(args.scaling == 'strong')) if multi else None
@@ -171,20 +178,23 @@ def main():
     all_labels[:3] = torch.tensor([0, 1, 2])
     first = shard.start if multi else 0
     labels = all_labels[first:first + S].clone()
+    replicated = multi and args.head == 'replicated'
     if multi:
         if total_subgraphs % world:
-            raise SystemExit('the replicated head needs equal shards: %d subgraphs over %d ranks' % (total_subgraphs, world))
-        hp['dp_gather_embeddings'] = True
+            raise SystemExit('equal shards needed (mean of means / replicated head): %d subgraphs over %d ranks' % (total_subgraphs, world))
+        hp['dp_gather_embeddings'] = replicated
     model = SubGNN.from_memory(hp, g, {'train': subs, 'val': [], 'test': []},
                                {'train': labels, 'val': labels[:0], 'test': labels[:0]}, emb, num_classes=3)
     model.train()
+    if multi and not replicated:
+        torch.cuda.manual_seed(0x5eed + rank)                    # dropout masks of the ranks' own rows: independent streams
     table = model.node_embeddings.weight
     head = {id(p) for m_ in (model.lin, model.lin2, model.lin3) for p in m_.parameters()}
     if multi:
         # table: reduce-scatter + owner-computes Adam (dist.ShardedTableAdam); everything else: torch's fused Adam
         small = [p for p in model.parameters() if p.requires_grad and p is not table]
         opt = torch.optim.Adam(small, lr=hp['learning_rate'], fused=True)
-        table_opt = sdist.ShardedTableAdam(table, hp['learning_rate'])
+        table_opt = sdist.ShardedTableAdam(table, hp['learning_rate'], average=not replicated)
         model._table_sync = table_opt.wait
         channel_params = [p for p in small if id(p) not in head]
         labels_dev = all_labels.to(dev)
@@ -198,7 +208,7 @@ def main():
         timer = hotpath.StageTimer(timed)
         hotpath.prepare_sparse(model, 'train', timer, shard)
         batch = hotpath.full_split_batch(model, 'train')
-        if multi:
+        if replicated:
             batch['label'] = labels_dev                          # the head runs on the gathered global batch
         out = model.training_step(batch, 0)
         timer.mark('forward')
@@ -210,10 +220,15 @@ def main():
             opt.zero_grad(set_to_none=True)
             timer.mark('optimizer')
             return timer, float(out['loss'].detach())
-        # The loss is the mean over the GLOBAL batch and the head is replicated: head gradients are already
-        # complete and identical on every rank; channel parameters (message-passing layers, LSTM, the table)
-        # hold this rank's share of the sum.
-        sdist.all_reduce_gradients(channel_params, average=False)
+        if replicated:
+            # The loss is the mean over the GLOBAL batch and the head is replicated: head gradients are already
+            # complete and identical on every rank; channel parameters (message-passing layers, LSTM, the table)
+            # hold this rank's share of the sum.
+            sdist.all_reduce_gradients(channel_params, average=False)
+        else:
+            # every rank's loss is the mean over its own (equally many) subgraphs: the global mean is the mean of
+            # those, and so are all gradients (the table's: ShardedTableAdam(average=True))
+            sdist.all_reduce_gradients(small, average=True)
         sq = table_opt.reduce_grad()
         torch.distributed.all_reduce(sq)
         total = torch.sqrt(sq + sum((p.grad.float() ** 2).sum() for p in small if p.grad is not None))
@@ -265,6 +280,10 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     hotpath.check_pending(model)                                 # the last pass's BFS level hints (raises if one was too small)
+    if multi and not replicated:                                 # the reported loss: mean over the global batch = mean of the ranks' means
+        lt = torch.tensor([loss], device=dev, dtype=torch.float64)
+        dist.all_reduce(lt)
+        loss = float(lt.item()) / world
     for tm in timers:
         for k, v in tm.summary().items():
             stage_ms[k] = stage_ms.get(k, 0.0) + v / args.steps
@@ -335,8 +354,10 @@ def main():
                                (n, args.m, int(rowptr[-1]) // 2, args.subgraphs, args.subgraph_nodes,
                                 'per GPU' if args.scaling == 'weak' else 'in total', args.embed),
                    'subgraphs_per_gpu': S, 'subgraphs_total': total_subgraphs,
-                   'parallelism': 'dp%d (subgraph shards; RCCL all-gather of the channel embeddings into a replicated head, '
-                                  'all-reduce of channel gradients, reduce-scatter / all-gather of the embedding table)' % world},
+                   'parallelism': ('dp%d (subgraph shards; head on the rank\'s own rows, all-reduce of the small gradients, '
+                                   'reduce-scatter / all-gather of the embedding table)' % world) if not replicated else
+                                  ('dp%d (subgraph shards; RCCL all-gather of the channel embeddings into a replicated head, '
+                                   'all-reduce of channel gradients, reduce-scatter / all-gather of the embedding table)' % world)},
         'roofline': {'kernel': 'degseq_wave_kernel<true, false, false> (sgnn_degree_sequence: structure-channel CSR gather, '
                                'every neighbour list streamed)',
                      'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',

@@ -140,6 +140,34 @@ def _worker_dp_ops(rank, world, port, q):
         sh.wait()
         opt_ref.step()
         ok['adam%d' % it] = torch.allclose(table.detach(), ref.detach(), atol=1e-6)
+    # --- the sharded-head form of data parallelism (bench.py --head sharded): every rank's loss is the mean over its
+    #     own rows; averaged small gradients + ShardedTableAdam(average=True) == one process on the global batch
+    gen = torch.Generator().manual_seed(9)
+    Xall, yall = torch.randn(world * 6, 5, generator=gen), torch.randint(0, 3, (world * 6,), generator=gen)
+    emb0, W0 = torch.randn(7, 5, generator=gen), torch.randn(3, 5, generator=gen)
+    ids_all = torch.randint(0, 7, (world * 6,), generator=gen)
+
+    def loss_of(emb, W, sl):
+        return torch.nn.functional.cross_entropy((Xall[sl] + emb[ids_all[sl]]) @ W.t(), yall[sl])
+    emb_r, W_r = torch.nn.Parameter(emb0.clone()), torch.nn.Parameter(W0.clone())
+    opt_r = torch.optim.Adam([emb_r, W_r], lr=0.05)
+    emb_d, W_d = torch.nn.Parameter(emb0.clone()), torch.nn.Parameter(W0.clone())
+    opt_d = torch.optim.Adam([W_d], lr=0.05)
+    sh2 = D.ShardedTableAdam(emb_d, 0.05, average=True)
+    mine_sl = slice(rank * 6, (rank + 1) * 6)
+    for it in range(3):
+        opt_r.zero_grad()
+        loss_of(emb_r, W_r, slice(0, world * 6)).backward()
+        opt_r.step()
+        emb_d.grad = W_d.grad = None
+        loss_of(emb_d, W_d, mine_sl).backward()
+        D.all_reduce_gradients([W_d], average=True)
+        sh2.reduce_grad()
+        opt_d.step()
+        sh2.step()
+        sh2.wait()
+        ok['dp_mean_of_means%d' % it] = torch.allclose(W_d.detach(), W_r.detach(), atol=1e-6) and \
+            torch.allclose(emb_d.detach(), emb_r.detach(), atol=1e-6)
     # --- sparse (row id, row) exchange ----------------------------------------------------------------
     g = torch.zeros(200, 4)
     mine = torch.tensor([3, 50, 77]) + rank
