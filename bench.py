@@ -83,7 +83,7 @@ def parse():
     ap.add_argument('--embedding-dtype', choices=['fp32', 'fp16'], default='fp32',
                     help="fp16: the fused kernels read an IEEE-half copy of the embedding table (fp32 accumulate, fp32 master)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-sample', type=int, default=1024)
+    ap.add_argument('--cpu-sample', type=int, default=2048)
     return ap.parse_args()
 
 

@@ -13,8 +13,7 @@ def lib():
     global _LIB
     if _LIB is None:
         so = os.path.join(_HERE, '_build', 'liboracle_c.so')
-        if not os.path.exists(so):
-            subprocess.check_call(['make', '-C', _HERE])
+        subprocess.check_call(['make', '-s', '-C', _HERE])             # (a no-op when the library is newer than its source)
         _LIB = ctypes.CDLL(so)
     return _LIB
 
@@ -56,4 +55,15 @@ def sp_similarity(apsp, set_ptr, set_nodes):
     out = np.zeros((n, apsp.shape[1]), dtype=np.float32)
     lib().oc_sp_similarity(_p(np.ascontiguousarray(apsp)), ctypes.c_int64(apsp.shape[1]), _p(set_ptr), _p(set_nodes),
                            ctypes.c_int64(n), _p(out))
+    return out
+
+
+def bfs_min_hops_to_sets(rowptr, col, sources, set_ptr, set_nodes):
+    """(n_sets, n_sources) float32: min over a set's members of the hop count from each source, 0 where a member is
+    unreachable (oc_bfs_min_hops_to_sets; one BFS per source, sources shared among the host's cores)."""
+    n_sets, n_src = len(set_ptr) - 1, len(sources)
+    out = np.zeros((n_sets, n_src), dtype=np.float32)
+    src = np.ascontiguousarray(sources, dtype=np.int32)
+    lib().oc_bfs_min_hops_to_sets(_p(rowptr), _p(col), ctypes.c_int64(len(rowptr) - 2), _p(src), ctypes.c_int64(n_src),
+                                  _p(set_ptr), _p(set_nodes), ctypes.c_int64(n_sets), _p(out))
     return out

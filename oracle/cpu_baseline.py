@@ -9,8 +9,11 @@ extrapolated linearly, stage by stage:
   per-subgraph stages (components, 1-hop border, N/P anchor draws, degree sequences, DTW against
       all structure patches, position similarities, forward + backward + Adam)  -> timed on
       ``n_sample`` subgraphs, scaled by S / n_sample;
-  shared stages (structure patches + their walks, multi-source BFS from the P-border anchors) ->
-      timed on a few patches / sources, scaled to the full count, counted once per pass.
+  shared stages (structure patches + their walks: timed on a few patches and scaled; one BFS per P-border anchor
+      over the whole graph: run for ALL sources in C, the sources shared among the host's cores) -> counted once
+      per pass.
+The C stages (DTW, BFS) use OpenMP over the host's cores; the Python / numpy integer stages are single-threaded and
+the torch stages use torch's thread pool -- "cores" reports the OpenMP / torch thread count.
 """
 import time
 
@@ -19,23 +22,6 @@ import torch
 
 from . import cbind, float_half as FH, integer_half as IH, tape as T
 from .graph import CSRGraph
-
-
-def _bfs_hops_numpy(rowptr, col, src, n):
-    dist = np.full(n + 1, 255, dtype=np.uint8)
-    dist[src] = 0
-    frontier = np.array([src], dtype=np.int64)
-    level = 0
-    while len(frontier) and level < 254:
-        level += 1
-        starts, ends = rowptr[frontier], rowptr[frontier + 1]
-        lens = ends - starts
-        idx = np.repeat(starts - np.cumsum(lens) + lens, lens) + np.arange(int(lens.sum()))
-        nb = np.unique(col[idx])
-        nb = nb[dist[nb] == 255]
-        dist[nb] = level
-        frontier = nb.astype(np.int64)
-    return dist
 
 
 def run(rowptr, col, subs, hp, emb, labels, n_sample, S_total):
@@ -61,11 +47,6 @@ def run(rowptr, col, subs, hp, emb, labels, n_sample, S_total):
     bw = IH.perform_random_walks(G, patches, hp['n_triangular_walks'], hp['random_walk_len'], hp['rw_beta'], False, seed)
     t['shared_patches_walks'] = (time.perf_counter() - t0) * n_patches / np_s
     pext = IH.position_anchors_border(G, hp['n_anchor_patches_pos_out'], seed, 0)
-    nb_s = min(4, len(pext))
-    t0 = time.perf_counter()
-    dist = np.stack([_bfs_hops_numpy(rowptr, col, int(s), n) for s in pext[:nb_s]])
-    t['shared_pext_bfs'] = (time.perf_counter() - t0) * len(pext) / nb_s
-    dist = np.concatenate([dist] * (len(pext) // nb_s + 1))[:len(pext)]
     allp = np.concatenate([patches] * (n_patches // np_s + 1))[:n_patches]
     iw = np.concatenate([iw] * (n_patches // np_s + 1))[:n_patches]
     bw = np.concatenate([bw] * (n_patches // np_s + 1))[:n_patches]
@@ -116,11 +97,12 @@ def run(rowptr, col, subs, hp, emb, labels, n_sample, S_total):
     int_sim = cbind.fastdtw_sim(cp, ci, pp, pi, 0).reshape(S, C, -1)
     bor_sim = cbind.fastdtw_sim(cp, ce, pp, pe, 0).reshape(S, C, -1)
     t['dtw'] = time.perf_counter() - t0
+    # position channel: one BFS per P-border anchor over the whole graph (C, the sources shared among the cores) and the
+    # min over every sampled component's members.  The BFS part does not depend on the number of subgraphs: a shared stage,
+    # run in full; the per-component minimum is part of the same call and small beside it.
     t0 = time.perf_counter()
-    d = dist.astype(np.int64)
-    d[d == 255] = 0
-    p_out = np.stack([d[:, r[r != 0]].min(axis=1) if (r != 0).any() else np.zeros(len(pext)) for r in rows])
-    t['position_sims'] = time.perf_counter() - t0
+    p_out = cbind.bfs_min_hops_to_sets(rowptr, col, pext, cp, cf)
+    t['shared_pext_bfs_all_sources'] = time.perf_counter() - t0
 
     # ---- float half: forward + backward + Adam on the sample ---------------------------------
     D = emb.shape[1]
@@ -183,10 +165,11 @@ def run(rowptr, col, subs, hp, emb, labels, n_sample, S_total):
     return {'value': S_total / est_pass, 'unit': 'subgraphs/s', 'cores': int(torch.get_num_threads()),
             'kind': 'port',
             'sample': ('oracle (C + numpy + torch-CPU, same sparse algorithm) on %d of %d subgraphs; per-subgraph stages '
-                       'scaled x%.0f, shared stages (structure patches/walks on %d of %d patches, P-border BFS on %d of %d '
-                       'sources, dense embedding-table Adam) scaled and counted once; integer stages are single-threaded, '
-                       'torch stages use %d threads; %.1f s of CPU work measured'
-                       % (n_sample, S_total, S_total / n_sample, np_s, n_patches, nb_s, len(pext), torch.get_num_threads(),
+                       'scaled x%.0f; shared stages counted once (structure patches/walks on %d of %d patches, scaled; one BFS '
+                       'per P-border anchor for all %d sources; dense embedding-table Adam); DTW and BFS in C with OpenMP over '
+                       'the cores, the other integer stages single-threaded Python / numpy, torch stages on %d threads; %.1f s '
+                       'of CPU work measured'
+                       % (n_sample, S_total, S_total / n_sample, np_s, n_patches, len(pext), torch.get_num_threads(),
                           time.perf_counter() - t_all)),
             'stage_seconds_measured': {k: round(v, 3) for k, v in t.items()},
             'estimated_full_pass_s': round(est_pass, 1)}

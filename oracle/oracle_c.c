@@ -146,6 +146,8 @@ static double fastdtw_rec(const double* x, int lx, const double* y, int ly, int 
 void oc_fastdtw_sim(const int64_t* x_ptr, const int32_t* x_val, int64_t n_x,
                     const int64_t* y_ptr, const int32_t* y_val, int64_t n_y, int tie_order, float* out)
 {
+    /* rows are independent: the host's cores share them (bench.py's cpu_baseline leg; results do not depend on it) */
+#pragma omp parallel for schedule(dynamic, 16)
     for (int64_t r = 0; r < n_x; ++r) {
         const int lx = (int)(x_ptr[r + 1] - x_ptr[r]);
         double* x = (double*)malloc(sizeof(double) * (lx > 0 ? lx : 1));
@@ -181,5 +183,45 @@ void oc_sp_similarity(const double* apsp, int64_t n_cols, const int64_t* set_ptr
             }
             out[r * n_cols + c] = res;
         }
+    }
+}
+
+/* Position-channel similarities the way the sparse path defines them (subgnn_amd/hotpath.py; values identical to the
+ * reference's dense gather, SubGNN/SubGNN.py:763-772): one breadth-first search per source over the CSR graph (ids
+ * 1..n, row v of rowptr / col = the neighbours of id v, row 0 empty: oracle/graph.py), then out[set, source] = min over the set's members of the hop count,
+ * 0 if some member is unreachable (the reference's matrix holds 0 there and its row-min runs over it).
+ * Sources are independent: shared among the host's cores. */
+void oc_bfs_min_hops_to_sets(const int64_t* rowptr, const int32_t* col, int64_t n, const int32_t* sources, int64_t n_src,
+                             const int64_t* set_ptr, const int32_t* set_nodes, int64_t n_sets, float* out)
+{
+#pragma omp parallel
+    {
+        int32_t* dist = (int32_t*)malloc(sizeof(int32_t) * (size_t)(n + 1));
+        int32_t* queue = (int32_t*)malloc(sizeof(int32_t) * (size_t)(n + 1));
+#pragma omp for schedule(dynamic, 1)
+        for (int64_t s = 0; s < n_src; ++s) {
+            for (int64_t v = 0; v <= n; ++v) dist[v] = -1;
+            int64_t head = 0, tail = 0;
+            dist[sources[s]] = 0;
+            queue[tail++] = sources[s];
+            while (head < tail) {
+                const int32_t u = queue[head++];
+                for (int64_t e = rowptr[u]; e < rowptr[u + 1]; ++e) {
+                    const int32_t w = col[e];
+                    if (dist[w] < 0) { dist[w] = dist[u] + 1; queue[tail++] = w; }
+                }
+            }
+            for (int64_t r = 0; r < n_sets; ++r) {
+                int32_t m = 0;
+                int first = 1, missing = 0;
+                for (int64_t i = set_ptr[r]; i < set_ptr[r + 1]; ++i) {
+                    const int32_t d = dist[set_nodes[i]];
+                    if (d < 0) { missing = 1; break; }
+                    if (first || d < m) { m = d; first = 0; }
+                }
+                out[r * n_src + s] = (missing || first) ? 0.f : (float)m;
+            }
+        }
+        free(dist); free(queue);
     }
 }

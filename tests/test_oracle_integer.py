@@ -272,3 +272,18 @@ def test_fastdtw_tie_orders_bound_exact_dtw():
         for i in range(0, 300, 7):
             for j in range(0, 300, 11):
                 assert got[i, j] == np.float32(FD.calc_dtw(xs[i], ys[j], t))
+
+
+def test_c_bfs_min_hops_matches_the_apsp_golden(tiny):
+    """oracle_c's per-source BFS + min over members (the cpu_baseline leg's position stage) against the reference's
+    all-pairs matrix: the g4 position similarities of the golden, for every anchor node as a source."""
+    from oracle import cbind
+    G = _graph(tiny)
+    rowptr, col = G.csr()
+    cc = tiny['g2_cc_ids_train']
+    S, C, L = cc.shape
+    ptr, flat = cbind.ragged([[int(v) for v in r if v] for r in cc.reshape(S * C, L)])
+    src = np.arange(1, len(rowptr) - 1, dtype=np.int32)              # every node id as a source: the dense slab's columns
+    got = cbind.bfs_min_hops_to_sets(rowptr, col, src, ptr, flat)
+    want = tiny['g4_np_sim_train'].reshape(S * C, -1)
+    assert np.array_equal(got, want.astype(np.float32))
