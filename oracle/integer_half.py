@@ -425,3 +425,22 @@ def trim_zero_columns(x):
     flat = x.reshape(B * C, L)
     keep = np.abs(flat).sum(axis=0) != 0
     return flat[:, keep].reshape(B, C, -1)
+
+
+def bfs_hops_numpy(rowptr, col, src, n):
+    """Hop distance from node id ``src`` to every id of a CSR graph (row v = neighbours of id v), uint8, 255 = not
+    reached: a level-synchronous numpy BFS for the parity tests of graphs too large for the all-pairs matrix."""
+    dist = np.full(n + 1, 255, dtype=np.uint8)
+    dist[src] = 0
+    frontier = np.array([src], dtype=np.int64)
+    level = 0
+    while len(frontier) and level < 254:
+        level += 1
+        starts, ends = rowptr[frontier], rowptr[frontier + 1]
+        lens = ends - starts
+        idx = np.repeat(starts - np.cumsum(lens) + lens, lens) + np.arange(int(lens.sum()))
+        nb = np.unique(col[idx])
+        nb = nb[dist[nb] == 255]
+        dist[nb] = level
+        frontier = nb.astype(np.int64)
+    return dist

@@ -22,7 +22,7 @@ import torch
 
 from helpers import assert_close
 from oracle import cbind, float_half as FH, graph as OG, integer_half as IH, tape as OT
-from oracle.cpu_baseline import _bfs_hops_numpy
+from oracle.integer_half import bfs_hops_numpy as _bfs_hops_numpy
 
 pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
