@@ -164,8 +164,8 @@ def main():
     hp = dict(ALL_DENSITY_HP)
     hp['node_embed_size'] = args.embed
     hp['embedding_dtype'] = args.embedding_dtype
-    if os.environ.get('SGNN_OVERLAP_STREAMS'):
-        hp['overlap_streams'] = True
+    if os.environ.get('SGNN_OVERLAP_STREAMS'):                   # '0': one stream (stage times then add up)
+        hp['overlap_streams'] = os.environ['SGNN_OVERLAP_STREAMS'] != '0'
     if os.environ.get('SGNN_BENCH_HP'):                          # functional checks only (e.g. '{"lin_dropout": 0.0}')
         hp.update(json.loads(os.environ['SGNN_BENCH_HP']))
     S = len(subs)

@@ -147,17 +147,21 @@ def prepare_sparse(model, split='train', timer=None, shard=None):
     tape items of the GLOBAL subgraph numbers and padded widths are reduced over ranks, so that the
     sharded passes together reproduce the single-rank pass bit for bit.
 
-    Two HIP streams: the main stream runs components -> border BFS + neighbourhood draws ->
-    component degree sequences -> DTW; a side stream runs, concurrently with the (VALU-bound)
-    border stage, the latency-bound triangular walks and the memory-bound multi-source BFS of the
-    position channel.  hparams['overlap_streams'] = True enables it (default off: on this runtime the two streams' kernels were observed to execute back to back, so it buys nothing yet)."""
+    Two HIP streams (hparams['overlap_streams'], default True): after the components, the main stream runs the
+    border BFS + neighbourhood draws and the component degree sequences, a side stream runs the structure patches,
+    the position channel's multi-source BFS and the triangular walks; they join before the DTW.  The border kernel
+    (1024-thread workgroups around an LDS bitmap) and the walk kernels leave most wavefront slots of a CU empty and
+    the BFS kernels are memory-bound with small workgroups: on the benchmark the three stages take 4.7 ms back to
+    back and 4.0 ms overlapped (17.9 -> 17.0 ms per pass).  The DTW cannot share a CU (it holds every vector
+    register at two wavefronts per SIMD), so nothing is overlapped with it.  The strong-scaling form issues
+    collectives inside the position block and keeps one stream."""
     hp, g, dev = model.hparams, model.networkx_graph, model.device
     seed = int(hp.get('seed', 0)) & tape.MASK64
     check_pending(model)                           # (the previous pass's BFS level hints; see _bfs_levels)
     t = timer or StageTimer(False)
     L = hp['n_layers']
     main = torch.cuda.current_stream()
-    if hp.get('overlap_streams', False):
+    if hp.get('overlap_streams', True) and not (shard is not None and shard.deal_shared):
         if getattr(model, '_side_stream', None) is None:
             model._side_stream = torch.cuda.Stream()
         side = model._side_stream

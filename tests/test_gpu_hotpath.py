@@ -165,3 +165,52 @@ def test_bfs_level_hint_gives_the_same_similarities_and_a_short_hint_is_caught(t
     m.hparams['max_bfs_hops'] = 1
     with pytest.raises(RuntimeError, match='max_bfs_hops'):
         hotpath.prepare_sparse(m, 'train')
+
+
+def _pass_outputs(m, split='train'):
+    L = m.hparams['n_layers']
+    out = {'cc_ids': getattr(m, split + '_cc_ids'), 'structure_anchors': m.structure_anchors,
+           'int_walks': m.int_structure_anchor_random_walks, 'bor_walks': m.bor_structure_anchor_random_walks,
+           'int_struc': getattr(m, split + '_int_struc_similarities'), 'bor_struc': getattr(m, split + '_bor_struc_similarities')}
+    sims = getattr(m, split + '_neigh_pos_similarities')
+    for l in range(L):
+        out['N_in%d' % l] = m.anchors_neigh_int[split][l]
+        out['N_out%d' % l] = m.anchors_neigh_border[split][l]
+        out['P_in%d' % l] = m.anchors_pos_int[split][l]
+        out['P_out%d' % l] = m.anchors_pos_ext[l]
+        for key in (('N', 'out', l), ('P', 'out', l), ('P', 'in', l)):
+            v = sims[key]
+            out['sim_%s_%s%d' % key] = v.dense() if hasattr(v, 'dense') else v
+        patches, _, iw, bw = m.anchors_structure[l]
+        out['S_patches%d' % l], out['S_iw%d' % l], out['S_bw%d' % l] = patches, iw, bw
+    return {k: v.clone() for k, v in out.items()}
+
+
+@pytest.mark.parametrize('name', ['tiny', 'density'])
+def test_two_stream_pass_equals_the_one_stream_pass(name, tmp_path):
+    """hparams['overlap_streams']: the side stream (structure patches, position BFS, walks) and the main stream
+    (border BFS, draws, degree sequences) produce what the single-stream pass produces -- also on repeated passes,
+    when the caching allocator hands blocks freed on one stream to the other -- and a training step runs on it."""
+    from conftest import load_golden
+    from subgnn_amd import hotpath
+    golden = load_golden(name)
+    (one, two) = _models(golden, tmp_path)
+    one.hparams['overlap_streams'] = False
+    two.hparams['overlap_streams'] = True
+    hotpath.prepare_sparse(one, 'train')
+    want = _pass_outputs(one)
+    for rep in range(4):
+        hotpath.prepare_sparse(two, 'train')
+        assert two._side_stream is not None
+        got = _pass_outputs(two)
+        for k in want:
+            assert torch.equal(got[k], want[k]), (rep, k)
+        junk = [torch.randn(1 << 18, device=DEV) for _ in range(8)]      # churn the allocator between passes
+        del junk
+    two.load_state_dict(one.state_dict())
+    one.train(); two.train()
+    la = one.training_step(hotpath.full_split_batch(one, 'train'), 0)['loss']
+    lb = two.training_step(hotpath.full_split_batch(two, 'train'), 0)['loss']
+    la.backward(); lb.backward()
+    assert float(la) == float(lb)
+    assert torch.equal(one.node_embeddings.weight.grad, two.node_embeddings.weight.grad)
