@@ -75,6 +75,9 @@ def parse():
     ap.add_argument('--m', type=int, default=10)
     ap.add_argument('--subgraphs', type=int, default=50_000, help='subgraphs per GPU (weak) / in total (strong)')
     ap.add_argument('--scaling', choices=['weak', 'strong'], default='weak')
+    ap.add_argument('--no-pipeline', action='store_true',
+                    help='prepare every pass after the previous one has finished training (default: the sampling + similarity '
+                         'half of pass k+1 runs on a second HIP stream while pass k trains: hotpath.PassPipeline)')
     ap.add_argument('--head', choices=['sharded', 'replicated'], default='sharded',
                     help='N>1: the read-out + MLP head on the rank\'s own rows (gradients averaged), or replicated on the '
                          'all-gathered channel embeddings')
@@ -170,7 +173,10 @@ def main():
         hp.update(json.loads(os.environ['SGNN_BENCH_HP']))
     S = len(subs)
     multi = dist is not None and world > 1
-    shard = sdist.Shard(total_subgraphs, rank, world, deal_shared=(args.scaling == 'strong')) if multi else None
+    pipelined = not args.no_pipeline and not (multi and args.scaling == 'strong')
+    # the prepared pass's width reductions run beside the gradient exchange of the pass in training: own communicator
+    shard_group = dist.new_group() if (multi and pipelined) else None
+    shard = sdist.Shard(total_subgraphs, rank, world, deal_shared=(args.scaling == 'strong'), group=shard_group) if multi else None
     if multi and shard.size != S:
         raise SystemExit('shard size mismatch')
     # labels of the GLOBAL batch (a function of the global subgraph number): the replicated head needs them all
@@ -204,9 +210,19 @@ def main():
 
     stage_ms = {}
 
+    pipe = hotpath.PassPipeline(model, 'train', shard) if pipelined else None
+    side_timers = []
+
     def step(timed):
         timer = hotpath.StageTimer(timed)
-        hotpath.prepare_sparse(model, 'train', timer, shard)
+        if pipe is not None:
+            timer.mark('start')
+            pipe.install(timer)                                  # the pass prepared during the previous step
+            if timed:
+                side_timers.append(pipe.timer)
+            pipe.start(timed)                                    # the next one: side stream, beside this step's training
+        else:
+            hotpath.prepare_sparse(model, 'train', timer, shard)
         batch = hotpath.full_split_batch(model, 'train')
         if replicated:
             batch['label'] = labels_dev                          # the head runs on the gathered global batch
@@ -255,6 +271,8 @@ def main():
     # path and grows the caching allocator to its final footprint (with --warmup 1 the timed steps were
     # 30 ms instead of 20)
     PRIMING_PASSES = 2
+    if pipe is not None:
+        pipe.start()                                             # the first pass; every step starts the next one
     for _ in range(PRIMING_PASSES):
         step(False)
     for _ in range(args.warmup):
@@ -284,7 +302,7 @@ def main():
         lt = torch.tensor([loss], device=dev, dtype=torch.float64)
         dist.all_reduce(lt)
         loss = float(lt.item()) / world
-    for tm in timers:
+    for tm in timers + side_timers[1:]:                          # (side_timers[0] belongs to a pass prepared before the timed region)
         for k, v in tm.summary().items():
             stage_ms[k] = stage_ms.get(k, 0.0) + v / args.steps
     if os.environ.get('SGNN_BENCH_PER_STEP'):

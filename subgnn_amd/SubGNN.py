@@ -759,17 +759,22 @@ class SubGNN(nn.Module):
         moves this counter; graph_step.CapturedTrainStep compares it instead of object ids."""
         self.__dict__['_prep_generation'] = self.__dict__.get('_prep_generation', 0) + 1
 
+    def sim_cols_of(self, anchors_structure):
+        """{layer: device index tensor} for a set of sampled structure patches (an upload from host lists)."""
+        return {l: torch.as_tensor(indices, dtype=torch.int64, device=self.device)
+                for l, (_, indices, _, _) in anchors_structure.items()}
+
+    def set_sim_cols(self, anchors_structure, cols):
+        self.__dict__['_sim_cols_src'] = anchors_structure
+        self._sim_col_cache = cols
+
     def _build_sim_cols(self):
         """Per layer, the columns of the S similarity rows its sampled patches read (S.py:206-210),
         resident on the device so that forward never uploads anything."""
         src = getattr(self, 'anchors_structure', None)
         if src is not None and self.__dict__.get('_sim_cols_src') is src:
             return                                            # already uploaded for these patches
-        self.__dict__['_sim_cols_src'] = src
-        self._sim_col_cache = {}
-        if getattr(self, 'anchors_structure', None) is not None:
-            for l, (_, indices, _, _) in self.anchors_structure.items():
-                self._sim_col_cache[l] = torch.as_tensor(indices, dtype=torch.int64, device=self.device)
+        self.set_sim_cols(src, self.sim_cols_of(src) if src is not None else {})
 
     def test_epoch_end(self, outputs):
         """S.py:466-504."""

@@ -30,12 +30,13 @@ class Shard:
     sources of the position channel's multi-source BFS -- and exchange the results; pays when the
     shard is a slice of a fixed total (strong scaling), needs equal shard sizes."""
 
-    def __init__(self, total, rank=None, world=None, deal_shared=False, collectives=True):
+    def __init__(self, total, rank=None, world=None, deal_shared=False, collectives=True, group=None):
         self.world = world if world is not None else (dist.get_world_size() if is_initialized() else 1)
         self.rank = rank if rank is not None else (dist.get_rank() if is_initialized() else 0)
         self.total = int(total)
         self.start, self.stop = shard_range(self.total, self.rank, self.world)
         self.collectives = collectives and self.world > 1        # False: a single process replaying one rank's shard (tests)
+        self.group = group        # communicator of the width reductions (its own when passes are pipelined: hotpath.PassPipeline)
         self.deal_shared = bool(deal_shared) and self.collectives and self.total % self.world == 0
 
     @property
@@ -43,7 +44,7 @@ class Shard:
         return self.stop - self.start
 
     def reduce_max(self, t):
-        return all_reduce_max_(t) if self.collectives else t
+        return all_reduce_max_(t, self.group) if self.collectives else t
 
 
 class _Pending:
@@ -185,10 +186,10 @@ def all_to_all_row_blocks(x):
     return out
 
 
-def all_reduce_max_(t):
+def all_reduce_max_(t, group=None):
     """In-place MAX over ranks of a small device tensor (global padded widths, border sizes)."""
     if is_initialized() and dist.get_world_size() > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
     return t
 
 

@@ -141,8 +141,26 @@ def _dealt_position_sims(g, anchors, cc_sets, cc_ids, shard, max_hops):
     return torch.cat(cols, dim=1)
 
 
-def prepare_sparse(model, split='train', timer=None, shard=None):
-    """HIP-only prepare_data for one split (SubGNN.py:1024-1063 semantics, sparse similarities).
+class PassState:
+    """What one pass of ``prepare_pass`` produced for a split: the per-pass attributes of the model (component ids,
+    anchors, walks, similarity rows) by name, not yet visible to the model.  ``install_pass`` makes them the model's."""
+
+    def __init__(self, split):
+        self.split = split
+        self.attrs = {}            # attribute name -> value
+        self.per_split = {}        # attribute name (a dict keyed by split on the model) -> this split's value
+        self.sim_cols = None       # (anchors_structure, {layer: device index tensor}) when new patches were drawn
+        self.dtw_inputs = None     # between prepare_pass(defer_dtw=True) and finish_pass: what the DTW launches read
+
+    def tensors(self):
+        return [self.attrs, self.per_split, self.sim_cols[1] if self.sim_cols else None]
+
+
+def prepare_pass(model, split='train', timer=None, shard=None, defer_dtw=False):
+    """The sampling + similarity half of a pass (everything that does not read the embedding table), for one split
+    (SubGNN.py:1024-1063 semantics, sparse similarities) -> PassState.  The model's per-pass attributes are left
+    alone (only its per-split caches of pass-invariant facts are filled), so the pass can be prepared while the
+    previous one is still training on the model (PassPipeline).
     ``shard`` (dist.Shard): the model holds one rank's block of the split's subgraphs; draws then read the
     tape items of the GLOBAL subgraph numbers and padded widths are reduced over ranks, so that the
     sharded passes together reproduce the single-rank pass bit for bit.
@@ -157,6 +175,7 @@ def prepare_sparse(model, split='train', timer=None, shard=None):
     collectives inside the position block and keeps one stream."""
     hp, g, dev = model.hparams, model.networkx_graph, model.device
     seed = int(hp.get('seed', 0)) & tape.MASK64
+    st = PassState(split)
     check_pending(model)                           # (the previous pass's BFS level hints; see _bfs_levels)
     t = timer or StageTimer(False)
     L = hp['n_layers']
@@ -175,7 +194,7 @@ def prepare_sparse(model, split='train', timer=None, shard=None):
     labels = ops.cc_labels(g, subs)
     cc_ids = subgraph_utils.components_from_labels(subs.ptr, subs.nodes, labels, subs.max_len,
                                                    dims_reduce=shard.reduce_max if shard is not None else None)
-    setattr(model, split + '_cc_ids', cc_ids)
+    st.attrs[split + '_cc_ids'] = cc_ids
     S, C, Lc = cc_ids.shape
     if ops.DETERMINISTIC:
         # the component-embedding backward scatters per member id in sorted order: the members of a split's
@@ -205,26 +224,26 @@ def prepare_sparse(model, split='train', timer=None, shard=None):
         # trip of this block, and it is taken while the queue is still short -- everything after it
         # (multi-source BFS, views, walks) is queued without waiting, behind the long BFS launches.
         new_patches = hp['use_structure'] and (split != 'test' or getattr(model, 'structure_anchors', None) is None)
+        structure_anchors = getattr(model, 'structure_anchors', None)
         if new_patches:
-            model.structure_anchors = aps.sample_structure_anchor_patches(hp, g, dev, hp['max_sim_epochs'])
+            structure_anchors = st.attrs['structure_anchors'] = aps.sample_structure_anchor_patches(hp, g, dev, hp['max_sim_epochs'])
             if side is main:
                 t.mark('S_patches_walks')
         if hp['use_position']:
-            if getattr(model, 'anchors_pos_ext', None) is None or split != 'test':
-                model.anchors_pos_ext = aps.init_anchors_pos_ext(hp, g, dev)
+            anchors_pos_ext = getattr(model, 'anchors_pos_ext', None)
+            if anchors_pos_ext is None or split != 'test':
+                anchors_pos_ext = st.attrs['anchors_pos_ext'] = aps.init_anchors_pos_ext(hp, g, dev)
             pint = {l: ops.choice_ragged(subs, hp['n_anchor_patches_pos_in'], seed,
                                          tape.stream_id(tape.STREAM_P_INT, split, l), item_base=base) for l in range(L)}
-            if getattr(model, 'anchors_pos_int', None) is None:
-                model.anchors_pos_int = {}
-            model.anchors_pos_int[split] = pint
+            st.per_split['anchors_pos_int'] = pint
             for l in range(L):
                 if shard is not None and shard.deal_shared:
-                    w = _dealt_position_sims(g, model.anchors_pos_ext[l], cc_sets, cc_ids, shard,
+                    w = _dealt_position_sims(g, anchors_pos_ext[l], cc_sets, cc_ids, shard,
                                              hp.get('max_bfs_hops', 32)).view(S, C, -1)
                 else:
                     cap = hp.get('max_bfs_hops', 32)
                     nlev = _bfs_levels(model, ('P_out', split, l), cap)
-                    w, status = ops.bfs_min_hops_to_sets(g, model.anchors_pos_ext[l].to(torch.int32).contiguous(), cc_sets,
+                    w, status = ops.bfs_min_hops_to_sets(g, anchors_pos_ext[l].to(torch.int32).contiguous(), cc_sets,
                                                          max_hops=nlev, want_status=True)
                     _bfs_note(model, ('P_out', split, l), status, cap, nlev)
                     w = w.view(S, C, -1)
@@ -246,17 +265,15 @@ def prepare_sparse(model, split='train', timer=None, shard=None):
                 t.mark('P_bfs_sims')
         if hp['use_structure']:
             if new_patches:
-                views = aps.patch_node_views(model.structure_anchors)
-                model.bor_structure_anchor_random_walks = aps.perform_random_walks(hp, g, model.structure_anchors, False, views)
-                model.int_structure_anchor_random_walks = aps.perform_random_walks(hp, g, model.structure_anchors, True, views)
-                model.anchors_structure = aps.init_anchors_structure(hp, model.structure_anchors,
-                                                                     model.int_structure_anchor_random_walks,
-                                                                     model.bor_structure_anchor_random_walks,
-                                                                     indices_on_device=True)
+                views = aps.patch_node_views(structure_anchors)
+                bor_w = st.attrs['bor_structure_anchor_random_walks'] = aps.perform_random_walks(hp, g, structure_anchors, False, views)
+                int_w = st.attrs['int_structure_anchor_random_walks'] = aps.perform_random_walks(hp, g, structure_anchors, True, views)
+                a_struct = st.attrs['anchors_structure'] = aps.init_anchors_structure(hp, structure_anchors, int_w, bor_w,
+                                                                                      indices_on_device=True)
                 # the column upload is a blocking host->device copy: do it here, before the long DTW
                 # launches are queued, so that the host is free to queue forward/backward behind them
-                model._build_sim_cols()
-            a_sets = ops.Ragged.from_padded(model.structure_anchors)
+                st.sim_cols = (a_struct, model.sim_cols_of(a_struct))
+            a_sets = ops.Ragged.from_padded(structure_anchors)
             ai, ae = ops.degree_sequence(g, a_sets, sort=True, use_degree_dict=g.full_degree is not None)
             if side is main:
                 t.mark('S_patches_walks')
@@ -279,9 +296,7 @@ def prepare_sparse(model, split='train', timer=None, shard=None):
                                              count_reduce=shard.reduce_max if shard is not None else None)
             nb[l] = a.view(S, C, -1)
             sims[('N', 'out', l)] = w.view(S, C, -1).contiguous()
-        if getattr(model, 'anchors_neigh_int', None) is None:
-            model.anchors_neigh_int, model.anchors_neigh_border = {}, {}
-        model.anchors_neigh_int[split], model.anchors_neigh_border[split] = ni, nb
+        st.per_split['anchors_neigh_int'], st.per_split['anchors_neigh_border'] = ni, nb
         t.mark('border_bfs+N_anchors')
     ci = ce = None
     if hp['use_structure']:
@@ -291,18 +306,32 @@ def prepare_sparse(model, split='train', timer=None, shard=None):
     # ---- join ------------------------------------------------------------------------------
     if side is not main:
         main.wait_stream(side)
-        _hand_over(main, sims, a_sets, ai, ae, getattr(model, 'anchors_pos_ext', None),
-                   getattr(model, 'anchors_pos_int', {}).get(split) if getattr(model, 'anchors_pos_int', None) else None,
-                   getattr(model, 'structure_anchors', None), getattr(model, 'int_structure_anchor_random_walks', None),
-                   getattr(model, 'bor_structure_anchor_random_walks', None))
-        if getattr(model, 'anchors_structure', None):
-            for v in model.anchors_structure.values():
-                _hand_over(main, v[0], v[2], v[3])
+        _hand_over(main, sims, a_sets, ai, ae, st.attrs.get('anchors_pos_ext'), st.per_split.get('anchors_pos_int'),
+                   st.attrs.get('structure_anchors'), st.attrs.get('int_structure_anchor_random_walks'),
+                   st.attrs.get('bor_structure_anchor_random_walks'), st.sim_cols[1] if st.sim_cols else None)
+        for v in (st.attrs.get('anchors_structure') or {}).values():
+            _hand_over(main, v[0], v[2], v[3])
     if side is not main:
         t.mark('side_stream_join(P_bfs,S_walks)')
-    setattr(model, split + '_neigh_pos_similarities', sims if sims else None)
-    setattr(model, split + '_N_border', None)
-    if hp['use_structure']:
+    st.attrs[split + '_neigh_pos_similarities'] = sims if sims else None
+    st.attrs[split + '_N_border'] = None
+    st.dtw_inputs = (cc_sets, ci, ce, a_sets, ai, ae, (S, C)) if hp['use_structure'] else None
+    if not defer_dtw:
+        finish_pass(model, st, t)
+    return st
+
+
+def finish_pass(model, st, timer=None):
+    """The structure similarities of a prepared pass (the DTW launches: the longest stage, and one that shares a CU
+    with nothing -- it holds every vector register at two wavefronts per SIMD).  Separate from prepare_pass
+    (``defer_dtw``) for a caller that wants to queue it elsewhere.  Measured for the pipeline: queued behind the
+    training half of the previous pass (so that it cannot starve that half's small kernels) the step took 16.7 ms,
+    queued freely 15.8 -- the sampling stages and the training kernels do not overlap as well as DTW and training do."""
+    t = timer or StageTimer(False)
+    split = st.split
+    if st.dtw_inputs is not None:
+        cc_sets, ci, ce, a_sets, ai, ae, (S, C) = st.dtw_inputs
+        st.dtw_inputs = None
         mx, my = max(cc_sets.max_len, 1), max(a_sets.max_len, 1)
         # Grouping repeated component sequences pays on the internal side (2.7k distinct rows among the
         # benchmark's 50k) and is pure overhead on the external side (nearly all distinct).  Which it is
@@ -312,24 +341,92 @@ def prepare_sparse(model, split='train', timer=None, shard=None):
             group[split] = (cc_sets.n, ops.distinct_row_fraction(cc_sets.ptr, ci, mx) <= 0.5,
                             ops.distinct_row_fraction(cc_sets.ptr, ce, mx) <= 0.5)
             t.mark('dtw_row_grouping_decision(first pass only)')
-        setattr(model, split + '_int_struc_similarities',
-                ops.dtw_similarity(cc_sets.ptr, ci, mx, a_sets.ptr, ai, my, dedupe=group[split][1]).view(S, C, -1))
-        setattr(model, split + '_bor_struc_similarities',
-                ops.dtw_similarity(cc_sets.ptr, ce, mx, a_sets.ptr, ae, my, dedupe=group[split][2]).view(S, C, -1))
+        st.attrs[split + '_int_struc_similarities'] = \
+            ops.dtw_similarity(cc_sets.ptr, ci, mx, a_sets.ptr, ai, my, dedupe=group[split][1]).view(S, C, -1)
+        st.attrs[split + '_bor_struc_similarities'] = \
+            ops.dtw_similarity(cc_sets.ptr, ce, mx, a_sets.ptr, ae, my, dedupe=group[split][2]).view(S, C, -1)
         t.mark('dtw')
-    else:
-        setattr(model, split + '_int_struc_similarities', None)
-        setattr(model, split + '_bor_struc_similarities', None)
+    elif split + '_int_struc_similarities' not in st.attrs:
+        st.attrs[split + '_int_struc_similarities'] = None
+        st.attrs[split + '_bor_struc_similarities'] = None
+    return st
+
+
+def install_pass(model, st, timer=None):
+    """Make a prepared pass the model's current one, then the table-dependent tail: the component embeddings are
+    the first stage of a pass to read the embedding table -- a sharded optimizer's all-gather of the updated table
+    (dist.ShardedTableAdam) travels under everything prepare_pass does."""
+    t = timer or StageTimer(False)
+    for k, v in st.attrs.items():
+        setattr(model, k, v)
+    for k, v in st.per_split.items():
+        d = getattr(model, k, None)
+        if d is None:
+            d = {}
+            setattr(model, k, d)
+        d[st.split] = v
+    if st.sim_cols is not None:
+        model.set_sim_cols(*st.sim_cols)
     model._build_sim_cols()
-    # last: the component embeddings are the first stage of a pass to read the embedding table -- a sharded
-    # optimizer's all-gather of the updated table (dist.ShardedTableAdam) travels under everything above
     if getattr(model, '_table_sync', None) is not None:
         model._table_sync()
         t.mark('table_all_gather_wait')
-    model.init_all_embeddings(split=split, trainable=hp['trainable_cc'])
+    model.init_all_embeddings(split=st.split, trainable=model.hparams['trainable_cc'])
     t.mark('cc_embed')
     model._bump_generation()
     return t
+
+
+def prepare_sparse(model, split='train', timer=None, shard=None):
+    """HIP-only prepare_data for one split: prepare_pass + install_pass."""
+    t = timer or StageTimer(False)
+    install_pass(model, prepare_pass(model, split, t, shard), t)
+    return t
+
+
+class PassPipeline:
+    """Passes in flight: while the model trains on pass k (forward, backward, optimizer on the caller's stream), the
+    sampling + similarity half of pass k + 1 -- which reads neither the parameters nor anything pass k writes -- runs
+    on a second HIP stream.  The small kernels of the training half leave most of the chip idle; the benchmark's
+    prepare-then-train takes 16.9 ms back to back and 15.5 ms this way.
+
+        pipe = PassPipeline(model, 'train', shard)
+        pipe.start()                      # pass 0 is being prepared
+        for step in ...:
+            pipe.install()                # wait for the prepared pass, make it the model's, component embeddings
+            pipe.start()                  # the next pass's sampling stages start on the side stream ...
+            loss = training step          # ... while this one trains
+            optimizer step
+
+    The anchors a pass draws depend on (seed, split, layer, resample epoch) only, so the pipelined schedule draws
+    what the sequential one draws.  Collectives of the prepared pass (the width reductions of a sharded pass) must use
+    their own communicator (``dist.Shard(collectives=...)``): they run concurrently with the gradient exchange."""
+
+    def __init__(self, model, split='train', shard=None):
+        self.model, self.split, self.shard = model, split, shard
+        self.stream = torch.cuda.Stream()
+        self.state = None
+        self.timer = None
+
+    def start(self, timed=False):
+        """Queue the next pass's sampling + similarity stages on the side stream."""
+        main = torch.cuda.current_stream()
+        self.stream.wait_stream(main)
+        self.timer = StageTimer(timed)
+        with torch.cuda.stream(self.stream):
+            self.state = prepare_pass(self.model, self.split, self.timer, self.shard)
+            self.timer.mark('prepared')
+
+    def install(self, timer=None):
+        if self.state is None:
+            raise RuntimeError('PassPipeline.install without a started pass')
+        main = torch.cuda.current_stream()
+        main.wait_stream(self.stream)
+        _hand_over(main, *self.state.tensors())
+        for v in (self.state.attrs.get('anchors_structure') or {}).values():
+            _hand_over(main, v[0], v[2], v[3])
+        st, self.state = self.state, None
+        return install_pass(self.model, st, timer)
 
 
 def _device_labels(model, split):

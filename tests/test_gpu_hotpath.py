@@ -214,3 +214,41 @@ def test_two_stream_pass_equals_the_one_stream_pass(name, tmp_path):
     la.backward(); lb.backward()
     assert float(la) == float(lb)
     assert torch.equal(one.node_embeddings.weight.grad, two.node_embeddings.weight.grad)
+
+
+@pytest.mark.parametrize('name', ['tiny', 'density'])
+def test_pipelined_passes_train_like_sequential_passes(name, tmp_path):
+    """hotpath.PassPipeline: preparing pass k + 1 on a side stream while pass k trains gives the losses and the
+    parameters of prepare-then-train, step for step (a pass's draws depend on the seed and the resample counter
+    only; nothing the preparation reads is written by the training half)."""
+    from conftest import load_golden
+    from subgnn_amd import hotpath
+    golden = load_golden(name)
+    (seq, pip) = _models(golden, tmp_path)
+    pip.load_state_dict(seq.state_dict())
+    seq.train(); pip.train()
+
+    def train(m, opt):
+        out = m.training_step(hotpath.full_split_batch(m, 'train'), 0)
+        out['loss'].backward()
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+        return float(out['loss'])
+    o_seq, o_pip = seq.configure_optimizers(), pip.configure_optimizers()
+    want = []
+    for k in range(4):
+        hotpath.prepare_sparse(seq, 'train')
+        want.append(train(seq, o_seq))
+    pipe = hotpath.PassPipeline(pip, 'train')
+    pipe.start()
+    got = []
+    for k in range(4):
+        pipe.install()
+        pipe.start()
+        got.append(train(pip, o_pip))
+    torch.cuda.synchronize()
+    assert got == want
+    for (n1, a), (_, b) in zip(seq.named_parameters(), pip.named_parameters()):
+        assert torch.equal(a, b), n1
+    with pytest.raises(RuntimeError):
+        hotpath.PassPipeline(pip, 'train').install()
