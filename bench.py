@@ -372,6 +372,7 @@ def main():
                                (n, args.m, int(rowptr[-1]) // 2, args.subgraphs, args.subgraph_nodes,
                                 'per GPU' if args.scaling == 'weak' else 'in total', args.embed),
                    'subgraphs_per_gpu': S, 'subgraphs_total': total_subgraphs,
+                   'schedule': {'passes_pipelined': pipe is not None, 'two_stream_preparation': bool(hp.get('overlap_streams', True))},
                    'parallelism': ('dp%d (subgraph shards; head on the rank\'s own rows, all-reduce of the small gradients, '
                                    'reduce-scatter / all-gather of the embedding table)' % world) if not replicated else
                                   ('dp%d (subgraph shards; RCCL all-gather of the channel embeddings into a replicated head, '
@@ -397,6 +398,10 @@ def main():
                              'it actually reads).  out_of_cache: the same kernel on a BA n=8M m=16 graph (CSR 1.09 GB), '
                              'tools/degseq_hbm_probe.py + rocprofv3 counters, profiles/r02_degseq_traffic.json'},
         'stages_ms': {k: round(v, 3) for k, v in stage_ms.items()},
+        'stages_note': ('HIP-event time per stage on the stream it runs on; ' + ('pipelined: the preparation stages (components ... dtw) of pass k+1 '
+                        'run on a second stream beside cc_embed / forward / backward / optimizer of pass k, which stretch each other -- '
+                        'the stage times do not add up to the step (--no-pipeline with SGNN_OVERLAP_STREAMS=0: they do)' if pipe is not None
+                        else 'sequential passes')),
         'loss': loss, 'setup_s': round(t_gen, 1), 'priming_passes_before_warmup': PRIMING_PASSES,
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
