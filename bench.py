@@ -359,6 +359,24 @@ def main():
             out_of_cache[fam] = {form: {k: c[form][k] for k in ('ms_per_launch', 'algorithmic_frac_of_8TBs',
                                                                 'memory_side_frac_of_8TBs', 'traffic_over_algorithmic')}
                                  for form in ('streaming', 'shipped_search')}
+    # the kernel that dominates the pass by TIME is not an HBM kernel: the DTW launch is bound by fp64 vector issue.  Its
+    # counters are a committed measurement (tools/run_dtw_pmc.sh), quoted beside the roofline of the HBM-class kernel.
+    longest = None
+    pj = os.path.join(REPO, 'profiles', 'r02_dtw_pmc.json')
+    if os.path.exists(pj):
+        pm = json.load(open(pj))
+        kk = [k for k in pm if 'dtw_similarity' in k]
+        if kk and stage_ms.get('dtw'):
+            c = pm[kk[0]]
+            longest = {'kernel': kk[0].split('(')[0], 'bound': 'fp64 vector issue (not HBM, not MFMA)',
+                       'share_of_step': round(stage_ms['dtw'] / (1e3 * elapsed / args.steps), 3),
+                       'simd_valu_busy': round(2 * c['frac_wave_cycles_valu_active'], 3),
+                       'wave_cycles': {'issuing': round(c['frac_wave_cycles_issuing'], 3),
+                                       'waiting_on_memory_or_barrier': round(c['frac_wave_cycles_waiting_waitcnt_or_barrier'], 3),
+                                       'issue_stalled': round(c['frac_wave_cycles_issue_stalled'], 3)},
+                       'valu_instructions_per_wave': round(c['valu_instructions_per_wave']),
+                       'source': 'profiles/r02_dtw_pmc.json (rocprofv3 --pmc, committed measurement; 2 wavefronts per SIMD, so '
+                                 'SIMD busy = 2 x the per-wave VALU-active fraction)'}
     result = {
         'metric': 'subgraphs/sec fwd+bwd (all 3 channels on) + achieved HBM GB/s',
         'value': total_subgraphs * args.steps / elapsed, 'unit': 'subgraphs/s', 'n_gpus': world, 'steps': args.steps,
@@ -397,6 +415,7 @@ def main():
                              'runs shipped_form (same results; it is latency-, not bandwidth-bound: its frac prices the bytes '
                              'it actually reads).  out_of_cache: the same kernel on a BA n=8M m=16 graph (CSR 1.09 GB), '
                              'tools/degseq_hbm_probe.py + rocprofv3 counters, profiles/r02_degseq_traffic.json'},
+        'longest_kernel': longest,
         'stages_ms': {k: round(v, 3) for k, v in stage_ms.items()},
         'stages_note': ('HIP-event time per stage on the stream it runs on; ' + ('pipelined: the preparation stages (components ... dtw) of pass k+1 '
                         'run on a second stream beside cc_embed / forward / backward / optimizer of pass k, which stretch each other -- '
