@@ -78,6 +78,9 @@ def parse():
     ap.add_argument('--no-pipeline', action='store_true',
                     help='prepare every pass after the previous one has finished training (default: the sampling + similarity '
                          'half of pass k+1 runs on a second HIP stream while pass k trains: hotpath.PassPipeline)')
+    ap.add_argument('--pipeline-multi', action='store_true',
+                    help='N>1, weak scaling: pipeline the passes as at N=1 (the prepared pass reduces its padded widths on its '
+                         'own communicator while the pass in training exchanges gradients)')
     ap.add_argument('--head', choices=['sharded', 'replicated'], default='sharded',
                     help='N>1: the read-out + MLP head on the rank\'s own rows (gradients averaged), or replicated on the '
                          'all-gathered channel embeddings')
@@ -173,7 +176,10 @@ def main():
         hp.update(json.loads(os.environ['SGNN_BENCH_HP']))
     S = len(subs)
     multi = dist is not None and world > 1
-    pipelined = not args.no_pipeline and not (multi and args.scaling == 'strong')
+    # Multi-rank runs keep the sequential schedule unless asked (--pipeline-multi): the pipelined one issues the prepared
+    # pass's width reductions on a second stream beside the gradient exchange -- two communicators in flight, which a
+    # one-GPU functional check over gloo cannot validate for RCCL over xGMI
+    pipelined = not args.no_pipeline and (not multi or (args.pipeline_multi and args.scaling != 'strong'))
     # the prepared pass's width reductions run beside the gradient exchange of the pass in training: own communicator
     shard_group = dist.new_group() if (multi and pipelined) else None
     shard = sdist.Shard(total_subgraphs, rank, world, deal_shared=(args.scaling == 'strong'), group=shard_group) if multi else None
