@@ -276,8 +276,9 @@ int sgnn_bfs_min_hops_to_sets(const int64_t* rowptr, const int32_t* col, int64_t
  * unaffected; putting similar rows next to each other keeps a wavefront's lanes in step.
  * workspace: sgnn_dtw_workspace_bytes(n_x, max_x_len, n_y, max_y_len) bytes (any content).
  * ------------------------------------------------------------------------------------- */
-/* Keys whose ascending order is a good processing order (x_order) for sgnn_dtw_similarity: (length, four
- * quantiles of the row), packed into an int64 per x row.  Sorting by them is the caller's (any sort). */
+/* Keys whose ascending order is a good processing order (x_order) for sgnn_dtw_similarity: (length, up to six
+ * entries of the row's twice-halved series on a log scale), packed into an int64 per x row; empty rows sort first.
+ * Sorting by them is the caller's (any sort). */
 int sgnn_dtw_order_keys(const int64_t* x_ptr, const int32_t* x_val, int64_t n_x, int64_t* out_keys, void* stream);
 int64_t sgnn_dtw_workspace_bytes(int64_t n_x, int64_t max_x_len, int64_t n_y, int64_t max_y_len);
 /* test hook: force the general (workspace-resident) kernel instead of the register-resident one

@@ -1107,22 +1107,31 @@ __global__ __launch_bounds__(DTW_THREADS, MINB) void dtw_similarity_reg_kernel(
     }
 }
 
-// Processing-order key of the x rows of a DTW call: (length, the series sampled at its start, thirds and
-// end), saturating fields of 12 | 12 | 12 | 13 | 14 bits.  Rows are sorted degree sequences; sorting them by
-// this key puts series of similar shape side by side, so that the lanes of a wavefront sweep similar
-// windows (8.9 ms unordered, 7.5 ms in this order on the benchmark's external side).  One launch
-// instead of ~40 element-wise ones.
+// Processing-order key of the x rows of a DTW call: (length, the row's TWICE-HALVED series -- means of four
+// consecutive entries, what fastdtw's second coarsening level sees -- on a log scale, 8 steps per octave, up to six of
+// them, first to last).  A pair's finest-level window follows from its coarse warp paths, and those from the coarse
+// series: rows whose coarse series agree sweep the same windows, so the lanes of a wavefront (consecutive rows of the
+// order, same anchor) stay in step.  Replay of 32 wavefronts of the benchmark's external side through the oracle:
+// cells evaluated per pair on the finest level 558 with round 1's key (length, four quantiles of the raw row), 500
+// with this one (a lane's own window: 347); kernel 7.1 -> see DESIGN.  Results do not depend on the order.
 __global__ void dtw_order_keys_kernel(const int64_t* __restrict__ x_ptr, const int32_t* __restrict__ x_val, int64_t n_x,
                                       int64_t* __restrict__ keys)
 {
     const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (i >= n_x) return;
     const int64_t b = x_ptr[i], len = x_ptr[i + 1] - b;
-    int64_t key = 0;
-    if (len > 0) {
-        const int64_t q0 = x_val[b], q1 = x_val[b + len / 3], q2 = x_val[b + (2 * len) / 3], q3 = x_val[b + len - 1];
-        auto sat = [](int64_t v, int64_t m) { return v < 0 ? (int64_t)0 : (v > m ? m : v); };
-        key = (sat(len, 0xFFF) << 51) | (sat(q0, 0xFFF) << 39) | (sat(q1, 0xFFF) << 27) | (sat(q2, 0x1FFF) << 14) | sat(q3, 0x3FFF);
+    int64_t key = (len > 0xFFF ? (int64_t)0xFFF : len) << 48;
+    auto q8 = [](float v) { const int q = (int)lrintf(8.f * log2f(1.f + (v < 0.f ? 0.f : v))); return (int64_t)(q > 255 ? 255 : q); };
+    const int64_t n2 = len / 4;
+    if (n2 == 0) {
+        for (int64_t f = 0; f < len; ++f) key |= q8((float)x_val[b + f]) << (40 - 8 * f);
+    } else {
+        const int64_t nf = n2 < 6 ? n2 : 6;
+        for (int64_t f = 0; f < nf; ++f) {
+            const int64_t g = b + 4 * ((f * n2) / nf);
+            const float v = 0.25f * ((float)x_val[g] + (float)x_val[g + 1] + (float)x_val[g + 2] + (float)x_val[g + 3]);
+            key |= q8(v) << (40 - 8 * f);
+        }
     }
     keys[i] = key;
 }

@@ -602,7 +602,7 @@ def dtw_similarity(x_ptr, x_val, max_x, y_ptr, y_val, max_y, tie_order=0, order_
     """1/(1+fastdtw) for all (x row, y row) pairs -> (n_x, n_y) float32; empty x rows -> PAD.
     ``dedupe``: identical x rows (sorted degree sequences of small components repeat a lot: 50k BFS
     components of the benchmark have 2.7k distinct internal sequences) are computed once and the
-    result rows gathered back.  ``order_rows``: process the x rows sorted by (length, four quantiles) so
+    result rows gathered back.  ``order_rows``: process the x rows sorted by (length, coarse series) so
     that the lanes of a wavefront work on similar series.  Neither changes any value."""
     if dedupe and x_ptr.numel() - 1 > 1024 and max_x <= 64:
         # no host round trip: every row keeps its slot, the rows that repeat an earlier one are given
@@ -641,8 +641,8 @@ def dtw_similarity(x_ptr, x_val, max_x, y_ptr, y_val, max_y, tie_order=0, order_
         # (length, then the series sampled at its start, thirds and end): rows are sorted degree
         # sequences, four quantiles place a series' shape well enough that the lanes of a wavefront
         # sweep similar windows -- one int64 key per row (sgnn_dtw_order_keys), no host round trip.
-        # Measured on the benchmark's external side: unordered 8.9 ms, (length, median, sum) 8.1 ms,
-        # this key 7.5 ms, full lexicographic order 7.9 ms.
+        # Measured on the benchmark's external side (round 1 kernel): unordered 8.9 ms, (length, median, sum) 8.1 ms,
+        # (length, four quantiles) 7.5 ms, full lexicographic order 7.9 ms; round 2: the coarse-series key, see the kernel.
         key = torch.empty(nx, dtype=torch.int64, device=x_ptr.device)
         check(lib.sgnn_dtw_order_keys(_ptr(x_ptr), _ptr(x_val), nx, _ptr(key), _stream()), 'sgnn_dtw_order_keys')
         order = torch.argsort(key).to(torch.int32).contiguous()
