@@ -161,11 +161,49 @@ __global__ __launch_bounds__(256) void masked_sum_bwd_kernel(const float* __rest
     }
 }
 
+// the same with four consecutive columns per thread (16-byte loads and stores, one index division per four elements):
+// H a multiple of 4 and 16-byte aligned pointers -- the read-out of the benchmark (50k x 448) went from 2.5 to ~5 TB/s
+__global__ __launch_bounds__(256) void masked_sum_fwd4_kernel(const float4* __restrict__ x, const uint8_t* __restrict__ mask,
+                                                              int64_t B, int64_t C, int64_t H4, float4* __restrict__ out)
+{
+    const int64_t total = B * H4;
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = t / H4, h = t % H4;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int64_t c = 0; c < C; ++c)
+            if (mask[b * C + c]) {
+                const float4 v = x[(b * C + c) * H4 + h];
+                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+            }
+        out[t] = acc;
+    }
+}
+
+__global__ __launch_bounds__(256) void masked_sum_bwd4_kernel(const float4* __restrict__ g, const uint8_t* __restrict__ mask,
+                                                              int64_t B, int64_t C, int64_t H4, float4* __restrict__ gx)
+{
+    const int64_t total = B * C * H4;
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t bc = t / H4, h = t % H4;
+        gx[t] = mask[bc] ? g[(bc / C) * H4 + h] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+
+static inline bool ms_vec4_ok(const void* a, const void* b, int64_t H) {
+    return H % 4 == 0 && (((uintptr_t)a | (uintptr_t)b) & 15) == 0;
+}
+
 extern "C" int sgnn_masked_sum_fwd(const float* x, const uint8_t* mask, int64_t B, int64_t C, int64_t H,
                                    float* out, void* stream)
 {
     if (!x || !mask || !out || B < 0 || C < 0 || H < 0) return SGNN_ERR_BAD_ARG;
     if (B * H == 0) return SGNN_OK;
+    if (ms_vec4_ok(x, out, H)) {
+        hipLaunchKernelGGL(masked_sum_fwd4_kernel, dim3(sgnn_grid_for(B * (H / 4), 256)), dim3(256), 0, (hipStream_t)stream,
+                           (const float4*)x, mask, B, C, H / 4, (float4*)out);
+        SGNN_CHECK_LAUNCH();
+        return SGNN_OK;
+    }
     hipLaunchKernelGGL(masked_sum_fwd_kernel, dim3(sgnn_grid_for(B * H, 256)), dim3(256), 0, (hipStream_t)stream, x,
                        mask, B, C, H, out);
     SGNN_CHECK_LAUNCH();
@@ -177,6 +215,12 @@ extern "C" int sgnn_masked_sum_bwd(const float* grad_out, const uint8_t* mask, i
 {
     if (!grad_out || !mask || !grad_x || B < 0 || C < 0 || H < 0) return SGNN_ERR_BAD_ARG;
     if (B * C * H == 0) return SGNN_OK;
+    if (ms_vec4_ok(grad_out, grad_x, H)) {
+        hipLaunchKernelGGL(masked_sum_bwd4_kernel, dim3(sgnn_grid_for(B * C * (H / 4), 256)), dim3(256), 0, (hipStream_t)stream,
+                           (const float4*)grad_out, mask, B, C, H / 4, (float4*)grad_x);
+        SGNN_CHECK_LAUNCH();
+        return SGNN_OK;
+    }
     hipLaunchKernelGGL(masked_sum_bwd_kernel, dim3(sgnn_grid_for(B * C * H, 256)), dim3(256), 0, (hipStream_t)stream,
                        grad_out, mask, B, C, H, grad_x);
     SGNN_CHECK_LAUNCH();

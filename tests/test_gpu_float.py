@@ -241,11 +241,12 @@ def test_gather_rows_matches_embedding_with_padding_idx(det):
     assert float(Wg.grad[0].abs().max()) == 0.0
 
 
-def test_masked_sum():
+@pytest.mark.parametrize('shape', [(17, 5, 37), (33, 3, 448), (50, 1, 64)])     # scalar form; 16-byte form (H % 4 == 0)
+def test_masked_sum(shape):
     ops = _ops()
     g = torch.Generator().manual_seed(0)
-    x = torch.randn(17, 5, 37, generator=g)
-    mask = torch.rand(17, 5, generator=g) > 0.3
+    x = torch.randn(*shape, generator=g)
+    mask = torch.rand(shape[0], shape[1], generator=g) > 0.3
     xc = x.clone().requires_grad_(True)
     ref = (xc * mask.unsqueeze(-1)).sum(1)
     go = torch.randn(ref.shape, generator=g)
