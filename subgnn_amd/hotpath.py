@@ -337,14 +337,18 @@ def finish_pass(model, st, timer=None):
         # benchmark's 50k) and is pure overhead on the external side (nearly all distinct).  Which it is
         # depends only on the split's components and the graph: decided on the first pass, kept.
         group = model.__dict__.setdefault('_dtw_group_rows', {})
+        xprep = model.__dict__.setdefault('_dtw_x_prep', {})
         if group.get(split) is None or group[split][0] != cc_sets.n:
             group[split] = (cc_sets.n, ops.distinct_row_fraction(cc_sets.ptr, ci, mx) <= 0.5,
                             ops.distinct_row_fraction(cc_sets.ptr, ce, mx) <= 0.5)
+            xprep[split] = ({}, {})
             t.mark('dtw_row_grouping_decision(first pass only)')
+        # the component side of the DTW calls (grouping of repeated degree sequences, processing order) depends on the
+        # split's components only -- the same every pass: kept from the first one (xprep), like the dispatch orders
         st.attrs[split + '_int_struc_similarities'] = \
-            ops.dtw_similarity(cc_sets.ptr, ci, mx, a_sets.ptr, ai, my, dedupe=group[split][1]).view(S, C, -1)
+            ops.dtw_similarity(cc_sets.ptr, ci, mx, a_sets.ptr, ai, my, dedupe=group[split][1], x_prep=xprep[split][0]).view(S, C, -1)
         st.attrs[split + '_bor_struc_similarities'] = \
-            ops.dtw_similarity(cc_sets.ptr, ce, mx, a_sets.ptr, ae, my, dedupe=group[split][2]).view(S, C, -1)
+            ops.dtw_similarity(cc_sets.ptr, ce, mx, a_sets.ptr, ae, my, dedupe=group[split][2], x_prep=xprep[split][1]).view(S, C, -1)
         t.mark('dtw')
     elif split + '_int_struc_similarities' not in st.attrs:
         st.attrs[split + '_int_struc_similarities'] = None

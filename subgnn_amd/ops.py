@@ -598,13 +598,21 @@ def distinct_row_fraction(x_ptr, x_val, max_x):
 
 
 def dtw_similarity(x_ptr, x_val, max_x, y_ptr, y_val, max_y, tie_order=0, order_rows=True, dedupe=True, order=None,
-                   _live=None):
+                   _live=None, x_prep=None):
     """1/(1+fastdtw) for all (x row, y row) pairs -> (n_x, n_y) float32; empty x rows -> PAD.
     ``dedupe``: identical x rows (sorted degree sequences of small components repeat a lot: 50k BFS
     components of the benchmark have 2.7k distinct internal sequences) are computed once and the
     result rows gathered back.  ``order_rows``: process the x rows sorted by (length, coarse series) so
-    that the lanes of a wavefront work on similar series.  Neither changes any value."""
+    that the lanes of a wavefront work on similar series.  Neither changes any value.
+    ``x_prep``: a dict the caller keeps for THESE x rows (the degree sequences of a split's components are the same
+    every pass): the grouping of repeated rows and the processing order are computed on the first call and reused."""
     if dedupe and x_ptr.numel() - 1 > 1024 and max_x <= 64:
+        kept = x_prep.get('dedupe') if x_prep is not None else None
+        if kept is not None and kept[2].numel() == x_ptr.numel() - 1:
+            uptr, uval, rep, live = kept
+            out_u = dtw_similarity(uptr, uval, max_x, y_ptr, y_val, max_y, tie_order, order_rows, dedupe=False, order=order,
+                                   _live=live, x_prep=x_prep.setdefault('grouped', {}))
+            return out_u.index_select(0, rep)
         # no host round trip: every row keeps its slot, the rows that repeat an earlier one are given
         # length 0 (their pairs exit at once -- sorted by length they fill whole wavefronts) and read
         # their representative's result row afterwards
@@ -625,8 +633,10 @@ def dtw_similarity(x_ptr, x_val, max_x, y_ptr, y_val, max_y, tie_order=0, order_
             # range (a device-side pair, no round trip) so that it deals its lanes over the live rows only
             n_live = (lens > 0).sum()
             live = torch.stack((n - n_live, n_live))
+        if x_prep is not None:
+            x_prep['dedupe'] = (uptr, uval, rep, live)
         out_u = dtw_similarity(uptr, uval, max_x, y_ptr, y_val, max_y, tie_order, order_rows, dedupe=False, order=order,
-                               _live=live)
+                               _live=live, x_prep=x_prep.setdefault('grouped', {}) if x_prep is not None else None)
         return out_u.index_select(0, rep)
     lib = _lib.load()
     for t, nm in ((x_ptr, 'x_ptr'), (y_ptr, 'y_ptr')):
@@ -643,9 +653,13 @@ def dtw_similarity(x_ptr, x_val, max_x, y_ptr, y_val, max_y, tie_order=0, order_
         # sweep similar windows -- one int64 key per row (sgnn_dtw_order_keys), no host round trip.
         # Measured on the benchmark's external side (round 1 kernel): unordered 8.9 ms, (length, median, sum) 8.1 ms,
         # (length, four quantiles) 7.5 ms, full lexicographic order 7.9 ms; round 2: the coarse-series key, see the kernel.
-        key = torch.empty(nx, dtype=torch.int64, device=x_ptr.device)
-        check(lib.sgnn_dtw_order_keys(_ptr(x_ptr), _ptr(x_val), nx, _ptr(key), _stream()), 'sgnn_dtw_order_keys')
-        order = torch.argsort(key).to(torch.int32).contiguous()
+        order = x_prep.get('order') if x_prep is not None else None
+        if order is None or order.numel() != nx:
+            key = torch.empty(nx, dtype=torch.int64, device=x_ptr.device)
+            check(lib.sgnn_dtw_order_keys(_ptr(x_ptr), _ptr(x_val), nx, _ptr(key), _stream()), 'sgnn_dtw_order_keys')
+            order = torch.argsort(key).to(torch.int32).contiguous()
+            if x_prep is not None:
+                x_prep['order'] = order
     wsb = lib.sgnn_dtw_workspace_bytes(nx, max_x, ny, max_y)
     ws = torch.empty(wsb // 8 + 1, dtype=torch.int64, device=x_ptr.device)
     if _live is not None and order is not None:

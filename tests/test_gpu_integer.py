@@ -854,3 +854,23 @@ def test_degree_sequence_understated_set_bound_is_loud():
                                         r.n, 64, 1, p(oi), p(oe), None, ops._stream()), 'sgnn_degree_sequence')
     assert bool((oi[20:120] == torch.iinfo(torch.int32).min).all()) and bool((oe[20:120] == torch.iinfo(torch.int32).min).all())
     assert torch.equal(oi[:20], good_i[:20]) and torch.equal(oi[120:135], good_i[120:135])
+
+
+def test_dtw_similarity_kept_row_preparation(golden):
+    """x_prep: the grouping of repeated x rows and the processing order are kept by the caller and reused; same values."""
+    ops = _ops()
+    rng = np.random.default_rng(5)
+    base = [sorted(rng.integers(0, 9, size=rng.integers(1, 12)).tolist()) for _ in range(40)]
+    xs = [base[i] for i in rng.integers(0, 40, size=3000)]                  # many repeats: the grouping branch
+    ys = [sorted(rng.integers(0, 30, size=rng.integers(3, 25)).tolist()) for _ in range(9)]
+    X, Y = ops.Ragged.from_lists(xs, DEV), ops.Ragged.from_lists(ys, DEV)
+    want = ops.dtw_similarity(X.ptr, X.nodes, 12, Y.ptr, Y.nodes, 25)
+    keep = {}
+    for _ in range(3):
+        got = ops.dtw_similarity(X.ptr, X.nodes, 12, Y.ptr, Y.nodes, 25, x_prep=keep)
+        assert torch.equal(got, want)
+    assert 'dedupe' in keep and 'order' in keep['grouped']
+    keep2 = {}
+    for _ in range(2):
+        assert torch.equal(ops.dtw_similarity(X.ptr, X.nodes, 12, Y.ptr, Y.nodes, 25, dedupe=False, x_prep=keep2), want)
+    assert 'order' in keep2
