@@ -211,7 +211,9 @@ def main():
         channel_params = [p for p in small if id(p) not in head]
         labels_dev = all_labels.to(dev)
     else:
-        opt = model.configure_optimizers()
+        # clip + Adam with the 256 MB table in one HIP pass (optim.ClipAdam; torch's fused Adam for the small parameters)
+        from subgnn_amd import optim
+        opt = optim.ClipAdam(model.parameters(), hp['learning_rate'], max_norm=hp['grad_clip'])
     params = [p for p in model.parameters() if p.requires_grad]
 
     stage_ms = {}
@@ -237,8 +239,7 @@ def main():
         model.backward(None, out['loss'], None, 0)
         timer.mark('backward')
         if not multi:
-            torch.nn.utils.clip_grad_norm_(params, hp['grad_clip'])
-            opt.step()
+            opt.step()                                           # (clips first: ClipAdam)
             opt.zero_grad(set_to_none=True)
             timer.mark('optimizer')
             return timer, float(out['loss'].detach())

@@ -475,6 +475,16 @@ int sgnn_update_bwd(const float* grad_out, const float* out, const float* x, con
                     void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------
+ * a18  Adam on one large parameter in one pass (torch.optim.Adam's rule, no weight decay / amsgrad:
+ * SubGNN/SubGNN.py:1156-1161), with the caller's clip coefficient (train_config.py: gradient_clip_val) applied on the
+ * fly: grad_scale (nullable) is a DEVICE scalar, so the clip needs no host round trip.  step = 1 for the first update.
+ * zero_grad != 0: the gradient is zeroed in the same pass (the buffer can be handed out again without a fill).
+ * All four arrays float32[n], 16-byte aligned.
+ * ------------------------------------------------------------------------------------- */
+int sgnn_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
+                   float beta2, float eps, int64_t step, const float* grad_scale, int zero_grad, void* stream);
+
+/* ---------------------------------------------------------------------------------------
  * Measurement aid (no reference counterpart): streaming copy of n_bytes with 4 or 16 bytes per lane.
  * The rocprofv3 memory-side counters (FETCH_SIZE / WRITE_SIZE) are calibrated on it -- a known byte
  * count in the access width of the CSR gather -- before they are read as HBM traffic of

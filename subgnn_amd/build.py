@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIBDIR = os.path.join(HERE, 'lib')
 LIB = os.path.join(LIBDIR, 'libsubgnn_hip.so')
-SOURCES = ['lib.hip', 'degree_sequence.hip', 'graph_sets.hip', 'samplers.hip', 'similarity.hip', 'embed.hip', 'mpn.hip', 'attention.hip', 'lstm.hip', 'probe.hip', 'scatter.hip', 'update.hip']
+SOURCES = ['lib.hip', 'degree_sequence.hip', 'graph_sets.hip', 'samplers.hip', 'similarity.hip', 'embed.hip', 'mpn.hip', 'attention.hip', 'lstm.hip', 'probe.hip', 'scatter.hip', 'update.hip', 'optim.hip']
 ARCH = 'gfx950'
 
 

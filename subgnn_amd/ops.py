@@ -737,8 +737,22 @@ class _GradAcc:
 
     def buffer(self, shape, device):
         if self.buf is None:
-            self.buf = torch.zeros(shape, dtype=torch.float32, device=device)
+            self.buf = take_zeroed(shape, device)
         return self.buf
+
+
+_ZEROED = {}       # (shape, device) -> a gradient buffer an optimizer has zeroed in its update pass (optim.ClipAdam)
+
+
+def take_zeroed(shape, device):
+    """A zero-filled float32 buffer: one an optimizer handed back already zeroed (release_zeroed), else a fresh fill."""
+    buf = _ZEROED.pop((tuple(shape), torch.device(device)), None)
+    return buf if buf is not None else torch.zeros(shape, dtype=torch.float32, device=device)
+
+
+def release_zeroed(buf):
+    """``buf`` is all zeros and its owner is done with it: the next table-gradient accumulation takes it as is."""
+    _ZEROED[(tuple(buf.shape), buf.device)] = buf
 
 
 class _TableTap(torch.autograd.Function):
@@ -1059,6 +1073,15 @@ def update_layer(x, aggr, weight, bias):
     if x.is_cuda and x.dim() == 2 and x.shape[1] in UPDATE_DIMS and x.dtype == torch.float32:
         return _UpdateLayer.apply(x.contiguous(), aggr.contiguous(), weight, bias)
     return torch.relu(linear(torch.cat([x, aggr], dim=1), weight, bias))
+
+
+def adam_step(param, grad, exp_avg, exp_avg_sq, lr, betas, eps, step, grad_scale=None, zero_grad=False):
+    """One Adam update of a large float32 parameter in one pass (sgnn_adam_step); ``grad_scale``: device scalar."""
+    for t, nm in ((param, 'param'), (grad, 'grad'), (exp_avg, 'exp_avg'), (exp_avg_sq, 'exp_avg_sq'), (grad_scale, 'grad_scale')):
+        _req(t, torch.float32, nm)
+    check(_lib.load().sgnn_adam_step(_ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), param.numel(), float(lr),
+                                     float(betas[0]), float(betas[1]), float(eps), int(step), _ptr(grad_scale),
+                                     1 if zero_grad else 0, _stream()), 'sgnn_adam_step')
 
 
 class ZeroSims:

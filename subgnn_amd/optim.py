@@ -1,0 +1,64 @@
+"""Gradient clipping + Adam as the reference's caller runs them per step (train_config.py: Trainer(gradient_clip_val)
+-> clip_grad_norm_, then SubGNN.configure_optimizers' torch.optim.Adam, SubGNN/SubGNN.py:1156-1161), with the one large
+parameter -- the (N+1, D) embedding table -- updated by one HIP pass (sgnn_adam_step) instead of a multiply by the clip
+coefficient, four chunked multi-tensor launches and a zero fill of the gradient buffer on the next pass.
+
+The small parameters stay with torch's fused Adam (one launch for all of them).  Same update rule, same clipping rule
+(coefficient = min(1, max_norm / (total_norm + 1e-6)) over ALL parameters); the table's clip coefficient is a device
+scalar read by the kernel, so the step has no host round trip."""
+import torch
+
+from . import ops
+
+
+class ClipAdam:
+    """``step()`` = clip_grad_norm_(params, max_norm) followed by Adam(params, lr).step();  ``zero_grad()`` as usual."""
+
+    def __init__(self, params, lr, max_norm=None, betas=(0.9, 0.999), eps=1e-8, big_bytes=16 << 20):
+        params = [p for p in params if p.requires_grad]
+        self.lr, self.betas, self.eps, self.max_norm = float(lr), (float(betas[0]), float(betas[1])), float(eps), max_norm
+        self.big = [p for p in params if p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()
+                    and p.numel() * 4 >= big_bytes and p.data_ptr() % 16 == 0]
+        ids = {id(p) for p in self.big}
+        self.small = [p for p in params if id(p) not in ids]
+        self.small_opt = torch.optim.Adam(self.small, lr=lr, betas=betas, eps=eps,
+                                          fused=all(p.is_cuda for p in self.small)) if self.small else None
+        self.state = {id(p): {'step': 0, 'exp_avg': torch.zeros_like(p), 'exp_avg_sq': torch.zeros_like(p)} for p in self.big}
+
+    def step(self):
+        small_grads = [p.grad for p in self.small if p.grad is not None]
+        big = [p for p in self.big if p.grad is not None]
+        scale = None
+        if self.max_norm is not None and (small_grads or big):
+            norms = torch._foreach_norm(small_grads + [p.grad for p in big])
+            total = torch.linalg.vector_norm(torch.stack(norms))
+            coef = torch.clamp(self.max_norm / (total + 1e-6), max=1.0)
+            if small_grads:
+                torch._foreach_mul_(small_grads, coef)
+            scale = coef.reshape(1).float()
+        if self.small_opt is not None:
+            self.small_opt.step()
+        for p in big:
+            st = self.state[id(p)]
+            st['step'] += 1
+            g = p.grad
+            take = g.is_contiguous() and g.dtype == torch.float32 and g.data_ptr() % 16 == 0
+            if not take:
+                g = g.contiguous().float()
+            # the kernel zeroes the gradient it has just consumed: the buffer goes back to the fused ops'
+            # table-gradient accumulator as it is (ops.take_zeroed) instead of a 256 MB fill per pass
+            ops.adam_step(p.data, g, st['exp_avg'], st['exp_avg_sq'], self.lr, self.betas, self.eps, st['step'],
+                          grad_scale=scale, zero_grad=take)
+            if take:
+                ops.release_zeroed(g)
+                p.grad = None
+
+    def zero_grad(self, set_to_none=True):
+        if self.small_opt is not None:
+            self.small_opt.zero_grad(set_to_none=set_to_none)
+        for p in self.big:
+            if p.grad is not None:
+                if set_to_none:
+                    p.grad = None
+                else:
+                    p.grad.zero_()

@@ -431,6 +431,38 @@ def test_update_layer_partial_gradients_and_other_widths():
     assert_close(ops.update_layer(x, a, W, b), torch.relu(torch.cat([x, a], 1) @ W.t() + b), 'width 48', 1e-5)
 
 
+# ---- clip + Adam with the large parameter in one HIP pass (optim.ClipAdam) --------------------------------------
+
+@pytest.mark.parametrize('max_norm', [None, 0.5, 1e6])
+def test_clip_adam_matches_torch(max_norm):
+    """optim.ClipAdam == clip_grad_norm_ + torch.optim.Adam over several steps (a 'large' table of 1003 x 64 floats,
+    whose element count is not a multiple of 4 x 256, and three small parameters, one of them without a gradient)."""
+    from subgnn_amd import optim, ops
+    g = torch.Generator().manual_seed(7)
+    shapes = [(1003, 64), (64, 128), (64,), (5, 3)]
+    init = [torch.randn(*s, generator=g) for s in shapes]
+    ref = [torch.nn.Parameter(t.clone().to(DEV)) for t in init]
+    got = [torch.nn.Parameter(t.clone().to(DEV)) for t in init]
+    o_ref = torch.optim.Adam(ref, lr=0.01)
+    o_got = optim.ClipAdam(got, lr=0.01, max_norm=max_norm, big_bytes=1003 * 64 * 4)
+    assert len(o_got.big) == 1 and len(o_got.small) == 3
+    for it in range(4):
+        grads = [torch.randn(*s, generator=g).to(DEV) * (5.0 if it == 1 else 0.1) for s in shapes]
+        for ps, opt in ((ref, o_ref), (got, o_got)):
+            for i, (p, gr) in enumerate(zip(ps, grads)):
+                p.grad = None if i == 3 and it < 2 else gr.clone()
+        if max_norm is not None:
+            torch.nn.utils.clip_grad_norm_(ref, max_norm)
+        o_ref.step(); o_got.step()
+        assert got[0].grad is None                                  # consumed, zeroed and handed back
+        buf = ops.take_zeroed(shapes[0], torch.device(DEV))
+        assert float(buf.abs().max()) == 0.0
+        ops.release_zeroed(buf)
+        o_ref.zero_grad(); o_got.zero_grad()
+        for a, b, s in zip(got, ref, shapes):
+            assert_close(a.detach(), b.detach(), 'ClipAdam step %d %s' % (it, (s,)), 2e-6)
+
+
 # ---- a18 deterministic table-gradient scatter -------------------------------------------------------
 
 @pytest.mark.parametrize('D', [8, 64, 128, 200])
