@@ -397,7 +397,7 @@ def main():
                                (n, args.m, int(rowptr[-1]) // 2, args.subgraphs, args.subgraph_nodes,
                                 'per GPU' if args.scaling == 'weak' else 'in total', args.embed),
                    'subgraphs_per_gpu': S, 'subgraphs_total': total_subgraphs,
-                   'schedule': {'passes_pipelined': pipe is not None, 'two_stream_preparation': bool(hp.get('overlap_streams', True))},
+                   'schedule': {'passes_pipelined': pipe is not None, 'two_stream_preparation': bool(hp.get('overlap_streams', True)) and not (shard is not None and shard.deal_shared)},
                    'parallelism': ('dp%d (subgraph shards; head on the rank\'s own rows, all-reduce of the small gradients, '
                                    'reduce-scatter / all-gather of the embedding table)' % world) if not replicated else
                                   ('dp%d (subgraph shards; RCCL all-gather of the channel embeddings into a replicated head, '
