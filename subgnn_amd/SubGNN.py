@@ -631,7 +631,6 @@ class SubGNN(nn.Module):
                     res[side] = (o, p)
                 outputs.extend([res['I'][pick], res['B'][pick]])
         all_cc_embeds = torch.cat([init_cc_embeds] + outputs, dim=-1)
-        self._last_cc_embeds = all_cc_embeds.detach().reshape(B * C, -1)
         if hp.get('dp_gather_embeddings', False):
             # data parallelism over subgraph shards: the one exchange of the data path.  Every rank has
             # computed the per-component channel embeddings of ITS subgraphs; the all-gather (RCCL over xGMI)
