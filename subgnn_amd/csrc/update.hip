@@ -5,13 +5,13 @@
 // As torch ops the layer was cat (R x 2D written and read back) + a library GEMM whose 64-column output runs far from
 // the chip's width + relu, and five more launches per direction in the backward: 47 us forward, 215 us forward +
 // backward per layer at R = 50k, D = 64, six layers per pass (fused: 20 us and 96 us).  Here:
-//   forward   one wavefront per 32 rows.  v_mfma_f32_32x32x2_f32 takes A as (row = lane % 32, k = lane / 32): the lane
+//   forward   one wavefront per (32 rows, 32 output features).  v_mfma_f32_32x32x2_f32 takes A as (row = lane % 32, k = lane / 32): the lane
 //             with k-half 0 holds its row of x, the lane with k-half 1 the same row of aggr -- the contraction index
 //             is simply walked as (half, position), the same permutation on the W side -- so every lane reads ONE
 //             contiguous row of D floats straight into registers, no concatenation, no LDS staging.  Bias and relu are
 //             applied to the accumulator fragment.
 //   backward  dpre = grad_out * (out > 0) is formed on the fly in both kernels:
-//             dx kernel   [grad_x | grad_aggr] = dpre W, one wavefront per 32 rows, contraction over the D outputs;
+//             dx kernel   [grad_x | grad_aggr] = dpre W, one wavefront per (32 rows, 32 columns), contraction over the D outputs;
 //             dw kernel   grad_W = dpre^T [x | aggr] and grad_b = column sums of dpre, contracted over the rows: one
 //                         workgroup of four wavefronts per (block of UPD_ROWS rows, 32 output features), partial sums per block written
 //                         to the workspace and added up in block order by a small second kernel -- a fixed order, so
@@ -26,11 +26,15 @@ typedef float upd_f32x16 __attribute__((ext_vector_type(16)));
 #define UPD_ROWS (4 * UPD_WAVE_ROWS)   // rows per partial sum (a workgroup of four wavefronts)
 #define UPD_STEPS 8             // contraction steps of the weight gradient whose operands are in flight together
 #define UPD_KC 64               // contraction positions held in registers at a time (per k-half)
+#define UPD_SPLIT_BELOW 16384    // rows below which the output tiles of a row block go to separate wavefronts
 
 // accumulator element v of lane l: row 8 * (v / 4) + 4 * (l / 32) + v % 4, column l % 32
 __device__ __forceinline__ int upd_acc_row(int v, int h) { return 8 * (v >> 2) + 4 * h + (v & 3); }
 
-template <int D>
+// SPLIT: one wavefront per (32 rows, 32 output features), blockIdx.y = the feature tile -- for calls with few rows (a
+// batch: 448 rows of D = 128 were 14 wavefronts of 512 dependent MFMA + load steps each, 37 us; side by side 9 us);
+// else one wavefront per 32 rows walks all tiles with its row fragment kept in registers (50k rows: 20 us, split 26).
+template <int D, bool SPLIT>
 __global__ __launch_bounds__(64) void update_fwd_kernel(const float* __restrict__ x, const float* __restrict__ aggr,
                                                         const float* __restrict__ W, const float* __restrict__ b,
                                                         int64_t R, float* __restrict__ out)
@@ -48,7 +52,8 @@ __global__ __launch_bounds__(64) void update_fwd_kernel(const float* __restrict_
             a[4 * c] = v.x; a[4 * c + 1] = v.y; a[4 * c + 2] = v.z; a[4 * c + 3] = v.w;
         }
     }
-    for (int nt = 0; nt < D / 32; ++nt) {
+    const int nt0 = SPLIT ? (int)blockIdx.y : 0, nt1 = SPLIT ? nt0 + 1 : D / 32;
+    for (int nt = nt0; nt < nt1; ++nt) {
         upd_f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         const float* __restrict__ wrow = W + (int64_t)(nt * 32 + i) * (2 * D) + h * D;
 #pragma unroll 1
@@ -80,7 +85,7 @@ __global__ __launch_bounds__(64) void update_fwd_kernel(const float* __restrict_
 }
 
 // [grad_x | grad_aggr](r, c) = sum_n dpre(r, n) W(n, c): contraction index n walked as (half, position)
-template <int D>
+template <int D, bool SPLIT>
 __global__ __launch_bounds__(64) void update_bwd_dx_kernel(const float* __restrict__ g, const float* __restrict__ out,
                                                            const float* __restrict__ W, int64_t R,
                                                            float* __restrict__ gx, float* __restrict__ gaggr)
@@ -97,7 +102,8 @@ __global__ __launch_bounds__(64) void update_bwd_dx_kernel(const float* __restri
         a[4 * c] = ov.x > 0.f ? gv.x : 0.f; a[4 * c + 1] = ov.y > 0.f ? gv.y : 0.f;
         a[4 * c + 2] = ov.z > 0.f ? gv.z : 0.f; a[4 * c + 3] = ov.w > 0.f ? gv.w : 0.f;
     }
-    for (int ct = 0; ct < 2 * D / 32; ++ct) {
+    const int ct0 = SPLIT ? (int)blockIdx.y : 0, ct1 = SPLIT ? ct0 + 1 : 2 * D / 32;     // (SPLIT: see update_fwd_kernel)
+    for (int ct = ct0; ct < ct1; ++ct) {
         float* __restrict__ dst = ct * 32 < D ? gx : gaggr;
         if (!dst) continue;
         upd_f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -214,9 +220,12 @@ extern "C" int sgnn_update_fwd(const float* x, const float* aggr, const float* W
     if (R == 0) return SGNN_OK;
     hipStream_t st = (hipStream_t)stream;
     const unsigned grid = (unsigned)((R + 31) / 32);
-    if (D == 32) hipLaunchKernelGGL(update_fwd_kernel<32>, dim3(grid), dim3(64), 0, st, x, aggr, W, b, R, out);
-    else if (D == 64) hipLaunchKernelGGL(update_fwd_kernel<64>, dim3(grid), dim3(64), 0, st, x, aggr, W, b, R, out);
-    else hipLaunchKernelGGL(update_fwd_kernel<128>, dim3(grid), dim3(64), 0, st, x, aggr, W, b, R, out);
+    // few rows: the feature tiles side by side (more wavefronts than CUs only from ~8k rows on)
+#define UPD_LAUNCH_FWD(DD) do { if (split) hipLaunchKernelGGL((update_fwd_kernel<DD, true>), dim3(grid, DD / 32), dim3(64), 0, st, x, aggr, W, b, R, out); \
+                                else hipLaunchKernelGGL((update_fwd_kernel<DD, false>), dim3(grid), dim3(64), 0, st, x, aggr, W, b, R, out); } while (0)
+    const bool split = R < UPD_SPLIT_BELOW;
+    if (D == 32) UPD_LAUNCH_FWD(32); else if (D == 64) UPD_LAUNCH_FWD(64); else UPD_LAUNCH_FWD(128);
+#undef UPD_LAUNCH_FWD
     SGNN_CHECK_LAUNCH();
     return SGNN_OK;
 }
@@ -244,9 +253,11 @@ extern "C" int sgnn_update_bwd(const float* grad_out, const float* out, const fl
     }
     if (grad_x || grad_aggr) {
         const unsigned grid = (unsigned)((R + 31) / 32);
-        if (D == 32) hipLaunchKernelGGL(update_bwd_dx_kernel<32>, dim3(grid), dim3(64), 0, st, grad_out, out, W, R, grad_x, grad_aggr);
-        else if (D == 64) hipLaunchKernelGGL(update_bwd_dx_kernel<64>, dim3(grid), dim3(64), 0, st, grad_out, out, W, R, grad_x, grad_aggr);
-        else hipLaunchKernelGGL(update_bwd_dx_kernel<128>, dim3(grid), dim3(64), 0, st, grad_out, out, W, R, grad_x, grad_aggr);
+#define UPD_LAUNCH_DX(DD) do { if (split) hipLaunchKernelGGL((update_bwd_dx_kernel<DD, true>), dim3(grid, 2 * DD / 32), dim3(64), 0, st, grad_out, out, W, R, grad_x, grad_aggr); \
+                               else hipLaunchKernelGGL((update_bwd_dx_kernel<DD, false>), dim3(grid), dim3(64), 0, st, grad_out, out, W, R, grad_x, grad_aggr); } while (0)
+        const bool split = R < UPD_SPLIT_BELOW;
+        if (D == 32) UPD_LAUNCH_DX(32); else if (D == 64) UPD_LAUNCH_DX(64); else UPD_LAUNCH_DX(128);
+#undef UPD_LAUNCH_DX
         SGNN_CHECK_LAUNCH();
     }
     if (grad_W || grad_b) {

@@ -389,7 +389,7 @@ def test_lstm_unsupported_sizes_stay_on_the_library():
 # ---- a12 update(): fused relu([x | aggr] W^T + b) ------------------------------------------------------
 
 @pytest.mark.parametrize('D', [32, 64, 128])
-@pytest.mark.parametrize('R', [1, 31, 33, 257, 5000])
+@pytest.mark.parametrize('R', [1, 31, 33, 257, 5000, 17000])          # 17000: the one-wavefront-per-row-block form
 def test_update_layer_matches_torch(R, D):
     """sgnn_update_fwd / sgnn_update_bwd against cat + nn.Linear + relu in float64 (subgraph_mpn.py:233-241):
     output and all four gradients within 1e-5; two runs give the same bits."""

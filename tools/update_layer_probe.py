@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch.nn.functional as F
 from subgnn_amd import ops
 dev = 'cuda:0'
-R, D = 50000, 64
+R, D = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (50000, 64)
 cc = torch.randn(R, D, device=dev, requires_grad=True)
 agg = torch.randn(R, D, device=dev, requires_grad=True)
 lin = torch.nn.Linear(2 * D, D).to(dev)
