@@ -605,11 +605,17 @@ def dtw_similarity(x_ptr, x_val, max_x, y_ptr, y_val, max_y, tie_order=0, order_
     result rows gathered back.  ``order_rows``: process the x rows sorted by (length, coarse series) so
     that the lanes of a wavefront work on similar series.  Neither changes any value.
     ``x_prep``: a dict the caller keeps for THESE x rows (the degree sequences of a split's components are the same
-    every pass): the grouping of repeated rows and the processing order are computed on the first call and reused."""
+    every pass): the grouping of repeated rows and the processing order are computed on the first call and reused;
+    the series the kernel reads are always this call's ``x_val``."""
     if dedupe and x_ptr.numel() - 1 > 1024 and max_x <= 64:
         kept = x_prep.get('dedupe') if x_prep is not None else None
-        if kept is not None and kept[2].numel() == x_ptr.numel() - 1:
-            uptr, uval, rep, live = kept
+        if kept is not None and kept[1].numel() == x_ptr.numel() - 1:
+            # the grouping (which row stands for which, where the kept entries go) is reused; the VALUES the kernel reads
+            # are this call's: scattered again from x_val
+            uptr, rep, dst, live = kept
+            rows = Ragged(x_ptr, x_val, max_len=max_x).to_padded(width=max_x, fill=-1, dtype=torch.int32)
+            uval = torch.zeros(x_val.numel() + 1, dtype=torch.int32, device=x_ptr.device)
+            uval.scatter_(0, dst, rows.reshape(-1))
             out_u = dtw_similarity(uptr, uval, max_x, y_ptr, y_val, max_y, tie_order, order_rows, dedupe=False, order=order,
                                    _live=live, x_prep=x_prep.setdefault('grouped', {}))
             return out_u.index_select(0, rep)
@@ -634,7 +640,7 @@ def dtw_similarity(x_ptr, x_val, max_x, y_ptr, y_val, max_y, tie_order=0, order_
             n_live = (lens > 0).sum()
             live = torch.stack((n - n_live, n_live))
         if x_prep is not None:
-            x_prep['dedupe'] = (uptr, uval, rep, live)
+            x_prep['dedupe'] = (uptr, rep, dst.reshape(-1), live)
         out_u = dtw_similarity(uptr, uval, max_x, y_ptr, y_val, max_y, tie_order, order_rows, dedupe=False, order=order,
                                _live=live, x_prep=x_prep.setdefault('grouped', {}) if x_prep is not None else None)
         return out_u.index_select(0, rep)
