@@ -454,6 +454,11 @@ int sgnn_scatter_add_rows_sorted(const int32_t* order, const int32_t* key_sorted
                                  const float* G, int64_t D, const float* c1, const float* c2, const float* v,
                                  const int32_t* arg, float* table,
                                  void* workspace, int64_t workspace_bytes, void* stream);
+/* SHARED source, batch-sized calls, without atomics: per-row-tile partials in the workspace, added in tile order
+ * (grad_x (A, D) and grad_wp (D) are OVERWRITTEN, either may be NULL). */
+int64_t sgnn_mpn_bwd_shared_det_workspace_bytes(int64_t R, int64_t A, int64_t D);
+int sgnn_mpn_bwd_shared_det(const struct sgnn_mpn_args* args, const float* grad_agg, const float* grad_z,
+                            float* grad_x, float* grad_wp, void* workspace, int64_t workspace_bytes, void* stream);
 int sgnn_mpn_bwd_edges(const struct sgnn_mpn_args* args, const float* grad_z, int32_t* out_keys, float* out_c1,
                        float* out_c2, void* stream);
 int sgnn_mpn_bwd_wp_partial(const struct sgnn_mpn_args* args, const float* grad_z, float* partial, void* stream);

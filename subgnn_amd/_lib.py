@@ -85,6 +85,8 @@ SIGNATURES = {
     'sgnn_masked_sum_bwd': (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_i64, c_ptr, c_ptr]),
     'sgnn_probe_stream_copy': (c_int, [c_ptr, c_ptr, c_i64, c_int, c_ptr]),
     'sgnn_scatter_add_rows_workspace_bytes': (c_i64, [c_i64, c_i64]),
+    'sgnn_mpn_bwd_shared_det_workspace_bytes': (c_i64, [c_i64, c_i64, c_i64]),
+    'sgnn_mpn_bwd_shared_det': (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr]),
     'sgnn_adam_step': (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float,
                                c_i64, c_ptr, c_int, c_ptr]),
     'sgnn_update_fwd': (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr]),

@@ -245,6 +245,77 @@ __global__ __launch_bounds__(256) void mpn_bwd_shared_kernel(sgnn_mpn_args a, co
     }
 }
 
+// ---- deterministic backward for SHARED anchors -----------------------------------------------------------
+// The same contraction as mpn_bwd_shared_kernel, without atomics: every (row tile, anchor, column slice) item writes
+// its partial row to part_x[tile][anchor][:] and the tile's sum of w * g_z per anchor to part_s[tile][anchor]; a second
+// kernel adds the tiles in order (dX) and forms grad_wp[d] = sum_a (sum_tiles part_s[.][a]) * X[a][d] in anchor order.
+// Batch-sized calls only (the shard-sized ones are library GEMMs): the partials are n_tiles x A x D floats.
+__global__ __launch_bounds__(256) void mpn_bwd_shared_det_kernel(sgnn_mpn_args a, const float* __restrict__ grad_agg,
+                                                                 const float* __restrict__ grad_z,
+                                                                 float* __restrict__ part_x, float* __restrict__ part_s,
+                                                                 int64_t D4, int64_t tile_rows)
+{
+    const int64_t D = D4 * 4;
+    const int64_t tile = blockIdx.x;
+    const int64_t r0 = tile * tile_rows;
+    const int64_t r1 = (r0 + tile_rows < a.R) ? r0 + tile_rows : a.R;
+    for (int64_t item = (int64_t)blockIdx.y * blockDim.x + threadIdx.x; item < a.A * D4;
+         item += (int64_t)gridDim.y * blockDim.x) {
+        const int64_t ai = item / D4, dv = item % D4;
+        const int64_t id = a.ids ? a.ids[ai] : 1;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        float sgz = 0.f;
+        if (id != 0) {
+            const int64_t col = a.sim_col ? a.sim_col[ai] : (a.sims_per_edge ? ai : id - 1);
+            const float4 wp = reinterpret_cast<const float4*>(a.wp)[dv];
+            for (int64_t r = r0; r < r1; ++r) {
+                if (a.row_mask && !a.row_mask[r]) continue;
+                const float w = a.sims[r * a.sims_ld + col];
+                const float gz = grad_z ? grad_z[r * a.A + ai] : 0.f;
+                float4 ga = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (grad_agg) ga = reinterpret_cast<const float4*>(grad_agg)[r * D4 + dv];
+                acc.x += w * (ga.x + gz * wp.x); acc.y += w * (ga.y + gz * wp.y);
+                acc.z += w * (ga.z + gz * wp.z); acc.w += w * (ga.w + gz * wp.w);
+                sgz += w * gz;
+            }
+        }
+        reinterpret_cast<float4*>(part_x)[(tile * a.A + ai) * D4 + dv] = acc;
+        if (dv == 0) part_s[tile * a.A + ai] = sgz;
+    }
+}
+
+__global__ __launch_bounds__(256) void mpn_bwd_shared_reduce_kernel(sgnn_mpn_args a, const float* __restrict__ part_x,
+                                                                    const float* __restrict__ part_s, int64_t n_tiles,
+                                                                    float* __restrict__ grad_x, float* __restrict__ grad_wp)
+{
+    const int64_t AD = a.A * a.D;
+    const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (grad_x && t < AD) {
+        float s = 0.f;
+#pragma unroll 8
+        for (int64_t tile = 0; tile < n_tiles; ++tile) s += part_x[tile * AD + t];      // (loads independent, adds in tile order)
+        grad_x[t] = s;
+    }
+    if (grad_wp && blockIdx.x == 0) {
+        // per anchor, the tiles' sums of w * g_z in tile order (one anchor per thread, kept in the workspace's first
+        // row of part_s -- nobody reads that row any more), then grad_wp[d] = sum over the anchors, in anchor order
+        float* sg = const_cast<float*>(part_s);
+        for (int64_t ai = threadIdx.x; ai < a.A; ai += blockDim.x) {
+            float v = 0.f;
+#pragma unroll 8
+            for (int64_t tile = 0; tile < n_tiles; ++tile) v += part_s[tile * a.A + ai];
+            sg[ai] = v;
+        }
+        __syncthreads();
+        for (int64_t d = threadIdx.x; d < a.D; d += blockDim.x) {
+            float g = 0.f;
+#pragma unroll 8
+            for (int64_t ai = 0; ai < a.A; ++ai) g += sg[ai] * a.x[ai * a.D + d];
+            grad_wp[d] = g;
+        }
+    }
+}
+
 // ---- deterministic backward of the GATHER source (embedding-table gradient without atomics) ---------------
 // Per edge (component row r, anchor slot ai) of a GATHER layer: the target table row and the two
 // coefficients of its contribution  dE[id, :] += w * g_agg[r, :] + (w * g_z[r, ai]) * wp  -- the input of
@@ -419,3 +490,45 @@ extern "C" int sgnn_mpn_bwd_wp_partial(const sgnn_mpn_args* args, const float* g
     SGNN_CHECK_LAUNCH();
     return SGNN_OK;
 }
+
+static void mpn_shared_det_tiling(int64_t R, int64_t A, int64_t D4, int64_t* tile_rows, int64_t* n_tiles, int64_t* chunks)
+{
+    *chunks = (A * D4 + 255) / 256;
+    const int64_t want = (512 + *chunks - 1) / *chunks;                 // ~512 workgroups: two per CU; fewer tiles = a shorter reduction
+    int64_t tr = (R + want - 1) / want;
+    tr = tr < 4 ? 4 : (tr > MPN_SH_TILE ? MPN_SH_TILE : tr);
+    *tile_rows = tr;
+    *n_tiles = (R + tr - 1) / tr;
+}
+
+extern "C" int64_t sgnn_mpn_bwd_shared_det_workspace_bytes(int64_t R, int64_t A, int64_t D)
+{
+    if (R <= 0 || A <= 0 || D <= 0) return 0;
+    int64_t tr, nt, ch;
+    mpn_shared_det_tiling(R, A, D / 4, &tr, &nt, &ch);
+    return nt * A * (D + 1) * 4 + 64;
+}
+
+extern "C" int sgnn_mpn_bwd_shared_det(const sgnn_mpn_args* args, const float* grad_agg, const float* grad_z,
+                                       float* grad_x, float* grad_wp, void* workspace, int64_t workspace_bytes, void* stream)
+{
+    const int rc = mpn_check(args);
+    if (rc != SGNN_OK) return rc;
+    if (args->src != SGNN_SRC_SHARED) return SGNN_ERR_BAD_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (args->R == 0 || args->A == 0) return SGNN_OK;
+    if (!workspace || workspace_bytes < sgnn_mpn_bwd_shared_det_workspace_bytes(args->R, args->A, args->D)) return SGNN_ERR_BAD_ARG;
+    const int64_t D4 = args->D / 4;
+    int64_t tile_rows, n_tiles, chunks;
+    mpn_shared_det_tiling(args->R, args->A, D4, &tile_rows, &n_tiles, &chunks);
+    float* part_x = (float*)workspace;
+    float* part_s = part_x + n_tiles * args->A * args->D;
+    hipLaunchKernelGGL(mpn_bwd_shared_det_kernel, dim3((unsigned)n_tiles, (unsigned)chunks), dim3(256), 0, st, *args, grad_agg,
+                       grad_z, part_x, part_s, D4, tile_rows);
+    SGNN_CHECK_LAUNCH();
+    hipLaunchKernelGGL(mpn_bwd_shared_reduce_kernel, dim3((unsigned)((args->A * args->D + 255) / 256)), dim3(256), 0, st, *args,
+                       part_x, part_s, n_tiles, grad_x, grad_wp);
+    SGNN_CHECK_LAUNCH();
+    return SGNN_OK;
+}
+

@@ -939,6 +939,13 @@ class _MPN(torch.autograd.Function):
                 check(lib.sgnn_mpn_bwd_wp_partial(ctypes.byref(a), _ptr(g_z), _ptr(partial), _stream()),
                       'sgnn_mpn_bwd_wp_partial')
                 gwp = column_sum(partial)
+        elif (need_x or need_wp) and A > 0 and src == SRC_SHARED and DETERMINISTIC:
+            # row-tile partials added in tile order (sgnn_mpn_bwd_shared_det): no atomics
+            a = _mpn_args(src, x, ids, id_div, edge_mask, row_mask, sims, sim_col, sims_per_edge, wp, bp, R, A, D)
+            wsb = lib.sgnn_mpn_bwd_shared_det_workspace_bytes(R, A, D)
+            ws = torch.empty(wsb // 4 + 1, dtype=torch.float32, device=x.device)
+            check(lib.sgnn_mpn_bwd_shared_det(ctypes.byref(a), _ptr(g_agg), _ptr(g_z), _ptr(gx), _ptr(gwp), _ptr(ws), wsb,
+                                              _stream()), 'sgnn_mpn_bwd_shared_det')
         elif (need_x or need_wp) and A > 0:
             if ctx.half is not None:
                 x._sgnn_half = ctx.half               # saved tensors come back as new objects
@@ -1141,9 +1148,7 @@ def mpn(x, wp, bp, sims, *, src, R, A, ids=None, id_div=1, edge_mask=None, row_m
     sims2 = sims.reshape(R, -1)
     if not sims2.is_contiguous():
         sims2 = sims2.contiguous()
-    if src == SRC_SHARED and A > 0 and (R >= SHARED_GEMM_MIN_ROWS or DETERMINISTIC):
-        # (the hand-written SHARED backward adds row-tile partials with atomics: with DETERMINISTIC the GEMM form
-        # serves batch-sized calls too)
+    if src == SRC_SHARED and A > 0 and R >= SHARED_GEMM_MIN_ROWS:
         return _mpn_shared_gemm(x, wp, bp, sims2, ids, row_mask, sim_col, sims_per_edge, R, A)
     return _MPN.apply(x.contiguous(), wp.contiguous().view(-1), bp.contiguous().view(-1), sims2, ids, edge_mask,
                       row_mask, sim_col, src, id_div, sims_per_edge, R, A)

@@ -20,9 +20,8 @@ def _ops():
 
 @pytest.fixture(params=['sorted', 'atomics'])
 def det(request):
-    """Both backward forms of the ops that add into the embedding table: sorted segmented sums (the default,
-    bit-reproducible; batch-sized SHARED layers then run as GEMMs) and float atomics (+ the hand-written
-    SHARED kernels)."""
+    """Both backward forms of the ops that add into the embedding table: sorted segmented sums / tile partials added
+    in a fixed order (the default, bit-reproducible) and float atomics."""
     from subgnn_amd import ops
     ops.DETERMINISTIC = request.param == 'sorted'
     yield request.param
@@ -220,6 +219,25 @@ def test_mpn_shared_random(D, mode, R, A, det):
     assert_close(Xg.grad, Xc.grad, 'grad X')
     assert_close(wpg.grad, wpc.grad, 'grad wp')
     assert_close(bpg.grad, bpc.grad, 'grad bp')
+
+
+def test_mpn_shared_batch_backward_is_bit_reproducible():
+    """Batch-sized SHARED layer, default (deterministic) mode: the fused kernels with row-tile partials added in tile
+    order -- two runs give the same bits for every gradient."""
+    ops = _ops()
+    R, A, D, N, C = 450, 185, 128, 300, 3
+    E, _, row_mask, sims, wp, bp, gagg, gz = _rand_case(3, R, A, D, N, C)
+    g = torch.Generator().manual_seed(2)
+    X, col = torch.randn(A, D, generator=g), torch.randint(0, N, (A,), generator=g)
+    runs = []
+    for _ in range(2):
+        Xg, wpg, bpg = X.to(DEV).requires_grad_(True), wp.to(DEV).requires_grad_(True), bp.to(DEV).requires_grad_(True)
+        agg, z = ops.mpn(Xg, wpg, bpg, sims.to(DEV), src=ops.SRC_SHARED, R=R, A=A, row_mask=row_mask.to(torch.uint8).to(DEV),
+                         sim_col=col.to(DEV))
+        ((agg * gagg.to(DEV)).sum() + (z * gz.to(DEV)).sum()).backward()
+        runs.append((agg.detach(), z.detach(), Xg.grad, wpg.grad, bpg.grad))
+    for a, b in zip(*runs):
+        assert torch.equal(a, b)
 
 
 def test_gather_rows_matches_embedding_with_padding_idx(det):
