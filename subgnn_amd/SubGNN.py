@@ -603,7 +603,8 @@ class SubGNN(nn.Module):
         for nm in CC_SLOTS:
             state[nm] = torch.index_select(given[nm], 0, sidx) if hp['trainable_cc'] else init_cc_embeds
         B, C, _ = init_cc_embeds.shape
-        cc_embed_mask = (cc_ids != config.PAD_VALUE)[:, :, 0]
+        cc_embed_mask = cc_ids[:, :, 0] != config.PAD_VALUE          # (the first column only: a component is real iff it has a member)
+        cc_embed_mask._sgnn_u8 = cc_embed_mask.reshape(-1).to(torch.uint8)
         bn = hp.get('batch_norm', False)
         outputs = []
         for l in range(hp['n_layers']):

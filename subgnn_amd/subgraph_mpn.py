@@ -69,7 +69,10 @@ class SG_MPN(nn.Module):
             agg = torch.zeros((R, D), dtype=cc_embeds.dtype, device=cc_embeds.device)
             z = self.linear_position.bias.view(1, 1).expand(R, A)
             return self._finish(cc_embeds, agg, z, need_out)
-        row_mask = cc_embed_mask.reshape(R).to(torch.uint8).contiguous()
+        # (SubGNN._forward converts the mask once per forward and hangs it on the tensor: one launch instead of one per layer)
+        row_mask = getattr(cc_embed_mask, '_sgnn_u8', None)
+        if row_mask is None or row_mask.numel() != R:
+            row_mask = cc_embed_mask.reshape(R).to(torch.uint8).contiguous()
         agg, z = ops.mpn(x, self.linear_position.weight, self.linear_position.bias, sims, src=src, R=R, A=A, ids=ids,
                          id_div=id_div, row_mask=row_mask, sim_col=sim_col, sims_per_edge=sims_per_edge)
         return self._finish(cc_embeds, agg, z, need_out)
