@@ -192,8 +192,15 @@ def prepare_pass(model, split='train', timer=None, shard=None, defer_dtw=False):
         else getattr(model, '_subs_' + split)
     setattr(model, '_subs_' + split, subs)
     labels = ops.cc_labels(g, subs)
+    # the padded (components per subgraph, component length) is a property of the split's subgraph lists (and, sharded,
+    # of all ranks'): read back on the first pass, kept afterwards -- one statistics launch and one host round trip less
+    kept = model.__dict__.setdefault('_cc_dims', {})
+    tag = (id(getattr(model, split + '_sub_G')), subs.n)
+    hit = kept.get(split)
     cc_ids = subgraph_utils.components_from_labels(subs.ptr, subs.nodes, labels, subs.max_len,
-                                                   dims_reduce=shard.reduce_max if shard is not None else None)
+                                                   dims_reduce=shard.reduce_max if shard is not None else None,
+                                                   dims=hit[1] if hit is not None and hit[0] == tag else None)
+    kept[split] = (tag, tuple(cc_ids.shape[1:]))
     st.attrs[split + '_cc_ids'] = cc_ids
     S, C, Lc = cc_ids.shape
     if ops.DETERMINISTIC:

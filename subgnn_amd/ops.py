@@ -247,22 +247,27 @@ def cc_labels(g, subs):
     return out
 
 
-def cc_compact(sub_ptr, sub_nodes, labels, max_sub_len=0, dims_reduce=None):
+def cc_compact(sub_ptr, sub_nodes, labels, max_sub_len=0, dims_reduce=None, dims=None):
     """cc labels -> the padded (S, C, L) int64 component tensor of initialize_cc_ids, canonical order
     (components by their first node's position, nodes in subgraph order, duplicates dropped).
     ``dims_reduce``: callable applied to the device tensor [C, L] before it is read -- under data
-    parallelism the padded shape is a property of ALL ranks' subgraphs (dist.all_reduce_max_)."""
+    parallelism the padded shape is a property of ALL ranks' subgraphs (dist.all_reduce_max_).
+    ``dims``: the padded (C, L) of THESE subgraphs when the caller already knows it (it is a property of the subgraph
+    lists: hotpath keeps it per split) -- no statistics launch, no host round trip."""
     lib = _lib.load()
     _req(labels, torch.int32, 'labels')
     S = sub_ptr.numel() - 1
     dev = sub_ptr.device
-    stats = torch.zeros((2, max(S, 1)), dtype=torch.int32, device=dev)
-    check(lib.sgnn_cc_compact_stats(_ptr(sub_ptr), _ptr(sub_nodes), _ptr(labels), S, int(max_sub_len), _ptr(stats[0]),
-                                    _ptr(stats[1]), _stream()), 'sgnn_cc_compact_stats')
-    dims = stats.amax(dim=1)
-    if dims_reduce is not None:
-        dims = dims_reduce(dims)
-    C, L = (max(int(v), 1) for v in dims.tolist())                        # the one host round trip
+    if dims is not None:
+        C, L = int(dims[0]), int(dims[1])
+    else:
+        stats = torch.zeros((2, max(S, 1)), dtype=torch.int32, device=dev)
+        check(lib.sgnn_cc_compact_stats(_ptr(sub_ptr), _ptr(sub_nodes), _ptr(labels), S, int(max_sub_len), _ptr(stats[0]),
+                                        _ptr(stats[1]), _stream()), 'sgnn_cc_compact_stats')
+        d = stats.amax(dim=1)
+        if dims_reduce is not None:
+            d = dims_reduce(d)
+        C, L = (max(int(v), 1) for v in d.tolist())                       # the one host round trip
     out = torch.zeros((S, C, L), dtype=torch.int64, device=dev)
     check(lib.sgnn_cc_compact(_ptr(sub_ptr), _ptr(sub_nodes), _ptr(labels), S, int(max_sub_len), C, L, _ptr(out),
                               _stream()), 'sgnn_cc_compact')

@@ -111,8 +111,8 @@ def trim_zero_columns(x):
     return flat[:, keep].reshape(B, C, -1)
 
 
-def components_from_labels(sub_ptr, sub_nodes, labels, max_sub_len=0, dims_reduce=None):
+def components_from_labels(sub_ptr, sub_nodes, labels, max_sub_len=0, dims_reduce=None, dims=None):
     """cc labels (smallest position per component) -> padded (S, C, L) int64 component tensor
     in canonical order: components by their first node's position, nodes in subgraph order
     (duplicates dropped) -- sgnn_cc_compact (one statistics launch, one write launch)."""
-    return ops.cc_compact(sub_ptr, sub_nodes, labels, max_sub_len, dims_reduce)
+    return ops.cc_compact(sub_ptr, sub_nodes, labels, max_sub_len, dims_reduce, dims)
