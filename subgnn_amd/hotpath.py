@@ -254,7 +254,9 @@ def prepare_pass(model, split='train', timer=None, shard=None, defer_dtw=False):
                                                          max_hops=nlev, want_status=True)
                     _bfs_note(model, ('P_out', split, l), status, cap, nlev)
                     w = w.view(S, C, -1)
-                sims[('P', 'out', l)] = (w * real.unsqueeze(-1)).contiguous()
+                # (rows of padded components need no masking: an empty set receives no level in msbfs_set_reduce and
+                # keeps the 0 the output was cleared to -- test_sparse_prepare_equals_dense_prepare checks the raw rows)
+                sims[('P', 'out', l)] = w.contiguous()
                 if C == 1:
                     sims[('P', 'in', l)] = ops.ZeroSims((S, C, hp['n_anchor_patches_pos_in']), dev)
                 else:

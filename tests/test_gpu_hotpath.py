@@ -53,6 +53,8 @@ def test_sparse_prepare_equals_dense_prepare(name, tmp_path):
             edge = (ids != 0) & real.unsqueeze(-1)
             want = torch.gather(slab, 2, (ids - 1).clamp(min=0)) * edge
             got = sparse.train_neigh_pos_similarities[key]
+            if key[:2] == ('P', 'out'):
+                assert float((got * (~real).unsqueeze(-1)).abs().max()) == 0.0    # padded components: rows stay 0 unmasked
             got = (got.dense() if hasattr(got, 'dense') else got) * edge          # ops.ZeroSims: known-zero weights
             assert torch.equal(got, want), key
     assert torch.equal(dense.structure_anchors, sparse.structure_anchors)
