@@ -8,8 +8,14 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIBDIR = os.path.join(HERE, 'lib')
 LIB = os.path.join(LIBDIR, 'libsubgnn_hip.so')
-SOURCES = ['lib.hip', 'degree_sequence.hip', 'graph_sets.hip', 'samplers.hip', 'similarity.hip', 'embed.hip', 'mpn.hip', 'attention.hip', 'lstm.hip', 'probe.hip', 'scatter.hip', 'update.hip', 'optim.hip']
+SOURCES = ['lib.hip', 'degree_sequence.hip', 'graph_sets.hip', 'samplers.hip', 'similarity.hip', 'dtw.hip', 'embed.hip', 'mpn.hip', 'attention.hip', 'lstm.hip', 'probe.hip', 'scatter.hip', 'update.hip', 'optim.hip']
 ARCH = 'gfx950'
+# dtw.hip: no NaN can arise in the DP (costs are finite or +inf, only min and + are applied); telling the compiler so removes
+# the canonicalising v_max x, x it otherwise puts in front of every v_min_f64 (3 of 16 instructions per cell)
+# -disable-promote-alloca-to-vector: the row registers are arrays indexed statically once the row loops are unrolled, but the
+# AMDGPU alloca-to-vector promotion runs before that and turns arrays of <= 16 doubles into one vector value -- every update
+# of a row then copied the whole array (32 v_mov per row pair on the coarse levels)
+EXTRA_FLAGS = {'dtw.hip': ['-fno-honor-nans', '-mllvm', '-disable-promote-alloca-to-vector']}
 
 
 def _hipcc():
@@ -40,7 +46,7 @@ def build(force=False, verbose=True):
                 os.path.getmtime(src), os.path.getmtime(os.path.join(CSRC, 'common.h')),
                 os.path.getmtime(os.path.join(HERE, '..', 'include', 'subgnn_hip.h'))):
             cmd = [_hipcc(), '--offload-arch=' + ARCH, '-O3', '-fPIC', '-std=c++17', '-munsafe-fp-atomics',
-                   '-Wall', '-Wno-unused-function'] + os.environ.get('SGNN_HIPCC_FLAGS', '').split() + ['-c', src, '-o', o]
+                   '-Wall', '-Wno-unused-function'] + EXTRA_FLAGS.get(s, []) + os.environ.get('SGNN_HIPCC_FLAGS', '').split() + ['-c', src, '-o', o]
             if verbose:
                 print(' '.join(cmd), flush=True)
             subprocess.check_call(cmd)

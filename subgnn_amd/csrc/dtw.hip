@@ -1,0 +1,719 @@
+// Structure similarity 1/(1+fastdtw) (a11): pyramids, the general and the register-resident DP kernels.
+#include "common.h"
+#include <type_traits>
+
+// ---------------------------------------------------------------------------------------------
+// a11  1 / (1 + fastdtw(x, y, radius=1, dist=calc_dist))  (reference SubGNN/gamma.py:51-59)
+//
+// One lane per (component, anchor) pair; fp64 DP.  fastdtw's recursion is unrolled bottom-up:
+//   * a pre-kernel builds the halved series ("pyramid") of every x row and every y row ONCE
+//     (each x row meets every anchor, each anchor every x row), x transposed so that the lanes
+//     of a wavefront -- consecutive components, same anchor -- read it coalesced, y read
+//     wave-uniformly;
+//   * per pair, the coarsest level (either length < 3) runs a full-window DTW, and each finer
+//     level derives its window from the coarser warp path.  Because a warp path is monotone, the
+//     published expand_window (dilate by radius 1, project to the fine grid, keep one contiguous
+//     run per row starting no earlier than the previous row's) reduces to per-row bounds
+//       lo_i = max(0, 2*(first_col[max(ci-1,0)] - 1)),  hi_i = min(ly-1, 2*(last_col[min(ci+1,lxc-1)] + 1) + 1)
+//     with ci = i/2 and first/last_col the coarse path's column range per coarse row, so only
+//     those two small arrays travel between levels;
+//   * the DP keeps two rolling rows (the diagonal predecessor stays in a register) and a 2-bit
+//     predecessor code per window cell for the backtrack.
+// Per-lane state (~1.4 KB at 20 x 50) lives in a caller workspace, element-interleaved across
+// lanes so that lanes in lockstep touch consecutive addresses; the resident thread count is kept
+// small enough for that scratch to stay in the Infinity Cache (the first version's 3.5 KB x 131k
+// lanes spilled to HBM and waited on it 78 % of the time).  VALU / latency-bound (one fp64
+// divide per cell); not an HBM kernel.
+// ---------------------------------------------------------------------------------------------
+#define DTW_THREADS 256
+#ifndef DTW_BLOCKS
+#define DTW_BLOCKS (256 * 2)
+#endif
+#define DTW_NT ((int64_t)DTW_THREADS * DTW_BLOCKS)
+#ifndef DTW_REG_BLOCKS
+#define DTW_REG_BLOCKS (256 * 32)     // register variant: its scratch is LDS; many more workgroups than fit at once, so the tail of the launch is short (4096 / 8192: 4.65 / 4.51 ms)
+#endif
+#define DTW_REG_NT ((int64_t)DTW_THREADS * DTW_REG_BLOCKS)
+#define DTW_MAX_LEVELS 16
+
+struct DtwLayout {
+    int64_t MX, MY;
+    int64_t XL, YL;                // pyramid lengths per sequence (sum of M >> k)
+    int64_t n_dbl;                 // per lane: prev(MY) cur(MY)
+    int64_t n_i32;                 // per lane: rowstart(MX) lohi(MX) firstlast[2](MX each)
+    int64_t n_dir;                 // per lane: ceil(MX*MY/16) words of 2-bit codes
+    int64_t xoff[DTW_MAX_LEVELS], yoff[DTW_MAX_LEVELS];
+};
+
+static inline DtwLayout dtw_layout(int64_t MX, int64_t MY) {
+    DtwLayout L;
+    L.MX = MX; L.MY = MY;
+    int64_t xo = 0, yo = 0;
+    for (int k = 0; k < DTW_MAX_LEVELS; ++k) {
+        L.xoff[k] = xo; L.yoff[k] = yo;
+        xo += (MX >> k) > 0 ? (MX >> k) : 0;
+        yo += (MY >> k) > 0 ? (MY >> k) : 0;
+    }
+    L.XL = xo; L.YL = yo;
+    L.n_dbl = 2 * MY;
+    L.n_i32 = 4 * MX;
+    L.n_dir = (MX * MY + 15) / 16;
+    return L;
+}
+
+static inline int64_t dtw_align8(int64_t b) { return (b + 7) / 8 * 8; }
+
+// scratch both kernels carve out of the caller's workspace: the general kernel's per-lane state, or -- register variant with an
+// anchor series too long for its predecessor words to sit in LDS -- one 32-bit word per column of the backtracked levels and lane
+static inline bool dtw_words_in_lds(int64_t max_y_len) { return (max_y_len >> 1) * DTW_THREADS * 4 <= 48 * 1024; }
+static inline int64_t dtw_scratch_bytes(const DtwLayout& L) {
+    const int64_t lane = L.n_dbl * 8 + dtw_align8(L.n_i32 * 4) + dtw_align8(L.n_dir * 4);
+    int64_t scratch = DTW_NT * lane;
+    const int64_t reg = dtw_words_in_lds(L.MY) ? 0 : dtw_align8(DTW_REG_NT * (L.YL - L.MY) * 4);
+    return reg > scratch ? reg : scratch;
+}
+
+extern "C" int64_t sgnn_dtw_workspace_bytes(int64_t n_x, int64_t max_x_len, int64_t n_y, int64_t max_y_len) {
+    if (max_x_len < 1) max_x_len = 1;
+    if (max_y_len < 1) max_y_len = 1;
+    const DtwLayout L = dtw_layout(max_x_len, max_y_len);
+    return dtw_scratch_bytes(L)
+         + 2 * (n_x * L.XL * 8 + n_y * L.YL * 8) + dtw_align8(n_x * 4) + dtw_align8(n_y * 4);   // value + reciprocal pyramids
+}
+
+// pyramid of one series per thread.  transposed != 0: element e of sequence s at out[e * n + s].
+// rec (same layout) receives 1 / (value + 1), correctly rounded: the register kernel's cost
+// function divides by multiplying with it (see dtw_cost_rcp).
+// order (nullable): position s of the output holds sequence order[s] -- the register kernel walks the
+// x rows in the caller's processing order, and with the pyramids laid out in that order the lanes of
+// a wavefront read consecutive addresses instead of gathering 64 cache lines per load.
+__global__ void dtw_pyramid_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ val, int64_t n,
+                                   int64_t M, int64_t PL, int transposed, double* __restrict__ out,
+                                   double* __restrict__ rec, int32_t* __restrict__ len_out,
+                                   const int32_t* __restrict__ order)
+{
+    for (int64_t s = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; s < n; s += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t src = order ? order[s] : s;
+        const int64_t b = ptr[src];
+        int len = (int)(ptr[src + 1] - b);
+        len_out[s] = len;
+#define PYI(e) (transposed ? (int64_t)(e) * n + s : s * PL + (e))
+#define PY(e) out[PYI(e)]
+        for (int i = 0; i < len; ++i) { const double v = (double)val[b + i]; PY(i) = v; rec[PYI(i)] = 1.0 / (v + 1.0); }
+        int64_t off = 0;
+        int k = 0;
+        while (len >= 2 && k + 1 < DTW_MAX_LEVELS) {
+            const int64_t noff = off + (M >> k);
+            const int nlen = len / 2;
+            for (int i = 0; i < nlen; ++i) {
+                const double v = (PY(off + 2 * i) + PY(off + 2 * i + 1)) / 2.0;
+                PY(noff + i) = v;
+                rec[PYI(noff + i)] = 1.0 / (v + 1.0);
+            }
+            off = noff; len = nlen; ++k;
+        }
+#undef PY
+#undef PYI
+    }
+}
+
+__device__ static inline double dtw_cost(double a, double b) {            // gamma.py:51-52
+    const double mx = a > b ? a : b, mn = a > b ? b : a;
+    return (mx + 1.0) / (mn + 1.0) - 1.0;
+}
+
+// The same cost from a1 = a + 1, b1 = b + 1 and their correctly rounded reciprocals ra, rb, without
+// a divide instruction sequence: q0 = RN(mx * r), rem = mx - q0 * mn (exact in an fma),
+// q = RN(q0 + rem * r) is the correctly rounded quotient mx / mn when r = RN(1 / mn) (Markstein's
+// division step; it can only fail for divisors whose significand is all ones, and mn is a small
+// dyadic rational here).  tests/test_oracle_integer.py::test_reciprocal_division_is_exact runs the
+// identity exhaustively over the integer range and on 10^7 random dyadic pairs on the CPU.
+__device__ __forceinline__ double dtw_cost_rcp(double a1, double ra, double b1, double rb) {
+    // Both quotients, the larger one is max / min: rounding is monotone, so RN(a1 / b1) >= 1 >= RN(b1 / a1) when
+    // a1 >= b1 -- the division step only has to be exact for the quotient that is >= 1 (the direction the CPU test
+    // covers); the other one only has to stay <= 1, and b1 / a1 <= 1 - 2^-24 for these operands.  7 instructions
+    // instead of compare + two 64-bit selects + max + min + the division step.
+    const double qa0 = __dmul_rn(a1, rb), qb0 = __dmul_rn(b1, ra);
+    const double qa = __fma_rn(__fma_rn(-qa0, b1, a1), rb, qa0);
+    const double qb = __fma_rn(__fma_rn(-qb0, a1, b1), ra, qb0);
+    return __dadd_rn(fmax(qa, qb), -1.0);
+}
+
+// A cost for a cell outside the lane's window: only the HIGH word is replaced (one v_cndmask instead of the two a
+// 64-bit select of INF takes), giving a finite value >= 2^1023 whatever the low word holds.  Such a cell then carries
+// min(...) + BIG = BIG or INF: it loses every later comparison against a reachable cell, exactly like INF (no product
+// or difference is ever taken of these values, so no NaN can arise).
+__device__ __forceinline__ double dtw_mask_cost(bool in, double dt) {
+    return __hiloint2double(in ? __double2hiint(dt) : 0x7fe00000, __double2loint(dt));
+}
+
+__global__ __launch_bounds__(DTW_THREADS) void dtw_similarity_kernel(
+    const double* __restrict__ xpyr, const int32_t* __restrict__ xlen, int64_t n_x,
+    const double* __restrict__ ypyr, const int32_t* __restrict__ ylen, int64_t n_y,
+    int tie_order, float* __restrict__ out, double* __restrict__ wd, int32_t* __restrict__ wi,
+    uint32_t* __restrict__ wb, DtwLayout L)
+{
+    const int64_t NT = (int64_t)gridDim.x * blockDim.x;
+    const int64_t tid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+#define WD(k) wd[(int64_t)(k) * NT + tid]
+#define WI(k) wi[(int64_t)(k) * NT + tid]
+#define WB(k) wb[(int64_t)(k) * NT + tid]
+#define ROWSTART(i) WI(i)
+#define LOHI(i) WI(L.MX + (i))
+#define FL(h, i) WI((2 + (h)) * L.MX + (i))
+    // predecessor codes: 0 = (i-1,j), 1 = (i,j-1), 2 = (i-1,j-1); evaluation order per tie_order
+    // tie_order 0 / 1: first minimum over the three sums in that order; 2: the predecessor costs compared with <=
+    // (diagonal, then (i-1,j), then (i,j-1)) before the distance is added (oracle/fastdtw_restate.py)
+    const int o0 = tie_order == 0 ? 0 : 2, o1 = tie_order == 0 ? 1 : 0, o2 = tie_order == 0 ? 2 : 1;
+    const double INF = __longlong_as_double(0x7ff0000000000000ll);
+    const int64_t total = n_x * n_y;
+    for (int64_t pair = tid; pair < total; pair += NT) {
+        // consecutive lanes: consecutive components, same anchor
+        const int64_t a = pair / n_x, r = pair % n_x;
+        const int lx0 = xlen[r], ly0 = ylen[a];
+        if (lx0 == 0 || ly0 == 0) { out[r * n_y + a] = 0.f; continue; }     // padded row: PAD (SubGNN.py:831)
+        const double* __restrict__ yp = ypyr + a * L.YL;
+        int n_levels = 1;
+        {
+            int lx = lx0, ly = ly0;
+            while (lx >= 3 && ly >= 3) { lx >>= 1; ly >>= 1; ++n_levels; }
+        }
+        double result = 0.0;
+        for (int lev = n_levels - 1; lev >= 0; --lev) {
+            const int lx = lx0 >> lev, ly = ly0 >> lev;
+            const int64_t xo = L.xoff[lev], yo = L.yoff[lev];
+            const int hc = lev & 1, hp = (lev + 1) & 1;        // ping-pong halves of first/last
+            if (lev == n_levels - 1) {
+                int cells = 0;
+                for (int i = 0; i < lx; ++i) { LOHI(i) = (ly - 1) << 16; ROWSTART(i) = cells; cells += ly; }
+            } else {
+                const int lxc = lx0 >> (lev + 1);
+                int prev_lo = 0, cells = 0;
+                for (int i = 0; i < lx; ++i) {
+                    const int ci = i >> 1;
+                    const int ca = ci - 1 < 0 ? 0 : (ci - 1 > lxc - 1 ? lxc - 1 : ci - 1);
+                    const int cb = ci + 1 > lxc - 1 ? lxc - 1 : ci + 1;
+                    int lo = 2 * ((FL(hp, ca) & 0xffff) - 1);
+                    int hi = 2 * ((FL(hp, cb) >> 16) + 1) + 1;
+                    if (lo < prev_lo) lo = prev_lo;
+                    if (lo < 0) lo = 0;
+                    if (hi > ly - 1) hi = ly - 1;
+                    if (hi < lo) { lo = 1; hi = 0; }           // empty row marker
+                    LOHI(i) = (hi << 16) | lo;
+                    ROWSTART(i) = cells;
+                    if (hi >= lo) { cells += hi - lo + 1; prev_lo = lo; }
+                }
+            }
+            // DP over the window, row-major (any topological order gives the same cells)
+            int64_t prow = 0, crow = L.MY;
+            int plo = 0, phi = -1;
+            uint32_t acc = 0;
+            int cell = 0;
+            for (int i = 0; i < lx; ++i) {
+                const int lohi = LOHI(i);
+                const int lo = lohi & 0xffff, hi = lohi >> 16;
+                const double xi = xpyr[(xo + i) * n_x + r];
+                double left = INF;
+                double diag = INF;
+                if (i == 0) { if (lo == 0) diag = 0.0; }
+                else if (lo - 1 >= plo && lo - 1 <= phi) diag = WD(prow + lo - 1);
+                for (int j = lo; j <= hi; ++j) {
+                    const double dt = dtw_cost(xi, yp[yo + j]);
+                    double up = INF;
+                    if (i > 0 && j >= plo && j <= phi) up = WD(prow + j);
+                    double c[3];
+                    c[0] = up + dt; c[1] = left + dt; c[2] = diag + dt;
+                    int best = o0;
+                    double bc = c[o0];
+                    if (tie_order == 2) {
+                        best = (diag <= up && diag <= left) ? 2 : (up <= left ? 0 : 1);
+                        bc = c[best];
+                    } else {
+                        if (c[o1] < bc) { bc = c[o1]; best = o1; }
+                        if (c[o2] < bc) { bc = c[o2]; best = o2; }
+                    }
+                    WD(crow + j) = bc;
+                    acc |= (uint32_t)best << ((cell & 15) * 2);
+                    if ((cell & 15) == 15) { WB(cell >> 4) = acc; acc = 0; }
+                    ++cell;
+                    left = bc;
+                    diag = up;                                  // (i-1, j) is the diagonal of (i, j+1)
+                }
+                if (hi >= lo) { const int64_t t = prow; prow = crow; crow = t; plo = lo; phi = hi; }
+            }
+            if (cell & 15) WB(cell >> 4) = acc;
+            result = WD(prow + (ly - 1));
+            if (lev == 0) break;
+            // backtrack: column range of the path per row of THIS level
+            for (int q = 0; q < lx; ++q) FL(hc, q) = ((-1) << 16) | 0xffff;     // last = -1, first = 65535
+            int i = lx - 1, j = ly - 1;
+            while (i >= 0 && j >= 0) {
+                const int fl = FL(hc, i);
+                int first = fl & 0xffff, last = fl >> 16;
+                if (last < j) last = j;
+                if (first > j) first = j;
+                FL(hc, i) = (last << 16) | first;
+                const int lohi = LOHI(i);
+                const int lo = lohi & 0xffff, hi = lohi >> 16;
+                if (j < lo || j > hi) break;                    // cannot happen for a finite path
+                const int c = ROWSTART(i) + (j - lo);
+                const int d = (WB(c >> 4) >> ((c & 15) * 2)) & 3;
+                if (d == 0) --i; else if (d == 1) --j; else { --i; --j; }
+            }
+        }
+        out[r * n_y + a] = (float)(1.0 / (result + 1.0));
+    }
+#undef WD
+#undef WI
+#undef WB
+#undef ROWSTART
+#undef LOHI
+#undef FL
+}
+
+// ---- register-resident variant for components of at most DTW_R entries ---------------------------
+// One wavefront = 64 pairs that share the ANCHOR (y is wave-uniform) and hold 64 consecutive x rows of
+// the caller's processing order, one pair per lane.  The DP runs column-major (any topological order
+// fills identical cells and makes identical predecessor choices): the row values of the previous
+// column live in registers and are updated in place while the column index j walks the anchor series,
+// so the DP state never leaves the register file.  The row loop is fully unrolled (static register
+// indexing).
+//
+// Which (row, column) cells a wavefront evaluates is decided with SCALAR control (round 3; rounds 1-2
+// tested a 4-row block per lane and swept 554 cells of the finest level where a pair's own window has
+// 348 and the union over the 64 lanes 433-483):
+//   * fastdtw's window is the same for the fine rows 2p and 2p+1 (both come from coarse row p), so the
+//     unit is the ROW PAIR: one window test per pair and column;
+//   * per level the 64 lanes' windows are united per row pair (packed 16-bit max over the wavefront with
+//     DPP row shifts / broadcasts: hull [min lo, max hi]) and turned into a per-COLUMN range of row pairs
+//     [ra_j, rb_j] (lane c works out column c's range; the column loop fetches it with v_readlane);
+//   * a column enters the unrolled row chain at pair ra_j through a scalar branch tree and leaves it
+//     after pair rb_j: exactly the hull's cells are evaluated, lanes whose own window does not hold
+//     the cell get a cost >= 2^1023 (dtw_mask_cost).  A row is evaluated over one contiguous column
+//     interval; its register is INF before that interval and stale after it -- the only later reader
+//     of a stale register would be the diagonal of the entry row of a later column, which is taken
+//     from the register only when the row above the entry pair was evaluated in the previous column
+//     (scalar flag), and is INF otherwise.  Rows >= lx of the last pair compute values nobody reads.
+// One 32-bit word of 2-bit predecessor codes per column is the only per-cell state written to memory
+// (LDS, or the global scratch for long anchor series) on the levels that are backtracked (they have at
+// most DTW_R / 2 = 16 rows); the backtrack reads it back and keeps the per-row column range of the
+// path in LDS for the next finer level.  The finest level -- more than half of all cells -- is never
+// backtracked: it neither tracks nor stores predecessors, and takes one add instead of three.
+#define DTW_R 32
+#ifndef DTW_MINB12
+#define DTW_MINB12 3            // resident 256-thread blocks per CU the 12-row kernel is compiled for
+#endif
+#ifndef DTW_MINB32
+#define DTW_MINB32 2
+#endif
+#ifndef DTW_MINB20
+#define DTW_MINB20 3            // 168 registers: 3 wavefronts per SIMD (5.46 -> 4.65 ms on the benchmark's external side)
+#endif
+
+typedef unsigned short dtw_us2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t dtw_pkmax(uint32_t a, uint32_t b) {          // v_pk_max_u16
+    const dtw_us2 m = __builtin_elementwise_max(__builtin_bit_cast(dtw_us2, a), __builtin_bit_cast(dtw_us2, b));
+    return __builtin_bit_cast(uint32_t, m);
+}
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ uint32_t dtw_dpp(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, ROW_MASK, 0xf, false);
+}
+// both 16-bit halves maximised over the 64 lanes (all lanes must be executing); result wave-uniform
+__device__ __forceinline__ uint32_t dtw_wave_pkmax(uint32_t v) {
+    v = dtw_pkmax(v, dtw_dpp<0xb1, 0xf>(v));            // quad_perm [1,0,3,2]
+    v = dtw_pkmax(v, dtw_dpp<0x4e, 0xf>(v));            // quad_perm [2,3,0,1]
+    v = dtw_pkmax(v, dtw_dpp<0x124, 0xf>(v));           // row_ror:4
+    v = dtw_pkmax(v, dtw_dpp<0x128, 0xf>(v));           // row_ror:8   -> every lane holds its row's maximum
+    v = dtw_pkmax(v, dtw_dpp<0x142, 0xa>(v));           // row_bcast:15 into rows 1 and 3
+    v = dtw_pkmax(v, dtw_dpp<0x143, 0xc>(v));           // row_bcast:31 into rows 2 and 3
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+// One level of the register-resident DP for a wavefront, unrolled over RR (even) rows = RR / 2 row pairs.
+// fl: this lane's column of the workgroup's LDS table (stride DTW_THREADS words) holding the coarser
+// path's first | last << 16 column per row.  act: the lane has a pair and this level exists for it;
+// inactive lanes run along with empty windows.  ly / lyc are wave-uniform (one anchor per wavefront).
+// Predecessor codes of a non-finest level go to wl (LDS) when WLDS, else to the global scratch wq.
+template <int RR, int TIE, bool WLDS, bool FINEST>
+__device__ __forceinline__ double dtw_wave_level(
+    int32_t* __restrict__ fl, const double* __restrict__ xcol, const double* __restrict__ xrcol, int64_t n_x,
+    const double* __restrict__ ycol, const double* __restrict__ yrcol, bool act,
+    int lx, int ly, int lxc, int lyc, bool coarsest, uint32_t* __restrict__ wl, uint32_t* __restrict__ wq, int64_t NT)
+{
+    static_assert(RR % 2 == 0 && RR <= 32, "rows come in pairs");
+    constexpr int P = RR / 2;
+#define FLQ(q) fl[(q) * DTW_THREADS]
+    const double INF = __longlong_as_double(0x7ff0000000000000ll);
+    const int32_t EMPTY = 1;                                  // lo = 1, hi = 0
+    // ---- this lane's window per row pair (rows 2p and 2p+1 share coarse row p) ----
+    int32_t lohi[P];
+    if (coarsest) {
+#pragma unroll
+        for (int p = 0; p < P; ++p) lohi[p] = (act && 2 * p < lx) ? ((ly - 1) << 16) : EMPTY;
+    } else {
+        int prev_lo = 0;
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            const int ca = p - 1 < 0 ? 0 : p - 1;                            // <= lxc - 1 for every real row
+            const int cb = p + 1;                                            // rows past the coarse path's end
+            const int firstc = FLQ(ca) & 0xffff;                             // take its last column
+            const int lastc = (cb < lxc) ? (FLQ(cb < P ? cb : P - 1) >> 16) : (lyc - 1);
+            int lo = 2 * (firstc - 1);
+            int hi = 2 * (lastc + 1) + 1;
+            if (lo < prev_lo) lo = prev_lo;
+            if (lo < 0) lo = 0;
+            if (hi > ly - 1) hi = ly - 1;
+            int32_t v = (hi << 16) | lo;
+            if (hi < lo || 2 * p >= lx || !act) v = EMPTY; else prev_lo = lo;
+            lohi[p] = v;
+        }
+    }
+    // ---- hull of the 64 lanes' windows per row pair: (0x7fff - lo) << 16 | (hi + 1), both halves maximised ----
+    uint32_t hull[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        const uint32_t lo = lohi[p] & 0xffff, hi = (uint32_t)lohi[p] >> 16;
+        hull[p] = dtw_wave_pkmax(lohi[p] == EMPTY ? 0u : (((0x7fffu - lo) << 16) | (hi + 1)));
+    }
+    double xp1[RR], xr[RR], col[RR];
+#pragma unroll
+    for (int i = 0; i < RR; ++i) {
+        const int64_t ic = i < lx ? i : 0;                                   // rows past the series repeat row 0: nobody reads them,
+        xp1[i] = xcol[ic * n_x] + 1.0;                                       // and all loads of the level are in flight together
+        xr[i] = xrcol[ic * n_x];
+        col[i] = INF;
+    }
+    const int lane = threadIdx.x & 63;
+    uint32_t prev_am = 0;                                                    // the previous column's row-pair mask
+    for (int jc = 0; jc < ly; jc += 64) {
+        // lane c: the row pairs column jc + c touches in the hull, as a bit mask (pairs [ra, rb1)) | ra << 16
+        uint32_t tab;
+        {
+            const uint32_t c = (uint32_t)(jc + lane);
+            uint32_t ra = P, rb1 = 0;
+#pragma unroll
+            for (int p = P - 1; p >= 0; --p) ra = ((hull[p] & 0xffffu) > c) ? (uint32_t)p : ra;              // hi >= c
+#pragma unroll
+            for (int p = 0; p < P; ++p) rb1 = (hull[p] != 0u && (0x7fffu - (hull[p] >> 16)) <= c) ? (uint32_t)(p + 1) : rb1;
+            tab = rb1 > ra ? ((((1u << rb1) - 1u) & ~((1u << ra) - 1u)) | (ra << 16)) : 0u;
+        }
+        const int jend = jc + 64 < ly ? jc + 64 : ly;
+        double y_next = ycol[jc], yr_next = yrcol[jc];
+        for (int j = jc; j < jend; ++j) {
+            const double yp1 = y_next + 1.0, yr = yr_next;
+            if (j + 1 < ly) { y_next = ycol[j + 1]; yr_next = yrcol[j + 1]; }   // in flight during this column
+            const uint32_t t = (uint32_t)__builtin_amdgcn_readlane((int)tab, j - jc);
+            const uint32_t am = t & 0xffffu;                                 // 0: no lane holds this column (cannot happen for real series)
+            const int ra = (int)(t >> 16);
+            // the row above the entry pair was evaluated in the previous column: its register is D[2 ra - 1][j - 1]
+            const bool carry = ra > 0 && ((prev_am >> (ra - 1)) & 1u);
+            prev_am = am;
+            uint32_t word = 0;
+            // The row chain, written so that no value has to be copied between rows or at the chain's entry points:
+            //  * a cell's result goes INTO the row's register, and everything later cells need of the OLD value is
+            //    formed first -- on the finest level pm = min(D[i][j-1], D[i+1][j-1]) (the next row's left and diagonal
+            //    predecessors; min is exact, its grouping does not matter), elsewhere cd = D[i][j-1] + cost(i+1, j) (the
+            //    next row's diagonal candidate inside a pair; the tie rules need the three sums apart) and one copy dg of
+            //    the pair's last old value for the next pair;
+            //  * "up" is the register of the row above; the entry pair, whose row above is not part of this column, runs
+            //    its own copy of the pair's first cell with up = INF and joins the chain behind it.
+            double pm = INF, cd = INF, dg = INF, da = INF;
+            bool in_ = false;
+            double dt1_ = 0.0;
+#define DTW_IN(K) { const int lo_ = lohi[(K) < P ? (K) : 0] & 0xffff, hi_ = lohi[(K) < P ? (K) : 0] >> 16; in_ = j >= lo_ && j <= hi_; }
+#define DTW_COST(I) dtw_mask_cost(in_, dtw_cost_rcp(xp1[(I) < RR ? (I) : 0], xr[(I) < RR ? (I) : 0], yp1, yr))
+            // first cell of pair K (row 2K); UPV = the value above it
+#define DTW_CELL_A(K, UPV)                                                                                           \
+            {                                                                                                        \
+                constexpr int a_ = 2 * (K) < RR ? 2 * (K) : 0, b_ = 2 * (K) + 1 < RR ? 2 * (K) + 1 : 0;              \
+                const double dt0_ = DTW_COST(2 * (K));                                                               \
+                dt1_ = DTW_COST(2 * (K) + 1);                                                                        \
+                if constexpr (FINEST) {                                                                              \
+                    /* only the value is needed: rounding is monotone, so the smallest of the three rounded sums */  \
+                    /* is the rounded sum of the smallest candidate -- one add instead of three */                    \
+                    const double m_ = fmin(pm, (UPV));                                                               \
+                    pm = fmin(col[a_], col[b_]);                                                                     \
+                    col[a_] = m_ + dt0_;                                                                             \
+                } else {                                                                                             \
+                    const double c_up = (UPV) + dt0_, c_left = col[a_] + dt0_, c_diag = dg + dt0_;                   \
+                    const double mv = fmin(fmin(c_up, c_left), c_diag);      /* two v_min_f64 (no NaNs here) */       \
+                    /* predecessor = the first candidate, in the tie order, that attains the minimum; a cell */      \
+                    /* outside the lane's window is never read back, whatever code it gets */                        \
+                    uint32_t best;                                                                                   \
+                    if (TIE == 0) best = c_up == mv ? 0u : (c_left == mv ? 1u : 2u);        /* (i-1,j), (i,j-1), (i-1,j-1) */ \
+                    else if (TIE == 1) best = c_diag == mv ? 2u : (c_up == mv ? 0u : 1u);   /* (i-1,j-1), (i-1,j), (i,j-1) */ \
+                    else best = (dg <= (UPV) && dg <= col[a_]) ? 2u : ((UPV) <= col[a_] ? 0u : 1u);   /* on the predecessor costs, <= */ \
+                    word |= best << (2 * a_);                                                                        \
+                    if (TIE == 2) da = col[a_]; else cd = col[a_] + dt1_;    /* (i, j-1) is the diagonal of (i+1, j) */ \
+                    col[a_] = mv;                                                                                    \
+                }                                                                                                    \
+            }
+            // second cell of pair K (row 2K+1): the row above is the pair's first
+#define DTW_CELL_B(K)                                                                                                \
+            {                                                                                                        \
+                constexpr int a_ = 2 * (K) < RR ? 2 * (K) : 0, b_ = 2 * (K) + 1 < RR ? 2 * (K) + 1 : 0;              \
+                constexpr int c_ = 2 * (K) + 2 < RR ? 2 * (K) + 2 : b_;                                              \
+                if constexpr (FINEST) {                                                                              \
+                    const double m_ = fmin(pm, col[a_]);                                                             \
+                    pm = fmin(col[b_], col[c_]);                                                                     \
+                    col[b_] = m_ + dt1_;                                                                             \
+                } else {                                                                                             \
+                    const double c_up = col[a_] + dt1_, c_left = col[b_] + dt1_, c_diag = TIE == 2 ? da + dt1_ : cd; \
+                    const double mv = fmin(fmin(c_up, c_left), c_diag);                                              \
+                    uint32_t best;                                                                                   \
+                    if (TIE == 0) best = c_up == mv ? 0u : (c_left == mv ? 1u : 2u);                                 \
+                    else if (TIE == 1) best = c_diag == mv ? 2u : (c_up == mv ? 0u : 1u);                            \
+                    else best = (da <= col[a_] && da <= col[b_]) ? 2u : (col[a_] <= col[b_] ? 0u : 1u);              \
+                    word |= best << (2 * b_);                                                                        \
+                    dg = col[b_];                                            /* the next pair's diagonal */           \
+                    col[b_] = mv;                                                                                    \
+                }                                                                                                    \
+            }
+            // one structured, wave-uniform region per row pair (scalar bit test), skipped unless the column touches the
+            // pair.  At the entry pair the row above is not part of this column (nor of any later one: the ranges only
+            // move down): its register hands over the diagonal if it was evaluated in the previous column and is then
+            // set to INF for good, which makes it the "up" the first cell needs -- the chain itself has no special case.
+#define DTW_PAIR(K)                                                                                                  \
+            if ((K) < P && (am & (1u << (K)))) {                                                                     \
+                constexpr int u_ = (2 * (K) - 1) >= 0 && (2 * (K) - 1) < RR ? (2 * (K) - 1) : 0;                     \
+                DTW_IN(K)                                                                                            \
+                if ((K) == 0) {                                                                                      \
+                    const double diag = (j == 0) ? 0.0 : INF;                /* virtual origin D[-1][-1] = 0 */       \
+                    if constexpr (FINEST) pm = fmin(diag, col[0]); else dg = diag;                                   \
+                    DTW_CELL_A(K, INF)                                                                               \
+                } else {                                                                                             \
+                    if (ra == (K)) {                                                                                 \
+                        const double diag = carry ? col[u_] : INF;                                                   \
+                        if constexpr (FINEST) pm = fmin(diag, col[2 * (K) < RR ? 2 * (K) : 0]); else dg = diag;      \
+                        col[u_] = INF;                                                                               \
+                        asm volatile("" ::: "memory");                       /* keeps this a branch: as selects it costs every pair 9 instructions */ \
+                    }                                                                                                \
+                    DTW_CELL_A(K, col[u_])                                                                           \
+                }                                                                                                    \
+                DTW_CELL_B(K)                                                                                        \
+            }
+            DTW_PAIR(0) DTW_PAIR(1) DTW_PAIR(2) DTW_PAIR(3) DTW_PAIR(4) DTW_PAIR(5) DTW_PAIR(6) DTW_PAIR(7)
+            DTW_PAIR(8) DTW_PAIR(9) DTW_PAIR(10) DTW_PAIR(11) DTW_PAIR(12) DTW_PAIR(13) DTW_PAIR(14) DTW_PAIR(15)
+#undef DTW_IN
+#undef DTW_CELL_A
+#undef DTW_CELL_B
+#undef DTW_COST
+#undef DTW_PAIR
+            if (!FINEST) {                                                   // the finest level is never backtracked
+                if (WLDS) wl[j * DTW_THREADS] = word; else wq[(int64_t)j * NT] = word;
+            }
+        }
+    }
+    double result = 0.0;
+#pragma unroll
+    for (int i = 0; i < RR; ++i) if (i == lx - 1) result = col[i];
+    if (FINEST || !act) return result;
+#ifdef DTW_PROBE_NO_BACKTRACK
+    return result;
+#endif
+    // backtrack through the predecessor codes; record the path's column range per row
+#pragma unroll
+    for (int q = 0; q < RR; ++q) FLQ(q) = 0xffff;                            // first = 65535, last = 0
+    int i = lx - 1, j = ly - 1;
+    while (i >= 0 && j >= 0) {
+        const int v = FLQ(i);
+        int f = v & 0xffff, l = v >> 16;
+        f = j < f ? j : f;
+        l = j > l ? j : l;
+        FLQ(i) = (l << 16) | f;
+        const uint32_t word = WLDS ? wl[j * DTW_THREADS] : wq[(int64_t)j * NT];
+        const int d = (int)((word >> (2 * i)) & 3);
+        if (d == 0) --i; else if (d == 1) --j; else { --i; --j; }
+    }
+    return result;
+#undef FLQ
+}
+
+// RMAX = rows the instantiation can hold (12 / 20 / 32): the register budget -- and with it the
+// number of resident wavefronts that hide the fp64 dependency chains -- follows the longest
+// component of the call, not the longest the kernel family supports.  The levels that are backtracked
+// have at most RMAX / 2 rows: one instantiation of the level for them, one for the finest.
+template <int RMAX, int TIE, int MINB, bool WLDS>
+__global__ __launch_bounds__(DTW_THREADS, MINB) void dtw_similarity_reg_kernel(
+    const double* __restrict__ xpyr, const int32_t* __restrict__ xlen, int64_t n_x,
+    const double* __restrict__ ypyr, const int32_t* __restrict__ ylen, int64_t n_y,
+    float* __restrict__ out, uint32_t* __restrict__ wq, DtwLayout L, const int32_t* __restrict__ x_order,
+    const int64_t* __restrict__ x_live)
+{
+    constexpr int RH = ((RMAX / 2) + 1) & ~1;                 // rows of the coarser levels, even
+    __shared__ int32_t s_fl[RH * DTW_THREADS];
+    extern __shared__ uint32_t s_words[];                    // WLDS: (max_y_len / 2) x DTW_THREADS predecessor words
+    int32_t* fl = s_fl + threadIdx.x;
+    uint32_t* wl = s_words + threadIdx.x;
+    const int64_t NT = (int64_t)gridDim.x * blockDim.x;
+    const int64_t tid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    // x_live = {first, count}: only these positions of the processing order hold non-empty rows (the caller
+    // sorted the empty ones to the front and zeroed their output rows)
+    const int64_t first_live = x_live ? x_live[0] : 0;
+    const int64_t n_live = x_live ? x_live[1] : n_x;
+    const int64_t chunks = (n_live + 63) / 64;                // a task = one anchor x 64 consecutive positions
+    const int64_t n_tasks = chunks * n_y;
+    const int64_t n_waves = NT / 64;
+    const int64_t wave0 = __builtin_amdgcn_readfirstlane((int)(tid >> 6));
+    for (int64_t task = wave0; task < n_tasks; task += n_waves) {
+        const int64_t a = task / chunks;
+        const int64_t p0 = first_live + (task - a * chunks) * 64 + lane;   // position in the processing order:
+        const bool have = p0 < first_live + n_live;                        // the pyramids are laid out by position
+        const int64_t pos = have ? p0 : first_live;
+        const int64_t r = x_order ? x_order[pos] : pos;
+        const int ly0 = ylen[a];
+        const int lx0 = have ? xlen[pos] : 0;
+        const bool valid = have && lx0 > 0 && ly0 > 0;
+        int n_levels = 0;
+        if (valid) {
+            n_levels = 1;
+            int lx = lx0, ly = ly0;
+            while (lx >= 3 && ly >= 3) { lx >>= 1; ly >>= 1; ++n_levels; }
+        }
+        const int max_levels = (int)(dtw_wave_pkmax((uint32_t)n_levels) & 0xffff);
+        const double* __restrict__ yp = ypyr + a * L.YL;
+        double result = 0.0;
+        for (int lev = max_levels - 1; lev >= 0; --lev) {
+            const bool act = lev < n_levels;
+            const int lx = act ? lx0 >> lev : 0, ly = ly0 >> lev;
+            const int lxc = lx0 >> (lev + 1), lyc = ly0 >> (lev + 1);
+            const double* xcol = xpyr + L.xoff[lev] * n_x + pos;
+            const double* xrcol = xcol + L.XL * n_x;                        // reciprocal pyramids follow the values
+            const double* ycol = yp + L.yoff[lev];
+            const double* yrcol = ycol + L.YL * n_y;
+            uint32_t* w = wq + (L.yoff[lev] - L.MY) * NT + tid;         // levels >= 1 only (not dereferenced on level 0)
+            const bool coarsest = lev == n_levels - 1;
+#ifdef DTW_PROBE_NO_FINEST                                       /* measurement only: wrong results */
+            if (lev == 0) continue;
+#endif
+#ifdef DTW_PROBE_NO_COARSE
+            if (lev != 0) continue;
+#endif
+            if (lev == 0)
+                result = dtw_wave_level<RMAX, TIE, WLDS, true>(fl, xcol, xrcol, n_x, ycol, yrcol, act, lx, ly, lxc, lyc,
+                                                               coarsest, wl, w, NT);
+            else
+                dtw_wave_level<RH, TIE, WLDS, false>(fl, xcol, xrcol, n_x, ycol, yrcol, act, lx, ly, lxc, lyc, coarsest,
+                                                     wl, w, NT);
+        }
+        if (have) out[r * n_y + a] = valid ? (float)(1.0 / (result + 1.0)) : 0.f;
+    }
+}
+
+// Processing-order key of the x rows of a DTW call: (length, the row's TWICE-HALVED series -- means of four
+// consecutive entries, what fastdtw's second coarsening level sees -- on a log scale, 8 steps per octave, up to six of
+// them, first to last).  A pair's finest-level window follows from its coarse warp paths, and those from the coarse
+// series: rows whose coarse series agree sweep the same windows, so the lanes of a wavefront (consecutive rows of the
+// order, same anchor) stay in step.  Replay of 32 wavefronts of the benchmark's external side through the oracle:
+// cells evaluated per pair on the finest level 558 with round 1's key (length, four quantiles of the raw row), 500
+// with this one (a lane's own window: 347); kernel 7.1 -> see DESIGN.  Results do not depend on the order.
+__global__ void dtw_order_keys_kernel(const int64_t* __restrict__ x_ptr, const int32_t* __restrict__ x_val, int64_t n_x,
+                                      int64_t* __restrict__ keys)
+{
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= n_x) return;
+    const int64_t b = x_ptr[i], len = x_ptr[i + 1] - b;
+    int64_t key = (len > 0xFFF ? (int64_t)0xFFF : len) << 48;
+    auto q8 = [](float v) { const int q = (int)lrintf(8.f * log2f(1.f + (v < 0.f ? 0.f : v))); return (int64_t)(q > 255 ? 255 : q); };
+    const int64_t n2 = len / 4;
+    if (n2 == 0) {
+        for (int64_t f = 0; f < len; ++f) key |= q8((float)x_val[b + f]) << (40 - 8 * f);
+    } else {
+        const int64_t nf = n2 < 6 ? n2 : 6;
+        for (int64_t f = 0; f < nf; ++f) {
+            const int64_t g = b + 4 * ((f * n2) / nf);
+            const float v = 0.25f * ((float)x_val[g] + (float)x_val[g + 1] + (float)x_val[g + 2] + (float)x_val[g + 3]);
+            key |= q8(v) << (40 - 8 * f);
+        }
+    }
+    keys[i] = key;
+}
+
+extern "C" int sgnn_dtw_order_keys(const int64_t* x_ptr, const int32_t* x_val, int64_t n_x, int64_t* out_keys, void* stream)
+{
+    if (!x_ptr || !x_val || !out_keys || n_x < 0) return SGNN_ERR_BAD_ARG;
+    if (n_x == 0) return SGNN_OK;
+    hipLaunchKernelGGL(dtw_order_keys_kernel, dim3((unsigned)((n_x + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x_ptr,
+                       x_val, n_x, out_keys);
+    SGNN_CHECK_LAUNCH();
+    return SGNN_OK;
+}
+
+static int g_dtw_force_general = 0;
+/* test hook: 1 = always take the general (workspace-resident) kernel, 0 = pick by size */
+extern "C" int sgnn_dtw_force_general(int on) { const int old = g_dtw_force_general; g_dtw_force_general = on; return old; }
+
+static int dtw_run(const int64_t* x_ptr, const int32_t* x_val, int64_t n_x, int64_t max_x_len,
+                   const int64_t* y_ptr, const int32_t* y_val, int64_t n_y, int64_t max_y_len,
+                   int tie_order, const int32_t* x_order, const int64_t* x_live, float* out, void* workspace,
+                   int64_t workspace_bytes, void* stream)
+{
+    if (!x_ptr || !x_val || !y_ptr || !y_val || !out || !workspace || n_x < 0 || n_y < 0) return SGNN_ERR_BAD_ARG;
+    if (tie_order < 0 || tie_order > 2) return SGNN_ERR_BAD_ARG;
+    if (max_x_len < 1) max_x_len = 1;
+    if (max_y_len < 1) max_y_len = 1;
+    if (max_x_len > 32767 || max_y_len > 32767) return SGNN_ERR_SET_TOO_LARGE;
+    if (workspace_bytes < sgnn_dtw_workspace_bytes(n_x, max_x_len, n_y, max_y_len)) return SGNN_ERR_BAD_ARG;
+    if (n_x * n_y == 0) return SGNN_OK;
+    const DtwLayout L = dtw_layout(max_x_len, max_y_len);
+    hipStream_t st = (hipStream_t)stream;
+    char* w = (char*)workspace;
+    const int64_t scratch = dtw_scratch_bytes(L);
+    double* wd = (double*)w;
+    int32_t* wi = (int32_t*)(w + DTW_NT * L.n_dbl * 8);
+    uint32_t* wb = (uint32_t*)(w + DTW_NT * (L.n_dbl * 8 + dtw_align8(L.n_i32 * 4)));
+    uint32_t* wq = (uint32_t*)w;           w += scratch;
+    double* xpyr = (double*)w;             w += 2 * n_x * L.XL * 8;          // values, then reciprocals of value + 1
+    double* ypyr = (double*)w;             w += 2 * n_y * L.YL * 8;
+    int32_t* xlen = (int32_t*)w;           w += dtw_align8(n_x * 4);
+    int32_t* ylen = (int32_t*)w;
+    const bool use_reg = max_x_len <= DTW_R && !g_dtw_force_general;
+    hipLaunchKernelGGL(dtw_pyramid_kernel, dim3(sgnn_grid_for(n_x, 256)), dim3(256), 0, st, x_ptr, x_val, n_x,
+                       max_x_len, L.XL, 1, xpyr, xpyr + n_x * L.XL, xlen, use_reg ? x_order : (const int32_t*)nullptr);
+    SGNN_CHECK_LAUNCH();
+    hipLaunchKernelGGL(dtw_pyramid_kernel, dim3(sgnn_grid_for(n_y, 256)), dim3(256), 0, st, y_ptr, y_val, n_y,
+                       max_y_len, L.YL, 0, ypyr, ypyr + n_y * L.YL, ylen, (const int32_t*)nullptr);
+    SGNN_CHECK_LAUNCH();
+    if (use_reg) {
+        // predecessor words of the coarse levels in LDS when (max_y_len / 2) words per lane fit
+        const int64_t words = max_y_len >> 1;
+        const bool wlds = dtw_words_in_lds(max_y_len);
+        const size_t dyn = wlds ? (size_t)((words > 0 ? words : 1) * DTW_THREADS * 4) : 0;
+#define DTW_LAUNCH2(RMAX, TIE, MINB, WL) \
+        hipLaunchKernelGGL((dtw_similarity_reg_kernel<RMAX, TIE, MINB, WL>), dim3(DTW_REG_BLOCKS), dim3(DTW_THREADS), dyn, st, \
+                           xpyr, xlen, n_x, ypyr, ylen, n_y, out, wq, L, x_order, x_live)
+#define DTW_LAUNCH(RMAX, TIE, MINB) do { if (wlds) DTW_LAUNCH2(RMAX, TIE, MINB, true); else DTW_LAUNCH2(RMAX, TIE, MINB, false); } while (0)
+#define DTW_LAUNCH_T(RMAX, MINB) do { if (tie_order == 0) DTW_LAUNCH(RMAX, 0, MINB); else if (tie_order == 1) DTW_LAUNCH(RMAX, 1, MINB); else DTW_LAUNCH(RMAX, 2, MINB); } while (0)
+        if (max_x_len <= 12) DTW_LAUNCH_T(12, DTW_MINB12);
+        else if (max_x_len <= 20) DTW_LAUNCH_T(20, DTW_MINB20);
+        else DTW_LAUNCH_T(32, DTW_MINB32);
+#undef DTW_LAUNCH_T
+#undef DTW_LAUNCH2
+#undef DTW_LAUNCH
+    } else {
+        hipLaunchKernelGGL(dtw_similarity_kernel, dim3(DTW_BLOCKS), dim3(DTW_THREADS), 0, st, xpyr, xlen, n_x, ypyr,
+                           ylen, n_y, tie_order, out, wd, wi, wb, L);
+    }
+    SGNN_CHECK_LAUNCH();
+    return SGNN_OK;
+}
+
+extern "C" int sgnn_dtw_similarity(const int64_t* x_ptr, const int32_t* x_val, int64_t n_x, int64_t max_x_len,
+                                   const int64_t* y_ptr, const int32_t* y_val, int64_t n_y, int64_t max_y_len,
+                                   int tie_order, const int32_t* x_order, float* out, void* workspace,
+                                   int64_t workspace_bytes, void* stream)
+{
+    return dtw_run(x_ptr, x_val, n_x, max_x_len, y_ptr, y_val, n_y, max_y_len, tie_order, x_order, nullptr, out, workspace,
+                   workspace_bytes, stream);
+}
+
+extern "C" int sgnn_dtw_similarity_live(const int64_t* x_ptr, const int32_t* x_val, int64_t n_x, int64_t max_x_len,
+                                        const int64_t* y_ptr, const int32_t* y_val, int64_t n_y, int64_t max_y_len,
+                                        int tie_order, const int32_t* x_order, const int64_t* x_live_range, float* out,
+                                        void* workspace, int64_t workspace_bytes, void* stream)
+{
+    if (x_live_range && !x_order) return SGNN_ERR_BAD_ARG;
+    return dtw_run(x_ptr, x_val, n_x, max_x_len, y_ptr, y_val, n_y, max_y_len, tie_order, x_order, x_live_range, out,
+                   workspace, workspace_bytes, stream);
+}
