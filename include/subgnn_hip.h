@@ -5,9 +5,8 @@
  * Conventions
  *   - every pointer is a DEVICE pointer into caller-owned memory (torch tensors on the host
  *     side); nothing is allocated or freed inside; every call is asynchronous on `stream`
- *     (a hipStream_t passed as void*), graph-capturable, and stateless -- except for three process-wide
- *     test / tuning switches (sgnn_bfs_hops_tuning, sgnn_dtw_force_general, sgnn_walks_force_wave), which select
- *     between kernels that compute the same values and are not meant to be flipped while calls are in flight;
+ *     (a hipStream_t passed as void*), graph-capturable, and stateless: the library keeps no settings between
+ *     calls (where two kernels compute the same values, the choice is an argument of the call: `kernel`, `pull_alpha`);
  *   - return value: 0 = launched, negative = SGNN_ERR_* (argument errors are detected on the
  *     host before any launch; nothing throws across the ABI);
  *   - node ids are 1-based, 0 = PAD (reference config.py:9, SubGNN/SubGNN.py:554-559);
@@ -39,7 +38,7 @@ extern "C" {
 #define SGNN_ERR_LAUNCH         -4   /* hipGetLastError() after a launch */
 #define SGNN_ERR_UNSUPPORTED_D  -5   /* embedding width not supported by the vector path */
 
-#define SGNN_ABI_VERSION 3
+#define SGNN_ABI_VERSION 4
 int sgnn_abi_version(void);
 /* last hip error string for SGNN_ERR_LAUNCH (static storage) */
 const char* sgnn_last_error(void);
@@ -200,15 +199,14 @@ int sgnn_choice_ragged(const int64_t* ptr, const int32_t* seq, int64_t n_items, 
  * max_id: largest node id (rowptr has max_id + 2 entries); when the id range fits an LDS bitmap
  * (~1.1 M ids) a workgroup-per-walk kernel is used (adjacency to the previous node = one bit
  * test), else a wavefront-per-walk kernel (binary search in the sorted list); max_id <= 0 or
- * sgnn_walks_force_wave(1) select the latter.  Both give the same walks.
+ * kernel = 1 select the latter (kernel = 0: pick by graph size).  Both give the same walks.
  * ------------------------------------------------------------------------------------- */
 int sgnn_triangular_walks(const int64_t* rowptr, const int32_t* col, const int32_t* col_sorted, int64_t nnz,
                           const int32_t* node_order, int64_t n_nodes,
                           const int64_t* patch_ptr, const int32_t* patch_nodes,
                           const int64_t* inb_ptr, const int32_t* inb_nodes,
                           int mode, int64_t n_items, int64_t walks_per_patch, int64_t walk_len, double beta,
-                          uint64_t seed, uint64_t stream_id, int64_t max_id, int64_t* out, void* stream);
-int sgnn_walks_force_wave(int on);
+                          uint64_t seed, uint64_t stream_id, int64_t max_id, int kernel, int64_t* out, void* stream);
 
 /* in-border nodes of a patch (subgraph_utils.get_border_nodes, subgraph_utils.py:126-144, with
  * its id-1 / node-order indexing quirk): out_flag[i] = 1 iff patch_nodes[i] is a border node.
@@ -235,12 +233,10 @@ int sgnn_sp_similarity_dense(const double* apsp, int64_t n_cols,
  * workspace: sgnn_bfs_hops_workspace_bytes(max_id, n_sources, max_hops) bytes (any content).
  * The expansion is direction-optimising: a level pulls (every incomplete node ORs its neighbours'
  * frontier words) instead of pushing once the frontier's edge volume exceeds 1/alpha of all edges.
- * sgnn_bfs_hops_tuning sets alpha process-wide (default 32; 0 = always push); results do not depend
- * on it. */
+ * pull_alpha: that alpha (negative = the default, 32; 0 = always push); results do not depend on it. */
 int64_t sgnn_bfs_hops_workspace_bytes(int64_t max_id, int64_t n_sources, int max_hops);
-int sgnn_bfs_hops_tuning(int alpha);
 int sgnn_bfs_hops(const int64_t* rowptr, const int32_t* col, int64_t nnz, int64_t max_id,
-                  const int32_t* sources, int64_t n_sources, int max_hops, int node_major,
+                  const int32_t* sources, int64_t n_sources, int max_hops, int node_major, int pull_alpha,
                   uint8_t* dist, void* workspace, int64_t workspace_bytes, void* stream);
 /* out[r, a] = min over v in set r of (dist[a, v] == 255 ? 0 : dist[a, v])  (float32; empty set -> 0) */
 /* node_major != 0: dist is laid out (max_id + 1, n_sources) instead -- the sources of a node are
@@ -261,7 +257,7 @@ int sgnn_min_hops_to_sets(const uint8_t* dist, int64_t n_sources, int64_t max_id
  * margin afterwards, checking [1] at its next synchronisation point. */
 int64_t sgnn_bfs_min_hops_workspace_bytes(int64_t max_id, int64_t n_sources, int max_hops, int64_t n_sets);
 int sgnn_bfs_min_hops_to_sets(const int64_t* rowptr, const int32_t* col, int64_t nnz, int64_t max_id,
-                              const int32_t* sources, int64_t n_sources, int max_hops,
+                              const int32_t* sources, int64_t n_sources, int max_hops, int pull_alpha,
                               const int64_t* set_ptr, const int32_t* set_nodes, int64_t n_sets,
                               float* out, int32_t* out_status, void* workspace, int64_t workspace_bytes, void* stream);
 
@@ -281,12 +277,11 @@ int sgnn_bfs_min_hops_to_sets(const int64_t* rowptr, const int32_t* col, int64_t
  * Sorting by them is the caller's (any sort). */
 int sgnn_dtw_order_keys(const int64_t* x_ptr, const int32_t* x_val, int64_t n_x, int64_t* out_keys, void* stream);
 int64_t sgnn_dtw_workspace_bytes(int64_t n_x, int64_t max_x_len, int64_t n_y, int64_t max_y_len);
-/* test hook: force the general (workspace-resident) kernel instead of the register-resident one
- * that serves x rows of at most 32 entries; returns the previous setting */
-int sgnn_dtw_force_general(int on);
+/* kernel: 0 = pick by size (x rows of at most 32 entries: the register-resident kernel), 1 = the general
+ * (workspace-resident) kernel whatever the size -- same values, bit for bit */
 int sgnn_dtw_similarity(const int64_t* x_ptr, const int32_t* x_val, int64_t n_x, int64_t max_x_len,
                         const int64_t* y_ptr, const int32_t* y_val, int64_t n_y, int64_t max_y_len,
-                        int tie_order, const int32_t* x_order, float* out, void* workspace,
+                        int tie_order, int kernel, const int32_t* x_order, float* out, void* workspace,
                         int64_t workspace_bytes, void* stream);
 /* Same, for callers whose x rows are mostly empty (repeated rows given length 0 by a grouping step):
  * x_live_range (device, int64[2] = {first, count}, nullable) names the positions of the processing
@@ -295,7 +290,7 @@ int sgnn_dtw_similarity(const int64_t* x_ptr, const int32_t* x_val, int64_t n_x,
  * that no host round trip is needed to learn it. */
 int sgnn_dtw_similarity_live(const int64_t* x_ptr, const int32_t* x_val, int64_t n_x, int64_t max_x_len,
                              const int64_t* y_ptr, const int32_t* y_val, int64_t n_y, int64_t max_y_len,
-                             int tie_order, const int32_t* x_order, const int64_t* x_live_range, float* out,
+                             int tie_order, int kernel, const int32_t* x_order, const int64_t* x_live_range, float* out,
                              void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------

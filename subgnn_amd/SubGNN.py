@@ -140,6 +140,11 @@ class SubGNN(nn.Module):
             self.attention = AdditiveAttention(hid_dim, hid_dim, half_operands=str(hp.get('embedding_dtype', 'fp32')).lower()
                                                in ('fp16', 'float16', 'half'))
         hp.setdefault('structure_similarity_fn', 'dtw')
+        # predecessor rule of fastdtw's DP (0: the published pure-Python module, the default; 1 / 2: the variants a compiled
+        # build may implement -- oracle/__init__.py); reaches every DTW launch of the model, dense and sparse path
+        hp.setdefault('dtw_tie_order', 0)
+        if hp['dtw_tie_order'] not in (0, 1, 2):
+            raise ValueError("hparams['dtw_tie_order'] must be 0, 1 or 2")
         # hparams['deterministic'] (default True): gradients by sorted segmented sums and per-row partials -- bit-
         # reproducible; False: float atomics (fewer launches per batch-sized step, sums in arbitrary order).
         # Process-wide (ops.DETERMINISTIC), like the kernels' other switches.
@@ -337,7 +342,7 @@ class SubGNN(nn.Module):
         use_dict = g.full_degree is not None
         a_sets, a_seq = gamma.degree_sequences(g, self.structure_anchors, internal, use_dict)
         c_sets, c_seq = gamma.degree_sequences(g, cc_ids.reshape(S * C, L), internal, use_dict)
-        sims = gamma.dtw_similarity_matrix(c_sets, c_seq, a_sets, a_seq).view(S, C, -1)
+        sims = gamma.dtw_similarity_matrix(c_sets, c_seq, a_sets, a_seq, self.hparams['dtw_tie_order']).view(S, C, -1)
         np.save(fname, sims.cpu().numpy())
         return sims
 

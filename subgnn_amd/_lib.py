@@ -52,23 +52,20 @@ SIGNATURES = {
     'sgnn_sample_anchors_ragged': (c_int, [c_ptr, c_ptr, c_i64, c_ptr, c_i64, c_u64, c_u64, c_i64, c_ptr, c_ptr]),
     'sgnn_choice_ragged': (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_u64, c_u64, c_i64, c_ptr, c_ptr]),
     'sgnn_triangular_walks': (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_int,
-                                      c_i64, c_i64, c_i64, c_dbl, c_u64, c_u64, c_i64, c_ptr, c_ptr]),
-    'sgnn_walks_force_wave': (c_int, [c_int]),
+                                      c_i64, c_i64, c_i64, c_dbl, c_u64, c_u64, c_i64, c_int, c_ptr, c_ptr]),
     'sgnn_patch_in_border': (c_int, [c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_ptr, c_ptr]),
     'sgnn_sp_similarity_dense': (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_ptr, c_ptr]),
     'sgnn_bfs_hops_workspace_bytes': (c_i64, [c_i64, c_i64, c_int]),
-    'sgnn_bfs_hops_tuning': (c_int, [c_int]),
     'sgnn_bfs_min_hops_workspace_bytes': (c_i64, [c_i64, c_i64, c_int, c_i64]),
-    'sgnn_bfs_min_hops_to_sets': (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_i64, c_int, c_ptr, c_ptr, c_i64, c_ptr, c_ptr,
+    'sgnn_bfs_min_hops_to_sets': (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_i64, c_int, c_int, c_ptr, c_ptr, c_i64, c_ptr, c_ptr,
                                           c_ptr, c_i64, c_ptr]),
-    'sgnn_bfs_hops': (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_i64, c_int, c_int, c_ptr, c_ptr, c_i64, c_ptr]),
+    'sgnn_bfs_hops': (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_i64, c_int, c_int, c_int, c_ptr, c_ptr, c_i64, c_ptr]),
     'sgnn_min_hops_to_sets': (c_int, [c_ptr, c_i64, c_i64, c_int, c_ptr, c_ptr, c_i64, c_ptr, c_ptr]),
     'sgnn_dtw_workspace_bytes': (c_i64, [c_i64, c_i64, c_i64, c_i64]),
-    'sgnn_dtw_force_general': (c_int, [c_int]),
-    'sgnn_dtw_similarity': (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_i64, c_i64, c_int, c_ptr, c_ptr, c_ptr,
+    'sgnn_dtw_similarity': (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_i64, c_i64, c_int, c_int, c_ptr, c_ptr, c_ptr,
                                     c_i64, c_ptr]),
     'sgnn_dtw_order_keys': (c_int, [c_ptr, c_ptr, c_i64, c_ptr, c_ptr]),
-    'sgnn_dtw_similarity_live': (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_i64, c_i64, c_int, c_ptr, c_ptr, c_ptr,
+    'sgnn_dtw_similarity_live': (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_i64, c_i64, c_int, c_int, c_ptr, c_ptr, c_ptr,
                                          c_ptr, c_i64, c_ptr]),
     'sgnn_cc_embed_fwd': (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_int, c_i64, c_ptr, c_ptr, c_ptr]),
     'sgnn_cc_embed_bwd': (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_int, c_ptr, c_ptr, c_ptr]),
@@ -126,7 +123,7 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the header and the library disagree
         fn.restype = res
         fn.argtypes = args
-    if lib.sgnn_abi_version() != 3:
+    if lib.sgnn_abi_version() != 4:
         raise SubgnnHipError('ABI version mismatch')
     _lib = lib
     return lib

@@ -640,17 +640,13 @@ extern "C" int sgnn_dtw_order_keys(const int64_t* x_ptr, const int32_t* x_val, i
     return SGNN_OK;
 }
 
-static int g_dtw_force_general = 0;
-/* test hook: 1 = always take the general (workspace-resident) kernel, 0 = pick by size */
-extern "C" int sgnn_dtw_force_general(int on) { const int old = g_dtw_force_general; g_dtw_force_general = on; return old; }
-
 static int dtw_run(const int64_t* x_ptr, const int32_t* x_val, int64_t n_x, int64_t max_x_len,
                    const int64_t* y_ptr, const int32_t* y_val, int64_t n_y, int64_t max_y_len,
-                   int tie_order, const int32_t* x_order, const int64_t* x_live, float* out, void* workspace,
+                   int tie_order, int kernel, const int32_t* x_order, const int64_t* x_live, float* out, void* workspace,
                    int64_t workspace_bytes, void* stream)
 {
     if (!x_ptr || !x_val || !y_ptr || !y_val || !out || !workspace || n_x < 0 || n_y < 0) return SGNN_ERR_BAD_ARG;
-    if (tie_order < 0 || tie_order > 2) return SGNN_ERR_BAD_ARG;
+    if (tie_order < 0 || tie_order > 2 || kernel < 0 || kernel > 1) return SGNN_ERR_BAD_ARG;
     if (max_x_len < 1) max_x_len = 1;
     if (max_y_len < 1) max_y_len = 1;
     if (max_x_len > 32767 || max_y_len > 32767) return SGNN_ERR_SET_TOO_LARGE;
@@ -668,7 +664,7 @@ static int dtw_run(const int64_t* x_ptr, const int32_t* x_val, int64_t n_x, int6
     double* ypyr = (double*)w;             w += 2 * n_y * L.YL * 8;
     int32_t* xlen = (int32_t*)w;           w += dtw_align8(n_x * 4);
     int32_t* ylen = (int32_t*)w;
-    const bool use_reg = max_x_len <= DTW_R && !g_dtw_force_general;
+    const bool use_reg = max_x_len <= DTW_R && kernel == 0;
     hipLaunchKernelGGL(dtw_pyramid_kernel, dim3(sgnn_grid_for(n_x, 256)), dim3(256), 0, st, x_ptr, x_val, n_x,
                        max_x_len, L.XL, 1, xpyr, xpyr + n_x * L.XL, xlen, use_reg ? x_order : (const int32_t*)nullptr);
     SGNN_CHECK_LAUNCH();
@@ -701,19 +697,19 @@ static int dtw_run(const int64_t* x_ptr, const int32_t* x_val, int64_t n_x, int6
 
 extern "C" int sgnn_dtw_similarity(const int64_t* x_ptr, const int32_t* x_val, int64_t n_x, int64_t max_x_len,
                                    const int64_t* y_ptr, const int32_t* y_val, int64_t n_y, int64_t max_y_len,
-                                   int tie_order, const int32_t* x_order, float* out, void* workspace,
+                                   int tie_order, int kernel, const int32_t* x_order, float* out, void* workspace,
                                    int64_t workspace_bytes, void* stream)
 {
-    return dtw_run(x_ptr, x_val, n_x, max_x_len, y_ptr, y_val, n_y, max_y_len, tie_order, x_order, nullptr, out, workspace,
+    return dtw_run(x_ptr, x_val, n_x, max_x_len, y_ptr, y_val, n_y, max_y_len, tie_order, kernel, x_order, nullptr, out, workspace,
                    workspace_bytes, stream);
 }
 
 extern "C" int sgnn_dtw_similarity_live(const int64_t* x_ptr, const int32_t* x_val, int64_t n_x, int64_t max_x_len,
                                         const int64_t* y_ptr, const int32_t* y_val, int64_t n_y, int64_t max_y_len,
-                                        int tie_order, const int32_t* x_order, const int64_t* x_live_range, float* out,
-                                        void* workspace, int64_t workspace_bytes, void* stream)
+                                        int tie_order, int kernel, const int32_t* x_order, const int64_t* x_live_range,
+                                        float* out, void* workspace, int64_t workspace_bytes, void* stream)
 {
     if (x_live_range && !x_order) return SGNN_ERR_BAD_ARG;
-    return dtw_run(x_ptr, x_val, n_x, max_x_len, y_ptr, y_val, n_y, max_y_len, tie_order, x_order, x_live_range, out,
+    return dtw_run(x_ptr, x_val, n_x, max_x_len, y_ptr, y_val, n_y, max_y_len, tie_order, kernel, x_order, x_live_range, out,
                    workspace, workspace_bytes, stream);
 }

@@ -533,18 +533,14 @@ __global__ __launch_bounds__(WKB_THREADS) void triangular_walks_wg_kernel(
     }
 }
 
-static int g_walks_force_wave = 0;
-/* test hook: 1 = always take the wavefront-per-walk kernel, 0 = pick by graph size */
-extern "C" int sgnn_walks_force_wave(int on) { const int old = g_walks_force_wave; g_walks_force_wave = on; return old; }
-
 extern "C" int sgnn_triangular_walks(const int64_t* rowptr, const int32_t* col, const int32_t* col_sorted, int64_t nnz,
                                      const int32_t* node_order, int64_t n_nodes,
                                      const int64_t* patch_ptr, const int32_t* patch_nodes,
                                      const int64_t* inb_ptr, const int32_t* inb_nodes,
                                      int mode, int64_t n_items, int64_t walks_per_patch, int64_t walk_len, double beta,
-                                     uint64_t seed, uint64_t stream_id, int64_t max_id, int64_t* out, void* stream)
+                                     uint64_t seed, uint64_t stream_id, int64_t max_id, int kernel, int64_t* out, void* stream)
 {
-    if (!rowptr || !col || !col_sorted || !out || n_items < 0 || walk_len < 0 || mode < 0 || mode > 2)
+    if (!rowptr || !col || !col_sorted || !out || n_items < 0 || walk_len < 0 || mode < 0 || mode > 2 || kernel < 0 || kernel > 1)
         return SGNN_ERR_BAD_ARG;
     if (mode == 0 && (!node_order || n_nodes <= 0)) return SGNN_ERR_BAD_ARG;
     if (mode >= 1 && (!patch_ptr || !patch_nodes || walks_per_patch <= 0)) return SGNN_ERR_BAD_ARG;
@@ -552,7 +548,7 @@ extern "C" int sgnn_triangular_walks(const int64_t* rowptr, const int32_t* col, 
     if (nnz >= (1ll << 31)) return SGNN_ERR_NNZ_TOO_LARGE;
     if (n_items == 0 || walk_len == 0) return SGNN_OK;
     const int64_t words = (max_id + 32) / 32;
-    if (max_id > 0 && words * 4 <= WKB_LDS_BYTES && !g_walks_force_wave) {
+    if (max_id > 0 && words * 4 <= WKB_LDS_BYTES && kernel == 0) {
         static bool attr_set = false;
         if (!attr_set) {
             (void)hipFuncSetAttribute((const void*)triangular_walks_wg_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -65,14 +65,7 @@ extern "C" int sgnn_sp_similarity_dense(const double* apsp, int64_t n_cols,
 //            new bits; flags[level] says whether any bit was new (later levels exit early);
 //            fvol[level] = sum over new frontier words of the node's degree.
 // ---------------------------------------------------------------------------------------------
-static int g_bfs_alpha = 32;     // pull when frontier word-edges * alpha > nnz * n_words; 0 = never pull
-
-extern "C" int sgnn_bfs_hops_tuning(int alpha)
-{
-    if (alpha < 0) return SGNN_ERR_BAD_ARG;
-    g_bfs_alpha = alpha;
-    return SGNN_OK;
-}
+#define MSBFS_DEFAULT_ALPHA 32     // pull when frontier word-edges * alpha > nnz * n_words; 0 = never pull
 
 __global__ void msbfs_init_kernel(const int32_t* __restrict__ sources, int64_t n_sources, int64_t n_words,
                                   int64_t n_ids, uint64_t* __restrict__ seen, uint64_t* __restrict__ frontier,
@@ -443,8 +436,9 @@ __global__ void msbfs_status_kernel(const int32_t* __restrict__ flags, int max_h
 static int msbfs_run(const int64_t* rowptr, const int32_t* col, int64_t nnz, int64_t max_id,
                      const int32_t* sources, int64_t n_sources, int max_hops, int node_major, uint8_t* dist,
                      const int64_t* set_ptr, const int32_t* set_nodes, int64_t n_sets, float* set_out,
-                     void* workspace, hipStream_t st, int32_t* status = nullptr)
+                     void* workspace, hipStream_t st, int pull_alpha, int32_t* status = nullptr)
 {
+    const int g_bfs_alpha = pull_alpha < 0 ? MSBFS_DEFAULT_ALPHA : pull_alpha;
     const int64_t n_ids = max_id + 1;
     const int64_t n_words = (n_sources + 63) / 64;
     const int64_t ss = node_major ? 1 : n_ids, sv = node_major ? n_sources : 1;
@@ -503,7 +497,7 @@ static int msbfs_run(const int64_t* rowptr, const int32_t* col, int64_t nnz, int
 }
 
 extern "C" int sgnn_bfs_hops(const int64_t* rowptr, const int32_t* col, int64_t nnz, int64_t max_id,
-                             const int32_t* sources, int64_t n_sources, int max_hops, int node_major,
+                             const int32_t* sources, int64_t n_sources, int max_hops, int node_major, int pull_alpha,
                              uint8_t* dist, void* workspace, int64_t workspace_bytes, void* stream)
 {
     if (!rowptr || !col || !sources || !dist || !workspace || n_sources < 0 || max_hops < 1 || max_hops > 254)
@@ -512,7 +506,7 @@ extern "C" int sgnn_bfs_hops(const int64_t* rowptr, const int32_t* col, int64_t 
     if (workspace_bytes < sgnn_bfs_hops_workspace_bytes(max_id, n_sources, max_hops)) return SGNN_ERR_BAD_ARG;
     if (n_sources == 0) return SGNN_OK;
     return msbfs_run(rowptr, col, nnz, max_id, sources, n_sources, max_hops, node_major, dist, nullptr, nullptr, 0,
-                     nullptr, workspace, (hipStream_t)stream);
+                     nullptr, workspace, (hipStream_t)stream, pull_alpha);
 }
 
 extern "C" int64_t sgnn_bfs_min_hops_workspace_bytes(int64_t max_id, int64_t n_sources, int max_hops, int64_t n_sets) {
@@ -521,7 +515,7 @@ extern "C" int64_t sgnn_bfs_min_hops_workspace_bytes(int64_t max_id, int64_t n_s
 }
 
 extern "C" int sgnn_bfs_min_hops_to_sets(const int64_t* rowptr, const int32_t* col, int64_t nnz, int64_t max_id,
-                                         const int32_t* sources, int64_t n_sources, int max_hops,
+                                         const int32_t* sources, int64_t n_sources, int max_hops, int pull_alpha,
                                          const int64_t* set_ptr, const int32_t* set_nodes, int64_t n_sets,
                                          float* out, int32_t* out_status, void* workspace, int64_t workspace_bytes,
                                          void* stream)
@@ -533,7 +527,7 @@ extern "C" int sgnn_bfs_min_hops_to_sets(const int64_t* rowptr, const int32_t* c
     if (workspace_bytes < sgnn_bfs_min_hops_workspace_bytes(max_id, n_sources, max_hops, n_sets)) return SGNN_ERR_BAD_ARG;
     if (n_sources == 0 || n_sets == 0) return SGNN_OK;
     return msbfs_run(rowptr, col, nnz, max_id, sources, n_sources, max_hops, 0, nullptr, set_ptr, set_nodes, n_sets, out,
-                     workspace, (hipStream_t)stream, out_status);
+                     workspace, (hipStream_t)stream, pull_alpha, out_status);
 }
 
 __global__ void min_hops_to_sets_kernel(const uint8_t* __restrict__ dist, int64_t n_sources, int64_t n_ids,

@@ -342,6 +342,7 @@ def finish_pass(model, st, timer=None):
         cc_sets, ci, ce, a_sets, ai, ae, (S, C) = st.dtw_inputs
         st.dtw_inputs = None
         mx, my = max(cc_sets.max_len, 1), max(a_sets.max_len, 1)
+        tie = int(model.hparams.get('dtw_tie_order', 0))
         # Grouping repeated component sequences pays on the internal side (2.7k distinct rows among the
         # benchmark's 50k) and is pure overhead on the external side (nearly all distinct).  Which it is
         # depends only on the split's components and the graph: decided on the first pass, kept.
@@ -355,9 +356,9 @@ def finish_pass(model, st, timer=None):
         # the component side of the DTW calls (grouping of repeated degree sequences, processing order) depends on the
         # split's components only -- the same every pass: kept from the first one (xprep), like the dispatch orders
         st.attrs[split + '_int_struc_similarities'] = \
-            ops.dtw_similarity(cc_sets.ptr, ci, mx, a_sets.ptr, ai, my, dedupe=group[split][1], x_prep=xprep[split][0]).view(S, C, -1)
+            ops.dtw_similarity(cc_sets.ptr, ci, mx, a_sets.ptr, ai, my, tie, dedupe=group[split][1], x_prep=xprep[split][0]).view(S, C, -1)
         st.attrs[split + '_bor_struc_similarities'] = \
-            ops.dtw_similarity(cc_sets.ptr, ce, mx, a_sets.ptr, ae, my, dedupe=group[split][2], x_prep=xprep[split][1]).view(S, C, -1)
+            ops.dtw_similarity(cc_sets.ptr, ce, mx, a_sets.ptr, ae, my, tie, dedupe=group[split][2], x_prep=xprep[split][1]).view(S, C, -1)
         t.mark('dtw')
     elif split + '_int_struc_similarities' not in st.attrs:
         st.attrs[split + '_int_struc_similarities'] = None

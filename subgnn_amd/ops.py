@@ -453,8 +453,9 @@ def choice_ragged(sets, n_draws, seed, stream_id, item_base=0):
 
 
 def triangular_walks(g, mode, n_items, walk_len, beta, seed, stream_id, patches=None, in_border=None,
-                     walks_per_patch=1):
-    """mode 0 'graph' / 1 'inside' / 2 'border' -> (n_items, walk_len) int64, PAD filled."""
+                     walks_per_patch=1, kernel=0):
+    """mode 0 'graph' / 1 'inside' / 2 'border' -> (n_items, walk_len) int64, PAD filled.
+    kernel: 0 = pick by graph size, 1 = the wavefront-per-walk kernel (same walks)."""
     lib = _lib.load()
     out = torch.empty((n_items, walk_len), dtype=torch.int64, device=g.device)
     check(lib.sgnn_triangular_walks(_ptr(g.rowptr), _ptr(g.col), _ptr(g.col_sorted), g.nnz, _ptr(g.node_order),
@@ -463,7 +464,7 @@ def triangular_walks(g, mode, n_items, walk_len, beta, seed, stream_id, patches=
                                     _ptr(in_border.ptr) if in_border else None,
                                     _ptr(in_border.nodes) if in_border else None,
                                     mode, n_items, walks_per_patch, walk_len, float(beta), seed, stream_id,
-                                    g.max_id, _ptr(out), _stream()), 'sgnn_triangular_walks')
+                                    g.max_id, int(kernel), _ptr(out), _stream()), 'sgnn_triangular_walks')
     return out
 
 
@@ -497,14 +498,11 @@ def probe_stream_copy(src, dst, bytes_per_lane):
           'sgnn_probe_stream_copy')
 
 
-def bfs_hops_tuning(alpha):
-    """Direction switch of the multi-source BFS: pull once frontier edges * alpha > all edges (0 = always push)."""
-    check(_lib.load().sgnn_bfs_hops_tuning(int(alpha)), 'sgnn_bfs_hops_tuning')
-
-
-def bfs_hops(g, sources, max_hops=64, node_major=False):
+def bfs_hops(g, sources, max_hops=64, node_major=False, pull_alpha=-1):
     """uint8 hop counts (255 = not reached) by multi-source BFS: (n_sources, max_id+1), or
-    (max_id+1, n_sources) when ``node_major`` (coalesced for min_hops_to_sets)."""
+    (max_id+1, n_sources) when ``node_major`` (coalesced for min_hops_to_sets).
+    pull_alpha: direction switch -- pull once frontier edges * alpha > all edges (-1 = default 32, 0 = always push);
+    results do not depend on it."""
     lib = _lib.load()
     _req(sources, torch.int32, 'sources')
     ns = sources.numel()
@@ -513,11 +511,11 @@ def bfs_hops(g, sources, max_hops=64, node_major=False):
     wsb = lib.sgnn_bfs_hops_workspace_bytes(g.max_id, ns, max_hops)
     ws = torch.empty(wsb // 8 + 1, dtype=torch.int64, device=g.device)
     check(lib.sgnn_bfs_hops(_ptr(g.rowptr), _ptr(g.col), g.nnz, g.max_id, _ptr(sources), ns, max_hops,
-                            1 if node_major else 0, _ptr(dist), _ptr(ws), wsb, _stream()), 'sgnn_bfs_hops')
+                            1 if node_major else 0, int(pull_alpha), _ptr(dist), _ptr(ws), wsb, _stream()), 'sgnn_bfs_hops')
     return dist
 
 
-def bfs_min_hops_to_sets(g, sources, sets, max_hops=64, want_status=False):
+def bfs_min_hops_to_sets(g, sources, sets, max_hops=64, want_status=False, pull_alpha=-1):
     """min over the members of every set of the hop distance from every source -> (n_sets, n_sources)
     float32, 0 for unreachable pairs; one multi-source BFS, no (sources x nodes) hop table.
     ``want_status``: also an int32[2] device tensor -- [0] the last level that found anything, [1] whether level
@@ -530,7 +528,7 @@ def bfs_min_hops_to_sets(g, sources, sets, max_hops=64, want_status=False):
     wsb = lib.sgnn_bfs_min_hops_workspace_bytes(g.max_id, ns, max_hops, sets.n)
     ws = torch.empty(wsb // 8 + 1, dtype=torch.int64, device=g.device)
     check(lib.sgnn_bfs_min_hops_to_sets(_ptr(g.rowptr), _ptr(g.col), g.nnz, g.max_id, _ptr(sources), ns, max_hops,
-                                        _ptr(sets.ptr), _ptr(sets.nodes), sets.n, _ptr(out), _ptr(status), _ptr(ws), wsb,
+                                        int(pull_alpha), _ptr(sets.ptr), _ptr(sets.nodes), sets.n, _ptr(out), _ptr(status), _ptr(ws), wsb,
                                         _stream()), 'sgnn_bfs_min_hops_to_sets')
     return (out, status) if want_status else out
 
@@ -603,7 +601,7 @@ def distinct_row_fraction(x_ptr, x_val, max_x):
 
 
 def dtw_similarity(x_ptr, x_val, max_x, y_ptr, y_val, max_y, tie_order=0, order_rows=True, dedupe=True, order=None,
-                   _live=None, x_prep=None):
+                   _live=None, x_prep=None, kernel=0):
     """1/(1+fastdtw) for all (x row, y row) pairs -> (n_x, n_y) float32; empty x rows -> PAD.
     ``dedupe``: identical x rows (sorted degree sequences of small components repeat a lot: 50k BFS
     components of the benchmark have 2.7k distinct internal sequences) are computed once and the
@@ -611,7 +609,8 @@ def dtw_similarity(x_ptr, x_val, max_x, y_ptr, y_val, max_y, tie_order=0, order_
     that the lanes of a wavefront work on similar series.  Neither changes any value.
     ``x_prep``: a dict the caller keeps for THESE x rows (the degree sequences of a split's components are the same
     every pass): the grouping of repeated rows and the processing order are computed on the first call and reused;
-    the series the kernel reads are always this call's ``x_val``."""
+    the series the kernel reads are always this call's ``x_val``.
+    ``kernel``: 0 = pick by size, 1 = the general (workspace-resident) kernel; same values."""
     if dedupe and x_ptr.numel() - 1 > 1024 and max_x <= 64:
         kept = x_prep.get('dedupe') if x_prep is not None else None
         if kept is not None and kept[1].numel() == x_ptr.numel() - 1:
@@ -622,7 +621,7 @@ def dtw_similarity(x_ptr, x_val, max_x, y_ptr, y_val, max_y, tie_order=0, order_
             uval = torch.zeros(x_val.numel() + 1, dtype=torch.int32, device=x_ptr.device)
             uval.scatter_(0, dst, rows.reshape(-1))
             out_u = dtw_similarity(uptr, uval, max_x, y_ptr, y_val, max_y, tie_order, order_rows, dedupe=False, order=order,
-                                   _live=live, x_prep=x_prep.setdefault('grouped', {}))
+                                   _live=live, x_prep=x_prep.setdefault('grouped', {}), kernel=kernel)
             return out_u.index_select(0, rep)
         # no host round trip: every row keeps its slot, the rows that repeat an earlier one are given
         # length 0 (their pairs exit at once -- sorted by length they fill whole wavefronts) and read
@@ -647,7 +646,7 @@ def dtw_similarity(x_ptr, x_val, max_x, y_ptr, y_val, max_y, tie_order=0, order_
         if x_prep is not None:
             x_prep['dedupe'] = (uptr, rep, dst.reshape(-1), live)
         out_u = dtw_similarity(uptr, uval, max_x, y_ptr, y_val, max_y, tie_order, order_rows, dedupe=False, order=order,
-                               _live=live, x_prep=x_prep.setdefault('grouped', {}) if x_prep is not None else None)
+                               _live=live, x_prep=x_prep.setdefault('grouped', {}) if x_prep is not None else None, kernel=kernel)
         return out_u.index_select(0, rep)
     lib = _lib.load()
     for t, nm in ((x_ptr, 'x_ptr'), (y_ptr, 'y_ptr')):
@@ -675,11 +674,11 @@ def dtw_similarity(x_ptr, x_val, max_x, y_ptr, y_val, max_y, tie_order=0, order_
     ws = torch.empty(wsb // 8 + 1, dtype=torch.int64, device=x_ptr.device)
     if _live is not None and order is not None:
         check(lib.sgnn_dtw_similarity_live(_ptr(x_ptr), _ptr(x_val), nx, max_x, _ptr(y_ptr), _ptr(y_val), ny, max_y,
-                                           tie_order, _ptr(order), _ptr(_live), _ptr(out), _ptr(ws), wsb, _stream()),
+                                           tie_order, int(kernel), _ptr(order), _ptr(_live), _ptr(out), _ptr(ws), wsb, _stream()),
               'sgnn_dtw_similarity_live')
         return out
     check(lib.sgnn_dtw_similarity(_ptr(x_ptr), _ptr(x_val), nx, max_x, _ptr(y_ptr), _ptr(y_val), ny, max_y, tie_order,
-                                  _ptr(order), _ptr(out), _ptr(ws), wsb, _stream()), 'sgnn_dtw_similarity')
+                                  int(kernel), _ptr(order), _ptr(out), _ptr(ws), wsb, _stream()), 'sgnn_dtw_similarity')
     return out
 
 

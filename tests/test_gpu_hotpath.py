@@ -254,3 +254,29 @@ def test_pipelined_passes_train_like_sequential_passes(name, tmp_path):
         assert torch.equal(a, b), n1
     with pytest.raises(RuntimeError):
         hotpath.PassPipeline(pip, 'train').install()
+
+
+@pytest.mark.parametrize('tie', [1, 2])
+def test_dtw_tie_order_hparam_reaches_both_paths(tie, tmp_path):
+    """hparams['dtw_tie_order'] selects fastdtw's predecessor rule end to end: the dense prepare_data and the sparse
+    hot path both hand it to the DTW launch, and the structure similarities equal the oracle's under that rule."""
+    from conftest import load_golden
+    from oracle import cbind
+    from subgnn_amd import hotpath, gamma, ops
+    golden = load_golden('tiny')
+    dense, sparse = _models(golden, tmp_path, {'dtw_tie_order': tie})
+    dense.prepare_data()
+    hotpath.prepare_sparse(sparse, 'train')
+    assert torch.equal(dense.train_int_struc_similarities, sparse.train_int_struc_similarities)
+    assert torch.equal(dense.train_bor_struc_similarities, sparse.train_bor_struc_similarities)
+    S, C, L = dense.train_cc_ids.shape
+    g = dense.networkx_graph
+    use_dict = g.full_degree is not None
+    for internal, got in ((True, dense.train_int_struc_similarities), (False, dense.train_bor_struc_similarities)):
+        c_sets, c_seq = gamma.degree_sequences(g, dense.train_cc_ids.view(S * C, L), internal, use_dict)
+        a_sets, a_seq = gamma.degree_sequences(g, dense.structure_anchors, internal, use_dict)
+        ref = cbind.fastdtw_sim(c_sets.ptr.cpu().numpy(), c_seq.cpu().numpy()[:int(c_sets.ptr[-1])],
+                                a_sets.ptr.cpu().numpy(), a_seq.cpu().numpy()[:int(a_sets.ptr[-1])], tie)
+        assert np.array_equal(got.view(S * C, -1).cpu().numpy(), ref)
+    with pytest.raises(ValueError):
+        _models(golden, tmp_path, {'dtw_tie_order': 3})

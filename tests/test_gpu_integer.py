@@ -433,12 +433,8 @@ def test_sample_position_anchor_patches_per_subgraph(golden):
 @pytest.fixture(params=['workgroup', 'wavefront'])
 def walk_kernel(request):
     """Both walk kernels: a workgroup per walk with the LDS adjacency bitmap (the default when the
-    id range fits) and a wavefront per walk with binary searches."""
-    from subgnn_amd import _lib
-    lib = _lib.load()
-    lib.sgnn_walks_force_wave(1 if request.param == 'wavefront' else 0)
-    yield request.param
-    lib.sgnn_walks_force_wave(0)
+    id range fits) and a wavefront per walk with binary searches -- the ``kernel`` argument of the call."""
+    return 1 if request.param == 'wavefront' else 0
 
 
 def test_walks_golden(golden, walk_kernel):
@@ -447,13 +443,13 @@ def test_walks_golden(golden, walk_kernel):
     hp, seed = golden.hp, golden.seed
     sa = golden['g5_structure_anchors']
     n = sa.shape[0]
-    got = ops.triangular_walks(dg, 0, n, hp['sample_walk_len'], hp['rw_beta'], seed, T.stream_id(T.STREAM_STRUCT_PATCH))
+    got = ops.triangular_walks(dg, 0, n, hp['sample_walk_len'], hp['rw_beta'], seed, T.stream_id(T.STREAM_STRUCT_PATCH), kernel=walk_kernel)
     assert np.array_equal(got.cpu().numpy()[:, :sa.shape[1]], sa)
     assert (got.cpu().numpy()[:, sa.shape[1]:] == 0).all()
     W, Tn = hp['n_triangular_walks'], hp['random_walk_len']
     views = ops.Ragged.from_lists(golden.ragged('g5_views_int', 0), DEV)
     iw = ops.triangular_walks(dg, 1, n * W, Tn, hp['rw_beta'], seed, T.stream_id(T.STREAM_WALK_INT), patches=views,
-                              walks_per_patch=W)
+                              walks_per_patch=W, kernel=walk_kernel)
     assert np.array_equal(iw.view(n, W, Tn).cpu().numpy(), golden['g5_int_walks'])
     vb = ops.Ragged.from_lists(golden.ragged('g5_views_bor', 0), DEV)
     flags = ops.patch_in_border(dg, vb)
@@ -463,7 +459,7 @@ def test_walks_golden(golden, walk_kernel):
     assert inb_lists == golden.ragged('g5_in_border', 0)
     inb = ops.Ragged.from_lists(inb_lists, DEV)
     bw = ops.triangular_walks(dg, 2, n * W, Tn, hp['rw_beta'], seed, T.stream_id(T.STREAM_WALK_BOR), patches=vb,
-                              in_border=inb, walks_per_patch=W)
+                              in_border=inb, walks_per_patch=W, kernel=walk_kernel)
     assert np.array_equal(bw.view(n, W, Tn).cpu().numpy(), golden['g5_bor_walks'])
 
 
@@ -472,7 +468,7 @@ def test_walks_random_vs_oracle(walk_kernel):
     G = _rand_graph(400, 4, 9)
     dg = _dev_graph(G)
     patches = IH.sample_structure_anchor_patches(G, 40, 30, 0.4, 123)
-    got = ops.triangular_walks(dg, 0, 40, 30, 0.4, 123, T.stream_id(T.STREAM_STRUCT_PATCH)).cpu().numpy()
+    got = ops.triangular_walks(dg, 0, 40, 30, 0.4, 123, T.stream_id(T.STREAM_STRUCT_PATCH), kernel=walk_kernel).cpu().numpy()
     assert np.array_equal(got[:, :patches.shape[1]], patches)
     views = [IH.patch_unique_nodes(p) for p in patches]
     inb = [IH.patch_in_border_nodes(G, v) for v in views]
@@ -481,26 +477,21 @@ def test_walks_random_vs_oracle(walk_kernel):
         ref = IH.perform_random_walks(G, patches, 4, 12, 0.4, inside, 123)
         st = T.stream_id(T.STREAM_WALK_INT if inside else T.STREAM_WALK_BOR)
         got = ops.triangular_walks(dg, 1 if inside else 2, 160, 12, 0.4, 123, st, patches=vr, in_border=ir,
-                                   walks_per_patch=4).view(40, 4, 12).cpu().numpy()
+                                   walks_per_patch=4, kernel=walk_kernel).view(40, 4, 12).cpu().numpy()
         assert np.array_equal(got, ref)
 
 
 def test_walks_hubs_both_kernels_agree():
     """Long walks over hubs (lists longer than one 64-entry chunk per wavefront, several workgroup
     passes over the items): the two kernels return the same walks."""
-    from subgnn_amd import synthetic, _lib
+    from subgnn_amd import synthetic
     ops = _ops()
     n = 30000
     rowptr, col = synthetic.sorted_csr(synthetic.barabasi_albert_edges(n, 12, seed=4), n)
     dg = ops.DeviceGraph(rowptr, col, np.arange(1, n + 1, dtype=np.int32), DEV)
-    lib = _lib.load()
     out = {}
-    try:
-        for force in (0, 1):
-            lib.sgnn_walks_force_wave(force)
-            out[force] = ops.triangular_walks(dg, 0, 3000, 40, 0.65, 5, T.stream_id(T.STREAM_STRUCT_PATCH))
-    finally:
-        lib.sgnn_walks_force_wave(0)
+    for kernel in (0, 1):
+        out[kernel] = ops.triangular_walks(dg, 0, 3000, 40, 0.65, 5, T.stream_id(T.STREAM_STRUCT_PATCH), kernel=kernel)
     assert torch.equal(out[0], out[1]) and int((out[0] != 0).sum()) > 3000 * 20
 
 
@@ -518,10 +509,8 @@ def test_sp_similarity_dense_golden(golden):
 
 @pytest.fixture
 def bfs_alpha(request):
-    ops = _ops()
-    ops.bfs_hops_tuning(request.param)
-    yield request.param
-    ops.bfs_hops_tuning(32)
+    """Direction switch of the multi-source BFS (the ``pull_alpha`` argument of the calls)."""
+    return request.param
 
 
 @pytest.mark.parametrize('n_src', [70, 300])
@@ -540,13 +529,9 @@ def test_bfs_hops_push_pull_agree_and_match_scipy(n_src):
     src = np.random.default_rng(n_src).integers(1, n + 1, n_src).astype(np.int32)
     src[0] = n                                                           # an isolated source
     out = {}
-    try:
-        for alpha in (0, 256, 1 << 30):
-            ops.bfs_hops_tuning(alpha)
-            out[alpha] = ops.bfs_hops(dg, torch.from_numpy(src).to(DEV), max_hops=32)
-            out[(alpha, 't')] = ops.bfs_hops(dg, torch.from_numpy(src).to(DEV), max_hops=32, node_major=True)
-    finally:
-        ops.bfs_hops_tuning(32)
+    for alpha in (0, 256, 1 << 30):
+        out[alpha] = ops.bfs_hops(dg, torch.from_numpy(src).to(DEV), max_hops=32, pull_alpha=alpha)
+        out[(alpha, 't')] = ops.bfs_hops(dg, torch.from_numpy(src).to(DEV), max_hops=32, node_major=True, pull_alpha=alpha)
     assert torch.equal(out[0], out[256]) and torch.equal(out[0], out[1 << 30])
     for alpha in (0, 256, 1 << 30):
         assert torch.equal(out[(alpha, 't')].t().contiguous(), out[0])
@@ -573,7 +558,7 @@ def test_bfs_hops_matches_apsp(golden, bfs_alpha):
     G, dg = _graphs(golden)
     rng = np.random.default_rng(2)
     src = rng.choice(np.array(G.node_order), 70, replace=True).astype(np.int32)       # > 64: two words
-    dist = ops.bfs_hops(dg, torch.from_numpy(src).to(DEV), max_hops=32)
+    dist = ops.bfs_hops(dg, torch.from_numpy(src).to(DEV), max_hops=32, pull_alpha=bfs_alpha)
     apsp = golden['apsp']
     d = dist.cpu().numpy().astype(np.int64)
     for i, s in enumerate(src):
@@ -588,14 +573,14 @@ def test_bfs_hops_matches_apsp(golden, bfs_alpha):
     got = ops.min_hops_to_sets(dist, sets).cpu().numpy()
     ref = golden['g4_np_sim_train'].reshape(S * C, -1)[:, src - 1]
     assert np.array_equal(got, ref)
-    dist_t = ops.bfs_hops(dg, torch.from_numpy(src).to(DEV), max_hops=32, node_major=True)      # (ids, sources)
+    dist_t = ops.bfs_hops(dg, torch.from_numpy(src).to(DEV), max_hops=32, node_major=True, pull_alpha=bfs_alpha)      # (ids, sources)
     assert torch.equal(dist_t.t().contiguous(), dist)
     assert np.array_equal(ops.min_hops_to_sets(dist_t, sets, node_major=True).cpu().numpy(), ref)
     # fused form: BFS + min over members in one call, no hop table
-    assert np.array_equal(ops.bfs_min_hops_to_sets(dg, torch.from_numpy(src).to(DEV), sets, max_hops=32).cpu().numpy(), ref)
+    assert np.array_equal(ops.bfs_min_hops_to_sets(dg, torch.from_numpy(src).to(DEV), sets, max_hops=32, pull_alpha=bfs_alpha).cpu().numpy(), ref)
     # status: the last productive level == the largest finite hop count from these sources; enqueueing exactly that
     # many levels is reported as possibly incomplete (the last level found something), one more is complete
-    _, st = ops.bfs_min_hops_to_sets(dg, torch.from_numpy(src).to(DEV), sets, max_hops=32, want_status=True)
+    _, st = ops.bfs_min_hops_to_sets(dg, torch.from_numpy(src).to(DEV), sets, max_hops=32, want_status=True, pull_alpha=bfs_alpha)
     depth = int(d[d != 255].max())
     assert st.tolist() == [depth, 0]
     w1, st1 = ops.bfs_min_hops_to_sets(dg, torch.from_numpy(src).to(DEV), sets, max_hops=depth, want_status=True)
@@ -648,9 +633,8 @@ def test_dtw_random(tie):
 @pytest.mark.parametrize('tie', [0, 1, 2])
 def test_dtw_register_kernel_equals_general_kernel(tie):
     """x rows of <= 32 entries take the register-resident column-major kernel; it must agree bit for
-    bit with the C oracle and with the general kernel (forced through the test hook)."""
+    bit with the C oracle and with the general kernel (``kernel=1``)."""
     ops = _ops()
-    from subgnn_amd import _lib
     rng = np.random.default_rng(50 + tie)
     xs = [sorted(rng.integers(0, 30, int(rng.integers(0, 33))).tolist()) for _ in range(300)]
     xs[0], xs[1], xs[2] = [5], [1, 2], list(range(32))
@@ -661,12 +645,7 @@ def test_dtw_register_kernel_equals_general_kernel(tie):
     ref = cbind.fastdtw_sim(xp, xv, yp, yv, tie)
     t = lambda a: torch.from_numpy(a).to(DEV)
     fast = ops.dtw_similarity(t(xp), t(xv), 32, t(yp), t(yv), 60, tie).cpu().numpy()
-    lib = _lib.load()
-    old = lib.sgnn_dtw_force_general(1)
-    try:
-        general = ops.dtw_similarity(t(xp), t(xv), 32, t(yp), t(yv), 60, tie).cpu().numpy()
-    finally:
-        lib.sgnn_dtw_force_general(old)
+    general = ops.dtw_similarity(t(xp), t(xv), 32, t(yp), t(yv), 60, tie, kernel=1).cpu().numpy()
     assert np.array_equal(fast, ref)
     assert np.array_equal(general, ref)
 

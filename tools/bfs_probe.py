@@ -1,5 +1,5 @@
 """Timing of the multi-source BFS (position channel) on the benchmark graph for several push/pull
-switch points (sgnn_bfs_hops_tuning), checking that every setting returns the same hop table."""
+switch points (the pull_alpha argument), checking that every setting returns the same hop table."""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -23,14 +23,12 @@ for ns in (57, 183, 1000):
     src = torch.from_numpy(np.random.default_rng(5).integers(1, n + 1, ns).astype(np.int32)).to(dev)
     ref = None
     for alpha in (0, 16, 64, 256, 1024, 4096, 1 << 30):
-        ops.bfs_hops_tuning(alpha)
-        ms = timeit(lambda: ops.bfs_hops(g, src, max_hops=32, node_major=True))
-        d = ops.bfs_hops(g, src, max_hops=32, node_major=True)
+        ms = timeit(lambda: ops.bfs_hops(g, src, max_hops=32, node_major=True, pull_alpha=alpha))
+        d = ops.bfs_hops(g, src, max_hops=32, node_major=True, pull_alpha=alpha)
         if ref is None:
             ref = d
         print('sources %5d  alpha %10d  %8.3f ms  same=%s  max hop %d' % (ns, alpha, ms, bool(torch.equal(d, ref)),
                                                                          int(d[d != 255].max())))
-ops.bfs_hops_tuning(32)
 
 # the fused form the position channel uses (min over the members of 50k component sets)
 rng = np.random.default_rng(7)
@@ -38,10 +36,8 @@ sets = ops.Ragged.from_padded(torch.from_numpy(rng.integers(1, n + 1, (50_000, 2
 src = torch.from_numpy(np.random.default_rng(5).integers(1, n + 1, 183).astype(np.int32)).to(dev)
 ref = None
 for alpha in (0, 2, 4, 8, 16, 32, 64, 128, 256, 1024):
-    ops.bfs_hops_tuning(alpha)
-    ms = timeit(lambda: ops.bfs_min_hops_to_sets(g, src, sets, max_hops=32), reps=10)
-    w = ops.bfs_min_hops_to_sets(g, src, sets, max_hops=32)
+    ms = timeit(lambda: ops.bfs_min_hops_to_sets(g, src, sets, max_hops=32, pull_alpha=alpha), reps=10)
+    w = ops.bfs_min_hops_to_sets(g, src, sets, max_hops=32, pull_alpha=alpha)
     if ref is None:
         ref = w
     print('min-hops-to-sets 183 sources  alpha %6d  %8.3f ms  same=%s' % (alpha, ms, bool(torch.equal(w, ref))))
-ops.bfs_hops_tuning(32)

@@ -13,10 +13,7 @@ walks = ops.triangular_walks(g, 0, 210, 50, 0.65, 0, T.stream_id(T.STREAM_STRUCT
 a_sets = ops.Ragged.from_padded(walks)
 ai, ae = ops.degree_sequence(g, a_sets)
 ci, ce = ops.degree_sequence(g, sets)
-lib = _lib.load()
 for nm, cx, ax in (('ext', ce, ae), ('int', ci, ai)):
     fast = ops.dtw_similarity(sets.ptr, cx, K, a_sets.ptr, ax, 50)
-    old = lib.sgnn_dtw_force_general(1)
-    gen = ops.dtw_similarity(sets.ptr, cx, K, a_sets.ptr, ax, 50)
-    lib.sgnn_dtw_force_general(old)
+    gen = ops.dtw_similarity(sets.ptr, cx, K, a_sets.ptr, ax, 50, kernel=1)
     print(nm, 'equal', bool(torch.equal(fast, gen)), 'n diff', int((fast != gen).sum()))
