@@ -304,7 +304,7 @@ def main():
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-    hotpath.check_pending(model)                                 # the last pass's BFS level hints (raises if one was too small)
+    # (hinted BFS searches are verified inside install_pass, before a pass is consumed)
     if multi and not replicated:                                 # the reported loss: mean over the global batch = mean of the ranks' means
         lt = torch.tensor([loss], device=dev, dtype=torch.float64)
         dist.all_reduce(lt)

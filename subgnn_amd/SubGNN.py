@@ -147,8 +147,9 @@ class SubGNN(nn.Module):
             raise ValueError("hparams['dtw_tie_order'] must be 0, 1 or 2")
         # hparams['deterministic'] (default True): gradients by sorted segmented sums and per-row partials -- bit-
         # reproducible; False: float atomics (fewer launches per batch-sized step, sums in arbitrary order).
-        # Process-wide (ops.DETERMINISTIC), like the kernels' other switches.
-        ops.DETERMINISTIC = bool(hp.get('deterministic', True))
+        # The model's own choice: stated for the duration of its forward (ops.deterministic), recorded by every op's
+        # autograd context -- a second model with another setting does not change this one's backward.
+        self._deterministic = bool(hp.get('deterministic', True))
         self.metric_scores = []
         self.to(self.device)
 
@@ -591,8 +592,9 @@ class SubGNN(nn.Module):
         fused = hp.get('fused_forward', True)
         self.__dict__['_tapped_table'] = ops.tap_table(self.node_embeddings.weight, self._half_table()) if fused else None
         try:
-            return self._forward(dataset_type, N_I_cc_embed, N_B_cc_embed, S_I_cc_embed, S_B_cc_embed, P_I_cc_embed,
-                                 P_B_cc_embed, subgraph_ids, cc_ids, subgraph_idx, NP_sim, I_S_sim, B_S_sim)
+            with ops.deterministic(self._deterministic):
+                return self._forward(dataset_type, N_I_cc_embed, N_B_cc_embed, S_I_cc_embed, S_B_cc_embed, P_I_cc_embed,
+                                     P_B_cc_embed, subgraph_ids, cc_ids, subgraph_idx, NP_sim, I_S_sim, B_S_sim)
         finally:
             self.__dict__['_tapped_table'] = None
 

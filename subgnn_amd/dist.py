@@ -15,6 +15,14 @@ def is_initialized():
     return dist.is_available() and dist.is_initialized()
 
 
+def flat_collectives(group=None):
+    """Whether the group's backend has the flat-tensor collectives the fast path uses (all_gather_into_tensor,
+    reduce_scatter_tensor, all_to_all_single).  RCCL ("nccl") has; gloo (the CPU tests, the one-GPU multi-rank check)
+    takes the list forms.  Decided from the backend's NAME, once per call site -- a failing production collective is
+    an error to surface, not a reason to switch to another collective sequence on one rank."""
+    return is_initialized() and 'nccl' in str(dist.get_backend(group)).lower()
+
+
 def shard_range(n_items, rank, world):
     """Contiguous block of items owned by ``rank`` (sizes differ by at most one)."""
     base, rem = divmod(n_items, world)
@@ -82,9 +90,9 @@ def all_gather_rows(x, equal_rows=False, async_op=False):
     x = x.contiguous()
     out = torch.empty((world * m,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
     parts = None
-    try:
+    if flat_collectives():
         work = dist.all_gather_into_tensor(out, x, async_op=True)
-    except (RuntimeError, NotImplementedError):               # backends without the flat form
+    else:                                                     # backends without the flat form
         parts = [torch.empty_like(x) for _ in range(world)]
         work = dist.all_gather(parts, x, async_op=True)
 
@@ -175,9 +183,9 @@ def all_to_all_row_blocks(x):
         return x
     x = x.contiguous()
     out = torch.empty_like(x)
-    try:
+    if flat_collectives():
         dist.all_to_all_single(out, x)
-    except (RuntimeError, NotImplementedError):             # backends without all-to-all: gather everything, keep ours
+    else:                                                   # backends without all-to-all: gather everything, keep ours
         world, r = dist.get_world_size(), dist.get_rank()
         rows = x.shape[0] // world
         parts = [torch.empty_like(x) for _ in range(world)]
@@ -233,9 +241,9 @@ class ShardedTableAdam:
         g = self.p.grad.reshape(-1)
         body = g[:self.chunk * self.world]
         if self.world > 1:
-            try:
+            if flat_collectives():
                 dist.reduce_scatter_tensor(self.gslice, body)
-            except (RuntimeError, NotImplementedError):     # backends without reduce-scatter
+            else:                                           # backends without reduce-scatter
                 full = body.clone()
                 dist.all_reduce(full)
                 self.gslice.copy_(full[self.lo:self.hi])
@@ -270,13 +278,17 @@ class ShardedTableAdam:
         if self.world > 1:
             body = flat[:self.chunk * self.world]
             mine = flat[self.lo:self.hi].clone()            # the collective must not read and write the same bytes
-            try:
+            if flat_collectives():
                 self._pending = dist.all_gather_into_tensor(body, mine, async_op=True)
-            except (RuntimeError, NotImplementedError):
+            else:
                 parts = [torch.empty_like(mine) for _ in range(self.world)]
-                dist.all_gather(parts, mine)
-                body.copy_(torch.cat(parts))
-                self._pending = None
+                work = dist.all_gather(parts, mine, async_op=True)   # asynchronous like the flat form; wait() lands the rows
+
+                class _Land:
+                    def wait(_self):
+                        work.wait()
+                        body.copy_(torch.cat(parts))
+                self._pending = _Land()
 
     def wait(self):
         """Call before anything reads the parameter."""

@@ -77,45 +77,59 @@ def _bfs_levels(model, key, max_hops):
     """How many BFS levels to enqueue for the position channel's search ``key``.  The kernels run without a host
     synchronisation, so every enqueued level costs three launches whether or not the search has ended -- with the
     default cap of 32 hops and a small-world graph that is ~26 empty levels (~0.3 ms of a 19 ms pass).  The first
-    search of a kind runs the full cap and its status (last productive level) is read back once; later ones
-    enqueue that many levels plus a margin, and their status -- did the LAST level still find something? -- is
-    kept on the model and verified by ``check_pending`` at the next point where the host waits for the device anyway."""
+    search of a kind runs the full cap and its status (last productive level) is read back once; later ones enqueue
+    (levels needed so far + BFS_LEVEL_MARGIN productive levels + the one empty level that proves the search has ended)
+    and are verified BEFORE the pass is consumed (``_verify_bfs`` in install_pass)."""
     hint = model.__dict__.setdefault('_bfs_level_hint', {})
     k = hint.get(key)
-    return max_hops if k is None else min(max_hops, k + BFS_LEVEL_MARGIN)
+    return max_hops if k is None else min(max_hops, k + BFS_LEVEL_MARGIN + 1)
 
 
-def _bfs_note(model, key, status, max_hops, enqueued):
+def _bfs_note(model, st, key, status, max_hops, enqueued, redo):
+    """First search of a kind: read its status (one blocking read-back) and keep the depth.  Hinted search: copy the
+    status into pinned host memory behind the search (no wait here) and leave a check on the pass; ``redo`` runs the
+    search again with the full cap."""
     hint = model.__dict__.setdefault('_bfs_level_hint', {})
     if hint.get(key) is None:
-        last, more = status.tolist()                           # first search of this kind: one read-back
+        last, more = status.tolist()
         if more:
             raise RuntimeError('position-channel BFS: level %d still reached new nodes -- hparams["max_bfs_hops"] = %d '
                                'is smaller than the depth of this graph from the anchors' % (max_hops, max_hops))
         hint[key] = last
-    else:
-        model.__dict__.setdefault('_bfs_pending', []).append((key, status, enqueued, max_hops))
+        return
+    ring = model.__dict__.setdefault('_bfs_status_host', {})
+    slot = ring.setdefault(key, {'bufs': [torch.empty(2, dtype=torch.int32).pin_memory() for _ in range(4)], 'n': 0})
+    host = slot['bufs'][slot['n'] % len(slot['bufs'])]             # passes in flight never share a buffer (<= 2 are)
+    slot['n'] += 1
+    host.copy_(status, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream())
+    st.bfs_checks.append((key, host, ev, max_hops, enqueued, redo))
+
+
+def _verify_bfs(model, st):
+    """Before a prepared pass becomes the model's: did every hinted position-channel search end within the levels it
+    was given?  The status was copied to pinned memory right behind the search -- by now (the pass was prepared a step
+    ago under the pipeline, or the caller is about to wait for the table anyway) the copy has landed and the event
+    wait costs nothing.  A search that ran out of levels is REPEATED with the full cap and its similarities replaced
+    before anything reads them; only a graph deeper than hparams['max_bfs_hops'] itself is an error."""
+    hint = model.__dict__.setdefault('_bfs_level_hint', {})
+    for key, host, ev, cap, enqueued, redo in st.bfs_checks:
+        ev.synchronize()
+        last, more = int(host[0]), int(host[1])
+        if more and enqueued < cap:
+            last, more = redo(cap)
+            model.__dict__['_bfs_redone'] = model.__dict__.get('_bfs_redone', 0) + 1
+        if more:
+            raise RuntimeError('position-channel BFS: level %d still reached new nodes -- hparams["max_bfs_hops"] = %d '
+                               'is smaller than the depth of this graph from the anchors' % (cap, cap))
+        hint[key] = max(hint.get(key) or 0, last)                  # the hint only grows: anchors are redrawn every pass
+    st.bfs_checks = []
 
 
 def check_pending(model):
-    """Verify the searches queued since the last call (call it where the host has just waited for the device, e.g.
-    after reading the loss; ``prepare_sparse`` calls it on entry).  A search whose last enqueued level still found
-    something is an error, loudly: its similarities were incomplete.  The hint is dropped so that the next pass runs
-    the full cap again."""
-    pend = model.__dict__.pop('_bfs_pending', [])
-    if not pend:
-        return
-    got = torch.stack([st for _, st, _, _ in pend]).tolist() if len(pend) > 1 else [pend[0][1].tolist()]
-    bad = [(key, enq, cap) for (key, _, enq, cap), (_, more) in zip(pend, got) if more]
-    hint = model.__dict__.get('_bfs_level_hint', {})
-    for (key, _, _, _), (last, _) in zip(pend, got):
-        if key in hint:
-            hint[key] = max(hint[key], last)                   # the hint only grows: anchors are redrawn every pass
-    if bad:
-        for key, _, _ in bad:
-            hint.pop(key, None)
-        raise RuntimeError('position-channel BFS ran out of levels (search, levels enqueued, cap): %r -- the previous '
-                           'pass used incomplete similarities; the level hint has been dropped, repeat the pass' % (bad,))
+    """Kept for callers of round 2: the hinted searches are verified inside install_pass now, nothing is pending."""
+    return None
 
 
 def _dealt_position_sims(g, anchors, cc_sets, cc_ids, shard, max_hops):
@@ -132,13 +146,17 @@ def _dealt_position_sims(g, anchors, cc_sets, cc_ids, shard, max_hops):
     a, b = sdist.shard_range(A, shard.rank, shard.world)
     width = (A + shard.world - 1) // shard.world
     part = torch.zeros((all_sets.n, width), dtype=torch.float32, device=cc_ids.device)
+    status = torch.zeros(2, dtype=torch.int32, device=cc_ids.device)
     if b > a:
-        part[:, :b - a] = ops.bfs_min_hops_to_sets(g, anchors[a:b].to(torch.int32).contiguous(), all_sets, max_hops=max_hops)
+        part[:, :b - a], status = ops.bfs_min_hops_to_sets(g, anchors[a:b].to(torch.int32).contiguous(), all_sets,
+                                                           max_hops=max_hops, want_status=True)
+    # a graph deeper than max_hops from some rank's anchors must stop EVERY rank (the replicated form raises for it)
+    status = sdist.all_reduce_max_(status)
     got = sdist.all_to_all_row_blocks(part)                         # block j: rank j's anchors, my rows
     rows = S * C
     cols = [got[j * rows:(j + 1) * rows, :sdist.shard_range(A, j, shard.world)[1] - sdist.shard_range(A, j, shard.world)[0]]
             for j in range(shard.world)]
-    return torch.cat(cols, dim=1)
+    return torch.cat(cols, dim=1), status
 
 
 class PassState:
@@ -151,6 +169,7 @@ class PassState:
         self.per_split = {}        # attribute name (a dict keyed by split on the model) -> this split's value
         self.sim_cols = None       # (anchors_structure, {layer: device index tensor}) when new patches were drawn
         self.dtw_inputs = None     # between prepare_pass(defer_dtw=True) and finish_pass: what the DTW launches read
+        self.bfs_checks = []       # hinted position-channel searches to verify before the pass is consumed (_verify_bfs)
 
     def tensors(self):
         return [self.attrs, self.per_split, self.sim_cols[1] if self.sim_cols else None]
@@ -176,7 +195,6 @@ def prepare_pass(model, split='train', timer=None, shard=None, defer_dtw=False):
     hp, g, dev = model.hparams, model.networkx_graph, model.device
     seed = int(hp.get('seed', 0)) & tape.MASK64
     st = PassState(split)
-    check_pending(model)                           # (the previous pass's BFS level hints; see _bfs_levels)
     t = timer or StageTimer(False)
     L = hp['n_layers']
     main = torch.cuda.current_stream()
@@ -203,7 +221,7 @@ def prepare_pass(model, split='train', timer=None, shard=None, defer_dtw=False):
     kept[split] = (tag, tuple(cc_ids.shape[1:]))
     st.attrs[split + '_cc_ids'] = cc_ids
     S, C, Lc = cc_ids.shape
-    if ops.DETERMINISTIC:
+    if getattr(model, '_deterministic', ops.DETERMINISTIC):
         # the component-embedding backward scatters per member id in sorted order: the members of a split's
         # components are the same every pass, so their order is computed on the first pass and kept
         mo = model.__dict__.setdefault('_cc_member_order', {})
@@ -245,14 +263,25 @@ def prepare_pass(model, split='train', timer=None, shard=None, defer_dtw=False):
             st.per_split['anchors_pos_int'] = pint
             for l in range(L):
                 if shard is not None and shard.deal_shared:
-                    w = _dealt_position_sims(g, anchors_pos_ext[l], cc_sets, cc_ids, shard,
-                                             hp.get('max_bfs_hops', 32)).view(S, C, -1)
+                    cap = hp.get('max_bfs_hops', 32)
+                    w, status = _dealt_position_sims(g, anchors_pos_ext[l], cc_sets, cc_ids, shard, cap)
+                    w = w.view(S, C, -1)
+                    # full cap, all ranks' worst status: verified before the pass is consumed like the hinted searches
+                    # (nothing to repeat: running out of levels here means max_bfs_hops is too small)
+                    model.__dict__.setdefault('_bfs_level_hint', {}).setdefault(('P_out_dealt', split, l), 0)
+                    _bfs_note(model, st, ('P_out_dealt', split, l), status, cap, cap, None)
                 else:
                     cap = hp.get('max_bfs_hops', 32)
                     nlev = _bfs_levels(model, ('P_out', split, l), cap)
-                    w, status = ops.bfs_min_hops_to_sets(g, anchors_pos_ext[l].to(torch.int32).contiguous(), cc_sets,
-                                                         max_hops=nlev, want_status=True)
-                    _bfs_note(model, ('P_out', split, l), status, cap, nlev)
+                    src = anchors_pos_ext[l].to(torch.int32).contiguous()
+                    w, status = ops.bfs_min_hops_to_sets(g, src, cc_sets, max_hops=nlev, want_status=True)
+
+                    def redo(levels, src=src, l=l, sims=sims):
+                        # the hinted search ran out of levels: the same search with the full cap, similarities replaced
+                        w2, st2 = ops.bfs_min_hops_to_sets(g, src, cc_sets, max_hops=levels, want_status=True)
+                        sims[('P', 'out', l)] = w2.view(S, C, -1).contiguous()
+                        return st2.tolist()
+                    _bfs_note(model, st, ('P_out', split, l), status, cap, nlev, redo)
                     w = w.view(S, C, -1)
                 # (rows of padded components need no masking: an empty set receives no level in msbfs_set_reduce and
                 # keeps the 0 the output was cleared to -- test_sparse_prepare_equals_dense_prepare checks the raw rows)
@@ -371,6 +400,7 @@ def install_pass(model, st, timer=None):
     the first stage of a pass to read the embedding table -- a sharded optimizer's all-gather of the updated table
     (dist.ShardedTableAdam) travels under everything prepare_pass does."""
     t = timer or StageTimer(False)
+    _verify_bfs(model, st)                       # before anything of the pass is visible (repeats a search if it must)
     for k, v in st.attrs.items():
         setattr(model, k, v)
     for k, v in st.per_split.items():

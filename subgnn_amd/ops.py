@@ -686,7 +686,32 @@ def dtw_similarity(x_ptr, x_val, max_x, y_ptr, y_val, max_y, tie_order=0, order_
 # float half (autograd Functions)
 # ---------------------------------------------------------------------------------------
 
-DETERMINISTIC = True       # table gradients by sorted segmented sums (bit-reproducible); False: float atomics
+DETERMINISTIC = True       # table gradients by sorted segmented sums (bit-reproducible); False: float atomics.
+#                            The default for calls made outside a model's forward; a model states its own choice for the
+#                            duration of ITS forward with ``deterministic(flag)``, every op records the choice in its autograd
+#                            context and the backward follows the record -- two models with different settings do not
+#                            disturb each other.
+_DET_SCOPE = None
+
+
+class deterministic:
+    """``with ops.deterministic(flag):`` -- the backward form (sorted sums / float atomics) of the ops whose FORWARD runs
+    inside the block."""
+
+    def __init__(self, flag):
+        self.flag = bool(flag)
+
+    def __enter__(self):
+        global _DET_SCOPE
+        self.old, _DET_SCOPE = _DET_SCOPE, self.flag
+
+    def __exit__(self, *exc):
+        global _DET_SCOPE
+        _DET_SCOPE = self.old
+
+
+def _det_now():
+    return DETERMINISTIC if _DET_SCOPE is None else _DET_SCOPE
 
 
 def sort_edges_by_key(keys, max_key):
@@ -742,27 +767,34 @@ class _GradAcc:
     step.  With it the backward kernels atomically add into the same buffer and the table's
     gradient is produced once."""
 
-    def __init__(self):
+    def __init__(self, owner=None):
         self.buf = None
+        self.owner = owner         # the parameter whose gradient this is (it may hold a buffer an optimizer zeroed)
 
     def buffer(self, shape, device):
         if self.buf is None:
-            self.buf = take_zeroed(shape, device)
+            self.buf = take_zeroed(self.owner, shape, device)
         return self.buf
 
 
-_ZEROED = {}       # (shape, device) -> a gradient buffer an optimizer has zeroed in its update pass (optim.ClipAdam)
+def take_zeroed(owner, shape, device):
+    """A zero-filled float32 buffer for ``owner``'s gradient: the one an optimizer handed back already zeroed
+    (release_zeroed -- it hangs on the parameter, so it lives and dies with it and no other model can pick it up),
+    else a fresh fill."""
+    buf = owner.__dict__.pop('_sgnn_zeroed', None) if owner is not None else None
+    if buf is not None and tuple(buf.shape) == tuple(shape) and buf.device == torch.device(device):
+        return buf
+    return torch.zeros(shape, dtype=torch.float32, device=device)
 
 
-def take_zeroed(shape, device):
-    """A zero-filled float32 buffer: one an optimizer handed back already zeroed (release_zeroed), else a fresh fill."""
-    buf = _ZEROED.pop((tuple(shape), torch.device(device)), None)
-    return buf if buf is not None else torch.zeros(shape, dtype=torch.float32, device=device)
+def release_zeroed(owner, buf):
+    """``buf`` (the gradient of parameter ``owner``) is all zeros and the optimizer is done with it: the next
+    accumulation of that parameter's gradient takes it as is."""
+    owner._sgnn_zeroed = buf
 
 
-def release_zeroed(buf):
-    """``buf`` is all zeros and its owner is done with it: the next table-gradient accumulation takes it as is."""
-    _ZEROED[(tuple(buf.shape), buf.device)] = buf
+def drop_zeroed(owner):
+    owner.__dict__.pop('_sgnn_zeroed', None)
 
 
 class _TableTap(torch.autograd.Function):
@@ -790,7 +822,7 @@ def tap_table(E, half=None):
     ``half``: an IEEE-half copy of the table (same shape): the fused ops then READ the half copy
     (half the gather bytes, fp32 accumulation) while gradients still flow to the fp32 ``E``."""
     if torch.is_grad_enabled() and E.requires_grad:
-        acc = _GradAcc()
+        acc = _GradAcc(E)
         t = _TableTap.apply(E, acc)
         t._sgnn_acc = acc
     elif half is not None:
@@ -824,6 +856,7 @@ class _CCEmbed(torch.autograd.Function):
         ctx.save_for_backward(ptr, nodes, arg)
         ctx.aggregator, ctx.shape = aggregator, E.shape
         ctx.stride = stride
+        ctx.det = _det_now()
         return out
 
     @staticmethod
@@ -835,7 +868,7 @@ class _CCEmbed(torch.autograd.Function):
         g = g.contiguous()
         gE = ctx.acc.buffer(ctx.shape, g.device) if ctx.acc is not None else \
             torch.zeros(ctx.shape, dtype=torch.float32, device=g.device)
-        if DETERMINISTIC and ctx.shape[1] <= 256:
+        if ctx.det and ctx.shape[1] <= 256:
             # every (member, component) pair is an edge member -> component row; sorted by member, one owner per
             # table row (sgnn_scatter_add_rows_sorted).  Max aggregator: a column counts where the member is its argmax.
             n = ptr.numel() - 1
@@ -907,6 +940,7 @@ class _MPN(torch.autograd.Function):
         ctx.set_materialize_grads(False)              # an unused output (the N channel never reads z) arrives as None
         ctx.meta = (src, id_div, sims_per_edge, R, A, D)
         ctx.acc = getattr(x, '_sgnn_acc', None) if src == SRC_GATHER else None     # x is the tapped table
+        ctx.det = _det_now()
         ctx.half = getattr(x, '_sgnn_half', None) if src == SRC_GATHER else None
         return agg, z
 
@@ -926,7 +960,7 @@ class _MPN(torch.autograd.Function):
                 gx = torch.empty_like(x) if src == SRC_DENSE else torch.zeros_like(x)
         if need_wp:
             gwp = torch.zeros(D, dtype=torch.float32, device=x.device)
-        if (need_x or need_wp) and A > 0 and src == SRC_GATHER and DETERMINISTIC and D <= 256:
+        if (need_x or need_wp) and A > 0 and src == SRC_GATHER and ctx.det and D <= 256:
             # table gradient by a sorted segmented sum, read-out weight gradient by per-row partials: no atomics
             if ctx.half is not None:
                 x._sgnn_half = ctx.half
@@ -943,7 +977,7 @@ class _MPN(torch.autograd.Function):
                 check(lib.sgnn_mpn_bwd_wp_partial(ctypes.byref(a), _ptr(g_z), _ptr(partial), _stream()),
                       'sgnn_mpn_bwd_wp_partial')
                 gwp = column_sum(partial)
-        elif (need_x or need_wp) and A > 0 and src == SRC_SHARED and DETERMINISTIC:
+        elif (need_x or need_wp) and A > 0 and src == SRC_SHARED and ctx.det:
             # row-tile partials added in tile order (sgnn_mpn_bwd_shared_det): no atomics
             a = _mpn_args(src, x, ids, id_div, edge_mask, row_mask, sims, sim_col, sims_per_edge, wp, bp, R, A, D)
             wsb = lib.sgnn_mpn_bwd_shared_det_workspace_bytes(R, A, D)
@@ -955,7 +989,7 @@ class _MPN(torch.autograd.Function):
                 x._sgnn_half = ctx.half               # saved tensors come back as new objects
             a = _mpn_args(src, x, ids, id_div, edge_mask, row_mask, sims, sim_col, sims_per_edge, wp, bp, R, A, D)
             partial = None
-            if need_wp and src == SRC_DENSE and DETERMINISTIC:
+            if need_wp and src == SRC_DENSE and ctx.det:
                 a.flags = 1                           # SGNN_MPN_WP_PARTIAL: per-row partials, summed below in a fixed order
                 partial = torch.empty((R, D), dtype=torch.float32, device=x.device)
             check(lib.sgnn_mpn_bwd(ctypes.byref(a), _ptr(g_agg), _ptr(g_z), _ptr(gx), _ptr(partial if partial is not None else gwp),
@@ -1197,6 +1231,7 @@ class _GatherRows(torch.autograd.Function):
         flat = ids.reshape(-1)
         ctx.save_for_backward(flat)
         ctx.n_rows = weight.shape[0]
+        ctx.det = _det_now()
         ctx.acc = getattr(weight, '_sgnn_acc', None)
         half = getattr(weight, '_sgnn_half', None)
         src = weight if half is None else half
@@ -1205,7 +1240,7 @@ class _GatherRows(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad):
         flat, = ctx.saved_tensors
-        if DETERMINISTIC and grad.is_cuda and grad.shape[-1] <= 256:
+        if ctx.det and grad.is_cuda and grad.shape[-1] <= 256:
             g = grad.reshape(flat.numel(), -1).to(torch.float32).contiguous()
             buf = ctx.acc.buffer((ctx.n_rows, g.shape[1]), grad.device) if ctx.acc is not None else \
                 torch.zeros(ctx.n_rows, g.shape[1], dtype=torch.float32, device=grad.device)

@@ -12,7 +12,11 @@ from . import ops
 
 
 class ClipAdam:
-    """``step()`` = clip_grad_norm_(params, max_norm) followed by Adam(params, lr).step();  ``zero_grad()`` as usual."""
+    """``step()`` = clip_grad_norm_(params, max_norm) followed by Adam(params, lr).step();  ``zero_grad()`` as usual.
+    After ``step()`` the gradient of a large parameter is gone (``p.grad is None``): its buffer, zeroed by the update
+    kernel, hangs on the parameter (``ops.release_zeroed``) and becomes the next backward's accumulator -- a caller that
+    kept a reference to ``p.grad`` across ``step()`` holds that recycled buffer, not the old gradient.  ``release()``
+    drops the kept buffers."""
 
     def __init__(self, params, lr, max_norm=None, betas=(0.9, 0.999), eps=1e-8, big_bytes=16 << 20):
         params = [p for p in params if p.requires_grad]
@@ -50,8 +54,13 @@ class ClipAdam:
             ops.adam_step(p.data, g, st['exp_avg'], st['exp_avg_sq'], self.lr, self.betas, self.eps, st['step'],
                           grad_scale=scale, zero_grad=take)
             if take:
-                ops.release_zeroed(g)
+                ops.release_zeroed(p, g)
                 p.grad = None
+
+    def release(self):
+        """Drop the zeroed gradient buffers kept on the large parameters (256 MB for the benchmark's table)."""
+        for p in self.big:
+            ops.drop_zeroed(p)
 
     def zero_grad(self, set_to_none=True):
         if self.small_opt is not None:

@@ -473,12 +473,16 @@ def test_clip_adam_matches_torch(max_norm):
             torch.nn.utils.clip_grad_norm_(ref, max_norm)
         o_ref.step(); o_got.step()
         assert got[0].grad is None                                  # consumed, zeroed and handed back
-        buf = ops.take_zeroed(shapes[0], torch.device(DEV))
-        assert float(buf.abs().max()) == 0.0
-        ops.release_zeroed(buf)
+        kept = got[0].__dict__.get('_sgnn_zeroed')                  # it hangs on ITS parameter, nowhere else
+        buf = ops.take_zeroed(got[0], shapes[0], torch.device(DEV))
+        assert buf is kept and float(buf.abs().max()) == 0.0 and '_sgnn_zeroed' not in got[0].__dict__
+        assert ops.take_zeroed(ref[0], shapes[0], torch.device(DEV)) is not buf     # another parameter gets a fresh one
+        ops.release_zeroed(got[0], buf)
         o_ref.zero_grad(); o_got.zero_grad()
         for a, b, s in zip(got, ref, shapes):
             assert_close(a.detach(), b.detach(), 'ClipAdam step %d %s' % (it, (s,)), 2e-6)
+    o_got.release()
+    assert '_sgnn_zeroed' not in got[0].__dict__
 
 
 # ---- a18 deterministic table-gradient scatter -------------------------------------------------------
@@ -608,3 +612,26 @@ def test_table_gradient_is_bit_reproducible():
     assert torch.equal(g1, g2)
     assert float(g1[0].abs().max()) == 0
     assert_close(g1, g0, 'deterministic vs atomics', 1e-5)
+
+
+def test_deterministic_choice_is_per_forward_not_process_wide():
+    """A model states its backward form for the duration of ITS forward (ops.deterministic) and the ops record it:
+    a forward run under 'atomics' keeps its atomic backward although the scope has ended and another forward ran under
+    'sorted' in between -- and the other way round."""
+    from subgnn_amd import ops
+    g = torch.Generator().manual_seed(3)
+    E0 = torch.randn(50, 32, generator=g)
+    walk = torch.randint(1, 50, (40, 6), generator=g)
+
+    def fwd(flag):
+        E = E0.to(DEV).requires_grad_(True)
+        with ops.deterministic(flag):
+            out = ops.gather_rows(ops.tap_table(E), walk.to(DEV))
+        return E, out
+    Ea, oa = fwd(False)
+    Es, os_ = fwd(True)
+    assert oa.grad_fn.det is False and os_.grad_fn.det is True          # recorded per op
+    assert ops._det_now() is ops.DETERMINISTIC                           # the scopes have ended
+    (oa ** 2).sum().backward()
+    (os_ ** 2).sum().backward()
+    assert_close(Ea.grad, Es.grad, 'atomics vs sorted', 1e-5)

@@ -134,9 +134,11 @@ def test_sharded_passes_reproduce_the_single_rank_pass(name, world, tmp_path):
         assert torch.equal(part.train_bor_struc_similarities, full.train_bor_struc_similarities[a:b])
 
 
-def test_bfs_level_hint_gives_the_same_similarities_and_a_short_hint_is_caught(tmp_path):
-    """The second pass enqueues (levels the first pass needed + margin) BFS levels instead of max_bfs_hops: same
-    similarities; a hint that is too small is reported at the next pass's entry and dropped."""
+def test_bfs_level_hint_gives_the_same_similarities_and_a_short_hint_is_repaired(tmp_path):
+    """The second pass enqueues (levels the first pass needed + margin + the empty level that proves the end) BFS levels
+    instead of max_bfs_hops: same similarities.  A hint that is too small is noticed BEFORE the pass is consumed
+    (install_pass): the search is repeated with the full cap and the similarities replaced -- training never sees the
+    truncated ones; only a graph deeper than max_bfs_hops itself is an error."""
     from conftest import load_golden
     from subgnn_amd import hotpath
     golden = load_golden('density')
@@ -146,25 +148,39 @@ def test_bfs_level_hint_gives_the_same_similarities_and_a_short_hint_is_caught(t
     first = [m.train_neigh_pos_similarities[('P', 'out', l)].clone() for l in range(L)]
     hint = dict(m._bfs_level_hint)
     assert set(hint) == {('P_out', 'train', l) for l in range(L)} and all(1 <= v < 32 for v in hint.values())
-    hotpath.prepare_sparse(m, 'train')                                # hinted
-    assert len(m._bfs_pending) == L and all(enq == hint[key] + hotpath.BFS_LEVEL_MARGIN for key, _, enq, _ in m._bfs_pending)
+    st = hotpath.prepare_pass(m, 'train')                             # hinted
+    assert len(st.bfs_checks) == L
+    assert all(enq == hint[key] + hotpath.BFS_LEVEL_MARGIN + 1 for key, _, _, _, enq, _ in st.bfs_checks)
+    hotpath.install_pass(m, st)
+    assert not st.bfs_checks and not m.__dict__.get('_bfs_redone')
     for l in range(L):
         assert torch.equal(m.train_neigh_pos_similarities[('P', 'out', l)], first[l])
-    hotpath.check_pending(m)
-    assert not m.__dict__.get('_bfs_pending')
-    # a hint that is too small: the search stops early, and the next entry says so
+    # a search exactly (margin) levels deeper than the hint still passes without a repeat
     for key in hint:
-        m._bfs_level_hint[key] = 1 - hotpath.BFS_LEVEL_MARGIN         # enqueue exactly one level
+        m._bfs_level_hint[key] = hint[key] - hotpath.BFS_LEVEL_MARGIN
     hotpath.prepare_sparse(m, 'train')
-    with pytest.raises(RuntimeError, match='ran out of levels'):
-        hotpath.prepare_sparse(m, 'train')
-    assert not m._bfs_level_hint                                      # dropped: the next pass runs the full cap
-    hotpath.prepare_sparse(m, 'train')
+    assert not m.__dict__.get('_bfs_redone') and m._bfs_level_hint == hint
+    # a hint that is too small: the truncated similarities never reach the model
+    for key in hint:
+        m._bfs_level_hint[key] = -hotpath.BFS_LEVEL_MARGIN            # enqueue exactly one level
+    st = hotpath.prepare_pass(m, 'train')
+    short = [st.attrs['train_neigh_pos_similarities'][('P', 'out', l)].clone() for l in range(L)]
+    assert any(not torch.equal(short[l], first[l]) for l in range(L))  # (what the search produced before the check)
+    hotpath.install_pass(m, st)
+    assert m._bfs_redone == L and m._bfs_level_hint == hint            # repeated with the full cap, hint repaired
     for l in range(L):
         assert torch.equal(m.train_neigh_pos_similarities[('P', 'out', l)], first[l])
-    # the cap itself is checked too
-    m._bfs_level_hint.clear()
+    hotpath.prepare_sparse(m, 'train')
+    assert m._bfs_redone == L
+    for l in range(L):
+        assert torch.equal(m.train_neigh_pos_similarities[('P', 'out', l)], first[l])
+    # the cap itself is checked too: on the first search, and when a repeated search still runs out
     m.hparams['max_bfs_hops'] = 1
+    for key in hint:
+        m._bfs_level_hint[key] = 0                                    # hint + margin + 1 > cap: capped at 1 level
+    with pytest.raises(RuntimeError, match='max_bfs_hops'):
+        hotpath.prepare_sparse(m, 'train')
+    m._bfs_level_hint.clear()
     with pytest.raises(RuntimeError, match='max_bfs_hops'):
         hotpath.prepare_sparse(m, 'train')
 
