@@ -174,7 +174,13 @@ def forward(params, hparams, split, batch, anchors, cc_params=None):
     if hparams.get('ff_attn', False):
         # attention.AdditiveAttention + masked_softmax + weighted_sum (attention.py:22-57,130-139; S.py:298-301)
         q = params['attn_vector'].view(1, -1).repeat(B, 1)
-        inter = torch.tanh(q.matmul(params['attention._w_matrix']).unsqueeze(1) + allcc.matmul(params['attention._u_matrix']))
+        xu_x, xu_u = allcc, params['attention._u_matrix']
+        if str(hparams.get('embedding_dtype', 'fp32')).lower() in ('fp16', 'float16', 'half'):
+            # BASELINE configs[4] ("fp16 embeddings with MFMA attention scores"): the score contraction takes its operands
+            # rounded to IEEE half, products and sums in fp32 (values only: the product's backward differentiates the
+            # unrounded contraction, so gradients are compared with the fp32 restatement)
+            xu_x, xu_u = allcc.half().float(), xu_u.half().float()
+        inter = torch.tanh(q.matmul(params['attention._w_matrix']).unsqueeze(1) + xu_x.matmul(xu_u))
         scores = inter.matmul(params['attention._v_vector']).squeeze(2)
         m = mask.to(scores.dtype)
         w = F.softmax(scores * m, dim=-1) * m

@@ -386,3 +386,73 @@ def test_training_step_against_oracle(cfg):
     torch.nn.utils.clip_grad_norm_(m.parameters(), hp['grad_clip'])
     opt.step()
     assert not torch.equal(before, m.lin.weight.detach())
+
+
+def test_em_user_with_ff_attn_half_mfma_scores(tmp_path_factory):
+    """BASELINE configs[4] as worded -- "EM-USER (large components, border channel heavy), fp16 embeddings with MFMA
+    attention scores": the EM-USER stand-in with ``ff_attn`` on and the fp16-stored table (hid_dim 579, >= 20 components
+    per subgraph).  (1) a training step at the configuration's batch size (32 subgraphs: under 2048 component rows the
+    score contraction is the library GEMM on half-rounded operands + the fused epilogue); (2) the whole train split as
+    one batch (>= 5k component rows: the hand-written v_mfma_f32_32x32x8_f16 kernel -- counted).  Logits and loss against
+    the oracle with the same operand rounding within 1e-4 element-wise; gradients against the fp32 restatement within
+    half precision."""
+    from subgnn_amd import standins, _lib, hotpath
+    root = tmp_path_factory.mktemp('em_user_attn')
+    m, d, _ = standins.build_model(root, 'em_user', {'lin_dropout': 0.0, 'lstm_dropout': 0.0, 'ff_attn': True},
+                                   torch.device(DEV))
+    hp = m.hparams
+    assert hp['ff_attn'] and m.attention.half_operands and m.hid_dim <= 640
+    C = m.train_cc_ids.shape[1]
+    assert C >= 20 and m.train_cc_ids.shape[2] > 32                        # many components, long rows (the stand-in's pieces merge to >= 20)
+    lib = _lib.load()
+    calls = {'f16': 0, 'epi': 0}
+    real_f16, real_epi = lib.sgnn_attn_scores_fwd_f16, lib.sgnn_attn_scores_epilogue
+
+    def f16(*a):
+        calls['f16'] += 1
+        return real_f16(*a)
+
+    def epi(*a):
+        calls['epi'] += 1
+        return real_epi(*a)
+    lib.sgnn_attn_scores_fwd_f16, lib.sgnn_attn_scores_epilogue = f16, epi
+    try:
+        rng = np.random.default_rng(5)
+        # (1) the configuration's batch
+        B = hp['batch_size']
+        idx = torch.from_numpy(np.sort(rng.choice(len(m.train_sub_G), B, replace=False)))
+        m.train()
+        m.zero_grad(set_to_none=True)
+        batch = m.make_batch('train', idx)
+        out = m.training_step(batch, 0)
+        m.backward(None, out['loss'], None, 0)
+        assert calls == {'f16': 0, 'epi': 1} and B * batch['cc_ids'].shape[1] < 2048
+        logits = m._forward_batch('train', batch)
+        params, anchors, ob, ccp = _oracle_inputs(m, batch, idx)
+        ref_logits = FH.forward(params, hp, 'train', ob, anchors, ccp)
+        ref_loss = torch.nn.functional.cross_entropy(ref_logits, batch['label'].cpu())
+        assert_close(logits, ref_logits, 'logits (batch of 32, half-rounded score operands)')
+        assert_close(out['loss'], ref_loss, 'loss')
+        hp32 = dict(hp, embedding_dtype='fp32')
+        params32, _, _, ccp32 = _oracle_inputs(m, batch, idx)
+        l32 = torch.nn.functional.cross_entropy(FH.forward(params32, hp32, 'train', ob, anchors, ccp32), batch['label'].cpu())
+        l32.backward()
+        for k in ('attention._u_matrix', 'attention._w_matrix', 'attention._v_vector', 'attn_vector', 'lin.weight'):
+            assert_close(dict(m.named_parameters())[k].grad, params32[k].grad, 'grad ' + k, 5e-2)      # (the softmax weights come from half-rounded scores)
+        # (2) the whole split as one batch: the matrix-core kernel
+        calls.update(f16=0, epi=0)
+        full = hotpath.full_split_batch(m, 'train')
+        rows = full['cc_ids'].shape[0] * full['cc_ids'].shape[1]
+        assert rows >= 2048
+        m.eval()
+        with torch.no_grad():
+            got = m._forward_batch('train', full)
+        assert calls == {'f16': 1, 'epi': 0}
+        all_idx = torch.arange(full['cc_ids'].shape[0])
+        params, anchors, ob, ccp = _oracle_inputs(m, full, all_idx)
+        with torch.no_grad():
+            want = FH.forward(params, hp, 'train', ob, anchors, ccp)
+        assert_close(got, want, 'logits (whole split, v_mfma_f32_32x32x8_f16 scores)')
+    finally:
+        lib.sgnn_attn_scores_fwd_f16, lib.sgnn_attn_scores_epilogue = real_f16, real_epi
+        torch.cuda.empty_cache()

@@ -67,7 +67,7 @@ def test_sparse_prepare_equals_dense_prepare(name, tmp_path):
     with torch.no_grad():
         a = dense._forward_batch('train', dense.make_batch('train', idx))
         b = sparse._forward_batch('train', sparse.make_batch('train', idx))
-    assert_close(b, a, 'logits sparse vs dense', 1e-5)
+    assert_close(b, a, 'logits sparse vs dense', norm_tol=1e-5)
 
 
 def test_full_split_step_runs_and_is_deterministic(tmp_path):
