@@ -84,6 +84,29 @@ template <> __device__ __forceinline__ float4 sgnn_load4<__half>(const __half* b
     return make_float4(a.x, a.y, b.x, b.y);
 }
 
+
+// ---- wavefront scans on the DPP data path (no LDS round trips: a __shfl_up scan is six ds_bpermute latencies, ~700
+// cycles on a latency-bound kernel; this is ~16 VALU instructions).  All 64 lanes must be executing. -------------------
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ int32_t sgnn_dpp0(int32_t v) {      // 0 where there is no source lane
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xf, true);
+}
+// inclusive prefix sum within each row of 16 lanes
+__device__ __forceinline__ int32_t sgnn_row_incl_scan(int32_t v) {
+    int32_t s = v + sgnn_dpp0<0x111, 0xf>(v);          // row_shr:1
+    s += sgnn_dpp0<0x112, 0xf>(v);                     // row_shr:2
+    s += sgnn_dpp0<0x113, 0xf>(v);                     // row_shr:3  -> sums of 4
+    s += sgnn_dpp0<0x114, 0xf>(s);                     // row_shr:4  -> sums of 8
+    s += sgnn_dpp0<0x118, 0xf>(s);                     // row_shr:8  -> the row's prefix
+    return s;
+}
+// inclusive prefix sum over the 64 lanes
+__device__ __forceinline__ int32_t sgnn_wave_incl_scan(int32_t v) {
+    int32_t s = sgnn_row_incl_scan(v);
+    s += sgnn_dpp0<0x142, 0xa>(s);                     // row_bcast:15 -> rows 1 and 3 take the row before them
+    s += sgnn_dpp0<0x143, 0xc>(s);                     // row_bcast:31 -> rows 2 and 3 take rows 0-1
+    return s;
+}
+
 // ---- small device helpers ---------------------------------------------------------------
 __device__ static inline uint32_t sgnn_hash32(uint32_t x) { return x * 2654435761u; }
 

@@ -744,13 +744,16 @@ extern "C" int sgnn_khop_border_arena(const int64_t* rowptr, const int32_t* col,
 //     pass B rebuilds each slice and answers the slots whose rank falls into it -- twice the edge
 //     traffic, against the ~9x of keeping the bitmap in L2.
 // ---------------------------------------------------------------------------------------------
-#define K1_THREADS 1024
+#define K1_THREADS 1024         // 16 wavefronts: the rank tables below are laid out for exactly this (64 groups of 16 lanes, one DPP row of wavefront totals)
 #define K1_MAX_SLICES 32
 #ifndef K1_INFLIGHT
 #define K1_INFLIGHT 4           // 64-entry chunk loads a wavefront issues before it sets any bit
 #endif
 #ifndef K1_RANK_UNROLL
 #define K1_RANK_UNROLL 8
+#endif
+#ifndef K1_LONG
+#define K1_LONG 512             // lists of at least this many entries are shared by all wavefronts of the workgroup
 #endif
 #ifndef K1_TAKE
 #define K1_TAKE 8               // sets per trip to the device-wide counter (all but the first of a trip are prefetched)
@@ -804,16 +807,16 @@ __global__ __launch_bounds__(K1_THREADS) void khop1_sample_kernel(
     __shared__ __attribute__((aligned(16))) int32_t s_pref[K1_THREADS];
     __shared__ int32_t s_wtot[K1_THREADS / 64 + 1];
     __shared__ int32_t s_cum[K1_MAX_SLICES + 1];
-    __shared__ int32_t s_rank[K1_THREADS / 16], s_an[K1_THREADS / 16];
     __shared__ long long s_next;
+    __shared__ uint32_t s_u0[K1_THREADS / 16], s_u1[K1_THREADS / 16];     // the first 64 slots' two tape draws of the set in hand
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int wave_s = __builtin_amdgcn_readfirstlane(tid >> 6);          // the same number, known to be uniform
     constexpr int NW = K1_THREADS / 64;
     const int grp = tid >> 4, gl = tid & 15, gshift = (lane >> 4) * 16;     // 64 groups of 16 lanes
-    const int64_t words_max = (slice_ids + 31) / 32;
+    const int words_alloc = (int)((((slice_ids + 31) / 32 + K1_THREADS - 1) / K1_THREADS) | 1) * K1_THREADS;   // host: k1_alloc_bytes
     {
         int4* bm4 = reinterpret_cast<int4*>(s_bm);
-        for (int64_t i = tid; i < (words_max + 3) / 4; i += K1_THREADS) bm4[i] = make_int4(0, 0, 0, 0);
+        for (int i = tid; i < words_alloc / 4; i += K1_THREADS) bm4[i] = make_int4(0, 0, 0, 0);
     }
     __syncthreads();
     int64_t si_next = 0, si_end = 0;
@@ -852,6 +855,15 @@ __global__ __launch_bounds__(K1_THREADS) void khop1_sample_kernel(
         // the expansion -- each step is issued long after the previous one returned, and the LDS-only barriers
         // in between leave the loads in flight: the set_ptr -> members -> row pointers -> lists chain of
         // dependent global latencies (~4 x 1 us per set on one resident workgroup) is paid once per trip
+        // The slots' tape draws (four 64-bit mixes each) do not depend on anything the set computes: ONE wavefront hashes
+        // them now, under the latency of the first loads, and the barriers of the expansion publish them -- hashed by
+        // every 16-lane group at draw time they were 11 wavefronts x ~130 vector instructions per set, a quarter of
+        // the kernel's vector work.  (The previous set's draw has finished: two barriers lie behind it.)
+        if (wave_s == NW - 1 && lane < smp.n_slots) {
+            const uint64_t h1_ = sgnn_tape_h1(smp.h0, (uint64_t)(s * smp.n_slots + lane + smp.item_base * smp.n_slots));
+            s_u0[lane] = (uint32_t)(sgnn_tape_draw(h1_, 0) >> 32);
+            s_u1[lane] = (uint32_t)(sgnn_tape_draw(h1_, 1) >> 32);
+        }
         const bool can_pf = !SLICED && set_order == nullptr && si_next < si_end && si_next < n_sets;
         int64_t nx_beg = 0, nx_end = 0;
         int32_t nx_v = 0;
@@ -891,56 +903,69 @@ __global__ __launch_bounds__(K1_THREADS) void khop1_sample_kernel(
                         r0 = (uint32_t)a;
                         deg = (int32_t)(b - a);
                     }
-                    int32_t incl = (deg + 63) >> 6;                                   // chunks of this member's list
-#pragma unroll
-                    for (int d = 1; d < 64; d <<= 1) { const int32_t t = __shfl_up(incl, d); if (lane >= d) incl += t; }
-                    const int32_t n_chunks = __builtin_amdgcn_readlane(incl, 63);
-                    // everything that locates a chunk is wave-uniform and kept in scalar registers: the member
-                    // index only ever moves forward, so a chunk costs about one v_readlane -- a 6-step search per
-                    // chunk in vector registers made this loop issue-bound (16 wavefronts x ~110 instructions per
-                    // chunk: 16 k cycles per set, whatever the loads did)
                     K1_T(6);                                       // (debug) tile ready
                     // step 1 of the prefetch, issued only now: a load issued before the prefetched row pointers
                     // above are consumed would have to complete first (the counter of outstanding loads cannot
                     // tell them apart across the loop's back edge)
                     if (t0 == 0 && can_pf && lane < nx_end - nx_beg) nx_v = set_nodes[nx_beg + lane];
-                    int m = 0;
-                    int32_t m_incl = __builtin_amdgcn_readlane(incl, 0);
-                    int32_t m_deg = __builtin_amdgcn_readlane(deg, 0);
-                    uint32_t m_r0 = (uint32_t)__builtin_amdgcn_readlane((int)r0, 0);
-                    for (int32_t q0 = wave_s; q0 < n_chunks; q0 += K1_INFLIGHT * NW) {
-                        int32_t c[K1_INFLIGHT];
-#pragma unroll
-                        for (int u = 0; u < K1_INFLIGHT; ++u) {
-                            const int32_t q = q0 + u * NW;
-                            c[u] = -1;
-                            if (q < n_chunks) {
-                                while (m_incl <= q) {                                 // scalar loop
-                                    ++m;
-                                    m_incl = __builtin_amdgcn_readlane(incl, m);
-                                    m_deg = __builtin_amdgcn_readlane(deg, m);
-                                    m_r0 = (uint32_t)__builtin_amdgcn_readlane((int)r0, m);
-                                }
-                                const int32_t t = (q - (m_incl - ((m_deg + 63) >> 6))) * 64 + lane;
-#ifdef K1_DEBUG_NO_LOAD
-                                if (t < m_deg) c[u] = (int32_t)((m_r0 + (uint32_t)t) * 2654435761u % (uint32_t)max_id);
+                    // Who reads what, without any search: a list of >= K1_LONG entries is shared by all wavefronts
+                    // (wavefront w takes the 64-entry chunks w, w + 16, ...), a shorter one belongs whole to wavefront
+                    // (member index) % 16.  Everything that selects a list is a ballot bit or a v_readlane -- rounds 1-2
+                    // numbered all chunks through and every wavefront walked the whole member list in scalar registers
+                    // to find its own: ~500 scalar instructions per wavefront and set.
+#define K1_OR_BIT(C) do { if ((C) >= 0) { const int32_t x_ = (C) - (int32_t)lo_id; K1_OR_AT(x_); } } while (0)
+#ifdef K1_DEBUG_NO_OR
+#define K1_OR_AT(X) do { if ((X) == 0x7fffffff) s_bm[0] = 1; } while (0)
 #else
-                                if (t < m_deg) c[u] = col[m_r0 + (uint32_t)t];
+#define K1_OR_AT(X) __hip_atomic_fetch_or(&s_bm[(X) >> 5], 1u << ((X) & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
 #endif
+#ifdef K1_DEBUG_NO_LOAD
+#define K1_COL(I) (int32_t)(((uint32_t)(I)) * 2654435761u % (uint32_t)max_id)
+#else
+#define K1_COL(I) col[(I)]
+#endif
+#ifdef K1_DEBUG_SKIP_CHUNKS
+                    if (false)
+#endif
+                    {
+                        uint64_t longs = __ballot(deg >= K1_LONG);
+                        while (longs) {                                               // scalar loop over the long lists
+                            const int m = __ffsll((long long)longs) - 1;
+                            longs &= longs - 1;
+                            const int32_t m_deg = __builtin_amdgcn_readlane(deg, m);
+                            const uint32_t m_r0 = (uint32_t)__builtin_amdgcn_readlane((int)r0, m);
+                            for (int32_t tb = wave_s * 64; tb < m_deg; tb += K1_INFLIGHT * NW * 64) {
+                                int32_t c[K1_INFLIGHT];
+#pragma unroll
+                                for (int u = 0; u < K1_INFLIGHT; ++u) {
+                                    const int32_t t = tb + u * NW * 64 + lane;
+                                    c[u] = t < m_deg ? K1_COL(m_r0 + (uint32_t)t) : -1;
+                                }
+#pragma unroll
+                                for (int u = 0; u < K1_INFLIGHT; ++u) K1_OR_BIT(c[u]);
                             }
                         }
+                        // (skipping the slots past a list's end with scalar tests, or unrolling the short lists exactly,
+                        // was slower: 1.48 -> 1.52-1.60 ms -- the branches cost more than the predicated-off instructions)
+                        for (int m = wave_s; m < 64 && t0 + m < n; m += NW) {          // this wavefront's short lists
+                            const int32_t m_deg = __builtin_amdgcn_readlane(deg, m);
+                            if (m_deg >= K1_LONG) continue;
+                            const uint32_t m_r0 = (uint32_t)__builtin_amdgcn_readlane((int)r0, m);
+                            for (int32_t tb = 0; tb < m_deg; tb += K1_INFLIGHT * 64) {
+                                int32_t c[K1_INFLIGHT];
 #pragma unroll
-                        for (int u = 0; u < K1_INFLIGHT; ++u) {
-                            if (c[u] >= 0) {
-                                const int32_t x = c[u] - (int32_t)lo_id;
-#ifdef K1_DEBUG_NO_OR
-                                if (x == 0x7fffffff) s_bm[0] = 1;
-#else
-                                __hip_atomic_fetch_or(&s_bm[x >> 5], 1u << (x & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#endif
+                                for (int u = 0; u < K1_INFLIGHT; ++u) {
+                                    const int32_t t = tb + u * 64 + lane;
+                                    c[u] = t < m_deg ? K1_COL(m_r0 + (uint32_t)t) : -1;
+                                }
+#pragma unroll
+                                for (int u = 0; u < K1_INFLIGHT; ++u) K1_OR_BIT(c[u]);
                             }
                         }
                     }
+#undef K1_OR_BIT
+#undef K1_OR_AT
+#undef K1_COL
                 }
                 K1_T(7);                                               // (debug) own chunks done
                 if (n == 0 && can_pf && lane < nx_end - nx_beg) nx_v = set_nodes[nx_beg + lane];    // (no tile ran step 1)
@@ -967,112 +992,138 @@ __global__ __launch_bounds__(K1_THREADS) void khop1_sample_kernel(
                 k1_lds_barrier();
                 K1_T(2);                                           // members un-set
                 // ---- rank table: popcount of each thread's run of words, exclusive prefix ----------------
-                const int64_t run = ((words + K1_THREADS - 1) / K1_THREADS) | 1;       // odd: conflict-free strides
-                const int64_t w0 = (int64_t)tid * run;
-                const int64_t w1 = w0 + run < words ? w0 + run : words;
+                const int run = (int)(((words + K1_THREADS - 1) / K1_THREADS) | 1);     // odd: conflict-free strides
                 int c = 0;
-                for (int64_t wb = w0; wb < w0 + run; wb += K1_RANK_UNROLL) {   // independent reads per step (a read per
-                    uint32_t x[K1_RANK_UNROLL];                                // iteration is a chain of LDS latencies)
+                {
+                    // 32-bit indices and no bounds tests (the allocation is run x K1_THREADS words, zero beyond `words`):
+                    // whole groups of eight independent reads, then the LAST eight words of the run, of which the ones the
+                    // groups have already counted are masked by loop-invariant scalars -- a read + a v_bcnt per word (the
+                    // first version selected every index and every count with scalar compares: ~10 instructions per word)
+                    const uint32_t* __restrict__ mine_ = s_bm + tid * run;
+#ifdef K1_DEBUG_SKIP_RANK
+                    if (false)
+#endif
+                    if (run >= 8) {
+                        for (int g = 0; g < (run >> 3); ++g) {
+                            uint32_t x[8];
 #pragma unroll
-                    for (int u = 0; u < K1_RANK_UNROLL; ++u) x[u] = wb + u < w1 ? s_bm[wb + u] : 0u;
+                            for (int u = 0; u < 8; ++u) x[u] = mine_[8 * g + u];
 #pragma unroll
-                    for (int u = 0; u < K1_RANK_UNROLL; ++u) c += __popc(x[u]);
+                            for (int u = 0; u < 8; ++u) c += __popc(x[u]);
+                        }
+                        const int first_new = 8 - (run & 7);                  // of the last eight words, those from here on are new
+                        const uint32_t* __restrict__ tail_ = mine_ + run - 8;
+                        uint32_t x[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) x[u] = tail_[u];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) c += u >= first_new ? __popc(x[u]) : 0;
+                    } else {
+                        for (int u = 0; u < run; ++u) c += __popc(mine_[u]);
+                    }
                 }
-                int inc = c;
-#pragma unroll
-                for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(inc, d); if (lane >= d) inc += t; }
+                // (the whole per-set chain below is latency, not throughput: one workgroup per CU, every step waits for
+                // the one before -- scans run on the DPP path, every wavefront scans the 16 wavefront totals itself
+                // instead of waiting for thread 0 to walk them, and no step goes through an LDS mailbox)
+                // s_pref holds WAVEFRONT-LOCAL exclusive prefixes and s_wtot the 16 wavefront totals: one barrier publishes
+                // both, and every 16-lane group scans the totals itself (a DPP row scan) where a second barrier used to
+                // separate "totals known" from "global prefixes written"
+                const int inc = sgnn_wave_incl_scan(c);
+                s_pref[tid] = inc - c;
                 if (lane == 63) s_wtot[wave] = inc;
                 k1_lds_barrier();
-                if (tid == 0) {
-                    int acc = 0;
-                    for (int w = 0; w < NW; ++w) { const int t = s_wtot[w]; s_wtot[w] = acc; acc += t; }
-                    s_wtot[NW] = acc;
-                    if (SLICED && pass == 0) { if (sl == 0) s_cum[0] = 0; s_cum[sl + 1] = s_cum[sl] + acc; }
+                const int wt = s_wtot[gl];                                        // NW = 16 totals, replicated in every row
+                const int wincl = sgnn_row_incl_scan(wt);
+                const int wexcl = wincl - wt;                                     // lane gl: ranks before wavefront gl's runs
+                const int total = __builtin_amdgcn_readlane(wincl, NW - 1);
+                if (SLICED && pass == 0) {
+                    if (tid == 0) { if (sl == 0) s_cum[0] = 0; s_cum[sl + 1] = (sl == 0 ? 0 : s_cum[sl]) + total; }
+                    k1_lds_barrier();                                             // (pass 1 reads s_cum)
                 }
-                k1_lds_barrier();
-                s_pref[tid] = s_wtot[wave] + inc - c;
-                const int total = s_wtot[NW];
-                k1_lds_barrier();
                 K1_T(3);                                           // rank table
                 if (!(SLICED && pass == 0)) {
                     cnt = SLICED ? s_cum[n_slices] : total;
                     const int cum_lo = SLICED ? s_cum[sl] : 0;
                     if (sl == 0 && tid == 0 && out_count) out_count[s] = cnt;
-                    // ---- the draw: 64 slots per round, a group of 16 lanes each ---------------------------
+                    // ---- the draw: 64 slots per round, a group of 16 lanes (one DPP row) each -----------------
+                    // Every lane of a group hashes its slot's tape draws itself (three 64-bit mixes: cheaper than a
+                    // trip through LDS and a barrier), the searches' prefix sums run on the DPP path inside the row,
+                    // and the lane that holds the answer writes it.
+#ifdef K1_DEBUG_SKIP_DRAW
+                    if (false)
+#endif
                     for (int64_t c0 = 0; c0 < smp.n_slots; c0 += K1_THREADS / 16) {
-                        // the slots' tape draws (three 64-bit mixes each) once per slot, by the first lanes of the
-                        // workgroup -- not once per lane of the group that then looks the rank up
-                        if (tid < K1_THREADS / 16) {
-                            int32_t rk = -1;
-                            int32_t an_ = 1;
-                            if (c0 + tid < smp.n_slots && cnt > 0) {
-                                const uint64_t h1_ = sgnn_tape_h1(smp.h0, (uint64_t)(s * smp.n_slots + c0 + tid + smp.item_base * smp.n_slots));
-                                rk = (int32_t)sgnn_nanchor_index(h1_, (uint32_t)cnt);
-                                an_ = sgnn_nanchor_allneg(h1_, (uint32_t)cnt) ? 1 : 0;
-                            }
-                            s_rank[tid] = rk;
-                            s_an[tid] = an_;
-                        }
-                        k1_lds_barrier();
                         if (c0 + wave_s * 4 >= smp.n_slots) continue;                // none of this wavefront's four slots exists
                         const int64_t slot = c0 + grp;
                         const bool active = slot < smp.n_slots;
                         const int64_t o = s * smp.n_slots + (active ? slot : 0);
-                        int rem = s_rank[grp];
-                        const uint8_t an = (uint8_t)s_an[grp];
+                        int rem = -1;
+                        uint8_t an = 1;
+                        if (active && cnt > 0) {
+                            uint32_t u0, u1;
+                            if (c0 == 0) { u0 = s_u0[grp]; u1 = s_u1[grp]; }                  // hashed at the set's start
+                            else {                                                            // more than 64 slots: the later rounds hash here
+                                const uint64_t h1_ = sgnn_tape_h1(smp.h0, (uint64_t)(s * smp.n_slots + slot + smp.item_base * smp.n_slots));
+                                u0 = (uint32_t)(sgnn_tape_draw(h1_, 0) >> 32);
+                                u1 = (uint32_t)(sgnn_tape_draw(h1_, 1) >> 32);
+                            }
+                            // sgnn_nanchor_index / sgnn_nanchor_allneg (common.h) on the two draws
+                            rem = (int32_t)(((uint64_t)u0 * (uint64_t)(uint32_t)cnt) >> 32);
+                            an = cnt > 32 ? 0 : ((cnt == 32 ? u1 == 0u : (u1 >> (32 - cnt)) == 0u) ? 1 : 0);
+                        }
                         rem -= cum_lo;
                         const bool mine = active && cnt > 0 && rem >= 0 && rem < total;       // the rank lies in this slice
                         if (!mine) rem = 0;
-                        // coarse: 16 prefixes, one per 64 runs
-                        const int v1 = s_pref[gl * 64];
-                        const uint32_t b1 = (uint32_t)(__ballot(v1 <= rem) >> gshift) & 0xffffu;
+                        // coarse: the wavefront whose runs hold the rank (16 exclusive prefixes, one per lane of the group)
+                        const uint32_t b1 = (uint32_t)(__ballot(wexcl <= rem) >> gshift) & 0xffffu;
                         const int blk = 31 - __clz((int)(b1 | 1u));
-                        // fine: the block's 64 prefixes, 4 per lane
+                        rem -= __shfl(wexcl, blk, 16);                                        // ranks inside that wavefront's runs
+                        // fine: the wavefront's 64 local prefixes, 4 per lane
                         const int4 e = *reinterpret_cast<const int4*>(&s_pref[blk * 64 + gl * 4]);
                         int n_le = __popc((uint32_t)(__ballot(e.x <= rem) >> gshift) & 0xffffu);
                         n_le += __popc((uint32_t)(__ballot(e.y <= rem) >> gshift) & 0xffffu);
                         n_le += __popc((uint32_t)(__ballot(e.z <= rem) >> gshift) & 0xffffu);
                         n_le += __popc((uint32_t)(__ballot(e.w <= rem) >> gshift) & 0xffffu);
                         const int T = blk * 64 + (n_le > 0 ? n_le - 1 : 0);
+                        // (the prefix of run T is one of the four values this group has just read: lane (T % 64) / 4 holds it)
                         rem -= s_pref[T];
                         // the run's words, 16 per round in word order
-                        const int64_t rw0 = (int64_t)T * run;
-                        const int64_t rw1 = rw0 + run < words ? rw0 + run : words;
+                        const int rw0 = T * run, rw1 = rw0 + run;
                         bool found = false;
-                        int32_t id = 0;
-                        for (int64_t wb = 0; wb < run; wb += 16) {                            // run is the same for every group
-                            const int64_t w = rw0 + wb + gl;
+                        for (int wb = 0; wb < run; wb += 16) {                                // run is the same for every group
+                            const int w = rw0 + wb + gl;
                             const uint32_t word = w < rw1 ? s_bm[w] : 0u;
                             const int pc = __popc(word);
-                            int incl = pc;
-#pragma unroll
-                            for (int d = 1; d < 16; d <<= 1) { const int t = __shfl_up(incl, d, 16); if (gl >= d) incl += t; }
+                            const int incl = sgnn_row_incl_scan(pc);
                             const uint32_t over = (uint32_t)(__ballot(incl > rem) >> gshift) & 0xffffu;
-                            const int tot16 = __shfl(incl, 15, 16);
+                            // the row's total = its lane 15: the four rows' totals read into scalars, each lane takes its row's
+                            const int t0_ = __builtin_amdgcn_readlane(incl, 15), t1_ = __builtin_amdgcn_readlane(incl, 31);
+                            const int t2_ = __builtin_amdgcn_readlane(incl, 47), t3_ = __builtin_amdgcn_readlane(incl, 63);
+                            const int tot16 = gshift == 0 ? t0_ : (gshift == 16 ? t1_ : (gshift == 32 ? t2_ : t3_));
                             if (!found && over) {
                                 const int L = __ffs((int)over) - 1;
-                                if (gl == L) id = (int32_t)(lo_id + w * 32 + k1_nth_set_bit(word, rem - (incl - pc)));
-                                id = __shfl(id, L, 16);
+                                if (mine && gl == L) {                                        // this lane's word holds the bit: it answers
+                                    smp.anchor[o] = lo_id + (int64_t)w * 32 + k1_nth_set_bit(word, rem - (incl - pc));
+                                    smp.allneg[o] = an;
+                                    smp.hop[o] = 1;
+                                }
                                 found = true;
                             }
                             if (!found) rem -= tot16;
                         }
-                        if (mine && gl == 0) {
-                            smp.anchor[o] = (int64_t)id;
-                            smp.allneg[o] = an;
-                            smp.hop[o] = 1;
-                        }
                         if (active && cnt == 0 && sl == 0 && gl == 0) { smp.anchor[o] = 0; smp.allneg[o] = 1; smp.hop[o] = 0; }
-                        if (c0 + K1_THREADS / 16 < smp.n_slots) k1_lds_barrier();             // s_rank is rewritten next round (only reached when every wavefront had slots)
                     }
                 }
                 // ---- wipe for the next slice / set ------------------------------------------------------
                 k1_lds_barrier();
                 K1_T(4);                                           // draw
+#ifndef K1_DEBUG_SKIP_WIPE
                 {
                     int4* bm4 = reinterpret_cast<int4*>(s_bm);
-                    for (int64_t i = tid; i < (words + 3) / 4; i += K1_THREADS) bm4[i] = make_int4(0, 0, 0, 0);
+                    const int n4 = (int)((words + 3) / 4);
+                    for (int i = tid; i < n4; i += K1_THREADS) bm4[i] = make_int4(0, 0, 0, 0);
                 }
+#endif
                 k1_lds_barrier();
                 K1_T(5);                                           // wipe
             }
@@ -1080,10 +1131,18 @@ __global__ __launch_bounds__(K1_THREADS) void khop1_sample_kernel(
     }
 }
 
+// The rank pass gives every thread a run of `run` words (odd: conflict-free strides) and reads them without bounds tests,
+// so the bitmap is allocated as run x K1_THREADS words (the padding is never set and stays zero).
+static inline int64_t k1_run(int64_t words) { return ((words + K1_THREADS - 1) / K1_THREADS) | 1; }
+static inline int64_t k1_alloc_bytes(int64_t slice_ids) { return k1_run((slice_ids + 31) / 32) * K1_THREADS * 4; }
+#define K1_LDS_MAX (155 * 1024)          // dynamic LDS the kernel may take (4.2 KB of static tables on top: 160 KB per CU)
+
 static int k1_plan(int64_t max_id, int64_t lds_budget, int64_t* slice_ids, int* n_slices)
 {
     const int64_t ids = max_id + 1;
-    const int64_t cap = (lds_budget / 16) * 16 * 8;                      // ids one slice can hold
+    int64_t cap = (lds_budget / 16) * 16 * 8;                            // ids one slice can hold
+    const int64_t run_max = ((K1_LDS_MAX / (K1_THREADS * 4)) - 1) | 1;   // largest odd run whose padded bitmap fits
+    if (cap > run_max * K1_THREADS * 32) cap = run_max * K1_THREADS * 32;
     if (cap < 128) return 0;
     int64_t ns = (ids + cap - 1) / cap;
     if (ns > K1_MAX_SLICES) return 0;
@@ -1135,12 +1194,12 @@ extern "C" int sgnn_khop_border_sample(const int64_t* rowptr, const int32_t* col
             { const hipError_t me = hipMemsetAsync(next_set, 0, 8, st); if (me != hipSuccess) { sgnn_set_last_error(me); return SGNN_ERR_LAUNCH; } }
             static bool attr_set = false;
             if (!attr_set) {
-                hipFuncSetAttribute((const void*)khop1_sample_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, KB_LDS_BYTES);
-                hipFuncSetAttribute((const void*)khop1_sample_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, KB_LDS_BYTES);
+                (void)hipFuncSetAttribute((const void*)khop1_sample_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, K1_LDS_MAX);
+                (void)hipFuncSetAttribute((const void*)khop1_sample_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, K1_LDS_MAX);
                 attr_set = true;
             }
             const int64_t nwg = kb_n_wg(n_sets, true);
-            const size_t lds = (size_t)((((slice_ids + 31) / 32 + 3) / 4) * 16);
+            const size_t lds = (size_t)k1_alloc_bytes(slice_ids);
             if (n_slices == 1)
                 hipLaunchKernelGGL(khop1_sample_kernel<false>, dim3((int)nwg), dim3(K1_THREADS), lds, st, rowptr, col, max_id,
                                    set_ptr, set_nodes, n_sets, out_count, smp, slice_ids, 1, next_set, set_order);
