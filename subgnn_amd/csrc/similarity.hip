@@ -65,33 +65,42 @@ extern "C" int sgnn_sp_similarity_dense(const double* apsp, int64_t n_cols,
 //            new bits; flags[level] says whether any bit was new (later levels exit early);
 //            fvol[level] = sum over new frontier words of the node's degree.
 // ---------------------------------------------------------------------------------------------
+// Row stride (in 64-bit words) of the per-node arrays seen / frontier / next: three words (129-192 sources, the benchmark's
+// 183) are padded to four -- a pull level gathers one row per neighbour, and a 24-byte row straddles two 32-byte sectors
+// every other time (1.5 sectors per gather on average), a 32-byte row is always one
+static inline int64_t msbfs_row_stride(int64_t n_words) { return n_words == 3 ? 4 : n_words; }
+
 #define MSBFS_DEFAULT_ALPHA 32     // pull when frontier word-edges * alpha > nnz * n_words; 0 = never pull
 
 __global__ void msbfs_init_kernel(const int32_t* __restrict__ sources, int64_t n_sources, int64_t n_words,
                                   int64_t n_ids, uint64_t* __restrict__ seen, uint64_t* __restrict__ frontier,
                                   uint64_t* __restrict__ next, uint8_t* __restrict__ dist, int32_t* __restrict__ flags,
                                   unsigned long long* __restrict__ fvol, uint32_t* __restrict__ fbits,
-                                  int max_hops)  // dist layout-agnostic: filled as a flat array
+                                  int max_hops, int64_t rs,  // dist layout-agnostic: filled as a flat array
+                                  uint64_t* __restrict__ set_seen, int64_t n_set_words, float* __restrict__ set_out, int64_t n_set_out)
 {
     const int64_t gtid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = gtid; i < 2 * ((n_ids + 31) / 32); i += gsz) fbits[i] = 0;   // frontier nodes | complete nodes
-    for (int64_t i = gtid; i < n_ids * n_words; i += gsz) { seen[i] = 0; frontier[i] = 0; next[i] = 0; }
+    for (int64_t i = gtid; i < n_ids * rs; i += gsz) { seen[i] = 0; frontier[i] = 0; next[i] = 0; }
+    // (the fused set reduction's state too: four memset launches less per search)
+    for (int64_t i = gtid; i < n_set_words; i += gsz) set_seen[i] = 0;
+    for (int64_t i = gtid; i < n_set_out; i += gsz) set_out[i] = 0.f;              // unreachable pairs hold 0
     if (dist) for (int64_t i = gtid; i < n_sources * n_ids; i += gsz) dist[i] = 255;
     for (int64_t i = gtid; i <= max_hops; i += gsz) { flags[i] = (i == 0) ? 1 : 0; fvol[i] = 0; }
 }
 
 __global__ void msbfs_seed_kernel(const int32_t* __restrict__ sources, int64_t n_sources, int64_t n_words,
                                   int64_t n_ids, uint64_t* __restrict__ seen, uint64_t* __restrict__ frontier,
-                                  uint8_t* __restrict__ dist, int64_t ss, int64_t sv, uint32_t* __restrict__ fbits)
+                                  uint8_t* __restrict__ dist, int64_t ss, int64_t sv, uint32_t* __restrict__ fbits, int64_t rs)
 {
     const int64_t s = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (s >= n_sources) return;
     const int32_t v = sources[s];
     atomicOr(&fbits[v >> 5], 1u << (v & 31));                 // level-0 frontier nodes
     const uint64_t bit = 1ull << (s & 63);
-    atomicOr((unsigned long long*)&seen[(int64_t)v * n_words + (s >> 6)], (unsigned long long)bit);
-    atomicOr((unsigned long long*)&frontier[(int64_t)v * n_words + (s >> 6)], (unsigned long long)bit);
+    atomicOr((unsigned long long*)&seen[(int64_t)v * rs + (s >> 6)], (unsigned long long)bit);
+    atomicOr((unsigned long long*)&frontier[(int64_t)v * rs + (s >> 6)], (unsigned long long)bit);
     if (dist) dist[s * ss + v * sv] = 0;
 }
 
@@ -100,15 +109,21 @@ __global__ void msbfs_seed_kernel(const int32_t* __restrict__ sources, int64_t n
 #define MSBFS_HUB_SLOTS 128
 #define MSBFS_PULL_HUB_DEGREE 512
 
+__device__ __forceinline__ uint32_t msbfs_row_or32(uint32_t v)
+{
+    // OR over the 16 lanes of a DPP row by rotations: every lane ends with the full value (no LDS crossbar trips:
+    // the xor-butterfly on __shfl_xor was 8 ds_bpermute per 64-bit word and call)
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xf, 0xf, false);     // row_ror:8
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x124, 0xf, 0xf, false);     // row_ror:4
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x122, 0xf, 0xf, false);     // row_ror:2
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x121, 0xf, 0xf, false);     // row_ror:1
+    return v;
+}
+
 __device__ __forceinline__ uint64_t msbfs_group_or(uint64_t x)
 {
-    // OR over the 16 lanes of a group (xor-butterfly: every lane ends with the full value)
-    for (int off = 8; off >= 1; off >>= 1) {
-        const uint32_t lo = __shfl_xor((int)(uint32_t)x, off, 64);
-        const uint32_t hi = __shfl_xor((int)(uint32_t)(x >> 32), off, 64);
-        x |= ((uint64_t)hi << 32) | lo;
-    }
-    return x;
+    // OR over the 16 lanes of a group (= one DPP row; all lanes of the wavefront must be executing)
+    return ((uint64_t)msbfs_row_or32((uint32_t)(x >> 32)) << 32) | msbfs_row_or32((uint32_t)x);
 }
 
 __global__ __launch_bounds__(256) void msbfs_expand_kernel(
@@ -116,7 +131,7 @@ __global__ __launch_bounds__(256) void msbfs_expand_kernel(
     int64_t n_sources, const uint64_t* __restrict__ seen, const uint64_t* __restrict__ frontier,
     uint64_t* __restrict__ next, const int32_t* __restrict__ flags, const unsigned long long* __restrict__ fvol,
     unsigned long long pull_above, int level, const uint32_t* __restrict__ fnode, unsigned long long sparse_below,
-    const uint32_t* __restrict__ fdone)
+    const uint32_t* __restrict__ fdone, int64_t rs)
 {
     if (flags[level - 1] == 0) return;                       // previous level found nothing
     const int sub = threadIdx.x & 15;
@@ -139,7 +154,7 @@ __global__ __launch_bounds__(256) void msbfs_expand_kernel(
         // and streamed by the whole workgroup afterwards.
         for (int64_t v = group; v < n_ids; v += n_groups) {
             uint64_t any = 0;
-            for (int64_t w = 0; w < n_words; ++w) any |= frontier[v * n_words + w];
+            for (int64_t w = 0; w < n_words; ++w) any |= frontier[v * rs + w];
             if (any == 0) continue;
             // one pass over the neighbour list for all source words: col[] is read once, and the
             // n_words seen/next words of a neighbour are contiguous
@@ -156,9 +171,9 @@ __global__ __launch_bounds__(256) void msbfs_expand_kernel(
             for (int64_t e = r0 + sub; e < r1; e += 16) {
                 const int64_t u = col[e];
                 for (int64_t w = 0; w < n_words; ++w) {
-                    const uint64_t f = frontier[v * n_words + w];
-                    const uint64_t m = f & ~seen[u * n_words + w];
-                    if (m) atomicOr((unsigned long long*)&next[u * n_words + w], (unsigned long long)m);
+                    const uint64_t f = frontier[v * rs + w];
+                    const uint64_t m = f & ~seen[u * rs + w];
+                    if (m) atomicOr((unsigned long long*)&next[u * rs + w], (unsigned long long)m);
                 }
             }
         }
@@ -170,9 +185,9 @@ __global__ __launch_bounds__(256) void msbfs_expand_kernel(
             for (int64_t e = r0 + threadIdx.x; e < r1; e += blockDim.x) {
                 const int64_t u = col[e];
                 for (int64_t w = 0; w < n_words; ++w) {
-                    const uint64_t f = frontier[v * n_words + w];
-                    const uint64_t m = f & ~seen[u * n_words + w];
-                    if (m) atomicOr((unsigned long long*)&next[u * n_words + w], (unsigned long long)m);
+                    const uint64_t f = frontier[v * rs + w];
+                    const uint64_t m = f & ~seen[u * rs + w];
+                    if (m) atomicOr((unsigned long long*)&next[u * rs + w], (unsigned long long)m);
                 }
             }
         }
@@ -193,7 +208,7 @@ __global__ __launch_bounds__(256) void msbfs_expand_kernel(
                 if (w < n_words) {
                     const int64_t left = n_sources - w * 64;
                     valid = left >= 64 ? ~0ull : ((1ull << left) - 1);
-                    valid &= ~seen[v * n_words + w];
+                    valid &= ~seen[v * rs + w];
                 }
                 need[k] = valid;
                 acc[k] = 0;
@@ -217,9 +232,15 @@ __global__ __launch_bounds__(256) void msbfs_expand_kernel(
                     // stays in L2, consulted before the 24-byte gather from the 24 MB word array -- while the
                     // frontier is sparse (once most nodes are on it the test only adds a load)
                     if (!sparse_frontier || ((fnode[u >> 5] >> (u & 31)) & 1u)) {
+                        if (rs == 4) {                       // a padded row = one 32-byte sector: two 16-byte loads, no per-word tests
+                            const ulonglong2 f01 = *reinterpret_cast<const ulonglong2*>(&frontier[u * 4]);
+                            const ulonglong2 f23 = *reinterpret_cast<const ulonglong2*>(&frontier[u * 4 + 2]);
+                            acc[0] |= f01.x; acc[1] |= f01.y; acc[2] |= f23.x; acc[3] |= f23.y;
+                        } else {
 #pragma unroll
-                        for (int k = 0; k < MSBFS_WCHUNK; ++k)
-                            if (need[k]) acc[k] |= frontier[u * n_words + w0 + k];  // completed words are not read
+                            for (int k = 0; k < MSBFS_WCHUNK; ++k)
+                                if (need[k]) acc[k] |= frontier[u * rs + w0 + k];  // completed words are not read
+                        }
                     }
                 }
                 if (++since == 8) {                          // every 128 neighbours: anything still missing?
@@ -235,7 +256,7 @@ __global__ __launch_bounds__(256) void msbfs_expand_kernel(
                 acc[k] = msbfs_group_or(acc[k]);
                 if (sub == k && w0 + k < n_words) {
                     const uint64_t m = acc[k] & need[k];
-                    if (m) next[v * n_words + w0 + k] = m;   // next[] is all zero before a pull level
+                    if (m) next[v * rs + w0 + k] = m;   // next[] is all zero before a pull level
                 }
             }
         }
@@ -256,7 +277,7 @@ __global__ __launch_bounds__(256) void msbfs_expand_kernel(
                 if (w < n_words) {
                     const int64_t left = n_sources - w * 64;
                     valid = left >= 64 ? ~0ull : ((1ull << left) - 1);
-                    valid &= ~seen[v * n_words + w];
+                    valid &= ~seen[v * rs + w];
                 }
                 need[k] = valid;
                 acc[k] = 0;
@@ -268,9 +289,15 @@ __global__ __launch_bounds__(256) void msbfs_expand_kernel(
             for (int64_t e = r0 + threadIdx.x; e < r1; e += blockDim.x) {
                 const int64_t u = col[e];
                 if (!sparse_frontier || ((fnode[u >> 5] >> (u & 31)) & 1u)) {
+                    if (rs == 4) {
+                        const ulonglong2 f01 = *reinterpret_cast<const ulonglong2*>(&frontier[u * 4]);
+                        const ulonglong2 f23 = *reinterpret_cast<const ulonglong2*>(&frontier[u * 4 + 2]);
+                        acc[0] |= f01.x; acc[1] |= f01.y; acc[2] |= f23.x; acc[3] |= f23.y;
+                    } else {
 #pragma unroll
-                    for (int k = 0; k < MSBFS_WCHUNK; ++k)
-                        if (need[k]) acc[k] |= frontier[u * n_words + w0 + k];
+                        for (int k = 0; k < MSBFS_WCHUNK; ++k)
+                            if (need[k]) acc[k] |= frontier[u * rs + w0 + k];
+                    }
                 }
             }
 #pragma unroll
@@ -279,7 +306,7 @@ __global__ __launch_bounds__(256) void msbfs_expand_kernel(
             __syncthreads();
             if (threadIdx.x < MSBFS_WCHUNK && w0 + threadIdx.x < n_words) {
                 const uint64_t m = s_acc[threadIdx.x] & need[threadIdx.x];
-                if (m) next[v * n_words + w0 + threadIdx.x] = m;
+                if (m) next[v * rs + w0 + threadIdx.x] = m;
             }
             __syncthreads();
         }
@@ -290,7 +317,7 @@ __global__ __launch_bounds__(256) void msbfs_commit_kernel(
     const int64_t* __restrict__ rowptr, int64_t n_ids, int64_t n_words, int64_t n_sources, uint64_t* __restrict__ seen,
     uint64_t* __restrict__ frontier, uint64_t* __restrict__ next, uint8_t* __restrict__ dist, int32_t* __restrict__ flags,
     unsigned long long* __restrict__ fvol, int level, int64_t ss, int64_t sv, uint32_t* __restrict__ fcur,
-    uint32_t* __restrict__ fdone)
+    uint32_t* __restrict__ fdone, int64_t rs)
 {
     if (flags[level - 1] == 0) return;
     // One lane per node, a wave per 64 consecutive nodes: the ballot of "some word of my node is new"
@@ -308,7 +335,7 @@ __global__ __launch_bounds__(256) void msbfs_commit_kernel(
         bool done = v < n_ids;
         if (v < n_ids) {
             for (int64_t w = 0; w < n_words; ++w) {
-                const int64_t i = v * n_words + w;
+                const int64_t i = v * rs + w;
                 const uint64_t nx = next[i];
                 const uint64_t sn = seen[i];
                 const uint64_t nw = nx & ~sn;
@@ -366,7 +393,7 @@ __global__ __launch_bounds__(256) void msbfs_commit_kernel(
 
 extern "C" int64_t sgnn_bfs_hops_workspace_bytes(int64_t max_id, int64_t n_sources, int max_hops) {
     const int64_t n_words = (n_sources + 63) / 64;
-    return 3 * (max_id + 1) * n_words * 8 + ((int64_t)max_hops + 2) * 8 + ((int64_t)max_hops + 2) * 4 +
+    return 3 * (max_id + 1) * msbfs_row_stride(n_words) * 8 + ((int64_t)max_hops + 2) * 8 + ((int64_t)max_hops + 2) * 4 +
            8 + 2 * ((max_id + 32) / 32) * 4;                      // + two frontier-node bitmaps
 }
 
@@ -377,17 +404,21 @@ extern "C" int64_t sgnn_bfs_hops_workspace_bytes(int64_t max_id, int64_t n_sourc
 __global__ __launch_bounds__(256) void msbfs_set_reduce_kernel(
     const uint64_t* __restrict__ frontier, int64_t n_words, int64_t n_sources,
     const int64_t* __restrict__ set_ptr, const int32_t* __restrict__ set_nodes, int64_t n_sets,
-    uint64_t* __restrict__ set_seen, float* __restrict__ out, const int32_t* __restrict__ flags, int level)
+    uint64_t* __restrict__ set_seen, float* __restrict__ out, const int32_t* __restrict__ flags, int level, int64_t rs)
 {
     if (level > 0 && flags[level] == 0) return;              // this level found nothing
     const int64_t total = n_sets * n_words;
     for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
         const int64_t r = t / n_words, w = t % n_words;
         uint64_t acc = 0;
-        for (int64_t i = set_ptr[r]; i < set_ptr[r + 1]; ++i) acc |= frontier[(int64_t)set_nodes[i] * n_words + w];
-        const uint64_t fresh = acc & ~set_seen[t];
+        const int64_t left_ = n_sources - w * 64;
+        const uint64_t full_ = left_ >= 64 ? ~0ull : ((1ull << left_) - 1);
+        const uint64_t have_ = set_seen[t];
+        if ((have_ & full_) == full_) continue;              // every source has reached the set: nothing left to record
+        for (int64_t i = set_ptr[r]; i < set_ptr[r + 1]; ++i) acc |= frontier[(int64_t)set_nodes[i] * rs + w];
+        const uint64_t fresh = acc & ~have_;
         if (fresh) {
-            set_seen[t] |= fresh;
+            set_seen[t] = have_ | fresh;
             uint64_t bits = fresh;
             while (bits) {
                 const int b = __ffsll((unsigned long long)bits) - 1;
@@ -404,13 +435,13 @@ __global__ __launch_bounds__(256) void msbfs_set_reduce_kernel(
 // the last level: AND the members' seen words, zero the sources missing from it.
 __global__ __launch_bounds__(256) void msbfs_set_finalize_kernel(
     const uint64_t* __restrict__ seen, int64_t n_words, int64_t n_sources,
-    const int64_t* __restrict__ set_ptr, const int32_t* __restrict__ set_nodes, int64_t n_sets, float* __restrict__ out)
+    const int64_t* __restrict__ set_ptr, const int32_t* __restrict__ set_nodes, int64_t n_sets, float* __restrict__ out, int64_t rs)
 {
     const int64_t total = n_sets * n_words;
     for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
         const int64_t r = t / n_words, w = t % n_words;
         uint64_t all = ~0ull;
-        for (int64_t i = set_ptr[r]; i < set_ptr[r + 1]; ++i) all &= seen[(int64_t)set_nodes[i] * n_words + w];
+        for (int64_t i = set_ptr[r]; i < set_ptr[r + 1]; ++i) all &= seen[(int64_t)set_nodes[i] * rs + w];
         uint64_t missing = ~all;
         while (missing) {
             const int b = __ffsll((unsigned long long)missing) - 1;
@@ -442,30 +473,29 @@ static int msbfs_run(const int64_t* rowptr, const int32_t* col, int64_t nnz, int
     const int64_t n_ids = max_id + 1;
     const int64_t n_words = (n_sources + 63) / 64;
     const int64_t ss = node_major ? 1 : n_ids, sv = node_major ? n_sources : 1;
+    const int64_t rs = msbfs_row_stride(n_words);
     uint64_t* seen = (uint64_t*)workspace;
-    uint64_t* frontier = seen + n_ids * n_words;
-    uint64_t* next = frontier + n_ids * n_words;
-    unsigned long long* fvol = (unsigned long long*)(next + n_ids * n_words);
+    uint64_t* frontier = seen + n_ids * rs;
+    uint64_t* next = frontier + n_ids * rs;
+    unsigned long long* fvol = (unsigned long long*)(next + n_ids * rs);
     int32_t* flags = (int32_t*)(fvol + max_hops + 2);
     uint32_t* fbits = (uint32_t*)(((uintptr_t)(flags + max_hops + 2) + 7) & ~(uintptr_t)7);
     const int64_t fwords = (n_ids + 31) / 32;
     uint64_t* set_seen = (uint64_t*)(((uintptr_t)(fbits + 2 * fwords) + 7) & ~(uintptr_t)7);
     const unsigned long long pull_above =
         g_bfs_alpha > 0 ? (unsigned long long)((nnz * n_words) / g_bfs_alpha) : ~0ull;
-    const int big = sgnn_grid_for(n_ids * ((dist && n_sources > n_words) ? n_sources : n_words), 256);
+    const int big = sgnn_grid_for(n_ids * ((dist && n_sources > rs) ? n_sources : rs), 256);
     hipLaunchKernelGGL(msbfs_init_kernel, dim3(big), dim3(256), 0, st, sources, n_sources, n_words, n_ids, seen,
-                       frontier, next, dist, flags, fvol, fbits, max_hops);
+                       frontier, next, dist, flags, fvol, fbits, max_hops, rs, set_seen, set_out ? n_sets * n_words : 0,
+                       set_out, set_out ? n_sets * n_sources : 0);
     SGNN_CHECK_LAUNCH();
     hipLaunchKernelGGL(msbfs_seed_kernel, dim3((int)((n_sources + 255) / 256)), dim3(256), 0, st, sources, n_sources,
-                       n_words, n_ids, seen, frontier, dist, ss, sv, fbits);
+                       n_words, n_ids, seen, frontier, dist, ss, sv, fbits, rs);
     SGNN_CHECK_LAUNCH();
     const int g_sets = set_out ? sgnn_grid_for(n_sets * n_words, 256) : 0;
     if (set_out) {
-        hipError_t me = hipMemsetAsync(set_seen, 0, (size_t)(n_sets * n_words * 8), st);
-        if (me == hipSuccess) me = hipMemsetAsync(set_out, 0, (size_t)(n_sets * n_sources * 4), st);  // unreachable pairs hold 0
-        if (me != hipSuccess) { sgnn_set_last_error(me); return SGNN_ERR_LAUNCH; }
         hipLaunchKernelGGL(msbfs_set_reduce_kernel, dim3(g_sets), dim3(256), 0, st, frontier, n_words, n_sources, set_ptr,
-                           set_nodes, n_sets, set_seen, set_out, flags, 0);
+                           set_nodes, n_sets, set_seen, set_out, flags, 0, rs);
         SGNN_CHECK_LAUNCH();
     }
     const int g_expand = sgnn_grid_for(n_ids * 16, 256);
@@ -473,20 +503,20 @@ static int msbfs_run(const int64_t* rowptr, const int32_t* col, int64_t nnz, int
     for (int level = 1; level <= max_hops; ++level) {
         hipLaunchKernelGGL(msbfs_expand_kernel, dim3(g_expand), dim3(256), 0, st, rowptr, col, n_ids, n_words, n_sources,
                            seen, frontier, next, flags, fvol, pull_above, level, fbits,
-                           (unsigned long long)((nnz * n_words) / 4), fbits + fwords);
+                           (unsigned long long)((nnz * n_words) / 4), fbits + fwords, rs);
         SGNN_CHECK_LAUNCH();
         hipLaunchKernelGGL(msbfs_commit_kernel, dim3(g_commit), dim3(256), 0, st, rowptr, n_ids, n_words, n_sources, seen,
-                           frontier, next, dist, flags, fvol, level, ss, sv, fbits, fbits + fwords);
+                           frontier, next, dist, flags, fvol, level, ss, sv, fbits, fbits + fwords, rs);
         SGNN_CHECK_LAUNCH();
         if (set_out) {
             hipLaunchKernelGGL(msbfs_set_reduce_kernel, dim3(g_sets), dim3(256), 0, st, frontier, n_words, n_sources,
-                               set_ptr, set_nodes, n_sets, set_seen, set_out, flags, level);
+                               set_ptr, set_nodes, n_sets, set_seen, set_out, flags, level, rs);
             SGNN_CHECK_LAUNCH();
         }
     }
     if (set_out) {
         hipLaunchKernelGGL(msbfs_set_finalize_kernel, dim3(g_sets), dim3(256), 0, st, seen, n_words, n_sources, set_ptr,
-                           set_nodes, n_sets, set_out);
+                           set_nodes, n_sets, set_out, rs);
         SGNN_CHECK_LAUNCH();
     }
     if (status) {
