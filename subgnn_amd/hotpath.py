@@ -132,6 +132,32 @@ def check_pending(model):
     return None
 
 
+def _pint_sims_streamed(g, uniq, inv, cc_sets, S, C, max_hops, chunk_bytes=1 << 30):
+    """P-internal similarities of multi-component subgraphs when the (distinct anchors x nodes) hop table would not fit
+    (round 2 raised NotImplementedError above 16 GiB; the reference has no such limit short of its N x N matrix,
+    SubGNN.py:752-781): the distinct anchors go through the fused search ``sgnn_bfs_min_hops_to_sets`` a block of
+    sources at a time -- no hop table, the largest temporary is (S*C, block) floats -- and every (subgraph, slot)
+    whose anchor falls into the block takes its column.  One multi-source BFS per block: slow for millions of distinct
+    anchors, but bounded in memory."""
+    U = int(uniq.numel())
+    rows = S * C
+    block = max(64, min(U, (chunk_bytes // (4 * max(rows, 1))) // 64 * 64))
+    w = torch.zeros((S, C, inv.shape[1]), dtype=torch.float32, device=inv.device)
+    src = uniq.to(torch.int32).contiguous()
+    rix = (torch.arange(S, device=inv.device).view(S, 1, 1) * C + torch.arange(C, device=inv.device).view(1, C, 1))
+    for a in range(0, U, block):
+        b = min(U, a + block)
+        part, status = ops.bfs_min_hops_to_sets(g, src[a:b], cc_sets, max_hops=max_hops, want_status=True)   # (S*C, b - a)
+        if int(status[1]):
+            raise RuntimeError('position-channel BFS: level %d still reached new nodes -- hparams["max_bfs_hops"] = %d '
+                               'is smaller than the depth of this graph from the anchors' % (max_hops, max_hops))
+        hit = (inv >= a) & (inv < b)                                               # (S, A)
+        col = (inv - a).clamp(0, b - a - 1).view(S, 1, -1).expand(S, C, -1)
+        got = part[rix.expand(S, C, inv.shape[1]), col]
+        w = torch.where(hit.view(S, 1, -1), got, w)
+    return w
+
+
 def _dealt_position_sims(g, anchors, cc_sets, cc_ids, shard, max_hops):
     """P-border similarities with the BFS sources dealt across ranks (strong scaling): this rank runs the
     multi-source BFS for ITS share of the shared anchors only -- one 64-source word instead of
@@ -290,14 +316,13 @@ def prepare_pass(model, split='train', timer=None, shard=None, defer_dtw=False):
                     sims[('P', 'in', l)] = ops.ZeroSims((S, C, hp['n_anchor_patches_pos_in']), dev)
                 else:
                     uniq, inv = torch.unique(pint[l], return_inverse=True)
-                    if uniq.numel() * (g.max_id + 1) > MAX_PINT_BYTES:
-                        raise NotImplementedError('sparse P-internal similarities for multi-component subgraphs need '
-                                                  'a BFS per distinct anchor: %d sources x %d nodes exceeds the %d GiB '
-                                                  'hop-table budget' % (uniq.numel(), g.max_id + 1, MAX_PINT_BYTES >> 30))
-                    d = ops.bfs_hops(g, uniq.to(torch.int32).contiguous(), max_hops=hp.get('max_bfs_hops', 32),
-                                     node_major=True)
-                    full = ops.min_hops_to_sets(d, cc_sets, node_major=True).view(S, C, -1)     # (S, C, U)
-                    w = torch.gather(full, 2, inv.view(S, 1, -1).expand(S, C, -1))
+                    if uniq.numel() * (g.max_id + 1) <= MAX_PINT_BYTES:
+                        d = ops.bfs_hops(g, uniq.to(torch.int32).contiguous(), max_hops=hp.get('max_bfs_hops', 32),
+                                         node_major=True)
+                        full = ops.min_hops_to_sets(d, cc_sets, node_major=True).view(S, C, -1)     # (S, C, U)
+                        w = torch.gather(full, 2, inv.view(S, 1, -1).expand(S, C, -1))
+                    else:
+                        w = _pint_sims_streamed(g, uniq, inv, cc_sets, S, C, hp.get('max_bfs_hops', 32))
                     sims[('P', 'in', l)] = (w * real.unsqueeze(-1)).contiguous()
             if side is main:
                 t.mark('P_bfs_sims')
