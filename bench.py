@@ -252,11 +252,13 @@ def main():
             # every rank's loss is the mean over its own (equally many) subgraphs: the global mean is the mean of
             # those, and so are all gradients (the table's: ShardedTableAdam(average=True))
             sdist.all_reduce_gradients(small, average=True)
+        timer.mark('coll_small_gradients_all_reduce')
         sq = table_opt.reduce_grad()
+        timer.mark('coll_table_gradient_reduce_scatter')
         torch.distributed.all_reduce(sq)
         total = torch.sqrt(sq + sum((p.grad.float() ** 2).sum() for p in small if p.grad is not None))
         coef = torch.clamp(hp['grad_clip'] / (total + 1e-6), max=1.0)         # clip_grad_norm_'s rule on the global norm
-        timer.mark('collectives')
+        timer.mark('coll_norm_all_reduce')
         for p in small:
             if p.grad is not None:
                 p.grad.mul_(coef)
@@ -323,6 +325,41 @@ def main():
         for i, tm in enumerate(timers):
             print('step', i, {k: round(v, 3) for k, v in tm.summary().items()}, file=sys.stderr)
             print('     host', {k: round(v, 3) for k, v in tm.host_summary().items()}, file=sys.stderr)
+
+    # ---- N > 1: what crossed the links, and north_star's exchange timed in this very run ---------------------------
+    collectives = None
+    if multi:
+        # "RCCL all-gather of per-channel embeddings over xGMI" (BASELINE.json north_star): the (components, hid_dim) fp32
+        # embeddings of this rank's shard gathered from every rank -- the collective the replicated head consumes inside
+        # the step (--head replicated); with the default sharded head nothing needs it, so it is timed here on its own,
+        # same shapes, same communicator, right after the timed steps
+        rows = int(model.train_cc_ids.shape[0] * model.train_cc_ids.shape[1])
+        x = torch.randn(rows, model.hid_dim, device=dev)
+        sdist.all_gather_rows(x, equal_rows=True)
+        torch.cuda.synchronize()
+        g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        g0.record()
+        for _ in range(5):
+            gathered = sdist.all_gather_rows(x, equal_rows=True)
+        g1.record()
+        torch.cuda.synchronize()
+        ns = torch.tensor([g0.elapsed_time(g1) / 5], device=dev, dtype=torch.float64)
+        dist.all_reduce(ns, op=dist.ReduceOp.MAX)
+        ns_ms = float(ns.item())
+        per_rank = rows * model.hid_dim * 4
+        collectives = {
+            'rccl_ranks': dist.get_world_size(), 'backend': dist.get_backend(),
+            'per_step_ms': {k[5:]: round(v, 3) for k, v in stage_ms.items() if k.startswith('coll_')},
+            'table_all_gather_wait_ms': round(stage_ms.get('table_all_gather_wait', 0.0), 3),
+            'table_bytes': int(table.numel() * 4),
+            'north_star_exchange': {
+                'what': 'all-gather of the per-component channel embeddings (rows_per_rank, hid_dim) fp32 from every rank '
+                        '(dist.all_gather_rows: what dist.gather_rows_replicated issues for the replicated head)',
+                'rows_per_rank': rows, 'hid_dim': int(model.hid_dim), 'bytes_per_rank': per_rank,
+                'gathered_rows': int(gathered.shape[0]), 'ms': round(ns_ms, 3),
+                'algbw_GBs': round(per_rank * (world - 1) / (ns_ms * 1e-3) / 1e9, 1) if ns_ms > 0 else None,
+                'inside_the_timed_step': bool(replicated)}}
+        del x, gathered
 
     # ---- roofline of the structure-channel CSR gather, measured live ------------------------
     cc_ids = model.train_cc_ids
@@ -433,6 +470,7 @@ def main():
                              'it actually reads).  out_of_cache: the same kernel on a BA n=8M m=16 graph (CSR 1.09 GB), '
                              'tools/degseq_hbm_probe.py + rocprofv3 counters, profiles/r02_degseq_traffic.json'},
         'longest_kernel': longest,
+        'collectives': collectives,
         'stages_ms': {k: round(v, 3) for k, v in stage_ms.items()},
         'stages_note': ('HIP-event time per stage on the stream it runs on; ' + ('pipelined: the preparation stages (components ... dtw) of pass k+1 '
                         'run on a second stream beside cc_embed / forward / backward / optimizer of pass k, which stretch each other -- '

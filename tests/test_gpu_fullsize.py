@@ -126,3 +126,53 @@ def test_walks_follow_edges_and_dtw_properties(full):
     ref = cbind.fastdtw_sim(xp, xf, ypp, yf, 0).reshape(40, 5)
     got = sim[torch.from_numpy(rows).to(DEV)][:, torch.from_numpy(cols_).to(DEV)].cpu().numpy()
     assert np.array_equal(got, ref)
+
+
+def test_one_shard_of_the_benchmark_reproduces_its_slice_of_the_unsharded_pass(full):
+    """BASELINE configs[3] as worded ("50k subgraphs, sharded across 8 x MI355X"): ONE of the eight 6 250-subgraph shards
+    of the 1M-node / 50k-subgraph workload (rank 3), prepared on its own with dist.Shard -- draws keyed by the global
+    subgraph numbers, padded widths as the all-reduce over the eight ranks would give them -- against the same slice of
+    the unsharded pass: component tensors, every anchor tensor, every similarity, bit for bit."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..'))
+    from bench import ALL_DENSITY_HP
+    from subgnn_amd import hotpath, ops
+    from subgnn_amd import dist as sdist
+    from subgnn_amd.SubGNN import SubGNN
+    g, subs = full['g'], full['subs']
+    hp = dict(ALL_DENSITY_HP)
+    emb = torch.randn(N, hp['node_embed_size'], generator=torch.Generator().manual_seed(0)).to(DEV)
+    labels = torch.randint(0, 3, (S,), generator=torch.Generator().manual_seed(0))
+    labels[:3] = torch.tensor([0, 1, 2])
+
+    def model(sub_lists, lab):
+        torch.manual_seed(0)
+        return SubGNN.from_memory(dict(hp), g, {'train': sub_lists, 'val': [], 'test': []},
+                                  {'train': lab, 'val': lab[:0], 'test': lab[:0]}, emb, num_classes=3)
+    whole = model(subs, labels)
+    hotpath.prepare_sparse(whole, 'train')
+    Sx, C, L = whole.train_cc_ids.shape
+    assert (Sx, C) == (S, 1)
+    width = ops.khop_border(g, ops.Ragged.from_padded(whole.train_cc_ids.reshape(S * C, L)), 1).lengths.max().view(1)
+    dims = torch.tensor([C, L], device=DEV)
+
+    class PlayedShard(sdist.Shard):                     # the MAX over ranks, known here from the unsharded pass
+        def reduce_max(self, t):
+            return torch.maximum(t, (dims if t.numel() == 2 else width).to(t.dtype))
+    sh = PlayedShard(S, 3, 8, collectives=False)
+    a, b = sh.start, sh.stop
+    assert b - a == 6250
+    part = model(subs[a:b], labels[a:b])
+    hotpath.prepare_sparse(part, 'train', shard=sh)
+    assert torch.equal(part.train_cc_ids, whole.train_cc_ids[a:b])
+    for l in range(hp['n_layers']):
+        assert torch.equal(part.anchors_neigh_int['train'][l], whole.anchors_neigh_int['train'][l][a:b])
+        assert torch.equal(part.anchors_neigh_border['train'][l], whole.anchors_neigh_border['train'][l][a:b])
+        assert torch.equal(part.anchors_pos_int['train'][l], whole.anchors_pos_int['train'][l][a:b])
+        assert torch.equal(part.anchors_pos_ext[l], whole.anchors_pos_ext[l])
+        for key in (('N', 'out', l), ('P', 'out', l)):
+            assert torch.equal(part.train_neigh_pos_similarities[key], whole.train_neigh_pos_similarities[key][a:b]), key
+    assert torch.equal(part.structure_anchors, whole.structure_anchors)
+    assert torch.equal(part.train_int_struc_similarities, whole.train_int_struc_similarities[a:b])
+    assert torch.equal(part.train_bor_struc_similarities, whole.train_bor_struc_similarities[a:b])
+    assert float(part.train_bor_struc_similarities.abs().sum()) > 0
