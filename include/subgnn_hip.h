@@ -82,7 +82,7 @@ int sgnn_degree_sequence_sorted_rows(const int64_t* rowptr, const int32_t* col, 
  * ------------------------------------------------------------------------------------- */
 int sgnn_cc_labels(const int64_t* rowptr, const int32_t* col_sorted, int64_t nnz,
                    const int64_t* sub_ptr, const int32_t* sub_nodes, int64_t n_subgraphs,
-                   int64_t max_sub_len /* longest subgraph, <= 2048; 0 = unknown */,
+                   int64_t max_sub_len /* longest subgraph, 0 = unknown; subgraphs > 2048 nodes get -1: sgnn_cc_labels_huge */,
                    int32_t* out_label, void* stream);
 /* Canonical order inside every set: ids ascending, equal ids in their original relative order.
  * The neighbourhood-anchor draw ranks "the ascending members" of a component / border set where the
@@ -96,12 +96,27 @@ int sgnn_sort_sets(const int64_t* set_ptr, const int32_t* set_nodes, int64_t n_s
  * canonical order: components by the position of their first node, nodes in subgraph order,
  * duplicates dropped, PAD = 0.  Two steps: _stats gives, per subgraph, the number of components and
  * the longest one (the caller takes the maxima C and L and zero-fills out (n_subgraphs, C, L) int64);
- * sgnn_cc_compact writes the ids.  max_sub_len: longest subgraph (<= 2048; 0 = unknown). */
+ * sgnn_cc_compact writes the ids.  max_sub_len: longest subgraph (0 = unknown); subgraphs of more than 2048 nodes are
+ * skipped here and served by sgnn_cc_compact_huge below. */
 int sgnn_cc_compact_stats(const int64_t* sub_ptr, const int32_t* sub_nodes, const int32_t* labels,
                           int64_t n_subgraphs, int64_t max_sub_len, int32_t* out_n_components,
                           int32_t* out_longest, void* stream);
 int sgnn_cc_compact(const int64_t* sub_ptr, const int32_t* sub_nodes, const int32_t* labels,
                     int64_t n_subgraphs, int64_t max_sub_len, int64_t C, int64_t L, int64_t* out, void* stream);
+/* The same three steps for subgraphs of MORE than 2048 nodes (the reference pads to any size, SubGNN/SubGNN.py:575-607):
+ * the calls above leave such subgraphs alone (labels -1, no statistics, no rows) and these fill them in -- call them
+ * after their counterpart on the same stream.  State lives in the caller's workspace
+ * (sgnn_cc_huge_workspace_bytes(total_nodes), total_nodes = sub_ptr[n_subgraphs]; any content): id -> first position
+ * table, union-find parents, ranks, counters, each subgraph at its own offset.  sgnn_cc_compact_huge: write == 0 gives
+ * the statistics (out_n_components / out_longest), write != 0 the rows of out (n_subgraphs, C, L). */
+int64_t sgnn_cc_huge_workspace_bytes(int64_t total_nodes);
+int sgnn_cc_labels_huge(const int64_t* rowptr, const int32_t* col, int64_t nnz, const int64_t* sub_ptr,
+                        const int32_t* sub_nodes, int64_t n_subgraphs, int64_t total_nodes, int32_t* out_label,
+                        void* workspace, int64_t workspace_bytes, void* stream);
+int sgnn_cc_compact_huge(const int64_t* sub_ptr, const int32_t* sub_nodes, const int32_t* labels,
+                         int64_t n_subgraphs, int64_t total_nodes, int write, int64_t C, int64_t L,
+                         int32_t* out_n_components, int32_t* out_longest, int64_t* out, void* workspace,
+                         int64_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * a8  k-hop border of a component, and the hop level of each border node.
@@ -215,6 +230,15 @@ int sgnn_patch_in_border(const int64_t* rowptr, const int32_t* col, int64_t nnz,
                          const int32_t* node_order, const int32_t* node_pos, int64_t n_nodes,
                          const int64_t* patch_ptr, const int32_t* patch_nodes, int64_t n_patches,
                          uint8_t* out_flag, void* stream);
+/* Patches of more than 2048 nodes (ego-graph patches around hubs): the call above marks their flags 255 and this one,
+ * issued after it on the same stream, fills them in; the membership table lives in the workspace
+ * (sgnn_patch_in_border_huge_workspace_bytes(total_nodes), total_nodes = patch_ptr[n_patches]). */
+int64_t sgnn_patch_in_border_huge_workspace_bytes(int64_t total_nodes);
+int sgnn_patch_in_border_huge(const int64_t* rowptr, const int32_t* col, int64_t nnz,
+                              const int32_t* node_order, const int32_t* node_pos, int64_t n_nodes,
+                              const int64_t* patch_ptr, const int32_t* patch_nodes, int64_t n_patches,
+                              int64_t total_nodes, uint8_t* out_flag, void* workspace, int64_t workspace_bytes,
+                              void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * a9  Shortest-path similarities.

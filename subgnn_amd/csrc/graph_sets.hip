@@ -189,8 +189,7 @@ static int cc_compact_launch(bool write, const int64_t* sub_ptr, const int32_t* 
                              int32_t* out_maxlen, int64_t* out, void* stream)
 {
     if (!sub_ptr || !sub_nodes || !labels || n_sub < 0) return SGNN_ERR_BAD_ARG;
-    if (max_sub_len > CC_MAX) return SGNN_ERR_SET_TOO_LARGE;
-    if (n_sub == 0) return SGNN_OK;
+    if (n_sub == 0) return SGNN_OK;                             // (subgraphs of more than CC_MAX nodes: sgnn_cc_compact_huge)
     hipStream_t st = (hipStream_t)stream;
     const int grid = (int)(n_sub < 256 * 64 ? n_sub : 256 * 64);
     if (write) {
@@ -225,6 +224,230 @@ extern "C" int sgnn_cc_compact(const int64_t* sub_ptr, const int32_t* sub_nodes,
     if (!out || C < 1 || L < 1) return SGNN_ERR_BAD_ARG;
     return cc_compact_launch(true, sub_ptr, sub_nodes, labels, n_subgraphs, max_sub_len, C, L, nullptr, nullptr, out,
                              stream);
+}
+
+// ---------------------------------------------------------------------------------------------
+// a7 for subgraphs of MORE than CC_MAX nodes (round 3: rounds 1-2 refused them; the reference pads to any size,
+// SubGNN/SubGNN.py:575-607).  The LDS tables of the kernels above do not hold such a set and their all-pairs test is
+// quadratic, so these take another route, one 256-thread workgroup per subgraph with its state in a caller workspace:
+// node id -> smallest position in an open-addressing table (2-4 slots per node), union-find parents in global memory,
+// and the induced edges found by streaming the members' neighbour lists against the table (work ~ sum of degrees).
+// Compaction: component rank = roots at smaller positions (a running workgroup scan), position inside a component =
+// members of the same component before me, counted chunk by chunk of 256 positions in subgraph order.
+// Layout of the workspace for a call over `total` nodes (sub_ptr[n_sub]): hkey[4 total] | hpos[4 total] | parent[total] |
+// rank[total] | cnt[total]  (int32 each); subgraph s uses the slices at its own offset, so no two workgroups meet.
+// ---------------------------------------------------------------------------------------------
+#define CCH_THREADS 256
+
+extern "C" int64_t sgnn_cc_huge_workspace_bytes(int64_t total_nodes)
+{
+    return (total_nodes < 0 ? 0 : total_nodes) * 11 * 4 + 64;
+}
+
+struct CchRegion { int32_t* hk; int32_t* hv; int32_t* par; int32_t* rank; int32_t* cnt; uint32_t H; };
+
+__device__ static inline CchRegion cch_region(int32_t* ws, int64_t total, int64_t beg, int n)
+{
+    CchRegion r;
+    r.hk = ws + 4 * beg;
+    r.hv = ws + 4 * total + 4 * beg;
+    r.par = ws + 8 * total + beg;
+    r.rank = ws + 9 * total + beg;
+    r.cnt = ws + 10 * total + beg;
+    uint32_t H = 1;
+    while (H < 2u * (uint32_t)n) H <<= 1;                      // <= 4 n
+    r.H = H;
+    return r;
+}
+
+__device__ static inline void cch_build_table(const CchRegion& r, const int32_t* __restrict__ nodes, int n)
+{
+    for (uint32_t i = threadIdx.x; i < r.H; i += CCH_THREADS) { r.hk[i] = 0; r.hv[i] = 0x7fffffff; }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += CCH_THREADS) {
+        const int32_t v = nodes[i];
+        uint32_t h = sgnn_hash32((uint32_t)v) & (r.H - 1);
+        while (true) {
+            const int32_t old = atomicCAS(&r.hk[h], 0, v);
+            if (old == 0 || old == v) { atomicMin(&r.hv[h], i); break; }
+            h = (h + 1) & (r.H - 1);
+        }
+    }
+    __syncthreads();
+}
+
+__device__ static inline int cch_lookup(const CchRegion& r, int32_t v)     // smallest position of id v in the set, -1 = absent
+{
+    uint32_t h = sgnn_hash32((uint32_t)v) & (r.H - 1);
+    while (true) {
+        const int32_t k = r.hk[h];
+        if (k == v) return r.hv[h];
+        if (k == 0) return -1;
+        h = (h + 1) & (r.H - 1);
+    }
+}
+
+__device__ static inline void cch_union(int32_t* par, int x, int y)
+{
+    while (true) {
+        x = cc_find(par, x);
+        y = cc_find(par, y);
+        if (x == y) return;
+        if (x < y) { const int t = x; x = y; y = t; }           // hook the larger root under the smaller: root = smallest position
+        if (atomicCAS(&par[x], x, y) == x) return;
+    }
+}
+
+__global__ __launch_bounds__(CCH_THREADS) void cc_huge_labels_kernel(
+    const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col, const int64_t* __restrict__ sub_ptr,
+    const int32_t* __restrict__ sub_nodes, int64_t n_sub, int32_t* __restrict__ out_label, int32_t* __restrict__ ws)
+{
+    const int64_t total = sub_ptr[n_sub];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int64_t s = blockIdx.x; s < n_sub; s += gridDim.x) {
+        const int64_t beg = sub_ptr[s];
+        const int n = (int)(sub_ptr[s + 1] - beg);
+        if (n <= CC_MAX) continue;                              // sgnn_cc_labels owns those
+        const CchRegion r = cch_region(ws, total, beg, n);
+        const int32_t* nodes = sub_nodes + beg;
+        for (int i = threadIdx.x; i < n; i += CCH_THREADS) r.par[i] = i;
+        cch_build_table(r, nodes, n);
+        // a member's list by one wavefront: every neighbour that is in the set joins the member's component;
+        // a repeated id joins its first occurrence
+        for (int i = wave; i < n; i += CCH_THREADS / 64) {
+            const int32_t v = nodes[i];
+            const int first = cch_lookup(r, v);
+            if (first != i) { if (lane == 0) cch_union(r.par, i, first); continue; }
+            const int64_t a = rowptr[v], b = rowptr[v + 1];
+            for (int64_t e = a + lane; e < b; e += 64) {
+                const int j = cch_lookup(r, col[e]);
+                if (j >= 0 && j != i) cch_union(r.par, i, j);
+            }
+        }
+        __threadfence_block();
+        __syncthreads();
+        for (int i = threadIdx.x; i < n; i += CCH_THREADS) out_label[beg + i] = cc_find(r.par, i);
+        __syncthreads();
+    }
+}
+
+template <bool WRITE>
+__global__ __launch_bounds__(CCH_THREADS) void cc_huge_compact_kernel(
+    const int64_t* __restrict__ sub_ptr, const int32_t* __restrict__ sub_nodes, const int32_t* __restrict__ labels,
+    int64_t n_sub, int64_t C, int64_t L, int32_t* __restrict__ out_ncc, int32_t* __restrict__ out_maxlen,
+    int64_t* __restrict__ out, int32_t* __restrict__ ws)
+{
+    __shared__ int32_t s_scan[CCH_THREADS];
+    __shared__ int32_t s_my[CCH_THREADS];
+    __shared__ int32_t s_red[CCH_THREADS];
+    const int64_t total = sub_ptr[n_sub];
+    const int tid = threadIdx.x;
+    for (int64_t s = blockIdx.x; s < n_sub; s += gridDim.x) {
+        const int64_t beg = sub_ptr[s];
+        const int n = (int)(sub_ptr[s + 1] - beg);
+        if (n <= CC_MAX) continue;
+        const CchRegion r = cch_region(ws, total, beg, n);
+        const int32_t* nodes = sub_nodes + beg;
+        const int32_t* lab = labels + beg;
+        for (int i = tid; i < n; i += CCH_THREADS) r.cnt[i] = 0;
+        cch_build_table(r, nodes, n);
+        // ranks of the roots: a running scan over the positions, 256 at a time
+        int running = 0;
+        for (int c0 = 0; c0 < n; c0 += CCH_THREADS) {
+            const int i = c0 + tid;
+            const int root = (i < n && lab[i] == i) ? 1 : 0;
+            s_scan[tid] = root;
+            __syncthreads();
+            for (int d = 1; d < CCH_THREADS; d <<= 1) {
+                const int t = tid >= d ? s_scan[tid - d] : 0;
+                __syncthreads();
+                s_scan[tid] += t;
+                __syncthreads();
+            }
+            if (root) r.rank[i] = running + s_scan[tid] - 1;
+            running += s_scan[CCH_THREADS - 1];
+            __syncthreads();
+        }
+        __threadfence_block();
+        __syncthreads();
+        // positions inside the components, in subgraph order
+        int maxlen = 0;
+        for (int c0 = 0; c0 < n; c0 += CCH_THREADS) {
+            const int i = c0 + tid;
+            int32_t v = 0, lb = -1;
+            bool keep = i < n;
+            if (keep) { v = nodes[i]; lb = lab[i]; keep = cch_lookup(r, v) == i; }       // repeated ids: first occurrence only
+            s_my[tid] = keep ? lb : -1 - tid;                   // distinct sentinels for dropped positions
+            __syncthreads();
+            int before = 0;
+            bool later = false;
+            const int lim = (n - c0) < CCH_THREADS ? (n - c0) : CCH_THREADS;
+            if (keep) {
+                for (int l = 0; l < lim; ++l) {
+                    const int32_t o = s_my[l];
+                    before += (o == lb && l < tid) ? 1 : 0;
+                    later = later || (o == lb && l > tid);
+                }
+            }
+            int within = 0;
+            if (keep) within = r.cnt[lb] + before;
+            __syncthreads();
+            if (keep && !later) r.cnt[lb] = within + 1;          // the component's last member of this chunk
+            if (keep) {
+                maxlen = within + 1 > maxlen ? within + 1 : maxlen;
+                if (WRITE) out[((int64_t)s * C + r.rank[lb]) * L + within] = (int64_t)v;
+            }
+            __threadfence_block();
+            __syncthreads();
+        }
+        if (!WRITE) {
+            s_red[tid] = maxlen;
+            __syncthreads();
+            for (int d = CCH_THREADS / 2; d >= 1; d >>= 1) {
+                if (tid < d) s_red[tid] = s_red[tid] > s_red[tid + d] ? s_red[tid] : s_red[tid + d];
+                __syncthreads();
+            }
+            if (tid == 0) { out_ncc[s] = running; out_maxlen[s] = s_red[0]; }
+        }
+        __syncthreads();
+    }
+}
+
+extern "C" int sgnn_cc_labels_huge(const int64_t* rowptr, const int32_t* col, int64_t nnz, const int64_t* sub_ptr,
+                                   const int32_t* sub_nodes, int64_t n_subgraphs, int64_t total_nodes, int32_t* out_label,
+                                   void* workspace, int64_t workspace_bytes, void* stream)
+{
+    if (!rowptr || !col || !sub_ptr || !sub_nodes || !out_label || !workspace || n_subgraphs < 0 || total_nodes < 0)
+        return SGNN_ERR_BAD_ARG;
+    if (nnz >= (1ll << 31)) return SGNN_ERR_NNZ_TOO_LARGE;
+    if (total_nodes >= (1ll << 28)) return SGNN_ERR_SET_TOO_LARGE;          // 4 x total must index with 32 bits
+    if (workspace_bytes < sgnn_cc_huge_workspace_bytes(total_nodes)) return SGNN_ERR_BAD_ARG;
+    if (n_subgraphs == 0) return SGNN_OK;
+    hipLaunchKernelGGL(cc_huge_labels_kernel, dim3((int)(n_subgraphs < 1024 ? n_subgraphs : 1024)), dim3(CCH_THREADS), 0,
+                       (hipStream_t)stream, rowptr, col, sub_ptr, sub_nodes, n_subgraphs, out_label, (int32_t*)workspace);
+    SGNN_CHECK_LAUNCH();
+    return SGNN_OK;
+}
+
+extern "C" int sgnn_cc_compact_huge(const int64_t* sub_ptr, const int32_t* sub_nodes, const int32_t* labels,
+                                    int64_t n_subgraphs, int64_t total_nodes, int write, int64_t C, int64_t L,
+                                    int32_t* out_n_components, int32_t* out_longest, int64_t* out, void* workspace,
+                                    int64_t workspace_bytes, void* stream)
+{
+    if (!sub_ptr || !sub_nodes || !labels || !workspace || n_subgraphs < 0 || total_nodes < 0) return SGNN_ERR_BAD_ARG;
+    if (write ? (!out || C < 1 || L < 1) : (!out_n_components || !out_longest)) return SGNN_ERR_BAD_ARG;
+    if (total_nodes >= (1ll << 28)) return SGNN_ERR_SET_TOO_LARGE;
+    if (workspace_bytes < sgnn_cc_huge_workspace_bytes(total_nodes)) return SGNN_ERR_BAD_ARG;
+    if (n_subgraphs == 0) return SGNN_OK;
+    const int grid = (int)(n_subgraphs < 1024 ? n_subgraphs : 1024);
+    if (write)
+        hipLaunchKernelGGL((cc_huge_compact_kernel<true>), dim3(grid), dim3(CCH_THREADS), 0, (hipStream_t)stream, sub_ptr,
+                           sub_nodes, labels, n_subgraphs, C, L, out_n_components, out_longest, out, (int32_t*)workspace);
+    else
+        hipLaunchKernelGGL((cc_huge_compact_kernel<false>), dim3(grid), dim3(CCH_THREADS), 0, (hipStream_t)stream, sub_ptr,
+                           sub_nodes, labels, n_subgraphs, C, L, out_n_components, out_longest, out, (int32_t*)workspace);
+    SGNN_CHECK_LAUNCH();
+    return SGNN_OK;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1290,3 +1513,83 @@ extern "C" int sgnn_patch_in_border(const int64_t* rowptr, const int32_t* col, i
     SGNN_CHECK_LAUNCH();
     return SGNN_OK;
 }
+
+// Patches of more than PB_MAX nodes (ego-graph patches around hubs): the membership table lives in the caller's workspace
+// (4 int32 slots per patch node at the patch's own offset) instead of LDS; the kernel above poisons those patches' flags
+// with 255 and this one overwrites them.  workspace: sgnn_patch_in_border_huge_workspace_bytes(total patch nodes).
+extern "C" int64_t sgnn_patch_in_border_huge_workspace_bytes(int64_t total_nodes)
+{
+    return (total_nodes < 0 ? 0 : total_nodes) * 4 * 4 + 64;
+}
+
+__global__ __launch_bounds__(256) void patch_in_border_huge_kernel(
+    const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+    const int32_t* __restrict__ node_order, const int32_t* __restrict__ node_pos,
+    const int64_t* __restrict__ patch_ptr, const int32_t* __restrict__ patch_nodes, int64_t n_patches,
+    uint8_t* __restrict__ out_flag, int32_t* __restrict__ ws)
+{
+    const int tid = threadIdx.x;
+    for (int64_t p = blockIdx.x; p < n_patches; p += gridDim.x) {
+        const int64_t beg = patch_ptr[p];
+        const int n = (int)(patch_ptr[p + 1] - beg);
+        if (n <= PB_MAX) continue;                              // sgnn_patch_in_border owns those
+        int32_t* hash = ws + 4 * beg;
+        uint32_t H = 1;
+        while (H < 2u * (uint32_t)n) H <<= 1;
+        for (uint32_t i = tid; i < H; i += 256) hash[i] = 0;
+        __syncthreads();
+        for (int i = tid; i < n; i += 256) {
+            const int32_t v = patch_nodes[beg + i];
+            uint32_t h = sgnn_hash32((uint32_t)v) & (H - 1);
+            while (true) {
+                const int32_t old = atomicCAS(&hash[h], 0, v);
+                if (old == 0 || old == v) break;
+                h = (h + 1) & (H - 1);
+            }
+        }
+        __threadfence_block();
+        __syncthreads();
+        for (int i = tid; i < n; i += 256) {
+            const int32_t x = patch_nodes[beg + i];
+            const int32_t px = node_order[x - 1];               // the reference's id - 1 / node-order quirk (su:139)
+            const int64_t r0 = rowptr[px], r1 = rowptr[px + 1];
+            uint8_t flag = 0;
+            for (int64_t e = r0; e < r1 && !flag; ++e) {
+                const int32_t y = node_pos[col[e]] + 1;
+                uint32_t h = sgnn_hash32((uint32_t)y) & (H - 1);
+                bool member = false;
+                while (true) {
+                    const int32_t kk = hash[h];
+                    if (kk == y) { member = true; break; }
+                    if (kk == 0) break;
+                    h = (h + 1) & (H - 1);
+                }
+                if (!member) flag = 1;
+            }
+            out_flag[beg + i] = flag;
+        }
+        __syncthreads();
+    }
+}
+
+extern "C" int sgnn_patch_in_border_huge(const int64_t* rowptr, const int32_t* col, int64_t nnz,
+                                         const int32_t* node_order, const int32_t* node_pos, int64_t n_nodes,
+                                         const int64_t* patch_ptr, const int32_t* patch_nodes, int64_t n_patches,
+                                         int64_t total_nodes, uint8_t* out_flag, void* workspace, int64_t workspace_bytes,
+                                         void* stream)
+{
+    if (!rowptr || !col || !node_order || !node_pos || !patch_ptr || !patch_nodes || !out_flag || !workspace || n_patches < 0 ||
+        total_nodes < 0)
+        return SGNN_ERR_BAD_ARG;
+    if (nnz >= (1ll << 31)) return SGNN_ERR_NNZ_TOO_LARGE;
+    if (total_nodes >= (1ll << 28)) return SGNN_ERR_SET_TOO_LARGE;
+    if (workspace_bytes < sgnn_patch_in_border_huge_workspace_bytes(total_nodes)) return SGNN_ERR_BAD_ARG;
+    (void)n_nodes;
+    if (n_patches == 0) return SGNN_OK;
+    hipLaunchKernelGGL(patch_in_border_huge_kernel, dim3((int)(n_patches < 1024 ? n_patches : 1024)), dim3(256), 0,
+                       (hipStream_t)stream, rowptr, col, node_order, node_pos, patch_ptr, patch_nodes, n_patches, out_flag,
+                       (int32_t*)workspace);
+    SGNN_CHECK_LAUNCH();
+    return SGNN_OK;
+}
+

@@ -237,13 +237,26 @@ def degree_sequence(g, sets, sort=True, use_degree_dict=True, want_external=True
     return out_i, out_e
 
 
+CC_LDS_MAX = 2048          # csrc/graph_sets.hip CC_MAX / PB_MAX: sets up to here keep their tables in LDS
+
+
+def _huge_ws(lib, total, device, query='sgnn_cc_huge_workspace_bytes'):
+    wsb = getattr(lib, query)(int(total))
+    return torch.empty(wsb // 4 + 1, dtype=torch.int32, device=device), wsb
+
+
 def cc_labels(g, subs):
+    """Component label (smallest position in the component) per subgraph position.  Subgraphs of more than 2048 nodes
+    take the workspace-backed kernel (sgnn_cc_labels_huge: tables in HBM instead of LDS, work ~ the members' degrees)."""
     lib = _lib.load()
-    if subs.max_len > 2048:
-        raise _lib.SubgnnHipError('sgnn_cc_labels: subgraph larger than 2048 nodes')
     out = torch.empty(subs.nodes.numel(), dtype=torch.int32, device=g.device)
     check(lib.sgnn_cc_labels(_ptr(g.rowptr), _ptr(g.col_sorted), g.nnz, _ptr(subs.ptr), _ptr(subs.nodes), subs.n,
                              int(subs.max_len), _ptr(out), _stream()), 'sgnn_cc_labels')
+    if subs.max_len > CC_LDS_MAX:
+        total = int(subs.total)
+        ws, wsb = _huge_ws(lib, total, g.device)
+        check(lib.sgnn_cc_labels_huge(_ptr(g.rowptr), _ptr(g.col_sorted), g.nnz, _ptr(subs.ptr), _ptr(subs.nodes), subs.n, total,
+                                      _ptr(out), _ptr(ws), wsb, _stream()), 'sgnn_cc_labels_huge')
     return out
 
 
@@ -258,12 +271,21 @@ def cc_compact(sub_ptr, sub_nodes, labels, max_sub_len=0, dims_reduce=None, dims
     _req(labels, torch.int32, 'labels')
     S = sub_ptr.numel() - 1
     dev = sub_ptr.device
+    huge = max_sub_len <= 0 or max_sub_len > CC_LDS_MAX      # subgraphs beyond the LDS tables: the workspace-backed kernels too
+    if huge and max_sub_len <= 0:
+        huge = S > 0 and int((sub_ptr[1:] - sub_ptr[:-1]).max().item()) > CC_LDS_MAX
+    if huge:
+        total = int(sub_ptr[-1].item())
+        ws, wsb = _huge_ws(lib, total, dev)
     if dims is not None:
         C, L = int(dims[0]), int(dims[1])
     else:
         stats = torch.zeros((2, max(S, 1)), dtype=torch.int32, device=dev)
         check(lib.sgnn_cc_compact_stats(_ptr(sub_ptr), _ptr(sub_nodes), _ptr(labels), S, int(max_sub_len), _ptr(stats[0]),
                                         _ptr(stats[1]), _stream()), 'sgnn_cc_compact_stats')
+        if huge:
+            check(lib.sgnn_cc_compact_huge(_ptr(sub_ptr), _ptr(sub_nodes), _ptr(labels), S, total, 0, 0, 0, _ptr(stats[0]),
+                                           _ptr(stats[1]), None, _ptr(ws), wsb, _stream()), 'sgnn_cc_compact_huge')
         d = stats.amax(dim=1)
         if dims_reduce is not None:
             d = dims_reduce(d)
@@ -271,6 +293,9 @@ def cc_compact(sub_ptr, sub_nodes, labels, max_sub_len=0, dims_reduce=None, dims
     out = torch.zeros((S, C, L), dtype=torch.int64, device=dev)
     check(lib.sgnn_cc_compact(_ptr(sub_ptr), _ptr(sub_nodes), _ptr(labels), S, int(max_sub_len), C, L, _ptr(out),
                               _stream()), 'sgnn_cc_compact')
+    if huge:
+        check(lib.sgnn_cc_compact_huge(_ptr(sub_ptr), _ptr(sub_nodes), _ptr(labels), S, total, 1, C, L, None, None, _ptr(out),
+                                       _ptr(ws), wsb, _stream()), 'sgnn_cc_compact_huge')
     return out
 
 
@@ -471,12 +496,16 @@ def triangular_walks(g, mode, n_items, walk_len, beta, seed, stream_id, patches=
 def patch_in_border(g, patches):
     """uint8 flag per patch node: is it an in-border node (su.get_border_nodes semantics)."""
     lib = _lib.load()
-    if patches.max_len > 2048:
-        raise _lib.SubgnnHipError('sgnn_patch_in_border: patch larger than 2048 nodes')
     out = torch.zeros(patches.nodes.numel(), dtype=torch.uint8, device=g.device)
     check(lib.sgnn_patch_in_border(_ptr(g.rowptr), _ptr(g.col), g.nnz, _ptr(g.node_order), _ptr(g.node_pos),
                                    g.n_nodes, _ptr(patches.ptr), _ptr(patches.nodes), patches.n, _ptr(out), _stream()),
           'sgnn_patch_in_border')
+    if patches.max_len > CC_LDS_MAX:                          # patches beyond the LDS table: membership table in HBM
+        total = int(patches.total)
+        ws, wsb = _huge_ws(lib, total, g.device, 'sgnn_patch_in_border_huge_workspace_bytes')
+        check(lib.sgnn_patch_in_border_huge(_ptr(g.rowptr), _ptr(g.col), g.nnz, _ptr(g.node_order), _ptr(g.node_pos),
+                                            g.n_nodes, _ptr(patches.ptr), _ptr(patches.nodes), patches.n, total, _ptr(out),
+                                            _ptr(ws), wsb, _stream()), 'sgnn_patch_in_border_huge')
     return out
 
 

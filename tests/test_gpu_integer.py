@@ -203,6 +203,57 @@ def test_cc_compact_large_and_duplicates():
         assert got == ref, i
 
 
+def test_cc_of_subgraphs_beyond_the_lds_tables():
+    """Subgraphs of 5000 and 3000 nodes (rounds 1-2 refused more than 2048; the reference pads to any size,
+    SubGNN.py:575-607) next to small ones, with repeated ids: labels and the padded component tensor from the
+    workspace-backed kernels (sgnn_cc_labels_huge / sgnn_cc_compact_huge) == the oracle, and the padded shape is tight."""
+    ops = _ops()
+    from subgnn_amd.subgraph_utils import components_from_labels
+    G = _rand_graph(9000, 2, 21)
+    dg = _dev_graph(G)
+    rng = np.random.default_rng(5)
+    ids = np.arange(1, G.max_id() + 1)
+    subs = [rng.choice(ids, 5000, replace=False).tolist(), rng.integers(1, G.max_id() + 1, 30).tolist(),
+            rng.choice(ids, 3000, replace=False).tolist(), [], rng.integers(1, G.max_id() + 1, 300).tolist()]
+    subs[0] = subs[0] + subs[0][:7]                            # repeated ids in a huge subgraph
+    subs[2][100] = subs[2][5]
+    r = ops.Ragged.from_lists(subs, DEV)
+    assert r.max_len > 2048
+    lab = ops.Ragged(r.ptr, ops.cc_labels(dg, r)).to_lists()
+    for s in (0, 1, 2, 4):
+        ref = {frozenset(c) for c in IH.connected_components(G, subs[s])}
+        assert _labels_to_sets(subs[s], lab[s]) == ref, s
+        for i, l in enumerate(lab[s]):
+            assert l <= i and lab[s][l] == l                   # the label is the smallest position in the component
+    out = components_from_labels(r.ptr, r.nodes, ops.cc_labels(dg, r), r.max_len).cpu().numpy()
+    refs = [IH.connected_components(G, s) if s else [] for s in subs]
+    assert out.shape == (5, max(len(c) for c in refs), max(len(cc) for c in refs for cc in c))
+    for i, s in enumerate(subs):
+        got = [[int(v) for v in row if v != 0] for row in out[i] if row[0] != 0]
+        assert got == refs[i], i
+    # a kept shape (no statistics launch) gives the same tensor
+    again = components_from_labels(r.ptr, r.nodes, ops.cc_labels(dg, r), r.max_len, dims=out.shape[1:]).cpu().numpy()
+    assert np.array_equal(again, out)
+
+
+def test_patch_in_border_beyond_the_lds_table():
+    """A patch of 5000 nodes (an ego-graph patch around hubs) next to small ones: in-border flags from the
+    workspace-backed kernel == the oracle (the reference's id - 1 / node-order quirk included)."""
+    ops = _ops()
+    G = _rand_graph(8000, 3, 17)
+    dg = _dev_graph(G)
+    rng = np.random.default_rng(3)
+    ids = np.arange(1, G.max_id() + 1)
+    views = [rng.choice(ids, 5000, replace=False).tolist(), rng.choice(ids, 40, replace=False).tolist(),
+             rng.choice(ids, 2500, replace=False).tolist()]
+    vr = ops.Ragged.from_lists(views, DEV)
+    flags = ops.Ragged(vr.ptr, ops.patch_in_border(dg, vr).to(torch.int32)).to_lists()
+    for v, f in zip(views, flags):
+        want = set(IH.patch_in_border_nodes(G, v))
+        assert [x for x, b in zip(v, f) if b] == [x for x in v if x in want]
+        assert set(f) <= {0, 1}
+
+
 # ---- a8 k-hop border ----------------------------------------------------------------------
 
 def test_khop_border_golden(golden):
