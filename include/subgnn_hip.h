@@ -73,6 +73,15 @@ int sgnn_degree_sequence_sorted_rows(const int64_t* rowptr, const int32_t* col, 
                                      const int64_t* set_ptr, const int32_t* set_nodes, int64_t n_sets,
                                      int64_t max_set_size, int sorted, int32_t* out_internal,
                                      int32_t* out_external, const int32_t* set_order, void* stream);
+/* Sets of more than 2048 entries (components of subgraphs with thousands of nodes): the two calls above leave them alone;
+ * this one, issued after either on the same stream, writes their degrees UNSORTED (same counting rules; the membership
+ * table lives in the workspace, sgnn_degree_sequence_huge_workspace_bytes(set_ptr[n_sets])); ordering such a set's slice
+ * is the caller's (any segment sort). */
+int64_t sgnn_degree_sequence_huge_workspace_bytes(int64_t total_entries);
+int sgnn_degree_sequence_huge(const int64_t* rowptr, const int32_t* col, int64_t nnz, const int32_t* full_degree,
+                              const int64_t* set_ptr, const int32_t* set_nodes, int64_t n_sets,
+                              int64_t total_entries, int32_t* out_internal, int32_t* out_external,
+                              void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * a7  Connected components of induced subgraphs.

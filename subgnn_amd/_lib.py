@@ -39,6 +39,8 @@ SIGNATURES = {
     'sgnn_cc_compact_stats': (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_ptr]),
     'sgnn_cc_compact': (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_i64, c_ptr, c_ptr]),
     'sgnn_cc_huge_workspace_bytes': (c_i64, [c_i64]),
+    'sgnn_degree_sequence_huge_workspace_bytes': (c_i64, [c_i64]),
+    'sgnn_degree_sequence_huge': (c_int, [c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_i64, c_ptr]),
     'sgnn_cc_labels_huge': (c_int, [c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_i64, c_ptr]),
     'sgnn_cc_compact_huge': (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_int, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr]),
     'sgnn_patch_in_border_huge_workspace_bytes': (c_i64, [c_i64]),

@@ -497,8 +497,7 @@ static int ds_run(const int64_t* rowptr, const int32_t* col, const int32_t* col_
     if (!rowptr || !col || !set_ptr || !set_nodes || !out_internal || n_sets < 0 || max_set_size <= 0)
         return SGNN_ERR_BAD_ARG;
     if (nnz >= (1ll << 31)) return SGNN_ERR_NNZ_TOO_LARGE;
-    if (max_set_size > DSB_MAX) return SGNN_ERR_SET_TOO_LARGE;
-    if (n_sets == 0) return SGNN_OK;
+    if (n_sets == 0) return SGNN_OK;                            // (sets of more than DSB_MAX entries: sgnn_degree_sequence_huge)
     hipStream_t st = (hipStream_t)stream;
     // 256-thread workgroups = 4 independent wavefronts, one set per wavefront: the hardware
     // dispatcher hands out workgroups as CUs free up, which balances the very uneven per-set
@@ -547,3 +546,90 @@ extern "C" int sgnn_degree_sequence_sorted_rows(const int64_t* rowptr, const int
     return ds_run(rowptr, col, col_sorted, nnz, full_degree, self_loops, set_ptr, set_nodes, n_sets, max_set_size, sorted,
                   out_internal, out_external, set_order, stream);
 }
+
+// Sets of more than DSB_MAX entries (components of subgraphs with thousands of nodes; rounds 1-2 refused them): the calls
+// above leave them alone and this one fills in their degrees UNSORTED -- the membership table lives in the caller's
+// workspace (4 int32 slots per entry at the set's own offset), a member's list is streamed by one wavefront, hits counted by
+// ballot.  Same counting rules as above (a self loop counts twice; a repeated member gets its own count).  Sorting such a
+// set is the caller's (any segment sort).  workspace: sgnn_degree_sequence_huge_workspace_bytes(set_ptr[n_sets]).
+extern "C" int64_t sgnn_degree_sequence_huge_workspace_bytes(int64_t total_entries)
+{
+    return (total_entries < 0 ? 0 : total_entries) * 4 * 4 + 64;
+}
+
+__global__ __launch_bounds__(256) void degseq_huge_kernel(
+    const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col, const int32_t* __restrict__ full_degree,
+    const int64_t* __restrict__ set_ptr, const int32_t* __restrict__ set_nodes, int64_t n_sets,
+    int32_t* __restrict__ out_int, int32_t* __restrict__ out_ext, int32_t* __restrict__ ws)
+{
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    for (int64_t s = blockIdx.x; s < n_sets; s += gridDim.x) {
+        const int64_t beg = set_ptr[s];
+        const int n = (int)(set_ptr[s + 1] - beg);
+        if (n <= DSB_MAX) continue;
+        int32_t* hash = ws + 4 * beg;
+        uint32_t H = 1;
+        while (H < 2u * (uint32_t)n) H <<= 1;
+        for (uint32_t i = tid; i < H; i += 256) hash[i] = 0;
+        __syncthreads();
+        for (int i = tid; i < n; i += 256) {
+            const int32_t v = set_nodes[beg + i];
+            uint32_t h = sgnn_hash32((uint32_t)v) & (H - 1);
+            while (true) {
+                const int32_t old = atomicCAS(&hash[h], 0, v);
+                if (old == 0 || old == v) break;
+                h = (h + 1) & (H - 1);
+            }
+        }
+        __threadfence_block();
+        __syncthreads();
+        for (int i = wave; i < n; i += 4) {
+            const int32_t v = set_nodes[beg + i];
+            const int64_t a = rowptr[v], b = rowptr[v + 1];
+            int hits = 0, self = 0;
+            for (int64_t e = a + lane; e < b + lane; e += 64) {          // uniform trip count per wavefront
+                bool hit = false, loop = false;
+                if (e < b) {
+                    const int32_t u = col[e];
+                    loop = (u == v);
+                    if (!loop) {
+                        uint32_t h = sgnn_hash32((uint32_t)u) & (H - 1);
+                        while (true) {
+                            const int32_t k = hash[h];
+                            if (k == u) { hit = true; break; }
+                            if (k == 0) break;
+                            h = (h + 1) & (H - 1);
+                        }
+                    }
+                }
+                hits += __popcll(__ballot(hit));
+                self += __popcll(__ballot(loop));
+            }
+            if (lane == 0) {
+                const int32_t internal = hits + 2 * self;
+                const int32_t full = full_degree ? full_degree[v] : (int32_t)(b - a) + self;
+                out_int[beg + i] = internal;
+                if (out_ext) out_ext[beg + i] = full - internal;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+extern "C" int sgnn_degree_sequence_huge(const int64_t* rowptr, const int32_t* col, int64_t nnz, const int32_t* full_degree,
+                                         const int64_t* set_ptr, const int32_t* set_nodes, int64_t n_sets,
+                                         int64_t total_entries, int32_t* out_internal, int32_t* out_external,
+                                         void* workspace, int64_t workspace_bytes, void* stream)
+{
+    if (!rowptr || !col || !set_ptr || !set_nodes || !out_internal || !workspace || n_sets < 0 || total_entries < 0)
+        return SGNN_ERR_BAD_ARG;
+    if (nnz >= (1ll << 31)) return SGNN_ERR_NNZ_TOO_LARGE;
+    if (total_entries >= (1ll << 28)) return SGNN_ERR_SET_TOO_LARGE;
+    if (workspace_bytes < sgnn_degree_sequence_huge_workspace_bytes(total_entries)) return SGNN_ERR_BAD_ARG;
+    if (n_sets == 0) return SGNN_OK;
+    hipLaunchKernelGGL(degseq_huge_kernel, dim3((int)(n_sets < 1024 ? n_sets : 1024)), dim3(256), 0, (hipStream_t)stream, rowptr,
+                       col, full_degree, set_ptr, set_nodes, n_sets, out_internal, out_external, (int32_t*)workspace);
+    SGNN_CHECK_LAUNCH();
+    return SGNN_OK;
+}
+

@@ -234,6 +234,21 @@ def degree_sequence(g, sets, sort=True, use_degree_dict=True, want_external=True
         check(lib.sgnn_degree_sequence(_ptr(g.rowptr), _ptr(g.col), g.nnz, _ptr(fd), _ptr(sl), _ptr(sets.ptr),
                                        _ptr(sets.nodes), sets.n, max(sets.max_len, 1), 1 if sort else 0, _ptr(out_i),
                                        _ptr(out_e), _ptr(order), _stream()), 'sgnn_degree_sequence')
+    if sets.max_len > CC_LDS_MAX:
+        # sets beyond the kernels' LDS tables: degrees from the workspace-backed kernel, each such slice ordered by a
+        # device sort (they are few: one sort per set)
+        total = int(sets.total)
+        ws, wsb = _huge_ws(lib, total, g.device, 'sgnn_degree_sequence_huge_workspace_bytes')
+        check(lib.sgnn_degree_sequence_huge(_ptr(g.rowptr), _ptr(g.col), g.nnz, _ptr(fd), _ptr(sets.ptr), _ptr(sets.nodes),
+                                            sets.n, total, _ptr(out_i), _ptr(out_e), _ptr(ws), wsb, _stream()),
+              'sgnn_degree_sequence_huge')
+        if sort:
+            ptr = sets.ptr.tolist()
+            for s in (sets.lengths > CC_LDS_MAX).nonzero().view(-1).tolist():
+                a, b = ptr[s], ptr[s + 1]
+                out_i[a:b] = torch.sort(out_i[a:b]).values
+                if out_e is not None:
+                    out_e[a:b] = torch.sort(out_e[a:b]).values
     return out_i, out_e
 
 

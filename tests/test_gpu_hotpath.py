@@ -322,3 +322,57 @@ def test_streamed_p_internal_similarities_equal_the_hop_table_form(tmp_path, mon
     for l in range(L):
         a, b = table.train_neigh_pos_similarities[('P', 'in', l)], streamed.train_neigh_pos_similarities[('P', 'in', l)]
         assert torch.equal(a, b) and float(a.abs().max()) > 0
+
+
+def test_a_subgraph_of_thousands_of_nodes_goes_through_the_whole_pass():
+    """No 2048-node limit (the reference pads to any size): a split with one 3000-node subgraph in several components
+    next to ordinary ones is prepared by the sparse path (components, border draws, position similarities, degree
+    sequences, DTW against rows of thousands of entries) and trained on for a step; the huge components and their
+    structure similarities equal the oracle's."""
+    import networkx as nx
+    from oracle import cbind, graph as OG, integer_half as IH
+    from subgnn_amd import hotpath, ops
+    from subgnn_amd.SubGNN import SubGNN
+    n = 7000
+    Gx = nx.barabasi_albert_graph(n, 3, seed=4)
+    G = OG.from_edge_pairs(list(Gx.edges()))
+    rowptr, col = G.csr()
+    rng = np.random.default_rng(1)
+    big = (rng.choice(np.arange(1, n + 1), 3000, replace=False)).tolist()
+    subs = [big] + [[int(v) for v in rng.choice(np.arange(1, n + 1), 15, replace=False)] for _ in range(11)]
+    labels = torch.tensor([i % 3 for i in range(len(subs))])
+    g = ops.DeviceGraph(rowptr, col, np.asarray(G.node_order, dtype=np.int32), DEV)
+    hp = {"use_neighborhood": True, "use_structure": True, "use_position": True, "seed": 3, "node_embed_size": 16,
+          "structure_patch_type": "triangular_random_walk", "lstm_aggregator": "last", "n_processes": 1,
+          "resample_anchor_patches": False, "freeze_node_embeds": False, "use_mpn_projection": True,
+          "compute_similarities": True, "sample_walk_len": 12, "n_triangular_walks": 3, "random_walk_len": 5, "rw_beta": 0.65,
+          "batch_size": 4, "learning_rate": 1e-3, "grad_clip": 1.0, "n_layers": 1, "neigh_sample_border_size": 1,
+          "n_anchor_patches_pos_out": 9, "n_anchor_patches_pos_in": 5, "n_anchor_patches_N_in": 4, "n_anchor_patches_N_out": 6,
+          "n_anchor_patches_structure": 5, "linear_hidden_dim_1": 16, "linear_hidden_dim_2": 8, "lin_dropout": 0.0,
+          "lstm_dropout": 0.0, "lstm_n_layers": 1, "cc_aggregator": "sum", "trainable_cc": False, "max_sim_epochs": 2,
+          "embedding_type": "gin"}
+    torch.manual_seed(0)
+    emb = torch.randn(n, 16, device=DEV)
+    m = SubGNN.from_memory(hp, g, {'train': subs, 'val': [], 'test': []},
+                           {'train': labels, 'val': labels[:0], 'test': labels[:0]}, emb, num_classes=3)
+    hotpath.prepare_sparse(m, 'train')
+    cc = m.train_cc_ids.cpu().numpy()
+    ref = IH.connected_components(G, big)
+    assert len(ref) > 5 and max(len(c) for c in ref) > 2048                       # a giant component and many small ones
+    assert [[int(v) for v in row if v != 0] for row in cc[0] if row[0] != 0] == ref
+    # structure similarities of the giant component's row against the C oracle
+    giant = int(np.argmax([len(c) for c in ref]))
+    a_sets = ops.Ragged.from_padded(m.structure_anchors)
+    for internal, got in ((True, m.train_int_struc_similarities), (False, m.train_bor_struc_similarities)):
+        from subgnn_amd import gamma
+        _, a_seq = gamma.degree_sequences(g, m.structure_anchors, internal, g.full_degree is not None)
+        cp, cf = cbind.ragged([ref[giant]])
+        ci, ce = cbind.degree_sequence(rowptr, col, None, cp, cf, True)
+        want = cbind.fastdtw_sim(cp, ci if internal else ce, a_sets.ptr.cpu().numpy(),
+                                 a_seq.cpu().numpy()[:int(a_sets.ptr[-1])], 0)
+        assert np.array_equal(got[0, giant].cpu().numpy(), want[0])
+    m.train()
+    batch = hotpath.full_split_batch(m, 'train')
+    out = m.training_step(batch, 0)
+    m.backward(None, out['loss'], None, 0)
+    assert torch.isfinite(out['loss']) and float(m.node_embeddings.weight.grad.abs().max()) > 0

@@ -104,14 +104,18 @@ def test_degree_sequence_random(sizes):
             assert np.array_equal(oe.cpu().numpy()[:n], ce)
 
 
-def test_degree_sequence_too_large_is_an_error():
+def test_degree_sequence_of_a_set_beyond_2048_is_served():
+    """Rounds 1-2 answered SGNN_ERR_SET_TOO_LARGE here; since round 3 such a set takes the workspace-backed kernel."""
     ops = _ops()
-    from subgnn_amd._lib import SubgnnHipError
     G = _rand_graph(3000, 3, 1)
     dg = _dev_graph(G)
-    r = ops.Ragged.from_lists([list(range(1, 2500))], DEV)
-    with pytest.raises(SubgnnHipError):
-        ops.degree_sequence(dg, r)
+    rp, col = G.csr()
+    members = list(range(1, 2500))
+    r = ops.Ragged.from_lists([members], DEV)
+    oi, oe = ops.degree_sequence(dg, r, use_degree_dict=False)
+    ptr, flat = cbind.ragged([members])
+    ci, ce = cbind.degree_sequence(rp, col, None, ptr, flat, True)
+    assert np.array_equal(oi.cpu().numpy(), ci) and np.array_equal(oe.cpu().numpy(), ce)
 
 
 # ---- a7 connected components --------------------------------------------------------------
@@ -234,6 +238,28 @@ def test_cc_of_subgraphs_beyond_the_lds_tables():
     # a kept shape (no statistics launch) gives the same tensor
     again = components_from_labels(r.ptr, r.nodes, ops.cc_labels(dg, r), r.max_len, dims=out.shape[1:]).cpu().numpy()
     assert np.array_equal(again, out)
+
+
+def test_degree_sequences_beyond_the_lds_tables():
+    """Sets of 5000 / 2600 entries (with a repeated member and self loops in the graph) next to small ones: internal and
+    external degree sequences, sorted and unsorted, with and without the degree dictionary == the C oracle."""
+    ops = _ops()
+    G = _rand_graph(9000, 3, 29)
+    dg = _dev_graph(G)
+    rowptr, col = G.csr()
+    rng = np.random.default_rng(8)
+    ids = np.arange(1, G.max_id() + 1)
+    big = rng.choice(ids, 5000, replace=False).tolist()
+    big[3], big[9], big[11] = 4, 1, 11                         # nodes with self loops (networkx degree counts them twice) and a hub
+    big[40] = big[41]
+    sets = [big, rng.integers(1, G.max_id() + 1, 50).tolist(), rng.choice(ids, 2600, replace=False).tolist(), [],
+            rng.integers(1, G.max_id() + 1, 700).tolist()]
+    r = ops.Ragged.from_lists(sets, DEV)
+    ptr, flat = cbind.ragged(sets)
+    for srt in (True, False):
+        ci, ce = cbind.degree_sequence(rowptr, col, None, ptr, flat, srt)
+        gi, ge = ops.degree_sequence(dg, r, sort=srt, use_degree_dict=False)
+        assert np.array_equal(gi.cpu().numpy()[:len(ci)], ci) and np.array_equal(ge.cpu().numpy()[:len(ce)], ce), srt
 
 
 def test_patch_in_border_beyond_the_lds_table():
