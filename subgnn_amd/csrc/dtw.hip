@@ -511,20 +511,26 @@ __device__ __forceinline__ double dtw_wave_level(
 #ifdef DTW_PROBE_NO_BACKTRACK
     return result;
 #endif
-    // backtrack through the predecessor codes; record the path's column range per row
-#pragma unroll
-    for (int q = 0; q < RR; ++q) FLQ(q) = 0xffff;                            // first = 65535, last = 0
+    // backtrack through the predecessor codes; record the path's column range per row.  The path enters a row at its
+    // LAST column and leaves it at its first, and it visits every row: one LDS write per row when the path leaves it (no
+    // initialisation, no read-modify-write per step), and the column's word of codes is fetched when the column changes
     int i = lx - 1, j = ly - 1;
+    int last = j;
+    uint32_t word = WLDS ? wl[j * DTW_THREADS] : wq[(int64_t)j * NT];
     while (i >= 0 && j >= 0) {
-        const int v = FLQ(i);
-        int f = v & 0xffff, l = v >> 16;
-        f = j < f ? j : f;
-        l = j > l ? j : l;
-        FLQ(i) = (l << 16) | f;
-        const uint32_t word = WLDS ? wl[j * DTW_THREADS] : wq[(int64_t)j * NT];
         const int d = (int)((word >> (2 * i)) & 3);
-        if (d == 0) --i; else if (d == 1) --j; else { --i; --j; }
+        if (d != 1) {                                                        // the path leaves row i here, at column j
+            FLQ(i) = (last << 16) | j;
+            --i;
+        }
+        if (d != 0) {
+            --j;
+            if (j >= 0) word = WLDS ? wl[j * DTW_THREADS] : wq[(int64_t)j * NT];
+        }
+        if (d != 1) last = j;                                                // ... and enters the row above at column j (or j - 1)
     }
+    // (a path that runs off the first column inside a row -- only possible through a window's edge -- leaves that row open)
+    if (i >= 0 && j < 0) FLQ(i) = (last << 16) | 0;
     return result;
 #undef FLQ
 }

@@ -326,7 +326,17 @@ def prepare_pass(model, split='train', timer=None, shard=None, defer_dtw=False):
                     sims[('P', 'in', l)] = (w * real.unsqueeze(-1)).contiguous()
             if side is main:
                 t.mark('P_bfs_sims')
-        if hp['use_structure']:
+        patch_ev = None
+        if hp['use_structure'] and side is not main:
+            patch_ev = torch.cuda.Event()
+            patch_ev.record(side)                       # the patches exist: their walks run on the main stream (below)
+
+        def structure_walks():
+            """Walks over the structure patches, the per-layer picks and the patches' degree sequences.  With two streams
+            this runs on the MAIN stream behind the component degree sequences (the side stream keeps the position BFS):
+            the side chain -- patches, BFS, walks: 2.5 ms -- was 0.8 ms longer than the main one (border, degree
+            sequences: 1.7 ms) and the DTW waited for it."""
+            nonlocal a_sets, ai, ae
             if new_patches:
                 views = aps.patch_node_views(structure_anchors)
                 bor_w = st.attrs['bor_structure_anchor_random_walks'] = aps.perform_random_walks(hp, g, structure_anchors, False, views)
@@ -338,8 +348,9 @@ def prepare_pass(model, split='train', timer=None, shard=None, defer_dtw=False):
                 st.sim_cols = (a_struct, model.sim_cols_of(a_struct))
             a_sets = ops.Ragged.from_padded(structure_anchors)
             ai, ae = ops.degree_sequence(g, a_sets, sort=True, use_degree_dict=g.full_degree is not None)
-            if side is main:
-                t.mark('S_patches_walks')
+        if hp['use_structure'] and side is main:
+            structure_walks()
+            t.mark('S_patches_walks')
     # ---- main stream: neighbourhood channel + component degree sequences --------------------
     if hp['use_neighborhood']:
         k = hp['neigh_sample_border_size']
@@ -366,16 +377,18 @@ def prepare_pass(model, split='train', timer=None, shard=None, defer_dtw=False):
         ci, ce = ops.degree_sequence(g, cc_sets, sort=True, use_degree_dict=g.full_degree is not None,
                                      order=set_order)
         t.mark('degree_sequences')
+    if hp['use_structure'] and side is not main:
+        main.wait_event(patch_ev)
+        _hand_over(main, structure_anchors)
+        structure_walks()
+        t.mark('S_walks')
     # ---- join ------------------------------------------------------------------------------
     if side is not main:
         main.wait_stream(side)
-        _hand_over(main, sims, a_sets, ai, ae, st.attrs.get('anchors_pos_ext'), st.per_split.get('anchors_pos_int'),
-                   st.attrs.get('structure_anchors'), st.attrs.get('int_structure_anchor_random_walks'),
-                   st.attrs.get('bor_structure_anchor_random_walks'), st.sim_cols[1] if st.sim_cols else None)
-        for v in (st.attrs.get('anchors_structure') or {}).values():
-            _hand_over(main, v[0], v[2], v[3])
+        _hand_over(main, sims, st.attrs.get('anchors_pos_ext'), st.per_split.get('anchors_pos_int'),
+                   st.attrs.get('structure_anchors'))
     if side is not main:
-        t.mark('side_stream_join(P_bfs,S_walks)')
+        t.mark('side_stream_join(S_patches,P_bfs)')
     st.attrs[split + '_neigh_pos_similarities'] = sims if sims else None
     st.attrs[split + '_N_border'] = None
     st.dtw_inputs = (cc_sets, ci, ce, a_sets, ai, ae, (S, C)) if hp['use_structure'] else None
