@@ -413,21 +413,22 @@ def main():
     # the kernel that dominates the pass by TIME is not an HBM kernel: the DTW launch is bound by fp64 vector issue.  Its
     # counters are a committed measurement (tools/run_dtw_pmc.sh), quoted beside the roofline of the HBM-class kernel.
     longest = None
-    pj = os.path.join(REPO, 'profiles', 'r02_dtw_pmc.json')
+    pj = os.path.join(REPO, 'profiles', 'r03_dtw_pmc.json')
     if os.path.exists(pj):
         pm = json.load(open(pj))
         kk = [k for k in pm if 'dtw_similarity' in k]
         if kk and stage_ms.get('dtw'):
             c = pm[kk[0]]
+            wps = int(c.get('wavefronts_per_simd', 3))
             longest = {'kernel': kk[0].split('(')[0], 'bound': 'fp64 vector issue (not HBM, not MFMA)',
                        'share_of_step': round(stage_ms['dtw'] / (1e3 * elapsed / args.steps), 3),
-                       'simd_valu_busy': round(2 * c['frac_wave_cycles_valu_active'], 3),
+                       'simd_valu_busy': round(c.get('simd_valu_busy_from_grbm', min(1.0, wps * c['frac_wave_cycles_valu_active'])), 3),
                        'wave_cycles': {'issuing': round(c['frac_wave_cycles_issuing'], 3),
                                        'waiting_on_memory_or_barrier': round(c['frac_wave_cycles_waiting_waitcnt_or_barrier'], 3),
                                        'issue_stalled': round(c['frac_wave_cycles_issue_stalled'], 3)},
-                       'valu_instructions_per_wave': round(c['valu_instructions_per_wave']),
-                       'source': 'profiles/r02_dtw_pmc.json (rocprofv3 --pmc, committed measurement; 2 wavefronts per SIMD, so '
-                                 'SIMD busy = 2 x the per-wave VALU-active fraction)'}
+                       'valu_instructions_per_64_pairs': round(c['valu_instructions_per_64_pairs']),
+                       'source': 'profiles/r03_dtw_pmc.json (rocprofv3 --pmc, committed measurement of the external-side launch; '
+                                 '%d wavefronts per SIMD; SIMD busy = 4 x SQ_ACTIVE_INST_VALU / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs))' % wps}
     result = {
         'metric': 'subgraphs/sec fwd+bwd (all 3 channels on) + achieved HBM GB/s',
         'value': total_subgraphs * args.steps / elapsed, 'unit': 'subgraphs/s', 'n_gpus': world, 'steps': args.steps,

@@ -37,6 +37,11 @@ for k, v in d.items():
             tasks = 210 * ((50000 + 63) // 64)
             r['valu_instructions_per_64_pairs'] = c['SQ_INSTS_VALU'] / tasks
             r['salu_instructions_per_64_pairs'] = c.get('SQ_INSTS_SALU', 0) / tasks
+        # occupancy of the shipped instantiation (DTW_MINB20 = 3 workgroups of 256 threads per CU = 3 wavefronts per SIMD)
+        r['wavefronts_per_simd'] = 3
+        if c.get('GRBM_GUI_ACTIVE') and c.get('SQ_ACTIVE_INST_VALU'):
+            # SQ_ACTIVE_INST_* count in units of 4 cycles; GRBM_GUI_ACTIVE is summed over the 8 XCDs; 1024 SIMDs
+            r['simd_valu_busy_from_grbm'] = 4 * c['SQ_ACTIVE_INST_VALU'] / (c['GRBM_GUI_ACTIVE'] / 8 * 1024)
         out[k] = r
 json.dump(out, open('gpurun_out/%s_dtw_pmc.json' % T, 'w'), indent=1)
 print(json.dumps(out, indent=1)[:3000])
