@@ -457,6 +457,32 @@ int sgnn_masked_sum_bwd(const float* grad_out, const uint8_t* mask, int64_t B, i
                         float* grad_x, void* stream);
 
 /* ---------------------------------------------------------------------------------------
+ * a16b  The tail of the forward pass without the (B, C, H) concatenation (SubGNN/SubGNN.py:286-312: cat of the
+ * channel outputs, then masked_sum): every piece is summed over a subgraph's real components straight into its
+ * column slot of the (B, H) subgraph embedding (row stride out_ld / grad_ld, in floats).
+ *   sgnn_masked_sum_slot_fwd/_bwd: a piece that exists as a tensor x (B, C, W) (component embeddings).
+ *   sgnn_readout_sum_fwd/_bwd: the read-out of a layer over SHARED anchors (subgraph_mpn.py:122-131: position read-out
+ *     of the messages + relu) when only the read-out is consumed.  With s[a] = X[a,:] . wp (A values, the caller's)
+ *       out[b, a] = sum over real components c of  relu(W[b,c,a] * s[a] + bp[0]),
+ *       W[b,c,a] = sims[(b C + c) sims_ld + (sim_col ? sim_col[a] : a)]    (sims NULL: W = 0)
+ *     row_mask (B C, nullable): 0 = padded component (contributes nothing).  Backward: grad_s[a] = sum_r g [z>0] W,
+ *     grad_bp = sum g [z>0], by per-row-block partials added in block order (no atomics: bit-reproducible);
+ *     either output may be NULL.  workspace: sgnn_readout_sum_bwd_workspace_bytes.
+ * ------------------------------------------------------------------------------------- */
+int sgnn_masked_sum_slot_fwd(const float* x, const uint8_t* mask, int64_t B, int64_t C, int64_t W, float* out,
+                             int64_t out_ld, void* stream);
+int sgnn_masked_sum_slot_bwd(const float* grad_out, int64_t grad_ld, const uint8_t* mask, int64_t B, int64_t C,
+                             int64_t W, float* grad_x, void* stream);
+int sgnn_readout_sum_fwd(const float* sims, int64_t sims_ld, const int64_t* sim_col, const float* s, const float* bp,
+                         const uint8_t* row_mask, int64_t B, int64_t C, int64_t A, float* out, int64_t out_ld,
+                         void* stream);
+int64_t sgnn_readout_sum_bwd_workspace_bytes(int64_t B, int64_t C, int64_t A);
+int sgnn_readout_sum_bwd(const float* grad_out, int64_t grad_ld, const float* sims, int64_t sims_ld,
+                         const int64_t* sim_col, const float* s, const float* bp, const uint8_t* row_mask, int64_t B,
+                         int64_t C, int64_t A, float* grad_s, float* grad_bp, void* workspace, int64_t workspace_bytes,
+                         void* stream);
+
+/* ---------------------------------------------------------------------------------------
  * a18  Embedding-table gradient without atomics (the backward of every op that gathers table rows:
  * autograd of SubGNN/SubGNN.py:609-622, anchor_patch_samplers.py:404-411, subgraph_mpn.py:227-231 as
  * run by loss.backward(), SubGNN/SubGNN.py:1163-1164).

@@ -264,8 +264,17 @@ class SubGNN(nn.Module):
         in a max exactly as it does in the reference -- and no host synchronisation (a compaction
         would need the number of non-PAD entries on the host) sits in the per-step path."""
         S, C, L = cc_id_list.shape
-        ids = cc_id_list.to(self.device).reshape(S * C * L).to(torch.int32)
-        ptr = torch.arange(S * C + 1, dtype=torch.int64, device=self.device) * L
+        # (hotpath.prepare_pass converts the ids beside the sampling stages and hangs them on the tensor)
+        ids = getattr(cc_id_list, '_sgnn_ids32', None)
+        if ids is None or ids.numel() != S * C * L:
+            ids = cc_id_list.to(self.device).reshape(S * C * L).to(torch.int32)
+        # the fixed-stride set pointers depend on the padded shape only: kept
+        memo = self.__dict__.setdefault('_fixed_stride_ptr', {})
+        ptr = memo.get((S * C, L))
+        if ptr is None:
+            if len(memo) > 64:
+                memo.clear()
+            ptr = memo[(S * C, L)] = torch.arange(S * C + 1, dtype=torch.int64, device=self.device) * L
         sets = ops.Ragged(ptr, ids.contiguous() if ids.numel() else torch.zeros(1, dtype=torch.int32, device=self.device),
                           max_len=L)
         # (hotpath.prepare_sparse attaches the members' sorted order to the split's cc_ids tensor: kept across passes)
@@ -279,14 +288,32 @@ class SubGNN(nn.Module):
             return tuple(Parameter(cc_embeddings.detach().clone()) for _ in CC_SLOTS)
         return tuple(cc_embeddings for _ in CC_SLOTS)
 
-    def init_all_embeddings(self, split='all', trainable=False):
+    def init_all_embeddings(self, split='all', trainable=False, lazy=False):
+        """S.py:624-650.  ``lazy`` (the per-pass caller, hotpath.install_pass): without ``trainable_cc`` nothing on the
+        path reads the six per-split copies (forward recomputes the component embeddings from the table, S.py:238-247),
+        so they are computed when somebody asks for the attribute instead of on every pass."""
         which = {'all': ('train', 'val', 'test'), 'train_val': ('train', 'val')}.get(split, (split,))
+        pending = self.__dict__.setdefault('_lazy_cc_embed', set())
         for sp in which:
+            if lazy and not (trainable and sp == 'train'):
+                for nm in CC_SLOTS:
+                    self.__dict__.pop('%s_%s_cc_embed' % (sp, nm), None)
+                pending.add(sp)
+                continue
+            pending.discard(sp)
             with torch.no_grad():
                 emb = self.initialize_cc_embeddings(getattr(self, sp + '_cc_ids'), self.hparams['cc_aggregator'])
             six = self.initialize_channel_embeddings(emb, trainable and sp == 'train')
             for nm, t in zip(CC_SLOTS, six):
                 setattr(self, '%s_%s_cc_embed' % (sp, nm), t)
+
+    def __getattr__(self, name):
+        if name.endswith('_cc_embed'):
+            sp = name.split('_', 1)[0]
+            if sp in self.__dict__.get('_lazy_cc_embed', ()):
+                self.init_all_embeddings(split=sp, trainable=False)
+                return self.__dict__[name]
+        return super().__getattr__(name)
 
     # ------------------------------------------------------------------ border sets -------
     def _sim_dir(self):
@@ -555,10 +582,14 @@ class SubGNN(nn.Module):
         return mpn_fn(self.networkx_graph, sims, cc_ids, cc_embeds, cc_embed_mask, ap, ae, am, idx)
 
     def _run_mpn_layer_fused(self, dataset_type, mpn_fn, sidx, cc_embeds, cc_embed_mask, sims, layer_num, channel,
-                             inside, need_out=True):
+                             inside, need_out=True, defer=False):
         """Same layer without the (B,C,A,D) tensor: anchors are gathered inside the kernel."""
         B, C, _ = cc_embeds.shape
         E = self._table()
+        whole = getattr(sidx, '_sgnn_identity', None)
+
+        def rows_of(t):
+            return t if whole is not None and t.shape[0] == whole else t.index_select(0, sidx)
         # NP_sim is either the reference's dense (B,C,N) slab (column = anchor id - 1) or, for
         # graphs where that slab cannot exist, a dict of already-gathered (B,C,A) edge weights
         # keyed (channel tag, side, layer) -- see hotpath.py
@@ -567,23 +598,23 @@ class SubGNN(nn.Module):
             sims = sims[(channel[0].upper(), 'in' if inside else 'out', layer_num)]
         if channel == 'neighborhood':
             src = self.anchors_neigh_int if inside else self.anchors_neigh_border
-            ids = src[dataset_type][layer_num].index_select(0, sidx).reshape(B * C, -1).contiguous()
+            ids = rows_of(src[dataset_type][layer_num]).reshape(B * C, -1).contiguous()
             return mpn_fn.forward_fused(sims, cc_embeds, cc_embed_mask, src=ops.SRC_GATHER, x=E, ids=ids,
-                                        sims_per_edge=per_edge, need_out=need_out)
+                                        sims_per_edge=per_edge, need_out=need_out, defer_readout=defer)
         if channel == 'position':
             if inside:
-                ids = self.anchors_pos_int[dataset_type][layer_num].index_select(0, sidx).contiguous()
+                ids = rows_of(self.anchors_pos_int[dataset_type][layer_num]).contiguous()
                 return mpn_fn.forward_fused(sims, cc_embeds, cc_embed_mask, src=ops.SRC_GATHER, x=E, ids=ids, id_div=C,
-                                            sims_per_edge=per_edge, need_out=need_out)
+                                            sims_per_edge=per_edge, need_out=need_out, defer_readout=defer)
             ids = self.anchors_pos_ext[layer_num]
             X = ops.gather_rows(E, ids)
             return mpn_fn.forward_fused(sims, cc_embeds, cc_embed_mask, src=ops.SRC_SHARED, x=X, ids=ids,
-                                        sims_per_edge=per_edge, need_out=need_out)
+                                        sims_per_edge=per_edge, need_out=need_out, defer_readout=defer)
         patches, indices, int_rw, bor_rw = self.anchors_structure[layer_num]
         X = aps.aggregate_structure_anchor_patch(self.hparams, self.networkx_graph, self.lstm, self.node_embeddings,
                                                  patches, int_rw if inside else bor_rw, inside, self.device, table=E)
         return mpn_fn.forward_fused(sims, cc_embeds, cc_embed_mask, src=ops.SRC_SHARED, x=X,
-                                    sim_col=self._sim_col_cache[layer_num], need_out=need_out)
+                                    sim_col=self._sim_col_cache[layer_num], need_out=need_out, defer_readout=defer)
 
     def forward(self, dataset_type, N_I_cc_embed, N_B_cc_embed, S_I_cc_embed, S_B_cc_embed, P_I_cc_embed,
                 P_B_cc_embed, subgraph_ids, cc_ids, subgraph_idx, NP_sim, I_S_sim, B_S_sim):
@@ -604,6 +635,8 @@ class SubGNN(nn.Module):
         fused = hp.get('fused_forward', True)
         init_cc_embeds = self.initialize_cc_embeddings(cc_ids, hp['cc_aggregator'])
         sidx = subgraph_idx.view(-1)
+        # hotpath.full_split_batch: the batch IS the split, in order -- selecting its rows would be a copy
+        sidx._sgnn_identity = getattr(subgraph_idx, '_sgnn_identity', None)
         given = {'N_I': N_I_cc_embed, 'N_B': N_B_cc_embed, 'S_I': S_I_cc_embed, 'S_B': S_B_cc_embed,
                  'P_I': P_I_cc_embed, 'P_B': P_B_cc_embed}
         state = {}
@@ -613,6 +646,9 @@ class SubGNN(nn.Module):
         cc_embed_mask = cc_ids[:, :, 0] != config.PAD_VALUE          # (the first column only: a component is real iff it has a member)
         cc_embed_mask._sgnn_u8 = cc_embed_mask.reshape(-1).to(torch.uint8)
         bn = hp.get('batch_norm', False)
+        # without an attention read-out or a gathered head the channel outputs are consumed only as their masked sum over a
+        # subgraph's components: every piece is summed straight into its slot of the subgraph embedding
+        slots = fused and not hp.get('ff_attn', False) and not hp.get('dp_gather_embeddings', False)
         outputs = []
         for l in range(hp['n_layers']):
             for channel, tag, flag, attr in CHANNELS:
@@ -628,7 +664,7 @@ class SubGNN(nn.Module):
                     slot = tag + '_' + side
                     if fused:
                         o, p = self._run_mpn_layer_fused(dataset_type, layer[name], sidx, state[slot], cc_embed_mask,
-                                                         sims, l, channel, inside, need_out=need_out)
+                                                         sims, l, channel, inside, need_out=need_out, defer=slots)
                     else:
                         o, p = self.run_mpn_layer(dataset_type, layer[name], subgraph_ids, subgraph_idx, cc_ids,
                                                   state[slot], cc_embed_mask, sims, layer_num=l, channel=channel,
@@ -638,6 +674,9 @@ class SubGNN(nn.Module):
                     state[slot] = o
                     res[side] = (o, p)
                 outputs.extend([res['I'][pick], res['B'][pick]])
+        if slots:
+            subgraph_embedding = ops.subgraph_embedding([init_cc_embeds] + outputs, cc_embed_mask._sgnn_u8, B, C)
+            return self._head(subgraph_embedding)
         all_cc_embeds = torch.cat([init_cc_embeds] + outputs, dim=-1)
         if hp.get('dp_gather_embeddings', False):
             # data parallelism over subgraph shards: the one exchange of the data path.  Every rank has
@@ -657,13 +696,20 @@ class SubGNN(nn.Module):
             subgraph_embedding = subgraph_utils.weighted_sum(all_cc_embeds, attn_weights)
         else:
             subgraph_embedding = subgraph_utils.masked_sum(all_cc_embeds, cc_embed_mask.unsqueeze(-1), dim=1)
+        return self._head(subgraph_embedding)
+
+    def _head(self, subgraph_embedding):
+        """S.py:304-312."""
         h = self.lin_dropout(F.relu(ops.linear(subgraph_embedding, self.lin.weight, self.lin.bias)))
         h = self.lin_dropout2(F.relu(ops.linear(h, self.lin2.weight, self.lin2.bias)))
         return ops.linear(h, self.lin3.weight, self.lin3.bias)
 
     # ------------------------------------------------------------------ steps -------------
     def _forward_batch(self, split, batch):
-        e = {nm: getattr(self, '%s_%s_cc_embed' % (split, nm)) for nm in CC_SLOTS}
+        if self.hparams['trainable_cc']:
+            e = {nm: getattr(self, '%s_%s_cc_embed' % (split, nm)) for nm in CC_SLOTS}
+        else:                                   # not read by forward (S.py:238-247)
+            e = {nm: None for nm in CC_SLOTS}
         return self.forward(split, e['N_I'], e['N_B'], e['S_I'], e['S_B'], e['P_I'], e['P_B'], batch['subgraph_ids'],
                             batch['cc_ids'], batch['subgraph_idx'], batch['NP_sim'], batch['I_S_sim'], batch['B_S_sim'])
 

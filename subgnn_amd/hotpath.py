@@ -62,6 +62,9 @@ def _hand_over(stream, *objs):
         if isinstance(o, torch.Tensor):
             if o.is_cuda:
                 o.record_stream(stream)
+            extra = getattr(o, '_sgnn_ids32', None)
+            if extra is not None:
+                extra.record_stream(stream)
         elif isinstance(o, ops.Ragged):
             _hand_over(stream, o.ptr, o.nodes)
         elif isinstance(o, dict):
@@ -254,6 +257,7 @@ def prepare_pass(model, split='train', timer=None, shard=None, defer_dtw=False):
         if mo.get(split) is None or mo[split][0].numel() != cc_ids.numel():
             mo[split] = ops.sort_edges_by_key(cc_ids.reshape(-1).to(torch.int32), g.max_id)
         cc_ids._sgnn_member_order = mo[split]
+    cc_ids._sgnn_ids32 = cc_ids.reshape(-1).to(torch.int32)        # what the component-embedding kernel reads
     base = shard.start if shard is not None else 0             # global number of this rank's first subgraph
     cc_sets = ops.Ragged.from_padded(cc_ids.reshape(S * C, Lc))
     real = (cc_ids[:, :, 0] != 0)
@@ -453,7 +457,7 @@ def install_pass(model, st, timer=None):
     if getattr(model, '_table_sync', None) is not None:
         model._table_sync()
         t.mark('table_all_gather_wait')
-    model.init_all_embeddings(split=st.split, trainable=model.hparams['trainable_cc'])
+    model.init_all_embeddings(split=st.split, trainable=model.hparams['trainable_cc'], lazy=True)
     t.mark('cc_embed')
     model._bump_generation()
     return t
@@ -521,6 +525,16 @@ def _device_labels(model, split):
     return cache[split][1]
 
 
+def _whole_split_index(model, S):
+    """arange(S) as the (S, 1) ``subgraph_idx`` of a batch, kept, and marked as the identity selection."""
+    memo = model.__dict__.setdefault('_whole_split_idx', {})
+    if S not in memo:
+        idx = torch.arange(S, device=model.device).view(-1, 1)
+        idx._sgnn_identity = S
+        memo[S] = idx
+    return memo[S]
+
+
 def full_split_batch(model, split):
     """The whole split as one batch (the large-shard launch shape of the benchmark)."""
     S = getattr(model, split + '_cc_ids').shape[0]
@@ -529,5 +543,5 @@ def full_split_batch(model, split):
             'N_border': None, 'NP_sim': getattr(model, split + '_neigh_pos_similarities'),
             'I_S_sim': getattr(model, split + '_int_struc_similarities'),
             'B_S_sim': getattr(model, split + '_bor_struc_similarities'),
-            'subgraph_idx': torch.arange(S, device=dev).view(-1, 1),
+            'subgraph_idx': _whole_split_index(model, S),
             'label': _device_labels(model, split)}

@@ -1198,7 +1198,7 @@ class ZeroSims:
 SHARED_GEMM_MIN_ROWS = 4096
 
 
-def _mpn_shared_gemm(x, wp, bp, sims2, ids, row_mask, sim_col, sims_per_edge, R, A):
+def _mpn_shared_gemm(x, wp, bp, sims2, ids, row_mask, sim_col, sims_per_edge, R, A, need_agg=True):
     """SRC_SHARED for shard-sized row counts: with one anchor matrix X (A, D) for all R rows the layer
     body IS a dense contraction -- agg = W X, read-out z = W * (X wp) + bp with W the (R, A) edge
     weights -- and so is its backward (dX = W^T g_agg + ...).  Plain GEMMs go to the library
@@ -1218,20 +1218,20 @@ def _mpn_shared_gemm(x, wp, bp, sims2, ids, row_mask, sim_col, sims_per_edge, R,
         edge = rm if edge is None else edge * rm
     if edge is not None:
         W = W * edge
-    agg = W @ x
+    agg = W @ x if need_agg else None          # (a layer whose updated embeddings nobody reads: read-out only)
     z = _ReadoutShared.apply(W, x @ wp.view(-1), bp)
     return agg, z
 
 
 def mpn(x, wp, bp, sims, *, src, R, A, ids=None, id_div=1, edge_mask=None, row_mask=None, sim_col=None,
-        sims_per_edge=False):
+        sims_per_edge=False, need_agg=True):
     """Fused anchor->component layer body.  x: DENSE (R,A,D) | GATHER E (rows,D) | SHARED (A,D).
     Returns agg (R,D) and the pre-activation read-out z (R,A)."""
     sims2 = sims.reshape(R, -1)
     if not sims2.is_contiguous():
         sims2 = sims2.contiguous()
     if src == SRC_SHARED and A > 0 and R >= SHARED_GEMM_MIN_ROWS:
-        return _mpn_shared_gemm(x, wp, bp, sims2, ids, row_mask, sim_col, sims_per_edge, R, A)
+        return _mpn_shared_gemm(x, wp, bp, sims2, ids, row_mask, sim_col, sims_per_edge, R, A, need_agg)
     return _MPN.apply(x.contiguous(), wp.contiguous().view(-1), bp.contiguous().view(-1), sims2, ids, edge_mask,
                       row_mask, sim_col, src, id_div, sims_per_edge, R, A)
 
@@ -1263,6 +1263,105 @@ class _MaskedSum(torch.autograd.Function):
 def masked_sum(x, mask):
     """subgraph_utils.masked_sum(x, mask.unsqueeze(-1), dim=1) for x (B,C,H), mask (B,C)."""
     return _MaskedSum.apply(x.contiguous(), mask.to(torch.uint8).contiguous())
+
+
+class ReadoutPiece:
+    """The read-out of a layer over SHARED anchors (or with all-zero edge weights) that nobody has materialised yet:
+    relu(W * s + bp) with W (R, A) = similarity columns x row mask, s (A) = X wp.  ``subgraph_embedding`` sums it over a
+    subgraph's components straight into the embedding's column slot (sgnn_readout_sum_fwd); ``dense()`` is the (B, C, A)
+    tensor for a consumer that wants it (attention read-out, gathered heads)."""
+
+    def __init__(self, sims2, sim_col, s, bp, A, row_mask, R):
+        self.sims2, self.sim_col, self.s, self.bp, self.A, self.row_mask, self.R = sims2, sim_col, s, bp, int(A), row_mask, int(R)
+
+    def dense(self, B, C):
+        if self.sims2 is None:
+            return torch.relu(self.bp.view(1, 1, 1).expand(B, C, self.A))
+        W = self.sims2.index_select(1, self.sim_col) if self.sim_col is not None else self.sims2[:, :self.A]
+        if self.row_mask is not None:
+            W = W * (self.row_mask != 0).to(W.dtype).view(-1, 1)
+        return torch.relu(_ReadoutShared.apply(W, self.s, self.bp)).view(B, C, self.A)
+
+
+class _SubgraphEmbedding(torch.autograd.Function):
+    """(B, H) subgraph embedding = [masked sum over components of every piece], written slot by slot: no (B, C, H)
+    concatenation (S.py:286-312).  pieces: tensors (B, C, w) and ReadoutPiece objects; tensors: the differentiable
+    inputs in piece order (x | s, bp)."""
+
+    @staticmethod
+    def forward(ctx, mask, B, C, pieces, *tensors):
+        lib = _lib.load()
+        _req(mask, torch.uint8, 'mask')
+        widths = [p.A if isinstance(p, ReadoutPiece) else p.shape[-1] for p in pieces]
+        H = sum(widths)
+        out = torch.empty((B, H), dtype=torch.float32, device=mask.device)
+        off, k, plan = 0, 0, []
+        for p, w in zip(pieces, widths):
+            dst = ctypes.c_void_p(out.data_ptr() + 4 * off)
+            if isinstance(p, ReadoutPiece):
+                s, bp = tensors[k], tensors[k + 1]
+                _req(s, torch.float32, 's'), _req(bp, torch.float32, 'bp'), _req(p.sims2, torch.float32, 'sims')
+                _req(p.sim_col, torch.int64, 'sim_col'), _req(p.row_mask, torch.uint8, 'row_mask')
+                if p.R != B * C or s.numel() != w:
+                    raise ValueError('read-out piece: %d rows for B C = %d, %d scores for %d anchors' % (p.R, B * C, s.numel(), w))
+                ld = p.sims2.shape[1] if p.sims2 is not None else 0
+                check(lib.sgnn_readout_sum_fwd(_ptr(p.sims2), ld, _ptr(p.sim_col), _ptr(s), _ptr(bp), _ptr(p.row_mask), B, C, w,
+                                               dst, H, _stream()), 'sgnn_readout_sum_fwd')
+                plan.append(('r', off, w, k, p))
+                k += 2
+            else:
+                x = tensors[k]
+                _req(x, torch.float32, 'piece')
+                if tuple(x.shape) != (B, C, w):
+                    raise ValueError('piece %s for (B, C) = (%d, %d)' % (tuple(x.shape), B, C))
+                check(lib.sgnn_masked_sum_slot_fwd(_ptr(x), _ptr(mask), B, C, w, dst, H, _stream()), 'sgnn_masked_sum_slot_fwd')
+                plan.append(('x', off, w, k, None))
+                k += 1
+            off += w
+        ctx.plan, ctx.dims = plan, (B, C, H)
+        ctx.save_for_backward(mask, *tensors)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        mask, *tensors = ctx.saved_tensors
+        B, C, H = ctx.dims
+        g = g.contiguous()
+        grads = [None] * len(tensors)
+        for kind, off, w, k, p in ctx.plan:
+            src = ctypes.c_void_p(g.data_ptr() + 4 * off)
+            if kind == 'x':
+                if ctx.needs_input_grad[4 + k]:
+                    gx = torch.empty((B, C, w), dtype=torch.float32, device=g.device)
+                    check(lib.sgnn_masked_sum_slot_bwd(src, H, _ptr(mask), B, C, w, _ptr(gx), _stream()), 'sgnn_masked_sum_slot_bwd')
+                    grads[k] = gx
+                continue
+            s, bp = tensors[k], tensors[k + 1]
+            need_s, need_b = ctx.needs_input_grad[4 + k], ctx.needs_input_grad[5 + k]
+            if not (need_s or need_b):
+                continue
+            gs = torch.empty(w, dtype=torch.float32, device=g.device) if need_s else None
+            gb = torch.empty(1, dtype=torch.float32, device=g.device) if need_b else None
+            wsb = lib.sgnn_readout_sum_bwd_workspace_bytes(B, C, w)
+            ws = torch.empty(wsb // 4 + 1, dtype=torch.float32, device=g.device)
+            ld = p.sims2.shape[1] if p.sims2 is not None else 0
+            check(lib.sgnn_readout_sum_bwd(src, H, _ptr(p.sims2), ld, _ptr(p.sim_col), _ptr(s), _ptr(bp), _ptr(p.row_mask), B, C, w,
+                                           _ptr(gs), _ptr(gb), _ptr(ws), wsb, _stream()), 'sgnn_readout_sum_bwd')
+            grads[k] = gs.view_as(s) if gs is not None else None
+            grads[k + 1] = gb.view_as(bp) if gb is not None else None
+        return (None, None, None, None) + tuple(grads)
+
+
+def subgraph_embedding(pieces, mask, B, C):
+    """cat(pieces, -1) summed over each subgraph's real components -> (B, H); mask (B C) uint8."""
+    tensors = []
+    for p in pieces:
+        if isinstance(p, ReadoutPiece):
+            tensors += [p.s.contiguous(), p.bp.contiguous().view(-1)]
+        else:
+            tensors.append(p.contiguous())
+    return _SubgraphEmbedding.apply(mask.reshape(-1).contiguous(), int(B), int(C), list(pieces), *tensors)
 
 
 class _GatherRows(torch.autograd.Function):

@@ -3,8 +3,10 @@
 Same constructor, same parameter names (``linear``, ``linear_position``: state-dict
 compatible), same ``forward`` signature and return values.  The body -- edge construction,
 similarity lookup, message = sim * x_anchor, add-aggregation per component, read-out -- is one
-HIP kernel (ops.mpn -> sgnn_mpn_fwd / sgnn_mpn_bwd); the Linear(2D -> D) + ReLU update is a
-plain GEMM left to rocBLAS through torch.
+HIP kernel (ops.mpn -> sgnn_mpn_fwd / sgnn_mpn_bwd; a shard-sized layer over SHARED anchors is a dense contraction and
+goes to the library); the Linear(2D -> D) + ReLU update is a
+fused fp32-MFMA kernel (ops.update_layer -> sgnn_update_fwd / sgnn_update_bwd; widths other than 32 / 64 / 128
+keep the library GEMM).
 """
 import torch
 import torch.nn as nn
@@ -58,21 +60,39 @@ class SG_MPN(nn.Module):
         return self._finish(cc_embeds, agg, z)
 
     def forward_fused(self, sims, cc_embeds, cc_embed_mask, *, src, x, ids=None, id_div=1, sim_col=None,
-                      sims_per_edge=False, need_out=True):
+                      sims_per_edge=False, need_out=True, defer_readout=False):
         """Fast path used by SubGNN.forward: the anchor rows are gathered inside the kernel
         (src GATHER: x = embedding table, ids (R/id_div, A)) or shared by all rows (src SHARED:
         x (A,D)), so the (B,C,A,D) tensor of get_anchor_patches is never materialised."""
         B, C, D = cc_embeds.shape
         R = B * C
         A = ids.shape[-1] if ids is not None else x.shape[0]
+        row_mask = getattr(cc_embed_mask, '_sgnn_u8', None)
+        if row_mask is None or row_mask.numel() != R:
+            row_mask = cc_embed_mask.reshape(R).to(torch.uint8).contiguous()
+        if defer_readout and not need_out and A > 0 and not self.hparams.get('norm_pos_struc_embed', False) \
+                and (isinstance(sims, ops.ZeroSims) or src == ops.SRC_SHARED):
+            # only the read-out of this layer is consumed, and only summed over a subgraph's components: it is written
+            # straight into its slot of the subgraph embedding (ops.subgraph_embedding)
+            wp, bp = self.linear_position.weight.view(-1), self.linear_position.bias
+            if isinstance(sims, ops.ZeroSims):
+                return None, ops.ReadoutPiece(None, None, torch.zeros(A, dtype=cc_embeds.dtype, device=cc_embeds.device), bp, A,
+                                              row_mask, R)
+            sims2 = sims.reshape(R, -1)
+            if not sims2.is_contiguous():
+                sims2 = sims2.contiguous()
+            s = x @ wp
+            if sim_col is None and not sims_per_edge:
+                sim_col = (ids - 1).clamp(min=0)
+            if ids is not None:
+                s = s * (ids != 0).to(s.dtype)
+            return None, ops.ReadoutPiece(sims2, sim_col, s, bp, A, row_mask, R)
         if isinstance(sims, ops.ZeroSims):          # all edge weights 0: messages vanish, read-out = bias
             agg = torch.zeros((R, D), dtype=cc_embeds.dtype, device=cc_embeds.device)
             z = self.linear_position.bias.view(1, 1).expand(R, A)
             return self._finish(cc_embeds, agg, z, need_out)
         # (SubGNN._forward converts the mask once per forward and hangs it on the tensor: one launch instead of one per layer)
-        row_mask = getattr(cc_embed_mask, '_sgnn_u8', None)
-        if row_mask is None or row_mask.numel() != R:
-            row_mask = cc_embed_mask.reshape(R).to(torch.uint8).contiguous()
         agg, z = ops.mpn(x, self.linear_position.weight, self.linear_position.bias, sims, src=src, R=R, A=A, ids=ids,
-                         id_div=id_div, row_mask=row_mask, sim_col=sim_col, sims_per_edge=sims_per_edge)
+                         id_div=id_div, row_mask=row_mask, sim_col=sim_col, sims_per_edge=sims_per_edge,
+                         need_agg=need_out)
         return self._finish(cc_embeds, agg, z, need_out)

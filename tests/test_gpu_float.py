@@ -280,6 +280,59 @@ def test_masked_sum(shape):
     assert_close(xg.grad, xc.grad, 'masked_sum grad', norm_tol=1e-6)
 
 
+@pytest.mark.parametrize('B,C,D,A1,A2', [(5, 1, 8, 7, 3), (37, 3, 30, 57, 183), (300, 2, 64, 42, 260), (1, 4, 12, 1, 33)])
+def test_subgraph_embedding_slots_equal_cat_and_masked_sum(B, C, D, A1, A2):
+    """ops.subgraph_embedding (component-embedding pieces + deferred shared-anchor read-outs, each summed into its column
+    slot) against the reference's tail written out in float64: relu(W * s + b) per (component, anchor), concatenation,
+    masked sum over the components (S.py:286-303, mpn:122-131).  Values and every gradient; twice -> identical bits."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(B * 131 + A2)
+    R = B * C
+    mask = torch.rand(B, C, generator=g) > 0.3
+    x0, x1 = torch.randn(B, C, D, generator=g), torch.randn(B, C, D, generator=g)
+    sims1 = torch.rand(R, A1, generator=g)                            # per-edge weights, columns in anchor order
+    wide = torch.rand(R, A2 + 9, generator=g)                         # a wider similarity row, columns picked by sim_col
+    col2 = torch.randperm(A2 + 9, generator=g)[:A2]
+    s1, s2 = torch.randn(A1, generator=g), torch.randn(A2, generator=g)
+    b1, b2, b0 = torch.randn(1, generator=g) * 0.3, torch.randn(1, generator=g) * 0.3, torch.tensor([0.2])
+    go = torch.randn(B, 2 * D + A1 + A2 + 5, generator=g)
+
+    def reference():
+        leaves = [t.double().clone().requires_grad_(True) for t in (x0, x1, s1, b1, s2, b2, b0)]
+        X0, X1, S1, B1, S2, B2, B0 = leaves
+        m = mask.double().view(B, C, 1)
+        r1 = torch.relu(sims1.double().view(B, C, A1) * S1 + B1)
+        r2 = torch.relu(wide.double()[:, col2].view(B, C, A2) * S2 + B2)
+        r0 = torch.relu(B0.view(1, 1, 1).expand(B, C, 5))              # all-zero edge weights: read-out = bias
+        out = (torch.cat([X0, r1, X1, r2, r0], dim=-1) * m).sum(1)
+        (out * go.double()).sum().backward()
+        return out, [t.grad for t in leaves]
+
+    def product():
+        leaves = [t.to(DEV).clone().requires_grad_(True) for t in (x0, x1, s1, b1, s2, b2, b0)]
+        X0, X1, S1, B1, S2, B2, B0 = leaves
+        mu8 = mask.reshape(-1).to(torch.uint8).to(DEV)
+        p1 = ops.ReadoutPiece(sims1.to(DEV), None, S1, B1, A1, mu8, R)
+        p2 = ops.ReadoutPiece(wide.to(DEV), col2.to(DEV), S2, B2, A2, mu8, R)
+        p0 = ops.ReadoutPiece(None, None, torch.zeros(5, device=DEV), B0, 5, mu8, R)
+        out = ops.subgraph_embedding([X0, p1, X1, p2, p0], mu8, B, C)
+        (out * go.to(DEV)).sum().backward()
+        dense = torch.cat([p1.dense(B, C), p2.dense(B, C), p0.dense(B, C)], dim=-1)
+        return out, [t.grad for t in leaves], dense
+
+    ref, ref_g = reference()
+    out, out_g, dense = product()
+    assert_close(out, ref.float(), 'subgraph embedding', norm_tol=1e-6)
+    for nm, a, b in zip(('x0', 'x1', 's1', 'b1', 's2', 'b2', 'b0'), out_g, ref_g):
+        assert_close(a, b.float(), 'subgraph embedding grad ' + nm, tol=2e-4, norm_tol=1e-5)
+    # the materialised form of a deferred piece (attention read-out, gathered head) is the same read-out
+    m = mask.view(B, C, 1).to(DEV)
+    off = D
+    assert_close((dense[..., :A1] * m).sum(1), out[:, off:off + A1], 'dense piece 1', norm_tol=1e-6)
+    out2, out_g2, _ = product()
+    assert torch.equal(out, out2) and all(torch.equal(a, b) for a, b in zip(out_g, out_g2))
+
+
 def test_missing_library_fails_loudly(monkeypatch):
     """No silent CPU fallback: a CPU tensor is rejected, and so is a missing library."""
     ops = _ops()
