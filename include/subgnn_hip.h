@@ -473,6 +473,19 @@ int sgnn_masked_sum_slot_fwd(const float* x, const uint8_t* mask, int64_t B, int
                              int64_t out_ld, void* stream);
 int sgnn_masked_sum_slot_bwd(const float* grad_out, int64_t grad_ld, const uint8_t* mask, int64_t B, int64_t C,
                              int64_t W, float* grad_x, void* stream);
+/* ---------------------------------------------------------------------------------------
+ * a17  Loss + accuracy of a step: nn.CrossEntropyLoss() with its default mean reduction (SubGNN/SubGNN.py:133, applied
+ * at SubGNN.py:1116-1124) and subgraph_utils.calc_accuracy (SubGNN/subgraph_utils.py:108-124: argmax == label, mean)
+ * in one pass over logits (B, K) row-major, labels int64 (B) in [0, K).  lse (B): the rows' log-sum-exp, kept for the
+ * backward.  loss, accuracy: one float each (accuracy nullable).  grad_logits = (softmax - onehot) * grad_loss[0] / B.
+ * Partial sums are added in a fixed order: bit-reproducible.
+ * ------------------------------------------------------------------------------------- */
+int64_t sgnn_cross_entropy_workspace_bytes(int64_t B);
+int sgnn_cross_entropy_fwd(const float* logits, const int64_t* labels, int64_t B, int64_t K, float* lse, float* loss,
+                           float* accuracy, void* workspace, int64_t workspace_bytes, void* stream);
+int sgnn_cross_entropy_bwd(const float* logits, const int64_t* labels, const float* lse, const float* grad_loss,
+                           int64_t B, int64_t K, float* grad_logits, void* stream);
+
 int sgnn_readout_sum_fwd(const float* sims, int64_t sims_ld, const int64_t* sim_col, const float* s, const float* bp,
                          const uint8_t* row_mask, int64_t B, int64_t C, int64_t A, float* out, int64_t out_ld,
                          void* stream);

@@ -582,7 +582,7 @@ class SubGNN(nn.Module):
         return mpn_fn(self.networkx_graph, sims, cc_ids, cc_embeds, cc_embed_mask, ap, ae, am, idx)
 
     def _run_mpn_layer_fused(self, dataset_type, mpn_fn, sidx, cc_embeds, cc_embed_mask, sims, layer_num, channel,
-                             inside, need_out=True, defer=False):
+                             inside, need_out=True, defer=False, need_pos=True):
         """Same layer without the (B,C,A,D) tensor: anchors are gathered inside the kernel."""
         B, C, _ = cc_embeds.shape
         E = self._table()
@@ -598,23 +598,30 @@ class SubGNN(nn.Module):
             sims = sims[(channel[0].upper(), 'in' if inside else 'out', layer_num)]
         if channel == 'neighborhood':
             src = self.anchors_neigh_int if inside else self.anchors_neigh_border
-            ids = rows_of(src[dataset_type][layer_num]).reshape(B * C, -1).contiguous()
+            anchors = src[dataset_type][layer_num]
+            ids = rows_of(anchors).reshape(B * C, -1).contiguous()
+            # (hotpath.prepare_pass: the gradient-independent half of this layer's table-gradient scatter, for these anchors)
+            plan = self.__dict__.get('_mpn_edge_plans', {}).get(dataset_type, {}).get(('N', inside, layer_num))
+            if plan is not None and not (whole is not None and plan['anchors'] is anchors and per_edge):
+                plan = None
             return mpn_fn.forward_fused(sims, cc_embeds, cc_embed_mask, src=ops.SRC_GATHER, x=E, ids=ids,
-                                        sims_per_edge=per_edge, need_out=need_out, defer_readout=defer)
+                                        sims_per_edge=per_edge, need_out=need_out, defer_readout=defer, need_pos=need_pos,
+                                        edge_plan=plan)
         if channel == 'position':
             if inside:
                 ids = rows_of(self.anchors_pos_int[dataset_type][layer_num]).contiguous()
                 return mpn_fn.forward_fused(sims, cc_embeds, cc_embed_mask, src=ops.SRC_GATHER, x=E, ids=ids, id_div=C,
-                                            sims_per_edge=per_edge, need_out=need_out, defer_readout=defer)
+                                            sims_per_edge=per_edge, need_out=need_out, defer_readout=defer, need_pos=need_pos)
             ids = self.anchors_pos_ext[layer_num]
             X = ops.gather_rows(E, ids)
             return mpn_fn.forward_fused(sims, cc_embeds, cc_embed_mask, src=ops.SRC_SHARED, x=X, ids=ids,
-                                        sims_per_edge=per_edge, need_out=need_out, defer_readout=defer)
+                                        sims_per_edge=per_edge, need_out=need_out, defer_readout=defer, need_pos=need_pos)
         patches, indices, int_rw, bor_rw = self.anchors_structure[layer_num]
         X = aps.aggregate_structure_anchor_patch(self.hparams, self.networkx_graph, self.lstm, self.node_embeddings,
                                                  patches, int_rw if inside else bor_rw, inside, self.device, table=E)
         return mpn_fn.forward_fused(sims, cc_embeds, cc_embed_mask, src=ops.SRC_SHARED, x=X,
-                                    sim_col=self._sim_col_cache[layer_num], need_out=need_out, defer_readout=defer)
+                                    sim_col=self._sim_col_cache[layer_num], need_out=need_out, defer_readout=defer,
+                                    need_pos=need_pos)
 
     def forward(self, dataset_type, N_I_cc_embed, N_B_cc_embed, S_I_cc_embed, S_B_cc_embed, P_I_cc_embed,
                 P_B_cc_embed, subgraph_ids, cc_ids, subgraph_idx, NP_sim, I_S_sim, B_S_sim):
@@ -664,7 +671,7 @@ class SubGNN(nn.Module):
                     slot = tag + '_' + side
                     if fused:
                         o, p = self._run_mpn_layer_fused(dataset_type, layer[name], sidx, state[slot], cc_embed_mask,
-                                                         sims, l, channel, inside, need_out=need_out, defer=slots)
+                                                         sims, l, channel, inside, need_out=need_out, defer=slots, need_pos=pick == 1)
                     else:
                         o, p = self.run_mpn_layer(dataset_type, layer[name], subgraph_ids, subgraph_idx, cc_ids,
                                                   state[slot], cc_embed_mask, sims, layer_num=l, channel=channel,
@@ -723,6 +730,12 @@ class SubGNN(nn.Module):
     def training_step(self, train_batch, batch_idx):
         labels = train_batch['label'].squeeze(-1)
         logits = self._forward_batch('train', train_batch)
+        if not self.multilabel and logits.is_cuda and logits.dim() == 2 and labels.dim() == 1 and logits.dtype == torch.float32 \
+                and type(self.loss) is nn.CrossEntropyLoss and self.hparams.get('fused_forward', True):
+            # cross entropy + accuracy in one pass over the logits (ops.cross_entropy_with_accuracy): the library's nll
+            # reduction runs on one workgroup (48 us at 50k rows) and the pair is 12 launches
+            loss, acc = ops.cross_entropy_with_accuracy(logits, labels)
+            return {'loss': loss, 'log': {'train_loss': loss, 'train_acc': acc}}
         loss, labels = self._loss(logits, labels)
         acc = subgraph_utils.calc_accuracy(logits, labels, multilabel_binarizer=self.multilabel_binarizer)
         return {'loss': loss, 'log': {'train_loss': loss, 'train_acc': acc}}

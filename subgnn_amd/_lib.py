@@ -90,6 +90,9 @@ SIGNATURES = {
     'sgnn_masked_sum_slot_fwd': (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_i64, c_ptr, c_i64, c_ptr]),
     'sgnn_masked_sum_slot_bwd': (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_i64, c_i64, c_ptr, c_ptr]),
     'sgnn_readout_sum_fwd': (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_ptr, c_i64, c_ptr]),
+    'sgnn_cross_entropy_workspace_bytes': (c_i64, [c_i64]),
+    'sgnn_cross_entropy_fwd': (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr]),
+    'sgnn_cross_entropy_bwd': (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr]),
     'sgnn_readout_sum_bwd_workspace_bytes': (c_i64, [c_i64, c_i64, c_i64]),
     'sgnn_readout_sum_bwd': (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_ptr, c_ptr,
                                      c_ptr, c_i64, c_ptr]),

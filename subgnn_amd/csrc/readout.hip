@@ -15,109 +15,157 @@
 // row-block partials, then one workgroup adds them in block order -- no atomics, bit-reproducible.
 #include "common.h"
 
-#define RO_ROWS_PER_BLOCK 128
+#define RO_ROWS_PER_BLOCK 64
+#define RO_TA 64                       // column lanes of a workgroup (one wavefront reads 256 consecutive bytes of a row)
+#define RO_TR 4                        // row lanes
 
 // ------------------------------------------------------------------------------------------------------------------
+// a thread owns four (subgraph, anchor) elements a quarter of the grid apart: their loads are independent and in flight
+// together (one element per thread was latency-bound: 45 us for 50k x 183, a wavefront's life being one load round trip)
 __global__ __launch_bounds__(256) void readout_sum_fwd_kernel(const float* __restrict__ sims, int64_t ld,
                                                               const int64_t* __restrict__ sim_col, const float* __restrict__ s,
                                                               const float* __restrict__ bp, const uint8_t* __restrict__ row_mask,
-                                                              int64_t B, int64_t C, int64_t A, float* __restrict__ out, int64_t out_ld)
+                                                              int64_t B, int32_t C, int32_t A, float* __restrict__ out, int64_t out_ld)
 {
-    const int64_t total = B * A;
+    const int64_t total = B * A, T = (int64_t)gridDim.x * 256;
+    const int64_t t0 = blockIdx.x * 256ll + threadIdx.x;
     const float bb = bp[0];
-    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t b = t / A, a = t - b * A;
-        const float sa = s[a];
-        const int64_t col = sim_col ? sim_col[a] : a;
-        float acc = 0.f;
-        for (int64_t c = 0; c < C; ++c) {
-            const int64_t r = b * C + c;
-            if (row_mask && !row_mask[r]) continue;
-            const float w = sims ? sims[r * ld + col] : 0.f;
-            acc += fmaxf(fmaf(w, sa, bb), 0.f);
-        }
-        out[b * out_ld + a] = acc;
+    int64_t b[4], col[4];
+    int32_t a[4];
+    float sa[4], acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int64_t t = t0 + j * T;
+        const bool on = t < total;
+        b[j] = on ? t / A : -1;
+        a[j] = on ? (int32_t)(t - b[j] * A) : 0;
+        sa[j] = s[a[j]];
+        col[j] = sim_col ? sim_col[a[j]] : a[j];
+        acc[j] = 0.f;
     }
+    for (int32_t c = 0; c < C; ++c) {
+        float w[4];
+        bool live[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int64_t r = b[j] * C + c;
+            live[j] = b[j] >= 0 && (!row_mask || row_mask[r]);
+            w[j] = (live[j] && sims) ? sims[r * ld + col[j]] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (live[j]) acc[j] += fmaxf(fmaf(w[j], sa[j], bb), 0.f);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (b[j] >= 0) out[b[j] * out_ld + a[j]] = acc[j];
 }
 
-// one workgroup per block of RO_ROWS_PER_BLOCK component rows; thread = (row lane tr, column lane ta); the row lanes'
-// sums are added in lane order through LDS.  partial layout [2][A][nblk] (d s, then d bp), block index fastest.
-template <int TA>
+// one workgroup per block of RO_ROWS_PER_BLOCK component rows, thread = (row lane tr, column lane ta), columns walked in
+// chunks of RO_TA; a thread's rows are loaded four at a time (independent loads in flight: the loop is latency-bound
+// otherwise -- 168 us for 50k x 183 with one dependent row per iteration).  d s: the row lanes' sums are added in lane
+// order through LDS -> partial_s [A][nblk]; d bp: all of the workgroup's terms added in a fixed order -> partial_b [nblk].
 __global__ __launch_bounds__(256) void readout_sum_bwd_partial_kernel(const float* __restrict__ g, int64_t g_ld,
                                                                       const float* __restrict__ sims, int64_t ld,
                                                                       const int64_t* __restrict__ sim_col, const float* __restrict__ s,
                                                                       const float* __restrict__ bp, const uint8_t* __restrict__ row_mask,
-                                                                      int64_t R, int64_t C, int64_t A, int64_t nblk,
-                                                                      float* __restrict__ partial)
+                                                                      int64_t R, int32_t C, int32_t A, int64_t nblk,
+                                                                      float* __restrict__ partial_s, float* __restrict__ partial_b)
 {
-    constexpr int TR = 256 / TA;
-    __shared__ float sh_s[TR][TA], sh_b[TR][TA];
-    const int ta = threadIdx.x % TA, tr = threadIdx.x / TA;
+    __shared__ float sh_s[RO_TR][RO_TA];
+    __shared__ float sh_b[256];
+    const int ta = threadIdx.x % RO_TA, tr = threadIdx.x / RO_TA;
     const int64_t blk = blockIdx.x;
-    const int64_t r0 = blk * RO_ROWS_PER_BLOCK, r1 = (r0 + RO_ROWS_PER_BLOCK < R) ? r0 + RO_ROWS_PER_BLOCK : R;
+    const int64_t r0 = blk * RO_ROWS_PER_BLOCK;
+    const int nrows = (int)((r0 + RO_ROWS_PER_BLOCK < R ? r0 + RO_ROWS_PER_BLOCK : R) - r0);
     const float bb = bp[0];
-    for (int64_t a0 = 0; a0 < A; a0 += TA) {
-        const int64_t a = a0 + ta;
-        float acc_s = 0.f, acc_b = 0.f;
+    constexpr int PER = RO_ROWS_PER_BLOCK / RO_TR;                     // rows per thread: tr, tr + TR, ...
+    // the rows' mask bits and subgraph numbers do not depend on the column chunk
+    uint32_t live = 0;
+    int32_t sub[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int i = tr + k * RO_TR;
+        if (i < nrows && (!row_mask || row_mask[r0 + i])) live |= 1u << k;
+        sub[k] = (int32_t)((uint32_t)(r0 + i) / (uint32_t)C);
+    }
+    float acc_b = 0.f;
+    for (int32_t a0 = 0; a0 < A; a0 += RO_TA) {
+        const int32_t a = a0 + ta;
+        float acc_s = 0.f;
         if (a < A) {
             const float sa = s[a];
             const int64_t col = sim_col ? sim_col[a] : a;
-            for (int64_t r = r0 + tr; r < r1; r += TR) {
-                if (row_mask && !row_mask[r]) continue;
-                const float w = sims ? sims[r * ld + col] : 0.f;
-                if (fmaf(w, sa, bb) > 0.f) {
-                    const float gz = g[(r / C) * g_ld + a];
-                    acc_s = fmaf(gz, w, acc_s);
-                    acc_b += gz;
+#pragma unroll
+            for (int k0 = 0; k0 < PER; k0 += 4) {
+                float w[4], gz[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int64_t r = r0 + tr + (k0 + j) * RO_TR;
+                    const bool on = (live >> (k0 + j)) & 1;
+                    w[j] = (on && sims) ? sims[r * ld + col] : 0.f;
+                    gz[j] = on ? g[(int64_t)sub[k0 + j] * g_ld + a] : 0.f;
                 }
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (((live >> (k0 + j)) & 1) && fmaf(w[j], sa, bb) > 0.f) {
+                        acc_s = fmaf(gz[j], w[j], acc_s);
+                        acc_b += gz[j];
+                    }
             }
         }
         sh_s[tr][ta] = acc_s;
-        sh_b[tr][ta] = acc_b;
         __syncthreads();
         if (tr == 0 && a < A) {
-            float vs = sh_s[0][ta], vb = sh_b[0][ta];
+            float vs = sh_s[0][ta];
 #pragma unroll
-            for (int k = 1; k < TR; ++k) { vs += sh_s[k][ta]; vb += sh_b[k][ta]; }
-            partial[a * nblk + blk] = vs;
-            partial[(A + a) * nblk + blk] = vb;
+            for (int k = 1; k < RO_TR; ++k) vs += sh_s[k][ta];
+            partial_s[(int64_t)a * nblk + blk] = vs;
         }
         __syncthreads();
     }
+    sh_b[threadIdx.x] = acc_b;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        float v = (sh_b[threadIdx.x] + sh_b[threadIdx.x + 64]) + (sh_b[threadIdx.x + 128] + sh_b[threadIdx.x + 192]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);          // fixed tree: the same order every run
+        if (threadIdx.x == 0) partial_b[blk] = v;
+    }
 }
 
-__device__ __forceinline__ float ro_wave_sum(float v) {          // fixed tree: the same order every run
+__device__ __forceinline__ float ro_wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
 
-// one workgroup of 16 wavefronts: wavefront w owns columns w, w + 16, ...; a lane adds every 64th block partial, the
-// wavefront's lanes are added by a fixed butterfly; d bp = the column sums added in column order per wavefront, then the
-// 16 wavefront sums in order.
-__global__ __launch_bounds__(1024) void readout_sum_bwd_finish_kernel(const float* __restrict__ partial, int64_t A, int64_t nblk,
-                                                                      float* __restrict__ grad_s, float* __restrict__ grad_bp)
+// one wavefront per column (4 per workgroup): a lane adds every 64th block partial, the lanes are added by a fixed
+// butterfly.  The workgroup after the last column group does the same for d bp.
+__global__ __launch_bounds__(256) void readout_sum_bwd_finish_kernel(const float* __restrict__ partial_s,
+                                                                     const float* __restrict__ partial_b, int32_t A, int64_t nblk,
+                                                                     float* __restrict__ grad_s, float* __restrict__ grad_bp)
 {
-    __shared__ float sh[16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float bsum = 0.f;
-    for (int64_t a = wave; a < A; a += 16) {
-        float vs = 0.f, vb = 0.f;
-        const float* ps = partial + a * nblk;
-        const float* pb = partial + (A + a) * nblk;
-        for (int64_t k = lane; k < nblk; k += 64) { vs += ps[k]; vb += pb[k]; }
-        vs = ro_wave_sum(vs);
-        vb = ro_wave_sum(vb);
-        if (lane == 0 && grad_s) grad_s[a] = vs;
-        bsum += vb;
+    const int32_t groups = (A + 3) / 4;
+    const float* p;
+    float* dst;
+    if ((int32_t)blockIdx.x < groups) {
+        const int32_t a = blockIdx.x * 4 + wave;
+        if (a >= A || !grad_s) return;
+        p = partial_s + (int64_t)a * nblk;
+        dst = grad_s + a;
+    } else {
+        if (wave != 0 || !grad_bp) return;
+        p = partial_b;
+        dst = grad_bp;
     }
-    if (lane == 0) sh[wave] = bsum;
-    __syncthreads();
-    if (threadIdx.x == 0 && grad_bp) {
-        float v = sh[0];
-        for (int k = 1; k < 16; ++k) v += sh[k];
-        grad_bp[0] = v;
-    }
+    float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;                      // four loads in flight; combined in a fixed order
+    int64_t k = lane;
+    for (; k + 192 < nblk; k += 256) { v0 += p[k]; v1 += p[k + 64]; v2 += p[k + 128]; v3 += p[k + 192]; }
+    for (; k < nblk; k += 64) v0 += p[k];
+    const float v = ro_wave_sum((v0 + v1) + (v2 + v3));
+    if (lane == 0) *dst = v;
 }
 
 extern "C" int sgnn_readout_sum_fwd(const float* sims, int64_t sims_ld, const int64_t* sim_col, const float* s, const float* bp,
@@ -125,9 +173,10 @@ extern "C" int sgnn_readout_sum_fwd(const float* sims, int64_t sims_ld, const in
                                     void* stream)
 {
     if (!s || !bp || !out || B < 0 || C < 0 || A < 0 || out_ld < A || (sims && sims_ld < 1)) return SGNN_ERR_BAD_ARG;
+    if (A > 0x7fffffff || C > 0x7fffffff || (B * A + 255) / 256 > 0x7fffffff) return SGNN_ERR_BAD_ARG;
     if (B * A == 0) return SGNN_OK;
-    hipLaunchKernelGGL(readout_sum_fwd_kernel, dim3(sgnn_grid_for(B * A, 256)), dim3(256), 0, (hipStream_t)stream, sims, sims_ld,
-                       sim_col, s, bp, row_mask, B, C, A, out, out_ld);
+    hipLaunchKernelGGL(readout_sum_fwd_kernel, dim3((unsigned)((B * A + 1023) / 1024)), dim3(256), 0, (hipStream_t)stream, sims,
+                       sims_ld, sim_col, s, bp, row_mask, B, (int32_t)C, (int32_t)A, out, out_ld);
     SGNN_CHECK_LAUNCH();
     return SGNN_OK;
 }
@@ -137,7 +186,7 @@ static inline int64_t ro_blocks(int64_t R) { return (R + RO_ROWS_PER_BLOCK - 1) 
 extern "C" int64_t sgnn_readout_sum_bwd_workspace_bytes(int64_t B, int64_t C, int64_t A)
 {
     if (B < 0 || C < 0 || A < 0) return -1;
-    return 2 * A * ro_blocks(B * C) * (int64_t)sizeof(float) + 16;
+    return (A + 1) * ro_blocks(B * C) * (int64_t)sizeof(float) + 16;
 }
 
 extern "C" int sgnn_readout_sum_bwd(const float* grad_out, int64_t grad_ld, const float* sims, int64_t sims_ld,
@@ -146,6 +195,7 @@ extern "C" int sgnn_readout_sum_bwd(const float* grad_out, int64_t grad_ld, cons
                                     void* stream)
 {
     if (!grad_out || !s || !bp || B < 0 || C < 0 || A < 0 || grad_ld < A || (sims && sims_ld < 1)) return SGNN_ERR_BAD_ARG;
+    if (A > 0x7fffffff || C > 0x7fffffff || B * C > 0x7fffffff) return SGNN_ERR_BAD_ARG;
     if (!grad_s && !grad_bp) return SGNN_OK;
     hipStream_t st = (hipStream_t)stream;
     const int64_t R = B * C;
@@ -155,17 +205,15 @@ extern "C" int sgnn_readout_sum_bwd(const float* grad_out, int64_t grad_ld, cons
         return SGNN_OK;
     }
     if (!workspace || workspace_bytes < sgnn_readout_sum_bwd_workspace_bytes(B, C, A)) return SGNN_ERR_BAD_ARG;
-    float* partial = (float*)workspace;
     const int64_t nblk = ro_blocks(R);
-#define RO_LAUNCH(TA) hipLaunchKernelGGL(readout_sum_bwd_partial_kernel<TA>, dim3((unsigned)nblk), dim3(256), 0, st, grad_out, \
-                                         grad_ld, sims, sims_ld, sim_col, s, bp, row_mask, R, C, A, nblk, partial)
-    if (A <= 32) RO_LAUNCH(32);
-    else if (A <= 64) RO_LAUNCH(64);
-    else if (A <= 128) RO_LAUNCH(128);
-    else RO_LAUNCH(256);
-#undef RO_LAUNCH
+    if (nblk > 0x7fffffff) return SGNN_ERR_BAD_ARG;
+    float* partial_s = (float*)workspace;
+    float* partial_b = partial_s + A * nblk;
+    hipLaunchKernelGGL(readout_sum_bwd_partial_kernel, dim3((unsigned)nblk), dim3(256), 0, st, grad_out, grad_ld, sims, sims_ld,
+                       sim_col, s, bp, row_mask, R, (int32_t)C, (int32_t)A, nblk, partial_s, partial_b);
     SGNN_CHECK_LAUNCH();
-    hipLaunchKernelGGL(readout_sum_bwd_finish_kernel, dim3(1), dim3(1024), 0, st, partial, A, nblk, grad_s, grad_bp);
+    hipLaunchKernelGGL(readout_sum_bwd_finish_kernel, dim3((unsigned)((A + 3) / 4 + 1)), dim3(256), 0, st, partial_s, partial_b,
+                       (int32_t)A, nblk, grad_s, grad_bp);
     SGNN_CHECK_LAUNCH();
     return SGNN_OK;
 }

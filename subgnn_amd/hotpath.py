@@ -62,9 +62,10 @@ def _hand_over(stream, *objs):
         if isinstance(o, torch.Tensor):
             if o.is_cuda:
                 o.record_stream(stream)
-            extra = getattr(o, '_sgnn_ids32', None)
-            if extra is not None:
-                extra.record_stream(stream)
+            for nm in ('_sgnn_ids32', '_sgnn_sorted'):
+                extra = getattr(o, nm, None)
+                if extra is not None:
+                    _hand_over(stream, extra)
         elif isinstance(o, ops.Ragged):
             _hand_over(stream, o.ptr, o.nodes)
         elif isinstance(o, dict):
@@ -272,6 +273,7 @@ def prepare_pass(model, split='train', timer=None, shard=None, defer_dtw=False):
     set_order = orders[split]
     sims = {}
     a_sets = ai = ae = None
+    det = bool(getattr(model, '_deterministic', ops.DETERMINISTIC))
     # ---- side stream: position channel + structure patches / walks -------------------------
     side.wait_stream(main)
     with torch.cuda.stream(side):
@@ -288,6 +290,9 @@ def prepare_pass(model, split='train', timer=None, shard=None, defer_dtw=False):
             anchors_pos_ext = getattr(model, 'anchors_pos_ext', None)
             if anchors_pos_ext is None or split != 'test':
                 anchors_pos_ext = st.attrs['anchors_pos_ext'] = aps.init_anchors_pos_ext(hp, g, dev)
+                if det:
+                    for v in anchors_pos_ext.values():
+                        ops.presort_ids(v, g.max_id)
             pint = {l: ops.choice_ragged(subs, hp['n_anchor_patches_pos_in'], seed,
                                          tape.stream_id(tape.STREAM_P_INT, split, l), item_base=base) for l in range(L)}
             st.per_split['anchors_pos_int'] = pint
@@ -347,6 +352,10 @@ def prepare_pass(model, split='train', timer=None, shard=None, defer_dtw=False):
                 int_w = st.attrs['int_structure_anchor_random_walks'] = aps.perform_random_walks(hp, g, structure_anchors, True, views)
                 a_struct = st.attrs['anchors_structure'] = aps.init_anchors_structure(hp, structure_anchors, int_w, bor_w,
                                                                                       indices_on_device=True)
+                if det:
+                    for v in a_struct.values():          # the walks' embedding lookups: their backward's sort, done here
+                        ops.presort_ids(v[2], g.max_id)
+                        ops.presort_ids(v[3], g.max_id)
                 # the column upload is a blocking host->device copy: do it here, before the long DTW
                 # launches are queued, so that the host is free to queue forward/backward behind them
                 st.sim_cols = (a_struct, model.sim_cols_of(a_struct))
@@ -360,7 +369,7 @@ def prepare_pass(model, split='train', timer=None, shard=None, defer_dtw=False):
         k = hp['neigh_sample_border_size']
         has_pad_c = (cc_sets.lengths < Lc).to(torch.uint8)
         cc_canon = ops.sort_ragged(cc_sets)                     # the draw ranks the ascending members
-        ni, nb = {}, {}
+        ni, nb, plans = {}, {}, {}
         for l in range(L):
             ni[l] = ops.sample_anchors_ragged(cc_canon, hp['n_anchor_patches_N_in'], seed,
                                               tape.stream_id(tape.STREAM_N_INT, split, l), has_pad_c,
@@ -374,7 +383,15 @@ def prepare_pass(model, split='train', timer=None, shard=None, defer_dtw=False):
                                              count_reduce=shard.reduce_max if shard is not None else None)
             nb[l] = a.view(S, C, -1)
             sims[('N', 'out', l)] = w.view(S, C, -1).contiguous()
+            D = hp['node_embed_size']
+            if det and hp.get('fused_forward', True) and D % 4 == 0 and D <= 256 and (D // 4) & (D // 4 - 1) == 0:
+                # the border layer's table gradient is a sorted scatter: its edge list and order are known here
+                plan = ops.mpn_edge_plan(sims[('N', 'out', l)], nb[l], real.reshape(-1).to(torch.uint8), R=S * C,
+                                         A=nb[l].shape[-1], D=D, max_key=g.max_id, sims_per_edge=True)
+                plan['anchors'] = nb[l]
+                plans[('N', False, l)] = plan
         st.per_split['anchors_neigh_int'], st.per_split['anchors_neigh_border'] = ni, nb
+        st.per_split['_mpn_edge_plans'] = plans
         t.mark('border_bfs+N_anchors')
     ci = ce = None
     if hp['use_structure']:

@@ -960,8 +960,9 @@ class _MPN(torch.autograd.Function):
     """agg (R,D), z (R,A) = gather-weight-aggregate + read-out; grads for x, wp (bp via z)."""
 
     @staticmethod
-    def forward(ctx, x, wp, bp, sims, ids, edge_mask, row_mask, sim_col, src, id_div, sims_per_edge, R, A):
+    def forward(ctx, x, wp, bp, sims, ids, edge_mask, row_mask, sim_col, src, id_div, sims_per_edge, R, A, edge_plan=None):
         lib = _lib.load()
+        ctx.edge_plan = edge_plan if src == SRC_GATHER else None
         _req(x, torch.float32, 'x')
         _req(wp, torch.float32, 'wp')
         _req(bp, torch.float32, 'bp')
@@ -1009,7 +1010,13 @@ class _MPN(torch.autograd.Function):
             if ctx.half is not None:
                 x._sgnn_half = ctx.half
             a = _mpn_args(src, x, ids, id_div, edge_mask, row_mask, sims, sim_col, sims_per_edge, wp, bp, R, A, D)
-            if need_x and (g_agg is not None or g_z is not None):
+            plan = ctx.edge_plan
+            if need_x and (g_agg is not None or g_z is not None) and plan is not None and plan['keys'].numel() == R * A:
+                # the static half of the edge list (target rows, weights, sorted order) came with the prepared pass
+                c2 = (plan['c1'] * g_z.reshape(-1)) if g_z is not None else None
+                scatter_add_rows(gx, plan['keys'], G=g_agg, edges_per_row=A, c1=plan['c1'], c2=c2, v=wp if c2 is not None else None,
+                                 presorted=plan['sorted'])
+            elif need_x and (g_agg is not None or g_z is not None):
                 keys = torch.empty(R * A, dtype=torch.int32, device=x.device)
                 c1 = torch.empty(R * A, dtype=torch.float32, device=x.device)
                 c2 = torch.empty(R * A, dtype=torch.float32, device=x.device) if g_z is not None else None
@@ -1046,7 +1053,7 @@ class _MPN(torch.autograd.Function):
             gwp = gwp.view_as(wp)
         if need_bp:
             gbp = g_z.sum().view_as(bp) if g_z is not None else torch.zeros_like(bp)
-        return (None if ctx.acc is not None else gx), gwp, gbp, None, None, None, None, None, None, None, None, None, None
+        return (None if ctx.acc is not None else gx), gwp, gbp, None, None, None, None, None, None, None, None, None, None, None
 
 
 def column_sum(t, chunk=512):
@@ -1223,8 +1230,23 @@ def _mpn_shared_gemm(x, wp, bp, sims2, ids, row_mask, sim_col, sims_per_edge, R,
     return agg, z
 
 
+def mpn_edge_plan(sims, ids, row_mask, *, R, A, D, max_key, id_div=1, sim_col=None, sims_per_edge=False):
+    """What the table-gradient scatter of a GATHER layer needs that does not depend on the gradients: per edge the target
+    row (0 = masked / zero weight) and the weight, and the edges' stable order by target row.  Computed with the prepared
+    pass (beside the sampling stages) instead of in the backward; handed to ``mpn(..., edge_plan=)``."""
+    lib = _lib.load()
+    sims2 = sims.reshape(R, -1).contiguous()
+    dummy = torch.zeros(max(D, 4), dtype=torch.float32, device=sims2.device)
+    ids = ids.reshape(-1, A).contiguous()
+    a = _mpn_args(SRC_GATHER, dummy, ids, id_div, None, row_mask, sims2, sim_col, sims_per_edge, dummy, dummy, R, A, D)
+    keys = torch.empty(R * A, dtype=torch.int32, device=sims2.device)
+    c1 = torch.empty(R * A, dtype=torch.float32, device=sims2.device)
+    check(lib.sgnn_mpn_bwd_edges(ctypes.byref(a), None, _ptr(keys), _ptr(c1), None, _stream()), 'sgnn_mpn_bwd_edges')
+    return {'keys': keys, 'c1': c1, 'sorted': sort_edges_by_key(keys, max_key), 'ids': ids}
+
+
 def mpn(x, wp, bp, sims, *, src, R, A, ids=None, id_div=1, edge_mask=None, row_mask=None, sim_col=None,
-        sims_per_edge=False, need_agg=True):
+        sims_per_edge=False, need_agg=True, edge_plan=None):
     """Fused anchor->component layer body.  x: DENSE (R,A,D) | GATHER E (rows,D) | SHARED (A,D).
     Returns agg (R,D) and the pre-activation read-out z (R,A)."""
     sims2 = sims.reshape(R, -1)
@@ -1233,7 +1255,7 @@ def mpn(x, wp, bp, sims, *, src, R, A, ids=None, id_div=1, edge_mask=None, row_m
     if src == SRC_SHARED and A > 0 and R >= SHARED_GEMM_MIN_ROWS:
         return _mpn_shared_gemm(x, wp, bp, sims2, ids, row_mask, sim_col, sims_per_edge, R, A, need_agg)
     return _MPN.apply(x.contiguous(), wp.contiguous().view(-1), bp.contiguous().view(-1), sims2, ids, edge_mask,
-                      row_mask, sim_col, src, id_div, sims_per_edge, R, A)
+                      row_mask, sim_col, src, id_div, sims_per_edge, R, A, edge_plan)
 
 
 class _MaskedSum(torch.autograd.Function):
@@ -1364,14 +1386,51 @@ def subgraph_embedding(pieces, mask, B, C):
     return _SubgraphEmbedding.apply(mask.reshape(-1).contiguous(), int(B), int(C), list(pieces), *tensors)
 
 
+class _CrossEntropy(torch.autograd.Function):
+    """(mean cross entropy, accuracy) of logits (B, K) against int64 labels (sgnn_cross_entropy_fwd / _bwd)."""
+
+    @staticmethod
+    def forward(ctx, logits, labels):
+        lib = _lib.load()
+        _req(logits, torch.float32, 'logits')
+        _req(labels, torch.int64, 'labels')
+        B, K = logits.shape
+        lse = torch.empty(B, dtype=torch.float32, device=logits.device)
+        res = torch.empty(2, dtype=torch.float32, device=logits.device)
+        wsb = lib.sgnn_cross_entropy_workspace_bytes(B)
+        ws = torch.empty(wsb // 4 + 1, dtype=torch.float32, device=logits.device)
+        check(lib.sgnn_cross_entropy_fwd(_ptr(logits), _ptr(labels), B, K, _ptr(lse), _ptr(res), ctypes.c_void_p(res.data_ptr() + 4),
+                                         _ptr(ws), wsb, _stream()), 'sgnn_cross_entropy_fwd')
+        ctx.save_for_backward(logits, labels, lse)
+        loss, acc = res[0], res[1:2]
+        ctx.mark_non_differentiable(acc)
+        return loss, acc
+
+    @staticmethod
+    def backward(ctx, g_loss, _g_acc):
+        lib = _lib.load()
+        logits, labels, lse = ctx.saved_tensors
+        B, K = logits.shape
+        g = torch.empty_like(logits)
+        check(lib.sgnn_cross_entropy_bwd(_ptr(logits), _ptr(labels), _ptr(lse), _ptr(g_loss.reshape(1).contiguous().float()), B, K,
+                                         _ptr(g), _stream()), 'sgnn_cross_entropy_bwd')
+        return g, None
+
+
+def cross_entropy_with_accuracy(logits, labels):
+    """nn.CrossEntropyLoss()(logits, labels) and calc_accuracy(logits, labels) -> (0-d loss, (1,) accuracy) in one pass."""
+    return _CrossEntropy.apply(logits.contiguous(), labels.contiguous())
+
+
 class _GatherRows(torch.autograd.Function):
     """``nn.Embedding(padding_idx=0)`` lookup for a handful of ids (the shared P anchors, the walks
     of the structure patches): the backward scatters the few rows with ``index_add_`` instead of
     torch's dense-embedding backward, which serialises a short id list on two workgroups."""
 
     @staticmethod
-    def forward(ctx, weight, ids):
+    def forward(ctx, weight, ids, presorted=None):
         flat = ids.reshape(-1)
+        ctx.presorted = presorted
         ctx.save_for_backward(flat)
         ctx.n_rows = weight.shape[0]
         ctx.det = _det_now()
@@ -1387,18 +1446,30 @@ class _GatherRows(torch.autograd.Function):
             g = grad.reshape(flat.numel(), -1).to(torch.float32).contiguous()
             buf = ctx.acc.buffer((ctx.n_rows, g.shape[1]), grad.device) if ctx.acc is not None else \
                 torch.zeros(ctx.n_rows, g.shape[1], dtype=torch.float32, device=grad.device)
-            scatter_add_rows(buf, flat.to(torch.int32).contiguous(), G=g, edges_per_row=1)      # key 0 = PAD: skipped
-            return (None if ctx.acc is not None else buf.to(grad.dtype)), None
+            pre = ctx.presorted
+            if pre is not None and pre[0].numel() == flat.numel():
+                scatter_add_rows(buf, pre[2], G=g, edges_per_row=1, presorted=pre[:2])
+            else:
+                scatter_add_rows(buf, flat.to(torch.int32).contiguous(), G=g, edges_per_row=1)      # key 0 = PAD: skipped
+            return (None if ctx.acc is not None else buf.to(grad.dtype)), None, None
         g = grad.reshape(flat.numel(), -1) * (flat != 0).unsqueeze(1).to(grad.dtype)     # PAD row takes no gradient
         if ctx.acc is not None:
             ctx.acc.buffer((ctx.n_rows, g.shape[1]), grad.device).index_add_(0, flat, g.to(torch.float32))
-            return None, None
-        return torch.zeros(ctx.n_rows, g.shape[1], dtype=grad.dtype, device=grad.device).index_add_(0, flat, g), None
+            return None, None, None
+        return torch.zeros(ctx.n_rows, g.shape[1], dtype=grad.dtype, device=grad.device).index_add_(0, flat, g), None, None
+
+
+def presort_ids(ids, max_key):
+    """Hang the stable order of ``ids`` by value on the tensor (``_sgnn_sorted`` = (sorted keys, order, int32 ids)): the
+    backward of ``gather_rows(table, ids)`` then skips its sort.  For id tensors that live as long as a prepared pass."""
+    k32 = ids.reshape(-1).to(torch.int32).contiguous()
+    ids._sgnn_sorted = sort_edges_by_key(k32, max_key) + (k32,)
+    return ids
 
 
 def gather_rows(weight, ids):
     """weight[ids] with the PAD row (id 0) excluded from the gradient (aps:404-411 embed_anchor_patch)."""
-    return _GatherRows.apply(weight, ids.to(torch.int64))
+    return _GatherRows.apply(weight, ids.to(torch.int64), getattr(ids, '_sgnn_sorted', None))
 
 
 class _BiLSTMLayer(torch.autograd.Function):

@@ -24,7 +24,7 @@ class SG_MPN(nn.Module):
         self.linear_position = nn.Linear(D, 1)
 
     # -- shared tail: update() and the read-out non-linearity (mpn:122-131, 233-241) -------
-    def _finish(self, cc_embeds, agg, z, need_out=True):
+    def _finish(self, cc_embeds, agg, z, need_out=True, need_pos=True):
         B, C, D = cc_embeds.shape
         if not need_out:
             # the caller reads only the position read-out of this layer (the last layer of the position / structure
@@ -35,6 +35,8 @@ class SG_MPN(nn.Module):
             out = ops.update_layer(cc_embeds.reshape(B * C, D), agg, self.linear.weight, self.linear.bias)
         else:
             out = agg
+        if not need_pos:                     # the neighbourhood channel hands on its component embeddings only
+            return (out.view(B, C, -1) if out is not None else None), None
         z = z.view(B, C, -1)
         if self.hparams.get('norm_pos_struc_embed', False):
             pos = F.normalize(z, p=2, dim=-1)
@@ -60,7 +62,7 @@ class SG_MPN(nn.Module):
         return self._finish(cc_embeds, agg, z)
 
     def forward_fused(self, sims, cc_embeds, cc_embed_mask, *, src, x, ids=None, id_div=1, sim_col=None,
-                      sims_per_edge=False, need_out=True, defer_readout=False):
+                      sims_per_edge=False, need_out=True, defer_readout=False, need_pos=True, edge_plan=None):
         """Fast path used by SubGNN.forward: the anchor rows are gathered inside the kernel
         (src GATHER: x = embedding table, ids (R/id_div, A)) or shared by all rows (src SHARED:
         x (A,D)), so the (B,C,A,D) tensor of get_anchor_patches is never materialised."""
@@ -90,9 +92,9 @@ class SG_MPN(nn.Module):
         if isinstance(sims, ops.ZeroSims):          # all edge weights 0: messages vanish, read-out = bias
             agg = torch.zeros((R, D), dtype=cc_embeds.dtype, device=cc_embeds.device)
             z = self.linear_position.bias.view(1, 1).expand(R, A)
-            return self._finish(cc_embeds, agg, z, need_out)
+            return self._finish(cc_embeds, agg, z, need_out, need_pos)
         # (SubGNN._forward converts the mask once per forward and hangs it on the tensor: one launch instead of one per layer)
         agg, z = ops.mpn(x, self.linear_position.weight, self.linear_position.bias, sims, src=src, R=R, A=A, ids=ids,
                          id_div=id_div, row_mask=row_mask, sim_col=sim_col, sims_per_edge=sims_per_edge,
-                         need_agg=need_out)
-        return self._finish(cc_embeds, agg, z, need_out)
+                         need_agg=need_out, edge_plan=edge_plan)
+        return self._finish(cc_embeds, agg, z, need_out, need_pos)

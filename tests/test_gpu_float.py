@@ -333,6 +333,31 @@ def test_subgraph_embedding_slots_equal_cat_and_masked_sum(B, C, D, A1, A2):
     assert torch.equal(out, out2) and all(torch.equal(a, b) for a, b in zip(out_g, out_g2))
 
 
+@pytest.mark.parametrize('B,K', [(1, 2), (77, 3), (5000, 5), (50000, 3)])
+def test_cross_entropy_with_accuracy_matches_torch(B, K):
+    """sgnn_cross_entropy_fwd/_bwd against nn.CrossEntropyLoss() + calc_accuracy (S.py:133, su:108-124) in float64."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(B + K)
+    x = torch.randn(B, K, generator=g) * 3
+    x[::7] = x[::7].round()                                     # ties between classes: argmax takes the first maximum
+    y = torch.randint(0, K, (B,), generator=g)
+    xr = x.double().clone().requires_grad_(True)
+    ref = F.cross_entropy(xr, y)
+    (ref * 1.7).backward()
+    acc_ref = (torch.argmax(x, 1) == y).float().mean()
+    xg = x.to(DEV).requires_grad_(True)
+    loss, acc = ops.cross_entropy_with_accuracy(xg, y.to(DEV))
+    (loss * 1.7).backward()
+    assert loss.dim() == 0 and acc.shape == (1,) and not acc.requires_grad
+    assert abs(float(loss) - float(ref)) <= 1e-5 * max(1.0, abs(float(ref)))
+    assert abs(float(acc) - float(acc_ref)) <= 1e-6
+    assert_close(xg.grad, xr.grad.float(), 'cross entropy grad', tol=2e-4, norm_tol=1e-6)
+    x2 = x.to(DEV).requires_grad_(True)
+    l2, _ = ops.cross_entropy_with_accuracy(x2, y.to(DEV))
+    (l2 * 1.7).backward()
+    assert torch.equal(l2, loss) and torch.equal(x2.grad, xg.grad)
+
+
 def test_missing_library_fails_loudly(monkeypatch):
     """No silent CPU fallback: a CPU tensor is rejected, and so is a missing library."""
     ops = _ops()
