@@ -553,8 +553,25 @@ int sgnn_update_bwd(const float* grad_out, const float* out, const float* x, con
  * zero_grad != 0: the gradient is zeroed in the same pass (the buffer can be handed out again without a fill).
  * All four arrays float32[n], 16-byte aligned.
  * ------------------------------------------------------------------------------------- */
+/* a18b  The caller's clip_grad_norm_ (train_config.py: Trainer(gradient_clip_val) -> torch.nn.utils.clip_grad_norm_):
+ * coefficient = min(1, max_norm / (total + 1e-6)), total = 2-norm over all gradients.  sgnn_grad_sumsq: sums of squares of
+ * one large float32 gradient (16-byte aligned) as sgnn_grad_sumsq_partials() per-workgroup values; sgnn_clip_coefficient adds
+ * them (any number of such arrays laid end to end) and the squares of other_norms (the small parameters' 2-norms) in a fixed
+ * order and writes the DEVICE scalars coef (for sgnn_adam_step's grad_scale) and total_norm (nullable). */
+int64_t sgnn_grad_sumsq_partials(void);
+int sgnn_grad_sumsq(const float* grad, int64_t n, float* partial, void* stream);
+int sgnn_clip_coefficient(const float* partial, int64_t n_partial, const float* other_norms, int64_t n_other,
+                          float max_norm, float* coef, float* total_norm, void* stream);
+
 int sgnn_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
                    float beta2, float eps, int64_t step, const float* grad_scale, int zero_grad, void* stream);
+/* The same with the step count in DEVICE memory (int64, starts at 0): incremented on the stream right before the update, read by
+ * the update for its bias corrections -- the form a step recorded into a hipGraph replays (a host counter would be frozen at
+ * its value at recording time). */
+int sgnn_adam_step_counted(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
+                           float beta2, float eps, int64_t* step_counter, const float* grad_scale, int zero_grad,
+                           void* stream);
+
 
 /* ---------------------------------------------------------------------------------------
  * Measurement aid (no reference counterpart): streaming copy of n_bytes with 4 or 16 bytes per lane.

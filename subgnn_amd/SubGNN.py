@@ -616,12 +616,29 @@ class SubGNN(nn.Module):
             X = ops.gather_rows(E, ids)
             return mpn_fn.forward_fused(sims, cc_embeds, cc_embed_mask, src=ops.SRC_SHARED, x=X, ids=ids,
                                         sims_per_edge=per_edge, need_out=need_out, defer_readout=defer, need_pos=need_pos)
-        patches, indices, int_rw, bor_rw = self.anchors_structure[layer_num]
-        X = aps.aggregate_structure_anchor_patch(self.hparams, self.networkx_graph, self.lstm, self.node_embeddings,
-                                                 patches, int_rw if inside else bor_rw, inside, self.device, table=E)
+        X = self._structure_anchor_embeddings(layer_num, E)[0 if inside else 1]
         return mpn_fn.forward_fused(sims, cc_embeds, cc_embed_mask, src=ops.SRC_SHARED, x=X,
                                     sim_col=self._sim_col_cache[layer_num], need_out=need_out, defer_readout=defer,
                                     need_pos=need_pos)
+
+    def _structure_anchor_embeddings(self, layer_num, E):
+        """aps:413-433 for the internal and the border walks of a layer's structure patches in ONE pass over the LSTM (same
+        parameters, independent sequences): (X_internal, X_border), each (patches, D); kept for the forward in progress."""
+        cache = self.__dict__.get('_fwd_cache')
+        key = ('S_X', layer_num)
+        if cache is not None and key in cache:
+            return cache[key]
+        patches, indices, int_rw, bor_rw = self.anchors_structure[layer_num]
+        n = patches.shape[0]
+        both = getattr(int_rw, '_sgnn_both', None)               # hotpath.prepare_pass: stacked, with the lookup's sort
+        if both is None or both.shape[0] != 2 * n or both.device != E.device:
+            both = torch.cat([int_rw.to(self.device), bor_rw.to(self.device)], 0)
+        X = aps.aggregate_structure_anchor_patch(self.hparams, self.networkx_graph, self.lstm, self.node_embeddings, both, both,
+                                                 None, self.device, table=E)
+        out = (X[:n], X[n:])
+        if cache is not None:
+            cache[key] = out
+        return out
 
     def forward(self, dataset_type, N_I_cc_embed, N_B_cc_embed, S_I_cc_embed, S_B_cc_embed, P_I_cc_embed,
                 P_B_cc_embed, subgraph_ids, cc_ids, subgraph_idx, NP_sim, I_S_sim, B_S_sim):
@@ -629,12 +646,14 @@ class SubGNN(nn.Module):
         hp = self.hparams
         fused = hp.get('fused_forward', True)
         self.__dict__['_tapped_table'] = ops.tap_table(self.node_embeddings.weight, self._half_table()) if fused else None
+        self.__dict__['_fwd_cache'] = {}
         try:
             with ops.deterministic(self._deterministic):
                 return self._forward(dataset_type, N_I_cc_embed, N_B_cc_embed, S_I_cc_embed, S_B_cc_embed, P_I_cc_embed,
                                      P_B_cc_embed, subgraph_ids, cc_ids, subgraph_idx, NP_sim, I_S_sim, B_S_sim)
         finally:
             self.__dict__['_tapped_table'] = None
+            self.__dict__['_fwd_cache'] = None
 
     def _forward(self, dataset_type, N_I_cc_embed, N_B_cc_embed, S_I_cc_embed, S_B_cc_embed, P_I_cc_embed,
                  P_B_cc_embed, subgraph_ids, cc_ids, subgraph_idx, NP_sim, I_S_sim, B_S_sim):

@@ -90,6 +90,9 @@ SIGNATURES = {
     'sgnn_masked_sum_slot_fwd': (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_i64, c_ptr, c_i64, c_ptr]),
     'sgnn_masked_sum_slot_bwd': (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_i64, c_i64, c_ptr, c_ptr]),
     'sgnn_readout_sum_fwd': (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_ptr, c_i64, c_ptr]),
+    'sgnn_grad_sumsq_partials': (c_i64, []),
+    'sgnn_grad_sumsq': (c_int, [c_ptr, c_i64, c_ptr, c_ptr]),
+    'sgnn_clip_coefficient': (c_int, [c_ptr, c_i64, c_ptr, c_i64, ctypes.c_float, c_ptr, c_ptr, c_ptr]),
     'sgnn_cross_entropy_workspace_bytes': (c_i64, [c_i64]),
     'sgnn_cross_entropy_fwd': (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr]),
     'sgnn_cross_entropy_bwd': (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr]),
@@ -102,6 +105,8 @@ SIGNATURES = {
     'sgnn_mpn_bwd_shared_det': (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr]),
     'sgnn_adam_step': (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float,
                                c_i64, c_ptr, c_int, c_ptr]),
+    'sgnn_adam_step_counted': (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, ctypes.c_float, ctypes.c_float, ctypes.c_float,
+                                       ctypes.c_float, c_ptr, c_ptr, c_int, c_ptr]),
     'sgnn_update_fwd': (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr]),
     'sgnn_update_bwd_workspace_bytes': (c_i64, [c_i64, c_i64]),
     'sgnn_update_bwd': (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr]),

@@ -79,9 +79,11 @@ def perform_random_walks(hparams, networkx_graph, anchor_patch_ids, inside, view
     return out.view(P, W, T)
 
 
-def sample_structure_anchor_patches(hparams, networkx_graph, device, max_sim_epochs):
+def sample_structure_anchor_patches(hparams, networkx_graph, device, max_sim_epochs, trim=True):
     """aps:210-243 -> (n sampled patches, max patch length) int64 (trailing all-PAD columns
-    trimmed, as padding to the longest patch does in the reference).
+    trimmed, as padding to the longest patch does in the reference; ``trim=False`` keeps the walks' full width -- the
+    longest patch is a value on the device, and reading it makes the host wait for everything queued on the stream:
+    the per-pass path does without, its consumers strip PAD entries themselves).
     'triangular_random_walk': every patch is a walk of sample_walk_len steps over the whole graph.
     'ego_graph' (aps:226-228): patch i = the nodes within structure_anchor_patch_radius hops of the i-th
     start node (the starts are one np.random.choice over the graph's nodes: tape item 0, draw i), centre
@@ -111,6 +113,8 @@ def sample_structure_anchor_patches(hparams, networkx_graph, device, max_sim_epo
         out = torch.where(srt == big, torch.zeros_like(srt), g.node_order[(srt - 1).clamp(min=0, max=g.n_nodes - 1)].long())
     else:
         raise NotImplementedError("structure_patch_type %r" % kind)
+    if not trim and kind == 'triangular_random_walk':
+        return out.contiguous()
     longest = int((out != PAD_VALUE).sum(1).max().item()) if n > 0 else 0
     return out[:, :max(longest, 1)].contiguous()
 

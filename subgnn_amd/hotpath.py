@@ -21,6 +21,8 @@ its slabs (tests/test_gpu_hotpath.py).
 """
 import time
 
+import collections
+
 import torch
 
 from . import ops, tape, gamma, subgraph_utils
@@ -62,7 +64,7 @@ def _hand_over(stream, *objs):
         if isinstance(o, torch.Tensor):
             if o.is_cuda:
                 o.record_stream(stream)
-            for nm in ('_sgnn_ids32', '_sgnn_sorted'):
+            for nm in ('_sgnn_ids32', '_sgnn_sorted', '_sgnn_both'):
                 extra = getattr(o, nm, None)
                 if extra is not None:
                     _hand_over(stream, extra)
@@ -277,13 +279,12 @@ def prepare_pass(model, split='train', timer=None, shard=None, defer_dtw=False):
     # ---- side stream: position channel + structure patches / walks -------------------------
     side.wait_stream(main)
     with torch.cuda.stream(side):
-        # The structure patches are drawn first: trimming them to the longest walk is the one host round
-        # trip of this block, and it is taken while the queue is still short -- everything after it
-        # (multi-source BFS, views, walks) is queued without waiting, behind the long BFS launches.
+        # The structure patches keep the walks' full width (no trim to the longest walk: that was a host round trip, and
+        # with a second prepared pass queued on this stream the host waited for that pass's DTW launch there).
         new_patches = hp['use_structure'] and (split != 'test' or getattr(model, 'structure_anchors', None) is None)
         structure_anchors = getattr(model, 'structure_anchors', None)
         if new_patches:
-            structure_anchors = st.attrs['structure_anchors'] = aps.sample_structure_anchor_patches(hp, g, dev, hp['max_sim_epochs'])
+            structure_anchors = st.attrs['structure_anchors'] = aps.sample_structure_anchor_patches(hp, g, dev, hp['max_sim_epochs'], trim=False)
             if side is main:
                 t.mark('S_patches_walks')
         if hp['use_position']:
@@ -353,9 +354,10 @@ def prepare_pass(model, split='train', timer=None, shard=None, defer_dtw=False):
                 a_struct = st.attrs['anchors_structure'] = aps.init_anchors_structure(hp, structure_anchors, int_w, bor_w,
                                                                                       indices_on_device=True)
                 if det:
-                    for v in a_struct.values():          # the walks' embedding lookups: their backward's sort, done here
-                        ops.presort_ids(v[2], g.max_id)
-                        ops.presort_ids(v[3], g.max_id)
+                    # forward runs the LSTM once over a layer's internal AND border walks (SubGNN._structure_anchor_embeddings):
+                    # the stacked walks and the sort their embedding lookup's backward needs are made here
+                    for v in a_struct.values():
+                        v[2]._sgnn_both = ops.presort_ids(torch.cat([v[2], v[3]], 0), g.max_id)
                 # the column upload is a blocking host->device copy: do it here, before the long DTW
                 # launches are queued, so that the host is free to queue forward/backward behind them
                 st.sim_cols = (a_struct, model.sim_cols_of(a_struct))
@@ -508,28 +510,177 @@ class PassPipeline:
     def __init__(self, model, split='train', shard=None):
         self.model, self.split, self.shard = model, split, shard
         self.stream = torch.cuda.Stream()
-        self.state = None
-        self.timer = None
+        self.pending = collections.deque()         # (state, its stage timer, event: prepared) in preparation order
+        self.timer = None                          # stage timer of the pass installed last
 
-    def start(self, timed=False):
-        """Queue the next pass's sampling + similarity stages on the side stream."""
+    @property
+    def state(self):
+        return self.pending[0][0] if self.pending else None
+
+    def start(self, timed=False, after=None):
+        """Queue the next pass's sampling + similarity stages on the side stream.  ``after``: an event on the caller's
+        stream to start behind (the end of ``install``) instead of behind everything queued there so far -- for a caller
+        that has already queued the training half (CapturedTraining), which the preparation does not depend on.
+        May be called again before ``install``: the passes are prepared one after the other on the side stream and
+        installed in that order -- with two in flight the side stream (the longer chain) never waits for the host."""
         main = torch.cuda.current_stream()
-        self.stream.wait_stream(main)
-        self.timer = StageTimer(timed)
+        if after is not None:
+            self.stream.wait_event(after)
+        else:
+            self.stream.wait_stream(main)
+        timer = StageTimer(timed)
         with torch.cuda.stream(self.stream):
-            self.state = prepare_pass(self.model, self.split, self.timer, self.shard)
-            self.timer.mark('prepared')
+            state = prepare_pass(self.model, self.split, timer, self.shard)
+            timer.mark('prepared')
+            done = torch.cuda.Event()
+            done.record()
+        self.pending.append((state, timer, done))
 
-    def install(self, timer=None):
-        if self.state is None:
+    def install(self, timer=None, installer=None):
+        """``installer(state, timer)``: what makes the prepared pass the model's (default install_pass; CapturedTraining.install
+        for a recorded training half)."""
+        if not self.pending:
             raise RuntimeError('PassPipeline.install without a started pass')
+        st, self.timer, done = self.pending.popleft()
         main = torch.cuda.current_stream()
-        main.wait_stream(self.stream)
-        _hand_over(main, *self.state.tensors())
-        for v in (self.state.attrs.get('anchors_structure') or {}).values():
+        main.wait_event(done)
+        _hand_over(main, *st.tensors())
+        for v in (st.attrs.get('anchors_structure') or {}).values():
             _hand_over(main, v[0], v[2], v[3])
-        st, self.state = self.state, None
+        if installer is not None:
+            installer(st, timer)
+            return timer
         return install_pass(self.model, st, timer)
+
+
+_TENSOR_ATTRS = ('_sgnn_ids32', '_sgnn_sorted', '_sgnn_both', '_sgnn_member_order')
+
+
+def _copy_into(dst, src, path, replaced, memo=None):
+    """Copy the tensors of ``src`` (a prepared pass's nest of dicts / tuples / tensors) into the tensors of ``dst`` where
+    shape, dtype and device agree -- the addresses a recorded training half reads stay valid -- and return what to keep
+    at this place.  Anything that cannot be copied is replaced and reported in ``replaced``.  ``memo``: storage already
+    copied in this call (a pass holds some tensors under several names)."""
+    memo = {} if memo is None else memo
+    if isinstance(src, torch.Tensor):
+        if isinstance(dst, torch.Tensor) and dst.shape == src.shape and dst.dtype == src.dtype and dst.device == src.device:
+            key = (src.data_ptr(), src.numel(), src.dtype, dst.data_ptr())
+            if dst.data_ptr() != src.data_ptr() and key not in memo:
+                dst.copy_(src)
+                memo[key] = True
+            for nm in _TENSOR_ATTRS:
+                v = getattr(src, nm, None)
+                if v is not None:
+                    setattr(dst, nm, _copy_into(getattr(dst, nm, None), v, path + '.' + nm, replaced, memo))
+            return dst
+        replaced.append(path)
+        return src
+    if isinstance(src, dict):
+        if not isinstance(dst, dict):
+            replaced.append(path)
+            return src
+        for k, v in src.items():
+            dst[k] = _copy_into(dst.get(k), v, '%s[%r]' % (path, k), replaced, memo)
+        return dst
+    if isinstance(src, (list, tuple)):
+        if not isinstance(dst, (list, tuple)) or len(dst) != len(src):
+            replaced.append(path)
+            return src
+        return type(src)(_copy_into(d, v, '%s[%d]' % (path, i), replaced, memo) for i, (d, v) in enumerate(zip(dst, src)))
+    return src                                   # ZeroSims, numbers, None
+
+
+# what a recorded training half never reads through a kernel (shapes only): may change shape between passes
+_SHAPE_ONLY = ('structure_anchors', 'anchors_structure', 'int_structure_anchor_random_walks', 'bor_structure_anchor_random_walks')
+
+
+def install_pass_static(model, st, timer=None):
+    """install_pass for a model whose training half is replayed from a hipGraph: the pass's tensors are COPIED into the
+    tensors of the pass that was installed when the graph was recorded (same shapes from pass to pass: the split's
+    subgraphs and the anchor counts do not change), so every address the recording reads stays valid.  Returns the
+    list of places where that was not possible (a shape changed): the caller records again."""
+    t = timer or StageTimer(False)
+    _verify_bfs(model, st)
+    replaced, memo = [], {}
+    for k, v in st.attrs.items():
+        setattr(model, k, _copy_into(getattr(model, k, None), v, k, replaced, memo))
+    for k, v in st.per_split.items():
+        d = getattr(model, k, None)
+        if d is None:
+            d = {}
+            setattr(model, k, d)
+        d[st.split] = _copy_into(d.get(st.split), v, '%s[%s]' % (k, st.split), replaced, memo)
+    if st.sim_cols is not None:
+        cur = model.__dict__.get('_sim_cols_static') or getattr(model, '_sim_col_cache', None)
+        cols = _copy_into(cur, st.sim_cols[1], '_sim_cols', replaced, memo)
+        model.__dict__['_sim_cols_static'] = cols
+        model.set_sim_cols(model.anchors_structure, cols)
+    model._build_sim_cols()
+    model.init_all_embeddings(split=st.split, trainable=model.hparams['trainable_cc'], lazy=True)
+    t.mark('install_copies')
+    model._bump_generation()
+    return [r for r in replaced if not r.startswith(_SHAPE_ONLY) or '_sgnn_both' in r]
+
+
+class CapturedTraining:
+    """The training half of a pass -- component embeddings, the three channels, head, loss, backward, gradient clipping,
+    Adam (SubGNN.training_step -> backward -> optim.ClipAdam.step) -- recorded once into a hipGraph and replayed per pass.
+    ~150 launches become one: the host needs ~0.1 ms instead of ~4 to queue them, so that under PassPipeline the training
+    kernels of pass k are on the device BEFORE the host starts queueing the preparation of pass k + 1 (queued behind the
+    preparation they started 4 ms late and ran into the DTW launch, which shares a CU with nothing).
+
+        trainer = CapturedTraining(model, ClipAdam(..., capturable=True))
+        per pass:  trainer.install(prepared_state);  loss, acc = trainer.step()
+
+    ``install`` keeps the recording's addresses valid (install_pass_static); a shape change records again.  The first
+    ``warmup`` steps run eagerly (lazy initialisations must not land in the recording).  Same kernels, same order, same
+    arithmetic as the eager step: losses and parameters are bit-equal (tests/test_gpu_hotpath.py)."""
+
+    def __init__(self, model, optimizer, split='train', warmup=2):
+        if not getattr(optimizer, 'capturable', False):
+            raise ValueError('CapturedTraining needs ClipAdam(capturable=True): a host step count cannot be replayed')
+        if getattr(model, '_table_sync', None) is not None:
+            raise ValueError('CapturedTraining is the single-rank form (collectives are not recorded)')
+        self.model, self.opt, self.split = model, optimizer, split
+        self.graph, self.loss, self.acc = None, None, None
+        self._warm_left = int(warmup)
+        self._installed = False
+        self.recordings = 0
+        self.last_changed = None
+
+    def install(self, st, timer=None):
+        if not self._installed or self.graph is None:
+            install_pass(self.model, st, timer)
+            self._installed = True
+            return
+        changed = install_pass_static(self.model, st, timer)
+        if changed:
+            self.graph = None                    # a tensor the recording reads was replaced: record again
+            self.last_changed = changed
+
+    def _body(self):
+        m = self.model
+        out = m.training_step(full_split_batch(m, self.split), 0)
+        m.backward(None, out['loss'], None, 0)
+        self.opt.step()
+        self.opt.zero_grad(set_to_none=True)
+        return out['loss'].detach(), out['log']['train_acc'].detach()
+
+    def step(self):
+        """-> (loss, accuracy): the recording's static outputs once it exists (clone to keep past the next step)."""
+        if self.graph is None:
+            if self._warm_left > 0:
+                self._warm_left -= 1
+                return self._body()
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self.loss, self.acc = self._body()
+            self.graph = g
+            self.recordings += 1
+        self.graph.replay()
+        self.model.invalidate_half_table()
+        return self.loss, self.acc
 
 
 def _device_labels(model, split):

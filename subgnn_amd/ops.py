@@ -1177,13 +1177,38 @@ def update_layer(x, aggr, weight, bias):
     return torch.relu(linear(torch.cat([x, aggr], dim=1), weight, bias))
 
 
-def adam_step(param, grad, exp_avg, exp_avg_sq, lr, betas, eps, step, grad_scale=None, zero_grad=False):
-    """One Adam update of a large float32 parameter in one pass (sgnn_adam_step); ``grad_scale``: device scalar."""
+def adam_step(param, grad, exp_avg, exp_avg_sq, lr, betas, eps, step, grad_scale=None, zero_grad=False, step_counter=None):
+    """One Adam update of a large float32 parameter in one pass (sgnn_adam_step); ``grad_scale``: device scalar.
+    ``step_counter``: int64 (1,) device tensor that replaces the host count ``step`` (incremented on the stream before the
+    update: the form a recorded step replays)."""
     for t, nm in ((param, 'param'), (grad, 'grad'), (exp_avg, 'exp_avg'), (exp_avg_sq, 'exp_avg_sq'), (grad_scale, 'grad_scale')):
         _req(t, torch.float32, nm)
+    if step_counter is not None:
+        _req(step_counter, torch.int64, 'step_counter')
+        check(_lib.load().sgnn_adam_step_counted(_ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), param.numel(), float(lr),
+                                                 float(betas[0]), float(betas[1]), float(eps), _ptr(step_counter), _ptr(grad_scale),
+                                                 1 if zero_grad else 0, _stream()), 'sgnn_adam_step_counted')
+        return
     check(_lib.load().sgnn_adam_step(_ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), param.numel(), float(lr),
                                      float(betas[0]), float(betas[1]), float(eps), int(step), _ptr(grad_scale),
                                      1 if zero_grad else 0, _stream()), 'sgnn_adam_step')
+
+
+def clip_coefficient(big_grads, small_grads, max_norm):
+    """clip_grad_norm_'s coefficient min(1, max_norm / (total + 1e-6)) as a (1,) device tensor: the large gradients are
+    reduced by sgnn_grad_sumsq (one launch each), the small ones by one multi-tensor norm."""
+    lib = _lib.load()
+    dev = (big_grads + small_grads)[0].device
+    P = int(lib.sgnn_grad_sumsq_partials())
+    partial = torch.empty(max(len(big_grads), 1) * P, dtype=torch.float32, device=dev)
+    for i, g in enumerate(big_grads):
+        _req(g, torch.float32, 'gradient')
+        check(lib.sgnn_grad_sumsq(_ptr(g), g.numel(), ctypes.c_void_p(partial.data_ptr() + 4 * i * P), _stream()), 'sgnn_grad_sumsq')
+    other = torch.stack(torch._foreach_norm(small_grads)).float() if small_grads else None
+    coef = torch.empty(1, dtype=torch.float32, device=dev)
+    check(lib.sgnn_clip_coefficient(_ptr(partial), len(big_grads) * P, _ptr(other), other.numel() if other is not None else 0,
+                                    float(max_norm), _ptr(coef), None, _stream()), 'sgnn_clip_coefficient')
+    return coef
 
 
 class ZeroSims:

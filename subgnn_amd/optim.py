@@ -18,28 +18,32 @@ class ClipAdam:
     kept a reference to ``p.grad`` across ``step()`` holds that recycled buffer, not the old gradient.  ``release()``
     drops the kept buffers."""
 
-    def __init__(self, params, lr, max_norm=None, betas=(0.9, 0.999), eps=1e-8, big_bytes=16 << 20):
+    def __init__(self, params, lr, max_norm=None, betas=(0.9, 0.999), eps=1e-8, big_bytes=16 << 20, capturable=False):
         params = [p for p in params if p.requires_grad]
         self.lr, self.betas, self.eps, self.max_norm = float(lr), (float(betas[0]), float(betas[1])), float(eps), max_norm
         self.big = [p for p in params if p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()
                     and p.numel() * 4 >= big_bytes and p.data_ptr() % 16 == 0]
         ids = {id(p) for p in self.big}
         self.small = [p for p in params if id(p) not in ids]
-        self.small_opt = torch.optim.Adam(self.small, lr=lr, betas=betas, eps=eps,
+        # capturable: every step count lives on the device, so that a step recorded into a hipGraph (hotpath.CapturedTraining)
+        # replays with the right bias corrections; same arithmetic either way
+        self.capturable = bool(capturable)
+        self.small_opt = torch.optim.Adam(self.small, lr=lr, betas=betas, eps=eps, capturable=self.capturable,
                                           fused=all(p.is_cuda for p in self.small)) if self.small else None
-        self.state = {id(p): {'step': 0, 'exp_avg': torch.zeros_like(p), 'exp_avg_sq': torch.zeros_like(p)} for p in self.big}
+        self.state = {id(p): {'step': 0, 'exp_avg': torch.zeros_like(p), 'exp_avg_sq': torch.zeros_like(p),
+                              'step_dev': torch.zeros(1, dtype=torch.int64, device=p.device) if self.capturable else None}
+                      for p in self.big}
 
     def step(self):
         small_grads = [p.grad for p in self.small if p.grad is not None]
         big = [p for p in self.big if p.grad is not None]
         scale = None
         if self.max_norm is not None and (small_grads or big):
-            norms = torch._foreach_norm(small_grads + [p.grad for p in big])
-            total = torch.linalg.vector_norm(torch.stack(norms))
-            coef = torch.clamp(self.max_norm / (total + 1e-6), max=1.0)
+            fast = [p.grad for p in big if p.grad.is_contiguous() and p.grad.dtype == torch.float32 and p.grad.data_ptr() % 16 == 0]
+            slow = [p.grad for p in big if not (p.grad.is_contiguous() and p.grad.dtype == torch.float32 and p.grad.data_ptr() % 16 == 0)]
+            scale = ops.clip_coefficient(fast, small_grads + slow, self.max_norm)
             if small_grads:
-                torch._foreach_mul_(small_grads, coef)
-            scale = coef.reshape(1).float()
+                torch._foreach_mul_(small_grads, scale[0])
         if self.small_opt is not None:
             self.small_opt.step()
         for p in big:
@@ -52,7 +56,7 @@ class ClipAdam:
             # the kernel zeroes the gradient it has just consumed: the buffer goes back to the fused ops'
             # table-gradient accumulator as it is (ops.take_zeroed) instead of a 256 MB fill per pass
             ops.adam_step(p.data, g, st['exp_avg'], st['exp_avg_sq'], self.lr, self.betas, self.eps, st['step'],
-                          grad_scale=scale, zero_grad=take)
+                          grad_scale=scale, zero_grad=take, step_counter=st['step_dev'])
             if take:
                 ops.release_zeroed(p, g)
                 p.grad = None

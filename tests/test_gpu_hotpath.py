@@ -57,7 +57,9 @@ def test_sparse_prepare_equals_dense_prepare(name, tmp_path):
                 assert float((got * (~real).unsqueeze(-1)).abs().max()) == 0.0    # padded components: rows stay 0 unmasked
             got = (got.dense() if hasattr(got, 'dense') else got) * edge          # ops.ZeroSims: known-zero weights
             assert torch.equal(got, want), key
-    assert torch.equal(dense.structure_anchors, sparse.structure_anchors)
+    # (the per-pass path keeps the walks' full width; the dense prepare trims trailing all-PAD columns like the reference)
+    w = dense.structure_anchors.shape[1]
+    assert torch.equal(dense.structure_anchors, sparse.structure_anchors[:, :w]) and not bool(sparse.structure_anchors[:, w:].any())
     assert torch.equal(dense.train_int_struc_similarities, sparse.train_int_struc_similarities)
     assert torch.equal(dense.train_bor_struc_similarities, sparse.train_bor_struc_similarities)
     # same logits through the per-edge similarity dict as through the dense slab
@@ -270,6 +272,55 @@ def test_pipelined_passes_train_like_sequential_passes(name, tmp_path):
         assert torch.equal(a, b), n1
     with pytest.raises(RuntimeError):
         hotpath.PassPipeline(pip, 'train').install()
+
+
+@pytest.mark.parametrize('name,big_bytes,pipelined', [('tiny', 1 << 30, True), ('tiny', 1024, False), ('density', 1024, True)])
+def test_training_half_replayed_from_a_hipgraph_trains_like_the_eager_step(name, big_bytes, pipelined, tmp_path):
+    """hotpath.CapturedTraining: the training half (training_step -> backward -> ClipAdam) recorded into a hipGraph on
+    the second pass and replayed, every later pass copied into the recording's tensors (install_pass_static) -- losses
+    and parameters equal the eager prepare-then-train schedule bit for bit over 5 passes (clip + Adam with device-side
+    step counts; without dropout: a replayed graph draws its masks from its own Philox offsets)."""
+    from conftest import load_golden
+    from subgnn_amd import hotpath, optim
+    golden = load_golden(name)
+    (seq, cap) = _models(golden, tmp_path, {'lin_dropout': 0.0, 'lstm_dropout': 0.0})
+    cap.load_state_dict(seq.state_dict())
+    seq.train(); cap.train()
+    lr, clip = 0.01, 0.5
+    o_seq = optim.ClipAdam(seq.parameters(), lr, max_norm=clip, big_bytes=big_bytes)
+    o_cap = optim.ClipAdam(cap.parameters(), lr, max_norm=clip, big_bytes=big_bytes, capturable=True)
+    assert (len(o_cap.big) > 0) == (big_bytes < (1 << 30))
+    want = []
+    for k in range(5):
+        hotpath.prepare_sparse(seq, 'train')
+        out = seq.training_step(hotpath.full_split_batch(seq, 'train'), 0)
+        out['loss'].backward()
+        o_seq.step()
+        o_seq.zero_grad(set_to_none=True)
+        want.append(float(out['loss']))
+    trainer = hotpath.CapturedTraining(cap, o_cap, 'train', warmup=1)
+    got = []
+    if pipelined:
+        pipe = hotpath.PassPipeline(cap, 'train')
+        pipe.start()
+    for k in range(5):
+        if pipelined:
+            pipe.install(installer=trainer.install)
+            ev = torch.cuda.Event()
+            ev.record()
+            loss, acc = trainer.step()
+            pipe.start(after=ev)
+        else:
+            trainer.install(hotpath.prepare_pass(cap, 'train'))
+            loss, acc = trainer.step()
+        got.append(float(loss))
+    torch.cuda.synchronize()
+    assert trainer.recordings == 1 and trainer.graph is not None, trainer.last_changed
+    assert got == want
+    for (n1, a), (_, b) in zip(seq.named_parameters(), cap.named_parameters()):
+        assert torch.equal(a, b), n1
+    with pytest.raises(ValueError):
+        hotpath.CapturedTraining(cap, optim.ClipAdam(cap.parameters(), lr), 'train')      # a host step count cannot be replayed
 
 
 @pytest.mark.parametrize('tie', [1, 2])

@@ -1,5 +1,5 @@
-"""List the host-synchronising torch calls of one bench pass (torch.cuda.set_sync_debug_mode('warn')):
-every place where the host waits for the device and so cannot run ahead of it.
+"""List the host-synchronising torch calls of the bench's steady-state steps (torch.cuda.set_sync_debug_mode('warn')): every
+place where the host waits for the device and so cannot run ahead of it.
 usage: python tools/find_syncs.py  (on a GPU box; prints file:line of each distinct sync)"""
 import os
 import sys
@@ -24,24 +24,23 @@ def showwarning(message, category, filename, lineno, file=None, line=None):
 
 warnings.showwarning = showwarning
 warnings.simplefilter('always')
-sys.argv = ['bench.py', '--no-cpu-baseline', '--steps', '1', '--warmup', '2']
-orig = bench.hotpath_prepare = None
+sys.argv = ['bench.py', '--no-cpu-baseline', '--steps', '3', '--warmup', '2'] + sys.argv[1:]
 from subgnn_amd import hotpath
-real = hotpath.prepare_sparse
+real = hotpath.prepare_pass
 calls = {'n': 0}
 
 
 def wrapped(*a, **k):
     calls['n'] += 1
-    if calls['n'] == 3:                       # the timed pass
+    if calls['n'] == 6:                       # steady state: priming and warm-up are over
         torch.cuda.set_sync_debug_mode('warn')
     return real(*a, **k)
 
 
-hotpath.prepare_sparse = wrapped
+hotpath.prepare_pass = wrapped
 try:
     bench.main()
 finally:
     torch.cuda.set_sync_debug_mode('default')
-    for key, n in seen.items():
-        print(n, ' <- '.join('%s:%d' % kk for kk in reversed(key)), file=sys.stderr)
+for k, n in sorted(seen.items(), key=lambda kv: -kv[1]):
+    print(n, ' <- '.join('%s:%d' % f for f in reversed(k)))
