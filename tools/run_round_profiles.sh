@@ -6,6 +6,7 @@ python bench.py > $O/${T}_final_bench_default.json 2> $O/${T}_final_bench_defaul
 # the sequential schedule on one stream (no pass pipelining, no two-stream preparation): stage times add up to the step
 SGNN_OVERLAP_STREAMS=0 python bench.py --no-pipeline --no-cpu-baseline --steps 10 > $O/${T}_final_bench_sequential.json 2>/dev/null
 python bench.py --no-pipeline --no-cpu-baseline --steps 10 > $O/${T}_final_bench_two_streams.json 2>/dev/null
+python bench.py --graph --no-cpu-baseline --steps 10 > $O/${T}_final_bench_graph.json 2>/dev/null
 bash tools/profile_bench.sh ${T}_final > /dev/null 2>&1
 python bench.py --subgraphs 6250 --no-cpu-baseline --steps 10 > $O/${T}_bench_shard6250.json 2>/dev/null
 for c in density_n ppi_bp hpo_metab em_user; do
