@@ -503,8 +503,8 @@ def main():
         'longest_kernel': longest,
         'collectives': collectives,
         'stages_ms': {k: round(v, 3) for k, v in stage_ms.items()},
-        'stages_note': ('HIP-event time per stage on the stream it runs on; ' + ('pipelined: the preparation stages (components ... dtw) of pass k+1 '
-                        'run on a second stream beside cc_embed / forward / backward / optimizer of pass k, which stretch each other -- '
+        'stages_note': ('HIP-event time per stage on the stream it runs on; ' + ('pipelined: the preparation stages (components ... dtw) of later passes '
+                        'run on a second stream beside cc_embed (which includes the wait for the prepared pass) / forward / backward / optimizer of pass k, which stretch each other -- '
                         'the stage times do not add up to the step (--no-pipeline with SGNN_OVERLAP_STREAMS=0: they do)' if pipe is not None
                         else 'sequential passes')),
         'loss': loss, 'setup_s': round(t_gen, 1), 'priming_passes_before_warmup': PRIMING_PASSES,
