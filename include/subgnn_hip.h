@@ -179,6 +179,11 @@ int sgnn_khop_border_sample(const int64_t* rowptr, const int32_t* col, const int
                             int64_t* out_anchor, uint8_t* out_hop, uint8_t* out_allneg, int64_t* out_count,
                             const int32_t* set_order /* nullable: dispatch order of the sets, a permutation */,
                             void* workspace, int64_t workspace_bytes, int bitmap_in_lds, void* stream);
+/* The PAD rule of anchor_patch_samplers.py:189-191 on the drawn anchors, in place: slot := PAD where out_allneg is set and the
+ * set's border is smaller than the padded matrix's width (width: device scalar, = max out_count, MAX-reduced over ranks when
+ * the sets are one shard); sims (n_sets, n_slots) float32 := hop level, 0 on PAD. */
+int sgnn_khop_sample_finish(int64_t* anchor, const uint8_t* hop, const uint8_t* allneg, const int64_t* counts,
+                            const int64_t* width, int64_t n_sets, int64_t n_slots, float* sims, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * a4  Neighbourhood anchor sampling from padded id matrices.

@@ -117,6 +117,64 @@ __global__ void dtw_pyramid_kernel(const int64_t* __restrict__ ptr, const int32_
     }
 }
 
+// The same pyramid with one WAVEFRONT per series (values staged in LDS, a level's elements spread over the lanes): for
+// the few long series of the anchor-patch side (210 series of 50 values on the benchmark) one thread per series is a
+// serial chain of ~100 fp64 divisions and dependent global round trips -- 80 us per call, twice per pass.
+__global__ __launch_bounds__(256) void dtw_pyramid_wave_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ val,
+                                                               int64_t n, int64_t M, int64_t PL, int transposed,
+                                                               double* __restrict__ out, double* __restrict__ rec,
+                                                               int32_t* __restrict__ len_out, const int32_t* __restrict__ order)
+{
+    extern __shared__ double pyr_sh[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t s = blockIdx.x * 4ll + wave;
+    if (s >= n) return;                                   // (whole wavefronts leave; no workgroup barrier below)
+    double* buf = pyr_sh + (int64_t)wave * 2 * M;
+    const int64_t src = order ? order[s] : s;
+    const int64_t b = ptr[src];
+    int len = (int)(ptr[src + 1] - b);
+    if (lane == 0) len_out[s] = len;
+#define PYI(e) (transposed ? (int64_t)(e) * n + s : s * PL + (e))
+    for (int i = lane; i < len; i += 64) {
+        const double v = (double)val[b + i];
+        buf[i] = v;
+        out[PYI(i)] = v;
+        rec[PYI(i)] = 1.0 / (v + 1.0);
+    }
+    int64_t off = 0;
+    int k = 0;
+    while (len >= 2 && k + 1 < DTW_MAX_LEVELS) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int64_t noff = off + (M >> k);
+        const int nlen = len / 2;
+        for (int i = lane; i < nlen; i += 64) {
+            const double v = (buf[off + 2 * i] + buf[off + 2 * i + 1]) / 2.0;
+            buf[noff + i] = v;
+            out[PYI(noff + i)] = v;
+            rec[PYI(noff + i)] = 1.0 / (v + 1.0);
+        }
+        off = noff; len = nlen; ++k;
+    }
+#undef PYI
+}
+
+// series per launch below which (and lengths up to which) the wavefront-per-series form is used
+#define DTW_PYR_WAVE_MAX_SERIES 8192
+#define DTW_PYR_WAVE_MAX_LEN 1024
+
+static void dtw_launch_pyramid(const int64_t* ptr, const int32_t* val, int64_t n, int64_t M, int64_t PL, int transposed,
+                               double* out, double* rec, int32_t* len_out, const int32_t* order, hipStream_t st)
+{
+    if (n <= DTW_PYR_WAVE_MAX_SERIES && M <= DTW_PYR_WAVE_MAX_LEN)
+        hipLaunchKernelGGL(dtw_pyramid_wave_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), (size_t)(4 * 2 * M * sizeof(double)), st,
+                           ptr, val, n, M, PL, transposed, out, rec, len_out, order);
+    else
+        hipLaunchKernelGGL(dtw_pyramid_kernel, dim3(sgnn_grid_for(n, 256)), dim3(256), 0, st, ptr, val, n, M, PL, transposed, out,
+                           rec, len_out, order);
+}
+
 __device__ static inline double dtw_cost(double a, double b) {            // gamma.py:51-52
     const double mx = a > b ? a : b, mn = a > b ? b : a;
     return (mx + 1.0) / (mn + 1.0) - 1.0;
@@ -671,11 +729,10 @@ static int dtw_run(const int64_t* x_ptr, const int32_t* x_val, int64_t n_x, int6
     int32_t* xlen = (int32_t*)w;           w += dtw_align8(n_x * 4);
     int32_t* ylen = (int32_t*)w;
     const bool use_reg = max_x_len <= DTW_R && kernel == 0;
-    hipLaunchKernelGGL(dtw_pyramid_kernel, dim3(sgnn_grid_for(n_x, 256)), dim3(256), 0, st, x_ptr, x_val, n_x,
-                       max_x_len, L.XL, 1, xpyr, xpyr + n_x * L.XL, xlen, use_reg ? x_order : (const int32_t*)nullptr);
+    dtw_launch_pyramid(x_ptr, x_val, n_x, max_x_len, L.XL, 1, xpyr, xpyr + n_x * L.XL, xlen,
+                       use_reg ? x_order : (const int32_t*)nullptr, st);
     SGNN_CHECK_LAUNCH();
-    hipLaunchKernelGGL(dtw_pyramid_kernel, dim3(sgnn_grid_for(n_y, 256)), dim3(256), 0, st, y_ptr, y_val, n_y,
-                       max_y_len, L.YL, 0, ypyr, ypyr + n_y * L.YL, ylen, (const int32_t*)nullptr);
+    dtw_launch_pyramid(y_ptr, y_val, n_y, max_y_len, L.YL, 0, ypyr, ypyr + n_y * L.YL, ylen, (const int32_t*)nullptr, st);
     SGNN_CHECK_LAUNCH();
     if (use_reg) {
         // predecessor words of the coarse levels in LDS when (max_y_len / 2) words per lane fit

@@ -1392,6 +1392,36 @@ extern "C" int64_t sgnn_khop_border_sample_workspace_bytes(int64_t max_id, int64
     return sgnn_khop_border_workspace_bytes(max_id, n_sets, bitmap_in_lds && kb_fits_lds(max_id) ? 1 : 0);
 }
 
+// The reference's PAD rule applied to the drawn border anchors (anchor_patch_samplers.py:189-191: the padded border matrix
+// holds 0 in its PAD columns, so PAD wins a slot when every real variate is negative AND the row has a PAD column, i.e. its
+// border is smaller than the matrix's width = the largest border) and the hop level as the slot's similarity (0 on PAD):
+// one pass instead of eleven element-wise launches.  width: DEVICE scalar (the caller may have MAX-reduced it over ranks).
+__global__ __launch_bounds__(256) void khop_sample_finish_kernel(int64_t* __restrict__ anchor, const uint8_t* __restrict__ hop,
+                                                                 const uint8_t* __restrict__ allneg, const int64_t* __restrict__ counts,
+                                                                 const int64_t* __restrict__ width, int64_t n_sets, int64_t n_slots,
+                                                                 float* __restrict__ sims)
+{
+    const int64_t t = blockIdx.x * 256ll + threadIdx.x;
+    if (t >= n_sets * n_slots) return;
+    const int64_t r = t / n_slots;
+    int64_t a = anchor[t];
+    if (allneg[t] != 0 && counts[r] < width[0]) { a = 0; anchor[t] = 0; }
+    sims[t] = a == 0 ? 0.f : (float)hop[t];
+}
+
+extern "C" int sgnn_khop_sample_finish(int64_t* anchor, const uint8_t* hop, const uint8_t* allneg, const int64_t* counts,
+                                       const int64_t* width, int64_t n_sets, int64_t n_slots, float* sims, void* stream)
+{
+    if (!anchor || !hop || !allneg || !counts || !width || !sims || n_sets < 0 || n_slots < 0) return SGNN_ERR_BAD_ARG;
+    const int64_t total = n_sets * n_slots;
+    if (total == 0) return SGNN_OK;
+    if ((total + 255) / 256 > 0x7fffffff) return SGNN_ERR_BAD_ARG;
+    hipLaunchKernelGGL(khop_sample_finish_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, anchor, hop,
+                       allneg, counts, width, n_sets, n_slots, sims);
+    SGNN_CHECK_LAUNCH();
+    return SGNN_OK;
+}
+
 extern "C" int sgnn_khop_border_sample(const int64_t* rowptr, const int32_t* col, const int32_t* col_sorted, int64_t nnz,
                                        int64_t max_id,
                                        const int64_t* set_ptr, const int32_t* set_nodes, int64_t n_sets, int k,

@@ -408,10 +408,9 @@ def khop_border_sample(g, sets, k, n_slots, seed, stream_id, bitmap_in_lds=None,
     width = counts.max().view(1)
     if count_reduce is not None:
         width = count_reduce(width)
-    has_pad = (counts < width).unsqueeze(1)
-    pad = (allneg != 0) & has_pad
-    anchor = torch.where(pad, torch.zeros_like(anchor), anchor)
-    sims = torch.where(pad | (anchor == 0), torch.zeros((), device=g.device), hop.to(torch.float32))
+    sims = torch.empty((sets.n, n_slots), dtype=torch.float32, device=g.device)
+    check(lib.sgnn_khop_sample_finish(_ptr(anchor), _ptr(hop), _ptr(allneg), _ptr(counts), _ptr(width.to(torch.int64)), sets.n, n_slots,
+                                      _ptr(sims), _stream()), 'sgnn_khop_sample_finish')
     return anchor, sims, counts
 
 
