@@ -347,9 +347,19 @@ def main():
         lt = torch.tensor([loss], device=dev, dtype=torch.float64)
         dist.all_reduce(lt)
         loss = float(lt.item()) / world
-    for tm in timers + side_timers[1:]:                          # (side_timers[0] belongs to a pass prepared before the timed region)
+    stage_n = {}
+    for tm in timers + side_timers:                              # (passes prepared before the timed region carry no marks)
         for k, v in tm.summary().items():
-            stage_ms[k] = stage_ms.get(k, 0.0) + v / args.steps
+            stage_ms[k] = stage_ms.get(k, 0.0) + v
+            stage_n[k] = stage_n.get(k, 0) + 1
+    for k in stage_ms:                                           # mean over the passes that were timed
+        stage_ms[k] /= stage_n[k]
+    if os.environ.get('SGNN_BENCH_PER_STEP') and len(side_timers) > 2:
+        # how long the preparation stream sat idle between one pass's last kernel and the next pass's first
+        for a, b in zip(side_timers[1:-1], side_timers[2:]):
+            if a.marks and b.marks:
+                print('prep stream: pass %.3f ms, then idle %.3f ms' % (a.marks[0][1].elapsed_time(a.marks[-1][1]),
+                                                                          a.marks[-1][1].elapsed_time(b.marks[0][1])), file=sys.stderr)
     if os.environ.get('SGNN_BENCH_PER_STEP'):
         for i, tm in enumerate(timers):
             print('step', i, {k: round(v, 3) for k, v in tm.summary().items()}, file=sys.stderr)
