@@ -145,7 +145,7 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the header and the library disagree
         fn.restype = res
         fn.argtypes = args
-    if lib.sgnn_abi_version() != 4:
+    if lib.sgnn_abi_version() != 5:
         raise SubgnnHipError('ABI version mismatch')
     _lib = lib
     return lib

@@ -222,7 +222,7 @@ def prepare_pass(model, split='train', timer=None, shard=None, defer_dtw=False):
     (1024-thread workgroups around an LDS bitmap) and the walk kernels leave most wavefront slots of a CU empty and
     the BFS kernels are memory-bound with small workgroups: on the benchmark the three stages take 4.7 ms back to
     back and 4.0 ms overlapped (17.9 -> 17.0 ms per pass).  The DTW cannot share a CU (it holds every vector
-    register at two wavefronts per SIMD), so nothing is overlapped with it.  The strong-scaling form issues
+    register at three wavefronts of 168 registers per SIMD), so nothing is overlapped with it.  The strong-scaling form issues
     collectives inside the position block and keeps one stream."""
     hp, g, dev = model.hparams, model.networkx_graph, model.device
     seed = int(hp.get('seed', 0)) & tape.MASK64
@@ -422,7 +422,7 @@ def prepare_pass(model, split='train', timer=None, shard=None, defer_dtw=False):
 
 def finish_pass(model, st, timer=None):
     """The structure similarities of a prepared pass (the DTW launches: the longest stage, and one that shares a CU
-    with nothing -- it holds every vector register at two wavefronts per SIMD).  Separate from prepare_pass
+    with nothing -- it holds every vector register at three wavefronts of 168 registers per SIMD).  Separate from prepare_pass
     (``defer_dtw``) for a caller that wants to queue it elsewhere.  Measured for the pipeline: queued behind the
     training half of the previous pass (so that it cannot starve that half's small kernels) the step took 16.7 ms,
     queued freely 15.8 -- the sampling stages and the training kernels do not overlap as well as DTW and training do."""
@@ -493,7 +493,8 @@ class PassPipeline:
     """Passes in flight: while the model trains on pass k (forward, backward, optimizer on the caller's stream), the
     sampling + similarity half of pass k + 1 -- which reads neither the parameters nor anything pass k writes -- runs
     on a second HIP stream.  The small kernels of the training half leave most of the chip idle; the benchmark's
-    prepare-then-train takes 16.9 ms back to back and 15.5 ms this way.
+    prepare-then-train takes 11.3 ms back to back and 10.2 ms this way (round 3; the step is close to the device's
+    total work: see DESIGN section 4, "What the pipeline is bound by").
 
         pipe = PassPipeline(model, 'train', shard)
         pipe.start()                      # pass 0 is being prepared
