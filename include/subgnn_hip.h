@@ -491,6 +491,13 @@ int sgnn_cross_entropy_fwd(const float* logits, const int64_t* labels, int64_t B
 int sgnn_cross_entropy_bwd(const float* logits, const int64_t* labels, const float* lse, const float* grad_loss,
                            int64_t B, int64_t K, float* grad_logits, void* stream);
 
+/* Column sums of a row-major matrix x (R rows of A floats, row stride ld): out[a] = sum_r x[r, a] -- the bias gradients of the
+ * head's Linear layers over a shard's rows (autograd of SubGNN/SubGNN.py:304-312).  Row-block partials added in block order:
+ * bit-reproducible.  workspace: sgnn_column_sum_workspace_bytes. */
+int64_t sgnn_column_sum_workspace_bytes(int64_t R, int64_t A);
+int sgnn_column_sum(const float* x, int64_t ld, int64_t R, int64_t A, float* out, void* workspace, int64_t workspace_bytes,
+                    void* stream);
+
 int sgnn_readout_sum_fwd(const float* sims, int64_t sims_ld, const int64_t* sim_col, const float* s, const float* bp,
                          const uint8_t* row_mask, int64_t B, int64_t C, int64_t A, float* out, int64_t out_ld,
                          void* stream);

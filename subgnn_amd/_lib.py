@@ -97,6 +97,8 @@ SIGNATURES = {
     'sgnn_cross_entropy_workspace_bytes': (c_i64, [c_i64]),
     'sgnn_cross_entropy_fwd': (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr]),
     'sgnn_cross_entropy_bwd': (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr]),
+    'sgnn_column_sum_workspace_bytes': (c_i64, [c_i64, c_i64]),
+    'sgnn_column_sum': (c_int, [c_ptr, c_i64, c_i64, c_i64, c_ptr, c_ptr, c_i64, c_ptr]),
     'sgnn_readout_sum_bwd_workspace_bytes': (c_i64, [c_i64, c_i64, c_i64]),
     'sgnn_readout_sum_bwd': (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_ptr, c_ptr,
                                      c_ptr, c_i64, c_ptr]),

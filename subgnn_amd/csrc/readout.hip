@@ -219,6 +219,75 @@ extern "C" int sgnn_readout_sum_bwd(const float* grad_out, int64_t grad_ld, cons
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// Column sums of a tall matrix x (R, A) -- the bias gradient of a Linear over R rows (autograd of SubGNN/SubGNN.py:304-312 and
+// of the read-out weights): per-256-row-block partials with four loads in flight per thread, then the block partials of a
+// column added in block order by one wavefront (readout_sum_bwd_finish_kernel).  torch's reduction over the leading
+// dimension of a tall, narrow matrix took three launches (a row-block view, two sums) + an add for the tail.
+// rows per block: 256 for a very tall matrix, fewer when that would leave the chip short of workgroups (>= ~1000 blocks)
+static inline int64_t cs_rows_per_block(int64_t R) {
+    int64_t rpb = (R + 1023) / 1024;
+    rpb = (rpb + RO_TR - 1) / RO_TR * RO_TR;
+    return rpb < 16 ? 16 : (rpb > 256 ? 256 : rpb);
+}
+__global__ __launch_bounds__(256) void column_sum_partial_kernel(const float* __restrict__ x, int64_t ld, int64_t R, int32_t A,
+                                                                 int64_t nblk, int64_t rpb, float* __restrict__ partial)
+{
+    __shared__ float sh[RO_TR][RO_TA];
+    const int ta = threadIdx.x % RO_TA, tr = threadIdx.x / RO_TA;
+    const int64_t blk = blockIdx.x;
+    const int64_t r0 = blk * rpb;
+    const int64_t r1 = r0 + rpb < R ? r0 + rpb : R;
+    for (int32_t a0 = 0; a0 < A; a0 += RO_TA) {
+        const int32_t a = a0 + ta;
+        float acc = 0.f;
+        if (a < A) {
+            int64_t r = r0 + tr;
+            for (; r + 3 * RO_TR < r1; r += 4 * RO_TR) {
+                const float v0 = x[r * ld + a], v1 = x[(r + RO_TR) * ld + a], v2 = x[(r + 2 * RO_TR) * ld + a],
+                            v3 = x[(r + 3 * RO_TR) * ld + a];
+                acc += v0; acc += v1; acc += v2; acc += v3;
+            }
+            for (; r < r1; r += RO_TR) acc += x[r * ld + a];
+        }
+        sh[tr][ta] = acc;
+        __syncthreads();
+        if (tr == 0 && a < A) {
+            float v = sh[0][ta];
+#pragma unroll
+            for (int k = 1; k < RO_TR; ++k) v += sh[k][ta];
+            partial[(int64_t)a * nblk + blk] = v;
+        }
+        __syncthreads();
+    }
+}
+
+extern "C" int64_t sgnn_column_sum_workspace_bytes(int64_t R, int64_t A)
+{
+    if (R < 0 || A < 0) return -1;
+    const int64_t rpb = cs_rows_per_block(R);
+    return A * ((R + rpb - 1) / rpb) * (int64_t)sizeof(float) + 16;
+}
+
+extern "C" int sgnn_column_sum(const float* x, int64_t ld, int64_t R, int64_t A, float* out, void* workspace, int64_t workspace_bytes,
+                               void* stream)
+{
+    if (!x || !out || R < 0 || A < 0 || ld < A || A > 0x7fffffff) return SGNN_ERR_BAD_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (A == 0) return SGNN_OK;
+    if (R == 0) return hipMemsetAsync(out, 0, A * sizeof(float), st) == hipSuccess ? SGNN_OK : SGNN_ERR_LAUNCH;
+    if (!workspace || workspace_bytes < sgnn_column_sum_workspace_bytes(R, A)) return SGNN_ERR_BAD_ARG;
+    const int64_t rpb = cs_rows_per_block(R);
+    const int64_t nblk = (R + rpb - 1) / rpb;
+    float* partial = (float*)workspace;
+    hipLaunchKernelGGL(column_sum_partial_kernel, dim3((unsigned)nblk), dim3(256), 0, st, x, ld, R, (int32_t)A, nblk, rpb, partial);
+    SGNN_CHECK_LAUNCH();
+    hipLaunchKernelGGL(readout_sum_bwd_finish_kernel, dim3((unsigned)((A + 3) / 4)), dim3(256), 0, st, partial, (const float*)nullptr,
+                       (int32_t)A, nblk, out, (float*)nullptr);
+    SGNN_CHECK_LAUNCH();
+    return SGNN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // masked sum of one channel output (B, C, W) into a column slot of the (B, H) subgraph embedding, and its backward out of
 // a slot of the embedding's gradient (SubGNN/subgraph_utils.py:213-237 applied per concatenated piece: no (B, C, H) tensor)
 template <typename V>

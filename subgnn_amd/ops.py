@@ -1061,11 +1061,44 @@ def column_sum(t, chunk=512):
     grid, 0.5 ms); summing row blocks first -- (R/chunk, chunk, A) over the middle dimension -- gives
     it R/chunk x A outputs to spread over the chip, and the second, small sum finishes."""
     R = t.shape[0]
+    if t.dim() == 2 and t.is_cuda and t.dtype == torch.float32 and R >= 1024 and t.stride(1) == 1 and t.stride(0) >= t.shape[1] \
+            and not t.requires_grad:
+        # sgnn_column_sum: row-block partials + one wavefront per column, two launches, fixed order
+        lib = _lib.load()
+        A = t.shape[1]
+        out = torch.empty(A, dtype=torch.float32, device=t.device)
+        wsb = lib.sgnn_column_sum_workspace_bytes(R, A)
+        ws = torch.empty(wsb // 4 + 1, dtype=torch.float32, device=t.device)
+        check(lib.sgnn_column_sum(_ptr(t), t.stride(0), R, A, _ptr(out), _ptr(ws), wsb, _stream()), 'sgnn_column_sum')
+        return out
     nb = R // chunk
     if t.dim() != 2 or nb < 8:
         return t.sum(0)
     head = t[:nb * chunk].view(nb, chunk, t.shape[1]).sum(1).sum(0)
     return head + t[nb * chunk:].sum(0) if nb * chunk < R else head
+
+
+def _block_rows(R, want=1024):
+    """Rows per block for a contraction split over row blocks: a divisor of R between want / 2 and 2 want when there is one
+    (no remainder block: one GEMM and one add less), else ``want``."""
+    for d in sorted(range(want // 2, 2 * want + 1), key=lambda d: abs(d - want)):
+        if R % d == 0:
+            return d
+    return want
+
+
+def contract_rows(a, b, rows_per_block=None):
+    """a^T b for tall a (R, m), b (R, n): an (m x n) result contracted over R >> m, n rows.  The library runs it on
+    (m / 64) x (n / 32) workgroups (16 of them for the LSTM's weight gradients: 40 us for 1.1 GFLOP); split over row
+    blocks -- one batched GEMM, then a sum in block order -- it fills the chip."""
+    R = a.shape[0]
+    if R < 4096 or not a.is_cuda:
+        return a.t() @ b
+    rows_per_block = rows_per_block or _block_rows(R)
+    nb = R // rows_per_block
+    k = nb * rows_per_block
+    head = torch.bmm(a[:k].reshape(nb, rows_per_block, -1).transpose(1, 2), b[:k].reshape(nb, rows_per_block, -1)).sum(0)
+    return head + a[k:].t() @ b[k:] if k < R else head
 
 
 class _ReadoutShared(torch.autograd.Function):
@@ -1093,9 +1126,7 @@ class _LinearTallSkinny(torch.autograd.Function):
     """y = x W^T + b for a tall x (R >> features).  The library picks a single-pass kernel for the
     weight gradient g^T x -- an (out x in) result contracted over R = 50k rows runs on (out/32) x
     (in/64) workgroups, 4 of the 256 CUs, ~200 us.  Here the contraction is split over row blocks
-    (one batched GEMM, then a small sum), which fills the chip."""
-
-    SPLIT_ROWS = 1024
+    (one batched GEMM, then a small sum), which fills the chip (contract_rows)."""
 
     @staticmethod
     def forward(ctx, x, W, b):
@@ -1110,14 +1141,7 @@ class _LinearTallSkinny(torch.autograd.Function):
         gx = g @ W if ctx.needs_input_grad[0] else None
         gW = None
         if ctx.needs_input_grad[1]:
-            R = x.shape[0]
-            k = _LinearTallSkinny.SPLIT_ROWS
-            nb = R // k
-            if nb >= 2:
-                head = torch.bmm(g[:nb * k].view(nb, k, -1).transpose(1, 2), x[:nb * k].view(nb, k, -1)).sum(0)
-                gW = head + g[nb * k:].t() @ x[nb * k:] if nb * k < R else head
-            else:
-                gW = g.t() @ x
+            gW = contract_rows(g, x)
         gb = column_sum(g) if ctx.has_bias and ctx.needs_input_grad[2] else None
         return gx, gW, gb
 
@@ -1535,10 +1559,10 @@ class _BiLSTMLayer(torch.autograd.Function):
               'sgnn_lstm_bwd')
         dg = dgates.view(B * T, 8 * H)
         dx = (dg @ wih).view(B, T, I) if ctx.needs_input_grad[0] else None
-        dwih = dg.t() @ x2                                                      # (8H, I)
-        dg3 = dgates.view(B * T, 2, 4 * H)
-        dwhh = [dg3[:, d, :].t() @ hprev[d].view(B * T, H) for d in (0, 1)]
-        db = (torch.ones((1, B * T), dtype=dg.dtype, device=dg.device) @ dg).view(8 * H)
+        dwih = contract_rows(dg, x2)                                            # (8H, I)
+        dgd = dgates.view(B * T, 2, 4 * H).transpose(0, 1).contiguous()         # (2, B T, 4H): one direction's gates contiguous
+        dwhh = [contract_rows(dgd[d], hprev[d].view(B * T, H)) for d in (0, 1)]
+        db = column_sum(dg).view(8 * H)
         G = 4 * H
         return (dx, dwih[:G], dwhh[0], db[:G], db[:G], dwih[G:], dwhh[1], db[G:], db[G:])
 

@@ -717,3 +717,25 @@ def test_deterministic_choice_is_per_forward_not_process_wide():
     (oa ** 2).sum().backward()
     (os_ ** 2).sum().backward()
     assert_close(Ea.grad, Es.grad, 'atomics vs sorted', norm_tol=1e-5)
+
+
+@pytest.mark.parametrize('R,A,view', [(1024, 1, False), (5000, 37, False), (50000, 183, False), (20000, 64, True)])
+def test_column_sum_matches_float64_and_repeats(R, A, view):
+    """ops.column_sum (sgnn_column_sum: row-block partials + one wavefront per column) against a float64 sum; a column
+    slice of a wider matrix (row stride > A) as the head's backward hands it over; twice -> identical bits."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(R + A)
+    wide = torch.randn(R, A + (7 if view else 0), generator=g).to(DEV)
+    x = wide[:, 3:3 + A] if view else wide
+    out = ops.column_sum(x)
+    assert_close(out, x.double().sum(0).float(), 'column sum', tol=2e-4, norm_tol=1e-6)
+    assert torch.equal(out, ops.column_sum(x))
+
+
+def test_contract_rows_matches_the_plain_product():
+    ops = _ops()
+    g = torch.Generator().manual_seed(3)
+    a, b = torch.randn(16800, 96, generator=g).to(DEV), torch.randn(16800, 64, generator=g).to(DEV)
+    ref = (a.double().t() @ b.double()).float()
+    assert_close(ops.contract_rows(a, b), ref, 'contract_rows', tol=2e-4, norm_tol=1e-6)
+    assert_close(ops.contract_rows(a[:1000], b[:1000]), (a[:1000].double().t() @ b[:1000].double()).float(), 'small', tol=2e-4, norm_tol=1e-5)
