@@ -224,7 +224,8 @@ int sgnn_choice_ragged(const int64_t* ptr, const int32_t* seq, int64_t n_items, 
  *                     start uniform over the patch's node view  patch_ptr/patch_nodes (unique)
  *   mode 2  'border': start uniform over in_border nodes (inb_ptr/inb_nodes); neighbours
  *                     restricted to in_border U (V \ patch) (aps:141-143)
- * out: (n_items, walk_len) int64, PAD filled.  One tape item per walk (item = walk index).
+ * out: (n_items, walk_len) int64, PAD filled.  One tape item per walk (item = item_base + walk index: a rank that runs a
+ * share of a launch's walks -- with the patches of that share only, for modes 1 and 2 -- draws what the whole launch would).
  * max_id: largest node id (rowptr has max_id + 2 entries); when the id range fits an LDS bitmap
  * (~1.1 M ids) a workgroup-per-walk kernel is used (adjacency to the previous node = one bit
  * test), else a wavefront-per-walk kernel (binary search in the sorted list); max_id <= 0 or
@@ -235,7 +236,8 @@ int sgnn_triangular_walks(const int64_t* rowptr, const int32_t* col, const int32
                           const int64_t* patch_ptr, const int32_t* patch_nodes,
                           const int64_t* inb_ptr, const int32_t* inb_nodes,
                           int mode, int64_t n_items, int64_t walks_per_patch, int64_t walk_len, double beta,
-                          uint64_t seed, uint64_t stream_id, int64_t max_id, int kernel, int64_t* out, void* stream);
+                          uint64_t seed, uint64_t stream_id, int64_t item_base, int64_t max_id, int kernel, int64_t* out,
+                          void* stream);
 
 /* in-border nodes of a patch (subgraph_utils.get_border_nodes, subgraph_utils.py:126-144, with
  * its id-1 / node-order indexing quirk): out_flag[i] = 1 iff patch_nodes[i] is a border node.

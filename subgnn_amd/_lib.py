@@ -59,7 +59,7 @@ SIGNATURES = {
     'sgnn_sample_anchors_ragged': (c_int, [c_ptr, c_ptr, c_i64, c_ptr, c_i64, c_u64, c_u64, c_i64, c_ptr, c_ptr]),
     'sgnn_choice_ragged': (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_u64, c_u64, c_i64, c_ptr, c_ptr]),
     'sgnn_triangular_walks': (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_int,
-                                      c_i64, c_i64, c_i64, c_dbl, c_u64, c_u64, c_i64, c_int, c_ptr, c_ptr]),
+                                      c_i64, c_i64, c_i64, c_dbl, c_u64, c_u64, c_i64, c_i64, c_int, c_ptr, c_ptr]),
     'sgnn_patch_in_border': (c_int, [c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_ptr, c_ptr]),
     'sgnn_sp_similarity_dense': (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_ptr, c_ptr]),
     'sgnn_bfs_hops_workspace_bytes': (c_i64, [c_i64, c_i64, c_int]),

@@ -61,8 +61,10 @@ def in_border_sets(graph, views):
     return ops.Ragged.from_mask(padded, fpad != 0)
 
 
-def perform_random_walks(hparams, networkx_graph, anchor_patch_ids, inside, views=None, in_border=None):
-    """aps:118-158 -> (n_patches, n_triangular_walks, random_walk_len) int64, PAD filled."""
+def perform_random_walks(hparams, networkx_graph, anchor_patch_ids, inside, views=None, in_border=None, first_patch=0):
+    """aps:118-158 -> (n_patches, n_triangular_walks, random_walk_len) int64, PAD filled.
+    ``first_patch``: the given patches are rows first_patch ... of a longer patch list (a rank's share of the shared
+    patches under strong scaling): their walks read the tape items of the whole list's walk numbers."""
     g = networkx_graph
     ids = anchor_patch_ids.to(g.device)
     P = ids.shape[0]
@@ -70,16 +72,17 @@ def perform_random_walks(hparams, networkx_graph, anchor_patch_ids, inside, view
     views = views if views is not None else patch_node_views(ids)
     if inside:
         out = ops.triangular_walks(g, 1, P * W, T, hparams['rw_beta'], _seed(hparams),
-                                   tape.stream_id(tape.STREAM_WALK_INT), patches=views, walks_per_patch=W)
+                                   tape.stream_id(tape.STREAM_WALK_INT), patches=views, walks_per_patch=W,
+                                   item_base=first_patch * W)
     else:
         in_border = in_border if in_border is not None else in_border_sets(g, views)
         out = ops.triangular_walks(g, 2, P * W, T, hparams['rw_beta'], _seed(hparams),
                                    tape.stream_id(tape.STREAM_WALK_BOR), patches=views, in_border=in_border,
-                                   walks_per_patch=W)
+                                   walks_per_patch=W, item_base=first_patch * W)
     return out.view(P, W, T)
 
 
-def sample_structure_anchor_patches(hparams, networkx_graph, device, max_sim_epochs, trim=True):
+def sample_structure_anchor_patches(hparams, networkx_graph, device, max_sim_epochs, trim=True, share=None):
     """aps:210-243 -> (n sampled patches, max patch length) int64 (trailing all-PAD columns
     trimmed, as padding to the longest patch does in the reference; ``trim=False`` keeps the walks' full width -- the
     longest patch is a value on the device, and reading it makes the host wait for everything queued on the stream:
@@ -92,6 +95,11 @@ def sample_structure_anchor_patches(hparams, networkx_graph, device, max_sim_epo
     g = networkx_graph
     n = max_sim_epochs * hparams['n_anchor_patches_structure'] * hparams['n_layers']
     kind = hparams['structure_patch_type']
+    if kind == 'triangular_random_walk' and share is not None:
+        # share = (first walk, one past the last): this call draws a rank's share of the n walks (same tape items)
+        lo, hi = share
+        return ops.triangular_walks(g, 0, hi - lo, hparams['sample_walk_len'], hparams['rw_beta'], _seed(hparams),
+                                    tape.stream_id(tape.STREAM_STRUCT_PATCH), item_base=lo).contiguous()
     if kind == 'triangular_random_walk':
         out = ops.triangular_walks(g, 0, n, hparams['sample_walk_len'], hparams['rw_beta'], _seed(hparams),
                                    tape.stream_id(tape.STREAM_STRUCT_PATCH))

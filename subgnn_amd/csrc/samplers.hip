@@ -255,7 +255,7 @@ __global__ __launch_bounds__(64) void triangular_walks_kernel(
     const int64_t* __restrict__ patch_ptr, const int32_t* __restrict__ patch_nodes,
     const int64_t* __restrict__ inb_ptr, const int32_t* __restrict__ inb_nodes,
     int mode, int64_t n_items, int64_t walks_per_patch, int64_t walk_len, double beta,
-    uint64_t h0, int64_t* __restrict__ out)
+    uint64_t h0, int64_t item_base, int64_t* __restrict__ out)
 {
     __shared__ uint64_t s_tri[WK_CHUNKS], s_non[WK_CHUNKS];
     __shared__ int32_t s_hp[WK_HASH], s_hi[WK_HASH];
@@ -267,7 +267,7 @@ __global__ __launch_bounds__(64) void triangular_walks_kernel(
         c.rowptr = rowptr; c.col = col; c.col_sorted = col_sorted; c.mode = mode;
         c.patch = nullptr; c.n_patch = 0; c.inb = nullptr; c.n_inb = 0;
         c.hpatch = nullptr; c.hinb = nullptr; c.pp = 0; c.pi = 0;
-        const uint64_t h1 = sgnn_tape_h1(h0, (uint64_t)item);
+        const uint64_t h1 = sgnn_tape_h1(h0, (uint64_t)(item_base + item));   // the walk's GLOBAL number: a dealt share draws what the whole launch would
         uint64_t j = 0;
         int32_t prev;
         __syncthreads();                            // previous item's LDS tables are no longer read
@@ -459,7 +459,7 @@ __global__ __launch_bounds__(WKB_THREADS) void triangular_walks_wg_kernel(
     const int64_t* __restrict__ patch_ptr, const int32_t* __restrict__ patch_nodes,
     const int64_t* __restrict__ inb_ptr, const int32_t* __restrict__ inb_nodes,
     int mode, int64_t n_items, int64_t walks_per_patch, int64_t walk_len, double beta,
-    uint64_t h0, int64_t* __restrict__ out, int64_t words)
+    uint64_t h0, int64_t item_base, int64_t* __restrict__ out, int64_t words)
 {
     extern __shared__ uint32_t s_adj[];                    // bitmap over node ids: N(prev)
     __shared__ uint64_t s_tri[WK_CHUNKS], s_non[WK_CHUNKS];
@@ -475,7 +475,7 @@ __global__ __launch_bounds__(WKB_THREADS) void triangular_walks_wg_kernel(
         c.rowptr = rowptr; c.col = col; c.col_sorted = col_sorted; c.mode = mode;
         c.patch = nullptr; c.n_patch = 0; c.inb = nullptr; c.n_inb = 0;
         c.hpatch = nullptr; c.hinb = nullptr; c.pp = 0; c.pi = 0;
-        const uint64_t h1 = sgnn_tape_h1(h0, (uint64_t)item);
+        const uint64_t h1 = sgnn_tape_h1(h0, (uint64_t)(item_base + item));   // the walk's GLOBAL number: a dealt share draws what the whole launch would
         uint64_t j = 0;
         int32_t prev;
         __syncthreads();                            // previous item's LDS tables are no longer read
@@ -538,9 +538,10 @@ extern "C" int sgnn_triangular_walks(const int64_t* rowptr, const int32_t* col, 
                                      const int64_t* patch_ptr, const int32_t* patch_nodes,
                                      const int64_t* inb_ptr, const int32_t* inb_nodes,
                                      int mode, int64_t n_items, int64_t walks_per_patch, int64_t walk_len, double beta,
-                                     uint64_t seed, uint64_t stream_id, int64_t max_id, int kernel, int64_t* out, void* stream)
+                                     uint64_t seed, uint64_t stream_id, int64_t item_base, int64_t max_id, int kernel, int64_t* out,
+                                     void* stream)
 {
-    if (!rowptr || !col || !col_sorted || !out || n_items < 0 || walk_len < 0 || mode < 0 || mode > 2 || kernel < 0 || kernel > 1)
+    if (!rowptr || !col || !col_sorted || !out || n_items < 0 || walk_len < 0 || mode < 0 || mode > 2 || kernel < 0 || kernel > 1 || item_base < 0)
         return SGNN_ERR_BAD_ARG;
     if (mode == 0 && (!node_order || n_nodes <= 0)) return SGNN_ERR_BAD_ARG;
     if (mode >= 1 && (!patch_ptr || !patch_nodes || walks_per_patch <= 0)) return SGNN_ERR_BAD_ARG;
@@ -558,13 +559,13 @@ extern "C" int sgnn_triangular_walks(const int64_t* rowptr, const int32_t* col, 
         hipLaunchKernelGGL(triangular_walks_wg_kernel, dim3((int)(n_items < 2048 ? n_items : 2048)), dim3(WKB_THREADS),
                            (size_t)(words * 4), (hipStream_t)stream, rowptr, col, col_sorted, node_order, n_nodes, patch_ptr,
                            patch_nodes, inb_ptr, inb_nodes, mode, n_items, walks_per_patch, walk_len, beta,
-                           sgnn_tape_h0(seed, stream_id), out, words);
+                           sgnn_tape_h0(seed, stream_id), item_base, out, words);
         SGNN_CHECK_LAUNCH();
         return SGNN_OK;
     }
     hipLaunchKernelGGL(triangular_walks_kernel, dim3((int)(n_items < 256 * 32 ? n_items : 256 * 32)), dim3(64), 0, (hipStream_t)stream,
                        rowptr, col, col_sorted, node_order, n_nodes, patch_ptr, patch_nodes, inb_ptr, inb_nodes,
-                       mode, n_items, walks_per_patch, walk_len, beta, sgnn_tape_h0(seed, stream_id), out);
+                       mode, n_items, walks_per_patch, walk_len, beta, sgnn_tape_h0(seed, stream_id), item_base, out);
     SGNN_CHECK_LAUNCH();
     return SGNN_OK;
 }

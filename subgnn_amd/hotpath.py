@@ -164,6 +164,21 @@ def _pint_sims_streamed(g, uniq, inv, cc_sets, S, C, max_hops, chunk_bytes=1 << 
     return w
 
 
+def _deal_rows(shard, n, compute, tail_shape, dtype, device):
+    """Strong scaling: rows [0, n) of a result every rank needs (walks over the shared structure patches) computed as
+    ``world`` equal shares -- ``compute(lo, hi)`` -> rows lo..hi-1 -- and all-gathered (ranks in order, equal row counts
+    known on the host: no size exchange).  Bit-identical to computing all rows on every rank when ``compute`` keys its
+    draws by global row numbers."""
+    from . import dist as sdist
+    per = -(-n // shard.world)
+    lo = min(shard.rank * per, n)
+    hi = min(lo + per, n)
+    part = compute(lo, hi) if hi > lo else torch.zeros((0,) + tuple(tail_shape), dtype=dtype, device=device)
+    if part.shape[0] < per:
+        part = torch.cat([part, part.new_zeros((per - part.shape[0],) + tuple(part.shape[1:]))], 0)
+    return sdist.all_gather_rows(part.contiguous(), equal_rows=True)[:n]
+
+
 def _dealt_position_sims(g, anchors, cc_sets, cc_ids, shard, max_hops):
     """P-border similarities with the BFS sources dealt across ranks (strong scaling): this rank runs the
     multi-source BFS for ITS share of the shared anchors only -- one 64-source word instead of
@@ -284,7 +299,14 @@ def prepare_pass(model, split='train', timer=None, shard=None, defer_dtw=False):
         new_patches = hp['use_structure'] and (split != 'test' or getattr(model, 'structure_anchors', None) is None)
         structure_anchors = getattr(model, 'structure_anchors', None)
         if new_patches:
-            structure_anchors = st.attrs['structure_anchors'] = aps.sample_structure_anchor_patches(hp, g, dev, hp['max_sim_epochs'], trim=False)
+            if shard is not None and shard.deal_shared and hp['structure_patch_type'] == 'triangular_random_walk':
+                # strong scaling: every rank walks an eighth of the shared patches (tape items = global walk numbers)
+                n_p = hp['max_sim_epochs'] * hp['n_anchor_patches_structure'] * hp['n_layers']
+                structure_anchors = _deal_rows(shard, n_p, lambda lo, hi: aps.sample_structure_anchor_patches(
+                    hp, g, dev, hp['max_sim_epochs'], trim=False, share=(lo, hi)), (hp['sample_walk_len'],), torch.int64, dev)
+                st.attrs['structure_anchors'] = structure_anchors
+            else:
+                structure_anchors = st.attrs['structure_anchors'] = aps.sample_structure_anchor_patches(hp, g, dev, hp['max_sim_epochs'], trim=False)
             if side is main:
                 t.mark('S_patches_walks')
         if hp['use_position']:
@@ -347,10 +369,23 @@ def prepare_pass(model, split='train', timer=None, shard=None, defer_dtw=False):
             the side chain -- patches, BFS, walks: 2.5 ms -- was 0.8 ms longer than the main one (border, degree
             sequences: 1.7 ms) and the DTW waited for it."""
             nonlocal a_sets, ai, ae
-            if new_patches:
+            if new_patches and shard is not None and shard.deal_shared:
+                # the walks over the shared patches, dealt: a rank builds the node views of ITS patches only
+                W_, T_ = hp['n_triangular_walks'], hp['random_walk_len']
+
+                def both(lo, hi):
+                    mine = structure_anchors[lo:hi].contiguous()
+                    v = aps.patch_node_views(mine)
+                    return torch.stack([aps.perform_random_walks(hp, g, mine, False, v, first_patch=lo),
+                                        aps.perform_random_walks(hp, g, mine, True, v, first_patch=lo)], 1)
+                walks = _deal_rows(shard, structure_anchors.shape[0], both, (2, W_, T_), torch.int64, dev)
+                bor_w = st.attrs['bor_structure_anchor_random_walks'] = walks[:, 0].contiguous()
+                int_w = st.attrs['int_structure_anchor_random_walks'] = walks[:, 1].contiguous()
+            elif new_patches:
                 views = aps.patch_node_views(structure_anchors)
                 bor_w = st.attrs['bor_structure_anchor_random_walks'] = aps.perform_random_walks(hp, g, structure_anchors, False, views)
                 int_w = st.attrs['int_structure_anchor_random_walks'] = aps.perform_random_walks(hp, g, structure_anchors, True, views)
+            if new_patches:
                 a_struct = st.attrs['anchors_structure'] = aps.init_anchors_structure(hp, structure_anchors, int_w, bor_w,
                                                                                       indices_on_device=True)
                 if det:

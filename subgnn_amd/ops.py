@@ -492,9 +492,10 @@ def choice_ragged(sets, n_draws, seed, stream_id, item_base=0):
 
 
 def triangular_walks(g, mode, n_items, walk_len, beta, seed, stream_id, patches=None, in_border=None,
-                     walks_per_patch=1, kernel=0):
+                     walks_per_patch=1, kernel=0, item_base=0):
     """mode 0 'graph' / 1 'inside' / 2 'border' -> (n_items, walk_len) int64, PAD filled.
-    kernel: 0 = pick by graph size, 1 = the wavefront-per-walk kernel (same walks)."""
+    kernel: 0 = pick by graph size, 1 = the wavefront-per-walk kernel (same walks).
+    item_base: global number of this call's first walk (a share of a larger launch: same draws)."""
     lib = _lib.load()
     out = torch.empty((n_items, walk_len), dtype=torch.int64, device=g.device)
     check(lib.sgnn_triangular_walks(_ptr(g.rowptr), _ptr(g.col), _ptr(g.col_sorted), g.nnz, _ptr(g.node_order),
@@ -502,7 +503,7 @@ def triangular_walks(g, mode, n_items, walk_len, beta, seed, stream_id, patches=
                                     _ptr(patches.nodes) if patches else None,
                                     _ptr(in_border.ptr) if in_border else None,
                                     _ptr(in_border.nodes) if in_border else None,
-                                    mode, n_items, walks_per_patch, walk_len, float(beta), seed, stream_id,
+                                    mode, n_items, walks_per_patch, walk_len, float(beta), seed, stream_id, int(item_base),
                                     g.max_id, int(kernel), _ptr(out), _stream()), 'sgnn_triangular_walks')
     return out
 

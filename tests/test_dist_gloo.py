@@ -58,6 +58,15 @@ def _worker(rank, world, port, q):
     D.all_reduce_gradients(list(w.parameters()) + [extra], big_bytes=1 << 20)
     ok_grad = ok_grad and torch.allclose(extra.grad, torch.arange(4.0) / world) and \
         torch.allclose(w.weight.grad, ref.weight.grad)
+    # strong scaling's dealing of shared per-pass work (hotpath._deal_rows): 7 rows of a result every rank needs, computed
+    # as ceil(7 / 2) = 4 + 3 rows keyed by GLOBAL row numbers, gathered in rank order -> what one rank would compute alone
+    from subgnn_amd import hotpath
+    shard = D.Shard(8, deal_shared=True)
+    table = torch.arange(7 * 5, dtype=torch.int64).view(7, 5) * 3 + 1
+    dealt = hotpath._deal_rows(shard, 7, lambda lo, hi: table[lo:hi].clone(), (5,), torch.int64, 'cpu')
+    ok_gather = ok_gather and shard.deal_shared and torch.equal(dealt, table)
+    one = hotpath._deal_rows(shard, 1, lambda lo, hi: table[lo:hi].clone(), (5,), torch.int64, 'cpu')      # rank 1's share is empty
+    ok_gather = ok_gather and torch.equal(one, table[:1])
     q.put((rank, (a, b), bool(ok_gather), bool(ok_grad)))
     dist.destroy_process_group()
 

@@ -558,6 +558,34 @@ def test_walks_random_vs_oracle(walk_kernel):
         assert np.array_equal(got, ref)
 
 
+def test_a_share_of_the_walks_draws_what_the_whole_launch_draws(walk_kernel):
+    """item_base: a rank that runs walks [lo, hi) of a launch -- with the node views / in-border sets of ITS patches only
+    for the patch walks -- gets rows lo..hi-1 of the whole launch, bit for bit (strong scaling deals the shared patches'
+    walks this way: hotpath._deal_rows)."""
+    ops = _ops()
+    G = _rand_graph(500, 4, 21)
+    dg = _dev_graph(G)
+    sid = T.stream_id(T.STREAM_STRUCT_PATCH)
+    whole = ops.triangular_walks(dg, 0, 37, 25, 0.5, 77, sid, kernel=walk_kernel)
+    for lo, hi in ((0, 10), (10, 29), (29, 37)):
+        part = ops.triangular_walks(dg, 0, hi - lo, 25, 0.5, 77, sid, kernel=walk_kernel, item_base=lo)
+        assert torch.equal(part, whole[lo:hi])
+    patches = whole.cpu().numpy()
+    views = [IH.patch_unique_nodes(p) for p in patches]
+    inb = [IH.patch_in_border_nodes(G, v) for v in views]
+    W = 3
+    for inside in (True, False):
+        st = T.stream_id(T.STREAM_WALK_INT if inside else T.STREAM_WALK_BOR)
+        mode = 1 if inside else 2
+        full = ops.triangular_walks(dg, mode, 37 * W, 11, 0.5, 77, st, patches=ops.Ragged.from_lists(views, DEV),
+                                    in_border=ops.Ragged.from_lists(inb, DEV), walks_per_patch=W, kernel=walk_kernel).view(37, W, 11)
+        for lo, hi in ((0, 19), (19, 37)):
+            part = ops.triangular_walks(dg, mode, (hi - lo) * W, 11, 0.5, 77, st, patches=ops.Ragged.from_lists(views[lo:hi], DEV),
+                                        in_border=ops.Ragged.from_lists(inb[lo:hi], DEV), walks_per_patch=W, kernel=walk_kernel,
+                                        item_base=lo * W).view(hi - lo, W, 11)
+            assert torch.equal(part, full[lo:hi])
+
+
 def test_walks_hubs_both_kernels_agree():
     """Long walks over hubs (lists longer than one 64-entry chunk per wavefront, several workgroup
     passes over the items): the two kernels return the same walks."""
