@@ -185,6 +185,23 @@ int sgnn_khop_border_sample(const int64_t* rowptr, const int32_t* col, const int
 int sgnn_khop_sample_finish(int64_t* anchor, const uint8_t* hop, const uint8_t* allneg, const int64_t* counts,
                             const int64_t* width, int64_t n_sets, int64_t n_slots, float* sims, void* stream);
 
+/* Padded id rows (n_rows, row_len) int64 -> ragged sets: PAD (0) entries stripped -- or, with mask (uint8, same shape), the
+ * entries whose mask is 0 -- order kept (how gamma.py:27, anchor_patch_samplers.py:131 and SubGNN.py:769 strip PAD).
+ * sgnn_pack_rows_count writes the rows' kept counts; the caller's exclusive prefix sum of them is ptr (n_rows + 1);
+ * sgnn_pack_rows_write writes the kept ids (as int32) behind ptr[row]. */
+/* keep (n_rows, row_len) uint8: 1 where ids[r, i] != PAD and no earlier entry of the row holds the same id -- the node view of
+ * a patch (unique nodes of a walk, first occurrence first: anchor_patch_samplers.py:131-138) as a mask for sgnn_pack_rows_*. */
+int sgnn_first_occurrence_mask(const int64_t* ids, int64_t n_rows, int64_t row_len, uint8_t* keep, void* stream);
+/* The flagged entries (flags uint8, aligned with set_nodes) of every ragged set, order kept -- a patch's in-border nodes
+ * (subgraph_utils.py:126-144 via sgnn_patch_in_border).  counts != NULL: write the sets' flagged counts; counts == NULL: write
+ * the flagged ids behind out_ptr[set] (the caller's exclusive prefix sum of the counts). */
+int sgnn_filter_sets(const int64_t* set_ptr, const int32_t* set_nodes, const uint8_t* flags, int64_t n_sets, int64_t* counts,
+                     const int64_t* out_ptr, int32_t* out_nodes, void* stream);
+int sgnn_pack_rows_count(const int64_t* ids, const uint8_t* mask, int64_t n_rows, int64_t row_len, int64_t* counts,
+                         void* stream);
+int sgnn_pack_rows_write(const int64_t* ids, const uint8_t* mask, int64_t n_rows, int64_t row_len, const int64_t* ptr,
+                         int32_t* nodes, void* stream);
+
 /* ---------------------------------------------------------------------------------------
  * a4  Neighbourhood anchor sampling from padded id matrices.
  * Replaces anchor_patch_samplers.sample_neighborhood_anchor_patch (anchor_patch_samplers.py:

@@ -93,6 +93,10 @@ SIGNATURES = {
     'sgnn_grad_sumsq_partials': (c_i64, []),
     'sgnn_grad_sumsq': (c_int, [c_ptr, c_i64, c_ptr, c_ptr]),
     'sgnn_clip_coefficient': (c_int, [c_ptr, c_i64, c_ptr, c_i64, ctypes.c_float, c_ptr, c_ptr, c_ptr]),
+    'sgnn_first_occurrence_mask': (c_int, [c_ptr, c_i64, c_i64, c_ptr, c_ptr]),
+    'sgnn_filter_sets': (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr]),
+    'sgnn_pack_rows_count': (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr]),
+    'sgnn_pack_rows_write': (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_ptr]),
     'sgnn_khop_sample_finish': (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr]),
     'sgnn_cross_entropy_workspace_bytes': (c_i64, [c_i64]),
     'sgnn_cross_entropy_fwd': (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr]),

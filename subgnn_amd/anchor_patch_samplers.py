@@ -34,7 +34,9 @@ def patch_node_views(anchor_patch_ids):
     P, L = anchor_patch_ids.shape
     dev = anchor_patch_ids.device
     ids = anchor_patch_ids
-    if P * L * L <= VIEW_PAIRWISE_MAX:
+    if P * L * L <= VIEW_PAIRWISE_MAX and ids.is_cuda:
+        keep = ops.first_occurrence_mask(ids)                                     # one launch: entry i against the i entries before it
+    elif P * L * L <= VIEW_PAIRWISE_MAX:
         earlier = torch.ones(L, L, dtype=torch.bool, device=dev).tril(-1)          # [i, j]: j < i
         dup = ((ids.unsqueeze(2) == ids.unsqueeze(1)) & earlier.unsqueeze(0)).any(dim=2)
         keep = ~dup & (ids != PAD_VALUE)
@@ -53,6 +55,8 @@ def patch_node_views(anchor_patch_ids):
 def in_border_sets(graph, views):
     """per patch: the view nodes with an edge leaving the patch (su.get_border_nodes)."""
     flags = ops.patch_in_border(graph, views)
+    if flags.is_cuda:
+        return ops.filter_sets(views, flags)
     L = views._max_len
     if L is None:
         L = views.max_len

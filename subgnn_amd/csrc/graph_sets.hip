@@ -530,6 +530,114 @@ __global__ __launch_bounds__(256) void sort_sets_kernel(const int64_t* __restric
     }
 }
 
+// ---- padded id rows -> ragged sets (PAD / masked entries stripped, order kept) ---------------------------------------------
+// Every stage takes its node sets as CSR-style (ptr, nodes); the reference-shaped tensors are padded (rows, L) int64
+// matrices (component ids S.py:575-607, structure patches aps:210-243, node views aps:131).  Two passes around the caller's
+// prefix sum: counts per row, then the kept entries written behind the row's offset.  (As torch ops this was thirteen
+// launches per conversion -- a triangular GEMM for the ranks, where, scatter ... -- four conversions per pass.)
+__global__ __launch_bounds__(256) void pack_rows_count_kernel(const int64_t* __restrict__ ids, const uint8_t* __restrict__ mask,
+                                                              int64_t n, int64_t L, int64_t* __restrict__ counts)
+{
+    const int64_t r = blockIdx.x * 256ll + threadIdx.x;
+    if (r >= n) return;
+    int64_t c = 0;
+    for (int64_t j = 0; j < L; ++j) c += mask ? (mask[r * L + j] != 0) : (ids[r * L + j] != 0);
+    counts[r] = c;
+}
+
+__global__ __launch_bounds__(256) void pack_rows_write_kernel(const int64_t* __restrict__ ids, const uint8_t* __restrict__ mask,
+                                                              int64_t n, int64_t L, const int64_t* __restrict__ ptr,
+                                                              int32_t* __restrict__ nodes)
+{
+    const int64_t r = blockIdx.x * 256ll + threadIdx.x;
+    if (r >= n) return;
+    int64_t o = ptr[r];
+    for (int64_t j = 0; j < L; ++j) {
+        const int64_t v = ids[r * L + j];
+        if (mask ? (mask[r * L + j] != 0) : (v != 0)) nodes[o++] = (int32_t)v;
+    }
+}
+
+// keep[r, i] = ids[r, i] is not PAD and no earlier entry of row r holds the same id: the node view of a patch (the unique nodes
+// of a walk in first-occurrence order, anchor_patch_samplers.py:131-138) as a mask for sgnn_pack_rows_*
+__global__ __launch_bounds__(256) void first_occurrence_kernel(const int64_t* __restrict__ ids, int64_t n, int64_t L,
+                                                               uint8_t* __restrict__ keep)
+{
+    const int64_t t = blockIdx.x * 256ll + threadIdx.x;
+    if (t >= n * L) return;
+    const int64_t r = t / L, i = t - r * L;
+    const int64_t v = ids[t];
+    bool k = v != 0;
+    for (int64_t j = 0; k && j < i; ++j) k = ids[r * L + j] != v;
+    keep[t] = k ? 1 : 0;
+}
+
+extern "C" int sgnn_first_occurrence_mask(const int64_t* ids, int64_t n_rows, int64_t row_len, uint8_t* keep, void* stream)
+{
+    if (!ids || !keep || n_rows < 0 || row_len < 0) return SGNN_ERR_BAD_ARG;
+    const int64_t total = n_rows * row_len;
+    if (total == 0) return SGNN_OK;
+    if ((total + 255) / 256 > 0x7fffffff) return SGNN_ERR_BAD_ARG;
+    hipLaunchKernelGGL(first_occurrence_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ids, n_rows,
+                       row_len, keep);
+    SGNN_CHECK_LAUNCH();
+    return SGNN_OK;
+}
+
+// the flagged entries of every ragged set, order kept (a patch's in-border nodes among its view nodes,
+// subgraph_utils.py:126-144): counts, then -- around the caller's prefix sum -- the packed write
+__global__ __launch_bounds__(256) void filter_sets_kernel(const int64_t* __restrict__ set_ptr, const int32_t* __restrict__ set_nodes,
+                                                          const uint8_t* __restrict__ flags, int64_t n_sets,
+                                                          int64_t* __restrict__ counts, const int64_t* __restrict__ out_ptr,
+                                                          int32_t* __restrict__ out_nodes)
+{
+    const int64_t s = blockIdx.x * 256ll + threadIdx.x;
+    if (s >= n_sets) return;
+    const int64_t b = set_ptr[s], e = set_ptr[s + 1];
+    if (counts) {
+        int64_t c = 0;
+        for (int64_t i = b; i < e; ++i) c += flags[i] != 0;
+        counts[s] = c;
+    } else {
+        int64_t o = out_ptr[s];
+        for (int64_t i = b; i < e; ++i)
+            if (flags[i]) out_nodes[o++] = set_nodes[i];
+    }
+}
+
+extern "C" int sgnn_filter_sets(const int64_t* set_ptr, const int32_t* set_nodes, const uint8_t* flags, int64_t n_sets,
+                                int64_t* counts, const int64_t* out_ptr, int32_t* out_nodes, void* stream)
+{
+    if (!set_ptr || !set_nodes || !flags || n_sets < 0 || (!counts && (!out_ptr || !out_nodes))) return SGNN_ERR_BAD_ARG;
+    if (n_sets == 0) return SGNN_OK;
+    hipLaunchKernelGGL(filter_sets_kernel, dim3((unsigned)((n_sets + 255) / 256)), dim3(256), 0, (hipStream_t)stream, set_ptr, set_nodes,
+                       flags, n_sets, counts, out_ptr, out_nodes);
+    SGNN_CHECK_LAUNCH();
+    return SGNN_OK;
+}
+
+extern "C" int sgnn_pack_rows_count(const int64_t* ids, const uint8_t* mask, int64_t n_rows, int64_t row_len, int64_t* counts,
+                                    void* stream)
+{
+    if (!ids || !counts || n_rows < 0 || row_len < 0) return SGNN_ERR_BAD_ARG;
+    if (n_rows == 0) return SGNN_OK;
+    hipLaunchKernelGGL(pack_rows_count_kernel, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ids, mask, n_rows,
+                       row_len, counts);
+    SGNN_CHECK_LAUNCH();
+    return SGNN_OK;
+}
+
+extern "C" int sgnn_pack_rows_write(const int64_t* ids, const uint8_t* mask, int64_t n_rows, int64_t row_len, const int64_t* ptr,
+                                    int32_t* nodes, void* stream)
+{
+    if (!ids || !ptr || !nodes || n_rows < 0 || row_len < 0) return SGNN_ERR_BAD_ARG;
+    if (n_rows == 0) return SGNN_OK;
+    hipLaunchKernelGGL(pack_rows_write_kernel, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ids, mask, n_rows,
+                       row_len, ptr, nodes);
+    SGNN_CHECK_LAUNCH();
+    return SGNN_OK;
+}
+
 extern "C" int sgnn_sort_sets(const int64_t* set_ptr, const int32_t* set_nodes, int64_t n_sets, int64_t max_set_size,
                               int32_t* out_nodes, int32_t* out_pos, void* stream)
 {

@@ -70,7 +70,7 @@ class Ragged:
         """(rows, L) padded int64 ids -> ragged, PAD stripped, order kept (gamma.py:27,
         aps:131, S.py:769 all strip PAD this way)."""
         assert ids.dim() == 2
-        return Ragged.from_mask(ids, ids != PAD)
+        return Ragged.from_mask(ids, None)
 
     @staticmethod
     def from_mask(ids, mask):
@@ -78,12 +78,25 @@ class Ragged:
         a host round trip: the packed position of an entry is its row's offset plus its rank among the
         row's kept entries, dropped entries go to one spare slot behind the data (the node array is an
         arena of rows*L + 1 entries; ``ptr`` says what is live)."""
-        assert ids.dim() == 2 and mask.shape == ids.shape
+        assert ids.dim() == 2 and (mask is None or mask.shape == ids.shape)
         n, L = ids.shape
         dev = ids.device
         ptr = torch.zeros(n + 1, dtype=torch.int64, device=dev)
         if n == 0 or L == 0:
             return Ragged(ptr, torch.zeros(1, dtype=torch.int32, device=dev), max_len=L)
+        if ids.is_cuda and ids.dtype == torch.int64:
+            # counts per row, prefix sum, packed write (sgnn_pack_rows_count / _write): mask None = strip PAD
+            lib = _lib.load()
+            ids = ids.contiguous()
+            m8 = None if mask is None else mask.to(torch.uint8).contiguous()
+            counts = torch.empty(n, dtype=torch.int64, device=dev)
+            check(lib.sgnn_pack_rows_count(_ptr(ids), _ptr(m8), n, L, _ptr(counts), _stream()), 'sgnn_pack_rows_count')
+            torch.cumsum(counts, 0, out=ptr[1:])
+            nodes = torch.zeros(n * L + 1, dtype=torch.int32, device=dev)      # an arena: ptr says what is live
+            check(lib.sgnn_pack_rows_write(_ptr(ids), _ptr(m8), n, L, _ptr(ptr), _ptr(nodes), _stream()), 'sgnn_pack_rows_write')
+            return Ragged(ptr, nodes, max_len=L)
+        if mask is None:
+            mask = ids != PAD
         # rank of an entry among its row's kept entries.  torch's scan along the innermost dimension of
         # a (50k, 20) matrix takes 0.15 ms; for the short rows of this path the same numbers come out of
         # one small GEMM with a triangular matrix (counts < 2^24 are exact in fp32)
@@ -202,6 +215,34 @@ class DeviceGraph:
 # ---------------------------------------------------------------------------------------
 # integer half
 # ---------------------------------------------------------------------------------------
+
+def first_occurrence_mask(ids):
+    """(rows, L) int64 -> uint8 mask: non-PAD entries that no earlier entry of their row repeats (sgnn_first_occurrence_mask)."""
+    _req(ids, torch.int64, 'ids')
+    ids = ids.contiguous()
+    keep = torch.empty(ids.shape, dtype=torch.uint8, device=ids.device)
+    check(_lib.load().sgnn_first_occurrence_mask(_ptr(ids), ids.shape[0], ids.shape[1], _ptr(keep), _stream()),
+          'sgnn_first_occurrence_mask')
+    return keep
+
+
+def filter_sets(sets, flags):
+    """The entries of every set whose flag (uint8, aligned with sets.nodes) is set, order kept -> Ragged (sgnn_filter_sets)."""
+    lib = _lib.load()
+    _req(flags, torch.uint8, 'flags')
+    dev = sets.ptr.device
+    counts = torch.empty(sets.n, dtype=torch.int64, device=dev)
+    ptr = torch.zeros(sets.n + 1, dtype=torch.int64, device=dev)
+    if sets.n == 0:
+        return Ragged(ptr, torch.zeros(1, dtype=torch.int32, device=dev), max_len=0)
+    check(lib.sgnn_filter_sets(_ptr(sets.ptr), _ptr(sets.nodes), _ptr(flags), sets.n, _ptr(counts), None, None, _stream()),
+          'sgnn_filter_sets')
+    torch.cumsum(counts, 0, out=ptr[1:])
+    nodes = torch.zeros(max(sets.nodes.numel(), 1), dtype=torch.int32, device=dev)       # an arena: ptr says what is live
+    check(lib.sgnn_filter_sets(_ptr(sets.ptr), _ptr(sets.nodes), _ptr(flags), sets.n, None, _ptr(ptr), _ptr(nodes), _stream()),
+          'sgnn_filter_sets')
+    return Ragged(ptr, nodes, max_len=sets._max_len)
+
 
 def heaviest_first(g, sets):
     """Dispatch order for set kernels whose cost is the members' total degree: heaviest sets first."""
