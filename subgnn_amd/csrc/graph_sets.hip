@@ -28,6 +28,8 @@ __global__ __launch_bounds__(64) void cc_labels_kernel(
 {
     __shared__ int32_t s_id[NMAX];
     __shared__ int32_t s_parent[NMAX];
+    __shared__ int64_t s_r0[NMAX];                          // the members' row starts and degrees: read once, not per pair
+    __shared__ int32_t s_deg[NMAX];
     const int lane = threadIdx.x;
     for (int64_t s = blockIdx.x; s < n_sub; s += gridDim.x) {
         const int64_t beg = sub_ptr[s];
@@ -38,30 +40,44 @@ __global__ __launch_bounds__(64) void cc_labels_kernel(
             for (int i = lane; i < n; i += 64) out_label[beg + i] = -1;
             continue;
         }
-        for (int i = lane; i < n; i += 64) { s_id[i] = sub_nodes[beg + i]; s_parent[i] = i; }
+        for (int i = lane; i < n; i += 64) {
+            const int32_t v = sub_nodes[beg + i];
+            const int64_t a0 = rowptr[v];
+            s_id[i] = v; s_parent[i] = i; s_r0[i] = a0; s_deg[i] = (int32_t)(rowptr[v + 1] - a0);
+        }
         __syncthreads();
-        const int64_t npairs = (int64_t)n * n;
-        for (int64_t p = lane; p < npairs; p += 64) {
-            int i = (int)(p / n), j = (int)(p % n);
-            if (i >= j) continue;
-            const int32_t a = s_id[i], b = s_id[j];
-            bool linked = (a == b);
-            if (!linked) {
-                const int64_t a0 = rowptr[a], a1 = rowptr[a + 1], b0 = rowptr[b], b1 = rowptr[b + 1];
-                if (a1 - a0 <= b1 - b0) linked = sgnn_sorted_contains(col_sorted + a0, (int32_t)(a1 - a0), b);
-                else linked = sgnn_sorted_contains(col_sorted + b0, (int32_t)(b1 - b0), a);
-            }
-            if (linked) {
-                int x = i, y = j;
-                while (true) {
-                    x = cc_find(s_parent, x);
-                    y = cc_find(s_parent, y);
-                    if (x == y) break;
-                    if (x < y) { const int t = x; x = y; y = t; }       // hook x (larger) under y
-                    const int32_t old = atomicCAS(&s_parent[x], x, y);
-                    if (old == x) break;
+        // the n (n - 1) / 2 pairs i < j, 64 per round (j-major: pair p = j (j - 1) / 2 + i); the loop ends as soon as n - 1
+        // unions have succeeded -- the subgraph is one component and no further pair can change a label (a BFS subgraph
+        // of 20 nodes is connected after about half of its 190 pairs)
+        const int64_t npairs = (int64_t)n * (n - 1) / 2;
+        int unions = 0;
+        for (int64_t p0 = 0; p0 < npairs && unions < n - 1; p0 += 64) {
+            const int64_t p = p0 + lane;
+            bool merged = false;
+            if (p < npairs) {
+                int j = (int)((1.0 + sqrt(1.0 + 8.0 * (double)p)) * 0.5);
+                while ((int64_t)j * (j - 1) / 2 > p) --j;
+                while ((int64_t)(j + 1) * j / 2 <= p) ++j;
+                const int i = (int)(p - (int64_t)j * (j - 1) / 2);
+                const int32_t a = s_id[i], b = s_id[j];
+                bool linked = (a == b);
+                if (!linked) {
+                    if (s_deg[i] <= s_deg[j]) linked = sgnn_sorted_contains(col_sorted + s_r0[i], s_deg[i], b);
+                    else linked = sgnn_sorted_contains(col_sorted + s_r0[j], s_deg[j], a);
+                }
+                if (linked) {
+                    int x = i, y = j;
+                    while (true) {
+                        x = cc_find(s_parent, x);
+                        y = cc_find(s_parent, y);
+                        if (x == y) break;
+                        if (x < y) { const int t = x; x = y; y = t; }       // hook x (larger) under y
+                        const int32_t old = atomicCAS(&s_parent[x], x, y);
+                        if (old == x) { merged = true; break; }
+                    }
                 }
             }
+            unions += __popcll(__ballot(merged));           // every successful hook removes one component
         }
         __syncthreads();
         for (int i = lane; i < n; i += 64) out_label[beg + i] = cc_find(s_parent, i);
