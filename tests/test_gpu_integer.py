@@ -958,3 +958,41 @@ def test_dtw_similarity_kept_row_preparation(golden):
     for _ in range(2):
         assert torch.equal(ops.dtw_similarity(X.ptr, X.nodes, 12, Y.ptr, Y.nodes, 25, dedupe=False, x_prep=keep2), want)
     assert 'order' in keep2
+
+
+# ---- padded rows -> ragged sets, node views, in-border filter (the set plumbing every stage goes through) -----------------
+
+@pytest.mark.parametrize('n,L', [(1, 1), (37, 20), (2000, 7), (210, 50), (3, 300)])
+def test_ragged_from_padded_and_from_mask_strip_entries_in_order(n, L):
+    """sgnn_pack_rows_count / _write against plain python: PAD entries (or masked-out ones) removed, order kept, rows that
+    are all PAD give empty sets (gamma.py:27, aps:131, S.py:769)."""
+    ops = _ops()
+    rng = np.random.default_rng(n * 131 + L)
+    ids = rng.integers(0, 9, size=(n, L)).astype(np.int64) * rng.integers(0, 2, size=(n, L))
+    ids[0] = 0
+    r = ops.Ragged.from_padded(torch.from_numpy(ids).to(DEV))
+    assert r.to_lists() == [[int(v) for v in row if v != 0] for row in ids]
+    mask = rng.integers(0, 2, size=(n, L)).astype(bool)
+    r = ops.Ragged.from_mask(torch.from_numpy(ids).to(DEV), torch.from_numpy(mask).to(DEV))
+    assert r.to_lists() == [[int(v) for v, k in zip(row, mk) if k] for row, mk in zip(ids, mask)]
+
+
+def test_first_occurrence_mask_and_filter_sets():
+    """sgnn_first_occurrence_mask = the node view of a walk (unique ids, first occurrence first, PAD dropped: aps:131-138);
+    sgnn_filter_sets = the flagged entries of every set in order (the in-border nodes among a patch's view nodes)."""
+    ops = _ops()
+    rng = np.random.default_rng(5)
+    ids = rng.integers(0, 12, size=(300, 40)).astype(np.int64)
+    keep = ops.first_occurrence_mask(torch.from_numpy(ids).to(DEV)).cpu().numpy().astype(bool)
+    for row, k in zip(ids, keep):
+        seen, want = set(), []
+        for v in row:
+            want.append(v != 0 and v not in seen)
+            seen.add(v)
+        assert k.tolist() == want
+    lists = [rng.integers(1, 1000, size=rng.integers(0, 30)).tolist() for _ in range(500)]
+    sets = ops.Ragged.from_lists(lists, DEV)
+    flags = [rng.integers(0, 2, size=len(l)).tolist() for l in lists]
+    flat = torch.tensor([f for fl in flags for f in fl] + [0] * (sets.nodes.numel() - sum(map(len, lists))), dtype=torch.uint8, device=DEV)
+    got = ops.filter_sets(sets, flat)
+    assert got.to_lists() == [[v for v, f in zip(l, fl) if f] for l, fl in zip(lists, flags)]
