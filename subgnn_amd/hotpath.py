@@ -414,10 +414,18 @@ def prepare_pass(model, split='train', timer=None, shard=None, defer_dtw=False):
             sims[('N', 'in', l)] = ops.ZeroSims(ni[l].shape, dev)
             # border BFS fused with the border-anchor draw (rank query on the visited bitmap): the
             # border is never materialised
-            a, w, _ = ops.khop_border_sample(g, cc_sets, k, hp['n_anchor_patches_N_out'], seed,
-                                             tape.stream_id(tape.STREAM_N_BOR, split, l),     # taken dynamically: a dispatch order buys nothing here
-                                             item_base=base * C,
-                                             count_reduce=shard.reduce_max if shard is not None else None)
+            # the padded border matrix's width (the largest border: the PAD rule needs it) is a property of the split's
+            # components and the graph, not of the draw: reduced (over the ranks too) on the first pass, kept afterwards
+            widths = model.__dict__.setdefault('_border_width', {})
+            wkey = (split, k, cc_sets.n, shard.world if shard is not None else 1)
+            a, w, counts = ops.khop_border_sample(g, cc_sets, k, hp['n_anchor_patches_N_out'], seed,
+                                                  tape.stream_id(tape.STREAM_N_BOR, split, l),     # taken dynamically: a dispatch order buys nothing here
+                                                  item_base=base * C,
+                                                  count_reduce=shard.reduce_max if shard is not None else None,
+                                                  width=widths.get(wkey))
+            if wkey not in widths:
+                wmax = counts.max().view(1)
+                widths[wkey] = shard.reduce_max(wmax) if shard is not None else wmax
             nb[l] = a.view(S, C, -1)
             sims[('N', 'out', l)] = w.view(S, C, -1).contiguous()
             D = hp['node_embed_size']

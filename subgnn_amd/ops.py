@@ -418,7 +418,7 @@ def khop_border_one_pass(g, sets, bitmap_in_lds=None):
 
 
 def khop_border_sample(g, sets, k, n_slots, seed, stream_id, bitmap_in_lds=None, order=None, item_base=0,
-                       count_reduce=None):
+                       count_reduce=None, width=None):
     """k-hop border BFS + neighbourhood-border anchor draw without a padded border matrix.  Returns
     anchors (n_sets, n_slots) int64 with the reference's PAD rule applied, their hop levels as
     float32 similarities (0 on PAD) and the border sizes.  One fused kernel: the draw is a rank
@@ -446,9 +446,13 @@ def khop_border_sample(g, sets, k, n_slots, seed, stream_id, bitmap_in_lds=None,
     # padded row (width = the largest border) has at least one PAD column
     # (``count_reduce``: applied to the device scalar holding the largest border when these sets are one shard
     # of the matrix -- the padded width is a property of ALL rows: dist.all_reduce_max_)
-    width = counts.max().view(1)
-    if count_reduce is not None:
-        width = count_reduce(width)
+    # ``width``: that maximum as a device scalar when the caller has kept it (border sizes depend on the sets and the
+    # graph only, not on the draw: hotpath keeps it per split after the first pass -- no reduction launch, and under
+    # data parallelism no collective, in later passes)
+    if width is None:
+        width = counts.max().view(1)
+        if count_reduce is not None:
+            width = count_reduce(width)
     sims = torch.empty((sets.n, n_slots), dtype=torch.float32, device=g.device)
     check(lib.sgnn_khop_sample_finish(_ptr(anchor), _ptr(hop), _ptr(allneg), _ptr(counts), _ptr(width.to(torch.int64)), sets.n, n_slots,
                                       _ptr(sims), _stream()), 'sgnn_khop_sample_finish')
