@@ -249,3 +249,37 @@ def test_density_recipe_against_the_reference_run():
     assert list(st['labels']) == [str(l) for l in z['recipe_labels']]
     assert np.array_equal(np.array(st['values']), z['recipe_density'])
     assert mask == z['recipe_mask'].tolist()
+
+
+def test_block_rows_prefers_a_divisor_near_the_wanted_block():
+    """ops._block_rows: the row-block size of a split contraction divides the row count when a divisor exists between
+    want / 2 and 2 want (no remainder GEMM), and is the divisor nearest to ``want``."""
+    from subgnn_amd import ops
+    assert ops._block_rows(50000) == 1000 and 50000 % 1000 == 0
+    assert ops._block_rows(16800) in (1050, 1120, 1200, 840, 800) and 16800 % ops._block_rows(16800) == 0
+    assert abs(ops._block_rows(16800) - 1024) == min(abs(d - 1024) for d in range(512, 2049) if 16800 % d == 0)
+    assert ops._block_rows(1024 * 7) == 1024
+    p = 100003                                   # a prime: no divisor in range
+    assert ops._block_rows(p) == 1024
+
+
+def test_copy_into_keeps_addresses_and_reports_what_it_had_to_replace():
+    """hotpath._copy_into (install_pass_static): tensors of equal shape / dtype are copied INTO the kept tensors (the
+    addresses a recorded training half reads stay valid), attributes hung on tensors follow, a shape change is replaced
+    and reported, storage seen twice is copied once."""
+    from subgnn_amd import hotpath
+    kept_a, kept_b = torch.zeros(4, 3), torch.zeros(5, dtype=torch.int64)
+    kept_a._sgnn_ids32 = torch.zeros(12, dtype=torch.int32)
+    dst = {'a': kept_a, 'nest': {0: (kept_b, None, 7)}, 'gone': torch.zeros(2)}
+    new_a = torch.arange(12.).view(4, 3)
+    new_a._sgnn_ids32 = torch.arange(12, dtype=torch.int32)
+    new_b = torch.arange(5)
+    src = {'a': new_a, 'nest': {0: (new_b, None, 8)}, 'gone': torch.zeros(3), 'alias': new_a}
+    replaced = []
+    out = hotpath._copy_into(dst, src, 'root', replaced)
+    assert out is dst and out['a'] is kept_a and torch.equal(kept_a, new_a)
+    assert out['a']._sgnn_ids32.data_ptr() == kept_a._sgnn_ids32.data_ptr() and torch.equal(kept_a._sgnn_ids32, new_a._sgnn_ids32)
+    assert out['nest'][0][0] is kept_b and torch.equal(kept_b, new_b) and out['nest'][0][2] == 8
+    assert out['gone'].shape == (3,) and any("gone" in r for r in replaced)
+    assert out['alias'] is new_a and any('alias' in r for r in replaced)      # nothing kept under that name yet: replaced
+    assert len(replaced) == 2
