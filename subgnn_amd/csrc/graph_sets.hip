@@ -1171,8 +1171,8 @@ __global__ __launch_bounds__(K1_THREADS) void khop1_sample_kernel(
     unsigned long long t_last = clock64();
 #endif
     bool have_pf = false;
-    uint32_t pf_r0 = 0;
-    int32_t pf_deg = 0, pf_v = 0;
+    uint32_t pf_r0 = 0, pf_r1 = 0;                           // the prefetched row's start and end, RAW: see step 2 below
+    int32_t nx_v = 0;                                        // the NEXT set's first 64 members (prefetch step 1); read back as v_pf one set later
     int64_t trip0 = 0, trip_ptr = 0;
     while (true) {
         if (si_next >= si_end) {
@@ -1194,8 +1194,7 @@ __global__ __launch_bounds__(K1_THREADS) void khop1_sample_kernel(
         // (the first 64 members' row pointers may have been fetched while the previous set was being processed)
         const int64_t beg = set_order ? set_ptr[s] : sgnn_readlane64(trip_ptr, tj);
         const int n = (int)((set_order ? set_ptr[s + 1] : sgnn_readlane64(trip_ptr, tj + 1)) - beg);
-        const uint32_t r0_pf = pf_r0;
-        const int32_t deg_pf = pf_deg;
+        const uint32_t r0_pf = pf_r0, r1_pf = pf_r1;
         const bool use_pf = have_pf;
         have_pf = false;
         // the next set of this trip, if there is one: its members are loaded now and their row pointers after
@@ -1213,12 +1212,11 @@ __global__ __launch_bounds__(K1_THREADS) void khop1_sample_kernel(
         }
         const bool can_pf = !SLICED && set_order == nullptr && si_next < si_end && si_next < n_sets;
         int64_t nx_beg = 0, nx_end = 0;
-        int32_t nx_v = 0;
         if (can_pf) {
             nx_beg = sgnn_readlane64(trip_ptr, tj + 1);
             nx_end = sgnn_readlane64(trip_ptr, tj + 2);
         }
-        const int32_t v_pf = pf_v;                                 // this set's first 64 members, if prefetched
+        const int32_t v_pf = nx_v;                                 // this set's first 64 members, if prefetched (copied HERE, a set after the load: no wait)
         int32_t v_tile0 = 0;
         int cnt = 0;
         for (int pass = 0; pass < (SLICED ? 2 : 1); ++pass) {
@@ -1234,7 +1232,7 @@ __global__ __launch_bounds__(K1_THREADS) void khop1_sample_kernel(
                 for (int t0 = 0; t0 < n; t0 += 64) {
                     uint32_t r0 = 0;
                     int32_t deg = 0;
-                    if (t0 == 0 && use_pf) { r0 = r0_pf; deg = deg_pf; v_tile0 = v_pf; }
+                    if (t0 == 0 && use_pf) { r0 = r0_pf; deg = (int32_t)(r1_pf - r0_pf); v_tile0 = v_pf; }
                     else if (t0 + lane < n) {
                         const int32_t v = set_nodes[beg + t0 + lane];
                         if (t0 == 0) v_tile0 = v;
@@ -1317,23 +1315,38 @@ __global__ __launch_bounds__(K1_THREADS) void khop1_sample_kernel(
                 K1_T(7);                                               // (debug) own chunks done
                 if (n == 0 && can_pf && lane < nx_end - nx_beg) nx_v = set_nodes[nx_beg + lane];    // (no tile ran step 1)
                 if (can_pf) {                                          // step 2 of the prefetch: the next set's row pointers
-                    pf_r0 = 0; pf_deg = 0;
+                    // (the loaded words go into pf_r0 / pf_r1 untouched: forming the degree here made the compiler wait for the
+                    // load on the spot -- the whole prefetch latency sat in front of the expansion's barrier)
+                    // Only the LOW words of the two row pointers are loaded (nnz < 2^31), each into its own register: a 16-byte
+                    // load left two dead registers in its destination, the allocator put a live value into one of them, and that copy
+                    // waited for the load as well.
+                    pf_r0 = 0; pf_r1 = 0;
                     if (lane < nx_end - nx_beg) {
-                        const int64_t a = rowptr[nx_v], b = rowptr[nx_v + 1];
-                        pf_r0 = (uint32_t)a;
-                        pf_deg = (int32_t)(b - a);
+                        const uint32_t* __restrict__ rp32 = reinterpret_cast<const uint32_t*>(rowptr) + 2 * (int64_t)nx_v;
+                        pf_r0 = rp32[0];
+                        pf_r1 = rp32[2];
                     }
-                    pf_v = nx_v;
                     have_pf = true;
                 }
                 k1_lds_barrier();
                 K1_T(1);                                           // expansion
                 // ---- the members themselves are not border ---------------------------------------------
-                for (int i = tid; i < n; i += K1_THREADS) {
-                    const int64_t v = i < 64 ? (int64_t)v_tile0 : (int64_t)set_nodes[beg + i];    // wavefront 0 still holds the first tile
+                // (two separate paths: with the load of the members beyond the first tile in the same loop, the wait for it sat on
+                // the common path -- and, the counter of outstanding loads being in-order, waited for the prefetch above as well)
+                if (tid < 64 && tid < n) {                                           // wavefront 0 still holds the first tile
+                    const int64_t v = (int64_t)v_tile0;
                     if (v >= lo_id && v < hi_id) {
                         const int32_t x = (int32_t)(v - lo_id);
                         __hip_atomic_fetch_and(&s_bm[x >> 5], ~(1u << (x & 31)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                }
+                if (n > 64) {
+                    for (int i = 64 + tid; i < n; i += K1_THREADS) {
+                        const int64_t v = (int64_t)set_nodes[beg + i];
+                        if (v >= lo_id && v < hi_id) {
+                            const int32_t x = (int32_t)(v - lo_id);
+                            __hip_atomic_fetch_and(&s_bm[x >> 5], ~(1u << (x & 31)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        }
                     }
                 }
                 k1_lds_barrier();
