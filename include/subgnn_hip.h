@@ -38,7 +38,7 @@ extern "C" {
 #define SGNN_ERR_LAUNCH         -4   /* hipGetLastError() after a launch */
 #define SGNN_ERR_UNSUPPORTED_D  -5   /* embedding width not supported by the vector path */
 
-#define SGNN_ABI_VERSION 5
+#define SGNN_ABI_VERSION 6
 int sgnn_abi_version(void);
 /* last hip error string for SGNN_ERR_LAUNCH (static storage) */
 const char* sgnn_last_error(void);
@@ -500,8 +500,11 @@ int sgnn_masked_sum_slot_bwd(const float* grad_out, int64_t grad_ld, const uint8
 /* ---------------------------------------------------------------------------------------
  * a17  Loss + accuracy of a step: nn.CrossEntropyLoss() with its default mean reduction (SubGNN/SubGNN.py:133, applied
  * at SubGNN.py:1116-1124) and subgraph_utils.calc_accuracy (SubGNN/subgraph_utils.py:108-124: argmax == label, mean)
- * in one pass over logits (B, K) row-major, labels int64 (B) in [0, K).  lse (B): the rows' log-sum-exp, kept for the
- * backward.  loss, accuracy: one float each (accuracy nullable).  grad_logits = (softmax - onehot) * grad_loss[0] / B.
+ * in one pass over logits (B, K) row-major, labels int64 (B) in [0, K) or -100 (nn.CrossEntropyLoss's ignore_index: the row
+ * contributes nothing and the mean is over the other rows; any other label outside [0, K) makes the loss NaN -- the library
+ * raises).  lse (B + 1 floats): the rows' log-sum-exp and, in lse[B], the number of rows not ignored, kept for the
+ * backward.  loss, accuracy: one float each (accuracy nullable; over all B rows).
+ * grad_logits = (softmax - onehot) * grad_loss[0] / lse[B].
  * Partial sums are added in a fixed order: bit-reproducible.
  * ------------------------------------------------------------------------------------- */
 int64_t sgnn_cross_entropy_workspace_bytes(int64_t B);

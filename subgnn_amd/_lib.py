@@ -151,7 +151,7 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the header and the library disagree
         fn.restype = res
         fn.argtypes = args
-    if lib.sgnn_abi_version() != 5:
+    if lib.sgnn_abi_version() != 6:
         raise SubgnnHipError('ABI version mismatch')
     _lib = lib
     return lib

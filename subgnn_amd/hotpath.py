@@ -103,10 +103,10 @@ def _bfs_note(model, st, key, status, max_hops, enqueued, redo):
                                'is smaller than the depth of this graph from the anchors' % (max_hops, max_hops))
         hint[key] = last
         return
-    ring = model.__dict__.setdefault('_bfs_status_host', {})
-    slot = ring.setdefault(key, {'bufs': [torch.empty(2, dtype=torch.int32).pin_memory() for _ in range(4)], 'n': 0})
-    host = slot['bufs'][slot['n'] % len(slot['bufs'])]             # passes in flight never share a buffer (<= 2 are)
-    slot['n'] += 1
+    # one pinned status buffer per check, taken from a free list and returned by _verify_bfs once it has been read: any
+    # number of passes may be in flight (PassPipeline.start can run ahead as far as the caller likes)
+    pool = model.__dict__.setdefault('_bfs_status_pool', [])
+    host = pool.pop() if pool else torch.empty(2, dtype=torch.int32).pin_memory()
     host.copy_(status, non_blocking=True)
     ev = torch.cuda.Event()
     ev.record(torch.cuda.current_stream())
@@ -130,6 +130,7 @@ def _verify_bfs(model, st):
             raise RuntimeError('position-channel BFS: level %d still reached new nodes -- hparams["max_bfs_hops"] = %d '
                                'is smaller than the depth of this graph from the anchors' % (cap, cap))
         hint[key] = max(hint.get(key) or 0, last)                  # the hint only grows: anchors are redrawn every pass
+        model.__dict__.setdefault('_bfs_status_pool', []).append(host)
     st.bfs_checks = []
 
 
@@ -309,6 +310,11 @@ def prepare_pass(model, split='train', timer=None, shard=None, defer_dtw=False):
                 structure_anchors = st.attrs['structure_anchors'] = aps.sample_structure_anchor_patches(hp, g, dev, hp['max_sim_epochs'], trim=False)
             if side is main:
                 t.mark('S_patches_walks')
+        patch_ev = None
+        if hp['use_structure'] and side is not main:
+            patch_ev = torch.cuda.Event()
+            patch_ev.record(side)                       # the patches exist: their walks run on the main stream (below) and
+            #                                             wait for the patches only, not for the position BFS queued next
         if hp['use_position']:
             anchors_pos_ext = getattr(model, 'anchors_pos_ext', None)
             if anchors_pos_ext is None or split != 'test':
@@ -335,7 +341,9 @@ def prepare_pass(model, split='train', timer=None, shard=None, defer_dtw=False):
                     w, status = ops.bfs_min_hops_to_sets(g, src, cc_sets, max_hops=nlev, want_status=True)
 
                     def redo(levels, src=src, l=l, sims=sims):
-                        # the hinted search ran out of levels: the same search with the full cap, similarities replaced
+                        # the hinted search ran out of levels: the same search with the full cap, similarities replaced.
+                        # It runs on the INSTALLING stream: what it reads was allocated on the preparation stream
+                        _hand_over(torch.cuda.current_stream(), src, cc_sets)
                         w2, st2 = ops.bfs_min_hops_to_sets(g, src, cc_sets, max_hops=levels, want_status=True)
                         sims[('P', 'out', l)] = w2.view(S, C, -1).contiguous()
                         return st2.tolist()
@@ -358,11 +366,6 @@ def prepare_pass(model, split='train', timer=None, shard=None, defer_dtw=False):
                     sims[('P', 'in', l)] = (w * real.unsqueeze(-1)).contiguous()
             if side is main:
                 t.mark('P_bfs_sims')
-        patch_ev = None
-        if hp['use_structure'] and side is not main:
-            patch_ev = torch.cuda.Event()
-            patch_ev.record(side)                       # the patches exist: their walks run on the main stream (below)
-
         def structure_walks():
             """Walks over the structure patches, the per-layer picks and the patches' degree sequences.  With two streams
             this runs on the MAIN stream behind the component degree sequences (the side stream keeps the position BFS):

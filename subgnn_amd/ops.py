@@ -5,6 +5,7 @@ below runs a hand-written HIP kernel of libsubgnn_hip.so on the current stream. 
 must already live on the GPU; nothing here falls back to a CPU implementation.
 """
 import ctypes
+import functools
 
 import numpy as np
 import torch
@@ -1124,6 +1125,7 @@ def column_sum(t, chunk=512):
     return head + t[nb * chunk:].sum(0) if nb * chunk < R else head
 
 
+@functools.lru_cache(maxsize=None)
 def _block_rows(R, want=1024):
     """Rows per block for a contraction split over row blocks: a divisor of R between want / 2 and 2 want when there is one
     (no remainder block: one GEMM and one add less), else ``want``."""
@@ -1489,7 +1491,7 @@ class _CrossEntropy(torch.autograd.Function):
         _req(logits, torch.float32, 'logits')
         _req(labels, torch.int64, 'labels')
         B, K = logits.shape
-        lse = torch.empty(B, dtype=torch.float32, device=logits.device)
+        lse = torch.empty(B + 1, dtype=torch.float32, device=logits.device)      # [B]: rows not ignored (label -100)
         res = torch.empty(2, dtype=torch.float32, device=logits.device)
         wsb = lib.sgnn_cross_entropy_workspace_bytes(B)
         ws = torch.empty(wsb // 4 + 1, dtype=torch.float32, device=logits.device)

@@ -324,7 +324,7 @@ def test_subgraph_embedding_slots_equal_cat_and_masked_sum(B, C, D, A1, A2):
     out, out_g, dense = product()
     assert_close(out, ref.float(), 'subgraph embedding', norm_tol=1e-6)
     for nm, a, b in zip(('x0', 'x1', 's1', 'b1', 's2', 'b2', 'b0'), out_g, ref_g):
-        assert_close(a, b.float(), 'subgraph embedding grad ' + nm, tol=2e-4, norm_tol=1e-5)
+        assert_close(a, b.float(), 'subgraph embedding grad ' + nm, norm_tol=1e-5)
     # the materialised form of a deferred piece (attention read-out, gathered head) is the same read-out
     m = mask.view(B, C, 1).to(DEV)
     off = D
@@ -351,11 +351,37 @@ def test_cross_entropy_with_accuracy_matches_torch(B, K):
     assert loss.dim() == 0 and acc.shape == (1,) and not acc.requires_grad
     assert abs(float(loss) - float(ref)) <= 1e-5 * max(1.0, abs(float(ref)))
     assert abs(float(acc) - float(acc_ref)) <= 1e-6
-    assert_close(xg.grad, xr.grad.float(), 'cross entropy grad', tol=2e-4, norm_tol=1e-6)
+    assert_close(xg.grad, xr.grad.float(), 'cross entropy grad', tol=1e-4, norm_tol=1e-6)
     x2 = x.to(DEV).requires_grad_(True)
     l2, _ = ops.cross_entropy_with_accuracy(x2, y.to(DEV))
     (l2 * 1.7).backward()
     assert torch.equal(l2, loss) and torch.equal(x2.grad, xg.grad)
+
+
+def test_cross_entropy_ignore_index_and_bad_labels():
+    """nn.CrossEntropyLoss() semantics for labels outside [0, K): ignore_index (-100) rows are left out of the MEAN as
+    well as of the sum; any other bad label raises in the library and must not pass silently here (NaN loss)."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(5)
+    B, K = 3000, 4
+    x = torch.randn(B, K, generator=g)
+    y = torch.randint(0, K, (B,), generator=g)
+    y[::3] = -100
+    xr = x.double().clone().requires_grad_(True)
+    ref = F.cross_entropy(xr, y)
+    ref.backward()
+    xg = x.to(DEV).requires_grad_(True)
+    loss, acc = ops.cross_entropy_with_accuracy(xg, y.to(DEV))
+    loss.backward()
+    assert abs(float(loss) - float(ref)) <= 1e-5 * max(1.0, abs(float(ref)))
+    assert_close(xg.grad, xr.grad.float(), 'cross entropy grad with ignored rows', tol=1e-4, norm_tol=1e-6)
+    assert torch.equal(xg.grad[::3], torch.zeros_like(xg.grad[::3]))
+    assert abs(float(acc) - float((torch.argmax(x, 1) == y).float().mean())) <= 1e-6      # accuracy: every row counts
+    y[1] = K
+    bad, _ = ops.cross_entropy_with_accuracy(x.to(DEV), y.to(DEV))
+    assert torch.isnan(bad)
+    with pytest.raises((IndexError, RuntimeError)):
+        F.cross_entropy(x, y)
 
 
 def test_missing_library_fails_loudly(monkeypatch):
@@ -465,16 +491,18 @@ def test_lstm_module_uses_fused_layers_and_matches_library(layers, agg, D):
     out = m(x)
     out.square().sum().backward()
     gx, gw = x.grad.clone(), [p.grad.clone() for p in m.parameters()]
-    x.grad = None
-    m.zero_grad()
-    lib_out, _ = m.lstm(x)
-    lib = m.linear(lib_out[:, -1, :] if agg == 'last' else lib_out.sum(dim=1))
+    # reference: the same parameters through the library's nn.LSTM + Linear in FLOAT64 on the CPU (the device library in
+    # float32 is itself ~1e-4 away from it on the weight gradients: rounds 1-3 compared against that with rtol 1e-3)
+    import copy
+    r = copy.deepcopy(m).cpu().double()
+    xr = x.detach().cpu().double().requires_grad_(True)
+    lib_out, _ = r.lstm(xr)
+    lib = r.linear(lib_out[:, -1, :] if agg == 'last' else lib_out.sum(dim=1))
     lib.square().sum().backward()
-    assert torch.allclose(out, lib, rtol=1e-4, atol=1e-5)
-    assert torch.allclose(gx, x.grad, rtol=1e-3, atol=1e-5)
-    for a, p in zip(gw, m.parameters()):
-        s = max(float(p.grad.abs().max()), 1.0)
-        assert torch.allclose(a / s, p.grad / s, rtol=1e-3, atol=2e-5)
+    assert_close(out, lib, 'LSTM module output')
+    assert_close(gx, xr.grad, 'LSTM module d x')
+    for (nm, q), a in zip(r.named_parameters(), gw):
+        assert_close(a, q.grad, 'LSTM module d ' + nm)
 
 
 def test_lstm_unsupported_sizes_stay_on_the_library():
@@ -728,7 +756,7 @@ def test_column_sum_matches_float64_and_repeats(R, A, view):
     wide = torch.randn(R, A + (7 if view else 0), generator=g).to(DEV)
     x = wide[:, 3:3 + A] if view else wide
     out = ops.column_sum(x)
-    assert_close(out, x.double().sum(0).float(), 'column sum', tol=2e-4, norm_tol=1e-6)
+    assert_close(out, x.double().sum(0).float(), 'column sum', norm_tol=1e-6)
     assert torch.equal(out, ops.column_sum(x))
 
 
@@ -737,5 +765,5 @@ def test_contract_rows_matches_the_plain_product():
     g = torch.Generator().manual_seed(3)
     a, b = torch.randn(16800, 96, generator=g).to(DEV), torch.randn(16800, 64, generator=g).to(DEV)
     ref = (a.double().t() @ b.double()).float()
-    assert_close(ops.contract_rows(a, b), ref, 'contract_rows', tol=2e-4, norm_tol=1e-6)
-    assert_close(ops.contract_rows(a[:1000], b[:1000]), (a[:1000].double().t() @ b[:1000].double()).float(), 'small', tol=2e-4, norm_tol=1e-5)
+    assert_close(ops.contract_rows(a, b), ref, 'contract_rows', norm_tol=1e-6)
+    assert_close(ops.contract_rows(a[:1000], b[:1000]), (a[:1000].double().t() @ b[:1000].double()).float(), 'small', norm_tol=1e-5)
