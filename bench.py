@@ -148,6 +148,17 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit('launch with torch.distributed.run --nproc-per-node %d' % args.gpus)
+    # N = 1: the inputs are generated first (numpy only) and the worker processes of the cpu_baseline leg are forked HERE, before
+    # anything initialises the GPU (a forked child must not inherit HIP state; they idle until the timed region is over)
+    early = None
+    if world == 1 and 'RANK' not in os.environ:
+        early = build_inputs(args, 0, 1)
+        if not args.no_cpu_baseline:
+            try:
+                from oracle import cpu_baseline
+                cpu_baseline.start_pool(early[0], early[1])
+            except Exception as ex:                      # no pool: the Python stages run in this process
+                print('cpu_baseline worker pool not started: %r' % (ex,), file=sys.stderr)
     # SGNN_DIST_BACKEND=gloo: functional check of the multi-rank path on a box with fewer GPUs than ranks
     # (ranks then share GPUs and the collectives go through host memory); never a measurement
     backend = os.environ.get('SGNN_DIST_BACKEND', 'nccl')
@@ -170,7 +181,7 @@ def main():
     if dist:
         dist.barrier()
 
-    rowptr, col, subs, total_subgraphs, t_gen = build_inputs(args, rank, world)
+    rowptr, col, subs, total_subgraphs, t_gen = early if early is not None else build_inputs(args, rank, world)
     n = args.nodes
     g = ops.DeviceGraph(rowptr, col, np.arange(1, n + 1, dtype=np.int32), dev)
     torch.manual_seed(0)
@@ -530,6 +541,11 @@ def main():
             result['cpu_baseline'] = cpu_baseline.run(rowptr, col, subs, hp, emb.cpu(), labels, args.cpu_sample, S)
         except Exception as ex:                      # the baseline must never hide the GPU number
             result['cpu_baseline'] = {'error': repr(ex)}
+        finally:
+            try:
+                cpu_baseline.stop_pool()
+            except Exception:
+                pass
     if rank == 0:
         print(json.dumps(result))
     if dist:

@@ -12,9 +12,19 @@ extrapolated linearly, stage by stage:
   shared stages (structure patches + their walks: timed on a few patches and scaled; one BFS per P-border anchor
       over the whole graph: run for ALL sources in C, the sources shared among the host's cores) -> counted once
       per pass.
-The C stages (DTW, BFS) use OpenMP over the host's cores; the Python / numpy integer stages are single-threaded and
-the torch stages use torch's thread pool -- "cores" reports the OpenMP / torch thread count.
+The C stages (DTW, BFS) use OpenMP over the host's cores, the torch stages torch's thread pool, and (round 4) the
+Python / numpy integer stages -- structure patches + walks, components, borders, anchor draws -- are dealt to a pool of
+worker PROCESSES, one per core (``start_pool``: forked by bench.py BEFORE the GPU is initialised, so the workers hold no
+HIP state; without a pool the stages run in this process, single-threaded).  "cores" reports the thread / process count.
+
+``calibration``: profiles/r04_cpu_calibration.json holds the imported REFERENCE and this port timed on the same inputs on
+the build container's 8 cores (tools/bench_density_n.py --mode reference / port: BASELINE.json configs[0]'s dataset, with
+the neighbourhood channel only and with all three channels): ratio = reference time / port time, so
+value / ratio estimates "the reference's own CPU path" at a size where the reference itself cannot run (BASELINE.md
+section 3, steps i-iii).
 """
+import json
+import os
 import time
 
 import numpy as np
@@ -23,10 +33,85 @@ import torch
 from . import cbind, float_half as FH, integer_half as IH, tape as T
 from .graph import CSRGraph
 
+_POOL = None
+_W = {}            # what the workers see (set before the fork)
+
+
+def start_pool(rowptr, col, procs=None):
+    """Fork the worker processes (call before anything initialises the GPU).  The graph arrays are shared copy-on-write."""
+    global _POOL
+    import multiprocessing as mp
+    _W['G'] = CSRGraph(rowptr, col)
+    procs = procs or os.cpu_count() or 1
+    if procs > 1 and _POOL is None:
+        _POOL = (mp.get_context('fork').Pool(procs), procs)
+    return _POOL
+
+
+def stop_pool():
+    global _POOL
+    if _POOL is not None:
+        _POOL[0].terminate()
+        _POOL = None
+
+
+def _pmap(fn, items, timeout=600):
+    """fn over items on the pool (order kept); in this process when there is no pool."""
+    items = list(items)
+    if _POOL is None or len(items) < 2:
+        return [fn(x) for x in items]
+    chunk = max(1, len(items) // (4 * _POOL[1]))
+    return _POOL[0].map_async(fn, items, chunksize=chunk).get(timeout)
+
+
+def _w_patch(a):
+    i, walk_len, beta, seed = a
+    return IH.triangular_walk(_W['G'], walk_len, beta, IH._Draws(seed, T.stream_id(T.STREAM_STRUCT_PATCH), i), 'graph')
+
+
+def _w_walks(a):
+    row, W, Tn, beta, seed = a
+    G = _W['G']
+    return (IH.perform_random_walks(G, row[None, :], W, Tn, beta, True, seed)[0],
+            IH.perform_random_walks(G, row[None, :], W, Tn, beta, False, seed)[0])
+
+
+def _w_components(s):
+    return IH.connected_components(_W['G'], s)
+
+
+def _w_border(r):
+    G = _W['G']
+    members = r[r != 0]
+    if len(members) == 0:
+        return np.zeros(0, dtype=np.int64)
+    nb = np.unique(np.concatenate([G.neighbors(int(v)) for v in members]))
+    return np.setdiff1d(nb, members).astype(np.int64)
+
+
+def _w_anchors(a):
+    r, ids, A, kind, width, seed = a
+    out = np.zeros(A, dtype=np.int64)
+    if len(ids):
+        real = np.sort(ids)
+        st = T.stream_id(kind, 'train', 0)
+        for i in range(A):
+            k = T.nanchor_pick(seed, st, r * A + i, len(real), len(real) < width)
+            out[i] = 0 if k < 0 else real[k]
+    return out
+
+
+def _calibration():
+    f = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'profiles', 'r04_cpu_calibration.json')
+    if not os.path.exists(f):
+        return None
+    with open(f) as fh:
+        return json.load(fh)
+
 
 def run(rowptr, col, subs, hp, emb, labels, n_sample, S_total):
     t_all = time.perf_counter()
-    G = CSRGraph(rowptr, col)
+    G = _W['G'] = CSRGraph(rowptr, col) if _POOL is None else _W['G']
     n = G.n
     seed = int(hp.get('seed', 0))
     rng = np.random.default_rng(0)
@@ -36,16 +121,14 @@ def run(rowptr, col, subs, hp, emb, labels, n_sample, S_total):
 
     # ---- shared stages on a sub-sample, scaled ---------------------------------------------
     n_patches = hp['max_sim_epochs'] * hp['n_anchor_patches_structure'] * L
-    np_s = min(8, n_patches)
+    np_s = n_patches                                  # round 4: every patch (dealt to the pool), nothing scaled
     t0 = time.perf_counter()
     patches = np.zeros((np_s, hp['sample_walk_len']), dtype=np.int64)
-    for i in range(np_s):
-        w = IH.triangular_walk(G, hp['sample_walk_len'], hp['rw_beta'],
-                               IH._Draws(seed, T.stream_id(T.STREAM_STRUCT_PATCH), i), 'graph')
+    for i, w in enumerate(_pmap(_w_patch, [(i, hp['sample_walk_len'], hp['rw_beta'], seed) for i in range(np_s)])):
         patches[i, :len(w)] = w
-    iw = IH.perform_random_walks(G, patches, hp['n_triangular_walks'], hp['random_walk_len'], hp['rw_beta'], True, seed)
-    bw = IH.perform_random_walks(G, patches, hp['n_triangular_walks'], hp['random_walk_len'], hp['rw_beta'], False, seed)
-    t['shared_patches_walks'] = (time.perf_counter() - t0) * n_patches / np_s
+    both = _pmap(_w_walks, [(patches[i], hp['n_triangular_walks'], hp['random_walk_len'], hp['rw_beta'], seed) for i in range(np_s)])
+    iw, bw = np.stack([b[0] for b in both]), np.stack([b[1] for b in both])
+    t['shared_patches_walks'] = time.perf_counter() - t0
     pext = IH.position_anchors_border(G, hp['n_anchor_patches_pos_out'], seed, 0)
     allp = np.concatenate([patches] * (n_patches // np_s + 1))[:n_patches]
     iw = np.concatenate([iw] * (n_patches // np_s + 1))[:n_patches]
@@ -57,36 +140,19 @@ def run(rowptr, col, subs, hp, emb, labels, n_sample, S_total):
 
     # ---- per-subgraph stages on the sample -------------------------------------------------
     t0 = time.perf_counter()
-    ccs = [IH.connected_components(G, s) for s in sample]
+    ccs = _pmap(_w_components, sample)
     cc_ids = IH.pad_cc_ids(ccs)
     t['components'] = time.perf_counter() - t0
     S, C, Lc = cc_ids.shape
     rows = cc_ids.reshape(S * C, Lc)
     t0 = time.perf_counter()
-    borders = []
-    for r in rows:
-        members = r[r != 0]
-        if len(members) == 0:
-            borders.append(np.zeros(0, dtype=np.int64))
-            continue
-        nb = np.unique(np.concatenate([G.neighbors(int(v)) for v in members]))
-        borders.append(np.setdiff1d(nb, members).astype(np.int64))
+    borders = _pmap(_w_border, list(rows))
     t['border'] = time.perf_counter() - t0
     t0 = time.perf_counter()
     A_in, A_out = hp['n_anchor_patches_N_in'], hp['n_anchor_patches_N_out']
     maxb = max(len(b) for b in borders)
-    n_int = np.zeros((S * C, A_in), dtype=np.int64)
-    n_bor = np.zeros((S * C, A_out), dtype=np.int64)
-    for r in range(S * C):
-        for ids, A, out, kind, width in ((rows[r][rows[r] != 0], A_in, n_int, T.STREAM_N_INT, Lc),
-                                         (borders[r], A_out, n_bor, T.STREAM_N_BOR, maxb)):
-            if len(ids) == 0:
-                continue
-            real = np.sort(ids)
-            st = T.stream_id(kind, 'train', 0)
-            for i in range(A):
-                k = T.nanchor_pick(seed, st, r * A + i, len(real), len(real) < width)
-                out[r, i] = 0 if k < 0 else real[k]
+    n_int = np.stack(_pmap(_w_anchors, [(r, rows[r][rows[r] != 0], A_in, T.STREAM_N_INT, Lc, seed) for r in range(S * C)]))
+    n_bor = np.stack(_pmap(_w_anchors, [(r, borders[r], A_out, T.STREAM_N_BOR, maxb, seed) for r in range(S * C)]))
     p_int = IH.position_anchors_internal(sample, hp['n_anchor_patches_pos_in'], seed, 'train', 0)
     t['anchors'] = time.perf_counter() - t0
     t0 = time.perf_counter()
@@ -162,14 +228,30 @@ def run(rowptr, col, subs, hp, emb, labels, n_sample, S_total):
     per_sample = sum(v for k, v in t.items() if not k.startswith('shared_'))
     shared = sum(v for k, v in t.items() if k.startswith('shared_')) + t_table
     est_pass = shared + per_sample * S_total / n_sample
-    return {'value': S_total / est_pass, 'unit': 'subgraphs/s', 'cores': int(torch.get_num_threads()),
-            'kind': 'port',
-            'sample': ('oracle (C + numpy + torch-CPU, same sparse algorithm) on %d of %d subgraphs; per-subgraph stages '
-                       'scaled x%.0f; shared stages counted once (structure patches/walks on %d of %d patches, scaled; one BFS '
-                       'per P-border anchor for all %d sources; dense embedding-table Adam); DTW and BFS in C with OpenMP over '
-                       'the cores, the other integer stages single-threaded Python / numpy, torch stages on %d threads; %.1f s '
-                       'of CPU work measured'
-                       % (n_sample, S_total, S_total / n_sample, np_s, n_patches, len(pext), torch.get_num_threads(),
-                          time.perf_counter() - t_all)),
-            'stage_seconds_measured': {k: round(v, 3) for k, v in t.items()},
-            'estimated_full_pass_s': round(est_pass, 1)}
+    workers = _POOL[1] if _POOL is not None else 1
+    res = {'value': S_total / est_pass, 'unit': 'subgraphs/s', 'cores': int(max(torch.get_num_threads(), workers)),
+           'kind': 'port',
+           'sample': ('oracle (C + numpy + torch-CPU, same sparse algorithm) on %d of %d subgraphs; per-subgraph stages '
+                      'scaled x%.0f; shared stages counted once (all %d structure patches and their walks; one BFS '
+                      'per P-border anchor for all %d sources; dense embedding-table Adam); DTW and BFS in C with OpenMP over '
+                      'the cores, the Python / numpy integer stages on %d worker processes, torch stages on %d threads; %.1f s '
+                      'of CPU work measured'
+                      % (n_sample, S_total, S_total / n_sample, n_patches, len(pext), workers, torch.get_num_threads(),
+                         time.perf_counter() - t_all)),
+           'stage_seconds_measured': {k: round(v, 3) for k, v in t.items()},
+           'estimated_full_pass_s': round(est_pass, 1)}
+    cal = _calibration()
+    if cal is not None:
+        c = cal['all_density']
+        res['calibration'] = {
+            'reference_ms_per_step': c['reference_ms_per_step'], 'port_ms_per_step': c['port_ms_per_step'], 'ratio': c['ratio'],
+            'reference_prepare_data_s': c['reference_prepare_data_s'], 'port_prepare_data_s': c['port_prepare_data_s'],
+            'prepare_ratio': c['prepare_ratio'], 'cores': cal['cores'],
+            'n_density_channel_only': {k: cal['n_density'][k] for k in ('reference_ms_per_step', 'port_ms_per_step', 'ratio')},
+            'what': 'imported reference vs this port, same inputs (configs[0] dataset, all three channels on; neighbourhood only '
+                    'beside it), build container, 8 cores: profiles/r04_cpu_calibration.json (tools/bench_density_n.py)',
+            'value_calibrated_to_reference': S_total / est_pass / c['ratio'],
+            'note': 'value / ratio (the training-step ratio; the reference\'s prepare_data is a further %sx slower than the '
+                    'port\'s, with its pure-Python fastdtw stand-in) -- an ESTIMATE of the reference\'s own CPU path at a size '
+                    'where its dense N x N structures cannot be built' % c['prepare_ratio']}
+    return res

@@ -122,3 +122,43 @@ def write_dataset_from_golden(g, root, name='ds', with_ego=None):
         with open(os.path.join(d, 'ego_graphs.txt'), 'w') as f:
             json.dump(ego, f)
     return name
+
+
+SLOTS = ('N_I', 'N_B', 'S_I', 'S_B', 'P_I', 'P_B')
+
+
+def oracle_inputs(m, batch, idx):
+    """The product's prepared state as the containers oracle/float_half.py takes (CPU tensors)."""
+    hp = m.hparams
+    Lr = hp['n_layers']
+    cpu = lambda t: t.detach().cpu()
+    params = {}
+    for k, v in m.state_dict().items():
+        v = cpu(v).clone()
+        if v.dtype == torch.float32:
+            v.requires_grad_(True)
+        params[k] = v
+    if str(hp.get('embedding_dtype', 'fp32')) == 'fp16':
+        # the fused kernels gather from the IEEE-half copy of the table (fp32 accumulate)
+        params['node_embeddings.weight'] = params['node_embeddings.weight'].detach().half().float().requires_grad_(True)
+    anchors = {'N_int': {}, 'N_bor': {}, 'P_int': {}, 'P_ext': {}, 'S': {}}
+    if hp['use_neighborhood']:
+        anchors['N_int'] = {'train': {l: cpu(m.anchors_neigh_int['train'][l]) for l in range(Lr)}}
+        anchors['N_bor'] = {'train': {l: cpu(m.anchors_neigh_border['train'][l]) for l in range(Lr)}}
+    if hp['use_position']:
+        anchors['P_int'] = {'train': {l: cpu(m.anchors_pos_int['train'][l]) for l in range(Lr)}}
+        anchors['P_ext'] = {l: cpu(m.anchors_pos_ext[l]) for l in range(Lr)}
+    if hp['use_structure']:
+        for l in range(Lr):
+            p, i, a, b = m.anchors_structure[l]
+            anchors['S'][l] = (cpu(p), [int(v) for v in (i.tolist() if torch.is_tensor(i) else i)], cpu(a), cpu(b))
+    npsim = batch['NP_sim']
+    if isinstance(npsim, dict):
+        npsim = {k: cpu(v.dense() if hasattr(v, 'dense') else v) for k, v in npsim.items()}
+    elif npsim is not None:
+        npsim = cpu(npsim)
+    ob = {'cc_ids': cpu(batch['cc_ids']), 'subgraph_idx': cpu(batch['subgraph_idx']), 'NP_sim': npsim,
+          'I_S_sim': cpu(batch['I_S_sim']) if batch['I_S_sim'] is not None else None,
+          'B_S_sim': cpu(batch['B_S_sim']) if batch['B_S_sim'] is not None else None}
+    ccp = {nm: params['train_%s_cc_embed' % nm] for nm in SLOTS} if hp['trainable_cc'] else None
+    return params, anchors, ob, ccp

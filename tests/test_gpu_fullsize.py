@@ -176,3 +176,133 @@ def test_one_shard_of_the_benchmark_reproduces_its_slice_of_the_unsharded_pass(f
     assert torch.equal(part.train_int_struc_similarities, whole.train_int_struc_similarities[a:b])
     assert torch.equal(part.train_bor_struc_similarities, whole.train_bor_struc_similarities[a:b])
     assert float(part.train_bor_struc_similarities.abs().sum()) > 0
+
+
+@pytest.mark.parametrize('n_layers', [1, 2])
+def test_training_half_at_shard_size_matches_the_oracle(full, n_layers):
+    """The TRAINING half the benchmark times (SubGNN.py:225-348 forward + loss, :1156-1164 backward + clip + Adam) on the
+    configs[3] workload at shard size: the 1M-node graph, ALL_DENSITY_HP, 8 192 subgraphs as one batch -- so that every
+    shard-size branch runs (counted below): the shared-anchor layers as library GEMMs (ops._mpn_shared_gemm, rows >=
+    SHARED_GEMM_MIN_ROWS), the head's tall linears (_LinearTallSkinny, rows >= 8192) with their split contractions
+    (contract_rows) and column sums, the slot-fused read-out (ReadoutPiece / sgnn_readout_sum_*), the fused cross entropy,
+    the edge plans and sorted id lists made with the prepared pass, the MFMA update layer, ClipAdam with the table's
+    one-pass Adam.  n_layers = 1 is the benchmark's configuration (every shared-anchor layer is the channel's last one:
+    read-out pieces only); n_layers = 2 adds a first layer whose shared-anchor bodies are the library contractions
+    (ops._mpn_shared_gemm, rows >= SHARED_GEMM_MIN_ROWS) and whose update feeds a second layer.  Dropout 0.  Logits, loss, every gradient and every parameter after one clip + Adam step against
+    oracle/float_half.py + clip_grad_norm_ + torch.optim.Adam fed the product's prepared state: element-wise 1e-4."""
+    import sys, os, collections
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..'))
+    from bench import ALL_DENSITY_HP
+    from helpers import assert_close, rel_err, oracle_inputs
+    from oracle import float_half as FH
+    from subgnn_amd import hotpath, ops, optim, _lib
+    from subgnn_amd.SubGNN import SubGNN
+    g, subs = full['g'], full['subs']
+    B = 8192
+    hp = dict(ALL_DENSITY_HP, lin_dropout=0.0, lstm_dropout=0.0, n_layers=n_layers)
+    D = hp['node_embed_size']
+    emb = torch.randn(N, D, generator=torch.Generator().manual_seed(0)).to(DEV)
+    labels = torch.randint(0, 3, (B,), generator=torch.Generator().manual_seed(0))
+    torch.manual_seed(0)
+    m = SubGNN.from_memory(dict(hp), g, {'train': subs[:B], 'val': [], 'test': []},
+                           {'train': labels, 'val': labels[:0], 'test': labels[:0]}, emb, num_classes=3)
+    m.train()
+    lib = _lib.load()
+    calls = collections.Counter()
+    py_names = ('_mpn_shared_gemm', 'contract_rows', 'column_sum', 'mpn_edge_plan', 'presort_ids', 'update_layer',
+                'cross_entropy_with_accuracy', 'subgraph_embedding', 'clip_coefficient', 'adam_step')
+    lib_names = ('sgnn_readout_sum_fwd', 'sgnn_readout_sum_bwd', 'sgnn_update_fwd', 'sgnn_update_bwd', 'sgnn_scatter_add_rows',
+                 'sgnn_cross_entropy_fwd', 'sgnn_cross_entropy_bwd', 'sgnn_adam_step', 'sgnn_lstm_fwd', 'sgnn_lstm_bwd',
+                 'sgnn_cc_embed_fwd', 'sgnn_mpn_fwd', 'sgnn_mpn_bwd')
+    saved_py = {n: getattr(ops, n) for n in py_names}
+    saved_lib = {n: getattr(lib, n) for n in lib_names if hasattr(lib, n)}
+    tall = collections.Counter()
+    real_tall = ops._LinearTallSkinny.apply
+
+    def counted(name, fn):
+        def w(*a, **k):
+            calls[name] += 1
+            return fn(*a, **k)
+        return w
+    real_linear = ops.linear
+
+    def linear(x, weight, bias):
+        if x.dim() == 2 and x.shape[0] >= 8192:
+            tall['rows>=8192'] += 1
+        return real_linear(x, weight, bias)
+    for n, f in saved_py.items():
+        setattr(ops, n, counted(n, f))
+    for n, f in saved_lib.items():
+        setattr(lib, n, counted(n, f))
+    ops.linear = linear
+    try:
+        hotpath.prepare_sparse(m, 'train')
+        S_, C, Lc = m.train_cc_ids.shape
+        assert (S_, C) == (B, 1) and B * C >= ops.SHARED_GEMM_MIN_ROWS
+        opt = optim.ClipAdam(m.parameters(), hp['learning_rate'], max_norm=hp['grad_clip'])
+        assert [tuple(p.shape) for p in opt.big] == [(N + 1, D)]
+        before = {k: v.detach().clone() for k, v in m.state_dict().items() if v.dtype == torch.float32}
+        batch = hotpath.full_split_batch(m, 'train')
+        out = m.training_step(batch, 0)
+        with torch.no_grad():
+            logits = m._forward_batch('train', batch)
+        m.backward(None, out['loss'], None, 0)
+        grads = {k: (p.grad.detach().clone() if p.grad is not None else None) for k, p in m.named_parameters()}
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+        torch.cuda.synchronize()
+    finally:
+        for n, f in saved_py.items():
+            setattr(ops, n, f)
+        for n, f in saved_lib.items():
+            setattr(lib, n, f)
+        ops.linear = real_linear
+    # ---- the shard-size branches ran -------------------------------------------------------------------------------
+    assert calls['_mpn_shared_gemm'] >= (3 if n_layers > 1 else 0), calls      # first layer: P-border + both structure sides
+    assert tall['rows>=8192'] >= 3, tall                   # the head's three linears over >= 8192 rows
+    assert calls['contract_rows'] >= 3 and calls['column_sum'] >= 3, calls
+    assert calls['mpn_edge_plan'] >= 1 and calls['presort_ids'] >= 2, calls
+    assert calls['cross_entropy_with_accuracy'] >= 1 and calls['sgnn_cross_entropy_bwd'] == 1, calls
+    assert calls['subgraph_embedding'] >= 1 and calls['sgnn_readout_sum_fwd'] >= 1 and calls['sgnn_readout_sum_bwd'] >= 1, calls
+    assert calls['sgnn_update_fwd'] >= 1 and calls['sgnn_update_bwd'] >= 1, calls
+    assert calls['clip_coefficient'] == 1 and calls['sgnn_adam_step'] == 1, calls
+    assert calls['sgnn_lstm_fwd'] >= 1 and calls['sgnn_lstm_bwd'] >= 1, calls
+    # ---- the oracle on the product's prepared state ----------------------------------------------------------------
+    params, anchors, ob, ccp = oracle_inputs(m, batch, torch.arange(B))
+    for k, v in params.items():                            # the state BEFORE the step (state_dict() above is after it)
+        if k in before:
+            v.data.copy_(before[k].cpu())
+    ref_logits = FH.forward(params, hp, 'train', ob, anchors, ccp)
+    ref_loss = torch.nn.functional.cross_entropy(ref_logits, labels)
+    ref_loss.backward()
+    assert_close(logits, ref_logits, 'logits at shard size')
+    assert_close(out['loss'], ref_loss, 'loss at shard size')
+    checked = 0
+    for k, gp in grads.items():
+        ref = params[k].grad
+        if gp is None or ref is None:
+            other = ref if gp is None else gp
+            assert other is None or float(other.abs().max()) == 0, k
+            continue
+        assert_close(gp, ref, 'grad ' + k)
+        checked += 1
+    assert checked >= 12, checked
+    assert float(grads['node_embeddings.weight'][0].abs().max()) == 0
+    # clip_grad_norm_ + Adam as the caller runs them (train_config.py Trainer(gradient_clip_val); SubGNN.py:1156-1161)
+    leaves = [v for k, v in params.items() if v.requires_grad and v.grad is not None]
+    torch.nn.utils.clip_grad_norm_(leaves, hp['grad_clip'])
+    torch.optim.Adam(leaves, lr=hp['learning_rate']).step()
+    after = {k: v.detach() for k, v in m.state_dict().items() if v.dtype == torch.float32}
+    worst = {}
+    for k, v in params.items():
+        if not (v.requires_grad and v.grad is not None):
+            continue
+        assert_close(after[k], v.detach(), 'parameter after clip + Adam: ' + k)
+        # the UPDATE itself (parameters of size ~1 moved by ~lr would pass the line above whatever the step did): Adam's
+        # first step is lr * g / (|g| + eps) -- insensitive to the gradient's error except where |g| ~ eps = 1e-8
+        du, dr = (after[k] - before[k]).cpu(), v.detach() - before[k].cpu()
+        worst[k] = rel_err(du, dr)
+        assert worst[k] < 1e-3, (k, worst[k])
+    untouched = (grads['node_embeddings.weight'].abs().sum(1) == 0)
+    assert torch.equal(after['node_embeddings.weight'][untouched], before['node_embeddings.weight'][untouched])
+    print('shard-size training half: calls', dict(calls), 'worst update errors', {k: '%.1e' % e for k, e in worst.items()})
