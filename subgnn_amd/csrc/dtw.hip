@@ -358,6 +358,9 @@ __global__ __launch_bounds__(DTW_THREADS) void dtw_similarity_kernel(
 // path in LDS for the next finer level.  The finest level -- more than half of all cells -- is never
 // backtracked: it neither tracks nor stores predecessors, and takes one add instead of three.
 #define DTW_R 32
+#ifndef DTW_OLD_COARSE
+#define DTW_OLD_COARSE 0          // 1: the coarse levels of rounds 1-3 (one column array, 2-bit codes at fixed positions) for every instantiation
+#endif
 #ifndef DTW_MINB12
 #define DTW_MINB12 3            // resident 256-thread blocks per CU the 12-row kernel is compiled for
 #endif
@@ -593,6 +596,184 @@ __device__ __forceinline__ double dtw_wave_level(
 #undef FLQ
 }
 
+// ---- coarse levels, round 4: two column arrays + predecessor bits shifted in through the carry ----------------------------
+// The levels that are backtracked paid ~23 vector instructions per cell where the finest level pays 12 (ISA count): per row pair
+// three v_mov_b64 (a cell's old value had to be copied out of the row's register before the new one went in: it is the next
+// row's diagonal) and per cell two v_cndmask + an OR (+ v_mov of the shifted constants) to turn two compare masks into a 2-bit
+// code at the row's fixed position of the column's word.  Here
+//   * the DP keeps TWO column arrays, read (column j - 1) and written (column j) alternately -- a cell reads up = cur[i - 1],
+//     left = prev[i], diagonal = prev[i - 1] and writes cur[i]: no copies; the column loop is unrolled by two so that the
+//     arrays keep static registers.  A row is evaluated over one contiguous column interval and both of its registers are +inf
+//     before it, so prev[] of a row that joins the sweep in this column is +inf by itself; the entry pair's row above (not
+//     part of this column, nor of any later one) is made +inf in cur[] and -- unless it was evaluated in the previous
+//     column -- in prev[];
+//   * the two compare masks of a cell (wave-wide lane masks in scalar registers) are shifted into the lane's word through the
+//     carry input of v_addc_co_u32 (word = 2 word + bit): two instructions per cell.  The bits of the rows a column evaluated
+//     follow each other in evaluation order, the last row in the lowest two bits; the column's last row number (wave-uniform)
+//     sits in bits 27..31, so the back-trace finds row i's bits at 2 (last_row - i).  Needs 2 RR <= 27: the levels of the
+//     12- and 20-row instantiations (6 / 10 rows); the 32-row one keeps the fixed-position words.
+// Bits per tie rule (first, second): 0: (c_up == min, c_left == min); 1: (c_diag == min, c_up == min); 2: (diag <= up && diag
+// <= left, up <= left) on the predecessor costs -- decoded only along the path.
+__device__ __forceinline__ uint32_t dtw_shift_in(uint32_t word, uint64_t lane_mask)
+{
+    uint32_t out;
+    asm("v_addc_co_u32_e64 %0, vcc, %1, %1, %2" : "=v"(out) : "v"(word), "s"(lane_mask) : "vcc");
+    return out;
+}
+
+template <int RR, int TIE, bool WLDS>
+__device__ __forceinline__ void dtw_wave_level_pp(
+    int32_t* __restrict__ fl, const double* __restrict__ xcol, const double* __restrict__ xrcol, int64_t n_x,
+    const double* __restrict__ ycol, const double* __restrict__ yrcol, bool act,
+    int lx, int ly, int lxc, int lyc, bool coarsest, uint32_t* __restrict__ wl, uint32_t* __restrict__ wq, int64_t NT)
+{
+    static_assert(RR % 2 == 0 && 2 * RR <= 27, "two bits per row below the row number");
+    constexpr int P = RR / 2;
+#define FLQ(q) fl[(q) * DTW_THREADS]
+    const double INF = __longlong_as_double(0x7ff0000000000000ll);
+    const int32_t EMPTY = 1;
+    int32_t lohi[P];
+    if (coarsest) {
+#pragma unroll
+        for (int p = 0; p < P; ++p) lohi[p] = (act && 2 * p < lx) ? ((ly - 1) << 16) : EMPTY;
+    } else {
+        int prev_lo = 0;
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            const int ca = p - 1 < 0 ? 0 : p - 1;
+            const int cb = p + 1;
+            const int firstc = FLQ(ca) & 0xffff;
+            const int lastc = (cb < lxc) ? (FLQ(cb < P ? cb : P - 1) >> 16) : (lyc - 1);
+            int lo = 2 * (firstc - 1);
+            int hi = 2 * (lastc + 1) + 1;
+            if (lo < prev_lo) lo = prev_lo;
+            if (lo < 0) lo = 0;
+            if (hi > ly - 1) hi = ly - 1;
+            int32_t v = (hi << 16) | lo;
+            if (hi < lo || 2 * p >= lx || !act) v = EMPTY; else prev_lo = lo;
+            lohi[p] = v;
+        }
+    }
+    uint32_t hull[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        const uint32_t lo = lohi[p] & 0xffff, hi = (uint32_t)lohi[p] >> 16;
+        hull[p] = dtw_wave_pkmax(lohi[p] == EMPTY ? 0u : (((0x7fffu - lo) << 16) | (hi + 1)));
+    }
+    double xp1[RR], xr[RR], cA[RR], cB[RR];
+#pragma unroll
+    for (int i = 0; i < RR; ++i) {
+        const int64_t ic = i < lx ? i : 0;
+        xp1[i] = xcol[ic * n_x] + 1.0;
+        xr[i] = xrcol[ic * n_x];
+        cA[i] = INF;
+        cB[i] = INF;
+    }
+    const int lane = threadIdx.x & 63;
+    uint32_t prev_am = 0;
+    for (int jc = 0; jc < ly; jc += 64) {
+        uint32_t tab;
+        {
+            const uint32_t c = (uint32_t)(jc + lane);
+            uint32_t ra = P, rb1 = 0;
+#pragma unroll
+            for (int p = P - 1; p >= 0; --p) ra = ((hull[p] & 0xffffu) > c) ? (uint32_t)p : ra;
+#pragma unroll
+            for (int p = 0; p < P; ++p) rb1 = (hull[p] != 0u && (0x7fffu - (hull[p] >> 16)) <= c) ? (uint32_t)(p + 1) : rb1;
+            // pairs [ra, rb1) as a mask | ra << 16 | the column's last row 2 rb1 - 1, already at its place in the word (bits 27..31)
+            tab = rb1 > ra ? ((((1u << rb1) - 1u) & ~((1u << ra) - 1u)) | (ra << 16) | ((2u * rb1 - 1u) << 27)) : 0u;
+        }
+        const int jend = jc + 64 < ly ? jc + 64 : ly;
+        double y_next = ycol[jc], yr_next = yrcol[jc];
+#define DTWP_IN(K) { const int lo_ = lohi[(K) < P ? (K) : 0] & 0xffff, hi_ = lohi[(K) < P ? (K) : 0] >> 16; in_ = J_ >= lo_ && J_ <= hi_; }
+#define DTWP_COST(I) dtw_mask_cost(in_, dtw_cost_rcp(xp1[(I) < RR ? (I) : 0], xr[(I) < RR ? (I) : 0], yp1, yr))
+        // one cell: UPV / LEFT / DIAG are the three predecessors' values, OUT the register the cell's value goes into
+#define DTWP_CELL(UPV, LEFT, DIAG, DT, OUT)                                                                          \
+            {                                                                                                        \
+                const double c_up = (UPV) + (DT), c_left = (LEFT) + (DT), c_diag = (DIAG) + (DT);                    \
+                const double mv = fmin(fmin(c_up, c_left), c_diag);                                                  \
+                if (TIE == 0) { word = dtw_shift_in(word, __ballot(c_up == mv)); word = dtw_shift_in(word, __ballot(c_left == mv)); } \
+                else if (TIE == 1) { word = dtw_shift_in(word, __ballot(c_diag == mv)); word = dtw_shift_in(word, __ballot(c_up == mv)); } \
+                else { word = dtw_shift_in(word, __ballot((DIAG) <= (UPV)) & __ballot((DIAG) <= (LEFT)));           \
+                       word = dtw_shift_in(word, __ballot((UPV) <= (LEFT))); }                                      \
+                (OUT) = mv;                                                                                          \
+            }
+#define DTWP_PAIR(K, PREV, CUR)                                                                                      \
+            if ((K) < P && (am & (1u << (K)))) {                                                                     \
+                constexpr int a_ = 2 * (K) < RR ? 2 * (K) : 0, b_ = 2 * (K) + 1 < RR ? 2 * (K) + 1 : 0;              \
+                constexpr int u_ = (2 * (K) - 1) >= 0 && (2 * (K) - 1) < RR ? (2 * (K) - 1) : 0;                     \
+                bool in_;                                                                                            \
+                DTWP_IN(K)                                                                                           \
+                const double dt0_ = DTWP_COST(2 * (K));                                                              \
+                const double dt1_ = DTWP_COST(2 * (K) + 1);                                                          \
+                if ((K) == 0) {                                                                                      \
+                    const double diag0_ = (J_ == 0) ? 0.0 : INF;             /* virtual origin D[-1][-1] = 0 */       \
+                    DTWP_CELL(INF, PREV[a_], diag0_, dt0_, CUR[a_])                                                  \
+                } else {                                                                                             \
+                    if (ra == (K)) {                                         /* the row above is not part of this column */ \
+                        CUR[u_] = INF;                                                                               \
+                        if (!carry) PREV[u_] = INF;                                                                  \
+                        asm volatile("" ::: "memory");                       /* keeps this a branch */               \
+                    }                                                                                                \
+                    DTWP_CELL(CUR[u_], PREV[a_], PREV[u_], dt0_, CUR[a_])                                            \
+                }                                                                                                    \
+                DTWP_CELL(CUR[a_], PREV[b_], PREV[a_], dt1_, CUR[b_])                                                \
+            }
+#define DTWP_COLUMN(JJ, PREV, CUR)                                                                                   \
+            {                                                                                                        \
+                const int J_ = (JJ);                                                                                 \
+                const double yp1 = y_next + 1.0, yr = yr_next;                                                       \
+                if (J_ + 1 < ly) { y_next = ycol[J_ + 1]; yr_next = yrcol[J_ + 1]; }                                 \
+                const uint32_t t = (uint32_t)__builtin_amdgcn_readlane((int)tab, J_ - jc);                           \
+                const uint32_t am = t & 0xffffu;                                                                     \
+                const int ra = (int)((t >> 16) & 0x7ffu);                                                            \
+                const bool carry = ra > 0 && ((prev_am >> (ra - 1)) & 1u);                                           \
+                prev_am = am;                                                                                        \
+                uint32_t word = 0;                                                                                   \
+                DTWP_PAIR(0, PREV, CUR) DTWP_PAIR(1, PREV, CUR) DTWP_PAIR(2, PREV, CUR) DTWP_PAIR(3, PREV, CUR)      \
+                DTWP_PAIR(4, PREV, CUR) DTWP_PAIR(5, PREV, CUR)                                                      \
+                word |= t & 0xf8000000u;                                     /* the column's last row */             \
+                if (WLDS) wl[J_ * DTW_THREADS] = word; else wq[(int64_t)J_ * NT] = word;                             \
+            }
+        int j = jc;
+        for (; j + 1 < jend; j += 2) {
+            DTWP_COLUMN(j, cB, cA)
+            DTWP_COLUMN(j + 1, cA, cB)
+        }
+        if (j < jend) DTWP_COLUMN(j, cB, cA)
+#undef DTWP_IN
+#undef DTWP_COST
+#undef DTWP_CELL
+#undef DTWP_PAIR
+#undef DTWP_COLUMN
+    }
+    if (!act) return;
+#ifdef DTW_PROBE_NO_BACKTRACK
+    return;
+#endif
+    int i = lx - 1, j = ly - 1;
+    int last = j;
+    uint32_t word = WLDS ? wl[j * DTW_THREADS] : wq[(int64_t)j * NT];
+    while (i >= 0 && j >= 0) {
+        const int sh = 2 * ((int)(word >> 27) - i);
+        const uint32_t b = (word >> sh) & 3u;                                // first bit << 1 | second bit
+        int d;
+        if (TIE == 0) d = (b & 2u) ? 0 : ((b & 1u) ? 1 : 2);
+        else d = (b & 2u) ? 2 : ((b & 1u) ? 0 : 1);
+        if (d != 1) {
+            FLQ(i) = (last << 16) | j;
+            --i;
+        }
+        if (d != 0) {
+            --j;
+            if (j >= 0) word = WLDS ? wl[j * DTW_THREADS] : wq[(int64_t)j * NT];
+        }
+        if (d != 1) last = j;
+    }
+    if (i >= 0 && j < 0) FLQ(i) = (last << 16) | 0;
+#undef FLQ
+}
+
 // RMAX = rows the instantiation can hold (12 / 20 / 32): the register budget -- and with it the
 // number of resident wavefronts that hide the fp64 dependency chains -- follows the longest
 // component of the call, not the longest the kernel family supports.  The levels that are backtracked
@@ -657,6 +838,8 @@ __global__ __launch_bounds__(DTW_THREADS, MINB) void dtw_similarity_reg_kernel(
             if (lev == 0)
                 result = dtw_wave_level<RMAX, TIE, WLDS, true>(fl, xcol, xrcol, n_x, ycol, yrcol, act, lx, ly, lxc, lyc,
                                                                coarsest, wl, w, NT);
+            else if constexpr (2 * RH <= 27 && !DTW_OLD_COARSE)
+                dtw_wave_level_pp<RH, TIE, WLDS>(fl, xcol, xrcol, n_x, ycol, yrcol, act, lx, ly, lxc, lyc, coarsest, wl, w, NT);
             else
                 dtw_wave_level<RH, TIE, WLDS, false>(fl, xcol, xrcol, n_x, ycol, yrcol, act, lx, ly, lxc, lyc, coarsest,
                                                      wl, w, NT);

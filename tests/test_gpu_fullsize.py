@@ -269,9 +269,13 @@ def test_training_half_at_shard_size_matches_the_oracle(full, n_layers):
     assert calls['sgnn_lstm_fwd'] >= 1 and calls['sgnn_lstm_bwd'] >= 1, calls
     # ---- the oracle on the product's prepared state ----------------------------------------------------------------
     params, anchors, ob, ccp = oracle_inputs(m, batch, torch.arange(B))
-    for k, v in params.items():                            # the state BEFORE the step (state_dict() above is after it)
-        if k in before:
-            v.data.copy_(before[k].cpu())
+    # the oracle in FLOAT64 on the state BEFORE the step (state_dict() above is after it): a float32 restatement carries
+    # its own summation error on the small elements of a gradient contracted over 8192 x 183 terms
+    for k in list(params):
+        if params[k].dtype == torch.float32:
+            params[k] = (before[k].cpu() if k in before else params[k].detach()).double().requires_grad_(True)
+    ob = {k: ({kk: (vv.double() if torch.is_tensor(vv) and vv.dtype == torch.float32 else vv) for kk, vv in v.items()} if isinstance(v, dict)
+              else (v.double() if torch.is_tensor(v) and v.dtype == torch.float32 else v)) for k, v in ob.items()}
     ref_logits = FH.forward(params, hp, 'train', ob, anchors, ccp)
     ref_loss = torch.nn.functional.cross_entropy(ref_logits, labels)
     ref_loss.backward()
@@ -293,16 +297,37 @@ def test_training_half_at_shard_size_matches_the_oracle(full, n_layers):
     torch.nn.utils.clip_grad_norm_(leaves, hp['grad_clip'])
     torch.optim.Adam(leaves, lr=hp['learning_rate']).step()
     after = {k: v.detach() for k, v in m.state_dict().items() if v.dtype == torch.float32}
-    worst = {}
+    # Parameters after the step against the oracle's.  Adam's first step moves an element by lr * g / (|g| + eps): where the
+    # gradient is tiny (|g| ~ eps = 1e-8: dead units of the head) the step is sensitive to the 1e-4 the two gradients may
+    # differ by -- an element of lin2.weight with g ~ 1e-8 moved by 0.95 lr here and by 1.0 lr in the oracle -- so an element
+    # is allowed 1e-4 relative PLUS what the asserted gradient tolerance can move Adam's step: lr * dg / (|g| + eps) (<= 2 lr)
+    lr_, eps_ = hp['learning_rate'], 1e-8
     for k, v in params.items():
         if not (v.requires_grad and v.grad is not None):
             continue
-        assert_close(after[k], v.detach(), 'parameter after clip + Adam: ' + k)
-        # the UPDATE itself (parameters of size ~1 moved by ~lr would pass the line above whatever the step did): Adam's
-        # first step is lr * g / (|g| + eps) -- insensitive to the gradient's error except where |g| ~ eps = 1e-8
-        du, dr = (after[k] - before[k]).cpu(), v.detach() - before[k].cpu()
-        worst[k] = rel_err(du, dr)
-        assert worst[k] < 1e-3, (k, worst[k])
+        gref = v.grad.double().abs()                                 # (clipped in place above: the gradient Adam saw)
+        dg = 1e-4 * gref + 1e-6 * float(gref.max())                  # the element-wise gradient tolerance asserted above
+        step_slack = (lr_ * dg / (gref + eps_)).clamp(max=2 * lr_)
+        allowed = 1e-4 * v.detach().double().abs() + 1e-6 * float(v.detach().abs().max()) + step_slack
+        err = (after[k].cpu().double() - v.detach().double()).abs()
+        worst_i = int(torch.argmax(err / allowed))
+        assert bool((err <= allowed).all()), ('parameter after clip + Adam: ' + k, float(err.view(-1)[worst_i]), float(allowed.view(-1)[worst_i]))
+    # ... and the UPDATE itself (parameters of size ~1 moved by ~lr pass the line above whatever the step did).  Adam's first
+    # step is lr * g / (|g| + eps): where |g| ~ eps = 1e-8 it amplifies the 1e-4 the two gradients may differ by (3 % on the
+    # worst table element here), so the update is checked against Adam's rule applied in float64 to the PRODUCT's own
+    # gradients (whose parity is asserted above): |update - rule| <= 1e-4 |rule| + one float32 rounding of the parameter
+    g64 = {k: g.double() for k, g in grads.items() if g is not None}
+    total = torch.sqrt(sum((g * g).sum() for g in g64.values()))
+    coef = torch.clamp(hp['grad_clip'] / (total + 1e-6), max=1.0)
+    b1, b2, eps, lr = 0.9, 0.999, 1e-8, hp['learning_rate']
+    worst = {}
+    for k, g in g64.items():
+        gc = g * coef
+        rule = -lr * ((1 - b1) * gc / (1 - b1)) / (torch.sqrt((1 - b2) * gc * gc / (1 - b2)) + eps)
+        got = after[k].double() - before[k].double()
+        slack = 1e-4 * rule.abs() + 2 * 2.0 ** -24 * before[k].double().abs() + 1e-12
+        worst[k] = float(((got - rule).abs() / slack).max())
+        assert worst[k] <= 1.0, (k, worst[k])
     untouched = (grads['node_embeddings.weight'].abs().sum(1) == 0)
     assert torch.equal(after['node_embeddings.weight'][untouched], before['node_embeddings.weight'][untouched])
-    print('shard-size training half: calls', dict(calls), 'worst update errors', {k: '%.1e' % e for k, e in worst.items()})
+    print('shard-size training half: calls', dict(calls), 'worst update error / allowed', {k: '%.2f' % e for k, e in worst.items()})

@@ -18,6 +18,9 @@ Variants (bisecting the cause; combinable):
   no_tall           ops.linear always takes the library path (no split-contraction backward)
   no_shared_gemm    SHARED layers by the hand-written kernel at every size (ops.SHARED_GEMM_MIN_ROWS = infinity)
   atomics_off       ROCBLAS_DEFAULT_ATOMICS_MODE=0 in the child's environment
+  dropout           lin_dropout as in the benchmark's hyper-parameters (default here: 0)
+  nosync            no host synchronisation inside the run: the per-pass losses are kept on the device and checksummed at the
+                    end (use with --detail-passes 0), so the host runs ahead as it does in bench.py
   pipelined         the passes go through hotpath.PassPipeline (two in flight) as bench.py's default schedule does
 """
 import argparse
@@ -79,6 +82,9 @@ def child(args):
         os.replace(cache + '.tmp.npz', cache)
     g = ops.DeviceGraph(rowptr, col, np.arange(1, n + 1, dtype=np.int32), dev)
     hp = dict(bench.ALL_DENSITY_HP, lin_dropout=0.0)
+    if 'dropout' in variants:
+        hp['lin_dropout'] = bench.ALL_DENSITY_HP['lin_dropout']
+        torch.cuda.manual_seed(0)
     if 'one_stream' in variants:
         hp['overlap_streams'] = False
     emb = torch.randn(n, hp['node_embed_size'], generator=torch.Generator().manual_seed(0))
@@ -117,6 +123,7 @@ def child(args):
             for i, v in enumerate(o):
                 walk('%s[%d]' % (prefix, i), v)
 
+    kept = []
     pipe = None
     if 'pipelined' in variants:
         pipe = hotpath.PassPipeline(model, 'train')
@@ -136,7 +143,10 @@ def child(args):
                 walk(tag + 'prepared/' + nm, getattr(model, nm, None))
         batch = hotpath.full_split_batch(model, 'train')
         out = model.training_step(batch, 0)
-        ck(tag + 'loss', out['loss'])
+        if 'nosync' in variants:
+            kept.append((tag + 'loss', out['loss'].detach().clone()))
+        else:
+            ck(tag + 'loss', out['loss'])
         model.backward(None, out['loss'], None, 0)
         if p_ < args.detail_passes:
             for nm, p in model.named_parameters():
@@ -148,6 +158,10 @@ def child(args):
             for nm, p in model.named_parameters():
                 ck(tag + 'param_after/' + nm, p)
     torch.cuda.synchronize()
+    for nm, t in kept:
+        ck(nm, t)
+    for nm, p in model.named_parameters():
+        ck('final/' + nm, p)
     with open(args.child, 'w') as f:
         json.dump({'loss': float(out['loss']), 'sums': sums}, f)
 
