@@ -140,6 +140,51 @@ def degseq_algorithmic_bytes(rowptr, sets_lists, search=False):
     return total
 
 
+XGMI_LINK_GBS = 153.0          # per direction and link; 7 links per GPU (MI355X_MICROARCH.md)
+
+
+def projection(args, result, model, S):
+    """8-GPU estimates from THIS run's measured step + bytes / link rate, so that a SCALE run can be read against them.  Not a
+    measurement.  BASELINE.json words configs[3] as "50k subgraphs, sharded across 8": that is the STRONG form (--scaling
+    strong, 6 250 subgraphs per GPU); the tier's multi-GPU contract (per-GPU work fixed) and bench.py's default are the WEAK
+    form (50k subgraphs per GPU) -- both are projected."""
+    W = 8
+    step = result['ms_per_step']
+    table_bytes = int(model.node_embeddings.weight.numel() * 4)
+    small_bytes = int(sum(p.numel() for p in model.parameters() if p.requires_grad and p is not model.node_embeddings.weight) * 4)
+    per_link = table_bytes / W                                   # a reduce-scatter / all-gather moves 1/W of the buffer per peer
+    direct_ms = per_link / (XGMI_LINK_GBS * 1e9) * 1e3            # all 7 links busy at once (direct exchange)
+    ring_ms = (W - 1) * per_link / (XGMI_LINK_GBS * 1e9) * 1e3    # one link per step (ring)
+    adam_ms = result['stages_ms'].get('optimizer', 0.5)
+    out = {'n_gpus': W, 'not_a_measurement': True,
+           'collective_bytes_per_step': {'table_gradient_reduce_scatter': table_bytes, 'table_all_gather(hidden under the next preparation)': table_bytes,
+                                         'small_gradients_all_reduce': small_bytes},
+           'reduce_scatter_ms': {'direct_7_links': round(direct_ms, 3), 'ring': round(ring_ms, 3)}}
+    # weak: every rank runs this run's step on its own 50k subgraphs; + the exposed reduce-scatter + a latency-bound small
+    # all-reduce (~0.1 ms); - 7/8 of the table's Adam (owner-computes on 1/8 of the rows)
+    for name, rs in (('direct', direct_ms), ('ring', ring_ms)):
+        ms = step + rs + 0.1 - adam_ms * (W - 1) / W
+        out['weak_' + name] = {'ms_per_step': round(ms, 2), 'subgraphs_per_s': round(W * S / ms * 1e3), 'speedup_vs_1gpu': round(W * step / ms, 2)}
+    # strong: a 6 250-subgraph shard's step as measured on one GPU (committed line of `bench.py --subgraphs 6250`), same additions
+    for tag in ('r04', 'r03'):
+        f = os.path.join(REPO, 'profiles', tag + '_bench_shard6250.json')
+        if os.path.exists(f) and S == 50_000:
+            try:
+                sh = json.load(open(f))
+                for name, rs in (('direct', direct_ms), ('ring', ring_ms)):
+                    ms = sh['ms_per_step'] + rs + 0.1 - sh['stages_ms'].get('optimizer', adam_ms) * (W - 1) / W
+                    out['strong_' + name] = {'ms_per_step': round(ms, 2), 'subgraphs_per_s': round(S / ms * 1e3),
+                                             'speedup_vs_1gpu': round(step / ms, 2)}
+                out['strong_source'] = 'profiles/%s_bench_shard6250.json: %.2f ms per 6 250-subgraph pass on one GPU' % (tag, sh['ms_per_step'])
+            except Exception:
+                pass
+            break
+    out['note'] = ('BASELINE.json configs[3] ("50k subgraphs, sharded across 8") is the strong form: walks over the shared patches, one BFS word '
+                   'per rank, the dense 256 MB table gradient and launch overhead do not shrink with the shard, so it is bound near 2-3x; the '
+                   '>= 6x target is reachable in the weak form (50k per GPU: what `bench.py --gpus 8` runs by default)')
+    return out
+
+
 def main():
     args = parse()
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -240,6 +285,59 @@ def main():
 
     stage_ms = {}
     kept_passes = []
+    hooked = {}
+    if os.environ.get('SGNN_BENCH_CHECKSUMS') == '2':
+        # gradients flowing INTO every head layer / the subgraph embedding, cloned by autograd hooks (no sync): names the first
+        # operation of the backward whose result differs between processes
+        real_linear, real_embed = ops.linear, ops.subgraph_embedding
+        counter = {'n': 0}
+
+        def _tap(y, name):
+            if torch.is_tensor(y) and y.requires_grad:
+                y.register_hook(lambda g_, name=name: hooked.__setitem__(name, g_.detach().clone()))
+            return y
+
+        def linear_tapped(x, w, b):
+            counter['n'] += 1
+            return _tap(real_linear(x, w, b), 'hook/d_out_of_linear_%dx%d' % (w.shape[0], w.shape[1]))
+
+        def embed_tapped(*a, **k):
+            return _tap(real_embed(*a, **k), 'hook/d_subgraph_embedding')
+        ops.linear, ops.subgraph_embedding = linear_tapped, embed_tapped
+        real_ce, real_cc = ops.cross_entropy_with_accuracy, ops.cc_embed
+
+        def ce_tapped(logits, labels_):
+            hooked['fwd/logits'] = logits.detach().clone()
+            return real_ce(logits, labels_)
+
+        def cc_tapped(*a, **k):
+            y = real_cc(*a, **k)
+            hooked['fwd/cc_embed_%d' % len([1 for n_ in hooked if n_.startswith('fwd/cc_embed')])] = y.detach().clone()
+            return y
+        ops.cross_entropy_with_accuracy, ops.cc_embed = ce_tapped, cc_tapped
+
+        def embed_tapped2(*a, **k):
+            y = real_embed(*a, **k)
+            hooked['fwd/subgraph_embedding'] = y.detach().clone()
+            return _tap(y, 'hook/d_subgraph_embedding')
+        ops.subgraph_embedding = embed_tapped2
+
+        def snapshot_prepared():
+            def walk(prefix, o):
+                if isinstance(o, torch.Tensor):
+                    hooked['prep/' + prefix] = o.detach().clone()
+                elif isinstance(o, dict):
+                    for k_, v_ in o.items():
+                        walk('%s[%r]' % (prefix, k_), v_)
+                elif isinstance(o, (list, tuple)):
+                    for i_, v_ in enumerate(o):
+                        walk('%s[%d]' % (prefix, i_), v_)
+            for nm in ('train_cc_ids', 'train_neigh_pos_similarities', 'train_int_struc_similarities', 'train_bor_struc_similarities',
+                       'anchors_neigh_int', 'anchors_neigh_border', 'anchors_pos_int', 'anchors_pos_ext', 'anchors_structure',
+                       'structure_anchors', '_mpn_edge_plans'):
+                walk(nm, getattr(model, nm, None))
+            for k_, p_ in model.named_parameters():
+                hooked['param_before/' + k_] = p_.detach().clone()
 
     pipe = hotpath.PassPipeline(model, 'train', shard) if pipelined else None
     side_timers = []
@@ -270,6 +368,8 @@ def main():
             pipe.start(timed)                                    # the next one: side stream, beside this step's training
         else:
             hotpath.prepare_sparse(model, 'train', timer, shard)
+        if os.environ.get('SGNN_BENCH_CHECKSUMS') == '2':
+            snapshot_prepared()
         batch = hotpath.full_split_batch(model, 'train')
         if replicated:
             batch['label'] = labels_dev                          # the head runs on the gathered global batch
@@ -278,8 +378,10 @@ def main():
         model.backward(None, out['loss'], None, 0)
         timer.mark('backward')
         if os.environ.get('SGNN_BENCH_CHECKSUMS') == '2':        # every pass's loss and gradients, cloned on the device (no sync)
-            kept_passes.append((out['loss'].detach().clone(), {k_: p_.grad.detach().clone() for k_, p_ in model.named_parameters()
-                                                                 if p_.grad is not None}))
+            grads_ = {k_: p_.grad.detach().clone() for k_, p_ in model.named_parameters() if p_.grad is not None}
+            grads_.update(hooked)
+            hooked.clear()
+            kept_passes.append((out['loss'].detach().clone(), grads_))
         if not multi:
             opt.step()                                           # (clips first: ClipAdam)
             opt.zero_grad(set_to_none=True)
@@ -547,7 +649,7 @@ def main():
                                'subgraphs x %d nodes %s, all_density hparams (N 10/43, P 57/183, S 42, 1 layer), '
                                'D=%d, full pass = sampling + similarities + fwd + bwd + Adam' %
                                (n, args.m, int(rowptr[-1]) // 2, args.subgraphs, args.subgraph_nodes,
-                                'per GPU' if args.scaling == 'weak' else 'in total', args.embed),
+                                'per GPU (weak form; BASELINE configs[3] "50k sharded across 8" as worded is --scaling strong)' if args.scaling == 'weak' else 'in total (strong form: BASELINE configs[3] as worded)', args.embed),
                    'subgraphs_per_gpu': S, 'subgraphs_total': total_subgraphs,
                    'schedule': {'passes_pipelined': pipe is not None, 'training_half_from_hipgraph': trainer is not None,
                                 'prepared_passes_in_flight': (max(1, args.pipeline_depth) if not multi else 1) if pipe is not None else 0, 'two_stream_preparation': bool(hp.get('overlap_streams', True)) and not (shard is not None and shard.deal_shared)},
@@ -594,6 +696,8 @@ def main():
         # device synchronisation after each:
         'first_pass_ms': round(first_pass_ms, 2), 'second_pass_ms': round(second_pass_ms, 2),
     }
+    if world == 1 and args.scaling == 'weak':
+        result['projection'] = projection(args, result, model, S)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
             from oracle import cpu_baseline

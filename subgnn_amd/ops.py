@@ -1610,9 +1610,13 @@ class _BiLSTMLayer(torch.autograd.Function):
         dwih = contract_rows(dg, x2)                                            # (8H, I)
         dgd = dgates.view(B * T, 2, 4 * H).transpose(0, 1).contiguous()         # (2, B T, 4H): one direction's gates contiguous
         dwhh = [contract_rows(dgd[d], hprev[d].view(B * T, H)) for d in (0, 1)]
-        db = column_sum(dg).view(8 * H)
+        # bias_ih and bias_hh receive the same gradient VALUES but must not receive the same MEMORY: autograd hands a view
+        # over to .grad as it is, and an in-place multi-tensor update of the gradient list (clip_grad_norm_'s _foreach_mul_)
+        # then scales the shared buffer once per alias, from concurrently running chunks -- g c or g c^2 depending on timing
+        # (round 4: the cross-process 7th-digit loss drift was this race on lstm.bias_{ih,hh}_l0_reverse).  One copy:
+        db = column_sum(dg).view(8 * H).repeat(2)                              # [ih: forward, reverse | hh: forward, reverse]
         G = 4 * H
-        return (dx, dwih[:G], dwhh[0], db[:G], db[:G], dwih[G:], dwhh[1], db[G:], db[G:])
+        return (dx, dwih[:G], dwhh[0], db[:G], db[2 * G:3 * G], dwih[G:], dwhh[1], db[G:2 * G], db[3 * G:])
 
 
 def lstm_supported(input_size, hidden_size):

@@ -97,10 +97,14 @@ class Trainer:
     gradient clipping, validation every epoch, best-by-monitor bookkeeping."""
 
     def __init__(self, max_epochs, gradient_clip_val=0.0, monitor='val_micro_f1', mode='max', log=print,
-                 hip_graph_step=False):
+                 hip_graph_step=True):
         self.max_epochs, self.clip, self.monitor, self.mode, self.log = max_epochs, gradient_clip_val, monitor, mode, log
         self.best, self.history = None, []
-        self.hip_graph_step = hip_graph_step
+        # Full batches replay a recorded step (graph_step.CapturedTrainStep) unless hparams['hip_graph_step'] is False: at the
+        # reference's batch sizes the eager step is bound by the host's ~250 launches (3.5-11.5 ms against 1.3-4.6 ms replayed,
+        # profiles/r03_bench_standin_*.json).  A short last batch runs eagerly; a model whose step cannot be recorded (an
+        # operation that needs the host inside training_step) is reported and trained eagerly.
+        self.hip_graph_step = bool(hip_graph_step) and torch.cuda.is_available()
 
     def _eager_step(self, model, opt, batch, bi):
         out = model.training_step(batch, bi)
@@ -128,10 +132,17 @@ class Trainer:
                 if captured is None or captured.stale():
                     captured = CapturedTrainStep(model, opt, loader.bs, self.clip, warmup=3 if captured is None else 0)
                 for bi, idx in enumerate(loader.index_batches()):
-                    if idx.numel() == loader.bs:
-                        losses.append(captured.replay(idx)[0].clone())
-                    else:
-                        losses.append(self._eager_step(model, opt, model.make_batch('train', idx), bi))
+                    if idx.numel() == loader.bs and self.hip_graph_step:
+                        try:
+                            losses.append(captured.replay(idx)[0].clone())
+                            continue
+                        except RuntimeError as ex:
+                            if captured.graph is not None:
+                                raise                                # a recorded step failed: nothing to fall back from
+                            self.log('hip_graph_step: the training step could not be recorded (%s); training eagerly' % (ex,))
+                            self.hip_graph_step = False
+                            torch.cuda.synchronize()
+                    losses.append(self._eager_step(model, opt, model.make_batch('train', idx), bi))
             else:
                 for bi, batch in enumerate(loader):
                     losses.append(self._eager_step(model, opt, batch, bi))
@@ -160,7 +171,7 @@ def train_model(run_config, trial=None, results_dir=None, log=print):
     monitor = opt_cfg.get('monitor_metric', 'val_micro_f1')
     mode = 'max' if opt_cfg.get('opt_direction', 'maximize') == 'maximize' else 'min'
     trainer = Trainer(hp['max_epochs'], hp.get('grad_clip', 0.0), monitor, mode, log,
-                      hip_graph_step=bool(hp.get('hip_graph_step', False)))
+                      hip_graph_step=bool(hp.get('hip_graph_step', True)))
     if results_dir is not None:
         Path(results_dir).mkdir(parents=True, exist_ok=True)
         with open(Path(results_dir) / 'hyperparams.json', 'w') as f:

@@ -505,6 +505,32 @@ def test_lstm_module_uses_fused_layers_and_matches_library(layers, agg, D):
         assert_close(a, q.grad, 'LSTM module d ' + nm)
 
 
+def test_lstm_bias_gradients_do_not_share_memory():
+    """bias_ih and bias_hh get equal gradient values in separate buffers: sharing one buffer made clip_grad_norm_'s in-place
+    multi-tensor scaling hit it twice from concurrent chunks (g c or g c^2 by timing -- the cross-process loss drift of
+    rounds 2-3).  After clipping, every bias gradient is exactly coefficient x the unclipped gradient."""
+    from subgnn_amd.SubGNN import LSTM
+    torch.manual_seed(5)
+    m = LSTM(64, 64, dropout=0.0, num_layers=2, aggregator='last').to(DEV)
+    x = torch.randn(40, 10, 64, device=DEV)
+    m(x).square().sum().backward()
+    named = dict(m.named_parameters())
+    biases = [k for k in named if 'bias' in k and k.startswith('lstm.')]
+    assert len(biases) == 8
+    ptrs = [named[k].grad.untyped_storage().data_ptr() for k in biases]
+    spans = sorted((named[k].grad.data_ptr(), named[k].grad.data_ptr() + named[k].grad.numel() * 4) for k in biases)
+    assert all(a[1] <= b[0] for a, b in zip(spans[:-1], spans[1:])), 'bias gradients overlap in memory'
+    for sfx in ('l0', 'l0_reverse', 'l1', 'l1_reverse'):
+        assert torch.equal(named['lstm.bias_ih_' + sfx].grad, named['lstm.bias_hh_' + sfx].grad)
+    before = {k: named[k].grad.clone() for k in biases}
+    total = torch.nn.utils.clip_grad_norm_(m.parameters(), 0.01)
+    coef = torch.clamp(0.01 / (total + 1e-6), max=1.0)
+    assert float(coef) < 0.5
+    for k in biases:
+        assert torch.equal(named[k].grad, before[k] * coef), k
+    del ptrs
+
+
 def test_lstm_unsupported_sizes_stay_on_the_library():
     from subgnn_amd import ops
     from subgnn_amd.SubGNN import LSTM

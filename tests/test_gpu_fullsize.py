@@ -247,6 +247,10 @@ def test_training_half_at_shard_size_matches_the_oracle(full, n_layers):
         with torch.no_grad():
             logits = m._forward_batch('train', batch)
         m.backward(None, out['loss'], None, 0)
+        # no two parameters' gradients may share memory (an in-place multi-tensor update -- clip_grad_norm_ -- would hit it twice)
+        spans = sorted((p.grad.data_ptr(), p.grad.data_ptr() + p.grad.numel() * p.grad.element_size(), k)
+                       for k, p in m.named_parameters() if p.grad is not None)
+        assert all(a[1] <= b[0] for a, b in zip(spans[:-1], spans[1:])), [(a[2], b[2]) for a, b in zip(spans[:-1], spans[1:]) if a[1] > b[0]]
         grads = {k: (p.grad.detach().clone() if p.grad is not None else None) for k, p in m.named_parameters()}
         opt.step()
         opt.zero_grad(set_to_none=True)

@@ -29,8 +29,11 @@ for i, c in enumerate(runs[1:], 1):
     for pi, (pa, pb) in enumerate(zip(ref.get('passes', []), c.get('passes', []))):
         if pa != pb:
             names = [k for k in pa['grads'] if pa['grads'][k] != pb['grads'].get(k)]
-            print('run %d: first differing pass (priming passes included) %d: loss differs %s; %d of %d gradients differ: %s'
-                  % (i, pi, pa['loss'] != pb['loss'], len(names), len(pa['grads']), names[:12]))
+            same = [k for k in pa['grads'] if pa['grads'][k] == pb['grads'].get(k) and not k.startswith(('prep/', 'param_before/'))]
+            print('   differing prepared tensors / parameters before the pass / forward values:',
+                  [k for k in names if k.startswith(('prep/', 'param_before/', 'fwd/'))][:20])
+            print('run %d: first differing pass (priming passes included) %d: loss differs %s; %d of %d gradients differ; EQUAL: %s'
+                  % (i, pi, pa['loss'] != pb['loss'], len(names), len(pa['grads']), same))
             break
     print('run %d differs from run 0: first differing timed step %s (losses %r vs %r); %d of %d parameters differ: %s'
           % (i, step, ref['losses'][step] if step is not None else None, c['losses'][step] if step is not None else None,
