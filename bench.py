@@ -81,11 +81,14 @@ def parse():
     ap.add_argument('--pipeline-depth', type=int, default=2,
                     help='prepared passes in flight under the pipeline: with 2 the preparation stream (the longer chain) is '
                          'never idle while the host installs a pass and queues its training half')
-    ap.add_argument('--graph', action='store_true',
-                    help='N=1: replay the training half from a hipGraph recorded on the second priming pass '
-                         '(hotpath.CapturedTraining; bit-equal to the eager step).  Not the default: the device runs a '
-                         'recorded kernel sequence no faster than the eagerly queued one, and copying each pass into the '
-                         'recording\'s tensors costs 0.2-0.4 ms -- measured 10.7 against 10.4 ms per pass')
+    ap.add_argument('--graph', choices=['auto', 'off', 'train', 'both'], default='auto', nargs='?', const='train',
+                    help='N=1: what is replayed from hipGraphs.  train: the training half (hotpath.CapturedTraining; every prepared pass '
+                         'is copied into the recording\'s tensors); both: preparation AND training half, two alternating slots, no '
+                         'copies (hotpath.GraphedPasses: bit-equal, but a recorded two-stream preparation replays SLOWER than the eager one '
+                         'on this runtime -- 4.5 ms); off: everything queued eagerly; auto (default): train for shards of up to 16 384 '
+                         'subgraphs -- where the pass is bound by the host\'s ~265 launches (6 250 subgraphs: 4.4-4.7 ms eager) -- and off '
+                         'above (50k subgraphs: the device is the bound, 9.5 ms either way).  '
+                         'All forms are bit-equal (tests/test_gpu_hotpath.py)')
     ap.add_argument('--pipeline-multi', action='store_true',
                     help='N>1, weak scaling: pipeline the passes as at N=1 (the prepared pass reduces its padded widths on its '
                          'own communicator while the pass in training exchanges gradients)')
@@ -277,11 +280,17 @@ def main():
     else:
         # clip + Adam with the 256 MB table in one HIP pass (optim.ClipAdam; torch's fused Adam for the small parameters)
         from subgnn_amd import optim
-        opt = optim.ClipAdam(model.parameters(), hp['learning_rate'], max_norm=hp['grad_clip'], capturable=args.graph)
+        graph_mode = args.graph
+        if graph_mode == 'auto':
+            graph_mode = 'train' if S <= 16384 else 'off'
+        opt = optim.ClipAdam(model.parameters(), hp['learning_rate'], max_norm=hp['grad_clip'], capturable=graph_mode != 'off')
     params = [p for p in model.parameters() if p.requires_grad]
     # N = 1: the training half (component embeddings .. Adam) is recorded into a hipGraph on the second priming pass and
     # replayed: same kernels, one launch
-    trainer = hotpath.CapturedTraining(model, opt, 'train', warmup=1) if (not multi and args.graph) else None
+    if multi:
+        graph_mode = 'off'
+    trainer = hotpath.CapturedTraining(model, opt, 'train', warmup=1) if graph_mode == 'train' else None
+    graphed = hotpath.GraphedPasses(model, opt, 'train', warmup=2) if graph_mode == 'both' else None
 
     stage_ms = {}
     kept_passes = []
@@ -339,11 +348,16 @@ def main():
             for k_, p_ in model.named_parameters():
                 hooked['param_before/' + k_] = p_.detach().clone()
 
-    pipe = hotpath.PassPipeline(model, 'train', shard) if pipelined else None
+    pipe = hotpath.PassPipeline(model, 'train', shard) if (pipelined and graphed is None) else None
     side_timers = []
 
     def step(timed):
         timer = hotpath.StageTimer(timed)
+        if graphed is not None:
+            timer.mark('start')
+            loss, _acc = graphed.step()                          # two graph launches: this pass's training half, the next pass's preparation
+            timer.mark('pass(hipGraphs: training half; the next preparation beside it)')
+            return timer, loss
         if trainer is not None:
             timer.mark('start')
             if pipe is not None:
@@ -423,7 +437,7 @@ def main():
     # kept per split (dispatch order, row-grouping decision), the second is the first to run the steady
     # path and grows the caching allocator to its final footprint (with --warmup 1 the timed steps were
     # 30 ms instead of 20)
-    PRIMING_PASSES = 2
+    PRIMING_PASSES = 2 if graphed is None else 4                 # (graphed: two eager passes, then one recording per slot)
     torch.cuda.synchronize()
     t_cold = time.perf_counter()
     if pipe is not None:
@@ -571,11 +585,17 @@ def main():
         _, _, k1_counts = ops.khop_border_sample(g, cc_sets, hp['neigh_sample_border_size'], hp['n_anchor_patches_N_out'], k1_seed, k1_stream)
         k1_ms = timed(lambda: ops.khop_border_sample(g, cc_sets, hp['neigh_sample_border_size'], hp['n_anchor_patches_N_out'],
                                                      k1_seed, k1_stream, width=model._border_width.get(('train', hp['neigh_sample_border_size'], cc_sets.n, 1))))
-        k1_bytes = list_bytes + 4 * (n_members + int(k1_counts.sum()))           # 8(d) a8: frontier lists + 4 (|CC| + |border|), k = 1
+        # 8(d) a8, k = 1: the frontier's lists + 4 (|CC| + |border|).  The kernel never writes the border (the draw is a rank query
+        # on the bitmap): achieved / frac price what it has to READ (lists + members); the formula with the border the reference
+        # materialises is beside it
+        k1_bytes = list_bytes + 4 * n_members
+        k1_bytes_8d = k1_bytes + 4 * int(k1_counts.sum())
         rooflines.append({'kernel': 'khop1_sample_kernel<false> (sgnn_khop_border_sample: one-hop border + N-border draw, a8 + a4)',
                           'bound': 'hbm', 'algorithmic_bytes_per_launch': k1_bytes, 'ms_per_launch': k1_ms,
                           'achieved': k1_bytes / (k1_ms * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                           'frac': k1_bytes / (k1_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                          'survey_8d_bytes_with_the_border_written': k1_bytes_8d,
+                          'frac_on_survey_8d_bytes': k1_bytes_8d / (k1_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                           'stage_ms_in_timed_region': stage_ms.get('border_bfs+N_anchors'),
                           'note': 'issue- and barrier-bound on one 1024-thread workgroup per CU around a 125 KB LDS bitmap (profiles/r03_khop1_pmc.json), '
                                   'not memory-bound; the lists come from L2 / Infinity Cache (the CSR is 88 MB)'})
@@ -651,7 +671,7 @@ def main():
                                (n, args.m, int(rowptr[-1]) // 2, args.subgraphs, args.subgraph_nodes,
                                 'per GPU (weak form; BASELINE configs[3] "50k sharded across 8" as worded is --scaling strong)' if args.scaling == 'weak' else 'in total (strong form: BASELINE configs[3] as worded)', args.embed),
                    'subgraphs_per_gpu': S, 'subgraphs_total': total_subgraphs,
-                   'schedule': {'passes_pipelined': pipe is not None, 'training_half_from_hipgraph': trainer is not None,
+                   'schedule': {'passes_pipelined': pipe is not None or graphed is not None, 'hipgraphs': graph_mode, 'training_half_from_hipgraph': trainer is not None or graphed is not None,
                                 'prepared_passes_in_flight': (max(1, args.pipeline_depth) if not multi else 1) if pipe is not None else 0, 'two_stream_preparation': bool(hp.get('overlap_streams', True)) and not (shard is not None and shard.deal_shared)},
                    'parallelism': ('dp%d (subgraph shards; head on the rank\'s own rows, all-reduce of the small gradients, '
                                    'reduce-scatter / all-gather of the embedding table)' % world) if not replicated else

@@ -96,6 +96,18 @@ def _bfs_note(model, st, key, status, max_hops, enqueued, redo):
     status into pinned host memory behind the search (no wait here) and leave a check on the pass; ``redo`` runs the
     search again with the full cap."""
     hint = model.__dict__.setdefault('_bfs_level_hint', {})
+    if torch.cuda.is_current_stream_capturing():
+        # the pass is being recorded into a hipGraph (GraphedPasses): the status travels to a pinned buffer that belongs to the
+        # recording (every replay rewrites it); no event -- the replay's own completion event orders the read
+        if hint.get(key) is None:
+            raise RuntimeError('a recorded pass needs the BFS depth of an earlier eager pass (GraphedPasses warms up first)')
+        pool = model.__dict__.setdefault('_bfs_status_pool', [])
+        if not pool:                                 # (pinning allocates host memory: not allowed while a stream is capturing)
+            raise RuntimeError('no pinned status buffer left for a recorded search: GraphedPasses._record provides them')
+        host = pool.pop()
+        host.copy_(status, non_blocking=True)
+        st.bfs_checks.append((key, host, None, max_hops, enqueued, None))
+        return
     if hint.get(key) is None:
         last, more = status.tolist()
         if more:
@@ -113,7 +125,11 @@ def _bfs_note(model, st, key, status, max_hops, enqueued, redo):
     st.bfs_checks.append((key, host, ev, max_hops, enqueued, redo))
 
 
-def _verify_bfs(model, st):
+class BfsLevelsExhausted(RuntimeError):
+    """A recorded pass's hinted position-channel search ran out of levels (the hint has been raised to the cap)."""
+
+
+def _verify_bfs(model, st, keep=False):
     """Before a prepared pass becomes the model's: did every hinted position-channel search end within the levels it
     was given?  The status was copied to pinned memory right behind the search -- by now (the pass was prepared a step
     ago under the pipeline, or the caller is about to wait for the table anyway) the copy has landed and the event
@@ -121,17 +137,23 @@ def _verify_bfs(model, st):
     before anything reads them; only a graph deeper than hparams['max_bfs_hops'] itself is an error."""
     hint = model.__dict__.setdefault('_bfs_level_hint', {})
     for key, host, ev, cap, enqueued, redo in st.bfs_checks:
-        ev.synchronize()
+        if ev is not None:
+            ev.synchronize()
         last, more = int(host[0]), int(host[1])
         if more and enqueued < cap:
+            if redo is None:                         # a recorded pass cannot repeat a search: its owner records again
+                hint[key] = cap
+                raise BfsLevelsExhausted(key)
             last, more = redo(cap)
             model.__dict__['_bfs_redone'] = model.__dict__.get('_bfs_redone', 0) + 1
         if more:
             raise RuntimeError('position-channel BFS: level %d still reached new nodes -- hparams["max_bfs_hops"] = %d '
                                'is smaller than the depth of this graph from the anchors' % (cap, cap))
         hint[key] = max(hint.get(key) or 0, last)                  # the hint only grows: anchors are redrawn every pass
-        model.__dict__.setdefault('_bfs_status_pool', []).append(host)
-    st.bfs_checks = []
+        if ev is not None:
+            model.__dict__.setdefault('_bfs_status_pool', []).append(host)
+    if not keep:
+        st.bfs_checks = []
 
 
 def check_pending(model):
@@ -451,7 +473,14 @@ def prepare_pass(model, split='train', timer=None, shard=None, defer_dtw=False):
         _hand_over(main, structure_anchors)
         structure_walks()
         t.mark('S_walks')
-    # ---- join ------------------------------------------------------------------------------
+    # ---- structure similarities (main), then the join ---------------------------------------
+    # The DTW launches read the degree sequences only, nothing the side stream computes: they are queued BEFORE the join, so a
+    # position search that is still running (small shards: the search does not shrink with the shard, everything else does)
+    # overlaps with them instead of delaying them (6 250 subgraphs: the main chain reaches this point after ~1.3 ms, the search
+    # ends at ~1.6).  At the benchmark's 50k subgraphs the search has long finished when the main chain gets here.
+    st.dtw_inputs = (cc_sets, ci, ce, a_sets, ai, ae, (S, C)) if hp['use_structure'] else None
+    if not defer_dtw:
+        finish_pass(model, st, t)
     if side is not main:
         main.wait_stream(side)
         _hand_over(main, sims, st.attrs.get('anchors_pos_ext'), st.per_split.get('anchors_pos_int'),
@@ -460,9 +489,6 @@ def prepare_pass(model, split='train', timer=None, shard=None, defer_dtw=False):
         t.mark('side_stream_join(S_patches,P_bfs)')
     st.attrs[split + '_neigh_pos_similarities'] = sims if sims else None
     st.attrs[split + '_N_border'] = None
-    st.dtw_inputs = (cc_sets, ci, ce, a_sets, ai, ae, (S, C)) if hp['use_structure'] else None
-    if not defer_dtw:
-        finish_pass(model, st, t)
     return st
 
 
@@ -613,7 +639,11 @@ def _copy_into(dst, src, path, replaced, memo=None):
         if isinstance(dst, torch.Tensor) and dst.shape == src.shape and dst.dtype == src.dtype and dst.device == src.device:
             key = (src.data_ptr(), src.numel(), src.dtype, dst.data_ptr())
             if dst.data_ptr() != src.data_ptr() and key not in memo:
-                dst.copy_(src)
+                pairs = memo.get('__pairs__')
+                if pairs is not None and dst.is_contiguous() and src.is_contiguous():
+                    pairs.append((dst, src))         # copied together at the end (install_pass_static: one launch per dtype)
+                else:
+                    dst.copy_(src)
                 memo[key] = True
             for nm in _TENSOR_ATTRS:
                 v = getattr(src, nm, None)
@@ -648,7 +678,9 @@ def install_pass_static(model, st, timer=None):
     list of places where that was not possible (a shape changed): the caller records again."""
     t = timer or StageTimer(False)
     _verify_bfs(model, st)
-    replaced, memo = [], {}
+    # the ~40 tensors of a pass are copied by ONE multi-tensor launch per dtype (torch._foreach_copy_) instead of one small
+    # launch each: at shard size the copies were 0.67 ms of a 3.5 ms pass, all of it launch overhead
+    replaced, memo = [], {'__pairs__': []}
     for k, v in st.attrs.items():
         setattr(model, k, _copy_into(getattr(model, k, None), v, k, replaced, memo))
     for k, v in st.per_split.items():
@@ -662,6 +694,13 @@ def install_pass_static(model, st, timer=None):
         cols = _copy_into(cur, st.sim_cols[1], '_sim_cols', replaced, memo)
         model.__dict__['_sim_cols_static'] = cols
         model.set_sim_cols(model.anchors_structure, cols)
+    by_type = {}
+    for d_, s_ in memo['__pairs__']:
+        by_type.setdefault((d_.dtype, d_.device), ([], []))
+        by_type[(d_.dtype, d_.device)][0].append(d_.view(-1))
+        by_type[(d_.dtype, d_.device)][1].append(s_.view(-1))
+    for dsts, srcs in by_type.values():
+        torch._foreach_copy_(dsts, srcs)
     model._build_sim_cols()
     model.init_all_embeddings(split=st.split, trainable=model.hparams['trainable_cc'], lazy=True)
     t.mark('install_copies')
@@ -728,6 +767,122 @@ class CapturedTraining:
         self.graph.replay()
         self.model.invalidate_half_table()
         return self.loss, self.acc
+
+
+class GraphedPasses:
+    """BOTH halves of a pass replayed from hipGraphs, two slots: the sampling + similarity half (prepare_pass: ~130 launches
+    on two streams) recorded into one graph that writes the pass's tensors at FIXED addresses, the training half
+    (CapturedTraining's body: ~135 launches) recorded into a second graph that reads exactly those addresses -- nothing is
+    installed or copied between them (CapturedTraining alone copies every pass into its recording's tensors: 0.7 ms of a 3.5 ms
+    pass at shard size).  Two such pairs alternate, so that slot B's preparation replays on a second stream while slot A
+    trains:
+
+        passes = GraphedPasses(model, ClipAdam(..., capturable=True))
+        per pass:  loss, acc = passes.step()
+
+    A step queues two graph launches: at the strong-scaling shard size (6 250 subgraphs, where the pass is bound by the
+    host's ~265 launches) 4.7 ms eager -> 3.5 ms with the training half recorded -> see DESIGN 4 for this form.  Same kernels,
+    same order, same arithmetic as prepare_pass + install_pass + the eager step: losses and parameters are bit-equal
+    (tests/test_gpu_hotpath.py).  What a recording cannot contain -- a host round trip (torch.unique of the P-internal
+    anchors of multi-component subgraphs), collectives -- raises at record time; the caller falls back to PassPipeline.
+    The hinted position-channel searches are verified after every replay (status in pinned memory); one that ran out of
+    levels raises the hint and both slots are recorded again."""
+
+    class _Slot:
+        def __init__(self):
+            self.prep = self.train = self.state = self.loss = self.acc = None
+            self.prep_done, self.train_done = torch.cuda.Event(), torch.cuda.Event()
+            self.checks = []
+            self.prepared = False
+
+    def __init__(self, model, optimizer, split='train', warmup=2):
+        if not getattr(optimizer, 'capturable', False):
+            raise ValueError('GraphedPasses needs ClipAdam(capturable=True): a host step count cannot be replayed')
+        if getattr(model, '_table_sync', None) is not None:
+            raise ValueError('GraphedPasses is the single-rank form (collectives are not recorded)')
+        self.model, self.opt, self.split = model, optimizer, split
+        self.slots = [None, None]
+        self.stream = torch.cuda.Stream()
+        self.k = 0
+        self._warm_left = int(warmup)
+        self.recordings = 0
+
+    def _body(self):
+        m = self.model
+        out = m.training_step(full_split_batch(m, self.split), 0)
+        m.backward(None, out['loss'], None, 0)
+        self.opt.step()
+        self.opt.zero_grad(set_to_none=True)
+        return out['loss'].detach(), out['log']['train_acc'].detach()
+
+    def _record(self, i):
+        """Slot i: record its preparation, run it once (a capture executes nothing), make its tensors the model's, record the
+        training half on them."""
+        slot = self._Slot()
+        pool = self.model.__dict__.setdefault('_bfs_status_pool', [])
+        while len(pool) < 4 * max(1, int(self.model.hparams['n_layers'])):      # pinned buffers the recorded searches will take
+            pool.append(torch.empty(2, dtype=torch.int32).pin_memory())
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            slot.state = prepare_pass(self.model, self.split)
+        slot.prep = g
+        slot.checks = list(slot.state.bfs_checks)
+        g.replay()
+        torch.cuda.synchronize()
+        try:
+            install_pass(self.model, slot.state)             # (verifies the searches of the replay above)
+        except BfsLevelsExhausted:
+            return self._record(i)                           # (the hint is the cap now: this happens at most once)
+        slot.state.bfs_checks = list(slot.checks)
+        g2 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g2):
+            slot.loss, slot.acc = self._body()
+        slot.train = g2
+        slot.prepared = True                                  # the replay above IS this slot's next pass
+        slot.prep_done.record()
+        self.slots[i] = slot
+        self.recordings += 1
+        return slot
+
+    def step(self):
+        """One pass -> (loss, accuracy): the recording's static outputs (clone to keep past the slot's next use)."""
+        if self._warm_left > 0:
+            # eager passes first: per-split caches, BFS depth hints, lazy initialisations and the allocator's growth must not
+            # land in a recording
+            self._warm_left -= 1
+            install_pass(self.model, prepare_pass(self.model, self.split))
+            return self._body()
+        i = self.k & 1
+        main = torch.cuda.current_stream()
+        slot = self.slots[i] or self._record(i)
+        if not slot.prepared:                                  # (only the very first use of slot 1: nothing was queued for it yet)
+            self._queue_prep(slot, main)
+        main.wait_event(slot.prep_done)
+        slot.prep_done.synchronize()                           # prepared a step ago: no wait in steady state
+        slot.state.bfs_checks = list(slot.checks)
+        try:
+            _verify_bfs(self.model, slot.state, keep=True)
+        except BfsLevelsExhausted:
+            torch.cuda.synchronize()
+            self.slots = [None, None]                          # deeper searches from now on: record again
+            return self.step()
+        slot.train.replay()
+        slot.train_done.record(main)
+        slot.prepared = False
+        self.model.invalidate_half_table()
+        other = self.slots[1 - i]
+        if other is not None:                                  # its preparation, beside this pass's training
+            self._queue_prep(other, main)
+        self.k += 1
+        return slot.loss, slot.acc
+
+    def _queue_prep(self, slot, main):
+        with torch.cuda.stream(self.stream):
+            self.stream.wait_event(slot.train_done)            # the slot's tensors are still being trained on until then
+            slot.prep.replay()
+            slot.prep_done.record(self.stream)
+        slot.prepared = True
 
 
 def _device_labels(model, split):

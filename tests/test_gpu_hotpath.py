@@ -323,6 +323,43 @@ def test_training_half_replayed_from_a_hipgraph_trains_like_the_eager_step(name,
         hotpath.CapturedTraining(cap, optim.ClipAdam(cap.parameters(), lr), 'train')      # a host step count cannot be replayed
 
 
+@pytest.mark.parametrize('name,big_bytes', [('density', 1024), ('density', 1 << 30)])
+def test_both_halves_replayed_from_hipgraphs_train_like_the_eager_passes(name, big_bytes, tmp_path):
+    """hotpath.GraphedPasses: the sampling + similarity half AND the training half of a pass recorded into hipGraphs, two
+    alternating slots (slot B's preparation replays on a second stream while slot A trains), nothing installed or copied
+    between the halves -- losses and parameters equal the eager prepare-then-train schedule bit for bit over 9 passes
+    (two eager warm-up passes, one recording per slot, five replayed passes)."""
+    from conftest import load_golden
+    from subgnn_amd import hotpath, optim
+    golden = load_golden(name)
+    (seq, cap) = _models(golden, tmp_path, {'lin_dropout': 0.0, 'lstm_dropout': 0.0})
+    cap.load_state_dict(seq.state_dict())
+    seq.train(); cap.train()
+    lr, clip = 0.01, 0.5
+    o_seq = optim.ClipAdam(seq.parameters(), lr, max_norm=clip, big_bytes=big_bytes)
+    o_cap = optim.ClipAdam(cap.parameters(), lr, max_norm=clip, big_bytes=big_bytes, capturable=True)
+    want = []
+    for k in range(9):
+        hotpath.prepare_sparse(seq, 'train')
+        out = seq.training_step(hotpath.full_split_batch(seq, 'train'), 0)
+        out['loss'].backward()
+        o_seq.step()
+        o_seq.zero_grad(set_to_none=True)
+        want.append(float(out['loss']))
+    passes = hotpath.GraphedPasses(cap, o_cap, 'train', warmup=2)
+    got = []
+    for k in range(9):
+        loss, acc = passes.step()
+        got.append(float(loss))
+    torch.cuda.synchronize()
+    assert passes.recordings == 2 and all(s is not None for s in passes.slots)
+    assert got == want
+    for (n1, a), (_, b) in zip(seq.named_parameters(), cap.named_parameters()):
+        assert torch.equal(a, b), n1
+    with pytest.raises(ValueError):
+        hotpath.GraphedPasses(cap, optim.ClipAdam(cap.parameters(), lr), 'train')
+
+
 @pytest.mark.parametrize('tie', [1, 2])
 def test_dtw_tie_order_hparam_reaches_both_paths(tie, tmp_path):
     """hparams['dtw_tie_order'] selects fastdtw's predecessor rule end to end: the dense prepare_data and the sparse
