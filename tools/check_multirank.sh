@@ -7,10 +7,10 @@ for head in sharded replicated; do
 for mode in weak strong; do
   tag=${mode}_${head}
   timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port $((29500 + RANDOM % 1000)) \
-    bench.py --gpus 2 --steps 2 --warmup 1 --nodes 200000 --subgraphs 4000 --scaling $mode --head $head --pipeline-multi --no-cpu-baseline 2> gpurun_out/r03_multirank_$tag.err | tail -1 > gpurun_out/r03_multirank_$tag.json
+    bench.py --gpus 2 --steps 2 --warmup 1 --nodes 200000 --subgraphs 4000 --scaling $mode --head $head --pipeline-multi --no-cpu-baseline 2> gpurun_out/${TAG:-r04}_multirank_$tag.err | tail -1 > gpurun_out/${TAG:-r04}_multirank_$tag.json
   python - <<PY
 import json
-d = json.load(open('gpurun_out/r03_multirank_$tag.json'))
+d = json.load(open('gpurun_out/${TAG:-r04}_multirank_$tag.json'))
 print('$tag', d['n_gpus'], d['scaling'], d['config']['subgraphs_total'], d['ms_per_step'], d['loss'], d['stages_ms'], d['collectives'])
 PY
 done
