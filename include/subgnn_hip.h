@@ -38,7 +38,7 @@ extern "C" {
 #define SGNN_ERR_LAUNCH         -4   /* hipGetLastError() after a launch */
 #define SGNN_ERR_UNSUPPORTED_D  -5   /* embedding width not supported by the vector path */
 
-#define SGNN_ABI_VERSION 6
+#define SGNN_ABI_VERSION 7
 int sgnn_abi_version(void);
 /* last hip error string for SGNN_ERR_LAUNCH (static storage) */
 const char* sgnn_last_error(void);
@@ -201,6 +201,18 @@ int sgnn_pack_rows_count(const int64_t* ids, const uint8_t* mask, int64_t n_rows
                          void* stream);
 int sgnn_pack_rows_write(const int64_t* ids, const uint8_t* mask, int64_t n_rows, int64_t row_len, const int64_t* ptr,
                          int32_t* nodes, void* stream);
+/* The same packings in ONE launch for up to sgnn_pack_fused_max_rows() rows / sets (the few hundred structure patches of a pass:
+ * anchor_patch_samplers.py:131-138 node views, subgraph_utils.py:126-144 in-border sets, gamma.py:27 PAD stripping): counts,
+ * prefix sum, packed write and the zeroed tail of the arena by one workgroup.  mode 0: keep non-PAD ids; 1: keep where
+ * mask != 0; 2: keep non-PAD ids that no earlier entry of the row repeats (first occurrence).  ptr: n_rows + 1 entries
+ * (all written); nodes: an arena of n_rows * row_len + 1 entries (all written).  sgnn_filter_sets_fused: out_nodes is an arena
+ * of arena_entries entries (>= the flagged total), all written. */
+int64_t sgnn_pack_fused_max_rows(void);
+int64_t sgnn_pack_fused_max_entries(void);   /* n_rows * row_len (the sets' arena for the filter) may not exceed this: entries are staged in LDS */
+int sgnn_pack_rows_fused(const int64_t* ids, const uint8_t* mask, int mode, int64_t n_rows, int64_t row_len, int64_t* ptr,
+                         int32_t* nodes, void* stream);
+int sgnn_filter_sets_fused(const int64_t* set_ptr, const int32_t* set_nodes, const uint8_t* flags, int64_t n_sets,
+                           int64_t arena_entries, int64_t* out_ptr, int32_t* out_nodes, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * a4  Neighbourhood anchor sampling from padded id matrices.

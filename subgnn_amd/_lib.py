@@ -97,6 +97,10 @@ SIGNATURES = {
     'sgnn_filter_sets': (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr]),
     'sgnn_pack_rows_count': (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr]),
     'sgnn_pack_rows_write': (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_ptr]),
+    'sgnn_pack_fused_max_rows': (c_i64, []),
+    'sgnn_pack_fused_max_entries': (c_i64, []),
+    'sgnn_pack_rows_fused': (c_int, [c_ptr, c_ptr, c_int, c_i64, c_i64, c_ptr, c_ptr, c_ptr]),
+    'sgnn_filter_sets_fused': (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_ptr]),
     'sgnn_khop_sample_finish': (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr]),
     'sgnn_cross_entropy_workspace_bytes': (c_i64, [c_i64]),
     'sgnn_cross_entropy_fwd': (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr]),
@@ -151,7 +155,7 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the header and the library disagree
         fn.restype = res
         fn.argtypes = args
-    if lib.sgnn_abi_version() != 6:
+    if lib.sgnn_abi_version() != 7:
         raise SubgnnHipError('ABI version mismatch')
     _lib = lib
     return lib

@@ -632,6 +632,167 @@ extern "C" int sgnn_filter_sets(const int64_t* set_ptr, const int32_t* set_nodes
     return SGNN_OK;
 }
 
+// ---- the same packing in ONE launch for small inputs (round 4) -------------------------------------------------------
+// A few hundred structure patches are packed three times per pass (node views, in-border sets, degree-sequence sets): as
+// count + prefix sum + write that is 5-6 launches each (two fills, a count, one or two scan kernels, a write) for microseconds
+// of work -- at shard size the pass is bound by the host's launches.  One 1024-thread workgroup does all of it: every thread
+// owns up to SGNN_PACK_FUSED_RPT consecutive rows, keeps their keep-masks in registers (rows of up to 64 entries; longer rows
+// are re-evaluated), the block scans the per-thread totals, rows are written in place and the arena's tail is zeroed.
+// mode 0: keep non-PAD entries; 1: keep where mask != 0; 2: keep non-PAD entries that no earlier entry of the row repeats
+// (the node view of a patch: first_occurrence_kernel + pack in one).
+#define SGNN_PACK_FUSED_THREADS 1024
+#define SGNN_PACK_FUSED_RPT 8
+#define SGNN_PACK_FUSED_MAX_ROWS (SGNN_PACK_FUSED_THREADS * SGNN_PACK_FUSED_RPT)
+
+__device__ __forceinline__ int64_t pack_block_excl_scan(int64_t c, int64_t* s_wave, int64_t* total)
+{
+    // exclusive prefix of c over the 1024 threads: wave scans (shuffles) + the 16 wave totals through LDS
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int64_t inc = c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int64_t up = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += up;
+    }
+    if (lane == 63) s_wave[wave] = inc;
+    __syncthreads();
+    int64_t before = 0, all = 0;
+    for (int w = 0; w < SGNN_PACK_FUSED_THREADS / 64; ++w) {
+        const int64_t t = s_wave[w];
+        if (w < wave) before += t;
+        all += t;
+    }
+    *total = all;
+    return before + inc - c;
+}
+
+// LDS staging (round 4, second version: the first one let a thread walk its rows out of global memory -- 1250 dependent
+// compares per 50-entry row for the first-occurrence mode: 100+ us on one workgroup, slower than the launches it replaced):
+// all entries are loaded coalesced into LDS (ids as int32, one keep byte each), the keep flags are computed one THREAD PER
+// ENTRY against the LDS copy (no early exit: independent reads), then the row owners count, the block scans, and the rows
+// are written from LDS.  Entries are limited by the LDS (SGNN_PACK_FUSED_MAX_ENTRIES).
+#define SGNN_PACK_FUSED_MAX_ENTRIES 24576
+
+__global__ __launch_bounds__(SGNN_PACK_FUSED_THREADS) void pack_rows_fused_kernel(
+    const int64_t* __restrict__ ids, const uint8_t* __restrict__ mask, int mode, int64_t n, int64_t L,
+    int64_t* __restrict__ ptr, int32_t* __restrict__ nodes)
+{
+    extern __shared__ int32_t s_pack[];                      // n * L ids, then n * L keep bytes
+    __shared__ int64_t s_wave[SGNN_PACK_FUSED_THREADS / 64];
+    const int total_e = (int)(n * L);
+    int32_t* s_ids = s_pack;
+    uint8_t* s_keep = reinterpret_cast<uint8_t*>(s_pack + total_e);
+    for (int t = threadIdx.x; t < total_e; t += SGNN_PACK_FUSED_THREADS) s_ids[t] = (int32_t)ids[t];
+    __syncthreads();
+    const int Li = (int)L;
+    for (int t = threadIdx.x; t < total_e; t += SGNN_PACK_FUSED_THREADS) {
+        const int32_t v = s_ids[t];
+        bool k;
+        if (mode == 1) k = mask[t] != 0;
+        else {
+            k = v != 0;
+            if (mode == 2 && k) {
+                const int r = t / Li, i = t - r * Li;
+                bool dup = false;
+                for (int q = 0; q < i; ++q) dup |= s_ids[r * Li + q] == v;
+                k = !dup;
+            }
+        }
+        s_keep[t] = k ? 1 : 0;
+    }
+    __syncthreads();
+    const int64_t rpt = (n + SGNN_PACK_FUSED_THREADS - 1) / SGNN_PACK_FUSED_THREADS;      // <= SGNN_PACK_FUSED_RPT (host-checked)
+    const int64_t r0 = threadIdx.x * rpt;
+    int64_t c = 0;
+    for (int64_t k = 0; k < rpt; ++k) {
+        const int64_t r = r0 + k;
+        if (r < n)
+            for (int j = 0; j < Li; ++j) c += s_keep[r * Li + j];
+    }
+    int64_t total;
+    int64_t o = pack_block_excl_scan(c, s_wave, &total);
+    for (int64_t k = 0; k < rpt; ++k) {
+        const int64_t r = r0 + k;
+        if (r < n) {
+            ptr[r] = o;
+            for (int j = 0; j < Li; ++j)
+                if (s_keep[r * Li + j]) nodes[o++] = s_ids[r * Li + j];
+        }
+    }
+    if (threadIdx.x == 0) ptr[n] = total;
+    for (int64_t i = total + threadIdx.x; i <= n * L; i += SGNN_PACK_FUSED_THREADS) nodes[i] = 0;     // the arena's tail (and spare slot)
+}
+
+__global__ __launch_bounds__(SGNN_PACK_FUSED_THREADS) void filter_sets_fused_kernel(
+    const int64_t* __restrict__ set_ptr, const int32_t* __restrict__ set_nodes, const uint8_t* __restrict__ flags, int64_t n,
+    int64_t arena, int64_t* __restrict__ out_ptr, int32_t* __restrict__ out_nodes)
+{
+    extern __shared__ int32_t s_pack[];                      // the sets' entries, then their flag bytes
+    __shared__ int64_t s_wave[SGNN_PACK_FUSED_THREADS / 64];
+    const int64_t base = set_ptr[0];
+    const int total_e = (int)(set_ptr[n] - base);            // <= SGNN_PACK_FUSED_MAX_ENTRIES (host: the arena's size bounds it)
+    int32_t* s_ids = s_pack;
+    uint8_t* s_keep = reinterpret_cast<uint8_t*>(s_pack + total_e);
+    for (int t = threadIdx.x; t < total_e; t += SGNN_PACK_FUSED_THREADS) { s_ids[t] = set_nodes[base + t]; s_keep[t] = flags[base + t] != 0; }
+    __syncthreads();
+    const int64_t rpt = (n + SGNN_PACK_FUSED_THREADS - 1) / SGNN_PACK_FUSED_THREADS;
+    const int64_t r0 = threadIdx.x * rpt;
+    int64_t c = 0;
+    for (int64_t k = 0; k < rpt; ++k) {
+        const int64_t r = r0 + k;
+        if (r < n)
+            for (int64_t i = set_ptr[r] - base; i < set_ptr[r + 1] - base; ++i) c += s_keep[i];
+    }
+    int64_t total;
+    int64_t o = pack_block_excl_scan(c, s_wave, &total);
+    for (int64_t k = 0; k < rpt; ++k) {
+        const int64_t r = r0 + k;
+        if (r < n) {
+            out_ptr[r] = o;
+            for (int64_t i = set_ptr[r] - base; i < set_ptr[r + 1] - base; ++i)
+                if (s_keep[i]) out_nodes[o++] = s_ids[i];
+        }
+    }
+    if (threadIdx.x == 0) out_ptr[n] = total;
+    for (int64_t i = total + threadIdx.x; i < arena; i += SGNN_PACK_FUSED_THREADS) out_nodes[i] = 0;
+}
+
+extern "C" int64_t sgnn_pack_fused_max_rows(void) { return SGNN_PACK_FUSED_MAX_ROWS; }
+extern "C" int64_t sgnn_pack_fused_max_entries(void) { return SGNN_PACK_FUSED_MAX_ENTRIES; }
+
+extern "C" int sgnn_pack_rows_fused(const int64_t* ids, const uint8_t* mask, int mode, int64_t n_rows, int64_t row_len,
+                                    int64_t* ptr, int32_t* nodes, void* stream)
+{
+    if (!ids || !ptr || !nodes || n_rows < 1 || row_len < 1 || mode < 0 || mode > 2 || (mode == 1 && !mask)) return SGNN_ERR_BAD_ARG;
+    if (n_rows > SGNN_PACK_FUSED_MAX_ROWS || n_rows * row_len > SGNN_PACK_FUSED_MAX_ENTRIES) return SGNN_ERR_SET_TOO_LARGE;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)pack_rows_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SGNN_PACK_FUSED_MAX_ENTRIES * 5 + 16);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(pack_rows_fused_kernel, dim3(1), dim3(SGNN_PACK_FUSED_THREADS), (size_t)(n_rows * row_len * 5 + 16), (hipStream_t)stream,
+                       ids, mask, mode, n_rows, row_len, ptr, nodes);
+    SGNN_CHECK_LAUNCH();
+    return SGNN_OK;
+}
+
+extern "C" int sgnn_filter_sets_fused(const int64_t* set_ptr, const int32_t* set_nodes, const uint8_t* flags, int64_t n_sets,
+                                      int64_t arena_entries, int64_t* out_ptr, int32_t* out_nodes, void* stream)
+{
+    if (!set_ptr || !set_nodes || !flags || !out_ptr || !out_nodes || n_sets < 1 || arena_entries < 1) return SGNN_ERR_BAD_ARG;
+    // (the sets' entries are staged in LDS: the caller's arena -- at least the sets' total -- bounds them)
+    if (n_sets > SGNN_PACK_FUSED_MAX_ROWS || arena_entries > SGNN_PACK_FUSED_MAX_ENTRIES) return SGNN_ERR_SET_TOO_LARGE;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)filter_sets_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SGNN_PACK_FUSED_MAX_ENTRIES * 5 + 16);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(filter_sets_fused_kernel, dim3(1), dim3(SGNN_PACK_FUSED_THREADS), (size_t)(arena_entries * 5 + 16), (hipStream_t)stream,
+                       set_ptr, set_nodes, flags, n_sets, arena_entries, out_ptr, out_nodes);
+    SGNN_CHECK_LAUNCH();
+    return SGNN_OK;
+}
+
 extern "C" int sgnn_pack_rows_count(const int64_t* ids, const uint8_t* mask, int64_t n_rows, int64_t row_len, int64_t* counts,
                                     void* stream)
 {

@@ -126,14 +126,59 @@ __device__ __forceinline__ uint64_t msbfs_group_or(uint64_t x)
     return ((uint64_t)msbfs_row_or32((uint32_t)(x >> 32)) << 32) | msbfs_row_or32((uint32_t)x);
 }
 
+// Per level, for every set: which sources reached one of its members for the first time?  The new
+// frontier words of the members are OR-ed, masked with what the set has not seen yet, and the level
+// is written for those sources: out[set, source] = min over members of the hop distance, without a
+// (sources x nodes) hop table.  One thread per (set, word).  Round 4: not a launch of its own any more -- level L's
+// reduction is the prologue of level L + 1's expand launch (both only READ the frontier words level L's commit wrote; the
+// reduction writes set_seen / out, which no expand touches) and the last level's runs inside the finalize launch, thread for
+// thread in front of the finalisation of the same (set, word): 3 launches per level -> 2.
+__device__ __forceinline__ void msbfs_set_reduce_item(
+    const uint64_t* __restrict__ frontier, int64_t n_words, int64_t n_sources,
+    const int64_t* __restrict__ set_ptr, const int32_t* __restrict__ set_nodes,
+    uint64_t* __restrict__ set_seen, float* __restrict__ out, int level, int64_t rs, int64_t t)
+{
+    const int64_t r = t / n_words, w = t % n_words;
+    uint64_t acc = 0;
+    const int64_t left_ = n_sources - w * 64;
+    const uint64_t full_ = left_ >= 64 ? ~0ull : ((1ull << left_) - 1);
+    const uint64_t have_ = set_seen[t];
+    if ((have_ & full_) == full_) return;                    // every source has reached the set: nothing left to record
+    for (int64_t i = set_ptr[r]; i < set_ptr[r + 1]; ++i) acc |= frontier[(int64_t)set_nodes[i] * rs + w];
+    const uint64_t fresh = acc & ~have_;
+    if (fresh) {
+        set_seen[t] = have_ | fresh;
+        uint64_t bits = fresh;
+        while (bits) {
+            const int b = __ffsll((unsigned long long)bits) - 1;
+            bits &= bits - 1;
+            const int64_t s = w * 64 + b;
+            if (s < n_sources) out[r * n_sources + s] = (float)level;
+        }
+    }
+}
+
+struct MsbfsSets {                 // the fused set reduction's operands (n_sets = 0: none)
+    const int64_t* set_ptr;
+    const int32_t* set_nodes;
+    int64_t n_sets;
+    uint64_t* set_seen;
+    float* out;
+};
+
 __global__ __launch_bounds__(256) void msbfs_expand_kernel(
     const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col, int64_t n_ids, int64_t n_words,
     int64_t n_sources, const uint64_t* __restrict__ seen, const uint64_t* __restrict__ frontier,
     uint64_t* __restrict__ next, const int32_t* __restrict__ flags, const unsigned long long* __restrict__ fvol,
     unsigned long long pull_above, int level, const uint32_t* __restrict__ fnode, unsigned long long sparse_below,
-    const uint32_t* __restrict__ fdone, int64_t rs)
+    const uint32_t* __restrict__ fdone, int64_t rs, MsbfsSets sets)
 {
-    if (flags[level - 1] == 0) return;                       // previous level found nothing
+    if (level > 1 && flags[level - 1] == 0) return;          // previous level found nothing (nothing to reduce either)
+    if (sets.n_sets > 0) {                                   // the previous level's set reduction (level 0: the seeds)
+        const int64_t total = sets.n_sets * n_words;
+        for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x)
+            msbfs_set_reduce_item(frontier, n_words, n_sources, sets.set_ptr, sets.set_nodes, sets.set_seen, sets.out, level - 1, rs, t);
+    }
     const int sub = threadIdx.x & 15;
     // node ids are dealt out to the workgroups round-robin (group g of workgroup b takes b + G*(g + 16 i)):
     // consecutive ids -- the oldest, highest-degree nodes of a preferential-attachment graph sit next to
@@ -432,48 +477,19 @@ extern "C" int64_t sgnn_bfs_hops_workspace_bytes(int64_t max_id, int64_t n_sourc
            8 + 2 * ((max_id + 32) / 32) * 4;                      // + two frontier-node bitmaps
 }
 
-// Per level, for every set: which sources reached one of its members for the first time?  The new
-// frontier words of the members are OR-ed, masked with what the set has not seen yet, and the level
-// is written for those sources: out[set, source] = min over members of the hop distance, without a
-// (sources x nodes) hop table.  One thread per (set, word).
-__global__ __launch_bounds__(256) void msbfs_set_reduce_kernel(
-    const uint64_t* __restrict__ frontier, int64_t n_words, int64_t n_sources,
-    const int64_t* __restrict__ set_ptr, const int32_t* __restrict__ set_nodes, int64_t n_sets,
-    uint64_t* __restrict__ set_seen, float* __restrict__ out, const int32_t* __restrict__ flags, int level, int64_t rs)
-{
-    if (level > 0 && flags[level] == 0) return;              // this level found nothing
-    const int64_t total = n_sets * n_words;
-    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t r = t / n_words, w = t % n_words;
-        uint64_t acc = 0;
-        const int64_t left_ = n_sources - w * 64;
-        const uint64_t full_ = left_ >= 64 ? ~0ull : ((1ull << left_) - 1);
-        const uint64_t have_ = set_seen[t];
-        if ((have_ & full_) == full_) continue;              // every source has reached the set: nothing left to record
-        for (int64_t i = set_ptr[r]; i < set_ptr[r + 1]; ++i) acc |= frontier[(int64_t)set_nodes[i] * rs + w];
-        const uint64_t fresh = acc & ~have_;
-        if (fresh) {
-            set_seen[t] = have_ | fresh;
-            uint64_t bits = fresh;
-            while (bits) {
-                const int b = __ffsll((unsigned long long)bits) - 1;
-                bits &= bits - 1;
-                const int64_t s = w * 64 + b;
-                if (s < n_sources) out[r * n_sources + s] = (float)level;
-            }
-        }
-    }
-}
-
 // The reference's matrix holds 0 for unreachable pairs, and its row-min runs over those zeros: a
 // source that never reaches SOME member of a set gives 0 for the whole set (SubGNN.py:772).  After
 // the last level: AND the members' seen words, zero the sources missing from it.
 __global__ __launch_bounds__(256) void msbfs_set_finalize_kernel(
     const uint64_t* __restrict__ seen, int64_t n_words, int64_t n_sources,
-    const int64_t* __restrict__ set_ptr, const int32_t* __restrict__ set_nodes, int64_t n_sets, float* __restrict__ out, int64_t rs)
+    const int64_t* __restrict__ set_ptr, const int32_t* __restrict__ set_nodes, int64_t n_sets, float* __restrict__ out, int64_t rs,
+    const uint64_t* __restrict__ frontier, uint64_t* __restrict__ set_seen, const int32_t* __restrict__ flags, int last_level)
 {
     const int64_t total = n_sets * n_words;
+    const bool reduce_last = flags[last_level] != 0;         // the last enqueued level found something: its reduction is still due
     for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        if (reduce_last)
+            msbfs_set_reduce_item(frontier, n_words, n_sources, set_ptr, set_nodes, set_seen, out, last_level, rs, t);
         const int64_t r = t / n_words, w = t % n_words;
         uint64_t all = ~0ull;
         for (int64_t i = set_ptr[r]; i < set_ptr[r + 1]; ++i) all &= seen[(int64_t)set_nodes[i] * rs + w];
@@ -528,30 +544,22 @@ static int msbfs_run(const int64_t* rowptr, const int32_t* col, int64_t nnz, int
                        n_words, n_ids, seen, frontier, dist, ss, sv, fbits, rs);
     SGNN_CHECK_LAUNCH();
     const int g_sets = set_out ? sgnn_grid_for(n_sets * n_words, 256) : 0;
-    if (set_out) {
-        hipLaunchKernelGGL(msbfs_set_reduce_kernel, dim3(g_sets), dim3(256), 0, st, frontier, n_words, n_sources, set_ptr,
-                           set_nodes, n_sets, set_seen, set_out, flags, 0, rs);
-        SGNN_CHECK_LAUNCH();
-    }
+    MsbfsSets sets;
+    sets.set_ptr = set_ptr; sets.set_nodes = set_nodes; sets.n_sets = set_out ? n_sets : 0; sets.set_seen = set_seen; sets.out = set_out;
     const int g_expand = sgnn_grid_for(n_ids * 16, 256);
     const int g_commit = sgnn_grid_for(n_ids, 256, 256 * 4);
     for (int level = 1; level <= max_hops; ++level) {
         hipLaunchKernelGGL(msbfs_expand_kernel, dim3(g_expand), dim3(256), 0, st, rowptr, col, n_ids, n_words, n_sources,
                            seen, frontier, next, flags, fvol, pull_above, level, fbits,
-                           (unsigned long long)((nnz * n_words) / 4), fbits + fwords, rs);
+                           (unsigned long long)((nnz * n_words) / 4), fbits + fwords, rs, sets);
         SGNN_CHECK_LAUNCH();
         hipLaunchKernelGGL(msbfs_commit_kernel, dim3(g_commit), dim3(256), 0, st, rowptr, n_ids, n_words, n_sources, seen,
                            frontier, next, dist, flags, fvol, level, ss, sv, fbits, fbits + fwords, rs);
         SGNN_CHECK_LAUNCH();
-        if (set_out) {
-            hipLaunchKernelGGL(msbfs_set_reduce_kernel, dim3(g_sets), dim3(256), 0, st, frontier, n_words, n_sources,
-                               set_ptr, set_nodes, n_sets, set_seen, set_out, flags, level, rs);
-            SGNN_CHECK_LAUNCH();
-        }
     }
     if (set_out) {
         hipLaunchKernelGGL(msbfs_set_finalize_kernel, dim3(g_sets), dim3(256), 0, st, seen, n_words, n_sources, set_ptr,
-                           set_nodes, n_sets, set_out, rs);
+                           set_nodes, n_sets, set_out, rs, frontier, set_seen, flags, max_hops);
         SGNN_CHECK_LAUNCH();
     }
     if (status) {

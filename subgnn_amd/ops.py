@@ -74,7 +74,12 @@ class Ragged:
         return Ragged.from_mask(ids, None)
 
     @staticmethod
-    def from_mask(ids, mask):
+    def from_first_occurrence(ids):
+        """The node view of every row: its non-PAD ids without repeats, first occurrences kept in order (aps:131-138)."""
+        return Ragged.from_mask(ids, None, first_occurrence=True)
+
+    @staticmethod
+    def from_mask(ids, mask, first_occurrence=False):
         """The masked entries of every row of a padded (rows, L) matrix, packed, order kept -- without
         a host round trip: the packed position of an entry is its row's offset plus its rank among the
         row's kept entries, dropped entries go to one spare slot behind the data (the node array is an
@@ -89,6 +94,16 @@ class Ragged:
             # counts per row, prefix sum, packed write (sgnn_pack_rows_count / _write): mask None = strip PAD
             lib = _lib.load()
             ids = ids.contiguous()
+            if n <= PACK_FUSED_MAX_ROWS and n * L <= PACK_FUSED_MAX_ENTRIES and (mask is None or mask.dtype == torch.uint8 or first_occurrence):
+                # a few hundred rows (the structure patches): one launch does count, scan, write and the arena's zero tail
+                m8 = None if (mask is None or first_occurrence) else mask.contiguous()
+                ptr = torch.empty(n + 1, dtype=torch.int64, device=dev)
+                nodes = torch.empty(n * L + 1, dtype=torch.int32, device=dev)
+                check(lib.sgnn_pack_rows_fused(_ptr(ids), _ptr(m8), 2 if first_occurrence else (0 if m8 is None else 1), n, L,
+                                               _ptr(ptr), _ptr(nodes), _stream()), 'sgnn_pack_rows_fused')
+                return Ragged(ptr, nodes, max_len=L)
+            if first_occurrence:
+                mask = first_occurrence_mask(ids)
             m8 = None if mask is None else mask.to(torch.uint8).contiguous()
             counts = torch.empty(n, dtype=torch.int64, device=dev)
             check(lib.sgnn_pack_rows_count(_ptr(ids), _ptr(m8), n, L, _ptr(counts), _stream()), 'sgnn_pack_rows_count')
@@ -96,6 +111,10 @@ class Ragged:
             nodes = torch.zeros(n * L + 1, dtype=torch.int32, device=dev)      # an arena: ptr says what is live
             check(lib.sgnn_pack_rows_write(_ptr(ids), _ptr(m8), n, L, _ptr(ptr), _ptr(nodes), _stream()), 'sgnn_pack_rows_write')
             return Ragged(ptr, nodes, max_len=L)
+        if first_occurrence:
+            Lq = ids.shape[1]
+            earlier = torch.ones(Lq, Lq, dtype=torch.bool, device=dev).tril(-1)
+            mask = ~((ids.unsqueeze(2) == ids.unsqueeze(1)) & earlier.unsqueeze(0)).any(dim=2) & (ids != PAD)
         if mask is None:
             mask = ids != PAD
         # rank of an entry among its row's kept entries.  torch's scan along the innermost dimension of
@@ -236,6 +255,13 @@ def filter_sets(sets, flags):
     ptr = torch.zeros(sets.n + 1, dtype=torch.int64, device=dev)
     if sets.n == 0:
         return Ragged(ptr, torch.zeros(1, dtype=torch.int32, device=dev), max_len=0)
+    if sets.n <= PACK_FUSED_MAX_ROWS and sets.nodes.numel() <= PACK_FUSED_MAX_ENTRIES:
+        arena = max(sets.nodes.numel(), 1)
+        ptr = torch.empty(sets.n + 1, dtype=torch.int64, device=dev)
+        nodes = torch.empty(arena, dtype=torch.int32, device=dev)
+        check(lib.sgnn_filter_sets_fused(_ptr(sets.ptr), _ptr(sets.nodes), _ptr(flags), sets.n, arena, _ptr(ptr), _ptr(nodes), _stream()),
+              'sgnn_filter_sets_fused')
+        return Ragged(ptr, nodes, max_len=sets._max_len)
     check(lib.sgnn_filter_sets(_ptr(sets.ptr), _ptr(sets.nodes), _ptr(flags), sets.n, _ptr(counts), None, None, _stream()),
           'sgnn_filter_sets')
     torch.cumsum(counts, 0, out=ptr[1:])
@@ -294,6 +320,8 @@ def degree_sequence(g, sets, sort=True, use_degree_dict=True, want_external=True
     return out_i, out_e
 
 
+PACK_FUSED_MAX_ROWS = 8192    # csrc/graph_sets.hip SGNN_PACK_FUSED_MAX_ROWS / _MAX_ENTRIES: packings this small take one launch
+PACK_FUSED_MAX_ENTRIES = 24576
 CC_LDS_MAX = 2048          # csrc/graph_sets.hip CC_MAX / PB_MAX: sets up to here keep their tables in LDS
 
 

@@ -996,3 +996,49 @@ def test_first_occurrence_mask_and_filter_sets():
     flat = torch.tensor([f for fl in flags for f in fl] + [0] * (sets.nodes.numel() - sum(map(len, lists))), dtype=torch.uint8, device=DEV)
     got = ops.filter_sets(sets, flat)
     assert got.to_lists() == [[v for v, f in zip(l, fl) if f] for l, fl in zip(lists, flags)]
+
+
+
+@pytest.mark.parametrize('n,L', [(1, 1), (7, 5), (210, 50), (350, 70), (8192, 3), (1228, 20), (1500, 70), (9000, 20)])
+def test_fused_packings_equal_the_reference_packing(n, L):
+    """sgnn_pack_rows_fused / sgnn_filter_sets_fused (one launch for up to 8192 rows) against numpy: PAD stripping (gamma.py:27),
+    masks, first occurrences (a patch's node view, aps:131-138: rows longer than the 64 mask bits a thread keeps included),
+    flagged entries of ragged sets (su:126-144); ptr, the packed entries and the ZEROED tail of the arena.  Inputs beyond 8192 rows
+    or 24 576 entries (the LDS staging) take the count / scan / write launches: same results."""
+    from subgnn_amd import ops
+    rng = np.random.default_rng(n * 131 + L)
+    ids = rng.integers(0, 12, size=(n, L)).astype(np.int64)          # many repeats and PADs
+    ids[rng.random((n, L)) < 0.2] = 0
+    mask = (rng.random((n, L)) < 0.5).astype(np.uint8)
+    t = torch.from_numpy(ids).to(DEV)
+
+    def check(r, keep):
+        ptr, nodes = r.ptr.cpu().numpy(), r.nodes.cpu().numpy()
+        want = [ids[i][keep[i]] for i in range(n)]
+        lens = np.array([len(w) for w in want])
+        assert np.array_equal(ptr, np.concatenate([[0], np.cumsum(lens)]))
+        flat = np.concatenate(want) if lens.sum() else np.zeros(0, dtype=np.int64)
+        assert np.array_equal(nodes[:len(flat)], flat)
+        assert nodes.shape[0] == n * L + 1 and not nodes[len(flat):].any()
+    check(ops.Ragged.from_padded(t), ids != 0)
+    check(ops.Ragged.from_mask(t, torch.from_numpy(mask).to(DEV)), mask != 0)
+    first = np.zeros((n, L), dtype=bool)
+    for i in range(n):
+        seen = set()
+        for j in range(L):
+            v = ids[i, j]
+            if v != 0 and v not in seen:
+                first[i, j] = True
+                seen.add(v)
+    check(ops.Ragged.from_first_occurrence(t), first)
+    # ragged sets + flags
+    sets = ops.Ragged.from_padded(t)
+    flags = (rng.random(int(sets.nodes.numel())) < 0.4).astype(np.uint8)
+    got = ops.filter_sets(sets, torch.from_numpy(flags).to(DEV))
+    p, v = sets.ptr.cpu().numpy(), sets.nodes.cpu().numpy()
+    want = [v[p[i]:p[i + 1]][flags[p[i]:p[i + 1]] != 0] for i in range(n)]
+    lens = np.array([len(w) for w in want])
+    assert np.array_equal(got.ptr.cpu().numpy(), np.concatenate([[0], np.cumsum(lens)]))
+    gv = got.nodes.cpu().numpy()
+    assert np.array_equal(gv[:lens.sum()], np.concatenate(want) if lens.sum() else np.zeros(0, dtype=np.int32))
+    assert not gv[lens.sum():].any()
