@@ -483,8 +483,15 @@ extern "C" int64_t sgnn_bfs_hops_workspace_bytes(int64_t max_id, int64_t n_sourc
 __global__ __launch_bounds__(256) void msbfs_set_finalize_kernel(
     const uint64_t* __restrict__ seen, int64_t n_words, int64_t n_sources,
     const int64_t* __restrict__ set_ptr, const int32_t* __restrict__ set_nodes, int64_t n_sets, float* __restrict__ out, int64_t rs,
-    const uint64_t* __restrict__ frontier, uint64_t* __restrict__ set_seen, const int32_t* __restrict__ flags, int last_level)
+    const uint64_t* __restrict__ frontier, uint64_t* __restrict__ set_seen, const int32_t* __restrict__ flags, int last_level,
+    int32_t* __restrict__ status)
 {
+    if (status && blockIdx.x == 0 && threadIdx.x == 0) {     // (msbfs_status_kernel's work: one launch less per search)
+        int last = 0;
+        for (int l = 1; l <= last_level; ++l) if (flags[l]) last = l;
+        status[0] = last;
+        status[1] = flags[last_level] != 0;
+    }
     const int64_t total = n_sets * n_words;
     const bool reduce_last = flags[last_level] != 0;         // the last enqueued level found something: its reduction is still due
     for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
@@ -559,10 +566,10 @@ static int msbfs_run(const int64_t* rowptr, const int32_t* col, int64_t nnz, int
     }
     if (set_out) {
         hipLaunchKernelGGL(msbfs_set_finalize_kernel, dim3(g_sets), dim3(256), 0, st, seen, n_words, n_sources, set_ptr,
-                           set_nodes, n_sets, set_out, rs, frontier, set_seen, flags, max_hops);
+                           set_nodes, n_sets, set_out, rs, frontier, set_seen, flags, max_hops, status);
         SGNN_CHECK_LAUNCH();
     }
-    if (status) {
+    if (status && !set_out) {
         hipLaunchKernelGGL(msbfs_status_kernel, dim3(1), dim3(64), 0, st, flags, max_hops, status);
         SGNN_CHECK_LAUNCH();
     }

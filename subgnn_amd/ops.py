@@ -735,9 +735,20 @@ def dtw_similarity(x_ptr, x_val, max_x, y_ptr, y_val, max_y, tie_order=0, order_
             # the grouping (which row stands for which, where the kept entries go) is reused; the VALUES the kernel reads
             # are this call's: scattered again from x_val
             uptr, rep, dst, live = kept
-            rows = Ragged(x_ptr, x_val, max_len=max_x).to_padded(width=max_x, fill=-1, dtype=torch.int32)
+            # where every ENTRY of x_val goes (kept rows: their slot; entries of rows that repeat an earlier row: the spare
+            # slot): the padded form's map restricted to the real entries, made once -- two launches per pass (zeros, scatter)
+            # instead of the eight of padding the rows again
+            dst_e = x_prep.get('dedupe_entry_dst')
+            if dst_e is None or dst_e.numel() != x_val.numel():
+                nrow = x_ptr.numel() - 1
+                j = torch.arange(max_x, device=x_ptr.device).view(1, -1)
+                real = j < (x_ptr[1:] - x_ptr[:-1]).view(-1, 1)
+                dst_e = dst.view(nrow, max_x)[real].contiguous()                 # row-major = the order of x_val
+                if dst_e.numel() < x_val.numel():                               # (x_val may carry an arena tail behind the last row)
+                    dst_e = torch.cat([dst_e, dst_e.new_full((x_val.numel() - dst_e.numel(),), x_val.numel())])
+                x_prep['dedupe_entry_dst'] = dst_e
             uval = torch.zeros(x_val.numel() + 1, dtype=torch.int32, device=x_ptr.device)
-            uval.scatter_(0, dst, rows.reshape(-1))
+            uval.scatter_(0, dst_e, x_val)
             out_u = dtw_similarity(uptr, uval, max_x, y_ptr, y_val, max_y, tie_order, order_rows, dedupe=False, order=order,
                                    _live=live, x_prep=x_prep.setdefault('grouped', {}), kernel=kernel)
             return out_u.index_select(0, rep)
