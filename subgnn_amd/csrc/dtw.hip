@@ -1,6 +1,7 @@
 // Structure similarity 1/(1+fastdtw) (a11): pyramids, the general and the register-resident DP kernels.
 #include "common.h"
 #include <type_traits>
+#include <cstdlib>
 
 // ---------------------------------------------------------------------------------------------
 // a11  1 / (1 + fastdtw(x, y, radius=1, dist=calc_dist))  (reference SubGNN/gamma.py:51-59)
@@ -921,7 +922,10 @@ static int dtw_run(const int64_t* x_ptr, const int32_t* x_val, int64_t n_x, int6
         // predecessor words of the coarse levels in LDS when (max_y_len / 2) words per lane fit
         const int64_t words = max_y_len >> 1;
         const bool wlds = dtw_words_in_lds(max_y_len);
-        const size_t dyn = wlds ? (size_t)((words > 0 ? words : 1) * DTW_THREADS * 4) : 0;
+        // SGNN_DTW_LDS_PAD (bytes, measurement only: tools/dtw_overlap_probe.py): extra dynamic LDS per workgroup, which lowers the
+        // number of resident workgroups per CU (>= 20 KB: two instead of three) and leaves vector registers to other streams' kernels
+        static const long lds_pad = getenv("SGNN_DTW_LDS_PAD") ? atol(getenv("SGNN_DTW_LDS_PAD")) : 0;
+        const size_t dyn = (wlds ? (size_t)((words > 0 ? words : 1) * DTW_THREADS * 4) : 0) + (size_t)(lds_pad > 0 ? lds_pad : 0);
 #define DTW_LAUNCH2(RMAX, TIE, MINB, WL) \
         hipLaunchKernelGGL((dtw_similarity_reg_kernel<RMAX, TIE, MINB, WL>), dim3(DTW_REG_BLOCKS), dim3(DTW_THREADS), dyn, st, \
                            xpyr, xlen, n_x, ypyr, ylen, n_y, out, wq, L, x_order, x_live)

@@ -337,57 +337,71 @@ def prepare_pass(model, split='train', timer=None, shard=None, defer_dtw=False):
             patch_ev = torch.cuda.Event()
             patch_ev.record(side)                       # the patches exist: their walks run on the main stream (below) and
             #                                             wait for the patches only, not for the position BFS queued next
-        if hp['use_position']:
-            anchors_pos_ext = getattr(model, 'anchors_pos_ext', None)
-            if anchors_pos_ext is None or split != 'test':
-                anchors_pos_ext = st.attrs['anchors_pos_ext'] = aps.init_anchors_pos_ext(hp, g, dev)
-                if det:
-                    for v in anchors_pos_ext.values():
-                        ops.presort_ids(v, g.max_id)
-            pint = {l: ops.choice_ragged(subs, hp['n_anchor_patches_pos_in'], seed,
-                                         tape.stream_id(tape.STREAM_P_INT, split, l), item_base=base) for l in range(L)}
-            st.per_split['anchors_pos_int'] = pint
-            for l in range(L):
-                if shard is not None and shard.deal_shared:
-                    cap = hp.get('max_bfs_hops', 32)
-                    w, status = _dealt_position_sims(g, anchors_pos_ext[l], cc_sets, cc_ids, shard, cap)
-                    w = w.view(S, C, -1)
-                    # full cap, all ranks' worst status: verified before the pass is consumed like the hinted searches
-                    # (nothing to repeat: running out of levels here means max_bfs_hops is too small)
-                    model.__dict__.setdefault('_bfs_level_hint', {}).setdefault(('P_out_dealt', split, l), 0)
-                    _bfs_note(model, st, ('P_out_dealt', split, l), status, cap, cap, None)
-                else:
-                    cap = hp.get('max_bfs_hops', 32)
-                    nlev = _bfs_levels(model, ('P_out', split, l), cap)
-                    src = anchors_pos_ext[l].to(torch.int32).contiguous()
-                    w, status = ops.bfs_min_hops_to_sets(g, src, cc_sets, max_hops=nlev, want_status=True)
-
-                    def redo(levels, src=src, l=l, sims=sims):
-                        # the hinted search ran out of levels: the same search with the full cap, similarities replaced.
-                        # It runs on the INSTALLING stream: what it reads was allocated on the preparation stream
-                        _hand_over(torch.cuda.current_stream(), src, cc_sets)
-                        w2, st2 = ops.bfs_min_hops_to_sets(g, src, cc_sets, max_hops=levels, want_status=True)
-                        sims[('P', 'out', l)] = w2.view(S, C, -1).contiguous()
-                        return st2.tolist()
-                    _bfs_note(model, st, ('P_out', split, l), status, cap, nlev, redo)
-                    w = w.view(S, C, -1)
-                # (rows of padded components need no masking: an empty set receives no level in msbfs_set_reduce and
-                # keeps the 0 the output was cleared to -- test_sparse_prepare_equals_dense_prepare checks the raw rows)
-                sims[('P', 'out', l)] = w.contiguous()
-                if C == 1:
-                    sims[('P', 'in', l)] = ops.ZeroSims((S, C, hp['n_anchor_patches_pos_in']), dev)
-                else:
-                    uniq, inv = torch.unique(pint[l], return_inverse=True)
-                    if uniq.numel() * (g.max_id + 1) <= MAX_PINT_BYTES:
-                        d = ops.bfs_hops(g, uniq.to(torch.int32).contiguous(), max_hops=hp.get('max_bfs_hops', 32),
-                                         node_major=True)
-                        full = ops.min_hops_to_sets(d, cc_sets, node_major=True).view(S, C, -1)     # (S, C, U)
-                        w = torch.gather(full, 2, inv.view(S, 1, -1).expand(S, C, -1))
+        def position_block():
+            """Position channel: the shared P-border anchors, the per-subgraph P-internal draws and the multi-source BFS."""
+            if hp['use_position']:
+                anchors_pos_ext = getattr(model, 'anchors_pos_ext', None)
+                if anchors_pos_ext is None or split != 'test':
+                    anchors_pos_ext = st.attrs['anchors_pos_ext'] = aps.init_anchors_pos_ext(hp, g, dev)
+                    if det:
+                        for v in anchors_pos_ext.values():
+                            ops.presort_ids(v, g.max_id)
+                pint = {l: ops.choice_ragged(subs, hp['n_anchor_patches_pos_in'], seed,
+                                             tape.stream_id(tape.STREAM_P_INT, split, l), item_base=base) for l in range(L)}
+                st.per_split['anchors_pos_int'] = pint
+                for l in range(L):
+                    if shard is not None and shard.deal_shared:
+                        cap = hp.get('max_bfs_hops', 32)
+                        w, status = _dealt_position_sims(g, anchors_pos_ext[l], cc_sets, cc_ids, shard, cap)
+                        w = w.view(S, C, -1)
+                        # full cap, all ranks' worst status: verified before the pass is consumed like the hinted searches
+                        # (nothing to repeat: running out of levels here means max_bfs_hops is too small)
+                        model.__dict__.setdefault('_bfs_level_hint', {}).setdefault(('P_out_dealt', split, l), 0)
+                        _bfs_note(model, st, ('P_out_dealt', split, l), status, cap, cap, None)
                     else:
-                        w = _pint_sims_streamed(g, uniq, inv, cc_sets, S, C, hp.get('max_bfs_hops', 32))
-                    sims[('P', 'in', l)] = (w * real.unsqueeze(-1)).contiguous()
-            if side is main:
-                t.mark('P_bfs_sims')
+                        cap = hp.get('max_bfs_hops', 32)
+                        nlev = _bfs_levels(model, ('P_out', split, l), cap)
+                        src = anchors_pos_ext[l].to(torch.int32).contiguous()
+                        w, status = ops.bfs_min_hops_to_sets(g, src, cc_sets, max_hops=nlev, want_status=True)
+
+                        def redo(levels, src=src, l=l, sims=sims):
+                            # the hinted search ran out of levels: the same search with the full cap, similarities replaced.
+                            # It runs on the INSTALLING stream: what it reads was allocated on the preparation stream
+                            _hand_over(torch.cuda.current_stream(), src, cc_sets)
+                            w2, st2 = ops.bfs_min_hops_to_sets(g, src, cc_sets, max_hops=levels, want_status=True)
+                            sims[('P', 'out', l)] = w2.view(S, C, -1).contiguous()
+                            return st2.tolist()
+                        _bfs_note(model, st, ('P_out', split, l), status, cap, nlev, redo)
+                        w = w.view(S, C, -1)
+                    # (rows of padded components need no masking: an empty set receives no level in msbfs_set_reduce and
+                    # keeps the 0 the output was cleared to -- test_sparse_prepare_equals_dense_prepare checks the raw rows)
+                    sims[('P', 'out', l)] = w.contiguous()
+                    if C == 1:
+                        sims[('P', 'in', l)] = ops.ZeroSims((S, C, hp['n_anchor_patches_pos_in']), dev)
+                    else:
+                        uniq, inv = torch.unique(pint[l], return_inverse=True)
+                        if uniq.numel() * (g.max_id + 1) <= MAX_PINT_BYTES:
+                            d = ops.bfs_hops(g, uniq.to(torch.int32).contiguous(), max_hops=hp.get('max_bfs_hops', 32),
+                                             node_major=True)
+                            full = ops.min_hops_to_sets(d, cc_sets, node_major=True).view(S, C, -1)     # (S, C, U)
+                            w = torch.gather(full, 2, inv.view(S, 1, -1).expand(S, C, -1))
+                        else:
+                            w = _pint_sims_streamed(g, uniq, inv, cc_sets, S, C, hp.get('max_bfs_hops', 32))
+                        sims[('P', 'in', l)] = (w * real.unsqueeze(-1)).contiguous()
+                if side is main:
+                    t.mark('P_bfs_sims')
+        # Where the position search runs.  It is memory-bound (pull levels gather a 32-byte row per edge) and the DTW launches are
+        # bound by fp64 vector issue: started TOGETHER the two share the chip (tools/dtw_overlap_probe.py: DTW 4.6 ms + search
+        # 1.5 ms take 5.0 ms side by side, 69 % of the search hidden; degree sequences, walks and the table's Adam hide
+        # completely, the one-hop border kernel 38 %).  hparams['bfs_beside_dtw'] queues the search behind an event the main
+        # stream records right before the DTW launches.  Measured in the pipelined schedule (round 4): the border stage drops
+        # from 2.66 to 1.90 ms and the DTW stage grows from 5.2 to 6.2 -- the step stays at 9.4-9.5 ms, because the training
+        # half of the previous pass already fills what the DTW launch leaves free: the device is saturated by total work, the
+        # schedule only moves it around.  Default False (the search beside the border kernel, as before).
+        late_bfs = bool(hp.get('bfs_beside_dtw', False)) and side is not main and hp['use_structure'] and hp['use_position'] \
+            and not defer_dtw and not (shard is not None and shard.deal_shared)
+        if not late_bfs:
+            position_block()
         def structure_walks():
             """Walks over the structure patches, the per-layer picks and the patches' degree sequences.  With two streams
             this runs on the MAIN stream behind the component degree sequences (the side stream keeps the position BFS):
@@ -479,6 +493,12 @@ def prepare_pass(model, split='train', timer=None, shard=None, defer_dtw=False):
     # overlaps with them instead of delaying them (6 250 subgraphs: the main chain reaches this point after ~1.3 ms, the search
     # ends at ~1.6).  At the benchmark's 50k subgraphs the search has long finished when the main chain gets here.
     st.dtw_inputs = (cc_sets, ci, ce, a_sets, ai, ae, (S, C)) if hp['use_structure'] else None
+    if late_bfs:
+        dtw_ev = torch.cuda.Event()
+        dtw_ev.record(main)                                 # the DTW launches are queued right behind this ...
+        with torch.cuda.stream(side):
+            side.wait_event(dtw_ev)                         # ... and the position search starts with them
+            position_block()
     if not defer_dtw:
         finish_pass(model, st, t)
     if side is not main:
