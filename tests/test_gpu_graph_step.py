@@ -106,3 +106,27 @@ def test_training_step_is_bit_reproducible(tiny, tmp_path):
     sd0, sd1 = m0.state_dict(), m1.state_dict()
     for k in sd0:
         assert torch.equal(sd0[k], sd1[k]), k
+
+
+def test_step_that_cannot_be_recorded_is_trained_eagerly(tiny, tmp_path, monkeypatch):
+    """hip_graph_step is the trainer's default: a training_step with a host round trip in it (here: the loss read back on the
+    host) cannot be recorded -- the trainer says so, switches the recording off and trains eagerly; the run still equals the
+    eager run of the same model."""
+    from subgnn_amd.SubGNN import SubGNN
+    (tmp_path / 'a').mkdir()
+    (tmp_path / 'b').mkdir()
+    real = SubGNN.training_step
+
+    def syncing_step(self, batch, batch_idx):
+        out = real(self, batch, batch_idx)
+        float(out['loss'].detach())                          # a host synchronisation: illegal while a stream is capturing
+        return out
+    monkeypatch.setattr(SubGNN, 'training_step', syncing_step)
+    m0, t0 = _fit(tiny, tmp_path / 'a', False, False, epochs=4)
+    m1, t1 = _fit(tiny, tmp_path / 'b', True, False, epochs=4)
+    assert not t0.hip_graph_step and not t1.hip_graph_step    # asked for, could not be recorded, reported and switched off
+    l0 = torch.tensor([e['train_loss'] for e in t0.history])
+    l1 = torch.tensor([e['train_loss'] for e in t1.history])
+    assert torch.allclose(l0, l1, rtol=1e-5, atol=1e-6), (l0, l1)
+    x = torch.ones(8, device=m1.device)
+    assert float((x * 2).sum()) == 16.0                       # the device is healthy after the failed capture
