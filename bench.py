@@ -28,14 +28,17 @@ One step = one full pass of the hot path over the rank's shard, everything on th
        every rank's embeddings requires, at world x the head work per rank.
 value = subgraphs processed by all ranks / max-over-ranks step time.
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-  roofline      the structure-channel CSR gather (sgnn_degree_sequence, the kernel BASELINE.json's
-                target names) as a bandwidth: SURVEY.md 8(d) algorithmic bytes / time of the launch
-                that moves them (every neighbour list streamed), HIP events on the launching
-                stream, peak 8 TB/s; hbm_frac = memory-side counter bytes / same time; the shipped
-                launch (long lists binary-searched) with ITS byte count next to it.
-  cpu_baseline  the oracle (plain C + numpy + torch-CPU restatement of the same algorithm)
-                timed on this box's host cores on a bounded sample (rank 0, N = 1 only).
+Prints ONE JSON line on rank 0 (contract in the task statement) with these extra objects:
+  roofline      the structure-channel CSR gather (sgnn_degree_sequence, the kernel BASELINE.json's target names) AS THE PASS RUNS
+                IT (lists of >= 512 entries binary-searched): the bytes that launch reads / its time inside the timed region, peak
+                8 TB/s; streaming_form beside it = the launch that moves SURVEY.md 8(d)'s algorithmic bytes (every neighbour list
+                streamed), 20 launches back to back, HIP events on the launching stream, with the memory-side counter traffic
+                (hbm_frac) from the committed rocprofv3 passes.
+  rooflines     the other HBM-class kernels of the pass priced the same way (one-hop border + draw, position BFS).
+  projection    N = 1 only: 8-GPU estimates (weak and strong form) from this run's step + bytes / link rate; not a measurement.
+  cpu_baseline  the oracle (plain C + numpy + torch-CPU restatement of the same algorithm) timed on this box's host cores on a
+                bounded sample (rank 0, N = 1 only; Python stages on worker processes forked before the GPU is initialised), with
+                its calibration against the imported reference (profiles/r04_cpu_calibration.json).
 """
 import argparse
 import json
