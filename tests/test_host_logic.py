@@ -283,3 +283,46 @@ def test_copy_into_keeps_addresses_and_reports_what_it_had_to_replace():
     assert out['gone'].shape == (3,) and any("gone" in r for r in replaced)
     assert out['alias'] is new_a and any('alias' in r for r in replaced)      # nothing kept under that name yet: replaced
     assert len(replaced) == 2
+
+
+def test_cpu_baseline_worker_pool_equals_serial():
+    """oracle/cpu_baseline.py deals its Python stages to worker processes (forked before the GPU is initialised in bench.py):
+    the pooled map keeps the order and the values of the serial one."""
+    from subgnn_amd import synthetic
+    from oracle import cpu_baseline as cb
+    n = 3000
+    rowptr, col = synthetic.sorted_csr(synthetic.barabasi_albert_edges(n, 4, seed=1), n)
+    subs = synthetic.bfs_subgraphs(rowptr, col, 40, 8, seed=2)
+    cb.stop_pool()
+    cb._W['G'] = cb.CSRGraph(rowptr, col)
+    serial = [cb._w_components(s) for s in subs]
+    assert cb._pmap(cb._w_components, subs) == serial            # no pool: in this process
+    try:
+        assert cb.start_pool(rowptr, col, procs=3)[1] == 3
+        assert cb._pmap(cb._w_components, subs) == serial
+        rows = [np.asarray(s, dtype=np.int64) for s in subs]
+        got = cb._pmap(cb._w_border, rows)
+        want = [cb._w_border(r) for r in rows]
+        assert all(np.array_equal(a, b) for a, b in zip(got, want))
+    finally:
+        cb.stop_pool()
+    assert cb._POOL is None
+
+
+def test_bench_projection_from_a_measured_step():
+    """bench.projection: 8-GPU estimates from the N = 1 step, marked as not measured; the weak form gains what the exposed
+    reduce-scatter costs and the owner-computes Adam saves."""
+    import types
+    import bench
+    table = torch.nn.Parameter(torch.zeros(1_000_001, 64))
+    model = types.SimpleNamespace(node_embeddings=types.SimpleNamespace(weight=table),
+                                  parameters=lambda: [table, torch.nn.Parameter(torch.zeros(10, 10))])
+    res = {'ms_per_step': 10.0, 'stages_ms': {'optimizer': 0.8}}
+    p = bench.projection(types.SimpleNamespace(), res, model, 50_000)
+    assert p['not_a_measurement'] and p['n_gpus'] == 8
+    assert p['collective_bytes_per_step']['table_gradient_reduce_scatter'] == 1_000_001 * 64 * 4
+    assert p['collective_bytes_per_step']['small_gradients_all_reduce'] == 400
+    d, r = p['weak_direct'], p['weak_ring']
+    assert d['ms_per_step'] < r['ms_per_step'] and 7.0 < r['speedup_vs_1gpu'] <= d['speedup_vs_1gpu'] <= 8.8
+    assert abs(d['ms_per_step'] - (10.0 + p['reduce_scatter_ms']['direct_7_links'] + 0.1 - 0.7)) < 0.02
+    assert abs(p['reduce_scatter_ms']['ring'] - 7 * p['reduce_scatter_ms']['direct_7_links']) < 0.01
