@@ -464,3 +464,41 @@ def test_a_subgraph_of_thousands_of_nodes_goes_through_the_whole_pass():
     out = m.training_step(batch, 0)
     m.backward(None, out['loss'], None, 0)
     assert torch.isfinite(out['loss']) and float(m.node_embeddings.weight.grad.abs().max()) > 0
+
+
+@pytest.mark.parametrize('name', ['tiny', 'density'])
+def test_position_search_queued_beside_the_dtw_prepares_the_same_pass(name, tmp_path):
+    """hparams['bfs_beside_dtw'] only moves the position channel's block (shared anchors, P-internal draws, multi-source BFS)
+    behind an event recorded right before the DTW launches: every tensor of the prepared pass is the same, over two passes
+    (the second one uses the kept per-split state and the hinted search depth)."""
+    from conftest import load_golden
+    from subgnn_amd import hotpath
+    golden = load_golden(name)
+    a, b = _models(golden, tmp_path)
+    b.hparams['bfs_beside_dtw'] = True
+
+    def snapshot(m):
+        out = {}
+
+        def walk(prefix, o):
+            if isinstance(o, torch.Tensor):
+                out[prefix] = o.detach().clone()
+            elif isinstance(o, dict):
+                for k, v in o.items():
+                    walk('%s[%r]' % (prefix, k), v)
+            elif isinstance(o, (list, tuple)):
+                for i, v in enumerate(o):
+                    walk('%s[%d]' % (prefix, i), v)
+        for nm in ('train_cc_ids', 'train_neigh_pos_similarities', 'train_int_struc_similarities', 'train_bor_struc_similarities',
+                   'anchors_neigh_int', 'anchors_neigh_border', 'anchors_pos_int', 'anchors_pos_ext', 'anchors_structure',
+                   'structure_anchors'):
+            walk(nm, getattr(m, nm, None))
+        return out
+    for _ in range(2):
+        hotpath.prepare_sparse(a, 'train')
+        hotpath.prepare_sparse(b, 'train')
+        torch.cuda.synchronize()
+        sa, sb = snapshot(a), snapshot(b)
+        assert sa.keys() == sb.keys() and len(sa) > 10
+        for k in sa:
+            assert torch.equal(sa[k], sb[k]), k
