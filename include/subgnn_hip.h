@@ -448,7 +448,7 @@ int sgnn_mpn_bwd(const sgnn_mpn_args* args, const float* grad_agg, const float* 
  * out[r] = sum_j v_j tanh(XU[r, j] + qW[r / rows_per_batch, j]). */
 int sgnn_attn_scores_epilogue(const float* XU, const float* qW, const float* v, int64_t R, int64_t H,
                               int64_t rows_per_batch, float* out, void* stream);
-/* half operands on the matrix cores, one kernel (v_mfma_f32_32x32x8_f16, fp32 accumulate; X and U are rounded to IEEE
+/* half operands on the matrix cores, one kernel (v_mfma_f32_32x32x16_f16, fp32 accumulate; X and U are rounded to IEEE
  * half on the way in; four wavefronts per workgroup share each 32-column panel of U through LDS): the fp16 form of
  * BASELINE.json configs[4].  H <= 640, else SGNN_ERR_UNSUPPORTED_D (the caller takes the exact form).
  * workspace: sgnn_attn_scores_f16_workspace_bytes(H) bytes (the transposed half copy of U). */

@@ -37,11 +37,22 @@ _POOL = None
 _W = {}            # what the workers see (set before the fork)
 
 
+def _graph_identity(rowptr, col):
+    """(n, nnz, checksum over a stride of the arrays): tells the graph the pool was forked with from another one."""
+    rp, c = np.asarray(rowptr), np.asarray(col)
+    step_r, step_c = max(1, len(rp) // 4096), max(1, len(c) // 4096)
+    return (len(rp) - 1, int(rp[-1]) if len(rp) else 0, int(rp[::step_r].astype(np.int64).sum()), int(c[::step_c].astype(np.int64).sum()))
+
+
 def start_pool(rowptr, col, procs=None):
-    """Fork the worker processes (call before anything initialises the GPU).  The graph arrays are shared copy-on-write."""
+    """Fork the worker processes (call before anything initialises the GPU).  The graph arrays are shared copy-on-write.
+    A pool that exists for another graph is replaced."""
     global _POOL
     import multiprocessing as mp
+    if _POOL is not None and _W.get('G_id') != _graph_identity(rowptr, col):
+        stop_pool()
     _W['G'] = CSRGraph(rowptr, col)
+    _W['G_id'] = _graph_identity(rowptr, col)
     procs = procs or os.cpu_count() or 1
     if procs > 1 and _POOL is None:
         _POOL = (mp.get_context('fork').Pool(procs), procs)
@@ -111,6 +122,9 @@ def _calibration():
 
 def run(rowptr, col, subs, hp, emb, labels, n_sample, S_total):
     t_all = time.perf_counter()
+    if _POOL is not None and _W.get('G_id') != _graph_identity(rowptr, col):
+        # the pool's workers hold the graph start_pool() forked into them: a run() on ANOTHER graph must not use it
+        stop_pool()
     G = _W['G'] = CSRGraph(rowptr, col) if _POOL is None else _W['G']
     n = G.n
     seed = int(hp.get('seed', 0))

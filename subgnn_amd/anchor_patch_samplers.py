@@ -34,7 +34,8 @@ def patch_node_views(anchor_patch_ids):
     P, L = anchor_patch_ids.shape
     dev = anchor_patch_ids.device
     ids = anchor_patch_ids
-    if P * L * L <= VIEW_PAIRWISE_MAX and ids.is_cuda and ids.dtype == torch.int64 and 0 < P <= ops.PACK_FUSED_MAX_ROWS and 0 < P * L <= ops.PACK_FUSED_MAX_ENTRIES:
+    if P * L * L <= VIEW_PAIRWISE_MAX and ids.is_cuda and ids.dtype == torch.int64 and 0 < P <= ops.pack_fused_limits()[0] \
+            and 0 < P * L <= ops.pack_fused_limits()[1]:
         return ops.Ragged.from_first_occurrence(ids)                              # ONE launch: first occurrences found and packed
     if P * L * L <= VIEW_PAIRWISE_MAX and ids.is_cuda:
         keep = ops.first_occurrence_mask(ids)                                     # one launch: entry i against the i entries before it

@@ -259,10 +259,13 @@ __device__ __forceinline__ void ds_count(const int32_t* __restrict__ col, const 
 #ifndef DS_MIN_WAVES
 #define DS_MIN_WAVES 5         // wavefronts per SIMD the register allocation aims for (86 VGPRs -> 5); 4 / 5 / 6 / 7 / 8 measured 0.392 / 0.391 / 0.396 / 0.398 / 0.401 ms: not occupancy-bound
 #endif
+#ifndef DS_MIN_WAVES_SEARCH
+#define DS_MIN_WAVES_SEARCH 4  // the SEARCH instantiations keep phase A0's slot bookkeeping live across the streaming phases: under the 5-wave
+#endif                         // budget (96 VGPRs) they spilled 4 registers to scratch (20 B per lane: 59 MB written per launch for 8 MB of output)
 // SEARCH: instantiation given the row-sorted CSR (long lists searched) -- the same code with col_sorted == nullptr
 // would do, but profiles should tell the two forms of the launch apart.
 template <bool SORTED, bool FEW = false, bool SEARCH = false>
-__global__ __launch_bounds__(64 * DS_WAVES) __attribute__((amdgpu_waves_per_eu(DS_MIN_WAVES))) void degseq_wave_kernel(
+__global__ __launch_bounds__(64 * DS_WAVES) __attribute__((amdgpu_waves_per_eu(SEARCH ? DS_MIN_WAVES_SEARCH : DS_MIN_WAVES))) void degseq_wave_kernel(
     const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
     const int32_t* __restrict__ full_degree, const uint8_t* __restrict__ self_loops,
     const int64_t* __restrict__ set_ptr, const int32_t* __restrict__ set_nodes, int64_t n_sets,

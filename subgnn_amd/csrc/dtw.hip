@@ -617,9 +617,16 @@ __device__ __forceinline__ double dtw_wave_level(
 // <= left, up <= left) on the predecessor costs -- decoded only along the path.
 __device__ __forceinline__ uint32_t dtw_shift_in(uint32_t word, uint64_t lane_mask)
 {
+#if defined(__gfx950__) || defined(__gfx942__) || defined(__gfx90a__)
+    // (VOP3 v_addc_co_u32 with a 64-bit scalar carry-in: the gfx9 family's wave64 encoding)
     uint32_t out;
     asm("v_addc_co_u32_e64 %0, vcc, %1, %1, %2" : "=v"(out) : "v"(word), "s"(lane_mask) : "vcc");
     return out;
+#elif defined(__HIP_DEVICE_COMPILE__)
+#error "dtw_shift_in: hand-written gfx9 wave64 instruction -- build with -DDTW_OLD_COARSE=1 for another target"
+#else
+    return 2u * word + (uint32_t)(lane_mask & 1u);              // host pass of the single-source compile: never executed
+#endif
 }
 
 template <int RR, int TIE, bool WLDS>
@@ -924,8 +931,13 @@ static int dtw_run(const int64_t* x_ptr, const int32_t* x_val, int64_t n_x, int6
         const bool wlds = dtw_words_in_lds(max_y_len);
         // SGNN_DTW_LDS_PAD (bytes, measurement only: tools/dtw_overlap_probe.py): extra dynamic LDS per workgroup, which lowers the
         // number of resident workgroups per CU (>= 20 KB: two instead of three) and leaves vector registers to other streams' kernels
+        // -- compiled in only with -DDTW_PROBE_LDS_PAD (the production launch reads no environment variable), clamped to what is left
+        // of a workgroup's 64 KB
+        size_t dyn = wlds ? (size_t)((words > 0 ? words : 1) * DTW_THREADS * 4) : 0;
+#ifdef DTW_PROBE_LDS_PAD
         static const long lds_pad = getenv("SGNN_DTW_LDS_PAD") ? atol(getenv("SGNN_DTW_LDS_PAD")) : 0;
-        const size_t dyn = (wlds ? (size_t)((words > 0 ? words : 1) * DTW_THREADS * 4) : 0) + (size_t)(lds_pad > 0 ? lds_pad : 0);
+        if (lds_pad > 0) dyn += (size_t)(lds_pad < (long)(48 * 1024 - (long)dyn) ? lds_pad : (48 * 1024 > (long)dyn ? 48 * 1024 - (long)dyn : 0));
+#endif
 #define DTW_LAUNCH2(RMAX, TIE, MINB, WL) \
         hipLaunchKernelGGL((dtw_similarity_reg_kernel<RMAX, TIE, MINB, WL>), dim3(DTW_REG_BLOCKS), dim3(DTW_THREADS), dyn, st, \
                            xpyr, xlen, n_x, ypyr, ylen, n_y, out, wq, L, x_order, x_live)

@@ -636,8 +636,8 @@ extern "C" int sgnn_filter_sets(const int64_t* set_ptr, const int32_t* set_nodes
 // A few hundred structure patches are packed three times per pass (node views, in-border sets, degree-sequence sets): as
 // count + prefix sum + write that is 5-6 launches each (two fills, a count, one or two scan kernels, a write) for microseconds
 // of work -- at shard size the pass is bound by the host's launches.  One 1024-thread workgroup does all of it: every thread
-// owns up to SGNN_PACK_FUSED_RPT consecutive rows, keeps their keep-masks in registers (rows of up to 64 entries; longer rows
-// are re-evaluated), the block scans the per-thread totals, rows are written in place and the arena's tail is zeroed.
+// owns up to SGNN_PACK_FUSED_RPT consecutive rows; the entries and their keep flags are staged in LDS (see below), the block
+// scans the per-thread totals, rows are written from LDS and the arena's tail is zeroed.
 // mode 0: keep non-PAD entries; 1: keep where mask != 0; 2: keep non-PAD entries that no earlier entry of the row repeats
 // (the node view of a patch: first_occurrence_kernel + pack in one).
 #define SGNN_PACK_FUSED_THREADS 1024
@@ -757,19 +757,48 @@ __global__ __launch_bounds__(SGNN_PACK_FUSED_THREADS) void filter_sets_fused_ker
     for (int64_t i = total + threadIdx.x; i < arena; i += SGNN_PACK_FUSED_THREADS) out_nodes[i] = 0;
 }
 
+// Entries one fused launch can stage on the CURRENT device: 5 bytes of LDS each, capped by the compile-time figure (sized for
+// gfx950's 160 KB).  Per device, not per process: a part with less LDS advertises less and its callers take the multi-launch path.
+static int64_t pack_fused_entries_limit()
+{
+    static int64_t lim[64];                                  // 0 = not asked yet (a racing first call writes the same value)
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return SGNN_PACK_FUSED_MAX_ENTRIES;   // no device here: the compile-time figure
+    if (lim[dev] == 0) {
+        int lds = 0;
+        if (hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess || lds <= 0) lds = 64 * 1024;
+        const int64_t e = ((int64_t)lds - 16) / 5;
+        lim[dev] = e < SGNN_PACK_FUSED_MAX_ENTRIES ? (e > 0 ? e : 1) : SGNN_PACK_FUSED_MAX_ENTRIES;
+    }
+    return lim[dev];
+}
+// the opt-in to more than 64 KB of dynamic LDS, once per kernel AND device; its failure is reported, not discarded
+static int pack_fused_opt_in(const void* kernel, bool* done /* [64] */, size_t bytes)
+{
+    if (bytes <= 64 * 1024) return SGNN_OK;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return SGNN_ERR_LAUNCH;
+    if (!done[dev]) {
+        if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(pack_fused_entries_limit() * 5 + 16)) != hipSuccess) {
+            (void)hipGetLastError();
+            return SGNN_ERR_SET_TOO_LARGE;                   // the caller's multi-launch path serves this input
+        }
+        done[dev] = true;
+    }
+    return SGNN_OK;
+}
+
 extern "C" int64_t sgnn_pack_fused_max_rows(void) { return SGNN_PACK_FUSED_MAX_ROWS; }
-extern "C" int64_t sgnn_pack_fused_max_entries(void) { return SGNN_PACK_FUSED_MAX_ENTRIES; }
+extern "C" int64_t sgnn_pack_fused_max_entries(void) { return pack_fused_entries_limit(); }
 
 extern "C" int sgnn_pack_rows_fused(const int64_t* ids, const uint8_t* mask, int mode, int64_t n_rows, int64_t row_len,
                                     int64_t* ptr, int32_t* nodes, void* stream)
 {
     if (!ids || !ptr || !nodes || n_rows < 1 || row_len < 1 || mode < 0 || mode > 2 || (mode == 1 && !mask)) return SGNN_ERR_BAD_ARG;
-    if (n_rows > SGNN_PACK_FUSED_MAX_ROWS || n_rows * row_len > SGNN_PACK_FUSED_MAX_ENTRIES) return SGNN_ERR_SET_TOO_LARGE;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)pack_rows_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SGNN_PACK_FUSED_MAX_ENTRIES * 5 + 16);
-        attr_set = true;
-    }
+    if (n_rows > SGNN_PACK_FUSED_MAX_ROWS || n_rows * row_len > pack_fused_entries_limit()) return SGNN_ERR_SET_TOO_LARGE;
+    static bool attr_set[64];
+    const int rc = pack_fused_opt_in((const void*)pack_rows_fused_kernel, attr_set, (size_t)(n_rows * row_len * 5 + 16));
+    if (rc != SGNN_OK) return rc;
     hipLaunchKernelGGL(pack_rows_fused_kernel, dim3(1), dim3(SGNN_PACK_FUSED_THREADS), (size_t)(n_rows * row_len * 5 + 16), (hipStream_t)stream,
                        ids, mask, mode, n_rows, row_len, ptr, nodes);
     SGNN_CHECK_LAUNCH();
@@ -781,12 +810,10 @@ extern "C" int sgnn_filter_sets_fused(const int64_t* set_ptr, const int32_t* set
 {
     if (!set_ptr || !set_nodes || !flags || !out_ptr || !out_nodes || n_sets < 1 || arena_entries < 1) return SGNN_ERR_BAD_ARG;
     // (the sets' entries are staged in LDS: the caller's arena -- at least the sets' total -- bounds them)
-    if (n_sets > SGNN_PACK_FUSED_MAX_ROWS || arena_entries > SGNN_PACK_FUSED_MAX_ENTRIES) return SGNN_ERR_SET_TOO_LARGE;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)filter_sets_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SGNN_PACK_FUSED_MAX_ENTRIES * 5 + 16);
-        attr_set = true;
-    }
+    if (n_sets > SGNN_PACK_FUSED_MAX_ROWS || arena_entries > pack_fused_entries_limit()) return SGNN_ERR_SET_TOO_LARGE;
+    static bool attr_set[64];
+    const int rc = pack_fused_opt_in((const void*)filter_sets_fused_kernel, attr_set, (size_t)(arena_entries * 5 + 16));
+    if (rc != SGNN_OK) return rc;
     hipLaunchKernelGGL(filter_sets_fused_kernel, dim3(1), dim3(SGNN_PACK_FUSED_THREADS), (size_t)(arena_entries * 5 + 16), (hipStream_t)stream,
                        set_ptr, set_nodes, flags, n_sets, arena_entries, out_ptr, out_nodes);
     SGNN_CHECK_LAUNCH();

@@ -32,6 +32,25 @@ def make_capturable(optimizer):
     return optimizer
 
 
+def make_eager(optimizer):
+    """Undo make_capturable for an optimizer that goes back to eager steps (the trainer's fallback): with ``capturable``
+    left on, torch's Adam keeps the device-side step arithmetic -- not the code path of a run that never asked for a
+    recorded step.  The step counters stay tensors; torch accepts device or host counters in either mode."""
+    for g in optimizer.param_groups:
+        if 'capturable' in g:
+            g['capturable'] = False
+    for st in optimizer.state.values():
+        if 'step' in st and torch.is_tensor(st['step']) and st['step'].is_cuda:
+            st['step'] = st['step'].cpu()
+    return optimizer
+
+
+class StepNotRecordable(RuntimeError):
+    """The training step could not be RECORDED (an operation inside it needs the host while the stream is capturing).
+    Raised by CapturedTrainStep._record only: an error of the eager warm-up steps, or of a replay, is the step's own
+    failure and propagates as it is."""
+
+
 class CapturedTrainStep:
     """Record ``step(idx)`` for batches of exactly ``batch_size`` subgraphs of ``split``.
 
@@ -74,8 +93,12 @@ class CapturedTrainStep:
     def _record(self):
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            self.loss, self.acc = self._body()
+        try:
+            with torch.cuda.graph(g):
+                self.loss, self.acc = self._body()
+        except RuntimeError as ex:
+            self.loss = self.acc = None
+            raise StepNotRecordable(str(ex)) from ex
         self.graph = g
 
     def replay(self, idx):

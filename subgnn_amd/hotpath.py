@@ -81,7 +81,8 @@ BFS_LEVEL_MARGIN = 2
 
 def _bfs_levels(model, key, max_hops):
     """How many BFS levels to enqueue for the position channel's search ``key``.  The kernels run without a host
-    synchronisation, so every enqueued level costs three launches whether or not the search has ended -- with the
+    synchronisation, so every enqueued level costs two launches (expand, which also reduces the previous level over the
+    sets, and commit) whether or not the search has ended -- with the
     default cap of 32 hops and a small-world graph that is ~26 empty levels (~0.3 ms of a 19 ms pass).  The first
     search of a kind runs the full cap and its status (last productive level) is read back once; later ones enqueue
     (levels needed so far + BFS_LEVEL_MARGIN productive levels + the one empty level that proves the search has ended)
@@ -136,10 +137,24 @@ def _verify_bfs(model, st, keep=False):
     wait costs nothing.  A search that ran out of levels is REPEATED with the full cap and its similarities replaced
     before anything reads them; only a graph deeper than hparams['max_bfs_hops'] itself is an error."""
     hint = model.__dict__.setdefault('_bfs_level_hint', {})
-    for key, host, ev, cap, enqueued, redo in st.bfs_checks:
-        if ev is not None:
-            ev.synchronize()
-        last, more = int(host[0]), int(host[1])
+    checks = list(st.bfs_checks)
+    # every status is READ first (all copies have landed once the last event has), and the pinned buffers of an eager pass go
+    # back to the free list in one place whatever happens below: a raise in the middle of the loop used to leave the buffers
+    # of the remaining checks outside the pool while st.bfs_checks still listed the ones already returned
+    results = []
+    try:
+        for key, host, ev, cap, enqueued, redo in checks:
+            if ev is not None:
+                ev.synchronize()
+            results.append((int(host[0]), int(host[1])))
+    finally:
+        if not keep:
+            st.bfs_checks = []
+            pool = model.__dict__.setdefault('_bfs_status_pool', [])
+            for key, host, ev, cap, enqueued, redo in checks:
+                if ev is not None:                       # (a recording's buffers -- ev None -- belong to the recording: release_checks)
+                    pool.append(host)
+    for (key, host, ev, cap, enqueued, redo), (last, more) in zip(checks, results):
         if more and enqueued < cap:
             if redo is None:                         # a recorded pass cannot repeat a search: its owner records again
                 hint[key] = cap
@@ -150,10 +165,14 @@ def _verify_bfs(model, st, keep=False):
             raise RuntimeError('position-channel BFS: level %d still reached new nodes -- hparams["max_bfs_hops"] = %d '
                                'is smaller than the depth of this graph from the anchors' % (cap, cap))
         hint[key] = max(hint.get(key) or 0, last)                  # the hint only grows: anchors are redrawn every pass
-        if ev is not None:
-            model.__dict__.setdefault('_bfs_status_pool', []).append(host)
-    if not keep:
-        st.bfs_checks = []
+
+
+def release_checks(model, checks):
+    """The pinned status buffers of a recording that is being dropped go back to the free list (GraphedPasses)."""
+    pool = model.__dict__.setdefault('_bfs_status_pool', [])
+    for c in checks:
+        if c[1] is not None and not any(c[1] is h for h in pool):
+            pool.append(c[1])
 
 
 def check_pending(model):
@@ -853,6 +872,7 @@ class GraphedPasses:
         try:
             install_pass(self.model, slot.state)             # (verifies the searches of the replay above)
         except BfsLevelsExhausted:
+            release_checks(self.model, slot.checks)
             return self._record(i)                           # (the hint is the cap now: this happens at most once)
         slot.state.bfs_checks = list(slot.checks)
         g2 = torch.cuda.CUDAGraph()
@@ -885,6 +905,9 @@ class GraphedPasses:
             _verify_bfs(self.model, slot.state, keep=True)
         except BfsLevelsExhausted:
             torch.cuda.synchronize()
+            for sl in self.slots:                              # the dropped recordings' pinned status buffers return to the pool
+                if sl is not None:
+                    release_checks(self.model, sl.checks)
             self.slots = [None, None]                          # deeper searches from now on: record again
             return self.step()
         slot.train.replay()

@@ -94,7 +94,8 @@ class Ragged:
             # counts per row, prefix sum, packed write (sgnn_pack_rows_count / _write): mask None = strip PAD
             lib = _lib.load()
             ids = ids.contiguous()
-            if n <= PACK_FUSED_MAX_ROWS and n * L <= PACK_FUSED_MAX_ENTRIES and (mask is None or mask.dtype == torch.uint8 or first_occurrence):
+            fused_rows, fused_entries = pack_fused_limits()
+            if n <= fused_rows and n * L <= fused_entries and (mask is None or mask.dtype == torch.uint8 or first_occurrence):
                 # a few hundred rows (the structure patches): one launch does count, scan, write and the arena's zero tail
                 m8 = None if (mask is None or first_occurrence) else mask.contiguous()
                 ptr = torch.empty(n + 1, dtype=torch.int64, device=dev)
@@ -255,7 +256,8 @@ def filter_sets(sets, flags):
     ptr = torch.zeros(sets.n + 1, dtype=torch.int64, device=dev)
     if sets.n == 0:
         return Ragged(ptr, torch.zeros(1, dtype=torch.int32, device=dev), max_len=0)
-    if sets.n <= PACK_FUSED_MAX_ROWS and sets.nodes.numel() <= PACK_FUSED_MAX_ENTRIES:
+    fused_rows, fused_entries = pack_fused_limits()
+    if sets.n <= fused_rows and sets.nodes.numel() <= fused_entries:
         arena = max(sets.nodes.numel(), 1)
         ptr = torch.empty(sets.n + 1, dtype=torch.int64, device=dev)
         nodes = torch.empty(arena, dtype=torch.int32, device=dev)
@@ -320,8 +322,20 @@ def degree_sequence(g, sets, sort=True, use_degree_dict=True, want_external=True
     return out_i, out_e
 
 
-PACK_FUSED_MAX_ROWS = 8192    # csrc/graph_sets.hip SGNN_PACK_FUSED_MAX_ROWS / _MAX_ENTRIES: packings this small take one launch
-PACK_FUSED_MAX_ENTRIES = 24576
+_PACK_FUSED = {}
+
+
+def pack_fused_limits():
+    """(rows, entries) one fused packing launch serves on the current device -- asked of the library
+    (sgnn_pack_fused_max_rows / _max_entries: the entries follow the device's LDS), once per device."""
+    dev = torch.cuda.current_device() if torch.cuda.is_available() else -1
+    lim = _PACK_FUSED.get(dev)
+    if lim is None:
+        lib = _lib.load()
+        lim = _PACK_FUSED[dev] = (int(lib.sgnn_pack_fused_max_rows()), int(lib.sgnn_pack_fused_max_entries()))
+    return lim
+
+
 CC_LDS_MAX = 2048          # csrc/graph_sets.hip CC_MAX / PB_MAX: sets up to here keep their tables in LDS
 
 
@@ -1715,7 +1729,7 @@ def attn_scores(X, U, qW, v, rows_per_batch, half_operands=False):
     """score[r] = sum_j v_j tanh(qW[r // rows_per_batch, j] + (X U)[r, j]) for X (R, H).
     Exact form: library GEMM + the fused epilogue (sgnn_attn_scores_epilogue).  ``half_operands``: X and U are
     rounded to IEEE half and the whole thing is one hand-written kernel on the matrix cores
-    (v_mfma_f32_32x32x8_f16, fp32 accumulate; for H <= 640 and at least a few thousand rows); the backward pass
+    (v_mfma_f32_32x32x16_f16, fp32 accumulate; for H <= 640 and at least a few thousand rows); the backward pass
     recomputes in fp32 either way."""
     return _AttnScores.apply(X.contiguous(), U.contiguous(), qW.contiguous(), v.contiguous().view(-1), int(rows_per_batch),
                              bool(half_operands))

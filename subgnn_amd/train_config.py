@@ -103,7 +103,9 @@ class Trainer:
         # Full batches replay a recorded step (graph_step.CapturedTrainStep) unless hparams['hip_graph_step'] is False: at the
         # reference's batch sizes the eager step is bound by the host's ~250 launches (3.5-11.5 ms against 1.3-4.6 ms replayed,
         # profiles/r03_bench_standin_*.json).  A short last batch runs eagerly; a model whose step cannot be recorded (an
-        # operation that needs the host inside training_step) is reported and trained eagerly.
+        # operation that needs the host inside training_step) is reported and trained eagerly.  With
+        # hparams['resample_anchor_patches'] the prepared tensors change at every epoch end, so the step is recorded again
+        # once per epoch (a device synchronisation + one capture: ~the cost of 3-4 eager steps per epoch).
         self.hip_graph_step = bool(hip_graph_step) and torch.cuda.is_available()
 
     def _eager_step(self, model, opt, batch, bi):
@@ -120,7 +122,7 @@ class Trainer:
         opt = model.configure_optimizers()
         captured = None
         if self.hip_graph_step:
-            from .graph_step import CapturedTrainStep, make_capturable
+            from .graph_step import CapturedTrainStep, StepNotRecordable, make_capturable, make_eager
             make_capturable(opt)
         for epoch in range(self.max_epochs):
             model.train()
@@ -136,11 +138,13 @@ class Trainer:
                         try:
                             losses.append(captured.replay(idx)[0].clone())
                             continue
-                        except RuntimeError as ex:
-                            if captured.graph is not None:
-                                raise                                # a recorded step failed: nothing to fall back from
+                        except StepNotRecordable as ex:
+                            # only a failure of the RECORDING falls back (an error of the eager warm-up steps or of a replay is
+                            # the step's own and propagates); the optimizer returns to its eager form: the steps that follow
+                            # are the ones hip_graph_step=False would have run
                             self.log('hip_graph_step: the training step could not be recorded (%s); training eagerly' % (ex,))
                             self.hip_graph_step = False
+                            make_eager(opt)
                             torch.cuda.synchronize()
                     losses.append(self._eager_step(model, opt, model.make_batch('train', idx), bi))
             else:

@@ -47,3 +47,12 @@ def test_cpu_tensors_are_rejected():
     from subgnn_amd import ops, _lib
     with pytest.raises(_lib.SubgnnHipError):
         ops.Ragged(torch.zeros(2, dtype=torch.int64), torch.zeros(1, dtype=torch.int32))
+
+
+def test_fused_packing_limits_come_from_the_library():
+    """the Python gate of the one-launch packings must not drift from the library's (device-dependent) limits."""
+    from subgnn_amd import ops, _lib
+    lib = _lib.load()
+    rows, entries = ops.pack_fused_limits()
+    assert rows == lib.sgnn_pack_fused_max_rows() and entries == lib.sgnn_pack_fused_max_entries()
+    assert rows == 8192 and 1 <= entries <= 24576           # (without a device: the compile-time figures, sized for gfx950's LDS)

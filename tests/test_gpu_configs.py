@@ -356,7 +356,7 @@ def test_em_user_with_ff_attn_half_mfma_scores(tmp_path_factory):
     attention scores": the EM-USER stand-in with ``ff_attn`` on and the fp16-stored table (hid_dim 579, >= 20 components
     per subgraph).  (1) a training step at the configuration's batch size (32 subgraphs: under 2048 component rows the
     score contraction is the library GEMM on half-rounded operands + the fused epilogue); (2) the whole train split as
-    one batch (>= 5k component rows: the hand-written v_mfma_f32_32x32x8_f16 kernel -- counted).  Logits and loss against
+    one batch (>= 5k component rows: the hand-written v_mfma_f32_32x32x16_f16 kernel -- counted).  Logits and loss against
     the oracle with the same operand rounding within 1e-4 element-wise; gradients against the fp32 restatement within
     half precision."""
     from subgnn_amd import standins, _lib, hotpath
@@ -415,7 +415,7 @@ def test_em_user_with_ff_attn_half_mfma_scores(tmp_path_factory):
         params, anchors, ob, ccp = _oracle_inputs(m, full, all_idx)
         with torch.no_grad():
             want = FH.forward(params, hp, 'train', ob, anchors, ccp)
-        assert_close(got, want, 'logits (whole split, v_mfma_f32_32x32x8_f16 scores)')
+        assert_close(got, want, 'logits (whole split, v_mfma_f32_32x32x16_f16 scores)')
     finally:
         lib.sgnn_attn_scores_fwd_f16, lib.sgnn_attn_scores_epilogue = real_f16, real_epi
         torch.cuda.empty_cache()

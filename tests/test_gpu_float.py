@@ -418,7 +418,7 @@ def test_attn_scores_mfma(R, H, C):
 @pytest.mark.parametrize('kernel', ['mfma', 'auto'])
 @pytest.mark.parametrize('R,H,C', [(5, 8, 1), (70, 37, 7), (193, 420, 1), (640, 615, 4), (300, 640, 1), (129, 128, 1), (4100, 420, 1)])
 def test_attn_scores_mfma_half_operands(R, H, C, kernel, monkeypatch):
-    """The fp16 form (v_mfma_f32_32x32x8_f16, BASELINE configs[4]): against fp32 arithmetic on the half-ROUNDED
+    """The fp16 form (v_mfma_f32_32x32x16_f16, BASELINE configs[4]): against fp32 arithmetic on the half-ROUNDED
     operands it is exact up to the accumulation order (products of halves are exact in fp32); against the
     unrounded reference it is within half precision.  Sizes cover all three register instantiations, partial row
     tiles and column panels, several rows per batch; the backward pass is the fp32 recomputation."""

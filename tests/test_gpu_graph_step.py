@@ -130,3 +130,30 @@ def test_step_that_cannot_be_recorded_is_trained_eagerly(tiny, tmp_path, monkeyp
     assert torch.allclose(l0, l1, rtol=1e-5, atol=1e-6), (l0, l1)
     x = torch.ones(8, device=m1.device)
     assert float((x * 2).sum()) == 16.0                       # the device is healthy after the failed capture
+
+
+def test_an_error_of_the_eager_warm_up_steps_is_not_taken_for_a_failed_recording(tiny, tmp_path, monkeypatch):
+    """only a failure inside the RECORDING falls back to eager training; a genuine error of the step itself (here:
+    raised by the second call, one of the three eager warm-up steps of CapturedTrainStep) reaches the caller as it is."""
+    from subgnn_amd.SubGNN import SubGNN
+    (tmp_path / 'a').mkdir()
+    real = SubGNN.training_step
+    calls = {'n': 0}
+
+    def failing_step(self, batch, batch_idx):
+        calls['n'] += 1
+        if calls['n'] == 2:
+            raise RuntimeError('boom: the step itself is broken')
+        return real(self, batch, batch_idx)
+    monkeypatch.setattr(SubGNN, 'training_step', failing_step)
+    with pytest.raises(RuntimeError, match='boom'):
+        _fit(tiny, tmp_path / 'a', True, False, epochs=2)
+
+
+def test_fallback_returns_the_optimizer_to_its_eager_form(tiny, tmp_path, monkeypatch):
+    from subgnn_amd import graph_step
+    opt = torch.optim.Adam([torch.nn.Parameter(torch.zeros(4, device='cuda'))], lr=0.1)
+    graph_step.make_capturable(opt)
+    assert all(g['capturable'] for g in opt.param_groups)
+    graph_step.make_eager(opt)
+    assert not any(g['capturable'] for g in opt.param_groups)

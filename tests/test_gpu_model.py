@@ -288,7 +288,7 @@ def test_get_anchor_patches_g9(tiny, tmp_path, ch, inside):
 
 def test_ff_attn_with_fp16_takes_the_half_mfma_scores(tiny, tmp_path):
     """BASELINE configs[4] wiring: embedding_dtype = 'fp16' + ff_attn -> the attention scores of the read-out run
-    on v_mfma_f32_32x32x8_f16 (AdditiveAttention.half_operands); logits stay within half precision of the
+    on v_mfma_f32_32x32x16_f16 (AdditiveAttention.half_operands); logits stay within half precision of the
     exact model and every parameter still receives a gradient."""
     g = tiny
     t = 'g11_ff_attn/'
