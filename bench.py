@@ -35,7 +35,10 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with these extra
                 streamed), 20 launches back to back, HIP events on the launching stream, with the memory-side counter traffic
                 (hbm_frac) from the committed rocprofv3 passes.
   rooflines     the other HBM-class kernels of the pass priced the same way (one-hop border + draw, position BFS).
-  projection    N = 1 only: 8-GPU estimates (weak and strong form) from this run's step + bytes / link rate; not a measurement.
+  projection    N = 1 only: 8-GPU estimates from THIS run's measurements + bytes / link rate; not a measurement.  weak_*: from the
+                sequential two-stream schedule N > 1 runs by default, timed live (sequential_ms_per_step); strong_*: from shard6250.
+  shard6250     N = 1 only: rank 0's 6 250-subgraph block of the 50k (BASELINE configs[3] as worded), timed in this process.
+  configs       N = 1 only: the batch-sized training steps of the BASELINE configs[0,1,2,4] stand-ins (replayed + eager ms, kernels).
   cpu_baseline  the oracle (plain C + numpy + torch-CPU restatement of the same algorithm) timed on this box's host cores on a
                 bounded sample (rank 0, N = 1 only; Python stages on worker processes forked before the GPU is initialised), with
                 its calibration against the imported reference (profiles/r04_cpu_calibration.json).
@@ -102,6 +105,11 @@ def parse():
     ap.add_argument('--embed', type=int, default=64)
     ap.add_argument('--embedding-dtype', choices=['fp32', 'fp16'], default='fp32',
                     help="fp16: the fused kernels read an IEEE-half copy of the embedding table (fp32 accumulate, fp32 master)")
+    ap.add_argument('--no-extras', action='store_true',
+                    help='N=1: skip what is measured beside the headline in the same run -- the sequential two-stream schedule (what N>1 '
+                         'runs by default: the projection is computed from it), the live 6 250-subgraph strong-scaling shard, and the '
+                         'batch-sized training steps of the BASELINE configs[0,1,2,4] stand-ins (the ``configs`` object)')
+    ap.add_argument('--extras-budget-s', type=float, default=100.0, help='wall-clock budget of the stand-in configurations')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-sample', type=int, default=2048)
     return ap.parse_args()
@@ -149,13 +157,17 @@ def degseq_algorithmic_bytes(rowptr, sets_lists, search=False):
 XGMI_LINK_GBS = 153.0          # per direction and link; 7 links per GPU (MI355X_MICROARCH.md)
 
 
-def projection(args, result, model, S):
-    """8-GPU estimates from THIS run's measured step + bytes / link rate, so that a SCALE run can be read against them.  Not a
+def projection(args, result, model, S, sequential_ms=None, shard_line=None):
+    """8-GPU estimates from THIS run's measurements + bytes / link rate, so that a SCALE run can be read against them.  Not a
     measurement.  BASELINE.json words configs[3] as "50k subgraphs, sharded across 8": that is the STRONG form (--scaling
     strong, 6 250 subgraphs per GPU); the tier's multi-GPU contract (per-GPU work fixed) and bench.py's default are the WEAK
-    form (50k subgraphs per GPU) -- both are projected."""
+    form (50k subgraphs per GPU) -- both are projected.
+    weak_*: from the schedule ``--gpus 8`` RUNS by default -- sequential passes, two-stream preparation (N > 1 pipelines only
+    with --pipeline-multi) -- timed live in this process (``sequential_ms``); the pipelined figure is beside it.
+    strong_*: from the 6 250-subgraph shard timed live in this process (``shard_line``), not from a committed file."""
     W = 8
-    step = result['ms_per_step']
+    step_pipelined = result['ms_per_step']
+    step = sequential_ms if sequential_ms else step_pipelined
     table_bytes = int(model.node_embeddings.weight.numel() * 4)
     small_bytes = int(sum(p.numel() for p in model.parameters() if p.requires_grad and p is not model.node_embeddings.weight) * 4)
     per_link = table_bytes / W                                   # a reduce-scatter / all-gather moves 1/W of the buffer per peer
@@ -163,31 +175,91 @@ def projection(args, result, model, S):
     ring_ms = (W - 1) * per_link / (XGMI_LINK_GBS * 1e9) * 1e3    # one link per step (ring)
     adam_ms = result['stages_ms'].get('optimizer', 0.5)
     out = {'n_gpus': W, 'not_a_measurement': True,
+           'what_gpus_8_runs_by_default': 'weak form (50k subgraphs per GPU), sequential passes with the two-stream preparation, head on '
+                                          'the rank\'s own rows; --pipeline-multi pipelines the passes as at N = 1, --scaling strong is '
+                                          'BASELINE configs[3] as worded',
            'collective_bytes_per_step': {'table_gradient_reduce_scatter': table_bytes, 'table_all_gather(hidden under the next preparation)': table_bytes,
                                          'small_gradients_all_reduce': small_bytes},
-           'reduce_scatter_ms': {'direct_7_links': round(direct_ms, 3), 'ring': round(ring_ms, 3)}}
-    # weak: every rank runs this run's step on its own 50k subgraphs; + the exposed reduce-scatter + a latency-bound small
-    # all-reduce (~0.1 ms); - 7/8 of the table's Adam (owner-computes on 1/8 of the rows)
+           'reduce_scatter_ms': {'direct_7_links': round(direct_ms, 3), 'ring': round(ring_ms, 3)},
+           'one_gpu_ms_per_step': {'pipelined(this line\'s value)': round(step_pipelined, 3),
+                                   'sequential_two_stream(what N>1 runs; timed live beside it)': round(sequential_ms, 3) if sequential_ms else None}}
+    # weak: every rank runs the sequential step on its own 50k subgraphs; + the exposed reduce-scatter + a latency-bound small
+    # all-reduce (~0.1 ms); - 7/8 of the table's Adam (owner-computes on 1/8 of the rows).  Speed-up against THIS line's value
+    # (the pipelined one-GPU step): what SCALE's N = 8 over N = 1 ratio would show.
     for name, rs in (('direct', direct_ms), ('ring', ring_ms)):
         ms = step + rs + 0.1 - adam_ms * (W - 1) / W
-        out['weak_' + name] = {'ms_per_step': round(ms, 2), 'subgraphs_per_s': round(W * S / ms * 1e3), 'speedup_vs_1gpu': round(W * step / ms, 2)}
-    # strong: a 6 250-subgraph shard's step as measured on one GPU (committed line of `bench.py --subgraphs 6250`), same additions
-    for tag in ('r04', 'r03'):
-        f = os.path.join(REPO, 'profiles', tag + '_bench_shard6250.json')
-        if os.path.exists(f) and S == 50_000:
-            try:
-                sh = json.load(open(f))
-                for name, rs in (('direct', direct_ms), ('ring', ring_ms)):
-                    ms = sh['ms_per_step'] + rs + 0.1 - sh['stages_ms'].get('optimizer', adam_ms) * (W - 1) / W
-                    out['strong_' + name] = {'ms_per_step': round(ms, 2), 'subgraphs_per_s': round(S / ms * 1e3),
-                                             'speedup_vs_1gpu': round(step / ms, 2)}
-                out['strong_source'] = 'profiles/%s_bench_shard6250.json: %.2f ms per 6 250-subgraph pass on one GPU' % (tag, sh['ms_per_step'])
-            except Exception:
-                pass
-            break
+        out['weak_' + name] = {'ms_per_step': round(ms, 2), 'subgraphs_per_s': round(W * S / ms * 1e3), 'speedup_vs_1gpu': round(W * step_pipelined / ms, 2)}
+        msp = step_pipelined + rs + 0.1 - adam_ms * (W - 1) / W
+        out['weak_' + name + '_with_--pipeline-multi'] = {'ms_per_step': round(msp, 2), 'speedup_vs_1gpu': round(W * step_pipelined / msp, 2)}
+    # strong: the 6 250-subgraph shard's step as measured in this process, same additions
+    if shard_line and S == 50_000:
+        for name, rs in (('direct', direct_ms), ('ring', ring_ms)):
+            ms = shard_line['ms_per_step'] + rs + 0.1 - shard_line['stages_ms'].get('optimizer', adam_ms) * (W - 1) / W
+            out['strong_' + name] = {'ms_per_step': round(ms, 2), 'subgraphs_per_s': round(S / ms * 1e3),
+                                     'speedup_vs_1gpu': round(step_pipelined / ms, 2)}
+        out['strong_source'] = 'this run: %.2f ms per 6 250-subgraph pass on one GPU (shard6250 object of this line)' % shard_line['ms_per_step']
     out['note'] = ('BASELINE.json configs[3] ("50k subgraphs, sharded across 8") is the strong form: walks over the shared patches, one BFS word '
-                   'per rank, the dense 256 MB table gradient and launch overhead do not shrink with the shard, so it is bound near 2-3x; the '
-                   '>= 6x target is reachable in the weak form (50k per GPU: what `bench.py --gpus 8` runs by default)')
+                   'per rank, the dense 256 MB table gradient and launch overhead do not shrink with the shard; the >= 6x target is '
+                   'reachable in the weak form (50k per GPU: what `bench.py --gpus 8` runs by default)')
+    return out
+
+
+def time_shard(g, subs, labels, emb, hp, steps, warmup, depth=2):
+    """The strong-scaling shard (BASELINE configs[3] as worded: 50k subgraphs dealt to 8 GPUs = 6 250 per GPU) timed on THIS GPU in
+    THIS process: rank 0's block of the benchmark's subgraphs, the schedule `bench.py --subgraphs 6250` picks (training half
+    replayed from a hipGraph, passes pipelined, two prepared passes in flight).  -> dict for the line's ``shard6250`` object."""
+    from subgnn_amd import hotpath, optim
+    from subgnn_amd.SubGNN import SubGNN
+    S = len(subs)
+    model = SubGNN.from_memory(dict(hp), g, {'train': subs, 'val': [], 'test': []},
+                               {'train': labels, 'val': labels[:0], 'test': labels[:0]}, emb, num_classes=3)
+    model.train()
+    opt = optim.ClipAdam(model.parameters(), hp['learning_rate'], max_norm=hp['grad_clip'], capturable=True)
+    trainer = hotpath.CapturedTraining(model, opt, 'train', warmup=1)
+    pipe = hotpath.PassPipeline(model, 'train', None)
+    side_timers = []
+
+    def step(timed):
+        timer = hotpath.StageTimer(timed)
+        timer.mark('start')
+        pipe.install(timer, installer=trainer.install)
+        if timed:
+            side_timers.append(pipe.timer)
+        installed = torch.cuda.Event()
+        installed.record()
+        loss, _acc = trainer.step()
+        timer.mark('training_half(hipGraph)')
+        pipe.start(timed, after=installed)
+        return timer, loss
+    torch.cuda.synchronize()
+    t_cold = time.perf_counter()
+    for _ in range(depth):
+        pipe.start()
+    step(False)
+    torch.cuda.synchronize()
+    first_ms = (time.perf_counter() - t_cold) * 1e3
+    for _ in range(1 + warmup):
+        step(False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    timers = []
+    for _ in range(steps):
+        tm, loss = step(True)
+        timers.append(tm)
+    torch.cuda.synchronize()
+    ms = 1e3 * (time.perf_counter() - t0) / steps
+    stage, cnt = {}, {}
+    for tm in timers + side_timers:
+        for k, v in tm.summary().items():
+            stage[k] = stage.get(k, 0.0) + v
+            cnt[k] = cnt.get(k, 0) + 1
+    # the table's Adam inside the recorded half is not a stage of its own: priced from the 50k run's optimizer stage by the caller
+    out = {'subgraphs': S, 'ms_per_step': ms, 'subgraphs_per_s': S / ms * 1e3, 'steps': steps, 'warmup': warmup,
+           'schedule': 'training half replayed from a hipGraph, passes pipelined, %d prepared passes in flight' % depth,
+           'first_pass_ms': round(first_ms, 1), 'recordings': trainer.recordings,
+           'stages_ms': {k: round(v / cnt[k], 3) for k, v in stage.items()}, 'loss': float(loss)}
+    del trainer, pipe, opt, model
+    torch.cuda.empty_cache()
     return out
 
 
@@ -351,12 +423,14 @@ def main():
             for k_, p_ in model.named_parameters():
                 hooked['param_before/' + k_] = p_.detach().clone()
 
-    pipe = hotpath.PassPipeline(model, 'train', shard) if (pipelined and graphed is None) else None
+    pipe = pipe_main = hotpath.PassPipeline(model, 'train', shard) if (pipelined and graphed is None) else None
     side_timers = []
 
-    def step(timed):
+    def step(timed, sequential=False):
+        # ``sequential``: this step in the schedule N > 1 runs by default (the pass prepared after the previous one has trained)
         timer = hotpath.StageTimer(timed)
-        if graphed is not None:
+        pipe = None if sequential else pipe_main
+        if graphed is not None and not sequential:
             timer.mark('start')
             loss, _acc = graphed.step()                          # two graph launches: this pass's training half, the next pass's preparation
             timer.mark('pass(hipGraphs: training half; the next preparation beside it)')
@@ -600,7 +674,7 @@ def main():
                           'survey_8d_bytes_with_the_border_written': k1_bytes_8d,
                           'frac_on_survey_8d_bytes': k1_bytes_8d / (k1_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                           'stage_ms_in_timed_region': stage_ms.get('border_bfs+N_anchors'),
-                          'note': 'issue- and barrier-bound on one 1024-thread workgroup per CU around a 125 KB LDS bitmap (profiles/r03_khop1_pmc.json), '
+                          'note': 'issue- and barrier-bound on one 1024-thread workgroup per CU around a 125 KB LDS bitmap (profiles/r04_khop1_pmc.json), '
                                   'not memory-bound; the lists come from L2 / Infinity Cache (the CSR is 88 MB)'})
     if hp['use_position']:
         src = model.anchors_pos_ext[0].to(torch.int32).contiguous()
@@ -661,6 +735,50 @@ def main():
                        'valu_instructions_per_64_pairs': round(c['valu_instructions_per_64_pairs']),
                        'source': 'profiles/' + os.path.basename(pj) + ' (rocprofv3 --pmc, committed measurement of the external-side launch; '
                                  '%d wavefronts per SIMD; SIMD busy = 4 x SQ_ACTIVE_INST_VALU / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs))' % wps}
+    # ---- N = 1: measured beside the headline, in this process -----------------------------------------
+    sequential_ms = shard_line = configs_obj = None
+    if world == 1 and not args.no_extras and graphed is None:
+        # (1) the schedule `--gpus 8` runs by default: sequential passes, two-stream preparation -- what projection.weak_* uses
+        for _ in range(2):
+            step(False, sequential=True)
+        torch.cuda.synchronize()
+        t_s = time.perf_counter()
+        n_seq = max(5, min(args.steps, 10))
+        for _ in range(n_seq):
+            step(False, sequential=True)
+        torch.cuda.synchronize()
+        sequential_ms = 1e3 * (time.perf_counter() - t_s) / n_seq
+        # (2) the strong-scaling shard of BASELINE configs[3] as worded (50k subgraphs over 8 GPUs): rank 0's 6 250, live
+        if S == 50_000:
+            try:
+                shard_line = time_shard(g, subs[:S // 8], labels[:S // 8].clone(), emb, hp, steps=max(10, args.steps), warmup=3,
+                                        depth=max(1, args.pipeline_depth))
+                shard_line['stages_ms'].setdefault('optimizer', stage_ms.get('optimizer', 0.5))
+            except Exception as ex:
+                shard_line = None
+                print('shard6250 not measured: %r' % (ex,), file=sys.stderr)
+        # (3) the batch-sized training steps of the other BASELINE configurations (stand-ins: SURVEY 8, statistics unverified),
+        # replayed from a hipGraph and eager, with the kernels one step launches
+        from subgnn_amd import standins
+        configs_obj = {'note': 'BASELINE.json configs[0,1,2,4] as stand-in datasets in the reference\'s file formats (subgnn_amd/standins.py), each '
+                               'built, prepared and trained in THIS process after the timed region: ms per batch-sized training step (fwd + '
+                               'bwd + clip + Adam), replayed from a hipGraph (the trainer\'s default) and eager; kernels_per_step by torch\'s '
+                               'profiler on one eager step (None if the profiler could not run)'}
+        t_x = time.perf_counter()
+        for key, name in (('configs[0]', 'density_n'), ('configs[1]', 'ppi_bp'), ('configs[2]', 'hpo_metab'), ('configs[4]', 'em_user')):
+            if time.perf_counter() - t_x > args.extras_budget_s:
+                configs_obj[key] = {'skipped': 'extras budget of %.0f s used up' % args.extras_budget_s}
+                continue
+            try:
+                t_c = time.perf_counter()
+                line = standins.bench_config(name, steps=20, warmup=5)
+                configs_obj[key] = {'standin': name, 'workload': line['config']['workload'], 'batch': line['config']['cc_ids_shape'],
+                                    'ms_per_step_replayed': round(line['ms_per_step'], 3), 'ms_per_step_eager': round(line['eager']['ms_per_step'], 3),
+                                    'subgraphs_per_s': round(line['value']), 'kernels_per_step': line['kernels_per_step'],
+                                    'prepare_data_s': line['prepare_data_s'], 'wall_s': round(time.perf_counter() - t_c, 1)}
+            except Exception as ex:
+                configs_obj[key] = {'standin': name, 'error': repr(ex)[:300]}
+        torch.cuda.empty_cache()
     result = {
         'metric': 'subgraphs/sec fwd+bwd (all 3 channels on) + achieved HBM GB/s',
         'value': total_subgraphs * args.steps / elapsed, 'unit': 'subgraphs/s', 'n_gpus': world, 'steps': args.steps,
@@ -723,7 +841,13 @@ def main():
         'first_pass_ms': round(first_pass_ms, 2), 'second_pass_ms': round(second_pass_ms, 2),
     }
     if world == 1 and args.scaling == 'weak':
-        result['projection'] = projection(args, result, model, S)
+        result['projection'] = projection(args, result, model, S, sequential_ms, shard_line)
+    if sequential_ms is not None:
+        result['sequential_ms_per_step'] = round(sequential_ms, 3)
+    if shard_line is not None:
+        result['shard6250'] = shard_line
+    if configs_obj is not None:
+        result['configs'] = configs_obj
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
             from oracle import cpu_baseline

@@ -38,7 +38,7 @@ extern "C" {
 #define SGNN_ERR_LAUNCH         -4   /* hipGetLastError() after a launch */
 #define SGNN_ERR_UNSUPPORTED_D  -5   /* embedding width not supported by the vector path */
 
-#define SGNN_ABI_VERSION 7
+#define SGNN_ABI_VERSION 8
 int sgnn_abi_version(void);
 /* last hip error string for SGNN_ERR_LAUNCH (static storage) */
 const char* sgnn_last_error(void);
@@ -320,13 +320,16 @@ int sgnn_min_hops_to_sets(const uint8_t* dist, int64_t n_sources, int64_t max_id
  * table: after every BFS level each set ORs its members' new frontier words and records the level for
  * the sources it sees for the first time.  out: (n_sets, n_sources) float32.
  * All max_hops levels are enqueued without a host synchronisation (levels behind the last productive one exit at
- * once).  out_status (nullable, int32[2], device): [0] = the last level that found anything, [1] = 1 if level
- * max_hops itself still did -- the caller enqueued too few levels and the result may be incomplete.  A caller that
- * repeats the same search (the same graph and anchors every pass) can read [0] once and pass max_hops = [0] + a
- * margin afterwards, checking [1] at its next synchronisation point. */
+ * once).  out_status (nullable, int32[4], device): [0] = the last level that found anything, [1] = 1 if level
+ * max_hops itself still did -- the caller enqueued too few levels and the result may be incomplete, [2] = the first
+ * level that pulled (0: none), [3] = 0.  A caller that repeats the same search (the same graph and anchors every pass)
+ * can read [0] once and pass max_hops = [0] + a margin afterwards, checking [1] at its next synchronisation point.
+ * push_levels: the levels that may still push -- each costs a commit launch besides its expand launch; beyond them a
+ * level pulls whatever its frontier (one launch: a pull level writes the next version of the seen rows itself).
+ * < 0: all of them.  Results do not depend on it; a repeated search passes [2] + a margin. */
 int64_t sgnn_bfs_min_hops_workspace_bytes(int64_t max_id, int64_t n_sources, int max_hops, int64_t n_sets);
 int sgnn_bfs_min_hops_to_sets(const int64_t* rowptr, const int32_t* col, int64_t nnz, int64_t max_id,
-                              const int32_t* sources, int64_t n_sources, int max_hops, int pull_alpha,
+                              const int32_t* sources, int64_t n_sources, int max_hops, int pull_alpha, int push_levels,
                               const int64_t* set_ptr, const int32_t* set_nodes, int64_t n_sets,
                               float* out, int32_t* out_status, void* workspace, int64_t workspace_bytes, void* stream);
 

@@ -64,7 +64,7 @@ SIGNATURES = {
     'sgnn_sp_similarity_dense': (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_ptr, c_ptr]),
     'sgnn_bfs_hops_workspace_bytes': (c_i64, [c_i64, c_i64, c_int]),
     'sgnn_bfs_min_hops_workspace_bytes': (c_i64, [c_i64, c_i64, c_int, c_i64]),
-    'sgnn_bfs_min_hops_to_sets': (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_i64, c_int, c_int, c_ptr, c_ptr, c_i64, c_ptr, c_ptr,
+    'sgnn_bfs_min_hops_to_sets': (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_i64, c_int, c_int, c_int, c_ptr, c_ptr, c_i64, c_ptr, c_ptr,
                                           c_ptr, c_i64, c_ptr]),
     'sgnn_bfs_hops': (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_i64, c_int, c_int, c_int, c_ptr, c_ptr, c_i64, c_ptr]),
     'sgnn_min_hops_to_sets': (c_int, [c_ptr, c_i64, c_i64, c_int, c_ptr, c_ptr, c_i64, c_ptr, c_ptr]),
@@ -155,7 +155,7 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the header and the library disagree
         fn.restype = res
         fn.argtypes = args
-    if lib.sgnn_abi_version() != 7:
+    if lib.sgnn_abi_version() != 8:
         raise SubgnnHipError('ABI version mismatch')
     _lib = lib
     return lib

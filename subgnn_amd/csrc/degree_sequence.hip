@@ -74,7 +74,9 @@ __device__ static inline int32_t ds_wave_sum(int32_t v) {
 
 // hits of every member's neighbour list in the set's table -> cnt (per lane = per member); SELF:
 // count the self-loop entries of each list here (the caller has no per-node self-loop table)
-template <bool P1, bool SELF>
+// INFL: 256-byte loads in flight while a long list is streamed (DS_INFLIGHT; the SEARCH instantiations never stream a list of
+// DS_SEARCH = 512 entries or more, so their full-block loop would be dead weight in the register budget: they take 8)
+template <bool P1, bool SELF, int INFL = DS_INFLIGHT>
 __device__ __forceinline__ void ds_count(const int32_t* __restrict__ col, const int32_t* __restrict__ col_sorted,
                                          const int32_t* hash, uint32_t k24, int P, int lane, int n, int32_t v,
                                          bool dup, int32_t deg, uint32_t r0, int32_t& cnt, int32_t& selfc)
@@ -179,12 +181,12 @@ __device__ __forceinline__ void ds_count(const int32_t* __restrict__ col, const 
             base += i4 * 4;
         }
 #endif
-        for (; base + 64 * DS_INFLIGHT <= m_deg; base += 64 * DS_INFLIGHT) {   // full blocks: DS_INFLIGHT x 256 B loads in flight
-            int32_t u[DS_INFLIGHT];
+        for (; base + 64 * INFL <= m_deg; base += 64 * INFL) {   // full blocks: INFL x 256 B loads in flight
+            int32_t u[INFL];
 #pragma unroll
-            for (int q = 0; q < DS_INFLIGHT; ++q) u[q] = list[base + q * 64 + lane];
+            for (int q = 0; q < INFL; ++q) u[q] = list[base + q * 64 + lane];
 #pragma unroll
-            for (int q = 0; q < DS_INFLIGHT; ++q) {
+            for (int q = 0; q < INFL; ++q) {
                 tot += (int32_t)__popcll(__ballot(ds_probe<P1>(hash, u[q], k24, P) != 0));
                 if (SELF) st += (int32_t)__popcll(__ballot(u[q] == m_v));
             }
@@ -260,8 +262,10 @@ __device__ __forceinline__ void ds_count(const int32_t* __restrict__ col, const 
 #define DS_MIN_WAVES 5         // wavefronts per SIMD the register allocation aims for (86 VGPRs -> 5); 4 / 5 / 6 / 7 / 8 measured 0.392 / 0.391 / 0.396 / 0.398 / 0.401 ms: not occupancy-bound
 #endif
 #ifndef DS_MIN_WAVES_SEARCH
-#define DS_MIN_WAVES_SEARCH 4  // the SEARCH instantiations keep phase A0's slot bookkeeping live across the streaming phases: under the 5-wave
-#endif                         // budget (96 VGPRs) they spilled 4 registers to scratch (20 B per lane: 59 MB written per launch for 8 MB of output)
+#define DS_MIN_WAVES_SEARCH 5  // the SEARCH instantiations: 85 VGPRs with 8 loads in flight (INFL below).  With DS_INFLIGHT = 32 in flight they
+#endif                         // needed 102: under this 5-wave budget (96) round 4's build spilled 4 registers to scratch -- 20 B per lane, 59 MB
+                               // written per launch for 8 MB of output -- and un-spilled at 4 waves the launch was SLOWER (0.243 ms back to back
+                               // against 0.212 spilled: it is latency-bound, occupancy matters more than 5 scratch dwords)
 // SEARCH: instantiation given the row-sorted CSR (long lists searched) -- the same code with col_sorted == nullptr
 // would do, but profiles should tell the two forms of the launch apart.
 template <bool SORTED, bool FEW = false, bool SEARCH = false>
@@ -275,6 +279,7 @@ __global__ __launch_bounds__(64 * DS_WAVES) __attribute__((amdgpu_waves_per_eu(S
     // one hash table per wavefront; a wavefront's LDS operations execute in issue order, so the
     // waves of a workgroup never need a workgroup barrier (they work on different sets)
     __shared__ int32_t hash_all[DS_WAVES][DS_HASH];
+    constexpr int INFL = SEARCH ? 8 : DS_INFLIGHT;
     const int lane = threadIdx.x & 63;
     int32_t* hash = hash_all[threadIdx.x >> 6];
     for (int64_t si = (int64_t)blockIdx.x * DS_WAVES + (threadIdx.x >> 6); si < n_sets; si += (int64_t)gridDim.x * DS_WAVES) {
@@ -334,11 +339,11 @@ __global__ __launch_bounds__(64 * DS_WAVES) __attribute__((amdgpu_waves_per_eu(S
         int32_t cnt = 0, selfc = 0;
         if (self_loops != nullptr) {
             if (lane < n) selfc = self_loops[v];
-            if (P <= 1) ds_count<true, false>(col, SEARCH ? col_sorted : nullptr, hash, k24, P, lane, n, v, dup, deg, r0, cnt, selfc);
-            else ds_count<false, false>(col, SEARCH ? col_sorted : nullptr, hash, k24, P, lane, n, v, dup, deg, r0, cnt, selfc);
+            if (P <= 1) ds_count<true, false, INFL>(col, SEARCH ? col_sorted : nullptr, hash, k24, P, lane, n, v, dup, deg, r0, cnt, selfc);
+            else ds_count<false, false, INFL>(col, SEARCH ? col_sorted : nullptr, hash, k24, P, lane, n, v, dup, deg, r0, cnt, selfc);
         } else {
-            if (P <= 1) ds_count<true, true>(col, SEARCH ? col_sorted : nullptr, hash, k24, P, lane, n, v, dup, deg, r0, cnt, selfc);
-            else ds_count<false, true>(col, SEARCH ? col_sorted : nullptr, hash, k24, P, lane, n, v, dup, deg, r0, cnt, selfc);
+            if (P <= 1) ds_count<true, true, INFL>(col, SEARCH ? col_sorted : nullptr, hash, k24, P, lane, n, v, dup, deg, r0, cnt, selfc);
+            else ds_count<false, true, INFL>(col, SEARCH ? col_sorted : nullptr, hash, k24, P, lane, n, v, dup, deg, r0, cnt, selfc);
         }
         cnt += selfc;                                        // a self loop counts twice (networkx)
         int32_t full = deg + selfc;

@@ -64,6 +64,23 @@ extern "C" int sgnn_sp_similarity_dense(const double* apsp, int64_t n_cols,
 //   commit : new = next & ~seen; seen |= new; frontier = new; dist[src][node] = level for the
 //            new bits; flags[level] says whether any bit was new (later levels exit early);
 //            fvol[level] = sum over new frontier words of the node's degree.
+// Round 5: a PULL level is ONE launch and the search stays in pull mode once it has entered it.
+//   * what a pulling node needs from a neighbour u is "has source s reached u before this level" -- seen[u], not the
+//     frontier: for a node v that s has not reached, a neighbour with dist(u, s) <= level - 2 cannot exist (v would have been
+//     reached a level earlier), so seen and frontier give the same answer.  The level therefore reads ONE version of the
+//     seen rows and writes the next version into another buffer (seen' = seen | new): no next[] accumulation, no commit pass
+//     over three 32 MB arrays per level (30-34 us each on the benchmark), no zeroing.
+//   * the three per-node arrays (seen / next / frontier) rotate as versions: pull number k reads B[k % 3], writes B[(k+1) % 3];
+//     B[(k+2) % 3] -- the version before -- is what the fused set reduction of the NEXT launch subtracts to get the bits that
+//     were new (it runs as that launch's prologue, while the launch already overwrites the oldest version: two buffers would
+//     race).  Rows of nodes that every source has reached are never rewritten (the done bitmap skips them): they go stale in
+//     two of the three buffers, which nobody notices -- all neighbours of a complete node are complete one level later and
+//     skipped too, the set reduction masks with what a set has already recorded, and the finalisation ORs the three versions
+//     (every version is a subset of the truth and the newest write of a row is exact).
+//   * push levels walk the frontier-node BITMAP (125 KB) to find their nodes instead of reading every node's frontier row
+//     (32 MB): level 1 of the benchmark's search went from 55 us to the time of its 183 lists.
+//   * host side: a commit launch is enqueued only for the first ``push_levels`` levels (the caller's hint, from the status of
+//     an earlier search: [2] = the level that switched to pull); beyond them the device pulls whatever the frontier's size.
 // ---------------------------------------------------------------------------------------------
 // Row stride (in 64-bit words) of the per-node arrays seen / frontier / next: three words (129-192 sources, the benchmark's
 // 183) are padded to four -- a pull level gathers one row per neighbour, and a 24-byte row straddles two 32-byte sectors
@@ -108,6 +125,9 @@ __global__ void msbfs_seed_kernel(const int32_t* __restrict__ sources, int64_t n
 #define MSBFS_HUB_DEGREE 128     // push: lists this long go to the whole workgroup
 #define MSBFS_HUB_SLOTS 128
 #define MSBFS_PULL_HUB_DEGREE 512
+#ifndef MSBFS_PULL_CHECK
+#define MSBFS_PULL_CHECK 2        // pull: rounds of 16 neighbours between two tests of "is anything still missing" (round 4: 8)
+#endif
 
 __device__ __forceinline__ uint32_t msbfs_row_or32(uint32_t v)
 {
@@ -136,14 +156,23 @@ __device__ __forceinline__ uint64_t msbfs_group_or(uint64_t x)
 __device__ __forceinline__ void msbfs_set_reduce_item(
     const uint64_t* __restrict__ frontier, int64_t n_words, int64_t n_sources,
     const int64_t* __restrict__ set_ptr, const int32_t* __restrict__ set_nodes,
-    uint64_t* __restrict__ set_seen, float* __restrict__ out, int level, int64_t rs, int64_t t)
+    uint64_t* __restrict__ set_seen, float* __restrict__ out, int level, int64_t rs, int64_t t,
+    const uint64_t* __restrict__ older = nullptr)
 {
+    // ``older`` == nullptr: ``frontier`` holds the level's new bits (a push level's commit wrote them); else ``frontier`` is the
+    // seen version the level wrote and ``older`` the one it read: the new bits are their difference
     const int64_t r = t / n_words, w = t % n_words;
     uint64_t acc = 0;
     const int64_t left_ = n_sources - w * 64;
     const uint64_t full_ = left_ >= 64 ? ~0ull : ((1ull << left_) - 1);
     const uint64_t have_ = set_seen[t];
     if ((have_ & full_) == full_) return;                    // every source has reached the set: nothing left to record
+    if (older) {
+        for (int64_t i = set_ptr[r]; i < set_ptr[r + 1]; ++i) {
+            const int64_t o = (int64_t)set_nodes[i] * rs + w;
+            acc |= frontier[o] & ~older[o];
+        }
+    } else
     for (int64_t i = set_ptr[r]; i < set_ptr[r + 1]; ++i) acc |= frontier[(int64_t)set_nodes[i] * rs + w];
     const uint64_t fresh = acc & ~have_;
     if (fresh) {
@@ -166,18 +195,43 @@ struct MsbfsSets {                 // the fused set reduction's operands (n_sets
     float* out;
 };
 
-__global__ __launch_bounds__(256) void msbfs_expand_kernel(
+struct MsbfsBufs { uint64_t* b[3]; };      // seen, next, frontier: in pull mode three versions of the seen rows (see above)
+
+// Which form level ``level`` takes, the same answer in every launch that asks: pull(l) for l >= 2 is sticky --
+// pull(l - 1), or the frontier volume level l - 1 left behind exceeds the threshold, or l lies beyond the levels the
+// host enqueued a commit launch for.  pulls_before = number of pull levels in front of ``level`` (the version rotation's k).
+__device__ __forceinline__ void msbfs_mode(const unsigned long long* __restrict__ fvol, unsigned long long pull_above,
+                                           int push_levels, int level, bool& pull, bool& prev_pull, int& pulls_before)
+{
+    bool p = false, pp = false;
+    int k = 0;
+    for (int l = 2; l <= level; ++l) {
+        const bool pl = p || l > push_levels || (pull_above != ~0ull && fvol[l - 1] > pull_above);
+        if (l < level) k += pl ? 1 : 0;
+        pp = p;
+        p = pl;
+    }
+    pull = p; prev_pull = (level >= 2) ? pp : false; pulls_before = k;
+}
+
+__global__ __launch_bounds__(256) void msbfs_level_kernel(
     const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col, int64_t n_ids, int64_t n_words,
-    int64_t n_sources, const uint64_t* __restrict__ seen, const uint64_t* __restrict__ frontier,
-    uint64_t* __restrict__ next, const int32_t* __restrict__ flags, const unsigned long long* __restrict__ fvol,
-    unsigned long long pull_above, int level, const uint32_t* __restrict__ fnode, unsigned long long sparse_below,
-    const uint32_t* __restrict__ fdone, int64_t rs, MsbfsSets sets)
+    int64_t n_sources, MsbfsBufs B, int32_t* __restrict__ flags, const unsigned long long* __restrict__ fvol,
+    unsigned long long pull_above, int push_levels, int level, const uint32_t* __restrict__ fnode,
+    uint32_t* __restrict__ fdone, int64_t rs, MsbfsSets sets, uint8_t* __restrict__ dist, int64_t ss, int64_t sv)
 {
     if (level > 1 && flags[level - 1] == 0) return;          // previous level found nothing (nothing to reduce either)
+    bool pull, prev_pull;
+    int k;
+    msbfs_mode(fvol, pull_above, push_levels, level, pull, prev_pull, k);
     if (sets.n_sets > 0) {                                   // the previous level's set reduction (level 0: the seeds)
         const int64_t total = sets.n_sets * n_words;
+        // the previous level pushed (or seeded): its commit left the new bits in B[2]; it pulled: it wrote version B[k % 3]
+        // from B[(k + 2) % 3] -- neither is written by this launch (a pull writes B[(k + 1) % 3], a push B[1] with k = 0)
+        const uint64_t* cur = prev_pull ? B.b[k % 3] : B.b[2];
+        const uint64_t* old = prev_pull ? B.b[(k + 2) % 3] : nullptr;
         for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x)
-            msbfs_set_reduce_item(frontier, n_words, n_sources, sets.set_ptr, sets.set_nodes, sets.set_seen, sets.out, level - 1, rs, t);
+            msbfs_set_reduce_item(cur, n_words, n_sources, sets.set_ptr, sets.set_nodes, sets.set_seen, sets.out, level - 1, rs, t, old);
     }
     const int sub = threadIdx.x & 15;
     // node ids are dealt out to the workgroups round-robin (group g of workgroup b takes b + G*(g + 16 i)):
@@ -185,22 +239,22 @@ __global__ __launch_bounds__(256) void msbfs_expand_kernel(
     // each other at the low ids -- land in different workgroups
     const int64_t group = blockIdx.x + (int64_t)gridDim.x * (threadIdx.x >> 4);
     const int64_t n_groups = (int64_t)gridDim.x * (blockDim.x >> 4);
-    const bool pull = level > 1 && pull_above != ~0ull && fvol[level - 1] > pull_above;
-    const bool sparse_frontier = fvol[level - 1] < sparse_below;
     __shared__ int32_t s_hub[MSBFS_HUB_SLOTS];
     __shared__ int s_nhub;
     __shared__ unsigned long long s_acc[MSBFS_WCHUNK];
     if (threadIdx.x == 0) s_nhub = 0;
     __syncthreads();
     if (!pull) {
+        const uint64_t* __restrict__ seen = B.b[0];
+        uint64_t* __restrict__ next = B.b[1];
+        const uint64_t* __restrict__ frontier = B.b[2];
         // A frontier node's list is streamed by its 16-lane group -- except long lists (hubs: a BA graph
         // of 1M nodes has lists of 10k+ entries, and hubs are on the frontier from level 1 on), which one
         // group would walk for a millisecond while the rest of the chip is done: those are parked in LDS
-        // and streamed by the whole workgroup afterwards.
+        // and streamed by the whole workgroup afterwards.  Frontier nodes are found in the frontier-node bitmap
+        // (one bit per node, written by the seed / commit launch), not by reading every node's row.
         for (int64_t v = group; v < n_ids; v += n_groups) {
-            uint64_t any = 0;
-            for (int64_t w = 0; w < n_words; ++w) any |= frontier[v * rs + w];
-            if (any == 0) continue;
+            if (!((fnode[v >> 5] >> (v & 31)) & 1u)) continue;
             // one pass over the neighbour list for all source words: col[] is read once, and the
             // n_words seen/next words of a neighbour are contiguous
             const int64_t r0 = rowptr[v], r1 = rowptr[v + 1];
@@ -238,73 +292,108 @@ __global__ __launch_bounds__(256) void msbfs_expand_kernel(
         }
         return;
     }
+    // ---- pull: version k -> version k + 1 of the seen rows, in one launch ----------------------------------------------
+    const uint64_t* __restrict__ in = B.b[k % 3];
+    uint64_t* __restrict__ out = B.b[(k + 1) % 3];
+    bool found = false;                                      // this thread recorded a new bit
     for (int64_t v = group; v < n_ids; v += n_groups) {
-        // one bit per node: every source has reached it (kept by commit) -- from level 3-4 on that is
-        // almost every node, and the test replaces the row-pointer and seen-word loads of the skip path
+        // one bit per node: every source has reached it -- from level 3-4 on that is almost every node; such a row is
+        // not read, not rewritten (it goes stale in the other versions: harmless, see the header)
         if ((fdone[v >> 5] >> (v & 31)) & 1u) continue;
         const int64_t r0 = rowptr[v], r1 = rowptr[v + 1];
-        for (int64_t w0 = 0; w0 < n_words; w0 += MSBFS_WCHUNK) {
-            uint64_t need[MSBFS_WCHUNK], acc[MSBFS_WCHUNK];
+        bool all_done = true, parked = false;
+        for (int64_t w0 = 0; w0 < rs && !parked; w0 += MSBFS_WCHUNK) {
+            uint64_t have[MSBFS_WCHUNK], need[MSBFS_WCHUNK], acc[MSBFS_WCHUNK];
             uint64_t missing = 0;
+            if (rs == 4) {
+                const ulonglong2 s01 = *reinterpret_cast<const ulonglong2*>(&in[v * 4]);
+                const ulonglong2 s23 = *reinterpret_cast<const ulonglong2*>(&in[v * 4 + 2]);
+                have[0] = s01.x; have[1] = s01.y; have[2] = s23.x; have[3] = s23.y;
+            } else {
 #pragma unroll
-            for (int k = 0; k < MSBFS_WCHUNK; ++k) {
-                const int64_t w = w0 + k;
+                for (int q = 0; q < MSBFS_WCHUNK; ++q) have[q] = (w0 + q < rs) ? in[v * rs + w0 + q] : 0;
+            }
+#pragma unroll
+            for (int q = 0; q < MSBFS_WCHUNK; ++q) {
+                const int64_t w = w0 + q;
                 uint64_t valid = 0;
                 if (w < n_words) {
                     const int64_t left = n_sources - w * 64;
                     valid = left >= 64 ? ~0ull : ((1ull << left) - 1);
-                    valid &= ~seen[v * rs + w];
                 }
-                need[k] = valid;
-                acc[k] = 0;
-                missing |= valid;
+                need[q] = valid & ~have[q];
+                acc[q] = 0;
+                missing |= need[q];
             }
-            if (missing == 0) continue;                      // this node has every source of the chunk
-            if (r1 - r0 >= MSBFS_PULL_HUB_DEGREE) {          // long list: the whole workgroup, below
+            if (missing != 0 && r1 - r0 >= MSBFS_PULL_HUB_DEGREE) {          // long list: the whole workgroup, below
                 int slot = 0;
                 if (sub == 0) slot = atomicAdd(&s_nhub, 1);
                 slot = __shfl(slot, (threadIdx.x & 63) & ~15, 64);
                 if (slot < MSBFS_HUB_SLOTS) {
                     if (sub == 0) s_hub[slot] = (int32_t)v;
-                    break;                                   // all chunks of this node are done there
+                    parked = true;                           // all chunks of this node are done there
+                    break;
                 }
             }
-            int since = 0;
-            for (int64_t e = r0 + sub; e < r1 + sub; e += 16) {          // uniform trip count per group
-                if (e < r1) {
-                    const int64_t u = col[e];
-                    // one bit per node says whether it is on the frontier at all: a 125 KB table that
-                    // stays in L2, consulted before the 24-byte gather from the 24 MB word array -- while the
-                    // frontier is sparse (once most nodes are on it the test only adds a load)
-                    if (!sparse_frontier || ((fnode[u >> 5] >> (u & 31)) & 1u)) {
+            if (missing != 0) {
+                int since = 0;
+                for (int64_t e = r0 + sub; e < r1 + sub; e += 16) {          // uniform trip count per group
+                    if (e < r1) {
+                        const int64_t u = col[e];
                         if (rs == 4) {                       // a padded row = one 32-byte sector: two 16-byte loads, no per-word tests
-                            const ulonglong2 f01 = *reinterpret_cast<const ulonglong2*>(&frontier[u * 4]);
-                            const ulonglong2 f23 = *reinterpret_cast<const ulonglong2*>(&frontier[u * 4 + 2]);
+                            const ulonglong2 f01 = *reinterpret_cast<const ulonglong2*>(&in[u * 4]);
+                            const ulonglong2 f23 = *reinterpret_cast<const ulonglong2*>(&in[u * 4 + 2]);
                             acc[0] |= f01.x; acc[1] |= f01.y; acc[2] |= f23.x; acc[3] |= f23.y;
                         } else {
 #pragma unroll
-                            for (int k = 0; k < MSBFS_WCHUNK; ++k)
-                                if (need[k]) acc[k] |= frontier[u * rs + w0 + k];  // completed words are not read
+                            for (int q = 0; q < MSBFS_WCHUNK; ++q)
+                                if (need[q]) acc[q] |= in[u * rs + w0 + q];      // completed words are not read
+                        }
+                    }
+                    if (++since == MSBFS_PULL_CHECK) {       // every MSBFS_PULL_CHECK x 16 neighbours: anything still missing?
+                        since = 0;
+                        uint64_t left = 0;
+#pragma unroll
+                        for (int q = 0; q < MSBFS_WCHUNK; ++q) { acc[q] = msbfs_group_or(acc[q]); left |= need[q] & ~acc[q]; }
+                        if (left == 0) break;
+                    }
+                }
+            }
+            uint64_t fresh[MSBFS_WCHUNK];
+#pragma unroll
+            for (int q = 0; q < MSBFS_WCHUNK; ++q) {
+                acc[q] = missing != 0 ? msbfs_group_or(acc[q]) : 0;
+                fresh[q] = acc[q] & need[q];
+                if (need[q] & ~fresh[q]) all_done = false;
+            }
+            // the next version of the row, every word of it (the target buffer holds an older version)
+            if (sub == 0) {
+                if (rs == 4) {
+                    *reinterpret_cast<ulonglong2*>(&out[v * 4]) = make_ulonglong2(have[0] | fresh[0], have[1] | fresh[1]);
+                    *reinterpret_cast<ulonglong2*>(&out[v * 4 + 2]) = make_ulonglong2(have[2] | fresh[2], have[3] | fresh[3]);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < MSBFS_WCHUNK; ++q)
+                        if (w0 + q < rs) out[v * rs + w0 + q] = have[q] | fresh[q];
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < MSBFS_WCHUNK; ++q) {
+                if (sub == q && fresh[q]) {
+                    found = true;
+                    if (dist) {
+                        uint64_t bits = fresh[q];
+                        while (bits) {
+                            const int b = __ffsll((unsigned long long)bits) - 1;
+                            bits &= bits - 1;
+                            const int64_t sidx = (w0 + q) * 64 + b;
+                            if (sidx < n_sources) dist[sidx * ss + v * sv] = (uint8_t)level;
                         }
                     }
                 }
-                if (++since == 8) {                          // every 128 neighbours: anything still missing?
-                    since = 0;
-                    uint64_t left = 0;
-#pragma unroll
-                    for (int k = 0; k < MSBFS_WCHUNK; ++k) { acc[k] = msbfs_group_or(acc[k]); left |= need[k] & ~acc[k]; }
-                    if (left == 0) break;
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < MSBFS_WCHUNK; ++k) {
-                acc[k] = msbfs_group_or(acc[k]);
-                if (sub == k && w0 + k < n_words) {
-                    const uint64_t m = acc[k] & need[k];
-                    if (m) next[v * rs + w0 + k] = m;   // next[] is all zero before a pull level
-                }
             }
         }
+        if (!parked && all_done && sub == 0) atomicOr(&fdone[v >> 5], 1u << (v & 31));
     }
     // parked long lists: 256 lanes per list, the words OR-ed through LDS
     __syncthreads();
@@ -312,59 +401,85 @@ __global__ __launch_bounds__(256) void msbfs_expand_kernel(
     for (int h = 0; h < n_hub; ++h) {
         const int64_t v = s_hub[h];
         const int64_t r0 = rowptr[v], r1 = rowptr[v + 1];
-        for (int64_t w0 = 0; w0 < n_words; w0 += MSBFS_WCHUNK) {
-            uint64_t need[MSBFS_WCHUNK], acc[MSBFS_WCHUNK];
+        bool all_done = true;
+        for (int64_t w0 = 0; w0 < rs; w0 += MSBFS_WCHUNK) {
+            uint64_t have[MSBFS_WCHUNK], need[MSBFS_WCHUNK], acc[MSBFS_WCHUNK];
             uint64_t missing = 0;
 #pragma unroll
-            for (int k = 0; k < MSBFS_WCHUNK; ++k) {
-                const int64_t w = w0 + k;
+            for (int q = 0; q < MSBFS_WCHUNK; ++q) {
+                const int64_t w = w0 + q;
                 uint64_t valid = 0;
+                have[q] = w < rs ? in[v * rs + w] : 0;
                 if (w < n_words) {
                     const int64_t left = n_sources - w * 64;
                     valid = left >= 64 ? ~0ull : ((1ull << left) - 1);
-                    valid &= ~seen[v * rs + w];
                 }
-                need[k] = valid;
-                acc[k] = 0;
-                missing |= valid;
+                need[q] = valid & ~have[q];
+                acc[q] = 0;
+                missing |= need[q];
             }
-            if (missing == 0) continue;                      // uniform over the workgroup
             if (threadIdx.x < MSBFS_WCHUNK) s_acc[threadIdx.x] = 0;
             __syncthreads();
-            for (int64_t e = r0 + threadIdx.x; e < r1; e += blockDim.x) {
-                const int64_t u = col[e];
-                if (!sparse_frontier || ((fnode[u >> 5] >> (u & 31)) & 1u)) {
+            if (missing != 0) {                              // uniform over the workgroup
+                for (int64_t e = r0 + threadIdx.x; e < r1; e += blockDim.x) {
+                    const int64_t u = col[e];
                     if (rs == 4) {
-                        const ulonglong2 f01 = *reinterpret_cast<const ulonglong2*>(&frontier[u * 4]);
-                        const ulonglong2 f23 = *reinterpret_cast<const ulonglong2*>(&frontier[u * 4 + 2]);
+                        const ulonglong2 f01 = *reinterpret_cast<const ulonglong2*>(&in[u * 4]);
+                        const ulonglong2 f23 = *reinterpret_cast<const ulonglong2*>(&in[u * 4 + 2]);
                         acc[0] |= f01.x; acc[1] |= f01.y; acc[2] |= f23.x; acc[3] |= f23.y;
                     } else {
 #pragma unroll
-                        for (int k = 0; k < MSBFS_WCHUNK; ++k)
-                            if (need[k]) acc[k] |= frontier[u * rs + w0 + k];
+                        for (int q = 0; q < MSBFS_WCHUNK; ++q)
+                            if (need[q]) acc[q] |= in[u * rs + w0 + q];
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < MSBFS_WCHUNK; ++q)
+                    if (acc[q]) atomicOr(&s_acc[q], (unsigned long long)acc[q]);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < MSBFS_WCHUNK; ++q) {          // (static register indices: thread q finishes word q)
+                if ((int)threadIdx.x == q && w0 + q < rs) {
+                    const uint64_t m = s_acc[q] & need[q];
+                    out[v * rs + w0 + q] = have[q] | m;
+                    if (m) {
+                        found = true;
+                        if (dist) {
+                            uint64_t bits = m;
+                            while (bits) {
+                                const int b = __ffsll((unsigned long long)bits) - 1;
+                                bits &= bits - 1;
+                                const int64_t sidx = (w0 + q) * 64 + b;
+                                if (sidx < n_sources) dist[sidx * ss + v * sv] = (uint8_t)level;
+                            }
+                        }
                     }
                 }
             }
 #pragma unroll
-            for (int k = 0; k < MSBFS_WCHUNK; ++k)
-                if (acc[k]) atomicOr(&s_acc[k], (unsigned long long)acc[k]);
-            __syncthreads();
-            if (threadIdx.x < MSBFS_WCHUNK && w0 + threadIdx.x < n_words) {
-                const uint64_t m = s_acc[threadIdx.x] & need[threadIdx.x];
-                if (m) next[v * rs + w0 + threadIdx.x] = m;
-            }
+            for (int q = 0; q < MSBFS_WCHUNK; ++q)
+                if (need[q] & ~s_acc[q]) all_done = false;   // (every thread reads the same words)
             __syncthreads();
         }
+        if (all_done && threadIdx.x == 0) atomicOr(&fdone[v >> 5], 1u << (v & 31));
     }
+    if (__syncthreads_or(found ? 1 : 0) && threadIdx.x == 0) atomicOr(&flags[level], 1);
 }
 
 __global__ __launch_bounds__(256) void msbfs_commit_kernel(
     const int64_t* __restrict__ rowptr, int64_t n_ids, int64_t n_words, int64_t n_sources, uint64_t* __restrict__ seen,
     uint64_t* __restrict__ frontier, uint64_t* __restrict__ next, uint8_t* __restrict__ dist, int32_t* __restrict__ flags,
     unsigned long long* __restrict__ fvol, int level, int64_t ss, int64_t sv, uint32_t* __restrict__ fcur,
-    uint32_t* __restrict__ fdone, int64_t rs)
+    uint32_t* __restrict__ fdone, int64_t rs, unsigned long long pull_above, int push_levels)
 {
     if (flags[level - 1] == 0) return;
+    {
+        bool pull, prev_pull;
+        int k;
+        msbfs_mode(fvol, pull_above, push_levels, level, pull, prev_pull, k);
+        if (pull) return;                                    // a pull level commits itself (version rotation): nothing to do
+    }
     // One lane per node, a wave per 64 consecutive nodes: the ballot of "some word of my node is new"
     // IS the two 32-bit words of the frontier-node bitmap for those nodes -- plain stores, every word of
     // fcur rewritten each level (nobody reads it while this kernel runs: expand of this level is done).
@@ -477,6 +592,28 @@ extern "C" int64_t sgnn_bfs_hops_workspace_bytes(int64_t max_id, int64_t n_sourc
            8 + 2 * ((max_id + 32) / 32) * 4;                      // + two frontier-node bitmaps
 }
 
+// status[0] = the last level that found anything, [1] = 1 if the LAST enqueued level still found something (too few levels
+// enqueued), [2] = the first level that pulled among the levels that ran (0: none did) -- what a caller that repeats the
+// search hands back as ``push_levels`` (+ a margin), [3] = 0
+__device__ static inline void msbfs_write_status(const int32_t* __restrict__ flags, const unsigned long long* __restrict__ fvol,
+                                                 unsigned long long pull_above, int push_levels, int last_level,
+                                                 int32_t* __restrict__ status)
+{
+    int last = 0;
+    for (int l = 1; l <= last_level; ++l) if (flags[l]) last = l;
+    status[0] = last;
+    status[1] = flags[last_level] != 0;
+    int first_pull = 0;
+    for (int l = 2; l <= last + 1 && l <= last_level && first_pull == 0; ++l) {
+        bool pull, prev_pull;
+        int k;
+        msbfs_mode(fvol, pull_above, push_levels, l, pull, prev_pull, k);
+        if (pull) first_pull = l;
+    }
+    status[2] = first_pull;
+    status[3] = 0;
+}
+
 // The reference's matrix holds 0 for unreachable pairs, and its row-min runs over those zeros: a
 // source that never reaches SOME member of a set gives 0 for the whole set (SubGNN.py:772).  After
 // the last level: AND the members' seen words, zero the sources missing from it.
@@ -484,22 +621,32 @@ __global__ __launch_bounds__(256) void msbfs_set_finalize_kernel(
     const uint64_t* __restrict__ seen, int64_t n_words, int64_t n_sources,
     const int64_t* __restrict__ set_ptr, const int32_t* __restrict__ set_nodes, int64_t n_sets, float* __restrict__ out, int64_t rs,
     const uint64_t* __restrict__ frontier, uint64_t* __restrict__ set_seen, const int32_t* __restrict__ flags, int last_level,
-    int32_t* __restrict__ status)
+    int32_t* __restrict__ status, const uint64_t* __restrict__ nextbuf, const unsigned long long* __restrict__ fvol,
+    unsigned long long pull_above, int push_levels)
 {
     if (status && blockIdx.x == 0 && threadIdx.x == 0) {     // (msbfs_status_kernel's work: one launch less per search)
-        int last = 0;
-        for (int l = 1; l <= last_level; ++l) if (flags[l]) last = l;
-        status[0] = last;
-        status[1] = flags[last_level] != 0;
+        msbfs_write_status(flags, fvol, pull_above, push_levels, last_level, status);
     }
     const int64_t total = n_sets * n_words;
     const bool reduce_last = flags[last_level] != 0;         // the last enqueued level found something: its reduction is still due
+    bool pull, prev_pull;
+    int k;
+    msbfs_mode(fvol, pull_above, push_levels, last_level, pull, prev_pull, k);
+    const uint64_t* B[3] = {seen, nextbuf, frontier};
+    // the last level's new bits: its commit left them in the frontier rows (push), or they are the difference of the version
+    // it wrote and the one it read (pull number k: B[(k + 1) % 3] from B[k % 3])
+    const uint64_t* lcur = pull ? B[(k + 1) % 3] : frontier;
+    const uint64_t* lold = pull ? B[k % 3] : nullptr;
     for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
         if (reduce_last)
-            msbfs_set_reduce_item(frontier, n_words, n_sources, set_ptr, set_nodes, set_seen, out, last_level, rs, t);
+            msbfs_set_reduce_item(lcur, n_words, n_sources, set_ptr, set_nodes, set_seen, out, last_level, rs, t, lold);
         const int64_t r = t / n_words, w = t % n_words;
         uint64_t all = ~0ull;
-        for (int64_t i = set_ptr[r]; i < set_ptr[r + 1]; ++i) all &= seen[(int64_t)set_nodes[i] * rs + w];
+        // the truth about a node is the OR of the three versions (each a subset of it, the newest write of a row exact)
+        for (int64_t i = set_ptr[r]; i < set_ptr[r + 1]; ++i) {
+            const int64_t o = (int64_t)set_nodes[i] * rs + w;
+            all &= seen[o] | nextbuf[o] | frontier[o];
+        }
         uint64_t missing = ~all;
         while (missing) {
             const int b = __ffsll((unsigned long long)missing) - 1;
@@ -510,23 +657,21 @@ __global__ __launch_bounds__(256) void msbfs_set_finalize_kernel(
     }
 }
 
-// status[0] = the last level that found anything, status[1] = 1 if the LAST enqueued level still found something
-// (the search may be incomplete: the caller enqueued too few levels)
-__global__ void msbfs_status_kernel(const int32_t* __restrict__ flags, int max_hops, int32_t* __restrict__ status)
+__global__ void msbfs_status_kernel(const int32_t* __restrict__ flags, int max_hops, int32_t* __restrict__ status,
+                                    const unsigned long long* __restrict__ fvol, unsigned long long pull_above, int push_levels)
 {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        int last = 0;
-        for (int l = 1; l <= max_hops; ++l) if (flags[l]) last = l;
-        status[0] = last;
-        status[1] = flags[max_hops] != 0;
-    }
+    if (threadIdx.x == 0 && blockIdx.x == 0) msbfs_write_status(flags, fvol, pull_above, push_levels, max_hops, status);
 }
 
 static int msbfs_run(const int64_t* rowptr, const int32_t* col, int64_t nnz, int64_t max_id,
                      const int32_t* sources, int64_t n_sources, int max_hops, int node_major, uint8_t* dist,
                      const int64_t* set_ptr, const int32_t* set_nodes, int64_t n_sets, float* set_out,
-                     void* workspace, hipStream_t st, int pull_alpha, int32_t* status = nullptr)
+                     void* workspace, hipStream_t st, int pull_alpha, int32_t* status = nullptr, int push_levels = -1)
 {
+    // push_levels: levels that may still push (a commit launch is enqueued for each); beyond them the search pulls.  < 0, or
+    // alpha = 0 (never pull: the caller's choice): every level
+    if (push_levels < 0 || pull_alpha == 0 || push_levels > max_hops) push_levels = max_hops;
+    if (push_levels < 1) push_levels = 1;                    // (level 1 always pushes: the seeds' lists)
     const int g_bfs_alpha = pull_alpha < 0 ? MSBFS_DEFAULT_ALPHA : pull_alpha;
     const int64_t n_ids = max_id + 1;
     const int64_t n_words = (n_sources + 63) / 64;
@@ -555,22 +700,26 @@ static int msbfs_run(const int64_t* rowptr, const int32_t* col, int64_t nnz, int
     sets.set_ptr = set_ptr; sets.set_nodes = set_nodes; sets.n_sets = set_out ? n_sets : 0; sets.set_seen = set_seen; sets.out = set_out;
     const int g_expand = sgnn_grid_for(n_ids * 16, 256);
     const int g_commit = sgnn_grid_for(n_ids, 256, 256 * 4);
+    MsbfsBufs bufs;
+    bufs.b[0] = seen; bufs.b[1] = next; bufs.b[2] = frontier;
     for (int level = 1; level <= max_hops; ++level) {
-        hipLaunchKernelGGL(msbfs_expand_kernel, dim3(g_expand), dim3(256), 0, st, rowptr, col, n_ids, n_words, n_sources,
-                           seen, frontier, next, flags, fvol, pull_above, level, fbits,
-                           (unsigned long long)((nnz * n_words) / 4), fbits + fwords, rs, sets);
+        hipLaunchKernelGGL(msbfs_level_kernel, dim3(g_expand), dim3(256), 0, st, rowptr, col, n_ids, n_words, n_sources,
+                           bufs, flags, fvol, pull_above, push_levels, level, fbits, fbits + fwords, rs, sets, dist, ss, sv);
         SGNN_CHECK_LAUNCH();
-        hipLaunchKernelGGL(msbfs_commit_kernel, dim3(g_commit), dim3(256), 0, st, rowptr, n_ids, n_words, n_sources, seen,
-                           frontier, next, dist, flags, fvol, level, ss, sv, fbits, fbits + fwords, rs);
-        SGNN_CHECK_LAUNCH();
+        if (level <= push_levels) {                          // (a level beyond them pulls: it commits itself)
+            hipLaunchKernelGGL(msbfs_commit_kernel, dim3(g_commit), dim3(256), 0, st, rowptr, n_ids, n_words, n_sources, seen,
+                               frontier, next, dist, flags, fvol, level, ss, sv, fbits, fbits + fwords, rs, pull_above, push_levels);
+            SGNN_CHECK_LAUNCH();
+        }
     }
     if (set_out) {
         hipLaunchKernelGGL(msbfs_set_finalize_kernel, dim3(g_sets), dim3(256), 0, st, seen, n_words, n_sources, set_ptr,
-                           set_nodes, n_sets, set_out, rs, frontier, set_seen, flags, max_hops, status);
+                           set_nodes, n_sets, set_out, rs, frontier, set_seen, flags, max_hops, status, next, fvol, pull_above,
+                           push_levels);
         SGNN_CHECK_LAUNCH();
     }
     if (status && !set_out) {
-        hipLaunchKernelGGL(msbfs_status_kernel, dim3(1), dim3(64), 0, st, flags, max_hops, status);
+        hipLaunchKernelGGL(msbfs_status_kernel, dim3(1), dim3(64), 0, st, flags, max_hops, status, fvol, pull_above, push_levels);
         SGNN_CHECK_LAUNCH();
     }
     return SGNN_OK;
@@ -595,7 +744,7 @@ extern "C" int64_t sgnn_bfs_min_hops_workspace_bytes(int64_t max_id, int64_t n_s
 }
 
 extern "C" int sgnn_bfs_min_hops_to_sets(const int64_t* rowptr, const int32_t* col, int64_t nnz, int64_t max_id,
-                                         const int32_t* sources, int64_t n_sources, int max_hops, int pull_alpha,
+                                         const int32_t* sources, int64_t n_sources, int max_hops, int pull_alpha, int push_levels,
                                          const int64_t* set_ptr, const int32_t* set_nodes, int64_t n_sets,
                                          float* out, int32_t* out_status, void* workspace, int64_t workspace_bytes,
                                          void* stream)
@@ -607,7 +756,7 @@ extern "C" int sgnn_bfs_min_hops_to_sets(const int64_t* rowptr, const int32_t* c
     if (workspace_bytes < sgnn_bfs_min_hops_workspace_bytes(max_id, n_sources, max_hops, n_sets)) return SGNN_ERR_BAD_ARG;
     if (n_sources == 0 || n_sets == 0) return SGNN_OK;
     return msbfs_run(rowptr, col, nnz, max_id, sources, n_sources, max_hops, 0, nullptr, set_ptr, set_nodes, n_sets, out,
-                     workspace, (hipStream_t)stream, pull_alpha, out_status);
+                     workspace, (hipStream_t)stream, pull_alpha, out_status, push_levels);
 }
 
 __global__ void min_hops_to_sets_kernel(const uint8_t* __restrict__ dist, int64_t n_sources, int64_t n_ids,

@@ -35,13 +35,15 @@ def make_capturable(optimizer):
 def make_eager(optimizer):
     """Undo make_capturable for an optimizer that goes back to eager steps (the trainer's fallback): with ``capturable``
     left on, torch's Adam keeps the device-side step arithmetic -- not the code path of a run that never asked for a
-    recorded step.  The step counters stay tensors; torch accepts device or host counters in either mode."""
+    recorded step.  The step counters stay tensors (host ones for the unfused optimizer, as it creates them)."""
+    fused = any(g.get('fused') for g in optimizer.param_groups)
     for g in optimizer.param_groups:
         if 'capturable' in g:
             g['capturable'] = False
-    for st in optimizer.state.values():
-        if 'step' in st and torch.is_tensor(st['step']) and st['step'].is_cuda:
-            st['step'] = st['step'].cpu()
+    if not fused:                                   # (torch's fused Adam keeps its step counters on the device in either mode)
+        for st in optimizer.state.values():
+            if 'step' in st and torch.is_tensor(st['step']) and st['step'].is_cuda:
+                st['step'] = st['step'].cpu()
     return optimizer
 
 

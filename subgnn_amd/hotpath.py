@@ -92,6 +92,17 @@ def _bfs_levels(model, key, max_hops):
     return max_hops if k is None else min(max_hops, k + BFS_LEVEL_MARGIN + 1)
 
 
+BFS_PUSH_MARGIN = 1
+
+
+def _bfs_push_levels(model, key):
+    """How many levels of the search ``key`` may still push (each is a second launch, the commit): the level at which the
+    first search of the kind switched to pulling, plus a margin; -1 (all of them) until that is known or when it never
+    pulled.  Beyond them the device pulls whatever the frontier -- same results (ops.bfs_min_hops_to_sets)."""
+    k = model.__dict__.setdefault('_bfs_push_hint', {}).get(key)
+    return -1 if not k else int(k) - 1 + BFS_PUSH_MARGIN
+
+
 def _bfs_note(model, st, key, status, max_hops, enqueued, redo):
     """First search of a kind: read its status (one blocking read-back) and keep the depth.  Hinted search: copy the
     status into pinned host memory behind the search (no wait here) and leave a check on the pass; ``redo`` runs the
@@ -110,7 +121,8 @@ def _bfs_note(model, st, key, status, max_hops, enqueued, redo):
         st.bfs_checks.append((key, host, None, max_hops, enqueued, None))
         return
     if hint.get(key) is None:
-        last, more = status.tolist()
+        last, more, first_pull = status.tolist()[:3]
+        model.__dict__.setdefault('_bfs_push_hint', {})[key] = first_pull
         if more:
             raise RuntimeError('position-channel BFS: level %d still reached new nodes -- hparams["max_bfs_hops"] = %d '
                                'is smaller than the depth of this graph from the anchors' % (max_hops, max_hops))
@@ -119,7 +131,7 @@ def _bfs_note(model, st, key, status, max_hops, enqueued, redo):
     # one pinned status buffer per check, taken from a free list and returned by _verify_bfs once it has been read: any
     # number of passes may be in flight (PassPipeline.start can run ahead as far as the caller likes)
     pool = model.__dict__.setdefault('_bfs_status_pool', [])
-    host = pool.pop() if pool else torch.empty(2, dtype=torch.int32).pin_memory()
+    host = pool.pop() if pool else torch.empty(4, dtype=torch.int32).pin_memory()
     host.copy_(status, non_blocking=True)
     ev = torch.cuda.Event()
     ev.record(torch.cuda.current_stream())
@@ -147,6 +159,9 @@ def _verify_bfs(model, st, keep=False):
             if ev is not None:
                 ev.synchronize()
             results.append((int(host[0]), int(host[1])))
+            if int(host[2]) > 0:                     # the level that switched to pull: the push hint only grows
+                ph = model.__dict__.setdefault('_bfs_push_hint', {})
+                ph[key] = max(ph.get(key) or 0, int(host[2]))
     finally:
         if not keep:
             st.bfs_checks = []
@@ -159,7 +174,7 @@ def _verify_bfs(model, st, keep=False):
             if redo is None:                         # a recorded pass cannot repeat a search: its owner records again
                 hint[key] = cap
                 raise BfsLevelsExhausted(key)
-            last, more = redo(cap)
+            last, more = redo(cap)[:2]
             model.__dict__['_bfs_redone'] = model.__dict__.get('_bfs_redone', 0) + 1
         if more:
             raise RuntimeError('position-channel BFS: level %d still reached new nodes -- hparams["max_bfs_hops"] = %d '
@@ -235,7 +250,7 @@ def _dealt_position_sims(g, anchors, cc_sets, cc_ids, shard, max_hops):
     a, b = sdist.shard_range(A, shard.rank, shard.world)
     width = (A + shard.world - 1) // shard.world
     part = torch.zeros((all_sets.n, width), dtype=torch.float32, device=cc_ids.device)
-    status = torch.zeros(2, dtype=torch.int32, device=cc_ids.device)
+    status = torch.zeros(4, dtype=torch.int32, device=cc_ids.device)
     if b > a:
         part[:, :b - a], status = ops.bfs_min_hops_to_sets(g, anchors[a:b].to(torch.int32).contiguous(), all_sets,
                                                            max_hops=max_hops, want_status=True)
@@ -381,7 +396,8 @@ def prepare_pass(model, split='train', timer=None, shard=None, defer_dtw=False):
                         cap = hp.get('max_bfs_hops', 32)
                         nlev = _bfs_levels(model, ('P_out', split, l), cap)
                         src = anchors_pos_ext[l].to(torch.int32).contiguous()
-                        w, status = ops.bfs_min_hops_to_sets(g, src, cc_sets, max_hops=nlev, want_status=True)
+                        w, status = ops.bfs_min_hops_to_sets(g, src, cc_sets, max_hops=nlev, want_status=True,
+                                                             push_levels=_bfs_push_levels(model, ('P_out', split, l)))
 
                         def redo(levels, src=src, l=l, sims=sims):
                             # the hinted search ran out of levels: the same search with the full cap, similarities replaced.
@@ -860,7 +876,7 @@ class GraphedPasses:
         slot = self._Slot()
         pool = self.model.__dict__.setdefault('_bfs_status_pool', [])
         while len(pool) < 4 * max(1, int(self.model.hparams['n_layers'])):      # pinned buffers the recorded searches will take
-            pool.append(torch.empty(2, dtype=torch.int32).pin_memory())
+            pool.append(torch.empty(4, dtype=torch.int32).pin_memory())
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):

@@ -647,20 +647,22 @@ def bfs_hops(g, sources, max_hops=64, node_major=False, pull_alpha=-1):
     return dist
 
 
-def bfs_min_hops_to_sets(g, sources, sets, max_hops=64, want_status=False, pull_alpha=-1):
+def bfs_min_hops_to_sets(g, sources, sets, max_hops=64, want_status=False, pull_alpha=-1, push_levels=-1):
     """min over the members of every set of the hop distance from every source -> (n_sets, n_sources)
     float32, 0 for unreachable pairs; one multi-source BFS, no (sources x nodes) hop table.
-    ``want_status``: also an int32[2] device tensor -- [0] the last level that found anything, [1] whether level
-    ``max_hops`` itself still did (too few levels enqueued: the result may be incomplete)."""
+    ``want_status``: also an int32[4] device tensor -- [0] the last level that found anything, [1] whether level
+    ``max_hops`` itself still did (too few levels enqueued: the result may be incomplete), [2] the first level that pulled.
+    ``push_levels``: levels that may still push (each costs a second launch); beyond them every level pulls.  -1 = all;
+    results do not depend on it."""
     lib = _lib.load()
     _req(sources, torch.int32, 'sources')
     ns = sources.numel()
     out = torch.empty((sets.n, ns), dtype=torch.float32, device=g.device)
-    status = torch.zeros(2, dtype=torch.int32, device=g.device) if want_status else None
+    status = torch.zeros(4, dtype=torch.int32, device=g.device) if want_status else None
     wsb = lib.sgnn_bfs_min_hops_workspace_bytes(g.max_id, ns, max_hops, sets.n)
     ws = torch.empty(wsb // 8 + 1, dtype=torch.int64, device=g.device)
     check(lib.sgnn_bfs_min_hops_to_sets(_ptr(g.rowptr), _ptr(g.col), g.nnz, g.max_id, _ptr(sources), ns, max_hops,
-                                        int(pull_alpha), _ptr(sets.ptr), _ptr(sets.nodes), sets.n, _ptr(out), _ptr(status), _ptr(ws), wsb,
+                                        int(pull_alpha), int(push_levels), _ptr(sets.ptr), _ptr(sets.nodes), sets.n, _ptr(out), _ptr(status), _ptr(ws), wsb,
                                         _stream()), 'sgnn_bfs_min_hops_to_sets')
     return (out, status) if want_status else out
 

@@ -146,3 +146,122 @@ def build_model(root, name, hp_over=None, device=None, prepare=True):
         else:
             model.prepare_data()
     return model, d, n_edges
+
+
+def count_kernels(fn):
+    """Device kernels ``fn()`` launches (memory copies and fills by the runtime included), counted by torch's profiler
+    (roctracer / rocprofiler-sdk underneath); None where the profiler cannot run (e.g. under rocprofv3, which owns the
+    tracing interface).  Measurement aid of the launch-bound configurations: not on any product path."""
+    try:
+        from torch.profiler import ProfilerActivity, profile
+        torch.cuda.synchronize()
+        with profile(activities=[ProfilerActivity.CUDA]) as prof:
+            fn()
+            torch.cuda.synchronize()
+        n = 0
+        for ev in prof.events():
+            dt = str(getattr(ev, 'device_type', ''))
+            if 'CUDA' in dt or 'PrivateUse' in dt:
+                n += 1
+        return n if n > 0 else None
+    except Exception:
+        return None
+
+
+def time_steps(model, opt, hp, steps, warmup, graph, count=False):
+    """ms per batch-sized training step (fwd + bwd + clip + Adam: Trainer.fit's body) -> (ms, last loss, kernels per step).
+    ``graph``: replayed from a hipGraph (graph_step.CapturedTrainStep) instead of queued eagerly."""
+    import time
+    B = hp['batch_size']
+
+    def index_batches():
+        while True:
+            for idx in model.train_dataloader().index_batches():
+                if idx.numel() == B:
+                    yield idx
+    it = index_batches()
+    if graph:
+        from .graph_step import CapturedTrainStep
+        cap = CapturedTrainStep(model, opt, B, hp['grad_clip'])
+
+        def step():
+            return cap.replay(next(it))[0]
+    else:
+        def step():
+            out = model.training_step(model.make_batch('train', next(it)), 0)
+            opt.zero_grad(set_to_none=True)
+            model.backward(None, out['loss'], opt, 0)
+            torch.nn.utils.clip_grad_norm_(model.parameters(), hp['grad_clip'])
+            opt.step()
+            return out['loss']
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step()
+    torch.cuda.synchronize()
+    ms = 1e3 * (time.perf_counter() - t0) / steps
+    n_k = count_kernels(step) if count else None
+    return ms, float(loss.detach()), n_k
+
+
+def bench_config(name, steps=30, warmup=5, deterministic=True, root=None, count=True):
+    """One BASELINE configuration's stand-in end to end -> dict: dataset write, graph metrics, prepare_data, then the
+    batch-sized training step eager and replayed (ms per step, subgraphs/s, kernels per step).  What bench.py's
+    ``configs`` object and tools/bench_standin.py report."""
+    import tempfile
+    import time
+    from . import config, hotpath, precompute_graph_metrics as pgm
+    from .SubGNN import SubGNN, dataset_paths
+    P = PRESETS[name]
+    hp = dict(P['hp'])
+    hp['deterministic'] = bool(deterministic)
+    root = root or tempfile.mkdtemp(prefix=name + '_')
+    t0 = time.time()
+    d, n_edges = write_standin(root, name)
+    t_write = time.time() - t0
+    t0 = time.time()
+    pgm.calculate_stats(d, shortest_paths=not P['sparse'], ego=not P['sparse'])
+    t_metrics = time.time() - t0
+    old_root = config.PROJECT_ROOT
+    config.PROJECT_ROOT = root
+    try:
+        torch.manual_seed(3)
+        model = SubGNN(dict(hp), **dataset_paths(name + '_standin'))
+        stages = None
+        torch.cuda.synchronize()
+        t0 = time.time()
+        if P['sparse']:
+            timer = hotpath.StageTimer(True)
+            for sp in ('val', 'train'):       # val first: it also pays the one-time code-object loads
+                hotpath.prepare_sparse(model, sp, timer if sp == 'train' else None)
+            torch.cuda.synchronize()
+            stages = {k: round(v, 3) for k, v in timer.summary().items()}
+        else:
+            model.prepare_data()
+            torch.cuda.synchronize()
+        t_prep = time.time() - t0
+        opt = model.configure_optimizers()
+        model.train()
+        ms_eager, loss, k_eager = time_steps(model, opt, model.hparams, steps, warmup, graph=False, count=count)
+        ms_graph, loss_g, _ = time_steps(model, opt, model.hparams, steps, warmup, graph=True)
+    finally:
+        config.PROJECT_ROOT = old_root
+    B = hp['batch_size']
+    return {
+        'metric': 'subgraphs/sec fwd+bwd (all 3 channels on)' if (hp['use_position'] and hp['use_structure']) else
+                  'subgraphs/sec fwd+bwd (neighborhood channel only: configs[0] as BASELINE words it)',
+        'unit': 'subgraphs/s', 'n_gpus': 1,
+        'value': B * 1e3 / ms_graph, 'ms_per_step': ms_graph, 'hip_graph_step': True,
+        'eager': {'value': B * 1e3 / ms_eager, 'ms_per_step': ms_eager},
+        'kernels_per_step': k_eager,
+        'steps': steps, 'warmup': warmup, 'higher_is_better': True, 'dtype': 'f32', 'data': 'synthetic (stand-in)',
+        'config': {'workload': '%s stand-in (BA n=%d m=%d, %d edges, %d subgraphs), %s prepare, batch of %d, training '
+                               'step = fwd + bwd + clip + Adam' % (name, P['n'], P.get('m', 5), n_edges, P['n_sub'],
+                                                                   'sparse' if P['sparse'] else 'dense reference-shaped', B),
+                   'cc_ids_shape': list(model.train_cc_ids.shape), 'n_layers': hp['n_layers'],
+                   'structure_patches': int(model.structure_anchors.shape[0]) if getattr(model, 'structure_anchors', None) is not None else 0},
+        'deterministic_backward': bool(deterministic), 'prepare_data_s': round(t_prep, 2), 'prepare_stages_ms_train_split': stages,
+        'dataset_write_s': round(t_write, 2), 'graph_metrics_s': round(t_metrics, 2),
+        'loss': loss, 'loss_graph': loss_g}

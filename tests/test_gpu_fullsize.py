@@ -88,6 +88,14 @@ def test_bfs_levels_against_scipy(full):
     # fused min over members == two-step form on the full 50k sets
     two = ops.min_hops_to_sets(dist, full['sets'])
     assert torch.equal(ops.bfs_min_hops_to_sets(g, torch.from_numpy(src).to(DEV), full['sets'], max_hops=32), two)
+    # the hinted form the pass runs (levels and push levels capped from an earlier search's status): same rows
+    w, st = ops.bfs_min_hops_to_sets(g, torch.from_numpy(src).to(DEV), full['sets'], max_hops=32, want_status=True)
+    last, more, first_pull, _ = st.tolist()
+    assert more == 0 and first_pull >= 2 and torch.equal(w, two)
+    for cap in (1, first_pull - 1, first_pull):
+        w2, st2 = ops.bfs_min_hops_to_sets(g, torch.from_numpy(src).to(DEV), full['sets'], max_hops=last + 3, want_status=True,
+                                           push_levels=cap)
+        assert torch.equal(w2, two) and st2.tolist()[:2] == [last, 0], cap
 
 
 def test_walks_follow_edges_and_dtw_properties(full):

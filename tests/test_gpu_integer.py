@@ -647,6 +647,23 @@ def test_bfs_hops_push_pull_agree_and_match_scipy(n_src):
     sets = ops.Ragged.from_lists(sets_l, DEV)
     two_step = ops.min_hops_to_sets(out[256], sets)
     assert torch.equal(ops.bfs_min_hops_to_sets(dg, torch.from_numpy(src).to(DEV), sets, max_hops=32), two_step)
+    # round 5: a pull level is one launch that writes the next VERSION of the seen rows (three rotating buffers), and the
+    # caller may cap the levels that can still push (``push_levels``: beyond them the device pulls whatever the frontier).
+    # Neither changes a value: every cap x every direction switch against the two-step form; status[2] = first pull level
+    firsts = set()
+    for alpha in (0, 8, 256, 1 << 30):
+        for cap in (-1, 1, 2, 3, 5):
+            w, st = ops.bfs_min_hops_to_sets(dg, torch.from_numpy(src).to(DEV), sets, max_hops=32, want_status=True,
+                                             pull_alpha=alpha, push_levels=cap)
+            assert torch.equal(w, two_step), (alpha, cap)
+            last, more, first_pull, _ = st.tolist()
+            assert more == 0 and last == int(out[0][out[0] != 255].max())
+            if alpha == 0:
+                assert first_pull == 0                                    # never pulls: the caller's choice wins over the cap
+            elif cap > 0:
+                assert 2 <= first_pull <= cap + 1
+            firsts.add(first_pull)
+    assert len(firsts) >= 3                                               # the search really switched at different levels
     A = sp.csr_matrix((np.ones(len(col), dtype=np.int8), col.astype(np.int64) - 1, rowptr[1:] - rowptr[1]), shape=(n, n))
     ref = shortest_path(A, method='D', unweighted=True, indices=src[:40].astype(np.int64) - 1)
     got = out[0][:40, 1:].cpu().numpy().astype(np.float64)
@@ -687,13 +704,13 @@ def test_bfs_hops_matches_apsp(golden, bfs_alpha):
     # many levels is reported as possibly incomplete (the last level found something), one more is complete
     _, st = ops.bfs_min_hops_to_sets(dg, torch.from_numpy(src).to(DEV), sets, max_hops=32, want_status=True, pull_alpha=bfs_alpha)
     depth = int(d[d != 255].max())
-    assert st.tolist() == [depth, 0]
+    assert st.tolist()[:2] == [depth, 0]
     w1, st1 = ops.bfs_min_hops_to_sets(dg, torch.from_numpy(src).to(DEV), sets, max_hops=depth, want_status=True)
-    assert st1.tolist() == [depth, 1] and np.array_equal(w1.cpu().numpy(), ref)
+    assert st1.tolist()[:2] == [depth, 1] and np.array_equal(w1.cpu().numpy(), ref)
     w2, st2 = ops.bfs_min_hops_to_sets(dg, torch.from_numpy(src).to(DEV), sets, max_hops=depth + 1, want_status=True)
-    assert st2.tolist() == [depth, 0] and np.array_equal(w2.cpu().numpy(), ref)
+    assert st2.tolist()[:2] == [depth, 0] and np.array_equal(w2.cpu().numpy(), ref)
     _, st3 = ops.bfs_min_hops_to_sets(dg, torch.from_numpy(src).to(DEV), sets, max_hops=depth - 1, want_status=True)
-    assert st3.tolist() == [depth - 1, 1]
+    assert st3.tolist()[:2] == [depth - 1, 1]
 
 
 # ---- a11 DTW ------------------------------------------------------------------------------

@@ -58,7 +58,7 @@ for mod in (ops, aps, subgraph_utils, gamma):
     for name, fn in list(vars(mod).items()):
         if isinstance(fn, types.FunctionType) and not name.startswith('__'):
             setattr(mod, name, wrap(mod, name, fn))
-model.__dict__.setdefault('_bfs_status_pool', []).extend(torch.empty(2, dtype=torch.int32).pin_memory() for _ in range(8))
+model.__dict__.setdefault('_bfs_status_pool', []).extend(torch.empty(4, dtype=torch.int32).pin_memory() for _ in range(8))
 gr = torch.cuda.CUDAGraph()
 try:
     with torch.cuda.graph(gr):
