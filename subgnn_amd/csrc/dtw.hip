@@ -188,14 +188,14 @@ __device__ static inline double dtw_cost(double a, double b) {            // gam
 // dyadic rational here).  tests/test_oracle_integer.py::test_reciprocal_division_is_exact runs the
 // identity exhaustively over the integer range and on 10^7 random dyadic pairs on the CPU.
 __device__ __forceinline__ double dtw_cost_rcp(double a1, double ra, double b1, double rb) {
-    // Both quotients, the larger one is max / min: rounding is monotone, so RN(a1 / b1) >= 1 >= RN(b1 / a1) when
-    // a1 >= b1 -- the division step only has to be exact for the quotient that is >= 1 (the direction the CPU test
-    // covers); the other one only has to stay <= 1, and b1 / a1 <= 1 - 2^-24 for these operands.  7 instructions
-    // instead of compare + two 64-bit selects + max + min + the division step.
-    const double qa0 = __dmul_rn(a1, rb), qb0 = __dmul_rn(b1, ra);
-    const double qa = __fma_rn(__fma_rn(-qa0, b1, a1), rb, qa0);
-    const double qb = __fma_rn(__fma_rn(-qb0, a1, b1), ra, qb0);
-    return __dadd_rn(fmax(qa, qb), -1.0);
+    // max / min with ONE division step (round 5; rounds 2-4 formed both quotients and took the larger: 8 fp64 instructions, this
+    // is 7, and every one of them issues at half rate on gfx950): mx = max(a1, b1), mn = min(a1, b1), and the correctly rounded
+    // reciprocal of mn is max(ra, rb) -- rounding is monotone, so a1 <= b1 implies RN(1 / a1) >= RN(1 / b1).  The quotient is
+    // then the same correctly rounded mx / mn >= 1 the larger of the two quotients was (the direction the CPU test covers).
+    const double mx = fmax(a1, b1), mn = fmin(a1, b1), r = fmax(ra, rb);
+    const double q0 = __dmul_rn(mx, r);
+    const double q = __fma_rn(__fma_rn(-q0, mn, mx), r, q0);
+    return __dadd_rn(q, -1.0);
 }
 
 // A cost for a cell outside the lane's window: only the HIGH word is replaced (one v_cndmask instead of the two a

@@ -98,7 +98,7 @@ __global__ void msbfs_init_kernel(const int32_t* __restrict__ sources, int64_t n
 {
     const int64_t gtid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = gtid; i < 2 * ((n_ids + 31) / 32); i += gsz) fbits[i] = 0;   // frontier nodes | complete nodes
+    for (int64_t i = gtid; i < 2 * ((n_ids + 31) / 32) + (n_ids + 3) / 4; i += gsz) fbits[i] = 0;   // frontier-node bits | ever-on-the-frontier bits | one "complete" BYTE per node
     for (int64_t i = gtid; i < n_ids * rs; i += gsz) { seen[i] = 0; frontier[i] = 0; next[i] = 0; }
     // (the fused set reduction's state too: four memset launches less per search)
     for (int64_t i = gtid; i < n_set_words; i += gsz) set_seen[i] = 0;
@@ -115,6 +115,7 @@ __global__ void msbfs_seed_kernel(const int32_t* __restrict__ sources, int64_t n
     if (s >= n_sources) return;
     const int32_t v = sources[s];
     atomicOr(&fbits[v >> 5], 1u << (v & 31));                 // level-0 frontier nodes
+    atomicOr(&fbits[((n_ids + 31) / 32) + (v >> 5)], 1u << (v & 31));   // ... which have a non-empty seen row from now on
     const uint64_t bit = 1ull << (s & 63);
     atomicOr((unsigned long long*)&seen[(int64_t)v * rs + (s >> 6)], (unsigned long long)bit);
     atomicOr((unsigned long long*)&frontier[(int64_t)v * rs + (s >> 6)], (unsigned long long)bit);
@@ -218,7 +219,8 @@ __global__ __launch_bounds__(256) void msbfs_level_kernel(
     const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col, int64_t n_ids, int64_t n_words,
     int64_t n_sources, MsbfsBufs B, int32_t* __restrict__ flags, const unsigned long long* __restrict__ fvol,
     unsigned long long pull_above, int push_levels, int level, const uint32_t* __restrict__ fnode,
-    uint32_t* __restrict__ fdone, int64_t rs, MsbfsSets sets, uint8_t* __restrict__ dist, int64_t ss, int64_t sv)
+    const uint32_t* __restrict__ fany, uint8_t* __restrict__ fdone, int64_t rs, MsbfsSets sets, uint8_t* __restrict__ dist,
+    int64_t ss, int64_t sv)
 {
     if (level > 1 && flags[level - 1] == 0) return;          // previous level found nothing (nothing to reduce either)
     bool pull, prev_pull;
@@ -296,10 +298,14 @@ __global__ __launch_bounds__(256) void msbfs_level_kernel(
     const uint64_t* __restrict__ in = B.b[k % 3];
     uint64_t* __restrict__ out = B.b[(k + 1) % 3];
     bool found = false;                                      // this thread recorded a new bit
+    // the first pull level behind push levels: the commits kept one bit per node "has ever been on a frontier" = its seen row is
+    // not empty (125 KB, L2-resident), consulted before the 32-byte gather -- on the benchmark's level 3 about half of the
+    // neighbours still have an empty row.  Later pull levels do not maintain the bits (and hardly any row is empty by then).
+    const bool filter = (k == 0);
     for (int64_t v = group; v < n_ids; v += n_groups) {
         // one bit per node: every source has reached it -- from level 3-4 on that is almost every node; such a row is
         // not read, not rewritten (it goes stale in the other versions: harmless, see the header)
-        if ((fdone[v >> 5] >> (v & 31)) & 1u) continue;
+        if (fdone[v]) continue;
         const int64_t r0 = rowptr[v], r1 = rowptr[v + 1];
         bool all_done = true, parked = false;
         for (int64_t w0 = 0; w0 < rs && !parked; w0 += MSBFS_WCHUNK) {
@@ -340,14 +346,16 @@ __global__ __launch_bounds__(256) void msbfs_level_kernel(
                 for (int64_t e = r0 + sub; e < r1 + sub; e += 16) {          // uniform trip count per group
                     if (e < r1) {
                         const int64_t u = col[e];
-                        if (rs == 4) {                       // a padded row = one 32-byte sector: two 16-byte loads, no per-word tests
-                            const ulonglong2 f01 = *reinterpret_cast<const ulonglong2*>(&in[u * 4]);
-                            const ulonglong2 f23 = *reinterpret_cast<const ulonglong2*>(&in[u * 4 + 2]);
-                            acc[0] |= f01.x; acc[1] |= f01.y; acc[2] |= f23.x; acc[3] |= f23.y;
-                        } else {
+                        if (!filter || ((fany[u >> 5] >> (u & 31)) & 1u)) {
+                            if (rs == 4) {                   // a padded row = one 32-byte sector: two 16-byte loads, no per-word tests
+                                const ulonglong2 f01 = *reinterpret_cast<const ulonglong2*>(&in[u * 4]);
+                                const ulonglong2 f23 = *reinterpret_cast<const ulonglong2*>(&in[u * 4 + 2]);
+                                acc[0] |= f01.x; acc[1] |= f01.y; acc[2] |= f23.x; acc[3] |= f23.y;
+                            } else {
 #pragma unroll
-                            for (int q = 0; q < MSBFS_WCHUNK; ++q)
-                                if (need[q]) acc[q] |= in[u * rs + w0 + q];      // completed words are not read
+                                for (int q = 0; q < MSBFS_WCHUNK; ++q)
+                                    if (need[q]) acc[q] |= in[u * rs + w0 + q];  // completed words are not read
+                            }
                         }
                     }
                     if (++since == MSBFS_PULL_CHECK) {       // every MSBFS_PULL_CHECK x 16 neighbours: anything still missing?
@@ -393,7 +401,9 @@ __global__ __launch_bounds__(256) void msbfs_level_kernel(
                 }
             }
         }
-        if (!parked && all_done && sub == 0) atomicOr(&fdone[v >> 5], 1u << (v & 31));
+        // (a byte per node, plain store: as bits in shared words this was an atomic OR per completing node -- 830k of them on the
+        // level that completes most nodes, from workgroups on all XCDs into 1000 cache lines: 2.5x the level's time)
+        if (!parked && all_done && sub == 0) fdone[v] = 1;
     }
     // parked long lists: 256 lanes per list, the words OR-ed through LDS
     __syncthreads();
@@ -423,6 +433,7 @@ __global__ __launch_bounds__(256) void msbfs_level_kernel(
             if (missing != 0) {                              // uniform over the workgroup
                 for (int64_t e = r0 + threadIdx.x; e < r1; e += blockDim.x) {
                     const int64_t u = col[e];
+                    if (filter && !((fany[u >> 5] >> (u & 31)) & 1u)) continue;
                     if (rs == 4) {
                         const ulonglong2 f01 = *reinterpret_cast<const ulonglong2*>(&in[u * 4]);
                         const ulonglong2 f23 = *reinterpret_cast<const ulonglong2*>(&in[u * 4 + 2]);
@@ -462,7 +473,7 @@ __global__ __launch_bounds__(256) void msbfs_level_kernel(
                 if (need[q] & ~s_acc[q]) all_done = false;   // (every thread reads the same words)
             __syncthreads();
         }
-        if (all_done && threadIdx.x == 0) atomicOr(&fdone[v >> 5], 1u << (v & 31));
+        if (all_done && threadIdx.x == 0) fdone[v] = 1;
     }
     if (__syncthreads_or(found ? 1 : 0) && threadIdx.x == 0) atomicOr(&flags[level], 1);
 }
@@ -471,7 +482,7 @@ __global__ __launch_bounds__(256) void msbfs_commit_kernel(
     const int64_t* __restrict__ rowptr, int64_t n_ids, int64_t n_words, int64_t n_sources, uint64_t* __restrict__ seen,
     uint64_t* __restrict__ frontier, uint64_t* __restrict__ next, uint8_t* __restrict__ dist, int32_t* __restrict__ flags,
     unsigned long long* __restrict__ fvol, int level, int64_t ss, int64_t sv, uint32_t* __restrict__ fcur,
-    uint32_t* __restrict__ fdone, int64_t rs, unsigned long long pull_above, int push_levels)
+    uint8_t* __restrict__ fdone, int64_t rs, unsigned long long pull_above, int push_levels)
 {
     if (flags[level - 1] == 0) return;
     {
@@ -558,13 +569,14 @@ __global__ __launch_bounds__(256) void msbfs_commit_kernel(
             }
         }
         const unsigned long long mask = __ballot(n_new != 0);
-        const unsigned long long dmask = __ballot(done);
-        if (lane == 0) {
+        if (v < n_ids) fdone[v] = done ? 1 : 0;                 // (64 consecutive bytes per wavefront)
+        if (lane == 0) {                                        // (this wavefront owns the two words: plain read-modify-write)
+            uint32_t* __restrict__ fany = fcur + fwords;
             fcur[base >> 5] = (uint32_t)mask;
-            fdone[base >> 5] = (uint32_t)dmask;
+            if ((uint32_t)mask) fany[base >> 5] |= (uint32_t)mask;
             if ((base >> 5) + 1 < fwords) {
                 fcur[(base >> 5) + 1] = (uint32_t)(mask >> 32);
-                fdone[(base >> 5) + 1] = (uint32_t)(dmask >> 32);
+                if ((uint32_t)(mask >> 32)) fany[(base >> 5) + 1] |= (uint32_t)(mask >> 32);
             }
         }
     }
@@ -589,7 +601,7 @@ __global__ __launch_bounds__(256) void msbfs_commit_kernel(
 extern "C" int64_t sgnn_bfs_hops_workspace_bytes(int64_t max_id, int64_t n_sources, int max_hops) {
     const int64_t n_words = (n_sources + 63) / 64;
     return 3 * (max_id + 1) * msbfs_row_stride(n_words) * 8 + ((int64_t)max_hops + 2) * 8 + ((int64_t)max_hops + 2) * 4 +
-           8 + 2 * ((max_id + 32) / 32) * 4;                      // + two frontier-node bitmaps
+           8 + 2 * ((max_id + 32) / 32) * 4 + ((max_id + 4) / 4) * 4 + 8;   // + the frontier-node bitmaps (now | ever) + one "complete" byte per node
 }
 
 // status[0] = the last level that found anything, [1] = 1 if the LAST enqueued level still found something (too few levels
@@ -622,7 +634,7 @@ __global__ __launch_bounds__(256) void msbfs_set_finalize_kernel(
     const int64_t* __restrict__ set_ptr, const int32_t* __restrict__ set_nodes, int64_t n_sets, float* __restrict__ out, int64_t rs,
     const uint64_t* __restrict__ frontier, uint64_t* __restrict__ set_seen, const int32_t* __restrict__ flags, int last_level,
     int32_t* __restrict__ status, const uint64_t* __restrict__ nextbuf, const unsigned long long* __restrict__ fvol,
-    unsigned long long pull_above, int push_levels)
+    unsigned long long pull_above, int push_levels, const uint8_t* __restrict__ fdone)
 {
     if (status && blockIdx.x == 0 && threadIdx.x == 0) {     // (msbfs_status_kernel's work: one launch less per search)
         msbfs_write_status(flags, fvol, pull_above, push_levels, last_level, status);
@@ -633,6 +645,14 @@ __global__ __launch_bounds__(256) void msbfs_set_finalize_kernel(
     int k;
     msbfs_mode(fvol, pull_above, push_levels, last_level, pull, prev_pull, k);
     const uint64_t* B[3] = {seen, nextbuf, frontier};
+    // pull levels that ran: the newest version of the seen rows is B[n_written % 3] (no pull: the commits kept B[0] current)
+    int n_written = 0;
+    for (int l = 2; l <= last_level && flags[l - 1] != 0; ++l) {
+        bool pl, ppl;
+        int kk;
+        msbfs_mode(fvol, pull_above, push_levels, l, pl, ppl, kk);
+        n_written += pl ? 1 : 0;
+    }
     // the last level's new bits: its commit left them in the frontier rows (push), or they are the difference of the version
     // it wrote and the one it read (pull number k: B[(k + 1) % 3] from B[k % 3])
     const uint64_t* lcur = pull ? B[(k + 1) % 3] : frontier;
@@ -642,10 +662,11 @@ __global__ __launch_bounds__(256) void msbfs_set_finalize_kernel(
             msbfs_set_reduce_item(lcur, n_words, n_sources, set_ptr, set_nodes, set_seen, out, last_level, rs, t, lold);
         const int64_t r = t / n_words, w = t % n_words;
         uint64_t all = ~0ull;
-        // the truth about a node is the OR of the three versions (each a subset of it, the newest write of a row exact)
+        // a member every source has reached (its "complete" byte: set by the commit or the pull level that saw it) restricts
+        // nothing; any other member's row is exact in the version written last (complete rows are the only ones that go stale)
         for (int64_t i = set_ptr[r]; i < set_ptr[r + 1]; ++i) {
-            const int64_t o = (int64_t)set_nodes[i] * rs + w;
-            all &= seen[o] | nextbuf[o] | frontier[o];
+            const int64_t v = set_nodes[i];
+            if (!fdone[v]) all &= B[n_written % 3][v * rs + w];
         }
         uint64_t missing = ~all;
         while (missing) {
@@ -684,7 +705,8 @@ static int msbfs_run(const int64_t* rowptr, const int32_t* col, int64_t nnz, int
     int32_t* flags = (int32_t*)(fvol + max_hops + 2);
     uint32_t* fbits = (uint32_t*)(((uintptr_t)(flags + max_hops + 2) + 7) & ~(uintptr_t)7);
     const int64_t fwords = (n_ids + 31) / 32;
-    uint64_t* set_seen = (uint64_t*)(((uintptr_t)(fbits + 2 * fwords) + 7) & ~(uintptr_t)7);
+    uint8_t* fdone = (uint8_t*)(fbits + 2 * fwords);             // n_ids bytes, rounded up to whole words
+    uint64_t* set_seen = (uint64_t*)(((uintptr_t)(fbits + 2 * fwords + (n_ids + 3) / 4) + 7) & ~(uintptr_t)7);
     const unsigned long long pull_above =
         g_bfs_alpha > 0 ? (unsigned long long)((nnz * n_words) / g_bfs_alpha) : ~0ull;
     const int big = sgnn_grid_for(n_ids * ((dist && n_sources > rs) ? n_sources : rs), 256);
@@ -704,18 +726,18 @@ static int msbfs_run(const int64_t* rowptr, const int32_t* col, int64_t nnz, int
     bufs.b[0] = seen; bufs.b[1] = next; bufs.b[2] = frontier;
     for (int level = 1; level <= max_hops; ++level) {
         hipLaunchKernelGGL(msbfs_level_kernel, dim3(g_expand), dim3(256), 0, st, rowptr, col, n_ids, n_words, n_sources,
-                           bufs, flags, fvol, pull_above, push_levels, level, fbits, fbits + fwords, rs, sets, dist, ss, sv);
+                           bufs, flags, fvol, pull_above, push_levels, level, fbits, fbits + fwords, fdone, rs, sets, dist, ss, sv);
         SGNN_CHECK_LAUNCH();
         if (level <= push_levels) {                          // (a level beyond them pulls: it commits itself)
             hipLaunchKernelGGL(msbfs_commit_kernel, dim3(g_commit), dim3(256), 0, st, rowptr, n_ids, n_words, n_sources, seen,
-                               frontier, next, dist, flags, fvol, level, ss, sv, fbits, fbits + fwords, rs, pull_above, push_levels);
+                               frontier, next, dist, flags, fvol, level, ss, sv, fbits, fdone, rs, pull_above, push_levels);
             SGNN_CHECK_LAUNCH();
         }
     }
     if (set_out) {
         hipLaunchKernelGGL(msbfs_set_finalize_kernel, dim3(g_sets), dim3(256), 0, st, seen, n_words, n_sources, set_ptr,
                            set_nodes, n_sets, set_out, rs, frontier, set_seen, flags, max_hops, status, next, fvol, pull_above,
-                           push_levels);
+                           push_levels, fdone);
         SGNN_CHECK_LAUNCH();
     }
     if (status && !set_out) {

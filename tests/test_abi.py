@@ -32,7 +32,7 @@ def test_workspace_queries_run_on_the_host():
     assert lib.sgnn_khop_border_workspace_bytes(1000, 10, 0) == 10 * (((1000 + 32) // 32) * 4 + 1001 * 4) + 16
     assert lib.sgnn_khop_border_workspace_bytes(1000, 10, 1) == 10 * 1001 * 4 + 16
     assert lib.sgnn_dtw_workspace_bytes(100, 20, 10, 50) > 0
-    assert lib.sgnn_bfs_hops_workspace_bytes(1000, 70, 16) == 3 * 1001 * 2 * 8 + 18 * 8 + 18 * 4 + 8 + 2 * ((1000 + 32) // 32) * 4
+    assert lib.sgnn_bfs_hops_workspace_bytes(1000, 70, 16) == 3 * 1001 * 2 * 8 + 18 * 8 + 18 * 4 + 8 + 2 * ((1000 + 32) // 32) * 4 + ((1000 + 4) // 4) * 4 + 8
 
 
 def test_argument_errors_are_reported_not_thrown():
