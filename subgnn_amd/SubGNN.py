@@ -628,6 +628,24 @@ class SubGNN(nn.Module):
         key = ('S_X', layer_num)
         if cache is not None and key in cache:
             return cache[key]
+        L = self.hparams['n_layers']
+        if L > 1 and cache is not None:
+            # The walks of ALL layers in one pass over the LSTM: the anchor embeddings of a layer depend on the table and the LSTM's
+            # parameters only (aps:413-433), not on what the layers below computed, and the LSTM is shared by the layers -- so the
+            # n_layers x (internal, border) batches are one batch.  Same arithmetic per sequence; one recurrence launch per LSTM
+            # layer and direction pair instead of n_layers of them, one set of weight-gradient contractions, no accumulation of
+            # n_layers partial weight gradients (HPO-METAB stand-in, 4 layers: 8 -> 2 recurrences each way).
+            if ('S_X_all',) not in cache:
+                walks = self._all_structure_walks()
+                Xall = aps.aggregate_structure_anchor_patch(self.hparams, self.networkx_graph, self.lstm, self.node_embeddings,
+                                                            walks, walks, None, self.device, table=E)
+                off = 0
+                for l in range(L):
+                    n_l = self.anchors_structure[l][0].shape[0]
+                    cache[('S_X', l)] = (Xall[off:off + n_l], Xall[off + n_l:off + 2 * n_l])
+                    off += 2 * n_l
+                cache[('S_X_all',)] = True
+            return cache[key]
         patches, indices, int_rw, bor_rw = self.anchors_structure[layer_num]
         n = patches.shape[0]
         both = getattr(int_rw, '_sgnn_both', None)               # hotpath.prepare_pass: stacked, with the lookup's sort
@@ -639,6 +657,24 @@ class SubGNN(nn.Module):
         if cache is not None:
             cache[key] = out
         return out
+
+    def _all_structure_walks(self):
+        """[layer 0: internal walks, border walks | layer 1: ... ] of the sampled structure patches, stacked once per set of
+        anchors (hung on layer 0's internal walks as ``_sgnn_all``, with the sort its embedding lookup's backward needs when the
+        backward is the deterministic one): built outside any recording by ``_build_sim_cols`` -- or here, the first time."""
+        a = self.anchors_structure
+        first = a[0][2]
+        walks = getattr(first, '_sgnn_all', None)
+        want = sum(2 * a[l][0].shape[0] for l in range(self.hparams['n_layers']))
+        if walks is None or walks.shape[0] != want or walks.device != self.node_embeddings.weight.device:
+            walks = torch.cat([t.to(self.device) for l in range(self.hparams['n_layers']) for t in (a[l][2], a[l][3])], 0)
+            if self._deterministic and walks.is_cuda:
+                ops.presort_ids(walks, self.networkx_graph.max_id)
+            try:
+                first._sgnn_all = walks
+            except AttributeError:
+                pass
+        return walks
 
     def forward(self, dataset_type, N_I_cc_embed, N_B_cc_embed, S_I_cc_embed, S_B_cc_embed, P_I_cc_embed,
                 P_B_cc_embed, subgraph_ids, cc_ids, subgraph_idx, NP_sim, I_S_sim, B_S_sim):
@@ -857,6 +893,9 @@ class SubGNN(nn.Module):
         """Per layer, the columns of the S similarity rows its sampled patches read (S.py:206-210),
         resident on the device so that forward never uploads anything."""
         src = getattr(self, 'anchors_structure', None)
+        if src is not None and self.hparams['n_layers'] > 1 and self.hparams.get('fused_forward', True) and torch.is_tensor(src[0][2]) \
+                and not (torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()):
+            self._all_structure_walks()                       # (the layers' walks stacked for the one LSTM pass of forward)
         if src is not None and self.__dict__.get('_sim_cols_src') is src:
             return                                            # already uploaded for these patches
         self.set_sim_cols(src, self.sim_cols_of(src) if src is not None else {})

@@ -23,6 +23,10 @@
 #include <rocprim/iterator/counting_iterator.hpp>
 
 #define SC_RUN 64
+#define SC_RUN_SMALL 16        // run length of batch-sized launches: a wavefront walks its run edge by edge, so 64-edge runs make a launch of a
+                               // few thousand edges a chain of 64 dependent steps on a handful of wavefronts (HPO-METAB stand-in, batch of 64:
+                               // 21 launches of 31 us per step); 16-edge runs give the same launch four times the wavefronts
+#define SC_SMALL_EDGES 65536   // launches up to this many edges take the short runs
 #define SC_AHEAD 8             // carry slots in flight per wavefront in the chain kernel
 #define SC_MAXC 4              // columns per lane: D <= 256
 
@@ -51,14 +55,15 @@ struct ScArgs {
 // per SIMD hide those waits better than 3 with 159 registers each (benchmark, 2.1 M border edges: 293 us with 64 rows
 // in flight, 218 with 8; what remains is the random 256-byte read-modify-write of ~0.9 M distinct table rows in HBM).
 // (16, 1) with the argmax ids, (16, 2) for D <= 128, (8, 4) up to 256.
-template <int AHEAD, int MAXC>
+template <int AHEAD, int MAXC, int RUN = SC_RUN>
 __global__ __launch_bounds__(256) void scatter_runs_kernel(ScArgs a)
 {
+    static_assert(RUN <= 64 && AHEAD <= RUN, "one sorted position per lane");
     const int lane = threadIdx.x & 63;
     const int64_t run = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int64_t p0 = run * SC_RUN;
+    const int64_t p0 = run * RUN;
     if (p0 >= a.E) return;
-    const int cnt = (int)(a.E - p0 < SC_RUN ? a.E - p0 : SC_RUN);
+    const int cnt = (int)(a.E - p0 < RUN ? a.E - p0 : RUN);
     const int64_t D = a.D;
     // one sorted position per lane
     int32_t k_l = 0, row_l = 0;
@@ -208,9 +213,12 @@ __global__ __launch_bounds__(256) void scatter_chains_kernel(ScArgs a, int64_t n
         if (lane + 64 * c < D) a.table[(int64_t)key * D + lane + 64 * c] += acc[c];
 }
 
+static inline int sc_run_len(int64_t n_edges) { return n_edges <= SC_SMALL_EDGES ? SC_RUN_SMALL : SC_RUN; }
+
 extern "C" int64_t sgnn_scatter_add_rows_workspace_bytes(int64_t n_edges, int64_t D)
 {
-    const int64_t n_runs = (n_edges + SC_RUN - 1) / SC_RUN;
+    const int run = sc_run_len(n_edges);
+    const int64_t n_runs = (n_edges + run - 1) / run;
     return n_runs * 2 * (D * 4 + 8) + 64;
 }
 
@@ -262,7 +270,8 @@ extern "C" int sgnn_scatter_add_rows_sorted(const int32_t* order, const int32_t*
     if (n_edges >= (1ll << 31)) return SGNN_ERR_SET_TOO_LARGE;
     if (n_edges == 0) return SGNN_OK;
     if (!workspace || workspace_bytes < sgnn_scatter_add_rows_workspace_bytes(n_edges, D)) return SGNN_ERR_BAD_ARG;
-    const int64_t n_runs = (n_edges + SC_RUN - 1) / SC_RUN;
+    const int run_len = sc_run_len(n_edges);
+    const int64_t n_runs = (n_edges + run_len - 1) / run_len;
     ScArgs a;
     a.order = order; a.key = key_sorted; a.E = n_edges; a.edge_row = edge_row; a.edges_per_row = edges_per_row;
     a.G = G; a.D = D; a.c1 = c1; a.c2 = c2; a.v = v; a.arg = arg; a.table = table;
@@ -271,7 +280,13 @@ extern "C" int sgnn_scatter_add_rows_sorted(const int32_t* order, const int32_t*
     a.carry_flag = a.carry_key + n_runs * 2;
     hipStream_t st = (hipStream_t)stream;
     const unsigned grid = (unsigned)((n_runs + 3) / 4);
-    if (D <= 64 && !arg && n_runs <= 8192) hipLaunchKernelGGL((scatter_runs_kernel<64, 1>), dim3(grid), dim3(256), 0, st, a);
+    if (run_len == SC_RUN_SMALL) {
+        // batch-sized launch: whole short runs in flight (16 rows requested together), one instantiation per column count
+        if (D <= 64) hipLaunchKernelGGL((scatter_runs_kernel<SC_RUN_SMALL, 1, SC_RUN_SMALL>), dim3(grid), dim3(256), 0, st, a);
+        else if (D <= 128) hipLaunchKernelGGL((scatter_runs_kernel<SC_RUN_SMALL, 2, SC_RUN_SMALL>), dim3(grid), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((scatter_runs_kernel<8, 4, SC_RUN_SMALL>), dim3(grid), dim3(256), 0, st, a);
+    }
+    else if (D <= 64 && !arg && n_runs <= 8192) hipLaunchKernelGGL((scatter_runs_kernel<64, 1>), dim3(grid), dim3(256), 0, st, a);
     else if (D <= 64 && !arg) hipLaunchKernelGGL((scatter_runs_kernel<8, 1>), dim3(grid), dim3(256), 0, st, a);
     else if (D <= 64) hipLaunchKernelGGL((scatter_runs_kernel<16, 1>), dim3(grid), dim3(256), 0, st, a);   // (+ the argmax ids: 2 registers per row)
     else if (D <= 128) hipLaunchKernelGGL((scatter_runs_kernel<16, 2>), dim3(grid), dim3(256), 0, st, a);

@@ -64,7 +64,7 @@ def _hand_over(stream, *objs):
         if isinstance(o, torch.Tensor):
             if o.is_cuda:
                 o.record_stream(stream)
-            for nm in ('_sgnn_ids32', '_sgnn_sorted', '_sgnn_both'):
+            for nm in ('_sgnn_ids32', '_sgnn_sorted', '_sgnn_both', '_sgnn_all'):
                 extra = getattr(o, nm, None)
                 if extra is not None:
                     _hand_over(stream, extra)
@@ -467,6 +467,9 @@ def prepare_pass(model, split='train', timer=None, shard=None, defer_dtw=False):
                     # the stacked walks and the sort their embedding lookup's backward needs are made here
                     for v in a_struct.values():
                         v[2]._sgnn_both = ops.presort_ids(torch.cat([v[2], v[3]], 0), g.max_id)
+                    if L > 1:                            # (forward runs ONE LSTM pass over the walks of all layers)
+                        a_struct[0][2]._sgnn_all = ops.presort_ids(
+                            torch.cat([t for l in range(L) for t in (a_struct[l][2], a_struct[l][3])], 0), g.max_id)
                 # the column upload is a blocking host->device copy: do it here, before the long DTW
                 # launches are queued, so that the host is free to queue forward/backward behind them
                 st.sim_cols = (a_struct, model.sim_cols_of(a_struct))
@@ -681,7 +684,7 @@ class PassPipeline:
         return install_pass(self.model, st, timer)
 
 
-_TENSOR_ATTRS = ('_sgnn_ids32', '_sgnn_sorted', '_sgnn_both', '_sgnn_member_order')
+_TENSOR_ATTRS = ('_sgnn_ids32', '_sgnn_sorted', '_sgnn_both', '_sgnn_all', '_sgnn_member_order')
 
 
 def _copy_into(dst, src, path, replaced, memo=None):
@@ -760,7 +763,7 @@ def install_pass_static(model, st, timer=None):
     model.init_all_embeddings(split=st.split, trainable=model.hparams['trainable_cc'], lazy=True)
     t.mark('install_copies')
     model._bump_generation()
-    return [r for r in replaced if not r.startswith(_SHAPE_ONLY) or '_sgnn_both' in r]
+    return [r for r in replaced if not r.startswith(_SHAPE_ONLY) or '_sgnn_both' in r or '_sgnn_all' in r]
 
 
 class CapturedTraining:
