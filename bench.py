@@ -518,13 +518,20 @@ def main():
     torch.cuda.synchronize()
     t_cold = time.perf_counter()
     if pipe is not None:
-        for _ in range(max(1, args.pipeline_depth if not multi else 1)):
-            pipe.start()                                         # the first pass(es); every step starts another one
+        for k_ in range(max(1, args.pipeline_depth if not multi else 1)):
+            pipe.start(timed=(k_ == 0))                          # the first pass(es); every step starts another one
     priming_ms = []
-    for _ in range(PRIMING_PASSES):
-        step(False)
+    first_breakdown = None
+    for k_ in range(PRIMING_PASSES):
+        tm_ = step(k_ == 0)[0]
         torch.cuda.synchronize()
         priming_ms.append((time.perf_counter() - t_cold) * 1e3)  # cumulative: [cold first pass, + the second]
+        if k_ == 0:
+            # where the cold pass's time goes (HIP events per stage; the preparation stages of a pipelined run come from the
+            # preparation stream's timer).  Kept out of the timed region's stage averages.
+            first_breakdown = {k: round(v, 2) for k, v in tm_.summary().items()}
+            if side_timers:
+                first_breakdown.update({k: round(v, 2) for k, v in side_timers.pop().summary().items()})
     first_pass_ms = priming_ms[0]                                # cold: no kept orders / hints / shapes, allocator empty
     second_pass_ms = priming_ms[1] - priming_ms[0]
     for _ in range(args.warmup):
@@ -839,6 +846,10 @@ def main():
         # The cold first pass (nothing kept, allocator empty, kernels' first launch) and the second one, host-timed with a
         # device synchronisation after each:
         'first_pass_ms': round(first_pass_ms, 2), 'second_pass_ms': round(second_pass_ms, 2),
+        'first_pass_breakdown_ms': first_breakdown,
+        # one-time start-up paid at model construction instead of inside the first pass (ops.warm_up: this library's code objects,
+        # BLAS handles, the torch kernels of the preparation)
+        'warm_up_ms_at_construction': round(1e3 * getattr(model, 'warm_up_s', 0.0), 1),
     }
     if world == 1 and args.scaling == 'weak':
         result['projection'] = projection(args, result, model, S, sequential_ms, shard_line)

@@ -40,6 +40,10 @@ extern "C" {
 
 #define SGNN_ABI_VERSION 8
 int sgnn_abi_version(void);
+/* Load the code objects of every translation unit of the library on the current device (one empty launch each on ``stream``):
+ * what the first call of each kernel family would otherwise pay, 5-25 ms at a time, inside the reference's one-time
+ * prepare_data (SubGNN/SubGNN.py:1024-1063).  Idempotent and cheap when they are loaded.  0 = ok. */
+int sgnn_warm_up(void* stream);
 /* last hip error string for SGNN_ERR_LAUNCH (static storage) */
 const char* sgnn_last_error(void);
 

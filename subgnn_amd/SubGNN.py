@@ -152,6 +152,9 @@ class SubGNN(nn.Module):
         self._deterministic = bool(hp.get('deterministic', True))
         self.metric_scores = []
         self.to(self.device)
+        # one-time start-up of the device libraries and of this library's code objects: paid here, once per process, not
+        # in the middle of prepare_data (hparams['warm_up'] = False leaves it to the first pass)
+        self.warm_up_s = ops.warm_up(self.device) if (self.device.type == 'cuda' and hp.get('warm_up', True)) else 0.0
 
     # ------------------------------------------------------------------ data -------------
     def read_data(self):

@@ -29,6 +29,7 @@ class MpnArgs(ctypes.Structure):
 # name -> (restype, argtypes); mirrors include/subgnn_hip.h line by line
 SIGNATURES = {
     'sgnn_abi_version': (c_int, []),
+    'sgnn_warm_up': (c_int, [c_ptr]),
     'sgnn_last_error': (ctypes.c_char_p, []),
     'sgnn_degree_sequence': (c_int, [c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_int, c_ptr, c_ptr,
                                      c_ptr, c_ptr]),

@@ -200,3 +200,5 @@ extern "C" int sgnn_attn_scores_fwd_f16(const float* X, const float* U, const fl
     SGNN_CHECK_LAUNCH();
     return SGNN_OK;
 }
+
+SGNN_DEFINE_WARM(attention)

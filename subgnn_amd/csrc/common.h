@@ -121,3 +121,14 @@ __device__ static inline bool sgnn_sorted_contains(const int32_t* __restrict__ a
     return lo < n && a[lo] == key;
 }
 
+
+// ---- code-object warm-up ------------------------------------------------------------------------------------------------
+// The HIP runtime loads a translation unit's code object when the first of its kernels is launched (5-25 ms each, per
+// device): a cold first pass paid that sixteen times in the middle of the reference's one-time prepare_data.  Every .hip file
+// defines one empty kernel; sgnn_warm_up() (lib.hip) launches them all, so that a caller can pay the loads once, up front.
+#define SGNN_DEFINE_WARM(name)                                                                                       \
+    __global__ void sgnn_warm_kernel_##name() {}                                                                      \
+    extern "C" int sgnn_warm_##name(void* stream) {                                                                   \
+        hipLaunchKernelGGL(sgnn_warm_kernel_##name, dim3(1), dim3(64), 0, (hipStream_t)stream);                       \
+        return hipGetLastError() == hipSuccess ? 0 : -1;                                                              \
+    }

@@ -641,3 +641,5 @@ extern "C" int sgnn_degree_sequence_huge(const int64_t* rowptr, const int32_t* c
     return SGNN_OK;
 }
 
+
+SGNN_DEFINE_WARM(degree_sequence)

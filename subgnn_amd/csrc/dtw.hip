@@ -975,3 +975,5 @@ extern "C" int sgnn_dtw_similarity_live(const int64_t* x_ptr, const int32_t* x_v
     return dtw_run(x_ptr, x_val, n_x, max_x_len, y_ptr, y_val, n_y, max_y_len, tie_order, kernel, x_order, x_live_range, out,
                    workspace, workspace_bytes, stream);
 }
+
+SGNN_DEFINE_WARM(dtw)

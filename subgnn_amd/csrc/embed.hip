@@ -226,3 +226,5 @@ extern "C" int sgnn_masked_sum_bwd(const float* grad_out, const uint8_t* mask, i
     SGNN_CHECK_LAUNCH();
     return SGNN_OK;
 }
+
+SGNN_DEFINE_WARM(embed)

@@ -1948,3 +1948,5 @@ extern "C" int sgnn_patch_in_border_huge(const int64_t* rowptr, const int32_t* c
     return SGNN_OK;
 }
 
+
+SGNN_DEFINE_WARM(graph_sets)

@@ -109,3 +109,5 @@ extern "C" int sgnn_cross_entropy_bwd(const float* logits, const int64_t* labels
     SGNN_CHECK_LAUNCH();
     return SGNN_OK;
 }
+
+SGNN_DEFINE_WARM(loss)

@@ -268,3 +268,5 @@ extern "C" int sgnn_lstm_bwd(const float* whh, const float* gates, const float* 
     LSTM_DISPATCH(LSTM_BWD);
 #undef LSTM_BWD
 }
+
+SGNN_DEFINE_WARM(lstm)

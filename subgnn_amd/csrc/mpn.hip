@@ -532,3 +532,5 @@ extern "C" int sgnn_mpn_bwd_shared_det(const sgnn_mpn_args* args, const float* g
     return SGNN_OK;
 }
 
+
+SGNN_DEFINE_WARM(mpn)

@@ -163,3 +163,5 @@ extern "C" int sgnn_clip_coefficient(const float* partial, int64_t n_partial, co
     SGNN_CHECK_LAUNCH();
     return SGNN_OK;
 }
+
+SGNN_DEFINE_WARM(optim)

@@ -21,3 +21,5 @@ extern "C" int sgnn_probe_stream_copy(const void* src, void* dst, int64_t n_byte
     SGNN_CHECK_LAUNCH();
     return SGNN_OK;
 }
+
+SGNN_DEFINE_WARM(probe)

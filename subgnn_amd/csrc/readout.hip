@@ -354,3 +354,5 @@ extern "C" int sgnn_masked_sum_slot_bwd(const float* grad_out, int64_t grad_ld, 
     SGNN_CHECK_LAUNCH();
     return SGNN_OK;
 }
+
+SGNN_DEFINE_WARM(readout)

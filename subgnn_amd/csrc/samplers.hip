@@ -569,3 +569,5 @@ extern "C" int sgnn_triangular_walks(const int64_t* rowptr, const int32_t* col, 
     SGNN_CHECK_LAUNCH();
     return SGNN_OK;
 }
+
+SGNN_DEFINE_WARM(samplers)

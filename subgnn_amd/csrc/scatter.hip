@@ -296,3 +296,5 @@ extern "C" int sgnn_scatter_add_rows_sorted(const int32_t* order, const int32_t*
     SGNN_CHECK_LAUNCH();
     return SGNN_OK;
 }
+
+SGNN_DEFINE_WARM(scatter)

@@ -812,3 +812,5 @@ extern "C" int sgnn_min_hops_to_sets(const uint8_t* dist, int64_t n_sources, int
     SGNN_CHECK_LAUNCH();
     return SGNN_OK;
 }
+
+SGNN_DEFINE_WARM(similarity)

@@ -27,6 +27,8 @@ typedef float upd_f32x16 __attribute__((ext_vector_type(16)));
 #define UPD_STEPS 8             // contraction steps of the weight gradient whose operands are in flight together
 #define UPD_KC 64               // contraction positions held in registers at a time (per k-half)
 #define UPD_SPLIT_BELOW 16384    // rows below which the output tiles of a row block go to separate wavefronts
+#define UPD_KSPLIT_BELOW 4096    // rows below which a tile's contraction is split over the four wavefronts of a workgroup
+#define UPD_WAVE_ROWS_SMALL 16   // rows per wavefront of the weight-gradient kernel for calls below UPD_KSPLIT_BELOW rows
 
 // accumulator element v of lane l: row 8 * (v / 4) + 4 * (l / 32) + v % 4, column l % 32
 __device__ __forceinline__ int upd_acc_row(int v, int h) { return 8 * (v >> 2) + 4 * h + (v & 3); }
@@ -84,6 +86,51 @@ __global__ __launch_bounds__(64) void update_fwd_kernel(const float* __restrict_
     }
 }
 
+// KSPLIT: batch-sized calls (a few hundred rows: R / 32 x D / 32 tiles do not fill the chip, and one wavefront per tile walks
+// 2 D / 2 dependent MFMA + load steps: 12.5 us per call at R = 128, D = 128 -- 20 calls per step of the 4-layer HPO-METAB
+// stand-in).  A workgroup of four wavefronts per tile, each contracting a quarter of the positions of both halves; the partial
+// accumulators are added in wavefront order through LDS (a fixed order: bit-reproducible).
+template <int D>
+__global__ __launch_bounds__(256) void update_fwd_ksplit_kernel(const float* __restrict__ x, const float* __restrict__ aggr,
+                                                                const float* __restrict__ W, const float* __restrict__ b,
+                                                                int64_t R, float* __restrict__ out)
+{
+    constexpr int Q = D / 4;                                             // positions per wavefront (8 / 16 / 32)
+    __shared__ float s_part[3 * 16 * 64];
+    const int lane = threadIdx.x & 63, i = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t row0 = (int64_t)blockIdx.x * 32;
+    const int64_t row = row0 + i < R ? row0 + i : R - 1;
+    const int nt = blockIdx.y;
+    const float* __restrict__ src = (h ? aggr : x) + row * D + wave * Q;
+    const float* __restrict__ wrow = W + (int64_t)(nt * 32 + i) * (2 * D) + h * D + wave * Q;
+    float a[Q], w[Q];
+#pragma unroll
+    for (int c = 0; c < Q / 4; ++c) {
+        const float4 v = reinterpret_cast<const float4*>(src)[c];
+        const float4 u = reinterpret_cast<const float4*>(wrow)[c];
+        a[4 * c] = v.x; a[4 * c + 1] = v.y; a[4 * c + 2] = v.z; a[4 * c + 3] = v.w;
+        w[4 * c] = u.x; w[4 * c + 1] = u.y; w[4 * c + 2] = u.z; w[4 * c + 3] = u.w;
+    }
+    upd_f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < Q; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], w[s], acc, 0, 0, 0);
+    if (wave > 0) {
+#pragma unroll
+        for (int v = 0; v < 16; ++v) s_part[((wave - 1) * 16 + v) * 64 + lane] = acc[v];
+    }
+    __syncthreads();
+    if (wave != 0) return;
+    const int col = nt * 32 + i;
+    const float bias = b ? b[col] : 0.f;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+        const float sum = ((acc[v] + s_part[v * 64 + lane]) + s_part[(16 + v) * 64 + lane]) + s_part[(32 + v) * 64 + lane];
+        const int64_t r = row0 + upd_acc_row(v, h);
+        if (r < R) out[r * D + col] = fmaxf(sum + bias, 0.f);
+    }
+}
+
 // [grad_x | grad_aggr](r, c) = sum_n dpre(r, n) W(n, c): contraction index n walked as (half, position)
 template <int D, bool SPLIT>
 __global__ __launch_bounds__(64) void update_bwd_dx_kernel(const float* __restrict__ g, const float* __restrict__ out,
@@ -122,7 +169,7 @@ __global__ __launch_bounds__(64) void update_bwd_dx_kernel(const float* __restri
 // partial grad_W(n, c) = sum over the block's rows of dpre(r, n) [x | aggr](r, c); partial grad_b(n) = sum dpre(r, n).
 // blockIdx.x = row block, blockIdx.y = tile of 32 output features n.  The rows are the contraction: step s covers
 // rows r0 + 2 s + (lane / 32).
-template <int D>
+template <int D, int WR = UPD_WAVE_ROWS>
 __global__ __launch_bounds__(256) void update_bwd_dw_kernel(const float* __restrict__ g, const float* __restrict__ out,
                                                            const float* __restrict__ x, const float* __restrict__ aggr,
                                                            int64_t R, float* __restrict__ pW, float* __restrict__ pb)
@@ -131,7 +178,7 @@ __global__ __launch_bounds__(256) void update_bwd_dw_kernel(const float* __restr
     __shared__ float s_acc[(CT * 16 + 1) * 64];
     const int lane = threadIdx.x & 63, i = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int64_t r0 = (int64_t)blockIdx.x * UPD_ROWS + (int64_t)wave * UPD_WAVE_ROWS;
+    const int64_t r0 = (int64_t)blockIdx.x * (4 * WR) + (int64_t)wave * WR;
     const int nt = blockIdx.y;
     upd_f32x16 acc[CT];
 #pragma unroll
@@ -139,7 +186,7 @@ __global__ __launch_bounds__(256) void update_bwd_dw_kernel(const float* __restr
 #pragma unroll
         for (int v = 0; v < 16; ++v) acc[c][v] = 0.f;
     float bsum = 0.f;
-    const int64_t r_end = r0 + UPD_WAVE_ROWS < R ? r0 + UPD_WAVE_ROWS : R;
+    const int64_t r_end = r0 + WR < R ? r0 + WR : R;
     // UPD_STEPS contraction steps (2 rows each) at a time: all their operands are requested together, then the MFMAs
     // run back to back -- one step at a time the wavefront waited a memory round trip per step (154 us at R = 50k)
     for (int64_t rb = r0; rb < r_end; rb += 2 * UPD_STEPS) {
@@ -221,7 +268,8 @@ extern "C" int sgnn_update_fwd(const float* x, const float* aggr, const float* W
     hipStream_t st = (hipStream_t)stream;
     const unsigned grid = (unsigned)((R + 31) / 32);
     // few rows: the feature tiles side by side (more wavefronts than CUs only from ~8k rows on)
-#define UPD_LAUNCH_FWD(DD) do { if (split) hipLaunchKernelGGL((update_fwd_kernel<DD, true>), dim3(grid, DD / 32), dim3(64), 0, st, x, aggr, W, b, R, out); \
+#define UPD_LAUNCH_FWD(DD) do { if (R < UPD_KSPLIT_BELOW) hipLaunchKernelGGL((update_fwd_ksplit_kernel<DD>), dim3(grid, DD / 32), dim3(256), 0, st, x, aggr, W, b, R, out); \
+                                else if (split) hipLaunchKernelGGL((update_fwd_kernel<DD, true>), dim3(grid, DD / 32), dim3(64), 0, st, x, aggr, W, b, R, out); \
                                 else hipLaunchKernelGGL((update_fwd_kernel<DD, false>), dim3(grid), dim3(64), 0, st, x, aggr, W, b, R, out); } while (0)
     const bool split = R < UPD_SPLIT_BELOW;
     if (D == 32) UPD_LAUNCH_FWD(32); else if (D == 64) UPD_LAUNCH_FWD(64); else UPD_LAUNCH_FWD(128);
@@ -230,9 +278,13 @@ extern "C" int sgnn_update_fwd(const float* x, const float* aggr, const float* W
     return SGNN_OK;
 }
 
+// rows per partial sum: batch-sized calls (a few hundred rows) take 16 rows per wavefront -- with 64 a call of 128 rows was one
+// row block: two busy wavefronts per feature tile walking 32 dependent steps (28 us; 8 such calls per HPO-METAB stand-in step)
+static inline int64_t upd_block_rows(int64_t R) { return 4 * (R < UPD_KSPLIT_BELOW ? UPD_WAVE_ROWS_SMALL : UPD_WAVE_ROWS); }
+
 extern "C" int64_t sgnn_update_bwd_workspace_bytes(int64_t R, int64_t D)
 {
-    const int64_t nb = (R + UPD_ROWS - 1) / UPD_ROWS;
+    const int64_t nb = (R + upd_block_rows(R) - 1) / upd_block_rows(R);
     return nb * (D * 2 * D + D) * 4 + 64;
 }
 
@@ -262,11 +314,16 @@ extern "C" int sgnn_update_bwd(const float* grad_out, const float* out, const fl
     }
     if (grad_W || grad_b) {
         if (!workspace || workspace_bytes < sgnn_update_bwd_workspace_bytes(R, D)) return SGNN_ERR_BAD_ARG;
-        const int64_t nb = (R + UPD_ROWS - 1) / UPD_ROWS;
+        const int64_t nb = (R + upd_block_rows(R) - 1) / upd_block_rows(R);
         float* pW = (float*)workspace;
         float* pb = pW + nb * D * 2 * D;
         const dim3 grid((unsigned)nb, (unsigned)(D / 32));
-        if (D == 32) hipLaunchKernelGGL(update_bwd_dw_kernel<32>, grid, dim3(256), 0, st, grad_out, out, x, aggr, R, pW, pb);
+        if (R < UPD_KSPLIT_BELOW) {
+            if (D == 32) hipLaunchKernelGGL((update_bwd_dw_kernel<32, UPD_WAVE_ROWS_SMALL>), grid, dim3(256), 0, st, grad_out, out, x, aggr, R, pW, pb);
+            else if (D == 64) hipLaunchKernelGGL((update_bwd_dw_kernel<64, UPD_WAVE_ROWS_SMALL>), grid, dim3(256), 0, st, grad_out, out, x, aggr, R, pW, pb);
+            else hipLaunchKernelGGL((update_bwd_dw_kernel<128, UPD_WAVE_ROWS_SMALL>), grid, dim3(256), 0, st, grad_out, out, x, aggr, R, pW, pb);
+        }
+        else if (D == 32) hipLaunchKernelGGL(update_bwd_dw_kernel<32>, grid, dim3(256), 0, st, grad_out, out, x, aggr, R, pW, pb);
         else if (D == 64) hipLaunchKernelGGL(update_bwd_dw_kernel<64>, grid, dim3(256), 0, st, grad_out, out, x, aggr, R, pW, pb);
         else hipLaunchKernelGGL(update_bwd_dw_kernel<128>, grid, dim3(256), 0, st, grad_out, out, x, aggr, R, pW, pb);
         SGNN_CHECK_LAUNCH();
@@ -281,3 +338,5 @@ extern "C" int sgnn_update_bwd(const float* grad_out, const float* out, const fl
     }
     return SGNN_OK;
 }
+
+SGNN_DEFINE_WARM(update)

@@ -136,13 +136,19 @@ class Ragged:
 
     @staticmethod
     def from_lists(lists, device):
-        ptr = np.zeros(len(lists) + 1, dtype=np.int64)
-        for i, l in enumerate(lists):
-            ptr[i + 1] = ptr[i] + len(l)
-        flat = np.zeros(max(int(ptr[-1]), 1), dtype=np.int32)
-        for i, l in enumerate(lists):
-            flat[ptr[i]:ptr[i + 1]] = l
-        ml = max((len(l) for l in lists), default=0)
+        """One concatenated array + offsets, built without a Python loop over the lists (50k subgraph lists: the loop was
+        ~150 ms of the cold first pass), uploaded with two copies."""
+        import itertools
+        n = len(lists)
+        lens = np.fromiter(map(len, lists), dtype=np.int64, count=n)
+        ptr = np.zeros(n + 1, dtype=np.int64)
+        np.cumsum(lens, out=ptr[1:])
+        total = int(ptr[-1])
+        if total:
+            flat = np.fromiter(itertools.chain.from_iterable(lists), dtype=np.int32, count=total)
+        else:
+            flat = np.zeros(1, dtype=np.int32)
+        ml = int(lens.max()) if n else 0
         return Ragged(torch.from_numpy(ptr).to(device), torch.from_numpy(flat).to(device), max_len=ml)
 
     def to_padded(self, width=None, fill=PAD, dtype=torch.int64):
@@ -233,6 +239,43 @@ class DeviceGraph:
         return self
 
 
+_WARM = set()
+
+
+def warm_up(device=None):
+    """Pay the one-time start-up costs of the path NOW (a model's constructor calls this) instead of inside the first pass:
+    the code objects of libsubgnn_hip.so (sgnn_warm_up: one empty launch per translation unit), the BLAS libraries' handles and
+    first kernels (the head's and the LSTM's GEMM shapes), and the handful of torch kernels the preparation uses.  Once per
+    device and process; ~0.3-0.5 s the first time.  Nothing here computes a result anybody reads."""
+    if not torch.cuda.is_available():
+        return 0.0
+    dev = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+    if dev.type != 'cuda' or str(dev) in _WARM:
+        return 0.0
+    import time
+    t0 = time.perf_counter()
+    _WARM.add(str(dev))
+    with torch.cuda.device(dev):
+        check(_lib.load().sgnn_warm_up(_stream()), 'sgnn_warm_up')
+        # torch kernels of the preparation (sorts, scans, gathers, scatters, reductions) on a few elements each
+        i64 = torch.arange(8, device=dev)
+        i32 = i64.to(torch.int32)
+        f32 = torch.rand(8, 8, device=dev, requires_grad=True)
+        torch.cumsum(i64, 0); torch.sort(i64); torch.argsort(i32); i64.index_select(0, i64 % 4); i64.max(); (i64 != 0).sum()
+        torch.zeros(9, dtype=torch.int64, device=dev).scatter_(0, i64, i64); torch.where(i64 > 3, i64, i64 - 1)
+        torch.unique(i64 % 3, return_inverse=True); torch.repeat_interleave(i64, 2); torch.stack((i64.sum(), i64.sum()))
+        # the BLAS libraries (rocBLAS / hipBLASLt): handle creation + the GEMM forms the float half uses, forward and backward
+        w = torch.rand(8, 8, device=dev, requires_grad=True)
+        b = torch.rand(8, device=dev, requires_grad=True)
+        y = torch.nn.functional.dropout(torch.relu(torch.nn.functional.linear(f32, w, b)), 0.1, True)
+        y = y + torch.addmm(b, f32, w.t()) + torch.bmm(f32.view(2, 4, 8), w.view(2, 8, 4).transpose(1, 2).contiguous().transpose(1, 2)).reshape(8, 4).sum() \
+            + (f32 @ b).view(-1, 1) + torch.cat([f32, w], 0)[:8]
+        y.sum().backward()
+        torch._foreach_norm([w.grad, b.grad])
+        torch.cuda.synchronize(dev)
+    return time.perf_counter() - t0
+
+
 # ---------------------------------------------------------------------------------------
 # integer half
 # ---------------------------------------------------------------------------------------
@@ -280,7 +323,12 @@ def heaviest_first(g, sets):
     csum = torch.zeros(tot + 1, dtype=torch.int64, device=g.device)
     torch.cumsum(deg, 0, out=csum[1:])
     work = csum[sets.ptr[1:]] - csum[sets.ptr[:-1]]
-    return torch.argsort(work, descending=True).to(torch.int32).contiguous()
+    # descending by work = ascending by (cap - work) under the library's own stable radix sort (sgnn_sort_edges_by_key) -- the
+    # first use of torch.argsort loaded another library's sort (0.2 s of the cold first pass).  Only an ORDER of dispatch:
+    # works beyond the cap tie at the front.
+    cap = (1 << 31) - 1
+    key = (cap - work.clamp(max=cap)).to(torch.int32).contiguous()
+    return sort_edges_by_key(key, cap)[1]
 
 
 def degree_sequence(g, sets, sort=True, use_degree_dict=True, want_external=True, use_self_loop_table=True, order=None,
