@@ -743,7 +743,7 @@ def main():
                        'source': 'profiles/' + os.path.basename(pj) + ' (rocprofv3 --pmc, committed measurement of the external-side launch; '
                                  '%d wavefronts per SIMD; SIMD busy = 4 x SQ_ACTIVE_INST_VALU / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs))' % wps}
     # ---- N = 1: measured beside the headline, in this process -----------------------------------------
-    sequential_ms = shard_line = configs_obj = None
+    sequential_ms = shard_line = configs_obj = pool_reuse_ms = None
     if world == 1 and not args.no_extras and graphed is None:
         # (1) the schedule `--gpus 8` runs by default: sequential passes, two-stream preparation -- what projection.weak_* uses
         for _ in range(2):
@@ -755,6 +755,34 @@ def main():
             step(False, sequential=True)
         torch.cuda.synchronize()
         sequential_ms = 1e3 * (time.perf_counter() - t_s) / n_seq
+        # (1b) the reference's own amortisation (NOT the headline): the structure-patch pool -- patches, walks,
+        # degree sequences, DTW rows of all max_sim_epochs x 42 patches -- rebuilt every max_sim_epochs passes only, the passes
+        # in between re-pick their 42 from it (hotpath.PassPipeline(pool_epochs=...)); same pipelined schedule otherwise
+        if pipe_main is not None and trainer is None and hp['use_structure'] and hp.get('max_sim_epochs', 1) > 1:
+            try:
+                pe = int(hp['max_sim_epochs'])
+                pool_pipe = hotpath.PassPipeline(model, 'train', shard, pool_epochs=pe)
+                for _ in range(max(1, args.pipeline_depth)):
+                    pool_pipe.start()
+
+                def pool_step():
+                    pool_pipe.install()
+                    pool_pipe.start()
+                    out = model.training_step(hotpath.full_split_batch(model, 'train'), 0)
+                    model.backward(None, out['loss'], None, 0)
+                    opt.step()
+                    opt.zero_grad(set_to_none=True)
+                for _ in range(pe):
+                    pool_step()
+                torch.cuda.synchronize()
+                t_p = time.perf_counter()
+                for _ in range(2 * pe):
+                    pool_step()
+                torch.cuda.synchronize()
+                pool_reuse_ms = 1e3 * (time.perf_counter() - t_p) / (2 * pe)
+                del pool_pipe
+            except Exception as ex:
+                print('pool-reuse schedule not measured: %r' % (ex,), file=sys.stderr)
         # (2) the strong-scaling shard of BASELINE configs[3] as worded (50k subgraphs over 8 GPUs): rank 0's 6 250, live
         if S == 50_000:
             try:
@@ -855,6 +883,13 @@ def main():
         result['projection'] = projection(args, result, model, S, sequential_ms, shard_line)
     if sequential_ms is not None:
         result['sequential_ms_per_step'] = round(sequential_ms, 3)
+    if pool_reuse_ms is not None:
+        result['extra'] = {'pool_reuse_ms_per_step': round(pool_reuse_ms, 3), 'pool_reuse_subgraphs_per_s': round(S / pool_reuse_ms * 1e3),
+                           'pool_epochs': int(hp['max_sim_epochs']),
+                           'note': 'NOT the headline: the structure-patch pool (210 patches: walks, degree sequences, DTW rows) rebuilt every '
+                                   'max_sim_epochs passes, re-picked from in between (the reference samples and scores the pool once so that '
+                                   're-picking is free: SubGNN.py:783-833, anchor_patch_samplers.py:316-328); mean over two pool cycles, '
+                                   'pipelined schedule; bit-equal per consumed column (tests/test_gpu_hotpath.py::test_pool_reuse_pass_equals_a_full_pass)'}
     if shard_line is not None:
         result['shard6250'] = shard_line
     if configs_obj is not None:

@@ -372,6 +372,28 @@ __global__ __launch_bounds__(DTW_THREADS) void dtw_similarity_kernel(
 #define DTW_MINB20 3            // 168 registers: 3 wavefronts per SIMD (5.46 -> 4.65 ms on the benchmark's external side)
 #endif
 
+#ifdef DTW_PROBE_COUNT
+// Measurement build (tools/dtw_budget.py): what the register kernel executes per level, for the per-level instruction budget.
+// [level][0] wavefront-levels run, [1] cells evaluated by the wavefront (the lanes' union: per column 2 x pairs touched),
+// [2] cells of the lanes' own windows (summed over lanes), [3] columns swept, [4] (column, row pair) visits, [5] back-trace
+// steps (summed over lanes), [6] lanes with a pair at this level
+__device__ unsigned long long g_dtw_counts[8][8];
+extern "C" int sgnn_dtw_probe_counts(unsigned long long* out, int reset)
+{
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dtw_counts), sizeof(unsigned long long) * 64) != hipSuccess) return -1;
+    if (reset) { static unsigned long long z[64]; if (hipMemcpyToSymbol(HIP_SYMBOL(g_dtw_counts), z, sizeof(z)) != hipSuccess) return -1; }
+    return 0;
+}
+__device__ __forceinline__ unsigned long long dtw_probe_wave_sum(unsigned long long v)
+{
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+#define DTW_COUNT(LEV, WHAT, V) do { if ((threadIdx.x & 63) == 0) atomicAdd(&g_dtw_counts[(LEV) & 7][WHAT], (unsigned long long)(V)); } while (0)
+#else
+#define DTW_COUNT(LEV, WHAT, V) do { } while (0)
+#endif
+
 typedef unsigned short dtw_us2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t dtw_pkmax(uint32_t a, uint32_t b) {          // v_pk_max_u16
     const dtw_us2 m = __builtin_elementwise_max(__builtin_bit_cast(dtw_us2, a), __builtin_bit_cast(dtw_us2, b));
@@ -400,7 +422,7 @@ template <int RR, int TIE, bool WLDS, bool FINEST>
 __device__ __forceinline__ double dtw_wave_level(
     int32_t* __restrict__ fl, const double* __restrict__ xcol, const double* __restrict__ xrcol, int64_t n_x,
     const double* __restrict__ ycol, const double* __restrict__ yrcol, bool act,
-    int lx, int ly, int lxc, int lyc, bool coarsest, uint32_t* __restrict__ wl, uint32_t* __restrict__ wq, int64_t NT)
+    int lx, int ly, int lxc, int lyc, bool coarsest, uint32_t* __restrict__ wl, uint32_t* __restrict__ wq, int64_t NT, int lev = 0)
 {
     static_assert(RR % 2 == 0 && RR <= 32, "rows come in pairs");
     constexpr int P = RR / 2;
@@ -437,6 +459,16 @@ __device__ __forceinline__ double dtw_wave_level(
         const uint32_t lo = lohi[p] & 0xffff, hi = (uint32_t)lohi[p] >> 16;
         hull[p] = dtw_wave_pkmax(lohi[p] == EMPTY ? 0u : (((0x7fffu - lo) << 16) | (hi + 1)));
     }
+#ifdef DTW_PROBE_COUNT
+    {
+        unsigned long long own = 0;
+        for (int p = 0; p < P; ++p)
+            if (lohi[p] != EMPTY) own += (unsigned long long)(((uint32_t)lohi[p] >> 16) - (lohi[p] & 0xffff) + 1) * (2 * p + 1 < lx ? 2 : 1);
+        own = dtw_probe_wave_sum(own);
+        const unsigned long long lanes = dtw_probe_wave_sum(act ? 1ull : 0ull);
+        DTW_COUNT(lev, 0, 1); DTW_COUNT(lev, 2, own); DTW_COUNT(lev, 6, lanes);
+    }
+#endif
     double xp1[RR], xr[RR], col[RR];
 #pragma unroll
     for (int i = 0; i < RR; ++i) {
@@ -467,6 +499,7 @@ __device__ __forceinline__ double dtw_wave_level(
             const uint32_t t = (uint32_t)__builtin_amdgcn_readlane((int)tab, j - jc);
             const uint32_t am = t & 0xffffu;                                 // 0: no lane holds this column (cannot happen for real series)
             const int ra = (int)(t >> 16);
+            DTW_COUNT(lev, 1, 2 * __builtin_popcount(am)); DTW_COUNT(lev, 3, 1); DTW_COUNT(lev, 4, __builtin_popcount(am));
             // the row above the entry pair was evaluated in the previous column: its register is D[2 ra - 1][j - 1]
             const bool carry = ra > 0 && ((prev_am >> (ra - 1)) & 1u);
             prev_am = am;
@@ -579,7 +612,13 @@ __device__ __forceinline__ double dtw_wave_level(
     int i = lx - 1, j = ly - 1;
     int last = j;
     uint32_t word = WLDS ? wl[j * DTW_THREADS] : wq[(int64_t)j * NT];
+#ifdef DTW_PROBE_COUNT
+    unsigned long long bt_steps = 0;
+#endif
     while (i >= 0 && j >= 0) {
+#ifdef DTW_PROBE_COUNT
+        ++bt_steps;
+#endif
         const int d = (int)((word >> (2 * i)) & 3);
         if (d != 1) {                                                        // the path leaves row i here, at column j
             FLQ(i) = (last << 16) | j;
@@ -593,6 +632,9 @@ __device__ __forceinline__ double dtw_wave_level(
     }
     // (a path that runs off the first column inside a row -- only possible through a window's edge -- leaves that row open)
     if (i >= 0 && j < 0) FLQ(i) = (last << 16) | 0;
+#ifdef DTW_PROBE_COUNT
+    atomicAdd(&g_dtw_counts[lev & 7][5], bt_steps);
+#endif
     return result;
 #undef FLQ
 }
@@ -633,7 +675,7 @@ template <int RR, int TIE, bool WLDS>
 __device__ __forceinline__ void dtw_wave_level_pp(
     int32_t* __restrict__ fl, const double* __restrict__ xcol, const double* __restrict__ xrcol, int64_t n_x,
     const double* __restrict__ ycol, const double* __restrict__ yrcol, bool act,
-    int lx, int ly, int lxc, int lyc, bool coarsest, uint32_t* __restrict__ wl, uint32_t* __restrict__ wq, int64_t NT)
+    int lx, int ly, int lxc, int lyc, bool coarsest, uint32_t* __restrict__ wl, uint32_t* __restrict__ wq, int64_t NT, int lev = 0)
 {
     static_assert(RR % 2 == 0 && 2 * RR <= 27, "two bits per row below the row number");
     constexpr int P = RR / 2;
@@ -668,6 +710,16 @@ __device__ __forceinline__ void dtw_wave_level_pp(
         const uint32_t lo = lohi[p] & 0xffff, hi = (uint32_t)lohi[p] >> 16;
         hull[p] = dtw_wave_pkmax(lohi[p] == EMPTY ? 0u : (((0x7fffu - lo) << 16) | (hi + 1)));
     }
+#ifdef DTW_PROBE_COUNT
+    {
+        unsigned long long own = 0;
+        for (int p = 0; p < P; ++p)
+            if (lohi[p] != EMPTY) own += (unsigned long long)(((uint32_t)lohi[p] >> 16) - (lohi[p] & 0xffff) + 1) * (2 * p + 1 < lx ? 2 : 1);
+        own = dtw_probe_wave_sum(own);
+        const unsigned long long lanes = dtw_probe_wave_sum(act ? 1ull : 0ull);
+        DTW_COUNT(lev, 0, 1); DTW_COUNT(lev, 2, own); DTW_COUNT(lev, 6, lanes);
+    }
+#endif
     double xp1[RR], xr[RR], cA[RR], cB[RR];
 #pragma unroll
     for (int i = 0; i < RR; ++i) {
@@ -735,6 +787,7 @@ __device__ __forceinline__ void dtw_wave_level_pp(
                 const uint32_t t = (uint32_t)__builtin_amdgcn_readlane((int)tab, J_ - jc);                           \
                 const uint32_t am = t & 0xffffu;                                                                     \
                 const int ra = (int)((t >> 16) & 0x7ffu);                                                            \
+                DTW_COUNT(lev, 1, 2 * __builtin_popcount(am)); DTW_COUNT(lev, 3, 1); DTW_COUNT(lev, 4, __builtin_popcount(am)); \
                 const bool carry = ra > 0 && ((prev_am >> (ra - 1)) & 1u);                                           \
                 prev_am = am;                                                                                        \
                 uint32_t word = 0;                                                                                   \
@@ -762,7 +815,13 @@ __device__ __forceinline__ void dtw_wave_level_pp(
     int i = lx - 1, j = ly - 1;
     int last = j;
     uint32_t word = WLDS ? wl[j * DTW_THREADS] : wq[(int64_t)j * NT];
+#ifdef DTW_PROBE_COUNT
+    unsigned long long bt_steps = 0;
+#endif
     while (i >= 0 && j >= 0) {
+#ifdef DTW_PROBE_COUNT
+        ++bt_steps;
+#endif
         const int sh = 2 * ((int)(word >> 27) - i);
         const uint32_t b = (word >> sh) & 3u;                                // first bit << 1 | second bit
         int d;
@@ -779,6 +838,9 @@ __device__ __forceinline__ void dtw_wave_level_pp(
         if (d != 1) last = j;
     }
     if (i >= 0 && j < 0) FLQ(i) = (last << 16) | 0;
+#ifdef DTW_PROBE_COUNT
+    atomicAdd(&g_dtw_counts[lev & 7][5], bt_steps);
+#endif
 #undef FLQ
 }
 
@@ -845,12 +907,12 @@ __global__ __launch_bounds__(DTW_THREADS, MINB) void dtw_similarity_reg_kernel(
 #endif
             if (lev == 0)
                 result = dtw_wave_level<RMAX, TIE, WLDS, true>(fl, xcol, xrcol, n_x, ycol, yrcol, act, lx, ly, lxc, lyc,
-                                                               coarsest, wl, w, NT);
+                                                               coarsest, wl, w, NT, lev);
             else if constexpr (2 * RH <= 27 && !DTW_OLD_COARSE)
-                dtw_wave_level_pp<RH, TIE, WLDS>(fl, xcol, xrcol, n_x, ycol, yrcol, act, lx, ly, lxc, lyc, coarsest, wl, w, NT);
+                dtw_wave_level_pp<RH, TIE, WLDS>(fl, xcol, xrcol, n_x, ycol, yrcol, act, lx, ly, lxc, lyc, coarsest, wl, w, NT, lev);
             else
                 dtw_wave_level<RH, TIE, WLDS, false>(fl, xcol, xrcol, n_x, ycol, yrcol, act, lx, ly, lxc, lyc, coarsest,
-                                                     wl, w, NT);
+                                                     wl, w, NT, lev);
         }
         if (have) out[r * n_y + a] = valid ? (float)(1.0 / (result + 1.0)) : 0.f;
     }

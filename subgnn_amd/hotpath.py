@@ -274,12 +274,22 @@ class PassState:
         self.sim_cols = None       # (anchors_structure, {layer: device index tensor}) when new patches were drawn
         self.dtw_inputs = None     # between prepare_pass(defer_dtw=True) and finish_pass: what the DTW launches read
         self.bfs_checks = []       # hinted position-channel searches to verify before the pass is consumed (_verify_bfs)
+        self.pool_reused = False   # the pass re-picked from an earlier pass's structure-patch pool (prepare_pass(pool=...))
 
     def tensors(self):
         return [self.attrs, self.per_split, self.sim_cols[1] if self.sim_cols else None]
 
 
-def prepare_pass(model, split='train', timer=None, shard=None, defer_dtw=False):
+def pool_of(st):
+    """The structure-patch pool a full pass built (patches, walks, similarity rows of every pool patch): what a later pass may
+    reuse instead of rebuilding it (``prepare_pass(pool=...)``)."""
+    sp = st.split
+    return {'structure_anchors': st.attrs['structure_anchors'],
+            'int_w': st.attrs['int_structure_anchor_random_walks'], 'bor_w': st.attrs['bor_structure_anchor_random_walks'],
+            'int_sims': st.attrs[sp + '_int_struc_similarities'], 'bor_sims': st.attrs[sp + '_bor_struc_similarities']}
+
+
+def prepare_pass(model, split='train', timer=None, shard=None, defer_dtw=False, pool=None):
     """The sampling + similarity half of a pass (everything that does not read the embedding table), for one split
     (SubGNN.py:1024-1063 semantics, sparse similarities) -> PassState.  The model's per-pass attributes are left
     alone (only its per-split caches of pass-invariant facts are filled), so the pass can be prepared while the
@@ -295,10 +305,17 @@ def prepare_pass(model, split='train', timer=None, shard=None, defer_dtw=False):
     the BFS kernels are memory-bound with small workgroups: on the benchmark the three stages take 4.7 ms back to
     back and 4.0 ms overlapped (17.9 -> 17.0 ms per pass).  The DTW cannot share a CU (it holds every vector
     register at three wavefronts of 168 registers per SIMD), so nothing is overlapped with it.  The strong-scaling form issues
-    collectives inside the position block and keeps one stream."""
+    collectives inside the position block and keeps one stream.
+    ``pool`` (``pool_of`` an earlier pass of the same split): the structure-patch pool is REUSED -- no patches, walks, degree
+    sequences or DTW launches; the pass re-picks its layers' patches from the pool (init_anchors_structure) and reads the
+    pool's similarity rows.  The reference's design: max_sim_epochs x n_anchor_patches_structure x n_layers patches are sampled
+    and scored once (SubGNN.py:783-833, anchor_patch_samplers.py:210-243) so that re-picking is free (aps:316-328)."""
     hp, g, dev = model.hparams, model.networkx_graph, model.device
+    if pool is not None and (shard is not None and shard.deal_shared):
+        raise ValueError('pool reuse is not combined with the dealt (strong-scaling) form')
     seed = int(hp.get('seed', 0)) & tape.MASK64
     st = PassState(split)
+    st.pool_reused = pool is not None
     t = timer or StageTimer(False)
     L = hp['n_layers']
     main = torch.cuda.current_stream()
@@ -353,8 +370,8 @@ def prepare_pass(model, split='train', timer=None, shard=None, defer_dtw=False):
     with torch.cuda.stream(side):
         # The structure patches keep the walks' full width (no trim to the longest walk: that was a host round trip, and
         # with a second prepared pass queued on this stream the host waited for that pass's DTW launch there).
-        new_patches = hp['use_structure'] and (split != 'test' or getattr(model, 'structure_anchors', None) is None)
-        structure_anchors = getattr(model, 'structure_anchors', None)
+        new_patches = hp['use_structure'] and pool is None and (split != 'test' or getattr(model, 'structure_anchors', None) is None)
+        structure_anchors = getattr(model, 'structure_anchors', None) if pool is None else pool['structure_anchors']
         if new_patches:
             if shard is not None and shard.deal_shared and hp['structure_patch_type'] == 'triangular_random_walk':
                 # strong scaling: every rank walks an eighth of the shared patches (tape items = global walk numbers)
@@ -459,7 +476,11 @@ def prepare_pass(model, split='train', timer=None, shard=None, defer_dtw=False):
                 views = aps.patch_node_views(structure_anchors)
                 bor_w = st.attrs['bor_structure_anchor_random_walks'] = aps.perform_random_walks(hp, g, structure_anchors, False, views)
                 int_w = st.attrs['int_structure_anchor_random_walks'] = aps.perform_random_walks(hp, g, structure_anchors, True, views)
-            if new_patches:
+            if pool is not None:
+                int_w, bor_w = pool['int_w'], pool['bor_w']
+                st.attrs['structure_anchors'] = structure_anchors
+                st.attrs['int_structure_anchor_random_walks'], st.attrs['bor_structure_anchor_random_walks'] = int_w, bor_w
+            if new_patches or pool is not None:
                 a_struct = st.attrs['anchors_structure'] = aps.init_anchors_structure(hp, structure_anchors, int_w, bor_w,
                                                                                       indices_on_device=True)
                 if det:
@@ -473,6 +494,8 @@ def prepare_pass(model, split='train', timer=None, shard=None, defer_dtw=False):
                 # the column upload is a blocking host->device copy: do it here, before the long DTW
                 # launches are queued, so that the host is free to queue forward/backward behind them
                 st.sim_cols = (a_struct, model.sim_cols_of(a_struct))
+            if pool is not None:
+                return                                   # the pool's similarity rows exist: no degree sequences, no DTW
             a_sets = ops.Ragged.from_padded(structure_anchors)
             ai, ae = ops.degree_sequence(g, a_sets, sort=True, use_degree_dict=g.full_degree is not None)
         if hp['use_structure'] and side is main:
@@ -516,7 +539,7 @@ def prepare_pass(model, split='train', timer=None, shard=None, defer_dtw=False):
         st.per_split['_mpn_edge_plans'] = plans
         t.mark('border_bfs+N_anchors')
     ci = ce = None
-    if hp['use_structure']:
+    if hp['use_structure'] and pool is None:
         ci, ce = ops.degree_sequence(g, cc_sets, sort=True, use_degree_dict=g.full_degree is not None,
                                      order=set_order)
         t.mark('degree_sequences')
@@ -530,7 +553,9 @@ def prepare_pass(model, split='train', timer=None, shard=None, defer_dtw=False):
     # position search that is still running (small shards: the search does not shrink with the shard, everything else does)
     # overlaps with them instead of delaying them (6 250 subgraphs: the main chain reaches this point after ~1.3 ms, the search
     # ends at ~1.6).  At the benchmark's 50k subgraphs the search has long finished when the main chain gets here.
-    st.dtw_inputs = (cc_sets, ci, ce, a_sets, ai, ae, (S, C)) if hp['use_structure'] else None
+    st.dtw_inputs = (cc_sets, ci, ce, a_sets, ai, ae, (S, C)) if (hp['use_structure'] and pool is None) else None
+    if pool is not None and hp['use_structure']:
+        st.attrs[split + '_int_struc_similarities'], st.attrs[split + '_bor_struc_similarities'] = pool['int_sims'], pool['bor_sims']
     if late_bfs:
         dtw_ev = torch.cuda.Event()
         dtw_ev.record(main)                                 # the DTW launches are queued right behind this ...
@@ -638,11 +663,14 @@ class PassPipeline:
     what the sequential one draws.  Collectives of the prepared pass (the width reductions of a sharded pass) must use
     their own communicator (``dist.Shard(collectives=...)``): they run concurrently with the gradient exchange."""
 
-    def __init__(self, model, split='train', shard=None):
+    def __init__(self, model, split='train', shard=None, pool_epochs=1):
+        """``pool_epochs`` > 1: the structure-patch pool (patches, walks, DTW rows) is rebuilt every ``pool_epochs`` passes only
+        and re-picked from in between (prepare_pass(pool=...)); the reference's own schedule with hparams['max_sim_epochs']."""
         self.model, self.split, self.shard = model, split, shard
         self.stream = torch.cuda.Stream()
         self.pending = collections.deque()         # (state, its stage timer, event: prepared) in preparation order
         self.timer = None                          # stage timer of the pass installed last
+        self.pool_epochs, self._n_started, self._pool = max(1, int(pool_epochs)), 0, None
 
     @property
     def state(self):
@@ -660,8 +688,12 @@ class PassPipeline:
         else:
             self.stream.wait_stream(main)
         timer = StageTimer(timed)
+        reuse = self._pool if (self.pool_epochs > 1 and self._n_started % self.pool_epochs != 0) else None
         with torch.cuda.stream(self.stream):
-            state = prepare_pass(self.model, self.split, timer, self.shard)
+            state = prepare_pass(self.model, self.split, timer, self.shard, pool=reuse)
+            if reuse is None and self.pool_epochs > 1 and self.model.hparams['use_structure']:
+                self._pool = pool_of(state)
+            self._n_started += 1
             timer.mark('prepared')
             done = torch.cuda.Event()
             done.record()

@@ -502,3 +502,44 @@ def test_position_search_queued_beside_the_dtw_prepares_the_same_pass(name, tmp_
         assert sa.keys() == sb.keys() and len(sa) > 10
         for k in sa:
             assert torch.equal(sa[k], sb[k]), k
+
+
+@pytest.mark.parametrize('name', ['tiny', 'density'])
+def test_pool_reuse_pass_equals_a_full_pass(name, tmp_path):
+    """a pass that REUSES the structure-patch pool of an earlier pass (no patches, walks, degree sequences, DTW:
+    hotpath.prepare_pass(pool=...), PassPipeline(pool_epochs=max_sim_epochs)) hands the model bit for bit what a full pass does --
+    every similarity column the forward consumes, the re-picked patches and walks, and hence the logits."""
+    from conftest import load_golden
+    from subgnn_amd import hotpath
+    golden = load_golden(name)
+    full, reuse = _models(golden, tmp_path)
+    first = hotpath.prepare_pass(reuse, 'train')
+    hotpath.install_pass(reuse, first)
+    st = hotpath.prepare_pass(reuse, 'train', pool=hotpath.pool_of(first))
+    assert st.pool_reused and not first.pool_reused                   # nothing of the structure pool was rebuilt
+    hotpath.install_pass(reuse, st)
+    hotpath.prepare_sparse(full, 'train')
+    assert torch.equal(full.structure_anchors, reuse.structure_anchors)
+    for sim in ('train_int_struc_similarities', 'train_bor_struc_similarities'):
+        assert torch.equal(getattr(full, sim), getattr(reuse, sim))
+    for l in range(full.hparams['n_layers']):
+        for a, b in zip(full.anchors_structure[l], reuse.anchors_structure[l]):
+            assert torch.equal(torch.as_tensor(a), torch.as_tensor(b).to(torch.as_tensor(a).device))
+        assert torch.equal(full._sim_col_cache[l], reuse._sim_col_cache[l])
+    reuse.load_state_dict(full.state_dict())
+    full.eval(); reuse.eval()
+    with torch.no_grad():
+        a = full._forward_batch('train', hotpath.full_split_batch(full, 'train'))
+        b = reuse._forward_batch('train', hotpath.full_split_batch(reuse, 'train'))
+    assert torch.equal(a, b)
+    # the pipelined form: passes 0 and 2 rebuild the pool, pass 1 re-picks from it
+    pipe = hotpath.PassPipeline(reuse, 'train', pool_epochs=2)
+    kinds = []
+    for _ in range(3):
+        pipe.start()
+        kinds.append(pipe.pending[-1][0].pool_reused)
+        pipe.install()
+        with torch.no_grad():
+            assert torch.equal(reuse._forward_batch('train', hotpath.full_split_batch(reuse, 'train')), a)
+    torch.cuda.synchronize()
+    assert kinds == [False, True, False]
