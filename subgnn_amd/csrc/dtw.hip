@@ -362,6 +362,9 @@ __global__ __launch_bounds__(DTW_THREADS) void dtw_similarity_kernel(
 #ifndef DTW_OLD_COARSE
 #define DTW_OLD_COARSE 0          // 1: the coarse levels of rounds 1-3 (one column array, 2-bit codes at fixed positions) for every instantiation
 #endif
+#ifndef DTW_NO_ROW_MAJOR
+#define DTW_NO_ROW_MAJOR 0        // 1: round 4's coarse levels (a word of predecessor bits per column in LDS, cell-by-cell back-trace) also for levels of <= 32 columns
+#endif
 #ifndef DTW_MINB12
 #define DTW_MINB12 3            // resident 256-thread blocks per CU the 12-row kernel is compiled for
 #endif
@@ -844,6 +847,188 @@ __device__ __forceinline__ void dtw_wave_level_pp(
 #undef FLQ
 }
 
+// ---- coarse levels, round 5: predecessor bits kept ROW-major in registers, the back-trace one step per ROW ------------------
+// Round 4's levels wrote one word of predecessor bits per column to LDS and walked the path back cell by cell: ~45 dependent
+// steps per pair over the three coarse levels of the benchmark (26 + 13 + 6), each a chain of ~20 vector instructions around an
+// LDS read whose address depends on the step before -- a per-lane serial loop inside a kernel whose every other part runs in
+// lockstep.  Here
+//   * each ROW keeps two 32-bit words (the two compare masks of its cells, one bit per evaluated column, shifted in through the
+//     carry exactly as before -- still two instructions per cell, no per-column word, no LDS store).  A row is evaluated over
+//     one contiguous column interval -- its pair's hull [ulo, uhi], wave-uniform -- so column j's bit sits at position uhi - j.
+//     Needs a level of at most 32 columns (anchor series of up to 65 entries); longer ones keep dtw_wave_level_pp;
+//   * the warp path visits every row, from the last to the first, and inside a row it can only move LEFT: the cells it crosses
+//     in row i are a run of "left" codes that starts at the column it entered the row.  With the row's bits in a register that
+//     run is a count of trailing ones -- shift, complement, find-first-set -- and the code at the run's end says whether the
+//     path goes up or diagonally.  The back-trace is a loop over ROWS, unrolled (all lanes are in the same row at the same
+//     time; only the column differs), ~12 vector instructions per row and no memory access but the row's (first, last) write.
+// Same predecessor rule, same path, same windows for the finer level: bit-identical to the cell-by-cell walk.
+template <int RR, int TIE>
+__device__ __forceinline__ void dtw_wave_level_rm(
+    int32_t* __restrict__ fl, const double* __restrict__ xcol, const double* __restrict__ xrcol, int64_t n_x,
+    const double* __restrict__ ycol, const double* __restrict__ yrcol, bool act,
+    int lx, int ly, int lxc, int lyc, bool coarsest, int lev = 0)
+{
+    static_assert(RR % 2 == 0 && RR <= 16, "rows come in pairs; two words of bits per row");
+    constexpr int P = RR / 2;
+#define FLQ(q) fl[(q) * DTW_THREADS]
+    const double INF = __longlong_as_double(0x7ff0000000000000ll);
+    const int32_t EMPTY = 1;
+    int32_t lohi[P];
+    if (coarsest) {
+#pragma unroll
+        for (int p = 0; p < P; ++p) lohi[p] = (act && 2 * p < lx) ? ((ly - 1) << 16) : EMPTY;
+    } else {
+        int prev_lo = 0;
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            const int ca = p - 1 < 0 ? 0 : p - 1;
+            const int cb = p + 1;
+            const int firstc = FLQ(ca) & 0xffff;
+            const int lastc = (cb < lxc) ? (FLQ(cb < P ? cb : P - 1) >> 16) : (lyc - 1);
+            int lo = 2 * (firstc - 1);
+            int hi = 2 * (lastc + 1) + 1;
+            if (lo < prev_lo) lo = prev_lo;
+            if (lo < 0) lo = 0;
+            if (hi > ly - 1) hi = ly - 1;
+            int32_t v = (hi << 16) | lo;
+            if (hi < lo || 2 * p >= lx || !act) v = EMPTY; else prev_lo = lo;
+            lohi[p] = v;
+        }
+    }
+    uint32_t hull[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        const uint32_t lo = lohi[p] & 0xffff, hi = (uint32_t)lohi[p] >> 16;
+        hull[p] = dtw_wave_pkmax(lohi[p] == EMPTY ? 0u : (((0x7fffu - lo) << 16) | (hi + 1)));
+    }
+#ifdef DTW_PROBE_COUNT
+    {
+        unsigned long long own = 0;
+        for (int p = 0; p < P; ++p)
+            if (lohi[p] != EMPTY) own += (unsigned long long)(((uint32_t)lohi[p] >> 16) - (lohi[p] & 0xffff) + 1) * (2 * p + 1 < lx ? 2 : 1);
+        own = dtw_probe_wave_sum(own);
+        const unsigned long long lanes = dtw_probe_wave_sum(act ? 1ull : 0ull);
+        DTW_COUNT(lev, 0, 1); DTW_COUNT(lev, 2, own); DTW_COUNT(lev, 6, lanes);
+    }
+#endif
+    double xp1[RR], xr[RR], cA[RR], cB[RR];
+    uint32_t mA[RR], mB[RR];                                                 // the rows' bits: first / second compare mask of every cell
+#pragma unroll
+    for (int i = 0; i < RR; ++i) {
+        const int64_t ic = i < lx ? i : 0;
+        xp1[i] = xcol[ic * n_x] + 1.0;
+        xr[i] = xrcol[ic * n_x];
+        cA[i] = INF;
+        cB[i] = INF;
+        mA[i] = 0u;
+        mB[i] = 0u;
+    }
+    const int lane = threadIdx.x & 63;
+    uint32_t prev_am = 0;
+    {                                                                        // (at most 32 columns: one table)
+        uint32_t tab;
+        {
+            const uint32_t c = (uint32_t)lane;
+            uint32_t ra = P, rb1 = 0;
+#pragma unroll
+            for (int p = P - 1; p >= 0; --p) ra = ((hull[p] & 0xffffu) > c) ? (uint32_t)p : ra;
+#pragma unroll
+            for (int p = 0; p < P; ++p) rb1 = (hull[p] != 0u && (0x7fffu - (hull[p] >> 16)) <= c) ? (uint32_t)(p + 1) : rb1;
+            tab = rb1 > ra ? ((((1u << rb1) - 1u) & ~((1u << ra) - 1u)) | (ra << 16)) : 0u;
+        }
+        double y_next = ycol[0], yr_next = yrcol[0];
+#define DTWR_IN(K) { const int lo_ = lohi[(K) < P ? (K) : 0] & 0xffff, hi_ = lohi[(K) < P ? (K) : 0] >> 16; in_ = J_ >= lo_ && J_ <= hi_; }
+#define DTWR_COST(I) dtw_mask_cost(in_, dtw_cost_rcp(xp1[(I) < RR ? (I) : 0], xr[(I) < RR ? (I) : 0], yp1, yr))
+        // one cell of row ROW: UPV / LEFT / DIAG are the three predecessors' values, OUT the register the cell's value goes into
+#define DTWR_CELL(UPV, LEFT, DIAG, DT, OUT, ROW)                                                                     \
+            {                                                                                                        \
+                const double c_up = (UPV) + (DT), c_left = (LEFT) + (DT), c_diag = (DIAG) + (DT);                    \
+                const double mv = fmin(fmin(c_up, c_left), c_diag);                                                  \
+                if (TIE == 0) { mA[ROW] = dtw_shift_in(mA[ROW], __ballot(c_up == mv)); mB[ROW] = dtw_shift_in(mB[ROW], __ballot(c_left == mv)); } \
+                else if (TIE == 1) { mA[ROW] = dtw_shift_in(mA[ROW], __ballot(c_diag == mv)); mB[ROW] = dtw_shift_in(mB[ROW], __ballot(c_up == mv)); } \
+                else { mA[ROW] = dtw_shift_in(mA[ROW], __ballot((DIAG) <= (UPV)) & __ballot((DIAG) <= (LEFT)));     \
+                       mB[ROW] = dtw_shift_in(mB[ROW], __ballot((UPV) <= (LEFT))); }                                 \
+                (OUT) = mv;                                                                                          \
+            }
+#define DTWR_PAIR(K, PREV, CUR)                                                                                      \
+            if ((K) < P && (am & (1u << (K)))) {                                                                     \
+                constexpr int a_ = 2 * (K) < RR ? 2 * (K) : 0, b_ = 2 * (K) + 1 < RR ? 2 * (K) + 1 : 0;              \
+                constexpr int u_ = (2 * (K) - 1) >= 0 && (2 * (K) - 1) < RR ? (2 * (K) - 1) : 0;                     \
+                bool in_;                                                                                            \
+                DTWR_IN(K)                                                                                           \
+                const double dt0_ = DTWR_COST(2 * (K));                                                              \
+                const double dt1_ = DTWR_COST(2 * (K) + 1);                                                          \
+                if ((K) == 0) {                                                                                      \
+                    const double diag0_ = (J_ == 0) ? 0.0 : INF;             /* virtual origin D[-1][-1] = 0 */       \
+                    DTWR_CELL(INF, PREV[a_], diag0_, dt0_, CUR[a_], a_)                                              \
+                } else {                                                                                             \
+                    if (ra == (K)) {                                         /* the row above is not part of this column */ \
+                        CUR[u_] = INF;                                                                               \
+                        if (!carry) PREV[u_] = INF;                                                                  \
+                        asm volatile("" ::: "memory");                       /* keeps this a branch */               \
+                    }                                                                                                \
+                    DTWR_CELL(CUR[u_], PREV[a_], PREV[u_], dt0_, CUR[a_], a_)                                        \
+                }                                                                                                    \
+                DTWR_CELL(CUR[a_], PREV[b_], PREV[a_], dt1_, CUR[b_], b_)                                            \
+            }
+#define DTWR_COLUMN(JJ, PREV, CUR)                                                                                   \
+            {                                                                                                        \
+                const int J_ = (JJ);                                                                                 \
+                const double yp1 = y_next + 1.0, yr = yr_next;                                                       \
+                if (J_ + 1 < ly) { y_next = ycol[J_ + 1]; yr_next = yrcol[J_ + 1]; }                                 \
+                const uint32_t t = (uint32_t)__builtin_amdgcn_readlane((int)tab, J_);                                \
+                const uint32_t am = t & 0xffffu;                                                                     \
+                const int ra = (int)((t >> 16) & 0x7ffu);                                                            \
+                DTW_COUNT(lev, 1, 2 * __builtin_popcount(am)); DTW_COUNT(lev, 3, 1); DTW_COUNT(lev, 4, __builtin_popcount(am)); \
+                const bool carry = ra > 0 && ((prev_am >> (ra - 1)) & 1u);                                           \
+                prev_am = am;                                                                                        \
+                DTWR_PAIR(0, PREV, CUR) DTWR_PAIR(1, PREV, CUR) DTWR_PAIR(2, PREV, CUR) DTWR_PAIR(3, PREV, CUR)      \
+                DTWR_PAIR(4, PREV, CUR) DTWR_PAIR(5, PREV, CUR) DTWR_PAIR(6, PREV, CUR) DTWR_PAIR(7, PREV, CUR)      \
+            }
+        int j = 0;
+        for (; j + 1 < ly; j += 2) {
+            DTWR_COLUMN(j, cB, cA)
+            DTWR_COLUMN(j + 1, cA, cB)
+        }
+        if (j < ly) DTWR_COLUMN(j, cB, cA)
+#undef DTWR_IN
+#undef DTWR_COST
+#undef DTWR_CELL
+#undef DTWR_PAIR
+#undef DTWR_COLUMN
+    }
+#ifdef DTW_PROBE_NO_BACKTRACK
+    return;
+#endif
+    // ---- back-trace, one step per row ------------------------------------------------------------------------------------
+    int j = act ? ly - 1 : -1;                                               // the column the path enters the current row at
+#pragma unroll
+    for (int i = RR - 1; i >= 0; --i) {
+        const uint32_t h = hull[i >> 1];
+        const int uhi = (int)(h & 0xffffu) - 1, ulo = 0x7fff - (int)(h >> 16);       // the row's evaluated columns (wave-uniform)
+        if (i < lx && j >= 0) {
+            const int pos = uhi - j;                                         // column j's bit
+            const uint32_t valid = (uhi - ulo + 1) >= 32 ? ~0u : ((1u << (uhi - ulo + 1)) - 1u);
+            const uint32_t A = mA[i], B = mB[i];
+            // the cells whose predecessor is (i, j - 1): rule 0: not up, left; rules 1 / 2: neither first nor second
+            const uint32_t is_left = (TIE == 0 ? (~A & B) : (~A & ~B)) & valid;
+            const uint32_t tl = (pos >= 0 && pos < 32) ? (is_left >> pos) : 0u;
+            int run = __ffs((int)~tl) - 1;                                   // trailing ones (tl has a zero: bit 31 - pos at the latest ... see valid)
+            if (run < 0) run = 32;
+            if (run > j) run = j;                                            // (a run into column 0 ends there)
+            const int first = j - run;
+            FLQ(i) = (j << 16) | first;
+            const int p2 = pos + run;
+            const uint32_t a2 = (p2 >= 0 && p2 < 32) ? ((A >> p2) & 1u) : 0u, b2 = (p2 >= 0 && p2 < 32) ? ((B >> p2) & 1u) : 0u;
+            // at the run's end: up, diagonal -- or still left, when the run was cut at column 0: the path ends in this row
+            const bool up = TIE == 0 ? (a2 != 0u) : (a2 == 0u && b2 != 0u);
+            const bool left_still = TIE == 0 ? (a2 == 0u && b2 != 0u) : (a2 == 0u && b2 == 0u);
+            j = left_still ? -1 : (up ? first : first - 1);
+        }
+    }
+#undef FLQ
+}
+
 // RMAX = rows the instantiation can hold (12 / 20 / 32): the register budget -- and with it the
 // number of resident wavefronts that hide the fp64 dependency chains -- follows the longest
 // component of the call, not the longest the kernel family supports.  The levels that are backtracked
@@ -908,8 +1093,14 @@ __global__ __launch_bounds__(DTW_THREADS, MINB) void dtw_similarity_reg_kernel(
             if (lev == 0)
                 result = dtw_wave_level<RMAX, TIE, WLDS, true>(fl, xcol, xrcol, n_x, ycol, yrcol, act, lx, ly, lxc, lyc,
                                                                coarsest, wl, w, NT, lev);
-            else if constexpr (2 * RH <= 27 && !DTW_OLD_COARSE)
-                dtw_wave_level_pp<RH, TIE, WLDS>(fl, xcol, xrcol, n_x, ycol, yrcol, act, lx, ly, lxc, lyc, coarsest, wl, w, NT, lev);
+            else if constexpr (2 * RH <= 27 && !DTW_OLD_COARSE) {
+                // (wave-uniform: one anchor per wavefront.  Only in the instantiation whose words sit in LDS -- anchor series of up to
+                // 96 entries: the other one serves longer series, whose first coarse level has more than 32 columns anyway)
+                if (WLDS && ly <= 32 && !DTW_NO_ROW_MAJOR)
+                    dtw_wave_level_rm<RH, TIE>(fl, xcol, xrcol, n_x, ycol, yrcol, act, lx, ly, lxc, lyc, coarsest, lev);
+                else
+                    dtw_wave_level_pp<RH, TIE, WLDS>(fl, xcol, xrcol, n_x, ycol, yrcol, act, lx, ly, lxc, lyc, coarsest, wl, w, NT, lev);
+            }
             else
                 dtw_wave_level<RH, TIE, WLDS, false>(fl, xcol, xrcol, n_x, ycol, yrcol, act, lx, ly, lxc, lyc, coarsest,
                                                      wl, w, NT, lev);
