@@ -11,9 +11,9 @@ sys.path.insert(0, os.path.join(REPO, 'tools'))
 import kernel_resources as KR                                      # noqa: E402
 
 LIBDIR = os.path.join(REPO, 'subgnn_amd', 'lib')
-# known and accepted: the 32-row DTW instantiation (components of 21..32 nodes: not on the benchmark's path) sits at the 256-register
-# ceiling of 2 blocks per CU with 2 registers in scratch outside its column loop
-ALLOWED_VGPR_SPILLS = {'dtw_similarity_reg_kernel<32': 2}
+# (round 4's build had one accepted entry -- the 32-row DTW instantiation with 2 registers in scratch; the one-division cost
+# function of round 5 freed them: no kernel of the library spills)
+ALLOWED_VGPR_SPILLS = {}
 # library kernels instantiated from headers (rocPRIM's sort): not ours to tune; their scratch is the library's choice
 FOREIGN = ('rocprim::',)
 

@@ -11,7 +11,7 @@ extra = sys.argv[2:]
 runs = []
 for i in range(n):
     env = dict(os.environ, SGNN_BENCH_CHECKSUMS=os.environ.get('SGNN_BENCH_CHECKSUMS', '1'))
-    r = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), '--no-cpu-baseline'] + extra, env=env, stdout=subprocess.PIPE,
+    r = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), '--no-cpu-baseline', '--no-extras'] + extra, env=env, stdout=subprocess.PIPE,
                        stderr=subprocess.DEVNULL, text=True)
     line = [l for l in r.stdout.splitlines() if l.startswith('{')]
     if not line:

@@ -6,7 +6,7 @@ export TMPDIR=/tmp
 T=$1
 D=gpurun_out/${T}_prof
 rm -rf $D
-SGNN_OVERLAP_STREAMS=0 rocprofv3 --kernel-trace --stats --output-format csv -d $D -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-pipeline > gpurun_out/${T}_bench_profiled.json 2> gpurun_out/${T}_prof.err
+SGNN_OVERLAP_STREAMS=0 rocprofv3 --kernel-trace --stats --output-format csv -d $D -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras --no-pipeline > gpurun_out/${T}_bench_profiled.json 2> gpurun_out/${T}_prof.err
 KT=$(find $D -name "*kernel_trace.csv" | head -1)
 KS=$(find $D -name "*kernel_stats.csv" | head -1)
 cp $KS gpurun_out/${T}_kernel_stats.csv
