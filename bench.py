@@ -681,7 +681,7 @@ def main():
                           'survey_8d_bytes_with_the_border_written': k1_bytes_8d,
                           'frac_on_survey_8d_bytes': k1_bytes_8d / (k1_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                           'stage_ms_in_timed_region': stage_ms.get('border_bfs+N_anchors'),
-                          'note': 'issue- and barrier-bound on one 1024-thread workgroup per CU around a 125 KB LDS bitmap (profiles/r04_khop1_pmc.json), '
+                          'note': 'issue- and barrier-bound on one 1024-thread workgroup per CU around a 125 KB LDS bitmap (r04 counters: 26 % of wave-cycles issuing, 57 % waiting; r05: its load phase runs at the fabric\'s rate, DESIGN 4), '
                                   'not memory-bound; the lists come from L2 / Infinity Cache (the CSR is 88 MB)'})
     if hp['use_position']:
         src = model.anchors_pos_ext[0].to(torch.int32).contiguous()
@@ -704,7 +704,7 @@ def main():
                                   'words x (16 N + 4 E): the pull levels gather a 32-byte row per edge out of 128-byte lines (DESIGN 4)'})
     traffic = traffic_src = hbm_frac = traffic_shipped = None
     out_of_cache = None
-    tf = next((f_ for f_ in (os.path.join(REPO, 'profiles', t_ + '_degseq_traffic.json') for t_ in ('r04', 'r02')) if os.path.exists(f_)), None)
+    tf = next((f_ for f_ in (os.path.join(REPO, 'profiles', t_ + '_degseq_traffic.json') for t_ in ('r05', 'r04', 'r02')) if os.path.exists(f_)), None)
     tf_name = 'profiles/' + os.path.basename(tf) if tf else None
     if tf:
         # PMC passes cannot run inside this process; these are the committed rocprofv3 measurements
@@ -726,7 +726,7 @@ def main():
     # the kernel that dominates the pass by TIME is not an HBM kernel: the DTW launch is bound by fp64 vector issue.  Its
     # counters are a committed measurement (tools/run_dtw_pmc.sh), quoted beside the roofline of the HBM-class kernel.
     longest = None
-    pj = next((f_ for f_ in (os.path.join(REPO, 'profiles', t_ + '_dtw_pmc.json') for t_ in ('r04', 'r03')) if os.path.exists(f_)), None)
+    pj = next((f_ for f_ in (os.path.join(REPO, 'profiles', t_ + '_dtw_pmc.json') for t_ in ('r05', 'r04', 'r03')) if os.path.exists(f_)), None)
     if pj:
         pm = json.load(open(pj))
         kk = [k for k in pm if 'dtw_similarity' in k]
