@@ -1110,7 +1110,7 @@ __global__ __launch_bounds__(DTW_THREADS, MINB) void dtw_similarity_reg_kernel(
 }
 
 // Processing-order key of the x rows of a DTW call: (length, the row's TWICE-HALVED series -- means of four
-// consecutive entries, what fastdtw's second coarsening level sees -- on a log scale, 8 steps per octave, up to six of
+// consecutive entries, what fastdtw's second coarsening level sees -- on a log scale, 4 steps per octave (round 5; 8 before), up to six of
 // them, first to last).  A pair's finest-level window follows from its coarse warp paths, and those from the coarse
 // series: rows whose coarse series agree sweep the same windows, so the lanes of a wavefront (consecutive rows of the
 // order, same anchor) stay in step.  Replay of 32 wavefronts of the benchmark's external side through the oracle:
@@ -1123,7 +1123,14 @@ __global__ void dtw_order_keys_kernel(const int64_t* __restrict__ x_ptr, const i
     if (i >= n_x) return;
     const int64_t b = x_ptr[i], len = x_ptr[i + 1] - b;
     int64_t key = (len > 0xFFF ? (int64_t)0xFFF : len) << 48;
-    auto q8 = [](float v) { const int q = (int)lrintf(8.f * log2f(1.f + (v < 0.f ? 0.f : v))); return (int64_t)(q > 255 ? 255 : q); };
+#ifndef DTW_KEY_STEPS
+#define DTW_KEY_STEPS 4.f       // log-scale steps per octave.  Round 5, cells a wavefront evaluates on the finest level (tools/dtw_budget.py; a
+#endif                          // lane's own window: 346.2) and the external side: 2 / 4 / 8 / 16 steps: 435.9 / 425.6 / 438.6 / 463.1 cells, 3.90 / 3.88 / 3.97 / 4.08 ms;
+                                // components in reverse (largest degrees first) 581 cells, middle-out 480: the ascending order stays
+#ifndef DTW_KEY_ORDER
+#define DTW_KEY_ORDER 0
+#endif
+    auto q8 = [](float v) { const int q = (int)lrintf(DTW_KEY_STEPS * log2f(1.f + (v < 0.f ? 0.f : v))); return (int64_t)(q > 255 ? 255 : q); };
     const int64_t n2 = len / 4;
     if (n2 == 0) {
         for (int64_t f = 0; f < len; ++f) key |= q8((float)x_val[b + f]) << (40 - 8 * f);
@@ -1132,7 +1139,10 @@ __global__ void dtw_order_keys_kernel(const int64_t* __restrict__ x_ptr, const i
         for (int64_t f = 0; f < nf; ++f) {
             const int64_t g = b + 4 * ((f * n2) / nf);
             const float v = 0.25f * ((float)x_val[g] + (float)x_val[g + 1] + (float)x_val[g + 2] + (float)x_val[g + 3]);
-            key |= q8(v) << (40 - 8 * f);
+            int64_t slot = f;                                        // significance of component f (0 = most significant)
+            if (DTW_KEY_ORDER == 1) slot = nf - 1 - f;               // the largest degrees first
+            else if (DTW_KEY_ORDER == 2) { const int64_t mid = nf / 2; const int64_t dlt = f - mid; slot = dlt == 0 ? 0 : (dlt > 0 ? 2 * dlt - 1 : -2 * dlt); if (slot >= nf) slot = nf - 1; }   // middle out
+            key |= q8(v) << (40 - 8 * slot);
         }
     }
     keys[i] = key;
