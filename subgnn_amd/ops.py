@@ -145,7 +145,10 @@ class Ragged:
         np.cumsum(lens, out=ptr[1:])
         total = int(ptr[-1])
         if total:
-            flat = np.fromiter(itertools.chain.from_iterable(lists), dtype=np.int32, count=total)
+            try:
+                flat = np.fromiter(itertools.chain.from_iterable(lists), dtype=np.int32, count=total)
+            except (TypeError, ValueError):                 # lists of arrays / tensors: element-wise iteration does not apply
+                flat = np.concatenate([np.asarray(l, dtype=np.int32).reshape(-1) for l in lists])
         else:
             flat = np.zeros(1, dtype=np.int32)
         ml = int(lens.max()) if n else 0

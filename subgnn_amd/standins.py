@@ -16,7 +16,7 @@ constructor reads them like real data.
                          three channels on (4 layers, 360 structure patches: DTW stressed)
   em_user    configs[4]  BA n=57 333 m=80 (~4.5 M edges), 324 subgraphs of ~155 nodes in ~52 pieces;
                          best_model_hyperparameters/em_user/hyperparams.json (k=2 border, B=32,
-                         trainable_cc) with all three channels on, fp16-stored table; the dense
+                         trainable_cc) with all three channels on, fp16-stored table, ff_attn read-out; the dense
                          (N, N) float64 hop matrix would be 26 GB -> hotpath.prepare_sparse
 """
 import os
@@ -87,7 +87,10 @@ PRESETS = {
             "n_triangular_walks": 10, "random_walk_len": 23, "sample_walk_len": 22, "rw_beta": 0.1816027331132596,
             "lstm_dropout": 0.01599628663889252, "lin_dropout": 0.003486968525571843, "lstm_n_layers": 1,
             "cc_aggregator": "sum", "trainable_cc": True, "structure_similarity_fn": "dtw",
-            "embedding_dtype": "fp16"})),          # configs[4]: "fp16 embeddings"
+            "embedding_dtype": "fp16", "ff_attn": True})),      # configs[4]: "fp16 embeddings with MFMA attention scores"
+            # (the attention read-out over a batch's 32 x 20 component rows: 640 rows take the library GEMM on half-rounded
+            # operands + the fused epilogue; the hand-written v_mfma_f32_32x32x16_f16 kernel serves calls of >= 2048 rows --
+            # whole-split evaluation, tests/test_gpu_configs.py::test_em_user_with_ff_attn_half_mfma_scores)
 }
 
 
