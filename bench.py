@@ -806,10 +806,12 @@ def main():
                 continue
             try:
                 t_c = time.perf_counter()
-                line = standins.bench_config(name, steps=20, warmup=5)
+                line = standins.bench_config(name, steps=20, warmup=5, also_atomics=True)
                 configs_obj[key] = {'standin': name, 'workload': line['config']['workload'], 'batch': line['config']['cc_ids_shape'],
                                     'ms_per_step_replayed': round(line['ms_per_step'], 3), 'ms_per_step_eager': round(line['eager']['ms_per_step'], 3),
                                     'subgraphs_per_s': round(line['value']), 'kernels_per_step': line['kernels_per_step'],
+                                    'with_float_atomics(hparams deterministic=False; not the default)': None if not line.get('atomics') else {
+                                        'ms_per_step_replayed': round(line['atomics']['ms_per_step'], 3), 'kernels_per_step': line['atomics']['kernels_per_step']},
                                     'prepare_data_s': line['prepare_data_s'], 'wall_s': round(time.perf_counter() - t_c, 1)}
             except Exception as ex:
                 configs_obj[key] = {'standin': name, 'error': repr(ex)[:300]}

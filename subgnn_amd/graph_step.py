@@ -65,7 +65,10 @@ class CapturedTrainStep:
         self.model, self.opt, self.B, self.clip, self.split = model, optimizer, int(batch_size), clip, split
         self.idx = torch.zeros(self.B, dtype=torch.int64, device=model.device)
         self._token = self._anchor_token()
-        make_capturable(optimizer)
+        if hasattr(optimizer, 'param_groups'):
+            make_capturable(optimizer)
+        elif not getattr(optimizer, 'capturable', False):          # optim.ClipAdam: its step counts must live on the device
+            raise ValueError('CapturedTrainStep needs an optimizer whose step count is device-resident (ClipAdam(capturable=True))')
         self.graph, self.loss, self.acc = None, None, None
         self._warm_left = warmup
 

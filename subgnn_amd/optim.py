@@ -75,3 +75,38 @@ class ClipAdam:
                     p.grad = None
                 else:
                     p.grad.zero_()
+
+
+    def make_eager(self):
+        """Back to host-side step counts (the trainer's fallback when a step cannot be recorded): same arithmetic."""
+        self.capturable = False
+        if self.small_opt is not None:
+            from .graph_step import make_eager
+            make_eager(self.small_opt)
+        for st in self.state.values():
+            st['step_dev'] = None
+        return self
+
+
+TRAINER_BIG_BYTES = 6 << 20        # the embedding table of the stand-ins (7.5-30 MB), not their per-split component embeddings (4.6 MB each: torch's fused multi-tensor Adam takes those together)
+
+
+def accelerate(optimizer, max_norm=None, capturable=False, big_bytes=TRAINER_BIG_BYTES):
+    """What ``train_config.Trainer`` steps with: the optimizer ``configure_optimizers`` returned when it is anything but a plain
+    ``torch.optim.Adam`` over CUDA parameters -- else a ClipAdam with the same learning rate, betas and eps that also applies
+    the trainer's ``gradient_clip_val`` (so the caller must NOT clip again): the embedding table (and any other parameter of at
+    least ``big_bytes``) is updated by one ``sgnn_adam_step`` launch and the clip coefficient is a device scalar -- at a batch
+    of 64 torch's chunked multi-tensor Adam over a 9 MB table and the ten small launches of ``clip_grad_norm_`` were ~140 us of
+    a 1.5 ms step (PPI-BP stand-in).  Same update rule (tests/test_gpu_float.py::test_clip_adam_matches_torch)."""
+    if isinstance(optimizer, ClipAdam):
+        return optimizer
+    if type(optimizer) is not torch.optim.Adam or len(optimizer.param_groups) != 1 or len(optimizer.state) != 0:
+        return optimizer
+    g = optimizer.param_groups[0]
+    if g.get('weight_decay', 0) or g.get('amsgrad', False) or g.get('maximize', False) or g.get('differentiable', False):
+        return optimizer
+    params = [p for p in g['params'] if p.requires_grad]
+    if not params or not all(p.is_cuda for p in params) or torch.is_tensor(g['lr']):
+        return optimizer
+    return ClipAdam(params, g['lr'], max_norm=(max_norm if max_norm and max_norm > 0 else None), betas=g['betas'], eps=g['eps'],
+                    big_bytes=big_bytes, capturable=capturable)

@@ -183,9 +183,11 @@ def time_steps(model, opt, hp, steps, warmup, graph, count=False):
                 if idx.numel() == B:
                     yield idx
     it = index_batches()
+    from .optim import ClipAdam
+    own_clip = isinstance(opt, ClipAdam)                     # (clips inside its step: train_config.Trainer does the same)
     if graph:
         from .graph_step import CapturedTrainStep
-        cap = CapturedTrainStep(model, opt, B, hp['grad_clip'])
+        cap = CapturedTrainStep(model, opt, B, 0.0 if own_clip else hp['grad_clip'])
 
         def step():
             return cap.replay(next(it))[0]
@@ -194,7 +196,8 @@ def time_steps(model, opt, hp, steps, warmup, graph, count=False):
             out = model.training_step(model.make_batch('train', next(it)), 0)
             opt.zero_grad(set_to_none=True)
             model.backward(None, out['loss'], opt, 0)
-            torch.nn.utils.clip_grad_norm_(model.parameters(), hp['grad_clip'])
+            if not own_clip:
+                torch.nn.utils.clip_grad_norm_(model.parameters(), hp['grad_clip'])
             opt.step()
             return out['loss']
     for _ in range(warmup):
@@ -209,7 +212,7 @@ def time_steps(model, opt, hp, steps, warmup, graph, count=False):
     return ms, float(loss.detach()), n_k
 
 
-def bench_config(name, steps=30, warmup=5, deterministic=True, root=None, count=True):
+def bench_config(name, steps=30, warmup=5, deterministic=True, root=None, count=True, also_atomics=False):
     """One BASELINE configuration's stand-in end to end -> dict: dataset write, graph metrics, prepare_data, then the
     batch-sized training step eager and replayed (ms per step, subgraphs/s, kernels per step).  What bench.py's
     ``configs`` object and tools/bench_standin.py report."""
@@ -245,10 +248,30 @@ def bench_config(name, steps=30, warmup=5, deterministic=True, root=None, count=
             model.prepare_data()
             torch.cuda.synchronize()
         t_prep = time.time() - t0
-        opt = model.configure_optimizers()
+        from .optim import accelerate
+        opt = accelerate(model.configure_optimizers(), hp['grad_clip'], capturable=True)     # what train_config.Trainer steps with
         model.train()
         ms_eager, loss, k_eager = time_steps(model, opt, model.hparams, steps, warmup, graph=False, count=count)
         ms_graph, loss_g, _ = time_steps(model, opt, model.hparams, steps, warmup, graph=True)
+        ms_atomics = k_atomics = None
+        if also_atomics and deterministic:
+            # the same dataset with hparams['deterministic'] = False (float atomics in the backward pass: no sorts, no segmented
+            # sums -- fewer kernels, sums in arbitrary order): replayed only
+            hp2 = dict(hp)
+            hp2['deterministic'] = False
+            torch.manual_seed(3)
+            m2 = SubGNN(hp2, **dataset_paths(name + '_standin'))
+            if P['sparse']:
+                for sp in ('val', 'train'):
+                    hotpath.prepare_sparse(m2, sp)
+            else:
+                m2.prepare_data()
+            o2 = accelerate(m2.configure_optimizers(), hp['grad_clip'], capturable=True)
+            m2.train()
+            ms_atomics, _, _ = time_steps(m2, o2, m2.hparams, steps, warmup, graph=True)
+            if count:
+                _, _, k_atomics = time_steps(m2, o2, m2.hparams, 1, 2, graph=False, count=True)
+            del m2, o2
     finally:
         config.PROJECT_ROOT = old_root
     B = hp['batch_size']
@@ -259,6 +282,8 @@ def bench_config(name, steps=30, warmup=5, deterministic=True, root=None, count=
         'value': B * 1e3 / ms_graph, 'ms_per_step': ms_graph, 'hip_graph_step': True,
         'eager': {'value': B * 1e3 / ms_eager, 'ms_per_step': ms_eager},
         'kernels_per_step': k_eager,
+        'atomics': None if ms_atomics is None else {'ms_per_step': ms_atomics, 'value': B * 1e3 / ms_atomics, 'kernels_per_step': k_atomics,
+                                                    'what': "hparams['deterministic'] = False: float atomics in the backward pass (not bit-reproducible)"},
         'steps': steps, 'warmup': warmup, 'higher_is_better': True, 'dtype': 'f32', 'data': 'synthetic (stand-in)',
         'config': {'workload': '%s stand-in (BA n=%d m=%d, %d edges, %d subgraphs), %s prepare, batch of %d, training '
                                'step = fwd + bwd + clip + Adam' % (name, P['n'], P.get('m', 5), n_edges, P['n_sub'],

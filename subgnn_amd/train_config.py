@@ -32,6 +32,7 @@ import torch
 
 from . import config
 from .SubGNN import SubGNN, dataset_paths
+from .optim import ClipAdam, accelerate
 
 
 def read_json(fname):
@@ -112,18 +113,21 @@ class Trainer:
         out = model.training_step(batch, bi)
         opt.zero_grad(set_to_none=True)
         model.backward(self, out['loss'], opt, 0)
-        if self.clip and self.clip > 0:
+        if self.clip and self.clip > 0 and not isinstance(opt, ClipAdam):      # (ClipAdam clips inside its step)
             torch.nn.utils.clip_grad_norm_(model.parameters(), self.clip)
         opt.step()
         return out['loss'].detach()
 
     def fit(self, model):
         model.prepare_data()
-        opt = model.configure_optimizers()
+        # plain Adam over CUDA parameters (what configure_optimizers returns) becomes optim.ClipAdam: same update and clipping
+        # rule, the embedding table in one HIP pass, the clip coefficient a device scalar (optim.accelerate)
+        opt = accelerate(model.configure_optimizers(), self.clip, capturable=self.hip_graph_step)
         captured = None
         if self.hip_graph_step:
             from .graph_step import CapturedTrainStep, StepNotRecordable, make_capturable, make_eager
-            make_capturable(opt)
+            if not isinstance(opt, ClipAdam):
+                make_capturable(opt)
         for epoch in range(self.max_epochs):
             model.train()
             losses = []
@@ -132,7 +136,8 @@ class Trainer:
                 # full batches replay the recorded step (graph_step.py); a ragged last batch, or
                 # anchors resampled at the end of the previous epoch, fall back / record again
                 if captured is None or captured.stale():
-                    captured = CapturedTrainStep(model, opt, loader.bs, self.clip, warmup=3 if captured is None else 0)
+                    captured = CapturedTrainStep(model, opt, loader.bs, 0.0 if isinstance(opt, ClipAdam) else self.clip,
+                                                 warmup=3 if captured is None else 0)
                 for bi, idx in enumerate(loader.index_batches()):
                     if idx.numel() == loader.bs and self.hip_graph_step:
                         try:
@@ -144,7 +149,7 @@ class Trainer:
                             # are the ones hip_graph_step=False would have run
                             self.log('hip_graph_step: the training step could not be recorded (%s); training eagerly' % (ex,))
                             self.hip_graph_step = False
-                            make_eager(opt)
+                            opt.make_eager() if isinstance(opt, ClipAdam) else make_eager(opt)
                             torch.cuda.synchronize()
                     losses.append(self._eager_step(model, opt, model.make_batch('train', idx), bi))
             else:

@@ -157,3 +157,34 @@ def test_fallback_returns_the_optimizer_to_its_eager_form(tiny, tmp_path, monkey
     assert all(g['capturable'] for g in opt.param_groups)
     graph_step.make_eager(opt)
     assert not any(g['capturable'] for g in opt.param_groups)
+
+
+def test_trainer_steps_with_clipadam_and_matches_plain_adam(tiny, tmp_path, monkeypatch):
+    """The trainer swaps configure_optimizers' plain Adam for optim.ClipAdam (optim.accelerate: the table in one sgnn_adam_step
+    launch, clip coefficient on the device, no separate clip_grad_norm_): same losses and parameters as the plain path
+    (clip_grad_norm_ + torch's Adam), eager and replayed."""
+    from subgnn_amd import optim, train_config
+    for d in 'abc':
+        (tmp_path / d).mkdir()
+    seen = []
+    real = optim.accelerate
+
+    def spy(opt, *a, **k):
+        out = real(opt, *a, **k)
+        seen.append(type(out).__name__)
+        return out
+    monkeypatch.setattr(train_config, 'accelerate', spy)
+    m1, t1 = _fit(tiny, tmp_path / 'a', False, False, epochs=4)
+    m2, t2 = _fit(tiny, tmp_path / 'b', True, False, epochs=4)
+    assert seen == ['ClipAdam', 'ClipAdam']
+    monkeypatch.setattr(train_config, 'accelerate', lambda opt, *a, **k: opt)
+    m0, t0 = _fit(tiny, tmp_path / 'c', False, False, epochs=4)
+    l0 = torch.tensor([e['train_loss'] for e in t0.history])
+    for t in (t1, t2):
+        l = torch.tensor([e['train_loss'] for e in t.history])
+        assert torch.allclose(l0, l, rtol=1e-5, atol=1e-6), (l0, l)
+    sd0 = m0.state_dict()
+    for m in (m1, m2):
+        sd = m.state_dict()
+        for k in sd0:
+            assert torch.allclose(sd0[k].float(), sd[k].float(), rtol=1e-5, atol=1e-5), k

@@ -42,7 +42,8 @@ def main():
     ap.add_argument('--no-count', action='store_true', help='skip the kernels-per-step count (torch profiler)')
     args = ap.parse_args()
     from subgnn_amd.standins import bench_config
-    print(json.dumps(bench_config(args.config, args.steps, args.warmup, deterministic=not args.atomics, count=not args.no_count)))
+    print(json.dumps(bench_config(args.config, args.steps, args.warmup, deterministic=not args.atomics, count=not args.no_count,
+                                  also_atomics=not args.atomics)))
 
 
 if __name__ == '__main__':

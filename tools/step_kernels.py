@@ -33,7 +33,8 @@ def main():
             hotpath.prepare_sparse(model, sp)
     else:
         model.prepare_data()
-    opt = model.configure_optimizers()
+    from subgnn_amd.optim import ClipAdam, accelerate
+    opt = accelerate(model.configure_optimizers(), model.hparams['grad_clip'], capturable=True)      # what train_config.Trainer steps with
     model.train()
     hp = model.hparams
     it = iter([i for i in model.train_dataloader().index_batches() if i.numel() == hp['batch_size']] * 50)
@@ -42,7 +43,8 @@ def main():
         out = model.training_step(model.make_batch('train', next(it)), 0)
         opt.zero_grad(set_to_none=True)
         model.backward(None, out['loss'], opt, 0)
-        torch.nn.utils.clip_grad_norm_(model.parameters(), hp['grad_clip'])
+        if not isinstance(opt, ClipAdam):
+            torch.nn.utils.clip_grad_norm_(model.parameters(), hp['grad_clip'])
         opt.step()
     for _ in range(5):
         step()
