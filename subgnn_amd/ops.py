@@ -1246,13 +1246,29 @@ def contract_rows(a, b, rows_per_block=None):
     (m / 64) x (n / 32) workgroups (16 of them for the LSTM's weight gradients: 40 us for 1.1 GFLOP); split over row
     blocks -- one batched GEMM, then a sum in block order -- it fills the chip."""
     R = a.shape[0]
-    if R < 4096 or not a.is_cuda:
+    if R < 2048 or not a.is_cuda:
         return a.t() @ b
-    rows_per_block = rows_per_block or _block_rows(R)
+    rows_per_block = rows_per_block or _block_rows(R, 1024 if R >= 8192 else 512)
     nb = R // rows_per_block
     k = nb * rows_per_block
     head = torch.bmm(a[:k].reshape(nb, rows_per_block, -1).transpose(1, 2), b[:k].reshape(nb, rows_per_block, -1)).sum(0)
     return head + a[k:].t() @ b[k:] if k < R else head
+
+
+def contract_rows_batched(a, b, want=512):
+    """a[g]^T b[g] for g in range(G): a (G, R, m), b (G, R, n) -> (G, m, n), one ``bmm`` over (group, row block) pairs and a sum
+    over the blocks in block order (a fixed order: reproducible)."""
+    G, R = a.shape[0], a.shape[1]
+    if R < 2 * want or not a.is_cuda:
+        return torch.bmm(a.transpose(1, 2), b)
+    rows = _block_rows(R, want)
+    nb = R // rows
+    k = nb * rows
+    part = torch.bmm(a[:, :k].reshape(G * nb, rows, -1).transpose(1, 2), b[:, :k].reshape(G * nb, rows, -1))
+    out = part.view(G, nb, part.shape[1], part.shape[2]).sum(1)
+    if k < R:
+        out = out + torch.bmm(a[:, k:].transpose(1, 2), b[:, k:])
+    return out
 
 
 class _ReadoutShared(torch.autograd.Function):
@@ -1715,7 +1731,9 @@ class _BiLSTMLayer(torch.autograd.Function):
         dx = (dg @ wih).view(B, T, I) if ctx.needs_input_grad[0] else None
         dwih = contract_rows(dg, x2)                                            # (8H, I)
         dgd = dgates.view(B * T, 2, 4 * H).transpose(0, 1).contiguous()         # (2, B T, 4H): one direction's gates contiguous
-        dwhh = [contract_rows(dgd[d], hprev[d].view(B * T, H)) for d in (0, 1)]
+        # both directions' W_hh gradients in ONE batched contraction, the rows split into blocks when there are enough of them
+        # (two library GEMMs of 512 x 128 outputs over a few thousand rows each ran 26 us apiece on a handful of workgroups)
+        dwhh = contract_rows_batched(dgd, hprev.view(2, B * T, H))              # (2, 4H, H)
         # bias_ih and bias_hh receive the same gradient VALUES but must not receive the same MEMORY: autograd hands a view
         # over to .grad as it is, and an in-place multi-tensor update of the gradient list (clip_grad_norm_'s _foreach_mul_)
         # then scales the shared buffer once per alias, from concurrently running chunks -- g c or g c^2 depending on timing
