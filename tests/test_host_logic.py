@@ -326,3 +326,33 @@ def test_bench_projection_from_a_measured_step():
     assert d['ms_per_step'] < r['ms_per_step'] and 7.0 < r['speedup_vs_1gpu'] <= d['speedup_vs_1gpu'] <= 8.8
     assert abs(d['ms_per_step'] - (10.0 + p['reduce_scatter_ms']['direct_7_links'] + 0.1 - 0.7)) < 0.02
     assert abs(p['reduce_scatter_ms']['ring'] - 7 * p['reduce_scatter_ms']['direct_7_links']) < 0.01
+
+
+def test_trainer_optimizer_swap_only_for_plain_adam_on_the_device():
+    """optim.accelerate (what train_config.Trainer steps with): anything but a fresh plain torch.optim.Adam over CUDA parameters
+    is handed back untouched -- CPU parameters, another optimizer class, weight decay, a second parameter group, existing state."""
+    import torch
+    from subgnn_amd import optim
+    p = [torch.nn.Parameter(torch.zeros(4, 3)), torch.nn.Parameter(torch.zeros(3))]
+    for opt in (torch.optim.Adam(p, lr=0.1), torch.optim.SGD(p, lr=0.1), torch.optim.Adam(p, lr=0.1, weight_decay=0.01),
+                torch.optim.Adam([{'params': p[:1]}, {'params': p[1:]}], lr=0.1), torch.optim.AdamW(p, lr=0.1)):
+        assert optim.accelerate(opt, 0.5, capturable=True) is opt
+    used = torch.optim.Adam(p, lr=0.1)
+    p[0].grad = torch.ones_like(p[0])
+    used.step()
+    assert optim.accelerate(used, 0.5) is used                  # (state exists: the swap would drop it)
+
+
+def test_batched_row_contraction_matches_einsum():
+    import torch
+    from subgnn_amd import ops
+    g = torch.Generator().manual_seed(0)
+    a, b = torch.randn(2, 37, 5, generator=g), torch.randn(2, 37, 3, generator=g)
+    assert torch.allclose(ops.contract_rows_batched(a, b), torch.einsum('grm,grn->gmn', a, b), atol=1e-5)
+
+
+def test_kernel_count_is_none_without_a_device():
+    import torch
+    from subgnn_amd import standins
+    if not torch.cuda.is_available():
+        assert standins.count_kernels(lambda: None) is None
