@@ -223,6 +223,7 @@ def bench_config(name, steps=30, warmup=5, deterministic=True, root=None, count=
     P = PRESETS[name]
     hp = dict(P['hp'])
     hp['deterministic'] = bool(deterministic)
+    own_root = root is None
     root = root or tempfile.mkdtemp(prefix=name + '_')
     t0 = time.time()
     d, n_edges = write_standin(root, name)
@@ -274,6 +275,9 @@ def bench_config(name, steps=30, warmup=5, deterministic=True, root=None, count=
             del m2, o2
     finally:
         config.PROJECT_ROOT = old_root
+        if own_root:                       # (the dense stand-ins write an (N, N) float64 hop matrix: 1.7-2.3 GB each)
+            import shutil
+            shutil.rmtree(root, ignore_errors=True)
     B = hp['batch_size']
     return {
         'metric': 'subgraphs/sec fwd+bwd (all 3 channels on)' if (hp['use_position'] and hp['use_structure']) else
