@@ -343,3 +343,70 @@ def test_training_half_at_shard_size_matches_the_oracle(full, n_layers):
     untouched = (grads['node_embeddings.weight'].abs().sum(1) == 0)
     assert torch.equal(after['node_embeddings.weight'][untouched], before['node_embeddings.weight'][untouched])
     print('shard-size training half: calls', dict(calls), 'worst update error / allowed', {k: '%.2f' % e for k, e in worst.items()})
+
+
+def test_one_50k_batch_equals_its_chunks(full):
+    """The float half on ALL 50 000 subgraphs as ONE batch -- the launch shape bench.py times (hotpath.full_split_batch) --
+    against the same model run over seven chunks of <= 8 192 subgraphs (SubGNN.make_batch; the last chunk has 848 rows and
+    takes the small-R kernels: K-split update layer, un-split contractions, short scatter runs).  The forward is row-wise in
+    the subgraph (SubGNN.py:225-348 has no cross-subgraph term without batch norm) and the loss is a mean, so
+        logits(full)[chunk] = logits(chunk)      and      grad(full) = sum_chunks  n_chunk / S * grad(chunk)
+    hold exactly in real arithmetic: a size-independent property that covers the 50k launch itself, which the oracle cannot
+    replay in seconds (the test above pins the 8 192-row shape to the float64 oracle).  Tolerances: logits 1e-5 of the
+    largest logit; gradients element-wise 1e-4 relative + 1e-6 of the tensor's largest element (tests/helpers.assert_close)."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..'))
+    from bench import ALL_DENSITY_HP
+    from helpers import assert_close
+    from subgnn_amd import hotpath
+    from subgnn_amd.SubGNN import SubGNN
+    g, subs = full['g'], full['subs']
+    hp = dict(ALL_DENSITY_HP, lin_dropout=0.0, lstm_dropout=0.0)
+    D = hp['node_embed_size']
+    emb = torch.randn(N, D, generator=torch.Generator().manual_seed(1)).to(DEV)
+    labels = torch.randint(0, 3, (S,), generator=torch.Generator().manual_seed(1))
+    torch.manual_seed(1)
+    m = SubGNN.from_memory(dict(hp), g, {'train': subs, 'val': [], 'test': []},
+                           {'train': labels, 'val': labels[:0], 'test': labels[:0]}, emb, num_classes=3)
+    m.train()
+    hotpath.prepare_sparse(m, 'train')
+    assert m.train_cc_ids.shape[0] == S
+    batch = hotpath.full_split_batch(m, 'train')
+    out = m.training_step(batch, 0)
+    with torch.no_grad():
+        logits = m._forward_batch('train', batch)
+    m.backward(None, out['loss'], None, 0)
+    torch.cuda.synchronize()
+    full_grads = {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None}
+    full_loss = float(out['loss'].detach())
+    for p in m.parameters():
+        p.grad = None
+    CH = 8192
+    pieces, loss_sum = [], 0.0
+    for lo in range(0, S, CH):
+        idx = torch.arange(lo, min(S, lo + CH))
+        b = m.make_batch('train', idx)
+        o = m.training_step(b, 0)
+        with torch.no_grad():
+            pieces.append(m._forward_batch('train', b))
+        w = idx.numel() / S
+        m.backward(None, o['loss'] * w, None, 0)
+        loss_sum += float(o['loss'].detach()) * w
+    torch.cuda.synchronize()
+    assert len(pieces) == 7 and pieces[-1].shape[0] == S - 6 * CH
+    chunked = torch.cat(pieces)
+    scale = float(logits.abs().max())
+    assert float((logits - chunked).abs().max()) <= 1e-5 * scale, (float((logits - chunked).abs().max()), scale)
+    assert abs(full_loss - loss_sum) <= 1e-5 * abs(full_loss), (full_loss, loss_sum)
+    checked = 0
+    for k, p in m.named_parameters():
+        if k not in full_grads:
+            assert p.grad is None or float(p.grad.abs().max()) == 0, k
+            continue
+        assert p.grad is not None, k
+        assert_close(full_grads[k], p.grad, 'grad ' + k + ' (one batch vs chunks)')
+        checked += 1
+    assert checked >= 12, checked
+    # the table's gradient touches exactly the rows some subgraph, border set or anchor patch reads; row 0 is the padding row
+    assert float(full_grads['node_embeddings.weight'][0].abs().max()) == 0
+    assert torch.equal(full_grads['node_embeddings.weight'].abs().sum(1) > 0, m.node_embeddings.weight.grad.abs().sum(1) > 0)
