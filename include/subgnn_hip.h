@@ -38,7 +38,7 @@ extern "C" {
 #define SGNN_ERR_LAUNCH         -4   /* hipGetLastError() after a launch */
 #define SGNN_ERR_UNSUPPORTED_D  -5   /* embedding width not supported by the vector path */
 
-#define SGNN_ABI_VERSION 8
+#define SGNN_ABI_VERSION 9
 int sgnn_abi_version(void);
 /* Load the code objects of every translation unit of the library on the current device (one empty launch each on ``stream``):
  * what the first call of each kernel family would otherwise pay, 5-25 ms at a time, inside the reference's one-time
@@ -624,6 +624,33 @@ int sgnn_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq,
 int sgnn_adam_step_counted(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
                            float beta2, float eps, int64_t* step_counter, const float* grad_scale, int zero_grad,
                            void* stream);
+
+/* a18c  The whole optimizer tail of a step -- clip_grad_norm_ over ALL parameters (train_config.py: Trainer(gradient_clip_val))
+ * followed by torch.optim.Adam over all of them (SubGNN/SubGNN.py:1156-1161) -- in two launches per 72 tensors.  The tensor lists
+ * are HOST arrays of DEVICE pointers (float32, 4-byte aligned at least; 16-byte aligned tensors take the vector path), numels[i]
+ * elements each.
+ *   sgnn_optim_partials(numels, n)          how many floats sgnn_optim_sumsq writes (one per workgroup; -1 = bad argument)
+ *   sgnn_optim_sumsq(grads, ...)            per-workgroup sums of squares of every gradient -> partial[]; the step counts
+ *                                           step_counters[counter_slots[i]] (step_counters nullable: DEVICE int64[]; counter_slots
+ *                                           nullable: HOST int64[n_tensors], default i) each advance by one in the same launch
+ *   sgnn_optim_count(step_counters, ...)    the advance alone (a step without clipping)
+ *   sgnn_optim_adam(...)                    every workgroup adds partial[0..n_partial) in one fixed order, forms
+ *                                           coefficient = min(1, max_norm / (sqrt(sum) + 1e-6)) and updates its chunk with the
+ *                                           gradient times the coefficient (max_norm <= 0: no clipping, partial unused).
+ *                                           Step counts: EXACTLY ONE of steps (HOST int64[n_tensors], >= 1: this update's
+ *                                           number, per tensor) and step_counters (DEVICE, tensor i reads step_counters[counter_slots[i]] after
+ *                                           sgnn_optim_sumsq / sgnn_optim_count advanced them -- the form a recorded step replays).
+ *                                           zero_grad (nullable HOST int32[n_tensors]): != 0 zeroes that gradient in the same
+ *                                           pass.  coef_out (nullable DEVICE float[2]): the coefficient and the total norm.
+ * The gradients themselves are NOT scaled in memory (clip_grad_norm_ scales them in place; here they are consumed). */
+int64_t sgnn_optim_partials(const int64_t* numels, int64_t n_tensors);
+int sgnn_optim_sumsq(const float* const* grads, const int64_t* numels, int64_t n_tensors, float* partial,
+                     int64_t* step_counters, const int64_t* counter_slots, void* stream);
+int sgnn_optim_count(int64_t* step_counters, const int64_t* counter_slots, int64_t n_tensors, void* stream);
+int sgnn_optim_adam(float* const* params, float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
+                    const int64_t* numels, const int32_t* zero_grad, int64_t n_tensors, float lr, float beta1, float beta2,
+                    float eps, const int64_t* steps, const int64_t* step_counters, const int64_t* counter_slots,
+                    const float* partial, int64_t n_partial, float max_norm, float* coef_out, void* stream);
 
 
 /* ---------------------------------------------------------------------------------------

@@ -119,6 +119,11 @@ SIGNATURES = {
                                c_i64, c_ptr, c_int, c_ptr]),
     'sgnn_adam_step_counted': (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, ctypes.c_float, ctypes.c_float, ctypes.c_float,
                                        ctypes.c_float, c_ptr, c_ptr, c_int, c_ptr]),
+    'sgnn_optim_partials': (c_i64, [c_ptr, c_i64]),
+    'sgnn_optim_sumsq': (c_int, [c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr]),
+    'sgnn_optim_count': (c_int, [c_ptr, c_ptr, c_i64, c_ptr]),
+    'sgnn_optim_adam': (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, ctypes.c_float, ctypes.c_float, ctypes.c_float,
+                                ctypes.c_float, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, ctypes.c_float, c_ptr, c_ptr]),
     'sgnn_update_fwd': (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr]),
     'sgnn_update_bwd_workspace_bytes': (c_i64, [c_i64, c_i64]),
     'sgnn_update_bwd': (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr]),
@@ -156,7 +161,7 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the header and the library disagree
         fn.restype = res
         fn.argtypes = args
-    if lib.sgnn_abi_version() != 8:
+    if lib.sgnn_abi_version() != 9:
         raise SubgnnHipError('ABI version mismatch')
     _lib = lib
     return lib

@@ -164,4 +164,217 @@ extern "C" int sgnn_clip_coefficient(const float* partial, int64_t n_partial, co
     return SGNN_OK;
 }
 
+
+// ---- the whole optimizer tail in two launches -----------------------------------------------------------------------------
+// clip_grad_norm_ + Adam over EVERY parameter (train_config.py: Trainer(gradient_clip_val); SubGNN/SubGNN.py:1156-1161).  As
+// library calls a batch-sized step paid ~12 launches and ~155 us here (a multi-tensor norm + clean-up + stack, the coefficient,
+// a multi-tensor multiply, torch's fused Adam in two launches of 40-50 us each -- it evaluates pow() in double per thread --
+// a count kernel and the table's pass) of a 1.0-2.9 ms step.  Here: launch 1 = per-workgroup sums of squares of every gradient
+// (+ the device step counts advance), launch 2 = every workgroup adds the partials in one fixed order (the same value in all
+// of them), forms the coefficient and updates its chunk.  Tensors travel as kernel arguments (pointers of gradients change from
+// step to step in eager mode and are frozen into a recorded step), OPT_MAXT per launch.
+#define OPT_MAXT 72
+#define OPT_CHUNK 4096                    // floats per workgroup iteration: 256 lanes x 4 float4
+#define OPT_MAX_BLOCKS 2048               // per tensor; larger tensors stride
+
+struct OptTensors {
+    float* p[OPT_MAXT]; float* g[OPT_MAXT]; float* m[OPT_MAXT]; float* v[OPT_MAXT];
+    long long n[OPT_MAXT];
+    int blk[OPT_MAXT + 1];                // first workgroup of tensor t inside this launch
+    int zero[OPT_MAXT];
+    int slot[OPT_MAXT];                   // which device step count belongs to tensor t
+    int count;
+};
+
+__device__ __forceinline__ int opt_find(const OptTensors& T, int b)
+{
+    int lo = 0, hi = T.count - 1;         // largest t with blk[t] <= b
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (T.blk[mid] <= b) lo = mid; else hi = mid - 1; }
+    return lo;
+}
+
+__global__ __launch_bounds__(256) void optim_sumsq_kernel(const OptTensors T, float* __restrict__ partial, int64_t* __restrict__ counters)
+{
+    __shared__ float sh[256];
+    const int b = blockIdx.x, t = opt_find(T, b), nb = T.blk[t + 1] - T.blk[t];
+    const float* __restrict__ g = T.g[t];
+    const int64_t n = T.n[t];
+    if (counters && b == 0 && (int)threadIdx.x < T.count) counters[T.slot[threadIdx.x]] += 1;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if ((((uintptr_t)g) & 15) == 0) {
+        const int64_t n4 = n >> 2;
+        const float4* __restrict__ g4 = (const float4*)g;
+        for (int64_t i = (int64_t)(b - T.blk[t]) * 256 + threadIdx.x; i < n4; i += (int64_t)nb * 256) {
+            const float4 x = g4[i];
+            a0 = fmaf(x.x, x.x, a0); a1 = fmaf(x.y, x.y, a1); a2 = fmaf(x.z, x.z, a2); a3 = fmaf(x.w, x.w, a3);
+        }
+        if (b == T.blk[t] && (int64_t)threadIdx.x < n - n4 * 4) { const float x = g[n4 * 4 + threadIdx.x]; a0 = fmaf(x, x, a0); }
+    } else {
+        for (int64_t i = (int64_t)(b - T.blk[t]) * 256 + threadIdx.x; i < n; i += (int64_t)nb * 256) { const float x = g[i]; a0 = fmaf(x, x, a0); }
+    }
+    sh[threadIdx.x] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        float v = (sh[threadIdx.x] + sh[threadIdx.x + 64]) + (sh[threadIdx.x + 128] + sh[threadIdx.x + 192]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        if (threadIdx.x == 0) partial[b] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void optim_adam_kernel(const OptTensors T, const float* __restrict__ partial, int n_partial, float max_norm,
+                                                         float* __restrict__ coef_out, float lr, float b1, float b2, float eps,
+                                                         long long host_step, const int64_t* __restrict__ counters)
+{
+    __shared__ double shd[256];
+    const int b = blockIdx.x, t = opt_find(T, b), nb = T.blk[t + 1] - T.blk[t];
+    float gs = 1.f;
+    if (max_norm > 0.f) {                 // the same additions in the same order in every workgroup: one coefficient for all
+        double acc = 0.0;
+        for (int k = threadIdx.x; k < n_partial; k += 256) acc += (double)partial[k];
+        shd[threadIdx.x] = acc;
+        __syncthreads();
+        for (int w = 128; w > 0; w >>= 1) {
+            if ((int)threadIdx.x < w) shd[threadIdx.x] += shd[threadIdx.x + w];
+            __syncthreads();
+        }
+        const float total = (float)sqrt(shd[0]);
+        gs = fminf(max_norm / (total + 1e-6f), 1.f);
+        if (coef_out && b == 0 && threadIdx.x == 0) { coef_out[0] = gs; coef_out[1] = total; }
+    }
+    const double st = counters ? (double)counters[T.slot[t]] : (double)host_step;
+    const float step_size = (float)((double)lr / (1.0 - pow((double)b1, st)));
+    const float rsqrt_bc2 = (float)(1.0 / sqrt(1.0 - pow((double)b2, st)));
+    float* __restrict__ p = T.p[t]; float* __restrict__ g = T.g[t]; float* __restrict__ m = T.m[t]; float* __restrict__ v = T.v[t];
+    const int64_t n = T.n[t];
+    const int zero = T.zero[t];
+    if (((((uintptr_t)p) | ((uintptr_t)g) | ((uintptr_t)m) | ((uintptr_t)v)) & 15) == 0) {
+        const int64_t n4 = n >> 2;
+        float4* p4 = (float4*)p; float4* g4 = (float4*)g; float4* m4 = (float4*)m; float4* v4 = (float4*)v;
+        for (int64_t i = (int64_t)(b - T.blk[t]) * 256 + threadIdx.x; i < n4; i += (int64_t)nb * 256) {
+            float4 pp = p4[i], gg = g4[i], mm = m4[i], vv = v4[i];
+            float* P = &pp.x; float* G = &gg.x; float* M = &mm.x; float* V = &vv.x;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float gk = G[k] * gs;
+                M[k] = M[k] + (1.f - b1) * (gk - M[k]);
+                V[k] = b2 * V[k] + (1.f - b2) * gk * gk;
+                P[k] -= step_size * M[k] / (sqrtf(V[k]) * rsqrt_bc2 + eps);
+            }
+            p4[i] = pp; m4[i] = mm; v4[i] = vv;
+            if (zero) g4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        if (b == T.blk[t] && (int64_t)threadIdx.x < n - n4 * 4) {
+            const int64_t i = n4 * 4 + threadIdx.x;
+            const float gk = g[i] * gs;
+            const float mk = m[i] + (1.f - b1) * (gk - m[i]);
+            const float vk = b2 * v[i] + (1.f - b2) * gk * gk;
+            m[i] = mk; v[i] = vk;
+            p[i] -= step_size * mk / (sqrtf(vk) * rsqrt_bc2 + eps);
+            if (zero) g[i] = 0.f;
+        }
+    } else {
+        for (int64_t i = (int64_t)(b - T.blk[t]) * 256 + threadIdx.x; i < n; i += (int64_t)nb * 256) {
+            const float gk = g[i] * gs;
+            const float mk = m[i] + (1.f - b1) * (gk - m[i]);
+            const float vk = b2 * v[i] + (1.f - b2) * gk * gk;
+            m[i] = mk; v[i] = vk;
+            p[i] -= step_size * mk / (sqrtf(vk) * rsqrt_bc2 + eps);
+            if (zero) g[i] = 0.f;
+        }
+    }
+}
+
+struct OptSlots { int slot[OPT_MAXT]; int count; };
+__global__ void optim_count_kernel(int64_t* counters, const OptSlots S) { if ((int)threadIdx.x < S.count) counters[S.slot[threadIdx.x]] += 1; }
+
+static inline int opt_blocks(int64_t n)
+{
+    int64_t b = (n + OPT_CHUNK - 1) / OPT_CHUNK;
+    return (int)(b < 1 ? 1 : (b > OPT_MAX_BLOCKS ? OPT_MAX_BLOCKS : b));
+}
+
+extern "C" int64_t sgnn_optim_partials(const int64_t* numels, int64_t n_tensors)
+{
+    if (n_tensors < 0 || (n_tensors && !numels)) return -1;
+    int64_t total = 0;
+    for (int64_t i = 0; i < n_tensors; ++i) { if (numels[i] < 0) return -1; total += opt_blocks(numels[i]); }
+    return total;
+}
+
+// one launch group = tensors [from, to): fills T, returns its workgroup count
+static int opt_fill(OptTensors& T, float* const* params, float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
+                    const int64_t* numels, const int32_t* zero_grad, const int64_t* slots, int64_t from, int64_t to)
+{
+    int blocks = 0;
+    T.count = (int)(to - from);
+    for (int64_t i = from; i < to; ++i) {
+        const int k = (int)(i - from);
+        T.p[k] = params ? params[i] : nullptr; T.g[k] = grads[i];
+        T.m[k] = exp_avg ? exp_avg[i] : nullptr; T.v[k] = exp_avg_sq ? exp_avg_sq[i] : nullptr;
+        T.n[k] = numels[i]; T.blk[k] = blocks; T.zero[k] = zero_grad ? zero_grad[i] : 0; T.slot[k] = (int)(slots ? slots[i] : i);
+        blocks += opt_blocks(numels[i]);
+    }
+    T.blk[T.count] = blocks;
+    return blocks;
+}
+
+extern "C" int sgnn_optim_sumsq(const float* const* grads, const int64_t* numels, int64_t n_tensors, float* partial,
+                                int64_t* step_counters, const int64_t* counter_slots, void* stream)
+{
+    if (n_tensors < 0 || (n_tensors && (!grads || !numels || !partial))) return SGNN_ERR_BAD_ARG;
+    for (int64_t i = 0; i < n_tensors; ++i) if (!grads[i] || numels[i] < 0 || (((uintptr_t)grads[i]) & 3)) return SGNN_ERR_BAD_ARG;
+    int64_t base = 0;
+    for (int64_t from = 0; from < n_tensors; from += OPT_MAXT) {
+        const int64_t to = from + OPT_MAXT < n_tensors ? from + OPT_MAXT : n_tensors;
+        OptTensors T;
+        const int blocks = opt_fill(T, nullptr, (float* const*)grads, nullptr, nullptr, numels, nullptr, counter_slots, from, to);
+        hipLaunchKernelGGL(optim_sumsq_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, T, partial + base, step_counters);
+        SGNN_CHECK_LAUNCH();
+        base += blocks;
+    }
+    return SGNN_OK;
+}
+
+extern "C" int sgnn_optim_count(int64_t* step_counters, const int64_t* counter_slots, int64_t n_tensors, void* stream)
+{
+    if (n_tensors < 0 || (n_tensors && !step_counters)) return SGNN_ERR_BAD_ARG;
+    for (int64_t from = 0; from < n_tensors; from += OPT_MAXT) {
+        OptSlots S;
+        S.count = (int)(n_tensors - from < OPT_MAXT ? n_tensors - from : OPT_MAXT);
+        for (int k = 0; k < S.count; ++k) S.slot[k] = (int)(counter_slots ? counter_slots[from + k] : from + k);
+        hipLaunchKernelGGL(optim_count_kernel, dim3(1), dim3(128), 0, (hipStream_t)stream, step_counters, S);
+        SGNN_CHECK_LAUNCH();
+    }
+    return SGNN_OK;
+}
+
+extern "C" int sgnn_optim_adam(float* const* params, float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
+                               const int64_t* numels, const int32_t* zero_grad, int64_t n_tensors, float lr, float beta1, float beta2,
+                               float eps, const int64_t* steps, const int64_t* step_counters, const int64_t* counter_slots,
+                               const float* partial, int64_t n_partial, float max_norm, float* coef_out, void* stream)
+{
+    if (n_tensors < 0 || (n_tensors && (!params || !grads || !exp_avg || !exp_avg_sq || !numels))) return SGNN_ERR_BAD_ARG;
+    if ((steps == nullptr) == (step_counters == nullptr) && n_tensors) return SGNN_ERR_BAD_ARG;      // exactly one of the two
+    if (max_norm > 0.f && (!partial || n_partial < 0 || n_partial > 0x7fffffffll)) return SGNN_ERR_BAD_ARG;
+    for (int64_t i = 0; i < n_tensors; ++i) {
+        if (!params[i] || !grads[i] || !exp_avg[i] || !exp_avg_sq[i] || numels[i] < 0 || (steps && steps[i] < 1)) return SGNN_ERR_BAD_ARG;
+        if ((((uintptr_t)params[i]) | ((uintptr_t)grads[i]) | ((uintptr_t)exp_avg[i]) | ((uintptr_t)exp_avg_sq[i])) & 3) return SGNN_ERR_BAD_ARG;
+    }
+    int64_t from = 0;
+    bool first = true;
+    while (from < n_tensors) {
+        int64_t to = from + 1;                     // a launch = up to OPT_MAXT consecutive tensors with the same host step count
+        while (to < n_tensors && to - from < OPT_MAXT && (!steps || steps[to] == steps[from])) ++to;
+        OptTensors T;
+        const int blocks = opt_fill(T, params, grads, exp_avg, exp_avg_sq, numels, zero_grad, counter_slots, from, to);
+        hipLaunchKernelGGL(optim_adam_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, T, partial, (int)n_partial, max_norm,
+                           first ? coef_out : nullptr, lr, beta1, beta2, eps, (long long)(steps ? steps[from] : 0), step_counters);
+        SGNN_CHECK_LAUNCH();
+        first = false;
+        from = to;
+    }
+    return SGNN_OK;
+}
+
 SGNN_DEFINE_WARM(optim)

@@ -1387,6 +1387,69 @@ def adam_step(param, grad, exp_avg, exp_avg_sq, lr, betas, eps, step, grad_scale
                                      1 if zero_grad else 0, _stream()), 'sgnn_adam_step')
 
 
+class OptimTail:
+    """clip_grad_norm_ + Adam over a fixed list of float32 CUDA parameters in two launches (sgnn_optim_sumsq, sgnn_optim_adam:
+    train_config.py Trainer(gradient_clip_val) + SubGNN/SubGNN.py:1156-1161).  Holds the pointer tables of the parameters and
+    their moments (they never move) and rebuilds the gradient pointers per step (they do, in eager mode)."""
+
+    def __init__(self, params, exp_avg, exp_avg_sq, zero_grad):
+        self.n = len(params)
+        self.params, self.exp_avg, self.exp_avg_sq = list(params), list(exp_avg), list(exp_avg_sq)
+        for t in self.params + self.exp_avg + self.exp_avg_sq:
+            _req(t, torch.float32, 'parameter / moment')
+        self.numels = np.array([p.numel() for p in params], dtype=np.int64)
+        self.p_ptr = np.array([p.data_ptr() for p in params], dtype=np.uint64)
+        self.m_ptr = np.array([t.data_ptr() for t in exp_avg], dtype=np.uint64)
+        self.v_ptr = np.array([t.data_ptr() for t in exp_avg_sq], dtype=np.uint64)
+        self.zero = np.array([1 if z else 0 for z in zero_grad], dtype=np.int32)
+
+    def step(self, which, grads, lr, betas, eps, max_norm, steps=None, step_counters=None):
+        """``which``: indices (ascending) of the parameters that have a gradient this step, ``grads`` theirs (float32,
+        contiguous).  ``steps``: host step numbers per listed parameter -- or ``step_counters``: int64 device tensor over ALL
+        parameters of the list (those of ``which`` advance).  Returns the (2,) device tensor [coefficient, total norm] when
+        clipping, else None."""
+        lib = _lib.load()
+        k = len(which)
+        if k == 0:
+            return None
+        for p_i, g in zip(which, grads):
+            _req(g, torch.float32, 'gradient')
+            if g.numel() != int(self.numels[p_i]):
+                raise ValueError('gradient of parameter %d has %d elements, the parameter %d' % (p_i, g.numel(), int(self.numels[p_i])))
+        idx = np.asarray(which, dtype=np.int64)
+        full = k == self.n
+        numels = self.numels if full else np.ascontiguousarray(self.numels[idx])
+        p_ptr, m_ptr, v_ptr = ((self.p_ptr, self.m_ptr, self.v_ptr) if full
+                               else tuple(np.ascontiguousarray(a[idx]) for a in (self.p_ptr, self.m_ptr, self.v_ptr)))
+        zero = self.zero if full else np.ascontiguousarray(self.zero[idx])
+        g_ptr = np.fromiter((g.data_ptr() for g in grads), dtype=np.uint64, count=k)
+        dev = grads[0].device
+        st = _stream()
+        counters = None
+        slots = None
+        if step_counters is not None:
+            _req(step_counters, torch.int64, 'step_counters')
+            if step_counters.numel() != self.n:
+                raise ValueError('step_counters holds %d counts for %d parameters' % (step_counters.numel(), self.n))
+            counters = _ptr(step_counters)
+            slots = None if full else idx.ctypes.data
+        out = partial = None
+        n_partial = 0
+        if max_norm is not None and max_norm > 0:
+            n_partial = int(lib.sgnn_optim_partials(numels.ctypes.data, k))
+            partial = torch.empty(n_partial, dtype=torch.float32, device=dev)
+            out = torch.empty(2, dtype=torch.float32, device=dev)
+            check(lib.sgnn_optim_sumsq(g_ptr.ctypes.data, numels.ctypes.data, k, _ptr(partial), counters, slots, st), 'sgnn_optim_sumsq')
+        elif counters is not None:
+            check(lib.sgnn_optim_count(counters, slots, k, st), 'sgnn_optim_count')
+        host_steps = None if counters is not None else np.asarray(steps, dtype=np.int64)
+        check(lib.sgnn_optim_adam(p_ptr.ctypes.data, g_ptr.ctypes.data, m_ptr.ctypes.data, v_ptr.ctypes.data, numels.ctypes.data,
+                                  zero.ctypes.data, k, float(lr), float(betas[0]), float(betas[1]), float(eps),
+                                  host_steps.ctypes.data if host_steps is not None else None, counters, slots, _ptr(partial), n_partial,
+                                  float(max_norm) if partial is not None else 0.0, _ptr(out), st), 'sgnn_optim_adam')
+        return out
+
+
 def clip_coefficient(big_grads, small_grads, max_norm):
     """clip_grad_norm_'s coefficient min(1, max_norm / (total + 1e-6)) as a (1,) device tensor: the large gradients are
     reduced by sgnn_grad_sumsq (one launch each), the small ones by one multi-tensor norm."""

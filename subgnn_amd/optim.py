@@ -18,7 +18,7 @@ class ClipAdam:
     kept a reference to ``p.grad`` across ``step()`` holds that recycled buffer, not the old gradient.  ``release()``
     drops the kept buffers."""
 
-    def __init__(self, params, lr, max_norm=None, betas=(0.9, 0.999), eps=1e-8, big_bytes=16 << 20, capturable=False):
+    def __init__(self, params, lr, max_norm=None, betas=(0.9, 0.999), eps=1e-8, big_bytes=16 << 20, capturable=False, fuse_tail=True):
         params = [p for p in params if p.requires_grad]
         self.lr, self.betas, self.eps, self.max_norm = float(lr), (float(betas[0]), float(betas[1])), float(eps), max_norm
         self.big = [p for p in params if p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()
@@ -33,8 +33,54 @@ class ClipAdam:
         self.state = {id(p): {'step': 0, 'exp_avg': torch.zeros_like(p), 'exp_avg_sq': torch.zeros_like(p),
                               'step_dev': torch.zeros(1, dtype=torch.int64, device=p.device) if self.capturable else None}
                       for p in self.big}
+        # every parameter float32, contiguous, on one GPU (the model's case): the whole tail -- norm of all gradients, clip
+        # coefficient, Adam on all of them -- is two launches (ops.OptimTail) instead of torch's multi-tensor norm, multiply and
+        # fused Adam (two 40-50 us launches: pow() in double per thread) around the table's pass: ~155 -> ~30 us per step
+        self.tail = None
+        devs = {p.device for p in params}
+        if fuse_tail and params and len(devs) == 1 and all(p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() for p in params):
+            self.all = self.big + self.small                    # the table first: its workgroups start first
+            ids = {id(p) for p in self.big}
+            self.small_opt = None
+            for p in self.small:
+                self.state[id(p)] = {'step': 0, 'exp_avg': torch.zeros_like(p), 'exp_avg_sq': torch.zeros_like(p), 'step_dev': None}
+            self.tail = ops.OptimTail(self.all, [self.state[id(p)]['exp_avg'] for p in self.all],
+                                      [self.state[id(p)]['exp_avg_sq'] for p in self.all], [id(p) in ids for p in self.all])
+            self.counters = torch.zeros(len(self.all), dtype=torch.int64, device=params[0].device) if self.capturable else None
+            self.last_clip = None                               # (2,) device tensor [coefficient, total norm] of the last step
+
+    def _step_fused(self):
+        which, grads, takes = [], [], []
+        for i, p in enumerate(self.all):
+            g = p.grad
+            if g is None:
+                continue
+            take = g.is_contiguous() and g.dtype == torch.float32
+            which.append(i)
+            grads.append(g if take else g.contiguous().float())
+            takes.append(take)
+        if not which:
+            return
+        steps = None
+        if self.counters is None:
+            steps = []
+            for i in which:
+                st = self.state[id(self.all[i])]
+                st['step'] += 1
+                steps.append(st['step'])
+        self.last_clip = self.tail.step(which, grads, self.lr, self.betas, self.eps, self.max_norm, steps=steps,
+                                        step_counters=self.counters)
+        for i, g, take in zip(which, grads, takes):
+            p = self.all[i]
+            if self.tail.zero[i] and take:                      # (the kernel zeroed the gradient it consumed)
+                ops.release_zeroed(p, g)
+                p.grad = None
+            elif self.tail.zero[i]:
+                p.grad = None
 
     def step(self):
+        if self.tail is not None:
+            return self._step_fused()
         small_grads = [p.grad for p in self.small if p.grad is not None]
         big = [p for p in self.big if p.grad is not None]
         scale = None
@@ -69,7 +115,7 @@ class ClipAdam:
     def zero_grad(self, set_to_none=True):
         if self.small_opt is not None:
             self.small_opt.zero_grad(set_to_none=set_to_none)
-        for p in self.big:
+        for p in (self.big if self.tail is None else self.all):
             if p.grad is not None:
                 if set_to_none:
                     p.grad = None
@@ -83,6 +129,11 @@ class ClipAdam:
         if self.small_opt is not None:
             from .graph_step import make_eager
             make_eager(self.small_opt)
+        if self.tail is not None and self.counters is not None:
+            done = self.counters.tolist()
+            for p, n in zip(self.all, done):
+                self.state[id(p)]['step'] = int(n)
+            self.counters = None
         for st in self.state.values():
             st['step_dev'] = None
         return self

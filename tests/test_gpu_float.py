@@ -621,6 +621,95 @@ def test_clip_adam_matches_torch(max_norm):
     assert '_sgnn_zeroed' not in got[0].__dict__
 
 
+@pytest.mark.parametrize('capturable', [False, True])
+def test_clip_adam_fused_tail_many_tensors(capturable):
+    """The two-launch optimizer tail (sgnn_optim_sumsq + sgnn_optim_adam) on 150 parameters -- more than one launch group of
+    72 --: sizes from 1 to 70 001 elements (one spans several workgroups, most end in a scalar tail), every third one a view
+    4 bytes past a 16-byte boundary (scalar path), parameters whose gradient is missing on some steps (torch.optim.Adam
+    skips them and their step counts fall behind: host counts and device counts alike), against clip_grad_norm_ +
+    torch.optim.Adam; the reported total norm against clip_grad_norm_'s; then make_eager() (device counts -> host counts)
+    and two more steps.  Also ClipAdam(fuse_tail=False), the library-call form, gives the same parameters."""
+    from subgnn_amd import optim
+    g = torch.Generator().manual_seed(11)
+    sizes = [1, 2, 3, 5, 64, 127, 1000, 4096, 4097, 70001] + [int(x) for x in torch.randint(1, 3000, (140,), generator=g)]
+    init = [torch.randn(n, generator=g) for n in sizes]
+
+    def make():
+        out = []
+        for i, t in enumerate(init):
+            if i % 3 == 2:
+                base = torch.zeros(t.numel() + 1, device=DEV)
+                view = base[1:]
+                view.copy_(t)
+                assert view.data_ptr() % 16 == 4
+                out.append(torch.nn.Parameter(view))
+            else:
+                out.append(torch.nn.Parameter(t.clone().to(DEV)))
+        return out
+    ref, got, lib_form = make(), make(), make()
+    o_ref = torch.optim.Adam(ref, lr=0.01)
+    o_got = optim.ClipAdam(got, lr=0.01, max_norm=0.7, big_bytes=70001 * 4, capturable=capturable)
+    o_lib = optim.ClipAdam(lib_form, lr=0.01, max_norm=0.7, big_bytes=70001 * 4, capturable=capturable, fuse_tail=False)
+    assert o_got.tail is not None and o_got.small_opt is None and len(o_got.big) == 1 and o_lib.tail is None
+    for it in range(6):
+        if it == 4:
+            o_got.make_eager(); o_lib.make_eager()
+            assert o_got.counters is None
+        grads = [torch.randn(n, generator=g).to(DEV) * (3.0 if it % 2 else 0.05) for n in sizes]
+        for ps in (ref, got, lib_form):
+            for i, (p, gr) in enumerate(zip(ps, grads)):
+                p.grad = None if (i % 7 == 3 and it in (1, 2)) or (i == 9 and it == 3) else gr.clone()
+        total = torch.nn.utils.clip_grad_norm_(ref, 0.7)
+        o_ref.step(); o_got.step(); o_lib.step()
+        coef, norm = o_got.last_clip.tolist()
+        assert abs(norm - float(total)) <= 1e-5 * float(total), (norm, float(total))
+        assert abs(coef - min(1.0, 0.7 / (float(total) + 1e-6))) <= 1e-6
+        for opt in (o_ref, o_got, o_lib):
+            opt.zero_grad()
+        for k, (a, b, c) in enumerate(zip(got, ref, lib_form)):
+            assert_close(a.detach(), b.detach(), 'fused tail step %d parameter %d (%d elements)' % (it, k, sizes[k]), norm_tol=2e-6)
+            assert_close(c.detach(), b.detach(), 'library form step %d parameter %d' % (it, k), norm_tol=2e-6)
+    steps = [o_got.state[id(p)]['step'] for p in got]
+    assert steps[0] == 6 and steps[3] == 4 and steps[9] == 5, steps[:12]
+
+
+def test_clip_adam_fused_tail_replays_from_a_hipgraph():
+    """The tail recorded into a hipGraph (device step counts) and replayed five times == five eager steps of torch's."""
+    from subgnn_amd import optim
+    g = torch.Generator().manual_seed(12)
+    sizes = [70001, 640, 3, 129]
+    init = [torch.randn(n, generator=g) for n in sizes]
+    ref = [torch.nn.Parameter(t.clone().to(DEV)) for t in init]
+    got = [torch.nn.Parameter(t.clone().to(DEV)) for t in init]
+    o_ref = torch.optim.Adam(ref, lr=0.01)
+    o_got = optim.ClipAdam(got, lr=0.01, max_norm=0.3, big_bytes=70001 * 4, capturable=True)
+    static = [torch.zeros(n, device=DEV) for n in sizes]
+    for p, sg in zip(got, static):
+        p.grad = sg
+    stream = torch.cuda.Stream()
+    stream.wait_stream(torch.cuda.current_stream())
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(stream):
+        with torch.cuda.graph(graph, stream=stream):
+            for p, sg in zip(got, static):
+                p.grad = sg
+            o_got.step()
+    torch.cuda.current_stream().wait_stream(stream)
+    assert int(o_got.counters.sum()) == 0                            # recording runs nothing
+    for it in range(5):
+        grads = [torch.randn(n, generator=g).to(DEV) * (2.0 if it == 2 else 0.1) for n in sizes]
+        for p, gr, sg in zip(ref, grads, static):
+            p.grad = gr.clone()
+            sg.copy_(gr)
+        torch.nn.utils.clip_grad_norm_(ref, 0.3)
+        o_ref.step()
+        graph.replay()
+        torch.cuda.synchronize()
+        for k, (a, b) in enumerate(zip(got, ref)):
+            assert_close(a.detach(), b.detach(), 'replayed tail step %d parameter %d' % (it, k), norm_tol=2e-6)
+    assert o_got.counters.tolist() == [5, 5, 5, 5]
+
+
 # ---- a18 deterministic table-gradient scatter -------------------------------------------------------
 
 @pytest.mark.parametrize('D', [8, 64, 128, 200])
