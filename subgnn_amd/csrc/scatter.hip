@@ -20,6 +20,7 @@
 #include "common.h"
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/block/block_radix_sort.hpp>
 #include <rocprim/iterator/counting_iterator.hpp>
 
 #define SC_RUN 64
@@ -234,6 +235,44 @@ static hipError_t sc_sort(void* temp, size_t& temp_bytes, const int32_t* keys, i
                                      rocprim::counting_iterator<int32_t>(0), order_out, (size_t)n, 0u, (unsigned)bits, st);
 }
 
+// Batch-sized lists (a step of 64 subgraphs sorts 1-5 k edges 6-18 times): rocPRIM's device sort is a block sort + 2-7 merge
+// launches of ~4.7 us each whatever the size.  Here ONE workgroup of 1024 lanes radix-sorts up to SC_ONE_WG (key, position) pairs
+// (rocprim::block_radix_sort: 8 bits per pass over the bits the keys can have, stable): one launch.  (A bitonic network over
+// (key | position) words in LDS was tried first: 91 barrier stages, ~20 us per sort -- slower than the launches it replaced.)
+#define SC_ONE_WG 8192
+template <int IPT>
+__global__ __launch_bounds__(1024) void sort_one_wg_kernel(const int32_t* __restrict__ keys, int n, int bits,
+                                                           int32_t* __restrict__ key_sorted, int32_t* __restrict__ order)
+{
+    using Sort = rocprim::block_radix_sort<uint32_t, 1024, IPT, int32_t>;
+    __shared__ typename Sort::storage_type storage;
+    uint32_t k[IPT];
+    int32_t v[IPT];
+#pragma unroll
+    for (int u = 0; u < IPT; ++u) {
+        const int i = threadIdx.x * IPT + u;                   // blocked arrangement: the sort is stable in this order
+        k[u] = i < n ? (uint32_t)keys[i] : 0xFFFFFFFFu;        // padding ties with the largest key at worst, and comes after it
+        v[u] = i;
+    }
+    Sort().sort(k, v, storage, 0u, (unsigned)bits);
+#pragma unroll
+    for (int u = 0; u < IPT; ++u) {
+        const int i = threadIdx.x * IPT + u;
+        if (i < n) { key_sorted[i] = (int32_t)k[u]; order[i] = v[u]; }
+    }
+}
+
+static bool sc_sort_one_wg(const int32_t* keys, int32_t* keys_out, int32_t* order_out, int64_t n, int bits, hipStream_t st)
+{
+    if (n > SC_ONE_WG) return false;
+    const int m = (int)n;
+    if (m <= 1024) hipLaunchKernelGGL(sort_one_wg_kernel<1>, dim3(1), dim3(1024), 0, st, keys, m, bits, keys_out, order_out);
+    else if (m <= 2048) hipLaunchKernelGGL(sort_one_wg_kernel<2>, dim3(1), dim3(1024), 0, st, keys, m, bits, keys_out, order_out);
+    else if (m <= 4096) hipLaunchKernelGGL(sort_one_wg_kernel<4>, dim3(1), dim3(1024), 0, st, keys, m, bits, keys_out, order_out);
+    else hipLaunchKernelGGL(sort_one_wg_kernel<8>, dim3(1), dim3(1024), 0, st, keys, m, bits, keys_out, order_out);
+    return true;
+}
+
 extern "C" int64_t sgnn_sort_edges_by_key_workspace_bytes(int64_t n_edges, int64_t max_key)
 {
     if (n_edges <= 0) return 0;
@@ -250,6 +289,7 @@ extern "C" int sgnn_sort_edges_by_key(const int32_t* keys, int64_t n_edges, int6
     if (!keys || !key_sorted || !order || !workspace) return SGNN_ERR_BAD_ARG;
     if (n_edges >= (1ll << 31)) return SGNN_ERR_SET_TOO_LARGE;
     const int bits = sc_key_bits(max_key);
+    if (sc_sort_one_wg(keys, key_sorted, order, n_edges, bits, (hipStream_t)stream)) { SGNN_CHECK_LAUNCH(); return SGNN_OK; }
     size_t need = 0;
     if (sc_sort(nullptr, need, nullptr, nullptr, nullptr, n_edges, bits, nullptr) != hipSuccess) return SGNN_ERR_LAUNCH;
     if ((int64_t)need > workspace_bytes) return SGNN_ERR_BAD_ARG;

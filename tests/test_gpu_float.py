@@ -753,8 +753,10 @@ def test_scatter_add_rows_sorted_matches_index_add_and_is_reproducible(D):
     assert_close(table, want2.float(), 'scatter (rows)', norm_tol=1e-5)
 
 
-@pytest.mark.parametrize('n,max_key', [(1, 5), (63, 1), (1000, 999), (300_000, 1_000_000), (70_000, (1 << 31) - 1)])
+@pytest.mark.parametrize('n,max_key', [(1, 5), (2, 3), (3, 1 << 30), (63, 1), (1000, 999), (4096, 1_000_000), (4097, 1_000_000), (5000, (1 << 31) - 1),
+                                       (8191, 17_000), (8192, 1_000_000), (8193, 57_000), (300_000, 1_000_000), (70_000, (1 << 31) - 1)])
 def test_sort_edges_by_key_is_a_stable_sort(n, max_key):
+    """Up to 8192 keys: the one-workgroup LDS sort (32-bit words while key bits + position bits <= 32, else 64-bit); beyond: rocPRIM."""
     from subgnn_amd import ops
     g = torch.Generator().manual_seed(n)
     keys = torch.randint(0, min(max_key, 5000) + 1, (n,), generator=g).to(torch.int32)
