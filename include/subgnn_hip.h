@@ -516,6 +516,15 @@ int sgnn_masked_sum_slot_fwd(const float* x, const uint8_t* mask, int64_t B, int
                              int64_t out_ld, void* stream);
 int sgnn_masked_sum_slot_bwd(const float* grad_out, int64_t grad_ld, const uint8_t* mask, int64_t B, int64_t C,
                              int64_t W, float* grad_x, void* stream);
+/* The same for n_pieces tensors in one launch (per 96 pieces): xs[i] (B, C, widths[i]) summed into columns
+ * [offsets[i], offsets[i] + widths[i]) of out (B, out_ld); backward: grad_xs[i] (B, C, widths[i]) written from those columns of
+ * grad_out (a null grad_xs[i] is skipped).  xs / grad_xs / widths / offsets are HOST arrays (of DEVICE pointers).  The form a
+ * batch-sized step uses: 22 pieces of a 4-layer model are one launch each way instead of 22. */
+int sgnn_masked_sum_slots_fwd(const float* const* xs, const int64_t* widths, const int64_t* offsets, int64_t n_pieces,
+                              const uint8_t* mask, int64_t B, int64_t C, float* out, int64_t out_ld, void* stream);
+int sgnn_masked_sum_slots_bwd(const float* grad_out, int64_t grad_ld, const uint8_t* mask, int64_t B, int64_t C,
+                              float* const* grad_xs, const int64_t* widths, const int64_t* offsets, int64_t n_pieces, void* stream);
+
 /* ---------------------------------------------------------------------------------------
  * a17  Loss + accuracy of a step: nn.CrossEntropyLoss() with its default mean reduction (SubGNN/SubGNN.py:133, applied
  * at SubGNN.py:1116-1124) and subgraph_utils.calc_accuracy (SubGNN/subgraph_utils.py:108-124: argmax == label, mean)
@@ -594,6 +603,13 @@ int sgnn_mpn_bwd_wp_partial(const struct sgnn_mpn_args* args, const float* grad_
  * ------------------------------------------------------------------------------------- */
 int sgnn_update_fwd(const float* x, const float* aggr, const float* W, const float* b, int64_t R, int64_t D,
                     float* out, void* stream);
+/* The forward with aggr as the anchor-chunk partial aggregates sgnn_mpn_fwd writes, aggr_chunks (n_chunks, R, D): added in
+ * chunk order while they are loaded (no separate reduction launch per layer) and, when aggr_sum (R, D) is given, written out
+ * once for sgnn_update_bwd.  n_chunks > 1 needs R <= sgnn_update_fwd_chunks_max_rows() (the batch-sized launch shape: the
+ * only one sgnn_mpn_fwd splits). */
+int64_t sgnn_update_fwd_chunks_max_rows(void);
+int sgnn_update_fwd_chunks(const float* x, const float* aggr_chunks, int64_t n_chunks, const float* W, const float* b,
+                           int64_t R, int64_t D, float* out, float* aggr_sum, void* stream);
 int64_t sgnn_update_bwd_workspace_bytes(int64_t R, int64_t D);
 int sgnn_update_bwd(const float* grad_out, const float* out, const float* x, const float* aggr, const float* W,
                     int64_t R, int64_t D, float* grad_x, float* grad_aggr, float* grad_W, float* grad_b,

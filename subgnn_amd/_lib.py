@@ -90,6 +90,8 @@ SIGNATURES = {
     'sgnn_masked_sum_bwd': (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_i64, c_ptr, c_ptr]),
     'sgnn_masked_sum_slot_fwd': (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_i64, c_ptr, c_i64, c_ptr]),
     'sgnn_masked_sum_slot_bwd': (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_i64, c_i64, c_ptr, c_ptr]),
+    'sgnn_masked_sum_slots_fwd': (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_i64, c_i64, c_ptr, c_i64, c_ptr]),
+    'sgnn_masked_sum_slots_bwd': (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_i64, c_ptr]),
     'sgnn_readout_sum_fwd': (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_ptr, c_i64, c_ptr]),
     'sgnn_grad_sumsq_partials': (c_i64, []),
     'sgnn_grad_sumsq': (c_int, [c_ptr, c_i64, c_ptr, c_ptr]),
@@ -125,6 +127,8 @@ SIGNATURES = {
     'sgnn_optim_adam': (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, ctypes.c_float, ctypes.c_float, ctypes.c_float,
                                 ctypes.c_float, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, ctypes.c_float, c_ptr, c_ptr]),
     'sgnn_update_fwd': (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr]),
+    'sgnn_update_fwd_chunks_max_rows': (c_i64, []),
+    'sgnn_update_fwd_chunks': (c_int, [c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_ptr]),
     'sgnn_update_bwd_workspace_bytes': (c_i64, [c_i64, c_i64]),
     'sgnn_update_bwd': (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr]),
     'sgnn_sort_edges_by_key_workspace_bytes': (c_i64, [c_i64, c_i64]),

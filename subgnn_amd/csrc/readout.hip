@@ -355,4 +355,101 @@ extern "C" int sgnn_masked_sum_slot_bwd(const float* grad_out, int64_t grad_ld, 
     return SGNN_OK;
 }
 
+// ---- every tensor piece of the embedding in one launch -----------------------------------------------------------------------
+// A batch-sized step of a 4-layer model sums 22 pieces of 64 x C x (34..128) floats: 22 launches of 2.5 us each way.  The pieces
+// travel as kernel arguments; a work item is one (subgraph, column of the concatenation of the listed pieces).
+#define RO_MAX_SLOTS 96
+struct RoSlots {
+    const float* x[RO_MAX_SLOTS];         // fwd: piece (B, C, w);   bwd: gradient out (B, C, w), may be null (not wanted)
+    int w[RO_MAX_SLOTS];
+    int off[RO_MAX_SLOTS];                // the piece's first column in the (B, H) embedding
+    int col0[RO_MAX_SLOTS + 1];           // its first column in the concatenation of the LISTED pieces
+    int count;
+};
+
+__device__ __forceinline__ int ro_find(const RoSlots& S, int j)
+{
+    int lo = 0, hi = S.count - 1;
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (S.col0[mid] <= j) lo = mid; else hi = mid - 1; }
+    return lo;
+}
+
+__global__ __launch_bounds__(256) void masked_sum_slots_fwd_kernel(const RoSlots S, const uint8_t* __restrict__ mask, int64_t B, int64_t C,
+                                                                   float* __restrict__ out, int64_t H)
+{
+    const int64_t W = S.col0[S.count], total = B * W;
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = t / W;
+        const int j = (int)(t - b * W), k = ro_find(S, j), jj = j - S.col0[k], w = S.w[k];
+        const float* __restrict__ x = S.x[k];
+        float acc = 0.f;
+        for (int64_t c = 0; c < C; ++c)
+            if (mask[b * C + c]) acc += x[(b * C + c) * w + jj];
+        out[b * H + S.off[k] + jj] = acc;
+    }
+}
+
+__global__ __launch_bounds__(256) void masked_sum_slots_bwd_kernel(const RoSlots S, const float* __restrict__ g, int64_t H,
+                                                                   const uint8_t* __restrict__ mask, int64_t B, int64_t C)
+{
+    const int64_t W = S.col0[S.count], total = B * C * W;
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t bc = t / W;
+        const int j = (int)(t - bc * W), k = ro_find(S, j), jj = j - S.col0[k];
+        float* __restrict__ gx = const_cast<float*>(S.x[k]);
+        if (gx) gx[bc * S.w[k] + jj] = mask[bc] ? g[(bc / C) * H + S.off[k] + jj] : 0.f;
+    }
+}
+
+static int ro_fill(RoSlots& S, const float* const* ptrs, const int64_t* widths, const int64_t* offsets, int64_t from, int64_t to,
+                   int64_t H, bool need_ptr)
+{
+    int col = 0;
+    S.count = (int)(to - from);
+    for (int64_t i = from; i < to; ++i) {
+        const int k = (int)(i - from);
+        if (widths[i] < 0 || offsets[i] < 0 || offsets[i] + widths[i] > H || widths[i] > (1 << 24)) return -1;
+        if (need_ptr && widths[i] > 0 && !ptrs[i]) return -1;
+        S.x[k] = ptrs[i]; S.w[k] = (int)widths[i]; S.off[k] = (int)offsets[i]; S.col0[k] = col;
+        col += (int)widths[i];
+    }
+    S.col0[S.count] = col;
+    return col;
+}
+
+extern "C" int sgnn_masked_sum_slots_fwd(const float* const* xs, const int64_t* widths, const int64_t* offsets, int64_t n_pieces,
+                                         const uint8_t* mask, int64_t B, int64_t C, float* out, int64_t out_ld, void* stream)
+{
+    if (n_pieces < 0 || B < 0 || C < 0 || (n_pieces && (!xs || !widths || !offsets || !mask || !out))) return SGNN_ERR_BAD_ARG;
+    for (int64_t from = 0; from < n_pieces; from += RO_MAX_SLOTS) {
+        const int64_t to = from + RO_MAX_SLOTS < n_pieces ? from + RO_MAX_SLOTS : n_pieces;
+        RoSlots S;
+        const int W = ro_fill(S, xs, widths, offsets, from, to, out_ld, true);
+        if (W < 0) return SGNN_ERR_BAD_ARG;
+        if (B * W == 0) continue;
+        hipLaunchKernelGGL(masked_sum_slots_fwd_kernel, dim3(sgnn_grid_for(B * W, 256)), dim3(256), 0, (hipStream_t)stream, S, mask, B, C,
+                           out, out_ld);
+        SGNN_CHECK_LAUNCH();
+    }
+    return SGNN_OK;
+}
+
+extern "C" int sgnn_masked_sum_slots_bwd(const float* grad_out, int64_t grad_ld, const uint8_t* mask, int64_t B, int64_t C,
+                                         float* const* grad_xs, const int64_t* widths, const int64_t* offsets, int64_t n_pieces,
+                                         void* stream)
+{
+    if (n_pieces < 0 || B < 0 || C < 0 || (n_pieces && (!grad_xs || !widths || !offsets || !mask || !grad_out))) return SGNN_ERR_BAD_ARG;
+    for (int64_t from = 0; from < n_pieces; from += RO_MAX_SLOTS) {
+        const int64_t to = from + RO_MAX_SLOTS < n_pieces ? from + RO_MAX_SLOTS : n_pieces;
+        RoSlots S;
+        const int W = ro_fill(S, (const float* const*)grad_xs, widths, offsets, from, to, grad_ld, false);
+        if (W < 0) return SGNN_ERR_BAD_ARG;
+        if (B * C * W == 0) continue;
+        hipLaunchKernelGGL(masked_sum_slots_bwd_kernel, dim3(sgnn_grid_for(B * C * W, 256)), dim3(256), 0, (hipStream_t)stream, S, grad_out,
+                           grad_ld, mask, B, C);
+        SGNN_CHECK_LAUNCH();
+    }
+    return SGNN_OK;
+}
+
 SGNN_DEFINE_WARM(readout)

@@ -93,7 +93,8 @@ __global__ __launch_bounds__(64) void update_fwd_kernel(const float* __restrict_
 template <int D>
 __global__ __launch_bounds__(256) void update_fwd_ksplit_kernel(const float* __restrict__ x, const float* __restrict__ aggr,
                                                                 const float* __restrict__ W, const float* __restrict__ b,
-                                                                int64_t R, float* __restrict__ out)
+                                                                int64_t R, float* __restrict__ out, int n_chunks,
+                                                                float* __restrict__ aggr_sum)
 {
     constexpr int Q = D / 4;                                             // positions per wavefront (8 / 16 / 32)
     __shared__ float s_part[3 * 16 * 64];
@@ -107,7 +108,16 @@ __global__ __launch_bounds__(256) void update_fwd_ksplit_kernel(const float* __r
     float a[Q], w[Q];
 #pragma unroll
     for (int c = 0; c < Q / 4; ++c) {
-        const float4 v = reinterpret_cast<const float4*>(src)[c];
+        float4 v = reinterpret_cast<const float4*>(src)[c];
+        if (h && n_chunks > 1) {
+            // aggr arrives as the anchor-chunk partials of sgnn_mpn_fwd, (n_chunks, R, D): added here in chunk order (the sum the
+            // caller used to make with a reduction launch per layer), and written out once for the backward pass
+            for (int k = 1; k < n_chunks; ++k) {
+                const float4 p = reinterpret_cast<const float4*>(src + (int64_t)k * R * D)[c];
+                v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+            }
+            if (aggr_sum && nt == 0 && row0 + i < R) reinterpret_cast<float4*>(aggr_sum + row * D + wave * Q)[c] = v;
+        }
         const float4 u = reinterpret_cast<const float4*>(wrow)[c];
         a[4 * c] = v.x; a[4 * c + 1] = v.y; a[4 * c + 2] = v.z; a[4 * c + 3] = v.w;
         w[4 * c] = u.x; w[4 * c + 1] = u.y; w[4 * c + 2] = u.z; w[4 * c + 3] = u.w;
@@ -242,11 +252,14 @@ __global__ __launch_bounds__(256) void update_bwd_dw_kernel(const float* __restr
 // out[j] = sum over blocks of part[block * n + j], in a fixed order: a workgroup owns 64 outputs; its four wavefronts
 // each add up a contiguous quarter of the blocks, and the quarters are added in order through LDS
 __global__ __launch_bounds__(256) void update_reduce_kernel(const float* __restrict__ part, int64_t n_blocks, int64_t n,
-                                                            float* __restrict__ out)
+                                                            float* __restrict__ out, unsigned first_groups,
+                                                            const float* __restrict__ part2, int64_t n2, float* __restrict__ out2)
 {
     __shared__ float s_q[4 * 64];
     const int o = threadIdx.x & 63, q = threadIdx.x >> 6;
-    const int64_t j = (int64_t)blockIdx.x * 64 + o;
+    unsigned group = blockIdx.x;
+    if (group >= first_groups) { group -= first_groups; part = part2; n = n2; out = out2; }       // the second array's workgroups
+    const int64_t j = (int64_t)group * 64 + o;
     const int64_t per = (n_blocks + 3) / 4;
     const int64_t b0 = q * per, b1 = b0 + per < n_blocks ? b0 + per : n_blocks;
     float s = 0.f;
@@ -259,8 +272,26 @@ __global__ __launch_bounds__(256) void update_reduce_kernel(const float* __restr
     if (q == 0 && j < n) out[j] = ((s_q[o] + s_q[64 + o]) + s_q[128 + o]) + s_q[192 + o];
 }
 
+static int update_fwd_run(const float* x, const float* aggr, int n_chunks, const float* W, const float* b, int64_t R, int64_t D,
+                          float* out, float* aggr_sum, void* stream);
+
 extern "C" int sgnn_update_fwd(const float* x, const float* aggr, const float* W, const float* b, int64_t R, int64_t D,
                                float* out, void* stream)
+{
+    return update_fwd_run(x, aggr, 1, W, b, R, D, out, nullptr, stream);
+}
+
+extern "C" int64_t sgnn_update_fwd_chunks_max_rows(void) { return UPD_KSPLIT_BELOW - 1; }
+
+extern "C" int sgnn_update_fwd_chunks(const float* x, const float* aggr_chunks, int64_t n_chunks, const float* W, const float* b,
+                                      int64_t R, int64_t D, float* out, float* aggr_sum, void* stream)
+{
+    if (n_chunks < 1 || n_chunks > 4096 || (n_chunks > 1 && R >= UPD_KSPLIT_BELOW)) return SGNN_ERR_BAD_ARG;
+    return update_fwd_run(x, aggr_chunks, (int)n_chunks, W, b, R, D, out, aggr_sum, stream);
+}
+
+static int update_fwd_run(const float* x, const float* aggr, int n_chunks, const float* W, const float* b, int64_t R, int64_t D,
+                          float* out, float* aggr_sum, void* stream)
 {
     if (!x || !aggr || !W || !out || R < 0) return SGNN_ERR_BAD_ARG;
     if (D != 32 && D != 64 && D != 128) return SGNN_ERR_UNSUPPORTED_D;
@@ -268,7 +299,7 @@ extern "C" int sgnn_update_fwd(const float* x, const float* aggr, const float* W
     hipStream_t st = (hipStream_t)stream;
     const unsigned grid = (unsigned)((R + 31) / 32);
     // few rows: the feature tiles side by side (more wavefronts than CUs only from ~8k rows on)
-#define UPD_LAUNCH_FWD(DD) do { if (R < UPD_KSPLIT_BELOW) hipLaunchKernelGGL((update_fwd_ksplit_kernel<DD>), dim3(grid, DD / 32), dim3(256), 0, st, x, aggr, W, b, R, out); \
+#define UPD_LAUNCH_FWD(DD) do { if (R < UPD_KSPLIT_BELOW) hipLaunchKernelGGL((update_fwd_ksplit_kernel<DD>), dim3(grid, DD / 32), dim3(256), 0, st, x, aggr, W, b, R, out, n_chunks, aggr_sum); \
                                 else if (split) hipLaunchKernelGGL((update_fwd_kernel<DD, true>), dim3(grid, DD / 32), dim3(64), 0, st, x, aggr, W, b, R, out); \
                                 else hipLaunchKernelGGL((update_fwd_kernel<DD, false>), dim3(grid), dim3(64), 0, st, x, aggr, W, b, R, out); } while (0)
     const bool split = R < UPD_SPLIT_BELOW;
@@ -327,14 +358,10 @@ extern "C" int sgnn_update_bwd(const float* grad_out, const float* out, const fl
         else if (D == 64) hipLaunchKernelGGL(update_bwd_dw_kernel<64>, grid, dim3(256), 0, st, grad_out, out, x, aggr, R, pW, pb);
         else hipLaunchKernelGGL(update_bwd_dw_kernel<128>, grid, dim3(256), 0, st, grad_out, out, x, aggr, R, pW, pb);
         SGNN_CHECK_LAUNCH();
-        if (grad_W) {
-            hipLaunchKernelGGL(update_reduce_kernel, dim3((unsigned)((D * 2 * D + 63) / 64)), dim3(256), 0, st, pW, nb, D * 2 * D, grad_W);
-            SGNN_CHECK_LAUNCH();
-        }
-        if (grad_b) {
-            hipLaunchKernelGGL(update_reduce_kernel, dim3((unsigned)((D + 63) / 64)), dim3(256), 0, st, pb, nb, D, grad_b);
-            SGNN_CHECK_LAUNCH();
-        }
+        // one launch for both: workgroups [0, nW) own 64 elements of grad_W each, the rest 64 of grad_b
+        const unsigned nW = grad_W ? (unsigned)((D * 2 * D + 63) / 64) : 0u, nB = grad_b ? (unsigned)((D + 63) / 64) : 0u;
+        hipLaunchKernelGGL(update_reduce_kernel, dim3(nW + nB), dim3(256), 0, st, pW, nb, D * 2 * D, grad_W, nW, pb, D, grad_b);
+        SGNN_CHECK_LAUNCH();
     }
     return SGNN_OK;
 }

@@ -1112,7 +1112,8 @@ class _MPN(torch.autograd.Function):
     """agg (R,D), z (R,A) = gather-weight-aggregate + read-out; grads for x, wp (bp via z)."""
 
     @staticmethod
-    def forward(ctx, x, wp, bp, sims, ids, edge_mask, row_mask, sim_col, src, id_div, sims_per_edge, R, A, edge_plan=None):
+    def forward(ctx, x, wp, bp, sims, ids, edge_mask, row_mask, sim_col, src, id_div, sims_per_edge, R, A, edge_plan=None,
+                keep_chunks=False):
         lib = _lib.load()
         ctx.edge_plan = edge_plan if src == SRC_GATHER else None
         _req(x, torch.float32, 'x')
@@ -1132,7 +1133,9 @@ class _MPN(torch.autograd.Function):
             chunks = lib.sgnn_mpn_fwd_chunks(ctypes.byref(a))       # batch-sized calls split a row's anchors
             agg = torch.empty((chunks, R, D), dtype=torch.float32, device=x.device)
             check(lib.sgnn_mpn_fwd(ctypes.byref(a), _ptr(agg), _ptr(z), _stream()), 'sgnn_mpn_fwd')
-            agg = agg[0] if chunks == 1 else agg.sum(0)              # a fixed order: no atomics
+            if not keep_chunks:
+                agg = agg[0] if chunks == 1 else agg.sum(0)          # a fixed order: no atomics
+            # (keep_chunks: the (chunks, R, D) partials go to update_layer, which adds them while it loads them)
         ctx.save_for_backward(x, wp, bp, sims, ids, edge_mask, row_mask, sim_col)
         ctx.set_materialize_grads(False)              # an unused output (the N channel never reads z) arrives as None
         ctx.meta = (src, id_div, sims_per_edge, R, A, D)
@@ -1147,6 +1150,11 @@ class _MPN(torch.autograd.Function):
         x, wp, bp, sims, ids, edge_mask, row_mask, sim_col = ctx.saved_tensors
         src, id_div, sims_per_edge, R, A, D = ctx.meta
         need_x, need_wp, need_bp = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2]
+        if g_agg is not None and g_agg.dim() == 3:
+            # the forward handed out its anchor-chunk partials; their consumer adds them, so every chunk receives the same gradient
+            if g_agg.shape[0] > 1 and g_agg.stride(0) != 0:
+                raise RuntimeError('mpn: the chunk partials of the aggregate were consumed by something other than a sum over chunks')
+            g_agg = g_agg[0]
         g_agg = g_agg.contiguous() if g_agg is not None else None
         g_z = g_z.contiguous() if g_z is not None else None
         gx = gwp = gbp = None
@@ -1205,7 +1213,7 @@ class _MPN(torch.autograd.Function):
             gwp = gwp.view_as(wp)
         if need_bp:
             gbp = g_z.sum().view_as(bp) if g_z is not None else torch.zeros_like(bp)
-        return (None if ctx.acc is not None else gx), gwp, gbp, None, None, None, None, None, None, None, None, None, None, None
+        return (None if ctx.acc is not None else gx), gwp, gbp, None, None, None, None, None, None, None, None, None, None, None, None
 
 
 def column_sum(t, chunk=512):
@@ -1336,10 +1344,19 @@ class _UpdateLayer(torch.autograd.Function):
         for t, nm in ((x, 'x'), (aggr, 'aggr'), (W, 'W'), (b, 'b')):
             _req(t, torch.float32, nm)
         R, D = x.shape
-        if aggr.shape != x.shape or tuple(W.shape) != (D, 2 * D):
+        if tuple(aggr.shape[-2:]) != (R, D) or tuple(W.shape) != (D, 2 * D):
             raise ValueError('update layer: x %s, aggr %s, W %s' % (tuple(x.shape), tuple(aggr.shape), tuple(W.shape)))
         out = torch.empty((R, D), dtype=torch.float32, device=x.device)
-        check(lib.sgnn_update_fwd(_ptr(x), _ptr(aggr), _ptr(W), _ptr(b), R, D, _ptr(out), _stream()), 'sgnn_update_fwd')
+        ctx.chunks = aggr.shape[0] if aggr.dim() == 3 else 0
+        if ctx.chunks > 1:
+            # the anchor-chunk partials of ops.mpn, added while they are loaded; their sum is kept for the backward
+            total = torch.empty((R, D), dtype=torch.float32, device=x.device)
+            check(lib.sgnn_update_fwd_chunks(_ptr(x), _ptr(aggr), ctx.chunks, _ptr(W), _ptr(b), R, D, _ptr(out), _ptr(total), _stream()),
+                  'sgnn_update_fwd_chunks')
+            aggr = total
+        else:
+            aggr = aggr[0] if ctx.chunks else aggr
+            check(lib.sgnn_update_fwd(_ptr(x), _ptr(aggr), _ptr(W), _ptr(b), R, D, _ptr(out), _stream()), 'sgnn_update_fwd')
         ctx.save_for_backward(x, aggr, W, out)
         ctx.has_bias = b is not None
         return out
@@ -1359,15 +1376,25 @@ class _UpdateLayer(torch.autograd.Function):
         ws = torch.empty(wsb // 4 + 1, dtype=torch.float32, device=x.device) if (gW is not None or gb is not None) else None
         check(lib.sgnn_update_bwd(_ptr(g), _ptr(out), _ptr(x), _ptr(aggr), _ptr(W), R, D, _ptr(gx), _ptr(ga), _ptr(gW),
                                   _ptr(gb), _ptr(ws), wsb, _stream()), 'sgnn_update_bwd')
+        if ga is not None and ctx.chunks:
+            ga = ga.unsqueeze(0).expand(ctx.chunks, R, D)            # d(sum over chunks): the same gradient for every chunk
         return gx, ga, gW, gb
 
 
 def update_layer(x, aggr, weight, bias):
     """relu(nn.Linear(2 D, D)(cat([x, aggr], 1))) for (R, D) inputs (subgraph_mpn.py:233-241).  The fused HIP form
     for D in UPDATE_DIMS; other widths keep the library GEMM (torch) around the same arithmetic."""
+    if aggr.dim() == 3 and not (x.is_cuda and x.dim() == 2 and x.shape[1] in UPDATE_DIMS and x.dtype == torch.float32
+                                and (aggr.shape[0] == 1 or x.shape[0] <= update_chunks_max_rows())):
+        aggr = aggr[0] if aggr.shape[0] == 1 else aggr.sum(0)       # chunk partials (ops.mpn(keep_chunks=True)) nobody adds in passing
     if x.is_cuda and x.dim() == 2 and x.shape[1] in UPDATE_DIMS and x.dtype == torch.float32:
         return _UpdateLayer.apply(x.contiguous(), aggr.contiguous(), weight, bias)
     return torch.relu(linear(torch.cat([x, aggr], dim=1), weight, bias))
+
+
+@functools.lru_cache(maxsize=None)
+def update_chunks_max_rows():
+    return int(_lib.load().sgnn_update_fwd_chunks_max_rows())
 
 
 def adam_step(param, grad, exp_avg, exp_avg_sq, lr, betas, eps, step, grad_scale=None, zero_grad=False, step_counter=None):
@@ -1527,16 +1554,17 @@ def mpn_edge_plan(sims, ids, row_mask, *, R, A, D, max_key, id_div=1, sim_col=No
 
 
 def mpn(x, wp, bp, sims, *, src, R, A, ids=None, id_div=1, edge_mask=None, row_mask=None, sim_col=None,
-        sims_per_edge=False, need_agg=True, edge_plan=None):
+        sims_per_edge=False, need_agg=True, edge_plan=None, keep_chunks=False):
     """Fused anchor->component layer body.  x: DENSE (R,A,D) | GATHER E (rows,D) | SHARED (A,D).
-    Returns agg (R,D) and the pre-activation read-out z (R,A)."""
+    Returns agg (R,D) and the pre-activation read-out z (R,A).  ``keep_chunks``: agg may come back as the (chunks, R, D)
+    anchor-chunk partials of a batch-sized call, for a consumer that adds them itself (``update_layer``)."""
     sims2 = sims.reshape(R, -1)
     if not sims2.is_contiguous():
         sims2 = sims2.contiguous()
     if src == SRC_SHARED and A > 0 and R >= SHARED_GEMM_MIN_ROWS:
         return _mpn_shared_gemm(x, wp, bp, sims2, ids, row_mask, sim_col, sims_per_edge, R, A, need_agg)
     return _MPN.apply(x.contiguous(), wp.contiguous().view(-1), bp.contiguous().view(-1), sims2, ids, edge_mask,
-                      row_mask, sim_col, src, id_div, sims_per_edge, R, A, edge_plan)
+                      row_mask, sim_col, src, id_div, sims_per_edge, R, A, edge_plan, keep_chunks)
 
 
 class _MaskedSum(torch.autograd.Function):
@@ -1586,6 +1614,9 @@ class ReadoutPiece:
         return torch.relu(_ReadoutShared.apply(W, self.s, self.bp)).view(B, C, self.A)
 
 
+SLOTS_TOGETHER_BELOW = 1 << 22          # (B C H) elements: below, the tensor pieces of a read-out share one launch
+
+
 class _SubgraphEmbedding(torch.autograd.Function):
     """(B, H) subgraph embedding = [masked sum over components of every piece], written slot by slot: no (B, C, H)
     concatenation (S.py:286-312).  pieces: tensors (B, C, w) and ReadoutPiece objects; tensors: the differentiable
@@ -1599,6 +1630,11 @@ class _SubgraphEmbedding(torch.autograd.Function):
         H = sum(widths)
         out = torch.empty((B, H), dtype=torch.float32, device=mask.device)
         off, k, plan = 0, 0, []
+        # batch-sized calls: all tensor pieces in one launch each way (scalar lanes; the shard-sized call keeps a vectorised
+        # launch per piece, where the bytes matter and the launches do not)
+        n_x = sum(1 for p in pieces if not isinstance(p, ReadoutPiece))
+        together = n_x >= 2 and B * C * H <= SLOTS_TOGETHER_BELOW
+        slots = []
         for p, w in zip(pieces, widths):
             dst = ctypes.c_void_p(out.data_ptr() + 4 * off)
             if isinstance(p, ReadoutPiece):
@@ -1617,11 +1653,18 @@ class _SubgraphEmbedding(torch.autograd.Function):
                 _req(x, torch.float32, 'piece')
                 if tuple(x.shape) != (B, C, w):
                     raise ValueError('piece %s for (B, C) = (%d, %d)' % (tuple(x.shape), B, C))
-                check(lib.sgnn_masked_sum_slot_fwd(_ptr(x), _ptr(mask), B, C, w, dst, H, _stream()), 'sgnn_masked_sum_slot_fwd')
+                if together:
+                    slots.append((x.data_ptr(), w, off))
+                else:
+                    check(lib.sgnn_masked_sum_slot_fwd(_ptr(x), _ptr(mask), B, C, w, dst, H, _stream()), 'sgnn_masked_sum_slot_fwd')
                 plan.append(('x', off, w, k, None))
                 k += 1
             off += w
-        ctx.plan, ctx.dims = plan, (B, C, H)
+        if slots:
+            ptrs, ws, offs = (np.array(v, dtype=t) for v, t in zip(zip(*slots), (np.uint64, np.int64, np.int64)))
+            check(lib.sgnn_masked_sum_slots_fwd(ptrs.ctypes.data, ws.ctypes.data, offs.ctypes.data, len(slots), _ptr(mask), B, C,
+                                                _ptr(out), H, _stream()), 'sgnn_masked_sum_slots_fwd')
+        ctx.plan, ctx.dims, ctx.together = plan, (B, C, H), together
         ctx.save_for_backward(mask, *tensors)
         return out
 
@@ -1632,10 +1675,20 @@ class _SubgraphEmbedding(torch.autograd.Function):
         B, C, H = ctx.dims
         g = g.contiguous()
         grads = [None] * len(tensors)
+        if ctx.together:
+            slots = []
+            for kind, off, w, k, p in ctx.plan:
+                if kind == 'x' and ctx.needs_input_grad[4 + k]:
+                    grads[k] = torch.empty((B, C, w), dtype=torch.float32, device=g.device)
+                    slots.append((grads[k].data_ptr(), w, off))
+            if slots:
+                ptrs, ws, offs = (np.array(v, dtype=t) for v, t in zip(zip(*slots), (np.uint64, np.int64, np.int64)))
+                check(lib.sgnn_masked_sum_slots_bwd(_ptr(g), H, _ptr(mask), B, C, ptrs.ctypes.data, ws.ctypes.data, offs.ctypes.data,
+                                                    len(slots), _stream()), 'sgnn_masked_sum_slots_bwd')
         for kind, off, w, k, p in ctx.plan:
             src = ctypes.c_void_p(g.data_ptr() + 4 * off)
             if kind == 'x':
-                if ctx.needs_input_grad[4 + k]:
+                if ctx.needs_input_grad[4 + k] and not ctx.together:
                     gx = torch.empty((B, C, w), dtype=torch.float32, device=g.device)
                     check(lib.sgnn_masked_sum_slot_bwd(src, H, _ptr(mask), B, C, w, _ptr(gx), _stream()), 'sgnn_masked_sum_slot_bwd')
                     grads[k] = gx

@@ -34,7 +34,7 @@ class SG_MPN(nn.Module):
             # applied to every component row, padded ones included (mpn:168,239)
             out = ops.update_layer(cc_embeds.reshape(B * C, D), agg, self.linear.weight, self.linear.bias)
         else:
-            out = agg
+            out = agg if agg.dim() == 2 else (agg[0] if agg.shape[0] == 1 else agg.sum(0))
         if not need_pos:                     # the neighbourhood channel hands on its component embeddings only
             return (out.view(B, C, -1) if out is not None else None), None
         z = z.view(B, C, -1)
@@ -94,7 +94,9 @@ class SG_MPN(nn.Module):
             z = self.linear_position.bias.view(1, 1).expand(R, A)
             return self._finish(cc_embeds, agg, z, need_out, need_pos)
         # (SubGNN._forward converts the mask once per forward and hangs it on the tensor: one launch instead of one per layer)
+        # (the anchor-chunk partials of a batch-sized call go to the update layer as they are: it adds them while loading)
         agg, z = ops.mpn(x, self.linear_position.weight, self.linear_position.bias, sims, src=src, R=R, A=A, ids=ids,
                          id_div=id_div, row_mask=row_mask, sim_col=sim_col, sims_per_edge=sims_per_edge,
-                         need_agg=need_out, edge_plan=edge_plan)
+                         need_agg=need_out, edge_plan=edge_plan,
+                         keep_chunks=bool(need_out and self.hparams['use_mpn_projection']))
         return self._finish(cc_embeds, agg, z, need_out, need_pos)

@@ -280,12 +280,16 @@ def test_masked_sum(shape):
     assert_close(xg.grad, xc.grad, 'masked_sum grad', norm_tol=1e-6)
 
 
+@pytest.mark.parametrize('together', [True, False])
 @pytest.mark.parametrize('B,C,D,A1,A2', [(5, 1, 8, 7, 3), (37, 3, 30, 57, 183), (300, 2, 64, 42, 260), (1, 4, 12, 1, 33)])
-def test_subgraph_embedding_slots_equal_cat_and_masked_sum(B, C, D, A1, A2):
+def test_subgraph_embedding_slots_equal_cat_and_masked_sum(B, C, D, A1, A2, together, monkeypatch):
     """ops.subgraph_embedding (component-embedding pieces + deferred shared-anchor read-outs, each summed into its column
     slot) against the reference's tail written out in float64: relu(W * s + b) per (component, anchor), concatenation,
-    masked sum over the components (S.py:286-303, mpn:122-131).  Values and every gradient; twice -> identical bits."""
+    masked sum over the components (S.py:286-303, mpn:122-131).  Values and every gradient; twice -> identical bits.
+    ``together``: the tensor pieces in one launch each way (sgnn_masked_sum_slots_fwd / _bwd: batch-sized calls) or one
+    vectorised launch per piece (shard-sized calls)."""
     ops = _ops()
+    monkeypatch.setattr(ops, 'SLOTS_TOGETHER_BELOW', (1 << 22) if together else 0)
     g = torch.Generator().manual_seed(B * 131 + A2)
     R = B * C
     mask = torch.rand(B, C, generator=g) > 0.3
