@@ -658,6 +658,12 @@ int sgnn_adam_step_counted(float* param, float* grad, float* exp_avg, float* exp
  *                                           sgnn_optim_sumsq / sgnn_optim_count advanced them -- the form a recorded step replays).
  *                                           zero_grad (nullable HOST int32[n_tensors]): != 0 zeroes that gradient in the same
  *                                           pass.  coef_out (nullable DEVICE float[2]): the coefficient and the total norm.
+ *                                           row_lens / row_seen (both nullable HOST arrays): tensor i is a table of rows of
+ *                                           row_lens[i] floats (a power of two, 4..256) with one DEVICE byte per row,
+ *                                           row_seen[i] (zero-initialised by the caller, owned by the optimizer state): set once
+ *                                           the row has had a non-zero gradient.  A row with an all-zero gradient and a clear
+ *                                           byte has m = v = 0 and Adam's update of it is exactly zero: it is skipped after the
+ *                                           read of its gradient (one such table per launch; bit-identical to the dense update).
  * The gradients themselves are NOT scaled in memory (clip_grad_norm_ scales them in place; here they are consumed). */
 int64_t sgnn_optim_partials(const int64_t* numels, int64_t n_tensors);
 int sgnn_optim_sumsq(const float* const* grads, const int64_t* numels, int64_t n_tensors, float* partial,
@@ -666,6 +672,7 @@ int sgnn_optim_count(int64_t* step_counters, const int64_t* counter_slots, int64
 int sgnn_optim_adam(float* const* params, float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
                     const int64_t* numels, const int32_t* zero_grad, int64_t n_tensors, float lr, float beta1, float beta2,
                     float eps, const int64_t* steps, const int64_t* step_counters, const int64_t* counter_slots,
+                    const int64_t* row_lens, unsigned char* const* row_seen,
                     const float* partial, int64_t n_partial, float max_norm, float* coef_out, void* stream);
 
 

@@ -125,7 +125,7 @@ SIGNATURES = {
     'sgnn_optim_sumsq': (c_int, [c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr]),
     'sgnn_optim_count': (c_int, [c_ptr, c_ptr, c_i64, c_ptr]),
     'sgnn_optim_adam': (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, ctypes.c_float, ctypes.c_float, ctypes.c_float,
-                                ctypes.c_float, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, ctypes.c_float, c_ptr, c_ptr]),
+                                ctypes.c_float, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, ctypes.c_float, c_ptr, c_ptr]),
     'sgnn_update_fwd': (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr]),
     'sgnn_update_fwd_chunks_max_rows': (c_i64, []),
     'sgnn_update_fwd_chunks': (c_int, [c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_ptr]),

@@ -184,6 +184,13 @@ struct OptTensors {
     int zero[OPT_MAXT];
     int slot[OPT_MAXT];                   // which device step count belongs to tensor t
     int count;
+    // one tensor of the launch may be a table of rows with a per-row "ever had a gradient" byte: a row whose gradient is all
+    // zero and that never had one has m = v = 0, so Adam leaves it exactly as it is (update = step_size * 0 / (0 + eps)) --
+    // it costs the read of its gradient instead of four reads and three or four writes.  A shard's subgraphs, border sets and
+    // anchor patches reach ~40 % of a million-node table's rows (7 % for one of 8 strong-scaling shards), the same ones every pass.
+    int rows_t;                           // index of that tensor in this launch, -1 = none
+    int row_lanes;                        // float4 lanes per row: a power of two <= 64
+    unsigned char* seen;
 };
 
 __device__ __forceinline__ int opt_find(const OptTensors& T, int b)
@@ -251,6 +258,34 @@ __global__ __launch_bounds__(256) void optim_adam_kernel(const OptTensors T, con
     if (((((uintptr_t)p) | ((uintptr_t)g) | ((uintptr_t)m) | ((uintptr_t)v)) & 15) == 0) {
         const int64_t n4 = n >> 2;
         float4* p4 = (float4*)p; float4* g4 = (float4*)g; float4* m4 = (float4*)m; float4* v4 = (float4*)v;
+        if (t == T.rows_t) {
+            // (n = rows * 4 L and a wavefront's 64 consecutive float4 start at a multiple of 64: a row's lanes share a wavefront)
+            const int L = T.row_lanes, lane = threadIdx.x & 63, sh = 31 - __builtin_clz(L);
+            const unsigned long long rowmask = (L == 64 ? ~0ull : ((1ull << L) - 1ull)) << (lane & ~(L - 1));
+            unsigned char* __restrict__ seen = T.seen;
+            for (int64_t i = (int64_t)(b - T.blk[t]) * 256 + threadIdx.x; i < n4; i += (int64_t)nb * 256) {
+                float4 gg = g4[i];
+                const int64_t row = i >> sh;
+                const bool nz = gg.x != 0.f || gg.y != 0.f || gg.z != 0.f || gg.w != 0.f;
+                const bool any = (__ballot(nz) & rowmask) != 0ull;
+                const bool was = seen[row] != 0;
+                if (any || was) {
+                    float4 pp = p4[i], mm = m4[i], vv = v4[i];
+                    float* P = &pp.x; float* G = &gg.x; float* M = &mm.x; float* V = &vv.x;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float gk = G[k] * gs;
+                        M[k] = M[k] + (1.f - b1) * (gk - M[k]);
+                        V[k] = b2 * V[k] + (1.f - b2) * gk * gk;
+                        P[k] -= step_size * M[k] / (sqrtf(V[k]) * rsqrt_bc2 + eps);
+                    }
+                    p4[i] = pp; m4[i] = mm; v4[i] = vv;
+                    if (zero && any) g4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (!was && (lane & (L - 1)) == 0) seen[row] = 1;
+                }
+            }
+            return;
+        }
         for (int64_t i = (int64_t)(b - T.blk[t]) * 256 + threadIdx.x; i < n4; i += (int64_t)nb * 256) {
             float4 pp = p4[i], gg = g4[i], mm = m4[i], vv = v4[i];
             float* P = &pp.x; float* G = &gg.x; float* M = &mm.x; float* V = &vv.x;
@@ -316,6 +351,7 @@ static int opt_fill(OptTensors& T, float* const* params, float* const* grads, fl
         blocks += opt_blocks(numels[i]);
     }
     T.blk[T.count] = blocks;
+    T.rows_t = -1; T.row_lanes = 1; T.seen = nullptr;
     return blocks;
 }
 
@@ -352,6 +388,7 @@ extern "C" int sgnn_optim_count(int64_t* step_counters, const int64_t* counter_s
 extern "C" int sgnn_optim_adam(float* const* params, float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
                                const int64_t* numels, const int32_t* zero_grad, int64_t n_tensors, float lr, float beta1, float beta2,
                                float eps, const int64_t* steps, const int64_t* step_counters, const int64_t* counter_slots,
+                               const int64_t* row_lens, unsigned char* const* row_seen,
                                const float* partial, int64_t n_partial, float max_norm, float* coef_out, void* stream)
 {
     if (n_tensors < 0 || (n_tensors && (!params || !grads || !exp_avg || !exp_avg_sq || !numels))) return SGNN_ERR_BAD_ARG;
@@ -368,6 +405,12 @@ extern "C" int sgnn_optim_adam(float* const* params, float* const* grads, float*
         while (to < n_tensors && to - from < OPT_MAXT && (!steps || steps[to] == steps[from])) ++to;
         OptTensors T;
         const int blocks = opt_fill(T, params, grads, exp_avg, exp_avg_sq, numels, zero_grad, counter_slots, from, to);
+        for (int64_t i = from; i < to && row_lens && row_seen && T.rows_t < 0; ++i) {
+            const int64_t D = row_lens[i];
+            if (!row_seen[i] || D < 4 || D > 256 || (D & (D - 1)) != 0 || numels[i] % D != 0) continue;      // 1..64 float4 lanes per row
+            if ((((uintptr_t)params[i]) | ((uintptr_t)grads[i]) | ((uintptr_t)exp_avg[i]) | ((uintptr_t)exp_avg_sq[i])) & 15) continue;
+            T.rows_t = (int)(i - from); T.row_lanes = (int)(D / 4); T.seen = row_seen[i];
+        }
         hipLaunchKernelGGL(optim_adam_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, T, partial, (int)n_partial, max_norm,
                            first ? coef_out : nullptr, lr, beta1, beta2, eps, (long long)(steps ? steps[from] : 0), step_counters);
         SGNN_CHECK_LAUNCH();

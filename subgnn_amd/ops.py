@@ -1419,7 +1419,9 @@ class OptimTail:
     train_config.py Trainer(gradient_clip_val) + SubGNN/SubGNN.py:1156-1161).  Holds the pointer tables of the parameters and
     their moments (they never move) and rebuilds the gradient pointers per step (they do, in eager mode)."""
 
-    def __init__(self, params, exp_avg, exp_avg_sq, zero_grad):
+    def __init__(self, params, exp_avg, exp_avg_sq, zero_grad, row_skip=()):
+        """``row_skip``: indices of 2-D parameters whose untouched rows the update may skip (a byte per row, kept here: set once
+        a row has had a non-zero gradient; a row without one has m = v = 0 and Adam does not move it)."""
         self.n = len(params)
         self.params, self.exp_avg, self.exp_avg_sq = list(params), list(exp_avg), list(exp_avg_sq)
         for t in self.params + self.exp_avg + self.exp_avg_sq:
@@ -1429,6 +1431,15 @@ class OptimTail:
         self.m_ptr = np.array([t.data_ptr() for t in exp_avg], dtype=np.uint64)
         self.v_ptr = np.array([t.data_ptr() for t in exp_avg_sq], dtype=np.uint64)
         self.zero = np.array([1 if z else 0 for z in zero_grad], dtype=np.int32)
+        self.row_len = np.zeros(self.n, dtype=np.int64)
+        self.seen_ptr = np.zeros(self.n, dtype=np.uint64)
+        self.seen = {}
+        for i in row_skip:
+            p = params[i]
+            D = p.shape[-1] if p.dim() == 2 else 0
+            if D >= 4 and D <= 256 and (D & (D - 1)) == 0 and p.data_ptr() % 16 == 0:
+                self.seen[i] = torch.zeros(p.shape[0], dtype=torch.uint8, device=p.device)
+                self.row_len[i], self.seen_ptr[i] = D, self.seen[i].data_ptr()
 
     def step(self, which, grads, lr, betas, eps, max_norm, steps=None, step_counters=None):
         """``which``: indices (ascending) of the parameters that have a gradient this step, ``grads`` theirs (float32,
@@ -1449,6 +1460,8 @@ class OptimTail:
         p_ptr, m_ptr, v_ptr = ((self.p_ptr, self.m_ptr, self.v_ptr) if full
                                else tuple(np.ascontiguousarray(a[idx]) for a in (self.p_ptr, self.m_ptr, self.v_ptr)))
         zero = self.zero if full else np.ascontiguousarray(self.zero[idx])
+        row_len = self.row_len if full else np.ascontiguousarray(self.row_len[idx])
+        seen_ptr = self.seen_ptr if full else np.ascontiguousarray(self.seen_ptr[idx])
         g_ptr = np.fromiter((g.data_ptr() for g in grads), dtype=np.uint64, count=k)
         dev = grads[0].device
         st = _stream()
@@ -1472,7 +1485,9 @@ class OptimTail:
         host_steps = None if counters is not None else np.asarray(steps, dtype=np.int64)
         check(lib.sgnn_optim_adam(p_ptr.ctypes.data, g_ptr.ctypes.data, m_ptr.ctypes.data, v_ptr.ctypes.data, numels.ctypes.data,
                                   zero.ctypes.data, k, float(lr), float(betas[0]), float(betas[1]), float(eps),
-                                  host_steps.ctypes.data if host_steps is not None else None, counters, slots, _ptr(partial), n_partial,
+                                  host_steps.ctypes.data if host_steps is not None else None, counters, slots,
+                                  row_len.ctypes.data if self.seen else None, seen_ptr.ctypes.data if self.seen else None,
+                                  _ptr(partial), n_partial,
                                   float(max_norm) if partial is not None else 0.0, _ptr(out), st), 'sgnn_optim_adam')
         return out
 

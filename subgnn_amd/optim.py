@@ -18,7 +18,8 @@ class ClipAdam:
     kept a reference to ``p.grad`` across ``step()`` holds that recycled buffer, not the old gradient.  ``release()``
     drops the kept buffers."""
 
-    def __init__(self, params, lr, max_norm=None, betas=(0.9, 0.999), eps=1e-8, big_bytes=16 << 20, capturable=False, fuse_tail=True):
+    def __init__(self, params, lr, max_norm=None, betas=(0.9, 0.999), eps=1e-8, big_bytes=16 << 20, capturable=False, fuse_tail=True,
+                 skip_untouched_rows=True):
         params = [p for p in params if p.requires_grad]
         self.lr, self.betas, self.eps, self.max_norm = float(lr), (float(betas[0]), float(betas[1])), float(eps), max_norm
         self.big = [p for p in params if p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()
@@ -45,7 +46,8 @@ class ClipAdam:
             for p in self.small:
                 self.state[id(p)] = {'step': 0, 'exp_avg': torch.zeros_like(p), 'exp_avg_sq': torch.zeros_like(p), 'step_dev': None}
             self.tail = ops.OptimTail(self.all, [self.state[id(p)]['exp_avg'] for p in self.all],
-                                      [self.state[id(p)]['exp_avg_sq'] for p in self.all], [id(p) in ids for p in self.all])
+                                      [self.state[id(p)]['exp_avg_sq'] for p in self.all], [id(p) in ids for p in self.all],
+                                      row_skip=range(len(self.big)) if skip_untouched_rows else ())
             self.counters = torch.zeros(len(self.all), dtype=torch.int64, device=params[0].device) if self.capturable else None
             self.last_clip = None                               # (2,) device tensor [coefficient, total norm] of the last step
 

@@ -677,6 +677,43 @@ def test_clip_adam_fused_tail_many_tensors(capturable):
     assert steps[0] == 6 and steps[3] == 4 and steps[9] == 5, steps[:12]
 
 
+@pytest.mark.parametrize('D', [4, 32, 64, 128, 256, 48])
+def test_clip_adam_skips_untouched_table_rows_bit_exactly(D):
+    """The table's Adam update skips rows that have no gradient now and never had one (m = v = 0: Adam leaves such a row as it
+    is): bit-identical to the dense update (skip_untouched_rows=False) over steps whose gradients touch different row sets --
+    a row touched once keeps decaying afterwards --, and equal to clip_grad_norm_ + torch.optim.Adam.  D = 48 is not a power of
+    two: no skipping there, same results."""
+    from subgnn_amd import optim
+    g = torch.Generator().manual_seed(D)
+    rows = 5001
+    init = [torch.randn(rows, D, generator=g), torch.randn(D, 7, generator=g)]
+    models = [[torch.nn.Parameter(t.clone().to(DEV)) for t in init] for _ in range(3)]
+    o_skip = optim.ClipAdam(models[0], lr=0.01, max_norm=0.5, big_bytes=rows * D * 4)
+    o_dense = optim.ClipAdam(models[1], lr=0.01, max_norm=0.5, big_bytes=rows * D * 4, skip_untouched_rows=False)
+    o_ref = torch.optim.Adam(models[2], lr=0.01)
+    assert (len(o_skip.tail.seen) == 1) == (D != 48) and not o_dense.tail.seen
+    touched = torch.zeros(rows, dtype=torch.bool)
+    for it in range(6):
+        pick = torch.rand(rows, generator=g) < (0.0 if it == 3 else 0.15)           # step 3: no row at all
+        pick[0] = False                                                             # the PAD row never has a gradient
+        touched |= pick
+        gt = torch.randn(rows, D, generator=g) * pick.unsqueeze(1)
+        gs = torch.randn(D, 7, generator=g)
+        for ps in models:
+            ps[0].grad, ps[1].grad = gt.clone().to(DEV), gs.clone().to(DEV)
+        torch.nn.utils.clip_grad_norm_(models[2], 0.5)
+        o_skip.step(); o_dense.step(); o_ref.step()
+        for opt in (o_skip, o_dense, o_ref):
+            opt.zero_grad()
+        assert torch.equal(models[0][0], models[1][0]) and torch.equal(models[0][1], models[1][1]), it
+        for name in ('exp_avg', 'exp_avg_sq'):
+            assert torch.equal(o_skip.state[id(models[0][0])][name], o_dense.state[id(models[1][0])][name]), (it, name)
+        assert_close(models[0][0].detach(), models[2][0].detach(), 'table after step %d' % it, norm_tol=2e-6)
+        if D != 48:
+            assert torch.equal(o_skip.tail.seen[0].cpu().bool(), touched), it
+    assert torch.equal(models[0][0][~touched.to(DEV)].cpu(), init[0][~touched])    # untouched rows: the initial bits
+
+
 def test_clip_adam_fused_tail_replays_from_a_hipgraph():
     """The tail recorded into a hipGraph (device step counts) and replayed five times == five eager steps of torch's."""
     from subgnn_amd import optim
