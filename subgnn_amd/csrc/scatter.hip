@@ -231,6 +231,9 @@ static inline int sc_key_bits(int64_t max_key) { int b = 1; while (b < 31 && (1l
 static hipError_t sc_sort(void* temp, size_t& temp_bytes, const int32_t* keys, int32_t* keys_out, int32_t* order_out,
                           int64_t n, int bits, hipStream_t st)
 {
+    // (rocPRIM's default: a merge sort up to 2^20 keys -- a block sort + two launches per doubling --, the one-sweep radix sort
+    // beyond.  Forcing one-sweep from 8 193 keys on was measured: 15 k-100 k keys, the batch-sized steps' lists, sort SLOWER that
+    // way (DENSITY stand-in step 0.86 -> 1.22 ms, PPI-BP 1.35 -> 1.45) and the 269 k keys of a 6 250-subgraph shard no faster.)
     return rocprim::radix_sort_pairs(temp, temp_bytes, reinterpret_cast<const uint32_t*>(keys), reinterpret_cast<uint32_t*>(keys_out),
                                      rocprim::counting_iterator<int32_t>(0), order_out, (size_t)n, 0u, (unsigned)bits, st);
 }
