@@ -429,9 +429,12 @@ typedef struct sgnn_mpn_args {
     int32_t        x_f16;      /* GATHER only: x points at an IEEE half table (rows, D), read as
                                 * half and accumulated in fp32 (gradients stay fp32) */
     int32_t        flags;      /* SGNN_MPN_WP_PARTIAL: sgnn_mpn_bwd (DENSE) writes grad_wp as per-row partial sums (R, D)
-                                * for the caller to add up in a fixed order, instead of adding into (D) with atomics */
+                                * for the caller to add up in a fixed order, instead of adding into (D) with atomics.
+                                * SGNN_MPN_RELU_Z: sgnn_mpn_fwd writes the read-out AFTER its non-linearity, relu(z) (mpn:122-131
+                                * generate_pos_struc_embeddings applies it next), instead of the pre-activation */
 } sgnn_mpn_args;
 #define SGNN_MPN_WP_PARTIAL 1
+#define SGNN_MPN_RELU_Z     2
 
 /* Batch-sized calls (a few hundred rows) split the anchors of a row over sgnn_mpn_fwd_chunks(args) chunks so that
  * the launch fills the chip; chunk c writes its partial aggregate to agg + c * R * D and the caller adds the

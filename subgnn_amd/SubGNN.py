@@ -593,6 +593,32 @@ class SubGNN(nn.Module):
 
         def rows_of(t):
             return t if whole is not None and t.shape[0] == whole else t.index_select(0, sidx)
+
+        def layer_rows(src, tag):
+            """rows_of(src[dataset_type][layer_num]) -- for a batch, the rows of ALL layers' anchor tensors in one gather (they
+            are stacked once per preparation): a 4-layer step made 12 gathers of a few KB each, now 3."""
+            t = src[dataset_type][layer_num]
+            L = self.hparams['n_layers']
+            cache = self.__dict__.get('_fwd_cache')
+            if (whole is not None and t.shape[0] == whole) or L < 2 or cache is None:
+                return rows_of(t)
+            key = ('anchor_rows', tag, dataset_type)
+            if key not in cache:
+                gen = self.__dict__.get('_prep_generation', 0)
+                stacks = self.__dict__.setdefault('_anchor_stacks', {})
+                ent = stacks.get(key)
+                per_layer = [src[dataset_type][l] for l in range(L)]
+                if ent is None or ent[0] != gen or any(a is not b for a, b in zip(ent[1], per_layer)):
+                    if any(p.shape != per_layer[0].shape or p.dtype != per_layer[0].dtype for p in per_layer) \
+                            or (t.is_cuda and torch.cuda.is_current_stream_capturing()):
+                        # (a stack made while a step is being recorded would live in the recording's memory pool and be re-made
+                        # by every replay: the per-layer gathers serve that recording; eager steps before it build the stack)
+                        cache[key] = None
+                        return rows_of(t)
+                    ent = stacks[key] = (gen, per_layer, torch.stack(per_layer, 0))
+                cache[key] = ent[2].index_select(1, sidx.reshape(-1))                 # (L, B, ...)
+            got = cache[key]
+            return rows_of(t) if got is None else got[layer_num]
         # NP_sim is either the reference's dense (B,C,N) slab (column = anchor id - 1) or, for
         # graphs where that slab cannot exist, a dict of already-gathered (B,C,A) edge weights
         # keyed (channel tag, side, layer) -- see hotpath.py
@@ -602,7 +628,7 @@ class SubGNN(nn.Module):
         if channel == 'neighborhood':
             src = self.anchors_neigh_int if inside else self.anchors_neigh_border
             anchors = src[dataset_type][layer_num]
-            ids = rows_of(anchors).reshape(B * C, -1).contiguous()
+            ids = layer_rows(src, 'N_in' if inside else 'N_out').reshape(B * C, -1).contiguous()
             # (hotpath.prepare_pass: the gradient-independent half of this layer's table-gradient scatter, for these anchors)
             plan = self.__dict__.get('_mpn_edge_plans', {}).get(dataset_type, {}).get(('N', inside, layer_num))
             if plan is not None and not (whole is not None and plan['anchors'] is anchors and per_edge):
@@ -612,7 +638,7 @@ class SubGNN(nn.Module):
                                         edge_plan=plan)
         if channel == 'position':
             if inside:
-                ids = rows_of(self.anchors_pos_int[dataset_type][layer_num]).contiguous()
+                ids = layer_rows(self.anchors_pos_int, 'P_in').contiguous()
                 return mpn_fn.forward_fused(sims, cc_embeds, cc_embed_mask, src=ops.SRC_GATHER, x=E, ids=ids, id_div=C,
                                             sims_per_edge=per_edge, need_out=need_out, defer_readout=defer, need_pos=need_pos)
             ids = self.anchors_pos_ext[layer_num]

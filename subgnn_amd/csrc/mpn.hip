@@ -30,6 +30,7 @@ __global__ __launch_bounds__(256) void mpn_fwd_kernel(sgnn_mpn_args a, float* __
     const T* xt = reinterpret_cast<const T*>(a.x);
     const int lanes = (int)D4;
     const float bp = a.bp[0];
+    const bool relu_z = (a.flags & SGNN_MPN_RELU_Z) != 0;
     // batch-sized calls (a few hundred component rows) do not fill the chip with one lane group per row and
     // walk their anchors one dependent load after the other: the anchors are then split over grid.y
     const int64_t a_per = (a.A + gridDim.y - 1) / gridDim.y;
@@ -66,7 +67,7 @@ __global__ __launch_bounds__(256) void mpn_fwd_kernel(sgnn_mpn_args a, float* __
                 const float dot = group_sum(wp.x * x.x + wp.y * x.y + wp.z * x.z + wp.w * x.w, lanes);
                 zval = w * dot + bp;
             }
-            if (dv == 0 && z) z[r * a.A + ai] = zval;
+            if (dv == 0 && z) z[r * a.A + ai] = relu_z ? fmaxf(zval, 0.f) : zval;
         }
         // anchor chunks of one row: each writes its partial aggregate to its own (R, D) slice, the caller adds them up
         reinterpret_cast<float4*>(agg)[(int64_t)blockIdx.y * total + t] = acc;

@@ -1113,9 +1113,10 @@ class _MPN(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, wp, bp, sims, ids, edge_mask, row_mask, sim_col, src, id_div, sims_per_edge, R, A, edge_plan=None,
-                keep_chunks=False):
+                keep_chunks=False, relu_z=False):
         lib = _lib.load()
         ctx.edge_plan = edge_plan if src == SRC_GATHER else None
+        ctx.relu_z = bool(relu_z)
         _req(x, torch.float32, 'x')
         _req(wp, torch.float32, 'wp')
         _req(bp, torch.float32, 'bp')
@@ -1130,13 +1131,15 @@ class _MPN(torch.autograd.Function):
             agg = torch.zeros((R, D), dtype=torch.float32, device=x.device)
         else:
             a = _mpn_args(src, x, ids, id_div, edge_mask, row_mask, sims, sim_col, sims_per_edge, wp, bp, R, A, D)
+            if relu_z:
+                a.flags = 2                                         # SGNN_MPN_RELU_Z: the read-out leaves the kernel activated
             chunks = lib.sgnn_mpn_fwd_chunks(ctypes.byref(a))       # batch-sized calls split a row's anchors
             agg = torch.empty((chunks, R, D), dtype=torch.float32, device=x.device)
             check(lib.sgnn_mpn_fwd(ctypes.byref(a), _ptr(agg), _ptr(z), _stream()), 'sgnn_mpn_fwd')
             if not keep_chunks:
                 agg = agg[0] if chunks == 1 else agg.sum(0)          # a fixed order: no atomics
             # (keep_chunks: the (chunks, R, D) partials go to update_layer, which adds them while it loads them)
-        ctx.save_for_backward(x, wp, bp, sims, ids, edge_mask, row_mask, sim_col)
+        ctx.save_for_backward(x, wp, bp, sims, ids, edge_mask, row_mask, sim_col, *((z,) if relu_z else ()))
         ctx.set_materialize_grads(False)              # an unused output (the N channel never reads z) arrives as None
         ctx.meta = (src, id_div, sims_per_edge, R, A, D)
         ctx.acc = getattr(x, '_sgnn_acc', None) if src == SRC_GATHER else None     # x is the tapped table
@@ -1147,8 +1150,10 @@ class _MPN(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_agg, g_z):
         lib = _lib.load()
-        x, wp, bp, sims, ids, edge_mask, row_mask, sim_col = ctx.saved_tensors
+        x, wp, bp, sims, ids, edge_mask, row_mask, sim_col = ctx.saved_tensors[:8]
         src, id_div, sims_per_edge, R, A, D = ctx.meta
+        if ctx.relu_z and g_z is not None:
+            g_z = torch.ops.aten.threshold_backward(g_z.contiguous(), ctx.saved_tensors[8], 0.0)     # through the fused relu
         need_x, need_wp, need_bp = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2]
         if g_agg is not None and g_agg.dim() == 3:
             # the forward handed out its anchor-chunk partials; their consumer adds them, so every chunk receives the same gradient
@@ -1158,13 +1163,17 @@ class _MPN(torch.autograd.Function):
         g_agg = g_agg.contiguous() if g_agg is not None else None
         g_z = g_z.contiguous() if g_z is not None else None
         gx = gwp = gbp = None
+        # (the deterministic SHARED backward assigns every element of both gradients, the deterministic GATHER one replaces
+        # grad_wp by a column sum: no zero fills for those -- a 4-layer batch-sized step made ~40 of them)
+        assigned = A > 0 and src == SRC_SHARED and ctx.det
         if need_x:
             if ctx.acc is not None:
                 gx = ctx.acc.buffer(x.shape, x.device)          # the kernel adds into the shared buffer
             else:
-                gx = torch.empty_like(x) if src == SRC_DENSE else torch.zeros_like(x)
+                gx = torch.empty_like(x) if (src == SRC_DENSE or assigned) else torch.zeros_like(x)
         if need_wp:
-            gwp = torch.zeros(D, dtype=torch.float32, device=x.device)
+            replaced = A > 0 and src == SRC_GATHER and ctx.det and D <= 256 and g_z is not None
+            gwp = None if replaced else (torch.empty if assigned else torch.zeros)(D, dtype=torch.float32, device=x.device)
         if (need_x or need_wp) and A > 0 and src == SRC_GATHER and ctx.det and D <= 256:
             # table gradient by a sorted segmented sum, read-out weight gradient by per-row partials: no atomics
             if ctx.half is not None:
@@ -1213,7 +1222,7 @@ class _MPN(torch.autograd.Function):
             gwp = gwp.view_as(wp)
         if need_bp:
             gbp = g_z.sum().view_as(bp) if g_z is not None else torch.zeros_like(bp)
-        return (None if ctx.acc is not None else gx), gwp, gbp, None, None, None, None, None, None, None, None, None, None, None, None
+        return (None if ctx.acc is not None else gx), gwp, gbp, None, None, None, None, None, None, None, None, None, None, None, None, None
 
 
 def column_sum(t, chunk=512):
@@ -1569,17 +1578,19 @@ def mpn_edge_plan(sims, ids, row_mask, *, R, A, D, max_key, id_div=1, sim_col=No
 
 
 def mpn(x, wp, bp, sims, *, src, R, A, ids=None, id_div=1, edge_mask=None, row_mask=None, sim_col=None,
-        sims_per_edge=False, need_agg=True, edge_plan=None, keep_chunks=False):
+        sims_per_edge=False, need_agg=True, edge_plan=None, keep_chunks=False, relu_z=False):
     """Fused anchor->component layer body.  x: DENSE (R,A,D) | GATHER E (rows,D) | SHARED (A,D).
     Returns agg (R,D) and the pre-activation read-out z (R,A).  ``keep_chunks``: agg may come back as the (chunks, R, D)
-    anchor-chunk partials of a batch-sized call, for a consumer that adds them itself (``update_layer``)."""
+    anchor-chunk partials of a batch-sized call, for a consumer that adds them itself (``update_layer``).  ``relu_z``: the
+    read-out comes back activated, relu(z) (what generate_pos_struc_embeddings, mpn:122-131, makes of it next)."""
     sims2 = sims.reshape(R, -1)
     if not sims2.is_contiguous():
         sims2 = sims2.contiguous()
     if src == SRC_SHARED and A > 0 and R >= SHARED_GEMM_MIN_ROWS:
-        return _mpn_shared_gemm(x, wp, bp, sims2, ids, row_mask, sim_col, sims_per_edge, R, A, need_agg)
+        agg, z = _mpn_shared_gemm(x, wp, bp, sims2, ids, row_mask, sim_col, sims_per_edge, R, A, need_agg)
+        return agg, (torch.relu(z) if relu_z else z)
     return _MPN.apply(x.contiguous(), wp.contiguous().view(-1), bp.contiguous().view(-1), sims2, ids, edge_mask,
-                      row_mask, sim_col, src, id_div, sims_per_edge, R, A, edge_plan, keep_chunks)
+                      row_mask, sim_col, src, id_div, sims_per_edge, R, A, edge_plan, keep_chunks, relu_z)
 
 
 class _MaskedSum(torch.autograd.Function):

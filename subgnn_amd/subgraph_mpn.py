@@ -24,7 +24,7 @@ class SG_MPN(nn.Module):
         self.linear_position = nn.Linear(D, 1)
 
     # -- shared tail: update() and the read-out non-linearity (mpn:122-131, 233-241) -------
-    def _finish(self, cc_embeds, agg, z, need_out=True, need_pos=True):
+    def _finish(self, cc_embeds, agg, z, need_out=True, need_pos=True, activated=False):
         B, C, D = cc_embeds.shape
         if not need_out:
             # the caller reads only the position read-out of this layer (the last layer of the position / structure
@@ -41,7 +41,7 @@ class SG_MPN(nn.Module):
         if self.hparams.get('norm_pos_struc_embed', False):
             pos = F.normalize(z, p=2, dim=-1)
         else:
-            pos = F.relu(z)
+            pos = z if activated else F.relu(z)       # (activated: the layer kernel wrote relu(z) itself)
         return (out.view(B, C, -1) if out is not None else None), pos
 
     def forward(self, networkx_graph, sims, cc_ids, cc_embeds, cc_embed_mask, anchor_patches, anchor_embeds,
@@ -94,9 +94,10 @@ class SG_MPN(nn.Module):
             z = self.linear_position.bias.view(1, 1).expand(R, A)
             return self._finish(cc_embeds, agg, z, need_out, need_pos)
         # (SubGNN._forward converts the mask once per forward and hangs it on the tensor: one launch instead of one per layer)
+        relu_z = bool(need_pos and not self.hparams.get('norm_pos_struc_embed', False))
         # (the anchor-chunk partials of a batch-sized call go to the update layer as they are: it adds them while loading)
         agg, z = ops.mpn(x, self.linear_position.weight, self.linear_position.bias, sims, src=src, R=R, A=A, ids=ids,
                          id_div=id_div, row_mask=row_mask, sim_col=sim_col, sims_per_edge=sims_per_edge,
                          need_agg=need_out, edge_plan=edge_plan,
-                         keep_chunks=bool(need_out and self.hparams['use_mpn_projection']))
-        return self._finish(cc_embeds, agg, z, need_out, need_pos)
+                         keep_chunks=bool(need_out and self.hparams['use_mpn_projection']), relu_z=relu_z)
+        return self._finish(cc_embeds, agg, z, need_out, need_pos, activated=relu_z)
