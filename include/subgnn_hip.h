@@ -428,6 +428,8 @@ typedef struct sgnn_mpn_args {
     const float*   bp;         /* (1) linear_position.bias   */
     int32_t        x_f16;      /* GATHER only: x points at an IEEE half table (rows, D), read as
                                 * half and accumulated in fp32 (gradients stay fp32) */
+    const float*   z_act;      /* nullable, (R, A): the read-out as sgnn_mpn_fwd wrote it under SGNN_MPN_RELU_Z.  When set, every
+                                * backward entry point takes grad_z through that relu: an entry whose z_act is not > 0 counts as 0 */
     int32_t        flags;      /* SGNN_MPN_WP_PARTIAL: sgnn_mpn_bwd (DENSE) writes grad_wp as per-row partial sums (R, D)
                                 * for the caller to add up in a fixed order, instead of adding into (D) with atomics.
                                 * SGNN_MPN_RELU_Z: sgnn_mpn_fwd writes the read-out AFTER its non-linearity, relu(z) (mpn:122-131
@@ -572,7 +574,8 @@ int sgnn_readout_sum_bwd(const float* grad_out, int64_t grad_ld, const float* si
  * Every table row has one writer and a fixed summation order: results are bit-reproducible.
  * sgnn_mpn_bwd_edges: keys and coefficients of a GATHER message-passing layer's backward (c1 = the edge
  * weight w, c2 = w * grad_z; masked or zero-weight edges get key 0); sgnn_mpn_bwd_wp_partial: that layer's
- * read-out weight gradient as per-row partial sums (R, D) for the caller to add up.
+ * read-out weight gradient as per-row partial sums (R, partial_ld) for the caller to add up; partial_ld = D, or D + 1: then
+ * column D holds the row's sum of grad_z (through args->z_act), the per-row partial of the read-out bias's gradient.
  * ------------------------------------------------------------------------------------- */
 int64_t sgnn_scatter_add_rows_workspace_bytes(int64_t n_edges, int64_t D);
 /* The stable sort the scatter needs: key_sorted / order (int32, n_edges each) from keys in [0, max_key] -- a radix
@@ -587,13 +590,16 @@ int sgnn_scatter_add_rows_sorted(const int32_t* order, const int32_t* key_sorted
                                  const int32_t* arg, float* table,
                                  void* workspace, int64_t workspace_bytes, void* stream);
 /* SHARED source, batch-sized calls, without atomics: per-row-tile partials in the workspace, added in tile order
- * (grad_x (A, D) and grad_wp (D) are OVERWRITTEN, either may be NULL). */
+ * (grad_x (A, D), grad_wp (D) and grad_bp (1) -- the read-out bias's gradient, the sum of every entry of grad_z taken through
+ * args->z_act -- are OVERWRITTEN, each may be NULL). */
 int64_t sgnn_mpn_bwd_shared_det_workspace_bytes(int64_t R, int64_t A, int64_t D);
 int sgnn_mpn_bwd_shared_det(const struct sgnn_mpn_args* args, const float* grad_agg, const float* grad_z,
-                            float* grad_x, float* grad_wp, void* workspace, int64_t workspace_bytes, void* stream);
+                            float* grad_x, float* grad_wp, float* grad_bp, void* workspace, int64_t workspace_bytes,
+                            void* stream);
 int sgnn_mpn_bwd_edges(const struct sgnn_mpn_args* args, const float* grad_z, int32_t* out_keys, float* out_c1,
                        float* out_c2, void* stream);
-int sgnn_mpn_bwd_wp_partial(const struct sgnn_mpn_args* args, const float* grad_z, float* partial, void* stream);
+int sgnn_mpn_bwd_wp_partial(const struct sgnn_mpn_args* args, const float* grad_z, float* partial, int64_t partial_ld,
+                            void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * a12  update(): out = relu([x | aggr] W^T + b) and its backward (SubGNN/subgraph_mpn.py:233-241 with the

@@ -23,7 +23,7 @@ class MpnArgs(ctypes.Structure):
                 ('R', c_i64), ('A', c_i64), ('D', c_i64),
                 ('x', c_ptr), ('ids', c_ptr), ('id_div', c_i64), ('edge_mask', c_ptr), ('row_mask', c_ptr),
                 ('sims', c_ptr), ('sims_ld', c_i64), ('sim_col', c_ptr), ('wp', c_ptr), ('bp', c_ptr),
-                ('x_f16', ctypes.c_int32), ('flags', ctypes.c_int32)]
+                ('x_f16', ctypes.c_int32), ('z_act', c_ptr), ('flags', ctypes.c_int32)]
 
 
 # name -> (restype, argtypes); mirrors include/subgnn_hip.h line by line
@@ -116,7 +116,7 @@ SIGNATURES = {
     'sgnn_probe_stream_copy': (c_int, [c_ptr, c_ptr, c_i64, c_int, c_ptr]),
     'sgnn_scatter_add_rows_workspace_bytes': (c_i64, [c_i64, c_i64]),
     'sgnn_mpn_bwd_shared_det_workspace_bytes': (c_i64, [c_i64, c_i64, c_i64]),
-    'sgnn_mpn_bwd_shared_det': (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr]),
+    'sgnn_mpn_bwd_shared_det': (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr]),
     'sgnn_adam_step': (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float,
                                c_i64, c_ptr, c_int, c_ptr]),
     'sgnn_adam_step_counted': (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, ctypes.c_float, ctypes.c_float, ctypes.c_float,
@@ -136,7 +136,7 @@ SIGNATURES = {
     'sgnn_scatter_add_rows_sorted': (c_int, [c_ptr, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr,
                                              c_ptr, c_i64, c_ptr]),
     'sgnn_mpn_bwd_edges': (c_int, [ctypes.POINTER(MpnArgs), c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
-    'sgnn_mpn_bwd_wp_partial': (c_int, [ctypes.POINTER(MpnArgs), c_ptr, c_ptr, c_ptr]),
+    'sgnn_mpn_bwd_wp_partial': (c_int, [ctypes.POINTER(MpnArgs), c_ptr, c_ptr, c_i64, c_ptr]),
 }
 
 ERRORS = {-1: 'SGNN_ERR_BAD_ARG', -2: 'SGNN_ERR_SET_TOO_LARGE', -3: 'SGNN_ERR_NNZ_TOO_LARGE',

@@ -15,6 +15,14 @@
 // wave-instruction footprint is whole contiguous rows (the full-rate shape on gfx950).
 #include "common.h"
 
+// grad of the read-out entry idx as the backward kernels consume it: through the fused relu when the forward wrote relu(z)
+// (a.z_act = that output; SGNN_MPN_RELU_Z) -- what a separate threshold launch per layer did before
+__device__ static inline float mpn_gz(const sgnn_mpn_args& a, const float* __restrict__ grad_z, int64_t idx) {
+    if (!grad_z) return 0.f;
+    const float g = grad_z[idx];
+    return (a.z_act && !(a.z_act[idx] > 0.f)) ? 0.f : g;
+}
+
 __device__ static inline float group_sum(float v, int lanes) {
     for (int d = lanes >> 1; d >= 1; d >>= 1) v += __shfl_xor(v, d);
     return v;
@@ -110,7 +118,7 @@ __global__ __launch_bounds__(256) void mpn_bwd_kernel(sgnn_mpn_args a, const flo
             if (edge) {
                 const int64_t col = a.sim_col ? a.sim_col[ai] : (a.sims_per_edge ? ai : id - 1);
                 const float w = a.sims[r * a.sims_ld + col];
-                const float gz = grad_z ? grad_z[r * a.A + ai] : 0.f;
+                const float gz = mpn_gz(a, grad_z, r * a.A + ai);
                 dx.x = w * (ga.x + gz * wp.x); dx.y = w * (ga.y + gz * wp.y);
                 dx.z = w * (ga.z + gz * wp.z); dx.w = w * (ga.w + gz * wp.w);
                 if (grad_wp && gz != 0.f) {
@@ -174,7 +182,7 @@ __global__ __launch_bounds__(256) void mpn_bwd_gather_kernel(sgnn_mpn_args a, co
             const int64_t col = a.sim_col ? a.sim_col[ai] : (a.sims_per_edge ? ai : id - 1);
             const float w = a.sims[r * a.sims_ld + col];
             if (w == 0.f) continue;
-            const float gz = grad_z ? grad_z[r * a.A + ai] : 0.f;
+            const float gz = mpn_gz(a, grad_z, r * a.A + ai);
             if (grad_x) atomicAdd(grad_x + id * D + d, w * (ga + gz * wp));
             if (grad_wp && gz != 0.f)
                 gw += gz * w * (a.x_f16 ? __half2float(reinterpret_cast<const __half*>(a.x)[id * D + d]) : a.x[id * D + d]);
@@ -222,7 +230,7 @@ __global__ __launch_bounds__(256) void mpn_bwd_shared_kernel(sgnn_mpn_args a, co
             for (int64_t r = r0; r < r1; ++r) {
                 if (a.row_mask && !a.row_mask[r]) continue;
                 const float w = a.sims[r * a.sims_ld + col];
-                const float gz = grad_z ? grad_z[r * a.A + ai] : 0.f;
+                const float gz = mpn_gz(a, grad_z, r * a.A + ai);
                 float4 ga = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (grad_agg) ga = reinterpret_cast<const float4*>(grad_agg)[r * D4 + dv];
                 acc.x += w * (ga.x + gz * wp.x); acc.y += w * (ga.y + gz * wp.y);
@@ -254,7 +262,7 @@ __global__ __launch_bounds__(256) void mpn_bwd_shared_kernel(sgnn_mpn_args a, co
 __global__ __launch_bounds__(256) void mpn_bwd_shared_det_kernel(sgnn_mpn_args a, const float* __restrict__ grad_agg,
                                                                  const float* __restrict__ grad_z,
                                                                  float* __restrict__ part_x, float* __restrict__ part_s,
-                                                                 int64_t D4, int64_t tile_rows)
+                                                                 float* __restrict__ part_b, int64_t D4, int64_t tile_rows)
 {
     const int64_t D = D4 * 4;
     const int64_t tile = blockIdx.x;
@@ -272,7 +280,7 @@ __global__ __launch_bounds__(256) void mpn_bwd_shared_det_kernel(sgnn_mpn_args a
             for (int64_t r = r0; r < r1; ++r) {
                 if (a.row_mask && !a.row_mask[r]) continue;
                 const float w = a.sims[r * a.sims_ld + col];
-                const float gz = grad_z ? grad_z[r * a.A + ai] : 0.f;
+                const float gz = mpn_gz(a, grad_z, r * a.A + ai);
                 float4 ga = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (grad_agg) ga = reinterpret_cast<const float4*>(grad_agg)[r * D4 + dv];
                 acc.x += w * (ga.x + gz * wp.x); acc.y += w * (ga.y + gz * wp.y);
@@ -281,14 +289,35 @@ __global__ __launch_bounds__(256) void mpn_bwd_shared_det_kernel(sgnn_mpn_args a
             }
         }
         reinterpret_cast<float4*>(part_x)[(tile * a.A + ai) * D4 + dv] = acc;
-        if (dv == 0) part_s[tile * a.A + ai] = sgz;
+        if (dv == 0) {
+            part_s[tile * a.A + ai] = sgz;
+            if (part_b) {                 // grad_bp's share: the read-out bias reaches every entry, masked ones included
+                float sb = 0.f;
+                for (int64_t r = r0; r < r1; ++r) sb += mpn_gz(a, grad_z, r * a.A + ai);
+                part_b[tile * a.A + ai] = sb;
+            }
+        }
     }
 }
 
 __global__ __launch_bounds__(256) void mpn_bwd_shared_reduce_kernel(sgnn_mpn_args a, const float* __restrict__ part_x,
                                                                     const float* __restrict__ part_s, int64_t n_tiles,
-                                                                    float* __restrict__ grad_x, float* __restrict__ grad_wp)
+                                                                    float* __restrict__ grad_x, float* __restrict__ grad_wp,
+                                                                    const float* __restrict__ part_b, float* __restrict__ grad_bp)
 {
+    if (grad_bp && blockIdx.x == gridDim.x - 1) {
+        // one wavefront's worth of work: per lane a strided share of the (tile, anchor) partials, then the lanes in order
+        __shared__ float s_b[256];
+        float v = 0.f;
+        for (int64_t k = threadIdx.x; k < n_tiles * a.A; k += blockDim.x) v += part_b[k];
+        s_b[threadIdx.x] = v;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float t = 0.f;
+            for (int k = 0; k < 256; ++k) t += s_b[k];
+            grad_bp[0] = t;
+        }
+    }
     const int64_t AD = a.A * a.D;
     const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (grad_x && t < AD) {
@@ -338,25 +367,29 @@ __global__ __launch_bounds__(256) void mpn_bwd_edges_kernel(sgnn_mpn_args a, con
         }
         keys[e] = w != 0.f ? (int32_t)id : 0;
         c1[e] = w;
-        if (c2) c2[e] = grad_z ? w * grad_z[e] : 0.f;
+        if (c2) c2[e] = w * mpn_gz(a, grad_z, e);
     }
 }
 
 // grad_wp of a GATHER layer as per-row partial sums (no atomics): partial[r, d] = sum_ai g_z[r, ai] * w * x[id, d];
 // the caller sums the rows (a fixed reduction tree).
 __global__ __launch_bounds__(256) void mpn_bwd_wp_partial_kernel(sgnn_mpn_args a, const float* __restrict__ grad_z,
-                                                                 float* __restrict__ partial)
+                                                                 float* __restrict__ partial, int64_t ld)
 {
-    const int64_t D = a.D, total = a.R * D;
+    // ld == D + 1: column D of a row is the sum of the row's (gated) read-out gradients -- grad_bp's per-row partial: the
+    // read-out bias reaches EVERY entry (masked edges and padded rows read out bp itself)
+    const int64_t D = a.D, total = a.R * ld;
     for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t r = t / D, d = t % D;
+        const int64_t r = t / ld, d = t % ld;
         float gw = 0.f;
-        if (!a.row_mask || a.row_mask[r]) {
+        if (d == D) {
+            for (int64_t ai = 0; ai < a.A; ++ai) gw += mpn_gz(a, grad_z, r * a.A + ai);
+        } else if (!a.row_mask || a.row_mask[r]) {
             const int64_t idrow = (a.id_div > 1 ? r / a.id_div : r) * a.A;
             for (int64_t ai = 0; ai < a.A; ++ai) {
                 const int64_t id = a.ids[idrow + ai];
                 if (id == 0) continue;
-                const float gz = grad_z[r * a.A + ai];
+                const float gz = mpn_gz(a, grad_z, r * a.A + ai);
                 if (gz == 0.f) continue;
                 const int64_t col = a.sim_col ? a.sim_col[ai] : (a.sims_per_edge ? ai : id - 1);
                 const float w = a.sims[r * a.sims_ld + col];
@@ -480,14 +513,16 @@ extern "C" int sgnn_mpn_bwd_edges(const sgnn_mpn_args* args, const float* grad_z
     return SGNN_OK;
 }
 
-extern "C" int sgnn_mpn_bwd_wp_partial(const sgnn_mpn_args* args, const float* grad_z, float* partial, void* stream)
+extern "C" int sgnn_mpn_bwd_wp_partial(const sgnn_mpn_args* args, const float* grad_z, float* partial, int64_t partial_ld,
+                                       void* stream)
 {
     const int rc = mpn_check(args);
     if (rc != SGNN_OK) return rc;
     if (args->src != SGNN_SRC_GATHER || !grad_z || !partial) return SGNN_ERR_BAD_ARG;
+    if (partial_ld != args->D && partial_ld != args->D + 1) return SGNN_ERR_BAD_ARG;
     if (args->R == 0) return SGNN_OK;
-    hipLaunchKernelGGL(mpn_bwd_wp_partial_kernel, dim3(sgnn_grid_for(args->R * args->D, 256, 8192)), dim3(256), 0,
-                       (hipStream_t)stream, *args, grad_z, partial);
+    hipLaunchKernelGGL(mpn_bwd_wp_partial_kernel, dim3(sgnn_grid_for(args->R * partial_ld, 256, 8192)), dim3(256), 0,
+                       (hipStream_t)stream, *args, grad_z, partial, partial_ld);
     SGNN_CHECK_LAUNCH();
     return SGNN_OK;
 }
@@ -507,11 +542,12 @@ extern "C" int64_t sgnn_mpn_bwd_shared_det_workspace_bytes(int64_t R, int64_t A,
     if (R <= 0 || A <= 0 || D <= 0) return 0;
     int64_t tr, nt, ch;
     mpn_shared_det_tiling(R, A, D / 4, &tr, &nt, &ch);
-    return nt * A * (D + 1) * 4 + 64;
+    return nt * A * (D + 2) * 4 + 64;
 }
 
 extern "C" int sgnn_mpn_bwd_shared_det(const sgnn_mpn_args* args, const float* grad_agg, const float* grad_z,
-                                       float* grad_x, float* grad_wp, void* workspace, int64_t workspace_bytes, void* stream)
+                                       float* grad_x, float* grad_wp, float* grad_bp, void* workspace, int64_t workspace_bytes,
+                                       void* stream)
 {
     const int rc = mpn_check(args);
     if (rc != SGNN_OK) return rc;
@@ -524,11 +560,12 @@ extern "C" int sgnn_mpn_bwd_shared_det(const sgnn_mpn_args* args, const float* g
     mpn_shared_det_tiling(args->R, args->A, D4, &tile_rows, &n_tiles, &chunks);
     float* part_x = (float*)workspace;
     float* part_s = part_x + n_tiles * args->A * args->D;
+    float* part_b = grad_bp ? part_s + n_tiles * args->A : nullptr;
     hipLaunchKernelGGL(mpn_bwd_shared_det_kernel, dim3((unsigned)n_tiles, (unsigned)chunks), dim3(256), 0, st, *args, grad_agg,
-                       grad_z, part_x, part_s, D4, tile_rows);
+                       grad_z, part_x, part_s, part_b, D4, tile_rows);
     SGNN_CHECK_LAUNCH();
     hipLaunchKernelGGL(mpn_bwd_shared_reduce_kernel, dim3((unsigned)((args->A * args->D + 255) / 256)), dim3(256), 0, st, *args,
-                       part_x, part_s, n_tiles, grad_x, grad_wp);
+                       part_x, part_s, n_tiles, grad_x, grad_wp, part_b, grad_bp);
     SGNN_CHECK_LAUNCH();
     return SGNN_OK;
 }

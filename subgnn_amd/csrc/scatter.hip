@@ -269,10 +269,10 @@ static bool sc_sort_one_wg(const int32_t* keys, int32_t* keys_out, int32_t* orde
 {
     if (n > SC_ONE_WG) return false;
     const int m = (int)n;
-    if (m <= 1024) hipLaunchKernelGGL(sort_one_wg_kernel<1>, dim3(1), dim3(1024), 0, st, keys, m, bits, keys_out, order_out);
-    else if (m <= 2048) hipLaunchKernelGGL(sort_one_wg_kernel<2>, dim3(1), dim3(1024), 0, st, keys, m, bits, keys_out, order_out);
-    else if (m <= 4096) hipLaunchKernelGGL(sort_one_wg_kernel<4>, dim3(1), dim3(1024), 0, st, keys, m, bits, keys_out, order_out);
-    else hipLaunchKernelGGL(sort_one_wg_kernel<8>, dim3(1), dim3(1024), 0, st, keys, m, bits, keys_out, order_out);
+    // (the sort's time grows with the items per lane: 6.5 us at 1, 26 us at 8 -- the step of a 4-layer model sorts 4 352 keys 8 times)
+#define SC_ONE_WG_CASE(IPT) if (m <= 1024 * IPT) { hipLaunchKernelGGL(sort_one_wg_kernel<IPT>, dim3(1), dim3(1024), 0, st, keys, m, bits, keys_out, order_out); return true; }
+    SC_ONE_WG_CASE(1) SC_ONE_WG_CASE(2) SC_ONE_WG_CASE(3) SC_ONE_WG_CASE(4) SC_ONE_WG_CASE(5) SC_ONE_WG_CASE(6) SC_ONE_WG_CASE(8)
+#undef SC_ONE_WG_CASE
     return true;
 }
 

@@ -108,19 +108,29 @@ __global__ __launch_bounds__(256) void update_fwd_ksplit_kernel(const float* __r
     float a[Q], w[Q];
 #pragma unroll
     for (int c = 0; c < Q / 4; ++c) {
-        float4 v = reinterpret_cast<const float4*>(src)[c];
-        if (h && n_chunks > 1) {
-            // aggr arrives as the anchor-chunk partials of sgnn_mpn_fwd, (n_chunks, R, D): added here in chunk order (the sum the
-            // caller used to make with a reduction launch per layer), and written out once for the backward pass
-            for (int k = 1; k < n_chunks; ++k) {
-                const float4 p = reinterpret_cast<const float4*>(src + (int64_t)k * R * D)[c];
-                v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
-            }
-            if (aggr_sum && nt == 0 && row0 + i < R) reinterpret_cast<float4*>(aggr_sum + row * D + wave * Q)[c] = v;
-        }
+        const float4 v = reinterpret_cast<const float4*>(src)[c];
         const float4 u = reinterpret_cast<const float4*>(wrow)[c];
         a[4 * c] = v.x; a[4 * c + 1] = v.y; a[4 * c + 2] = v.z; a[4 * c + 3] = v.w;
         w[4 * c] = u.x; w[4 * c + 1] = u.y; w[4 * c + 2] = u.z; w[4 * c + 3] = u.w;
+    }
+    if (n_chunks > 1) {
+        // aggr arrives as the anchor-chunk partials of sgnn_mpn_fwd, (n_chunks, R, D): added here in chunk order (the sum the
+        // caller used to make with a reduction launch per layer), and written out once for the backward pass.  A chunk's
+        // Q / 4 loads are issued together (one memory latency per chunk, not per 16 bytes).
+        if (h) {
+            for (int k = 1; k < n_chunks; ++k) {
+                float4 p[Q / 4];
+#pragma unroll
+                for (int c = 0; c < Q / 4; ++c) p[c] = reinterpret_cast<const float4*>(src + (int64_t)k * R * D)[c];
+#pragma unroll
+                for (int c = 0; c < Q / 4; ++c) { a[4 * c] += p[c].x; a[4 * c + 1] += p[c].y; a[4 * c + 2] += p[c].z; a[4 * c + 3] += p[c].w; }
+            }
+            if (aggr_sum && nt == 0 && row0 + i < R) {
+#pragma unroll
+                for (int c = 0; c < Q / 4; ++c)
+                    reinterpret_cast<float4*>(aggr_sum + row * D + wave * Q)[c] = make_float4(a[4 * c], a[4 * c + 1], a[4 * c + 2], a[4 * c + 3]);
+            }
+        }
     }
     upd_f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll

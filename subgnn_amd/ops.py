@@ -1152,9 +1152,18 @@ class _MPN(torch.autograd.Function):
         lib = _lib.load()
         x, wp, bp, sims, ids, edge_mask, row_mask, sim_col = ctx.saved_tensors[:8]
         src, id_div, sims_per_edge, R, A, D = ctx.meta
-        if ctx.relu_z and g_z is not None:
-            g_z = torch.ops.aten.threshold_backward(g_z.contiguous(), ctx.saved_tensors[8], 0.0)     # through the fused relu
         need_x, need_wp, need_bp = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2]
+        # The gradient of the read-out goes through the fused relu.  Where every reader of grad_z is one of the deterministic
+        # kernels below, they apply the gate themselves (args.z_act) and produce the read-out bias's gradient too -- a threshold
+        # launch and a reduction launch less per layer body; anywhere else the gated gradient is materialised first.
+        z_act = ctx.saved_tensors[8] if ctx.relu_z else None
+        gather_det = A > 0 and src == SRC_GATHER and ctx.det and D <= 256
+        shared_det = A > 0 and src == SRC_SHARED and ctx.det
+        planned = gather_det and ctx.edge_plan is not None and ctx.edge_plan['keys'].numel() == R * A
+        in_kernel = z_act is not None and g_z is not None and (need_x or need_wp) and ((gather_det and not planned) or shared_det)
+        if z_act is not None and g_z is not None and not in_kernel:
+            g_z = torch.ops.aten.threshold_backward(g_z.contiguous(), z_act, 0.0)
+        z_gate = z_act if in_kernel else None
         if g_agg is not None and g_agg.dim() == 3:
             # the forward handed out its anchor-chunk partials; their consumer adds them, so every chunk receives the same gradient
             if g_agg.shape[0] > 1 and g_agg.stride(0) != 0:
@@ -1179,6 +1188,7 @@ class _MPN(torch.autograd.Function):
             if ctx.half is not None:
                 x._sgnn_half = ctx.half
             a = _mpn_args(src, x, ids, id_div, edge_mask, row_mask, sims, sim_col, sims_per_edge, wp, bp, R, A, D)
+            a.z_act = _ptr(z_gate)
             plan = ctx.edge_plan
             if need_x and (g_agg is not None or g_z is not None) and plan is not None and plan['keys'].numel() == R * A:
                 # the static half of the edge list (target rows, weights, sorted order) came with the prepared pass
@@ -1193,16 +1203,23 @@ class _MPN(torch.autograd.Function):
                       'sgnn_mpn_bwd_edges')
                 scatter_add_rows(gx, keys, G=g_agg, edges_per_row=A, c1=c1, c2=c2, v=wp if c2 is not None else None)
             if need_wp and g_z is not None:
-                partial = torch.empty((R, D), dtype=torch.float32, device=x.device)
-                check(lib.sgnn_mpn_bwd_wp_partial(ctypes.byref(a), _ptr(g_z), _ptr(partial), _stream()),
+                ld = D + 1 if need_bp else D            # (column D: the row's share of the read-out bias's gradient)
+                partial = torch.empty((R, ld), dtype=torch.float32, device=x.device)
+                check(lib.sgnn_mpn_bwd_wp_partial(ctypes.byref(a), _ptr(g_z), _ptr(partial), ld, _stream()),
                       'sgnn_mpn_bwd_wp_partial')
-                gwp = column_sum(partial)
+                col = column_sum(partial)
+                gwp = col[:D]
+                if need_bp:
+                    gbp = col[D:].view_as(bp)
         elif (need_x or need_wp) and A > 0 and src == SRC_SHARED and ctx.det:
             # row-tile partials added in tile order (sgnn_mpn_bwd_shared_det): no atomics
             a = _mpn_args(src, x, ids, id_div, edge_mask, row_mask, sims, sim_col, sims_per_edge, wp, bp, R, A, D)
+            a.z_act = _ptr(z_gate)
             wsb = lib.sgnn_mpn_bwd_shared_det_workspace_bytes(R, A, D)
             ws = torch.empty(wsb // 4 + 1, dtype=torch.float32, device=x.device)
-            check(lib.sgnn_mpn_bwd_shared_det(ctypes.byref(a), _ptr(g_agg), _ptr(g_z), _ptr(gx), _ptr(gwp), _ptr(ws), wsb,
+            if need_bp and g_z is not None:
+                gbp = torch.empty_like(bp)
+            check(lib.sgnn_mpn_bwd_shared_det(ctypes.byref(a), _ptr(g_agg), _ptr(g_z), _ptr(gx), _ptr(gwp), _ptr(gbp), _ptr(ws), wsb,
                                               _stream()), 'sgnn_mpn_bwd_shared_det')
         elif (need_x or need_wp) and A > 0:
             if ctx.half is not None:
@@ -1220,7 +1237,9 @@ class _MPN(torch.autograd.Function):
             gx.zero_()
         if need_wp:
             gwp = gwp.view_as(wp)
-        if need_bp:
+        if need_bp and gbp is None:
+            if g_z is not None and z_gate is not None:          # gated inside the kernels only: the sum needs the gated values
+                g_z = torch.ops.aten.threshold_backward(g_z, z_gate, 0.0)
             gbp = g_z.sum().view_as(bp) if g_z is not None else torch.zeros_like(bp)
         return (None if ctx.acc is not None else gx), gwp, gbp, None, None, None, None, None, None, None, None, None, None, None, None, None
 
