@@ -589,6 +589,17 @@ int sgnn_scatter_add_rows_sorted(const int32_t* order, const int32_t* key_sorted
                                  const float* G, int64_t D, const float* c1, const float* c2, const float* v,
                                  const int32_t* arg, float* table,
                                  void* workspace, int64_t workspace_bytes, void* stream);
+/* n_lists scatters into ONE table as one sorted list: the edge lists are concatenated (list order, then position), sorted once
+ * (stable) and scattered once -- the form a batch-sized training step uses for the 6-18 short lists (1-30 k edges: one per layer
+ * body, the component embeddings, the shared anchors' lookups) it adds to the embedding table's gradient: one pack launch, one
+ * sort, two scatter launches instead of 6-18 times (sort + two).  keys / n_edges / edge_row / edges_per_row / G / c1 / c2 / v:
+ * HOST arrays over the lists, each entry as the argument of that name of sgnn_scatter_add_rows_sorted (DEVICE pointers; every
+ * G[k] has D columns; no argmax form).  Every table row has one writer and a fixed order of addition. */
+int64_t sgnn_scatter_add_rows_multi_workspace_bytes(int64_t total_edges, int64_t D, int64_t max_key);
+int sgnn_scatter_add_rows_multi(int64_t n_lists, const int32_t* const* keys, const int64_t* n_edges,
+                                const int32_t* const* edge_row, const int64_t* edges_per_row, const float* const* G,
+                                const float* const* c1, const float* const* c2, const float* const* v, int64_t D,
+                                int64_t max_key, float* table, void* workspace, int64_t workspace_bytes, void* stream);
 /* SHARED source, batch-sized calls, without atomics: per-row-tile partials in the workspace, added in tile order
  * (grad_x (A, D), grad_wp (D) and grad_bp (1) -- the read-out bias's gradient, the sum of every entry of grad_z taken through
  * args->z_act -- are OVERWRITTEN, each may be NULL). */

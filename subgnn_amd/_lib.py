@@ -135,6 +135,9 @@ SIGNATURES = {
     'sgnn_sort_edges_by_key': (c_int, [c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_i64, c_ptr]),
     'sgnn_scatter_add_rows_sorted': (c_int, [c_ptr, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr,
                                              c_ptr, c_i64, c_ptr]),
+    'sgnn_scatter_add_rows_multi_workspace_bytes': (c_i64, [c_i64, c_i64, c_i64]),
+    'sgnn_scatter_add_rows_multi': (c_int, [c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr,
+                                            c_i64, c_ptr]),
     'sgnn_mpn_bwd_edges': (c_int, [ctypes.POINTER(MpnArgs), c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
     'sgnn_mpn_bwd_wp_partial': (c_int, [ctypes.POINTER(MpnArgs), c_ptr, c_ptr, c_i64, c_ptr]),
 }

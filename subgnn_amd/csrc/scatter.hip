@@ -47,6 +47,10 @@ struct ScArgs {
     int32_t* carry_key;        // 2 per run: head, tail
     int32_t* carry_flag;       // 2 per run: bit 0 = present, bit 1 (head only) = the segment runs on into the next run
     float* carry_val;          // 2 per run x D
+    // MULTI (several scatters into one table as ONE sorted list, sgnn_scatter_add_rows_multi): per edge the ADDRESS of its
+    // source row (0 = none) and of its v (0 = none); c1 / c2 are then per-edge arrays over the concatenated edges
+    const unsigned long long* src_rows;
+    const unsigned long long* v_rows;
 };
 
 // AHEAD source rows are requested together, MAXC columns per lane.  For D <= 64: (64, 1) when the launch has fewer
@@ -56,7 +60,14 @@ struct ScArgs {
 // per SIMD hide those waits better than 3 with 159 registers each (benchmark, 2.1 M border edges: 293 us with 64 rows
 // in flight, 218 with 8; what remains is the random 256-byte read-modify-write of ~0.9 M distinct table rows in HBM).
 // (16, 1) with the argmax ids, (16, 2) for D <= 128, (8, 4) up to 256.
-template <int AHEAD, int MAXC, int RUN = SC_RUN>
+__device__ __forceinline__ unsigned long long sc_readlane64(unsigned long long v, int lane)
+{
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, lane);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), lane);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+template <int AHEAD, int MAXC, int RUN = SC_RUN, bool MULTI = false>
 __global__ __launch_bounds__(256) void scatter_runs_kernel(ScArgs a)
 {
     static_assert(RUN <= 64 && AHEAD <= RUN, "one sorted position per lane");
@@ -69,10 +80,12 @@ __global__ __launch_bounds__(256) void scatter_runs_kernel(ScArgs a)
     // one sorted position per lane
     int32_t k_l = 0, row_l = 0;
     float c1_l = 0.f, c2_l = 0.f;
+    unsigned long long src_l = 0ull, v_l = 0ull;
     if (lane < cnt) {
         k_l = a.key[p0 + lane];
         const int64_t e = a.order[p0 + lane];
-        row_l = a.edge_row ? a.edge_row[e] : (int32_t)(e / a.edges_per_row);
+        if (MULTI) { src_l = a.src_rows[e]; v_l = a.v_rows[e]; }
+        else row_l = a.edge_row ? a.edge_row[e] : (int32_t)(e / a.edges_per_row);
         c1_l = a.c1 ? a.c1[e] : 1.f;
         c2_l = a.c2 ? a.c2[e] : 0.f;
     }
@@ -80,7 +93,7 @@ __global__ __launch_bounds__(256) void scatter_runs_kernel(ScArgs a)
     const int32_t next_key = p0 + cnt < a.E ? a.key[p0 + cnt] : -1;
     float vv[MAXC];
 #pragma unroll
-    for (int c = 0; c < MAXC; ++c) vv[c] = (a.v && lane + 64 * c < D) ? a.v[lane + 64 * c] : 0.f;
+    for (int c = 0; c < MAXC; ++c) vv[c] = (!MULTI && a.v && lane + 64 * c < D) ? a.v[lane + 64 * c] : 0.f;
     float acc[MAXC];
 #pragma unroll
     for (int c = 0; c < MAXC; ++c) acc[c] = 0.f;
@@ -89,7 +102,7 @@ __global__ __launch_bounds__(256) void scatter_runs_kernel(ScArgs a)
     // column -- the stable sort keeps the entries of one source row adjacent inside a segment, so "same row as
     // the previous entry of this key" identifies the repeats (also across the run boundary)
     int64_t last_row = -1;
-    if (a.arg && p0 > 0 && prev_key == cur) {
+    if (!MULTI && a.arg && p0 > 0 && prev_key == cur) {
         const int64_t pe = a.order[p0 - 1];
         last_row = a.edge_row ? a.edge_row[pe] : pe / a.edges_per_row;
     }
@@ -132,8 +145,24 @@ __global__ __launch_bounds__(256) void scatter_runs_kernel(ScArgs a)
     // cache round trips per wavefront (0.27 ms for the benchmark's 2.1 M border edges).
     for (int j0 = 0; j0 < cnt; j0 += AHEAD) {
         float g[AHEAD][MAXC];
+        float wv[MULTI ? AHEAD : 1][MAXC];
         int32_t am[AHEAD][MAXC];
         // (keys ascend: the PAD edges -- masked or zero-weight ones -- fill whole runs at the front; no rows are read for them)
+        if (MULTI) {
+            if (__builtin_amdgcn_readlane(k_l, (j0 + AHEAD - 1) < cnt ? (j0 + AHEAD - 1) : cnt - 1) != 0) {
+#pragma unroll
+                for (int u = 0; u < AHEAD; ++u) {
+                    const float* sp = reinterpret_cast<const float*>(sc_readlane64(src_l, (j0 + u) & 63));   // lanes past cnt hold 0
+                    const float* vp = reinterpret_cast<const float*>(sc_readlane64(v_l, (j0 + u) & 63));
+#pragma unroll
+                    for (int c = 0; c < MAXC; ++c) {
+                        const int64_t d = lane + 64 * c;
+                        g[u][c] = (sp && d < D) ? sp[d] : 0.f;
+                        wv[u][c] = (vp && d < D) ? vp[d] : 0.f;
+                    }
+                }
+            }
+        } else
         if (a.G && __builtin_amdgcn_readlane(k_l, (j0 + AHEAD - 1) < cnt ? (j0 + AHEAD - 1) : cnt - 1) != 0) {
 #pragma unroll
             for (int u = 0; u < AHEAD; ++u) {
@@ -154,18 +183,22 @@ __global__ __launch_bounds__(256) void scatter_runs_kernel(ScArgs a)
             if (k != cur) { flush(cur, false); cur = k; last_row = -1; }
             if (k == 0) continue;
             const int64_t row = __builtin_amdgcn_readlane(row_l, j);
-            if (a.arg) { if (row == last_row) continue; last_row = row; }
+            if (!MULTI && a.arg) { if (row == last_row) continue; last_row = row; }
             const float c1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c1_l), j));
             const float c2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c2_l), j));
 #pragma unroll
             for (int c = 0; c < MAXC; ++c) {
                 if (lane + 64 * c < D) {
-                    float val = c2 * vv[c];
-                    if (a.G) {
-                        if (a.arg) { if (am[u][c] == k) val += c1 * g[u][c]; }
-                        else val += c1 * g[u][c];
+                    if (MULTI) {
+                        acc[c] += c2 * wv[u][c] + c1 * g[u][c];
+                    } else {
+                        float val = c2 * vv[c];
+                        if (a.G) {
+                            if (a.arg) { if (am[u][c] == k) val += c1 * g[u][c]; }
+                            else val += c1 * g[u][c];
+                        }
+                        acc[c] += val;
                     }
-                    acc[c] += val;
                 }
             }
         }
@@ -318,6 +351,7 @@ extern "C" int sgnn_scatter_add_rows_sorted(const int32_t* order, const int32_t*
     ScArgs a;
     a.order = order; a.key = key_sorted; a.E = n_edges; a.edge_row = edge_row; a.edges_per_row = edges_per_row;
     a.G = G; a.D = D; a.c1 = c1; a.c2 = c2; a.v = v; a.arg = arg; a.table = table;
+    a.src_rows = nullptr; a.v_rows = nullptr;
     a.carry_val = (float*)workspace;
     a.carry_key = (int32_t*)(a.carry_val + n_runs * 2 * D);
     a.carry_flag = a.carry_key + n_runs * 2;
@@ -334,6 +368,129 @@ extern "C" int sgnn_scatter_add_rows_sorted(const int32_t* order, const int32_t*
     else if (D <= 64) hipLaunchKernelGGL((scatter_runs_kernel<16, 1>), dim3(grid), dim3(256), 0, st, a);   // (+ the argmax ids: 2 registers per row)
     else if (D <= 128) hipLaunchKernelGGL((scatter_runs_kernel<16, 2>), dim3(grid), dim3(256), 0, st, a);
     else hipLaunchKernelGGL((scatter_runs_kernel<8, 4>), dim3(grid), dim3(256), 0, st, a);
+    SGNN_CHECK_LAUNCH();
+    hipLaunchKernelGGL(scatter_chains_kernel, dim3(grid), dim3(256), 0, st, a, n_runs);
+    SGNN_CHECK_LAUNCH();
+    return SGNN_OK;
+}
+
+// ---- several scatters into one table as ONE sorted list ---------------------------------------------------------------------
+// A batch-sized training step scatters 6-18 short edge lists (1-30 k edges each: one per layer body, the component embeddings,
+// the shared anchors' lookups) into the same table gradient: 6-18 sorts + 12-36 scatter launches, each a few microseconds of
+// work behind 4-13 us of launch and sort latency.  Here the lists are concatenated (one pack launch writes, per edge, its key,
+// the ADDRESS of its source row and of its v, and its two coefficients), sorted once and scattered once.  Each table row still
+// has one writer and a fixed order of addition (by list, then by position in the list: the sort is stable).
+#define SC_MAX_JOBS 40
+struct ScPackJob {
+    const int32_t* keys; const int32_t* edge_row; const float* G; const float* c1; const float* c2; const float* v;
+    long long edges_per_row, n, off;
+    int blk;
+};
+struct ScPack { ScPackJob j[SC_MAX_JOBS]; int blk_end; int count; };
+
+__global__ __launch_bounds__(256) void scatter_pack_kernel(const ScPack P, int64_t D, int32_t* __restrict__ key_all,
+                                                           unsigned long long* __restrict__ src_rows,
+                                                           unsigned long long* __restrict__ v_rows, float* __restrict__ c1_all,
+                                                           float* __restrict__ c2_all)
+{
+    const int b = blockIdx.x;
+    int lo = 0, hi = P.count - 1;                    // the block's list: largest t with blk[t] <= b
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (P.j[mid].blk <= b) lo = mid; else hi = mid - 1; }
+    const ScPackJob& J = P.j[lo];
+    const int64_t i = (int64_t)(b - J.blk) * 256 + threadIdx.x;
+    if (i >= J.n) return;
+    const int64_t e = J.off + i;
+    const int64_t row = J.edge_row ? J.edge_row[i] : i / J.edges_per_row;
+    key_all[e] = J.keys[i];
+    src_rows[e] = J.G ? (unsigned long long)(uintptr_t)(J.G + row * D) : 0ull;
+    const float c2 = J.c2 ? J.c2[i] : 0.f;
+    v_rows[e] = (J.v && J.c2) ? (unsigned long long)(uintptr_t)J.v : 0ull;
+    c1_all[e] = J.c1 ? J.c1[i] : 1.f;
+    c2_all[e] = c2;
+}
+
+static inline int64_t sc_align(int64_t x) { return (x + 255) & ~255ll; }
+
+extern "C" int64_t sgnn_scatter_add_rows_multi_workspace_bytes(int64_t total_edges, int64_t D, int64_t max_key)
+{
+    if (total_edges <= 0) return 0;
+    // keys, sorted keys, order (4 B each), source / v addresses (8 B each), two coefficients (4 B each), the sort's and the scatter's own
+    return sc_align(total_edges * 4) * 5 + sc_align(total_edges * 8) * 2 + sc_align(sgnn_sort_edges_by_key_workspace_bytes(total_edges, max_key))
+           + sc_align(sgnn_scatter_add_rows_workspace_bytes(total_edges, D)) + 256;
+}
+
+extern "C" int sgnn_scatter_add_rows_multi(int64_t n_lists, const int32_t* const* keys, const int64_t* n_edges,
+                                           const int32_t* const* edge_row, const int64_t* edges_per_row, const float* const* G,
+                                           const float* const* c1, const float* const* c2, const float* const* v, int64_t D,
+                                           int64_t max_key, float* table, void* workspace, int64_t workspace_bytes, void* stream)
+{
+    if (n_lists < 0 || D <= 0 || !table || (n_lists && (!keys || !n_edges || !edge_row || !edges_per_row || !G || !c1 || !c2 || !v)))
+        return SGNN_ERR_BAD_ARG;
+    if (D > 64 * SC_MAXC) return SGNN_ERR_UNSUPPORTED_D;
+    int64_t total = 0;
+    for (int64_t k = 0; k < n_lists; ++k) {
+        if (n_edges[k] < 0 || (n_edges[k] && !keys[k]) || (!G[k] && !c2[k]) || (c2[k] && !v[k]) || (!edge_row[k] && edges_per_row[k] < 1))
+            return SGNN_ERR_BAD_ARG;
+        total += n_edges[k];
+    }
+    if (total >= (1ll << 31)) return SGNN_ERR_SET_TOO_LARGE;
+    if (total == 0) return SGNN_OK;
+    if (!workspace || workspace_bytes < sgnn_scatter_add_rows_multi_workspace_bytes(total, D, max_key)) return SGNN_ERR_BAD_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    char* w = (char*)workspace;
+    int32_t* key_all = (int32_t*)w; w += sc_align(total * 4);
+    int32_t* key_sorted = (int32_t*)w; w += sc_align(total * 4);
+    int32_t* order = (int32_t*)w; w += sc_align(total * 4);
+    float* c1_all = (float*)w; w += sc_align(total * 4);
+    float* c2_all = (float*)w; w += sc_align(total * 4);
+    unsigned long long* src_rows = (unsigned long long*)w; w += sc_align(total * 8);
+    unsigned long long* v_rows = (unsigned long long*)w; w += sc_align(total * 8);
+    void* sort_ws = w;
+    const int64_t sort_bytes = sc_align(sgnn_sort_edges_by_key_workspace_bytes(total, max_key));
+    w += sort_bytes;
+    void* scatter_ws = w;
+    // 1. pack
+    int64_t off = 0;
+    for (int64_t from = 0; from < n_lists; from += SC_MAX_JOBS) {
+        const int64_t to = from + SC_MAX_JOBS < n_lists ? from + SC_MAX_JOBS : n_lists;
+        ScPack P;
+        int blocks = 0;
+        P.count = 0;
+        for (int64_t k = from; k < to; ++k) {
+            if (n_edges[k] == 0) continue;
+            ScPackJob& J = P.j[P.count++];
+            J.keys = keys[k]; J.edge_row = edge_row[k]; J.G = G[k]; J.c1 = c1[k]; J.c2 = c2[k]; J.v = v[k];
+            J.edges_per_row = edges_per_row[k]; J.n = n_edges[k]; J.off = off; J.blk = blocks;
+            blocks += (int)((n_edges[k] + 255) / 256);
+            off += n_edges[k];
+        }
+        P.blk_end = blocks;
+        if (!P.count) continue;
+        hipLaunchKernelGGL(scatter_pack_kernel, dim3(blocks), dim3(256), 0, st, P, D, key_all, src_rows, v_rows, c1_all, c2_all);
+        SGNN_CHECK_LAUNCH();
+    }
+    // 2. one stable sort of all keys
+    int rc = sgnn_sort_edges_by_key(key_all, total, max_key, key_sorted, order, sort_ws, sort_bytes, stream);
+    if (rc != SGNN_OK) return rc;
+    // 3. one scatter
+    const int run_len = sc_run_len(total);
+    const int64_t n_runs = (total + run_len - 1) / run_len;
+    ScArgs a;
+    a.order = order; a.key = key_sorted; a.E = total; a.edge_row = nullptr; a.edges_per_row = 1;
+    a.G = nullptr; a.D = D; a.c1 = c1_all; a.c2 = c2_all; a.v = nullptr; a.arg = nullptr; a.table = table;
+    a.src_rows = src_rows; a.v_rows = v_rows;
+    a.carry_val = (float*)scatter_ws;
+    a.carry_key = (int32_t*)(a.carry_val + n_runs * 2 * D);
+    a.carry_flag = a.carry_key + n_runs * 2;
+    const unsigned grid = (unsigned)((n_runs + 3) / 4);
+    if (run_len == SC_RUN_SMALL) {
+        if (D <= 64) hipLaunchKernelGGL((scatter_runs_kernel<SC_RUN_SMALL, 1, SC_RUN_SMALL, true>), dim3(grid), dim3(256), 0, st, a);
+        else if (D <= 128) hipLaunchKernelGGL((scatter_runs_kernel<SC_RUN_SMALL, 2, SC_RUN_SMALL, true>), dim3(grid), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((scatter_runs_kernel<8, 4, SC_RUN_SMALL, true>), dim3(grid), dim3(256), 0, st, a);
+    }
+    else if (D <= 64) hipLaunchKernelGGL((scatter_runs_kernel<16, 1, SC_RUN, true>), dim3(grid), dim3(256), 0, st, a);
+    else if (D <= 128) hipLaunchKernelGGL((scatter_runs_kernel<16, 2, SC_RUN, true>), dim3(grid), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((scatter_runs_kernel<8, 4, SC_RUN, true>), dim3(grid), dim3(256), 0, st, a);
     SGNN_CHECK_LAUNCH();
     hipLaunchKernelGGL(scatter_chains_kernel, dim3(grid), dim3(256), 0, st, a, n_runs);
     SGNN_CHECK_LAUNCH();

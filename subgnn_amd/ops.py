@@ -928,12 +928,17 @@ def sort_edges_by_key(keys, max_key):
     return sk, order
 
 
+SCATTER_TOGETHER_BELOW = 1 << 16       # edges: shorter lists into a tapped table wait for the step's other lists (one sort, one scatter)
+
+
 def scatter_add_rows(table, keys, G=None, edge_row=None, edges_per_row=1, c1=None, c2=None, v=None, arg=None,
-                     presorted=None):
+                     presorted=None, together=None):
     """table[keys[e], :] += c1[e] * G[row(e), :] + c2[e] * v   without atomics (sgnn_scatter_add_rows_sorted):
     the edges are sorted stably by target row and every row is summed by one owner in that order, so the
     result is bit-reproducible.  keys int32 (E), 0 = no contribution; row(e) = edge_row[e] or e // edges_per_row.
-    presorted: sort_edges_by_key(keys, ...) of these very keys, when the caller keeps it."""
+    presorted: sort_edges_by_key(keys, ...) of these very keys, when the caller keeps it.
+    together: the _GradAcc whose buffer ``table`` is -- a short list without a kept order then only joins the accumulator's
+    pending lists, which are sorted and scattered as ONE list when the table's gradient is handed over (_GradAcc.flush)."""
     lib = _lib.load()
     E = keys.numel()
     if E == 0:
@@ -945,6 +950,10 @@ def scatter_add_rows(table, keys, G=None, edge_row=None, edges_per_row=1, c1=Non
     _req(edge_row, torch.int32, 'edge_row')
     _req(arg, torch.int32, 'arg')
     D = table.shape[1]
+    if together is not None and presorted is None and arg is None and E < SCATTER_TOGETHER_BELOW and D <= 256 \
+            and (G is None or (G.dim() == 2 and G.shape[1] == D and G.is_contiguous())):
+        together.jobs.append((keys.reshape(-1), G, edge_row, int(edges_per_row), c1, c2, v))
+        return table
     sk, order = presorted if presorted is not None else sort_edges_by_key(keys.reshape(-1), table.shape[0] - 1)
     if sk.numel() != E or order.numel() != E:
         raise ValueError('presorted order does not belong to these keys')
@@ -966,11 +975,40 @@ class _GradAcc:
     def __init__(self, owner=None):
         self.buf = None
         self.owner = owner         # the parameter whose gradient this is (it may hold a buffer an optimizer zeroed)
+        self.jobs = []             # short edge lists waiting to be scattered together (scatter_add_rows(together=))
 
     def buffer(self, shape, device):
         if self.buf is None:
             self.buf = take_zeroed(self.owner, shape, device)
         return self.buf
+
+    def flush(self):
+        """Scatter the pending lists into the buffer as one sorted list (sgnn_scatter_add_rows_multi)."""
+        jobs, self.jobs = self.jobs, []
+        if not jobs:
+            return
+        if self.owner is None:
+            raise RuntimeError('pending table-gradient lists without a table')
+        table = self.buffer(tuple(self.owner.shape), jobs[0][0].device)
+        if len(jobs) == 1:                               # nothing to share a sort with
+            keys, G, edge_row, epr, c1, c2, v = jobs[0]
+            scatter_add_rows(table, keys, G=G, edge_row=edge_row, edges_per_row=epr, c1=c1, c2=c2, v=v)
+            return
+        lib = _lib.load()
+        n = len(jobs)
+        D = table.shape[1]
+
+        def ptrs(k):
+            return np.array([0 if j[k] is None else j[k].data_ptr() for j in jobs], dtype=np.uint64)
+        keys_p, G_p, row_p, c1_p, c2_p, v_p = ptrs(0), ptrs(1), ptrs(2), ptrs(4), ptrs(5), ptrs(6)
+        n_edges = np.array([j[0].numel() for j in jobs], dtype=np.int64)
+        epr = np.array([j[3] for j in jobs], dtype=np.int64)
+        total, max_key = int(n_edges.sum()), table.shape[0] - 1
+        wsb = lib.sgnn_scatter_add_rows_multi_workspace_bytes(total, D, max_key)
+        ws = torch.empty(wsb // 8 + 1, dtype=torch.int64, device=table.device)
+        check(lib.sgnn_scatter_add_rows_multi(n, keys_p.ctypes.data, n_edges.ctypes.data, row_p.ctypes.data, epr.ctypes.data,
+                                              G_p.ctypes.data, c1_p.ctypes.data, c2_p.ctypes.data, v_p.ctypes.data, D, max_key,
+                                              _ptr(table), _ptr(ws), wsb, _stream()), 'sgnn_scatter_add_rows_multi')
 
 
 def take_zeroed(owner, shape, device):
@@ -1007,6 +1045,7 @@ class _TableTap(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
+        ctx.acc.flush()                                  # the short lists that waited for each other: one sort, one scatter
         buf, ctx.acc.buf = ctx.acc.buf, None
         if buf is None:
             return g, None
@@ -1071,12 +1110,12 @@ class _CCEmbed(torch.autograd.Function):
             E = nodes.numel()
             am = arg if ctx.aggregator == 1 else None
             if ctx.stride > 0:                         # fixed-stride sets: row = entry // stride
-                scatter_add_rows(gE, nodes, G=g, edges_per_row=ctx.stride, arg=am, presorted=ctx.presorted)
+                scatter_add_rows(gE, nodes, G=g, edges_per_row=ctx.stride, arg=am, presorted=ctx.presorted, together=ctx.acc)
             else:                                      # ragged (the node array may be an arena longer than ptr[-1])
                 pos = torch.arange(E, device=g.device)
                 rows = (torch.searchsorted(ptr, pos, right=True) - 1).clamp_(min=0, max=max(n - 1, 0)).to(torch.int32)
                 keys = torch.where(pos < ptr[-1], nodes, torch.zeros_like(nodes))
-                scatter_add_rows(gE, keys.contiguous(), G=g, edge_row=rows.contiguous(), arg=am)
+                scatter_add_rows(gE, keys.contiguous(), G=g, edge_row=rows.contiguous(), arg=am, together=ctx.acc)
         else:
             check(lib.sgnn_cc_embed_bwd(_ptr(g), ctx.shape[1], _ptr(ptr), _ptr(nodes), ptr.numel() - 1, ctx.aggregator,
                                         _ptr(arg), _ptr(gE), _stream()), 'sgnn_cc_embed_bwd')
@@ -1194,14 +1233,14 @@ class _MPN(torch.autograd.Function):
                 # the static half of the edge list (target rows, weights, sorted order) came with the prepared pass
                 c2 = (plan['c1'] * g_z.reshape(-1)) if g_z is not None else None
                 scatter_add_rows(gx, plan['keys'], G=g_agg, edges_per_row=A, c1=plan['c1'], c2=c2, v=wp if c2 is not None else None,
-                                 presorted=plan['sorted'])
+                                 presorted=plan['sorted'], together=ctx.acc)
             elif need_x and (g_agg is not None or g_z is not None):
                 keys = torch.empty(R * A, dtype=torch.int32, device=x.device)
                 c1 = torch.empty(R * A, dtype=torch.float32, device=x.device)
                 c2 = torch.empty(R * A, dtype=torch.float32, device=x.device) if g_z is not None else None
                 check(lib.sgnn_mpn_bwd_edges(ctypes.byref(a), _ptr(g_z), _ptr(keys), _ptr(c1), _ptr(c2), _stream()),
                       'sgnn_mpn_bwd_edges')
-                scatter_add_rows(gx, keys, G=g_agg, edges_per_row=A, c1=c1, c2=c2, v=wp if c2 is not None else None)
+                scatter_add_rows(gx, keys, G=g_agg, edges_per_row=A, c1=c1, c2=c2, v=wp if c2 is not None else None, together=ctx.acc)
             if need_wp and g_z is not None:
                 ld = D + 1 if need_bp else D            # (column D: the row's share of the read-out bias's gradient)
                 partial = torch.empty((R, ld), dtype=torch.float32, device=x.device)
@@ -1827,9 +1866,9 @@ class _GatherRows(torch.autograd.Function):
                 torch.zeros(ctx.n_rows, g.shape[1], dtype=torch.float32, device=grad.device)
             pre = ctx.presorted
             if pre is not None and pre[0].numel() == flat.numel():
-                scatter_add_rows(buf, pre[2], G=g, edges_per_row=1, presorted=pre[:2])
+                scatter_add_rows(buf, pre[2], G=g, edges_per_row=1, presorted=pre[:2], together=ctx.acc)
             else:
-                scatter_add_rows(buf, flat.to(torch.int32).contiguous(), G=g, edges_per_row=1)      # key 0 = PAD: skipped
+                scatter_add_rows(buf, flat.to(torch.int32).contiguous(), G=g, edges_per_row=1, together=ctx.acc)      # key 0 = PAD: skipped
             return (None if ctx.acc is not None else buf.to(grad.dtype)), None, None
         g = grad.reshape(flat.numel(), -1) * (flat != 0).unsqueeze(1).to(grad.dtype)     # PAD row takes no gradient
         if ctx.acc is not None:
