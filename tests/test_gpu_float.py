@@ -794,6 +794,62 @@ def test_scatter_add_rows_sorted_matches_index_add_and_is_reproducible(D):
     assert_close(table, want2.float(), 'scatter (rows)', norm_tol=1e-5)
 
 
+@pytest.mark.parametrize('D,n_lists', [(32, 3), (64, 7), (128, 45), (200, 4)])
+def test_scatter_lists_together_equal_one_after_the_other(D, n_lists):
+    """sgnn_scatter_add_rows_multi (ops._GradAcc.flush: the short lists of a step packed, sorted once, scattered once) against
+    the same lists scattered one after the other and against a float64 index_add: lists with and without source rows, with
+    explicit rows and rows by division, with and without the two coefficient terms, PAD keys, a hub target shared by every
+    list; 45 lists span two pack launches.  Two runs give the same bits."""
+    from subgnn_amd import ops
+    g = torch.Generator().manual_seed(D + n_lists)
+    n_rows = 3000
+    table_owner = torch.nn.Parameter(torch.zeros(n_rows, D, device=DEV))
+    want = torch.zeros(n_rows, D, dtype=torch.float64)
+    jobs = []
+    for k in range(n_lists):
+        R, A = int(torch.randint(1, 60, (1,), generator=g)), int(torch.randint(1, 40, (1,), generator=g))
+        E = R * A
+        keys = torch.randint(0, n_rows, (E,), generator=g)
+        keys[torch.rand(E, generator=g) < 0.2] = 11                                  # a hub every list adds to
+        keys[torch.rand(E, generator=g) < 0.1] = 0                                   # PAD
+        kind = k % 4
+        G = torch.randn(R, D, generator=g) if kind != 3 else None                    # kind 3: only the c2 * v term
+        rows = torch.randint(0, R, (E,), generator=g) if kind == 1 else torch.arange(E) // A
+        c1 = torch.randn(E, generator=g) if kind in (0, 2) else None
+        c2 = torch.randn(E, generator=g) if kind in (2, 3) else None
+        v = torch.randn(D, generator=g) if c2 is not None else None
+        contrib = torch.zeros(E, D, dtype=torch.float64)
+        if G is not None:
+            contrib += (c1.double().unsqueeze(1) if c1 is not None else 1.0) * G.double()[rows]
+        if c2 is not None:
+            contrib += c2.double().unsqueeze(1) * v.double()
+        contrib[keys == 0] = 0
+        want.index_add_(0, keys, contrib)
+        d = lambda t: None if t is None else t.to(DEV)
+        jobs.append(dict(keys=d(keys.to(torch.int32)), G=d(G), edge_row=d(rows.to(torch.int32)) if kind == 1 else None,
+                         edges_per_row=A, c1=d(c1), c2=d(c2), v=d(v)))
+    want[0] = 0
+    outs = []
+    for _ in range(2):
+        acc = ops._GradAcc(table_owner)
+        buf = acc.buffer((n_rows, D), torch.device(DEV))
+        buf.zero_()
+        for j in jobs:
+            ops.scatter_add_rows(buf, j['keys'], G=j['G'], edge_row=j['edge_row'], edges_per_row=j['edges_per_row'], c1=j['c1'],
+                                 c2=j['c2'], v=j['v'], together=acc)
+        assert len(acc.jobs) == n_lists and float(buf.abs().max()) == 0.0            # nothing has been added yet
+        acc.flush()
+        assert not acc.jobs
+        outs.append(buf.clone())
+    assert torch.equal(outs[0], outs[1])
+    one_by_one = torch.zeros(n_rows, D, device=DEV)
+    for j in jobs:
+        ops.scatter_add_rows(one_by_one, j['keys'], G=j['G'], edge_row=j['edge_row'], edges_per_row=j['edges_per_row'], c1=j['c1'],
+                             c2=j['c2'], v=j['v'])
+    assert_close(outs[0], want.float(), 'lists together vs float64', norm_tol=1e-5)
+    assert_close(outs[0], one_by_one, 'lists together vs one after the other', norm_tol=1e-5)
+
+
 @pytest.mark.parametrize('n,max_key', [(1, 5), (2, 3), (3, 1 << 30), (63, 1), (1000, 999), (4096, 1_000_000), (4097, 1_000_000), (5000, (1 << 31) - 1),
                                        (8191, 17_000), (8192, 1_000_000), (8193, 57_000), (300_000, 1_000_000), (70_000, (1 << 31) - 1)])
 def test_sort_edges_by_key_is_a_stable_sort(n, max_key):
