@@ -379,12 +379,19 @@ __global__ __launch_bounds__(256) void mpn_bwd_wp_partial_kernel(sgnn_mpn_args a
     // ld == D + 1: column D of a row is the sum of the row's (gated) read-out gradients -- grad_bp's per-row partial: the
     // read-out bias reaches EVERY entry (masked edges and padded rows read out bp itself)
     const int64_t D = a.D, total = a.R * ld;
+    // work items [0, R D): the weight partials; [R D, R ld): one per row for the bias column -- kept apart from the others so that
+    // only the last wavefronts run that branch (interleaved as column D of each row it doubled the launch's time)
     for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t r = t / ld, d = t % ld;
+        if (t >= a.R * D) {
+            const int64_t r = t - a.R * D;
+            float gb = 0.f;
+            for (int64_t ai = 0; ai < a.A; ++ai) gb += mpn_gz(a, grad_z, r * a.A + ai);
+            partial[r * ld + D] = gb;
+            continue;
+        }
+        const int64_t r = t / D, d = t % D;
         float gw = 0.f;
-        if (d == D) {
-            for (int64_t ai = 0; ai < a.A; ++ai) gw += mpn_gz(a, grad_z, r * a.A + ai);
-        } else if (!a.row_mask || a.row_mask[r]) {
+        if (!a.row_mask || a.row_mask[r]) {
             const int64_t idrow = (a.id_div > 1 ? r / a.id_div : r) * a.A;
             for (int64_t ai = 0; ai < a.A; ++ai) {
                 const int64_t id = a.ids[idrow + ai];
@@ -397,7 +404,7 @@ __global__ __launch_bounds__(256) void mpn_bwd_wp_partial_kernel(sgnn_mpn_args a
                 gw += gz * w * (a.x_f16 ? __half2float(reinterpret_cast<const __half*>(a.x)[id * D + d]) : a.x[id * D + d]);
             }
         }
-        partial[t] = gw;
+        partial[r * ld + d] = gw;
     }
 }
 
