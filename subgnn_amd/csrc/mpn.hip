@@ -28,6 +28,7 @@ __device__ static inline float group_sum(float v, int lanes) {
     return v;
 }
 
+#define MPN_U 4
 // T: element type of the GATHER table (float, or __half for an fp16-stored table; fp32 accumulate)
 template <int SRC, typename T = float>
 __global__ __launch_bounds__(256) void mpn_fwd_kernel(sgnn_mpn_args a, float* __restrict__ agg, float* __restrict__ z,
@@ -50,32 +51,63 @@ __global__ __launch_bounds__(256) void mpn_fwd_kernel(sgnn_mpn_args a, float* __
         const float4 wp = reinterpret_cast<const float4*>(a.wp)[dv];
         const int64_t idrow = (a.id_div > 1 ? r / a.id_div : r) * a.A;
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int64_t ai = a0; ai < a1; ++ai) {
-            int64_t id = 1;
-            bool edge;
-            if (SRC == SGNN_SRC_DENSE) {
-                edge = a.edge_mask[r * a.A + ai] != 0;
-                if (a.ids) id = a.ids[idrow + ai];
-            } else if (SRC == SGNN_SRC_GATHER) {
-                id = a.ids[idrow + ai];
-                edge = (id != 0) && row_real;
-            } else {
-                if (a.ids) id = a.ids[ai];
-                edge = row_real && (id != 0);
+        // MPN_U anchors at a time: their ids, then their weights, then their rows are requested together and only then consumed --
+        // one anchor after the other (id -> weight -> row -> the read-out's store) a batch-sized call was a chain of 3 A dependent
+        // round trips per lane (the stores to z keep the compiler from hoisting the next anchor's loads itself)
+        for (int64_t ai0 = a0; ai0 < a1; ai0 += MPN_U) {
+            int64_t id[MPN_U];
+            bool edge[MPN_U];
+            float w[MPN_U];
+            float4 x[MPN_U];
+#pragma unroll
+            for (int u = 0; u < MPN_U; ++u) {
+                const int64_t ai = ai0 + u;
+                id[u] = 1;
+                edge[u] = false;
+                if (ai < a1) {
+                    if (SRC == SGNN_SRC_DENSE) {
+                        edge[u] = a.edge_mask[r * a.A + ai] != 0;
+                        if (a.ids) id[u] = a.ids[idrow + ai];
+                    } else if (SRC == SGNN_SRC_GATHER) {
+                        id[u] = a.ids[idrow + ai];
+                        edge[u] = (id[u] != 0) && row_real;
+                    } else {
+                        if (a.ids) id[u] = a.ids[ai];
+                        edge[u] = row_real && (id[u] != 0);
+                    }
+                }
             }
-            float zval = bp;
-            if (edge) {                                       // uniform over the row's lanes
-                const int64_t col = a.sim_col ? a.sim_col[ai] : (a.sims_per_edge ? ai : id - 1);
-                const float w = a.sims[r * a.sims_ld + col];
-                float4 x;
-                if (SRC == SGNN_SRC_DENSE) x = x4[(r * a.A + ai) * D4 + dv];
-                else if (SRC == SGNN_SRC_GATHER) x = sgnn_load4<T>(xt, id, D4, dv);
-                else x = x4[ai * D4 + dv];
-                acc.x += w * x.x; acc.y += w * x.y; acc.z += w * x.z; acc.w += w * x.w;
-                const float dot = group_sum(wp.x * x.x + wp.y * x.y + wp.z * x.z + wp.w * x.w, lanes);
-                zval = w * dot + bp;
+#pragma unroll
+            for (int u = 0; u < MPN_U; ++u) {
+                w[u] = 0.f;
+                if (edge[u]) {                                    // uniform over the row's lanes
+                    const int64_t ai = ai0 + u;
+                    const int64_t col = a.sim_col ? a.sim_col[ai] : (a.sims_per_edge ? ai : id[u] - 1);
+                    w[u] = a.sims[r * a.sims_ld + col];
+                }
             }
-            if (dv == 0 && z) z[r * a.A + ai] = relu_z ? fmaxf(zval, 0.f) : zval;
+#pragma unroll
+            for (int u = 0; u < MPN_U; ++u) {
+                x[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (edge[u]) {
+                    const int64_t ai = ai0 + u;
+                    if (SRC == SGNN_SRC_DENSE) x[u] = x4[(r * a.A + ai) * D4 + dv];
+                    else if (SRC == SGNN_SRC_GATHER) x[u] = sgnn_load4<T>(xt, id[u], D4, dv);
+                    else x[u] = x4[ai * D4 + dv];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < MPN_U; ++u) {
+                const int64_t ai = ai0 + u;
+                if (ai >= a1) break;
+                float zval = bp;
+                if (edge[u]) {
+                    acc.x += w[u] * x[u].x; acc.y += w[u] * x[u].y; acc.z += w[u] * x[u].z; acc.w += w[u] * x[u].w;
+                    const float dot = group_sum(wp.x * x[u].x + wp.y * x[u].y + wp.z * x[u].z + wp.w * x[u].w, lanes);
+                    zval = w[u] * dot + bp;
+                }
+                if (dv == 0 && z) z[r * a.A + ai] = relu_z ? fmaxf(zval, 0.f) : zval;
+            }
         }
         // anchor chunks of one row: each writes its partial aggregate to its own (R, D) slice, the caller adds them up
         reinterpret_cast<float4*>(agg)[(int64_t)blockIdx.y * total + t] = acc;

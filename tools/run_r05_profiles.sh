@@ -18,5 +18,6 @@ python -c "
 import os
 from subgnn_amd import build
 os.utime(os.path.join(build.CSRC,'dtw.hip')); build.build(verbose=False)" > /dev/null 2>&1
-for c in ppi_bp hpo_metab; do python tools/step_kernels.py --config $c --out gpurun_out/r05_step_kernels_$c.txt > /dev/null 2>&1; tail -1 gpurun_out/r05_step_kernels_$c.txt; done
+for c in density_n ppi_bp hpo_metab; do python tools/step_kernels.py --config $c --out gpurun_out/r05_step_kernels_$c.txt > /dev/null 2>&1; tail -1 gpurun_out/r05_step_kernels_$c.txt; done
+bash tools/run_r05u.sh > /dev/null 2>&1
 ls gpurun_out | grep "^r05_" | wc -l
