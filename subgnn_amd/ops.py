@@ -1517,6 +1517,15 @@ class OptimTail:
         k = len(which)
         if k == 0:
             return None
+        # (a parameter whose storage was replaced since construction -- ``p.data = ...`` -- must not be updated at its old address)
+        now = np.fromiter((p.data_ptr() for p in self.params), dtype=np.uint64, count=self.n)
+        if not np.array_equal(now, self.p_ptr):
+            moved = [i for i in range(self.n) if now[i] != self.p_ptr[i]]
+            for i in moved:
+                _req(self.params[i], torch.float32, 'parameter')
+                if self.params[i].numel() != int(self.numels[i]):
+                    raise ValueError('parameter %d changed its size under the optimizer' % i)
+            self.p_ptr = now
         for p_i, g in zip(which, grads):
             _req(g, torch.float32, 'gradient')
             if g.numel() != int(self.numels[p_i]):

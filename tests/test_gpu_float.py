@@ -714,6 +714,29 @@ def test_clip_adam_skips_untouched_table_rows_bit_exactly(D):
     assert torch.equal(models[0][0][~touched.to(DEV)].cpu(), init[0][~touched])    # untouched rows: the initial bits
 
 
+def test_clip_adam_follows_a_parameter_whose_storage_was_replaced():
+    """``p.data = other_tensor`` between two steps (a reloaded checkpoint assigned rather than copied): the next step updates the
+    parameter where it lives now."""
+    from subgnn_amd import optim
+    g = torch.Generator().manual_seed(5)
+    init = [torch.randn(300, 64, generator=g), torch.randn(64, 9, generator=g)]
+    ref = [torch.nn.Parameter(t.clone().to(DEV)) for t in init]
+    got = [torch.nn.Parameter(t.clone().to(DEV)) for t in init]
+    o_ref, o_got = torch.optim.Adam(ref, lr=0.01), optim.ClipAdam(got, lr=0.01, max_norm=0.5, big_bytes=300 * 64 * 4)
+    for it in range(3):
+        if it == 1:
+            for p in got:
+                p.data = p.data.clone()                       # new storage, same values
+        grads = [torch.randn(*t.shape, generator=g).to(DEV) for t in init]
+        for ps in (ref, got):
+            for p, gr in zip(ps, grads):
+                p.grad = gr.clone()
+        torch.nn.utils.clip_grad_norm_(ref, 0.5)
+        o_ref.step(); o_got.step()
+        for a, b in zip(got, ref):
+            assert_close(a.detach(), b.detach(), 'step %d' % it, norm_tol=2e-6)
+
+
 def test_clip_adam_fused_tail_replays_from_a_hipgraph():
     """The tail recorded into a hipGraph (device step counts) and replayed five times == five eager steps of torch's."""
     from subgnn_amd import optim
