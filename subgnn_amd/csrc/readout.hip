@@ -43,18 +43,26 @@ __global__ __launch_bounds__(256) void readout_sum_fwd_kernel(const float* __res
         col[j] = sim_col ? sim_col[a[j]] : a[j];
         acc[j] = 0.f;
     }
-    for (int32_t c = 0; c < C; ++c) {
-        float w[4];
-        bool live[4];
+    // four components at a time: 16 independent loads in flight (a batch of subgraphs with 7-50 components each walked them one
+    // round trip after the other: the dense similarity slab is a cache miss per element)
+    for (int32_t c0 = 0; c0 < C; c0 += 4) {
+        float w[4][4];
+        bool live[4][4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int64_t r = b[j] * C + c;
-            live[j] = b[j] >= 0 && (!row_mask || row_mask[r]);
-            w[j] = (live[j] && sims) ? sims[r * ld + col[j]] : 0.f;
+        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int64_t r = b[j] * C + c0 + u;
+                live[u][j] = b[j] >= 0 && c0 + u < C && (!row_mask || row_mask[r]);
+                w[u][j] = (live[u][j] && sims) ? sims[r * ld + col[j]] : 0.f;
+            }
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (live[j]) acc[j] += fmaxf(fmaf(w[j], sa[j], bb), 0.f);
+        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (live[u][j]) acc[j] += fmaxf(fmaf(w[u][j], sa[j], bb), 0.f);
+        }
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j)
