@@ -477,22 +477,23 @@ int sgnn_attn_scores_fwd_f16(const float* X, const float* U, const float* qW, co
  * The non-recurrent contractions are plain GEMMs over all (sequence, step) rows and stay with the
  * caller's BLAS: the input projection before the forward call, dx / dW_ih / dW_hh / db after the
  * backward call.  Gate order i, f, g, o (torch).
- *   pre_x  (B, T, 2, 4H)   x W_ih^T + b_ih + b_hh per direction (0 = forward, 1 = reverse)
- *   whh    (2, 4H, H)      weight_hh per direction
+ *   pre_x  (2, B, T, 4H)   x W_ih^T + b_ih per direction (0 = forward, 1 = reverse), direction-major: each direction's
+ *                          rows are one GEMM's contiguous output
+ *   whh_f, whh_r (4H, H)   weight_hh per direction;  bhh_f, bhh_r (4H), nullable: bias_hh per direction, added here (the
+ *                          caller needs no concatenated weights and no summed biases: five small launches per layer less)
  *   y      (B, T, 2H)      [forward h_t | reverse h_t]  (torch's output layout)
- *   gates  (B, T, 2, 4H), cell (2, B, T, H), hprev (2, B, T, H) = h_{t-1} in the direction's order:
+ *   gates  (2, B, T, 4H), cell (2, B, T, H), hprev (2, B, T, H) = h_{t-1} in the direction's order:
  *          activations kept for the backward pass
- * backward: dy (B, T, 2H) -> dgates (B, T, 2, 4H), the gradient w.r.t. pre_x.  Then, with
- * dG = dgates viewed (B T, 8H):  dx = dG [W_ih_f; W_ih_r],  d[W_ih_f; W_ih_r] = dG^T x,
- * dW_hh[d] = dgates[:, :, d, :]^T hprev[d],  db = column sums of dG.
+ * backward: dy (B, T, 2H) -> dgates (2, B, T, 4H), the gradient w.r.t. pre_x.  Then, with dG[d] = dgates[d] viewed (B T, 4H):
+ * dx = dG[0] W_ih_f + dG[1] W_ih_r,  dW_ih[d] = dG[d]^T x,  dW_hh[d] = dG[d]^T hprev[d],  db[d] = column sums of dG[d].
  * Hidden sizes 32, 64, 128 (sgnn_lstm_supported), any input size; else SGNN_ERR_UNSUPPORTED_D -- the
  * caller keeps the library LSTM for those.
  * ------------------------------------------------------------------------------------- */
 int sgnn_lstm_supported(int64_t hidden_size);
-int sgnn_lstm_fwd(const float* pre_x, const float* whh, int64_t B, int64_t T, int64_t hidden_size,
-                  float* y, float* gates, float* cell, float* hprev, void* stream);
-int sgnn_lstm_bwd(const float* whh, const float* gates, const float* cell, const float* dy, int64_t B,
-                  int64_t T, int64_t hidden_size, float* dgates, void* stream);
+int sgnn_lstm_fwd(const float* pre_x, const float* whh_f, const float* whh_r, const float* bhh_f, const float* bhh_r,
+                  int64_t B, int64_t T, int64_t hidden_size, float* y, float* gates, float* cell, float* hprev, void* stream);
+int sgnn_lstm_bwd(const float* whh_f, const float* whh_r, const float* gates, const float* cell, const float* dy,
+                  int64_t B, int64_t T, int64_t hidden_size, float* dgates, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * a16  Masked sum over the components of a subgraph (subgraph_utils.masked_sum,

@@ -40,11 +40,14 @@ __device__ __forceinline__ void lstm_lds_barrier()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
-// pre_x: (B, T, 2, 4H) projected inputs incl. bias; whh: (2, 4H, H)
-// y: (B, T, 2H); gates: (B, T, 2, 4H); cst, hprev: (2, B, T, H)
+// pre_x: (2, B, T, 4H) projected inputs (direction-major: each direction's rows are one GEMM's contiguous output) incl. b_ih;
+// whh_f / whh_r: (4H, H) each; bhh_f / bhh_r: (4H) each, nullable -- added here, so that the caller needs neither a
+// concatenation of the two directions' weights nor a sum of the two bias vectors (five small launches per layer before)
+// y: (B, T, 2H); gates: (2, B, T, 4H); cst, hprev: (2, B, T, H)
 template <int H, int BT>
 __global__ __launch_bounds__(4 * H) void lstm_fwd_kernel(
-    const float* __restrict__ pre_x, const float* __restrict__ whh, int64_t B, int64_t T,
+    const float* __restrict__ pre_x, const float* __restrict__ whh_f, const float* __restrict__ whh_r,
+    const float* __restrict__ bhh_f, const float* __restrict__ bhh_r, int64_t B, int64_t T,
     float* __restrict__ y, float* __restrict__ gates, float* __restrict__ cst, float* __restrict__ hprev)
 {
     constexpr int G = 4 * H;
@@ -55,7 +58,9 @@ __global__ __launch_bounds__(4 * H) void lstm_fwd_kernel(
     const int64_t b0 = (int64_t)blockIdx.x * BT;
     float w[H];
 #pragma unroll
-    for (int k = 0; k < H; ++k) w[k] = whh[((int64_t)d * G + j) * H + k];
+    for (int k = 0; k < H; ++k) w[k] = (d ? whh_r : whh_f)[(int64_t)j * H + k];
+    const float* __restrict__ bhh = d ? bhh_r : bhh_f;
+    const float bj = bhh ? bhh[j] : 0.f;
     float c_own[OWN];
 #pragma unroll
     for (int q = 0; q < OWN; ++q) c_own[q] = 0.f;
@@ -65,7 +70,7 @@ __global__ __launch_bounds__(4 * H) void lstm_fwd_kernel(
         const int64_t t0 = d ? T - 1 : 0;
 #pragma unroll
         for (int b = 0; b < BT; ++b) {
-            cur[b] = (b0 + b < B) ? pre_x[(((b0 + b) * T + t0) * 2 + d) * G + j] : 0.f;
+            cur[b] = (b0 + b < B) ? pre_x[(((int64_t)d * B + b0 + b) * T + t0) * G + j] + bj : 0.f;
             nxt[b] = 0.f;
         }
     }
@@ -75,7 +80,7 @@ __global__ __launch_bounds__(4 * H) void lstm_fwd_kernel(
         if (step + 1 < T) {                                 // next step's projected input, in flight during this one
             const int64_t tn = d ? t - 1 : t + 1;
 #pragma unroll
-            for (int b = 0; b < BT; ++b) nxt[b] = (b0 + b < B) ? pre_x[(((b0 + b) * T + tn) * 2 + d) * G + j] : 0.f;
+            for (int b = 0; b < BT; ++b) nxt[b] = (b0 + b < B) ? pre_x[(((int64_t)d * B + b0 + b) * T + tn) * G + j] + bj : 0.f;
         }
         for (int idx = j; idx < BT * H; idx += G) {         // h_{t-1}, kept for the caller's dW_hh
             const int b = idx / H, k = idx % H;
@@ -110,7 +115,7 @@ __global__ __launch_bounds__(4 * H) void lstm_fwd_kernel(
                 c_own[q] = c;
                 s_h[b][u] = h;
                 if (b0 + b < B) {
-                    float* gp = gates + (((b0 + b) * T + t) * 2 + d) * G;
+                    float* gp = gates + (((int64_t)d * B + b0 + b) * T + t) * G;
                     gp[u] = gi; gp[H + u] = gf; gp[2 * H + u] = gg; gp[3 * H + u] = go;
                     cst[(((int64_t)d * B + b0 + b) * T + t) * H + u] = c;
                     y[((b0 + b) * T + t) * (2 * H) + d * H + u] = h;
@@ -123,10 +128,10 @@ __global__ __launch_bounds__(4 * H) void lstm_fwd_kernel(
     }
 }
 
-// dgates: (B, T, 2, 4H) written
+// dgates: (2, B, T, 4H) written (direction-major like gates: a direction's rows are contiguous for the caller's contractions)
 template <int H, int BT>
 __global__ __launch_bounds__(4 * H) void lstm_bwd_kernel(
-    const float* __restrict__ whh, const float* __restrict__ gates, const float* __restrict__ cst,
+    const float* __restrict__ whh_f, const float* __restrict__ whh_r, const float* __restrict__ gates, const float* __restrict__ cst,
     const float* __restrict__ dy, int64_t B, int64_t T, float* __restrict__ dgates)
 {
     constexpr int G = 4 * H;
@@ -141,7 +146,7 @@ __global__ __launch_bounds__(4 * H) void lstm_bwd_kernel(
     const int kcol = j % H, part = j / H;
     float wreg[ROWS];
 #pragma unroll
-    for (int r = 0; r < ROWS; ++r) wreg[r] = whh[((int64_t)d * G + part * ROWS + r) * H + kcol];
+    for (int r = 0; r < ROWS; ++r) wreg[r] = (d ? whh_r : whh_f)[(int64_t)(part * ROWS + r) * H + kcol];
     float dc_own[OWN];
 #pragma unroll
     for (int q = 0; q < OWN; ++q) dc_own[q] = 0.f;
@@ -158,7 +163,7 @@ __global__ __launch_bounds__(4 * H) void lstm_bwd_kernel(
                 const int b = p / H, u = p % H;
                 float pi = 0.f, pf = 0.f, pg = 0.f, po = 0.f;
                 if (b0 + b < B) {
-                    const int64_t rowg = ((b0 + b) * T + t) * 2 + d;
+                    const int64_t rowg = ((int64_t)d * B + b0 + b) * T + t;
                     const float* gp = gates + rowg * G;
                     const float gi = gp[u], gf = gp[H + u], gg = gp[2 * H + u], go = gp[3 * H + u];
                     const float c = cst[(((int64_t)d * B + b0 + b) * T + t) * H + u];
@@ -206,20 +211,20 @@ __global__ __launch_bounds__(4 * H) void lstm_bwd_kernel(
 }
 
 template <int H, int BT>
-static int lstm_launch_fwd(const float* pre_x, const float* whh, int64_t B, int64_t T, float* y, float* gates,
-                           float* cst, float* hprev, hipStream_t st)
+static int lstm_launch_fwd(const float* pre_x, const float* whh_f, const float* whh_r, const float* bhh_f, const float* bhh_r,
+                           int64_t B, int64_t T, float* y, float* gates, float* cst, float* hprev, hipStream_t st)
 {
-    hipLaunchKernelGGL((lstm_fwd_kernel<H, BT>), dim3((unsigned)((B + BT - 1) / BT), 2), dim3(4 * H), 0, st, pre_x, whh,
-                       B, T, y, gates, cst, hprev);
+    hipLaunchKernelGGL((lstm_fwd_kernel<H, BT>), dim3((unsigned)((B + BT - 1) / BT), 2), dim3(4 * H), 0, st, pre_x, whh_f, whh_r,
+                       bhh_f, bhh_r, B, T, y, gates, cst, hprev);
     SGNN_CHECK_LAUNCH();
     return SGNN_OK;
 }
 
 template <int H, int BT>
-static int lstm_launch_bwd(const float* whh, const float* gates, const float* cst, const float* dy, int64_t B, int64_t T,
-                           float* dgates, hipStream_t st)
+static int lstm_launch_bwd(const float* whh_f, const float* whh_r, const float* gates, const float* cst, const float* dy,
+                           int64_t B, int64_t T, float* dgates, hipStream_t st)
 {
-    hipLaunchKernelGGL((lstm_bwd_kernel<H, BT>), dim3((unsigned)((B + BT - 1) / BT), 2), dim3(4 * H), 0, st, whh, gates,
+    hipLaunchKernelGGL((lstm_bwd_kernel<H, BT>), dim3((unsigned)((B + BT - 1) / BT), 2), dim3(4 * H), 0, st, whh_f, whh_r, gates,
                        cst, dy, B, T, dgates);
     SGNN_CHECK_LAUNCH();
     return SGNN_OK;
@@ -245,26 +250,27 @@ extern "C" int sgnn_lstm_supported(int64_t hidden_size)
     return (hidden_size == 128 || hidden_size == 64 || hidden_size == 32) ? 1 : 0;
 }
 
-extern "C" int sgnn_lstm_fwd(const float* pre_x, const float* whh, int64_t B, int64_t T, int64_t hidden_size,
-                             float* y, float* gates, float* cell, float* hprev, void* stream)
+extern "C" int sgnn_lstm_fwd(const float* pre_x, const float* whh_f, const float* whh_r, const float* bhh_f, const float* bhh_r,
+                             int64_t B, int64_t T, int64_t hidden_size, float* y, float* gates, float* cell, float* hprev,
+                             void* stream)
 {
-    if (!pre_x || !whh || !y || !gates || !cell || !hprev || B < 0 || T < 0) return SGNN_ERR_BAD_ARG;
+    if (!pre_x || !whh_f || !whh_r || !y || !gates || !cell || !hprev || B < 0 || T < 0) return SGNN_ERR_BAD_ARG;
     if (!sgnn_lstm_supported(hidden_size)) return SGNN_ERR_UNSUPPORTED_D;
     if (B == 0 || T == 0) return SGNN_OK;
     hipStream_t st = (hipStream_t)stream;
-#define LSTM_FWD(HH, BB) lstm_launch_fwd<HH, BB>(pre_x, whh, B, T, y, gates, cell, hprev, st)
+#define LSTM_FWD(HH, BB) lstm_launch_fwd<HH, BB>(pre_x, whh_f, whh_r, bhh_f, bhh_r, B, T, y, gates, cell, hprev, st)
     LSTM_DISPATCH(LSTM_FWD);
 #undef LSTM_FWD
 }
 
-extern "C" int sgnn_lstm_bwd(const float* whh, const float* gates, const float* cell, const float* dy, int64_t B,
-                             int64_t T, int64_t hidden_size, float* dgates, void* stream)
+extern "C" int sgnn_lstm_bwd(const float* whh_f, const float* whh_r, const float* gates, const float* cell, const float* dy,
+                             int64_t B, int64_t T, int64_t hidden_size, float* dgates, void* stream)
 {
-    if (!whh || !gates || !cell || !dy || !dgates || B < 0 || T < 0) return SGNN_ERR_BAD_ARG;
+    if (!whh_f || !whh_r || !gates || !cell || !dy || !dgates || B < 0 || T < 0) return SGNN_ERR_BAD_ARG;
     if (!sgnn_lstm_supported(hidden_size)) return SGNN_ERR_UNSUPPORTED_D;
     if (B == 0 || T == 0) return SGNN_OK;
     hipStream_t st = (hipStream_t)stream;
-#define LSTM_BWD(HH, BB) lstm_launch_bwd<HH, BB>(whh, gates, cell, dy, B, T, dgates, st)
+#define LSTM_BWD(HH, BB) lstm_launch_bwd<HH, BB>(whh_f, whh_r, gates, cell, dy, B, T, dgates, st)
     LSTM_DISPATCH(LSTM_BWD);
 #undef LSTM_BWD
 }

@@ -1911,45 +1911,48 @@ class _BiLSTMLayer(torch.autograd.Function):
         _req(x, torch.float32, 'x')
         B, T, I = x.shape
         H = w_hh_f.shape[1]
-        wih = torch.cat((w_ih_f, w_ih_r), 0)                                   # (8H, I)
-        bias = torch.cat((b_ih_f + b_hh_f, b_ih_r + b_hh_r), 0)
         x2 = x.reshape(B * T, I)
-        pre_x = torch.addmm(bias, x2, wih.t())                                 # (B T, 8H) = (B, T, 2, 4H)
-        whh = torch.stack((w_hh_f, w_hh_r)).contiguous()
         dev = x.device
+        # direction-major projected inputs: each direction's rows are one GEMM's contiguous output (no concatenation of the two
+        # weight matrices); bias_hh is added inside the recurrence kernel (no sum of the bias vectors, no stacked W_hh)
+        pre_x = torch.empty((2, B * T, 4 * H), dtype=torch.float32, device=dev)
+        torch.addmm(b_ih_f, x2, w_ih_f.t(), out=pre_x[0])
+        torch.addmm(b_ih_r, x2, w_ih_r.t(), out=pre_x[1])
         y = torch.empty((B, T, 2 * H), dtype=torch.float32, device=dev)
-        gates = torch.empty((B, T, 2, 4 * H), dtype=torch.float32, device=dev)
+        gates = torch.empty((2, B, T, 4 * H), dtype=torch.float32, device=dev)
         cell = torch.empty((2, B, T, H), dtype=torch.float32, device=dev)
         hprev = torch.empty((2, B, T, H), dtype=torch.float32, device=dev)
-        check(lib.sgnn_lstm_fwd(_ptr(pre_x), _ptr(whh), B, T, H, _ptr(y), _ptr(gates), _ptr(cell), _ptr(hprev),
-                                _stream()), 'sgnn_lstm_fwd')
-        ctx.save_for_backward(x2, wih, whh, gates, cell, hprev)
+        for t, nm in ((w_hh_f, 'weight_hh'), (w_hh_r, 'weight_hh_reverse'), (b_hh_f, 'bias_hh'), (b_hh_r, 'bias_hh_reverse')):
+            _req(t, torch.float32, nm)
+        check(lib.sgnn_lstm_fwd(_ptr(pre_x), _ptr(w_hh_f), _ptr(w_hh_r), _ptr(b_hh_f), _ptr(b_hh_r), B, T, H, _ptr(y), _ptr(gates),
+                                _ptr(cell), _ptr(hprev), _stream()), 'sgnn_lstm_fwd')
+        ctx.save_for_backward(x2, w_ih_f, w_ih_r, w_hh_f, w_hh_r, gates, cell, hprev)
         ctx.dims = (B, T, I, H)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         lib = _lib.load()
-        x2, wih, whh, gates, cell, hprev = ctx.saved_tensors
+        x2, w_ih_f, w_ih_r, w_hh_f, w_hh_r, gates, cell, hprev = ctx.saved_tensors
         B, T, I, H = ctx.dims
         dy = dy.contiguous()
-        dgates = torch.empty_like(gates)
-        check(lib.sgnn_lstm_bwd(_ptr(whh), _ptr(gates), _ptr(cell), _ptr(dy), B, T, H, _ptr(dgates), _stream()),
+        dgates = torch.empty_like(gates)                                        # (2, B, T, 4H)
+        check(lib.sgnn_lstm_bwd(_ptr(w_hh_f), _ptr(w_hh_r), _ptr(gates), _ptr(cell), _ptr(dy), B, T, H, _ptr(dgates), _stream()),
               'sgnn_lstm_bwd')
-        dg = dgates.view(B * T, 8 * H)
-        dx = (dg @ wih).view(B, T, I) if ctx.needs_input_grad[0] else None
-        dwih = contract_rows(dg, x2)                                            # (8H, I)
-        dgd = dgates.view(B * T, 2, 4 * H).transpose(0, 1).contiguous()         # (2, B T, 4H): one direction's gates contiguous
-        # both directions' W_hh gradients in ONE batched contraction, the rows split into blocks when there are enough of them
-        # (two library GEMMs of 512 x 128 outputs over a few thousand rows each ran 26 us apiece on a handful of workgroups)
-        dwhh = contract_rows_batched(dgd, hprev.view(2, B * T, H))              # (2, 4H, H)
+        dg = dgates.view(2, B * T, 4 * H)
+        dx = torch.addmm(dg[0] @ w_ih_f, dg[1], w_ih_r).view(B, T, I) if ctx.needs_input_grad[0] else None
+        # both directions' weight gradients in ONE batched contraction each, the rows split into blocks when there are enough
+        # of them (library GEMMs of 512 x 128 outputs over a few thousand rows ran 26 us apiece on a handful of workgroups);
+        # a direction's gate gradients are contiguous: no transposed copy of dgates (75 MB at 1850 x 10 steps, H = 128)
+        dwih = contract_rows_batched(dg, x2.unsqueeze(0).expand(2, B * T, I))   # (2, 4H, I)
+        dwhh = contract_rows_batched(dg, hprev.view(2, B * T, H))               # (2, 4H, H)
         # bias_ih and bias_hh receive the same gradient VALUES but must not receive the same MEMORY: autograd hands a view
         # over to .grad as it is, and an in-place multi-tensor update of the gradient list (clip_grad_norm_'s _foreach_mul_)
         # then scales the shared buffer once per alias, from concurrently running chunks -- g c or g c^2 depending on timing
         # (round 4: the cross-process 7th-digit loss drift was this race on lstm.bias_{ih,hh}_l0_reverse).  One copy:
-        db = column_sum(dg).view(8 * H).repeat(2)                              # [ih: forward, reverse | hh: forward, reverse]
-        G = 4 * H
-        return (dx, dwih[:G], dwhh[0], db[:G], db[2 * G:3 * G], dwih[G:], dwhh[1], db[G:2 * G], db[3 * G:])
+        db_f, db_r = column_sum(dg[0]), column_sum(dg[1])
+        db = torch.stack((db_f, db_r, db_f, db_r))                              # [ih: forward, reverse | hh: forward, reverse]
+        return (dx, dwih[0], dwhh[0], db[0], db[2], dwih[1], dwhh[1], db[1], db[3])
 
 
 def lstm_supported(input_size, hidden_size):
