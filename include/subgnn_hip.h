@@ -271,6 +271,15 @@ int sgnn_triangular_walks(const int64_t* rowptr, const int32_t* col, const int32
                           int mode, int64_t n_items, int64_t walks_per_patch, int64_t walk_len, double beta,
                           uint64_t seed, uint64_t stream_id, int64_t item_base, int64_t max_id, int kernel, int64_t* out,
                           void* stream);
+/* The internal AND the border walks over the same patches (aps:118-158, which the reference calls twice: inside = True / False)
+ * in ONE launch: out (2, n_items, walk_len) int64, [0] = internal walks (tape stream stream_id_int), [1] = border walks
+ * (stream_id_bor) -- the walks the two calls of sgnn_triangular_walks (modes 1 and 2) produce.  Only where the graph's id
+ * bitmap fits LDS (max_id < ~1.1 M): SGNN_ERR_SET_TOO_LARGE otherwise, and the caller makes the two calls. */
+int sgnn_triangular_walks_both(const int64_t* rowptr, const int32_t* col, const int32_t* col_sorted, int64_t nnz,
+                               const int64_t* patch_ptr, const int32_t* patch_nodes, const int64_t* inb_ptr,
+                               const int32_t* inb_nodes, int64_t n_items, int64_t walks_per_patch, int64_t walk_len,
+                               double beta, uint64_t seed, uint64_t stream_id_int, uint64_t stream_id_bor,
+                               int64_t item_base, int64_t max_id, int64_t* out, void* stream);
 
 /* in-border nodes of a patch (subgraph_utils.get_border_nodes, subgraph_utils.py:126-144, with
  * its id-1 / node-order indexing quirk): out_flag[i] = 1 iff patch_nodes[i] is a border node.

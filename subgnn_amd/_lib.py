@@ -59,6 +59,8 @@ SIGNATURES = {
     'sgnn_sample_anchors_padded': (c_int, [c_ptr, c_i64, c_i64, c_i64, c_u64, c_u64, c_ptr, c_ptr]),
     'sgnn_sample_anchors_ragged': (c_int, [c_ptr, c_ptr, c_i64, c_ptr, c_i64, c_u64, c_u64, c_i64, c_ptr, c_ptr]),
     'sgnn_choice_ragged': (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_u64, c_u64, c_i64, c_ptr, c_ptr]),
+    'sgnn_triangular_walks_both': (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_dbl, c_u64,
+                                           c_u64, c_u64, c_i64, c_i64, c_ptr, c_ptr]),
     'sgnn_triangular_walks': (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_int,
                                       c_i64, c_i64, c_i64, c_dbl, c_u64, c_u64, c_i64, c_i64, c_int, c_ptr, c_ptr]),
     'sgnn_patch_in_border': (c_int, [c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_ptr, c_ptr]),

@@ -89,6 +89,20 @@ def perform_random_walks(hparams, networkx_graph, anchor_patch_ids, inside, view
     return out.view(P, W, T)
 
 
+def perform_random_walks_both(hparams, networkx_graph, anchor_patch_ids, views=None, in_border=None, first_patch=0):
+    """perform_random_walks(..., inside=True) and (..., inside=False) (aps:118-158) over the same patches in one launch ->
+    (internal walks, border walks), each (n_patches, n_triangular_walks, random_walk_len) int64."""
+    g = networkx_graph
+    ids = anchor_patch_ids.to(g.device)
+    P = ids.shape[0]
+    W, T = hparams['n_triangular_walks'], hparams['random_walk_len']
+    views = views if views is not None else patch_node_views(ids)
+    in_border = in_border if in_border is not None else in_border_sets(g, views)
+    out = ops.triangular_walks_both(g, P * W, T, hparams['rw_beta'], _seed(hparams), tape.stream_id(tape.STREAM_WALK_INT),
+                                    tape.stream_id(tape.STREAM_WALK_BOR), views, in_border, W, item_base=first_patch * W)
+    return out[0].view(P, W, T), out[1].view(P, W, T)
+
+
 def sample_structure_anchor_patches(hparams, networkx_graph, device, max_sim_epochs, trim=True, share=None):
     """aps:210-243 -> (n sampled patches, max patch length) int64 (trailing all-PAD columns
     trimmed, as padding to the longest patch does in the reference; ``trim=False`` keeps the walks' full width -- the

@@ -458,8 +458,8 @@ __global__ __launch_bounds__(WKB_THREADS) void triangular_walks_wg_kernel(
     const int32_t* __restrict__ node_order, int64_t n_nodes,
     const int64_t* __restrict__ patch_ptr, const int32_t* __restrict__ patch_nodes,
     const int64_t* __restrict__ inb_ptr, const int32_t* __restrict__ inb_nodes,
-    int mode, int64_t n_items, int64_t walks_per_patch, int64_t walk_len, double beta,
-    uint64_t h0, int64_t item_base, int64_t* __restrict__ out, int64_t words)
+    int mode_all, int64_t n_items, int64_t walks_per_patch, int64_t walk_len, double beta,
+    uint64_t h0_all, int64_t item_base, int64_t* __restrict__ out, int64_t words, uint64_t h0_border)
 {
     extern __shared__ uint32_t s_adj[];                    // bitmap over node ids: N(prev)
     __shared__ uint64_t s_tri[WK_CHUNKS], s_non[WK_CHUNKS];
@@ -468,9 +468,18 @@ __global__ __launch_bounds__(WKB_THREADS) void triangular_walks_wg_kernel(
     const int tid = threadIdx.x;
     for (int64_t i = tid; i < words; i += WKB_THREADS) s_adj[i] = 0;
     __syncthreads();
-    for (int64_t item = blockIdx.x; item < n_items; item += gridDim.x) {
-        int64_t* o = out + item * walk_len;
+    for (int64_t item_all = blockIdx.x; item_all < n_items; item_all += gridDim.x) {
+        int64_t* o = out + item_all * walk_len;
         for (int64_t t = tid; t < walk_len; t += WKB_THREADS) o[t] = 0;
+        // mode 3: the internal walks (items [0, n / 2): mode 1) and the border walks (items [n / 2, n): mode 2) of the same
+        // patches in ONE launch -- each side draws from its own tape stream under its own walk numbers, as two launches would
+        int mode = mode_all;
+        int64_t item = item_all;
+        uint64_t h0 = h0_all;
+        if (mode_all == 3) {
+            const int64_t half = n_items >> 1;
+            if (item_all >= half) { mode = 2; item = item_all - half; h0 = h0_border; } else mode = 1;
+        }
         WalkCtx c;
         c.rowptr = rowptr; c.col = col; c.col_sorted = col_sorted; c.mode = mode;
         c.patch = nullptr; c.n_patch = 0; c.inb = nullptr; c.n_inb = 0;
@@ -559,13 +568,43 @@ extern "C" int sgnn_triangular_walks(const int64_t* rowptr, const int32_t* col, 
         hipLaunchKernelGGL(triangular_walks_wg_kernel, dim3((int)(n_items < 2048 ? n_items : 2048)), dim3(WKB_THREADS),
                            (size_t)(words * 4), (hipStream_t)stream, rowptr, col, col_sorted, node_order, n_nodes, patch_ptr,
                            patch_nodes, inb_ptr, inb_nodes, mode, n_items, walks_per_patch, walk_len, beta,
-                           sgnn_tape_h0(seed, stream_id), item_base, out, words);
+                           sgnn_tape_h0(seed, stream_id), item_base, out, words, (uint64_t)0);
         SGNN_CHECK_LAUNCH();
         return SGNN_OK;
     }
     hipLaunchKernelGGL(triangular_walks_kernel, dim3((int)(n_items < 256 * 32 ? n_items : 256 * 32)), dim3(64), 0, (hipStream_t)stream,
                        rowptr, col, col_sorted, node_order, n_nodes, patch_ptr, patch_nodes, inb_ptr, inb_nodes,
                        mode, n_items, walks_per_patch, walk_len, beta, sgnn_tape_h0(seed, stream_id), item_base, out);
+    SGNN_CHECK_LAUNCH();
+    return SGNN_OK;
+}
+
+// Internal AND border walks over the same patches (aps:118-158 called twice by the reference: inside = True / False) in one
+// launch where the graph's id bitmap fits LDS: out (2, n_items, walk_len), [0] = internal (tape stream stream_id_int), [1] =
+// border (stream_id_bor).  Returns SGNN_ERR_SET_TOO_LARGE when it does not fit: the caller then makes the two launches.
+extern "C" int sgnn_triangular_walks_both(const int64_t* rowptr, const int32_t* col, const int32_t* col_sorted, int64_t nnz,
+                                          const int64_t* patch_ptr, const int32_t* patch_nodes, const int64_t* inb_ptr,
+                                          const int32_t* inb_nodes, int64_t n_items, int64_t walks_per_patch, int64_t walk_len,
+                                          double beta, uint64_t seed, uint64_t stream_id_int, uint64_t stream_id_bor,
+                                          int64_t item_base, int64_t max_id, int64_t* out, void* stream)
+{
+    if (!rowptr || !col || !col_sorted || !out || !patch_ptr || !patch_nodes || !inb_ptr || !inb_nodes || n_items < 0 || walk_len < 0
+        || walks_per_patch <= 0 || item_base < 0)
+        return SGNN_ERR_BAD_ARG;
+    if (nnz >= (1ll << 31)) return SGNN_ERR_NNZ_TOO_LARGE;
+    if (n_items == 0 || walk_len == 0) return SGNN_OK;
+    const int64_t words = (max_id + 32) / 32;
+    if (max_id <= 0 || words * 4 > WKB_LDS_BYTES) return SGNN_ERR_SET_TOO_LARGE;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)triangular_walks_wg_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WKB_LDS_BYTES);
+        attr_set = true;
+    }
+    const int64_t both = 2 * n_items;
+    hipLaunchKernelGGL(triangular_walks_wg_kernel, dim3((int)(both < 2048 ? both : 2048)), dim3(WKB_THREADS), (size_t)(words * 4),
+                       (hipStream_t)stream, rowptr, col, col_sorted, (const int32_t*)nullptr, (int64_t)0, patch_ptr, patch_nodes, inb_ptr,
+                       inb_nodes, 3, both, walks_per_patch, walk_len, beta, sgnn_tape_h0(seed, stream_id_int), item_base, out, words,
+                       sgnn_tape_h0(seed, stream_id_bor));
     SGNN_CHECK_LAUNCH();
     return SGNN_OK;
 }

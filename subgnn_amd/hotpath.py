@@ -467,15 +467,16 @@ def prepare_pass(model, split='train', timer=None, shard=None, defer_dtw=False, 
                 def both(lo, hi):
                     mine = structure_anchors[lo:hi].contiguous()
                     v = aps.patch_node_views(mine)
-                    return torch.stack([aps.perform_random_walks(hp, g, mine, False, v, first_patch=lo),
-                                        aps.perform_random_walks(hp, g, mine, True, v, first_patch=lo)], 1)
+                    iw, bw = aps.perform_random_walks_both(hp, g, mine, v, first_patch=lo)
+                    return torch.stack([bw, iw], 1)
                 walks = _deal_rows(shard, structure_anchors.shape[0], both, (2, W_, T_), torch.int64, dev)
                 bor_w = st.attrs['bor_structure_anchor_random_walks'] = walks[:, 0].contiguous()
                 int_w = st.attrs['int_structure_anchor_random_walks'] = walks[:, 1].contiguous()
             elif new_patches:
                 views = aps.patch_node_views(structure_anchors)
-                bor_w = st.attrs['bor_structure_anchor_random_walks'] = aps.perform_random_walks(hp, g, structure_anchors, False, views)
-                int_w = st.attrs['int_structure_anchor_random_walks'] = aps.perform_random_walks(hp, g, structure_anchors, True, views)
+                # (internal and border walks in ONE launch: 1050 + 1050 one-workgroup-per-CU walks fill the chip's rounds better)
+                int_w, bor_w = aps.perform_random_walks_both(hp, g, structure_anchors, views)
+                st.attrs['bor_structure_anchor_random_walks'], st.attrs['int_structure_anchor_random_walks'] = bor_w, int_w
             if pool is not None:
                 int_w, bor_w = pool['int_w'], pool['bor_w']
                 st.attrs['structure_anchors'] = structure_anchors

@@ -647,6 +647,26 @@ def triangular_walks(g, mode, n_items, walk_len, beta, seed, stream_id, patches=
     return out
 
 
+def triangular_walks_both(g, n_items, walk_len, beta, seed, stream_id_int, stream_id_bor, patches, in_border, walks_per_patch,
+                          item_base=0):
+    """The internal and the border walks over the same patches in ONE launch -> (2, n_items, walk_len) int64, [0] internal,
+    [1] border: what triangular_walks(mode 1) and triangular_walks(mode 2) return.  Falls back to those two calls where the
+    graph's id bitmap does not fit LDS."""
+    lib = _lib.load()
+    out = torch.empty((2, n_items, walk_len), dtype=torch.int64, device=g.device)
+    rc = lib.sgnn_triangular_walks_both(_ptr(g.rowptr), _ptr(g.col), _ptr(g.col_sorted), g.nnz, _ptr(patches.ptr), _ptr(patches.nodes),
+                                        _ptr(in_border.ptr), _ptr(in_border.nodes), n_items, walks_per_patch, walk_len, float(beta),
+                                        seed, stream_id_int, stream_id_bor, int(item_base), g.max_id, _ptr(out), _stream())
+    if rc == -2:                                                        # SGNN_ERR_SET_TOO_LARGE: no LDS bitmap for this graph
+        out[0] = triangular_walks(g, 1, n_items, walk_len, beta, seed, stream_id_int, patches=patches,
+                                  walks_per_patch=walks_per_patch, item_base=item_base)
+        out[1] = triangular_walks(g, 2, n_items, walk_len, beta, seed, stream_id_bor, patches=patches, in_border=in_border,
+                                  walks_per_patch=walks_per_patch, item_base=item_base)
+        return out
+    check(rc, 'sgnn_triangular_walks_both')
+    return out
+
+
 def patch_in_border(g, patches):
     """uint8 flag per patch node: is it an in-border node (su.get_border_nodes semantics)."""
     lib = _lib.load()

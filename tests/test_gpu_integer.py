@@ -558,6 +558,28 @@ def test_walks_random_vs_oracle(walk_kernel):
         assert np.array_equal(got, ref)
 
 
+def test_internal_and_border_walks_in_one_launch_equal_the_oracle():
+    """sgnn_triangular_walks_both: the internal and the border walks of the same patches in ONE launch against the oracle's two
+    calls (aps:118-158 with inside = True / False), and a share of it (item_base) against the whole."""
+    ops = _ops()
+    G = _rand_graph(400, 4, 9)
+    dg = _dev_graph(G)
+    patches = IH.sample_structure_anchor_patches(G, 40, 30, 0.4, 123)
+    views = [IH.patch_unique_nodes(p) for p in patches]
+    inb = [IH.patch_in_border_nodes(G, v) for v in views]
+    vr, ir = ops.Ragged.from_lists(views, DEV), ops.Ragged.from_lists(inb, DEV)
+    both = ops.triangular_walks_both(dg, 160, 12, 0.4, 123, T.stream_id(T.STREAM_WALK_INT), T.stream_id(T.STREAM_WALK_BOR), vr, ir, 4)
+    assert tuple(both.shape) == (2, 160, 12)
+    for k, inside in enumerate((True, False)):
+        ref = IH.perform_random_walks(G, patches, 4, 12, 0.4, inside, 123)
+        assert np.array_equal(both[k].view(40, 4, 12).cpu().numpy(), ref), inside
+    lo, hi = 13, 29                                                  # patches 13..28 as a share: same walks
+    vs, is_ = ops.Ragged.from_lists(views[lo:hi], DEV), ops.Ragged.from_lists(inb[lo:hi], DEV)
+    part = ops.triangular_walks_both(dg, (hi - lo) * 4, 12, 0.4, 123, T.stream_id(T.STREAM_WALK_INT), T.stream_id(T.STREAM_WALK_BOR),
+                                     vs, is_, 4, item_base=lo * 4)
+    assert torch.equal(part, both[:, lo * 4:hi * 4])
+
+
 def test_a_share_of_the_walks_draws_what_the_whole_launch_draws(walk_kernel):
     """item_base: a rank that runs walks [lo, hi) of a launch -- with the node views / in-border sets of ITS patches only
     for the patch walks -- gets rows lo..hi-1 of the whole launch, bit for bit (strong scaling deals the shared patches'
