@@ -640,6 +640,20 @@ int sgnn_update_fwd(const float* x, const float* aggr, const float* W, const flo
 int64_t sgnn_update_fwd_chunks_max_rows(void);
 int sgnn_update_fwd_chunks(const float* x, const float* aggr_chunks, int64_t n_chunks, const float* W, const float* b,
                            int64_t R, int64_t D, float* out, float* aggr_sum, void* stream);
+/* The update layers of n bodies of ONE message-passing layer (up to sgnn_update_many_max_bodies() channel sides of a batch-sized
+ * step: same R <= sgnn_update_fwd_chunks_max_rows(), same D) in one launch each way -- forward 1 launch, backward 3 (dx, dW
+ * partials, reduce) instead of n and 3 n.  All pointer tables are HOST arrays of n DEVICE pointers with the meaning of the
+ * single-body arguments; aggr_chunks[k] is (n_chunks[k], R, D), its sum goes to aggr_sum[k] (required when n_chunks[k] > 1).
+ * Backward: grad_out[k] NULL = body k received no gradient and is skipped; else grad_x[k] / grad_aggr[k] may be NULL and
+ * grad_W[k], grad_b[k] are both written; workspace n * sgnn_update_bwd_workspace_bytes(R, D). */
+int64_t sgnn_update_many_max_bodies(void);
+int sgnn_update_fwd_many(int64_t n, const float* const* x, const float* const* aggr_chunks, const int64_t* n_chunks,
+                         const float* const* W, const float* const* b, int64_t R, int64_t D, float* const* out,
+                         float* const* aggr_sum, void* stream);
+int sgnn_update_bwd_many(int64_t n, const float* const* grad_out, const float* const* out, const float* const* x,
+                         const float* const* aggr, const float* const* W, int64_t R, int64_t D, float* const* grad_x,
+                         float* const* grad_aggr, float* const* grad_W, float* const* grad_b, void* workspace,
+                         int64_t workspace_bytes, void* stream);
 int64_t sgnn_update_bwd_workspace_bytes(int64_t R, int64_t D);
 int sgnn_update_bwd(const float* grad_out, const float* out, const float* x, const float* aggr, const float* W,
                     int64_t R, int64_t D, float* grad_x, float* grad_aggr, float* grad_W, float* grad_b,

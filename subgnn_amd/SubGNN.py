@@ -585,7 +585,7 @@ class SubGNN(nn.Module):
         return mpn_fn(self.networkx_graph, sims, cc_ids, cc_embeds, cc_embed_mask, ap, ae, am, idx)
 
     def _run_mpn_layer_fused(self, dataset_type, mpn_fn, sidx, cc_embeds, cc_embed_mask, sims, layer_num, channel,
-                             inside, need_out=True, defer=False, need_pos=True):
+                             inside, need_out=True, defer=False, need_pos=True, defer_update=False):
         """Same layer without the (B,C,A,D) tensor: anchors are gathered inside the kernel."""
         B, C, _ = cc_embeds.shape
         E = self._table()
@@ -635,20 +635,22 @@ class SubGNN(nn.Module):
                 plan = None
             return mpn_fn.forward_fused(sims, cc_embeds, cc_embed_mask, src=ops.SRC_GATHER, x=E, ids=ids,
                                         sims_per_edge=per_edge, need_out=need_out, defer_readout=defer, need_pos=need_pos,
-                                        edge_plan=plan)
+                                        edge_plan=plan, defer_update=defer_update)
         if channel == 'position':
             if inside:
                 ids = layer_rows(self.anchors_pos_int, 'P_in').contiguous()
                 return mpn_fn.forward_fused(sims, cc_embeds, cc_embed_mask, src=ops.SRC_GATHER, x=E, ids=ids, id_div=C,
-                                            sims_per_edge=per_edge, need_out=need_out, defer_readout=defer, need_pos=need_pos)
+                                            sims_per_edge=per_edge, need_out=need_out, defer_readout=defer, need_pos=need_pos,
+                                            defer_update=defer_update)
             ids = self.anchors_pos_ext[layer_num]
             X = ops.gather_rows(E, ids)
             return mpn_fn.forward_fused(sims, cc_embeds, cc_embed_mask, src=ops.SRC_SHARED, x=X, ids=ids,
-                                        sims_per_edge=per_edge, need_out=need_out, defer_readout=defer, need_pos=need_pos)
+                                        sims_per_edge=per_edge, need_out=need_out, defer_readout=defer, need_pos=need_pos,
+                                        defer_update=defer_update)
         X = self._structure_anchor_embeddings(layer_num, E)[0 if inside else 1]
         return mpn_fn.forward_fused(sims, cc_embeds, cc_embed_mask, src=ops.SRC_SHARED, x=X,
                                     sim_col=self._sim_col_cache[layer_num], need_out=need_out, defer_readout=defer,
-                                    need_pos=need_pos)
+                                    need_pos=need_pos, defer_update=defer_update)
 
     def _structure_anchor_embeddings(self, layer_num, E):
         """aps:413-433 for the internal and the border walks of a layer's structure patches in ONE pass over the LSTM (same
@@ -742,11 +744,13 @@ class SubGNN(nn.Module):
         slots = fused and not hp.get('ff_attn', False) and not hp.get('dp_gather_embeddings', False)
         outputs = []
         for l in range(hp['n_layers']):
+            # the bodies of a layer (up to three channels x two sides) read the layer below only: their message-passing kernels
+            # run one after the other, their update layers TOGETHER (ops.update_layers: one launch each way for a batch-sized step)
+            bodies = []
             for channel, tag, flag, attr in CHANNELS:
                 if not hp[flag]:
                     continue
                 layer = getattr(self, attr)[l]
-                res = {}
                 pick = 0 if tag == 'N' else 1                      # N adds CC embeddings, P/S their read-outs
                 # the updated component embeddings of a P / S layer only feed the next layer: not computed for the last
                 need_out = pick == 0 or l + 1 < hp['n_layers']
@@ -755,16 +759,21 @@ class SubGNN(nn.Module):
                     slot = tag + '_' + side
                     if fused:
                         o, p = self._run_mpn_layer_fused(dataset_type, layer[name], sidx, state[slot], cc_embed_mask,
-                                                         sims, l, channel, inside, need_out=need_out, defer=slots, need_pos=pick == 1)
+                                                         sims, l, channel, inside, need_out=need_out, defer=slots, need_pos=pick == 1,
+                                                         defer_update=True)
                     else:
                         o, p = self.run_mpn_layer(dataset_type, layer[name], subgraph_ids, subgraph_idx, cc_ids,
                                                   state[slot], cc_embed_mask, sims, layer_num=l, channel=channel,
                                                   inside=inside)
-                    if bn and o is not None:
-                        o = layer[bnname](o.reshape(B * C, -1)).view(B, C, -1)
-                    state[slot] = o
-                    res[side] = (o, p)
-                outputs.extend([res['I'][pick], res['B'][pick]])
+                    bodies.append([slot, pick, o, p, layer[bnname] if bn else None])
+            pending = [b for b in bodies if isinstance(b[2], ops.PendingUpdate)]
+            for b, o in zip(pending, ops.update_layers([b[2] for b in pending])):
+                b[2] = o.view(b[2].shape[0], b[2].shape[1], -1)
+            for slot, pick, o, p, bn_layer in bodies:
+                if bn and o is not None:
+                    o = bn_layer(o.reshape(B * C, -1)).view(B, C, -1)
+                state[slot] = o
+                outputs.append((o, p)[pick])
         if slots:
             subgraph_embedding = ops.subgraph_embedding([init_cc_embeds] + outputs, cc_embed_mask._sgnn_u8, B, C)
             return self._head(subgraph_embedding)

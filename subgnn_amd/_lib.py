@@ -131,6 +131,10 @@ SIGNATURES = {
     'sgnn_update_fwd': (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr]),
     'sgnn_update_fwd_chunks_max_rows': (c_i64, []),
     'sgnn_update_fwd_chunks': (c_int, [c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_ptr]),
+    'sgnn_update_many_max_bodies': (c_i64, []),
+    'sgnn_update_fwd_many': (c_int, [c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_ptr]),
+    'sgnn_update_bwd_many': (c_int, [c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64,
+                                     c_ptr]),
     'sgnn_update_bwd_workspace_bytes': (c_i64, [c_i64, c_i64]),
     'sgnn_update_bwd': (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr]),
     'sgnn_sort_edges_by_key_workspace_bytes': (c_i64, [c_i64, c_i64]),

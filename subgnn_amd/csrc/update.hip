@@ -30,6 +30,18 @@ typedef float upd_f32x16 __attribute__((ext_vector_type(16)));
 #define UPD_KSPLIT_BELOW 4096    // rows below which a tile's contraction is split over the four wavefronts of a workgroup
 #define UPD_WAVE_ROWS_SMALL 16   // rows per wavefront of the weight-gradient kernel for calls below UPD_KSPLIT_BELOW rows
 
+// Several update layers of the same shape in ONE launch each way (the bodies of one message-passing layer: up to six channel
+// sides of a batch-sized step): blockIdx.z = body, its operands from this table (n = 0: the launch's own pointer arguments).
+#define UPD_MAX_BODIES 8
+struct UpdMany {
+    const float* x[UPD_MAX_BODIES]; const float* aggr[UPD_MAX_BODIES]; const float* W[UPD_MAX_BODIES]; const float* b[UPD_MAX_BODIES];
+    float* out[UPD_MAX_BODIES]; float* aggr_sum[UPD_MAX_BODIES];
+    const float* g[UPD_MAX_BODIES]; float* gx[UPD_MAX_BODIES]; float* gaggr[UPD_MAX_BODIES];
+    float* gW[UPD_MAX_BODIES]; float* gb[UPD_MAX_BODIES]; float* pW[UPD_MAX_BODIES]; float* pb[UPD_MAX_BODIES];
+    int n_chunks[UPD_MAX_BODIES];
+    int n;
+};
+
 // accumulator element v of lane l: row 8 * (v / 4) + 4 * (l / 32) + v % 4, column l % 32
 __device__ __forceinline__ int upd_acc_row(int v, int h) { return 8 * (v >> 2) + 4 * h + (v & 3); }
 
@@ -91,11 +103,19 @@ __global__ __launch_bounds__(64) void update_fwd_kernel(const float* __restrict_
 // stand-in).  A workgroup of four wavefronts per tile, each contracting a quarter of the positions of both halves; the partial
 // accumulators are added in wavefront order through LDS (a fixed order: bit-reproducible).
 template <int D>
-__global__ __launch_bounds__(256) void update_fwd_ksplit_kernel(const float* __restrict__ x, const float* __restrict__ aggr,
-                                                                const float* __restrict__ W, const float* __restrict__ b,
-                                                                int64_t R, float* __restrict__ out, int n_chunks,
-                                                                float* __restrict__ aggr_sum)
+__global__ __launch_bounds__(256) void update_fwd_ksplit_kernel(const float* __restrict__ x_, const float* __restrict__ aggr_,
+                                                                const float* __restrict__ W_, const float* __restrict__ b_,
+                                                                int64_t R, float* __restrict__ out_, int n_chunks_,
+                                                                float* __restrict__ aggr_sum_, const UpdMany M)
 {
+    const int z = blockIdx.z;
+    const float* __restrict__ x = M.n ? M.x[z] : x_;
+    const float* __restrict__ aggr = M.n ? M.aggr[z] : aggr_;
+    const float* __restrict__ W = M.n ? M.W[z] : W_;
+    const float* __restrict__ b = M.n ? M.b[z] : b_;
+    float* __restrict__ out = M.n ? M.out[z] : out_;
+    float* __restrict__ aggr_sum = M.n ? M.aggr_sum[z] : aggr_sum_;
+    const int n_chunks = M.n ? M.n_chunks[z] : n_chunks_;
     constexpr int Q = D / 4;                                             // positions per wavefront (8 / 16 / 32)
     __shared__ float s_part[3 * 16 * 64];
     const int lane = threadIdx.x & 63, i = lane & 31, h = lane >> 5;
@@ -153,10 +173,17 @@ __global__ __launch_bounds__(256) void update_fwd_ksplit_kernel(const float* __r
 
 // [grad_x | grad_aggr](r, c) = sum_n dpre(r, n) W(n, c): contraction index n walked as (half, position)
 template <int D, bool SPLIT>
-__global__ __launch_bounds__(64) void update_bwd_dx_kernel(const float* __restrict__ g, const float* __restrict__ out,
-                                                           const float* __restrict__ W, int64_t R,
-                                                           float* __restrict__ gx, float* __restrict__ gaggr)
+__global__ __launch_bounds__(64) void update_bwd_dx_kernel(const float* __restrict__ g_, const float* __restrict__ out_,
+                                                           const float* __restrict__ W_, int64_t R,
+                                                           float* __restrict__ gx_, float* __restrict__ gaggr_, const UpdMany M)
 {
+    const int z = blockIdx.z;
+    const float* __restrict__ g = M.n ? M.g[z] : g_;
+    if (!g) return;                                                      // (a body whose output received no gradient)
+    const float* __restrict__ out = M.n ? M.out[z] : out_;
+    const float* __restrict__ W = M.n ? M.W[z] : W_;
+    float* __restrict__ gx = M.n ? M.gx[z] : gx_;
+    float* __restrict__ gaggr = M.n ? M.gaggr[z] : gaggr_;
     constexpr int H = D / 2;                                             // contraction positions per k-half
     const int lane = threadIdx.x, i = lane & 31, h = lane >> 5;
     const int64_t row0 = (int64_t)blockIdx.x * 32;
@@ -190,10 +217,18 @@ __global__ __launch_bounds__(64) void update_bwd_dx_kernel(const float* __restri
 // blockIdx.x = row block, blockIdx.y = tile of 32 output features n.  The rows are the contraction: step s covers
 // rows r0 + 2 s + (lane / 32).
 template <int D, int WR = UPD_WAVE_ROWS>
-__global__ __launch_bounds__(256) void update_bwd_dw_kernel(const float* __restrict__ g, const float* __restrict__ out,
-                                                           const float* __restrict__ x, const float* __restrict__ aggr,
-                                                           int64_t R, float* __restrict__ pW, float* __restrict__ pb)
+__global__ __launch_bounds__(256) void update_bwd_dw_kernel(const float* __restrict__ g_, const float* __restrict__ out_,
+                                                           const float* __restrict__ x_, const float* __restrict__ aggr_,
+                                                           int64_t R, float* __restrict__ pW_, float* __restrict__ pb_, const UpdMany M)
 {
+    const int z = blockIdx.z;
+    const float* __restrict__ g = M.n ? M.g[z] : g_;
+    if (!g) return;
+    const float* __restrict__ out = M.n ? M.out[z] : out_;
+    const float* __restrict__ x = M.n ? M.x[z] : x_;
+    const float* __restrict__ aggr = M.n ? M.aggr[z] : aggr_;
+    float* __restrict__ pW = M.n ? M.pW[z] : pW_;
+    float* __restrict__ pb = M.n ? M.pb[z] : pb_;
     constexpr int CT = 2 * D / 32;                                       // column tiles of [x | aggr]
     __shared__ float s_acc[(CT * 16 + 1) * 64];
     const int lane = threadIdx.x & 63, i = lane & 31, h = lane >> 5;
@@ -263,8 +298,14 @@ __global__ __launch_bounds__(256) void update_bwd_dw_kernel(const float* __restr
 // each add up a contiguous quarter of the blocks, and the quarters are added in order through LDS
 __global__ __launch_bounds__(256) void update_reduce_kernel(const float* __restrict__ part, int64_t n_blocks, int64_t n,
                                                             float* __restrict__ out, unsigned first_groups,
-                                                            const float* __restrict__ part2, int64_t n2, float* __restrict__ out2)
+                                                            const float* __restrict__ part2, int64_t n2, float* __restrict__ out2,
+                                                            const UpdMany M)
 {
+    if (M.n) {
+        const int z = blockIdx.z;
+        if (!M.g[z]) return;
+        part = M.pW[z]; out = M.gW[z]; part2 = M.pb[z]; out2 = M.gb[z];
+    }
     __shared__ float s_q[4 * 64];
     const int o = threadIdx.x & 63, q = threadIdx.x >> 6;
     unsigned group = blockIdx.x;
@@ -281,6 +322,8 @@ __global__ __launch_bounds__(256) void update_reduce_kernel(const float* __restr
     __syncthreads();
     if (q == 0 && j < n) out[j] = ((s_q[o] + s_q[64 + o]) + s_q[128 + o]) + s_q[192 + o];
 }
+
+static const UpdMany UPD_NONE = {};
 
 static int update_fwd_run(const float* x, const float* aggr, int n_chunks, const float* W, const float* b, int64_t R, int64_t D,
                           float* out, float* aggr_sum, void* stream);
@@ -309,7 +352,7 @@ static int update_fwd_run(const float* x, const float* aggr, int n_chunks, const
     hipStream_t st = (hipStream_t)stream;
     const unsigned grid = (unsigned)((R + 31) / 32);
     // few rows: the feature tiles side by side (more wavefronts than CUs only from ~8k rows on)
-#define UPD_LAUNCH_FWD(DD) do { if (R < UPD_KSPLIT_BELOW) hipLaunchKernelGGL((update_fwd_ksplit_kernel<DD>), dim3(grid, DD / 32), dim3(256), 0, st, x, aggr, W, b, R, out, n_chunks, aggr_sum); \
+#define UPD_LAUNCH_FWD(DD) do { if (R < UPD_KSPLIT_BELOW) hipLaunchKernelGGL((update_fwd_ksplit_kernel<DD>), dim3(grid, DD / 32), dim3(256), 0, st, x, aggr, W, b, R, out, n_chunks, aggr_sum, UPD_NONE); \
                                 else if (split) hipLaunchKernelGGL((update_fwd_kernel<DD, true>), dim3(grid, DD / 32), dim3(64), 0, st, x, aggr, W, b, R, out); \
                                 else hipLaunchKernelGGL((update_fwd_kernel<DD, false>), dim3(grid), dim3(64), 0, st, x, aggr, W, b, R, out); } while (0)
     const bool split = R < UPD_SPLIT_BELOW;
@@ -346,8 +389,8 @@ extern "C" int sgnn_update_bwd(const float* grad_out, const float* out, const fl
     }
     if (grad_x || grad_aggr) {
         const unsigned grid = (unsigned)((R + 31) / 32);
-#define UPD_LAUNCH_DX(DD) do { if (split) hipLaunchKernelGGL((update_bwd_dx_kernel<DD, true>), dim3(grid, 2 * DD / 32), dim3(64), 0, st, grad_out, out, W, R, grad_x, grad_aggr); \
-                               else hipLaunchKernelGGL((update_bwd_dx_kernel<DD, false>), dim3(grid), dim3(64), 0, st, grad_out, out, W, R, grad_x, grad_aggr); } while (0)
+#define UPD_LAUNCH_DX(DD) do { if (split) hipLaunchKernelGGL((update_bwd_dx_kernel<DD, true>), dim3(grid, 2 * DD / 32), dim3(64), 0, st, grad_out, out, W, R, grad_x, grad_aggr, UPD_NONE); \
+                               else hipLaunchKernelGGL((update_bwd_dx_kernel<DD, false>), dim3(grid), dim3(64), 0, st, grad_out, out, W, R, grad_x, grad_aggr, UPD_NONE); } while (0)
         const bool split = R < UPD_SPLIT_BELOW;
         if (D == 32) UPD_LAUNCH_DX(32); else if (D == 64) UPD_LAUNCH_DX(64); else UPD_LAUNCH_DX(128);
 #undef UPD_LAUNCH_DX
@@ -360,19 +403,98 @@ extern "C" int sgnn_update_bwd(const float* grad_out, const float* out, const fl
         float* pb = pW + nb * D * 2 * D;
         const dim3 grid((unsigned)nb, (unsigned)(D / 32));
         if (R < UPD_KSPLIT_BELOW) {
-            if (D == 32) hipLaunchKernelGGL((update_bwd_dw_kernel<32, UPD_WAVE_ROWS_SMALL>), grid, dim3(256), 0, st, grad_out, out, x, aggr, R, pW, pb);
-            else if (D == 64) hipLaunchKernelGGL((update_bwd_dw_kernel<64, UPD_WAVE_ROWS_SMALL>), grid, dim3(256), 0, st, grad_out, out, x, aggr, R, pW, pb);
-            else hipLaunchKernelGGL((update_bwd_dw_kernel<128, UPD_WAVE_ROWS_SMALL>), grid, dim3(256), 0, st, grad_out, out, x, aggr, R, pW, pb);
+            if (D == 32) hipLaunchKernelGGL((update_bwd_dw_kernel<32, UPD_WAVE_ROWS_SMALL>), grid, dim3(256), 0, st, grad_out, out, x, aggr, R, pW, pb, UPD_NONE);
+            else if (D == 64) hipLaunchKernelGGL((update_bwd_dw_kernel<64, UPD_WAVE_ROWS_SMALL>), grid, dim3(256), 0, st, grad_out, out, x, aggr, R, pW, pb, UPD_NONE);
+            else hipLaunchKernelGGL((update_bwd_dw_kernel<128, UPD_WAVE_ROWS_SMALL>), grid, dim3(256), 0, st, grad_out, out, x, aggr, R, pW, pb, UPD_NONE);
         }
-        else if (D == 32) hipLaunchKernelGGL(update_bwd_dw_kernel<32>, grid, dim3(256), 0, st, grad_out, out, x, aggr, R, pW, pb);
-        else if (D == 64) hipLaunchKernelGGL(update_bwd_dw_kernel<64>, grid, dim3(256), 0, st, grad_out, out, x, aggr, R, pW, pb);
-        else hipLaunchKernelGGL(update_bwd_dw_kernel<128>, grid, dim3(256), 0, st, grad_out, out, x, aggr, R, pW, pb);
+        else if (D == 32) hipLaunchKernelGGL(update_bwd_dw_kernel<32>, grid, dim3(256), 0, st, grad_out, out, x, aggr, R, pW, pb, UPD_NONE);
+        else if (D == 64) hipLaunchKernelGGL(update_bwd_dw_kernel<64>, grid, dim3(256), 0, st, grad_out, out, x, aggr, R, pW, pb, UPD_NONE);
+        else hipLaunchKernelGGL(update_bwd_dw_kernel<128>, grid, dim3(256), 0, st, grad_out, out, x, aggr, R, pW, pb, UPD_NONE);
         SGNN_CHECK_LAUNCH();
         // one launch for both: workgroups [0, nW) own 64 elements of grad_W each, the rest 64 of grad_b
         const unsigned nW = grad_W ? (unsigned)((D * 2 * D + 63) / 64) : 0u, nB = grad_b ? (unsigned)((D + 63) / 64) : 0u;
-        hipLaunchKernelGGL(update_reduce_kernel, dim3(nW + nB), dim3(256), 0, st, pW, nb, D * 2 * D, grad_W, nW, pb, D, grad_b);
+        hipLaunchKernelGGL(update_reduce_kernel, dim3(nW + nB), dim3(256), 0, st, pW, nb, D * 2 * D, grad_W, nW, pb, D, grad_b, UPD_NONE);
         SGNN_CHECK_LAUNCH();
     }
+    return SGNN_OK;
+}
+
+// ---- the update layers of one message-passing layer's bodies in one launch each way ------------------------------------------
+// n bodies of the same (R, D), R below UPD_KSPLIT_BELOW (the batch-sized shape): forward 1 launch, backward 3 (dx, dW partials,
+// reduce) instead of n and 3 n.  Pointer tables are HOST arrays of DEVICE pointers.
+extern "C" int64_t sgnn_update_many_max_bodies(void) { return UPD_MAX_BODIES; }
+
+extern "C" int sgnn_update_fwd_many(int64_t n, const float* const* x, const float* const* aggr_chunks, const int64_t* n_chunks,
+                                    const float* const* W, const float* const* b, int64_t R, int64_t D, float* const* out,
+                                    float* const* aggr_sum, void* stream)
+{
+    if (n < 1 || n > UPD_MAX_BODIES || !x || !aggr_chunks || !n_chunks || !W || !b || !out || !aggr_sum || R < 0) return SGNN_ERR_BAD_ARG;
+    if (D != 32 && D != 64 && D != 128) return SGNN_ERR_UNSUPPORTED_D;
+    if (R >= UPD_KSPLIT_BELOW) return SGNN_ERR_BAD_ARG;
+    if (R == 0) return SGNN_OK;
+    UpdMany M = {};
+    M.n = (int)n;
+    for (int k = 0; k < n; ++k) {
+        if (!x[k] || !aggr_chunks[k] || !W[k] || !out[k] || n_chunks[k] < 1 || n_chunks[k] > 4096 || (n_chunks[k] > 1 && !aggr_sum[k]))
+            return SGNN_ERR_BAD_ARG;
+        M.x[k] = x[k]; M.aggr[k] = aggr_chunks[k]; M.W[k] = W[k]; M.b[k] = b[k]; M.out[k] = out[k]; M.aggr_sum[k] = aggr_sum[k];
+        M.n_chunks[k] = (int)n_chunks[k];
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((unsigned)((R + 31) / 32), (unsigned)(D / 32), (unsigned)n);
+    if (D == 32) hipLaunchKernelGGL((update_fwd_ksplit_kernel<32>), grid, dim3(256), 0, st, nullptr, nullptr, nullptr, nullptr, R, nullptr, 1, nullptr, M);
+    else if (D == 64) hipLaunchKernelGGL((update_fwd_ksplit_kernel<64>), grid, dim3(256), 0, st, nullptr, nullptr, nullptr, nullptr, R, nullptr, 1, nullptr, M);
+    else hipLaunchKernelGGL((update_fwd_ksplit_kernel<128>), grid, dim3(256), 0, st, nullptr, nullptr, nullptr, nullptr, R, nullptr, 1, nullptr, M);
+    SGNN_CHECK_LAUNCH();
+    return SGNN_OK;
+}
+
+/* grad_out[k] NULL: body k received no gradient and is skipped (its outputs are not written).  For the others grad_x[k] /
+ * grad_aggr[k] may be NULL; grad_W[k] and grad_b[k] are both written.  workspace: n * sgnn_update_bwd_workspace_bytes(R, D). */
+extern "C" int sgnn_update_bwd_many(int64_t n, const float* const* grad_out, const float* const* out, const float* const* x,
+                                    const float* const* aggr, const float* const* W, int64_t R, int64_t D, float* const* grad_x,
+                                    float* const* grad_aggr, float* const* grad_W, float* const* grad_b, void* workspace,
+                                    int64_t workspace_bytes, void* stream)
+{
+    if (n < 1 || n > UPD_MAX_BODIES || !grad_out || !out || !x || !aggr || !W || !grad_x || !grad_aggr || !grad_W || !grad_b || R < 1)
+        return SGNN_ERR_BAD_ARG;
+    if (D != 32 && D != 64 && D != 128) return SGNN_ERR_UNSUPPORTED_D;
+    if (R >= UPD_KSPLIT_BELOW) return SGNN_ERR_BAD_ARG;
+    const int64_t per = sgnn_update_bwd_workspace_bytes(R, D);
+    if (!workspace || workspace_bytes < n * per) return SGNN_ERR_BAD_ARG;
+    const int64_t nb = (R + upd_block_rows(R) - 1) / upd_block_rows(R);
+    UpdMany M = {};
+    M.n = (int)n;
+    bool any = false;
+    for (int k = 0; k < n; ++k) {
+        M.g[k] = grad_out[k];
+        if (!grad_out[k]) continue;
+        if (!out[k] || !x[k] || !aggr[k] || !W[k] || !grad_W[k] || !grad_b[k]) return SGNN_ERR_BAD_ARG;
+        any = true;
+        M.out[k] = const_cast<float*>(out[k]); M.x[k] = x[k]; M.aggr[k] = aggr[k]; M.W[k] = W[k];
+        M.gx[k] = grad_x[k]; M.gaggr[k] = grad_aggr[k]; M.gW[k] = grad_W[k]; M.gb[k] = grad_b[k];
+        M.pW[k] = (float*)((char*)workspace + k * per);
+        M.pb[k] = M.pW[k] + nb * D * 2 * D;
+    }
+    if (!any) return SGNN_OK;
+    hipStream_t st = (hipStream_t)stream;
+    {
+        const dim3 grid((unsigned)((R + 31) / 32), (unsigned)(2 * D / 32), (unsigned)n);
+        if (D == 32) hipLaunchKernelGGL((update_bwd_dx_kernel<32, true>), grid, dim3(64), 0, st, nullptr, nullptr, nullptr, R, nullptr, nullptr, M);
+        else if (D == 64) hipLaunchKernelGGL((update_bwd_dx_kernel<64, true>), grid, dim3(64), 0, st, nullptr, nullptr, nullptr, R, nullptr, nullptr, M);
+        else hipLaunchKernelGGL((update_bwd_dx_kernel<128, true>), grid, dim3(64), 0, st, nullptr, nullptr, nullptr, R, nullptr, nullptr, M);
+        SGNN_CHECK_LAUNCH();
+    }
+    {
+        const dim3 grid((unsigned)nb, (unsigned)(D / 32), (unsigned)n);
+        if (D == 32) hipLaunchKernelGGL((update_bwd_dw_kernel<32, UPD_WAVE_ROWS_SMALL>), grid, dim3(256), 0, st, nullptr, nullptr, nullptr, nullptr, R, nullptr, nullptr, M);
+        else if (D == 64) hipLaunchKernelGGL((update_bwd_dw_kernel<64, UPD_WAVE_ROWS_SMALL>), grid, dim3(256), 0, st, nullptr, nullptr, nullptr, nullptr, R, nullptr, nullptr, M);
+        else hipLaunchKernelGGL((update_bwd_dw_kernel<128, UPD_WAVE_ROWS_SMALL>), grid, dim3(256), 0, st, nullptr, nullptr, nullptr, nullptr, R, nullptr, nullptr, M);
+        SGNN_CHECK_LAUNCH();
+    }
+    const unsigned nW = (unsigned)((D * 2 * D + 63) / 64), nB = (unsigned)((D + 63) / 64);
+    hipLaunchKernelGGL(update_reduce_kernel, dim3(nW + nB, 1, (unsigned)n), dim3(256), 0, st, nullptr, nb, D * 2 * D, nullptr, nW, nullptr, D, nullptr, M);
+    SGNN_CHECK_LAUNCH();
     return SGNN_OK;
 }
 

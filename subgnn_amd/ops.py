@@ -1479,6 +1479,94 @@ def update_layer(x, aggr, weight, bias):
     return torch.relu(linear(torch.cat([x, aggr], dim=1), weight, bias))
 
 
+class PendingUpdate:
+    """An update layer that has not run yet: relu([x | aggr] W^T + b) for x (R, D), aggr (R, D) or the (chunks, R, D) partials
+    of ops.mpn -- what SG_MPN hands back when the caller collects the bodies of a layer (``update_layers``)."""
+
+    def __init__(self, x, aggr, weight, bias, shape):
+        self.x, self.aggr, self.weight, self.bias, self.shape = x, aggr, weight, bias, tuple(shape)
+
+
+def _ptr_table(ts):
+    return np.array([0 if t is None else t.data_ptr() for t in ts], dtype=np.uint64)
+
+
+class _UpdateLayerMany(torch.autograd.Function):
+    """n update layers of one shape in one launch each way (sgnn_update_fwd_many / sgnn_update_bwd_many): the bodies of one
+    message-passing layer of a batch-sized step.  Inputs: n, then (x, aggr, W, b) per body; outputs: n tensors (R, D)."""
+
+    @staticmethod
+    def forward(ctx, n, *ts):
+        lib = _lib.load()
+        xs, ags, Ws, bs = ts[0::4], ts[1::4], ts[2::4], ts[3::4]
+        R, D = xs[0].shape
+        for x, a, W, b in zip(xs, ags, Ws, bs):
+            for t, nm in ((x, 'x'), (a, 'aggr'), (W, 'W'), (b, 'b')):
+                _req(t, torch.float32, nm)
+            if tuple(x.shape) != (R, D) or tuple(a.shape[-2:]) != (R, D) or tuple(W.shape) != (D, 2 * D) or b is None:
+                raise ValueError('update layers of different shapes in one launch')
+        dev = xs[0].device
+        outs = [torch.empty((R, D), dtype=torch.float32, device=dev) for _ in range(n)]
+        chunks = [a.shape[0] if a.dim() == 3 else 1 for a in ags]
+        sums = [torch.empty((R, D), dtype=torch.float32, device=dev) if c > 1 else None for c in chunks]
+        nch = np.array(chunks, dtype=np.int64)
+        px, pa, pW, pb, po, ps = (_ptr_table(v) for v in (xs, ags, Ws, bs, outs, sums))
+        check(lib.sgnn_update_fwd_many(n, px.ctypes.data, pa.ctypes.data, nch.ctypes.data, pW.ctypes.data, pb.ctypes.data, R, D,
+                                       po.ctypes.data, ps.ctypes.data, _stream()), 'sgnn_update_fwd_many')
+        kept = [s_ if s_ is not None else (a[0] if a.dim() == 3 else a) for a, s_ in zip(ags, sums)]
+        ctx.save_for_backward(*xs, *kept, *Ws, *outs)
+        ctx.n, ctx.chunks, ctx.three_d = n, chunks, [a.dim() == 3 for a in ags]
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        lib = _lib.load()
+        n = ctx.n
+        sv = ctx.saved_tensors
+        xs, ags, Ws, outs = sv[:n], sv[n:2 * n], sv[2 * n:3 * n], sv[3 * n:4 * n]
+        R, D = xs[0].shape
+        dev = xs[0].device
+        gs = [g.contiguous() if g is not None else None for g in gs]
+        need = ctx.needs_input_grad
+        gx = [torch.empty_like(xs[k]) if gs[k] is not None and need[1 + 4 * k] else None for k in range(n)]
+        ga = [torch.empty((R, D), dtype=torch.float32, device=dev) if gs[k] is not None and need[2 + 4 * k] else None for k in range(n)]
+        gW = [torch.empty_like(Ws[k]) if gs[k] is not None else None for k in range(n)]
+        gb = [torch.empty(D, dtype=torch.float32, device=dev) if gs[k] is not None else None for k in range(n)]
+        per = lib.sgnn_update_bwd_workspace_bytes(R, D)
+        ws = torch.empty(n * per // 4 + 1, dtype=torch.float32, device=dev)
+        pg, po, px, pa, pW, pgx, pga, pgW, pgb = (_ptr_table(v) for v in (gs, outs, xs, ags, Ws, gx, ga, gW, gb))
+        check(lib.sgnn_update_bwd_many(n, pg.ctypes.data, po.ctypes.data, px.ctypes.data, pa.ctypes.data, pW.ctypes.data, R, D,
+                                       pgx.ctypes.data, pga.ctypes.data, pgW.ctypes.data, pgb.ctypes.data, _ptr(ws), n * per, _stream()),
+              'sgnn_update_bwd_many')
+        res = [None]
+        for k in range(n):
+            a = ga[k]
+            if a is not None and ctx.three_d[k]:
+                a = a.unsqueeze(0).expand(ctx.chunks[k], R, D)       # d(sum over chunks): the same gradient for every chunk
+            res += [gx[k], a, gW[k] if need[3 + 4 * k] else None, gb[k] if need[4 + 4 * k] else None]
+        return tuple(res)
+
+
+def update_layers(pending):
+    """The update layers of a list of PendingUpdate (the bodies of one message-passing layer) -> their outputs, in order: one
+    launch each way for the batch-sized shape, else one after the other (``update_layer``)."""
+    if not pending:
+        return []
+    p0 = pending[0]
+    R, D = p0.x.shape
+    same = all(tuple(p.x.shape) == (R, D) and p.bias is not None for p in pending)
+    if len(pending) >= 2 and same and p0.x.is_cuda and p0.x.dtype == torch.float32 and D in UPDATE_DIMS and 0 < R <= update_chunks_max_rows():
+        outs, cap = [], int(_lib.load().sgnn_update_many_max_bodies())
+        for lo in range(0, len(pending), cap):
+            group = pending[lo:lo + cap]
+            flat = []
+            for p in group:
+                flat += [p.x.contiguous(), p.aggr.contiguous(), p.weight, p.bias]
+            outs += list(_UpdateLayerMany.apply(len(group), *flat))
+        return outs
+    return [update_layer(p.x, p.aggr, p.weight, p.bias) for p in pending]
+
+
 @functools.lru_cache(maxsize=None)
 def update_chunks_max_rows():
     return int(_lib.load().sgnn_update_fwd_chunks_max_rows())

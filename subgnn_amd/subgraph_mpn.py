@@ -24,25 +24,29 @@ class SG_MPN(nn.Module):
         self.linear_position = nn.Linear(D, 1)
 
     # -- shared tail: update() and the read-out non-linearity (mpn:122-131, 233-241) -------
-    def _finish(self, cc_embeds, agg, z, need_out=True, need_pos=True, activated=False):
+    def _finish(self, cc_embeds, agg, z, need_out=True, need_pos=True, activated=False, defer_update=False):
         B, C, D = cc_embeds.shape
         if not need_out:
             # the caller reads only the position read-out of this layer (the last layer of the position / structure
             # channels: their updated component embeddings would feed a next layer that does not exist)
             out = None
+        elif self.hparams['use_mpn_projection'] and defer_update:
+            # the caller collects the bodies of this layer and runs their update layers together (ops.update_layers)
+            out = ops.PendingUpdate(cc_embeds.reshape(B * C, D), agg, self.linear.weight, self.linear.bias, (B, C))
         elif self.hparams['use_mpn_projection']:
             # applied to every component row, padded ones included (mpn:168,239)
             out = ops.update_layer(cc_embeds.reshape(B * C, D), agg, self.linear.weight, self.linear.bias)
         else:
             out = agg if agg.dim() == 2 else (agg[0] if agg.shape[0] == 1 else agg.sum(0))
+        shaped = (lambda o: o if (o is None or isinstance(o, ops.PendingUpdate)) else o.view(B, C, -1))
         if not need_pos:                     # the neighbourhood channel hands on its component embeddings only
-            return (out.view(B, C, -1) if out is not None else None), None
+            return shaped(out), None
         z = z.view(B, C, -1)
         if self.hparams.get('norm_pos_struc_embed', False):
             pos = F.normalize(z, p=2, dim=-1)
         else:
             pos = z if activated else F.relu(z)       # (activated: the layer kernel wrote relu(z) itself)
-        return (out.view(B, C, -1) if out is not None else None), pos
+        return shaped(out), pos
 
     def forward(self, networkx_graph, sims, cc_ids, cc_embeds, cc_embed_mask, anchor_patches, anchor_embeds,
                 anchor_mask, anchors_sim_index):
@@ -62,7 +66,7 @@ class SG_MPN(nn.Module):
         return self._finish(cc_embeds, agg, z)
 
     def forward_fused(self, sims, cc_embeds, cc_embed_mask, *, src, x, ids=None, id_div=1, sim_col=None,
-                      sims_per_edge=False, need_out=True, defer_readout=False, need_pos=True, edge_plan=None):
+                      sims_per_edge=False, need_out=True, defer_readout=False, need_pos=True, edge_plan=None, defer_update=False):
         """Fast path used by SubGNN.forward: the anchor rows are gathered inside the kernel
         (src GATHER: x = embedding table, ids (R/id_div, A)) or shared by all rows (src SHARED:
         x (A,D)), so the (B,C,A,D) tensor of get_anchor_patches is never materialised."""
@@ -92,7 +96,7 @@ class SG_MPN(nn.Module):
         if isinstance(sims, ops.ZeroSims):          # all edge weights 0: messages vanish, read-out = bias
             agg = torch.zeros((R, D), dtype=cc_embeds.dtype, device=cc_embeds.device)
             z = self.linear_position.bias.view(1, 1).expand(R, A)
-            return self._finish(cc_embeds, agg, z, need_out, need_pos)
+            return self._finish(cc_embeds, agg, z, need_out, need_pos, defer_update=defer_update)
         # (SubGNN._forward converts the mask once per forward and hangs it on the tensor: one launch instead of one per layer)
         relu_z = bool(need_pos and not self.hparams.get('norm_pos_struc_embed', False))
         # (the anchor-chunk partials of a batch-sized call go to the update layer as they are: it adds them while loading)
@@ -100,4 +104,4 @@ class SG_MPN(nn.Module):
                          id_div=id_div, row_mask=row_mask, sim_col=sim_col, sims_per_edge=sims_per_edge,
                          need_agg=need_out, edge_plan=edge_plan,
                          keep_chunks=bool(need_out and self.hparams['use_mpn_projection']), relu_z=relu_z)
-        return self._finish(cc_embeds, agg, z, need_out, need_pos, activated=relu_z)
+        return self._finish(cc_embeds, agg, z, need_out, need_pos, activated=relu_z, defer_update=defer_update)
