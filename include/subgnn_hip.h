@@ -452,6 +452,11 @@ typedef struct sgnn_mpn_args {
  * chunks up (a fixed order: no atomics).  agg: (chunks, R, D); 1 chunk for shard-sized calls. */
 int sgnn_mpn_fwd_chunks(const sgnn_mpn_args* args);
 int sgnn_mpn_fwd(const sgnn_mpn_args* args, float* agg /*(chunks,R,D)*/, float* z /*(R,A)*/, void* stream);
+/* The bodies of ONE message-passing layer (up to sgnn_mpn_fwd_many_max_bodies(): they read the layer below only) in one launch:
+ * args is a HOST array of n argument blocks, agg[k] / z[k] (HOST arrays of DEVICE pointers) as sgnn_mpn_fwd writes them for
+ * args[k] (agg[k]: sgnn_mpn_fwd_chunks(&args[k]) chunks; z[k] nullable).  Every body needs R > 0 and A > 0. */
+int64_t sgnn_mpn_fwd_many_max_bodies(void);
+int sgnn_mpn_fwd_many(int64_t n, const sgnn_mpn_args* args, float* const* agg, float* const* z, void* stream);
 /* grad_x: DENSE (R,A,D) written; GATHER (rows,D) accumulated with float atomics, row PAD
  * untouched (the atomics-free form of GATHER: sgnn_mpn_bwd_edges + sgnn_scatter_add_rows_sorted); SHARED (A,D)
  * accumulated.  grad_wp (D) accumulated, or (R,D) written with SGNN_MPN_WP_PARTIAL.  Any of them may be NULL. */

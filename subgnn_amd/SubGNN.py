@@ -726,6 +726,7 @@ class SubGNN(nn.Module):
                  P_B_cc_embed, subgraph_ids, cc_ids, subgraph_idx, NP_sim, I_S_sim, B_S_sim):
         hp = self.hparams
         fused = hp.get('fused_forward', True)
+        ops.drop_lazy_mpn()                                 # (launches a forward that did not finish left queued)
         init_cc_embeds = self.initialize_cc_embeddings(cc_ids, hp['cc_aggregator'])
         sidx = subgraph_idx.view(-1)
         # hotpath.full_split_batch: the batch IS the split, in order -- selecting its rows would be a copy
@@ -767,6 +768,7 @@ class SubGNN(nn.Module):
                                                   inside=inside)
                     bodies.append([slot, pick, o, p, layer[bnname] if bn else None])
             pending = [b for b in bodies if isinstance(b[2], ops.PendingUpdate)]
+            ops.flush_lazy_mpn()                       # the layer's queued message-passing launches, as one
             for b, o in zip(pending, ops.update_layers([b[2] for b in pending])):
                 b[2] = o.view(b[2].shape[0], b[2].shape[1], -1)
             for slot, pick, o, p, bn_layer in bodies:

@@ -81,6 +81,8 @@ SIGNATURES = {
     'sgnn_cc_embed_bwd': (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_int, c_ptr, c_ptr, c_ptr]),
     'sgnn_mpn_fwd_chunks': (c_int, [ctypes.POINTER(MpnArgs)]),
     'sgnn_mpn_fwd': (c_int, [ctypes.POINTER(MpnArgs), c_ptr, c_ptr, c_ptr]),
+    'sgnn_mpn_fwd_many_max_bodies': (c_i64, []),
+    'sgnn_mpn_fwd_many': (c_int, [c_i64, c_ptr, c_ptr, c_ptr, c_ptr]),
     'sgnn_mpn_bwd': (c_int, [ctypes.POINTER(MpnArgs), c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
     'sgnn_attn_scores_epilogue': (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_ptr, c_ptr]),
     'sgnn_attn_scores_f16_workspace_bytes': (c_i64, [c_i64]),

@@ -30,9 +30,11 @@ __device__ static inline float group_sum(float v, int lanes) {
 
 #define MPN_U 4
 // T: element type of the GATHER table (float, or __half for an fp16-stored table; fp32 accumulate)
+// (bx, gx, by, gy: the workgroup's place in its body's own grid -- blockIdx / gridDim for a single launch, a body's share of a
+// many-bodies launch otherwise)
 template <int SRC, typename T = float>
-__global__ __launch_bounds__(256) void mpn_fwd_kernel(sgnn_mpn_args a, float* __restrict__ agg, float* __restrict__ z,
-                                                      int64_t D4)
+__device__ __forceinline__ void mpn_fwd_body(const sgnn_mpn_args& a, float* __restrict__ agg, float* __restrict__ z, int64_t D4,
+                                             int64_t bx, int64_t gx, int64_t by, int64_t gy)
 {
     const int64_t total = a.R * D4;
     const float4* x4 = reinterpret_cast<const float4*>(a.x);
@@ -42,10 +44,10 @@ __global__ __launch_bounds__(256) void mpn_fwd_kernel(sgnn_mpn_args a, float* __
     const bool relu_z = (a.flags & SGNN_MPN_RELU_Z) != 0;
     // batch-sized calls (a few hundred component rows) do not fill the chip with one lane group per row and
     // walk their anchors one dependent load after the other: the anchors are then split over grid.y
-    const int64_t a_per = (a.A + gridDim.y - 1) / gridDim.y;
-    const int64_t a0 = blockIdx.y * a_per;
+    const int64_t a_per = (a.A + gy - 1) / gy;
+    const int64_t a0 = by * a_per;
     const int64_t a1 = a0 + a_per < a.A ? a0 + a_per : a.A;
-    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t t = bx * (int64_t)blockDim.x + threadIdx.x; t < total; t += gx * blockDim.x) {
         const int64_t r = t / D4, dv = t % D4;
         const bool row_real = a.row_mask ? (a.row_mask[r] != 0) : true;
         const float4 wp = reinterpret_cast<const float4*>(a.wp)[dv];
@@ -110,8 +112,37 @@ __global__ __launch_bounds__(256) void mpn_fwd_kernel(sgnn_mpn_args a, float* __
             }
         }
         // anchor chunks of one row: each writes its partial aggregate to its own (R, D) slice, the caller adds them up
-        reinterpret_cast<float4*>(agg)[(int64_t)blockIdx.y * total + t] = acc;
+        reinterpret_cast<float4*>(agg)[by * total + t] = acc;
     }
+}
+
+template <int SRC, typename T = float>
+__global__ __launch_bounds__(256) void mpn_fwd_kernel(sgnn_mpn_args a, float* __restrict__ agg, float* __restrict__ z,
+                                                      int64_t D4)
+{
+    mpn_fwd_body<SRC, T>(a, agg, z, D4, blockIdx.x, gridDim.x, blockIdx.y, gridDim.y);
+}
+
+// The layer bodies of ONE message-passing layer (up to three channels x two sides of a batch-sized step: they read the layer
+// below only) in one launch: blockIdx.z = body; a body's own grid is (gx[k], chunks[k]) inside the launch's (max, max).
+#define MPN_MAX_BODIES 8
+struct MpnMany {
+    sgnn_mpn_args a[MPN_MAX_BODIES];
+    float* agg[MPN_MAX_BODIES];
+    float* z[MPN_MAX_BODIES];
+    int gx[MPN_MAX_BODIES], gy[MPN_MAX_BODIES];
+};
+
+__global__ __launch_bounds__(256) void mpn_fwd_many_kernel(const MpnMany M)
+{
+    const int k = blockIdx.z;
+    if ((int)blockIdx.x >= M.gx[k] || (int)blockIdx.y >= M.gy[k]) return;
+    const sgnn_mpn_args& a = M.a[k];
+    const int64_t D4 = a.D / 4;
+    if (a.src == SGNN_SRC_DENSE) mpn_fwd_body<SGNN_SRC_DENSE>(a, M.agg[k], M.z[k], D4, blockIdx.x, M.gx[k], blockIdx.y, M.gy[k]);
+    else if (a.src == SGNN_SRC_GATHER && a.x_f16) mpn_fwd_body<SGNN_SRC_GATHER, __half>(a, M.agg[k], M.z[k], D4, blockIdx.x, M.gx[k], blockIdx.y, M.gy[k]);
+    else if (a.src == SGNN_SRC_GATHER) mpn_fwd_body<SGNN_SRC_GATHER>(a, M.agg[k], M.z[k], D4, blockIdx.x, M.gx[k], blockIdx.y, M.gy[k]);
+    else mpn_fwd_body<SGNN_SRC_SHARED>(a, M.agg[k], M.z[k], D4, blockIdx.x, M.gx[k], blockIdx.y, M.gy[k]);
 }
 
 // backward for DENSE (grad_x written) and GATHER (grad_x accumulated with atomics)
@@ -609,5 +640,29 @@ extern "C" int sgnn_mpn_bwd_shared_det(const sgnn_mpn_args* args, const float* g
     return SGNN_OK;
 }
 
+
+extern "C" int64_t sgnn_mpn_fwd_many_max_bodies(void) { return MPN_MAX_BODIES; }
+
+/* args: HOST array of n sgnn_mpn_args; agg[k] (sgnn_mpn_fwd_chunks(&args[k]), R_k, D_k) and z[k] (R_k, A_k) as sgnn_mpn_fwd writes
+ * them (z[k] nullable).  Bodies with R = 0 or A = 0 are the caller's to handle. */
+extern "C" int sgnn_mpn_fwd_many(int64_t n, const sgnn_mpn_args* args, float* const* agg, float* const* z, void* stream)
+{
+    if (n < 1 || n > MPN_MAX_BODIES || !args || !agg || !z) return SGNN_ERR_BAD_ARG;
+    MpnMany M;
+    int mx = 0, my = 0;
+    for (int k = 0; k < n; ++k) {
+        const int rc = mpn_check(&args[k]);
+        if (rc != SGNN_OK) return rc;
+        if (!agg[k] || args[k].R <= 0 || args[k].A <= 0) return SGNN_ERR_BAD_ARG;
+        M.a[k] = args[k]; M.agg[k] = agg[k]; M.z[k] = z[k];
+        M.gx[k] = sgnn_grid_for(args[k].R * (args[k].D / 4), 256);
+        M.gy[k] = mpn_fwd_chunks(&args[k]);
+        if (M.gx[k] > mx) mx = M.gx[k];
+        if (M.gy[k] > my) my = M.gy[k];
+    }
+    hipLaunchKernelGGL(mpn_fwd_many_kernel, dim3(mx, my, (unsigned)n), dim3(256), 0, (hipStream_t)stream, M);
+    SGNN_CHECK_LAUNCH();
+    return SGNN_OK;
+}
 
 SGNN_DEFINE_WARM(mpn)

@@ -1167,12 +1167,44 @@ def _mpn_args(src, x, ids, id_div, edge_mask, row_mask, sims, sim_col, sims_per_
     return a
 
 
+# Forward launches of layer bodies that wait for each other (ops.mpn(lazy=True)): the bodies of one message-passing layer read the
+# layer below only, so their kernels go out as ONE launch when the first consumer needs a result -- ``flush_lazy_mpn`` (called by
+# ``update_layers`` and by the layer loop of SubGNN.forward after every layer).  Entries keep their tensors alive.
+_LAZY_MPN = []
+
+
+def flush_lazy_mpn():
+    """Launch the queued layer bodies (sgnn_mpn_fwd_many, up to 8 per launch)."""
+    global _LAZY_MPN
+    queue, _LAZY_MPN = _LAZY_MPN, []
+    if not queue:
+        return
+    lib = _lib.load()
+    cap = int(lib.sgnn_mpn_fwd_many_max_bodies())
+    for lo in range(0, len(queue), cap):
+        group = queue[lo:lo + cap]
+        if len(group) == 1:
+            a, agg, z, _keep = group[0]
+            check(lib.sgnn_mpn_fwd(ctypes.byref(a), _ptr(agg), _ptr(z), _stream()), 'sgnn_mpn_fwd')
+            continue
+        arr = (MpnArgs * len(group))(*[g[0] for g in group])
+        pa, pz = _ptr_table([g[1] for g in group]), _ptr_table([g[2] for g in group])
+        check(lib.sgnn_mpn_fwd_many(len(group), ctypes.cast(arr, ctypes.c_void_p), pa.ctypes.data, pz.ctypes.data, _stream()),
+              'sgnn_mpn_fwd_many')
+
+
+def drop_lazy_mpn():
+    """Forget queued launches (a forward that did not finish)."""
+    global _LAZY_MPN
+    _LAZY_MPN = []
+
+
 class _MPN(torch.autograd.Function):
     """agg (R,D), z (R,A) = gather-weight-aggregate + read-out; grads for x, wp (bp via z)."""
 
     @staticmethod
     def forward(ctx, x, wp, bp, sims, ids, edge_mask, row_mask, sim_col, src, id_div, sims_per_edge, R, A, edge_plan=None,
-                keep_chunks=False, relu_z=False):
+                keep_chunks=False, relu_z=False, lazy=False):
         lib = _lib.load()
         ctx.edge_plan = edge_plan if src == SRC_GATHER else None
         ctx.relu_z = bool(relu_z)
@@ -1194,7 +1226,11 @@ class _MPN(torch.autograd.Function):
                 a.flags = 2                                         # SGNN_MPN_RELU_Z: the read-out leaves the kernel activated
             chunks = lib.sgnn_mpn_fwd_chunks(ctypes.byref(a))       # batch-sized calls split a row's anchors
             agg = torch.empty((chunks, R, D), dtype=torch.float32, device=x.device)
-            check(lib.sgnn_mpn_fwd(ctypes.byref(a), _ptr(agg), _ptr(z), _stream()), 'sgnn_mpn_fwd')
+            if lazy and keep_chunks and R > 0:
+                # the launch waits for the other bodies of its layer (flush_lazy_mpn); nothing reads agg / z before that
+                _LAZY_MPN.append((a, agg, z, (x, wp, bp, sims, ids, edge_mask, row_mask, sim_col, getattr(x, '_sgnn_half', None))))
+            else:
+                check(lib.sgnn_mpn_fwd(ctypes.byref(a), _ptr(agg), _ptr(z), _stream()), 'sgnn_mpn_fwd')
             if not keep_chunks:
                 agg = agg[0] if chunks == 1 else agg.sum(0)          # a fixed order: no atomics
             # (keep_chunks: the (chunks, R, D) partials go to update_layer, which adds them while it loads them)
@@ -1300,7 +1336,7 @@ class _MPN(torch.autograd.Function):
             if g_z is not None and z_gate is not None:          # gated inside the kernels only: the sum needs the gated values
                 g_z = torch.ops.aten.threshold_backward(g_z, z_gate, 0.0)
             gbp = g_z.sum().view_as(bp) if g_z is not None else torch.zeros_like(bp)
-        return (None if ctx.acc is not None else gx), gwp, gbp, None, None, None, None, None, None, None, None, None, None, None, None, None
+        return (None if ctx.acc is not None else gx), gwp, gbp, None, None, None, None, None, None, None, None, None, None, None, None, None, None
 
 
 def column_sum(t, chunk=512):
@@ -1550,6 +1586,7 @@ class _UpdateLayerMany(torch.autograd.Function):
 def update_layers(pending):
     """The update layers of a list of PendingUpdate (the bodies of one message-passing layer) -> their outputs, in order: one
     launch each way for the batch-sized shape, else one after the other (``update_layer``)."""
+    flush_lazy_mpn()                                 # the aggregates below come from layer bodies that may still be queued
     if not pending:
         return []
     p0 = pending[0]
@@ -1753,11 +1790,13 @@ def mpn_edge_plan(sims, ids, row_mask, *, R, A, D, max_key, id_div=1, sim_col=No
 
 
 def mpn(x, wp, bp, sims, *, src, R, A, ids=None, id_div=1, edge_mask=None, row_mask=None, sim_col=None,
-        sims_per_edge=False, need_agg=True, edge_plan=None, keep_chunks=False, relu_z=False):
+        sims_per_edge=False, need_agg=True, edge_plan=None, keep_chunks=False, relu_z=False, lazy=False):
     """Fused anchor->component layer body.  x: DENSE (R,A,D) | GATHER E (rows,D) | SHARED (A,D).
     Returns agg (R,D) and the pre-activation read-out z (R,A).  ``keep_chunks``: agg may come back as the (chunks, R, D)
     anchor-chunk partials of a batch-sized call, for a consumer that adds them itself (``update_layer``).  ``relu_z``: the
-    read-out comes back activated, relu(z) (what generate_pos_struc_embeddings, mpn:122-131, makes of it next)."""
+    read-out comes back activated, relu(z) (what generate_pos_struc_embeddings, mpn:122-131, makes of it next).  ``lazy`` (with
+    keep_chunks): the forward launch is queued and goes out with the other bodies of its layer (``flush_lazy_mpn``) -- the caller
+    must not read agg or z before that."""
     sims2 = sims.reshape(R, -1)
     if not sims2.is_contiguous():
         sims2 = sims2.contiguous()
@@ -1765,7 +1804,7 @@ def mpn(x, wp, bp, sims, *, src, R, A, ids=None, id_div=1, edge_mask=None, row_m
         agg, z = _mpn_shared_gemm(x, wp, bp, sims2, ids, row_mask, sim_col, sims_per_edge, R, A, need_agg)
         return agg, (torch.relu(z) if relu_z else z)
     return _MPN.apply(x.contiguous(), wp.contiguous().view(-1), bp.contiguous().view(-1), sims2, ids, edge_mask,
-                      row_mask, sim_col, src, id_div, sims_per_edge, R, A, edge_plan, keep_chunks, relu_z)
+                      row_mask, sim_col, src, id_div, sims_per_edge, R, A, edge_plan, keep_chunks, relu_z, lazy)
 
 
 class _MaskedSum(torch.autograd.Function):

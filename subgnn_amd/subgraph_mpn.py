@@ -103,5 +103,8 @@ class SG_MPN(nn.Module):
         agg, z = ops.mpn(x, self.linear_position.weight, self.linear_position.bias, sims, src=src, R=R, A=A, ids=ids,
                          id_div=id_div, row_mask=row_mask, sim_col=sim_col, sims_per_edge=sims_per_edge,
                          need_agg=need_out, edge_plan=edge_plan,
-                         keep_chunks=bool(need_out and self.hparams['use_mpn_projection']), relu_z=relu_z)
+                         keep_chunks=bool(need_out and self.hparams['use_mpn_projection']), relu_z=relu_z,
+                         # (queued with the other bodies of the layer when the caller collects them: it runs ops.update_layers /
+                         # ops.flush_lazy_mpn before anything reads agg or the read-out; a read-out that is normalised here is read here)
+                         lazy=bool(defer_update and (relu_z or not need_pos)))
         return self._finish(cc_embeds, agg, z, need_out, need_pos, activated=relu_z, defer_update=defer_update)
