@@ -1552,6 +1552,7 @@ class _UpdateLayerMany(torch.autograd.Function):
         kept = [s_ if s_ is not None else (a[0] if a.dim() == 3 else a) for a, s_ in zip(ags, sums)]
         ctx.save_for_backward(*xs, *kept, *Ws, *outs)
         ctx.n, ctx.chunks, ctx.three_d = n, chunks, [a.dim() == 3 for a in ags]
+        ctx.set_materialize_grads(False)             # a body whose output nobody reads arrives as None: its backward is skipped
         return tuple(outs)
 
     @staticmethod

@@ -139,6 +139,71 @@ def test_mpn_gather_random(D, A, det):
     assert float(Eg.grad[0].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize('D', [32, 128])
+def test_layer_bodies_together_equal_one_after_the_other(D, det):
+    """The batch-sized step's per-layer form -- the bodies' forward launches queued and sent as one (ops.mpn(lazy=True) +
+    ops.flush_lazy_mpn -> sgnn_mpn_fwd_many), their update layers in one launch each way (ops.update_layers ->
+    sgnn_update_fwd_many / _bwd_many) -- against the same bodies run one after the other: a GATHER body with 70 anchors (its
+    anchors split into chunks), a GATHER body with 9, a SHARED body, a body whose aggregate is all zero, one whose updated
+    embeddings nobody reads (no gradient arrives: its backward is skipped).  Outputs and every gradient bit for bit."""
+    ops = _ops()
+    R, N, C = 96, 300, 4
+    g = torch.Generator().manual_seed(D)
+    cases = []
+    for A in (70, 9):
+        E, ids, row_mask, sims, wp, bp, _, _ = _rand_case(D + A, R, A, D, N, C)
+        cases.append(dict(src=ops.SRC_GATHER, x=E, ids=ids, sims=sims, A=A, wp=wp, bp=bp, row_mask=row_mask, sim_col=None))
+    A = 40
+    X = torch.randn(A, D, generator=g)
+    cases.append(dict(src=ops.SRC_SHARED, x=X, ids=None, sims=torch.rand(R, A + 5, generator=g), A=A, wp=torch.randn(1, D, generator=g) * 0.3,
+                      bp=torch.randn(1, generator=g) * 0.1, row_mask=torch.rand(R, generator=g) > 0.2,
+                      sim_col=torch.randperm(A + 5, generator=g)[:A]))
+    cc = [torch.randn(R, D, generator=g) for _ in range(5)]
+    Ws = [torch.randn(D, 2 * D, generator=g) / (2 * D) ** 0.5 for _ in range(5)]
+    bs = [torch.randn(D, generator=g) * 0.1 for _ in range(5)]
+    go = [torch.randn(R, D, generator=g) for _ in range(5)]
+    gz = [torch.randn(R, c['A'], generator=g) for c in cases]
+
+    def run(together):
+        leaves = {}
+
+        def leaf(name, t):
+            leaves[name] = t.to(DEV).clone().requires_grad_(True)
+            return leaves[name]
+        pend, zs = [], []
+        for k, c in enumerate(cases):
+            agg, z = ops.mpn(leaf('x%d' % k, c['x']), leaf('wp%d' % k, c['wp']), leaf('bp%d' % k, c['bp']), c['sims'].to(DEV), src=c['src'],
+                             R=R, A=c['A'], ids=c['ids'].to(DEV) if c['ids'] is not None else None,
+                             row_mask=c['row_mask'].to(torch.uint8).to(DEV), sim_col=c['sim_col'].to(DEV) if c['sim_col'] is not None else None,
+                             keep_chunks=True, relu_z=True, lazy=together)
+            zs.append(z)
+            pend.append(ops.PendingUpdate(leaf('cc%d' % k, cc[k]), agg, leaf('W%d' % k, Ws[k]), leaf('b%d' % k, bs[k]), (R // C, C)))
+        zero = torch.zeros(R, D, device=DEV)
+        for k in (3, 4):                                           # all-zero aggregate; a body nobody reads
+            pend.append(ops.PendingUpdate(leaf('cc%d' % k, cc[k]), zero, leaf('W%d' % k, Ws[k]), leaf('b%d' % k, bs[k]), (R // C, C)))
+        if together:
+            assert len(ops._LAZY_MPN) == 3
+            outs = ops.update_layers(pend)
+            assert not ops._LAZY_MPN
+        else:
+            outs = [ops.update_layer(p.x, p.aggr, p.weight, p.bias) for p in pend]
+        loss = sum((o * go[k].to(DEV)).sum() for k, o in enumerate(outs) if k != 4) + sum((z * gz[k].to(DEV)).sum() for k, z in enumerate(zs))
+        loss.backward()
+        return [o.detach() for o in outs] + [z.detach() for z in zs], {n: t.grad for n, t in leaves.items()}
+    a_out, a_g = run(True)
+    b_out, b_g = run(False)
+    for i, (u, v) in enumerate(zip(a_out, b_out)):
+        assert torch.equal(u, v), i
+    assert a_g['W4'] is None and a_g['cc4'] is None and b_g['W4'] is None
+    for n in a_g:
+        if a_g[n] is None or b_g[n] is None:
+            assert a_g[n] is None and b_g[n] is None, n
+        elif det == 'sorted':
+            assert torch.equal(a_g[n], b_g[n]), n
+        else:
+            assert_close(a_g[n], b_g[n], 'grad ' + n, norm_tol=1e-5)
+
+
 @pytest.mark.parametrize('A', [9, 70])
 def test_mpn_dense_random(A, det):
     """SRC_DENSE (the reference-shaped (R, A, D) anchor tensor) on random inputs, with few and with many
