@@ -456,15 +456,35 @@ __global__ __launch_bounds__(256) void mpn_bwd_wp_partial_kernel(sgnn_mpn_args a
         float gw = 0.f;
         if (!a.row_mask || a.row_mask[r]) {
             const int64_t idrow = (a.id_div > 1 ? r / a.id_div : r) * a.A;
-            for (int64_t ai = 0; ai < a.A; ++ai) {
-                const int64_t id = a.ids[idrow + ai];
-                if (id == 0) continue;
-                const float gz = mpn_gz(a, grad_z, r * a.A + ai);
-                if (gz == 0.f) continue;
-                const int64_t col = a.sim_col ? a.sim_col[ai] : (a.sims_per_edge ? ai : id - 1);
-                const float w = a.sims[r * a.sims_ld + col];
-                if (w == 0.f) continue;
-                gw += gz * w * (a.x_f16 ? __half2float(reinterpret_cast<const __half*>(a.x)[id * D + d]) : a.x[id * D + d]);
+            // four anchors at a time: ids and read-out gradients, then weights, then table elements are requested together
+            // (one anchor after the other a row of 34-90 anchors was 4 A dependent round trips: 17 us for 128 rows)
+            for (int64_t ai0 = 0; ai0 < a.A; ai0 += MPN_U) {
+                int64_t id[MPN_U];
+                float gz[MPN_U], w[MPN_U], xv[MPN_U];
+#pragma unroll
+                for (int u = 0; u < MPN_U; ++u) {
+                    const int64_t ai = ai0 + u;
+                    id[u] = ai < a.A ? a.ids[idrow + ai] : 0;
+                    gz[u] = ai < a.A ? mpn_gz(a, grad_z, r * a.A + ai) : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < MPN_U; ++u) {
+                    const int64_t ai = ai0 + u;
+                    w[u] = 0.f;
+                    if (id[u] != 0 && gz[u] != 0.f) {
+                        const int64_t col = a.sim_col ? a.sim_col[ai] : (a.sims_per_edge ? ai : id[u] - 1);
+                        w[u] = a.sims[r * a.sims_ld + col];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < MPN_U; ++u) {
+                    xv[u] = 0.f;
+                    if (w[u] != 0.f)
+                        xv[u] = a.x_f16 ? __half2float(reinterpret_cast<const __half*>(a.x)[id[u] * D + d]) : a.x[id[u] * D + d];
+                }
+#pragma unroll
+                for (int u = 0; u < MPN_U; ++u)
+                    if (w[u] != 0.f) gw += gz[u] * w[u] * xv[u];
             }
         }
         partial[r * ld + d] = gw;
