@@ -626,6 +626,11 @@ int sgnn_mpn_bwd_edges(const struct sgnn_mpn_args* args, const float* grad_z, in
                        float* out_c2, void* stream);
 int sgnn_mpn_bwd_wp_partial(const struct sgnn_mpn_args* args, const float* grad_z, float* partial, int64_t partial_ld,
                             void* stream);
+/* sgnn_mpn_bwd_edges for up to sgnn_mpn_fwd_many_max_bodies() GATHER bodies in one launch (HOST arrays of n entries; out_c2[k] /
+ * grad_z[k] nullable as in the single form): the edge lists feed the step's combined table-gradient scatter, which runs when the
+ * table's gradient is handed over -- until then they can wait for each other. */
+int sgnn_mpn_bwd_edges_many(int64_t n, const struct sgnn_mpn_args* args, const float* const* grad_z, int32_t* const* out_keys,
+                            float* const* out_c1, float* const* out_c2, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * a12  update(): out = relu([x | aggr] W^T + b) and its backward (SubGNN/subgraph_mpn.py:233-241 with the

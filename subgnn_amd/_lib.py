@@ -147,6 +147,7 @@ SIGNATURES = {
     'sgnn_scatter_add_rows_multi': (c_int, [c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr,
                                             c_i64, c_ptr]),
     'sgnn_mpn_bwd_edges': (c_int, [ctypes.POINTER(MpnArgs), c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
+    'sgnn_mpn_bwd_edges_many': (c_int, [c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
     'sgnn_mpn_bwd_wp_partial': (c_int, [ctypes.POINTER(MpnArgs), c_ptr, c_ptr, c_i64, c_ptr]),
 }
 

@@ -414,12 +414,12 @@ __global__ __launch_bounds__(256) void mpn_bwd_shared_reduce_kernel(sgnn_mpn_arg
 // coefficients of its contribution  dE[id, :] += w * g_agg[r, :] + (w * g_z[r, ai]) * wp  -- the input of
 // sgnn_scatter_add_rows_sorted (scatter.hip) once the keys are sorted.  Masked edges (PAD anchor, padded
 // component row, weight exactly 0) get key 0.
-__global__ __launch_bounds__(256) void mpn_bwd_edges_kernel(sgnn_mpn_args a, const float* __restrict__ grad_z,
-                                                            int32_t* __restrict__ keys, float* __restrict__ c1,
-                                                            float* __restrict__ c2)
+__device__ __forceinline__ void mpn_bwd_edges_body(const sgnn_mpn_args& a, const float* __restrict__ grad_z,
+                                                   int32_t* __restrict__ keys, float* __restrict__ c1, float* __restrict__ c2,
+                                                   int64_t bx, int64_t gx)
 {
     const int64_t total = a.R * a.A;
-    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t e = bx * (int64_t)blockDim.x + threadIdx.x; e < total; e += gx * blockDim.x) {
         const int64_t r = e / a.A, ai = e % a.A;
         const bool row_real = a.row_mask ? (a.row_mask[r] != 0) : true;
         const int64_t id = a.ids[(a.id_div > 1 ? r / a.id_div : r) * a.A + ai];
@@ -432,6 +432,31 @@ __global__ __launch_bounds__(256) void mpn_bwd_edges_kernel(sgnn_mpn_args a, con
         c1[e] = w;
         if (c2) c2[e] = w * mpn_gz(a, grad_z, e);
     }
+}
+
+__global__ __launch_bounds__(256) void mpn_bwd_edges_kernel(sgnn_mpn_args a, const float* __restrict__ grad_z,
+                                                            int32_t* __restrict__ keys, float* __restrict__ c1,
+                                                            float* __restrict__ c2)
+{
+    mpn_bwd_edges_body(a, grad_z, keys, c1, c2, blockIdx.x, gridDim.x);
+}
+
+// the edge lists of several GATHER bodies in one launch (their consumer is the step's combined table-gradient scatter, which
+// runs when the table's gradient is handed over: the lists can wait for each other until then)
+struct MpnEdgesMany {
+    sgnn_mpn_args a[MPN_MAX_BODIES];
+    const float* gz[MPN_MAX_BODIES];
+    int32_t* keys[MPN_MAX_BODIES];
+    float* c1[MPN_MAX_BODIES];
+    float* c2[MPN_MAX_BODIES];
+    int gx[MPN_MAX_BODIES];
+};
+
+__global__ __launch_bounds__(256) void mpn_bwd_edges_many_kernel(const MpnEdgesMany M)
+{
+    const int k = blockIdx.y;
+    if ((int)blockIdx.x >= M.gx[k]) return;
+    mpn_bwd_edges_body(M.a[k], M.gz[k], M.keys[k], M.c1[k], M.c2[k], blockIdx.x, M.gx[k]);
 }
 
 // grad_wp of a GATHER layer as per-row partial sums (no atomics): partial[r, d] = sum_ai g_z[r, ai] * w * x[id, d];
@@ -599,6 +624,25 @@ extern "C" int sgnn_mpn_bwd_edges(const sgnn_mpn_args* args, const float* grad_z
     if (args->R * args->A == 0) return SGNN_OK;
     hipLaunchKernelGGL(mpn_bwd_edges_kernel, dim3(sgnn_grid_for(args->R * args->A, 256, 8192)), dim3(256), 0,
                        (hipStream_t)stream, *args, grad_z, out_keys, out_c1, out_c2);
+    SGNN_CHECK_LAUNCH();
+    return SGNN_OK;
+}
+
+extern "C" int sgnn_mpn_bwd_edges_many(int64_t n, const sgnn_mpn_args* args, const float* const* grad_z, int32_t* const* out_keys,
+                                       float* const* out_c1, float* const* out_c2, void* stream)
+{
+    if (n < 1 || n > MPN_MAX_BODIES || !args || !grad_z || !out_keys || !out_c1 || !out_c2) return SGNN_ERR_BAD_ARG;
+    MpnEdgesMany M;
+    int mx = 0;
+    for (int k = 0; k < n; ++k) {
+        const int rc = mpn_check(&args[k]);
+        if (rc != SGNN_OK) return rc;
+        if (args[k].src != SGNN_SRC_GATHER || !out_keys[k] || !out_c1[k] || args[k].R * args[k].A <= 0) return SGNN_ERR_BAD_ARG;
+        M.a[k] = args[k]; M.gz[k] = grad_z[k]; M.keys[k] = out_keys[k]; M.c1[k] = out_c1[k]; M.c2[k] = out_c2[k];
+        M.gx[k] = sgnn_grid_for(args[k].R * args[k].A, 256, 8192);
+        if (M.gx[k] > mx) mx = M.gx[k];
+    }
+    hipLaunchKernelGGL(mpn_bwd_edges_many_kernel, dim3(mx, (unsigned)n), dim3(256), 0, (hipStream_t)stream, M);
     SGNN_CHECK_LAUNCH();
     return SGNN_OK;
 }

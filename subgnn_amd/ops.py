@@ -996,6 +996,7 @@ class _GradAcc:
         self.buf = None
         self.owner = owner         # the parameter whose gradient this is (it may hold a buffer an optimizer zeroed)
         self.jobs = []             # short edge lists waiting to be scattered together (scatter_add_rows(together=))
+        self.producers = []        # layer bodies whose edge lists (keys, weights) are still to be written: (args, g_z, keys, c1, c2, keep)
 
     def buffer(self, shape, device):
         if self.buf is None:
@@ -1004,6 +1005,15 @@ class _GradAcc:
 
     def flush(self):
         """Scatter the pending lists into the buffer as one sorted list (sgnn_scatter_add_rows_multi)."""
+        producers, self.producers = self.producers, []
+        lib = _lib.load()
+        cap = int(lib.sgnn_mpn_fwd_many_max_bodies()) if producers else 1
+        for lo in range(0, len(producers), cap):                 # the waiting bodies' edge lists, eight bodies per launch
+            group = producers[lo:lo + cap]
+            arr = (MpnArgs * len(group))(*[g[0] for g in group])
+            pz, pk, p1, p2 = (_ptr_table([g[i] for g in group]) for i in (1, 2, 3, 4))
+            check(lib.sgnn_mpn_bwd_edges_many(len(group), ctypes.cast(arr, ctypes.c_void_p), pz.ctypes.data, pk.ctypes.data,
+                                              p1.ctypes.data, p2.ctypes.data, _stream()), 'sgnn_mpn_bwd_edges_many')
         jobs, self.jobs = self.jobs, []
         if not jobs:
             return
@@ -1014,7 +1024,6 @@ class _GradAcc:
             keys, G, edge_row, epr, c1, c2, v = jobs[0]
             scatter_add_rows(table, keys, G=G, edge_row=edge_row, edges_per_row=epr, c1=c1, c2=c2, v=v)
             return
-        lib = _lib.load()
         n = len(jobs)
         D = table.shape[1]
 
@@ -1294,9 +1303,20 @@ class _MPN(torch.autograd.Function):
                 keys = torch.empty(R * A, dtype=torch.int32, device=x.device)
                 c1 = torch.empty(R * A, dtype=torch.float32, device=x.device)
                 c2 = torch.empty(R * A, dtype=torch.float32, device=x.device) if g_z is not None else None
-                check(lib.sgnn_mpn_bwd_edges(ctypes.byref(a), _ptr(g_z), _ptr(keys), _ptr(c1), _ptr(c2), _stream()),
-                      'sgnn_mpn_bwd_edges')
+                waits = ctx.acc is not None and 0 < R * A < SCATTER_TOGETHER_BELOW and (g_agg is None or g_agg.shape[1] == D)
+                if waits:
+                    # the list joins the step's combined scatter (below): nothing reads it before the table's gradient is handed
+                    # over, so its launch waits for the other bodies' too (_GradAcc.flush -> sgnn_mpn_bwd_edges_many)
+                    a2 = _mpn_args(src, x, ids, id_div, edge_mask, row_mask, sims, sim_col, sims_per_edge, wp, bp, R, A, D)
+                    a2.z_act = _ptr(z_gate)
+                    ctx.acc.producers.append((a2, g_z, keys, c1, c2, (x, ids, row_mask, sims, sim_col, z_gate, ctx.half)))
+                else:
+                    check(lib.sgnn_mpn_bwd_edges(ctypes.byref(a), _ptr(g_z), _ptr(keys), _ptr(c1), _ptr(c2), _stream()),
+                          'sgnn_mpn_bwd_edges')
+                n_jobs = len(ctx.acc.jobs) if ctx.acc is not None else 0
                 scatter_add_rows(gx, keys, G=g_agg, edges_per_row=A, c1=c1, c2=c2, v=wp if c2 is not None else None, together=ctx.acc)
+                if waits and len(ctx.acc.jobs) == n_jobs:             # (the scatter did not wait after all: its list is needed now)
+                    raise RuntimeError('mpn backward: an edge list whose launch waits was scattered at once')
             if need_wp and g_z is not None:
                 ld = D + 1 if need_bp else D            # (column D: the row's share of the read-out bias's gradient)
                 partial = torch.empty((R, ld), dtype=torch.float32, device=x.device)
