@@ -1257,6 +1257,10 @@ class _MPN(torch.autograd.Function):
         x, wp, bp, sims, ids, edge_mask, row_mask, sim_col = ctx.saved_tensors[:8]
         src, id_div, sims_per_edge, R, A, D = ctx.meta
         need_x, need_wp, need_bp = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2]
+        if g_z is None:
+            # nobody read the read-out (the neighbourhood channel's bodies): its weight and bias get NO gradient -- None, as autograd
+            # gives an unused parameter, not two zero fills per body that the optimizer then carries through its norm and update
+            need_wp = need_bp = False
         # The gradient of the read-out goes through the fused relu.  Where every reader of grad_z is one of the deterministic
         # kernels below, they apply the gate themselves (args.z_act) and produce the read-out bias's gradient too -- a threshold
         # launch and a reduction launch less per layer body; anywhere else the gated gradient is materialised first.
