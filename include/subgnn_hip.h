@@ -730,6 +730,14 @@ int sgnn_optim_adam(float* const* params, float* const* grads, float* const* exp
                     const float* partial, int64_t n_partial, float max_norm, float* coef_out, void* stream);
 
 
+/* A batch's rows of up to sgnn_gather_rows_many_max() per-split tensors in ONE launch (the row gathers of _pad_collate,
+ * SubGNN/SubGNN.py:1068-1114: component ids, border ids, the channels' similarity rows, labels): dst[t][i, :] =
+ * src[t][idx[i], :] with rows as raw bytes -- row_bytes[t] each, src_rows[t] rows in the source (an index outside it reads row 0).
+ * src / dst / row_bytes / src_rows: HOST arrays (src / dst of DEVICE pointers); idx: DEVICE int64[B]. */
+int64_t sgnn_gather_rows_many_max(void);
+int sgnn_gather_rows_many(int64_t n, const void* const* src, void* const* dst, const int64_t* row_bytes,
+                          const int64_t* src_rows, const int64_t* idx, int64_t B, void* stream);
+
 /* ---------------------------------------------------------------------------------------
  * Measurement aid (no reference counterpart): streaming copy of n_bytes with 4 or 16 bytes per lane.
  * The rocprofv3 memory-side counters (FETCH_SIZE / WRITE_SIZE) are calibrated on it -- a known byte

@@ -518,15 +518,26 @@ class SubGNN(nn.Module):
         idx = torch.as_tensor(idx, dtype=torch.int64)
         didx = idx.to(self.device)
         cc, nb, npsim, isim, bsim = self._split_tensors(split)
+        if not idx.is_cuda and idx.numel() and (int(idx.min()) < 0 or int(idx.max()) >= cc.shape[0]):
+            raise IndexError('subgraph index out of range for split %r (%d subgraphs)' % (split, cc.shape[0]))
         sub_ids, lab, w_cc, w_nb = self._resident_split(split)
 
-        def pick(t):
+        # every per-subgraph tensor of the split that the batch reads, gathered in ONE launch (ops.index_rows_many): component
+        # ids, border ids, the similarity rows (one slab or a dict of per-layer edge weights), subgraph ids, labels
+        wanted = {'cc': cc, 'nb': nb, 'np': npsim, 'is': isim, 'bs': bsim, 'ids': sub_ids, 'lab': lab}
+        flat = [(name, key, v) for name, t in wanted.items()
+                for key, v in (t.items() if isinstance(t, dict) else [(None, t)]) if isinstance(v, torch.Tensor)]
+        got = ops.index_rows_many([v for _, _, v in flat], didx) if didx.is_cuda else [v.index_select(0, didx) for _, _, v in flat]
+        gathered = {(name, key): g for (name, key, _), g in zip(flat, got)}
+
+        def pick(name):
+            t = wanted[name]
             if t is None:
                 return None
             if isinstance(t, dict):
-                return {k: v.index_select(0, didx) for k, v in t.items()}
-            return t.index_select(0, didx)
-        batch_cc, batch_nb = pick(cc), pick(nb)
+                return {k: (gathered[(name, k)] if isinstance(v, torch.Tensor) else v.index_select(0, didx)) for k, v in t.items()}
+            return gathered[(name, None)] if isinstance(t, torch.Tensor) else t.index_select(0, didx)
+        batch_cc, batch_nb = pick('cc'), pick('nb')
         if trim:
             hidx = idx.cpu().numpy()
 
@@ -539,9 +550,9 @@ class SubGNN(nn.Module):
             batch_cc = drop_pad_columns(batch_cc, w_cc)
             if nb is not None:
                 batch_nb = drop_pad_columns(batch_nb, w_nb)
-        return {'subgraph_ids': pick(sub_ids), 'cc_ids': batch_cc, 'N_border': batch_nb,
-                'NP_sim': pick(npsim), 'I_S_sim': pick(isim), 'B_S_sim': pick(bsim),
-                'subgraph_idx': didx.view(-1, 1), 'label': pick(lab)}
+        return {'subgraph_ids': pick('ids'), 'cc_ids': batch_cc, 'N_border': batch_nb,
+                'NP_sim': pick('np'), 'I_S_sim': pick('is'), 'B_S_sim': pick('bs'),
+                'subgraph_idx': didx.view(-1, 1), 'label': pick('lab')}
 
     def _pad_collate(self, batch):
         """S.py:1068-1114 for a list of SubgraphDataset items."""

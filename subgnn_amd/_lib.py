@@ -117,6 +117,8 @@ SIGNATURES = {
     'sgnn_readout_sum_bwd_workspace_bytes': (c_i64, [c_i64, c_i64, c_i64]),
     'sgnn_readout_sum_bwd': (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_ptr, c_ptr,
                                      c_ptr, c_i64, c_ptr]),
+    'sgnn_gather_rows_many_max': (c_i64, []),
+    'sgnn_gather_rows_many': (c_int, [c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr]),
     'sgnn_probe_stream_copy': (c_int, [c_ptr, c_ptr, c_i64, c_int, c_ptr]),
     'sgnn_scatter_add_rows_workspace_bytes': (c_i64, [c_i64, c_i64]),
     'sgnn_mpn_bwd_shared_det_workspace_bytes': (c_i64, [c_i64, c_i64, c_i64]),

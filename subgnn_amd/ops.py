@@ -2058,6 +2058,32 @@ class _GatherRows(torch.autograd.Function):
         return torch.zeros(ctx.n_rows, g.shape[1], dtype=grad.dtype, device=grad.device).index_add_(0, flat, g), None, None
 
 
+def index_rows_many(tensors, idx):
+    """[t.index_select(0, idx) for t in tensors] in one launch (sgnn_gather_rows_many): the row gathers that assemble a batch
+    from a split's per-subgraph tensors.  ``tensors``: contiguous CUDA tensors with the same number of rows; ``idx``: int64 device
+    tensor.  Tensors it cannot take (not contiguous, other devices) go through index_select."""
+    lib = _lib.load()
+    out = [None] * len(tensors)
+    take = [k for k, t in enumerate(tensors) if t.is_cuda and t.is_contiguous() and t.dim() >= 1 and t.shape[0] > 0 and t.numel() > 0]
+    if not idx.is_cuda or idx.dtype != torch.int64 or not idx.is_contiguous() or idx.numel() == 0 or len(take) < 2:
+        take = []
+    for k, t in enumerate(tensors):
+        if k not in take:
+            out[k] = t.index_select(0, idx)
+    cap = int(lib.sgnn_gather_rows_many_max()) if take else 1
+    B = idx.numel()
+    for lo in range(0, len(take), cap):
+        group = take[lo:lo + cap]
+        for k in group:
+            out[k] = torch.empty((B,) + tuple(tensors[k].shape[1:]), dtype=tensors[k].dtype, device=tensors[k].device)
+        src, dst = _ptr_table([tensors[k] for k in group]), _ptr_table([out[k] for k in group])
+        rb = np.array([tensors[k][0].numel() * tensors[k].element_size() for k in group], dtype=np.int64)
+        rows = np.array([tensors[k].shape[0] for k in group], dtype=np.int64)
+        check(lib.sgnn_gather_rows_many(len(group), src.ctypes.data, dst.ctypes.data, rb.ctypes.data, rows.ctypes.data, _ptr(idx), B,
+                                        _stream()), 'sgnn_gather_rows_many')
+    return out
+
+
 def presort_ids(ids, max_key):
     """Hang the stable order of ``ids`` by value on the tensor (``_sgnn_sorted`` = (sorted keys, order, int32 ids)): the
     backward of ``gather_rows(table, ids)`` then skips its sort.  For id tensors that live as long as a prepared pass."""

@@ -558,6 +558,30 @@ def test_walks_random_vs_oracle(walk_kernel):
         assert np.array_equal(got, ref)
 
 
+def test_index_rows_many_equals_index_select():
+    """sgnn_gather_rows_many (ops.index_rows_many: a batch's rows of every per-split tensor in one launch) against
+    torch.index_select: int64 / int32 / float32 / uint8 tensors, rows of 1 byte to 1.2 MB, odd widths (byte and 4-byte paths),
+    repeated and unordered indices, a non-contiguous tensor (falls back), 30 tensors (two launches)."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(3)
+    S = 57
+    ts = [torch.randint(0, 1000, (S, 7, 8), generator=g), torch.randint(0, 1000, (S, 5), generator=g).to(torch.int32),
+          torch.randn(S, 3, 100003, generator=g), torch.randint(0, 255, (S,), generator=g).to(torch.uint8),
+          torch.randint(0, 255, (S, 3), generator=g).to(torch.uint8), torch.randn(S, generator=g), torch.randn(S, 13, generator=g),
+          torch.randn(S, 20, 6, generator=g)[:, ::2]]
+    ts += [torch.randn(S, k + 1, generator=g) for k in range(22)]
+    ts = [t.to(DEV) for t in ts]
+    ts[7] = torch.randn(S, 20, 6, generator=g).to(DEV)[:, ::2]
+    assert not ts[7].is_contiguous()
+    idx = torch.tensor([5, 0, 56, 5, 5, 31, 2, 2, 40], dtype=torch.int64, device=DEV)
+    got = ops.index_rows_many(ts, idx)
+    for t, o in zip(ts, got):
+        assert torch.equal(o, t.index_select(0, idx)) and o.dtype == t.dtype
+    assert ops.index_rows_many([], idx) == []
+    one = ops.index_rows_many(ts[:1], idx)                           # a single tensor: the library call
+    assert torch.equal(one[0], ts[0].index_select(0, idx))
+
+
 def test_internal_and_border_walks_in_one_launch_equal_the_oracle():
     """sgnn_triangular_walks_both: the internal and the border walks of the same patches in ONE launch against the oracle's two
     calls (aps:118-158 with inside = True / False), and a share of it (item_base) against the whole."""
