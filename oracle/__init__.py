@@ -16,8 +16,9 @@ Parity pins (see DESIGN.md section "Oracle"):
     restated from its published algorithm in oracle/fastdtw_restate.py) and the float
     summation order of torch-scatter's scatter-add (PyG 1.6.1, also absent).
     fastdtw's predecessor rule on ties is a switch (``tie_order`` 0 / 1 / 2, described in
-    fastdtw_restate.py).  The product defaults to 0, the pure-Python module's rule -- the only form of
-    that release whose source is unambiguous (a Python ``min`` over three tuples); 2 is the shape the
-    compiled variant most plausibly has.  All three are property-tested against exact DTW; the goldens
-    (g7) are a self-consistency pin under rule 0.
+    fastdtw_restate.py).  The product and the oracle default to 2, the shape the compiled variant most
+    plausibly has: the pure-Python module (rule 0) raises on the empty series of the reference's padded
+    component rows, so the reference's numbers came from the compiled one.  All three are property-tested
+    against exact DTW; the goldens g7 / g11 are a self-consistency pin under rule 0 (generated through the
+    restated pure-Python module), tests/golden/ties.npz pins rules 1 and 2 the same way.
 """

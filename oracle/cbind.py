@@ -42,7 +42,9 @@ def degree_sequence(rowptr, col, full_degree, set_ptr, set_nodes, sorted_=True):
     return oi[:n], oe[:n]
 
 
-def fastdtw_sim(x_ptr, x_val, y_ptr, y_val, tie_order=0):
+def fastdtw_sim(x_ptr, x_val, y_ptr, y_val, tie_order=None):
+    if tie_order is None:
+        from .fastdtw_restate import DEFAULT_TIE_ORDER as tie_order
     nx, ny = len(x_ptr) - 1, len(y_ptr) - 1
     out = np.zeros((nx, ny), dtype=np.float32)
     lib().oc_fastdtw_sim(_p(x_ptr), _p(x_val), ctypes.c_int64(nx), _p(y_ptr), _p(y_val), ctypes.c_int64(ny),

@@ -174,8 +174,8 @@ def run(rowptr, col, subs, hp, emb, labels, n_sample, S_total):
     ci, ce = cbind.degree_sequence(rowptr, col, None, cp, cf, True)
     t['degree_seq'] = time.perf_counter() - t0
     t0 = time.perf_counter()
-    int_sim = cbind.fastdtw_sim(cp, ci, pp, pi, 0).reshape(S, C, -1)
-    bor_sim = cbind.fastdtw_sim(cp, ce, pp, pe, 0).reshape(S, C, -1)
+    int_sim = cbind.fastdtw_sim(cp, ci, pp, pi).reshape(S, C, -1)
+    bor_sim = cbind.fastdtw_sim(cp, ce, pp, pe).reshape(S, C, -1)
     t['dtw'] = time.perf_counter() - t0
     # position channel: one BFS per P-border anchor over the whole graph (C, the sources shared among the cores) and the
     # min over every sampled component's members.  The BFS part does not depend on the number of subgraphs: a shared stage,

@@ -11,13 +11,18 @@ minimum over the predecessors in the order (i-1,j), (i,j-1), (i-1,j-1)).
 package may break ties differently (open point (a)):
 
   0  pure-Python module: min() over the three SUMS cost + dist in the order (i-1,j), (i,j-1), (i-1,j-1),
-     first minimum wins.  This is the rule the product defaults to: it is the one form of fastdtw 0.3.4
-     whose source text is unambiguous (a Python ``min`` over a tuple of tuples), and the reference's
-     environment file pins the package, not a build of it.
+     first minimum wins.  The one form of fastdtw 0.3.4 whose source text is unambiguous (a Python ``min``
+     over a tuple of tuples) -- and the one form that provably did NOT produce the reference's numbers: its
+     ``__dtw`` raises IndexError on the empty series every padded component row hands it (SubGNN.py:808-815;
+     the back-trace reads ``D[0, len_y][1]`` of an ``(inf,)`` default entry), so every multi-component
+     dataset of the reference ran the compiled variant.  ``fastdtw()`` below keeps 0 as ITS default (it
+     restates that module; the golden fixtures g7 / g11 were generated through it).
   1  the same first-minimum-over-sums rule with the diagonal first: (i-1,j-1), (i-1,j), (i,j-1).
   2  the shape a compiled loop most plausibly has: compare the three PREDECESSOR costs (not the sums) with
      ``<=`` -- the diagonal if it is <= both others, else (i-1,j) if it is <= (i,j-1), else (i,j-1) -- then
      add the distance.  Differs from 1 only where rounding makes or breaks a tie between sums.
+     DEFAULT_TIE_ORDER: what the product (subgnn_amd.config.DTW_TIE_ORDER) and the oracle's batched entry
+     points (calc_dtw, integer_half.structure_similarities, cbind.fastdtw_sim) use when none is given.
 
 All three are valid DTW recurrences: each returns a warp-path cost >= the exact DTW distance and equal to
 it whenever the window is the whole grid (either length < radius + 2, or a window that happens to cover it)
@@ -26,6 +31,7 @@ it whenever the window is the whole grid (either length < radius + 2, or a windo
 Test infrastructure only.
 """
 INF = float('inf')
+DEFAULT_TIE_ORDER = 2
 
 # predecessor orders: each entry is (di, dj) subtracted from (i, j)
 TIE_ORDERS = {
@@ -128,9 +134,11 @@ def exact_dtw(x, y, dist):
     return dtw_window([float(v) for v in x], [float(v) for v in y], None, dist)[0]
 
 
-def calc_dtw(component_degree, patch_degree, tie_order=0):
+def calc_dtw(component_degree, patch_degree, tie_order=None):
     """gamma.py:54-59.  Empty component rows (padded CC rows, SubGNN.py:808-815) are given
-    similarity 1/(0+1) here; the caller overwrites them with PAD (SubGNN.py:831)."""
+    similarity 1/(0+1) here; the caller overwrites them with PAD (SubGNN.py:831).
+    ``tie_order`` None: DEFAULT_TIE_ORDER."""
+    tie_order = DEFAULT_TIE_ORDER if tie_order is None else tie_order
     if len(component_degree) == 0 or len(patch_degree) == 0:
         return 1.0
     d, _ = fastdtw(component_degree, patch_degree, radius=1, dist=calc_dist, tie_order=tie_order)

@@ -198,7 +198,7 @@ def degree_sequence(G, nodes, degree_dict=None, internal=True, sort=True):
 # a11 structure similarities  (gamma.py:51-59, SubGNN.py:783-833)
 # ---------------------------------------------------------------------------------------
 
-def structure_similarities(G, cc_ids, structure_anchors, degree_dict, internal, tie_order=0):
+def structure_similarities(G, cc_ids, structure_anchors, degree_dict, internal, tie_order=None):
     S, C, _ = cc_ids.shape
     P = structure_anchors.shape[0]
     aseq = [degree_sequence(G, structure_anchors[a], degree_dict, internal) for a in range(P)]

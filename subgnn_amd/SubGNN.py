@@ -140,9 +140,9 @@ class SubGNN(nn.Module):
             self.attention = AdditiveAttention(hid_dim, hid_dim, half_operands=str(hp.get('embedding_dtype', 'fp32')).lower()
                                                in ('fp16', 'float16', 'half'))
         hp.setdefault('structure_similarity_fn', 'dtw')
-        # predecessor rule of fastdtw's DP (0: the published pure-Python module, the default; 1 / 2: the variants a compiled
-        # build may implement -- oracle/__init__.py); reaches every DTW launch of the model, dense and sparse path
-        hp.setdefault('dtw_tie_order', 0)
+        # predecessor rule of fastdtw's DP (0: the published pure-Python module; 1 / 2: the variants a compiled build may
+        # implement; default config.DTW_TIE_ORDER = 2, argued there); reaches every DTW launch of the model, dense and sparse path
+        hp.setdefault('dtw_tie_order', config.DTW_TIE_ORDER)
         if hp['dtw_tie_order'] not in (0, 1, 2):
             raise ValueError("hparams['dtw_tie_order'] must be 0, 1 or 2")
         # hparams['deterministic'] (default True): gradients by sorted segmented sums and per-row partials -- bit-

@@ -28,14 +28,14 @@ def get_degree_sequence(graph, nodes, degree_dict=None, internal=True):
     return vals[:n].cpu().tolist()
 
 
-def dtw_similarity_matrix(cc_sets, cc_seq, anchor_sets, anchor_seq, tie_order=0):
+def dtw_similarity_matrix(cc_sets, cc_seq, anchor_sets, anchor_seq, tie_order=None):
     """1/(1+fastdtw(cc, anchor, radius=1, dist=calc_dist)) for all pairs (gamma.py:51-59,
     SubGNN.py:811-822) -> (n_cc_rows, n_anchors) float32, empty (padded) rows = PAD."""
     return ops.dtw_similarity(cc_sets.ptr, cc_seq, max(cc_sets.max_len, 1),
                               anchor_sets.ptr, anchor_seq, max(anchor_sets.max_len, 1), tie_order)
 
 
-def calc_dtw(graph_device, component_degree, patch_degree, tie_order=0):
+def calc_dtw(graph_device, component_degree, patch_degree, tie_order=None):
     """gamma.calc_dtw for one pair of python lists (convenience; the hot path is batched)."""
     dev = graph_device
     x = ops.Ragged.from_lists([list(component_degree)], dev)

@@ -47,6 +47,23 @@ def make_eager(optimizer):
     return optimizer
 
 
+def abandon_capture(model, optimizer):
+    """After a capture that raised: the Python side of the step body ran although none of its kernels did.  Gradient buffers it
+    took or handed back belong to the dead capture's memory pool and were never zeroed (``ops.take_zeroed`` popped the table's
+    pre-zeroed buffer, ``ops.release_zeroed`` may have hung an un-executed one on a parameter), ``p.grad`` may point into that
+    pool, and the layer bodies it queued are still waiting.  Drop all of it: the eager steps that follow start from fresh fills."""
+    from . import ops
+    params = list(getattr(optimizer, 'all', None) or getattr(optimizer, 'big', None) or [])
+    seen = {id(p) for p in params}
+    params += [p for p in model.parameters() if id(p) not in seen]
+    for p in params:
+        ops.drop_zeroed(p)
+        p.grad = None
+    ops.drop_lazy_mpn()
+    model.__dict__['_tapped_table'] = None
+    model.__dict__['_fwd_cache'] = None
+
+
 class StepNotRecordable(RuntimeError):
     """The training step could not be RECORDED (an operation inside it needs the host while the stream is capturing).
     Raised by CapturedTrainStep._record only: an error of the eager warm-up steps, or of a replay, is the step's own
@@ -103,6 +120,7 @@ class CapturedTrainStep:
                 self.loss, self.acc = self._body()
         except RuntimeError as ex:
             self.loss = self.acc = None
+            abandon_capture(self.model, self.opt)
             raise StepNotRecordable(str(ex)) from ex
         self.graph = g
 

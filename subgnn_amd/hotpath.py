@@ -588,7 +588,7 @@ def finish_pass(model, st, timer=None):
         cc_sets, ci, ce, a_sets, ai, ae, (S, C) = st.dtw_inputs
         st.dtw_inputs = None
         mx, my = max(cc_sets.max_len, 1), max(a_sets.max_len, 1)
-        tie = int(model.hparams.get('dtw_tie_order', 0))
+        tie = int(model.hparams['dtw_tie_order'])
         # Grouping repeated component sequences pays on the internal side (2.7k distinct rows among the
         # benchmark's 50k) and is pure overhead on the external side (nearly all distinct).  Which it is
         # depends only on the split's components and the graph: decided on the first pass, kept.
@@ -851,8 +851,14 @@ class CapturedTraining:
                 return self._body()
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                self.loss, self.acc = self._body()
+            try:
+                with torch.cuda.graph(g):
+                    self.loss, self.acc = self._body()
+            except Exception:
+                from .graph_step import abandon_capture
+                self.loss = self.acc = None
+                abandon_capture(self.model, self.opt)      # (buffers of the dead capture must not reach an eager step)
+                raise
             self.graph = g
             self.recordings += 1
         self.graph.replay()

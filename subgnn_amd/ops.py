@@ -6,6 +6,7 @@ must already live on the GPU; nothing here falls back to a CPU implementation.
 """
 import ctypes
 import functools
+import threading
 
 import numpy as np
 import torch
@@ -249,7 +250,9 @@ def warm_up(device=None):
     """Pay the one-time start-up costs of the path NOW (a model's constructor calls this) instead of inside the first pass:
     the code objects of libsubgnn_hip.so (sgnn_warm_up: one empty launch per translation unit), the BLAS libraries' handles and
     first kernels (the head's and the LSTM's GEMM shapes), and the handful of torch kernels the preparation uses.  Once per
-    device and process; ~0.3-0.5 s the first time.  Nothing here computes a result anybody reads."""
+    device and process; ~0.3-0.5 s the first time.  Nothing here computes a result anybody reads, and nothing here moves a
+    random stream: the body runs inside ``torch.random.fork_rng`` (the CPU generator and this device's Philox offset are put
+    back), so the first model of a process draws the dropout masks every later same-seed model draws."""
     if not torch.cuda.is_available():
         return 0.0
     dev = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
@@ -258,7 +261,7 @@ def warm_up(device=None):
     import time
     t0 = time.perf_counter()
     _WARM.add(str(dev))
-    with torch.cuda.device(dev):
+    with torch.cuda.device(dev), torch.random.fork_rng(devices=[dev]):
         check(_lib.load().sgnn_warm_up(_stream()), 'sgnn_warm_up')
         # torch kernels of the preparation (sorts, scans, gathers, scatters, reductions) on a few elements each
         i64 = torch.arange(8, device=dev)
@@ -805,7 +808,7 @@ def distinct_row_fraction(x_ptr, x_val, max_x):
     return float((rep == torch.arange(n, device=rows.device)).sum().item()) / n
 
 
-def dtw_similarity(x_ptr, x_val, max_x, y_ptr, y_val, max_y, tie_order=0, order_rows=True, dedupe=True, order=None,
+def dtw_similarity(x_ptr, x_val, max_x, y_ptr, y_val, max_y, tie_order=None, order_rows=True, dedupe=True, order=None,
                    _live=None, x_prep=None, kernel=0):
     """1/(1+fastdtw) for all (x row, y row) pairs -> (n_x, n_y) float32; empty x rows -> PAD.
     ``dedupe``: identical x rows (sorted degree sequences of small components repeat a lot: 50k BFS
@@ -815,7 +818,11 @@ def dtw_similarity(x_ptr, x_val, max_x, y_ptr, y_val, max_y, tie_order=0, order_
     ``x_prep``: a dict the caller keeps for THESE x rows (the degree sequences of a split's components are the same
     every pass): the grouping of repeated rows and the processing order are computed on the first call and reused;
     the series the kernel reads are always this call's ``x_val``.
-    ``kernel``: 0 = pick by size, 1 = the general (workspace-resident) kernel; same values."""
+    ``kernel``: 0 = pick by size, 1 = the general (workspace-resident) kernel; same values.
+    ``tie_order``: fastdtw's predecessor rule (0 / 1 / 2); None = config.DTW_TIE_ORDER, the product's default."""
+    if tie_order is None:
+        from .config import DTW_TIE_ORDER as tie_order
+    tie_order = int(tie_order)
     if dedupe and x_ptr.numel() - 1 > 1024 and max_x <= 64:
         kept = x_prep.get('dedupe') if x_prep is not None else None
         if kept is not None and kept[1].numel() == x_ptr.numel() - 1:
@@ -1179,21 +1186,36 @@ def _mpn_args(src, x, ids, id_div, edge_mask, row_mask, sims, sim_col, sims_per_
 # Forward launches of layer bodies that wait for each other (ops.mpn(lazy=True)): the bodies of one message-passing layer read the
 # layer below only, so their kernels go out as ONE launch when the first consumer needs a result -- ``flush_lazy_mpn`` (called by
 # ``update_layers`` and by the layer loop of SubGNN.forward after every layer).  Entries keep their tensors alive.
-_LAZY_MPN = []
+# The queue belongs to the THREAD that runs the forward (another thread's forward can neither flush nor drop it) and every
+# entry remembers the stream it was queued under: launching it under another stream would order it against the wrong work, so
+# that raises instead (a forward runs under one stream).
+class _LazyQueue(threading.local):
+    def __init__(self):
+        self.entries = []
+
+
+_LAZY = _LazyQueue()
+
+
+def lazy_mpn_pending():
+    """Number of layer bodies queued by this thread and not launched yet."""
+    return len(_LAZY.entries)
 
 
 def flush_lazy_mpn():
     """Launch the queued layer bodies (sgnn_mpn_fwd_many, up to 8 per launch)."""
-    global _LAZY_MPN
-    queue, _LAZY_MPN = _LAZY_MPN, []
+    queue, _LAZY.entries = _LAZY.entries, []
     if not queue:
         return
+    now = torch.cuda.current_stream().cuda_stream
+    if any(q[4] != now for q in queue):
+        raise RuntimeError('ops.flush_lazy_mpn: layer bodies were queued under another stream than the one that launches them')
     lib = _lib.load()
     cap = int(lib.sgnn_mpn_fwd_many_max_bodies())
     for lo in range(0, len(queue), cap):
         group = queue[lo:lo + cap]
         if len(group) == 1:
-            a, agg, z, _keep = group[0]
+            a, agg, z = group[0][:3]
             check(lib.sgnn_mpn_fwd(ctypes.byref(a), _ptr(agg), _ptr(z), _stream()), 'sgnn_mpn_fwd')
             continue
         arr = (MpnArgs * len(group))(*[g[0] for g in group])
@@ -1203,9 +1225,8 @@ def flush_lazy_mpn():
 
 
 def drop_lazy_mpn():
-    """Forget queued launches (a forward that did not finish)."""
-    global _LAZY_MPN
-    _LAZY_MPN = []
+    """Forget this thread's queued launches (a forward that did not finish)."""
+    _LAZY.entries = []
 
 
 class _MPN(torch.autograd.Function):
@@ -1237,7 +1258,8 @@ class _MPN(torch.autograd.Function):
             agg = torch.empty((chunks, R, D), dtype=torch.float32, device=x.device)
             if lazy and keep_chunks and R > 0:
                 # the launch waits for the other bodies of its layer (flush_lazy_mpn); nothing reads agg / z before that
-                _LAZY_MPN.append((a, agg, z, (x, wp, bp, sims, ids, edge_mask, row_mask, sim_col, getattr(x, '_sgnn_half', None))))
+                _LAZY.entries.append((a, agg, z, (x, wp, bp, sims, ids, edge_mask, row_mask, sim_col, getattr(x, '_sgnn_half', None)),
+                                      torch.cuda.current_stream().cuda_stream))
             else:
                 check(lib.sgnn_mpn_fwd(ctypes.byref(a), _ptr(agg), _ptr(z), _stream()), 'sgnn_mpn_fwd')
             if not keep_chunks:

@@ -21,7 +21,11 @@ class ClipAdam:
     def __init__(self, params, lr, max_norm=None, betas=(0.9, 0.999), eps=1e-8, big_bytes=16 << 20, capturable=False, fuse_tail=True,
                  skip_untouched_rows=True):
         params = [p for p in params if p.requires_grad]
-        self.lr, self.betas, self.eps, self.max_norm = float(lr), (float(betas[0]), float(betas[1])), float(eps), max_norm
+        self.betas, self.eps, self.max_norm = (float(betas[0]), float(betas[1])), float(eps), max_norm
+        # one parameter group, torch-shaped: a learning-rate scheduler (or a caller) that writes param_groups[0]['lr'] is
+        # honoured by the next step (``lr`` below reads it); 'params' lists every parameter this optimizer updates
+        self.param_groups = [{'params': list(params), 'lr': float(lr), 'betas': self.betas, 'eps': self.eps, 'weight_decay': 0,
+                              'amsgrad': False, 'maximize': False, 'max_norm': max_norm}]
         self.big = [p for p in params if p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()
                     and p.numel() * 4 >= big_bytes and p.data_ptr() % 16 == 0]
         ids = {id(p) for p in self.big}
@@ -29,7 +33,7 @@ class ClipAdam:
         # capturable: every step count lives on the device, so that a step recorded into a hipGraph (hotpath.CapturedTraining)
         # replays with the right bias corrections; same arithmetic either way
         self.capturable = bool(capturable)
-        self.small_opt = torch.optim.Adam(self.small, lr=lr, betas=betas, eps=eps, capturable=self.capturable,
+        self.small_opt = torch.optim.Adam(self.small, lr=float(lr), betas=betas, eps=eps, capturable=self.capturable,
                                           fused=all(p.is_cuda for p in self.small)) if self.small else None
         self.state = {id(p): {'step': 0, 'exp_avg': torch.zeros_like(p), 'exp_avg_sq': torch.zeros_like(p),
                               'step_dev': torch.zeros(1, dtype=torch.int64, device=p.device) if self.capturable else None}
@@ -50,6 +54,14 @@ class ClipAdam:
                                       row_skip=range(len(self.big)) if skip_untouched_rows else ())
             self.counters = torch.zeros(len(self.all), dtype=torch.int64, device=params[0].device) if self.capturable else None
             self.last_clip = None                               # (2,) device tensor [coefficient, total norm] of the last step
+
+    @property
+    def lr(self):
+        return float(self.param_groups[0]['lr'])
+
+    @lr.setter
+    def lr(self, value):
+        self.param_groups[0]['lr'] = float(value)
 
     def _step_fused(self):
         which, grads, takes = [], [], []
@@ -83,6 +95,9 @@ class ClipAdam:
     def step(self):
         if self.tail is not None:
             return self._step_fused()
+        if self.small_opt is not None:
+            for g in self.small_opt.param_groups:               # (a scheduler writes THIS optimizer's group)
+                g['lr'] = self.lr
         small_grads = [p.grad for p in self.small if p.grad is not None]
         big = [p for p in self.big if p.grad is not None]
         scale = None
@@ -124,6 +139,58 @@ class ClipAdam:
                 else:
                     p.grad.zero_()
 
+
+    # -- checkpointing (torch.optim.Optimizer's surface: what a Lightning-style caller saves and restores) ----------------------
+    def _order(self):
+        return self.all if self.tail is not None else self.big
+
+    def state_dict(self):
+        """Moments, step counts and the row-skip bytes of every parameter this optimizer updates itself, by position in
+        ``param_groups[0]['params']`` (as torch keys optimizer state), + torch's own state dict of the small parameters when
+        they are stepped by torch's fused Adam.  Device step counters are read back (one host round trip)."""
+        pos = {id(p): i for i, p in enumerate(self.param_groups[0]['params'])}
+        counts = self.counters.tolist() if (self.tail is not None and self.counters is not None) else None
+        state = {}
+        for k, p in enumerate(self._order()):
+            st = self.state[id(p)]
+            step = counts[k] if counts is not None else (int(st['step_dev'].item()) if st.get('step_dev') is not None else st['step'])
+            ent = {'step': int(step), 'exp_avg': st['exp_avg'].detach().clone(), 'exp_avg_sq': st['exp_avg_sq'].detach().clone()}
+            if self.tail is not None and k in self.tail.seen:
+                ent['rows_seen'] = self.tail.seen[k].detach().clone()
+            state[pos[id(p)]] = ent
+        group = {k: v for k, v in self.param_groups[0].items() if k != 'params'}
+        group['params'] = list(range(len(self.param_groups[0]['params'])))
+        return {'state': state, 'param_groups': [group],
+                'small': self.small_opt.state_dict() if self.small_opt is not None else None}
+
+    def load_state_dict(self, sd):
+        """Inverse of ``state_dict``.  A checkpoint without the row-skip bytes (moments restored from elsewhere) marks every row
+        whose first moment is non-zero as seen -- a row with m = v = 0 is exactly the row Adam leaves alone, so skipping only
+        those stays bit-identical to the full update."""
+        params = self.param_groups[0]['params']
+        for k, v in sd['param_groups'][0].items():
+            if k != 'params':
+                self.param_groups[0][k] = v
+        self.max_norm = self.param_groups[0].get('max_norm', self.max_norm)
+        order = {id(p): k for k, p in enumerate(self._order())}
+        for i, ent in sd['state'].items():
+            p = params[int(i)]
+            st = self.state[id(p)]
+            st['exp_avg'].copy_(ent['exp_avg'])
+            st['exp_avg_sq'].copy_(ent['exp_avg_sq'])
+            st['step'] = int(ent['step'])
+            if st.get('step_dev') is not None:
+                st['step_dev'].fill_(int(ent['step']))
+            k = order[id(p)]
+            if self.tail is not None and self.counters is not None:
+                self.counters[k] = int(ent['step'])
+            if self.tail is not None and k in self.tail.seen:
+                seen = ent.get('rows_seen')
+                if seen is None:
+                    seen = ((st['exp_avg'] != 0) | (st['exp_avg_sq'] != 0)).reshape(p.shape[0], -1).any(1).to(torch.uint8)
+                self.tail.seen[k].copy_(seen)
+        if self.small_opt is not None and sd.get('small') is not None:
+            self.small_opt.load_state_dict(sd['small'])
 
     def make_eager(self):
         """Back to host-side step counts (the trainer's fallback when a step cannot be recorded): same arithmetic."""

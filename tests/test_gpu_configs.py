@@ -301,7 +301,7 @@ def test_degree_sequences_and_dtw(cfg):
     for sims, x, y in ((m.train_int_struc_similarities, xi, yi), (m.train_bor_struc_similarities, xe, ye)):
         assert tuple(sims.shape) == (S, C, sa.shape[0])
         got = sims.reshape(S * C, -1)[rsel][:, csel].cpu().numpy()
-        want = cbind.fastdtw_sim(xp, x, yp, y, 0)
+        want = cbind.fastdtw_sim(xp, x, yp, y, m.hparams['dtw_tie_order'])
         assert np.array_equal(got, want)
         pad = torch.from_numpy(cc[:, :, 0] == 0).to(sims.device)
         if bool(pad.any()):

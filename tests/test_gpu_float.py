@@ -182,9 +182,9 @@ def test_layer_bodies_together_equal_one_after_the_other(D, det):
         for k in (3, 4):                                           # all-zero aggregate; a body nobody reads
             pend.append(ops.PendingUpdate(leaf('cc%d' % k, cc[k]), zero, leaf('W%d' % k, Ws[k]), leaf('b%d' % k, bs[k]), (R // C, C)))
         if together:
-            assert len(ops._LAZY_MPN) == 3
+            assert ops.lazy_mpn_pending() == 3
             outs = ops.update_layers(pend)
-            assert not ops._LAZY_MPN
+            assert ops.lazy_mpn_pending() == 0
         else:
             outs = [ops.update_layer(p.x, p.aggr, p.weight, p.bias) for p in pend]
         loss = sum((o * go[k].to(DEV)).sum() for k, o in enumerate(outs) if k != 4) + sum((z * gz[k].to(DEV)).sum() for k, z in enumerate(zs))
@@ -459,6 +459,21 @@ def test_missing_library_fails_loudly(monkeypatch):
     from subgnn_amd import _lib
     with pytest.raises(_lib.SubgnnHipError):
         ops.masked_sum(torch.zeros(2, 2, 4), torch.ones(2, 2, dtype=torch.bool))
+
+
+def test_warm_up_moves_no_random_stream():
+    """ops.warm_up runs once per process inside the FIRST model's constructor, after the caller has seeded torch: it must leave
+    the CPU generator and the device's Philox state where they were, or the first model of a process draws other dropout masks
+    than every later same-seed model."""
+    ops = _ops()
+    torch.manual_seed(1234)
+    cpu0, dev0 = torch.get_rng_state(), torch.cuda.get_rng_state()
+    want = torch.rand(4, device=DEV)
+    torch.manual_seed(1234)
+    ops._WARM.clear()
+    assert ops.warm_up(torch.device(DEV)) > 0
+    assert torch.equal(torch.get_rng_state(), cpu0) and torch.equal(torch.cuda.get_rng_state(), dev0)
+    assert torch.equal(torch.rand(4, device=DEV), want)
 
 
 @pytest.mark.parametrize('R,H,C', [(5, 8, 1), (70, 37, 7), (193, 420, 1), (64, 615, 4)])
@@ -777,6 +792,54 @@ def test_clip_adam_skips_untouched_table_rows_bit_exactly(D):
         if D != 48:
             assert torch.equal(o_skip.tail.seen[0].cpu().bool(), touched), it
     assert torch.equal(models[0][0][~touched.to(DEV)].cpu(), init[0][~touched])    # untouched rows: the initial bits
+
+
+@pytest.mark.parametrize('capturable,fuse_tail', [(False, True), (True, True), (False, False)])
+def test_clip_adam_checkpoint_round_trip_and_param_groups(capturable, fuse_tail):
+    """ClipAdam has torch's optimizer surface: ``param_groups[0]['lr']`` written by a scheduler is what the next
+    step uses; ``state_dict`` / ``load_state_dict`` carry moments, step counts and the row-skip bytes, so that a restored
+    optimizer continues bit for bit -- and a checkpoint WITHOUT the row-skip bytes (moments restored from elsewhere) does too
+    (rows with a non-zero moment are marked seen on load: a skipped row would otherwise stop decaying)."""
+    from subgnn_amd import optim
+    g = torch.Generator().manual_seed(5)
+    rows, D = 3001, 32
+    init = [torch.randn(rows, D, generator=g), torch.randn(D, 9, generator=g), torch.randn(D, generator=g)]
+
+    def fresh():
+        ps = [torch.nn.Parameter(t.clone().to(DEV)) for t in init]
+        return ps, optim.ClipAdam(ps, lr=0.01, max_norm=0.5, big_bytes=rows * D * 4, capturable=capturable, fuse_tail=fuse_tail)
+
+    def grads(it):
+        gg = torch.Generator().manual_seed(100 + it)
+        pick = (torch.rand(rows, generator=gg) < 0.1).unsqueeze(1)
+        pick[0] = False
+        return [torch.randn(rows, D, generator=gg) * pick, torch.randn(D, 9, generator=gg), torch.randn(D, generator=gg)]
+
+    def run(ps, opt, its):
+        for it in its:
+            for p, gr in zip(ps, grads(it)):
+                p.grad = gr.clone().to(DEV)
+            if it == 2:
+                opt.param_groups[0]['lr'] = 0.003                     # a scheduler's write
+            opt.step()
+            opt.zero_grad()
+    a_ps, a = fresh()
+    run(a_ps, a, range(5))
+    assert a.lr == 0.003
+    b_ps, b = fresh()
+    run(b_ps, b, range(3))
+    sd = b.state_dict()
+    assert set(sd) >= {'state', 'param_groups'} and sd['param_groups'][0]['lr'] == 0.003 and sd['state'][0]['step'] == 3
+    for strip in (False, True):
+        c_ps, c = fresh()
+        for p, q in zip(c_ps, b_ps):
+            p.data.copy_(q.data)
+        sd2 = {'state': {k: {n: v for n, v in e.items() if not (strip and n == 'rows_seen')} for k, e in sd['state'].items()},
+               'param_groups': sd['param_groups'], 'small': sd.get('small')}
+        c.load_state_dict(sd2)
+        run(c_ps, c, range(3, 5))
+        for p, q in zip(c_ps, a_ps):
+            assert torch.equal(p.detach(), q.detach()), (capturable, fuse_tail, strip)
 
 
 def test_clip_adam_follows_a_parameter_whose_storage_was_replaced():

@@ -131,7 +131,7 @@ def test_walks_follow_edges_and_dtw_properties(full):
     ys = [yv[yp[c]:yp[c + 1]] for c in cols_]
     xp, xf = cbind.ragged([list(map(int, x)) for x in xs])
     ypp, yf = cbind.ragged([list(map(int, y)) for y in ys])
-    ref = cbind.fastdtw_sim(xp, xf, ypp, yf, 0).reshape(40, 5)
+    ref = cbind.fastdtw_sim(xp, xf, ypp, yf).reshape(40, 5)          # (both sides: the default predecessor rule)
     got = sim[torch.from_numpy(rows).to(DEV)][:, torch.from_numpy(cols_).to(DEV)].cpu().numpy()
     assert np.array_equal(got, ref)
 

@@ -457,7 +457,7 @@ def test_a_subgraph_of_thousands_of_nodes_goes_through_the_whole_pass():
         cp, cf = cbind.ragged([ref[giant]])
         ci, ce = cbind.degree_sequence(rowptr, col, None, cp, cf, True)
         want = cbind.fastdtw_sim(cp, ci if internal else ce, a_sets.ptr.cpu().numpy(),
-                                 a_seq.cpu().numpy()[:int(a_sets.ptr[-1])], 0)
+                                 a_seq.cpu().numpy()[:int(a_sets.ptr[-1])], m.hparams['dtw_tie_order'])
         assert np.array_equal(got[0, giant].cpu().numpy(), want[0])
     m.train()
     batch = hotpath.full_split_batch(m, 'train')

@@ -772,8 +772,19 @@ def test_dtw_golden(golden):
     ai, ae = ops.degree_sequence(dg, ra)
     ci, ce = ops.degree_sequence(dg, rc)
     for xa, xc, key in ((ai, ci, 'g7_int_struc_sim_train'), (ae, ce, 'g7_bor_struc_sim_train')):
-        got = ops.dtw_similarity(rc.ptr, xc, rc.max_len, ra.ptr, xa, ra.max_len).view(S, C, -1)
+        got = ops.dtw_similarity(rc.ptr, xc, rc.max_len, ra.ptr, xa, ra.max_len, 0).view(S, C, -1)      # (g7: rule 0)
         assert np.array_equal(got.cpu().numpy(), golden[key])
+    if golden.name in ('tiny', 'density'):
+        # the same boundary under rules 1 and 2 (tests/golden/ties.npz); no rule given = config.DTW_TIE_ORDER = 2
+        import os
+        from conftest import GOLDEN_DIR
+        from subgnn_amd import config
+        ties = np.load(os.path.join(GOLDEN_DIR, 'ties.npz'))
+        assert config.DTW_TIE_ORDER == 2
+        for xa, xc, key in ((ai, ci, 'int'), (ae, ce, 'bor')):
+            for tie in (1, 2, None):
+                got = ops.dtw_similarity(rc.ptr, xc, rc.max_len, ra.ptr, xa, ra.max_len, tie).view(S, C, -1)
+                assert np.array_equal(got.cpu().numpy(), ties['%s/g7_tie%d_%s_struc_sim_train' % (golden.name, tie or 2, key)])
 
 
 @pytest.mark.parametrize('tie', [0, 1, 2])

@@ -107,7 +107,28 @@ def test_g7_structure_similarities(golden):
     dd = _degdict(G)
     cc, sa = golden['g2_cc_ids_train'], golden['g5_structure_anchors']
     for internal, key in ((True, 'int'), (False, 'bor')):
-        assert np.array_equal(IH.structure_similarities(G, cc, sa, dd, internal), golden['g7_%s_struc_sim_train' % key])
+        assert np.array_equal(IH.structure_similarities(G, cc, sa, dd, internal, tie_order=0), golden['g7_%s_struc_sim_train' % key])
+
+
+@pytest.mark.parametrize('name', ['tiny', 'density'])
+def test_g7_structure_similarities_other_tie_rules(name):
+    """tests/golden/ties.npz: the same stage boundary under predecessor rules 1 and 2 (the product's default is 2), produced
+    by the reference's own compute_structure_patch_similarities through the fastdtw stand-in (make_goldens_ties.py);
+    a self-consistency pin like g7.  (On these small fixtures the three rules agree in value: the pins constrain, the
+    discriminating cases are the random series of test_fastdtw_tie_orders_bound_exact_dtw / test_dtw_random.)"""
+    from conftest import load_golden, GOLDEN_DIR
+    import os
+    golden = load_golden(name)
+    ties = np.load(os.path.join(GOLDEN_DIR, 'ties.npz'))
+    G = _graph(golden)
+    dd = _degdict(G)
+    cc, sa = golden['g2_cc_ids_train'], golden['g5_structure_anchors']
+    for tie in (1, 2):
+        for internal, key in ((True, 'int'), (False, 'bor')):
+            assert np.array_equal(IH.structure_similarities(G, cc, sa, dd, internal, tie_order=tie),
+                                  ties['%s/g7_tie%d_%s_struc_sim_train' % (name, tie, key)])
+    assert FD.DEFAULT_TIE_ORDER == 2 and np.array_equal(
+        IH.structure_similarities(G, cc, sa, dd, True), ties['%s/g7_tie2_int_struc_sim_train' % name])      # the default rule
 
 
 def test_fastdtw_never_below_exact_dtw():

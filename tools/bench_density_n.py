@@ -199,8 +199,8 @@ def run_port(root, steps, H1=H1):
             cp, cf = cbind.ragged([[int(v) for v in r if v] for r in cc_ids.reshape(S * C, Lc)])
             ci, ce = cbind.degree_sequence(rowptr, col, full, cp, cf, True)
             real = (cc_ids[:, :, 0] != 0)[..., None]
-            extra = (p_int, cbind.fastdtw_sim(cp, ci, pp, pi, 0).reshape(S, C, -1) * real,
-                     cbind.fastdtw_sim(cp, ce, pp, pe, 0).reshape(S, C, -1) * real)
+            extra = (p_int, cbind.fastdtw_sim(cp, ci, pp, pi).reshape(S, C, -1) * real,
+                     cbind.fastdtw_sim(cp, ce, pp, pe).reshape(S, C, -1) * real)
         prep[split] = (cc_ids, n_int, n_bor, sims, extra)
     t_prep = time.perf_counter() - t0
     cc_ids, n_int, n_bor, sims, extra = prep['train']
