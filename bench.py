@@ -157,7 +157,7 @@ def degseq_algorithmic_bytes(rowptr, sets_lists, search=False):
 XGMI_LINK_GBS = 153.0          # per direction and link; 7 links per GPU (MI355X_MICROARCH.md)
 
 
-def projection(args, result, model, S, sequential_ms=None, shard_line=None):
+def projection(args, result, model, S, sequential_ms=None, shard_line=None, strong_line=None):
     """8-GPU estimates from THIS run's measurements + bytes / link rate, so that a SCALE run can be read against them.  Not a
     measurement.  BASELINE.json words configs[3] as "50k subgraphs, sharded across 8": that is the STRONG form (--scaling
     strong, 6 250 subgraphs per GPU); the tier's multi-GPU contract (per-GPU work fixed) and bench.py's default are the WEAK
@@ -191,13 +191,27 @@ def projection(args, result, model, S, sequential_ms=None, shard_line=None):
         out['weak_' + name] = {'ms_per_step': round(ms, 2), 'subgraphs_per_s': round(W * S / ms * 1e3), 'speedup_vs_1gpu': round(W * step_pipelined / ms, 2)}
         msp = step_pipelined + rs + 0.1 - adam_ms * (W - 1) / W
         out['weak_' + name + '_with_--pipeline-multi'] = {'ms_per_step': round(msp, 2), 'speedup_vs_1gpu': round(W * step_pipelined / msp, 2)}
-    # strong: the 6 250-subgraph shard's step as measured in this process, same additions
-    if shard_line and S == 50_000:
+    # strong: the step of ONE rank of eight as that rank runs it, timed live in this process (strong_rank8: its own share of every
+    # dealt stage, one BFS word, Adam on its eighth of the table; peers' shares from recorded buffers) + what the links add: the
+    # table gradient's reduce-scatter, the small all-reduce (~0.1 ms, latency-bound), the bytes the dealt exchanges deliver at
+    # 7 links' rate + ~20 us of latency each.  (The table's all-gather travels under the next preparation.)
+    if strong_line and S == 50_000:
+        exchanges = max(1, len(strong_line['received_bytes_per_pass']))
+        dealt_ms = strong_line['received_bytes_total'] / (7 * XGMI_LINK_GBS * 1e9) * 1e3 + 0.02 * exchanges
+        for name, rs in (('direct', direct_ms), ('ring', ring_ms)):
+            ms = strong_line['ms_per_step_device'] + rs + 0.1 + dealt_ms
+            out['strong_' + name] = {'ms_per_step': round(ms, 2), 'subgraphs_per_s': round(S / ms * 1e3),
+                                     'speedup_vs_1gpu': round(step_pipelined / ms, 2)}
+        out['strong_source'] = ('this run: %.2f ms of device time per pass of rank %d of %d (strong_rank8 object of this line) + %.3f ms '
+                                'for the dealt exchanges\' %d bytes + reduce-scatter + 0.1 ms small all-reduce'
+                                % (strong_line['ms_per_step_device'], strong_line['rank'], strong_line['world'], dealt_ms,
+                                   strong_line['received_bytes_total']))
+    elif shard_line and S == 50_000:
         for name, rs in (('direct', direct_ms), ('ring', ring_ms)):
             ms = shard_line['ms_per_step'] + rs + 0.1 - shard_line['stages_ms'].get('optimizer', adam_ms) * (W - 1) / W
             out['strong_' + name] = {'ms_per_step': round(ms, 2), 'subgraphs_per_s': round(S / ms * 1e3),
                                      'speedup_vs_1gpu': round(step_pipelined / ms, 2)}
-        out['strong_source'] = 'this run: %.2f ms per 6 250-subgraph pass on one GPU (shard6250 object of this line)' % shard_line['ms_per_step']
+        out['strong_source'] = 'this run: %.2f ms per 6 250-subgraph pass on one GPU (shard6250 object of this line; strong_rank8 was not measured)' % shard_line['ms_per_step']
     out['note'] = ('BASELINE.json configs[3] ("50k subgraphs, sharded across 8") is the strong form: walks over the shared patches, one BFS word '
                    'per rank, the dense 256 MB table gradient and launch overhead do not shrink with the shard; the >= 6x target is '
                    'reachable in the weak form (50k per GPU: what `bench.py --gpus 8` runs by default)')
@@ -253,12 +267,148 @@ def time_shard(g, subs, labels, emb, hp, steps, warmup, depth=2):
         for k, v in tm.summary().items():
             stage[k] = stage.get(k, 0.0) + v
             cnt[k] = cnt.get(k, 0) + 1
+    host, hcnt = {}, {}
+    for tm in timers + side_timers:
+        for k, v in tm.host_summary().items():
+            host[k] = host.get(k, 0.0) + v
+            hcnt[k] = hcnt.get(k, 0) + 1
     # the table's Adam inside the recorded half is not a stage of its own: priced from the 50k run's optimizer stage by the caller
     out = {'subgraphs': S, 'ms_per_step': ms, 'subgraphs_per_s': S / ms * 1e3, 'steps': steps, 'warmup': warmup,
+           'host_ms_per_stage(time the host needs to queue it)': {k: round(v / hcnt[k], 3) for k, v in host.items()},
            'schedule': 'training half replayed from a hipGraph, passes pipelined, %d prepared passes in flight' % depth,
            'first_pass_ms': round(first_ms, 1), 'recordings': trainer.recordings,
            'stages_ms': {k: round(v / cnt[k], 3) for k, v in stage.items()}, 'loss': float(loss)}
     del trainer, pipe, opt, model
+    torch.cuda.empty_cache()
+    return out
+
+
+def dp_tail(small, opt, table, table_opt, clip, average, all_reduce_small=None, all_reduce_scalar=None, timer=None):
+    """What a data-parallel rank runs behind its backward pass (N > 1, and the emulated rank of ``strong_rank8``): all-reduce of
+    the small gradients, reduce-scatter of the table's, clip_grad_norm_'s rule on the GLOBAL norm (one multi-tensor norm launch
+    for the small gradients), torch's fused Adam on the small parameters, owner-computes Adam on the rank's slice of the table
+    (its all-gather is waited for before the next reader of the table), gradients dropped."""
+    t = timer
+    if all_reduce_small is not None:
+        all_reduce_small(small, average)
+    if t is not None:
+        t.mark('coll_small_gradients_all_reduce')
+    sq = table_opt.reduce_grad()
+    if t is not None:
+        t.mark('coll_table_gradient_reduce_scatter')
+    if all_reduce_scalar is not None:
+        all_reduce_scalar(sq)
+    grads = [p.grad for p in small if p.grad is not None]
+    if grads:
+        sq = sq + torch.stack(torch._foreach_norm(grads)).float().pow(2).sum()
+    coef = torch.clamp(clip / (torch.sqrt(sq) + 1e-6), max=1.0)         # clip_grad_norm_'s rule on the global norm
+    if t is not None:
+        t.mark('coll_norm_all_reduce')
+    if grads:
+        torch._foreach_mul_(grads, coef)
+    opt.step()
+    table_opt.step(grad_scale=coef)                              # its all-gather is waited for before the next reader of the table
+    for p in small:
+        p.grad = None
+    table.grad = None
+    if t is not None:
+        t.mark('optimizer')
+
+
+def time_strong_rank(g, subs, all_labels, emb, hp, full_model, steps, warmup, rank=3, world=8, depth=2):
+    """BASELINE configs[3] as worded -- 50k subgraphs dealt to 8 GPUs -- as ONE of those ranks runs it, timed on this GPU in this
+    process: rank ``rank`` of ``world`` of `bench.py --gpus 8 --scaling strong --pipeline-multi`, with the
+    collectives' results supplied by dist.EmulatedPeers (recorded on the first pass: the values are those of the real sharded
+    run; what a link would carry is priced by the caller from ``received_bytes``).  The rank's work per pass:
+      preparation (side stream)  its 6 250 subgraphs' components, border search + N draws, degree sequences; ITS eighth of the
+                                 210 structure patches and of their walks (all-gathered); ONE 64-source BFS word (its 23 of the
+                                 183 position anchors) over ALL ranks' 50k components (all-to-all); DTW of its 6 250 x 210 pairs;
+      training half (main)       forward + backward replayed from a hipGraph (hotpath.CapturedTraining(optimizer=None):
+                                 collectives are not recorded), then eagerly: gradient exchange, global-norm clip, fused Adam on the
+                                 small parameters, Adam on ITS eighth of the embedding table (dist.ShardedTableAdam).
+    -> dict for the line's ``strong_rank8`` object."""
+    from subgnn_amd import hotpath
+    from subgnn_amd import dist as sdist
+    from subgnn_amd.SubGNN import SubGNN
+    total = len(subs)
+    a, b = sdist.shard_range(total, rank, world)
+    dev = emb.device
+    emu = sdist.EmulatedPeers(rank, world)
+    cc_all = full_model.train_cc_ids
+    emu.provided['cc_ids_all'] = cc_all.reshape(-1, cc_all.shape[-1])
+    emu.maxima[2] = torch.tensor([cc_all.shape[1], cc_all.shape[2]], dtype=torch.int32, device=dev)
+    widths = [v for k_, v in full_model._border_width.items() if k_[0] == 'train']
+    if widths:
+        emu.maxima[1] = widths[0]
+    shard = sdist.Shard(total, rank, world, deal_shared=True, emulator=emu)
+    labels = all_labels[a:b].clone()
+    model = SubGNN.from_memory(dict(hp), g, {'train': subs[a:b], 'val': [], 'test': []},
+                               {'train': labels, 'val': labels[:0], 'test': labels[:0]}, emb, num_classes=3)
+    model.train()
+    table = model.node_embeddings.weight
+    small = [p for p in model.parameters() if p.requires_grad and p is not table]
+    opt = torch.optim.Adam(small, lr=hp['learning_rate'], fused=True)
+    table_opt = sdist.ShardedTableAdam(table, hp['learning_rate'], average=True, emulate=(rank, world))
+    model._table_sync = table_opt.wait
+    trainer = hotpath.CapturedTraining(model, None, 'train', warmup=1)
+    pipe = hotpath.PassPipeline(model, 'train', shard)
+    side_timers = []
+
+    def step(timed):
+        timer = hotpath.StageTimer(timed)
+        timer.mark('start')
+        pipe.install(timer, installer=trainer.install)
+        if timed:
+            side_timers.append(pipe.timer)
+        installed = torch.cuda.Event()
+        installed.record()
+        loss, _acc = trainer.step()
+        timer.mark('forward+backward(hipGraph)')
+        # the gradient exchange + optimizer are queued BEFORE the host starts on the next preparation (its ~130 eager launches take
+        # the host longer than the device needs for them: queued behind them the tail started 2.7 ms late)
+        dp_tail(small, opt, table, table_opt, hp['grad_clip'], True, timer=timer)
+        pipe.start(timed, after=installed)
+        timer.mark('(host: next pass queued)')
+        return timer, loss
+    torch.cuda.synchronize()
+    t_cold = time.perf_counter()
+    for _ in range(depth):
+        pipe.start()
+    step(False)
+    torch.cuda.synchronize()
+    first_ms = (time.perf_counter() - t_cold) * 1e3
+    for _ in range(1 + warmup):
+        step(False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    timers = []
+    for _ in range(steps):
+        tm, loss = step(True)
+        timers.append(tm)
+    torch.cuda.synchronize()
+    ms = 1e3 * (time.perf_counter() - t0) / steps
+    stage, cnt = {}, {}
+    for tm in timers + side_timers:
+        for k, v in tm.summary().items():
+            stage[k] = stage.get(k, 0.0) + v
+            cnt[k] = cnt.get(k, 0) + 1
+    host, hcnt = {}, {}
+    for tm in timers + side_timers:
+        for k, v in tm.host_summary().items():
+            host[k] = host.get(k, 0.0) + v
+            hcnt[k] = hcnt.get(k, 0) + 1
+    recv = {str(k): int(v) for k, v in emu.received_bytes.items()}
+    out = {'rank': rank, 'world': world, 'subgraphs_of_the_rank': b - a, 'subgraphs_total': total, 'ms_per_step_device': ms,
+           'steps': steps, 'warmup': warmup,
+           'schedule': 'rank %d of %d of --scaling strong --pipeline-multi: dealt preparation on a second stream (%d passes in flight), '
+                       'forward + backward replayed from a hipGraph, gradient exchange + sharded optimizer eager behind it; the peers\' '
+                       'shares of every exchange come from recorded buffers (dist.EmulatedPeers), no byte crosses a link' % (rank, world, depth),
+           'first_pass_ms': round(first_ms, 1), 'recordings': trainer.recordings,
+           'stages_ms': {k: round(v / cnt[k], 3) for k, v in stage.items()},
+           'host_ms_per_stage(time the host needs to queue it)': {k: round(v / hcnt[k], 3) for k, v in host.items()},
+           'received_bytes_per_pass': recv, 'received_bytes_total': int(sum(recv.values())),
+           'table_gradient_bytes': int(table.numel() * 4), 'loss_of_the_rank': float(loss)}
+    del trainer, pipe, opt, table_opt, model
     torch.cuda.empty_cache()
     return out
 
@@ -321,7 +471,7 @@ def main():
     # Multi-rank runs keep the sequential schedule unless asked (--pipeline-multi): the pipelined one issues the prepared
     # pass's width reductions on a second stream beside the gradient exchange -- two communicators in flight, which a
     # one-GPU functional check over gloo cannot validate for RCCL over xGMI
-    pipelined = not args.no_pipeline and (not multi or (args.pipeline_multi and args.scaling != 'strong'))
+    pipelined = not args.no_pipeline and (not multi or args.pipeline_multi)
     # the prepared pass's width reductions run beside the gradient exchange of the pass in training: own communicator
     shard_group = dist.new_group() if (multi and pipelined) else None
     shard = sdist.Shard(total_subgraphs, rank, world, deal_shared=(args.scaling == 'strong'), group=shard_group) if multi else None
@@ -363,8 +513,15 @@ def main():
     # N = 1: the training half (component embeddings .. Adam) is recorded into a hipGraph on the second priming pass and
     # replayed: same kernels, one launch
     if multi:
-        graph_mode = 'off'
-    trainer = hotpath.CapturedTraining(model, opt, 'train', warmup=1) if graph_mode == 'train' else None
+        # N > 1: what can be recorded is forward + backward (collectives are not): shards of up to 16 384 subgraphs (--scaling strong),
+        # with the sharded head; the gradient exchange and the sharded optimizer run eagerly behind every replay.  The default
+        # (weak) form keeps everything eager, as before
+        graph_mode = args.graph
+        if graph_mode == 'auto':
+            graph_mode = 'train' if (S <= 16384 and not replicated) else 'off'
+        if graph_mode == 'both' or (graph_mode == 'train' and replicated):
+            graph_mode = 'off'
+    trainer = hotpath.CapturedTraining(model, None if multi else opt, 'train', warmup=1) if graph_mode == 'train' else None
     graphed = hotpath.GraphedPasses(model, opt, 'train', warmup=2) if graph_mode == 'both' else None
 
     stage_ms = {}
@@ -446,7 +603,10 @@ def main():
             installed = torch.cuda.Event()
             installed.record()
             loss, _acc = trainer.step()                          # one graph launch: on the device before the host queues anything else
-            timer.mark('training_half(hipGraph)')
+            timer.mark('training_half(hipGraph)' if not multi else 'forward+backward(hipGraph)')
+            if multi:
+                multi_tail(timer)                                # gradient exchange + sharded optimizer: eager (collectives are not recorded),
+                #                                                  queued before the host starts on the next preparation
             if pipe is not None:
                 pipe.start(timed, after=installed)               # the next pass: side stream, beside this step's training
                 timer.mark('(host: next pass queued)')
@@ -478,31 +638,21 @@ def main():
             opt.zero_grad(set_to_none=True)
             timer.mark('optimizer')
             return timer, out['loss'].detach()
+        multi_tail(timer)
+        return timer, out['loss'].detach()
+
+    def multi_tail(timer):
         if replicated:
             # The loss is the mean over the GLOBAL batch and the head is replicated: head gradients are already
             # complete and identical on every rank; channel parameters (message-passing layers, LSTM, the table)
             # hold this rank's share of the sum.
-            sdist.all_reduce_gradients(channel_params, average=False)
+            reduce_small = lambda ps, avg: sdist.all_reduce_gradients(channel_params, average=False)
         else:
             # every rank's loss is the mean over its own (equally many) subgraphs: the global mean is the mean of
             # those, and so are all gradients (the table's: ShardedTableAdam(average=True))
-            sdist.all_reduce_gradients(small, average=True)
-        timer.mark('coll_small_gradients_all_reduce')
-        sq = table_opt.reduce_grad()
-        timer.mark('coll_table_gradient_reduce_scatter')
-        torch.distributed.all_reduce(sq)
-        total = torch.sqrt(sq + sum((p.grad.float() ** 2).sum() for p in small if p.grad is not None))
-        coef = torch.clamp(hp['grad_clip'] / (total + 1e-6), max=1.0)         # clip_grad_norm_'s rule on the global norm
-        timer.mark('coll_norm_all_reduce')
-        for p in small:
-            if p.grad is not None:
-                p.grad.mul_(coef)
-        opt.step()
-        table_opt.step(grad_scale=coef)                          # its all-gather is waited for inside the next prepare_sparse
-        opt.zero_grad(set_to_none=True)
-        table.grad = None
-        timer.mark('optimizer')
-        return timer, out['loss'].detach()
+            reduce_small = lambda ps, avg: sdist.all_reduce_gradients(ps, average=True)
+        dp_tail(small, opt, table, table_opt, hp['grad_clip'], not replicated, all_reduce_small=reduce_small,
+                all_reduce_scalar=torch.distributed.all_reduce, timer=timer)
 
     if dist:
         # communicator set-up happens lazily at the first collective of each kind and size class: do it
@@ -749,7 +899,7 @@ def main():
                        'source': 'profiles/' + os.path.basename(pj) + ' (rocprofv3 --pmc, committed measurement of the external-side launch; '
                                  '%d wavefronts per SIMD; SIMD busy = 4 x SQ_ACTIVE_INST_VALU / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs))' % wps}
     # ---- N = 1: measured beside the headline, in this process -----------------------------------------
-    sequential_ms = shard_line = configs_obj = pool_reuse_ms = None
+    sequential_ms = shard_line = strong_line = configs_obj = pool_reuse_ms = None
     if world == 1 and not args.no_extras and graphed is None:
         # (1) the schedule `--gpus 8` runs by default: sequential passes, two-stream preparation -- what projection.weak_* uses
         for _ in range(2):
@@ -798,6 +948,15 @@ def main():
             except Exception as ex:
                 shard_line = None
                 print('shard6250 not measured: %r' % (ex,), file=sys.stderr)
+            # (2b) ... and one rank of eight AS THAT RANK RUNS IT (dealt shared work, one BFS word, an eighth of the table's Adam)
+            try:
+                strong_line = time_strong_rank(g, subs, all_labels, emb, hp, model, steps=max(10, args.steps), warmup=3,
+                                               depth=max(1, args.pipeline_depth))
+            except Exception as ex:
+                strong_line = None
+                import traceback
+                traceback.print_exc()
+                print('strong_rank8 not measured: %r' % (ex,), file=sys.stderr)
         # (3) the batch-sized training steps of the other BASELINE configurations (stand-ins: SURVEY 8, statistics unverified),
         # replayed from a hipGraph and eager, with the kernels one step launches
         from subgnn_amd import standins
@@ -812,10 +971,11 @@ def main():
                 continue
             try:
                 t_c = time.perf_counter()
-                line = standins.bench_config(name, steps=20, warmup=5, also_atomics=True)
+                line = standins.bench_config(name, steps=20, warmup=5, also_atomics=True, epochs=4)
                 configs_obj[key] = {'standin': name, 'workload': line['config']['workload'], 'batch': line['config']['cc_ids_shape'],
                                     'ms_per_step_replayed': round(line['ms_per_step'], 3), 'ms_per_step_eager': round(line['eager']['ms_per_step'], 3),
                                     'subgraphs_per_s': round(line['value']), 'kernels_per_step': line['kernels_per_step'],
+                                    'epoch': line.get('epoch'),
                                     'with_float_atomics(hparams deterministic=False; not the default)': None if not line.get('atomics') else {
                                         'ms_per_step_replayed': round(line['atomics']['ms_per_step'], 3), 'kernels_per_step': line['atomics']['kernels_per_step']},
                                     'prepare_data_s': line['prepare_data_s'], 'wall_s': round(time.perf_counter() - t_c, 1)}
@@ -890,7 +1050,7 @@ def main():
         'warm_up_ms_at_construction': round(1e3 * getattr(model, 'warm_up_s', 0.0), 1),
     }
     if world == 1 and args.scaling == 'weak':
-        result['projection'] = projection(args, result, model, S, sequential_ms, shard_line)
+        result['projection'] = projection(args, result, model, S, sequential_ms, shard_line, strong_line)
     if sequential_ms is not None:
         result['sequential_ms_per_step'] = round(sequential_ms, 3)
     if pool_reuse_ms is not None:
@@ -902,6 +1062,8 @@ def main():
                                    'pipelined schedule; bit-equal per consumed column (tests/test_gpu_hotpath.py::test_pool_reuse_pass_equals_a_full_pass)'}
     if shard_line is not None:
         result['shard6250'] = shard_line
+    if strong_line is not None:
+        result['strong_rank8'] = strong_line
     if configs_obj is not None:
         result['configs'] = configs_obj
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

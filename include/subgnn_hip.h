@@ -38,7 +38,7 @@ extern "C" {
 #define SGNN_ERR_LAUNCH         -4   /* hipGetLastError() after a launch */
 #define SGNN_ERR_UNSUPPORTED_D  -5   /* embedding width not supported by the vector path */
 
-#define SGNN_ABI_VERSION 9
+#define SGNN_ABI_VERSION 10
 int sgnn_abi_version(void);
 /* Load the code objects of every translation unit of the library on the current device (one empty launch each on ``stream``):
  * what the first call of each kernel family would otherwise pay, 5-25 ms at a time, inside the reference's one-time
@@ -577,6 +577,26 @@ int sgnn_readout_sum_bwd(const float* grad_out, int64_t grad_ld, const float* si
                          int64_t C, int64_t A, float* grad_s, float* grad_bp, void* workspace, int64_t workspace_bytes,
                          void* stream);
 
+/* Every read-out piece of a step in ONE launch each way (n <= sgnn_readout_many_max() pieces; all arrays HOST arrays with one
+ * entry per piece, of DEVICE pointers where they hold pointers).  Piece k: similarity rows sims[k] (ld sims_ld[k]; NULL = all
+ * zero), columns sim_col[k] (nullable), anchor embeddings X[k] (A[k], D) with read-out weight wp[k] (D) -- the scores
+ * s[a] = X[a, :] . wp, 0 where ids[k][a] == 0 (ids nullable) or X[k] is NULL, are computed by the call into s[k] (A[k] floats) --
+ * bias bp[k], row mask row_mask[k] (nullable), column slot off[k] .. off[k] + A[k] of the (B, out_ld) embedding.
+ * Backward: grad_X[k] (A[k], D), grad_wp[k] (D), grad_bp[k] (1), each nullable; tickets: RO_MAX_PIECES uint32, zero before the
+ * first call and left zero.  Same sums in the same order as the single-piece calls. */
+int64_t sgnn_readout_many_max(void);
+int sgnn_readout_many_fwd(int64_t n, const float* const* sims, const int64_t* sims_ld, const int64_t* const* sim_col,
+                          const float* const* X, const float* const* wp, const float* const* bp,
+                          const int64_t* const* ids, const uint8_t* const* row_mask, float* const* s, const int64_t* A,
+                          const int64_t* off, int64_t D, int64_t B, int64_t C, float* out, int64_t out_ld, void* stream);
+int64_t sgnn_readout_many_bwd_workspace_bytes(int64_t n, const int64_t* A, int64_t B, int64_t C);
+int sgnn_readout_many_bwd(int64_t n, const float* grad_out, int64_t grad_ld, const float* const* sims, const int64_t* sims_ld,
+                          const int64_t* const* sim_col, const float* const* X, const float* const* wp,
+                          const float* const* bp, const int64_t* const* ids, const uint8_t* const* row_mask,
+                          float* const* s, const int64_t* A, const int64_t* off, int64_t D, int64_t B, int64_t C,
+                          float* const* grad_X, float* const* grad_wp, float* const* grad_bp, void* workspace,
+                          int64_t workspace_bytes, unsigned* tickets, void* stream);
+
 /* ---------------------------------------------------------------------------------------
  * a18  Embedding-table gradient without atomics (the backward of every op that gathers table rows:
  * autograd of SubGNN/SubGNN.py:609-622, anchor_patch_samplers.py:404-411, subgraph_mpn.py:227-231 as
@@ -732,11 +752,60 @@ int sgnn_optim_adam(float* const* params, float* const* grads, float* const* exp
 
 /* A batch's rows of up to sgnn_gather_rows_many_max() per-split tensors in ONE launch (the row gathers of _pad_collate,
  * SubGNN/SubGNN.py:1068-1114: component ids, border ids, the channels' similarity rows, labels): dst[t][i, :] =
- * src[t][idx[i], :] with rows as raw bytes -- row_bytes[t] each, src_rows[t] rows in the source (an index outside it reads row 0).
+ * src[t][idx[i], :] with rows as raw bytes -- row_bytes[t] each, src_rows[t] rows in the source.  An index outside the source
+ * (index_select raises for it) yields a ZERO row and sets *out_of_range (nullable DEVICE int32, never cleared here) to 1: the
+ * caller polls the flag.  n * B up to 2^30 (the pair travels in blockIdx.x).
  * src / dst / row_bytes / src_rows: HOST arrays (src / dst of DEVICE pointers); idx: DEVICE int64[B]. */
 int64_t sgnn_gather_rows_many_max(void);
 int sgnn_gather_rows_many(int64_t n, const void* const* src, void* const* dst, const int64_t* row_bytes,
-                          const int64_t* src_rows, const int64_t* idx, int64_t B, void* stream);
+                          const int64_t* src_rows, const int64_t* idx, int64_t B, int32_t* out_of_range, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * a16/a17 fused  The MLP head of SubGNN.forward + the loss of a training step (SubGNN/SubGNN.py:304-312: lin -> relu -> dropout
+ * -> lin2 -> relu -> dropout -> lin3; SubGNN.py:1116-1124: nn.CrossEntropyLoss + subgraph_utils.calc_accuracy) behind the first
+ * layer's GEMM: z1 = x W1^T + b1 (B, H1) comes from the caller's library GEMM, as does dx = dz1 W1 in the backward.
+ *   sgnn_head_supported(H1, H2, K)   1 when the widths fit the kernels' LDS tables (H1, H2 <= 128, K <= 32)
+ *   sgnn_head_blocks(B)              workgroups of either launch; the backward writes sgnn_head_partial_floats(H1, H2, K) floats
+ *                                    per workgroup: [gW3 (K H2) | gb3 (K) | gW2 (H2 H1) | gb2 (H2) | gb1 (H1)], to be added over the
+ *                                    workgroups in order (sgnn_reduce_partials)
+ *   sgnn_head_fwd    a1 = drop(relu(z1)) (B, H1), a2 = drop(relu(a1 W2^T + b2)) (B, H2), logits = a2 W3^T + b3 (B, K); with labels
+ *                    (int64 in [0, K) or -100, nullable) also lse (B + 1 floats, [B] = rows counted) and out = [mean loss,
+ *                    accuracy over all B rows, rows counted].  p: dropout probability of both layers; p > 0 reads rng =
+ *                    DEVICE int64[2] {seed, step} and ADVANCES step by one (the last workgroup does, after every workgroup has read
+ *                    it): masks are a pure function of (seed, step, layer, element), so a step replayed from a hipGraph draws new
+ *                    ones.  workspace: sgnn_head_fwd_workspace_bytes(B) bytes, its last 16 bytes ZERO before the first call (a
+ *                    ticket the launch leaves zero).  Loss partials are added in workgroup order: bit-reproducible.
+ *   sgnn_head_bwd    dlogits = (softmax - onehot) grad_loss[0] / rows[0] (+ grad_logits, nullable) -> dz1 (B, H1) and the
+ *                    per-workgroup partials above.  grad_loss nullable (then only grad_logits flows).
+ * ------------------------------------------------------------------------------------- */
+int sgnn_head_supported(int64_t H1, int64_t H2, int64_t K);
+int64_t sgnn_head_blocks(int64_t B);
+int64_t sgnn_head_partial_floats(int64_t H1, int64_t H2, int64_t K);
+int64_t sgnn_head_fwd_workspace_bytes(int64_t B);
+int sgnn_head_fwd(const float* z1, int64_t B, int64_t H1, int64_t H2, int64_t K, const float* W2, const float* b2,
+                  const float* W3, const float* b3, const int64_t* labels, float p, int64_t* rng, float* a1, float* a2,
+                  float* logits, float* lse, float* out, void* workspace, int64_t workspace_bytes, void* stream);
+int sgnn_head_bwd(const float* logits, const float* lse, const int64_t* labels, const float* grad_loss,
+                  const float* grad_logits, const float* rows, const float* a1, const float* a2, const float* W2,
+                  const float* W3, int64_t B, int64_t H1, int64_t H2, int64_t K, float p, float* dz1, float* partial,
+                  void* stream);
+
+/* A^T B for tall operands (the weight gradients of Linear / LSTM layers: outputs of a few thousand elements contracted over
+ * thousands of rows -- a library GEMM runs them on a handful of workgroups): job k contracts A[k] (R[k], M[k]) with B[k]
+ * (R[k], N[k]), row strides lda / ldb floats, over blocks of rows on the matrix cores (fp32 MFMA, fp32 accumulate) and writes
+ * part[k] = (sgnn_contract_rows_blocks(R[k]), M[k], N[k]) block partials; sgnn_reduce_partials adds them in block order (a fixed
+ * order: bit-reproducible).  Up to sgnn_contract_rows_max_jobs() jobs per launch.  All arrays are HOST arrays (of DEVICE
+ * pointers where they hold pointers).
+ * sgnn_reduce_partials: out[k][j] = sum_b part[k][b * n[k] + j] over n_blocks[k] blocks, up to sgnn_reduce_partials_max_jobs()
+ * jobs per launch. */
+int64_t sgnn_contract_rows_max_jobs(void);
+int64_t sgnn_contract_rows_blocks(int64_t R);
+int sgnn_contract_rows_partial(int64_t n_jobs, const float* const* A, const float* const* B, const int64_t* lda,
+                               const int64_t* ldb, const int64_t* M, const int64_t* N, const int64_t* R,
+                               float* const* part, void* stream);
+int64_t sgnn_reduce_partials_max_jobs(void);
+int sgnn_reduce_partials(int64_t n_jobs, const float* const* part, const int64_t* n_blocks, const int64_t* n,
+                         float* const* out, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Measurement aid (no reference counterpart): streaming copy of n_bytes with 4 or 16 bytes per lane.

@@ -748,8 +748,14 @@ class SubGNN(nn.Module):
         for nm in CC_SLOTS:
             state[nm] = torch.index_select(given[nm], 0, sidx) if hp['trainable_cc'] else init_cc_embeds
         B, C, _ = init_cc_embeds.shape
-        cc_embed_mask = cc_ids[:, :, 0] != config.PAD_VALUE          # (the first column only: a component is real iff it has a member)
-        cc_embed_mask._sgnn_u8 = cc_embed_mask.reshape(-1).to(torch.uint8)
+        made = getattr(cc_ids, '_sgnn_mask', None)                    # (hotpath.prepare_pass makes both beside the sampling stages)
+        made8 = getattr(cc_ids, '_sgnn_mask_u8', None)
+        if made is not None and made8 is not None and tuple(made.shape) == (B, C) and made8.numel() == B * C and made.device == cc_ids.device:
+            cc_embed_mask = made.view(B, C)                            # (a fresh view object: the attribute below must not land on the kept tensor)
+            cc_embed_mask._sgnn_u8 = made8
+        else:
+            cc_embed_mask = cc_ids[:, :, 0] != config.PAD_VALUE      # (the first column only: a component is real iff it has a member)
+            cc_embed_mask._sgnn_u8 = cc_embed_mask.reshape(-1).to(torch.uint8)
         bn = hp.get('batch_norm', False)
         # without an attention read-out or a gathered head the channel outputs are consumed only as their masked sum over a
         # subgraph's components: every piece is summed straight into its slot of the subgraph embedding
@@ -811,8 +817,36 @@ class SubGNN(nn.Module):
             subgraph_embedding = subgraph_utils.masked_sum(all_cc_embeds, cc_embed_mask.unsqueeze(-1), dim=1)
         return self._head(subgraph_embedding)
 
+    def _dropout_rng(self):
+        """{seed, step} of the fused head's dropout masks, int64 (2,) on the device: the seed is torch's CUDA seed at the first
+        training forward (``torch.manual_seed`` / ``torch.cuda.manual_seed`` as the caller set it: two same-seed models draw the
+        same masks, whatever ran before them in the process), the step is advanced by every training forward ON THE DEVICE, so
+        a step replayed from a hipGraph draws fresh masks.  Created outside any recording (an upload)."""
+        st = self.__dict__.get('_head_rng')
+        if st is None or st.device != self.node_embeddings.weight.device:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError('the dropout state of the head must exist before a step is recorded (run one eager training step first)')
+            seed = int(torch.cuda.initial_seed()) & ((1 << 63) - 1)
+            st = self.__dict__['_head_rng'] = torch.tensor([seed, 0], dtype=torch.int64, device=self.node_embeddings.weight.device)
+        return st
+
     def _head(self, subgraph_embedding):
-        """S.py:304-312."""
+        """S.py:304-312.  One fused launch behind the first layer's GEMM (ops.fused_head: csrc/head.hip) when the widths fit;
+        with the step's labels at hand (training_step leaves them in ``_head_labels``) the same launch computes the loss and
+        the accuracy and leaves them in ``_head_result``."""
+        hp = self.hparams
+        labels = self.__dict__.pop('_head_labels', None)
+        x = subgraph_embedding
+        if (hp.get('fused_forward', True) and hp.get('fused_head', True) and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2
+                and x.shape[0] > 0 and ops.head_supported(self.lin.out_features, self.lin2.out_features, self.lin3.out_features)
+                and all(l.bias is not None for l in (self.lin, self.lin2, self.lin3))):
+            p = float(self.lin_dropout.p) if self.training else 0.0
+            if labels is not None and (labels.dim() != 1 or labels.shape[0] != x.shape[0] or labels.dtype != torch.int64):
+                labels = None
+            logits, loss, acc = ops.fused_head(x, self.lin, self.lin2, self.lin3, labels, p, self._dropout_rng() if p > 0 else None)
+            if labels is not None:
+                self.__dict__['_head_result'] = (loss, acc)
+            return logits
         h = self.lin_dropout(F.relu(ops.linear(subgraph_embedding, self.lin.weight, self.lin.bias)))
         h = self.lin_dropout2(F.relu(ops.linear(h, self.lin2.weight, self.lin2.bias)))
         return ops.linear(h, self.lin3.weight, self.lin3.bias)
@@ -835,7 +869,19 @@ class SubGNN(nn.Module):
 
     def training_step(self, train_batch, batch_idx):
         labels = train_batch['label'].squeeze(-1)
-        logits = self._forward_batch('train', train_batch)
+        fusable = not self.multilabel and labels.is_cuda and labels.dim() == 1 and type(self.loss) is nn.CrossEntropyLoss \
+            and self.hparams.get('fused_forward', True)
+        self.__dict__.pop('_head_result', None)
+        if fusable:
+            self.__dict__['_head_labels'] = labels          # the head computes loss + accuracy in its own launch (_head)
+        try:
+            logits = self._forward_batch('train', train_batch)
+        finally:
+            self.__dict__.pop('_head_labels', None)
+        done = self.__dict__.pop('_head_result', None)
+        if done is not None:
+            loss, acc = done
+            return {'loss': loss, 'log': {'train_loss': loss, 'train_acc': acc}}
         if not self.multilabel and logits.is_cuda and logits.dim() == 2 and labels.dim() == 1 and logits.dtype == torch.float32 \
                 and type(self.loss) is nn.CrossEntropyLoss and self.hparams.get('fused_forward', True):
             # cross entropy + accuracy in one pass over the logits (ops.cross_entropy_with_accuracy): the library's nll
@@ -863,6 +909,8 @@ class SubGNN(nn.Module):
 
     def _epoch_metrics(self, outputs, p):
         from sklearn.metrics import roc_auc_score
+        if outputs and outputs[0][p + '_logits'].is_cuda:
+            ops.poll_index_errors(block=True)           # (a device-side batch index outside its split: reported here at the latest)
         logits = torch.cat([x[p + '_logits'] for x in outputs], dim=0).detach()
         labels = torch.cat([x[p + '_labels'] for x in outputs], dim=0)
         mb = self.multilabel_binarizer

@@ -118,7 +118,26 @@ SIGNATURES = {
     'sgnn_readout_sum_bwd': (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_ptr, c_ptr,
                                      c_ptr, c_i64, c_ptr]),
     'sgnn_gather_rows_many_max': (c_i64, []),
-    'sgnn_gather_rows_many': (c_int, [c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr]),
+    'sgnn_readout_many_max': (c_i64, []),
+    'sgnn_readout_many_fwd': (c_int, [c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64,
+                                      c_i64, c_ptr, c_i64, c_ptr]),
+    'sgnn_readout_many_bwd_workspace_bytes': (c_i64, [c_i64, c_ptr, c_i64, c_i64]),
+    'sgnn_readout_many_bwd': (c_int, [c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr,
+                                      c_i64, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_ptr]),
+    'sgnn_gather_rows_many': (c_int, [c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_ptr]),
+    'sgnn_head_supported': (c_int, [c_i64, c_i64, c_i64]),
+    'sgnn_head_blocks': (c_i64, [c_i64]),
+    'sgnn_head_partial_floats': (c_i64, [c_i64, c_i64, c_i64]),
+    'sgnn_head_fwd_workspace_bytes': (c_i64, [c_i64]),
+    'sgnn_head_fwd': (c_int, [c_ptr, c_i64, c_i64, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, ctypes.c_float, c_ptr, c_ptr, c_ptr,
+                              c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr]),
+    'sgnn_head_bwd': (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_i64,
+                              ctypes.c_float, c_ptr, c_ptr, c_ptr]),
+    'sgnn_contract_rows_max_jobs': (c_i64, []),
+    'sgnn_contract_rows_blocks': (c_i64, [c_i64]),
+    'sgnn_contract_rows_partial': (c_int, [c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
+    'sgnn_reduce_partials_max_jobs': (c_i64, []),
+    'sgnn_reduce_partials': (c_int, [c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
     'sgnn_probe_stream_copy': (c_int, [c_ptr, c_ptr, c_i64, c_int, c_ptr]),
     'sgnn_scatter_add_rows_workspace_bytes': (c_i64, [c_i64, c_i64]),
     'sgnn_mpn_bwd_shared_det_workspace_bytes': (c_i64, [c_i64, c_i64, c_i64]),
@@ -179,7 +198,7 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the header and the library disagree
         fn.restype = res
         fn.argtypes = args
-    if lib.sgnn_abi_version() != 9:
+    if lib.sgnn_abi_version() != 10:
         raise SubgnnHipError('ABI version mismatch')
     _lib = lib
     return lib

@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIBDIR = os.path.join(HERE, 'lib')
 LIB = os.path.join(LIBDIR, 'libsubgnn_hip.so')
-SOURCES = ['lib.hip', 'degree_sequence.hip', 'graph_sets.hip', 'samplers.hip', 'similarity.hip', 'dtw.hip', 'embed.hip', 'mpn.hip', 'attention.hip', 'lstm.hip', 'probe.hip', 'scatter.hip', 'update.hip', 'optim.hip', 'readout.hip', 'loss.hip']
+SOURCES = ['lib.hip', 'degree_sequence.hip', 'graph_sets.hip', 'samplers.hip', 'similarity.hip', 'dtw.hip', 'embed.hip', 'mpn.hip', 'attention.hip', 'lstm.hip', 'probe.hip', 'scatter.hip', 'update.hip', 'optim.hip', 'readout.hip', 'loss.hip', 'head.hip']
 ARCH = 'gfx950'
 # dtw.hip: no NaN can arise in the DP (costs are finite or +inf, only min and + are applied); telling the compiler so removes
 # the canonicalising v_max x, x it otherwise puts in front of every v_min_f64 (3 of 16 instructions per cell)

@@ -231,7 +231,9 @@ extern "C" int sgnn_masked_sum_bwd(const float* grad_out, const uint8_t* mask, i
 // _pad_collate (SubGNN/SubGNN.py:1068-1114) assembles a batch from the per-subgraph tensors of a split: component ids, border
 // ids, the similarity rows of three channels, labels -- 7-12 row gathers of a few KB to 30 MB each, one library launch apiece.
 // Here: dst[t][i, :] = src[t][idx[i], :] for every listed tensor (rows as raw bytes).  Tensors travel as kernel arguments;
-// blockIdx.y = (tensor, batch row), blockIdx.x strides over the row.
+// blockIdx.x = (tensor, batch row) -- the dimension that may be large: a whole split x 24 tensors --, blockIdx.y strides over
+// the row.  An index outside its source (index_select raises for it) yields a ZERO row and sets *out_of_range, which the
+// caller polls (ops.poll_index_errors): the failure stays observable although nothing here can raise.
 #define GM_MAX 24
 struct GatherMany {
     const unsigned char* src[GM_MAX];
@@ -241,17 +243,22 @@ struct GatherMany {
     int count;
 };
 
-__global__ __launch_bounds__(256) void gather_rows_many_kernel(const GatherMany G, const int64_t* __restrict__ idx, int64_t B)
+__global__ __launch_bounds__(256) void gather_rows_many_kernel(const GatherMany G, const int64_t* __restrict__ idx, int64_t B,
+                                                               int32_t* __restrict__ out_of_range)
 {
-    const int64_t y = blockIdx.y;
+    const int64_t y = blockIdx.x;
     const int t = (int)(y / B);
     const int64_t i = y - (int64_t)t * B;
-    int64_t r = idx[i];
-    if (r < 0 || r >= G.src_rows[t]) r = 0;                 // (torch raises for such an index; the caller checks host-side lists)
+    const int64_t r = idx[i];
     const int64_t nb = G.row_bytes[t];
-    const unsigned char* __restrict__ s = G.src[t] + r * nb;
     unsigned char* __restrict__ d = G.dst[t] + i * nb;
-    const int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x, stride = (int64_t)gridDim.x * 256;
+    const int64_t tid = (int64_t)blockIdx.y * 256 + threadIdx.x, stride = (int64_t)gridDim.y * 256;
+    if (r < 0 || r >= G.src_rows[t]) {
+        if (out_of_range && tid == 0) *out_of_range = 1;
+        for (int64_t k = tid; k < nb; k += stride) d[k] = 0;
+        return;
+    }
+    const unsigned char* __restrict__ s = G.src[t] + r * nb;
     if ((((uintptr_t)s | (uintptr_t)d | (uintptr_t)nb) & 15) == 0) {
         for (int64_t k = tid; k < nb / 16; k += stride) reinterpret_cast<uint4*>(d)[k] = reinterpret_cast<const uint4*>(s)[k];
     } else if ((((uintptr_t)s | (uintptr_t)d | (uintptr_t)nb) & 3) == 0) {
@@ -264,7 +271,7 @@ __global__ __launch_bounds__(256) void gather_rows_many_kernel(const GatherMany 
 extern "C" int64_t sgnn_gather_rows_many_max(void) { return GM_MAX; }
 
 extern "C" int sgnn_gather_rows_many(int64_t n, const void* const* src, void* const* dst, const int64_t* row_bytes,
-                                     const int64_t* src_rows, const int64_t* idx, int64_t B, void* stream)
+                                     const int64_t* src_rows, const int64_t* idx, int64_t B, int32_t* out_of_range, void* stream)
 {
     if (n < 0 || n > GM_MAX || B < 0 || (n && (!src || !dst || !row_bytes || !src_rows)) || (n && B && !idx)) return SGNN_ERR_BAD_ARG;
     if (n == 0 || B == 0) return SGNN_OK;
@@ -281,7 +288,7 @@ extern "C" int sgnn_gather_rows_many(int64_t n, const void* const* src, void* co
     int gx = (int)((longest + 16 * 256 * 4 - 1) / (16 * 256 * 4));          // ~4 vectors per lane for the longest row
     if (gx < 1) gx = 1;
     if (gx > 64) gx = 64;
-    hipLaunchKernelGGL(gather_rows_many_kernel, dim3((unsigned)gx, (unsigned)(n * B)), dim3(256), 0, (hipStream_t)stream, G, idx, B);
+    hipLaunchKernelGGL(gather_rows_many_kernel, dim3((unsigned)(n * B), (unsigned)gx), dim3(256), 0, (hipStream_t)stream, G, idx, B, out_of_range);
     SGNN_CHECK_LAUNCH();
     return SGNN_OK;
 }

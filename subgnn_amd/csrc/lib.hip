@@ -29,6 +29,7 @@ extern "C" int sgnn_warm_update(void*);
 extern "C" int sgnn_warm_optim(void*);
 extern "C" int sgnn_warm_readout(void*);
 extern "C" int sgnn_warm_loss(void*);
+extern "C" int sgnn_warm_head(void*);
 extern "C" int sgnn_warm_up(void* stream)
 {
     int bad = 0;
@@ -47,5 +48,6 @@ extern "C" int sgnn_warm_up(void* stream)
     bad += sgnn_warm_optim(stream) != 0;
     bad += sgnn_warm_readout(stream) != 0;
     bad += sgnn_warm_loss(stream) != 0;
+    bad += sgnn_warm_head(stream) != 0;
     return bad == 0 ? SGNN_OK : SGNN_ERR_LAUNCH;
 }

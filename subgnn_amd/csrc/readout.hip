@@ -226,6 +226,341 @@ extern "C" int sgnn_readout_sum_bwd(const float* grad_out, int64_t grad_ld, cons
     return SGNN_OK;
 }
 
+// ---- every read-out piece of a step in one launch each way ------------------------------------------------------------------
+// A pass has one read-out piece per channel side whose last layer runs over SHARED anchors or all-zero similarities (benchmark:
+// P internal, P border, S internal, S border).  Each was: s = X wp (a matrix-vector launch), its PAD mask (three element-wise
+// launches), the slot launch above; backward: partials + finish per piece, then the backward of s = X wp (two more products and
+// two multiplies) -- 11 launches forward and 15 backward per pass.  Here: the scores of all pieces in one launch
+// (readout_scores_kernel), all slots in one (blockIdx.y = piece), the backward partials in one, and one finish launch that
+// also turns d s into d X = d s wp^T (the wavefront that owns column a writes row a) and, in the piece's last workgroup (a
+// ticket), d wp = X^T d s and d bp.  Every sum keeps the fixed order of the single-piece kernels.
+#define RO_MAX_PIECES 8
+struct RoPieces {
+    const float* sims[RO_MAX_PIECES]; long long ld[RO_MAX_PIECES]; const int64_t* sim_col[RO_MAX_PIECES];
+    const float* X[RO_MAX_PIECES];            // (A, D) anchor embeddings; null: all scores zero (all-zero similarities)
+    const float* wp[RO_MAX_PIECES]; const float* bp[RO_MAX_PIECES];
+    const int64_t* ids[RO_MAX_PIECES];        // nullable (A): anchor id 0 = PAD -> score 0
+    const uint8_t* row_mask[RO_MAX_PIECES];
+    float* s[RO_MAX_PIECES];                  // (A) scores: written by the scores launch, read by the others
+    int A[RO_MAX_PIECES]; int off[RO_MAX_PIECES];
+    float* partial_s[RO_MAX_PIECES]; float* partial_b[RO_MAX_PIECES];
+    float* gX[RO_MAX_PIECES]; float* gwp[RO_MAX_PIECES]; float* gbp[RO_MAX_PIECES]; float* gs[RO_MAX_PIECES];
+    unsigned* ticket;                         // RO_MAX_PIECES counters, zero before the launch, left zero
+    int D; int count;
+};
+
+__global__ __launch_bounds__(256) void readout_scores_kernel(const RoPieces P)
+{
+    const int p = blockIdx.x, A = P.A[p], D = P.D;
+    const float* __restrict__ X = P.X[p];
+    const float* __restrict__ wp = P.wp[p];
+    const int64_t* __restrict__ ids = P.ids[p];
+    for (int a = threadIdx.x; a < A; a += 256) {
+        double v = 0.0;                          // (a few hundred dot products of D terms per step: accumulated in double, rounded once)
+        if (X && !(ids && ids[a] == 0)) {
+            const float* __restrict__ x = X + (int64_t)a * D;
+            for (int d = 0; d < D; ++d) v = fma((double)x[d], (double)wp[d], v);
+        }
+        P.s[p][a] = (float)v;
+    }
+}
+
+__global__ __launch_bounds__(256) void readout_sum_fwd_many_kernel(const RoPieces P, int64_t B, int32_t C, float* __restrict__ out,
+                                                                   int64_t out_ld)
+{
+    const int p = blockIdx.y, A = P.A[p];
+    const int64_t total = B * A;
+    if ((int64_t)blockIdx.x * 1024 >= total) return;
+    const int64_t T = ((total + 1023) / 1024) * 256;
+    const int64_t t0 = blockIdx.x * 256ll + threadIdx.x;
+    const float* __restrict__ sims = P.sims[p];
+    const int64_t* __restrict__ sim_col = P.sim_col[p];
+    const uint8_t* __restrict__ row_mask = P.row_mask[p];
+    const float* __restrict__ s = P.s[p];
+    const int64_t ld = P.ld[p];
+    const float bb = P.bp[p][0];
+    int64_t b[4], col[4];
+    int32_t a[4];
+    float sa[4], acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int64_t t = t0 + j * T;
+        const bool on = t < total;
+        b[j] = on ? t / A : -1;
+        a[j] = on ? (int32_t)(t - b[j] * A) : 0;
+        sa[j] = s[a[j]];
+        col[j] = sim_col ? sim_col[a[j]] : a[j];
+        acc[j] = 0.f;
+    }
+    for (int32_t c0 = 0; c0 < C; c0 += 4) {
+        float w[4][4];
+        bool live[4][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int64_t r = b[j] * C + c0 + u;
+                live[u][j] = b[j] >= 0 && c0 + u < C && (!row_mask || row_mask[r]);
+                w[u][j] = (live[u][j] && sims) ? sims[r * ld + col[j]] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (live[u][j]) acc[j] += fmaxf(fmaf(w[u][j], sa[j], bb), 0.f);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (b[j] >= 0) out[b[j] * out_ld + P.off[p] + a[j]] = acc[j];
+}
+
+__global__ __launch_bounds__(256) void readout_sum_bwd_partial_many_kernel(const RoPieces P, const float* __restrict__ g, int64_t g_ld,
+                                                                           int64_t R, int32_t C, int64_t nblk)
+{
+    __shared__ float sh_s[RO_TR][RO_TA];
+    __shared__ float sh_b[256];
+    const int p = blockIdx.y, A = P.A[p];
+    const float* __restrict__ sims = P.sims[p];
+    const int64_t* __restrict__ sim_col = P.sim_col[p];
+    const uint8_t* __restrict__ row_mask = P.row_mask[p];
+    const float* __restrict__ s = P.s[p];
+    const int64_t ld = P.ld[p];
+    g += P.off[p];
+    float* __restrict__ partial_s = P.partial_s[p];
+    float* __restrict__ partial_b = P.partial_b[p];
+    const int ta = threadIdx.x % RO_TA, tr = threadIdx.x / RO_TA;
+    const int64_t blk = blockIdx.x;
+    const int64_t r0 = blk * RO_ROWS_PER_BLOCK;
+    const int nrows = (int)((r0 + RO_ROWS_PER_BLOCK < R ? r0 + RO_ROWS_PER_BLOCK : R) - r0);
+    const float bb = P.bp[p][0];
+    constexpr int PER = RO_ROWS_PER_BLOCK / RO_TR;
+    uint32_t live = 0;
+    int32_t sub[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int i = tr + k * RO_TR;
+        if (i < nrows && (!row_mask || row_mask[r0 + i])) live |= 1u << k;
+        sub[k] = (int32_t)((uint32_t)(r0 + i) / (uint32_t)C);
+    }
+    float acc_b = 0.f;
+    for (int32_t a0 = 0; a0 < A; a0 += RO_TA) {
+        const int32_t a = a0 + ta;
+        float acc_s = 0.f;
+        if (a < A) {
+            const float sa = s[a];
+            const int64_t col = sim_col ? sim_col[a] : a;
+#pragma unroll
+            for (int k0 = 0; k0 < PER; k0 += 4) {
+                float w[4], gz[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int64_t r = r0 + tr + (k0 + j) * RO_TR;
+                    const bool on = (live >> (k0 + j)) & 1;
+                    w[j] = (on && sims) ? sims[r * ld + col] : 0.f;
+                    gz[j] = on ? g[(int64_t)sub[k0 + j] * g_ld + a] : 0.f;
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (((live >> (k0 + j)) & 1) && fmaf(w[j], sa, bb) > 0.f) {
+                        acc_s = fmaf(gz[j], w[j], acc_s);
+                        acc_b += gz[j];
+                    }
+            }
+        }
+        sh_s[tr][ta] = acc_s;
+        __syncthreads();
+        if (tr == 0 && a < A) {
+            float vs = sh_s[0][ta];
+#pragma unroll
+            for (int k = 1; k < RO_TR; ++k) vs += sh_s[k][ta];
+            partial_s[(int64_t)a * nblk + blk] = vs;
+        }
+        __syncthreads();
+    }
+    sh_b[threadIdx.x] = acc_b;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        float v = (sh_b[threadIdx.x] + sh_b[threadIdx.x + 64]) + (sh_b[threadIdx.x + 128] + sh_b[threadIdx.x + 192]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        if (threadIdx.x == 0) partial_b[blk] = v;
+    }
+}
+
+// workgroups [0, groups) of a piece: one wavefront per column a -> d s[a] (block partials added as in readout_sum_bwd_finish_kernel)
+// and row a of d X; workgroup `groups`: d bp; the LAST workgroup of the piece to finish: d wp[d] = sum_a d s[a] X[a, d], a in order.
+__global__ __launch_bounds__(256) void readout_bwd_finish_many_kernel(const RoPieces P, int64_t nblk, int max_groups)
+{
+    __shared__ int s_last;
+    const int p = blockIdx.y, A = P.A[p], D = P.D;
+    const int groups = (A + 3) / 4;
+    if ((int)blockIdx.x > groups) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float* src = nullptr;
+    int a = -1;
+    if ((int)blockIdx.x < groups) {
+        a = blockIdx.x * 4 + wave;
+        if (a < A) src = P.partial_s[p] + (int64_t)a * nblk; else a = -1;
+    } else if (wave == 0) src = P.partial_b[p];
+    if (src) {
+        float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+        int64_t k = lane;
+        for (; k + 192 < nblk; k += 256) { v0 += src[k]; v1 += src[k + 64]; v2 += src[k + 128]; v3 += src[k + 192]; }
+        for (; k < nblk; k += 64) v0 += src[k];
+        const float v = ro_wave_sum((v0 + v1) + (v2 + v3));
+        if (a >= 0) {
+            const bool pad = P.ids[p] && P.ids[p][a] == 0;
+            const float gs = pad ? 0.f : v;
+            if (lane == 0 && P.gs[p]) P.gs[p][a] = gs;
+            if (P.gX[p] && P.wp[p])
+                for (int d = lane; d < D; d += 64) P.gX[p][(int64_t)a * D + d] = gs * P.wp[p][d];
+        } else if (lane == 0 && P.gbp[p]) P.gbp[p][0] = v;
+    }
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = (atomicAdd(P.ticket + p, 1u) == (unsigned)groups) ? 1 : 0;
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    if (P.gwp[p] && P.X[p] && P.gs[p]) {
+        // d s staged in LDS (its volatile reads were one dependent round trip per anchor: 70 us for 183 anchors), anchors in chunks
+        __shared__ float s_gs[1024];
+        __shared__ float s_part[256];
+        const volatile float* gs = P.gs[p];
+        const float* __restrict__ X = P.X[p];
+        if (D <= 128 && 256 % D == 0) {
+            // the anchors in 256 / D contiguous ranges, one per group of D threads; the ranges' sums added in range order
+            const int nq = 256 / D, q = threadIdx.x / D, d = threadIdx.x - q * D;
+            double v = 0.0;
+            for (int a0 = 0; a0 < A; a0 += 1024) {
+                const int na = A - a0 < 1024 ? A - a0 : 1024;
+                __syncthreads();
+                for (int aa = threadIdx.x; aa < na; aa += 256) s_gs[aa] = gs[a0 + aa];
+                __syncthreads();
+                const int per = (na + nq - 1) / nq, lo = q * per, hi = lo + per < na ? lo + per : na;
+#pragma unroll 8
+                for (int aa = lo; aa < hi; ++aa) v = fma((double)s_gs[aa], (double)X[(int64_t)(a0 + aa) * D + d], v);
+            }
+            s_part[threadIdx.x] = (float)v;
+            __syncthreads();
+            if (q == 0) {
+                float sum = s_part[d];
+                for (int k = 1; k < nq; ++k) sum += s_part[k * D + d];
+                P.gwp[p][d] = sum;
+            }
+        } else {
+            float v[4] = {0.f, 0.f, 0.f, 0.f};                       // columns d, d + 256, ... of this thread (D <= 1024 here)
+            for (int a0 = 0; a0 < A; a0 += 1024) {
+                const int na = A - a0 < 1024 ? A - a0 : 1024;
+                __syncthreads();
+                for (int aa = threadIdx.x; aa < na; aa += 256) s_gs[aa] = gs[a0 + aa];
+                __syncthreads();
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int d = threadIdx.x + 256 * q;
+                    if (d < D) {
+#pragma unroll 8
+                        for (int aa = 0; aa < na; ++aa) v[q] = fmaf(s_gs[aa], X[(int64_t)(a0 + aa) * D + d], v[q]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { const int d = threadIdx.x + 256 * q; if (d < D) P.gwp[p][d] = v[q]; }
+        }
+    }
+    if (threadIdx.x == 0) P.ticket[p] = 0u;
+}
+
+// host arrays of DEVICE pointers, one entry per piece (n <= sgnn_readout_many_max()); D: width of the anchor embeddings
+extern "C" int64_t sgnn_readout_many_max(void) { return RO_MAX_PIECES; }
+
+static int ro_fill_pieces(RoPieces& P, int64_t n, const float* const* sims, const int64_t* sims_ld, const int64_t* const* sim_col,
+                          const float* const* X, const float* const* wp, const float* const* bp, const int64_t* const* ids,
+                          const uint8_t* const* row_mask, float* const* s, const int64_t* A, const int64_t* off, int64_t D, int64_t H)
+{
+    if (n < 1 || n > RO_MAX_PIECES || !sims || !sims_ld || !sim_col || !X || !wp || !bp || !ids || !row_mask || !s || !A || !off) return -1;
+    if (D < 1 || D > 1024) return -1;
+    P.count = (int)n; P.D = (int)D; P.ticket = nullptr;
+    for (int k = 0; k < n; ++k) {
+        if (!bp[k] || !s[k] || A[k] < 1 || A[k] > (1 << 24) || off[k] < 0 || off[k] + A[k] > H) return -1;
+        if (sims[k] && sims_ld[k] < 1) return -1;
+        if (X[k] && !wp[k]) return -1;
+        P.sims[k] = sims[k]; P.ld[k] = sims_ld[k]; P.sim_col[k] = sim_col[k]; P.X[k] = X[k]; P.wp[k] = wp[k]; P.bp[k] = bp[k];
+        P.ids[k] = ids[k]; P.row_mask[k] = row_mask[k]; P.s[k] = s[k]; P.A[k] = (int)A[k]; P.off[k] = (int)off[k];
+        P.partial_s[k] = P.partial_b[k] = P.gX[k] = P.gwp[k] = P.gbp[k] = P.gs[k] = nullptr;
+    }
+    for (int k = (int)n; k < RO_MAX_PIECES; ++k) {
+        P.sims[k] = P.X[k] = P.wp[k] = P.bp[k] = nullptr; P.sim_col[k] = P.ids[k] = nullptr; P.row_mask[k] = nullptr; P.s[k] = nullptr;
+        P.ld[k] = 0; P.A[k] = 0; P.off[k] = 0;
+        P.partial_s[k] = P.partial_b[k] = P.gX[k] = P.gwp[k] = P.gbp[k] = P.gs[k] = nullptr;
+    }
+    return 0;
+}
+
+extern "C" int sgnn_readout_many_fwd(int64_t n, const float* const* sims, const int64_t* sims_ld, const int64_t* const* sim_col,
+                                     const float* const* X, const float* const* wp, const float* const* bp,
+                                     const int64_t* const* ids, const uint8_t* const* row_mask, float* const* s, const int64_t* A,
+                                     const int64_t* off, int64_t D, int64_t B, int64_t C, float* out, int64_t out_ld, void* stream)
+{
+    if (!out || B < 0 || C < 0 || C > 0x7fffffff) return SGNN_ERR_BAD_ARG;
+    RoPieces P;
+    if (ro_fill_pieces(P, n, sims, sims_ld, sim_col, X, wp, bp, ids, row_mask, s, A, off, D, out_ld) != 0) return SGNN_ERR_BAD_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(readout_scores_kernel, dim3((unsigned)n), dim3(256), 0, st, P);
+    SGNN_CHECK_LAUNCH();
+    int64_t most = 0;
+    for (int k = 0; k < n; ++k) most = B * A[k] > most ? B * A[k] : most;
+    if (most == 0) return SGNN_OK;
+    if ((most + 1023) / 1024 > 0x7fffffff) return SGNN_ERR_BAD_ARG;
+    hipLaunchKernelGGL(readout_sum_fwd_many_kernel, dim3((unsigned)((most + 1023) / 1024), (unsigned)n), dim3(256), 0, st, P, B,
+                       (int32_t)C, out, out_ld);
+    SGNN_CHECK_LAUNCH();
+    return SGNN_OK;
+}
+
+/* workspace floats per piece: (A + 1) * blocks + A (d s); tickets: RO_MAX_PIECES uint32, zero before the first call */
+extern "C" int64_t sgnn_readout_many_bwd_workspace_bytes(int64_t n, const int64_t* A, int64_t B, int64_t C)
+{
+    if (n < 1 || n > RO_MAX_PIECES || !A || B < 0 || C < 0) return -1;
+    int64_t fl = 0;
+    for (int k = 0; k < n; ++k) fl += (A[k] + 1) * ro_blocks(B * C) + A[k];
+    return fl * 4 + 64;
+}
+
+extern "C" int sgnn_readout_many_bwd(int64_t n, const float* grad_out, int64_t grad_ld, const float* const* sims, const int64_t* sims_ld,
+                                     const int64_t* const* sim_col, const float* const* X, const float* const* wp,
+                                     const float* const* bp, const int64_t* const* ids, const uint8_t* const* row_mask,
+                                     float* const* s, const int64_t* A, const int64_t* off, int64_t D, int64_t B, int64_t C,
+                                     float* const* grad_X, float* const* grad_wp, float* const* grad_bp, void* workspace,
+                                     int64_t workspace_bytes, unsigned* tickets, void* stream)
+{
+    if (!grad_out || !grad_X || !grad_wp || !grad_bp || !tickets || B < 1 || C < 1 || C > 0x7fffffff || B * C > 0x7fffffff) return SGNN_ERR_BAD_ARG;
+    RoPieces P;
+    if (ro_fill_pieces(P, n, sims, sims_ld, sim_col, X, wp, bp, ids, row_mask, s, A, off, D, grad_ld) != 0) return SGNN_ERR_BAD_ARG;
+    if (!workspace || workspace_bytes < sgnn_readout_many_bwd_workspace_bytes(n, A, B, C)) return SGNN_ERR_BAD_ARG;
+    const int64_t nblk = ro_blocks(B * C);
+    float* w = (float*)workspace;
+    int max_groups = 0;
+    for (int k = 0; k < n; ++k) {
+        P.partial_s[k] = w; w += A[k] * nblk;
+        P.partial_b[k] = w; w += nblk;
+        P.gs[k] = w; w += A[k];
+        P.gX[k] = grad_X[k]; P.gwp[k] = grad_wp[k]; P.gbp[k] = grad_bp[k];
+        const int gr = (int)((A[k] + 3) / 4);
+        max_groups = gr > max_groups ? gr : max_groups;
+    }
+    P.ticket = tickets;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(readout_sum_bwd_partial_many_kernel, dim3((unsigned)nblk, (unsigned)n), dim3(256), 0, st, P, grad_out, grad_ld,
+                       B * C, (int32_t)C, nblk);
+    SGNN_CHECK_LAUNCH();
+    hipLaunchKernelGGL(readout_bwd_finish_many_kernel, dim3((unsigned)(max_groups + 1), (unsigned)n), dim3(256), 0, st, P, nblk, max_groups);
+    SGNN_CHECK_LAUNCH();
+    return SGNN_OK;
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // Column sums of a tall matrix x (R, A) -- the bias gradient of a Linear over R rows (autograd of SubGNN/SubGNN.py:304-312 and
 // of the read-out weights): per-256-row-block partials with four loads in flight per thread, then the block partials of a

@@ -30,6 +30,39 @@ def shard_range(n_items, rank, world):
     return start, start + base + (1 if rank < rem else 0)
 
 
+class EmulatedPeers:
+    """ONE process standing in for rank ``rank`` of ``world`` (bench.py's ``strong_rank8`` object, tests): the rank computes its
+    own share of every dealt stage exactly as a real rank does, and what the collectives would deliver from the peers comes
+    from buffers recorded beforehand -- on the first pass the emulator computes every rank's share itself (draws are keyed by
+    global numbers, anchors are redrawn identically every pass without ``resample_anchor_patches``), later passes copy the
+    recorded result (the device-side cost of receiving it) and overwrite the rank's own block with what it has just computed.
+    Values are therefore those of the real sharded run; no byte crosses a link (the caller prices the links)."""
+
+    def __init__(self, rank, world):
+        self.rank, self.world = int(rank), int(world)
+        self.kept = {}            # key -> the full result of an exchange, as every rank would hold it
+        self.provided = {}        # what only the other ranks could compute, supplied by the caller (all ranks' component ids)
+        self.maxima = {}          # numel -> device tensor: the global maxima a MAX all-reduce of that many values would return
+        self.received_bytes = {}  # key -> bytes per pass the rank would receive over the links
+
+    def exchange(self, key, mine, lo, hi, make_full, dim=0):
+        """The result of an all-gather / all-to-all whose ``lo:hi`` block (along ``dim``) this rank contributes."""
+        full = self.kept.get(key)
+        if full is None:
+            full = self.kept[key] = make_full().contiguous()
+            own = mine.numel() * mine.element_size()
+            self.received_bytes[key] = full.numel() * full.element_size() - own
+        out = full.clone()                                      # (what arrives from the peers: one copy of the buffer)
+        out.narrow(dim, lo, hi - lo).copy_(mine)
+        return out
+
+    def reduce_max(self, t):
+        m = self.maxima.get(t.numel())
+        if m is None:
+            raise RuntimeError('EmulatedPeers: no global maxima for a reduction of %d values' % t.numel())
+        return torch.maximum(t, m.to(t.device, t.dtype).view_as(t))
+
+
 class Shard:
     """This rank's contiguous block of a split's ``total`` subgraphs.  ``start`` is what makes a sharded
     pass reproduce the unsharded one bit for bit: every per-subgraph draw reads the tape item of the
@@ -38,20 +71,23 @@ class Shard:
     sources of the position channel's multi-source BFS -- and exchange the results; pays when the
     shard is a slice of a fixed total (strong scaling), needs equal shard sizes."""
 
-    def __init__(self, total, rank=None, world=None, deal_shared=False, collectives=True, group=None):
+    def __init__(self, total, rank=None, world=None, deal_shared=False, collectives=True, group=None, emulator=None):
         self.world = world if world is not None else (dist.get_world_size() if is_initialized() else 1)
         self.rank = rank if rank is not None else (dist.get_rank() if is_initialized() else 0)
         self.total = int(total)
         self.start, self.stop = shard_range(self.total, self.rank, self.world)
-        self.collectives = collectives and self.world > 1        # False: a single process replaying one rank's shard (tests)
+        self.emulator = emulator  # EmulatedPeers: the peers' shares come from recorded buffers instead of collectives
+        self.collectives = collectives and self.world > 1 and emulator is None   # False: a single process replaying one rank's shard
         self.group = group        # communicator of the width reductions (its own when passes are pipelined: hotpath.PassPipeline)
-        self.deal_shared = bool(deal_shared) and self.collectives and self.total % self.world == 0
+        self.deal_shared = bool(deal_shared) and (self.collectives or emulator is not None) and self.total % self.world == 0
 
     @property
     def size(self):
         return self.stop - self.start
 
     def reduce_max(self, t):
+        if self.emulator is not None:
+            return self.emulator.reduce_max(t)
         return all_reduce_max_(t, self.group) if self.collectives else t
 
 
@@ -220,10 +256,16 @@ class ShardedTableAdam:
     rows are touched per rank and ~95 % by the union of 8 ranks -- the gradient is dense; see
     ``sparse_row_all_reduce`` for the regime where it is not."""
 
-    def __init__(self, param, lr, betas=(0.9, 0.999), eps=1e-8, average=False):
+    def __init__(self, param, lr, betas=(0.9, 0.999), eps=1e-8, average=False, emulate=None):
+        """``emulate`` = (rank, world): one process standing in for that rank (EmulatedPeers): the slices, the moments and the
+        update are the rank's; the reduce-scatter delivers the rank's own gradient slice (the peers' contributions are not
+        available in one process -- the caller prices the links) and nothing is gathered."""
         self.p, self.lr, self.b1, self.b2, self.eps, self.average = param, lr, betas[0], betas[1], eps, average
         self.world = dist.get_world_size() if is_initialized() else 1
         self.rank = dist.get_rank() if is_initialized() else 0
+        self.emulated = emulate is not None
+        if self.emulated:
+            self.rank, self.world = int(emulate[0]), int(emulate[1])
         n = param.numel()
         self.chunk = n // self.world                      # equal slices; the < world trailing elements are replicated
         self.tail = n - self.chunk * self.world
@@ -240,7 +282,9 @@ class ShardedTableAdam:
         reduced slice (+ the replicated tail on rank 0 only), for a global clip norm."""
         g = self.p.grad.reshape(-1)
         body = g[:self.chunk * self.world]
-        if self.world > 1:
+        if self.emulated:
+            self.gslice.copy_(body[self.lo:self.hi])
+        elif self.world > 1:
             if flat_collectives():
                 dist.reduce_scatter_tensor(self.gslice, body)
             else:                                           # backends without reduce-scatter
@@ -265,6 +309,17 @@ class ShardedTableAdam:
         self.t += 1
         flat = self.p.data.view(-1)
         g = self.p.grad.reshape(-1)
+        own = flat[self.lo:self.hi]
+        if self.p.is_cuda and not self.tail and self.chunk > 0 and self.p.dtype == torch.float32 \
+                and (own.data_ptr() | self.gslice.data_ptr() | self.m.data_ptr() | self.v.data_ptr()) % 16 == 0:
+            # the owned slice in ONE pass (sgnn_adam_step: the rule below, the clip coefficient read from the device) instead of
+            # ten element-wise launches over a slice of millions of elements
+            from . import ops
+            scale = grad_scale.reshape(1).float() if torch.is_tensor(grad_scale) else (
+                None if grad_scale is None else torch.full((1,), float(grad_scale), dtype=torch.float32, device=self.p.device))
+            ops.adam_step(own, self.gslice, self.m, self.v, self.lr, (self.b1, self.b2), self.eps, self.t, grad_scale=scale)
+            self._gather_owned(flat)
+            return
         gs = self.gslice if not self.tail else torch.cat([self.gslice, g[self.chunk * self.world:]])
         if grad_scale is not None:
             gs = gs * grad_scale
@@ -275,7 +330,11 @@ class ShardedTableAdam:
         flat[self.lo:self.hi].add_(upd[:self.chunk], alpha=-self.lr)
         if self.tail:
             flat[self.chunk * self.world:].add_(upd[self.chunk:], alpha=-self.lr)
-        if self.world > 1:
+        self._gather_owned(flat)
+
+    def _gather_owned(self, flat):
+        """The asynchronous all-gather of the updated slices (``wait`` lands it)."""
+        if self.world > 1 and not self.emulated:
             body = flat[:self.chunk * self.world]
             mine = flat[self.lo:self.hi].clone()            # the collective must not read and write the same bytes
             if flat_collectives():

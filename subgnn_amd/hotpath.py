@@ -64,7 +64,7 @@ def _hand_over(stream, *objs):
         if isinstance(o, torch.Tensor):
             if o.is_cuda:
                 o.record_stream(stream)
-            for nm in ('_sgnn_ids32', '_sgnn_sorted', '_sgnn_both', '_sgnn_all'):
+            for nm in ('_sgnn_ids32', '_sgnn_sorted', '_sgnn_both', '_sgnn_all', '_sgnn_mask', '_sgnn_mask_u8'):
                 extra = getattr(o, nm, None)
                 if extra is not None:
                     _hand_over(stream, extra)
@@ -221,19 +221,54 @@ def _pint_sims_streamed(g, uniq, inv, cc_sets, S, C, max_hops, chunk_bytes=1 << 
     return w
 
 
-def _deal_rows(shard, n, compute, tail_shape, dtype, device):
+def _deal_rows(shard, n, compute, tail_shape, dtype, device, key=None):
     """Strong scaling: rows [0, n) of a result every rank needs (walks over the shared structure patches) computed as
     ``world`` equal shares -- ``compute(lo, hi)`` -> rows lo..hi-1 -- and all-gathered (ranks in order, equal row counts
     known on the host: no size exchange).  Bit-identical to computing all rows on every rank when ``compute`` keys its
-    draws by global row numbers."""
+    draws by global row numbers.  ``key``: names the exchange for an emulated rank (dist.EmulatedPeers)."""
     from . import dist as sdist
     per = -(-n // shard.world)
     lo = min(shard.rank * per, n)
     hi = min(lo + per, n)
     part = compute(lo, hi) if hi > lo else torch.zeros((0,) + tuple(tail_shape), dtype=dtype, device=device)
+    emu = getattr(shard, 'emulator', None)
+    if emu is not None:
+        def everybody():
+            return torch.cat([compute(min(r * per, n), min(r * per + per, n)) for r in range(shard.world) if min(r * per, n) < n], 0)
+        return emu.exchange(key, part, lo, hi, everybody)
     if part.shape[0] < per:
         part = torch.cat([part, part.new_zeros((per - part.shape[0],) + tuple(part.shape[1:]))], 0)
     return sdist.all_gather_rows(part.contiguous(), equal_rows=True)[:n]
+
+
+def _emulated_position_sims(g, anchors, cc_sets, cc_ids, shard, max_hops, key):
+    """_dealt_position_sims for ONE process standing in for a rank (dist.EmulatedPeers): the rank's own search -- its share of
+    the sources over EVERY rank's components -- runs as in the real form; the gathered component ids come from the emulator
+    (supplied by its owner: only the other ranks could compute them) and the other ranks' columns for this rank's rows from a
+    search over all sources recorded on the first pass."""
+    from . import dist as sdist
+    emu = shard.emulator
+    S, C, Lc = cc_ids.shape
+    A = anchors.numel()
+    rows = S * C
+    mine = cc_ids.reshape(rows, Lc)
+    all_cc = emu.exchange(('cc_ids', key), mine, shard.rank * rows, (shard.rank + 1) * rows, lambda: emu.provided['cc_ids_all'])
+    if all_cc.shape[0] != rows * shard.world or all_cc.shape[1] != Lc:
+        raise ValueError('EmulatedPeers: the supplied component ids are %s, this rank holds %s of %d ranks' % (tuple(all_cc.shape), (rows, Lc), shard.world))
+    all_sets = ops.Ragged.from_padded(all_cc)
+    a, b = sdist.shard_range(A, shard.rank, shard.world)
+    status = torch.zeros(4, dtype=torch.int32, device=cc_ids.device)
+    part = None
+    if b > a:
+        part, status = ops.bfs_min_hops_to_sets(g, anchors[a:b].to(torch.int32).contiguous(), all_sets, max_hops=max_hops, want_status=True)
+
+    def everybody():
+        full, st = ops.bfs_min_hops_to_sets(g, anchors.to(torch.int32).contiguous(), cc_sets, max_hops=max_hops, want_status=True)
+        if int(st[1]):
+            raise RuntimeError('position-channel BFS: hparams["max_bfs_hops"] = %d is smaller than the depth of this graph' % max_hops)
+        return full
+    block = part[shard.rank * rows:(shard.rank + 1) * rows] if part is not None else torch.zeros((rows, 0), dtype=torch.float32, device=cc_ids.device)
+    return emu.exchange(('P_out', key), block, a, b, everybody, dim=1), status
 
 
 def _dealt_position_sims(g, anchors, cc_sets, cc_ids, shard, max_hops):
@@ -305,7 +340,7 @@ def prepare_pass(model, split='train', timer=None, shard=None, defer_dtw=False, 
     the BFS kernels are memory-bound with small workgroups: on the benchmark the three stages take 4.7 ms back to
     back and 4.0 ms overlapped (17.9 -> 17.0 ms per pass).  The DTW cannot share a CU (it holds every vector
     register at three wavefronts of 168 registers per SIMD), so nothing is overlapped with it.  The strong-scaling form issues
-    collectives inside the position block and keeps one stream.
+    collectives inside the position block (side stream) and around the dealt patches / walks (main stream).
     ``pool`` (``pool_of`` an earlier pass of the same split): the structure-patch pool is REUSED -- no patches, walks, degree
     sequences or DTW launches; the pass re-picks its layers' patches from the pool (init_anchors_structure) and reads the
     pool's similarity rows.  The reference's design: max_sim_epochs x n_anchor_patches_structure x n_layers patches are sampled
@@ -319,7 +354,11 @@ def prepare_pass(model, split='train', timer=None, shard=None, defer_dtw=False, 
     t = timer or StageTimer(False)
     L = hp['n_layers']
     main = torch.cuda.current_stream()
-    if hp.get('overlap_streams', True) and not (shard is not None and shard.deal_shared):
+    # (the dealt -- strong-scaling -- form overlaps too: its exchanges are issued by this one host thread in one fixed order on
+    # every rank, and torch's process group runs them on its own stream behind whichever stream issued them: the position search
+    # with its all-to-all on the side stream beside the border / walks / DTW chain.  hparams['overlap_streams_dealt'] = False
+    # keeps the dealt form on one stream, as rounds 2-5 ran it)
+    if hp.get('overlap_streams', True) and (hp.get('overlap_streams_dealt', True) or not (shard is not None and shard.deal_shared)):
         if getattr(model, '_side_stream', None) is None:
             model._side_stream = torch.cuda.Stream()
         side = model._side_stream
@@ -353,6 +392,10 @@ def prepare_pass(model, split='train', timer=None, shard=None, defer_dtw=False, 
     base = shard.start if shard is not None else 0             # global number of this rank's first subgraph
     cc_sets = ops.Ragged.from_padded(cc_ids.reshape(S * C, Lc))
     real = (cc_ids[:, :, 0] != 0)
+    # which component rows are real, as forward reads it (SubGNN._forward: bool (S, C) and its uint8 twin): made here, beside the
+    # sampling stages, and carried on the tensor -- two small launches less per training half
+    cc_ids._sgnn_mask = real
+    cc_ids._sgnn_mask_u8 = real.reshape(-1).to(torch.uint8)
     t.mark('components')
     # dispatch order of the component sets, heaviest (largest total degree) first: a property of the
     # split's subgraphs and the graph, computed once per split and kept.  The set kernels whose cost is
@@ -377,7 +420,8 @@ def prepare_pass(model, split='train', timer=None, shard=None, defer_dtw=False, 
                 # strong scaling: every rank walks an eighth of the shared patches (tape items = global walk numbers)
                 n_p = hp['max_sim_epochs'] * hp['n_anchor_patches_structure'] * hp['n_layers']
                 structure_anchors = _deal_rows(shard, n_p, lambda lo, hi: aps.sample_structure_anchor_patches(
-                    hp, g, dev, hp['max_sim_epochs'], trim=False, share=(lo, hi)), (hp['sample_walk_len'],), torch.int64, dev)
+                    hp, g, dev, hp['max_sim_epochs'], trim=False, share=(lo, hi)), (hp['sample_walk_len'],), torch.int64, dev,
+                    key=('S_patches', split))
                 st.attrs['structure_anchors'] = structure_anchors
             else:
                 structure_anchors = st.attrs['structure_anchors'] = aps.sample_structure_anchor_patches(hp, g, dev, hp['max_sim_epochs'], trim=False)
@@ -403,7 +447,10 @@ def prepare_pass(model, split='train', timer=None, shard=None, defer_dtw=False, 
                 for l in range(L):
                     if shard is not None and shard.deal_shared:
                         cap = hp.get('max_bfs_hops', 32)
-                        w, status = _dealt_position_sims(g, anchors_pos_ext[l], cc_sets, cc_ids, shard, cap)
+                        if getattr(shard, 'emulator', None) is not None:
+                            w, status = _emulated_position_sims(g, anchors_pos_ext[l], cc_sets, cc_ids, shard, cap, (split, l))
+                        else:
+                            w, status = _dealt_position_sims(g, anchors_pos_ext[l], cc_sets, cc_ids, shard, cap)
                         w = w.view(S, C, -1)
                         # full cap, all ranks' worst status: verified before the pass is consumed like the hinted searches
                         # (nothing to repeat: running out of levels here means max_bfs_hops is too small)
@@ -469,7 +516,7 @@ def prepare_pass(model, split='train', timer=None, shard=None, defer_dtw=False, 
                     v = aps.patch_node_views(mine)
                     iw, bw = aps.perform_random_walks_both(hp, g, mine, v, first_patch=lo)
                     return torch.stack([bw, iw], 1)
-                walks = _deal_rows(shard, structure_anchors.shape[0], both, (2, W_, T_), torch.int64, dev)
+                walks = _deal_rows(shard, structure_anchors.shape[0], both, (2, W_, T_), torch.int64, dev, key=('S_walks', split))
                 bor_w = st.attrs['bor_structure_anchor_random_walks'] = walks[:, 0].contiguous()
                 int_w = st.attrs['int_structure_anchor_random_walks'] = walks[:, 1].contiguous()
             elif new_patches:
@@ -532,7 +579,7 @@ def prepare_pass(model, split='train', timer=None, shard=None, defer_dtw=False, 
             D = hp['node_embed_size']
             if det and hp.get('fused_forward', True) and D % 4 == 0 and D <= 256 and (D // 4) & (D // 4 - 1) == 0:
                 # the border layer's table gradient is a sorted scatter: its edge list and order are known here
-                plan = ops.mpn_edge_plan(sims[('N', 'out', l)], nb[l], real.reshape(-1).to(torch.uint8), R=S * C,
+                plan = ops.mpn_edge_plan(sims[('N', 'out', l)], nb[l], cc_ids._sgnn_mask_u8, R=S * C,
                                          A=nb[l].shape[-1], D=D, max_key=g.max_id, sims_per_edge=True)
                 plan['anchors'] = nb[l]
                 plans[('N', False, l)] = plan
@@ -717,7 +764,7 @@ class PassPipeline:
         return install_pass(self.model, st, timer)
 
 
-_TENSOR_ATTRS = ('_sgnn_ids32', '_sgnn_sorted', '_sgnn_both', '_sgnn_all', '_sgnn_member_order')
+_TENSOR_ATTRS = ('_sgnn_ids32', '_sgnn_sorted', '_sgnn_both', '_sgnn_all', '_sgnn_member_order', '_sgnn_mask', '_sgnn_mask_u8')
 
 
 def _copy_into(dst, src, path, replaced, memo=None):
@@ -814,11 +861,18 @@ class CapturedTraining:
     arithmetic as the eager step: losses and parameters are bit-equal (tests/test_gpu_hotpath.py)."""
 
     def __init__(self, model, optimizer, split='train', warmup=2):
-        if not getattr(optimizer, 'capturable', False):
+        """``optimizer`` None: the recording ends with the backward pass -- the data-parallel form, whose gradient exchange and
+        (sharded) optimizer run eagerly behind every replay: collectives are not recorded.  The gradients are then the recording's
+        STATIC tensors: ``step`` re-attaches them to the parameters after every replay (``p.grad = ...``), so the caller may
+        set them to None when it is done with them -- and must, before the next step."""
+        if optimizer is not None and not getattr(optimizer, 'capturable', False):
             raise ValueError('CapturedTraining needs ClipAdam(capturable=True): a host step count cannot be replayed')
-        if getattr(model, '_table_sync', None) is not None:
-            raise ValueError('CapturedTraining is the single-rank form (collectives are not recorded)')
+        if optimizer is not None and getattr(model, '_table_sync', None) is not None:
+            raise ValueError('a recording that contains the optimizer is the single-rank form (collectives are not recorded)')
+        if optimizer is None and model.hparams.get('dp_gather_embeddings', False):
+            raise ValueError('the replicated head gathers embeddings inside forward: not recordable')
         self.model, self.opt, self.split = model, optimizer, split
+        self.static_grads = None
         self.graph, self.loss, self.acc = None, None, None
         self._warm_left = int(warmup)
         self._installed = False
@@ -839,12 +893,18 @@ class CapturedTraining:
         m = self.model
         out = m.training_step(full_split_batch(m, self.split), 0)
         m.backward(None, out['loss'], None, 0)
-        self.opt.step()
-        self.opt.zero_grad(set_to_none=True)
+        if self.opt is not None:
+            self.opt.step()
+            self.opt.zero_grad(set_to_none=True)
         return out['loss'].detach(), out['log']['train_acc'].detach()
 
     def step(self):
         """-> (loss, accuracy): the recording's static outputs once it exists (clone to keep past the next step)."""
+        sync = getattr(self.model, '_table_sync', None)
+        if sync is not None:
+            sync()                               # (a sharded optimizer's all-gather of the table: the training half reads it)
+        if self.opt is None and any(p.grad is not None for p in self.model.parameters()):
+            raise RuntimeError('CapturedTraining without an optimizer: the caller must set the gradients to None after its update')
         if self.graph is None:
             if self._warm_left > 0:
                 self._warm_left -= 1
@@ -861,7 +921,12 @@ class CapturedTraining:
                 raise
             self.graph = g
             self.recordings += 1
+            if self.opt is None:
+                self.static_grads = [(p, p.grad) for p in self.model.parameters() if p.grad is not None]
         self.graph.replay()
+        if self.static_grads is not None:
+            for p, gr in self.static_grads:
+                p.grad = gr
         self.model.invalidate_half_table()
         return self.loss, self.acc
 

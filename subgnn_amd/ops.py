@@ -1777,6 +1777,24 @@ def clip_coefficient(big_grads, small_grads, max_norm):
     return coef
 
 
+_ZEROS = {}
+
+
+def zeros_cached(shape, dtype, device):
+    """A READ-ONLY all-zero tensor, kept per (shape, dtype, device): the aggregate of a layer body whose similarities are all
+    zero is the same zeros every step -- no fill launch per step.  (One that does not exist yet while a stream is capturing is
+    made for that recording only: a tensor created there belongs to the recording's pool.)"""
+    key = (tuple(shape), dtype, str(device))
+    t = _ZEROS.get(key)
+    if t is None and torch.device(device).type == 'cuda' and torch.cuda.is_current_stream_capturing():
+        return torch.zeros(shape, dtype=dtype, device=device)
+    if t is None:
+        if len(_ZEROS) > 16:
+            _ZEROS.clear()
+        t = _ZEROS[key] = torch.zeros(shape, dtype=dtype, device=device)
+    return t
+
+
 class ZeroSims:
     """Edge weights known to be all zero (the similarity of an anchor that lies inside its own
     component -- every N-internal edge, every P-internal edge of a single-component subgraph): the
@@ -1889,8 +1907,20 @@ class ReadoutPiece:
     subgraph's components straight into the embedding's column slot (sgnn_readout_sum_fwd); ``dense()`` is the (B, C, A)
     tensor for a consumer that wants it (attention read-out, gathered heads)."""
 
-    def __init__(self, sims2, sim_col, s, bp, A, row_mask, R):
+    def __init__(self, sims2, sim_col, s, bp, A, row_mask, R, X=None, wp=None, ids=None):
+        """``s`` given: the scores as a tensor (the caller made them).  ``s`` None: the scores are X wp (0 where ids == 0; all zero
+        without X) and ``subgraph_embedding`` computes them inside its own launches, for all such pieces of a step together
+        (sgnn_readout_many_fwd / _bwd: the gradients of X, wp and bp come out of the same two launches)."""
         self.sims2, self.sim_col, self.s, self.bp, self.A, self.row_mask, self.R = sims2, sim_col, s, bp, int(A), row_mask, int(R)
+        self.X, self.wp, self.ids = X, (wp.reshape(-1) if wp is not None else None), ids
+
+    def scores(self):
+        if self.s is not None:
+            return self.s
+        if self.X is None:
+            return torch.zeros(self.A, dtype=self.bp.dtype, device=self.bp.device)
+        s = self.X @ self.wp
+        return s * (self.ids != 0).to(s.dtype) if self.ids is not None else s
 
     def dense(self, B, C):
         if self.sims2 is None:
@@ -1898,7 +1928,7 @@ class ReadoutPiece:
         W = self.sims2.index_select(1, self.sim_col) if self.sim_col is not None else self.sims2[:, :self.A]
         if self.row_mask is not None:
             W = W * (self.row_mask != 0).to(W.dtype).view(-1, 1)
-        return torch.relu(_ReadoutShared.apply(W, self.s, self.bp)).view(B, C, self.A)
+        return torch.relu(_ReadoutShared.apply(W, self.scores(), self.bp)).view(B, C, self.A)
 
 
 SLOTS_TOGETHER_BELOW = 1 << 22          # (B C H) elements: below, the tensor pieces of a read-out share one launch
@@ -1922,9 +1952,20 @@ class _SubgraphEmbedding(torch.autograd.Function):
         n_x = sum(1 for p in pieces if not isinstance(p, ReadoutPiece))
         together = n_x >= 2 and B * C * H <= SLOTS_TOGETHER_BELOW
         slots = []
+        many = []                                    # (piece, its column offset, index of its first tensor, its scores buffer)
         for p, w in zip(pieces, widths):
             dst = ctypes.c_void_p(out.data_ptr() + 4 * off)
-            if isinstance(p, ReadoutPiece):
+            if isinstance(p, ReadoutPiece) and p.s is None:
+                X, wp, bp = tensors[k], tensors[k + 1], tensors[k + 2]
+                _req(X, torch.float32, 'X'), _req(wp, torch.float32, 'wp'), _req(bp, torch.float32, 'bp')
+                _req(p.sims2, torch.float32, 'sims'), _req(p.sim_col, torch.int64, 'sim_col'), _req(p.row_mask, torch.uint8, 'row_mask')
+                _req(p.ids, torch.int64, 'ids')
+                if p.R != B * C or (X is not None and (X.shape[0] != w or wp is None or wp.numel() != X.shape[1])):
+                    raise ValueError('read-out piece: %d rows for B C = %d, anchors %s for width %d' % (p.R, B * C, None if X is None else tuple(X.shape), w))
+                many.append((p, off, k, torch.empty(w, dtype=torch.float32, device=mask.device)))
+                plan.append(('m', off, w, k, p))
+                k += 3
+            elif isinstance(p, ReadoutPiece):
                 s, bp = tensors[k], tensors[k + 1]
                 _req(s, torch.float32, 's'), _req(bp, torch.float32, 'bp'), _req(p.sims2, torch.float32, 'sims')
                 _req(p.sim_col, torch.int64, 'sim_col'), _req(p.row_mask, torch.uint8, 'row_mask')
@@ -1951,6 +1992,14 @@ class _SubgraphEmbedding(torch.autograd.Function):
             ptrs, ws, offs = (np.array(v, dtype=t) for v, t in zip(zip(*slots), (np.uint64, np.int64, np.int64)))
             check(lib.sgnn_masked_sum_slots_fwd(ptrs.ctypes.data, ws.ctypes.data, offs.ctypes.data, len(slots), _ptr(mask), B, C,
                                                 _ptr(out), H, _stream()), 'sgnn_masked_sum_slots_fwd')
+        ctx.many = []
+        for group in _readout_groups(many, tensors):
+            t = _readout_tables(group, tensors)
+            check(lib.sgnn_readout_many_fwd(len(group), t['sims'].ctypes.data, t['ld'].ctypes.data, t['col'].ctypes.data, t['X'].ctypes.data,
+                                            t['wp'].ctypes.data, t['bp'].ctypes.data, t['ids'].ctypes.data, t['mask'].ctypes.data,
+                                            t['s'].ctypes.data, t['A'].ctypes.data, t['off'].ctypes.data, t['D'], B, C, _ptr(out), H,
+                                            _stream()), 'sgnn_readout_many_fwd')
+            ctx.many.append(group)
         ctx.plan, ctx.dims, ctx.together = plan, (B, C, H), together
         ctx.save_for_backward(mask, *tensors)
         return out
@@ -1972,8 +2021,30 @@ class _SubgraphEmbedding(torch.autograd.Function):
                 ptrs, ws, offs = (np.array(v, dtype=t) for v, t in zip(zip(*slots), (np.uint64, np.int64, np.int64)))
                 check(lib.sgnn_masked_sum_slots_bwd(_ptr(g), H, _ptr(mask), B, C, ptrs.ctypes.data, ws.ctypes.data, offs.ctypes.data,
                                                     len(slots), _stream()), 'sgnn_masked_sum_slots_bwd')
+        for group in ctx.many:
+            t = _readout_tables(group, tensors)
+            gX, gwp, gbp = [], [], []
+            for p, off, k, s_buf in group:
+                X = tensors[k]
+                gX.append(torch.empty_like(X) if (X is not None and ctx.needs_input_grad[4 + k]) else None)
+                gwp.append(torch.empty(X.shape[1], dtype=torch.float32, device=g.device) if (X is not None and ctx.needs_input_grad[5 + k]) else None)
+                gbp.append(torch.empty(1, dtype=torch.float32, device=g.device) if ctx.needs_input_grad[6 + k] else None)
+            wsb = lib.sgnn_readout_many_bwd_workspace_bytes(len(group), t['A'].ctypes.data, B, C)
+            ws = torch.empty(wsb // 4 + 1, dtype=torch.float32, device=g.device)
+            pgX, pgw, pgb = _ptr_table(gX), _ptr_table(gwp), _ptr_table(gbp)
+            check(lib.sgnn_readout_many_bwd(len(group), _ptr(g), H, t['sims'].ctypes.data, t['ld'].ctypes.data, t['col'].ctypes.data,
+                                            t['X'].ctypes.data, t['wp'].ctypes.data, t['bp'].ctypes.data, t['ids'].ctypes.data,
+                                            t['mask'].ctypes.data, t['s'].ctypes.data, t['A'].ctypes.data, t['off'].ctypes.data, t['D'],
+                                            B, C, pgX.ctypes.data, pgw.ctypes.data, pgb.ctypes.data, _ptr(ws), wsb,
+                                            _ptr(_readout_tickets(g.device)), _stream()), 'sgnn_readout_many_bwd')
+            for (p, off, k, s_buf), a, b_, c in zip(group, gX, gwp, gbp):
+                grads[k] = a
+                grads[k + 1] = b_.view_as(tensors[k + 1]) if b_ is not None else None
+                grads[k + 2] = c.view_as(tensors[k + 2]) if c is not None else None
         for kind, off, w, k, p in ctx.plan:
             src = ctypes.c_void_p(g.data_ptr() + 4 * off)
+            if kind == 'm':
+                continue
             if kind == 'x':
                 if ctx.needs_input_grad[4 + k] and not ctx.together:
                     gx = torch.empty((B, C, w), dtype=torch.float32, device=g.device)
@@ -1996,11 +2067,59 @@ class _SubgraphEmbedding(torch.autograd.Function):
         return (None, None, None, None) + tuple(grads)
 
 
+_RO_TICKETS = {}
+
+
+def _readout_tickets(device):
+    t = _RO_TICKETS.get(str(device))
+    if t is None:
+        t = _RO_TICKETS[str(device)] = torch.zeros(int(_lib.load().sgnn_readout_many_max()), dtype=torch.int32, device=device)
+    return t
+
+
+def _readout_groups(many, tensors):
+    """The in-kernel read-out pieces of a call in launch groups: up to sgnn_readout_many_max() pieces of one anchor width."""
+    if not many:
+        return []
+    cap = int(_lib.load().sgnn_readout_many_max())
+    by_d = {}
+    for ent in many:
+        X = tensors[ent[2]]
+        by_d.setdefault(None if X is None else int(X.shape[1]), []).append(ent)
+    free = by_d.pop(None, [])                         # (pieces without anchors -- all-zero similarities -- ride with any width)
+    widths = sorted(by_d) or [1]
+    by_d.setdefault(widths[0], [])
+    by_d[widths[0]] = free + by_d[widths[0]]
+    groups = []
+    for d in widths:
+        ents = sorted(by_d[d], key=lambda e: e[1])
+        groups += [ents[lo:lo + cap] for lo in range(0, len(ents), cap)]
+    return groups
+
+
+def _readout_tables(group, tensors):
+    """Host tables of one many-piece launch (kept alive by the caller for the duration of the call)."""
+    D = 1
+    for p, off, k, s_buf in group:
+        if tensors[k] is not None:
+            D = int(tensors[k].shape[1])
+    return {'sims': _ptr_table([p.sims2 for p, *_ in group]),
+            'ld': np.array([p.sims2.shape[1] if p.sims2 is not None else 0 for p, *_ in group], dtype=np.int64),
+            'col': _ptr_table([p.sim_col for p, *_ in group]), 'X': _ptr_table([tensors[k] for _, _, k, _ in group]),
+            'wp': _ptr_table([tensors[k + 1] for _, _, k, _ in group]), 'bp': _ptr_table([tensors[k + 2] for _, _, k, _ in group]),
+            'ids': _ptr_table([p.ids for p, *_ in group]), 'mask': _ptr_table([p.row_mask for p, *_ in group]),
+            's': _ptr_table([s_buf for *_, s_buf in group]), 'A': np.array([p.A for p, *_ in group], dtype=np.int64),
+            'off': np.array([off for _, off, _, _ in group], dtype=np.int64), 'D': D}
+
+
 def subgraph_embedding(pieces, mask, B, C):
     """cat(pieces, -1) summed over each subgraph's real components -> (B, H); mask (B C) uint8."""
     tensors = []
     for p in pieces:
-        if isinstance(p, ReadoutPiece):
+        if isinstance(p, ReadoutPiece) and p.s is None:
+            tensors += [p.X.contiguous() if p.X is not None else None, p.wp.contiguous() if p.wp is not None else None,
+                        p.bp.contiguous().view(-1)]
+        elif isinstance(p, ReadoutPiece):
             tensors += [p.s.contiguous(), p.bp.contiguous().view(-1)]
         else:
             tensors.append(p.contiguous())
@@ -2043,6 +2162,164 @@ def cross_entropy_with_accuracy(logits, labels):
     return _CrossEntropy.apply(logits.contiguous(), labels.contiguous())
 
 
+# ---------------------------------------------------------------------------------------
+# the MLP head + loss of a step (csrc/head.hip)
+# ---------------------------------------------------------------------------------------
+
+_HEAD_WS = {}
+
+
+def _head_workspace(device, B):
+    """The forward's per-workgroup loss partials + its ticket: one persistent buffer per device and workgroup count (the ticket
+    must be zero before the first launch and every launch leaves it zero; the partials are rewritten by every launch)."""
+    lib = _lib.load()
+    nb = int(lib.sgnn_head_blocks(int(B)))
+    key = (str(device), nb)
+    ws = _HEAD_WS.get(key)
+    if ws is None:
+        ws = _HEAD_WS[key] = torch.zeros(int(lib.sgnn_head_fwd_workspace_bytes(int(B))) // 4 + 1, dtype=torch.int32, device=device)
+    return ws
+
+
+def head_supported(H1, H2, K):
+    return bool(_lib.load().sgnn_head_supported(int(H1), int(H2), int(K)))
+
+
+def contract_rows_many(pairs):
+    """[a^T b for (a, b) in pairs] for tall row-major a (R, M), b (R, N) (row strides may exceed the widths): block partials on the
+    matrix cores in one launch per 8 pairs (sgnn_contract_rows_partial), added in block order by one sgnn_reduce_partials launch
+    per 8 -- bit-reproducible.  -> list of (M, N) tensors."""
+    lib = _lib.load()
+    outs = []
+    cap = min(int(lib.sgnn_contract_rows_max_jobs()), int(lib.sgnn_reduce_partials_max_jobs()))
+    for lo in range(0, len(pairs), cap):
+        group = pairs[lo:lo + cap]
+        for a, b in group:
+            _req2d(a, 'a'), _req2d(b, 'b')
+            if a.shape[0] != b.shape[0]:
+                raise ValueError('contract_rows_many: %d and %d rows' % (a.shape[0], b.shape[0]))
+        R = np.array([a.shape[0] for a, _ in group], dtype=np.int64)
+        M = np.array([a.shape[1] for a, _ in group], dtype=np.int64)
+        N = np.array([b.shape[1] for _, b in group], dtype=np.int64)
+        lda = np.array([a.stride(0) for a, _ in group], dtype=np.int64)
+        ldb = np.array([b.stride(0) for _, b in group], dtype=np.int64)
+        nb = np.array([int(lib.sgnn_contract_rows_blocks(int(r))) for r in R], dtype=np.int64)
+        dev = group[0][0].device
+        parts = [torch.empty((int(nb[k]), int(M[k]), int(N[k])), dtype=torch.float32, device=dev) for k in range(len(group))]
+        res = [torch.empty((int(M[k]), int(N[k])), dtype=torch.float32, device=dev) for k in range(len(group))]
+        pa, pb, pp, po = (_ptr_table(v) for v in ([a for a, _ in group], [b for _, b in group], parts, res))
+        check(lib.sgnn_contract_rows_partial(len(group), pa.ctypes.data, pb.ctypes.data, lda.ctypes.data, ldb.ctypes.data,
+                                             M.ctypes.data, N.ctypes.data, R.ctypes.data, pp.ctypes.data, _stream()),
+              'sgnn_contract_rows_partial')
+        n = M * N
+        check(lib.sgnn_reduce_partials(len(group), pp.ctypes.data, nb.ctypes.data, n.ctypes.data, po.ctypes.data, _stream()),
+              'sgnn_reduce_partials')
+        outs += res
+    return outs
+
+
+def _req2d(t, name):
+    if not (t.is_cuda and t.dtype == torch.float32 and t.dim() == 2 and t.stride(1) == 1 and t.stride(0) >= t.shape[1]):
+        raise ValueError('%s must be a float32 CUDA matrix with unit column stride' % name)
+
+
+class _FusedHead(torch.autograd.Function):
+    """logits, loss, accuracy = head(x): lin -> relu -> dropout -> lin2 -> relu -> dropout -> lin3 [-> cross entropy + accuracy]
+    (SubGNN.py:304-312, 1116-1124).  The first layer's GEMMs (z1 = x W1^T + b1, dx = dz1 W1) are the library's; everything else
+    is sgnn_head_fwd / sgnn_head_bwd, gW1 = dz1^T x on the matrix cores (sgnn_contract_rows_partial), and ONE reduction launch for
+    every weight and bias gradient of the head.  9 + 22 launches -> 2 + 4."""
+
+    @staticmethod
+    def forward(ctx, x, W1, b1, W2, b2, W3, b3, labels, p, rng):
+        lib = _lib.load()
+        for t, nm in ((x, 'x'), (W1, 'W1'), (b1, 'b1'), (W2, 'W2'), (b2, 'b2'), (W3, 'W3'), (b3, 'b3')):
+            _req(t, torch.float32, nm)
+        _req(labels, torch.int64, 'labels')
+        _req(rng, torch.int64, 'rng')
+        B, H1, H2, K = x.shape[0], W1.shape[0], W2.shape[0], W3.shape[0]
+        dev = x.device
+        z1 = torch.addmm(b1, x, W1.t()) if b1 is not None else x @ W1.t()
+        a1 = torch.empty((B, H1), dtype=torch.float32, device=dev)
+        a2 = torch.empty((B, H2), dtype=torch.float32, device=dev)
+        logits = torch.empty((B, K), dtype=torch.float32, device=dev)
+        lse = torch.empty(B + 1, dtype=torch.float32, device=dev) if labels is not None else None
+        out = torch.empty(3, dtype=torch.float32, device=dev) if labels is not None else None
+        ws = _head_workspace(dev, B)
+        check(lib.sgnn_head_fwd(_ptr(z1), B, H1, H2, K, _ptr(W2), _ptr(b2), _ptr(W3), _ptr(b3), _ptr(labels), float(p), _ptr(rng),
+                                _ptr(a1), _ptr(a2), _ptr(logits), _ptr(lse), _ptr(out), _ptr(ws), ws.numel() * 4, _stream()),
+              'sgnn_head_fwd')
+        ctx.save_for_backward(x, W1, W2, W3, a1, a2, logits, lse, labels, out)
+        ctx.p, ctx.dims = float(p), (B, H1, H2, K)
+        ctx.has_bias = (b1 is not None, b2 is not None, b3 is not None)
+        ctx.set_materialize_grads(False)
+        if labels is None:
+            return logits, None, None
+        loss, acc = out[0], out[1:2]
+        ctx.mark_non_differentiable(acc)
+        return logits, loss, acc
+
+    @staticmethod
+    def backward(ctx, g_logits, g_loss, _g_acc):
+        lib = _lib.load()
+        x, W1, W2, W3, a1, a2, logits, lse, labels, out = ctx.saved_tensors
+        B, H1, H2, K = ctx.dims
+        dev = x.device
+        if g_logits is None and g_loss is None:
+            return (None,) * 10
+        g_logits = g_logits.contiguous() if g_logits is not None else None
+        g_loss = g_loss.reshape(1).contiguous().float() if g_loss is not None else None
+        P = int(lib.sgnn_head_partial_floats(H1, H2, K))
+        nb = int(lib.sgnn_head_blocks(B))
+        dz1 = torch.empty((B, H1), dtype=torch.float32, device=dev)
+        partial = torch.empty((nb, P), dtype=torch.float32, device=dev)
+        check(lib.sgnn_head_bwd(_ptr(logits), _ptr(lse), _ptr(labels), _ptr(g_loss), _ptr(g_logits),
+                                ctypes.c_void_p(out.data_ptr() + 8) if out is not None else None, _ptr(a1), _ptr(a2), _ptr(W2),
+                                _ptr(W3), B, H1, H2, K, ctx.p, _ptr(dz1), _ptr(partial), _stream()), 'sgnn_head_bwd')
+        # gW1 = dz1^T x: block partials on the matrix cores; its blocks and the head kernel's partials are added by ONE launch
+        flat = torch.empty(P, dtype=torch.float32, device=dev)
+        jobs_part, jobs_nb, jobs_n, jobs_out = [partial], [nb], [P], [flat]
+        gW1 = None
+        if ctx.needs_input_grad[1]:
+            H0 = x.shape[1]
+            nbw = int(lib.sgnn_contract_rows_blocks(B))
+            pw = torch.empty((nbw, H1, H0), dtype=torch.float32, device=dev)
+            gW1 = torch.empty((H1, H0), dtype=torch.float32, device=dev)
+            # (the host arrays must outlive the call: named, not temporaries)
+            pa, pb, pp = _ptr_table([dz1]), _ptr_table([x]), _ptr_table([pw])
+            dims = np.array([H1, x.stride(0), H1, H0, B], dtype=np.int64)
+            check(lib.sgnn_contract_rows_partial(1, pa.ctypes.data, pb.ctypes.data, dims[0:1].ctypes.data, dims[1:2].ctypes.data,
+                                                 dims[2:3].ctypes.data, dims[3:4].ctypes.data, dims[4:5].ctypes.data,
+                                                 pp.ctypes.data, _stream()), 'sgnn_contract_rows_partial')
+            jobs_part.append(pw), jobs_nb.append(nbw), jobs_n.append(H1 * H0), jobs_out.append(gW1)
+        rp, ro = _ptr_table(jobs_part), _ptr_table(jobs_out)
+        rnb, rn = np.array(jobs_nb, dtype=np.int64), np.array(jobs_n, dtype=np.int64)
+        check(lib.sgnn_reduce_partials(len(jobs_part), rp.ctypes.data, rnb.ctypes.data, rn.ctypes.data, ro.ctypes.data, _stream()),
+              'sgnn_reduce_partials')
+        o = 0
+        gW3 = flat[o:o + K * H2].view(K, H2); o += K * H2
+        gb3 = flat[o:o + K]; o += K
+        gW2 = flat[o:o + H2 * H1].view(H2, H1); o += H2 * H1
+        gb2 = flat[o:o + H2]; o += H2
+        gb1 = flat[o:o + H1]
+        hb = ctx.has_bias
+        need = ctx.needs_input_grad
+        dx = dz1 @ W1 if need[0] else None
+        return (dx, gW1, gb1 if (hb[0] and need[2]) else None, gW2 if need[3] else None, gb2 if (hb[1] and need[4]) else None,
+                gW3 if need[5] else None, gb3 if (hb[2] and need[6]) else None, None, None, None)
+
+
+def fused_head(x, lin, lin2, lin3, labels=None, p=0.0, rng=None):
+    """The head's three Linear layers with relu + dropout(p) between them, and -- with ``labels`` -- the mean cross entropy and
+    the accuracy of the logits (``lin*``: nn.Linear modules).  -> (logits, loss or None, accuracy (1,) or None).
+    ``rng``: int64 (2,) device tensor {seed, step} when p > 0 (the launch advances step)."""
+    if p > 0 and rng is None:
+        raise ValueError('fused_head: dropout needs the {seed, step} tensor')
+    if x.stride(1) != 1 or x.stride(0) != x.shape[1]:
+        x = x.contiguous()
+    return _FusedHead.apply(x, lin.weight, lin.bias, lin2.weight, lin2.bias, lin3.weight, lin3.bias,
+                            labels.contiguous() if labels is not None else None, float(p), rng if p > 0 else None)
+
+
 class _GatherRows(torch.autograd.Function):
     """``nn.Embedding(padding_idx=0)`` lookup for a handful of ids (the shared P anchors, the walks
     of the structure patches): the backward scatters the few rows with ``index_add_`` instead of
@@ -2080,11 +2357,48 @@ class _GatherRows(torch.autograd.Function):
         return torch.zeros(ctx.n_rows, g.shape[1], dtype=grad.dtype, device=grad.device).index_add_(0, flat, g), None, None
 
 
+_INDEX_FLAGS = {}            # device -> (int32 flag tensor the gather kernels set, pinned host twin, event of the last copy)
+
+
+def _index_flag(device):
+    ent = _INDEX_FLAGS.get(str(device))
+    if ent is None:
+        ent = _INDEX_FLAGS[str(device)] = [torch.zeros(1, dtype=torch.int32, device=device),
+                                           torch.zeros(1, dtype=torch.int32).pin_memory(), None]
+    return ent
+
+
+def poll_index_errors(block=False):
+    """Raise IndexError if a device-side row gather (index_rows_many with a device-resident index vector, whose values the host
+    never sees) met an index outside its source since the last poll.  The kernel cannot raise: it writes a zero row and sets a
+    flag; the flag is copied to pinned memory behind every gather and read here once the copy has landed (``block``: wait for
+    it -- the epoch-end callers, which read results back anyway).  A recorded step's gathers set the same flag."""
+    if not _INDEX_FLAGS or torch.cuda.is_current_stream_capturing():
+        return
+    for dev, ent in list(_INDEX_FLAGS.items()):
+        flag, host, ev = ent
+        if block:
+            host.copy_(flag, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            ev.synchronize()
+        elif ev is None or not ev.query():
+            continue
+        ent[2] = None
+        if int(host[0]) != 0:
+            flag.zero_()
+            host.zero_()
+            raise IndexError('a batch index on %s was out of range for its split (device-side gather: the rows of such an index '
+                             'are zero-filled)' % dev)
+
+
 def index_rows_many(tensors, idx):
     """[t.index_select(0, idx) for t in tensors] in one launch (sgnn_gather_rows_many): the row gathers that assemble a batch
     from a split's per-subgraph tensors.  ``tensors``: contiguous CUDA tensors with the same number of rows; ``idx``: int64 device
     tensor.  Tensors it cannot take (not contiguous, other devices) go through index_select."""
     lib = _lib.load()
+    if idx.is_cuda:
+        poll_index_errors()                          # (an earlier gather's flag, if its copy has landed: never a wait)
     out = [None] * len(tensors)
     take = [k for k, t in enumerate(tensors) if t.is_cuda and t.is_contiguous() and t.dim() >= 1 and t.shape[0] > 0 and t.numel() > 0]
     if not idx.is_cuda or idx.dtype != torch.int64 or not idx.is_contiguous() or idx.numel() == 0 or len(take) < 2:
@@ -2101,8 +2415,13 @@ def index_rows_many(tensors, idx):
         src, dst = _ptr_table([tensors[k] for k in group]), _ptr_table([out[k] for k in group])
         rb = np.array([tensors[k][0].numel() * tensors[k].element_size() for k in group], dtype=np.int64)
         rows = np.array([tensors[k].shape[0] for k in group], dtype=np.int64)
+        ent = _index_flag(idx.device)
         check(lib.sgnn_gather_rows_many(len(group), src.ctypes.data, dst.ctypes.data, rb.ctypes.data, rows.ctypes.data, _ptr(idx), B,
-                                        _stream()), 'sgnn_gather_rows_many')
+                                        _ptr(ent[0]), _stream()), 'sgnn_gather_rows_many')
+        if not torch.cuda.is_current_stream_capturing():
+            ent[1].copy_(ent[0], non_blocking=True)            # read by poll_index_errors once it has landed
+            ent[2] = torch.cuda.Event()
+            ent[2].record()
     return out
 
 

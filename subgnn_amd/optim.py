@@ -6,6 +6,8 @@ coefficient, four chunked multi-tensor launches and a zero fill of the gradient 
 The small parameters stay with torch's fused Adam (one launch for all of them).  Same update rule, same clipping rule
 (coefficient = min(1, max_norm / (total_norm + 1e-6)) over ALL parameters); the table's clip coefficient is a device
 scalar read by the kernel, so the step has no host round trip."""
+import copy
+
 import torch
 
 from . import ops
@@ -161,7 +163,7 @@ class ClipAdam:
         group = {k: v for k, v in self.param_groups[0].items() if k != 'params'}
         group['params'] = list(range(len(self.param_groups[0]['params'])))
         return {'state': state, 'param_groups': [group],
-                'small': self.small_opt.state_dict() if self.small_opt is not None else None}
+                'small': copy.deepcopy(self.small_opt.state_dict()) if self.small_opt is not None else None}
 
     def load_state_dict(self, sd):
         """Inverse of ``state_dict``.  A checkpoint without the row-skip bytes (moments restored from elsewhere) marks every row
@@ -190,7 +192,7 @@ class ClipAdam:
                     seen = ((st['exp_avg'] != 0) | (st['exp_avg_sq'] != 0)).reshape(p.shape[0], -1).any(1).to(torch.uint8)
                 self.tail.seen[k].copy_(seen)
         if self.small_opt is not None and sd.get('small') is not None:
-            self.small_opt.load_state_dict(sd['small'])
+            self.small_opt.load_state_dict(copy.deepcopy(sd['small']))
 
     def make_eager(self):
         """Back to host-side step counts (the trainer's fallback when a step cannot be recorded): same arithmetic."""

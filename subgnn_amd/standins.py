@@ -212,7 +212,34 @@ def time_steps(model, opt, hp, steps, warmup, graph, count=False):
     return ms, float(loss.detach()), n_k
 
 
-def bench_config(name, steps=30, warmup=5, deterministic=True, root=None, count=True, also_atomics=False):
+def time_epochs(model, hp, epochs=4):
+    """Whole EPOCHS of the reference's loop (train_config.py:156-186 / SubGNN.py:350-464) on a prepared model, as
+    train_config.Trainer runs them: replayed training steps, the validation steps, validation_epoch_end (metrics,
+    init_all_embeddings, anchor resample when hparams ask for it) and any re-recording -> dict: wall ms per epoch (mean over
+    the epochs after the first, which also pays the eager warm-up steps and the recordings) and where it goes."""
+    import time
+    from .train_config import Trainer
+    tr = Trainer(epochs, hp.get('grad_clip', 0.0), log=lambda *a, **k: None, hip_graph_step=bool(hp.get('hip_graph_step', True)))
+    tr.phase_times = []
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    tr.fit(model, prepared=True)
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    later = tr.phase_times[1:] or tr.phase_times
+    keys = ('train_steps_s', 'validation_steps_s', 'validation_epoch_end_s')
+    mean = {k: 1e3 * sum(r.get(k, 0.0) for r in later) / len(later) for k in keys}
+    first = {k: round(1e3 * tr.phase_times[0].get(k, 0.0), 2) for k in keys}
+    return {'epochs': epochs, 'wall_s': round(wall, 3), 'epoch_ms': round(sum(mean.values()), 3),
+            'breakdown_ms': {k[:-2] + '_ms': round(v, 3) for k, v in mean.items()},
+            'first_epoch_ms(warm-up steps + recordings)': first,
+            'per_epoch': {k: later[-1].get(k) for k in ('replayed_steps', 'eager_steps', 'validation_batches')},
+            'recordings_after_the_first_epoch': sum(r.get('recordings', 0) for r in later),
+            'resample_anchor_patches': bool(hp.get('resample_anchor_patches', False)),
+            'monitor_last': tr.history[-1] if tr.history else None}
+
+
+def bench_config(name, steps=30, warmup=5, deterministic=True, root=None, count=True, also_atomics=False, epochs=0):
     """One BASELINE configuration's stand-in end to end -> dict: dataset write, graph metrics, prepare_data, then the
     batch-sized training step eager and replayed (ms per step, subgraphs/s, kernels per step).  What bench.py's
     ``configs`` object and tools/bench_standin.py report."""
@@ -254,6 +281,21 @@ def bench_config(name, steps=30, warmup=5, deterministic=True, root=None, count=
         model.train()
         ms_eager, loss, k_eager = time_steps(model, opt, model.hparams, steps, warmup, graph=False, count=count)
         ms_graph, loss_g, _ = time_steps(model, opt, model.hparams, steps, warmup, graph=True)
+        epoch = None
+        if epochs:
+            # whole epochs on a FRESH model of the same dataset (the timed steps above moved this one's parameters and step counts)
+            torch.manual_seed(3)
+            m_e = SubGNN(dict(hp), **dataset_paths(name + '_standin'))
+            if P['sparse']:
+                for sp in ('val', 'train'):
+                    hotpath.prepare_sparse(m_e, sp)
+            else:
+                m_e.prepare_data()
+            epoch = time_epochs(m_e, m_e.hparams, epochs)
+            n_full = epoch['per_epoch']['replayed_steps'] or 0
+            epoch['replayed_step_ms'] = round(ms_graph, 3)
+            epoch['epoch_over_steps'] = round(epoch['epoch_ms'] / max(n_full * ms_graph, 1e-9), 3) if n_full else None
+            del m_e
         ms_atomics = k_atomics = None
         if also_atomics and deterministic:
             # the same dataset with hparams['deterministic'] = False (float atomics in the backward pass: no sorts, no segmented
@@ -285,7 +327,7 @@ def bench_config(name, steps=30, warmup=5, deterministic=True, root=None, count=
         'unit': 'subgraphs/s', 'n_gpus': 1,
         'value': B * 1e3 / ms_graph, 'ms_per_step': ms_graph, 'hip_graph_step': True,
         'eager': {'value': B * 1e3 / ms_eager, 'ms_per_step': ms_eager},
-        'kernels_per_step': k_eager,
+        'kernels_per_step': k_eager, 'epoch': epoch,
         'atomics': None if ms_atomics is None else {'ms_per_step': ms_atomics, 'value': B * 1e3 / ms_atomics, 'kernels_per_step': k_atomics,
                                                     'what': "hparams['deterministic'] = False: float atomics in the backward pass (not bit-reproducible)"},
         'steps': steps, 'warmup': warmup, 'higher_is_better': True, 'dtype': 'f32', 'data': 'synthetic (stand-in)',

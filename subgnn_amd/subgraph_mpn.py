@@ -81,20 +81,19 @@ class SG_MPN(nn.Module):
             # only the read-out of this layer is consumed, and only summed over a subgraph's components: it is written
             # straight into its slot of the subgraph embedding (ops.subgraph_embedding)
             wp, bp = self.linear_position.weight.view(-1), self.linear_position.bias
+            # (the scores s = x wp -- 0 for a PAD anchor -- are computed inside ops.subgraph_embedding's launches, for all such
+            # pieces of the step together, and so is their backward: no matrix-vector / mask launches per piece)
             if isinstance(sims, ops.ZeroSims):
-                return None, ops.ReadoutPiece(None, None, torch.zeros(A, dtype=cc_embeds.dtype, device=cc_embeds.device), bp, A,
-                                              row_mask, R)
+                return None, ops.ReadoutPiece(None, None, None, bp, A, row_mask, R)
             sims2 = sims.reshape(R, -1)
             if not sims2.is_contiguous():
                 sims2 = sims2.contiguous()
-            s = x @ wp
             if sim_col is None and not sims_per_edge:
                 sim_col = (ids - 1).clamp(min=0)
-            if ids is not None:
-                s = s * (ids != 0).to(s.dtype)
-            return None, ops.ReadoutPiece(sims2, sim_col, s, bp, A, row_mask, R)
+            return None, ops.ReadoutPiece(sims2, sim_col, None, bp, A, row_mask, R, X=x, wp=wp,
+                                          ids=ids.reshape(-1).contiguous() if ids is not None else None)
         if isinstance(sims, ops.ZeroSims):          # all edge weights 0: messages vanish, read-out = bias
-            agg = torch.zeros((R, D), dtype=cc_embeds.dtype, device=cc_embeds.device)
+            agg = ops.zeros_cached((R, D), cc_embeds.dtype, cc_embeds.device)       # (read-only: nothing writes an aggregate)
             z = self.linear_position.bias.view(1, 1).expand(R, A)
             return self._finish(cc_embeds, agg, z, need_out, need_pos, defer_update=defer_update)
         # (SubGNN._forward converts the mask once per forward and hangs it on the tensor: one launch instead of one per layer)

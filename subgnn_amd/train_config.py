@@ -108,6 +108,18 @@ class Trainer:
         # hparams['resample_anchor_patches'] the prepared tensors change at every epoch end, so the step is recorded again
         # once per epoch (a device synchronisation + one capture: ~the cost of 3-4 eager steps per epoch).
         self.hip_graph_step = bool(hip_graph_step) and torch.cuda.is_available()
+        # measurement aid (standins.bench_config's ``epoch`` object): a list makes ``fit`` append one dict of wall-clock phase
+        # times per epoch (each phase then ends with a device synchronisation -- not for a production run)
+        self.phase_times = None
+
+    def _phase(self, rec, name, t0):
+        if rec is None:
+            return t0
+        import time
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        rec[name] = rec.get(name, 0.0) + (t1 - t0)
+        return t1
 
     def _eager_step(self, model, opt, batch, bi):
         out = model.training_step(batch, bi)
@@ -118,8 +130,11 @@ class Trainer:
         opt.step()
         return out['loss'].detach()
 
-    def fit(self, model):
-        model.prepare_data()
+    def fit(self, model, prepared=False):
+        """``prepared``: the caller has already run prepare_data (or hotpath.prepare_sparse for graphs whose dense structures
+        cannot exist)."""
+        if not prepared:
+            model.prepare_data()
         # plain Adam over CUDA parameters (what configure_optimizers returns) becomes optim.ClipAdam: same update and clipping
         # rule, the embedding table in one HIP pass, the clip coefficient a device scalar (optim.accelerate)
         opt = accelerate(model.configure_optimizers(), self.clip, capturable=self.hip_graph_step)
@@ -128,7 +143,14 @@ class Trainer:
             from .graph_step import CapturedTrainStep, StepNotRecordable, make_capturable, make_eager
             if not isinstance(opt, ClipAdam):
                 make_capturable(opt)
+        import time
         for epoch in range(self.max_epochs):
+            rec = None
+            if self.phase_times is not None:
+                rec = {'replayed_steps': 0, 'eager_steps': 0, 'recordings': 0}
+                self.phase_times.append(rec)
+                torch.cuda.synchronize()
+            t_ph = time.perf_counter()
             model.train()
             losses = []
             loader = model.train_dataloader()
@@ -138,10 +160,14 @@ class Trainer:
                 if captured is None or captured.stale():
                     captured = CapturedTrainStep(model, opt, loader.bs, 0.0 if isinstance(opt, ClipAdam) else self.clip,
                                                  warmup=3 if captured is None else 0)
+                    if rec is not None:
+                        rec['recordings'] += 1
                 for bi, idx in enumerate(loader.index_batches()):
                     if idx.numel() == loader.bs and self.hip_graph_step:
                         try:
                             losses.append(captured.replay(idx)[0].clone())
+                            if rec is not None:
+                                rec['replayed_steps' if captured.graph is not None and captured._warm_left == 0 else 'eager_steps'] += 1
                             continue
                         except StepNotRecordable as ex:
                             # only a failure of the RECORDING falls back (an error of the eager warm-up steps or of a replay is
@@ -152,13 +178,22 @@ class Trainer:
                             opt.make_eager() if isinstance(opt, ClipAdam) else make_eager(opt)
                             torch.cuda.synchronize()
                     losses.append(self._eager_step(model, opt, model.make_batch('train', idx), bi))
+                    if rec is not None:
+                        rec['eager_steps'] += 1
             else:
                 for bi, batch in enumerate(loader):
                     losses.append(self._eager_step(model, opt, batch, bi))
+                    if rec is not None:
+                        rec['eager_steps'] += 1
+            t_ph = self._phase(rec, 'train_steps_s', t_ph)
             model.eval()
             with torch.no_grad():
                 outs = [model.validation_step(b, i) for i, b in enumerate(model.val_dataloader())]
+                t_ph = self._phase(rec, 'validation_steps_s', t_ph)
+                if rec is not None:
+                    rec['validation_batches'] = len(outs)
                 res = model.validation_epoch_end(outs)
+                t_ph = self._phase(rec, 'validation_epoch_end_s', t_ph)
             val = float(res['log'][self.monitor])
             if self.best is None or (val > self.best if self.mode == 'max' else val < self.best):
                 self.best = val

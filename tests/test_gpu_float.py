@@ -1132,3 +1132,190 @@ def test_contract_rows_matches_the_plain_product():
     ref = (a.double().t() @ b.double()).float()
     assert_close(ops.contract_rows(a, b), ref, 'contract_rows', norm_tol=1e-6)
     assert_close(ops.contract_rows(a[:1000], b[:1000]), (a[:1000].double().t() @ b[:1000].double()).float(), 'small', norm_tol=1e-5)
+
+
+# ---- fused MLP head + loss (csrc/head.hip) ---------------------------------------------------------------------------------------
+
+def _head_modules(H0, H1, H2, K, seed):
+    g = torch.Generator().manual_seed(seed)
+    mods = [torch.nn.Linear(H0, H1), torch.nn.Linear(H1, H2), torch.nn.Linear(H2, K)]
+    for m in mods:                                     # (activations and logits of order 1: a softmax over logits of order 30 carries
+        m.weight.data = torch.randn(m.weight.shape, generator=g) / m.in_features ** 0.5      # 1e-6 x 30 of relative error by itself)
+        m.bias.data = torch.randn(m.bias.shape, generator=g) * 0.3
+    return mods
+
+
+@pytest.mark.parametrize('B,H0,H1,H2,K', [(1, 7, 3, 2, 1), (50, 33, 16, 8, 3), (64, 615, 64, 32, 6), (1000, 566, 64, 64, 3),
+                                          (4133, 130, 128, 128, 32), (9000, 70, 100, 37, 5)])
+def test_fused_head_matches_torch(B, H0, H1, H2, K):
+    """ops.fused_head (p = 0) == lin -> relu -> lin2 -> relu -> lin3 -> CrossEntropyLoss + accuracy of plain torch on the CPU:
+    logits, loss, accuracy and every gradient (x, three weights, three biases), rows not a multiple of the 32-row chunk, widths
+    not multiples of the MFMA tile, an ignored row (-100), several workgroups and several chunks per workgroup."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(B + H0)
+    x = torch.randn(B, H0, generator=g)
+    labels = torch.randint(0, K, (B,), generator=g)
+    if B > 10:
+        labels[3] = -100
+    # (the reference in float64: two fp32 evaluations with different summation orders differ by more than the tolerance on
+    # elements that are small by cancellation)
+    ref_m, got_m = [m.double() for m in _head_modules(H0, H1, H2, K, 3)], [m.to(DEV) for m in _head_modules(H0, H1, H2, K, 3)]
+    xr = x.double().requires_grad_(True)
+    lg_r = ref_m[2](F.relu(ref_m[1](F.relu(ref_m[0](xr)))))
+    loss_r = F.cross_entropy(lg_r, labels)
+    loss_r.backward()
+    acc_r = (lg_r.argmax(1) == labels).float().mean()
+    xg = x.to(DEV).requires_grad_(True)
+    lg, loss, acc = ops.fused_head(xg, got_m[0], got_m[1], got_m[2], labels.to(DEV), 0.0, None)
+    loss.backward()
+    assert_close(lg.detach(), lg_r.detach(), 'logits')
+    assert abs(float(loss.detach()) - float(loss_r.detach())) <= 1e-5 * max(1.0, abs(float(loss_r.detach())))
+    assert abs(float(acc) - float(acc_r)) < 1e-6
+    assert_close(xg.grad, xr.grad, 'grad x', norm_tol=2e-5)
+    for a, b, nm in zip(got_m, ref_m, ('lin', 'lin2', 'lin3')):
+        assert_close(a.weight.grad, b.weight.grad, 'grad %s.weight' % nm, norm_tol=2e-5)
+        assert_close(a.bias.grad, b.bias.grad, 'grad %s.bias' % nm, norm_tol=2e-5)
+    # without labels: logits only, and a gradient that arrives through the logits
+    for m in got_m:
+        m.zero_grad()
+    xg2 = x.to(DEV).requires_grad_(True)
+    lg2, l2, a2 = ops.fused_head(xg2, got_m[0], got_m[1], got_m[2], None, 0.0, None)
+    assert l2 is None and a2 is None and torch.equal(lg2, lg.detach())
+    go = torch.randn(B, K, generator=g)
+    (lg2 * go.to(DEV)).sum().backward()
+    for m in ref_m:
+        m.zero_grad()
+    xr2 = x.double().requires_grad_(True)
+    (ref_m[2](F.relu(ref_m[1](F.relu(ref_m[0](xr2))))) * go.double()).sum().backward()
+    assert_close(xg2.grad, xr2.grad, 'grad x through logits', norm_tol=2e-5)
+    assert_close(got_m[1].weight.grad, ref_m[1].weight.grad, 'grad lin2.weight through logits', norm_tol=2e-5)
+    # twice the same call: bit-identical (fixed summation orders, the ticket leaves its counter at zero)
+    lg3, loss3, _ = ops.fused_head(x.to(DEV), got_m[0], got_m[1], got_m[2], labels.to(DEV), 0.0, None)
+    assert torch.equal(lg3, lg.detach()) and torch.equal(loss3, loss.detach())
+
+
+def test_fused_head_dropout_masks():
+    """p > 0: every mask element is kept with probability 1 - p and scaled by 1 / (1 - p); the step counter advances on the
+    device (the next call draws other masks, the same {seed, step} the same ones); the backward gates exactly the kept,
+    activated elements."""
+    ops = _ops()
+    B, H0, H1, H2, K, p = 3000, 40, 64, 32, 4, 0.3
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(B, H0, generator=g).to(DEV)
+    mods = [m.to(DEV) for m in _head_modules(H0, H1, H2, K, 5)]
+    labels = torch.randint(0, K, (B,), generator=g).to(DEV)
+    rng = torch.tensor([1234, 0], dtype=torch.int64, device=DEV)
+    saved = {}
+
+    def run(state):
+        xx = x.clone().requires_grad_(True)
+        lg, loss, acc = ops.fused_head(xx, mods[0], mods[1], mods[2], labels, p, state)
+        a1 = loss.grad_fn.saved_tensors[4] if hasattr(loss.grad_fn, 'saved_tensors') else None
+        loss.backward()
+        return lg.detach(), a1, xx.grad
+    lg_a, a1_a, gx_a = run(rng)
+    assert rng.tolist() == [1234, 1]
+    lg_b, a1_b, _ = run(rng)
+    assert rng.tolist() == [1234, 2] and not torch.equal(lg_a, lg_b)
+    lg_c, a1_c, gx_c = run(torch.tensor([1234, 0], dtype=torch.int64, device=DEV))
+    assert torch.equal(lg_a, lg_c) and torch.equal(gx_a, gx_c)
+    z1 = torch.relu(F.linear(x, mods[0].weight, mods[0].bias))
+    live = z1 > 0
+    kept = (a1_a > 0) & live
+    frac = float(kept.sum()) / float(live.sum())
+    assert abs(frac - (1 - p)) < 0.01, frac
+    assert_close(a1_a[kept], z1[kept] / (1 - p), 'kept activations are scaled', norm_tol=1e-6)
+    assert float(a1_a[~kept].abs().max()) == 0.0
+    # eval-style call: p = 0 leaves the state alone
+    ops.fused_head(x, mods[0], mods[1], mods[2], labels, 0.0, None)
+    assert rng.tolist() == [1234, 2]
+
+
+@pytest.mark.parametrize('R', [5, 300, 5000, 40000])
+def test_contract_rows_many_matches_torch(R):
+    """a^T b on the matrix cores for tall operands (block partials + ordered reduction), several jobs per launch, widths that are
+    not multiples of 32, a strided operand (a column slice)."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(R)
+    shapes = [(64, 566), (3, 5), (256, 64), (100, 33), (32, 32), (1, 1), (130, 70), (64, 64), (17, 200)]
+    pairs, want = [], []
+    for M, N in shapes:
+        a, b = torch.randn(R, M, generator=g), torch.randn(R, N + 3, generator=g)
+        pairs.append((a.to(DEV), b.to(DEV)[:, 1:N + 1]))
+        want.append(a.double().t() @ b[:, 1:N + 1].double())
+    got = ops.contract_rows_many(pairs)
+    assert len(got) == len(shapes)
+    for (M, N), o, w in zip(shapes, got, want):
+        assert tuple(o.shape) == (M, N)
+        assert_close(o, w.float(), 'a^T b (%d x %d over %d rows)' % (M, N, R), norm_tol=2e-5)
+    again = ops.contract_rows_many(pairs)
+    assert all(torch.equal(a, b) for a, b in zip(got, again))
+
+
+def test_device_side_batch_index_out_of_range_is_reported():
+    """a device-resident batch index outside its split cannot raise inside the gather kernel; it yields zero rows and
+    sets a flag that ops.poll_index_errors turns into an IndexError."""
+    ops = _ops()
+    a = torch.arange(40, dtype=torch.float32, device=DEV).view(10, 4)
+    b = torch.arange(30, dtype=torch.int64, device=DEV).view(10, 3)
+    ops.poll_index_errors(block=True)
+    good = ops.index_rows_many([a, b], torch.tensor([9, 0, 3], device=DEV))
+    assert torch.equal(good[0], a[[9, 0, 3]]) and torch.equal(good[1], b[[9, 0, 3]])
+    ops.poll_index_errors(block=True)
+    bad = ops.index_rows_many([a, b], torch.tensor([2, 10, -1], device=DEV))
+    assert torch.equal(bad[0][0], a[2]) and float(bad[0][1:].abs().max()) == 0 and int(bad[1][1:].abs().max()) == 0
+    with pytest.raises(IndexError):
+        ops.poll_index_errors(block=True)
+    ops.poll_index_errors(block=True)                 # reported once
+
+
+@pytest.mark.parametrize('B,C', [(7, 3), (300, 2), (5000, 1)])
+def test_readout_pieces_with_scores_in_kernel(B, C):
+    """Read-out pieces whose scores s = X wp (0 for a PAD anchor) are computed inside ops.subgraph_embedding's own launches
+    (sgnn_readout_many_fwd / _bwd: all pieces of a step in two launches each way) against the same pieces with the scores made
+    by torch beforehand (one launch pair per piece + the autograd of s = X wp): embedding bit-equal, gradients of X, wp, bp and
+    of the tensor pieces equal; two anchor widths in one call (two launch groups), a piece without anchors (all-zero
+    similarities), nine pieces (more than one launch of eight)."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(B + C)
+    R = B * C
+    mask = (torch.rand(B, C, generator=g) > 0.3).reshape(-1).to(torch.uint8).to(DEV)
+    specs = [(11, 16, True), (40, 16, False), (5, 16, True), (183, 16, True), (7, 8, False), (42, 16, False), (3, 16, True), (9, 16, False),
+             (21, 16, True)]
+    data = []
+    for A, D, with_ids in specs:
+        wide = torch.rand(R, A + 4, generator=g)
+        col = torch.randperm(A + 4, generator=g)[:A]
+        ids = torch.randint(0, 3, (A,), generator=g) if with_ids else None
+        data.append((wide.to(DEV), col.to(DEV), torch.randn(A, D, generator=g), torch.randn(D, generator=g), torch.randn(1, generator=g) * 0.3,
+                     ids.to(DEV) if ids is not None else None, A))
+    x0 = torch.randn(B, C, 6, generator=g)
+    b0 = torch.tensor([0.25])
+    H = 6 + sum(A for A, _, _ in specs) + 4
+    go = torch.randn(B, H, generator=g).to(DEV)
+
+    def run(in_kernel):
+        X0 = x0.to(DEV).clone().requires_grad_(True)
+        B0 = b0.to(DEV).clone().requires_grad_(True)
+        leaves, pieces = [X0, B0], [X0]
+        for wide, col, X, wp, bp, ids, A in data:
+            Xl, wl, bl = [t.to(DEV).clone().requires_grad_(True) for t in (X, wp, bp)]
+            leaves += [Xl, wl, bl]
+            if in_kernel:
+                pieces.append(ops.ReadoutPiece(wide, col, None, bl, A, mask, R, X=Xl, wp=wl, ids=ids))
+            else:
+                s = Xl @ wl
+                if ids is not None:
+                    s = s * (ids != 0).to(s.dtype)
+                pieces.append(ops.ReadoutPiece(wide, col, s, bl, A, mask, R))
+        pieces.append(ops.ReadoutPiece(None, None, None if in_kernel else torch.zeros(4, device=DEV), B0, 4, mask, R))
+        out = ops.subgraph_embedding(pieces, mask, B, C)
+        (out * go).sum().backward()
+        return out.detach(), [t.grad for t in leaves]
+    out_a, g_a = run(True)
+    out_b, g_b = run(False)
+    assert_close(out_a, out_b, 'embedding', norm_tol=2e-6)       # (the scores' dot products are summed in another order than the library's)
+    for i, (a, b) in enumerate(zip(g_a, g_b)):
+        assert_close(a, b, 'gradient of leaf %d' % i, norm_tol=1e-5)
+    out_c, g_c = run(True)
+    assert torch.equal(out_a, out_c) and all(torch.equal(a, b) for a, b in zip(g_a, g_c))

@@ -184,6 +184,30 @@ def test_one_shard_of_the_benchmark_reproduces_its_slice_of_the_unsharded_pass(f
     assert torch.equal(part.train_int_struc_similarities, whole.train_int_struc_similarities[a:b])
     assert torch.equal(part.train_bor_struc_similarities, whole.train_bor_struc_similarities[a:b])
     assert float(part.train_bor_struc_similarities.abs().sum()) > 0
+    # ... and the same rank in the DEALT (strong-scaling) form, as ONE process with the peers' shares from recorded buffers
+    # (dist.EmulatedPeers: what bench.py's strong_rank8 object runs): the rank walks an eighth of the structure patches and of
+    # their walks, searches ITS 23 of the 183 position sources over all ranks' components, and still arrives at its slice of
+    # the unsharded pass, bit for bit -- on the recording pass AND on the passes that replay the recorded buffers
+    emu = sdist.EmulatedPeers(3, 8)
+    emu.provided['cc_ids_all'] = whole.train_cc_ids.reshape(S * C, L)
+    emu.maxima[2], emu.maxima[1] = dims.to(torch.int32), width
+    dealt_shard = sdist.Shard(S, 3, 8, deal_shared=True, emulator=emu)
+    assert dealt_shard.deal_shared and not dealt_shard.collectives
+    dealt = model(subs[a:b], labels[a:b])
+    for _pass in range(2):
+        hotpath.prepare_sparse(dealt, 'train', shard=dealt_shard)
+        assert torch.equal(dealt.train_cc_ids, whole.train_cc_ids[a:b])
+        assert torch.equal(dealt.structure_anchors, whole.structure_anchors)
+        assert torch.equal(dealt.int_structure_anchor_random_walks, whole.int_structure_anchor_random_walks)
+        assert torch.equal(dealt.bor_structure_anchor_random_walks, whole.bor_structure_anchor_random_walks)
+        for l in range(hp['n_layers']):
+            assert torch.equal(dealt.anchors_pos_ext[l], whole.anchors_pos_ext[l])
+            for key in (('N', 'out', l), ('P', 'out', l)):
+                assert torch.equal(dealt.train_neigh_pos_similarities[key], whole.train_neigh_pos_similarities[key][a:b]), key
+        assert torch.equal(dealt.train_int_struc_similarities, whole.train_int_struc_similarities[a:b])
+        assert torch.equal(dealt.train_bor_struc_similarities, whole.train_bor_struc_similarities[a:b])
+    assert set(k[0] if isinstance(k, tuple) else k for k in emu.received_bytes) >= {'S_patches', 'S_walks', 'cc_ids', 'P_out'}
+    assert 0 < sum(emu.received_bytes.values()) < 64 << 20
 
 
 @pytest.mark.parametrize('n_layers', [1, 2])
@@ -221,7 +245,8 @@ def test_training_half_at_shard_size_matches_the_oracle(full, n_layers):
                 'cross_entropy_with_accuracy', 'subgraph_embedding')
     lib_names = ('sgnn_readout_sum_fwd', 'sgnn_readout_sum_bwd', 'sgnn_update_fwd', 'sgnn_update_bwd', 'sgnn_scatter_add_rows',
                  'sgnn_cross_entropy_fwd', 'sgnn_cross_entropy_bwd', 'sgnn_optim_sumsq', 'sgnn_optim_adam', 'sgnn_lstm_fwd', 'sgnn_lstm_bwd',
-                 'sgnn_cc_embed_fwd', 'sgnn_mpn_fwd', 'sgnn_mpn_bwd')
+                 'sgnn_cc_embed_fwd', 'sgnn_mpn_fwd', 'sgnn_mpn_bwd', 'sgnn_head_fwd', 'sgnn_head_bwd', 'sgnn_contract_rows_partial',
+                 'sgnn_reduce_partials', 'sgnn_readout_many_fwd', 'sgnn_readout_many_bwd')
     saved_py = {n: getattr(ops, n) for n in py_names}
     saved_lib = {n: getattr(lib, n) for n in lib_names if hasattr(lib, n)}
     tall = collections.Counter()
@@ -271,11 +296,15 @@ def test_training_half_at_shard_size_matches_the_oracle(full, n_layers):
         ops.linear = real_linear
     # ---- the shard-size branches ran -------------------------------------------------------------------------------
     assert calls['_mpn_shared_gemm'] >= (3 if n_layers > 1 else 0), calls      # first layer: P-border + both structure sides
-    assert tall['rows>=8192'] >= 3, tall                   # the head's three linears over >= 8192 rows
-    assert calls['contract_rows'] >= 3 and calls['column_sum'] >= 3, calls
+    # the head + loss: one fused launch each way behind the first layer's GEMM (csrc/head.hip: two calls forward -- the training
+    # step and the no-grad forward above --, one backward), its first weight gradient on the matrix cores, one reduction launch
+    assert calls['sgnn_head_fwd'] == 2 and calls['sgnn_head_bwd'] == 1 and tall['rows>=8192'] == 0, (calls, tall)
+    assert calls['sgnn_contract_rows_partial'] >= 1 and calls['sgnn_reduce_partials'] >= 1, calls
     assert calls['mpn_edge_plan'] >= 1 and calls['presort_ids'] >= 2, calls
-    assert calls['cross_entropy_with_accuracy'] >= 1 and calls['sgnn_cross_entropy_bwd'] == 1, calls
-    assert calls['subgraph_embedding'] >= 1 and calls['sgnn_readout_sum_fwd'] >= 1 and calls['sgnn_readout_sum_bwd'] >= 1, calls
+    assert calls['cross_entropy_with_accuracy'] == 0 and calls['sgnn_cross_entropy_bwd'] == 0, calls      # (inside the head's launches)
+    # the read-out pieces (P internal / border, S internal / border of the last layer): all of them in one call each way
+    assert calls['subgraph_embedding'] >= 1 and calls['sgnn_readout_many_fwd'] == 2 and calls['sgnn_readout_many_bwd'] == 1, calls
+    assert calls['sgnn_readout_sum_fwd'] == 0 and calls['sgnn_readout_sum_bwd'] == 0, calls
     assert calls['sgnn_update_fwd'] >= 1 and calls['sgnn_update_bwd'] >= 1, calls
     assert calls['sgnn_optim_sumsq'] == 1 and calls['sgnn_optim_adam'] == 1, calls      # the whole optimizer tail: two library calls
     assert calls['sgnn_lstm_fwd'] >= 1 and calls['sgnn_lstm_bwd'] >= 1, calls
