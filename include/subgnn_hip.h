@@ -509,6 +509,23 @@ int sgnn_lstm_fwd(const float* pre_x, const float* whh_f, const float* whh_r, co
 int sgnn_lstm_bwd(const float* whh_f, const float* whh_r, const float* gates, const float* cell, const float* dy,
                   int64_t B, int64_t T, int64_t hidden_size, float* dgates, void* stream);
 
+/* The dense products around the recurrence, and the walk aggregator's tail (anchor_patch_samplers.py:413-433 / SubGNN.py:60-88:
+ * embedding lookup -> LSTM -> last step (or sum over steps) -> Linear -> sum over a patch's walks), in this library's launches:
+ *   sgnn_rows_gemm     out[z] (R, N) = X[row(r)] W_z^T + b_z for z = 0 (and 1 when W1 is given): fp32 MFMA; row(r) = ids[r] when
+ *                      ids (int64, nullable) is given -- the gather of the input rows is the operand load -- and the gathered
+ *                      rows are written to x_copy (R, K; nullable).  X rows of ldx floats, K % 8 == 0; W_z (N, K) row-major.
+ *   sgnn_rows_gemm_nt  out (R, N) = A[0] W0 + A[1] W1 with A (2, R, K) and W_z (K, N) row-major (dx of both directions).
+ *   sgnn_lstm_tail_fwd X (n_patches, D) = s W_lin^T + n_walks b_lin, s[p] = sum over the patch's walks of y[walk][T - 1] (last_only)
+ *                      or of every step; y (n_patches n_walks, T, H2); s_out (n_patches, H2) kept for the backward.
+ *   sgnn_lstm_tail_bwd dy (same shape as y, every element written), dW_lin (D, H2), db_lin (D) (both nullable) from dX and s. */
+int sgnn_rows_gemm(const float* X, const int64_t* ids, int64_t ldx, int64_t R, int64_t K, const float* W0, const float* W1,
+                   const float* b0, const float* b1, int64_t N, float* out, float* x_copy, void* stream);
+int sgnn_rows_gemm_nt(const float* A, int64_t R, int64_t K, const float* W0, const float* W1, int64_t N, float* out, void* stream);
+int sgnn_lstm_tail_fwd(const float* y, int64_t n_patches, int64_t n_walks, int64_t T, int64_t H2, int last_only,
+                       const float* W_lin, const float* b_lin, int64_t D, float* s_out, float* X, void* stream);
+int sgnn_lstm_tail_bwd(const float* dX, const float* s, int64_t n_patches, int64_t n_walks, int64_t T, int64_t H2,
+                       int last_only, const float* W_lin, int64_t D, float* dy, float* dW_lin, float* db_lin, void* stream);
+
 /* ---------------------------------------------------------------------------------------
  * a16  Masked sum over the components of a subgraph (subgraph_utils.masked_sum,
  * SubGNN/subgraph_utils.py:213-237, as used at SubGNN/SubGNN.py:303).  x (B,C,H), mask (B,C)

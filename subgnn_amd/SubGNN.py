@@ -59,6 +59,25 @@ class LSTM(nn.Module):
                 out = nn.functional.dropout(out, m.dropout, True)
         return out
 
+    def forward_walks(self, table, walk_ids, n_walks):
+        """The walk aggregator in one chain of this library's launches (aps:413-433): embedding lookup of ``walk_ids`` (B, T) ->
+        the LSTM layers -> last step / sum over steps -> Linear -> sum over every ``n_walks`` consecutive sequences -> (B /
+        n_walks, n_features).  The lookup is the first layer's operand load (ops.bilstm_layer_fused), the tail one launch
+        (ops.lstm_tail).  None where the fused form does not apply (the caller takes forward())."""
+        m = self.lstm
+        if not (table.is_cuda and table.dtype == torch.float32 and m.batch_first and m.bias and walk_ids.dim() == 2
+                and getattr(table, '_sgnn_half', None) is None and table.shape[1] == m.input_size
+                and ops.lstm_fused_supported(m.input_size, m.hidden_size) and walk_ids.shape[0] % n_walks == 0):
+            return None
+        out = None
+        for l in range(self.num_layers):
+            params = [getattr(m, '%s_l%d%s' % (n, l, sfx)) for sfx in ('', '_reverse')
+                      for n in ('weight_ih', 'weight_hh', 'bias_ih', 'bias_hh')]
+            out = ops.bilstm_layer_fused(table, params, ids=walk_ids) if l == 0 else ops.bilstm_layer_fused(out, params)
+            if l < self.num_layers - 1 and m.dropout > 0 and self.training:
+                out = nn.functional.dropout(out, m.dropout, True)
+        return ops.lstm_tail(out, self.linear.weight, self.linear.bias, n_walks, self.aggregator == 'last')
+
     def forward(self, input):
         m = self.lstm
         if (input.is_cuda and input.dtype == torch.float32 and m.batch_first and m.bias and input.dim() == 3
@@ -896,6 +915,12 @@ class SubGNN(nn.Module):
         p = 'test' if is_test else 'val'
         labels = batch['label'].squeeze(-1)
         logits = self._forward_batch(p, batch)
+        return self.val_test_outputs(p, logits, labels)
+
+    def val_test_outputs(self, p, logits, labels):
+        """What val_test_step makes of a batch's logits and labels (S.py:380-406): loss, accuracy, macro F1 + the logits and
+        labels themselves for the epoch's metrics.  Device tensors or host copies alike (the trainer's recorded validation
+        forward hands over host copies of a whole epoch's batches: one transfer instead of three read-backs per batch)."""
         loss, labels = self._loss(logits, labels)
         acc = subgraph_utils.calc_accuracy(logits, labels, multilabel_binarizer=self.multilabel_binarizer)
         f1 = subgraph_utils.calc_f1(logits, labels, avg_type='macro', multilabel_binarizer=self.multilabel_binarizer)
@@ -945,7 +970,9 @@ class SubGNN(nn.Module):
         logs = self._epoch_metrics(outputs, 'val')
         hp = self.hparams
         if not hp['trainable_cc']:
-            self.init_all_embeddings(split='train_val', trainable=False)
+            # (S.py:446-448 recomputes the six per-split copies of the component embeddings here; without trainable_cc nothing on
+            # the path reads them -- forward recomputes from the table, S.py:238-247 -- so they are made when somebody asks)
+            self.init_all_embeddings(split='train_val', trainable=False, lazy=True)
         if hp['resample_anchor_patches']:
             # a fresh tape stream for the new draws; hparams['seed'] (already written to hyperparams.json
             # by the caller, and what prepare_test_data draws from) stays what the caller set
@@ -959,20 +986,88 @@ class SubGNN(nn.Module):
         the tape streams of resample epoch ``_resample_epoch``."""
         hp, g = self.hparams, self.networkx_graph
         ep = self.__dict__.get('_resample_epoch', 0)
+        new = {}
         if hp['use_neighborhood']:
-            self.anchors_neigh_int, self.anchors_neigh_border = aps.init_anchors_neighborhood(
+            new['anchors_neigh_int'], new['anchors_neigh_border'] = aps.init_anchors_neighborhood(
                 'train_val', hp, g, self.device, self.train_cc_ids, self.val_cc_ids, None, self.train_N_border,
                 self.val_N_border, None, epoch=ep)
         if hp['use_position']:
-            self.anchors_pos_int = aps.init_anchors_pos_int('train_val', hp, g, self.device, self.train_sub_G,
-                                                            self.val_sub_G, self.test_sub_G, epoch=ep)
-            self.anchors_pos_ext = aps.init_anchors_pos_ext(hp, g, self.device, epoch=ep)
+            new['anchors_pos_int'] = aps.init_anchors_pos_int('train_val', hp, g, self.device, self.train_sub_G,
+                                                               self.val_sub_G, self.test_sub_G, epoch=ep)
+            new['anchors_pos_ext'] = aps.init_anchors_pos_ext(hp, g, self.device, epoch=ep)
         if hp['use_structure']:
-            self.anchors_structure = aps.init_anchors_structure(hp, self.structure_anchors,
-                                                                self.int_structure_anchor_random_walks,
-                                                                self.bor_structure_anchor_random_walks, epoch=ep)
+            new['anchors_structure'] = aps.init_anchors_structure(hp, self.structure_anchors,
+                                                                  self.int_structure_anchor_random_walks,
+                                                                  self.bor_structure_anchor_random_walks, epoch=ep)
+        if hp.get('resample_in_place', True) and self.device.type == 'cuda' and self._resample_in_place(new):
+            return                                     # same tensors, new draws: recorded steps stay valid (no generation bump)
+        for k, v in new.items():
+            setattr(self, k, v)
         self._build_sim_cols()
         self._bump_generation()
+
+    def _resample_in_place(self, new):
+        """The new draws COPIED into the tensors of the old ones where every shape agrees -- anchor counts and padded widths do
+        not change between resamples -- so that a recorded training / validation step (graph_step.py), which reads those
+        addresses, stays valid: a resample then costs its sampling launches + a few copies instead of a device synchronisation
+        and two recordings per epoch.  Also refreshed, in place: what was DERIVED from the old draws and is read by address -- the
+        structure similarity columns, the per-layer anchor stacks, the stacked walks of all layers with their sorted order.
+        -> False (nothing touched beyond copies that are about to be replaced anyway) when some shape changed: the caller
+        assigns the new containers and bumps the generation, as before."""
+        from . import hotpath
+        for k, v in new.items():
+            if getattr(self, k, None) is None:
+                return False
+        replaced, memo = [], {}
+        kept = {k: hotpath._copy_into(getattr(self, k), v, k, replaced, memo) for k, v in new.items()}
+        if replaced:
+            return False
+        for k, v in kept.items():
+            setattr(self, k, v)
+        src = getattr(self, 'anchors_structure', None)
+        if src is not None and 'anchors_structure' in new:
+            cols = self.sim_cols_of(src)
+            cur = getattr(self, '_sim_col_cache', None) or {}
+            if set(cols) != set(cur) or any(cols[l].shape != cur[l].shape for l in cols):
+                return False
+            for l in cols:
+                cur[l].copy_(cols[l])
+            self.__dict__['_sim_cols_src'] = src
+            first = src[0][2]
+            L = self.hparams['n_layers']
+            stacked = getattr(first, '_sgnn_all', None)
+            if stacked is not None:
+                fresh = torch.cat([t for l in range(L) for t in (src[l][2], src[l][3])], 0)
+                if fresh.shape != stacked.shape:
+                    return False
+                stacked.copy_(fresh)
+                old = getattr(stacked, '_sgnn_sorted', None)
+                if old is not None:
+                    k32 = stacked.reshape(-1).to(torch.int32)
+                    sk, order = ops.sort_edges_by_key(k32.contiguous(), self.networkx_graph.max_id)
+                    old[0].copy_(sk), old[1].copy_(order), old[2].copy_(k32)
+            for l in range(L):
+                both = getattr(src[l][2], '_sgnn_both', None)
+                if both is not None:
+                    fresh = torch.cat([src[l][2], src[l][3]], 0)
+                    if fresh.shape != both.shape:
+                        return False
+                    both.copy_(fresh)
+                    old = getattr(both, '_sgnn_sorted', None)
+                    if old is not None:
+                        k32 = both.reshape(-1).to(torch.int32)
+                        sk, order = ops.sort_edges_by_key(k32.contiguous(), self.networkx_graph.max_id)
+                        old[0].copy_(sk), old[1].copy_(order), old[2].copy_(k32)
+        for key, ent in (self.__dict__.get('_anchor_stacks') or {}).items():
+            ent[2].copy_(torch.stack(ent[1], 0))          # (ent[1]: the per-layer tensors, refreshed in place above)
+        for name in ('anchors_pos_ext',):
+            for v in (getattr(self, name, None) or {}).values():
+                old = getattr(v, '_sgnn_sorted', None)
+                if old is not None:
+                    k32 = v.reshape(-1).to(torch.int32)
+                    sk, order = ops.sort_edges_by_key(k32.contiguous(), self.networkx_graph.max_id)
+                    old[0].copy_(sk), old[1].copy_(order), old[2].copy_(k32)
+        return True
 
     def _bump_generation(self):
         """Every replacement of tensors a recorded step reads (prepared sets, anchors, similarity rows)

@@ -118,6 +118,10 @@ SIGNATURES = {
     'sgnn_readout_sum_bwd': (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_ptr, c_ptr,
                                      c_ptr, c_i64, c_ptr]),
     'sgnn_gather_rows_many_max': (c_i64, []),
+    'sgnn_rows_gemm': (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_ptr]),
+    'sgnn_rows_gemm_nt': (c_int, [c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_i64, c_ptr, c_ptr]),
+    'sgnn_lstm_tail_fwd': (c_int, [c_ptr, c_i64, c_i64, c_i64, c_i64, c_int, c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_ptr]),
+    'sgnn_lstm_tail_bwd': (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_i64, c_i64, c_int, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr]),
     'sgnn_readout_many_max': (c_i64, []),
     'sgnn_readout_many_fwd': (c_int, [c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64,
                                       c_i64, c_ptr, c_i64, c_ptr]),

@@ -261,7 +261,18 @@ def aggregate_structure_anchor_patch(hparams, networkx_graph, lstm, node_matrix,
                                      inside, device, table=None):
     """aps:413-433: walks (A, W, T) -> LSTM over each walk's embeddings -> sum over W -> (A, D)."""
     n = anchor_patch_ids.shape[0]
-    walk_embeds = ops.gather_rows(node_matrix.weight if table is None else table, all_patch_walks.to(device))
+    walks = all_patch_walks.to(device)
+    E = node_matrix.weight if table is None else table
+    if hparams.get('fused_forward', True) and hasattr(lstm, 'forward_walks') and walks.is_cuda and walks.dtype == torch.int64:
+        # lookup, LSTM, last step, Linear and the sum over a patch's walks as one chain of this library's launches
+        ids = walks.reshape(n * hparams['n_triangular_walks'], hparams['random_walk_len'])
+        pre = getattr(all_patch_walks, '_sgnn_sorted', None)
+        if pre is not None:
+            ids._sgnn_sorted = pre
+        X = lstm.forward_walks(E, ids, hparams['n_triangular_walks'])
+        if X is not None:
+            return X
+    walk_embeds = ops.gather_rows(E, walks)
     x = walk_embeds.view(n * hparams['n_triangular_walks'], hparams['random_walk_len'], hparams['node_embed_size'])
     h = lstm(x).view(n, hparams['n_triangular_walks'], -1)
     return torch.sum(h, dim=1)

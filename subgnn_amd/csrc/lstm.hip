@@ -275,4 +275,218 @@ extern "C" int sgnn_lstm_bwd(const float* whh_f, const float* whh_r, const float
 #undef LSTM_BWD
 }
 
+// ---- the products around the recurrence, in this library's own launches ---------------------------------------------------------
+// The walk aggregator (anchor_patch_samplers.py:413-433: embedding lookup of the walks -> LSTM -> last step -> Linear -> sum over a
+// patch's walks) is a few hundred sequences of 10-20 steps: its dense products -- input projection, dx, the tail's Linear -- are
+// GEMMs of a few thousand rows by 64-256 columns.  As library calls they were 3 + 2 launches forward and ~20 backward per LSTM
+// layer (gather, two addmm; in the backward two GEMMs + copies for dx, four weight contractions with their block sums, four
+// column sums, the zero-filled gradient of the last-step slice, the Linear's three products), each a 5-40 us launch around
+// microseconds of arithmetic.  Here:
+//   rows_gemm_kernel     out[z][r][n] = sum_k X[row(r)][k] W_z[n][k] + b_z[n] for z = 0, 1 (the two directions): fp32 MFMA, a lane
+//                        reads half of its (gathered) input row straight into registers -- the embedding lookup of the walks IS
+//                        the operand load; the gathered rows are written out once for the weight gradients
+//   rows_gemm_nt_kernel  dx[r][n] = sum_z sum_k A_z[r][k] W_z[k][n] (both directions into one accumulator)
+//   lstm_tail_*          X[p] = (sum over the patch's walks of the last step) W_lin^T + W b_lin, and its backward incl. the dense,
+//                        mostly zero d y the recurrence's backward reads
+// The weight gradients dW_ih, dW_hh, db of both directions are six jobs of sgnn_contract_rows_partial (head.hip).
+typedef float lstm_f32x16 __attribute__((ext_vector_type(16)));
+#define LSTM_KC 16
+
+__device__ __forceinline__ int lstm_acc_row(int v, int h) { return 8 * (v >> 2) + 4 * h + (v & 3); }
+
+// one wavefront per (32 rows, 32 output columns, direction z); K even, K / 2 a multiple of 4
+__global__ __launch_bounds__(64) void rows_gemm_kernel(const float* __restrict__ X, const int64_t* __restrict__ ids, int64_t ldx,
+                                                       int64_t R, int K, const float* __restrict__ W0, const float* __restrict__ W1,
+                                                       const float* __restrict__ b0, const float* __restrict__ b1, int N,
+                                                       float* __restrict__ out, float* __restrict__ xcopy)
+{
+    const int lane = threadIdx.x, i = lane & 31, h = lane >> 5, z = blockIdx.z, nt = blockIdx.y;
+    const int64_t row0 = (int64_t)blockIdx.x * 32;
+    const int64_t r = row0 + i < R ? row0 + i : R - 1;
+    const int64_t src_row = ids ? ids[r] : r;
+    const int Kh = K / 2;
+    const float* __restrict__ src = X + src_row * ldx + h * Kh;
+    const int n = nt * 32 + i;
+    const float* __restrict__ W = z ? W1 : W0;
+    const float* __restrict__ wrow = W + (int64_t)(n < N ? n : N - 1) * K + h * Kh;
+    lstm_f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const bool copy = xcopy && nt == 0 && z == 0 && row0 + i < R;
+    for (int kc = 0; kc < Kh; kc += LSTM_KC) {
+        float a[LSTM_KC], w[LSTM_KC];
+#pragma unroll
+        for (int c = 0; c < LSTM_KC / 4; ++c) {
+            float4 av = make_float4(0.f, 0.f, 0.f, 0.f), wv = av;
+            if (kc + 4 * c < Kh) {
+                av = *reinterpret_cast<const float4*>(src + kc + 4 * c);
+                wv = *reinterpret_cast<const float4*>(wrow + kc + 4 * c);
+                if (copy) *reinterpret_cast<float4*>(xcopy + (row0 + i) * K + h * Kh + kc + 4 * c) = av;
+            }
+            a[4 * c] = av.x; a[4 * c + 1] = av.y; a[4 * c + 2] = av.z; a[4 * c + 3] = av.w;
+            w[4 * c] = wv.x; w[4 * c + 1] = wv.y; w[4 * c + 2] = wv.z; w[4 * c + 3] = wv.w;
+        }
+#pragma unroll
+        for (int s = 0; s < LSTM_KC; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], w[s], acc, 0, 0, 0);
+    }
+    if (n >= N) return;
+    const float* __restrict__ b = z ? b1 : b0;
+    const float bias = b ? b[n] : 0.f;
+    float* __restrict__ dst = out + (int64_t)z * R * N;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+        const int64_t rr = row0 + lstm_acc_row(v, h);
+        if (rr < R) dst[rr * N + n] = acc[v] + bias;
+    }
+}
+
+// dx[r][n] = sum over z of sum_k A_z[r][k] W_z[k][n]; A_z = A + z * R * K (direction-major gate gradients), W_z (K, N) row-major
+__global__ __launch_bounds__(64) void rows_gemm_nt_kernel(const float* __restrict__ A, int64_t R, int K, const float* __restrict__ W0,
+                                                          const float* __restrict__ W1, int N, float* __restrict__ out)
+{
+    const int lane = threadIdx.x, i = lane & 31, h = lane >> 5, nt = blockIdx.y;
+    const int64_t row0 = (int64_t)blockIdx.x * 32;
+    const int64_t r = row0 + i < R ? row0 + i : R - 1;
+    const int Kh = K / 2;
+    const int n = nt * 32 + i, nn = n < N ? n : N - 1;
+    lstm_f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int z = 0; z < 2; ++z) {
+        const float* __restrict__ arow = A + ((int64_t)z * R + r) * K + h * Kh;
+        const float* __restrict__ wcol = (z ? W1 : W0) + (int64_t)(h * Kh) * N + nn;
+        for (int kc = 0; kc < Kh; kc += LSTM_KC) {
+            float a[LSTM_KC], w[LSTM_KC];
+#pragma unroll
+            for (int c = 0; c < LSTM_KC / 4; ++c) {
+                float4 av = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (kc + 4 * c < Kh) av = *reinterpret_cast<const float4*>(arow + kc + 4 * c);
+                a[4 * c] = av.x; a[4 * c + 1] = av.y; a[4 * c + 2] = av.z; a[4 * c + 3] = av.w;
+            }
+#pragma unroll
+            for (int s = 0; s < LSTM_KC; ++s) w[s] = kc + s < Kh ? wcol[(int64_t)(kc + s) * N] : 0.f;
+#pragma unroll
+            for (int s = 0; s < LSTM_KC; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], w[s], acc, 0, 0, 0);
+        }
+    }
+    if (n >= N) return;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+        const int64_t rr = row0 + lstm_acc_row(v, h);
+        if (rr < R) out[rr * N + n] = acc[v];
+    }
+}
+
+// X[p][d] = s[p] . W_lin[d] + n_walks b[d], s[p] = sum over the patch's walks of y[walk][T - 1][:] (last_only) or of every step;
+// one workgroup per patch; s (n_patches, 2H) is kept for the backward
+__global__ __launch_bounds__(256) void lstm_tail_fwd_kernel(const float* __restrict__ y, int64_t T, int H2, int n_walks, int last_only,
+                                                            const float* __restrict__ Wl, const float* __restrict__ bl, int D,
+                                                            float* __restrict__ s_out, float* __restrict__ X)
+{
+    extern __shared__ float s_sum[];                                      // [H2]
+    const int64_t p = blockIdx.x;
+    for (int c = threadIdx.x; c < H2; c += 256) {
+        float v = 0.f;
+        for (int w = 0; w < n_walks; ++w) {
+            const float* __restrict__ yw = y + ((p * n_walks + w) * T) * H2;
+            if (last_only) v += yw[(T - 1) * H2 + c];
+            else for (int64_t t = 0; t < T; ++t) v += yw[t * H2 + c];
+        }
+        s_sum[c] = v;
+        s_out[p * H2 + c] = v;
+    }
+    __syncthreads();
+    for (int d = threadIdx.x; d < D; d += 256) {
+        const float* __restrict__ wr = Wl + (int64_t)d * H2;
+        float v = 0.f;
+        for (int c = 0; c < H2; ++c) v = fmaf(s_sum[c], wr[c], v);
+        X[p * D + d] = v + (bl ? (float)n_walks * bl[d] : 0.f);
+    }
+}
+
+// workgroups [0, B): d y of one sequence -- zeros except the last step (last_only) / the same row at every step: g[b] = dX[b / n_walks] W_lin;
+// workgroups [B, B + ceil(D 2H / 256)): dW_lin[d][c] = sum_p dX[p][d] s[p][c] (patches in order); the workgroup after them: d b_lin
+__global__ __launch_bounds__(256) void lstm_tail_bwd_kernel(const float* __restrict__ dX, const float* __restrict__ s, int64_t n_patches,
+                                                            int64_t B, int64_t T, int H2, int n_walks, int last_only,
+                                                            const float* __restrict__ Wl, int D, float* __restrict__ dy,
+                                                            float* __restrict__ dWl, float* __restrict__ dbl)
+{
+    extern __shared__ float s_dx[];                                       // [D]
+    const int64_t blk = blockIdx.x;
+    if (blk < B) {
+        const int64_t p = blk / n_walks;
+        for (int d = threadIdx.x; d < D; d += 256) s_dx[d] = dX[p * D + d];
+        __syncthreads();
+        float* __restrict__ row = dy + blk * T * H2;
+        for (int c = threadIdx.x; c < H2; c += 256) {
+            float v = 0.f;
+            for (int d = 0; d < D; ++d) v = fmaf(s_dx[d], Wl[(int64_t)d * H2 + c], v);
+            for (int64_t t = 0; t < T; ++t) row[t * H2 + c] = (last_only && t != T - 1) ? 0.f : v;
+        }
+        return;
+    }
+    const int64_t e = (blk - B) * 256 + threadIdx.x, n_w = (int64_t)D * H2;
+    const int64_t w_blocks = (n_w + 255) / 256;
+    if (blk - B < w_blocks) {
+        if (e < n_w && dWl) {
+            const int d = (int)(e / H2), c = (int)(e - (int64_t)d * H2);
+            float v = 0.f;
+            for (int64_t p = 0; p < n_patches; ++p) v = fmaf(dX[p * D + d], s[p * H2 + c], v);
+            dWl[e] = v;
+        }
+        return;
+    }
+    if (dbl)
+        for (int d = threadIdx.x; d < D; d += 256) {
+            float v = 0.f;
+            for (int64_t p = 0; p < n_patches; ++p) v += dX[p * D + d];
+            dbl[d] = (float)n_walks * v;
+        }
+}
+
+extern "C" int sgnn_rows_gemm(const float* X, const int64_t* ids, int64_t ldx, int64_t R, int64_t K, const float* W0, const float* W1,
+                              const float* b0, const float* b1, int64_t N, float* out, float* x_copy, void* stream)
+{
+    if (!X || !W0 || !out || R < 0 || K < 8 || K % 8 != 0 || N < 1 || ldx < K || ldx % 4 != 0) return SGNN_ERR_BAD_ARG;
+    if (R == 0) return SGNN_OK;
+    if ((R + 31) / 32 > 0x7fffffff || (N + 31) / 32 > 65535) return SGNN_ERR_BAD_ARG;
+    hipLaunchKernelGGL(rows_gemm_kernel, dim3((unsigned)((R + 31) / 32), (unsigned)((N + 31) / 32), W1 ? 2u : 1u), dim3(64), 0,
+                       (hipStream_t)stream, X, ids, ldx, R, (int)K, W0, W1, b0, b1, (int)N, out, x_copy);
+    SGNN_CHECK_LAUNCH();
+    return SGNN_OK;
+}
+
+extern "C" int sgnn_rows_gemm_nt(const float* A, int64_t R, int64_t K, const float* W0, const float* W1, int64_t N, float* out,
+                                 void* stream)
+{
+    if (!A || !W0 || !W1 || !out || R < 0 || K < 8 || K % 8 != 0 || N < 1) return SGNN_ERR_BAD_ARG;
+    if (R == 0) return SGNN_OK;
+    if ((R + 31) / 32 > 0x7fffffff || (N + 31) / 32 > 65535) return SGNN_ERR_BAD_ARG;
+    hipLaunchKernelGGL(rows_gemm_nt_kernel, dim3((unsigned)((R + 31) / 32), (unsigned)((N + 31) / 32)), dim3(64), 0, (hipStream_t)stream,
+                       A, R, (int)K, W0, W1, (int)N, out);
+    SGNN_CHECK_LAUNCH();
+    return SGNN_OK;
+}
+
+extern "C" int sgnn_lstm_tail_fwd(const float* y, int64_t n_patches, int64_t n_walks, int64_t T, int64_t H2, int last_only,
+                                  const float* W_lin, const float* b_lin, int64_t D, float* s_out, float* X, void* stream)
+{
+    if (!y || !W_lin || !s_out || !X || n_patches < 0 || n_walks < 1 || T < 1 || H2 < 1 || H2 > 8192 || D < 1) return SGNN_ERR_BAD_ARG;
+    if (n_patches == 0) return SGNN_OK;
+    if (n_patches > 0x7fffffff) return SGNN_ERR_BAD_ARG;
+    hipLaunchKernelGGL(lstm_tail_fwd_kernel, dim3((unsigned)n_patches), dim3(256), (size_t)H2 * 4, (hipStream_t)stream, y, T, (int)H2,
+                       (int)n_walks, last_only, W_lin, b_lin, (int)D, s_out, X);
+    SGNN_CHECK_LAUNCH();
+    return SGNN_OK;
+}
+
+extern "C" int sgnn_lstm_tail_bwd(const float* dX, const float* s, int64_t n_patches, int64_t n_walks, int64_t T, int64_t H2,
+                                  int last_only, const float* W_lin, int64_t D, float* dy, float* dW_lin, float* db_lin, void* stream)
+{
+    if (!dX || !s || !W_lin || !dy || n_patches < 0 || n_walks < 1 || T < 1 || H2 < 1 || D < 1 || D > 8192) return SGNN_ERR_BAD_ARG;
+    if (n_patches == 0) return SGNN_OK;
+    const int64_t B = n_patches * n_walks, blocks = B + (D * H2 + 255) / 256 + 1;
+    if (blocks > 0x7fffffff) return SGNN_ERR_BAD_ARG;
+    hipLaunchKernelGGL(lstm_tail_bwd_kernel, dim3((unsigned)blocks), dim3(256), (size_t)D * 4, (hipStream_t)stream, dX, s, n_patches, B, T,
+                       (int)H2, (int)n_walks, last_only, W_lin, (int)D, dy, dW_lin, db_lin);
+    SGNN_CHECK_LAUNCH();
+    return SGNN_OK;
+}
+
 SGNN_DEFINE_WARM(lstm)

@@ -405,11 +405,16 @@ __global__ __launch_bounds__(256) void readout_bwd_finish_many_kernel(const RoPi
         if (a < A) src = P.partial_s[p] + (int64_t)a * nblk; else a = -1;
     } else if (wave == 0) src = P.partial_b[p];
     if (src) {
-        float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+        // (the block partials of a column are added in double: a column of 50k x C rows is ~800 partials whose sum is a gradient
+        // the LSTM's weight gradients are contracted from -- rounded once here instead of once per partial)
+        double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;
         int64_t k = lane;
         for (; k + 192 < nblk; k += 256) { v0 += src[k]; v1 += src[k + 64]; v2 += src[k + 128]; v3 += src[k + 192]; }
         for (; k < nblk; k += 64) v0 += src[k];
-        const float v = ro_wave_sum((v0 + v1) + (v2 + v3));
+        double vd = (v0 + v1) + (v2 + v3);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) vd += __shfl_xor(vd, o, 64);
+        const float v = (float)vd;
         if (a >= 0) {
             const bool pad = P.ids[p] && P.ids[p][a] == 0;
             const float gs = pad ? 0.f : v;

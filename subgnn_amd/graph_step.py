@@ -139,3 +139,53 @@ class CapturedTrainStep:
         # the replayed Adam step changed the master table without moving its host-side version counter
         self.model.invalidate_half_table()
         return self.loss, self.acc
+
+
+class CapturedEvalStep:
+    """The forward pass of a validation / test batch (SubGNN.val_test_step's device half: make_batch + forward, eval mode, no
+    gradients) recorded once for batches of exactly ``batch_size`` subgraphs of ``split`` and replayed with a new index vector:
+    an eager validation step is ~100 launches the host takes 2-6 ms to queue, a replay one.  A short last batch is padded with
+    index 0 by the caller (every row of a forward pass depends on its own subgraph only -- BatchNorm runs on its running
+    statistics in eval mode -- so the padded rows change nothing and are dropped).  ``replay`` returns the recording's static
+    logits and labels (clone to keep them past the next replay)."""
+
+    def __init__(self, model, batch_size, split='val', warmup=1):
+        if not torch.cuda.is_available():
+            raise RuntimeError('CapturedEvalStep needs the GPU: there is no CPU path')
+        self.model, self.B, self.split = model, int(batch_size), split
+        self.idx = torch.zeros(self.B, dtype=torch.int64, device=model.device)
+        self._token = model.__dict__.get('_prep_generation', 0)
+        self.graph = self.logits = self.labels = None
+        self._warm_left = warmup
+
+    def stale(self):
+        return self.model.__dict__.get('_prep_generation', 0) != self._token
+
+    def _body(self):
+        m = self.model
+        batch = m.make_batch(self.split, self.idx, trim=False)
+        return m._forward_batch(self.split, batch), batch['label']
+
+    def replay(self, idx):
+        idx = torch.as_tensor(idx)
+        if idx.numel() != self.B:
+            raise ValueError('captured step takes %d indices, got %d' % (self.B, idx.numel()))
+        if self.model.training or torch.is_grad_enabled():
+            raise RuntimeError('CapturedEvalStep replays an eval-mode, no-grad forward: call model.eval() under torch.no_grad()')
+        self.idx.copy_(idx.view(-1), non_blocking=True)
+        if self.graph is None:
+            if self._warm_left > 0:
+                self._warm_left -= 1
+                return self._body()
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            try:
+                with torch.cuda.graph(g):
+                    self.logits, self.labels = self._body()
+            except RuntimeError as ex:
+                self.logits = self.labels = None
+                abandon_capture(self.model, None)
+                raise StepNotRecordable(str(ex)) from ex
+            self.graph = g
+        self.graph.replay()
+        return self.logits, self.labels

@@ -641,17 +641,27 @@ def finish_pass(model, st, timer=None):
         # depends only on the split's components and the graph: decided on the first pass, kept.
         group = model.__dict__.setdefault('_dtw_group_rows', {})
         xprep = model.__dict__.setdefault('_dtw_x_prep', {})
-        if group.get(split) is None or group[split][0] != cc_sets.n:
-            group[split] = (cc_sets.n, ops.distinct_row_fraction(cc_sets.ptr, ci, mx) <= 0.5,
-                            ops.distinct_row_fraction(cc_sets.ptr, ce, mx) <= 0.5)
+        ent = group.get(split)
+        if ent is None or ent[0] != cc_sets.n:
+            # the first pass of a split does not group (a choice of kernels, never of values) and does not WAIT for the answer
+            # either: the distinct-row counts travel to pinned memory behind its launches (75 ms of read-back on the driver's
+            # box in round 5) and a later pass picks them up
+            ent = group[split] = (cc_sets.n, False, False,
+                                  (ops.distinct_rows_async(cc_sets.ptr, ci, mx), ops.distinct_rows_async(cc_sets.ptr, ce, mx)))
             xprep[split] = ({}, {})
-            t.mark('dtw_row_grouping_decision(first pass only)')
+            t.mark('dtw_row_grouping_counts_queued(first pass only)')
+        elif ent[3] is not None:
+            wait = torch.cuda.is_current_stream_capturing()          # (a recording needs the decision settled: the counts are long there)
+            fr = [ops.distinct_rows_ready(p, wait=wait) for p in ent[3]]
+            if all(f is not None for f in fr):
+                ent = group[split] = (cc_sets.n, fr[0] <= 0.5, fr[1] <= 0.5, None)
+                xprep[split] = ({}, {})
         # the component side of the DTW calls (grouping of repeated degree sequences, processing order) depends on the
         # split's components only -- the same every pass: kept from the first one (xprep), like the dispatch orders
         st.attrs[split + '_int_struc_similarities'] = \
-            ops.dtw_similarity(cc_sets.ptr, ci, mx, a_sets.ptr, ai, my, tie, dedupe=group[split][1], x_prep=xprep[split][0]).view(S, C, -1)
+            ops.dtw_similarity(cc_sets.ptr, ci, mx, a_sets.ptr, ai, my, tie, dedupe=ent[1], x_prep=xprep[split][0]).view(S, C, -1)
         st.attrs[split + '_bor_struc_similarities'] = \
-            ops.dtw_similarity(cc_sets.ptr, ce, mx, a_sets.ptr, ae, my, tie, dedupe=group[split][2], x_prep=xprep[split][1]).view(S, C, -1)
+            ops.dtw_similarity(cc_sets.ptr, ce, mx, a_sets.ptr, ae, my, tie, dedupe=ent[2], x_prep=xprep[split][1]).view(S, C, -1)
         t.mark('dtw')
     elif split + '_int_struc_similarities' not in st.attrs:
         st.attrs[split + '_int_struc_similarities'] = None

@@ -324,11 +324,13 @@ def filter_sets(sets, flags):
 
 def heaviest_first(g, sets):
     """Dispatch order for set kernels whose cost is the members' total degree: heaviest sets first."""
-    tot = int(sets.ptr[-1].item())
-    deg = (g.rowptr[1:] - g.rowptr[:-1])[sets.nodes[:tot].long()]
+    # (over the whole node array -- entries behind ptr[-1] are an arena's zero tail, PAD = node 0 of degree 0 -- so that no size
+    # is read back: the first pass of a split waited here for everything queued before it, 43 ms on the driver's box)
+    tot = sets.nodes.numel()
+    deg = (g.rowptr[1:] - g.rowptr[:-1])[sets.nodes.long().clamp_(0, g.max_id)]
     csum = torch.zeros(tot + 1, dtype=torch.int64, device=g.device)
     torch.cumsum(deg, 0, out=csum[1:])
-    work = csum[sets.ptr[1:]] - csum[sets.ptr[:-1]]
+    work = csum[sets.ptr[1:].clamp(max=tot)] - csum[sets.ptr[:-1].clamp(max=tot)]
     # descending by work = ascending by (cap - work) under the library's own stable radix sort (sgnn_sort_edges_by_key) -- the
     # first use of torch.argsort loaded another library's sort (0.2 s of the cold first pass).  Only an ORDER of dispatch:
     # works beyond the cap tie at the front.
@@ -806,6 +808,35 @@ def distinct_row_fraction(x_ptr, x_val, max_x):
     rows = Ragged(x_ptr, x_val, max_len=max_x).to_padded(width=max_x, fill=-1, dtype=torch.int32)
     rep = _row_representatives(rows)
     return float((rep == torch.arange(n, device=rows.device)).sum().item()) / n
+
+
+def distinct_rows_async(x_ptr, x_val, max_x):
+    """distinct_row_fraction without the wait: the count of distinct rows travels to pinned host memory behind the launches
+    queued here -> (pinned int64 (1,), event, n rows) or None where the answer is known (few rows / long rows: no grouping).
+    ``distinct_rows_ready`` reads it once the copy has landed."""
+    n = x_ptr.numel() - 1
+    if n <= 1024 or max_x > 64:
+        return None
+    rows = Ragged(x_ptr, x_val, max_len=max_x).to_padded(width=max_x, fill=-1, dtype=torch.int32)
+    rep = _row_representatives(rows)
+    cnt = (rep == torch.arange(n, device=rows.device)).sum().view(1)
+    host = torch.empty(1, dtype=torch.int64).pin_memory()
+    host.copy_(cnt, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record()
+    return host, ev, n
+
+
+def distinct_rows_ready(pending, wait=False):
+    """-> fraction of distinct rows, or None while the copy of ``distinct_rows_async`` is still in flight (``wait``: block)."""
+    if pending is None:
+        return 1.0
+    host, ev, n = pending
+    if wait:
+        ev.synchronize()
+    elif not ev.query():
+        return None
+    return float(int(host[0])) / n
 
 
 def dtw_similarity(x_ptr, x_val, max_x, y_ptr, y_val, max_y, tie_order=None, order_rows=True, dedupe=True, order=None,
@@ -2492,6 +2523,156 @@ class _BiLSTMLayer(torch.autograd.Function):
         db_f, db_r = column_sum(dg[0]), column_sum(dg[1])
         db = torch.stack((db_f, db_r, db_f, db_r))                              # [ih: forward, reverse | hh: forward, reverse]
         return (dx, dwih[0], dwhh[0], db[0], db[2], dwih[1], dwhh[1], db[1], db[3])
+
+
+_ONES = {}
+
+
+def _ones_column(rows, device):
+    key = str(device)
+    t = _ONES.get(key)
+    if t is None or t.numel() < rows:
+        if torch.cuda.is_current_stream_capturing():
+            return torch.ones(rows, 1, dtype=torch.float32, device=device)
+        t = _ONES[key] = torch.ones(max(rows, 8192), dtype=torch.float32, device=device)
+    return t[:rows].view(rows, 1)
+
+
+class _BiLSTMLayerFused(torch.autograd.Function):
+    """_BiLSTMLayer with its dense products in this library's launches (csrc/lstm.hip): the input projection of both directions
+    in ONE fp32-MFMA launch whose operand load IS the embedding lookup when ``ids`` is given (src = the table, ids (B, T) node ids;
+    else src = the dense input (B, T, I)); backward: the recurrence, ONE launch for the block partials of every weight and bias
+    gradient of both directions + one reduction (ops.contract_rows_many), one launch for dx -- which, for a lookup, joins the
+    step's combined table-gradient scatter.  3 + 2 launches forward -> 2, ~20 backward -> 4."""
+
+    @staticmethod
+    def forward(ctx, src, ids, presorted, w_ih_f, w_hh_f, b_ih_f, b_hh_f, w_ih_r, w_hh_r, b_ih_r, b_hh_r):
+        lib = _lib.load()
+        for t, nm in ((src, 'input'), (w_ih_f, 'weight_ih'), (w_hh_f, 'weight_hh'), (b_ih_f, 'bias_ih'), (b_hh_f, 'bias_hh'),
+                      (w_ih_r, 'weight_ih_reverse'), (w_hh_r, 'weight_hh_reverse'), (b_ih_r, 'bias_ih_reverse'), (b_hh_r, 'bias_hh_reverse')):
+            _req(t, torch.float32, nm)
+        gather = ids is not None
+        if gather:
+            _req(ids, torch.int64, 'ids')
+            B, T = ids.shape
+            I = src.shape[1]
+        else:
+            B, T, I = src.shape
+        H = w_hh_f.shape[1]
+        R = B * T
+        dev = src.device
+        pre_x = torch.empty((2, R, 4 * H), dtype=torch.float32, device=dev)
+        x2 = torch.empty((R, I), dtype=torch.float32, device=dev) if gather else src.view(R, I)
+        check(lib.sgnn_rows_gemm(_ptr(src), _ptr(ids), I, R, I, _ptr(w_ih_f), _ptr(w_ih_r), _ptr(b_ih_f), _ptr(b_ih_r), 4 * H, _ptr(pre_x),
+                                 _ptr(x2) if gather else None, _stream()), 'sgnn_rows_gemm')
+        y = torch.empty((B, T, 2 * H), dtype=torch.float32, device=dev)
+        gates = torch.empty((2, B, T, 4 * H), dtype=torch.float32, device=dev)
+        cell = torch.empty((2, B, T, H), dtype=torch.float32, device=dev)
+        hprev = torch.empty((2, B, T, H), dtype=torch.float32, device=dev)
+        check(lib.sgnn_lstm_fwd(_ptr(pre_x), _ptr(w_hh_f), _ptr(w_hh_r), _ptr(b_hh_f), _ptr(b_hh_r), B, T, H, _ptr(y), _ptr(gates),
+                                _ptr(cell), _ptr(hprev), _stream()), 'sgnn_lstm_fwd')
+        ctx.save_for_backward(x2, ids, w_ih_f, w_ih_r, w_hh_f, w_hh_r, gates, cell, hprev)
+        ctx.dims = (B, T, I, H)
+        ctx.gather, ctx.presorted = gather, presorted
+        ctx.acc = getattr(src, '_sgnn_acc', None) if gather else None
+        ctx.n_rows = src.shape[0] if gather else 0
+        ctx.det = _det_now()
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x2, ids, w_ih_f, w_ih_r, w_hh_f, w_hh_r, gates, cell, hprev = ctx.saved_tensors
+        B, T, I, H = ctx.dims
+        R = B * T
+        dy = dy.contiguous()
+        dgates = torch.empty_like(gates)
+        check(lib.sgnn_lstm_bwd(_ptr(w_hh_f), _ptr(w_hh_r), _ptr(gates), _ptr(cell), _ptr(dy), B, T, H, _ptr(dgates), _stream()),
+              'sgnn_lstm_bwd')
+        dg = dgates.view(2, R, 4 * H)
+        hp = hprev.view(2, R, H)
+        ones = _ones_column(R, dy.device)
+        # every weight and bias gradient of both directions: block partials in one launch, one reduction.  (bias_ih and bias_hh
+        # receive the same VALUES in DIFFERENT memory: an in-place multi-tensor update of the gradient list must not meet one
+        # buffer twice -- ops._BiLSTMLayer's note.)
+        dwih_f, dwih_r, dwhh_f, dwhh_r, dbi_f, dbi_r, dbh_f, dbh_r = contract_rows_many(
+            [(dg[0], x2), (dg[1], x2), (dg[0], hp[0]), (dg[1], hp[1]), (dg[0], ones), (dg[1], ones), (dg[0], ones), (dg[1], ones)])
+        g_src = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty((R, I), dtype=torch.float32, device=dy.device)
+            check(lib.sgnn_rows_gemm_nt(_ptr(dgates), R, 4 * H, _ptr(w_ih_f), _ptr(w_ih_r), I, _ptr(dx), _stream()), 'sgnn_rows_gemm_nt')
+            if not ctx.gather:
+                g_src = dx.view(B, T, I)
+            else:
+                flat = ids.reshape(-1)
+                if ctx.det and I <= 256:
+                    buf = ctx.acc.buffer((ctx.n_rows, I), dy.device) if ctx.acc is not None else \
+                        torch.zeros(ctx.n_rows, I, dtype=torch.float32, device=dy.device)
+                    pre = ctx.presorted
+                    if pre is not None and pre[0].numel() == flat.numel():
+                        scatter_add_rows(buf, pre[2], G=dx, edges_per_row=1, presorted=pre[:2], together=ctx.acc)
+                    else:
+                        scatter_add_rows(buf, flat.to(torch.int32).contiguous(), G=dx, edges_per_row=1, together=ctx.acc)   # key 0 = PAD: skipped
+                    g_src = None if ctx.acc is not None else buf
+                else:
+                    dxm = dx * (flat != 0).unsqueeze(1).to(dx.dtype)                       # PAD row takes no gradient
+                    if ctx.acc is not None:
+                        ctx.acc.buffer((ctx.n_rows, I), dy.device).index_add_(0, flat, dxm)
+                    else:
+                        g_src = torch.zeros(ctx.n_rows, I, dtype=torch.float32, device=dy.device).index_add_(0, flat, dxm)
+        return (g_src, None, None, dwih_f, dwhh_f, dbi_f.view(-1), dbh_f.view(-1), dwih_r, dwhh_r, dbi_r.view(-1), dbh_r.view(-1))
+
+
+class _LSTMTail(torch.autograd.Function):
+    """X (n, D) = sum over a patch's n_walks sequences of Linear(last step | sum over steps) (SubGNN.py:60-88 + aps:413-433's sum):
+    one launch each way (sgnn_lstm_tail_fwd / _bwd) instead of the slice, the Linear's GEMM and the sum -- and, backward, the
+    zero-filled gradient of the slice, its copy, the Linear's three products and the expansion of the sum."""
+
+    @staticmethod
+    def forward(ctx, y, W_lin, b_lin, n_walks, last_only):
+        lib = _lib.load()
+        for t, nm in ((y, 'y'), (W_lin, 'linear.weight'), (b_lin, 'linear.bias')):
+            _req(t, torch.float32, nm)
+        Bq, T, H2 = y.shape
+        n = Bq // n_walks
+        D = W_lin.shape[0]
+        s = torch.empty((n, H2), dtype=torch.float32, device=y.device)
+        X = torch.empty((n, D), dtype=torch.float32, device=y.device)
+        check(lib.sgnn_lstm_tail_fwd(_ptr(y), n, n_walks, T, H2, 1 if last_only else 0, _ptr(W_lin), _ptr(b_lin), D, _ptr(s), _ptr(X),
+                                     _stream()), 'sgnn_lstm_tail_fwd')
+        ctx.save_for_backward(s, W_lin)
+        ctx.dims = (n, n_walks, T, H2, D, bool(last_only), b_lin is not None)
+        return X
+
+    @staticmethod
+    def backward(ctx, dX):
+        lib = _lib.load()
+        s, W_lin = ctx.saved_tensors
+        n, n_walks, T, H2, D, last_only, has_bias = ctx.dims
+        dX = dX.contiguous()
+        dy = torch.empty((n * n_walks, T, H2), dtype=torch.float32, device=dX.device)
+        dW = torch.empty_like(W_lin) if ctx.needs_input_grad[1] else None
+        db = torch.empty(D, dtype=torch.float32, device=dX.device) if (has_bias and ctx.needs_input_grad[2]) else None
+        check(lib.sgnn_lstm_tail_bwd(_ptr(dX), _ptr(s), n, n_walks, T, H2, 1 if last_only else 0, _ptr(W_lin), D, _ptr(dy), _ptr(dW),
+                                     _ptr(db), _stream()), 'sgnn_lstm_tail_bwd')
+        return dy, dW, db, None, None
+
+
+def bilstm_layer_fused(src, params, ids=None):
+    """One bidirectional LSTM layer, dense products included (``_BiLSTMLayerFused``).  ``ids`` (B, T) int64: ``src`` is the
+    embedding table and the layer's input is its rows ``ids`` (PAD = row 0); else ``src`` is the dense input (B, T, I)."""
+    pre = getattr(ids, '_sgnn_sorted', None) if ids is not None else None
+    return _BiLSTMLayerFused.apply(src if ids is not None else src.contiguous(), ids.contiguous() if ids is not None else None, pre,
+                                   *[p.contiguous() for p in params])
+
+
+def lstm_tail(y, weight, bias, n_walks, last_only=True):
+    return _LSTMTail.apply(y.contiguous(), weight, bias, int(n_walks), bool(last_only))
+
+
+def lstm_fused_supported(input_size, hidden_size):
+    """The fused products need K % 8 == 0 on the input side (and the recurrence kernel's hidden sizes)."""
+    return lstm_supported(input_size, hidden_size) and int(input_size) % 8 == 0 and int(hidden_size) % 2 == 0
 
 
 def lstm_supported(input_size, hidden_size):

@@ -236,6 +236,7 @@ def time_epochs(model, hp, epochs=4):
             'per_epoch': {k: later[-1].get(k) for k in ('replayed_steps', 'eager_steps', 'validation_batches')},
             'recordings_after_the_first_epoch': sum(r.get('recordings', 0) for r in later),
             'resample_anchor_patches': bool(hp.get('resample_anchor_patches', False)),
+            'every_epoch_ms': [{k[:-2]: round(1e3 * r.get(k, 0.0), 2) for k in keys} for r in tr.phase_times],
             'monitor_last': tr.history[-1] if tr.history else None}
 
 

@@ -1319,3 +1319,59 @@ def test_readout_pieces_with_scores_in_kernel(B, C):
         assert_close(a, b, 'gradient of leaf %d' % i, norm_tol=1e-5)
     out_c, g_c = run(True)
     assert torch.equal(out_a, out_c) and all(torch.equal(a, b) for a, b in zip(g_a, g_c))
+
+
+@pytest.mark.parametrize('layers,agg,D,W', [(1, 'last', 64, 5), (2, 'last', 128, 5), (2, 'sum', 32, 3), (1, 'sum', 64, 1)])
+def test_walk_aggregator_in_library_launches_matches_float64(layers, agg, D, W):
+    """aps.aggregate_structure_anchor_patch (aps:413-433) through LSTM.forward_walks -- the embedding lookup as the operand load of
+    the first layer's input projection (sgnn_rows_gemm), weight / bias gradients of both directions as jobs of ONE contraction
+    launch, dx by sgnn_rows_gemm_nt into the table's combined scatter, the tail (last step or sum, Linear, sum over a patch's
+    walks) one launch each way -- against the same module in float64 on the CPU: the anchor embeddings, the gradient of the
+    table (PAD row untouched, rows of repeated ids accumulated) and of every LSTM / Linear parameter; bias gradients in separate
+    memory; and the unfused route (hparams['fused_forward'] = False) gives the same embeddings."""
+    import copy
+    from subgnn_amd.SubGNN import LSTM
+    from subgnn_amd import anchor_patch_samplers as aps
+    ops = _ops()
+    torch.manual_seed(layers * 10 + D)
+    n, T, N = 21, 7, 300
+    m = LSTM(D, D, dropout=0.0, num_layers=layers, aggregator=agg).to(DEV)
+    g = torch.Generator().manual_seed(W + D)
+    table = torch.randn(N + 1, D, generator=g) * 0.5
+    table[0] = 0
+    walks = torch.randint(0, N + 1, (n, W, T), generator=g)
+    walks[0, 0, 3:] = 0                                             # PAD steps
+    walks[1] = walks[2]                                             # repeated ids: their rows' gradients add up
+    hp = {'n_triangular_walks': W, 'random_walk_len': T, 'node_embed_size': D, 'fused_forward': True}
+    go = torch.randn(n, D, generator=g)
+
+    class Emb:                                                      # (node_matrix: only .weight is read)
+        pass
+    E = table.to(DEV).requires_grad_(True)
+    emb = Emb()
+    emb.weight = E
+    tapped = ops.tap_table(E)
+    wd = walks.to(DEV)
+    ops.presort_ids(wd, N)
+    X = aps.aggregate_structure_anchor_patch(hp, None, m, emb, wd, wd, None, torch.device(DEV), table=tapped)
+    (X * go.to(DEV)).sum().backward()
+    r = copy.deepcopy(m).cpu().double()
+    Er = table.double().requires_grad_(True)
+    xr = Er[walks.view(n * W, T)]
+    out, _ = r.lstm(xr)
+    Xr = r.linear(out[:, -1, :] if agg == 'last' else out.sum(dim=1)).view(n, W, -1).sum(1)
+    (Xr * go.double()).sum().backward()
+    assert_close(X, Xr, 'anchor embeddings')
+    assert float(E.grad[0].abs().max()) == 0.0                     # PAD row
+    gref = Er.grad.clone()
+    gref[0] = 0
+    assert_close(E.grad, gref, 'd table', norm_tol=1e-5)
+    named = dict(m.named_parameters())
+    for nm, q in r.named_parameters():
+        assert_close(named[nm].grad, q.grad, 'd ' + nm, norm_tol=2e-5)
+    biases = [k for k in named if 'bias' in k and k.startswith('lstm.')]
+    spans = sorted((named[k].grad.data_ptr(), named[k].grad.data_ptr() + named[k].grad.numel() * 4) for k in biases)
+    assert all(a[1] <= b[0] for a, b in zip(spans[:-1], spans[1:])), 'bias gradients overlap in memory'
+    with torch.no_grad():
+        X2 = aps.aggregate_structure_anchor_patch(dict(hp, fused_forward=False), None, m, emb, wd, wd, None, torch.device(DEV), table=E.detach())
+    assert_close(X2, X.detach(), 'unfused route', norm_tol=1e-5)

@@ -49,6 +49,15 @@ def test_captured_step_matches_eager(tiny, tmp_path, resample):
     for k in sd0:
         a, b = sd0[k].float(), sd1[k].float()
         assert torch.allclose(a, b, rtol=1e-5, atol=1e-5), (k, (a - b).abs().max())
+    # the validation epochs: the recorded forward (graph_step.CapturedEvalStep: every batch one replay, the short last batch padded,
+    # one transfer per epoch, metrics on the host copies) reports what the eager validation steps report
+    assert t1.__dict__.get('_captured_eval') is not None and t1._captured_eval.graph is not None
+    assert len(m0.metric_scores) == len(m1.metric_scores) == 7
+    for e0, e1 in zip(m0.metric_scores, m1.metric_scores):
+        assert e0.keys() == e1.keys()
+        for k in e0:
+            a, b = float(e0[k]), float(e1[k])
+            assert (a != a and b != b) or abs(a - b) <= 2e-5 * max(1.0, abs(a)), (k, a, b)
 
 
 def test_captured_step_rejects_other_batch_size(tiny, tmp_path):

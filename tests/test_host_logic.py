@@ -356,3 +356,28 @@ def test_kernel_count_is_none_without_a_device():
     from subgnn_amd import standins
     if not torch.cuda.is_available():
         assert standins.count_kernels(lambda: None) is None
+
+
+def test_f1_from_predictions_is_sklearns_f1_score():
+    """su.calc_f1 evaluates micro / macro F1 from the confusion counts (subgraph_utils.f1_from_predictions) instead of calling
+    sklearn per validation batch: same values, including the classes-without-predictions case sklearn warns about."""
+    import warnings
+    from sklearn.metrics import f1_score
+    from subgnn_amd.subgraph_utils import f1_from_predictions, calc_f1
+    rng = np.random.default_rng(0)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        for trial in range(120):
+            n, K = int(rng.integers(1, 80)), int(rng.integers(2, 8))
+            yt = rng.integers(0, K, n)
+            yp = rng.integers(0, K, n) if trial % 3 else rng.integers(0, 2, n)
+            Yt = rng.integers(0, 2, (n, K))
+            Yp = rng.integers(0, 2, (n, K)) if trial % 4 else np.zeros((n, K), dtype=np.int64)
+            for avg in ('micro', 'macro'):
+                assert abs(f1_from_predictions(yt, yp, avg) - f1_score(yt, yp, average=avg)) < 1e-12
+                assert abs(f1_from_predictions(Yt, Yp, avg) - f1_score(Yt, Yp, average=avg)) < 1e-12
+        logits = torch.randn(40, 5, generator=torch.Generator().manual_seed(1))
+        labels = torch.randint(0, 5, (40,), generator=torch.Generator().manual_seed(2))
+        for avg in ('micro', 'macro'):
+            got = calc_f1(logits, labels, avg)
+            assert got.dtype == torch.float32 and abs(float(got) - f1_score(labels, logits.argmax(1), average=avg)) < 1e-6

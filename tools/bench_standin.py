@@ -40,10 +40,11 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--atomics', action='store_true', help="hparams['deterministic'] = False: float atomics in the backward pass")
     ap.add_argument('--no-count', action='store_true', help='skip the kernels-per-step count (torch profiler)')
+    ap.add_argument('--epochs', type=int, default=0, help='also time this many whole epochs (train_config.Trainer)')
     args = ap.parse_args()
     from subgnn_amd.standins import bench_config
     print(json.dumps(bench_config(args.config, args.steps, args.warmup, deterministic=not args.atomics, count=not args.no_count,
-                                  also_atomics=not args.atomics)))
+                                  also_atomics=not args.atomics and not args.epochs, epochs=args.epochs)))
 
 
 if __name__ == '__main__':
