@@ -686,6 +686,12 @@ def main():
     second_pass_ms = priming_ms[1] - priming_ms[0]
     for _ in range(args.warmup):
         step(False)
+    # the process holds millions of small Python objects by now (50k subgraph lists, the CSR's numpy views ...): a generation-2
+    # collection in the middle of a timed region is a 40-60 ms pause (seen in the stand-ins' epoch timings: 29 / 92 / 41 ms for
+    # identical epochs).  Everything alive here stays alive: moved out of the collector's sight
+    import gc
+    gc.collect()
+    gc.freeze()
     torch.cuda.synchronize()
     if dist:
         dist.barrier()

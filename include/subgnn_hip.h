@@ -810,16 +810,17 @@ int sgnn_head_bwd(const float* logits, const float* lse, const int64_t* labels, 
 /* A^T B for tall operands (the weight gradients of Linear / LSTM layers: outputs of a few thousand elements contracted over
  * thousands of rows -- a library GEMM runs them on a handful of workgroups): job k contracts A[k] (R[k], M[k]) with B[k]
  * (R[k], N[k]), row strides lda / ldb floats, over blocks of rows on the matrix cores (fp32 MFMA, fp32 accumulate) and writes
- * part[k] = (sgnn_contract_rows_blocks(R[k]), M[k], N[k]) block partials; sgnn_reduce_partials adds them in block order (a fixed
- * order: bit-reproducible).  Up to sgnn_contract_rows_max_jobs() jobs per launch.  All arrays are HOST arrays (of DEVICE
+ * part[k] = (sgnn_contract_rows_blocks(R[k], M[k], N[k]), M[k], N[k]) block partials; sgnn_reduce_partials adds them in block order (a fixed
+ * order: bit-reproducible).  colsum_part (nullable; entries nullable): job k also writes (blocks, M[k]) partial COLUMN SUMS of A[k]
+ * (a bias gradient rides along with its weight's).  Up to sgnn_contract_rows_max_jobs() jobs per launch.  All arrays are HOST arrays (of DEVICE
  * pointers where they hold pointers).
  * sgnn_reduce_partials: out[k][j] = sum_b part[k][b * n[k] + j] over n_blocks[k] blocks, up to sgnn_reduce_partials_max_jobs()
  * jobs per launch. */
 int64_t sgnn_contract_rows_max_jobs(void);
-int64_t sgnn_contract_rows_blocks(int64_t R);
+int64_t sgnn_contract_rows_blocks(int64_t R, int64_t M, int64_t N);
 int sgnn_contract_rows_partial(int64_t n_jobs, const float* const* A, const float* const* B, const int64_t* lda,
                                const int64_t* ldb, const int64_t* M, const int64_t* N, const int64_t* R,
-                               float* const* part, void* stream);
+                               float* const* part, float* const* colsum_part, void* stream);
 int64_t sgnn_reduce_partials_max_jobs(void);
 int sgnn_reduce_partials(int64_t n_jobs, const float* const* part, const int64_t* n_blocks, const int64_t* n,
                          float* const* out, void* stream);

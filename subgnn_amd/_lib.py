@@ -138,8 +138,8 @@ SIGNATURES = {
     'sgnn_head_bwd': (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_i64,
                               ctypes.c_float, c_ptr, c_ptr, c_ptr]),
     'sgnn_contract_rows_max_jobs': (c_i64, []),
-    'sgnn_contract_rows_blocks': (c_i64, [c_i64]),
-    'sgnn_contract_rows_partial': (c_int, [c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
+    'sgnn_contract_rows_blocks': (c_i64, [c_i64, c_i64, c_i64]),
+    'sgnn_contract_rows_partial': (c_int, [c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
     'sgnn_reduce_partials_max_jobs': (c_i64, []),
     'sgnn_reduce_partials': (c_int, [c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
     'sgnn_probe_stream_copy': (c_int, [c_ptr, c_ptr, c_i64, c_int, c_ptr]),

@@ -354,6 +354,7 @@ __global__ __launch_bounds__(HEAD_THREADS) void head_bwd_kernel(const HeadBwd A)
 typedef float cr_f32x16 __attribute__((ext_vector_type(16)));
 struct CrJobs {
     const float* A[CR_MAX_JOBS]; const float* Bm[CR_MAX_JOBS]; float* part[CR_MAX_JOBS];
+    float* colsum[CR_MAX_JOBS];          // nullable: (blocks, M) partial column sums of A (a bias gradient rides along with its weight's)
     long long lda[CR_MAX_JOBS], ldb[CR_MAX_JOBS], R[CR_MAX_JOBS];
     int M[CR_MAX_JOBS], N[CR_MAX_JOBS], wr[CR_MAX_JOBS];
 };
@@ -383,6 +384,7 @@ __global__ __launch_bounds__(256) void contract_rows_partial_kernel(const CrJobs
     for (int c = 0; c < CR_NT; ++c)
 #pragma unroll
         for (int v = 0; v < 16; ++v) acc[c][v] = 0.f;
+    float bsum = 0.f;                                        // column sum of A over this wavefront's rows (used by n-group 0 only)
     for (int64_t rb = r0; rb < r_end; rb += 2 * CR_STEPS) {
         float av[CR_STEPS], bv[CR_STEPS][CR_NT];
 #pragma unroll
@@ -397,10 +399,14 @@ __global__ __launch_bounds__(256) void contract_rows_partial_kernel(const CrJobs
             }
         }
 #pragma unroll
-        for (int u = 0; u < CR_STEPS; ++u)
+        for (int u = 0; u < CR_STEPS; ++u) {
+            bsum += av[u];
 #pragma unroll
             for (int c = 0; c < CR_NT; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u][c], acc[c], 0, 0, 0);
+        }
     }
+    bsum += __shfl_xor(bsum, 32, 64);                        // the two row halves
+    __shared__ float s_b[64];
     for (int w = 0; w < 4; ++w) {
         if (wave == w) {
 #pragma unroll
@@ -411,10 +417,13 @@ __global__ __launch_bounds__(256) void contract_rows_partial_kernel(const CrJobs
                     if (w > 0) acc[c][v] += s_acc[idx];
                     if (w < 3) s_acc[idx] = acc[c][v];
                 }
+            if (w > 0) bsum += s_b[lane];
+            if (w < 3) s_b[lane] = bsum;
         }
         __syncthreads();
     }
     if (wave != 3) return;
+    if (J.colsum[z] && ng == 0 && h == 0 && m_ok) J.colsum[z][(int64_t)blockIdx.x * M + m] = bsum;
     float* __restrict__ dst = J.part[z] + (int64_t)blockIdx.x * M * N;
 #pragma unroll
     for (int c = 0; c < CR_NT; ++c) {
@@ -536,15 +545,30 @@ extern "C" int sgnn_head_bwd(const float* logits, const float* lse, const int64_
     return SGNN_OK;
 }
 
-// rows per wavefront of the contraction: long calls take long blocks (fewer partials to write and add)
-static inline int cr_wave_rows(int64_t R) { return R >= 4096 ? 64 : 16; }
+// rows per wavefront of a job: enough row blocks that blocks x output tiles fill the chip twice (~512 workgroups), no more -- every
+// block writes an M x N partial that the reduction reads back (a 512 x 128 output over 3 700 rows in 64-row blocks was 58
+// partials of 256 KB: 15 MB written and read for a 1 MB result) -- and at most 128 rows (16 a multiple: the step of the loop)
+static inline int cr_wave_rows(int64_t R, int64_t M, int64_t N)
+{
+    const int64_t tiles = ((M + 31) / 32) * ((((N + 31) / 32) + CR_NT - 1) / CR_NT);
+    int64_t blocks = 512 / (tiles < 1 ? 1 : tiles);
+    if (blocks < 1) blocks = 1;
+    int64_t wr = (R + 4 * blocks - 1) / (4 * blocks);
+    wr = (wr + 15) / 16 * 16;
+    return (int)(wr < 16 ? 16 : (wr > 128 ? 128 : wr));
+}
 
 extern "C" int64_t sgnn_contract_rows_max_jobs(void) { return CR_MAX_JOBS; }
-extern "C" int64_t sgnn_contract_rows_blocks(int64_t R) { return R < 0 ? -1 : (R + 4 * cr_wave_rows(R) - 1) / (4 * cr_wave_rows(R)); }
+extern "C" int64_t sgnn_contract_rows_blocks(int64_t R, int64_t M, int64_t N)
+{
+    if (R < 0 || M < 1 || N < 1) return -1;
+    const int64_t per = 4 * cr_wave_rows(R, M, N);
+    return (R + per - 1) / per;
+}
 
 extern "C" int sgnn_contract_rows_partial(int64_t n_jobs, const float* const* A, const float* const* Bm, const int64_t* lda,
                                           const int64_t* ldb, const int64_t* M, const int64_t* N, const int64_t* R,
-                                          float* const* part, void* stream)
+                                          float* const* part, float* const* colsum_part, void* stream)
 {
     if (n_jobs < 1 || n_jobs > CR_MAX_JOBS || !A || !Bm || !lda || !ldb || !M || !N || !R || !part) return SGNN_ERR_BAD_ARG;
     CrJobs J;
@@ -553,14 +577,15 @@ extern "C" int sgnn_contract_rows_partial(int64_t n_jobs, const float* const* A,
         if (!A[k] || !Bm[k] || !part[k] || M[k] < 1 || N[k] < 1 || M[k] > (1 << 20) || N[k] > (1 << 20) || R[k] < 0 || lda[k] < M[k] || ldb[k] < N[k])
             return SGNN_ERR_BAD_ARG;
         J.A[k] = A[k]; J.Bm[k] = Bm[k]; J.part[k] = part[k]; J.lda[k] = lda[k]; J.ldb[k] = ldb[k]; J.R[k] = R[k];
-        J.M[k] = (int)M[k]; J.N[k] = (int)N[k]; J.wr[k] = cr_wave_rows(R[k]);
-        const int64_t nb = sgnn_contract_rows_blocks(R[k]);
+        J.colsum[k] = colsum_part ? colsum_part[k] : nullptr;
+        J.M[k] = (int)M[k]; J.N[k] = (int)N[k]; J.wr[k] = cr_wave_rows(R[k], M[k], N[k]);
+        const int64_t nb = sgnn_contract_rows_blocks(R[k], M[k], N[k]);
         const int64_t tiles = ((M[k] + 31) / 32) * ((((N[k] + 31) / 32) + CR_NT - 1) / CR_NT);
         if (nb > 0x7fffffff || tiles > 65535) return SGNN_ERR_BAD_ARG;
         if ((unsigned)nb > gx) gx = (unsigned)nb;
         if ((unsigned)tiles > gy) gy = (unsigned)tiles;
     }
-    for (int k = (int)n_jobs; k < CR_MAX_JOBS; ++k) { J.A[k] = J.Bm[k] = nullptr; J.part[k] = nullptr; J.lda[k] = J.ldb[k] = J.R[k] = 0; J.M[k] = J.N[k] = 0; J.wr[k] = 16; }
+    for (int k = (int)n_jobs; k < CR_MAX_JOBS; ++k) { J.A[k] = J.Bm[k] = nullptr; J.part[k] = nullptr; J.colsum[k] = nullptr; J.lda[k] = J.ldb[k] = J.R[k] = 0; J.M[k] = J.N[k] = 0; J.wr[k] = 16; }
     if (gx == 0) return SGNN_OK;
     hipLaunchKernelGGL(contract_rows_partial_kernel, dim3(gx, gy, (unsigned)n_jobs), dim3(256), 0, (hipStream_t)stream, J);
     SGNN_CHECK_LAUNCH();

@@ -338,19 +338,78 @@ __global__ __launch_bounds__(64) void rows_gemm_kernel(const float* __restrict__
     }
 }
 
-// dx[r][n] = sum over z of sum_k A_z[r][k] W_z[k][n]; A_z = A + z * R * K (direction-major gate gradients), W_z (K, N) row-major
-__global__ __launch_bounds__(64) void rows_gemm_nt_kernel(const float* __restrict__ A, int64_t R, int K, const float* __restrict__ W0,
-                                                          const float* __restrict__ W1, int N, float* __restrict__ out)
+// The same product with a tile's contraction split over the four wavefronts of a workgroup (K % 32 == 0; used from K = 128 on: a
+// single wavefront walking K / 2 = 64-128 dependent MFMA + load steps ran the second LSTM layer's projection -- K = 2 H = 256 --
+// at a fifth of the matrix cores' rate); partial tiles added in wavefront order through LDS.
+__global__ __launch_bounds__(256) void rows_gemm_ksplit_kernel(const float* __restrict__ X, const int64_t* __restrict__ ids, int64_t ldx,
+                                                               int64_t R, int K, const float* __restrict__ W0, const float* __restrict__ W1,
+                                                               const float* __restrict__ b0, const float* __restrict__ b1, int N,
+                                                               float* __restrict__ out, float* __restrict__ xcopy)
 {
-    const int lane = threadIdx.x, i = lane & 31, h = lane >> 5, nt = blockIdx.y;
+    __shared__ float s_part[3 * 16 * 64];
+    const int lane = threadIdx.x & 63, i = lane & 31, h = lane >> 5, z = blockIdx.z, nt = blockIdx.y;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t row0 = (int64_t)blockIdx.x * 32;
     const int64_t r = row0 + i < R ? row0 + i : R - 1;
-    const int Kh = K / 2;
+    const int64_t src_row = ids ? ids[r] : r;
+    const int Kq = K / 8, k0 = wave * (K / 4) + h * Kq;              // positions per (wavefront, k-half); K / 8 is a multiple of 4
+    const float* __restrict__ src = X + src_row * ldx + k0;
+    const int n = nt * 32 + i;
+    const float* __restrict__ wrow = (z ? W1 : W0) + (int64_t)(n < N ? n : N - 1) * K + k0;
+    lstm_f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const bool copy = xcopy && nt == 0 && z == 0 && row0 + i < R;
+    for (int kc = 0; kc < Kq; kc += LSTM_KC) {
+        float a[LSTM_KC], w[LSTM_KC];
+#pragma unroll
+        for (int c = 0; c < LSTM_KC / 4; ++c) {
+            float4 av = make_float4(0.f, 0.f, 0.f, 0.f), wv = av;
+            if (kc + 4 * c < Kq) {
+                av = *reinterpret_cast<const float4*>(src + kc + 4 * c);
+                wv = *reinterpret_cast<const float4*>(wrow + kc + 4 * c);
+                if (copy) *reinterpret_cast<float4*>(xcopy + (row0 + i) * K + k0 + kc + 4 * c) = av;
+            }
+            a[4 * c] = av.x; a[4 * c + 1] = av.y; a[4 * c + 2] = av.z; a[4 * c + 3] = av.w;
+            w[4 * c] = wv.x; w[4 * c + 1] = wv.y; w[4 * c + 2] = wv.z; w[4 * c + 3] = wv.w;
+        }
+#pragma unroll
+        for (int s = 0; s < LSTM_KC; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], w[s], acc, 0, 0, 0);
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int v = 0; v < 16; ++v) s_part[((wave - 1) * 16 + v) * 64 + lane] = acc[v];
+    }
+    __syncthreads();
+    if (wave != 0 || n >= N) return;
+    const float* __restrict__ b = z ? b1 : b0;
+    const float bias = b ? b[n] : 0.f;
+    float* __restrict__ dst = out + (int64_t)z * R * N;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+        const float sum = ((acc[v] + s_part[v * 64 + lane]) + s_part[(16 + v) * 64 + lane]) + s_part[(32 + v) * 64 + lane];
+        const int64_t rr = row0 + lstm_acc_row(v, h);
+        if (rr < R) dst[rr * N + n] = sum + bias;
+    }
+}
+
+// dx[r][n] = sum over z of sum_k A_z[r][k] W_z[k][n]; A_z = A + z * R * K (direction-major gate gradients), W_z (K, N) row-major.
+// A workgroup of four wavefronts per (32 rows, 32 columns): wavefront w contracts direction w / 2, half w % 2 of its K positions
+// (a tile's 2 K = 512-1024 positions walked by ONE wavefront were a chain of that many dependent MFMA + load steps on a few
+// hundred wavefronts: 35 us for 3 700 rows); the four partial tiles are added in wavefront order through LDS (a fixed order).
+__global__ __launch_bounds__(256) void rows_gemm_nt_kernel(const float* __restrict__ A, int64_t R, int K, const float* __restrict__ W0,
+                                                           const float* __restrict__ W1, int N, float* __restrict__ out)
+{
+    __shared__ float s_part[3 * 16 * 64];
+    const int lane = threadIdx.x & 63, i = lane & 31, h = lane >> 5, nt = blockIdx.y;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t row0 = (int64_t)blockIdx.x * 32;
+    const int64_t r = row0 + i < R ? row0 + i : R - 1;
+    const int Kh = K / 4;                                   // positions per (wavefront, k-half)
     const int n = nt * 32 + i, nn = n < N ? n : N - 1;
     lstm_f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int z = 0; z < 2; ++z) {
-        const float* __restrict__ arow = A + ((int64_t)z * R + r) * K + h * Kh;
-        const float* __restrict__ wcol = (z ? W1 : W0) + (int64_t)(h * Kh) * N + nn;
+    {
+        const int z = wave >> 1, k0 = (wave & 1) * (K / 2) + h * Kh;
+        const float* __restrict__ arow = A + ((int64_t)z * R + r) * K + k0;
+        const float* __restrict__ wcol = (z ? W1 : W0) + (int64_t)k0 * N + nn;
         for (int kc = 0; kc < Kh; kc += LSTM_KC) {
             float a[LSTM_KC], w[LSTM_KC];
 #pragma unroll
@@ -365,11 +424,17 @@ __global__ __launch_bounds__(64) void rows_gemm_nt_kernel(const float* __restric
             for (int s = 0; s < LSTM_KC; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], w[s], acc, 0, 0, 0);
         }
     }
-    if (n >= N) return;
+    if (wave > 0) {
+#pragma unroll
+        for (int v = 0; v < 16; ++v) s_part[((wave - 1) * 16 + v) * 64 + lane] = acc[v];
+    }
+    __syncthreads();
+    if (wave != 0 || n >= N) return;
 #pragma unroll
     for (int v = 0; v < 16; ++v) {
+        const float sum = ((acc[v] + s_part[v * 64 + lane]) + s_part[(16 + v) * 64 + lane]) + s_part[(32 + v) * 64 + lane];
         const int64_t rr = row0 + lstm_acc_row(v, h);
-        if (rr < R) out[rr * N + n] = acc[v];
+        if (rr < R) out[rr * N + n] = sum;
     }
 }
 
@@ -446,8 +511,13 @@ extern "C" int sgnn_rows_gemm(const float* X, const int64_t* ids, int64_t ldx, i
     if (!X || !W0 || !out || R < 0 || K < 8 || K % 8 != 0 || N < 1 || ldx < K || ldx % 4 != 0) return SGNN_ERR_BAD_ARG;
     if (R == 0) return SGNN_OK;
     if ((R + 31) / 32 > 0x7fffffff || (N + 31) / 32 > 65535) return SGNN_ERR_BAD_ARG;
-    hipLaunchKernelGGL(rows_gemm_kernel, dim3((unsigned)((R + 31) / 32), (unsigned)((N + 31) / 32), W1 ? 2u : 1u), dim3(64), 0,
-                       (hipStream_t)stream, X, ids, ldx, R, (int)K, W0, W1, b0, b1, (int)N, out, x_copy);
+    const dim3 grid((unsigned)((R + 31) / 32), (unsigned)((N + 31) / 32), W1 ? 2u : 1u);
+    if (K >= 128 && K % 32 == 0)
+        hipLaunchKernelGGL(rows_gemm_ksplit_kernel, grid, dim3(256), 0, (hipStream_t)stream, X, ids, ldx, R, (int)K, W0, W1, b0, b1, (int)N,
+                           out, x_copy);
+    else
+        hipLaunchKernelGGL(rows_gemm_kernel, grid, dim3(64), 0, (hipStream_t)stream, X, ids, ldx, R, (int)K, W0, W1, b0, b1, (int)N, out,
+                           x_copy);
     SGNN_CHECK_LAUNCH();
     return SGNN_OK;
 }
@@ -455,10 +525,10 @@ extern "C" int sgnn_rows_gemm(const float* X, const int64_t* ids, int64_t ldx, i
 extern "C" int sgnn_rows_gemm_nt(const float* A, int64_t R, int64_t K, const float* W0, const float* W1, int64_t N, float* out,
                                  void* stream)
 {
-    if (!A || !W0 || !W1 || !out || R < 0 || K < 8 || K % 8 != 0 || N < 1) return SGNN_ERR_BAD_ARG;
+    if (!A || !W0 || !W1 || !out || R < 0 || K < 16 || K % 16 != 0 || N < 1) return SGNN_ERR_BAD_ARG;
     if (R == 0) return SGNN_OK;
     if ((R + 31) / 32 > 0x7fffffff || (N + 31) / 32 > 65535) return SGNN_ERR_BAD_ARG;
-    hipLaunchKernelGGL(rows_gemm_nt_kernel, dim3((unsigned)((R + 31) / 32), (unsigned)((N + 31) / 32)), dim3(64), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(rows_gemm_nt_kernel, dim3((unsigned)((R + 31) / 32), (unsigned)((N + 31) / 32)), dim3(256), 0, (hipStream_t)stream,
                        A, R, (int)K, W0, W1, (int)N, out);
     SGNN_CHECK_LAUNCH();
     return SGNN_OK;

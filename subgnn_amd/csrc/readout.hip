@@ -663,9 +663,12 @@ __global__ __launch_bounds__(256) void masked_sum_slot_bwd_kernel(const V* __res
     const int64_t total = B * C * Wv;
     for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
         const int64_t bc = t / Wv, h = t - bc * Wv;
-        V z;
-        if constexpr (sizeof(V) == 16) z = make_float4(0.f, 0.f, 0.f, 0.f); else z = 0.f;
-        gx[t] = mask[bc] ? g[(bc / C) * g_ldv + h] : z;
+        // (a select between a loaded float4 and a zero one went through a 32-byte scratch slot: the value is loaded or zeroed
+        // element by element instead)
+        V v;
+        if constexpr (sizeof(V) == 16) v = make_float4(0.f, 0.f, 0.f, 0.f); else v = 0.f;
+        if (mask[bc]) v = g[(bc / C) * g_ldv + h];
+        gx[t] = v;
     }
 }
 

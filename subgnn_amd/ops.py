@@ -2216,11 +2216,15 @@ def head_supported(H1, H2, K):
     return bool(_lib.load().sgnn_head_supported(int(H1), int(H2), int(K)))
 
 
-def contract_rows_many(pairs):
+def contract_rows_many(pairs, column_sums=()):
     """[a^T b for (a, b) in pairs] for tall row-major a (R, M), b (R, N) (row strides may exceed the widths): block partials on the
-    matrix cores in one launch per 8 pairs (sgnn_contract_rows_partial), added in block order by one sgnn_reduce_partials launch
-    per 8 -- bit-reproducible.  -> list of (M, N) tensors."""
+    matrix cores in one launch per group of pairs (sgnn_contract_rows_partial), added in block order by one sgnn_reduce_partials
+    launch -- bit-reproducible.  -> list of (M, N) tensors.  ``column_sums``: {pair index: k} -- pair i also yields k separate
+    copies of a.sum(0) (a Linear's bias gradient rides along with its weight's: no extra pass over a); they follow the products in
+    the returned list, in index order."""
     lib = _lib.load()
+    if column_sums:
+        return _contract_rows_with_sums(pairs, dict(column_sums))
     outs = []
     cap = min(int(lib.sgnn_contract_rows_max_jobs()), int(lib.sgnn_reduce_partials_max_jobs()))
     for lo in range(0, len(pairs), cap):
@@ -2234,19 +2238,53 @@ def contract_rows_many(pairs):
         N = np.array([b.shape[1] for _, b in group], dtype=np.int64)
         lda = np.array([a.stride(0) for a, _ in group], dtype=np.int64)
         ldb = np.array([b.stride(0) for _, b in group], dtype=np.int64)
-        nb = np.array([int(lib.sgnn_contract_rows_blocks(int(r))) for r in R], dtype=np.int64)
+        nb = np.array([int(lib.sgnn_contract_rows_blocks(int(r), int(m), int(n_))) for r, m, n_ in zip(R, M, N)], dtype=np.int64)
         dev = group[0][0].device
         parts = [torch.empty((int(nb[k]), int(M[k]), int(N[k])), dtype=torch.float32, device=dev) for k in range(len(group))]
         res = [torch.empty((int(M[k]), int(N[k])), dtype=torch.float32, device=dev) for k in range(len(group))]
         pa, pb, pp, po = (_ptr_table(v) for v in ([a for a, _ in group], [b for _, b in group], parts, res))
         check(lib.sgnn_contract_rows_partial(len(group), pa.ctypes.data, pb.ctypes.data, lda.ctypes.data, ldb.ctypes.data,
-                                             M.ctypes.data, N.ctypes.data, R.ctypes.data, pp.ctypes.data, _stream()),
+                                             M.ctypes.data, N.ctypes.data, R.ctypes.data, pp.ctypes.data, None, _stream()),
               'sgnn_contract_rows_partial')
         n = M * N
         check(lib.sgnn_reduce_partials(len(group), pp.ctypes.data, nb.ctypes.data, n.ctypes.data, po.ctypes.data, _stream()),
               'sgnn_reduce_partials')
         outs += res
     return outs
+
+
+def _contract_rows_with_sums(pairs, sums):
+    """contract_rows_many for one launch group whose pairs ``sums`` (index -> copies) also deliver column sums of ``a``."""
+    lib = _lib.load()
+    n_red = len(pairs) + sum(sums.values())
+    if len(pairs) > int(lib.sgnn_contract_rows_max_jobs()) or n_red > int(lib.sgnn_reduce_partials_max_jobs()):
+        raise ValueError('contract_rows_many(column_sums=): %d products + %d sums exceed one launch group' % (len(pairs), n_red - len(pairs)))
+    for a, b in pairs:
+        _req2d(a, 'a'), _req2d(b, 'b')
+    dev = pairs[0][0].device
+    R = np.array([a.shape[0] for a, _ in pairs], dtype=np.int64)
+    M = np.array([a.shape[1] for a, _ in pairs], dtype=np.int64)
+    N = np.array([b.shape[1] for _, b in pairs], dtype=np.int64)
+    lda = np.array([a.stride(0) for a, _ in pairs], dtype=np.int64)
+    ldb = np.array([b.stride(0) for _, b in pairs], dtype=np.int64)
+    nb = [int(lib.sgnn_contract_rows_blocks(int(r), int(m), int(n_))) for r, m, n_ in zip(R, M, N)]
+    parts = [torch.empty((nb[k], int(M[k]), int(N[k])), dtype=torch.float32, device=dev) for k in range(len(pairs))]
+    cparts = [torch.empty((nb[k], int(M[k])), dtype=torch.float32, device=dev) if k in sums else None for k in range(len(pairs))]
+    res = [torch.empty((int(M[k]), int(N[k])), dtype=torch.float32, device=dev) for k in range(len(pairs))]
+    extra, red_part, red_nb, red_n = [], list(parts), list(nb), [int(M[k] * N[k]) for k in range(len(pairs))]
+    for k in sorted(sums):
+        for _ in range(sums[k]):
+            extra.append(torch.empty(int(M[k]), dtype=torch.float32, device=dev))
+            red_part.append(cparts[k]), red_nb.append(nb[k]), red_n.append(int(M[k]))
+    pa, pb, pp, pc = (_ptr_table(v) for v in ([a for a, _ in pairs], [b for _, b in pairs], parts, cparts))
+    check(lib.sgnn_contract_rows_partial(len(pairs), pa.ctypes.data, pb.ctypes.data, lda.ctypes.data, ldb.ctypes.data, M.ctypes.data,
+                                         N.ctypes.data, R.ctypes.data, pp.ctypes.data, pc.ctypes.data, _stream()),
+          'sgnn_contract_rows_partial')
+    rp, ro = _ptr_table(red_part), _ptr_table(res + extra)
+    rnb, rn = np.array(red_nb, dtype=np.int64), np.array(red_n, dtype=np.int64)
+    check(lib.sgnn_reduce_partials(len(red_part), rp.ctypes.data, rnb.ctypes.data, rn.ctypes.data, ro.ctypes.data, _stream()),
+          'sgnn_reduce_partials')
+    return res + extra
 
 
 def _req2d(t, name):
@@ -2312,7 +2350,7 @@ class _FusedHead(torch.autograd.Function):
         gW1 = None
         if ctx.needs_input_grad[1]:
             H0 = x.shape[1]
-            nbw = int(lib.sgnn_contract_rows_blocks(B))
+            nbw = int(lib.sgnn_contract_rows_blocks(B, H1, H0))
             pw = torch.empty((nbw, H1, H0), dtype=torch.float32, device=dev)
             gW1 = torch.empty((H1, H0), dtype=torch.float32, device=dev)
             # (the host arrays must outlive the call: named, not temporaries)
@@ -2320,7 +2358,7 @@ class _FusedHead(torch.autograd.Function):
             dims = np.array([H1, x.stride(0), H1, H0, B], dtype=np.int64)
             check(lib.sgnn_contract_rows_partial(1, pa.ctypes.data, pb.ctypes.data, dims[0:1].ctypes.data, dims[1:2].ctypes.data,
                                                  dims[2:3].ctypes.data, dims[3:4].ctypes.data, dims[4:5].ctypes.data,
-                                                 pp.ctypes.data, _stream()), 'sgnn_contract_rows_partial')
+                                                 pp.ctypes.data, None, _stream()), 'sgnn_contract_rows_partial')
             jobs_part.append(pw), jobs_nb.append(nbw), jobs_n.append(H1 * H0), jobs_out.append(gW1)
         rp, ro = _ptr_table(jobs_part), _ptr_table(jobs_out)
         rnb, rn = np.array(jobs_nb, dtype=np.int64), np.array(jobs_n, dtype=np.int64)
@@ -2525,17 +2563,7 @@ class _BiLSTMLayer(torch.autograd.Function):
         return (dx, dwih[0], dwhh[0], db[0], db[2], dwih[1], dwhh[1], db[1], db[3])
 
 
-_ONES = {}
-
-
-def _ones_column(rows, device):
-    key = str(device)
-    t = _ONES.get(key)
-    if t is None or t.numel() < rows:
-        if torch.cuda.is_current_stream_capturing():
-            return torch.ones(rows, 1, dtype=torch.float32, device=device)
-        t = _ONES[key] = torch.ones(max(rows, 8192), dtype=torch.float32, device=device)
-    return t[:rows].view(rows, 1)
+LSTM_OWN_GEMM_MAX_H = 64       # hidden sizes up to here take this library's projection / dx kernels; wider ones the library's GEMMs
 
 
 class _BiLSTMLayerFused(torch.autograd.Function):
@@ -2563,8 +2591,14 @@ class _BiLSTMLayerFused(torch.autograd.Function):
         dev = src.device
         pre_x = torch.empty((2, R, 4 * H), dtype=torch.float32, device=dev)
         x2 = torch.empty((R, I), dtype=torch.float32, device=dev) if gather else src.view(R, I)
-        check(lib.sgnn_rows_gemm(_ptr(src), _ptr(ids), I, R, I, _ptr(w_ih_f), _ptr(w_ih_r), _ptr(b_ih_f), _ptr(b_ih_r), 4 * H, _ptr(pre_x),
-                                 _ptr(x2) if gather else None, _stream()), 'sgnn_rows_gemm')
+        if gather or H <= LSTM_OWN_GEMM_MAX_H:
+            check(lib.sgnn_rows_gemm(_ptr(src), _ptr(ids), I, R, I, _ptr(w_ih_f), _ptr(w_ih_r), _ptr(b_ih_f), _ptr(b_ih_r), 4 * H,
+                                     _ptr(pre_x), _ptr(x2) if gather else None, _stream()), 'sgnn_rows_gemm')
+        else:
+            # a plain dense GEMM of a few thousand rows by 512 columns over K = 256: the library's tiles run it at twice the rate
+            # of the one-wavefront-per-32x32 kernel (measured on the PPI-BP stand-in's second LSTM layer: 31 us against 67)
+            torch.addmm(b_ih_f, x2, w_ih_f.t(), out=pre_x[0])
+            torch.addmm(b_ih_r, x2, w_ih_r.t(), out=pre_x[1])
         y = torch.empty((B, T, 2 * H), dtype=torch.float32, device=dev)
         gates = torch.empty((2, B, T, 4 * H), dtype=torch.float32, device=dev)
         cell = torch.empty((2, B, T, H), dtype=torch.float32, device=dev)
@@ -2591,16 +2625,19 @@ class _BiLSTMLayerFused(torch.autograd.Function):
               'sgnn_lstm_bwd')
         dg = dgates.view(2, R, 4 * H)
         hp = hprev.view(2, R, H)
-        ones = _ones_column(R, dy.device)
-        # every weight and bias gradient of both directions: block partials in one launch, one reduction.  (bias_ih and bias_hh
-        # receive the same VALUES in DIFFERENT memory: an in-place multi-tensor update of the gradient list must not meet one
-        # buffer twice -- ops._BiLSTMLayer's note.)
-        dwih_f, dwih_r, dwhh_f, dwhh_r, dbi_f, dbi_r, dbh_f, dbh_r = contract_rows_many(
-            [(dg[0], x2), (dg[1], x2), (dg[0], hp[0]), (dg[1], hp[1]), (dg[0], ones), (dg[1], ones), (dg[0], ones), (dg[1], ones)])
+        # every weight and bias gradient of both directions: block partials in one launch, one reduction; the bias gradients are
+        # the column sums of the gate gradients the dW_ih jobs read anyway.  (bias_ih and bias_hh receive the same VALUES in
+        # DIFFERENT memory -- two outputs of the reduction: an in-place multi-tensor update of the gradient list must not meet one
+        # buffer twice, ops._BiLSTMLayer's note.)
+        dwih_f, dwih_r, dwhh_f, dwhh_r, dbi_f, dbh_f, dbi_r, dbh_r = contract_rows_many(
+            [(dg[0], x2), (dg[1], x2), (dg[0], hp[0]), (dg[1], hp[1])], column_sums={0: 2, 1: 2})
         g_src = None
         if ctx.needs_input_grad[0]:
-            dx = torch.empty((R, I), dtype=torch.float32, device=dy.device)
-            check(lib.sgnn_rows_gemm_nt(_ptr(dgates), R, 4 * H, _ptr(w_ih_f), _ptr(w_ih_r), I, _ptr(dx), _stream()), 'sgnn_rows_gemm_nt')
+            if H <= LSTM_OWN_GEMM_MAX_H:
+                dx = torch.empty((R, I), dtype=torch.float32, device=dy.device)
+                check(lib.sgnn_rows_gemm_nt(_ptr(dgates), R, 4 * H, _ptr(w_ih_f), _ptr(w_ih_r), I, _ptr(dx), _stream()), 'sgnn_rows_gemm_nt')
+            else:
+                dx = torch.addmm(dg[0] @ w_ih_f, dg[1], w_ih_r)       # (K = 4 H = 512 per direction: the library's GEMM, as above)
             if not ctx.gather:
                 g_src = dx.view(B, T, I)
             else:
