@@ -977,7 +977,7 @@ def main():
                 continue
             try:
                 t_c = time.perf_counter()
-                line = standins.bench_config(name, steps=20, warmup=5, also_atomics=True, epochs=4)
+                line = standins.bench_config(name, steps=20, warmup=5, also_atomics=True, epochs=9)
                 configs_obj[key] = {'standin': name, 'workload': line['config']['workload'], 'batch': line['config']['cc_ids_shape'],
                                     'ms_per_step_replayed': round(line['ms_per_step'], 3), 'ms_per_step_eager': round(line['eager']['ms_per_step'], 3),
                                     'subgraphs_per_s': round(line['value']), 'kernels_per_step': line['kernels_per_step'],

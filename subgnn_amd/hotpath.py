@@ -77,6 +77,7 @@ def _hand_over(stream, *objs):
 
 
 BFS_LEVEL_MARGIN = 2
+WALKS_ON_SIDE_MAX_SETS = 16384      # component rows up to which the structure walks run on the side stream ahead of the position search
 
 
 def _bfs_levels(model, key, max_hops):
@@ -499,13 +500,12 @@ def prepare_pass(model, split='train', timer=None, shard=None, defer_dtw=False, 
         # schedule only moves it around.  Default False (the search beside the border kernel, as before).
         late_bfs = bool(hp.get('bfs_beside_dtw', False)) and side is not main and hp['use_structure'] and hp['use_position'] \
             and not defer_dtw and not (shard is not None and shard.deal_shared)
-        if not late_bfs:
-            position_block()
-        def structure_walks():
-            """Walks over the structure patches, the per-layer picks and the patches' degree sequences.  With two streams
-            this runs on the MAIN stream behind the component degree sequences (the side stream keeps the position BFS):
-            the side chain -- patches, BFS, walks: 2.5 ms -- was 0.8 ms longer than the main one (border, degree
-            sequences: 1.7 ms) and the DTW waited for it."""
+        wos = hp.get('walks_on_side_stream')            # None: by size (below); True / False: forced
+        walks_on_side = (bool(wos) if wos is not None else cc_sets.n <= WALKS_ON_SIDE_MAX_SETS) and side is not main and hp['use_structure']
+
+        def structure_walks(degree_sequences=True):
+            """Walks over the structure patches and the per-layer picks (+ the patches' degree sequences unless the caller runs
+            them elsewhere).  Which stream: see ``walks_on_side`` below."""
             nonlocal a_sets, ai, ae
             if new_patches and shard is not None and shard.deal_shared:
                 # the walks over the shared patches, dealt: a rank builds the node views of ITS patches only
@@ -542,10 +542,27 @@ def prepare_pass(model, split='train', timer=None, shard=None, defer_dtw=False, 
                 # the column upload is a blocking host->device copy: do it here, before the long DTW
                 # launches are queued, so that the host is free to queue forward/backward behind them
                 st.sim_cols = (a_struct, model.sim_cols_of(a_struct))
-            if pool is not None:
+            if pool is not None or not degree_sequences:
                 return                                   # the pool's similarity rows exist: no degree sequences, no DTW
+            patch_degree_sequences()
+
+        def patch_degree_sequences():
+            """The structure patches' degree sequences: what the DTW launches read of the patches (not the walks)."""
+            nonlocal a_sets, ai, ae
             a_sets = ops.Ragged.from_padded(structure_anchors)
             ai, ae = ops.degree_sequence(g, a_sets, sort=True, use_degree_dict=g.full_degree is not None)
+        # Where the walks run.  For shards of up to WALKS_ON_SIDE_MAX_SETS component rows (round 6): on the SIDE stream, right
+        # behind the patches and AHEAD of the position search.  Nothing on the main chain reads the walks -- the DTW launches read
+        # the patches' degree sequences only -- so they leave it; and they no longer run BESIDE the search: a walk is one
+        # 1024-thread workgroup around a 125 KB LDS bitmap, it needs 16 free wavefront slots on one CU at once, and the search's
+        # small workgroups kept every CU's slots busy -- at 6 250 subgraphs the walks' stage took 1.3-1.45 ms on the main chain
+        # for 0.27 ms of kernel: the pass 3.08 -> 2.79 ms (same box, back to back).  At the benchmark's 50k subgraphs the main
+        # chain is the long one either way and the walks hide better there (8.82 vs 8.87 ms pipelined, 9.31 vs 9.60 sequential):
+        # they stay on the main chain, as rounds 3-5 had them.  hparams['walks_on_side_stream'] = True / False forces either.
+        if walks_on_side:
+            structure_walks(degree_sequences=False)
+        if not late_bfs:
+            position_block()
         if hp['use_structure'] and side is main:
             structure_walks()
             t.mark('S_patches_walks')
@@ -594,8 +611,13 @@ def prepare_pass(model, split='train', timer=None, shard=None, defer_dtw=False, 
     if hp['use_structure'] and side is not main:
         main.wait_event(patch_ev)
         _hand_over(main, structure_anchors)
-        structure_walks()
-        t.mark('S_walks')
+        if walks_on_side:
+            if pool is None:
+                patch_degree_sequences()
+            t.mark('S_patch_degree_sequences')
+        else:
+            structure_walks()
+            t.mark('S_walks')
     # ---- structure similarities (main), then the join ---------------------------------------
     # The DTW launches read the degree sequences only, nothing the side stream computes: they are queued BEFORE the join, so a
     # position search that is still running (small shards: the search does not shrink with the shard, everything else does)
@@ -615,7 +637,10 @@ def prepare_pass(model, split='train', timer=None, shard=None, defer_dtw=False, 
     if side is not main:
         main.wait_stream(side)
         _hand_over(main, sims, st.attrs.get('anchors_pos_ext'), st.per_split.get('anchors_pos_int'),
-                   st.attrs.get('structure_anchors'))
+                   st.attrs.get('structure_anchors'), st.attrs.get('int_structure_anchor_random_walks'),
+                   st.attrs.get('bor_structure_anchor_random_walks'), st.sim_cols[1] if st.sim_cols else None)
+        for v in (st.attrs.get('anchors_structure') or {}).values():
+            _hand_over(main, v[0], v[2], v[3])
     if side is not main:
         t.mark('side_stream_join(S_patches,P_bfs)')
     st.attrs[split + '_neigh_pos_similarities'] = sims if sims else None

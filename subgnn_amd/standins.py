@@ -226,11 +226,16 @@ def time_epochs(model, hp, epochs=4):
     tr.fit(model, prepared=True)
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
-    later = tr.phase_times[1:] or tr.phase_times
-    keys = ('train_steps_s', 'validation_steps_s', 'validation_epoch_end_s')
-    mean = {k: 1e3 * sum(r.get(k, 0.0) for r in later) / len(later) for k in keys}
+    later = tr.phase_times[2:] or tr.phase_times[1:] or tr.phase_times      # (epoch 0: warm-up steps + the training recording; epoch 1 may
+    keys = ('train_steps_s', 'validation_steps_s', 'validation_epoch_end_s')  #  still record the validation forward of a one-batch split)
+    # the MEDIAN epoch (every epoch is listed beside it): in a long-lived process single epochs stall by tens of ms for reasons
+    # outside the loop (allocator growth after an empty_cache, a collector pass) -- the mean of four epochs was 17 / 17 / 90 / 95 ms
+    order = sorted(later, key=lambda r: sum(r.get(k, 0.0) for k in keys))
+    med = order[(len(order) - 1) // 2]
+    mean = {k: 1e3 * med.get(k, 0.0) for k in keys}
     first = {k: round(1e3 * tr.phase_times[0].get(k, 0.0), 2) for k in keys}
     return {'epochs': epochs, 'wall_s': round(wall, 3), 'epoch_ms': round(sum(mean.values()), 3),
+            'epoch_ms_is': 'the median epoch of epochs 2.. (all listed in every_epoch_ms)',
             'breakdown_ms': {k[:-2] + '_ms': round(v, 3) for k, v in mean.items()},
             'first_epoch_ms(warm-up steps + recordings)': first,
             'per_epoch': {k: later[-1].get(k) for k in ('replayed_steps', 'eager_steps', 'validation_batches')},
