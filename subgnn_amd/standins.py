@@ -219,8 +219,12 @@ def time_epochs(model, hp, epochs=4):
     the epochs after the first, which also pays the eager warm-up steps and the recordings) and where it goes."""
     import time
     from .train_config import Trainer
+    import gc
     tr = Trainer(epochs, hp.get('grad_clip', 0.0), log=lambda *a, **k: None, hip_graph_step=bool(hp.get('hip_graph_step', True)))
     tr.phase_times = []
+    # (the dataset that was just written and loaded left a few million container objects behind, and a full collection over them
+    # -- every second or third epoch at these epochs' allocation rate -- is a 50-80 ms
+    # pause: epochs of 25 / 74 / 25 / 74 ms on the PPI-BP stand-in.  Trainer.fit freezes the heap itself after prepare_data.)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     tr.fit(model, prepared=True)

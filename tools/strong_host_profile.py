@@ -26,6 +26,7 @@ S = len(subs)
 labels = torch.randint(0, 3, (S,), generator=torch.Generator().manual_seed(0))
 full = SubGNN.from_memory(dict(hp), g, {'train': subs, 'val': [], 'test': []}, {'train': labels, 'val': labels[:0], 'test': labels[:0]}, emb, num_classes=3)
 hotpath.prepare_sparse(full, 'train')
+bench.time_strong_rank(g, subs, labels, emb, hp, full, steps=5, warmup=1)      # (imports, code objects: not the profile's business)
 torch.cuda.synchronize()
 pr = cProfile.Profile()
 pr.enable()
@@ -34,7 +35,7 @@ pr.disable()
 print('ms per step', line['ms_per_step_device'], line['stages_ms'])
 print('host', line['host_ms_per_stage(time the host needs to queue it)'])
 s = io.StringIO()
-pstats.Stats(pr, stream=s).sort_stats('cumulative').print_stats(60)
+pstats.Stats(pr, stream=s).sort_stats('cumulative').print_stats(45)
 print(s.getvalue()[:12000])
 s = io.StringIO()
 pstats.Stats(pr, stream=s).sort_stats('tottime').print_stats(30)
