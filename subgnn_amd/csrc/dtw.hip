@@ -365,6 +365,9 @@ __global__ __launch_bounds__(DTW_THREADS) void dtw_similarity_kernel(
 #ifndef DTW_NO_ROW_MAJOR
 #define DTW_NO_ROW_MAJOR 0        // 1: round 4's coarse levels (a word of predecessor bits per column in LDS, cell-by-cell back-trace) also for levels of <= 32 columns
 #endif
+#ifndef DTW_COARSE_ONE_SIZE
+#define DTW_COARSE_ONE_SIZE 0     // 1: every coarse level runs the RMAX / 2-row instantiation (rounds 4-5)
+#endif
 #ifndef DTW_MINB12
 #define DTW_MINB12 3            // resident 256-thread blocks per CU the 12-row kernel is compiled for
 #endif
@@ -534,13 +537,15 @@ __device__ __forceinline__ double dtw_wave_level(
                     col[a_] = m_ + dt0_;                                                                             \
                 } else {                                                                                             \
                     const double c_up = (UPV) + dt0_, c_left = col[a_] + dt0_, c_diag = dg + dt0_;                   \
-                    const double mv = fmin(fmin(c_up, c_left), c_diag);      /* two v_min_f64 (no NaNs here) */       \
+                    const double m1_ = fmin((UPV), col[a_]);                                                         \
+                    const double mv = TIE == 2 ? fmin(m1_, dg) + dt0_                                                \
+                                               : fmin(fmin(c_up, c_left), c_diag);   /* two v_min_f64 (no NaNs here) */ \
                     /* predecessor = the first candidate, in the tie order, that attains the minimum; a cell */      \
                     /* outside the lane's window is never read back, whatever code it gets */                        \
                     uint32_t best;                                                                                   \
                     if (TIE == 0) best = c_up == mv ? 0u : (c_left == mv ? 1u : 2u);        /* (i-1,j), (i,j-1), (i-1,j-1) */ \
                     else if (TIE == 1) best = c_diag == mv ? 2u : (c_up == mv ? 0u : 1u);   /* (i-1,j-1), (i-1,j), (i,j-1) */ \
-                    else best = (dg <= (UPV) && dg <= col[a_]) ? 2u : ((UPV) <= col[a_] ? 0u : 1u);   /* on the predecessor costs, <= */ \
+                    else best = dg <= m1_ ? 2u : ((UPV) <= col[a_] ? 0u : 1u);           /* on the predecessor costs, <= */ \
                     word |= best << (2 * a_);                                                                        \
                     if (TIE == 2) da = col[a_]; else cd = col[a_] + dt1_;    /* (i, j-1) is the diagonal of (i+1, j) */ \
                     col[a_] = mv;                                                                                    \
@@ -557,11 +562,12 @@ __device__ __forceinline__ double dtw_wave_level(
                     col[b_] = m_ + dt1_;                                                                             \
                 } else {                                                                                             \
                     const double c_up = col[a_] + dt1_, c_left = col[b_] + dt1_, c_diag = TIE == 2 ? da + dt1_ : cd; \
-                    const double mv = fmin(fmin(c_up, c_left), c_diag);                                              \
+                    const double m1_ = fmin(col[a_], col[b_]);                                                       \
+                    const double mv = TIE == 2 ? fmin(m1_, da) + dt1_ : fmin(fmin(c_up, c_left), c_diag);            \
                     uint32_t best;                                                                                   \
                     if (TIE == 0) best = c_up == mv ? 0u : (c_left == mv ? 1u : 2u);                                 \
                     else if (TIE == 1) best = c_diag == mv ? 2u : (c_up == mv ? 0u : 1u);                            \
-                    else best = (da <= col[a_] && da <= col[b_]) ? 2u : (col[a_] <= col[b_] ? 0u : 1u);              \
+                    else best = da <= m1_ ? 2u : (col[a_] <= col[b_] ? 0u : 1u);                                     \
                     word |= best << (2 * b_);                                                                        \
                     dg = col[b_];                                            /* the next pair's diagonal */           \
                     col[b_] = mv;                                                                                    \
@@ -754,10 +760,14 @@ __device__ __forceinline__ void dtw_wave_level_pp(
 #define DTWP_CELL(UPV, LEFT, DIAG, DT, OUT)                                                                          \
             {                                                                                                        \
                 const double c_up = (UPV) + (DT), c_left = (LEFT) + (DT), c_diag = (DIAG) + (DT);                    \
-                const double mv = fmin(fmin(c_up, c_left), c_diag);                                                  \
+                /* rule 2 picks on the predecessors' values: only the cell's value is needed of the sums, and rounding */ \
+                /* is monotone -- the smallest rounded sum is the rounded sum of the smallest predecessor: 1 add, not 3 */ \
+                /* (and "diagonal <= up and diagonal <= left" is ONE compare against min(up, left), which the value needs anyway) */ \
+                const double m1_ = fmin((UPV), (LEFT));                                                              \
+                const double mv = TIE == 2 ? fmin(m1_, (DIAG)) + (DT) : fmin(fmin(c_up, c_left), c_diag);            \
                 if (TIE == 0) { word = dtw_shift_in(word, __ballot(c_up == mv)); word = dtw_shift_in(word, __ballot(c_left == mv)); } \
                 else if (TIE == 1) { word = dtw_shift_in(word, __ballot(c_diag == mv)); word = dtw_shift_in(word, __ballot(c_up == mv)); } \
-                else { word = dtw_shift_in(word, __ballot((DIAG) <= (UPV)) & __ballot((DIAG) <= (LEFT)));           \
+                else { word = dtw_shift_in(word, __ballot((DIAG) <= m1_));                                           \
                        word = dtw_shift_in(word, __ballot((UPV) <= (LEFT))); }                                      \
                 (OUT) = mv;                                                                                          \
             }
@@ -943,10 +953,14 @@ __device__ __forceinline__ void dtw_wave_level_rm(
 #define DTWR_CELL(UPV, LEFT, DIAG, DT, OUT, ROW)                                                                     \
             {                                                                                                        \
                 const double c_up = (UPV) + (DT), c_left = (LEFT) + (DT), c_diag = (DIAG) + (DT);                    \
-                const double mv = fmin(fmin(c_up, c_left), c_diag);                                                  \
+                /* rule 2 picks on the predecessors' values: only the cell's value is needed of the sums, and rounding */ \
+                /* is monotone -- the smallest rounded sum is the rounded sum of the smallest predecessor: 1 add, not 3 */ \
+                /* (and "diagonal <= up and diagonal <= left" is ONE compare against min(up, left), which the value needs anyway) */ \
+                const double m1_ = fmin((UPV), (LEFT));                                                              \
+                const double mv = TIE == 2 ? fmin(m1_, (DIAG)) + (DT) : fmin(fmin(c_up, c_left), c_diag);            \
                 if (TIE == 0) { mA[ROW] = dtw_shift_in(mA[ROW], __ballot(c_up == mv)); mB[ROW] = dtw_shift_in(mB[ROW], __ballot(c_left == mv)); } \
                 else if (TIE == 1) { mA[ROW] = dtw_shift_in(mA[ROW], __ballot(c_diag == mv)); mB[ROW] = dtw_shift_in(mB[ROW], __ballot(c_up == mv)); } \
-                else { mA[ROW] = dtw_shift_in(mA[ROW], __ballot((DIAG) <= (UPV)) & __ballot((DIAG) <= (LEFT)));     \
+                else { mA[ROW] = dtw_shift_in(mA[ROW], __ballot((DIAG) <= m1_));                                     \
                        mB[ROW] = dtw_shift_in(mB[ROW], __ballot((UPV) <= (LEFT))); }                                 \
                 (OUT) = mv;                                                                                          \
             }
@@ -1096,8 +1110,21 @@ __global__ __launch_bounds__(DTW_THREADS, MINB) void dtw_similarity_reg_kernel(
             else if constexpr (2 * RH <= 27 && !DTW_OLD_COARSE) {
                 // (wave-uniform: one anchor per wavefront.  Only in the instantiation whose words sit in LDS -- anchor series of up to
                 // 96 entries: the other one serves longer series, whose first coarse level has more than 32 columns anyway)
-                if (WLDS && ly <= 32 && !DTW_NO_ROW_MAJOR)
-                    dtw_wave_level_rm<RH, TIE>(fl, xcol, xrcol, n_x, ycol, yrcol, act, lx, ly, lxc, lyc, coarsest, lev);
+                if (WLDS && ly <= 32 && !DTW_NO_ROW_MAJOR) {
+                    // Level lev of a series of <= RMAX entries has <= RMAX >> lev rows: the second coarse level and the ones
+                    // below it get instantiations of their own size (round 6).  Everything per row of the level function is
+                    // unrolled over its row count -- loading the series, clearing two column arrays and two bit rows, the
+                    // window and hull words, a back-trace step -- and with RH rows for every coarse level the 2-row and the
+                    // 5-row level of a 20-entry series paid ~500 vector instructions each for rows they do not have.
+                    constexpr int R2 = (((RMAX >> 2) + 1) & ~1) < 2 ? 2 : (((RMAX >> 2) + 1) & ~1);
+                    constexpr int R3 = (((RMAX >> 3) + 1) & ~1) < 2 ? 2 : (((RMAX >> 3) + 1) & ~1);
+                    if (DTW_COARSE_ONE_SIZE || lev == 1)
+                        dtw_wave_level_rm<RH, TIE>(fl, xcol, xrcol, n_x, ycol, yrcol, act, lx, ly, lxc, lyc, coarsest, lev);
+                    else if (lev == 2)
+                        dtw_wave_level_rm<R2, TIE>(fl, xcol, xrcol, n_x, ycol, yrcol, act, lx, ly, lxc, lyc, coarsest, lev);
+                    else
+                        dtw_wave_level_rm<R3, TIE>(fl, xcol, xrcol, n_x, ycol, yrcol, act, lx, ly, lxc, lyc, coarsest, lev);
+                }
                 else
                     dtw_wave_level_pp<RH, TIE, WLDS>(fl, xcol, xrcol, n_x, ycol, yrcol, act, lx, ly, lxc, lyc, coarsest, wl, w, NT, lev);
             }

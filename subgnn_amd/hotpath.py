@@ -675,12 +675,8 @@ def finish_pass(model, st, timer=None):
                                   (ops.distinct_rows_async(cc_sets.ptr, ci, mx), ops.distinct_rows_async(cc_sets.ptr, ce, mx)))
             xprep[split] = ({}, {})
             t.mark('dtw_row_grouping_counts_queued(first pass only)')
-        elif ent[3] is not None:
-            wait = torch.cuda.is_current_stream_capturing()          # (a recording needs the decision settled: the counts are long there)
-            fr = [ops.distinct_rows_ready(p, wait=wait) for p in ent[3]]
-            if all(f is not None for f in fr):
-                ent = group[split] = (cc_sets.n, fr[0] <= 0.5, fr[1] <= 0.5, None)
-                xprep[split] = ({}, {})
+        elif ent[3] is not None and not torch.cuda.is_current_stream_capturing():
+            ent = _settle_dtw_grouping(model, split, wait=False)
         # the component side of the DTW calls (grouping of repeated degree sequences, processing order) depends on the
         # split's components only -- the same every pass: kept from the first one (xprep), like the dispatch orders
         st.attrs[split + '_int_struc_similarities'] = \
@@ -692,6 +688,21 @@ def finish_pass(model, st, timer=None):
         st.attrs[split + '_int_struc_similarities'] = None
         st.attrs[split + '_bor_struc_similarities'] = None
     return st
+
+
+def _settle_dtw_grouping(model, split, wait):
+    """Pick up the distinct-row counts the split's first pass sent to pinned memory and decide which DTW side groups repeated
+    rows (a choice of kernels, never of values).  ``wait``: block until the copies have landed -- what a recording of the
+    preparation does BEFORE its capture starts (an event wait inside a capture invalidates it)."""
+    group = model.__dict__.setdefault('_dtw_group_rows', {})
+    ent = group.get(split)
+    if ent is None or ent[3] is None:
+        return ent
+    fr = [ops.distinct_rows_ready(p, wait=wait) for p in ent[3]]
+    if all(f is not None for f in fr):
+        ent = group[split] = (ent[0], fr[0] <= 0.5, fr[1] <= 0.5, None)
+        model.__dict__.setdefault('_dtw_x_prep', {})[split] = ({}, {})
+    return ent
 
 
 def install_pass(model, st, timer=None):
@@ -1001,6 +1012,8 @@ class GraphedPasses:
         self.slots = [None, None]
         self.stream = torch.cuda.Stream()
         self.k = 0
+        if int(warmup) < 2:
+            raise ValueError('GraphedPasses needs two eager passes before it records (the second one runs the kernels the first one chose)')
         self._warm_left = int(warmup)
         self.recordings = 0
 
@@ -1020,6 +1033,7 @@ class GraphedPasses:
         while len(pool) < 4 * max(1, int(self.model.hparams['n_layers'])):      # pinned buffers the recorded searches will take
             pool.append(torch.empty(4, dtype=torch.int32).pin_memory())
         torch.cuda.synchronize()
+        _settle_dtw_grouping(self.model, self.split, wait=True)     # (the recording keeps whatever kernels this decides on)
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
             slot.state = prepare_pass(self.model, self.split)
@@ -1050,7 +1064,12 @@ class GraphedPasses:
             # land in a recording
             self._warm_left -= 1
             install_pass(self.model, prepare_pass(self.model, self.split))
-            return self._body()
+            out = self._body()
+            # the first pass of a split sends its distinct-row counts to pinned memory and a LATER pass picks the DTW kernels'
+            # row grouping from them: settled here, so that the next warm-up pass builds the kept x-side preparation of the
+            # decided form eagerly (its first call indexes with a mask: not recordable)
+            _settle_dtw_grouping(self.model, self.split, wait=True)
+            return out
         i = self.k & 1
         main = torch.cuda.current_stream()
         slot = self.slots[i] or self._record(i)

@@ -908,6 +908,13 @@ def dtw_similarity(x_ptr, x_val, max_x, y_ptr, y_val, max_y, tie_order=None, ord
             live = torch.stack((n - n_live, n_live))
         if x_prep is not None:
             x_prep['dedupe'] = (uptr, rep, dst.reshape(-1), live)
+            # (the per-entry map of the kept path, made here as well: a mask index is a host round trip, and a caller that records
+            # its passes into a hipGraph has ONE eager pass left once the grouping is decided -- hotpath._settle_dtw_grouping)
+            real = j < (x_ptr[1:] - x_ptr[:-1]).view(-1, 1)
+            dst_e = dst[real].contiguous()
+            if dst_e.numel() < x_val.numel():
+                dst_e = torch.cat([dst_e, dst_e.new_full((x_val.numel() - dst_e.numel(),), x_val.numel())])
+            x_prep['dedupe_entry_dst'] = dst_e
         out_u = dtw_similarity(uptr, uval, max_x, y_ptr, y_val, max_y, tie_order, order_rows, dedupe=False, order=order,
                                _live=live, x_prep=x_prep.setdefault('grouped', {}) if x_prep is not None else None, kernel=kernel)
         return out_u.index_select(0, rep)

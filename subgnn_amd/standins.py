@@ -237,7 +237,7 @@ def time_epochs(model, hp, epochs=4):
     order = sorted(later, key=lambda r: sum(r.get(k, 0.0) for k in keys))
     med = order[(len(order) - 1) // 2]
     mean = {k: 1e3 * med.get(k, 0.0) for k in keys}
-    first = {k: round(1e3 * tr.phase_times[0].get(k, 0.0), 2) for k in keys}
+    first = {k[:-2]: round(1e3 * tr.phase_times[0].get(k, 0.0), 2) for k in keys}
     return {'epochs': epochs, 'wall_s': round(wall, 3), 'epoch_ms': round(sum(mean.values()), 3),
             'epoch_ms_is': 'the median epoch of epochs 2.. (all listed in every_epoch_ms)',
             'breakdown_ms': {k[:-2] + '_ms': round(v, 3) for k, v in mean.items()},

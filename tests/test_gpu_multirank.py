@@ -67,3 +67,20 @@ def test_two_rank_gradient_exchange_reproduces_the_single_rank_loss():
         assert d['collectives']['rccl_ranks'] == 2 and d['config']['subgraphs_total'] == 2000, name
         assert abs(d['loss'] - one['loss']) <= 1e-5 * abs(one['loss']), (name, d['loss'], one['loss'])
     assert graph['loss'] == eager['loss']                          # a replayed step is the eager step, bit for bit
+
+
+def test_every_schedule_of_the_single_rank_bench_trains_to_one_loss():
+    """bench.py's schedules at N = 1 on one workload (2 000 subgraphs: above the 1 024 rows where the DTW stage decides
+    about grouping repeated rows from counts that arrive asynchronously -- a recording of the preparation has to settle
+    that before its capture starts): eager, training half from a hipGraph, both halves from hipGraphs, sequential.
+    No dropout: one loss, bit for bit."""
+    base = ['--steps', '4', '--warmup', '1']                       # 2 priming passes + 1 + 4 = 7 updates
+    runs = {m: _bench(1, base + ['--graph', m], no_dropout=True) for m in ('off', 'train')}
+    # (both halves recorded: bench.py primes with 4 passes there -- two eager ones, then one recording per slot: 4 + 1 + 2 = 7)
+    runs['both'] = _bench(1, ['--steps', '2', '--warmup', '1', '--graph', 'both'], no_dropout=True)
+    assert runs['both']['priming_passes_before_warmup'] == 4 and runs['off']['priming_passes_before_warmup'] == 2
+    runs['sequential'] = _bench(1, base + ['--no-pipeline'], no_dropout=True)
+    assert runs['both']['config']['schedule']['hipgraphs'] == 'both'
+    assert runs['train']['config']['schedule']['training_half_from_hipgraph'] is True
+    losses = {m: d['loss'] for m, d in runs.items()}
+    assert len(set(losses.values())) == 1, losses
