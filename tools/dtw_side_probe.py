@@ -29,3 +29,14 @@ for _ in range(reps):
     out = f()
 torch.cuda.synchronize()
 print('%s %.3f ms per call (kept preparation), checksum %.6f' % (side, (time.perf_counter() - t) / reps * 1e3, float(out.double().sum())))
+if os.environ.get('DTW_PROBE_DUPS'):
+    # how often a column of the finest level repeats its predecessor's value (the y series is wave-uniform: a repeated value
+    # means the column's costs are the previous column's for every row and lane)
+    yp = ops.Ragged(a_sets.ptr, y, max_len=50).to_padded(width=50, fill=-1, dtype=torch.int32).cpu().numpy()
+    same = (yp[:, 1:] == yp[:, :-1]) & (yp[:, 1:] >= 0)
+    print('y series: %d x %d, mean length %.1f, columns equal to their predecessor: %.3f' % (yp.shape[0], yp.shape[1], (yp >= 0).sum(1).mean(), same.sum() / max(1, (yp[:, 1:] >= 0).sum())))
+    h = (yp[:, 0::2][:, :25].astype(np.float64) + yp[:, 1::2][:, :25]) / 2
+    print('level-1 columns equal to their predecessor: %.3f' % ((h[:, 1:] == h[:, :-1]).mean()))
+    xp = ops.Ragged(sets.ptr, x, max_len=NX).to_padded(width=NX, fill=-1, dtype=torch.int32).cpu().numpy()
+    print('x rows: entries equal to their predecessor: %.3f; pairs (2k, 2k+1) equal: %.3f' % ((xp[:, 1:] == xp[:, :-1]).mean(), (xp[:, 0::2] == xp[:, 1::2]).mean()))
+    print('distinct y values per series: %.1f' % np.mean([len(set(r[r >= 0])) for r in yp]))
