@@ -41,7 +41,7 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with these extra
   configs       N = 1 only: the batch-sized training steps of the BASELINE configs[0,1,2,4] stand-ins (replayed + eager ms, kernels).
   cpu_baseline  the oracle (plain C + numpy + torch-CPU restatement of the same algorithm) timed on this box's host cores on a
                 bounded sample (rank 0, N = 1 only; Python stages on worker processes forked before the GPU is initialised), with
-                its calibration against the imported reference (profiles/r04_cpu_calibration.json).
+                its calibration against the imported reference (profiles/r06_cpu_calibration.json; round 4: r04_cpu_calibration.json).
 """
 import argparse
 import json

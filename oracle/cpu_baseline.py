@@ -17,7 +17,7 @@ Python / numpy integer stages -- structure patches + walks, components, borders,
 worker PROCESSES, one per core (``start_pool``: forked by bench.py BEFORE the GPU is initialised, so the workers hold no
 HIP state; without a pool the stages run in this process, single-threaded).  "cores" reports the thread / process count.
 
-``calibration``: profiles/r04_cpu_calibration.json holds the imported REFERENCE and this port timed on the same inputs on
+``calibration``: profiles/r06_cpu_calibration.json (round 4: r04_...) holds the imported REFERENCE and this port timed on the same inputs on
 the build container's 8 cores (tools/bench_density_n.py --mode reference / port: BASELINE.json configs[0]'s dataset, with
 the neighbourhood channel only and with all three channels): ratio = reference time / port time, so
 value / ratio estimates "the reference's own CPU path" at a size where the reference itself cannot run (BASELINE.md
@@ -113,11 +113,16 @@ def _w_anchors(a):
 
 
 def _calibration():
-    f = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'profiles', 'r04_cpu_calibration.json')
-    if not os.path.exists(f):
-        return None
-    with open(f) as fh:
-        return json.load(fh)
+    """The newest calibration file under profiles/ (round 6's, else round 4's) -> (dict, file name) or None."""
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'profiles')
+    for name in ('r06_cpu_calibration.json', 'r04_cpu_calibration.json'):
+        f = os.path.join(d, name)
+        if os.path.exists(f):
+            with open(f) as fh:
+                cal = json.load(fh)
+            cal['_file'] = 'profiles/' + name
+            return cal
+    return None
 
 
 def run(rowptr, col, subs, hp, emb, labels, n_sample, S_total):
@@ -263,7 +268,8 @@ def run(rowptr, col, subs, hp, emb, labels, n_sample, S_total):
             'prepare_ratio': c['prepare_ratio'], 'cores': cal['cores'],
             'n_density_channel_only': {k: cal['n_density'][k] for k in ('reference_ms_per_step', 'port_ms_per_step', 'ratio')},
             'what': 'imported reference vs this port, same inputs (configs[0] dataset, all three channels on; neighbourhood only '
-                    'beside it), build container, 8 cores: profiles/r04_cpu_calibration.json (tools/bench_density_n.py)',
+                    'beside it), build container, 8 cores: %s (tools/bench_density_n.py)' % cal['_file'],
+            'taken': cal.get('taken', {'round': 4}),
             'value_calibrated_to_reference': S_total / est_pass / c['ratio'],
             'note': 'value / ratio (the training-step ratio; the reference\'s prepare_data is a further %sx slower than the '
                     'port\'s, with its pure-Python fastdtw stand-in) -- an ESTIMATE of the reference\'s own CPU path at a size '

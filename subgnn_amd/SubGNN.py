@@ -933,7 +933,7 @@ class SubGNN(nn.Module):
         return self.val_test_step(test_batch, batch_idx, is_test=True)
 
     def _epoch_metrics(self, outputs, p):
-        from sklearn.metrics import roc_auc_score
+        roc_auc_score = subgraph_utils.roc_auc              # sklearn's values without its per-call argument validation
         if outputs and outputs[0][p + '_logits'].is_cuda:
             ops.poll_index_errors(block=True)           # (a device-side batch index outside its split: reported here at the latest)
         logits = torch.cat([x[p + '_logits'] for x in outputs], dim=0).detach()
@@ -952,13 +952,13 @@ class SubGNN(nn.Module):
         lc, gc = labels.cpu(), logits.cpu()
         try:
             if self.multilabel:
-                logs[p + '_auroc'] = roc_auc_score(lc, torch.sigmoid(gc), multi_class='ovr')
+                logs[p + '_auroc'] = roc_auc_score(lc.numpy(), torch.sigmoid(gc).numpy(), multi_class='ovr')
             elif len(torch.unique(lc)) == 2:
-                logs[p + '_auroc'] = roc_auc_score(lc, F.softmax(gc, dim=1)[:, 1])
+                logs[p + '_auroc'] = roc_auc_score(lc.numpy(), F.softmax(gc, dim=1)[:, 1].numpy())
             else:
-                logs[p + '_auroc'] = roc_auc_score(lc, F.softmax(gc, dim=1), multi_class='ovr')
-            onehot = lc if self.multilabel else F.one_hot(lc, num_classes=gc.shape[1])
-            score = torch.sigmoid(gc) if self.multilabel else gc
+                logs[p + '_auroc'] = roc_auc_score(lc.numpy(), F.softmax(gc, dim=1).numpy(), multi_class='ovr')
+            onehot = (lc if self.multilabel else F.one_hot(lc, num_classes=gc.shape[1])).numpy()
+            score = (torch.sigmoid(gc) if self.multilabel else gc).numpy()
             for c in range(gc.shape[1]):
                 logs['%s_auroc_class_%d' % (p, c)] = roc_auc_score(onehot[:, c], score[:, c])
         except ValueError:

@@ -1293,9 +1293,6 @@ extern "C" int sgnn_khop_border_arena(const int64_t* rowptr, const int32_t* col,
 #ifndef K1_TAKE
 #define K1_TAKE 8               // sets per trip to the device-wide counter (all but the first of a trip are prefetched)
 #endif
-#ifndef K1_TAKE_BIG
-#define K1_TAKE_BIG 32          // ... while more than a quarter of the sets is left (<= 63: a trip's set_ptr slice is one load per lane)
-#endif
 
 #ifdef K1_DEBUG_TIMING
 __device__ unsigned long long k1_dbg[16];
@@ -1365,23 +1362,17 @@ __global__ __launch_bounds__(K1_THREADS) void khop1_sample_kernel(
     uint32_t pf_r0 = 0, pf_r1 = 0;                           // the prefetched row's start and end, RAW: see step 2 below
     int32_t nx_v = 0;                                        // the NEXT set's first 64 members (prefetch step 1); read back as v_pf one set later
     int64_t trip0 = 0, trip_ptr = 0;
-    int take_now = ((int64_t)K1_TAKE_BIG * gridDim.x < n_sets - (n_sets >> 2)) ? K1_TAKE_BIG : K1_TAKE;
     while (true) {
         if (si_next >= si_end) {
-            // Guided trips (round 6): a trip to the device-wide counter is a returning atomic on one contended address -- several
-            // microseconds under load, 13 % of a set's time at 8 sets per trip (profiles/r04_khop1_phases.txt) -- so the first
-            // three quarters of the sets are handed out K1_TAKE_BIG at a time and only the rest in trips of K1_TAKE, which keep
-            // the tail of the launch balanced.  The size of a trip follows from the previous answer (take_now).
-            if (tid == 0) s_next = (long long)atomicAdd(next_set, (unsigned long long)take_now);
+            if (tid == 0) s_next = (long long)atomicAdd(next_set, (unsigned long long)K1_TAKE);
             __syncthreads();
             si_next = s_next;
-            si_end = si_next + take_now;
-            take_now = (si_end + (int64_t)K1_TAKE_BIG * gridDim.x < n_sets - (n_sets >> 2)) ? K1_TAKE_BIG : K1_TAKE;
+            si_end = si_next + K1_TAKE;
             __syncthreads();
             // the trip's slice of set_ptr in one load (lane j: set si_next + j), read back lane by lane below
             trip0 = si_next;
             trip_ptr = 0;
-            if (set_order == nullptr && lane <= (int)(si_end - si_next) && si_next + lane <= n_sets) trip_ptr = set_ptr[si_next + lane];
+            if (set_order == nullptr && lane <= K1_TAKE && si_next + lane <= n_sets) trip_ptr = set_ptr[si_next + lane];
         }
         K1_T(0);                                                   // dispatch
         const int64_t si = si_next++;

@@ -111,6 +111,52 @@ def f1_from_predictions(y_true, y_pred, average):
     return float(f.mean()) if f.size else 0.0
 
 
+def _binary_auroc(y_true, y_score):
+    """Area under the ROC curve of one binary problem the way sklearn builds it: scores sorted descending (stable), the
+    cumulative true / false positive counts at the LAST entry of every run of equal scores, a (0, 0) point in front, trapezoids.
+    (sklearn drops collinear points first, roc_curve's drop_intermediate: the area is the same.)  nan when y_true holds one
+    class only: what the sklearn of this image returns (with a warning; the reference's pinned 0.20.2 raised ValueError there
+    and the reference's epoch end, which does not catch it, stopped the run)."""
+    import numpy as np
+    yt = np.asarray(y_true).reshape(-1)
+    ys = np.asarray(y_score, dtype=np.float64).reshape(-1)
+    classes = np.unique(yt)
+    if classes.size != 2:
+        return float('nan')
+    pos = yt == classes[1]
+    order = np.argsort(-ys, kind='mergesort')
+    ys, pos = ys[order], pos[order]
+    last = np.r_[np.nonzero(np.diff(ys))[0], ys.size - 1]               # last index of every run of equal scores
+    tps = np.cumsum(pos, dtype=np.float64)[last]
+    fps = 1.0 + last - tps
+    tpr = np.r_[0.0, tps] / tps[-1]
+    fpr = np.r_[0.0, fps] / fps[-1]
+    return float(np.sum(np.diff(fpr) * (tpr[1:] + tpr[:-1]) / 2.0))
+
+
+def roc_auc(y_true, y_score, multi_class=None):
+    """sklearn.metrics.roc_auc_score as the reference's epoch-end metrics call it (S.py:408-444): binary (y_score (n,)),
+    one-vs-rest macro average over the classes (integer y_true, y_score (n, K) class probabilities, multi_class='ovr') and
+    multilabel macro average (indicator y_true (n, K)).  Seven sklearn calls per validation epoch -- one per class and one for the
+    average -- were ~4 ms of argument validation on 200 subgraphs (a third of a PPI-BP stand-in epoch's host time); the values
+    are checked against sklearn's in tests/test_host_logic.py.  Raises ValueError where sklearn does (a class absent from the
+    split, a class count that differs from the score columns)."""
+    import numpy as np
+    yt, ys = np.asarray(y_true), np.asarray(y_score, dtype=np.float64)
+    if ys.ndim == 1:
+        return _binary_auroc(yt, ys)
+    if yt.ndim == 2:                                     # multilabel indicator
+        return float(np.mean([_binary_auroc(yt[:, c], ys[:, c]) for c in range(ys.shape[1])]))
+    if multi_class != 'ovr':
+        raise ValueError("roc_auc: multi-class scores need multi_class='ovr'")
+    classes = np.unique(yt)
+    if classes.size != ys.shape[1]:
+        raise ValueError("Number of classes in y_true not equal to the number of columns in 'y_score'")
+    if not np.allclose(1.0, ys.sum(axis=1)):
+        raise ValueError('Target scores need to be probabilities for multiclass roc_auc, i.e. they should sum up to 1.0 over classes')
+    return float(np.mean([_binary_auroc(yt == c, ys[:, i]) for i, c in enumerate(classes)]))
+
+
 def calc_f1(logits, labels, avg_type='macro', multilabel_binarizer=None):
     """su.calc_f1 (su:90-105): sklearn's f1_score of the arg-max (multilabel: sigmoid > 0.5) predictions."""
     if multilabel_binarizer is not None:

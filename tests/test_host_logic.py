@@ -381,3 +381,47 @@ def test_f1_from_predictions_is_sklearns_f1_score():
         for avg in ('micro', 'macro'):
             got = calc_f1(logits, labels, avg)
             assert got.dtype == torch.float32 and abs(float(got) - f1_score(labels, logits.argmax(1), average=avg)) < 1e-6
+
+
+def test_roc_auc_is_sklearns_roc_auc_score():
+    """The epoch-end AUROCs (S.py:408-444: one sklearn call for the average and one per class) come from
+    subgraph_utils.roc_auc: same values as this image's sklearn -- ties in the scores, binary / one-vs-rest / multilabel,
+    nan for a one-class binary problem, ValueError where the class count differs from the score columns (which
+    _epoch_metrics turns into nan)."""
+    import warnings
+    from sklearn.metrics import roc_auc_score
+    from subgnn_amd.subgraph_utils import roc_auc
+    rng = np.random.default_rng(5)
+
+    def both(f, *a, **k):
+        try:
+            return f(*a, **k)
+        except ValueError:
+            return 'ValueError'
+
+    def same(a, b):
+        if isinstance(a, str) or isinstance(b, str):
+            return a == b
+        return (np.isnan(a) and np.isnan(b)) or abs(a - b) < 1e-12
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        for trial in range(150):
+            n, K = int(rng.integers(2, 120)), int(rng.integers(3, 7))    # (two score columns are sklearn's binary case: 1-d scores)
+            score = rng.normal(size=n).astype(np.float32)
+            if trial % 3 == 0:
+                score = np.round(score * 2) / 2                                        # many tied scores
+            yb = rng.integers(0, 2, n) if trial % 7 else np.zeros(n, dtype=np.int64)  # (one class only: nan)
+            a, b = both(roc_auc, yb, score), both(roc_auc_score, yb, score)
+            assert same(a, b), (trial, a, b)
+            logits = rng.normal(size=(n, K)).astype(np.float32)
+            if trial % 4 == 0:
+                logits = np.round(logits)
+            e = np.exp(logits - logits.max(1, keepdims=True))
+            prob = (e / e.sum(1, keepdims=True))
+            ym = rng.integers(0, K, n)                                                 # (small n: a class may be absent: ValueError)
+            a, b = both(roc_auc, ym, prob, multi_class='ovr'), both(roc_auc_score, ym, prob, multi_class='ovr')
+            assert same(a, b), (trial, a, b)
+            Y = rng.integers(0, 2, (n, K))
+            sig = 1.0 / (1.0 + np.exp(-logits))
+            a, b = both(roc_auc, Y, sig, multi_class='ovr'), both(roc_auc_score, Y, sig, multi_class='ovr')
+            assert same(a, b), (trial, a, b)

@@ -15,7 +15,7 @@ python bench.py --subgraphs 6250 --no-cpu-baseline --no-extras --steps 20 --warm
 python bench.py --subgraphs 6250 --no-cpu-baseline --no-extras --steps 20 --warmup 3 --graph off > $O/${T}_bench_shard6250_eager.json 2>/dev/null
 python bench.py --subgraphs 6250 --no-cpu-baseline --no-extras --steps 20 --warmup 3 --graph both > $O/${T}_bench_shard6250_graph_both.json 2>/dev/null
 for c in density_n ppi_bp hpo_metab em_user; do
-  python tools/bench_standin.py --config $c > $O/${T}_bench_standin_$c.json 2> $O/${T}_bench_standin_$c.err
+  python tools/bench_standin.py --config $c --epochs 9 > $O/${T}_bench_standin_$c.json 2> $O/${T}_bench_standin_$c.err
 done
 bash tools/check_multirank.sh > $O/${T}_multirank_check.txt 2>&1
 ls -la $O | grep ${T}_ | head -40
