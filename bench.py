@@ -726,8 +726,9 @@ def main():
     for _ in range(args.warmup):
         step(False)
     # the process holds millions of small Python objects by now (50k subgraph lists, the CSR's numpy views ...): a generation-2
-    # collection in the middle of a timed region is a 40-60 ms pause (seen in the stand-ins' epoch timings: 29 / 92 / 41 ms for
-    # identical epochs).  Everything alive here stays alive: moved out of the collector's sight
+    # collection in the middle of a timed region would walk all of them.  Everything alive here stays alive: moved out of the
+    # collector's sight.  (The 30-60 ms holes that single steps and epochs show on this pool's boxes are the DEVICE's, not the
+    # collector's: tools/device_stall_probe.py, tools/epoch_stall_probe.py.)
     import gc
     gc.collect()
     gc.freeze()

@@ -202,12 +202,20 @@ def time_steps(model, opt, hp, steps, warmup, graph, count=False):
             return out['loss']
     for _ in range(warmup):
         step()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        loss = step()
-    torch.cuda.synchronize()
-    ms = 1e3 * (time.perf_counter() - t0) / steps
+    # ``steps`` steps, timed in up to five equal blocks, the MEDIAN block reported: the boxes of this pool hold the device for
+    # 30-60 ms two or three times in four seconds (tools/device_stall_probe.py: a stream of trivial kernels shows it), which
+    # is the whole of a 20-step measurement of a 0.4 ms step -- one line of the driver's run had DENSITY at 0.91 ms instead of 0.42
+    blocks = 5 if steps >= 10 else 1
+    per = max(1, steps // blocks)
+    times = []
+    for _ in range(blocks):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(per):
+            loss = step()
+        torch.cuda.synchronize()
+        times.append(1e3 * (time.perf_counter() - t0) / per)
+    ms = sorted(times)[(len(times) - 1) // 2]
     n_k = count_kernels(step) if count else None
     return ms, float(loss.detach()), n_k
 
@@ -222,9 +230,10 @@ def time_epochs(model, hp, epochs=4):
     import gc
     tr = Trainer(epochs, hp.get('grad_clip', 0.0), log=lambda *a, **k: None, hip_graph_step=bool(hp.get('hip_graph_step', True)))
     tr.phase_times = []
-    # (the dataset that was just written and loaded left a few million container objects behind, and a full collection over them
-    # -- every second or third epoch at these epochs' allocation rate -- is a 50-80 ms
-    # pause: epochs of 25 / 74 / 25 / 74 ms on the PPI-BP stand-in.  Trainer.fit freezes the heap itself after prepare_data.)
+    # (Trainer.fit freezes the heap after prepare_data: a full collection over the few million container objects the loaded
+    # dataset left behind costs tens of ms when it happens.  The 50-80 ms stalls of single epochs -- 22 / 78 / 22 / 78 ms on the
+    # PPI-BP stand-in -- are NOT the collector's, though: tools/epoch_stall_probe.py logs every collector pass and finds none;
+    # the device itself stalls, also under a stream of trivial kernels: tools/device_stall_probe.py)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     tr.fit(model, prepared=True)

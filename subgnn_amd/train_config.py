@@ -173,8 +173,8 @@ class Trainer:
             model.prepare_data()
         if model.hparams.get('gc_freeze', True):
             # everything prepare_data left behind (the loaded dataset: subgraph lists, the graph's containers) lives as long as the
-            # run: moved out of the cyclic collector's sight, so that a full collection -- every second or third epoch at an
-            # epoch's allocation rate -- does not walk a few million long-lived objects (a 50-80 ms pause in a 25 ms epoch)
+            # run: moved out of the cyclic collector's sight, so that a full collection does not walk a few million long-lived
+            # objects in the middle of an epoch
             import gc
             gc.collect()
             gc.freeze()

@@ -1,6 +1,7 @@
 #!/bin/bash
 # Everything profiles/r06_* holds, in one go on the GPU box:   bash tools/run_r06_profiles.sh
 export TMPDIR=/tmp
+export TAG=r06
 O=gpurun_out
 mkdir -p $O
 bash tools/run_round_profiles.sh r06 > $O/r06_round_profiles.log 2>&1
