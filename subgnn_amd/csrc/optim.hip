@@ -229,6 +229,9 @@ __global__ __launch_bounds__(256) void optim_sumsq_kernel(const OptTensors T, fl
     }
 }
 
+#ifndef OPT_ROW_SLICES
+#define OPT_ROW_SLICES 2
+#endif
 __global__ __launch_bounds__(256) void optim_adam_kernel(const OptTensors T, const float* __restrict__ partial, int n_partial, float max_norm,
                                                          float* __restrict__ coef_out, float lr, float b1, float b2, float eps,
                                                          long long host_step, const int64_t* __restrict__ counters)
@@ -263,25 +266,50 @@ __global__ __launch_bounds__(256) void optim_adam_kernel(const OptTensors T, con
             const int L = T.row_lanes, lane = threadIdx.x & 63, sh = 31 - __builtin_clz(L);
             const unsigned long long rowmask = (L == 64 ? ~0ull : ((1ull << L) - 1ull)) << (lane & ~(L - 1));
             unsigned char* __restrict__ seen = T.seen;
-            for (int64_t i = (int64_t)(b - T.blk[t]) * 256 + threadIdx.x; i < n4; i += (int64_t)nb * 256) {
-                float4 gg = g4[i];
-                const int64_t row = i >> sh;
-                const bool nz = gg.x != 0.f || gg.y != 0.f || gg.z != 0.f || gg.w != 0.f;
-                const bool any = (__ballot(nz) & rowmask) != 0ull;
-                const bool was = seen[row] != 0;
-                if (any || was) {
-                    float4 pp = p4[i], mm = m4[i], vv = v4[i];
-                    float* P = &pp.x; float* G = &gg.x; float* M = &mm.x; float* V = &vv.x;
+            // OPT_ROW_SLICES row slices per thread and iteration (round 6), all loads of an iteration issued before the first is used: the
+            // gradient slices first, then -- WITHOUT a branch: a lane whose row is skipped reads slot 0 of the tensor, a cached
+            // line -- parameter and both moments of both slices.  One slice per iteration with its p / m / v loads behind a
+            // branch on the gradient was two dependent memory round trips per 16 bytes of every stream: 2.8 TB/s.
+            const int64_t stride = (int64_t)nb * 256;
+            constexpr int U = OPT_ROW_SLICES;
+            for (int64_t i0 = (int64_t)(b - T.blk[t]) * 256 + threadIdx.x; i0 < n4; i0 += U * stride) {
+                float4 gg[U];
+                int64_t idx[U];
+                bool in[U], any[U], was[U], act[U];
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const float gk = G[k] * gs;
-                        M[k] = M[k] + (1.f - b1) * (gk - M[k]);
-                        V[k] = b2 * V[k] + (1.f - b2) * gk * gk;
-                        P[k] -= step_size * M[k] / (sqrtf(V[k]) * rsqrt_bc2 + eps);
+                for (int u = 0; u < U; ++u) {
+                    idx[u] = i0 + u * stride;
+                    in[u] = idx[u] < n4;                         // (wave-uniform: n4 is a multiple of 64 here)
+                    gg[u] = in[u] ? g4[idx[u]] : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const bool nz = gg[u].x != 0.f || gg[u].y != 0.f || gg[u].z != 0.f || gg[u].w != 0.f;
+                    any[u] = (__ballot(nz) & rowmask) != 0ull;
+                    was[u] = in[u] ? seen[idx[u] >> sh] != 0 : false;
+                    act[u] = in[u] && (any[u] || was[u]);
+                }
+                float4 pp[U], mm[U], vv[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int64_t j = act[u] ? idx[u] : 0;
+                    pp[u] = p4[j]; mm[u] = m4[j]; vv[u] = v4[j];
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    if (act[u]) {
+                        float* P = &pp[u].x; float* G = &gg[u].x; float* M = &mm[u].x; float* V = &vv[u].x;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const float gk = G[k] * gs;
+                            M[k] = M[k] + (1.f - b1) * (gk - M[k]);
+                            V[k] = b2 * V[k] + (1.f - b2) * gk * gk;
+                            P[k] -= step_size * M[k] / (sqrtf(V[k]) * rsqrt_bc2 + eps);
+                        }
+                        p4[idx[u]] = pp[u]; m4[idx[u]] = mm[u]; v4[idx[u]] = vv[u];
+                        if (zero && any[u]) g4[idx[u]] = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (!was[u] && (lane & (L - 1)) == 0) seen[idx[u] >> sh] = 1;
                     }
-                    p4[i] = pp; m4[i] = mm; v4[i] = vv;
-                    if (zero && any) g4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (!was && (lane & (L - 1)) == 0) seen[row] = 1;
                 }
             }
             return;
