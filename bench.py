@@ -30,7 +30,7 @@ value = subgraphs processed by all ranks / max-over-ranks step time.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with these extra objects:
   roofline      the structure-channel CSR gather (sgnn_degree_sequence, the kernel BASELINE.json's target names) AS THE PASS RUNS
-                IT (lists of >= 512 entries binary-searched): the bytes that launch reads / its time inside the timed region, peak
+                IT (lists of >= 512 entries answered from their membership bitmaps): the bytes that launch reads / its time inside the timed region, peak
                 8 TB/s; streaming_form beside it = the launch that moves SURVEY.md 8(d)'s algorithmic bytes (every neighbour list
                 streamed), 20 launches back to back, HIP events on the launching stream, with the memory-side counter traffic
                 (hbm_frac) from the committed rocprofv3 passes.
@@ -151,7 +151,11 @@ def degseq_algorithmic_bytes(rowptr, sets_lists, search=False):
     for s in sets_lists:
         d = deg[np.asarray(s, dtype=np.int64)].astype(np.int64)
         per_list = 4 * d
-        if search:
+        if search == 'bits':
+            # round 6 (sgnn_degree_sequence_hub_bitmaps): such a list has a membership bitmap and each of the |S| members reads ONE
+            # 4-byte word of it; every member also reads its hub_index entry
+            per_list = np.where(d >= DS_SEARCH, 4 * len(d), per_list) + 4
+        elif search:
             steps = np.floor(np.log2(np.maximum(d, 1))).astype(np.int64) + 2
             per_list = np.where(d >= DS_SEARCH, np.minimum(4 * d, 4 * steps * len(d)), per_list)
         total += int((16 + per_list).sum()) + 12 * len(d)
@@ -821,7 +825,8 @@ def main():
     cc_sets = ops.Ragged.from_padded(cc_ids.reshape(Sx * C, Lc))
     set_lists = cc_sets.to_lists()
     alg_bytes = degseq_algorithmic_bytes(rowptr, set_lists)                      # every list read in full
-    alg_bytes_search = degseq_algorithmic_bytes(rowptr, set_lists, search=True)  # what the shipped launch reads
+    ds_bits = g.hub_tables() is not None                                          # (the lists of >= 512 entries have membership bitmaps)
+    alg_bytes_search = degseq_algorithmic_bytes(rowptr, set_lists, search='bits' if ds_bits else True)   # what the shipped launch reads
     reps = 20
     ds_order = model._degseq_order['train']
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -906,7 +911,7 @@ def main():
                                   'words x (16 N + 4 E): the pull levels gather a 32-byte row per edge out of 128-byte lines (DESIGN 4)'})
     traffic = traffic_src = hbm_frac = traffic_shipped = None
     out_of_cache = None
-    tf = next((f_ for f_ in (os.path.join(REPO, 'profiles', t_ + '_degseq_traffic.json') for t_ in ('r05', 'r04', 'r02')) if os.path.exists(f_)), None)
+    tf = next((f_ for f_ in (os.path.join(REPO, 'profiles', t_ + '_degseq_traffic.json') for t_ in ('r06', 'r05', 'r04', 'r02')) if os.path.exists(f_)), None)
     tf_name = 'profiles/' + os.path.basename(tf) if tf else None
     if tf:
         # PMC passes cannot run inside this process; these are the committed rocprofv3 measurements
@@ -1063,8 +1068,10 @@ def main():
         # the kernel BASELINE.json's target names, as the pass RUNS it (lists of >= 512 entries binary-searched, not streamed):
         # its own bytes / its time inside the timed region.  The streaming form (every list read in full: the launch that moves
         # SURVEY 8(d)'s bytes) is beside it as streaming_form -- that is the figure the >= 40 % target is quoted on.
-        'roofline': {'kernel': 'degseq_wave_kernel<true, false, true> (sgnn_degree_sequence_sorted_rows: structure-channel CSR gather as '
-                               'the pass runs it; lists of >= %d entries searched)' % DS_SEARCH,
+        'roofline': {'kernel': ('degseq_wave_kernel<true, false, true> (sgnn_degree_sequence_hub_bitmaps: structure-channel CSR gather as '
+                                'the pass runs it; lists of >= %d entries answered from their membership bitmaps)' % DS_SEARCH) if ds_bits else
+                               ('degseq_wave_kernel<true, false, true> (sgnn_degree_sequence_sorted_rows: structure-channel CSR gather as '
+                                'the pass runs it; lists of >= %d entries searched)' % DS_SEARCH),
                      'bound': 'hbm', 'achieved': alg_bytes_search / (ds_ms * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                      'frac': alg_bytes_search / (ds_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                      # BASELINE.json's target (>= 40 % of the HBM roofline on the structure-channel CSR gather) is quoted on SURVEY 8(d)'s
@@ -1083,7 +1090,8 @@ def main():
                                         'algorithmic_bytes_per_launch': alg_bytes, 'traffic': traffic, 'hbm_frac': hbm_frac,
                                         'in_the_timed_pass': False},
                      'out_of_cache': out_of_cache,
-                     'note': 'achieved = the bytes THIS launch reads (16 + 4 min(deg, (floor(log2 deg) + 2) |S|) per searched list) / its time '
+                     'note': 'achieved = the bytes THIS launch reads (a list of >= 512 entries: 16 + 4 |S| -- one word of its membership bitmap per '
+                             'member, round 6; rounds 3-5 searched it: 16 + 4 min(deg, (floor(log2 deg) + 2) |S|)) / its time '
                              'inside the timed region: it is latency-bound, and faster than the form that streams SURVEY 8(d)\'s bytes '
                              '(survey_8d_bytes_over_this_time_GBs exceeds the peak: the launch does not move them).  streaming_form: 8(d) bytes / '
                              'time of the launch that streams them, 20 launches back to back after the timed region (HIP events); on the '

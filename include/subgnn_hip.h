@@ -38,7 +38,7 @@ extern "C" {
 #define SGNN_ERR_LAUNCH         -4   /* hipGetLastError() after a launch */
 #define SGNN_ERR_UNSUPPORTED_D  -5   /* embedding width not supported by the vector path */
 
-#define SGNN_ABI_VERSION 10
+#define SGNN_ABI_VERSION 11
 int sgnn_abi_version(void);
 /* Load the code objects of every translation unit of the library on the current device (one empty launch each on ``stream``):
  * what the first call of each kernel family would otherwise pay, 5-25 ms at a time, inside the reference's one-time
@@ -77,7 +77,20 @@ int sgnn_degree_sequence_sorted_rows(const int64_t* rowptr, const int32_t* col, 
                                      const int64_t* set_ptr, const int32_t* set_nodes, int64_t n_sets,
                                      int64_t max_set_size, int sorted, int32_t* out_internal,
                                      int32_t* out_external, const int32_t* set_order, void* stream);
-/* Sets of more than 2048 entries (components of subgraphs with thousands of nodes): the two calls above leave them alone;
+/* Same, with membership BITMAPS for the long lists (built once per graph by the caller): hub_index[v] >= 0 names row
+ * hub_index[v] of hub_bits (hub_words 32-bit words per row; bit x of the row = "node id x is in v's neighbour list"),
+ * -1 = no bitmap for v.  A list of >= sgnn_degree_sequence_search_threshold() entries that has a bitmap is neither streamed
+ * nor searched: every member of the set reads its one bit (gamma.get_degree_sequence, gamma.py:21-49: the membership test
+ * `w in subgraph` for a hub's neighbours, asked from the set's side).  Such lists WITHOUT a bitmap are searched when
+ * col_sorted is given (may be NULL), streamed otherwise.  Results are identical. */
+int sgnn_degree_sequence_hub_bitmaps(const int64_t* rowptr, const int32_t* col, const int32_t* col_sorted,
+                                     int64_t nnz, const int32_t* full_degree, const uint8_t* self_loops,
+                                     const int32_t* hub_index, const uint32_t* hub_bits, int64_t hub_words,
+                                     const int64_t* set_ptr, const int32_t* set_nodes, int64_t n_sets,
+                                     int64_t max_set_size, int sorted, int32_t* out_internal,
+                                     int32_t* out_external, const int32_t* set_order, void* stream);
+int64_t sgnn_degree_sequence_search_threshold(void);
+/* Sets of more than 2048 entries (components of subgraphs with thousands of nodes): the calls above leave them alone;
  * this one, issued after either on the same stream, writes their degrees UNSORTED (same counting rules; the membership
  * table lives in the workspace, sgnn_degree_sequence_huge_workspace_bytes(set_ptr[n_sets])); ordering such a set's slice
  * is the caller's (any segment sort). */

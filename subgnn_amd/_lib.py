@@ -35,6 +35,9 @@ SIGNATURES = {
                                      c_ptr, c_ptr]),
     'sgnn_degree_sequence_sorted_rows': (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_int,
                                                  c_ptr, c_ptr, c_ptr, c_ptr]),
+    'sgnn_degree_sequence_hub_bitmaps': (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_i64,
+                                                 c_i64, c_int, c_ptr, c_ptr, c_ptr, c_ptr]),
+    'sgnn_degree_sequence_search_threshold': (c_i64, []),
     'sgnn_cc_embed_fwd_f16': (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_int, c_i64, c_ptr, c_ptr, c_ptr]),
     'sgnn_cc_labels': (c_int, [c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr]),
     'sgnn_cc_compact_stats': (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_ptr]),
@@ -202,7 +205,7 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the header and the library disagree
         fn.restype = res
         fn.argtypes = args
-    if lib.sgnn_abi_version() != 10:
+    if lib.sgnn_abi_version() != 11:
         raise SubgnnHipError('ABI version mismatch')
     _lib = lib
     return lib

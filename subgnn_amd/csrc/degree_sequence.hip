@@ -27,6 +27,9 @@
 #ifndef DS_BIG
 #define DS_BIG 64
 #endif
+#ifndef DS_FLAT_LOADS
+#define DS_FLAT_LOADS 2         // 64-entry loads in flight per step of the flat range of the short lists (phase B)
+#endif
 #ifndef DS_SEARCH
 #define DS_SEARCH 512           // lists at least this long are searched (sorted rows given) instead of streamed (256 / 512 / 1024 / 2048 with three lists per round: 0.215 / 0.210 / 0.213 / 0.229 ms; all streamed: 0.372)
 #endif
@@ -79,15 +82,17 @@ __device__ static inline int32_t ds_wave_sum(int32_t v) {
 template <bool P1, bool SELF, int INFL = DS_INFLIGHT>
 __device__ __forceinline__ void ds_count(const int32_t* __restrict__ col, const int32_t* __restrict__ col_sorted,
                                          const int32_t* hash, uint32_t k24, int P, int lane, int n, int32_t v,
-                                         bool dup, int32_t deg, uint32_t r0, int32_t& cnt, int32_t& selfc)
+                                         bool dup, int32_t deg, uint32_t r0, int32_t& cnt, int32_t& selfc,
+                                         const uint32_t* __restrict__ hub_bits = nullptr, int64_t hub_words = 0, int32_t hidx = -1)
 {
     uint64_t big = __ballot(deg >= DS_BIG);
     // ---- phase A0: very long lists, when the caller has the rows in ascending order: the set is looked up
     // IN the list instead of the list in the set.  Every member (one lane each) binary-searches its id in the
     // list -- log2(deg) dependent 4-byte loads for the whole set, where streaming a 30k-entry hub list costs
     // 470 wave loads and as many table probes.  (Simple graph: an id occurs at most once in a list.)
-    if (col_sorted != nullptr) {
-        uint64_t huge = __ballot(deg >= DS_SEARCH);
+    if (col_sorted != nullptr || hub_bits != nullptr) {
+        // (without the sorted rows only the lists that HAVE a bitmap are taken out of the streaming phases)
+        uint64_t huge = __ballot(deg >= DS_SEARCH && (col_sorted != nullptr || hidx >= 0));
         big &= ~huge;
         // G = 64 / n lists are searched at a time: lane l works for list slot l / n as member l % n (a search
         // is a chain of dependent loads; a set of 20 members keeps three chains going in its 64 lanes)
@@ -109,19 +114,28 @@ __device__ __forceinline__ void ds_count(const int32_t* __restrict__ col, const 
             const bool act = slot < taken;
             const int ms = act ? m_of_slot : 0;
             const int32_t m_deg = act ? __shfl(deg, ms) : 0;
+            // A list whose membership BITMAP the caller has (round 6: sgnn_degree_sequence_hub_bitmaps; one bit per node id
+            // for every list of >= DS_SEARCH entries, built once per graph) answers "is my_v in the list" with ONE load of one
+            // word -- where the binary search is ~15 dependent loads, each of them a separate 64-byte request per lane (three
+            // hub lists per 20-node set: 900 such requests per set, a third of the launch's time in the address coalescer).
+            const int32_t m_hidx = __shfl(hidx, ms);
+            const bool by_bits = act && hub_bits != nullptr && m_hidx >= 0;
+            bool found_bits = false;
+            if (by_bits) found_bits = ((hub_bits[(int64_t)m_hidx * hub_words + ((uint32_t)my_v >> 5)] >> ((uint32_t)my_v & 31u)) & 1u) != 0u;
+            const bool by_search = act && !by_bits;              // (col_sorted is given whenever a list without a bitmap is parked here)
             const int32_t* __restrict__ list = col_sorted + __shfl(r0, ms);
             int32_t lo = 0, hi = m_deg;                           // lower bound of my_v in list[0, m_deg)
-            int steps = act ? 32 - __clz(m_deg) : 0;
+            int steps = by_search ? 32 - __clz(m_deg) : 0;
 #pragma unroll
             for (int d = 32; d >= 1; d >>= 1) { const int o = __shfl_xor(steps, d); steps = o > steps ? o : steps; }
             for (int it = 0; it < steps; ++it) {
                 const int32_t mid = (lo + hi) >> 1;
-                const int32_t x = lo < hi ? list[mid] : 0;
-                const bool right = lo < hi && x < my_v;
+                const int32_t x = (by_search && lo < hi) ? list[mid] : 0;
+                const bool right = by_search && lo < hi && x < my_v;
                 lo = right ? mid + 1 : lo;
                 hi = (lo < hi && !right) ? mid : hi;
             }
-            const bool found = act && lo < m_deg && list[lo < m_deg ? lo : 0] == my_v;
+            const bool found = by_bits ? found_bits : (by_search && lo < m_deg && list[lo < m_deg ? lo : 0] == my_v);
             const uint64_t fm = __ballot(found && !my_dup);       // an id listed twice in the set counts once
             const uint64_t fself = __ballot(found);
             // lane m of the set reads the count of the slot that searched ITS list (the first lane of every
@@ -219,10 +233,10 @@ __device__ __forceinline__ void ds_count(const int32_t* __restrict__ col, const 
     }
     const int32_t total = __shfl(incl, 63);
     const int32_t excl = incl - sdeg;
-    for (int32_t base = 0; base < total; base += 128) {
-        int32_t u[2], mv[2];
+    for (int32_t base = 0; base < total; base += 64 * DS_FLAT_LOADS) {
+        int32_t u[DS_FLAT_LOADS], mv[DS_FLAT_LOADS];
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
+        for (int q = 0; q < DS_FLAT_LOADS; ++q) {
             const int32_t t = base + q * 64 + lane;
             int lo = 0, hi = 63;                         // smallest m with incl[m] > t
 #pragma unroll
@@ -238,7 +252,8 @@ __device__ __forceinline__ void ds_count(const int32_t* __restrict__ col, const 
             u[q] = t < total ? col[m_r0 + (uint32_t)(t - m_excl)] : -1;
         }
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
+        for (int q = 0; q < DS_FLAT_LOADS; ++q) {
+            if (base + q * 64 >= total) break;                                   // (wave-uniform)
             const uint64_t mh = __ballot(ds_probe<P1>(hash, u[q], k24, P) != 0);
             const int32_t b0 = base + q * 64;
             int32_t lo_i = excl - b0, hi_i = incl - b0;  // this lane's member range in the step
@@ -274,7 +289,8 @@ __global__ __launch_bounds__(64 * DS_WAVES) __attribute__((amdgpu_waves_per_eu(S
     const int32_t* __restrict__ full_degree, const uint8_t* __restrict__ self_loops,
     const int64_t* __restrict__ set_ptr, const int32_t* __restrict__ set_nodes, int64_t n_sets,
     int32_t* __restrict__ out_int, int32_t* __restrict__ out_ext, const int32_t* __restrict__ set_order,
-    const int32_t* __restrict__ col_sorted)
+    const int32_t* __restrict__ col_sorted, const int32_t* __restrict__ hub_index, const uint32_t* __restrict__ hub_bits,
+    int64_t hub_words)
 {
     // one hash table per wavefront; a wavefront's LDS operations execute in issue order, so the
     // waves of a workgroup never need a workgroup barrier (they work on different sets)
@@ -297,11 +313,12 @@ __global__ __launch_bounds__(64 * DS_WAVES) __attribute__((amdgpu_waves_per_eu(S
             }
             continue;
         }
-        int32_t v = 0, deg = 0;
+        int32_t v = 0, deg = 0, hidx = -1;
         uint32_t r0 = 0;
         if (lane < n) {
             v = set_nodes[beg + lane];
             const int64_t a = rowptr[v], b = rowptr[v + 1];
+            if (SEARCH && hub_index != nullptr) hidx = hub_index[v];     // (>= 0: the list has a membership bitmap)
             r0 = (uint32_t)a;
             deg = (int32_t)(b - a);
         }
@@ -339,11 +356,15 @@ __global__ __launch_bounds__(64 * DS_WAVES) __attribute__((amdgpu_waves_per_eu(S
         int32_t cnt = 0, selfc = 0;
         if (self_loops != nullptr) {
             if (lane < n) selfc = self_loops[v];
-            if (P <= 1) ds_count<true, false, INFL>(col, SEARCH ? col_sorted : nullptr, hash, k24, P, lane, n, v, dup, deg, r0, cnt, selfc);
-            else ds_count<false, false, INFL>(col, SEARCH ? col_sorted : nullptr, hash, k24, P, lane, n, v, dup, deg, r0, cnt, selfc);
+            if (P <= 1) ds_count<true, false, INFL>(col, SEARCH ? col_sorted : nullptr, hash, k24, P, lane, n, v, dup, deg, r0, cnt, selfc,
+                                                   SEARCH ? hub_bits : nullptr, hub_words, hidx);
+            else ds_count<false, false, INFL>(col, SEARCH ? col_sorted : nullptr, hash, k24, P, lane, n, v, dup, deg, r0, cnt, selfc,
+                                                   SEARCH ? hub_bits : nullptr, hub_words, hidx);
         } else {
-            if (P <= 1) ds_count<true, true, INFL>(col, SEARCH ? col_sorted : nullptr, hash, k24, P, lane, n, v, dup, deg, r0, cnt, selfc);
-            else ds_count<false, true, INFL>(col, SEARCH ? col_sorted : nullptr, hash, k24, P, lane, n, v, dup, deg, r0, cnt, selfc);
+            if (P <= 1) ds_count<true, true, INFL>(col, SEARCH ? col_sorted : nullptr, hash, k24, P, lane, n, v, dup, deg, r0, cnt, selfc,
+                                                   SEARCH ? hub_bits : nullptr, hub_words, hidx);
+            else ds_count<false, true, INFL>(col, SEARCH ? col_sorted : nullptr, hash, k24, P, lane, n, v, dup, deg, r0, cnt, selfc,
+                                                   SEARCH ? hub_bits : nullptr, hub_words, hidx);
         }
         cnt += selfc;                                        // a self loop counts twice (networkx)
         int32_t full = deg + selfc;
@@ -500,7 +521,7 @@ static int ds_run(const int64_t* rowptr, const int32_t* col, const int32_t* col_
                   const int64_t* set_ptr, const int32_t* set_nodes, int64_t n_sets,
                   int64_t max_set_size, int sorted,
                   int32_t* out_internal, int32_t* out_external, const int32_t* set_order,
-                  void* stream)
+                  void* stream, const int32_t* hub_index = nullptr, const uint32_t* hub_bits = nullptr, int64_t hub_words = 0)
 {
     if (!rowptr || !col || !set_ptr || !set_nodes || !out_internal || n_sets < 0 || max_set_size <= 0)
         return SGNN_ERR_BAD_ARG;
@@ -514,8 +535,9 @@ static int ds_run(const int64_t* rowptr, const int32_t* col, const int32_t* col_
     const int grid = (int)(want < DS_GRID_CAP ? want : DS_GRID_CAP);
     const bool few = n_sets <= 4096;
 #define DS_LAUNCH2(S, F, X) hipLaunchKernelGGL((degseq_wave_kernel<S, F, X>), dim3(grid), dim3(64 * DS_WAVES), 0, st, rowptr, col, \
-                                           full_degree, self_loops, set_ptr, set_nodes, n_sets, out_internal, out_external, set_order, col_sorted)
-#define DS_LAUNCH(S, F) do { if (col_sorted) DS_LAUNCH2(S, F, true); else DS_LAUNCH2(S, F, false); } while (0)
+                                           full_degree, self_loops, set_ptr, set_nodes, n_sets, out_internal, out_external, set_order, col_sorted, \
+                                           hub_index, hub_bits, hub_words)
+#define DS_LAUNCH(S, F) do { if (col_sorted || hub_bits) DS_LAUNCH2(S, F, true); else DS_LAUNCH2(S, F, false); } while (0)
     if (sorted) { if (few) DS_LAUNCH(true, true); else DS_LAUNCH(true, false); }
     else { if (few) DS_LAUNCH(false, true); else DS_LAUNCH(false, false); }
 #undef DS_LAUNCH
@@ -554,6 +576,24 @@ extern "C" int sgnn_degree_sequence_sorted_rows(const int64_t* rowptr, const int
     return ds_run(rowptr, col, col_sorted, nnz, full_degree, self_loops, set_ptr, set_nodes, n_sets, max_set_size, sorted,
                   out_internal, out_external, set_order, stream);
 }
+
+// The same with membership bitmaps for the long lists (round 6): hub_index[v] >= 0 names row hub_index[v] of hub_bits
+// (hub_words 32-bit words per row, bit x of a row = "node id x is in v's list"), -1 = no bitmap; a list of at least
+// sgnn_degree_sequence_search_threshold() entries with a bitmap is neither streamed nor searched -- every member of the set reads
+// its one bit.  Lists of that length WITHOUT a bitmap are searched when col_sorted is given, streamed otherwise.  Same results.
+extern "C" int sgnn_degree_sequence_hub_bitmaps(const int64_t* rowptr, const int32_t* col, const int32_t* col_sorted,
+                                                int64_t nnz, const int32_t* full_degree, const uint8_t* self_loops,
+                                                const int32_t* hub_index, const uint32_t* hub_bits, int64_t hub_words,
+                                                const int64_t* set_ptr, const int32_t* set_nodes, int64_t n_sets,
+                                                int64_t max_set_size, int sorted, int32_t* out_internal,
+                                                int32_t* out_external, const int32_t* set_order, void* stream)
+{
+    if (!hub_index || !hub_bits || hub_words <= 0) return SGNN_ERR_BAD_ARG;
+    return ds_run(rowptr, col, col_sorted, nnz, full_degree, self_loops, set_ptr, set_nodes, n_sets, max_set_size, sorted,
+                  out_internal, out_external, set_order, stream, hub_index, hub_bits, hub_words);
+}
+
+extern "C" int64_t sgnn_degree_sequence_search_threshold(void) { return DS_SEARCH; }
 
 // Sets of more than DSB_MAX entries (components of subgraphs with thousands of nodes; rounds 1-2 refused them): the calls
 // above leave them alone and this one fills in their degrees UNSORTED -- the membership table lives in the caller's

@@ -251,6 +251,40 @@ class DeviceGraph:
         self.simple_rows = not bool(same.any()) if same is not None else True
         return self
 
+    HUB_BITMAP_BYTES = 1 << 30     # budget of the long lists' membership bitmaps (the benchmark graph: 380 lists x 122 KB = 47 MB)
+
+    def hub_tables(self):
+        """Membership bitmaps of the long neighbour lists, built on first use and kept: -> (hub_index int32 (max_id + 1,),
+        hub_bits int32 (H, W), W) or None (no list of >= sgnn_degree_sequence_search_threshold() entries, rows with repeated
+        ids, or more than HUB_BITMAP_BYTES of bitmaps: the kernel then searches / streams those lists as before).  Bit x of
+        row hub_index[v] says that node id x is in v's list: what lets sgnn_degree_sequence_hub_bitmaps ask "is this member a
+        neighbour of that hub" with one load instead of a binary search of the hub's list.  Device-side, no host round trip
+        beyond the hub count; a property of the graph."""
+        cached = self.__dict__.get('_hub_tables', False)
+        if cached is not False:
+            return cached
+        out = None
+        if getattr(self, 'simple_rows', False) and self.nnz > 0:
+            thr = int(_lib.load().sgnn_degree_sequence_search_threshold())
+            deg = self.rowptr[1:] - self.rowptr[:-1]
+            hubs = torch.nonzero(deg >= thr).view(-1)
+            H, W = int(hubs.numel()), (self.max_id + 1 + 31) // 32
+            if 0 < H and H * W * 4 <= self.HUB_BITMAP_BYTES:
+                dev = self.device
+                hub_index = torch.full((self.max_id + 1,), -1, dtype=torch.int32, device=dev)
+                hub_index[hubs] = torch.arange(H, dtype=torch.int32, device=dev)
+                hdeg = deg[hubs]
+                owner = torch.repeat_interleave(torch.arange(H, dtype=torch.int64, device=dev), hdeg)
+                start = torch.cumsum(hdeg, 0) - hdeg                                    # first entry of every hub in ``owner``
+                pos = torch.arange(owner.numel(), dtype=torch.int64, device=dev) - start[owner] + self.rowptr[hubs][owner]
+                x = self.col_sorted[pos].to(torch.int64)
+                words = torch.zeros(H * W, dtype=torch.int64, device=dev)
+                # (no id twice in a row -- simple_rows -- so the bits of a word are distinct powers of two: their sum is their OR)
+                words.index_add_(0, owner * W + (x >> 5), torch.ones_like(x) << (x & 31))
+                out = (hub_index, words.to(torch.int32).view(H, W).contiguous(), W)
+        self.__dict__['_hub_tables'] = out
+        return out
+
 
 _WARM = set()
 
@@ -349,18 +383,27 @@ def heaviest_first(g, sets):
 
 
 def degree_sequence(g, sets, sort=True, use_degree_dict=True, want_external=True, use_self_loop_table=True, order=None,
-                    search_long_lists=True):
+                    search_long_lists=True, hub_bitmaps=True):
     """gamma.get_degree_sequence for every set at once -> (internal, external) int32 flat
     tensors aligned with ``sets.nodes`` (each set's slice sorted ascending if ``sort``).
     ``search_long_lists``: hand the kernel the row-sorted CSR as well, so that hub lists are searched
-    for the set's members instead of streamed (same results; off = stream everything)."""
+    for the set's members instead of streamed (same results; off = stream everything).
+    ``hub_bitmaps``: ... and the graph's membership bitmaps of those lists (DeviceGraph.hub_tables), so that they are not
+    even searched: one bit per (member, hub list).  Same results; off = search."""
     lib = _lib.load()
     n_tot = sets.nodes.numel()
     out_i = torch.empty(n_tot, dtype=torch.int32, device=g.device)
     out_e = torch.empty(n_tot, dtype=torch.int32, device=g.device) if want_external else None
     fd = g.full_degree if use_degree_dict else None
     sl = g.self_loops if use_self_loop_table else None
-    if search_long_lists and getattr(g, 'simple_rows', False):
+    hub = g.hub_tables() if (search_long_lists and hub_bitmaps and getattr(g, 'simple_rows', False)) else None
+    if hub is not None:
+        check(lib.sgnn_degree_sequence_hub_bitmaps(_ptr(g.rowptr), _ptr(g.col), _ptr(g.col_sorted), g.nnz, _ptr(fd), _ptr(sl),
+                                                   _ptr(hub[0]), _ptr(hub[1]), hub[2],
+                                                   _ptr(sets.ptr), _ptr(sets.nodes), sets.n, max(sets.max_len, 1),
+                                                   1 if sort else 0, _ptr(out_i), _ptr(out_e), _ptr(order), _stream()),
+              'sgnn_degree_sequence_hub_bitmaps')
+    elif search_long_lists and getattr(g, 'simple_rows', False):
         check(lib.sgnn_degree_sequence_sorted_rows(_ptr(g.rowptr), _ptr(g.col), _ptr(g.col_sorted), g.nnz, _ptr(fd), _ptr(sl),
                                                    _ptr(sets.ptr), _ptr(sets.nodes), sets.n, max(sets.max_len, 1),
                                                    1 if sort else 0, _ptr(out_i), _ptr(out_e), _ptr(order), _stream()),

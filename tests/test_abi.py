@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), n
     assert sorted(_lib.SIGNATURES) == names        # the ctypes table mirrors the header
-    assert lib.sgnn_abi_version() == 10
+    assert lib.sgnn_abi_version() == 11
 
 
 def test_workspace_queries_run_on_the_host():

@@ -35,7 +35,11 @@ def algorithmic_bytes(deg_of_member, set_size, search):
     of 4 deg."""
     d = deg_of_member.astype(np.int64)
     per_list = 4 * d
-    if search:
+    if search == 'bits':
+        # round 6: the list has a membership bitmap -- each of the |S| members reads ONE 4-byte word of it; every member also
+        # reads its hub_index entry (4 bytes)
+        per_list = np.where(d >= DS_SEARCH, 4 * set_size, per_list) + 4
+    elif search:
         steps = np.floor(np.log2(np.maximum(d, 1))).astype(np.int64) + 2
         per_list = np.where(d >= DS_SEARCH, np.minimum(4 * d, 4 * steps * set_size), per_list)
     return int((16 + per_list).sum() + 12 * len(d))
@@ -96,7 +100,7 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / args.reps
-        ab = algorithmic_bytes(deg, K, search)
+        ab = algorithmic_bytes(deg, K, ('bits' if g.hub_tables() is not None else True) if search else False)
         out[form] = {'ms_per_launch': ms, 'algorithmic_bytes_per_launch': ab, 'achieved_GBs': ab / ms / 1e6,
                      'frac_of_8TBs': ab / ms / 1e6 / 8000.0}
     out['forms_agree'] = same
