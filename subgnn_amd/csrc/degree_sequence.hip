@@ -121,7 +121,9 @@ __device__ __forceinline__ void ds_count(const int32_t* __restrict__ col, const 
             const int32_t m_hidx = __shfl(hidx, ms);
             const bool by_bits = act && hub_bits != nullptr && m_hidx >= 0;
             bool found_bits = false;
-            if (by_bits) found_bits = ((hub_bits[(int64_t)m_hidx * hub_words + ((uint32_t)my_v >> 5)] >> ((uint32_t)my_v & 31u)) & 1u) != 0u;
+            // (the bitmaps are laid out BY NODE: row my_v holds one bit per hub list, so the lookups of one member against all the
+            // hubs of its set fall into one line -- 20 lines per 20-node set instead of 60 with one row per hub: 0.72 -> see DESIGN GB)
+            if (by_bits) found_bits = ((hub_bits[(int64_t)my_v * hub_words + ((uint32_t)m_hidx >> 5)] >> ((uint32_t)m_hidx & 31u)) & 1u) != 0u;
             const bool by_search = act && !by_bits;              // (col_sorted is given whenever a list without a bitmap is parked here)
             const int32_t* __restrict__ list = col_sorted + __shfl(r0, ms);
             int32_t lo = 0, hi = m_deg;                           // lower bound of my_v in list[0, m_deg)
@@ -577,8 +579,9 @@ extern "C" int sgnn_degree_sequence_sorted_rows(const int64_t* rowptr, const int
                   out_internal, out_external, set_order, stream);
 }
 
-// The same with membership bitmaps for the long lists (round 6): hub_index[v] >= 0 names row hub_index[v] of hub_bits
-// (hub_words 32-bit words per row, bit x of a row = "node id x is in v's list"), -1 = no bitmap; a list of at least
+// The same with membership bitmaps for the long lists (round 6): hub_index[v] >= 0 numbers the lists that have one, -1 = no
+// bitmap; hub_bits holds one row of hub_words 32-bit words PER NODE ID x, bit hub_index[v] of row x = "x is in v's list"
+// (by node, so that one member's lookups against all the hubs of its set share a line); a list of at least
 // sgnn_degree_sequence_search_threshold() entries with a bitmap is neither streamed nor searched -- every member of the set reads
 // its one bit.  Lists of that length WITHOUT a bitmap are searched when col_sorted is given, streamed otherwise.  Same results.
 extern "C" int sgnn_degree_sequence_hub_bitmaps(const int64_t* rowptr, const int32_t* col, const int32_t* col_sorted,

@@ -251,15 +251,16 @@ class DeviceGraph:
         self.simple_rows = not bool(same.any()) if same is not None else True
         return self
 
-    HUB_BITMAP_BYTES = 1 << 30     # budget of the long lists' membership bitmaps (the benchmark graph: 380 lists x 122 KB = 47 MB)
+    HUB_BITMAP_BYTES = 1 << 30     # budget of the long lists' membership bitmaps (the benchmark graph: 1M nodes x 380 bits = 48 MB)
 
     def hub_tables(self):
         """Membership bitmaps of the long neighbour lists, built on first use and kept: -> (hub_index int32 (max_id + 1,),
-        hub_bits int32 (H, W), W) or None (no list of >= sgnn_degree_sequence_search_threshold() entries, rows with repeated
-        ids, or more than HUB_BITMAP_BYTES of bitmaps: the kernel then searches / streams those lists as before).  Bit x of
-        row hub_index[v] says that node id x is in v's list: what lets sgnn_degree_sequence_hub_bitmaps ask "is this member a
-        neighbour of that hub" with one load instead of a binary search of the hub's list.  Device-side, no host round trip
-        beyond the hub count; a property of the graph."""
+        hub_bits int32 (max_id + 1, W), W) or None (no list of >= sgnn_degree_sequence_search_threshold() entries, rows with
+        repeated ids, or more than HUB_BITMAP_BYTES of bitmaps: the kernel then searches / streams those lists as before).
+        hub_index numbers the H long lists; bit hub_index[v] of ROW x says that node id x is in v's list (W = ceil(H / 32)
+        words per node: by node, so that one member's lookups against all the hubs of its set share a line): what lets
+        sgnn_degree_sequence_hub_bitmaps ask "is this member a neighbour of that hub" with one load instead of a binary search
+        of the hub's list.  Device-side, no host round trip beyond the hub count; a property of the graph."""
         cached = self.__dict__.get('_hub_tables', False)
         if cached is not False:
             return cached
@@ -268,8 +269,9 @@ class DeviceGraph:
             thr = int(_lib.load().sgnn_degree_sequence_search_threshold())
             deg = self.rowptr[1:] - self.rowptr[:-1]
             hubs = torch.nonzero(deg >= thr).view(-1)
-            H, W = int(hubs.numel()), (self.max_id + 1 + 31) // 32
-            if 0 < H and H * W * 4 <= self.HUB_BITMAP_BYTES:
+            H = int(hubs.numel())
+            W, rows_n = (H + 31) // 32, self.max_id + 1                                 # one row of W words per NODE id
+            if 0 < H and rows_n * W * 4 <= self.HUB_BITMAP_BYTES:
                 dev = self.device
                 hub_index = torch.full((self.max_id + 1,), -1, dtype=torch.int32, device=dev)
                 hub_index[hubs] = torch.arange(H, dtype=torch.int32, device=dev)
@@ -278,10 +280,10 @@ class DeviceGraph:
                 start = torch.cumsum(hdeg, 0) - hdeg                                    # first entry of every hub in ``owner``
                 pos = torch.arange(owner.numel(), dtype=torch.int64, device=dev) - start[owner] + self.rowptr[hubs][owner]
                 x = self.col_sorted[pos].to(torch.int64)
-                words = torch.zeros(H * W, dtype=torch.int64, device=dev)
+                words = torch.zeros(rows_n * W, dtype=torch.int64, device=dev)
                 # (no id twice in a row -- simple_rows -- so the bits of a word are distinct powers of two: their sum is their OR)
-                words.index_add_(0, owner * W + (x >> 5), torch.ones_like(x) << (x & 31))
-                out = (hub_index, words.to(torch.int32).view(H, W).contiguous(), W)
+                words.index_add_(0, x * W + (owner >> 5), torch.ones_like(owner) << (owner & 31))
+                out = (hub_index, words.to(torch.int32).view(rows_n, W).contiguous(), W)
         self.__dict__['_hub_tables'] = out
         return out
 
