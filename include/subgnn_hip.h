@@ -80,13 +80,17 @@ int sgnn_degree_sequence_sorted_rows(const int64_t* rowptr, const int32_t* col, 
 /* Same, with membership BITMAPS for the long lists (built once per graph by the caller): hub_index[v] >= 0 numbers the
  * lists that have one, -1 = no bitmap for v; hub_bits holds one row of hub_words 32-bit words per NODE ID x (rows 0 ..
  * max id), bit hub_index[v] of row x = "x is in v's neighbour list" (laid out by node: one member's lookups against all
- * the hubs of its set share a cache line).  A list of >= sgnn_degree_sequence_search_threshold() entries that has a bitmap is neither streamed
+ * the hubs of its set share a cache line).  node_info (may be NULL; 16-byte aligned): one record of four int32 per node id
+ * -- {row start, degree, hub number (0xffffff = none) | self-loop entries << 24, full degree} -- read INSTEAD of one line
+ * each out of rowptr, hub_index, self_loops and full_degree (info_degree != 0: external = the record's full degree - internal,
+ * else degree + self loops - internal).  A list of >= sgnn_degree_sequence_search_threshold() entries that has a bitmap is neither streamed
  * nor searched: every member of the set reads its one bit (gamma.get_degree_sequence, gamma.py:21-49: the membership test
  * `w in subgraph` for a hub's neighbours, asked from the set's side).  Such lists WITHOUT a bitmap are searched when
  * col_sorted is given (may be NULL), streamed otherwise.  Results are identical. */
 int sgnn_degree_sequence_hub_bitmaps(const int64_t* rowptr, const int32_t* col, const int32_t* col_sorted,
                                      int64_t nnz, const int32_t* full_degree, const uint8_t* self_loops,
                                      const int32_t* hub_index, const uint32_t* hub_bits, int64_t hub_words,
+                                     const int32_t* node_info, int info_degree,
                                      const int64_t* set_ptr, const int32_t* set_nodes, int64_t n_sets,
                                      int64_t max_set_size, int sorted, int32_t* out_internal,
                                      int32_t* out_external, const int32_t* set_order, void* stream);

@@ -35,8 +35,8 @@ SIGNATURES = {
                                      c_ptr, c_ptr]),
     'sgnn_degree_sequence_sorted_rows': (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_int,
                                                  c_ptr, c_ptr, c_ptr, c_ptr]),
-    'sgnn_degree_sequence_hub_bitmaps': (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_i64,
-                                                 c_i64, c_int, c_ptr, c_ptr, c_ptr, c_ptr]),
+    'sgnn_degree_sequence_hub_bitmaps': (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_int,
+                                                 c_ptr, c_ptr, c_i64, c_i64, c_int, c_ptr, c_ptr, c_ptr, c_ptr]),
     'sgnn_degree_sequence_search_threshold': (c_i64, []),
     'sgnn_cc_embed_fwd_f16': (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_int, c_i64, c_ptr, c_ptr, c_ptr]),
     'sgnn_cc_labels': (c_int, [c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr]),

@@ -292,7 +292,7 @@ __global__ __launch_bounds__(64 * DS_WAVES) __attribute__((amdgpu_waves_per_eu(S
     const int64_t* __restrict__ set_ptr, const int32_t* __restrict__ set_nodes, int64_t n_sets,
     int32_t* __restrict__ out_int, int32_t* __restrict__ out_ext, const int32_t* __restrict__ set_order,
     const int32_t* __restrict__ col_sorted, const int32_t* __restrict__ hub_index, const uint32_t* __restrict__ hub_bits,
-    int64_t hub_words)
+    int64_t hub_words, const int4* __restrict__ node_info, int info_degree)
 {
     // one hash table per wavefront; a wavefront's LDS operations execute in issue order, so the
     // waves of a workgroup never need a workgroup barrier (they work on different sets)
@@ -315,14 +315,26 @@ __global__ __launch_bounds__(64 * DS_WAVES) __attribute__((amdgpu_waves_per_eu(S
             }
             continue;
         }
-        int32_t v = 0, deg = 0, hidx = -1;
+        int32_t v = 0, deg = 0, hidx = -1, info_self = 0, info_full = 0;
         uint32_t r0 = 0;
+        const bool have_info = SEARCH && node_info != nullptr;           // (wave-uniform)
         if (lane < n) {
             v = set_nodes[beg + lane];
-            const int64_t a = rowptr[v], b = rowptr[v + 1];
-            if (SEARCH && hub_index != nullptr) hidx = hub_index[v];     // (>= 0: the list has a membership bitmap)
-            r0 = (uint32_t)a;
-            deg = (int32_t)(b - a);
+            if (have_info) {
+                // ONE 16-byte record per member (round 6: row start, degree, hub number | self loops << 24, full degree) instead of
+                // a line each out of rowptr, hub_index, self_loops and full_degree: 4 random requests per member were 80 per set
+                const int4 ni = node_info[v];
+                r0 = (uint32_t)ni.x;
+                deg = ni.y;
+                hidx = ((uint32_t)ni.z & 0xffffffu) == 0xffffffu ? -1 : (int32_t)((uint32_t)ni.z & 0xffffffu);
+                info_self = (int32_t)((uint32_t)ni.z >> 24);
+                info_full = ni.w;
+            } else {
+                const int64_t a = rowptr[v], b = rowptr[v + 1];
+                if (SEARCH && hub_index != nullptr) hidx = hub_index[v]; // (>= 0: the list has a membership bitmap)
+                r0 = (uint32_t)a;
+                deg = (int32_t)(b - a);
+            }
         }
         // ---- build the table: first multiplier under which no two members share a slot --------
         uint32_t k24 = ds_mult[0];
@@ -356,8 +368,8 @@ __global__ __launch_bounds__(64 * DS_WAVES) __attribute__((amdgpu_waves_per_eu(S
             if (P <= 1) break;
         }
         int32_t cnt = 0, selfc = 0;
-        if (self_loops != nullptr) {
-            if (lane < n) selfc = self_loops[v];
+        if (self_loops != nullptr || have_info) {
+            if (lane < n) selfc = have_info ? info_self : self_loops[v];
             if (P <= 1) ds_count<true, false, INFL>(col, SEARCH ? col_sorted : nullptr, hash, k24, P, lane, n, v, dup, deg, r0, cnt, selfc,
                                                    SEARCH ? hub_bits : nullptr, hub_words, hidx);
             else ds_count<false, false, INFL>(col, SEARCH ? col_sorted : nullptr, hash, k24, P, lane, n, v, dup, deg, r0, cnt, selfc,
@@ -370,7 +382,8 @@ __global__ __launch_bounds__(64 * DS_WAVES) __attribute__((amdgpu_waves_per_eu(S
         }
         cnt += selfc;                                        // a self loop counts twice (networkx)
         int32_t full = deg + selfc;
-        if (full_degree != nullptr && lane < n) full = full_degree[v];
+        if (have_info) { if (info_degree) full = info_full; }
+        else if (full_degree != nullptr && lane < n) full = full_degree[v];
         const int32_t internal = cnt;
         const int32_t external = full - cnt;
         if (!SORTED) {
@@ -523,7 +536,8 @@ static int ds_run(const int64_t* rowptr, const int32_t* col, const int32_t* col_
                   const int64_t* set_ptr, const int32_t* set_nodes, int64_t n_sets,
                   int64_t max_set_size, int sorted,
                   int32_t* out_internal, int32_t* out_external, const int32_t* set_order,
-                  void* stream, const int32_t* hub_index = nullptr, const uint32_t* hub_bits = nullptr, int64_t hub_words = 0)
+                  void* stream, const int32_t* hub_index = nullptr, const uint32_t* hub_bits = nullptr, int64_t hub_words = 0,
+                  const int32_t* node_info = nullptr, int info_degree = 0)
 {
     if (!rowptr || !col || !set_ptr || !set_nodes || !out_internal || n_sets < 0 || max_set_size <= 0)
         return SGNN_ERR_BAD_ARG;
@@ -538,7 +552,7 @@ static int ds_run(const int64_t* rowptr, const int32_t* col, const int32_t* col_
     const bool few = n_sets <= 4096;
 #define DS_LAUNCH2(S, F, X) hipLaunchKernelGGL((degseq_wave_kernel<S, F, X>), dim3(grid), dim3(64 * DS_WAVES), 0, st, rowptr, col, \
                                            full_degree, self_loops, set_ptr, set_nodes, n_sets, out_internal, out_external, set_order, col_sorted, \
-                                           hub_index, hub_bits, hub_words)
+                                           hub_index, hub_bits, hub_words, reinterpret_cast<const int4*>(node_info), info_degree)
 #define DS_LAUNCH(S, F) do { if (col_sorted || hub_bits) DS_LAUNCH2(S, F, true); else DS_LAUNCH2(S, F, false); } while (0)
     if (sorted) { if (few) DS_LAUNCH(true, true); else DS_LAUNCH(true, false); }
     else { if (few) DS_LAUNCH(false, true); else DS_LAUNCH(false, false); }
@@ -581,19 +595,23 @@ extern "C" int sgnn_degree_sequence_sorted_rows(const int64_t* rowptr, const int
 
 // The same with membership bitmaps for the long lists (round 6): hub_index[v] >= 0 numbers the lists that have one, -1 = no
 // bitmap; hub_bits holds one row of hub_words 32-bit words PER NODE ID x, bit hub_index[v] of row x = "x is in v's list"
-// (by node, so that one member's lookups against all the hubs of its set share a line); a list of at least
+// (by node, so that one member's lookups against all the hubs of its set share a line); node_info (may be NULL): one 16-byte
+// record per node id -- {row start, degree, hub number (0xffffff: none) | self-loop entries << 24, full degree} -- read INSTEAD
+// of rowptr / hub_index / self_loops / full_degree (info_degree: take the record's full degree, else degree + self loops); a list of at least
 // sgnn_degree_sequence_search_threshold() entries with a bitmap is neither streamed nor searched -- every member of the set reads
 // its one bit.  Lists of that length WITHOUT a bitmap are searched when col_sorted is given, streamed otherwise.  Same results.
 extern "C" int sgnn_degree_sequence_hub_bitmaps(const int64_t* rowptr, const int32_t* col, const int32_t* col_sorted,
                                                 int64_t nnz, const int32_t* full_degree, const uint8_t* self_loops,
                                                 const int32_t* hub_index, const uint32_t* hub_bits, int64_t hub_words,
+                                                const int32_t* node_info, int info_degree,
                                                 const int64_t* set_ptr, const int32_t* set_nodes, int64_t n_sets,
                                                 int64_t max_set_size, int sorted, int32_t* out_internal,
                                                 int32_t* out_external, const int32_t* set_order, void* stream)
 {
     if (!hub_index || !hub_bits || hub_words <= 0) return SGNN_ERR_BAD_ARG;
+    if (node_info && (((uintptr_t)node_info) & 15)) return SGNN_ERR_BAD_ARG;
     return ds_run(rowptr, col, col_sorted, nnz, full_degree, self_loops, set_ptr, set_nodes, n_sets, max_set_size, sorted,
-                  out_internal, out_external, set_order, stream, hub_index, hub_bits, hub_words);
+                  out_internal, out_external, set_order, stream, hub_index, hub_bits, hub_words, node_info, info_degree);
 }
 
 extern "C" int64_t sgnn_degree_sequence_search_threshold(void) { return DS_SEARCH; }

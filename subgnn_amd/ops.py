@@ -287,6 +287,25 @@ class DeviceGraph:
         self.__dict__['_hub_tables'] = out
         return out
 
+    def node_records(self):
+        """One 16-byte record per node id for the degree-sequence kernel (with hub_tables): int32 (max_id + 1, 4) = {row start,
+        degree, hub number (0xffffff: none) | self-loop entries << 24, full degree (the degree dict's, else degree + self
+        loops)} -- one load per set member instead of a line each out of rowptr, hub_index, self_loops and full_degree.  None
+        without hub tables.  Built on first use and kept."""
+        cached = self.__dict__.get('_node_records', False)
+        if cached is not False:
+            return cached
+        out = None
+        hub = self.hub_tables()
+        if hub is not None:
+            deg = (self.rowptr[1:] - self.rowptr[:-1]).to(torch.int32)
+            sl = self.self_loops.to(torch.int32)
+            z = ((sl.to(torch.int64) << 24) | torch.where(hub[0] >= 0, hub[0], torch.full_like(hub[0], 0xffffff)).to(torch.int64)).to(torch.int32)
+            full = self.full_degree if self.full_degree is not None else deg + sl
+            out = torch.stack([self.rowptr[:-1].to(torch.int32), deg, z, full.to(torch.int32)], 1).contiguous()
+        self.__dict__['_node_records'] = out
+        return out
+
 
 _WARM = set()
 
@@ -400,8 +419,11 @@ def degree_sequence(g, sets, sort=True, use_degree_dict=True, want_external=True
     sl = g.self_loops if use_self_loop_table else None
     hub = g.hub_tables() if (search_long_lists and hub_bitmaps and getattr(g, 'simple_rows', False)) else None
     if hub is not None:
+        # (the per-node records stand in for rowptr / hub_index / self_loops / full_degree when the self-loop table is wanted; their
+        # full degree is the graph's degree dict where it has one, degree + self loops otherwise: what fd = None gives)
+        rec = g.node_records() if use_self_loop_table else None
         check(lib.sgnn_degree_sequence_hub_bitmaps(_ptr(g.rowptr), _ptr(g.col), _ptr(g.col_sorted), g.nnz, _ptr(fd), _ptr(sl),
-                                                   _ptr(hub[0]), _ptr(hub[1]), hub[2],
+                                                   _ptr(hub[0]), _ptr(hub[1]), hub[2], _ptr(rec), 1 if use_degree_dict else 0,
                                                    _ptr(sets.ptr), _ptr(sets.nodes), sets.n, max(sets.max_len, 1),
                                                    1 if sort else 0, _ptr(out_i), _ptr(out_e), _ptr(order), _stream()),
               'sgnn_degree_sequence_hub_bitmaps')

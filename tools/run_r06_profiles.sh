@@ -17,6 +17,8 @@ DTW_PROBE_DUPS=1 python tools/dtw_side_probe.py external 5 2>&1 | grep -v amdgpu
 DTW_PROBE_DUPS=1 python tools/dtw_side_probe.py internal 5 2>&1 | grep -v amdgpu.ids >> $O/r06_dtw_side_probe.txt
 python tools/dtw_full_check.py 2>&1 | grep -v amdgpu.ids | tail -3 >> $O/r06_dtw_side_probe.txt
 python tools/bfs_probe.py > $O/r06_bfs_probe.json 2>/dev/null
+bash tools/run_hbm_probe.sh r06 > /dev/null 2>&1; python tools/make_traffic_profile.py $O r06 > $O/r06_degseq_traffic.json
+python tools/degseq_probe.py 20 search 2>&1 | grep -v amdgpu.ids > $O/r06_degseq_probe.txt
 python tools/epoch_stall_probe.py ppi_bp 12 2>&1 | grep -v amdgpu.ids > $O/r06_epoch_stall_probe.txt
 python tools/device_stall_probe.py 4 2>&1 | grep -v amdgpu.ids > $O/r06_device_stall_probe.txt
 python tools/device_stall_probe.py 4 2>&1 | grep -v amdgpu.ids >> $O/r06_device_stall_probe.txt
