@@ -489,6 +489,7 @@ class SubGNN(nn.Module):
     def prepare_data(self):
         """S.py:1024-1063."""
         self._prepare('train_val')
+        self.__dict__['_sparse_prepared'] = False          # (border sets and similarity slabs are kept: a resample re-draws from them)
 
     def prepare_test_data(self):
         """S.py:994-1022."""
@@ -986,6 +987,15 @@ class SubGNN(nn.Module):
         the tape streams of resample epoch ``_resample_epoch``."""
         hp, g = self.hparams, self.networkx_graph
         ep = self.__dict__.get('_resample_epoch', 0)
+        if self.__dict__.get('_sparse_prepared', False):
+            # prepared by hotpath.prepare_sparse: no border sets and no N x N similarity slabs are kept to re-draw from -- the
+            # similarities exist for the drawn anchors only -- so a resample is a new sparse pass over each prepared split, its
+            # N / P draws and structure picks keyed by the resample epoch (the structure patches and walks: the same tape items)
+            from . import hotpath
+            for sp in ('train', 'val'):
+                if getattr(self, sp + '_cc_ids', None) is not None and len(getattr(self, sp + '_sub_G', [])) > 0:
+                    hotpath.prepare_sparse(self, sp)
+            return
         new = {}
         if hp['use_neighborhood']:
             new['anchors_neigh_int'], new['anchors_neigh_border'] = aps.init_anchors_neighborhood(

@@ -325,7 +325,7 @@ def pool_of(st):
             'int_sims': st.attrs[sp + '_int_struc_similarities'], 'bor_sims': st.attrs[sp + '_bor_struc_similarities']}
 
 
-def prepare_pass(model, split='train', timer=None, shard=None, defer_dtw=False, pool=None):
+def prepare_pass(model, split='train', timer=None, shard=None, defer_dtw=False, pool=None, epoch=None):
     """The sampling + similarity half of a pass (everything that does not read the embedding table), for one split
     (SubGNN.py:1024-1063 semantics, sparse similarities) -> PassState.  The model's per-pass attributes are left
     alone (only its per-split caches of pass-invariant facts are filled), so the pass can be prepared while the
@@ -350,6 +350,9 @@ def prepare_pass(model, split='train', timer=None, shard=None, defer_dtw=False, 
     if pool is not None and (shard is not None and shard.deal_shared):
         raise ValueError('pool reuse is not combined with the dealt (strong-scaling) form')
     seed = int(hp.get('seed', 0)) & tape.MASK64
+    # the resample epoch of the draws (SubGNN.py:453-460: resample_anchor_patches draws fresh N / P anchors and re-picks the structure
+    # patches after every validation epoch; the patches and their walks are not drawn again): the model's, unless the caller says
+    ep = int(model.__dict__.get('_resample_epoch', 0)) if epoch is None else int(epoch)
     st = PassState(split)
     st.pool_reused = pool is not None
     t = timer or StageTimer(False)
@@ -438,12 +441,12 @@ def prepare_pass(model, split='train', timer=None, shard=None, defer_dtw=False, 
             if hp['use_position']:
                 anchors_pos_ext = getattr(model, 'anchors_pos_ext', None)
                 if anchors_pos_ext is None or split != 'test':
-                    anchors_pos_ext = st.attrs['anchors_pos_ext'] = aps.init_anchors_pos_ext(hp, g, dev)
+                    anchors_pos_ext = st.attrs['anchors_pos_ext'] = aps.init_anchors_pos_ext(hp, g, dev, epoch=ep)
                     if det:
                         for v in anchors_pos_ext.values():
                             ops.presort_ids(v, g.max_id)
                 pint = {l: ops.choice_ragged(subs, hp['n_anchor_patches_pos_in'], seed,
-                                             tape.stream_id(tape.STREAM_P_INT, split, l), item_base=base) for l in range(L)}
+                                             tape.stream_id(tape.STREAM_P_INT, split, l, ep), item_base=base) for l in range(L)}
                 st.per_split['anchors_pos_int'] = pint
                 for l in range(L):
                     if shard is not None and shard.deal_shared:
@@ -530,7 +533,7 @@ def prepare_pass(model, split='train', timer=None, shard=None, defer_dtw=False, 
                 st.attrs['int_structure_anchor_random_walks'], st.attrs['bor_structure_anchor_random_walks'] = int_w, bor_w
             if new_patches or pool is not None:
                 a_struct = st.attrs['anchors_structure'] = aps.init_anchors_structure(hp, structure_anchors, int_w, bor_w,
-                                                                                      indices_on_device=True)
+                                                                                      indices_on_device=True, epoch=ep)
                 if det:
                     # forward runs the LSTM once over a layer's internal AND border walks (SubGNN._structure_anchor_embeddings):
                     # the stacked walks and the sort their embedding lookup's backward needs are made here
@@ -574,7 +577,7 @@ def prepare_pass(model, split='train', timer=None, shard=None, defer_dtw=False, 
         ni, nb, plans = {}, {}, {}
         for l in range(L):
             ni[l] = ops.sample_anchors_ragged(cc_canon, hp['n_anchor_patches_N_in'], seed,
-                                              tape.stream_id(tape.STREAM_N_INT, split, l), has_pad_c,
+                                              tape.stream_id(tape.STREAM_N_INT, split, l, ep), has_pad_c,
                                               canonical=True, item_base=base * C).view(S, C, -1)
             sims[('N', 'in', l)] = ops.ZeroSims(ni[l].shape, dev)
             # border BFS fused with the border-anchor draw (rank query on the visited bitmap): the
@@ -584,7 +587,7 @@ def prepare_pass(model, split='train', timer=None, shard=None, defer_dtw=False, 
             widths = model.__dict__.setdefault('_border_width', {})
             wkey = (split, k, cc_sets.n, shard.world if shard is not None else 1)
             a, w, counts = ops.khop_border_sample(g, cc_sets, k, hp['n_anchor_patches_N_out'], seed,
-                                                  tape.stream_id(tape.STREAM_N_BOR, split, l),     # taken dynamically: a dispatch order buys nothing here
+                                                  tape.stream_id(tape.STREAM_N_BOR, split, l, ep),     # taken dynamically: a dispatch order buys nothing here
                                                   item_base=base * C,
                                                   count_reduce=shard.reduce_max if shard is not None else None,
                                                   width=widths.get(wkey))
@@ -727,6 +730,7 @@ def install_pass(model, st, timer=None):
         t.mark('table_all_gather_wait')
     model.init_all_embeddings(split=st.split, trainable=model.hparams['trainable_cc'], lazy=True)
     t.mark('cc_embed')
+    model.__dict__['_sparse_prepared'] = True       # (a resample is then a new sparse pass: SubGNN._prepare_anchors_only)
     model._bump_generation()
     return t
 
@@ -888,6 +892,7 @@ def install_pass_static(model, st, timer=None):
     model._build_sim_cols()
     model.init_all_embeddings(split=st.split, trainable=model.hparams['trainable_cc'], lazy=True)
     t.mark('install_copies')
+    model.__dict__['_sparse_prepared'] = True
     model._bump_generation()
     return [r for r in replaced if not r.startswith(_SHAPE_ONLY) or '_sgnn_both' in r or '_sgnn_all' in r]
 

@@ -35,10 +35,29 @@ def test_sparse_prepare_equals_dense_prepare(name, tmp_path):
     dense, sparse = _models(golden, tmp_path)
     dense.prepare_data()
     hotpath.prepare_sparse(sparse, 'train')
+    _compare_dense_and_sparse(dense, sparse)
+    # resample_anchor_patches (SubGNN.py:453-460) on both: the dense model re-draws from its kept border sets and slabs, the
+    # sparse one runs a new sparse pass keyed by the resample epoch (round 6: it used to fail on the border sets it never had) --
+    # fresh draws, the same on both paths, with their similarities
+    before = {l: sparse.anchors_neigh_border['train'][l].clone() for l in range(dense.hparams['n_layers'])}
+    p_before = {l: sparse.anchors_pos_ext[l].clone() for l in range(dense.hparams['n_layers'])}
+    for m in (dense, sparse):
+        m.__dict__['_resample_epoch'] = 1
+        m._prepare_anchors_only()
+    assert any(not torch.equal(before[l], sparse.anchors_neigh_border['train'][l]) for l in before)
+    assert any(not torch.equal(p_before[l], sparse.anchors_pos_ext[l]) for l in p_before)
+    _compare_dense_and_sparse(dense, sparse, structure_picks=True)
+
+
+def _compare_dense_and_sparse(dense, sparse, structure_picks=False):
     hp = dense.hparams
     assert torch.equal(dense.train_cc_ids, sparse.train_cc_ids)
     slab = dense.train_neigh_pos_similarities
     S, C, _ = slab.shape
+    if structure_picks and hp['use_structure']:
+        for l in range(hp['n_layers']):
+            a, b = dense.anchors_structure[l], sparse.anchors_structure[l]
+            assert [int(v) for v in a[1]] == [int(v) for v in b[1]]              # the re-picked patch numbers
     for l in range(hp['n_layers']):
         # anchors: identical draws (same tape; ragged sampler == padded sampler)
         assert torch.equal(dense.anchors_neigh_int['train'][l], sparse.anchors_neigh_int['train'][l])
@@ -70,6 +89,32 @@ def test_sparse_prepare_equals_dense_prepare(name, tmp_path):
         a = dense._forward_batch('train', dense.make_batch('train', idx))
         b = sparse._forward_batch('train', sparse.make_batch('train', idx))
     assert_close(b, a, 'logits sparse vs dense', norm_tol=1e-5)
+
+
+@pytest.mark.parametrize('graph_step', [False, True])
+def test_trainer_resamples_a_sparse_prepared_model_like_a_dense_one(graph_step, tmp_path):
+    """train_config.Trainer over two epochs with resample_anchor_patches on a model prepared by hotpath.prepare_sparse (graphs
+    whose N x N structures cannot exist): every epoch end draws epoch-keyed anchors with a new sparse pass -- and trains to the
+    losses of the dense-prepared twin, whose resample re-draws from its kept border sets (same tape, same similarities)."""
+    from conftest import load_golden
+    from subgnn_amd import hotpath
+    from subgnn_amd.train_config import Trainer
+    golden = load_golden('density')
+    dense, sparse = _models(golden, tmp_path, {'resample_anchor_patches': True, 'lstm_dropout': 0.0})
+    sparse.load_state_dict(dense.state_dict())
+    dense.prepare_data()
+    for sp in ('train', 'val'):
+        hotpath.prepare_sparse(sparse, sp)
+    hist = []
+    for m, prepared in ((dense, True), (sparse, True)):
+        # (graph_step: the recorded training step; the sparse model's resample installs new tensors, so it records again per epoch)
+        tr = Trainer(2, m.hparams.get('grad_clip', 0.0), log=lambda *a, **k: None, hip_graph_step=graph_step)
+        torch.manual_seed(5)                               # (the loaders' shuffles)
+        tr.fit(m, prepared=prepared)
+        assert m.__dict__['_resample_epoch'] == 2
+        hist.append([(h['train_loss'], h['val_loss']) for h in tr.history])
+    for (a, b), (c, d) in zip(*hist):
+        assert abs(a - c) <= 1e-5 * max(1.0, abs(a)) and abs(b - d) <= 1e-5 * max(1.0, abs(b)), hist
 
 
 def test_full_split_step_runs_and_is_deterministic(tmp_path):
