@@ -117,6 +117,37 @@ def test_trainer_resamples_a_sparse_prepared_model_like_a_dense_one(graph_step, 
         assert abs(a - c) <= 1e-5 * max(1.0, abs(a)) and abs(b - d) <= 1e-5 * max(1.0, abs(b)), hist
 
 
+def test_sparse_prepared_model_fits_and_tests_like_the_dense_one(tmp_path):
+    """The whole driver loop on a sparse-prepared model -- one epoch of train_config.Trainer, then the TEST split prepared by
+    hotpath.prepare_sparse(model, 'test') and Trainer.test -- gives the dense-prepared twin's test loss and metrics
+    (prepare_test_data, SubGNN.py:994-1022, and test_epoch_end, :466-520)."""
+    from conftest import load_golden
+    from subgnn_amd import hotpath
+    from subgnn_amd.train_config import Trainer
+    golden = load_golden('density')
+    dense, sparse = _models(golden, tmp_path, {'lstm_dropout': 0.0})
+    sparse.load_state_dict(dense.state_dict())
+    logs = []
+    for m, is_sparse in ((dense, False), (sparse, True)):
+        if is_sparse:
+            for sp in ('train', 'val'):
+                hotpath.prepare_sparse(m, sp)
+        else:
+            m.prepare_data()
+        tr = Trainer(1, m.hparams.get('grad_clip', 0.0), log=lambda *a, **k: None, hip_graph_step=False)
+        torch.manual_seed(5)
+        tr.fit(m, prepared=True)
+        if is_sparse:
+            hotpath.prepare_sparse(m, 'test')
+        else:
+            m.prepare_test_data()
+        out = tr.test(m)
+        logs.append({k: float(v) for k, v in out['log'].items() if any(t in k for t in ('loss', 'f1', 'acc'))})
+    assert logs[0].keys() == logs[1].keys() and 'test_loss' in logs[0]
+    for k in logs[0]:
+        assert abs(logs[0][k] - logs[1][k]) <= 1e-5 * max(1.0, abs(logs[0][k])), (k, logs)
+
+
 def test_full_split_step_runs_and_is_deterministic(tmp_path):
     from conftest import load_golden
     from subgnn_amd import hotpath
