@@ -131,3 +131,44 @@ def test_one_trainer_step_matches_the_reference(tiny, tmp_path):
                 assert_close(post[name], z[k], 'post-step ' + name, 1e-4)
                 n += 1
     assert n > 20
+
+
+def test_a_multilabel_dataset_runs_through_fit_and_test(tmp_path):
+    """Several labels per subgraph (HPO-NEURO's shape: su:24-92 reads ``label-label``, the loss becomes BCE with logits and the
+    metrics sigmoid-thresholded, SubGNN.py:133, su:90-124): the density fixture with every third label turned into a label pair,
+    through prepare_data, two epochs of the Trainer, prepare_test_data and Trainer.test -- eagerly and with recorded training /
+    validation steps, which have to agree (the recorded validation loss to float32 summation order)."""
+    from conftest import load_golden
+    from subgnn_amd import config
+    from subgnn_amd.SubGNN import SubGNN, dataset_paths
+    from subgnn_amd.train_config import Trainer
+    golden = load_golden('density')
+    name = write_dataset_from_golden(golden, tmp_path, with_ego=False)
+    f = os.path.join(str(tmp_path), name, 'subgraphs.pth')
+    rows = open(f).read().splitlines()
+    out = []
+    for i, r in enumerate(rows):
+        c = r.split('\t')
+        lab = int(c[1])
+        c[1] = '%d-%d' % (lab, (lab + 1) % 3) if i % 3 == 0 else str(lab)
+        out.append('\t'.join(c))
+    open(f, 'w').write('\n'.join(out) + '\n')
+    config.PROJECT_ROOT = tmp_path
+    runs = {}
+    for graph_step in (False, True):
+        hp = dict(golden.hp)
+        hp.update({'seed': golden.seed, 'neigh_sample_border_size': 2, 'lin_dropout': 0.0, 'lstm_dropout': 0.0})
+        torch.manual_seed(0)
+        m = SubGNN(hp, **dataset_paths(name))
+        assert m.multilabel and isinstance(m.loss, torch.nn.BCEWithLogitsLoss)
+        tr = Trainer(2, hp.get('grad_clip', 0.0), log=lambda *a, **k: None, hip_graph_step=graph_step)
+        torch.manual_seed(5)
+        tr.fit(m)
+        m.prepare_test_data()
+        t = tr.test(m)
+        runs[graph_step] = [v for h in tr.history for v in (h['train_loss'], h['val_loss'])] + \
+            [float(t['log'][k]) for k in ('test_loss', 'test_micro_f1', 'test_macro_f1', 'test_auroc')]
+        assert all(np.isfinite(runs[graph_step]))
+        assert runs[graph_step][2] < runs[graph_step][0]                  # the training loss went down
+    for a, b in zip(runs[False], runs[True]):
+        assert abs(a - b) <= 1e-6 * max(1.0, abs(a)), runs
