@@ -619,3 +619,66 @@ def test_pool_reuse_pass_equals_a_full_pass(name, tmp_path):
             assert torch.equal(reuse._forward_batch('train', hotpath.full_split_batch(reuse, 'train')), a)
     torch.cuda.synchronize()
     assert kinds == [False, True, False]
+
+
+@pytest.mark.parametrize('channels', ['N', 'P', 'S', 'NP', 'NS', 'PS', 'NPS'])
+def test_every_channel_combination_trains_on_both_prepare_paths(channels, tmp_path):
+    """use_neighborhood / use_position / use_structure in every combination (the reference's datasets switch them freely:
+    config_files/*/): the dense prepare_data and the sparse prepare give the same logits, the training step matches the oracle
+    (logits, loss, every gradient: 1e-4) and a recorded step replays the eager one bit for bit."""
+    from conftest import load_golden
+    from helpers import oracle_inputs
+    from oracle import float_half as FH
+    from subgnn_amd import hotpath, optim
+    from subgnn_amd.graph_step import CapturedTrainStep
+    golden = load_golden('density')
+    over = {'use_neighborhood': 'N' in channels, 'use_position': 'P' in channels, 'use_structure': 'S' in channels,
+            'lstm_dropout': 0.0}
+    dense, sparse = _models(golden, tmp_path, over)
+    sparse.load_state_dict(dense.state_dict())
+    dense.prepare_data()
+    hotpath.prepare_sparse(sparse, 'train')
+    hp = dense.hparams
+    idx = torch.arange(min(hp['batch_size'], len(dense.train_sub_G)))
+    dense.eval(); sparse.eval()
+    with torch.no_grad():
+        a = dense._forward_batch('train', dense.make_batch('train', idx))
+        b = sparse._forward_batch('train', sparse.make_batch('train', idx))
+    assert_close(b, a, 'logits sparse vs dense (%s)' % channels, norm_tol=1e-5)
+    # the training step against the oracle
+    m = dense
+    m.train()
+    m.zero_grad(set_to_none=True)
+    batch = m.make_batch('train', idx)
+    out = m.training_step(batch, 0)
+    m.backward(None, out['loss'], None, 0)
+    params, anchors, ob, ccp = oracle_inputs(m, batch, idx)
+    ref_logits = FH.forward(params, hp, 'train', ob, anchors, ccp)
+    ref_loss = torch.nn.functional.cross_entropy(ref_logits, batch['label'].cpu())
+    ref_loss.backward()
+    assert_close(out['loss'], ref_loss, 'loss (%s)' % channels)
+    checked = 0
+    for k, p in m.named_parameters():
+        ref = params[k].grad
+        if p.grad is None or ref is None:
+            assert (p.grad is None or float(p.grad.abs().max()) == 0) and (ref is None or float(ref.abs().max()) == 0), k
+            continue
+        assert_close(p.grad, ref, 'grad %s (%s)' % (k, channels))
+        checked += 1
+    assert checked >= 4
+    # a recorded step is the eager step
+    m.zero_grad(set_to_none=True)
+    twin = sparse
+    twin.load_state_dict(m.state_dict())
+    twin.train()
+    o1 = optim.ClipAdam(m.parameters(), 0.01, max_norm=0.5, capturable=True)
+    o2 = optim.ClipAdam(twin.parameters(), 0.01, max_norm=0.5, capturable=True)
+    cap = CapturedTrainStep(twin, o2, idx.numel(), 0.0, warmup=1)
+    for _ in range(3):
+        e = m.training_step(m.make_batch('train', idx), 0)
+        o1.zero_grad(set_to_none=True)
+        m.backward(None, e['loss'], o1, 0)
+        o1.step()
+        r = cap.replay(idx)[0]
+        le = float(e['loss'].detach())
+        assert abs(le - float(r)) <= 1e-5 * max(1.0, abs(le)), channels
