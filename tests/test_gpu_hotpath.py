@@ -682,3 +682,52 @@ def test_every_channel_combination_trains_on_both_prepare_paths(channels, tmp_pa
         r = cap.replay(idx)[0]
         le = float(e['loss'].detach())
         assert abs(le - float(r)) <= 1e-5 * max(1.0, abs(le)), channels
+
+
+@pytest.mark.parametrize('over', [
+    {'use_mpn_projection': False},
+    {'lstm_aggregator': 'sum'},
+    {'lstm_n_layers': 2, 'lstm_aggregator': 'sum'},
+    {'freeze_node_embeds': True},
+    {'n_layers': 3},
+    {'n_layers': 1, 'cc_aggregator': 'max', 'trainable_cc': True},
+    {'structure_patch_type': 'ego_graph', 'structure_anchor_patch_radius': 1},
+    {'linear_hidden_dim_1': 40, 'linear_hidden_dim_2': 12, 'node_embed_size': 8},
+], ids=lambda o: '+'.join('%s=%s' % kv for kv in o.items()))
+def test_less_common_hyperparameters_train_like_the_oracle(over, tmp_path):
+    """Options outside the five g11 variants -- no MPN projection, the LSTM aggregators and depths, frozen node embeddings, 3
+    layers, max component aggregation with trainable components, ego-graph structure patches, other head widths -- on the
+    density fixture: one training step (logits, loss, every gradient) against the oracle fed the product's prepared state."""
+    from conftest import load_golden
+    from helpers import oracle_inputs
+    from oracle import float_half as FH
+    golden = load_golden('density')
+    o = dict(over)
+    o['lstm_dropout'] = 0.0
+    m, _ = _models(golden, tmp_path, o)
+    m.prepare_data()
+    hp = m.hparams
+    idx = torch.arange(min(hp['batch_size'], len(m.train_sub_G)))
+    m.train()
+    m.zero_grad(set_to_none=True)
+    batch = m.make_batch('train', idx)
+    out = m.training_step(batch, 0)
+    m.backward(None, out['loss'], None, 0)
+    params, anchors, ob, ccp = oracle_inputs(m, batch, idx)
+    ref_logits = FH.forward(params, hp, 'train', ob, anchors, ccp)
+    ref_loss = torch.nn.functional.cross_entropy(ref_logits, batch['label'].cpu())
+    ref_loss.backward()
+    assert_close(out['loss'], ref_loss, 'loss %r' % (over,))
+    checked = 0
+    for k, p in m.named_parameters():
+        ref = params[k].grad
+        if k == 'node_embeddings.weight' and over.get('freeze_node_embeds'):
+            continue                                        # (frozen in the product; the oracle differentiates everything)
+        if p.grad is None or ref is None:
+            assert (p.grad is None or float(p.grad.abs().max()) == 0) and (ref is None or float(ref.abs().max()) == 0), k
+            continue
+        assert_close(p.grad, ref, 'grad %s %r' % (k, over))
+        checked += 1
+    assert checked >= 6
+    if over.get('freeze_node_embeds'):
+        assert m.node_embeddings.weight.grad is None and not m.node_embeddings.weight.requires_grad      # S.py:166-167
