@@ -731,3 +731,27 @@ def test_less_common_hyperparameters_train_like_the_oracle(over, tmp_path):
     assert checked >= 6
     if over.get('freeze_node_embeds'):
         assert m.node_embeddings.weight.grad is None and not m.node_embeddings.weight.requires_grad      # S.py:166-167
+
+
+def test_cached_similarity_files_are_read_back(tmp_path):
+    """compute_similarities = False (the reference's .npy cache, S.py:726-742, 852-873, 893-978): a second model on the same
+    dataset directory loads what the first one computed and saved -- border sets, shortest-path and structure similarities,
+    structure patches and walks -- and arrives at the same prepared state and the same logits."""
+    from conftest import load_golden
+    golden = load_golden('density')
+    first, second = _models(golden, tmp_path, {'lstm_dropout': 0.0})
+    first.prepare_data()
+    second.hparams['compute_similarities'] = False
+    second.load_state_dict(first.state_dict())
+    second.prepare_data()
+    for k in ('train_cc_ids', 'val_cc_ids', 'train_N_border', 'train_neigh_pos_similarities', 'val_neigh_pos_similarities',
+              'structure_anchors', 'int_structure_anchor_random_walks', 'bor_structure_anchor_random_walks',
+              'train_int_struc_similarities', 'train_bor_struc_similarities', 'val_int_struc_similarities'):
+        a, b = getattr(first, k), getattr(second, k)
+        assert torch.equal(a.to(b.dtype) if a.dtype != b.dtype else a, b), k
+    idx = torch.arange(6)
+    first.eval(); second.eval()
+    with torch.no_grad():
+        la = first._forward_batch('train', first.make_batch('train', idx))
+        lb = second._forward_batch('train', second.make_batch('train', idx))
+    assert torch.equal(la, lb)
