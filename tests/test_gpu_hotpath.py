@@ -755,3 +755,50 @@ def test_cached_similarity_files_are_read_back(tmp_path):
         la = first._forward_batch('train', first.make_batch('train', idx))
         lb = second._forward_batch('train', second.make_batch('train', idx))
     assert torch.equal(la, lb)
+
+
+def test_a_disconnected_graph_prepares_alike_on_both_paths(tmp_path):
+    """A base graph with a second connected component, and subgraphs that take nodes from both: components of one subgraph that
+    cannot reach each other, position anchors nobody reaches.  The reference's shortest-path matrix holds 0 for such pairs and its
+    row-min runs over those zeros (precompute_graph_metrics.py:20-25, SubGNN.py:772); the dense path (matrix from the GPU metric
+    precompute) and the sparse path (multi-source BFS with the same convention) have to agree on every anchor, every similarity
+    and the logits."""
+    import os
+    from conftest import load_golden
+    from subgnn_amd import config, hotpath
+    from subgnn_amd import precompute_graph_metrics as pgm
+    from subgnn_amd.SubGNN import SubGNN, dataset_paths
+    golden = load_golden('density')
+    name = write_dataset_from_golden(golden, tmp_path, with_ego=False)
+    d = os.path.join(str(tmp_path), name)
+    n0 = int(golden['g1_rowptr'].shape[0]) - 2                     # nodes 0 .. n0 - 1 in file ids
+    extra = list(range(n0, n0 + 10))                               # a 10-node path, attached to nothing
+    with open(os.path.join(d, 'edge_list.txt'), 'a') as f:
+        for a, b in zip(extra[:-1], extra[1:]):
+            f.write('%d %d\n' % (a, b))
+    emb = torch.load(os.path.join(d, 'gin_embeddings.pth'))
+    torch.save(torch.cat([emb, torch.randn(10, emb.shape[1], generator=torch.Generator().manual_seed(1))], 0),
+               os.path.join(d, 'gin_embeddings.pth'))
+    rows = open(os.path.join(d, 'subgraphs.pth')).read().splitlines()
+    out = []
+    for i, r in enumerate(rows):
+        c = r.split('\t')
+        if i % 4 == 0:                                             # every fourth subgraph reaches into the island
+            c[0] = c[0] + '-%d-%d' % (extra[(i // 4) % 9], extra[(i // 4) % 9 + 1])
+        out.append('\t'.join(c))
+    open(os.path.join(d, 'subgraphs.pth'), 'w').write('\n'.join(out) + '\n')
+    for fn in ('shortest_path_matrix.npy', 'degree_sequence.txt'):
+        os.remove(os.path.join(d, fn))
+    pgm.calculate_stats(d, shortest_paths=True, ego=False)
+    config.PROJECT_ROOT = tmp_path
+    models = []
+    for _ in range(2):
+        hp = dict(golden.hp)
+        hp.update({'seed': golden.seed, 'neigh_sample_border_size': 2, 'lin_dropout': 0.0, 'lstm_dropout': 0.0})
+        torch.manual_seed(0)
+        models.append(SubGNN(hp, **dataset_paths(name)))
+    dense, sparse = models
+    dense.prepare_data()
+    hotpath.prepare_sparse(sparse, 'train')
+    assert dense.train_cc_ids.shape[1] >= 2                        # subgraphs with more than one component exist
+    _compare_dense_and_sparse(dense, sparse)
