@@ -115,6 +115,27 @@ def test_degree_sequence_random(sizes):
             assert np.array_equal(oe.cpu().numpy()[:n], ce)
 
 
+def test_hub_bitmaps_respect_their_memory_budget():
+    """DeviceGraph.hub_tables builds nothing beyond HUB_BITMAP_BYTES (and nothing for a graph without long lists): the
+    degree-sequence call then searches the long lists as before -- same results."""
+    ops = _ops()
+    G = _rand_graph(3000, 6, 7)
+    small = _dev_graph(G, with_deg=False)
+    small.HUB_BITMAP_BYTES = 1024                      # (3002 nodes x 1 word = 12 KB would be needed)
+    assert small.hub_tables() is None and small.node_records() is None
+    full = _dev_graph(G, with_deg=False)
+    assert full.hub_tables() is not None and full.node_records().shape == (full.max_id + 1, 4)
+    rng = np.random.default_rng(1)
+    sets = [[1, 8] + rng.integers(1, G.max_id() + 1, 18).tolist() for _ in range(200)]
+    r = ops.Ragged.from_lists(sets, DEV)
+    a, b = ops.degree_sequence(small, r, use_degree_dict=False)
+    c, d = ops.degree_sequence(full, r, use_degree_dict=False)
+    assert torch.equal(a, c) and torch.equal(b, d)
+    import networkx as nx
+    flat = OG.from_edge_pairs(list(nx.path_graph(50).edges()))
+    assert _dev_graph(flat, with_deg=False).hub_tables() is None       # no list of >= 512 entries
+
+
 def test_degree_sequence_of_a_set_beyond_2048_is_served():
     """Rounds 1-2 answered SGNN_ERR_SET_TOO_LARGE here; since round 3 such a set takes the workspace-backed kernel."""
     ops = _ops()
